@@ -1,0 +1,279 @@
+/*
+ * sqlrs_hip.h — C ABI of the MI355X (gfx950) execution backend for the sqlrs
+ * `src/executor` hot path: Filter -> HashJoin (build + probe) -> HashAgg
+ * (update + finalize) -> Order.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one
+ * piece of a reference operator; the reference interface it stands in for is
+ * cited as  [ref: file:line]  relative to the sqlrs source tree.
+ *
+ * Data model = Arrow column buffers, passed as plain pointers + sizes:
+ *   - fixed-width columns: `values` = length * sizeof(T) little-endian
+ *   - BOOLEAN columns:     `values` = Arrow bitmap (LSB-first), ceil(length/8) B
+ *   - UTF8 columns:        `values` = bytes, `offsets` = (length+1) int32
+ *   - `validity`           = Arrow validity bitmap (LSB-first) or NULL (= all
+ *                            valid); array offset must be 0 (slice on the host)
+ *   - `mem`                = where the three pointers live (host or HBM)
+ * An arrow-rs `ArrayData` maps 1:1 (buffers()[i].as_ptr(), null_buffer()); the
+ * Rust shim a sqlrs maintainer would add is shown in INTEGRATION.md.
+ *
+ * Threading: one ctx = one HIP stream on one GPU; calls on a ctx are not
+ * re-entrant (the reference executor is single-threaded: executor/mod.rs:58-64).
+ * Distinct ctxs may be used from distinct threads / processes / GPUs.
+ *
+ * No CPU fallback exists in this library: without a usable gfx950 device
+ * sqlrs_ctx_create fails with SQLRS_ERR_DEVICE.
+ */
+#ifndef SQLRS_HIP_H
+#define SQLRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status -- */
+/* [ref: src/executor/mod.rs:67-85  enum ExecutorError {Storage, Arrow, InternalError}] */
+typedef enum sqlrs_status {
+  SQLRS_OK = 0,
+  SQLRS_ERR_ARROW = 1,    /* ExecutorError::Arrow          (bad buffers, divide by zero, ...) */
+  SQLRS_ERR_INTERNAL = 2, /* ExecutorError::InternalError  (unsupported dtype / shape)        */
+  SQLRS_ERR_STORAGE = 3,  /* ExecutorError::Storage        (never produced by this path)      */
+  SQLRS_ERR_DEVICE = 4    /* HIP runtime failure / no gfx950 device (no reference analogue)   */
+} sqlrs_status_t;
+
+/* ----------------------------------------------------------------- types -- */
+/* [ref: src/types/mod.rs:23-36  ScalarValue lattice: Null/Boolean/Float64/Int32/Int64/String]
+ * UINT32/UINT64 exist only for the join index pair arrays (hash_join.rs:218-219). */
+typedef enum sqlrs_dtype {
+  SQLRS_NULLTYPE = 0,
+  SQLRS_INT32 = 1,
+  SQLRS_INT64 = 2,
+  SQLRS_FLOAT64 = 3,
+  SQLRS_BOOLEAN = 4,
+  SQLRS_UTF8 = 5,
+  SQLRS_UINT32 = 6,
+  SQLRS_UINT64 = 7
+} sqlrs_dtype_t;
+
+typedef enum sqlrs_mem { SQLRS_MEM_HOST = 0, SQLRS_MEM_DEVICE = 1 } sqlrs_mem_t;
+
+/* One Arrow array.  [ref: arrow::array::ArrayRef as used by executor/evaluator.rs:13-28] */
+typedef struct sqlrs_column {
+  int32_t dtype;           /* sqlrs_dtype_t */
+  int32_t mem;             /* sqlrs_mem_t: address space of values/validity/offsets */
+  int64_t length;          /* rows */
+  int64_t null_count;      /* -1 = unknown (library counts bits when it needs to) */
+  const void *values;
+  const uint8_t *validity; /* NULL = no nulls */
+  const int32_t *offsets;  /* UTF8 only */
+} sqlrs_column_t;
+
+/* One RecordBatch.  [ref: arrow::record_batch::RecordBatch, the item type of
+ * BoxedExecutor, executor/mod.rs:34].  Batches returned by the library are
+ * owned by it until sqlrs_batch_release. */
+typedef struct sqlrs_batch {
+  int64_t num_rows;
+  int32_t num_columns;
+  int32_t reserved;
+  sqlrs_column_t *columns;
+  void *owner; /* private; NULL for caller-built batches */
+} sqlrs_batch_t;
+
+/* ----------------------------------------------------------- expressions -- */
+/* Postfix encoding of the BoundExpr subset evaluated on this path.
+ * [ref: src/executor/evaluator.rs:13-28 (eval_column), src/executor/array_compute.rs:70-90
+ *  (binary_op), src/binder/expression/mod.rs:18-27 (BoundExpr)] */
+typedef enum sqlrs_expr_op {
+  SQLRS_EXPR_INPUT_REF = 1, /* BoundExpr::InputRef  -> column `index`                       */
+  SQLRS_EXPR_CONSTANT = 2,  /* BoundExpr::Constant  -> dtype + (i | f | s), is_null         */
+  SQLRS_EXPR_TYPE_CAST = 3, /* BoundExpr::TypeCast  -> cast top of stack to `dtype`         */
+  /* BoundExpr::BinaryOp, sqlparser BinaryOperator names (array_compute.rs:75-88) */
+  SQLRS_EXPR_PLUS = 10,
+  SQLRS_EXPR_MINUS = 11,
+  SQLRS_EXPR_MULTIPLY = 12,
+  SQLRS_EXPR_DIVIDE = 13,
+  SQLRS_EXPR_GT = 14,
+  SQLRS_EXPR_LT = 15,
+  SQLRS_EXPR_GTEQ = 16,
+  SQLRS_EXPR_LTEQ = 17,
+  SQLRS_EXPR_EQ = 18,
+  SQLRS_EXPR_NOTEQ = 19,
+  SQLRS_EXPR_AND = 20, /* and_kleene */
+  SQLRS_EXPR_OR = 21   /* or_kleene  */
+} sqlrs_expr_op_t;
+
+typedef struct sqlrs_expr_node {
+  int32_t op;      /* sqlrs_expr_op_t */
+  int32_t dtype;   /* CONSTANT: value type; TYPE_CAST: target type */
+  int32_t index;   /* INPUT_REF: column index in the input batch */
+  int32_t is_null; /* CONSTANT: ScalarValue::X(None) */
+  int64_t i;       /* CONSTANT int32/int64/boolean payload */
+  double f;        /* CONSTANT float64 payload */
+  const char *s;   /* CONSTANT utf8 payload (NUL-terminated), else NULL */
+} sqlrs_expr_node_t;
+
+typedef struct sqlrs_expr {
+  const sqlrs_expr_node_t *nodes; /* postfix order */
+  int32_t num_nodes;
+  int32_t reserved;
+} sqlrs_expr_t;
+
+/* [ref: src/binder/table/join.rs:18-24  enum JoinType] (Cross never reaches HashJoin:
+ *  optimizer/physical_rewriter.rs:20-31) */
+typedef enum sqlrs_join_type {
+  SQLRS_JOIN_INNER = 0,
+  SQLRS_JOIN_LEFT = 1,
+  SQLRS_JOIN_RIGHT = 2,
+  SQLRS_JOIN_FULL = 3
+} sqlrs_join_type_t;
+
+/* [ref: src/binder/expression/agg_func.rs:10-15 AggFunc, :29-34 BoundAggFunc] */
+typedef enum sqlrs_agg_kind {
+  SQLRS_AGG_COUNT = 0,
+  SQLRS_AGG_SUM = 1,
+  SQLRS_AGG_MIN = 2,
+  SQLRS_AGG_MAX = 3
+} sqlrs_agg_kind_t;
+
+typedef struct sqlrs_agg_func {
+  int32_t func;         /* sqlrs_agg_kind_t */
+  int32_t distinct;     /* BoundAggFunc.distinct */
+  int32_t return_dtype; /* BoundAggFunc.return_type (SUM accumulates in this type, sum.rs:54) */
+  int32_t reserved;
+  sqlrs_expr_t arg;     /* BoundAggFunc.exprs[0]  (only exprs[0] is read: hash_agg.rs:65) */
+} sqlrs_agg_func_t;
+
+/* [ref: src/binder/statement/mod.rs:26-29  BoundOrderBy {expr, asc}] */
+typedef struct sqlrs_order_by {
+  sqlrs_expr_t expr;
+  int32_t asc;
+  int32_t reserved;
+} sqlrs_order_by_t;
+
+/* ---------------------------------------------------------------- context -- */
+typedef struct sqlrs_ctx sqlrs_ctx_t;
+
+/* Opens GPU `device_id`, creates the ctx stream and the device memory pool.
+ * Replaces nothing in the reference (it has no device); it is the handle a
+ * replacement ExecutorBuilder would hold [ref: src/executor/mod.rs:36-56]. */
+int sqlrs_ctx_create(int device_id, sqlrs_ctx_t **out);
+void sqlrs_ctx_destroy(sqlrs_ctx_t *ctx);
+/* Message of the last failed call on this ctx (valid until the next call). */
+const char *sqlrs_last_error(const sqlrs_ctx_t *ctx);
+/* Blocks until all work queued on the ctx stream is done. */
+int sqlrs_ctx_synchronize(sqlrs_ctx_t *ctx);
+/* The hipStream_t of the ctx as an opaque pointer (for event timing by callers). */
+void *sqlrs_ctx_stream(sqlrs_ctx_t *ctx);
+/* Bytes currently held by the ctx memory pool (live + cached). */
+int64_t sqlrs_ctx_pool_bytes(const sqlrs_ctx_t *ctx);
+/* Frees cached (not live) pool blocks back to the driver. */
+void sqlrs_ctx_pool_trim(sqlrs_ctx_t *ctx);
+
+/* Releases a batch returned by any call below (host or device resident). */
+void sqlrs_batch_release(sqlrs_batch_t *batch);
+/* Copies a batch (host or device) into freshly allocated memory of `out_mem`;
+ * this is the "Arrow column buffers move to HBM once per pipeline" step. */
+int sqlrs_batch_copy(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out);
+
+/* ----------------------------------------------------------------- Filter -- */
+/* [ref: src/executor/filter.rs:7-25  FilterExecutor{expr, child}::execute]
+ * One output batch per input batch, row order preserved, rows whose predicate
+ * is false or NULL dropped, empty batches still returned. */
+typedef struct sqlrs_filter sqlrs_filter_t;
+int sqlrs_filter_create(sqlrs_ctx_t *ctx, const sqlrs_expr_t *expr, sqlrs_filter_t **out);
+int sqlrs_filter_push(sqlrs_filter_t *f, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out);
+void sqlrs_filter_destroy(sqlrs_filter_t *f);
+
+/* Evaluates one expression on a batch -> one-column batch.
+ * [ref: src/executor/evaluator.rs:13-28  BoundExpr::eval_column] */
+int sqlrs_eval_expr(sqlrs_ctx_t *ctx, const sqlrs_expr_t *expr, const sqlrs_batch_t *in,
+                    int out_mem, sqlrs_batch_t **out);
+
+/* --------------------------------------------------------------- HashJoin -- */
+/* [ref: src/executor/join/hash_join.rs:16-23  HashJoinExecutor{left_child, right_child,
+ *  join_type, join_condition, join_output_schema}; execute :146-323]
+ * left = build side, right = probe side (hash_join.rs:162,208). */
+typedef struct sqlrs_hash_join sqlrs_hash_join_t;
+int sqlrs_hash_join_create(sqlrs_ctx_t *ctx, int join_type, int num_keys,
+                           const sqlrs_expr_t *left_keys,  /* JoinCondition::On.on[i].0 */
+                           const sqlrs_expr_t *right_keys, /* JoinCondition::On.on[i].1 */
+                           const sqlrs_expr_t *filter,     /* JoinCondition::On.filter or NULL */
+                           int num_right_columns,          /* right part of join_output_schema */
+                           const int32_t *right_dtypes,    /* (types of the all-NULL tail columns) */
+                           sqlrs_hash_join_t **out);
+/* build phase, one call per left batch  [ref: hash_join.rs:161-181] */
+int sqlrs_hash_join_build_push(sqlrs_hash_join_t *j, const sqlrs_batch_t *left);
+/* end of left stream: concat + finish the table  [ref: hash_join.rs:183-187] */
+int sqlrs_hash_join_build_finish(sqlrs_hash_join_t *j);
+/* probe phase, one call per right batch -> one joined batch (possibly 0 rows).
+ * If the build side received no batch, *out = NULL ("emit nothing", hash_join.rs:183-185).
+ * [ref: hash_join.rs:207-292] */
+int sqlrs_hash_join_probe_push(sqlrs_hash_join_t *j, const sqlrs_batch_t *right, int out_mem,
+                               sqlrs_batch_t **out);
+/* The index-pair form of one probe batch, before any gather: 2 columns
+ * (UINT64 left index, nullable; UINT32 right index), in the reference's order
+ * (probe-row major, build insertion order minor), join filter NOT applied.
+ * [ref: hash_join.rs:218-253  left_indices / right_indices] */
+int sqlrs_hash_join_probe_indices(sqlrs_hash_join_t *j, const sqlrs_batch_t *right, int out_mem,
+                                  sqlrs_batch_t **out);
+/* end of right stream: the unvisited-left tail batch for Left/Full (always a
+ * batch, possibly 0 rows), *out = NULL for Inner/Right or an empty build side.
+ * [ref: hash_join.rs:296-322] */
+int sqlrs_hash_join_finish(sqlrs_hash_join_t *j, int out_mem, sqlrs_batch_t **out);
+void sqlrs_hash_join_destroy(sqlrs_hash_join_t *j);
+
+/* ---------------------------------------------------------------- HashAgg -- */
+/* [ref: src/executor/aggregate/hash_agg.rs:15-19  HashAggExecutor{agg_funcs, group_by, child};
+ *  execute :32-150; accumulators aggregate/{count,sum,min_max}.rs]
+ * Output = one batch [group keys..., aggs...], groups in first-seen order.
+ * COUNT accumulates across batches (the reference assigns, count.rs:22: see DESIGN.md). */
+typedef struct sqlrs_hash_agg sqlrs_hash_agg_t;
+int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t *group_by,
+                          int num_aggs, const sqlrs_agg_func_t *aggs, sqlrs_hash_agg_t **out);
+/* [ref: hash_agg.rs:44-122] */
+int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in);
+/* [ref: hash_agg.rs:124-149]; with no pushed batch the reference panics (:125):
+ * here that is SQLRS_ERR_INTERNAL. */
+int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out);
+void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *a);
+
+/* ------------------------------------------------------------------ Order -- */
+/* [ref: src/executor/order.rs:8-67  OrderExecutor{order_by, child}::execute]
+ * NULLs first (SortOptions::default().nulls_first, order.rs:37-40), stable. */
+typedef struct sqlrs_order sqlrs_order_t;
+int sqlrs_order_create(sqlrs_ctx_t *ctx, int num_keys, const sqlrs_order_by_t *order_by,
+                       sqlrs_order_t **out);
+int sqlrs_order_push(sqlrs_order_t *o, const sqlrs_batch_t *in);
+int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out);
+void sqlrs_order_destroy(sqlrs_order_t *o);
+
+/* ------------------------------------------------- timing of device work -- */
+/* HIP-event timing on the ctx stream (bench.py measures the dominant kernel
+ * with these: torch.cuda.Event only sees torch's own stream). */
+typedef struct sqlrs_timer sqlrs_timer_t;
+int sqlrs_timer_create(sqlrs_ctx_t *ctx, sqlrs_timer_t **out);
+int sqlrs_timer_start(sqlrs_timer_t *t);
+int sqlrs_timer_stop(sqlrs_timer_t *t);
+/* synchronises on the stop event */
+int sqlrs_timer_elapsed_ms(sqlrs_timer_t *t, double *ms);
+void sqlrs_timer_destroy(sqlrs_timer_t *t);
+
+/* Per-kernel-class accumulated device time since the last reset, measured with
+ * HIP events around each launch group when profiling is enabled (off by
+ * default; enabling it serialises nothing but adds two event records per group). */
+int sqlrs_ctx_profile_enable(sqlrs_ctx_t *ctx, int on);
+int sqlrs_ctx_profile_reset(sqlrs_ctx_t *ctx);
+/* Writes up to `cap` entries; returns the number of classes. Names are static strings. */
+int sqlrs_ctx_profile_read(sqlrs_ctx_t *ctx, int cap, const char **names, double *total_ms,
+                           int64_t *launches);
+
+/* Library version string ("sqlrs-hip <semver> gfx950"). */
+const char *sqlrs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQLRS_HIP_H */
