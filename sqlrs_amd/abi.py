@@ -1,0 +1,360 @@
+"""ctypes mirror of include/sqlrs_hip.h plus pyarrow <-> sqlrs_batch_t marshalling.
+
+The same struct layouts are used by the HIP library (prefix ``sqlrs_``) and by the
+test-only CPU oracle (prefix ``oracle_``, loaded from ``oracle/`` by the tests, never
+from here).  ``Backend`` is parameterised by (shared object, prefix) so that the parity
+tests drive both through one code path.
+
+Reference vocabulary: a batch is an ``arrow::record_batch::RecordBatch``
+(executor/mod.rs:34), a column an ``ArrayRef``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence
+
+import pyarrow as pa
+
+# ---- enums (include/sqlrs_hip.h) -------------------------------------------------
+OK, ERR_ARROW, ERR_INTERNAL, ERR_STORAGE, ERR_DEVICE = 0, 1, 2, 3, 4
+NULLTYPE, INT32, INT64, FLOAT64, BOOLEAN, UTF8, UINT32, UINT64 = range(8)
+MEM_HOST, MEM_DEVICE = 0, 1
+JOIN_INNER, JOIN_LEFT, JOIN_RIGHT, JOIN_FULL = 0, 1, 2, 3
+AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX = 0, 1, 2, 3
+
+EXPR_INPUT_REF, EXPR_CONSTANT, EXPR_TYPE_CAST = 1, 2, 3
+(EXPR_PLUS, EXPR_MINUS, EXPR_MULTIPLY, EXPR_DIVIDE, EXPR_GT, EXPR_LT, EXPR_GTEQ, EXPR_LTEQ,
+ EXPR_EQ, EXPR_NOTEQ, EXPR_AND, EXPR_OR) = range(10, 22)
+
+_PA_TO_DTYPE = {
+    pa.int32(): INT32, pa.int64(): INT64, pa.float64(): FLOAT64, pa.bool_(): BOOLEAN,
+    pa.string(): UTF8, pa.uint32(): UINT32, pa.uint64(): UINT64,
+}
+_DTYPE_TO_PA = {v: k for k, v in _PA_TO_DTYPE.items()}
+_WIDTH = {INT32: 4, INT64: 8, FLOAT64: 8, UINT32: 4, UINT64: 8}
+
+
+def dtype_of(t: pa.DataType) -> int:
+    try:
+        return _PA_TO_DTYPE[t]
+    except KeyError:
+        raise ExecutorError(ERR_INTERNAL, f"unsupported arrow type {t}")
+
+
+def pa_type(dtype: int) -> pa.DataType:
+    return _DTYPE_TO_PA[dtype]
+
+
+class ExecutorError(RuntimeError):
+    """Mirror of ``ExecutorError`` (executor/mod.rs:67-85)."""
+
+    KINDS = {ERR_ARROW: "Arrow", ERR_INTERNAL: "InternalError", ERR_STORAGE: "Storage",
+             ERR_DEVICE: "Device"}
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{self.KINDS.get(status, status)}: {message}")
+        self.status = status
+        self.message = message
+
+
+# ---- structs ---------------------------------------------------------------------
+class Column(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("mem", C.c_int32), ("length", C.c_int64),
+                ("null_count", C.c_int64), ("values", C.c_void_p), ("validity", C.c_void_p),
+                ("offsets", C.c_void_p)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("num_rows", C.c_int64), ("num_columns", C.c_int32), ("reserved", C.c_int32),
+                ("columns", C.POINTER(Column)), ("owner", C.c_void_p)]
+
+
+class ExprNode(C.Structure):
+    _fields_ = [("op", C.c_int32), ("dtype", C.c_int32), ("index", C.c_int32),
+                ("is_null", C.c_int32), ("i", C.c_int64), ("f", C.c_double), ("s", C.c_char_p)]
+
+
+class Expr(C.Structure):
+    _fields_ = [("nodes", C.POINTER(ExprNode)), ("num_nodes", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class AggFunc(C.Structure):
+    _fields_ = [("func", C.c_int32), ("distinct", C.c_int32), ("return_dtype", C.c_int32),
+                ("reserved", C.c_int32), ("arg", Expr)]
+
+
+class OrderBy(C.Structure):
+    _fields_ = [("expr", Expr), ("asc", C.c_int32), ("reserved", C.c_int32)]
+
+
+# ---- pyarrow -> ABI --------------------------------------------------------------
+def _normalise(arr: pa.Array) -> pa.Array:
+    if isinstance(arr, pa.ChunkedArray):
+        arr = arr.combine_chunks() if arr.num_chunks != 1 else arr.chunk(0)
+    if arr.offset != 0:
+        # the ABI requires offset 0: re-materialise the slice
+        arr = pa.concat_arrays([arr, arr.slice(0, 0)])
+        if arr.offset != 0:
+            arr = pa.array(arr.to_pylist(), type=arr.type)
+    return arr
+
+
+class HostBatch:
+    """A caller-built sqlrs_batch_t over the buffers of a pyarrow RecordBatch (zero copy)."""
+
+    def __init__(self, rb: pa.RecordBatch):
+        self.arrays = [_normalise(rb.column(i)) for i in range(rb.num_columns)]
+        self.schema = rb.schema
+        n = len(self.arrays)
+        self.cols = (Column * max(n, 1))()
+        for i, arr in enumerate(self.arrays):
+            c = self.cols[i]
+            c.dtype = dtype_of(arr.type)
+            c.mem = MEM_HOST
+            c.length = len(arr)
+            c.null_count = arr.null_count
+            bufs = arr.buffers()
+            c.validity = bufs[0].address if (bufs[0] is not None and arr.null_count) else None
+            if c.dtype == UTF8:
+                c.offsets = bufs[1].address if bufs[1] is not None else None
+                c.values = bufs[2].address if bufs[2] is not None else None
+                if c.offsets is None:  # zero-length string array without buffers
+                    self._z = (C.c_int32 * 1)(0)
+                    c.offsets = C.addressof(self._z)
+            else:
+                c.values = bufs[1].address if bufs[1] is not None else None
+        self.abi = Batch(rb.num_rows, n, 0, C.cast(self.cols, C.POINTER(Column)), None)
+
+    @property
+    def ptr(self):
+        return C.byref(self.abi)
+
+
+def device_column(dtype: int, length: int, values_ptr: int, validity_ptr: Optional[int] = None,
+                  null_count: int = 0) -> Column:
+    """Column descriptor over HBM-resident buffers (e.g. torch tensors' data_ptr())."""
+    return Column(dtype, MEM_DEVICE, length, null_count if validity_ptr else 0, values_ptr,
+                  validity_ptr, None)
+
+
+class RawBatch:
+    """A caller-built sqlrs_batch_t from explicit Column descriptors (host or device)."""
+
+    def __init__(self, columns: Sequence[Column], num_rows: int, keepalive=None):
+        n = len(columns)
+        self.cols = (Column * max(n, 1))(*columns)
+        self.abi = Batch(num_rows, n, 0, C.cast(self.cols, C.POINTER(Column)), None)
+        self.keepalive = keepalive
+
+    @property
+    def ptr(self):
+        return C.byref(self.abi)
+
+
+class LibBatch:
+    """A batch owned by a library (host or device resident) until released."""
+
+    def __init__(self, backend: "Backend", p):
+        self.backend = backend
+        self.p = p  # POINTER(Batch)
+
+    @property
+    def ptr(self):
+        return self.p
+
+    @property
+    def num_rows(self) -> int:
+        return self.p.contents.num_rows
+
+    @property
+    def num_columns(self) -> int:
+        return self.p.contents.num_columns
+
+    def column(self, i: int) -> Column:
+        return self.p.contents.columns[i]
+
+    def to_arrow(self, names: Optional[Sequence[str]] = None) -> pa.RecordBatch:
+        """Copies a HOST resident library batch into a pyarrow RecordBatch."""
+        b = self.p.contents
+        arrays = []
+        for i in range(b.num_columns):
+            c = b.columns[i]
+            if c.mem != MEM_HOST:
+                raise ExecutorError(ERR_INTERNAL, "to_arrow on a device batch: copy it to host first")
+            n = c.length
+            nb = (n + 7) // 8
+            validity = None
+            if c.validity and c.null_count != 0:
+                validity = pa.py_buffer(C.string_at(c.validity, nb))
+            t = pa_type(c.dtype)
+            if c.dtype == UTF8:
+                offs = C.string_at(c.offsets, 4 * (n + 1))
+                end = int.from_bytes(offs[-4:], "little") if n >= 0 else 0
+                data = C.string_at(c.values, end) if end else b""
+                arr = pa.Array.from_buffers(t, n, [validity, pa.py_buffer(offs), pa.py_buffer(data)])
+            elif c.dtype == BOOLEAN:
+                arr = pa.Array.from_buffers(t, n, [validity, pa.py_buffer(C.string_at(c.values, nb))])
+            else:
+                arr = pa.Array.from_buffers(
+                    t, n, [validity, pa.py_buffer(C.string_at(c.values, _WIDTH[c.dtype] * n))])
+            arrays.append(arr)
+        if names is None:
+            names = [f"c{i}" for i in range(len(arrays))]
+        return pa.RecordBatch.from_arrays(arrays, names=list(names))
+
+    def release(self):
+        if self.p is not None:
+            self.backend.fn("batch_release")(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def as_batch(x):
+    """pyarrow RecordBatch / HostBatch / RawBatch / LibBatch -> object with .ptr"""
+    if isinstance(x, pa.RecordBatch):
+        return HostBatch(x)
+    if isinstance(x, pa.Table):
+        return HostBatch(x.combine_chunks().to_batches()[0] if x.num_rows else
+                         pa.RecordBatch.from_pylist([], schema=x.schema))
+    return x
+
+
+# ---- expressions -----------------------------------------------------------------
+class PackedExpr:
+    """Owns the node array behind one sqlrs_expr_t."""
+
+    def __init__(self, nodes: List[ExprNode]):
+        self.arr = (ExprNode * len(nodes))(*nodes)
+        self.abi = Expr(C.cast(self.arr, C.POINTER(ExprNode)), len(nodes), 0)
+
+
+def pack_exprs(exprs: Iterable) -> "tuple[C.Array, list]":
+    packed = [e.pack() for e in exprs]
+    arr = (Expr * max(len(packed), 1))(*[p.abi for p in packed])
+    return arr, packed
+
+
+# ---- backend ---------------------------------------------------------------------
+class Backend:
+    """One loaded implementation of the ABI (HIP library or, in tests, the CPU oracle)."""
+
+    def __init__(self, lib_path: str, prefix: str, ctx_arg: int = 0):
+        self.lib = C.CDLL(lib_path)
+        self.prefix = prefix
+        self.lib_path = lib_path
+        self._declare()
+        ctx = C.c_void_p()
+        st = self.fn("ctx_create")(ctx_arg, C.byref(ctx))
+        if st != OK:
+            raise ExecutorError(st, f"{prefix}ctx_create({ctx_arg}) failed: no usable device / library")
+        self.ctx = ctx
+
+    def fn(self, name: str):
+        return getattr(self.lib, self.prefix + name)
+
+    def _declare(self):
+        vp, pvp, i = C.c_void_p, C.POINTER(C.c_void_p), C.c_int
+        pb, ppb = C.POINTER(Batch), C.POINTER(C.POINTER(Batch))
+        pe = C.POINTER(Expr)
+        sig = {
+            "ctx_create": (i, [i, pvp]),
+            "ctx_destroy": (None, [vp]),
+            "last_error": (C.c_char_p, [vp]),
+            "batch_release": (None, [pb]),
+            "filter_create": (i, [vp, pe, pvp]),
+            "filter_push": (i, [vp, pb, i, ppb]),
+            "filter_destroy": (None, [vp]),
+            "eval_expr": (i, [vp, pe, pb, i, ppb]),
+            "hash_join_create": (i, [vp, i, i, pe, pe, pe, i, C.POINTER(C.c_int32), pvp]),
+            "hash_join_build_push": (i, [vp, pb]),
+            "hash_join_build_finish": (i, [vp]),
+            "hash_join_probe_push": (i, [vp, pb, i, ppb]),
+            "hash_join_probe_indices": (i, [vp, pb, i, ppb]),
+            "hash_join_finish": (i, [vp, i, ppb]),
+            "hash_join_destroy": (None, [vp]),
+            "hash_agg_create": (i, [vp, i, pe, i, C.POINTER(AggFunc), pvp]),
+            "hash_agg_push": (i, [vp, pb]),
+            "hash_agg_finish": (i, [vp, i, ppb]),
+            "hash_agg_destroy": (None, [vp]),
+            "order_create": (i, [vp, i, C.POINTER(OrderBy), pvp]),
+            "order_push": (i, [vp, pb]),
+            "order_finish": (i, [vp, i, ppb]),
+            "order_destroy": (None, [vp]),
+            "version": (C.c_char_p, []),
+        }
+        for name, (res, args) in sig.items():
+            f = self.fn(name)
+            f.restype = res
+            f.argtypes = args
+        # HIP-only entry points
+        optional = {
+            "ctx_synchronize": (i, [vp]),
+            "ctx_stream": (vp, [vp]),
+            "ctx_pool_bytes": (C.c_int64, [vp]),
+            "ctx_pool_trim": (None, [vp]),
+            "batch_copy": (i, [vp, pb, i, ppb]),
+            "timer_create": (i, [vp, pvp]),
+            "timer_start": (i, [vp]),
+            "timer_stop": (i, [vp]),
+            "timer_elapsed_ms": (i, [vp, C.POINTER(C.c_double)]),
+            "timer_destroy": (None, [vp]),
+            "ctx_profile_enable": (i, [vp, i]),
+            "ctx_profile_reset": (i, [vp]),
+            "ctx_profile_read": (i, [vp, i, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_int64)]),
+        }
+        for name, (res, args) in optional.items():
+            f = getattr(self.lib, self.prefix + name, None)
+            if f is not None:
+                f.restype = res
+                f.argtypes = args
+
+    def check(self, status: int):
+        if status != OK:
+            msg = self.fn("last_error")(self.ctx)
+            raise ExecutorError(status, (msg or b"").decode("utf-8", "replace"))
+
+    def wrap(self, p) -> Optional[LibBatch]:
+        return LibBatch(self, p) if p else None
+
+    def version(self) -> str:
+        return self.fn("version")().decode()
+
+    def close(self):
+        if self.ctx is not None:
+            self.fn("ctx_destroy")(self.ctx)
+            self.ctx = None
+
+    # ---- helpers on top of optional entry points
+    def synchronize(self):
+        self.check(self.fn("ctx_synchronize")(self.ctx))
+
+    def copy(self, batch, out_mem: int) -> LibBatch:
+        b = as_batch(batch)
+        out = C.POINTER(Batch)()
+        self.check(self.fn("batch_copy")(self.ctx, b.ptr, out_mem, C.byref(out)))
+        return self.wrap(out)
+
+    def to_device(self, batch) -> LibBatch:
+        return self.copy(batch, MEM_DEVICE)
+
+    def to_host(self, batch) -> LibBatch:
+        return self.copy(batch, MEM_HOST)
+
+    def profile(self, on: bool = True):
+        self.check(self.fn("ctx_profile_enable")(self.ctx, int(on)))
+        self.check(self.fn("ctx_profile_reset")(self.ctx))
+
+    def profile_read(self) -> dict:
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        n_l = (C.c_int64 * cap)()
+        n = self.fn("ctx_profile_read")(self.ctx, cap, names, ms, n_l)
+        return {names[k].decode(): (ms[k], n_l[k]) for k in range(min(n, cap))}

@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference's operator structs over the C ABI.
+
+Each class has the reference struct's fields and an ``execute()`` that yields
+RecordBatches, like the ``#[try_stream] execute(self) -> BoxedExecutor`` generators of
+src/executor/{filter.rs:7-25, join/hash_join.rs:16-23,146-323,
+aggregate/hash_agg.rs:15-19,32-150, order.rs:8-67}.  A child is any iterable of batches
+(the reference's tests fake children with ``futures::stream::iter(vec_of_batches)``,
+hash_join.rs:407-414); a batch is a ``pyarrow.RecordBatch`` (host) or an ``abi.LibBatch``
+(already HBM resident, e.g. the output of an upstream operator run with
+``out_mem=abi.MEM_DEVICE``), so a Filter -> HashJoin -> HashAgg chain moves its columns
+to HBM once.
+
+``backend`` is an ``abi.Backend``: the HIP library in the product (``sqlrs_amd.hip()``)
+— the parity tests pass the oracle's Backend to run the identical plan on the CPU
+restatement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence
+
+import pyarrow as pa
+
+from . import abi
+from .expr import AggFunc, BoundExpr, JoinCondition, OrderBy
+
+JoinType = {"inner": abi.JOIN_INNER, "left": abi.JOIN_LEFT, "right": abi.JOIN_RIGHT,
+            "full": abi.JOIN_FULL}
+
+
+def _emit(backend: abi.Backend, p, out_mem: int, names: Optional[Sequence[str]]):
+    lb = backend.wrap(p)
+    if lb is None:
+        return None
+    if out_mem == abi.MEM_DEVICE:
+        return lb
+    try:
+        return lb.to_arrow(names)
+    finally:
+        lb.release()
+
+
+def _names_of(batch) -> Optional[List[str]]:
+    if isinstance(batch, pa.RecordBatch):
+        return list(batch.schema.names)
+    return getattr(batch, "names", None)
+
+
+class FilterExecutor:
+    """``FilterExecutor { expr, child }`` (filter.rs:7-10)."""
+
+    def __init__(self, backend: abi.Backend, expr: BoundExpr, child: Iterable,
+                 out_mem: int = abi.MEM_HOST):
+        self.backend, self.expr, self.child, self.out_mem = backend, expr, child, out_mem
+
+    def execute(self):
+        be = self.backend
+        packed = self.expr.pack()
+        h = C.c_void_p()
+        be.check(be.fn("filter_create")(be.ctx, C.byref(packed.abi), C.byref(h)))
+        try:
+            for batch in self.child:  # filter.rs:15-24
+                b = abi.as_batch(batch)
+                out = C.POINTER(abi.Batch)()
+                be.check(be.fn("filter_push")(h, b.ptr, self.out_mem, C.byref(out)))
+                yield _emit(be, out, self.out_mem, _names_of(batch))
+        finally:
+            be.fn("filter_destroy")(h)
+
+
+class HashJoinExecutor:
+    """``HashJoinExecutor { left_child, right_child, join_type, join_condition,
+    join_output_schema }`` (hash_join.rs:16-23).  ``join_output_schema`` is a pyarrow
+    schema: field names ``"{table_id}.{column_id}"`` and forced nullability come from the
+    planner (catalog/mod.rs:131-137, logical_join.rs:82-116); the library only needs the
+    right-hand dtypes (all-NULL tail columns, hash_join.rs:309-317)."""
+
+    def __init__(self, backend: abi.Backend, left_child: Iterable, right_child: Iterable,
+                 join_type: str, join_condition: JoinCondition, join_output_schema: pa.Schema,
+                 num_left_columns: int, out_mem: int = abi.MEM_HOST):
+        self.backend = backend
+        self.left_child, self.right_child = left_child, right_child
+        self.join_type, self.join_condition = join_type, join_condition
+        self.join_output_schema = join_output_schema
+        self.num_left_columns = num_left_columns
+        self.out_mem = out_mem
+
+    def _create(self):
+        be = self.backend
+        keep = []
+        lk, k1 = abi.pack_exprs([l for l, _ in self.join_condition.on])
+        rk, k2 = abi.pack_exprs([r for _, r in self.join_condition.on])
+        keep += [lk, rk, k1, k2]
+        filt = None
+        if self.join_condition.filter is not None:
+            pf = self.join_condition.filter.pack()
+            keep.append(pf)
+            filt = C.byref(pf.abi)
+        right_fields = list(self.join_output_schema)[self.num_left_columns:]
+        rd = (C.c_int32 * max(len(right_fields), 1))(*[abi.dtype_of(f.type) for f in right_fields])
+        h = C.c_void_p()
+        be.check(be.fn("hash_join_create")(
+            be.ctx, JoinType[self.join_type.lower()], len(self.join_condition.on), lk, rk, filt,
+            len(right_fields), rd, C.byref(h)))
+        return h, keep
+
+    def execute(self, indices_only: bool = False):
+        be = self.backend
+        h, keep = self._create()
+        names = list(self.join_output_schema.names)
+        try:
+            for batch in self.left_child:  # build phase, hash_join.rs:161-181
+                b = abi.as_batch(batch)
+                be.check(be.fn("hash_join_build_push")(h, b.ptr))
+            be.check(be.fn("hash_join_build_finish")(h))
+            for batch in self.right_child:  # probe phase, hash_join.rs:207-292
+                b = abi.as_batch(batch)
+                out = C.POINTER(abi.Batch)()
+                if indices_only:
+                    be.check(be.fn("hash_join_probe_indices")(h, b.ptr, self.out_mem, C.byref(out)))
+                    r = _emit(be, out, self.out_mem, ["left_indices", "right_indices"])
+                else:
+                    be.check(be.fn("hash_join_probe_push")(h, b.ptr, self.out_mem, C.byref(out)))
+                    r = _emit(be, out, self.out_mem, names)
+                if r is not None:
+                    yield r
+            if not indices_only:
+                out = C.POINTER(abi.Batch)()  # tail, hash_join.rs:296-322
+                be.check(be.fn("hash_join_finish")(h, self.out_mem, C.byref(out)))
+                r = _emit(be, out, self.out_mem, names)
+                if r is not None:
+                    yield r
+        finally:
+            be.fn("hash_join_destroy")(h)
+
+
+class HashAggExecutor:
+    """``HashAggExecutor { agg_funcs, group_by, child }`` (hash_agg.rs:15-19)."""
+
+    def __init__(self, backend: abi.Backend, agg_funcs: List[AggFunc], group_by: List[BoundExpr],
+                 child: Iterable, out_mem: int = abi.MEM_HOST,
+                 output_names: Optional[Sequence[str]] = None):
+        self.backend, self.agg_funcs, self.group_by = backend, agg_funcs, group_by
+        self.child, self.out_mem, self.output_names = child, out_mem, output_names
+
+    def execute(self):
+        be = self.backend
+        keep = []
+        gb, k = abi.pack_exprs(self.group_by)
+        keep += [gb, k]
+        aggs = (abi.AggFunc * max(len(self.agg_funcs), 1))(
+            *[a.abi_struct(keep) for a in self.agg_funcs])
+        h = C.c_void_p()
+        be.check(be.fn("hash_agg_create")(be.ctx, len(self.group_by), gb, len(self.agg_funcs), aggs,
+                                          C.byref(h)))
+        try:
+            for batch in self.child:  # hash_agg.rs:44-122
+                b = abi.as_batch(batch)
+                be.check(be.fn("hash_agg_push")(h, b.ptr))
+            out = C.POINTER(abi.Batch)()  # hash_agg.rs:124-149: exactly one output batch
+            be.check(be.fn("hash_agg_finish")(h, self.out_mem, C.byref(out)))
+            yield _emit(be, out, self.out_mem, self.output_names)
+        finally:
+            be.fn("hash_agg_destroy")(h)
+
+
+class OrderExecutor:
+    """``OrderExecutor { order_by, child }`` (order.rs:8-11)."""
+
+    def __init__(self, backend: abi.Backend, order_by: List[OrderBy], child: Iterable,
+                 out_mem: int = abi.MEM_HOST):
+        self.backend, self.order_by, self.child, self.out_mem = backend, order_by, child, out_mem
+
+    def execute(self):
+        be = self.backend
+        keep = []
+        obs = []
+        for ob in self.order_by:
+            p = ob.expr.pack()
+            keep.append(p)
+            obs.append(abi.OrderBy(p.abi, int(ob.asc), 0))
+        arr = (abi.OrderBy * max(len(obs), 1))(*obs)
+        h = C.c_void_p()
+        be.check(be.fn("order_create")(be.ctx, len(obs), arr, C.byref(h)))
+        names = None
+        try:
+            for batch in self.child:  # order.rs:19-26
+                names = names or _names_of(batch)
+                b = abi.as_batch(batch)
+                be.check(be.fn("order_push")(h, b.ptr))
+            out = C.POINTER(abi.Batch)()
+            be.check(be.fn("order_finish")(h, self.out_mem, C.byref(out)))
+            yield _emit(be, out, self.out_mem, names)
+        finally:
+            be.fn("order_destroy")(h)
+
+
+def eval_column(backend: abi.Backend, expr: BoundExpr, batch, out_mem: int = abi.MEM_HOST):
+    """``BoundExpr::eval_column`` (evaluator.rs:13-28) -> one-column batch."""
+    packed = expr.pack()
+    b = abi.as_batch(batch)
+    out = C.POINTER(abi.Batch)()
+    backend.check(backend.fn("eval_expr")(backend.ctx, C.byref(packed.abi), b.ptr, out_mem,
+                                          C.byref(out)))
+    return _emit(backend, out, out_mem, ["expr"])
+
+
+def try_collect(executor) -> List:
+    """``try_collect`` (executor/mod.rs:58-64)."""
+    return list(executor.execute())
