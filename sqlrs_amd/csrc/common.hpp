@@ -1,0 +1,187 @@
+// common.hpp — host-side plumbing of libsqlrs_hip: errors, ctx (stream + device memory
+// pool + profiling), device columns / batches and the ABI <-> device conversions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "sqlrs_hip.h"
+
+namespace sq {
+
+struct Error {
+  int status;
+  std::string msg;
+};
+[[noreturn]] inline void fail(int status, const std::string &m) { throw Error{status, m}; }
+
+#define SQ_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      ::sq::fail(SQLRS_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+  } while (0)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+// bytes of an Arrow bitmap padded to whole u64 words (device kernels read/write words)
+inline size_t bitmap_bytes(int64_t rows) { return (size_t)ceil_div(rows, 64) * 8; }
+
+inline size_t width_of(int32_t dtype) {
+  switch (dtype) {
+  case SQLRS_INT32:
+  case SQLRS_UINT32:
+    return 4;
+  case SQLRS_INT64:
+  case SQLRS_UINT64:
+  case SQLRS_FLOAT64:
+    return 8;
+  default:
+    return 0;
+  }
+}
+
+// ------------------------------------------------------------------ memory pool --
+// Stream-ordered caching allocator: every kernel of a ctx runs on ctx->stream, so a block
+// released while work is in flight may be handed to later work on the same stream.
+struct Pool {
+  std::multimap<size_t, void *> free_blocks;
+  size_t live_bytes = 0, cached_bytes = 0;
+  void *alloc(size_t bytes, size_t *cap);
+  void release(void *p, size_t cap);
+  void trim();
+};
+
+struct Ctx;
+struct Buf {
+  Ctx *ctx;
+  void *p;
+  size_t cap;
+  Buf(Ctx *c, void *ptr, size_t n) : ctx(c), p(ptr), cap(n) {}
+  ~Buf();
+  Buf(const Buf &) = delete;
+  Buf &operator=(const Buf &) = delete;
+  template <class T> T *as() const { return (T *)p; }
+};
+using BufP = std::shared_ptr<Buf>;
+
+struct ProfEntry {
+  const char *name;
+  double total_ms = 0;
+  int64_t launches = 0;
+};
+struct ProfPending {
+  int entry;
+  hipEvent_t a, b;
+};
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  Pool pool;
+  int num_cus = 256;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfEntry> prof;
+  std::vector<ProfPending> prof_pending;
+  std::vector<hipEvent_t> event_pool;
+  // small pinned staging area for device->host scalars
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
+
+  BufP alloc(size_t bytes);
+  BufP alloc_zero(size_t bytes);
+  void sync() { SQ_HIP(hipStreamSynchronize(stream)); }
+  // copies `bytes` from device to the pinned area and synchronises; returns host pointer
+  const void *fetch(const void *dptr, size_t bytes);
+  template <class T> T fetch_value(const T *dptr) { return *(const T *)fetch(dptr, sizeof(T)); }
+  int prof_entry(const char *name);
+  void prof_resolve();
+};
+
+// RAII profiling scope: two event records around a launch group when enabled.
+struct ProfScope {
+  Ctx *ctx;
+  int entry = -1;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(Ctx *c, const char *name);
+  ~ProfScope();
+};
+
+// ------------------------------------------------------------- device columns --
+// A column whose buffers are in HBM.  Bitmaps (validity, BOOLEAN values) are padded to
+// whole u64 words.  `stride` 0 marks a broadcast scalar (1 element / 1 word buffers).
+struct DCol {
+  int32_t dtype = SQLRS_NULLTYPE;
+  int64_t length = 0;
+  int64_t null_count = 0; // -1 = unknown
+  int stride = 1;
+  const void *values = nullptr;
+  const uint64_t *validity = nullptr; // nullptr = all valid
+  const int32_t *offsets = nullptr;   // UTF8
+  int64_t data_bytes = 0;             // UTF8: bytes in `values`
+  uint64_t scalar_bits = 0;           // stride 0: host copy of the value (bit pattern)
+  bool scalar_null = false;           // stride 0: ScalarValue::X(None)
+  BufP own_values, own_validity, own_offsets; // keep-alive (null when borrowed)
+  bool has_nulls() const { return validity != nullptr && null_count != 0; }
+  template <class T> const T *v() const { return (const T *)values; }
+};
+
+struct DBatch {
+  int64_t rows = 0;
+  std::vector<DCol> cols;
+};
+
+// Lazily uploading view of a caller batch: a column is moved to HBM the first time an
+// operator touches it ("Arrow column buffers move to HBM once per pipeline").
+struct InBatch {
+  Ctx *ctx;
+  const sqlrs_batch_t *abi;
+  std::vector<DCol> cache;
+  std::vector<uint8_t> loaded;
+  InBatch(Ctx *c, const sqlrs_batch_t *b);
+  int64_t rows() const { return abi->num_rows; }
+  int num_columns() const { return abi->num_columns; }
+  int32_t dtype(int i) const { return abi->columns[i].dtype; }
+  const DCol &col(int i);
+  // all columns, device resident; owned=true forces private copies (for retaining operators)
+  DBatch materialize(bool owned);
+};
+
+DCol upload_column(Ctx *ctx, const sqlrs_column_t &c, bool force_copy);
+// Device batch -> library-owned ABI batch in `out_mem` (host: D2H into malloc'd buffers).
+sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem);
+DCol make_null_column(Ctx *ctx, int32_t dtype, int64_t n);
+int64_t count_nulls(Ctx *ctx, const DCol &c);
+
+template <class F> int guard(Ctx *ctx, F &&f) {
+  try {
+    f();
+    return SQLRS_OK;
+  } catch (const Error &e) {
+    if (ctx) ctx->last_error = e.msg;
+    return e.status;
+  } catch (const std::exception &e) {
+    if (ctx) ctx->last_error = e.what();
+    return SQLRS_ERR_INTERNAL;
+  }
+}
+
+// Expression (postfix) owned copy
+struct Expr {
+  std::vector<sqlrs_expr_node_t> nodes;
+  std::vector<std::string> strings;
+  bool empty() const { return nodes.empty(); }
+};
+Expr expr_from_abi(const sqlrs_expr_t *e);
+
+} // namespace sq
+
+struct sqlrs_ctx : sq::Ctx {};

@@ -1,0 +1,454 @@
+// ctx.hip — ctx lifecycle, device memory pool, ABI <-> HBM column conversion, timers.
+#include <cstdlib>
+
+#include "common.hpp"
+#include "prims.hpp"
+
+namespace sq {
+
+// ------------------------------------------------------------------------ pool --
+static size_t pool_size_class(size_t bytes) {
+  if (bytes < 512) return 512;
+  if (bytes <= (1u << 20)) { // next power of two
+    size_t s = 512;
+    while (s < bytes) s <<= 1;
+    return s;
+  }
+  return round_up(bytes, (size_t)2 << 20); // 2 MiB granules
+}
+
+void *Pool::alloc(size_t bytes, size_t *cap) {
+  size_t want = pool_size_class(bytes);
+  auto it = free_blocks.lower_bound(want);
+  if (it != free_blocks.end() && it->first <= want + want / 4 + (1u << 20)) {
+    void *p = it->second;
+    *cap = it->first;
+    cached_bytes -= it->first;
+    live_bytes += it->first;
+    free_blocks.erase(it);
+    return p;
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    trim();
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess)
+    fail(SQLRS_ERR_DEVICE, "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e));
+  *cap = want;
+  live_bytes += want;
+  return p;
+}
+void Pool::release(void *p, size_t cap) {
+  live_bytes -= cap;
+  cached_bytes += cap;
+  free_blocks.emplace(cap, p);
+}
+void Pool::trim() {
+  for (auto &kv : free_blocks) (void)hipFree(kv.second);
+  free_blocks.clear();
+  cached_bytes = 0;
+}
+
+Buf::~Buf() {
+  if (p) ctx->pool.release(p, cap);
+}
+
+BufP Ctx::alloc(size_t bytes) {
+  size_t cap = 0;
+  void *p = pool.alloc(bytes ? bytes : 8, &cap);
+  return std::make_shared<Buf>(this, p, cap);
+}
+BufP Ctx::alloc_zero(size_t bytes) {
+  BufP b = alloc(bytes);
+  SQ_HIP(hipMemsetAsync(b->p, 0, bytes ? bytes : 8, stream));
+  return b;
+}
+const void *Ctx::fetch(const void *dptr, size_t bytes) {
+  if (bytes > pinned_bytes) fail(SQLRS_ERR_INTERNAL, "fetch too large");
+  SQ_HIP(hipMemcpyAsync(pinned, dptr, bytes, hipMemcpyDeviceToHost, stream));
+  sync();
+  return pinned;
+}
+int Ctx::prof_entry(const char *name) {
+  for (size_t i = 0; i < prof.size(); i++)
+    if (prof[i].name == name || std::strcmp(prof[i].name, name) == 0) return (int)i;
+  prof.push_back(ProfEntry{name});
+  return (int)prof.size() - 1;
+}
+void Ctx::prof_resolve() {
+  if (prof_pending.empty()) return;
+  sync();
+  for (auto &p : prof_pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      prof[p.entry].total_ms += ms;
+      prof[p.entry].launches++;
+    }
+    event_pool.push_back(p.a);
+    event_pool.push_back(p.b);
+  }
+  prof_pending.clear();
+}
+
+ProfScope::ProfScope(Ctx *c, const char *name) : ctx(c) {
+  if (!c->prof_on) return;
+  entry = c->prof_entry(name);
+  auto get = [&]() {
+    if (!c->event_pool.empty()) {
+      hipEvent_t e = c->event_pool.back();
+      c->event_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    SQ_HIP(hipEventCreate(&e));
+    return e;
+  };
+  a = get();
+  b = get();
+  (void)hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope() {
+  if (entry < 0) return;
+  (void)hipEventRecord(b, ctx->stream);
+  ctx->prof_pending.push_back(ProfPending{entry, a, b});
+  if (ctx->prof_pending.size() > 4096) {
+    try {
+      ctx->prof_resolve();
+    } catch (...) {
+    }
+  }
+}
+
+// ------------------------------------------------------------------- columns --
+Expr expr_from_abi(const sqlrs_expr_t *e) {
+  Expr x;
+  if (!e || e->num_nodes <= 0 || !e->nodes) fail(SQLRS_ERR_INTERNAL, "empty expression");
+  x.nodes.assign(e->nodes, e->nodes + e->num_nodes);
+  x.strings.resize(x.nodes.size());
+  for (size_t i = 0; i < x.nodes.size(); i++) {
+    if (x.nodes[i].s) x.strings[i] = x.nodes[i].s;
+    x.nodes[i].s = nullptr;
+  }
+  return x;
+}
+
+static void copy_in(Ctx *ctx, void *dst, const void *src, size_t bytes, int mem) {
+  if (!bytes) return;
+  SQ_HIP(hipMemcpyAsync(dst, src, bytes,
+                        mem == SQLRS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                        ctx->stream));
+}
+
+DCol upload_column(Ctx *ctx, const sqlrs_column_t &c, bool force_copy) {
+  DCol d;
+  d.dtype = c.dtype;
+  d.length = c.length;
+  d.null_count = c.validity ? c.null_count : 0;
+  bool copy = force_copy || c.mem == SQLRS_MEM_HOST;
+  if (c.mem != SQLRS_MEM_HOST && c.mem != SQLRS_MEM_DEVICE) fail(SQLRS_ERR_ARROW, "bad column mem");
+  size_t nbits = (size_t)ceil_div(c.length, 8);
+  if (c.validity && c.null_count != 0) {
+    if (copy) {
+      d.own_validity = ctx->alloc_zero(bitmap_bytes(c.length));
+      copy_in(ctx, d.own_validity->p, c.validity, nbits, c.mem);
+      d.validity = d.own_validity->as<uint64_t>();
+    } else
+      d.validity = (const uint64_t *)c.validity;
+  }
+  switch (c.dtype) {
+  case SQLRS_BOOLEAN:
+    if (copy) {
+      d.own_values = ctx->alloc_zero(bitmap_bytes(c.length));
+      copy_in(ctx, d.own_values->p, c.values, nbits, c.mem);
+      d.values = d.own_values->p;
+    } else
+      d.values = c.values;
+    break;
+  case SQLRS_UTF8: {
+    if (!c.offsets) fail(SQLRS_ERR_ARROW, "utf8 column without offsets");
+    int32_t last = 0;
+    if (c.mem == SQLRS_MEM_HOST)
+      last = c.offsets[c.length];
+    else {
+      SQ_HIP(hipMemcpyAsync(&last, c.offsets + c.length, 4, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();
+    }
+    d.data_bytes = last;
+    if (copy) {
+      d.own_offsets = ctx->alloc(4 * (size_t)(c.length + 1));
+      copy_in(ctx, d.own_offsets->p, c.offsets, 4 * (size_t)(c.length + 1), c.mem);
+      d.offsets = d.own_offsets->as<int32_t>();
+      d.own_values = ctx->alloc((size_t)last + 8);
+      copy_in(ctx, d.own_values->p, c.values, (size_t)last, c.mem);
+      d.values = d.own_values->p;
+    } else {
+      d.offsets = c.offsets;
+      d.values = c.values;
+    }
+    break;
+  }
+  default: {
+    size_t w = width_of(c.dtype);
+    if (!w) fail(SQLRS_ERR_INTERNAL, "unsupported column dtype " + std::to_string(c.dtype));
+    if (copy) {
+      d.own_values = ctx->alloc(w * (size_t)c.length + 16);
+      copy_in(ctx, d.own_values->p, c.values, w * (size_t)c.length, c.mem);
+      d.values = d.own_values->p;
+    } else
+      d.values = c.values;
+  }
+  }
+  return d;
+}
+
+InBatch::InBatch(Ctx *c, const sqlrs_batch_t *b) : ctx(c), abi(b) {
+  if (!b) fail(SQLRS_ERR_ARROW, "null batch");
+  if (b->num_columns < 0 || (b->num_columns > 0 && !b->columns)) fail(SQLRS_ERR_ARROW, "bad batch");
+  for (int i = 0; i < b->num_columns; i++)
+    if (b->columns[i].length != b->num_rows) fail(SQLRS_ERR_ARROW, "column length != num_rows");
+  cache.resize((size_t)b->num_columns);
+  loaded.assign((size_t)b->num_columns, 0);
+}
+const DCol &InBatch::col(int i) {
+  if (i < 0 || i >= abi->num_columns) fail(SQLRS_ERR_INTERNAL, "input ref out of range");
+  if (!loaded[(size_t)i]) {
+    cache[(size_t)i] = upload_column(ctx, abi->columns[i], false);
+    loaded[(size_t)i] = 1;
+  }
+  return cache[(size_t)i];
+}
+DBatch InBatch::materialize(bool owned) {
+  DBatch b;
+  b.rows = abi->num_rows;
+  for (int i = 0; i < abi->num_columns; i++) {
+    if (owned && abi->columns[i].mem == SQLRS_MEM_DEVICE)
+      b.cols.push_back(upload_column(ctx, abi->columns[i], true));
+    else
+      b.cols.push_back(col(i));
+  }
+  return b;
+}
+
+int64_t count_nulls(Ctx *ctx, const DCol &c) {
+  if (!c.validity) return 0;
+  if (c.null_count >= 0) return c.null_count;
+  return count_clear_bits(ctx, c.validity, c.length);
+}
+
+// ------------------------------------------------------------ emitting batches --
+struct OwnedBatch {
+  sqlrs_batch_t abi;
+  std::vector<sqlrs_column_t> descs;
+  DBatch dev;                     // keeps device buffers alive (out_mem == DEVICE)
+  std::vector<void *> host_blocks; // malloc'd (out_mem == HOST)
+  ~OwnedBatch() {
+    for (void *p : host_blocks) std::free(p);
+  }
+};
+
+sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem) {
+  if (out_mem != SQLRS_MEM_HOST && out_mem != SQLRS_MEM_DEVICE)
+    fail(SQLRS_ERR_INTERNAL, "bad out_mem");
+  auto o = std::unique_ptr<OwnedBatch>(new OwnedBatch());
+  o->dev = std::move(b);
+  DBatch &d = o->dev;
+  const int64_t rows = d.rows;
+  o->descs.resize(d.cols.size());
+  for (size_t i = 0; i < d.cols.size(); i++) {
+    DCol &c = d.cols[i];
+    if (c.stride == 0) c = materialize_scalar(ctx, c, d.rows);
+    if (c.length != d.rows) fail(SQLRS_ERR_INTERNAL, "emit: column length mismatch");
+    if (c.validity && c.null_count < 0) c.null_count = count_clear_bits(ctx, c.validity, c.length);
+    if (c.validity && c.null_count == 0) {
+      c.validity = nullptr;
+      c.own_validity.reset();
+    }
+    sqlrs_column_t &s = o->descs[i];
+    s.dtype = c.dtype;
+    s.mem = out_mem;
+    s.length = c.length;
+    s.null_count = c.validity ? c.null_count : 0;
+    s.values = nullptr;
+    s.validity = nullptr;
+    s.offsets = nullptr;
+    if (out_mem == SQLRS_MEM_DEVICE) {
+      s.values = c.values;
+      s.validity = (const uint8_t *)c.validity;
+      s.offsets = c.offsets;
+      continue;
+    }
+    auto down = [&](const void *dptr, size_t bytes) -> void * {
+      void *h = std::malloc(bytes + 64);
+      if (!h) fail(SQLRS_ERR_INTERNAL, "host allocation failed");
+      o->host_blocks.push_back(h);
+      if (bytes) SQ_HIP(hipMemcpyAsync(h, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      return h;
+    };
+    size_t nbits = (size_t)ceil_div(c.length, 8);
+    if (c.validity) s.validity = (const uint8_t *)down(c.validity, nbits);
+    if (c.dtype == SQLRS_BOOLEAN)
+      s.values = down(c.values, nbits);
+    else if (c.dtype == SQLRS_UTF8) {
+      s.offsets = (const int32_t *)down(c.offsets, 4 * (size_t)(c.length + 1));
+      s.values = down(c.values, (size_t)c.data_bytes);
+    } else
+      s.values = down(c.values, width_of(c.dtype) * (size_t)c.length);
+  }
+  if (out_mem == SQLRS_MEM_HOST) {
+    ctx->sync();
+    o->dev = DBatch(); // device buffers go back to the pool
+  }
+  o->abi.num_rows = rows;
+  o->abi.num_columns = (int32_t)o->descs.size();
+  o->abi.reserved = 0;
+  o->abi.columns = o->descs.data();
+  o->abi.owner = o.get();
+  return &o.release()->abi;
+}
+
+} // namespace sq
+
+using namespace sq;
+
+// =============================================================== C entry points ==
+extern "C" {
+
+int sqlrs_ctx_create(int device_id, sqlrs_ctx_t **out) {
+  if (!out) return SQLRS_ERR_INTERNAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n)
+    return SQLRS_ERR_DEVICE; // no CPU fallback exists: fail loudly
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return SQLRS_ERR_DEVICE;
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return SQLRS_ERR_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return SQLRS_ERR_DEVICE;
+  auto *c = new sqlrs_ctx();
+  c->device = device_id;
+  c->num_cus = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) {
+    delete c;
+    return SQLRS_ERR_DEVICE;
+  }
+  c->pinned_bytes = 4096;
+  *out = c;
+  return SQLRS_OK;
+}
+
+void sqlrs_ctx_destroy(sqlrs_ctx_t *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &p : ctx->prof_pending) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  ctx->pool.trim();
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *sqlrs_last_error(const sqlrs_ctx_t *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int sqlrs_ctx_synchronize(sqlrs_ctx_t *ctx) {
+  return guard(ctx, [&] { ctx->sync(); });
+}
+void *sqlrs_ctx_stream(sqlrs_ctx_t *ctx) { return (void *)ctx->stream; }
+int64_t sqlrs_ctx_pool_bytes(const sqlrs_ctx_t *ctx) {
+  return (int64_t)(ctx->pool.live_bytes + ctx->pool.cached_bytes);
+}
+void sqlrs_ctx_pool_trim(sqlrs_ctx_t *ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->pool.trim();
+}
+
+void sqlrs_batch_release(sqlrs_batch_t *batch) {
+  if (batch && batch->owner) delete (OwnedBatch *)batch->owner;
+}
+
+int sqlrs_batch_copy(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out) {
+  return guard(ctx, [&] {
+    SQ_HIP(hipSetDevice(ctx->device));
+    InBatch ib(ctx, in);
+    DBatch b = ib.materialize(true);
+    *out = emit_batch(ctx, std::move(b), out_mem);
+  });
+}
+
+// ---- timers
+struct sqlrs_timer {
+  Ctx *ctx;
+  hipEvent_t a, b;
+};
+int sqlrs_timer_create(sqlrs_ctx_t *ctx, sqlrs_timer_t **out) {
+  return guard(ctx, [&] {
+    auto *t = new sqlrs_timer();
+    t->ctx = ctx;
+    SQ_HIP(hipEventCreate(&t->a));
+    SQ_HIP(hipEventCreate(&t->b));
+    *out = t;
+  });
+}
+int sqlrs_timer_start(sqlrs_timer_t *t) {
+  return guard(t->ctx, [&] { SQ_HIP(hipEventRecord(t->a, t->ctx->stream)); });
+}
+int sqlrs_timer_stop(sqlrs_timer_t *t) {
+  return guard(t->ctx, [&] { SQ_HIP(hipEventRecord(t->b, t->ctx->stream)); });
+}
+int sqlrs_timer_elapsed_ms(sqlrs_timer_t *t, double *ms) {
+  return guard(t->ctx, [&] {
+    SQ_HIP(hipEventSynchronize(t->b));
+    float f = 0;
+    SQ_HIP(hipEventElapsedTime(&f, t->a, t->b));
+    *ms = f;
+  });
+}
+void sqlrs_timer_destroy(sqlrs_timer_t *t) {
+  if (!t) return;
+  (void)hipEventDestroy(t->a);
+  (void)hipEventDestroy(t->b);
+  delete t;
+}
+
+int sqlrs_ctx_profile_enable(sqlrs_ctx_t *ctx, int on) {
+  return guard(ctx, [&] {
+    ctx->prof_resolve();
+    ctx->prof_on = on != 0;
+  });
+}
+int sqlrs_ctx_profile_reset(sqlrs_ctx_t *ctx) {
+  return guard(ctx, [&] {
+    ctx->prof_resolve();
+    for (auto &e : ctx->prof) {
+      e.total_ms = 0;
+      e.launches = 0;
+    }
+  });
+}
+int sqlrs_ctx_profile_read(sqlrs_ctx_t *ctx, int cap, const char **names, double *total_ms,
+                           int64_t *launches) {
+  try {
+    ctx->prof_resolve();
+  } catch (...) {
+    return 0;
+  }
+  int n = 0;
+  for (auto &e : ctx->prof) {
+    if (n < cap) {
+      names[n] = e.name;
+      total_ms[n] = e.total_ms;
+      launches[n] = e.launches;
+    }
+    n++;
+  }
+  return n;
+}
+
+const char *sqlrs_version(void) { return "sqlrs-hip 0.1.0 gfx950"; }
+
+} // extern "C"

@@ -1,0 +1,140 @@
+// device_utils.hpp — wave64 device helpers shared by every kernel file (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sq {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;          // 4 waves
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int TILE_WORDS = 64;      // selection-mask words per tile
+constexpr int TILE_ROWS = 4096;     // rows per tile of every mask / compaction kernel
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int mbcnt(uint64_t mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+  uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+  uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+  uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
+  uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+  uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64);
+  uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
+  return v;
+}
+// inclusive scan across the 64 lanes
+__device__ __forceinline__ uint32_t wave_iscan_u32(uint32_t v) {
+  int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_iscan_u64(uint64_t v) {
+  int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t t = shfl_up_u64(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+// ------------------------------------------------- decoupled look-back (tiles) --
+// One 8-byte descriptor per tile: bits 63..62 = status, low 62 bits = value.  The value
+// IS the flag (single aligned 8-byte agent-scope store/load), so no fence is needed
+// (MI355X_MICROARCH.md: data-tagged granules).  Tiles take their index from an atomic
+// ticket so every predecessor of a running tile is running or finished.
+constexpr uint64_t LB_AGG = 1ull << 62;
+constexpr uint64_t LB_PFX = 2ull << 62;
+constexpr uint64_t LB_VAL = (1ull << 62) - 1;
+
+__device__ __forceinline__ uint64_t lb_load(const uint64_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lb_store(uint64_t *p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by ALL 64 lanes of ONE wave.  Publishes this tile's aggregate, walks back over
+// predecessor descriptors 64 at a time and returns the tile's exclusive prefix.
+__device__ __forceinline__ uint64_t lookback_wave(uint64_t *desc, int64_t tile, uint64_t aggregate) {
+  const int lane = lane_id();
+  if (tile == 0) {
+    if (lane == 0) lb_store(&desc[0], LB_PFX | aggregate);
+    return 0;
+  }
+  if (lane == 0) lb_store(&desc[tile], LB_AGG | aggregate);
+  uint64_t excl = 0;
+  int64_t base = tile - 1;
+  while (true) {
+    int64_t t = base - lane;
+    uint64_t d = (t >= 0) ? lb_load(&desc[t]) : LB_PFX; // virtual tiles < 0: prefix 0
+    uint64_t status = d >> 62;
+    uint64_t invalid = __ballot(status == 0);
+    uint64_t pfx = __ballot(status == 2);
+    int first_pfx = pfx ? __builtin_ctzll(pfx) : 64;
+    uint64_t need = first_pfx == 64 ? ~0ull : ((1ull << first_pfx) - 1);
+    if (invalid & need) {
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    uint64_t v = (lane <= first_pfx) ? (d & LB_VAL) : 0;
+    excl += wave_sum_u64(v);
+    if (first_pfx < 64) break;
+    base -= 64;
+  }
+  if (lane == 0) lb_store(&desc[tile], LB_PFX | (excl + aggregate));
+  return excl;
+}
+
+// order-preserving transforms to unsigned keys (radix sort, min/max atomics)
+__device__ __forceinline__ uint64_t i64_to_ordered(int64_t v) { return (uint64_t)v ^ (1ull << 63); }
+__device__ __forceinline__ int64_t ordered_to_i64(uint64_t u) { return (int64_t)(u ^ (1ull << 63)); }
+__device__ __forceinline__ uint64_t f64_to_ordered(double f) { // IEEE total order
+  uint64_t b = (uint64_t)__double_as_longlong(f);
+  return (b >> 63) ? ~b : (b | (1ull << 63));
+}
+__device__ __forceinline__ double ordered_to_f64(uint64_t u) {
+  uint64_t b = (u >> 63) ? (u & ~(1ull << 63)) : ~u;
+  return __longlong_as_double((long long)b);
+}
+
+} // namespace sq

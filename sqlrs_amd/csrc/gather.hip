@@ -1,0 +1,374 @@
+// gather.hip — arrow `take` on device (hash_join.rs:25-45 build_batch, order.rs:47-64),
+// concat_batches (hash_join.rs:187, order.rs:28), scalar broadcast and bitmap helpers.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "prims.hpp"
+
+namespace sq {
+
+// out[i] = src[idx[i]]; one row per lane, so idx reads / out writes are coalesced and each
+// wave's 64 validity bits form exactly one output word (ballot).
+template <class T, class I>
+__global__ __launch_bounds__(BLOCK) void gather_kernel(const T *__restrict__ src,
+                                                       const uint64_t *__restrict__ src_validity,
+                                                       const I *__restrict__ idx,
+                                                       const uint64_t *__restrict__ idx_validity,
+                                                       int64_t n, T *__restrict__ out,
+                                                       uint64_t *__restrict__ out_validity) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool in_range = i < n;
+  bool valid = in_range;
+  I s = 0;
+  if (in_range) {
+    if (idx_validity) valid = (idx_validity[i >> 6] >> (i & 63)) & 1;
+    if (valid) {
+      s = idx[i];
+      if (src_validity) valid = (src_validity[s >> 6] >> (s & 63)) & 1;
+    }
+    out[i] = valid ? src[s] : T(0);
+  }
+  if (out_validity) {
+    uint64_t m = __ballot(valid);
+    if (lane_id() == 0 && (i & ~63ll) < n) out_validity[i >> 6] = m;
+  }
+}
+
+// BOOLEAN values: gather single bits
+template <class I>
+__global__ __launch_bounds__(BLOCK) void gather_bits_kernel(const uint64_t *__restrict__ src,
+                                                            const uint64_t *__restrict__ src_validity,
+                                                            const I *__restrict__ idx,
+                                                            const uint64_t *__restrict__ idx_validity,
+                                                            int64_t n, uint64_t *__restrict__ out,
+                                                            uint64_t *__restrict__ out_validity) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool valid = i < n, bit = false;
+  if (valid) {
+    if (idx_validity) valid = (idx_validity[i >> 6] >> (i & 63)) & 1;
+    if (valid) {
+      I s = idx[i];
+      if (src_validity) valid = (src_validity[s >> 6] >> (s & 63)) & 1;
+      bit = valid && ((src[s >> 6] >> (s & 63)) & 1);
+    }
+  }
+  uint64_t mb = __ballot(bit), mv = __ballot(valid);
+  if (lane_id() == 0 && (i & ~63ll) < n) {
+    out[i >> 6] = mb;
+    if (out_validity) out_validity[i >> 6] = mv;
+  }
+}
+
+// UTF8: lengths -> scan -> byte copy
+template <class I>
+__global__ void utf8_lengths_kernel(const int32_t *__restrict__ offsets,
+                                    const uint64_t *__restrict__ src_validity,
+                                    const I *__restrict__ idx,
+                                    const uint64_t *__restrict__ idx_validity, int64_t n,
+                                    uint32_t *__restrict__ len, uint64_t *__restrict__ out_validity) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool valid = i < n;
+  uint32_t l = 0;
+  if (valid) {
+    if (idx_validity) valid = (idx_validity[i >> 6] >> (i & 63)) & 1;
+    if (valid) {
+      I s = idx[i];
+      if (src_validity) valid = (src_validity[s >> 6] >> (s & 63)) & 1;
+      if (valid) l = (uint32_t)(offsets[s + 1] - offsets[s]);
+    }
+    len[i] = l;
+  }
+  if (out_validity) {
+    uint64_t m = __ballot(valid);
+    if (lane_id() == 0 && (i & ~63ll) < n) out_validity[i >> 6] = m;
+  }
+}
+template <class I>
+__global__ void utf8_copy_kernel(const uint8_t *__restrict__ src, const int32_t *__restrict__ offsets,
+                                 const I *__restrict__ idx, const uint32_t *__restrict__ len,
+                                 const uint32_t *__restrict__ new_off, int64_t n,
+                                 uint8_t *__restrict__ out, int32_t *__restrict__ out_offsets,
+                                 const uint64_t *total) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i == 0) out_offsets[n] = (int32_t)*total;
+  if (i >= n) return;
+  uint32_t o = new_off[i], l = len[i];
+  out_offsets[i] = (int32_t)o;
+  if (!l) return;
+  const uint8_t *s = src + offsets[idx[i]];
+  for (uint32_t k = 0; k < l; k++) out[o + k] = s[k];
+}
+
+template <class I>
+static DCol gather_impl(Ctx *ctx, const DCol &src, const I *idx, const uint64_t *idx_validity,
+                        int64_t n) {
+  DCol o;
+  o.dtype = src.dtype;
+  o.length = n;
+  const uint64_t *sv = (src.validity && src.null_count != 0) ? src.validity : nullptr;
+  bool nullable = sv || idx_validity;
+  uint64_t *ov = nullptr;
+  if (nullable) {
+    o.own_validity = ctx->alloc(bitmap_bytes(std::max<int64_t>(n, 1)));
+    o.validity = ov = o.own_validity->as<uint64_t>();
+    o.null_count = -1;
+  }
+  int64_t n64 = (int64_t)round_up((size_t)std::max<int64_t>(n, 1), 64);
+  dim3 g((unsigned)ceil_div(n64, BLOCK)), b(BLOCK);
+  ProfScope ps(ctx, "gather");
+  if (src.dtype == SQLRS_UTF8) {
+    BufP len = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
+    BufP noff = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
+    BufP total = ctx->alloc_zero(8);
+    o.own_offsets = ctx->alloc(4 * (size_t)(n + 1));
+    o.offsets = o.own_offsets->as<int32_t>();
+    if (n == 0) {
+      SQ_HIP(hipMemsetAsync(o.own_offsets->p, 0, 4, ctx->stream));
+      o.own_values = ctx->alloc(8);
+      o.values = o.own_values->p;
+      return o;
+    }
+    utf8_lengths_kernel<I><<<g, b, 0, ctx->stream>>>(src.offsets, sv, idx, idx_validity, n,
+                                                     len->as<uint32_t>(), ov);
+    SQ_HIP(hipGetLastError());
+    exclusive_scan_u32(ctx, len->as<uint32_t>(), n, nullptr, noff->as<uint32_t>(),
+                       total->as<uint64_t>());
+    uint64_t bytes = ctx->fetch_value(total->as<uint64_t>());
+    if (bytes > 0x7fffffffull) fail(SQLRS_ERR_ARROW, "utf8 take overflows int32 offsets");
+    o.data_bytes = (int64_t)bytes;
+    o.own_values = ctx->alloc((size_t)bytes + 8);
+    o.values = o.own_values->p;
+    utf8_copy_kernel<I><<<g, b, 0, ctx->stream>>>(src.v<uint8_t>(), src.offsets, idx,
+                                                  len->as<uint32_t>(), noff->as<uint32_t>(), n,
+                                                  o.own_values->as<uint8_t>(),
+                                                  o.own_offsets->as<int32_t>(), total->as<uint64_t>());
+    SQ_HIP(hipGetLastError());
+    return o;
+  }
+  if (src.dtype == SQLRS_BOOLEAN) {
+    o.own_values = ctx->alloc(bitmap_bytes(std::max<int64_t>(n, 1)));
+    o.values = o.own_values->p;
+    if (n == 0) return o;
+    gather_bits_kernel<I><<<g, b, 0, ctx->stream>>>(src.v<uint64_t>(), sv, idx, idx_validity, n,
+                                                    o.own_values->as<uint64_t>(), ov);
+    SQ_HIP(hipGetLastError());
+    return o;
+  }
+  size_t w = width_of(src.dtype);
+  if (!w) fail(SQLRS_ERR_INTERNAL, "take: unsupported dtype");
+  o.own_values = ctx->alloc(w * (size_t)std::max<int64_t>(n, 1) + 16);
+  o.values = o.own_values->p;
+  if (n == 0) return o;
+  if (w == 8)
+    gather_kernel<uint64_t, I><<<g, b, 0, ctx->stream>>>(src.v<uint64_t>(), sv, idx, idx_validity, n,
+                                                         o.own_values->as<uint64_t>(), ov);
+  else
+    gather_kernel<uint32_t, I><<<g, b, 0, ctx->stream>>>(src.v<uint32_t>(), sv, idx, idx_validity, n,
+                                                         o.own_values->as<uint32_t>(), ov);
+  SQ_HIP(hipGetLastError());
+  return o;
+}
+
+DCol gather_column(Ctx *ctx, const DCol &src_in, const void *idx, bool idx_is_u64,
+                   const uint64_t *idx_validity, int64_t n) {
+  DCol src = src_in.stride == 0 ? materialize_scalar(ctx, src_in, src_in.length) : src_in;
+  if (idx_is_u64) return gather_impl<uint64_t>(ctx, src, (const uint64_t *)idx, idx_validity, n);
+  return gather_impl<uint32_t>(ctx, src, (const uint32_t *)idx, idx_validity, n);
+}
+
+// ------------------------------------------------------------------ bit helpers --
+__global__ void count_clear_kernel(const uint64_t *__restrict__ bits, int64_t rows, int64_t nwords,
+                                   unsigned long long *out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  uint64_t c = 0;
+  for (int64_t w = i; w < nwords; w += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t v = ~bits[w];
+    int64_t rem = rows - w * 64;
+    if (rem < 64) v &= (1ull << rem) - 1;
+    c += (uint64_t)__popcll(v);
+  }
+  c = wave_sum_u64(c);
+  if (lane_id() == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+int64_t count_clear_bits(Ctx *ctx, const uint64_t *bits, int64_t rows) {
+  if (!bits || rows == 0) return 0;
+  BufP out = ctx->alloc_zero(8);
+  int64_t nwords = ceil_div(rows, 64);
+  unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(nwords, 256), 2048);
+  count_clear_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
+      bits, rows, nwords, out->as<unsigned long long>());
+  SQ_HIP(hipGetLastError());
+  return (int64_t)ctx->fetch_value(out->as<uint64_t>());
+}
+
+// Copies `n` bits from src (starting at bit 0) to dst starting at bit `dst_off` (dst zeroed).
+__global__ void append_bits_kernel(const uint64_t *__restrict__ src, int64_t n, int64_t dst_off,
+                                   unsigned long long *__restrict__ dst, int all_ones) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; // source word
+  int64_t nw = (n + 63) >> 6;
+  if (i >= nw) return;
+  uint64_t v = all_ones ? ~0ull : src[i];
+  int64_t rem = n - i * 64;
+  if (rem < 64) v &= (1ull << rem) - 1;
+  int64_t pos = dst_off + i * 64;
+  int sh = (int)(pos & 63);
+  int64_t dw = pos >> 6;
+  if (v << sh) atomicOr(&dst[dw], (unsigned long long)(v << sh));
+  if (sh && (v >> (64 - sh))) atomicOr(&dst[dw + 1], (unsigned long long)(v >> (64 - sh)));
+}
+
+__global__ void rebase_offsets_kernel(const int32_t *__restrict__ src, int64_t n, int32_t add,
+                                      int32_t *__restrict__ dst) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i <= n) dst[i] = src[i] + add;
+}
+
+DCol concat_columns(Ctx *ctx, const std::vector<const DCol *> &parts_in) {
+  if (parts_in.empty()) fail(SQLRS_ERR_INTERNAL, "concat of nothing");
+  std::vector<DCol> mat;
+  mat.reserve(parts_in.size());
+  for (const DCol *p : parts_in) mat.push_back(p->stride == 0 ? materialize_scalar(ctx, *p, p->length) : *p);
+  if (mat.size() == 1) return mat[0];
+  DCol o;
+  o.dtype = mat[0].dtype;
+  bool any_nulls = false;
+  int64_t total = 0, total_bytes = 0;
+  for (const DCol &p : mat) {
+    if (p.dtype != o.dtype) fail(SQLRS_ERR_ARROW, "concat_batches: schema mismatch");
+    total += p.length;
+    total_bytes += p.data_bytes;
+    any_nulls |= (p.validity && p.null_count != 0);
+  }
+  o.length = total;
+  ProfScope ps(ctx, "concat");
+  auto bits_concat = [&](bool validity) -> BufP {
+    BufP out = ctx->alloc_zero(bitmap_bytes(std::max<int64_t>(total, 1)) + 8);
+    int64_t off = 0;
+    for (const DCol &p : mat) {
+      const uint64_t *src = validity ? p.validity : p.v<uint64_t>();
+      int ones = validity && !(p.validity && p.null_count != 0);
+      int64_t nw = ceil_div(p.length, 64);
+      if (nw)
+        append_bits_kernel<<<dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, ctx->stream>>>(
+            src, p.length, off, out->as<unsigned long long>(), ones);
+      off += p.length;
+    }
+    SQ_HIP(hipGetLastError());
+    return out;
+  };
+  if (any_nulls) {
+    o.own_validity = bits_concat(true);
+    o.validity = o.own_validity->as<uint64_t>();
+    o.null_count = -1;
+  }
+  if (o.dtype == SQLRS_BOOLEAN) {
+    o.own_values = bits_concat(false);
+    o.values = o.own_values->p;
+    return o;
+  }
+  if (o.dtype == SQLRS_UTF8) {
+    if (total_bytes > 0x7fffffffll) fail(SQLRS_ERR_ARROW, "concat overflows int32 offsets");
+    o.own_offsets = ctx->alloc(4 * (size_t)(total + 1));
+    o.own_values = ctx->alloc((size_t)total_bytes + 8);
+    o.offsets = o.own_offsets->as<int32_t>();
+    o.values = o.own_values->p;
+    o.data_bytes = total_bytes;
+    int64_t roff = 0, boff = 0;
+    for (const DCol &p : mat) {
+      rebase_offsets_kernel<<<dim3((unsigned)ceil_div(p.length + 1, 256)), dim3(256), 0,
+                              ctx->stream>>>(p.offsets, p.length, (int32_t)boff,
+                                             o.own_offsets->as<int32_t>() + roff);
+      if (p.data_bytes)
+        SQ_HIP(hipMemcpyAsync(o.own_values->as<uint8_t>() + boff, p.values, (size_t)p.data_bytes,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+      roff += p.length;
+      boff += p.data_bytes;
+    }
+    SQ_HIP(hipGetLastError());
+    return o;
+  }
+  size_t w = width_of(o.dtype);
+  o.own_values = ctx->alloc(w * (size_t)std::max<int64_t>(total, 1) + 16);
+  o.values = o.own_values->p;
+  size_t off = 0;
+  for (const DCol &p : mat) {
+    if (p.length)
+      SQ_HIP(hipMemcpyAsync(o.own_values->as<uint8_t>() + off, p.values, w * (size_t)p.length,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+    off += w * (size_t)p.length;
+  }
+  return o;
+}
+
+// --------------------------------------------------------------- scalar fill --
+template <class T> __global__ void fill_kernel(T *out, int64_t n, T v) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = v;
+}
+
+DCol materialize_scalar(Ctx *ctx, const DCol &c, int64_t rows) {
+  if (c.stride != 0) return c;
+  if (c.scalar_null) return make_null_column(ctx, c.dtype, rows);
+  DCol o;
+  o.dtype = c.dtype;
+  o.length = rows;
+  int64_t n1 = std::max<int64_t>(rows, 1);
+  int64_t nw = ceil_div(n1, 64);
+  if (c.dtype == SQLRS_BOOLEAN) {
+    o.own_values = ctx->alloc(8 * (size_t)nw);
+    fill_kernel<uint64_t><<<dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, ctx->stream>>>(
+        o.own_values->as<uint64_t>(), nw, c.scalar_bits ? ~0ull : 0ull);
+    o.values = o.own_values->p;
+  } else if (c.dtype == SQLRS_UTF8) {
+    fail(SQLRS_ERR_INTERNAL, "utf8 constants are not supported on the device path");
+  } else {
+    size_t w = width_of(c.dtype);
+    if (!w) fail(SQLRS_ERR_INTERNAL, "constant of unsupported dtype");
+    o.own_values = ctx->alloc(w * (size_t)n1 + 16);
+    o.values = o.own_values->p;
+    if (w == 8)
+      fill_kernel<uint64_t><<<dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, ctx->stream>>>(
+          o.own_values->as<uint64_t>(), rows, c.scalar_bits);
+    else
+      fill_kernel<uint32_t><<<dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, ctx->stream>>>(
+          o.own_values->as<uint32_t>(), rows, (uint32_t)c.scalar_bits);
+  }
+  SQ_HIP(hipGetLastError());
+  return o;
+}
+
+DCol make_null_column(Ctx *ctx, int32_t dtype, int64_t n) {
+  DCol o;
+  o.dtype = dtype;
+  o.length = n;
+  o.null_count = n;
+  int64_t n1 = std::max<int64_t>(n, 1);
+  if (n > 0) {
+    o.own_validity = ctx->alloc_zero(bitmap_bytes(n1));
+    o.validity = o.own_validity->as<uint64_t>();
+  }
+  if (dtype == SQLRS_UTF8) {
+    o.own_offsets = ctx->alloc_zero(4 * (size_t)(n + 1));
+    o.offsets = o.own_offsets->as<int32_t>();
+    o.own_values = ctx->alloc(8);
+  } else if (dtype == SQLRS_BOOLEAN) {
+    o.own_values = ctx->alloc_zero(bitmap_bytes(n1));
+  } else {
+    size_t w = width_of(dtype);
+    if (!w) fail(SQLRS_ERR_INTERNAL, "null array of unsupported dtype");
+    o.own_values = ctx->alloc_zero(w * (size_t)n1);
+  }
+  o.values = o.own_values->p;
+  return o;
+}
+
+template <class T> __global__ void iota_kernel(T *out, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (T)i;
+}
+void iota_u32(Ctx *ctx, uint32_t *out, int64_t n) {
+  if (n <= 0) return;
+  iota_kernel<uint32_t><<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(out, n);
+  SQ_HIP(hipGetLastError());
+}
+
+} // namespace sq

@@ -1,0 +1,576 @@
+// join.hip — HashJoinExecutor on device (src/executor/join/hash_join.rs:146-323).
+//
+// Build (left child): open-addressing table in HBM, 16-byte slots {key, head, count}, linear
+// probing, slots claimed with one 64-bit CAS on the key.  Unique build keys (the PK-FK case,
+// detected during the build) store the build row directly in `head`; otherwise rows of one
+// key are laid out CSR-style in insertion order (stable radix sort by slot), which is what
+// makes the output pair order equal to the reference's Vec<usize> per hash (:172-177).
+//
+// Probe (right child): count matches per probe row -> exclusive scan -> fill, so pairs come
+// out probe-row major / build-insertion minor exactly like the reference loop (:225-248).
+// Algorithmic HBM bytes: 8 B per build row + 8 B per probe row + 12 B per emitted pair.
+// The table (16 B x 2 x build rows) is the random-access working set: at 1 M build rows it is
+// 32 MiB, i.e. L2 + Infinity-Cache resident (profiles/r01_ubench_mi355x.txt: ~66 G lookups/s).
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "prims.hpp"
+
+namespace sq {
+
+constexpr uint64_t EMPTY_KEY = ~0ull;
+
+struct Slot {
+  unsigned long long key;
+  uint32_t head;  // unique: build row; otherwise start into rows_by_slot
+  uint32_t count; // build rows with this key
+};
+
+__global__ void table_init_kernel(Slot *t, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) {
+    t[i].key = EMPTY_KEY;
+    t[i].head = 0;
+    t[i].count = 0;
+  }
+}
+
+// one build row per lane
+__global__ __launch_bounds__(BLOCK) void join_insert_kernel(const uint64_t *__restrict__ keys,
+                                                            const uint64_t *__restrict__ validity,
+                                                            int64_t n, Slot *table, uint64_t mask,
+                                                            uint32_t *__restrict__ row_slot,
+                                                            int *dup_flag) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t cap = mask + 1;
+  uint64_t key = keys[r];
+  uint64_t s;
+  if (validity && !((validity[r >> 6] >> (r & 63)) & 1))
+    s = cap; // all NULL keys share one slot (hash_utils.rs:91-104)
+  else if (key == EMPTY_KEY)
+    s = cap + 1;
+  else {
+    s = mix64(key) & mask;
+    while (true) {
+      unsigned long long cur = __hip_atomic_load(&table[s].key, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == key) break;
+      if (cur == EMPTY_KEY) {
+        unsigned long long prev = atomicCAS(&table[s].key, EMPTY_KEY, (unsigned long long)key);
+        if (prev == EMPTY_KEY || prev == key) break;
+      }
+      s = (s + 1) & mask;
+    }
+  }
+  uint32_t old = atomicAdd(&table[s].count, 1u);
+  if (old) *dup_flag = 1;
+  table[s].head = (uint32_t)r; // final only when every key is unique
+  row_slot[r] = (uint32_t)s;
+}
+
+__global__ void slot_counts_kernel(const Slot *__restrict__ t, int64_t n, uint32_t *__restrict__ c) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) c[i] = t[i].count;
+}
+__global__ void slot_heads_kernel(Slot *__restrict__ t, int64_t n, const uint32_t *__restrict__ h) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) t[i].head = h[i];
+}
+__global__ void u32_to_u64_kernel(const uint32_t *__restrict__ in, int64_t n, uint64_t *__restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
+__device__ __forceinline__ Slot load_slot(const Slot *p) {
+  ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
+  Slot s;
+  s.key = v.x;
+  s.head = (uint32_t)v.y;
+  s.count = (uint32_t)(v.y >> 32);
+  return s;
+}
+
+// returns the slot of `key` (count may be 0 for the two reserved slots) or count==0 on a miss
+__device__ __forceinline__ Slot probe_slot(const Slot *__restrict__ table, uint64_t mask, uint64_t key,
+                                           bool is_null) {
+  const uint64_t cap = mask + 1;
+  if (is_null) return load_slot(&table[cap]);
+  if (key == EMPTY_KEY) return load_slot(&table[cap + 1]);
+  uint64_t s = mix64(key) & mask;
+  while (true) {
+    Slot sl = load_slot(&table[s]);
+    if (sl.key == key) return sl;
+    if (sl.key == EMPTY_KEY) {
+      sl.count = 0;
+      return sl;
+    }
+    s = (s + 1) & mask;
+  }
+}
+
+// pass 1: pairs emitted by each probe row (Right/Full: an unmatched row emits one pair)
+__global__ __launch_bounds__(BLOCK) void join_count_kernel(const uint64_t *__restrict__ keys,
+                                                           const uint64_t *__restrict__ validity,
+                                                           int64_t n, const Slot *__restrict__ table,
+                                                           uint64_t mask, int outer_right,
+                                                           uint32_t *__restrict__ counts) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  bool is_null = validity && !((validity[r >> 6] >> (r & 63)) & 1);
+  Slot s = probe_slot(table, mask, keys[r], is_null);
+  uint32_t c = s.count;
+  if (outer_right && c == 0) c = 1;
+  counts[r] = c;
+}
+
+// pass 2: write the pairs at their scanned offsets
+__global__ __launch_bounds__(BLOCK) void join_fill_kernel(
+    const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n,
+    const Slot *__restrict__ table, uint64_t mask, int unique,
+    const uint32_t *__restrict__ rows_by_slot, const uint64_t *__restrict__ offsets,
+    uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx,
+    uint8_t *__restrict__ left_valid_bytes) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  bool is_null = validity && !((validity[r >> 6] >> (r & 63)) & 1);
+  Slot s = probe_slot(table, mask, keys[r], is_null);
+  uint64_t o = offsets[r];
+  if (s.count == 0) {
+    if (left_valid_bytes) { // Right/Full: (NULL, row)   hash_join.rs:241-246
+      left_idx[o] = 0;
+      right_idx[o] = (uint32_t)r;
+      left_valid_bytes[o] = 0;
+    }
+    return;
+  }
+  if (unique) {
+    left_idx[o] = s.head;
+    right_idx[o] = (uint32_t)r;
+    if (left_valid_bytes) left_valid_bytes[o] = 1;
+    return;
+  }
+  for (uint32_t j = 0; j < s.count; j++) {
+    left_idx[o + j] = rows_by_slot[s.head + j];
+    right_idx[o + j] = (uint32_t)r;
+    if (left_valid_bytes) left_valid_bytes[o + j] = 1;
+  }
+}
+
+__global__ void bytes_to_bits_kernel(const uint8_t *__restrict__ bytes, int64_t n,
+                                     uint64_t *__restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool b = (i < n) && bytes[i];
+  uint64_t m = __ballot(b);
+  if (lane_id() == 0 && i < n) out[i >> 6] = m;
+}
+
+// sets bit idx[i] for every valid i  (visited_left_side / visited_right_side)
+template <class I>
+__global__ void mark_bits_kernel(const I *__restrict__ idx, const uint64_t *__restrict__ idx_validity,
+                                 int64_t n, unsigned long long *__restrict__ bits) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (idx_validity && !((idx_validity[i >> 6] >> (i & 63)) & 1)) return;
+  uint64_t x = (uint64_t)idx[i];
+  atomicOr(&bits[x >> 6], 1ull << (x & 63));
+}
+
+} // namespace sq
+
+using namespace sq;
+
+struct sqlrs_hash_join {
+  Ctx *ctx = nullptr;
+  int join_type = 0;
+  std::vector<Expr> lkeys, rkeys;
+  bool has_filter = false;
+  Expr filter;
+  std::vector<int32_t> right_dtypes;
+  // build
+  std::vector<DBatch> left_batches;
+  std::vector<NKeys> left_key_parts;
+  bool finished = false, empty_build = true;
+  DBatch left;
+  int64_t nB = 0;
+  BufP table;
+  uint64_t mask = 0;
+  bool unique = true, exact = true;
+  int32_t key_dtype = SQLRS_INT64;
+  BufP rows_by_slot;
+  BufP visited; // bit per build row
+};
+
+namespace sq {
+
+struct Pairs {
+  int64_t m = 0;
+  BufP left, right;   // u64[m], u32[m]
+  BufP left_validity; // bitmap or null (Right/Full only)
+};
+
+static NKeys eval_keys(Ctx *ctx, const std::vector<Expr> &exprs,
+                       const std::function<const DCol &(int)> &col, int64_t rows) {
+  std::vector<DCol> kc;
+  for (const Expr &e : exprs) kc.push_back(eval_expr(ctx, e, col, rows, true));
+  return normalize_keys(ctx, kc, rows);
+}
+
+static void build_table(sqlrs_hash_join *j) {
+  Ctx *ctx = j->ctx;
+  // concat key parts
+  int64_t n = j->nB;
+  BufP keys = ctx->alloc(8 * (size_t)std::max<int64_t>(n, 1));
+  BufP validity;
+  bool any_null = false;
+  for (const NKeys &p : j->left_key_parts) any_null |= (p.validity != nullptr);
+  j->exact = j->left_key_parts[0].exact;
+  j->key_dtype = j->left_key_parts[0].dtype;
+  {
+    size_t off = 0;
+    std::vector<DCol> vparts;
+    for (const NKeys &p : j->left_key_parts) {
+      if (p.exact != j->exact || p.dtype != j->key_dtype)
+        fail(SQLRS_ERR_ARROW, "join key type changed between build batches");
+      if (p.rows)
+        SQ_HIP(hipMemcpyAsync(keys->as<uint8_t>() + off, p.keys->p, 8 * (size_t)p.rows,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+      off += 8 * (size_t)p.rows;
+    }
+    if (any_null) { // reuse the bitmap concat of concat_columns through BOOLEAN pseudo columns
+      std::vector<DCol> tmp(j->left_key_parts.size());
+      std::vector<const DCol *> ptrs;
+      for (size_t i = 0; i < tmp.size(); i++) {
+        const NKeys &p = j->left_key_parts[i];
+        tmp[i].dtype = SQLRS_INT64;
+        tmp[i].length = p.rows;
+        tmp[i].values = p.keys->p;
+        tmp[i].validity = p.validity;
+        tmp[i].null_count = p.validity ? -1 : 0;
+        ptrs.push_back(&tmp[i]);
+      }
+      DCol c = concat_columns(ctx, ptrs);
+      if (tmp.size() == 1) {
+        validity = j->left_key_parts[0].own_validity;
+        if (!validity) { // borrowed bitmap: copy it
+          validity = ctx->alloc(bitmap_bytes(n));
+          SQ_HIP(hipMemcpyAsync(validity->p, tmp[0].validity, bitmap_bytes(n),
+                                hipMemcpyDeviceToDevice, ctx->stream));
+        }
+      } else
+        validity = c.own_validity;
+    }
+  }
+  uint64_t cap = 64;
+  while (cap < 2 * (uint64_t)n) cap <<= 1;
+  j->mask = cap - 1;
+  int64_t nslots = (int64_t)cap + 2;
+  j->table = ctx->alloc(sizeof(Slot) * (size_t)nslots);
+  BufP row_slot = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
+  BufP dup = ctx->alloc_zero(8);
+  {
+    ProfScope ps(ctx, "join_build");
+    table_init_kernel<<<dim3((unsigned)ceil_div(nslots, 256)), dim3(256), 0, ctx->stream>>>(
+        j->table->as<Slot>(), nslots);
+    if (n)
+      join_insert_kernel<<<dim3((unsigned)ceil_div(n, BLOCK)), dim3(BLOCK), 0, ctx->stream>>>(
+          keys->as<uint64_t>(), validity ? validity->as<uint64_t>() : nullptr, n,
+          j->table->as<Slot>(), j->mask, row_slot->as<uint32_t>(), dup->as<int>());
+    SQ_HIP(hipGetLastError());
+  }
+  j->unique = ctx->fetch_value(dup->as<int>()) == 0;
+  if (!j->unique) {
+    // CSR: head = exclusive scan of counts in slot order; rows stably sorted by slot
+    ProfScope ps(ctx, "join_build_csr");
+    BufP counts = ctx->alloc(4 * (size_t)nslots), heads = ctx->alloc(4 * (size_t)nslots);
+    BufP total = ctx->alloc(8);
+    slot_counts_kernel<<<dim3((unsigned)ceil_div(nslots, 256)), dim3(256), 0, ctx->stream>>>(
+        j->table->as<Slot>(), nslots, counts->as<uint32_t>());
+    exclusive_scan_u32(ctx, counts->as<uint32_t>(), nslots, nullptr, heads->as<uint32_t>(),
+                       total->as<uint64_t>());
+    slot_heads_kernel<<<dim3((unsigned)ceil_div(nslots, 256)), dim3(256), 0, ctx->stream>>>(
+        j->table->as<Slot>(), nslots, heads->as<uint32_t>());
+    BufP k64 = ctx->alloc(8 * (size_t)n);
+    j->rows_by_slot = ctx->alloc(4 * (size_t)n);
+    u32_to_u64_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
+        row_slot->as<uint32_t>(), n, k64->as<uint64_t>());
+    iota_u32(ctx, j->rows_by_slot->as<uint32_t>(), n);
+    SQ_HIP(hipGetLastError());
+    int bits = 1;
+    while ((1ull << bits) < (uint64_t)nslots) bits++;
+    radix_sort_pairs(ctx, k64->as<uint64_t>(), j->rows_by_slot->as<uint32_t>(), n, 0, bits);
+  }
+}
+
+static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
+  Ctx *ctx = j->ctx;
+  if (pk.exact != j->exact || (pk.exact && pk.dtype != j->key_dtype))
+    fail(SQLRS_ERR_INTERNAL, "join keys of different types on the two sides are not supported");
+  Pairs p;
+  int64_t n = pk.rows;
+  int outer_right = j->join_type == SQLRS_JOIN_RIGHT || j->join_type == SQLRS_JOIN_FULL;
+  if (n == 0) {
+    p.left = ctx->alloc(8);
+    p.right = ctx->alloc(8);
+    return p;
+  }
+  if (n > 0xffffffffll) fail(SQLRS_ERR_INTERNAL, "probe batch larger than 2^32 rows");
+  BufP counts = ctx->alloc(4 * (size_t)n), offsets = ctx->alloc(8 * (size_t)n), total = ctx->alloc(8);
+  dim3 g((unsigned)ceil_div(n, BLOCK)), b(BLOCK);
+  {
+    ProfScope ps(ctx, "join_probe_count");
+    join_count_kernel<<<g, b, 0, ctx->stream>>>(pk.keys->as<uint64_t>(), pk.validity, n,
+                                                j->table->as<Slot>(), j->mask, outer_right,
+                                                counts->as<uint32_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  exclusive_scan_u32(ctx, counts->as<uint32_t>(), n, offsets->as<uint64_t>(), nullptr,
+                     total->as<uint64_t>());
+  p.m = (int64_t)ctx->fetch_value(total->as<uint64_t>());
+  int64_t m1 = std::max<int64_t>(p.m, 1);
+  p.left = ctx->alloc(8 * (size_t)m1);
+  p.right = ctx->alloc(4 * (size_t)m1);
+  BufP lvb;
+  if (outer_right) lvb = ctx->alloc((size_t)m1);
+  if (p.m) {
+    ProfScope ps(ctx, "join_probe_fill");
+    join_fill_kernel<<<g, b, 0, ctx->stream>>>(
+        pk.keys->as<uint64_t>(), pk.validity, n, j->table->as<Slot>(), j->mask, j->unique ? 1 : 0,
+        j->rows_by_slot ? j->rows_by_slot->as<uint32_t>() : nullptr, offsets->as<uint64_t>(),
+        p.left->as<uint64_t>(), p.right->as<uint32_t>(), lvb ? lvb->as<uint8_t>() : nullptr);
+    SQ_HIP(hipGetLastError());
+  }
+  if (outer_right) {
+    p.left_validity = ctx->alloc(bitmap_bytes(m1));
+    int64_t m64 = (int64_t)round_up((size_t)m1, 64);
+    bytes_to_bits_kernel<<<dim3((unsigned)ceil_div(m64, 256)), dim3(256), 0, ctx->stream>>>(
+        lvb->as<uint8_t>(), p.m, p.left_validity->as<uint64_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  return p;
+}
+
+static DBatch gather_pairs(sqlrs_hash_join *j, const DBatch &right, const Pairs &p) {
+  Ctx *ctx = j->ctx;
+  DBatch out;
+  out.rows = p.m;
+  const uint64_t *lv = p.left_validity ? p.left_validity->as<uint64_t>() : nullptr;
+  for (const DCol &c : j->left.cols) out.cols.push_back(gather_column(ctx, c, p.left->p, true, lv, p.m));
+  for (const DCol &c : right.cols) out.cols.push_back(gather_column(ctx, c, p.right->p, false, nullptr, p.m));
+  return out;
+}
+
+// apply_join_filter  (hash_join.rs:47-127)
+static void apply_filter(sqlrs_hash_join *j, const DBatch &right, Pairs &p) {
+  Ctx *ctx = j->ctx;
+  DBatch inter = gather_pairs(j, right, p); // intermediate batch (:256-262)
+  auto colfn = [&](int i) -> const DCol & {
+    if (i < 0 || (size_t)i >= inter.cols.size()) fail(SQLRS_ERR_INTERNAL, "input ref out of range");
+    return inter.cols[(size_t)i];
+  };
+  DCol mask = eval_expr(ctx, j->filter, colfn, inter.rows, false);
+  mask.length = inter.rows;
+  Selection sel = selection_from_mask(ctx, mask);
+  DCol lcol, rcol;
+  lcol.dtype = SQLRS_UINT64;
+  lcol.length = p.m;
+  lcol.values = p.left->p;
+  lcol.own_values = p.left;
+  if (p.left_validity) {
+    lcol.validity = p.left_validity->as<uint64_t>();
+    lcol.own_validity = p.left_validity;
+    lcol.null_count = -1;
+  }
+  rcol.dtype = SQLRS_UINT32;
+  rcol.length = p.m;
+  rcol.values = p.right->p;
+  rcol.own_values = p.right;
+  DCol lf = compact_column(ctx, lcol, sel), rf = compact_column(ctx, rcol, sel);
+  bool outer_right = j->join_type == SQLRS_JOIN_RIGHT || j->join_type == SQLRS_JOIN_FULL;
+  if (!outer_right) {
+    p.m = sel.count;
+    p.left = lf.own_values;
+    p.right = rf.own_values;
+    p.left_validity = lf.own_validity; // always all-valid here
+    return;
+  }
+  // keep every right row: rows that lost all their matches come back as (NULL, row) (:73-121)
+  int64_t nr = right.rows;
+  BufP visited = ctx->alloc_zero(bitmap_bytes(std::max<int64_t>(nr, 1)));
+  if (sel.count)
+    mark_bits_kernel<uint32_t><<<dim3((unsigned)ceil_div(sel.count, 256)), dim3(256), 0, ctx->stream>>>(
+        rf.v<uint32_t>(), nullptr, sel.count, visited->as<unsigned long long>());
+  SQ_HIP(hipGetLastError());
+  Selection unv = selection_from_clear_bits(ctx, visited->as<uint64_t>(), nr);
+  BufP uidx = selection_indices_u32(ctx, unv);
+  DCol ucol;
+  ucol.dtype = SQLRS_UINT32;
+  ucol.length = unv.count;
+  ucol.values = uidx->p;
+  ucol.own_values = uidx;
+  DCol lnull = make_null_column(ctx, SQLRS_UINT64, unv.count);
+  if (!lf.validity) lf.null_count = 0;
+  DCol l2 = concat_columns(ctx, {&lf, &lnull});
+  DCol r2 = concat_columns(ctx, {&rf, &ucol});
+  p.m = sel.count + unv.count;
+  p.left = l2.own_values;
+  p.right = r2.own_values;
+  p.left_validity = l2.own_validity;
+  if (!p.left_validity && unv.count == 0 && lf.own_validity) p.left_validity = lf.own_validity;
+}
+
+static DBatch probe_batch(sqlrs_hash_join *j, InBatch &ib, Pairs *pairs_only) {
+  Ctx *ctx = j->ctx;
+  auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
+  NKeys pk = eval_keys(ctx, j->rkeys, colfn, ib.rows());
+  Pairs p = probe_pairs(j, pk);
+  if (pairs_only) {
+    *pairs_only = p;
+    return DBatch();
+  }
+  DBatch right = ib.materialize(false);
+  if (j->has_filter) apply_filter(j, right, p);
+  if ((j->join_type == SQLRS_JOIN_LEFT || j->join_type == SQLRS_JOIN_FULL) && p.m) {
+    mark_bits_kernel<uint64_t><<<dim3((unsigned)ceil_div(p.m, 256)), dim3(256), 0, ctx->stream>>>(
+        p.left->as<uint64_t>(), p.left_validity ? p.left_validity->as<uint64_t>() : nullptr, p.m,
+        j->visited->as<unsigned long long>()); // :274-282
+    SQ_HIP(hipGetLastError());
+  }
+  return gather_pairs(j, right, p); // :284-291
+}
+
+} // namespace sq
+
+extern "C" {
+
+int sqlrs_hash_join_create(sqlrs_ctx_t *ctx, int join_type, int num_keys,
+                           const sqlrs_expr_t *left_keys, const sqlrs_expr_t *right_keys,
+                           const sqlrs_expr_t *filter, int num_right_columns,
+                           const int32_t *right_dtypes, sqlrs_hash_join_t **out) {
+  return guard(ctx, [&] {
+    if (num_keys < 1) fail(SQLRS_ERR_INTERNAL, "HashJoin must has on condition"); // :132
+    if (join_type < SQLRS_JOIN_INNER || join_type > SQLRS_JOIN_FULL)
+      fail(SQLRS_ERR_INTERNAL, "bad join type");
+    auto j = std::unique_ptr<sqlrs_hash_join>(new sqlrs_hash_join());
+    j->ctx = ctx;
+    j->join_type = join_type;
+    for (int i = 0; i < num_keys; i++) {
+      j->lkeys.push_back(expr_from_abi(&left_keys[i]));
+      j->rkeys.push_back(expr_from_abi(&right_keys[i]));
+    }
+    if (filter && filter->num_nodes > 0) {
+      j->has_filter = true;
+      j->filter = expr_from_abi(filter);
+    }
+    if (num_right_columns > 0) j->right_dtypes.assign(right_dtypes, right_dtypes + num_right_columns);
+    *out = j.release();
+  });
+}
+
+int sqlrs_hash_join_build_push(sqlrs_hash_join_t *j, const sqlrs_batch_t *left) {
+  return guard(j->ctx, [&] {
+    SQ_HIP(hipSetDevice(j->ctx->device));
+    if (j->finished) fail(SQLRS_ERR_INTERNAL, "build_push after build_finish");
+    InBatch ib(j->ctx, left);
+    DBatch b = ib.materialize(true);
+    auto colfn = [&](int i) -> const DCol & {
+      if (i < 0 || (size_t)i >= b.cols.size()) fail(SQLRS_ERR_INTERNAL, "input ref out of range");
+      return b.cols[(size_t)i];
+    };
+    j->left_key_parts.push_back(eval_keys(j->ctx, j->lkeys, colfn, b.rows));
+    j->left_batches.push_back(std::move(b));
+    j->empty_build = false;
+  });
+}
+
+int sqlrs_hash_join_build_finish(sqlrs_hash_join_t *j) {
+  return guard(j->ctx, [&] {
+    SQ_HIP(hipSetDevice(j->ctx->device));
+    if (j->finished) return;
+    j->finished = true;
+    if (j->empty_build) return; // the join emits nothing (:183-185)
+    Ctx *ctx = j->ctx;
+    size_t nc = j->left_batches[0].cols.size();
+    for (size_t c = 0; c < nc; c++) {
+      std::vector<const DCol *> parts;
+      for (DBatch &b : j->left_batches) {
+        if (b.cols.size() != nc) fail(SQLRS_ERR_ARROW, "concat_batches: schema mismatch");
+        parts.push_back(&b.cols[c]);
+      }
+      j->left.cols.push_back(concat_columns(ctx, parts));
+    }
+    for (DBatch &b : j->left_batches) j->nB += b.rows;
+    j->left.rows = j->nB;
+    if (j->nB > 0xffffffffll) fail(SQLRS_ERR_INTERNAL, "build side larger than 2^32 rows");
+    build_table(j);
+    j->left_batches.clear();
+    j->left_key_parts.clear();
+    if (j->join_type == SQLRS_JOIN_LEFT || j->join_type == SQLRS_JOIN_FULL)
+      j->visited = ctx->alloc_zero(bitmap_bytes(std::max<int64_t>(j->nB, 1)));
+  });
+}
+
+int sqlrs_hash_join_probe_push(sqlrs_hash_join_t *j, const sqlrs_batch_t *right, int out_mem,
+                               sqlrs_batch_t **out) {
+  return guard(j->ctx, [&] {
+    SQ_HIP(hipSetDevice(j->ctx->device));
+    if (!j->finished) fail(SQLRS_ERR_INTERNAL, "probe before build_finish");
+    *out = nullptr;
+    if (j->empty_build) return;
+    InBatch ib(j->ctx, right);
+    DBatch r = probe_batch(j, ib, nullptr);
+    *out = emit_batch(j->ctx, std::move(r), out_mem);
+  });
+}
+
+int sqlrs_hash_join_probe_indices(sqlrs_hash_join_t *j, const sqlrs_batch_t *right, int out_mem,
+                                  sqlrs_batch_t **out) {
+  return guard(j->ctx, [&] {
+    SQ_HIP(hipSetDevice(j->ctx->device));
+    if (!j->finished) fail(SQLRS_ERR_INTERNAL, "probe before build_finish");
+    *out = nullptr;
+    if (j->empty_build) return;
+    InBatch ib(j->ctx, right);
+    Pairs p;
+    probe_batch(j, ib, &p);
+    DBatch b;
+    b.rows = p.m;
+    DCol l, r;
+    l.dtype = SQLRS_UINT64;
+    l.length = p.m;
+    l.values = p.left->p;
+    l.own_values = p.left;
+    if (p.left_validity) {
+      l.validity = p.left_validity->as<uint64_t>();
+      l.own_validity = p.left_validity;
+      l.null_count = -1;
+    }
+    r.dtype = SQLRS_UINT32;
+    r.length = p.m;
+    r.values = p.right->p;
+    r.own_values = p.right;
+    b.cols.push_back(std::move(l));
+    b.cols.push_back(std::move(r));
+    *out = emit_batch(j->ctx, std::move(b), out_mem);
+  });
+}
+
+int sqlrs_hash_join_finish(sqlrs_hash_join_t *j, int out_mem, sqlrs_batch_t **out) {
+  return guard(j->ctx, [&] {
+    SQ_HIP(hipSetDevice(j->ctx->device));
+    if (!j->finished) fail(SQLRS_ERR_INTERNAL, "finish before build_finish");
+    *out = nullptr;
+    if (j->empty_build) return;
+    if (j->join_type != SQLRS_JOIN_LEFT && j->join_type != SQLRS_JOIN_FULL) return;
+    Ctx *ctx = j->ctx;
+    Selection sel = selection_from_clear_bits(ctx, j->visited->as<uint64_t>(), j->nB); // :298-301
+    DBatch b;
+    b.rows = sel.count;
+    for (const DCol &c : j->left.cols) b.cols.push_back(compact_column(ctx, c, sel));
+    for (int32_t dt : j->right_dtypes) b.cols.push_back(make_null_column(ctx, dt, sel.count));
+    *out = emit_batch(ctx, std::move(b), out_mem);
+  });
+}
+
+void sqlrs_hash_join_destroy(sqlrs_hash_join_t *j) { delete j; }
+
+} // extern "C"

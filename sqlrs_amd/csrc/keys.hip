@@ -1,0 +1,131 @@
+// keys.hip — join / group keys as one u64 per row (see prims.hpp NKeys).
+//
+// Reference semantics being preserved (hash_utils.rs:161-220, SURVEY §8a quirks 2-4,11):
+//  * keys are compared at their native width and f64 by bit pattern;
+//  * a NULL key never changes the running hash, so NULL keys equal each other;
+//  * multi-column / Utf8 keys are matched by 64-bit hash only — here with this library's own
+//    mixer instead of ahash (hash values are never observable in operator output).
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "prims.hpp"
+
+namespace sq {
+
+template <class T> __global__ void widen_kernel(const T *__restrict__ in, int64_t n,
+                                                uint64_t *__restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint64_t)(int64_t)in[i];
+}
+__global__ void widen_bool_kernel(const uint64_t *__restrict__ in, int64_t n,
+                                  uint64_t *__restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (in[i >> 6] >> (i & 63)) & 1;
+}
+
+__device__ __forceinline__ uint64_t combine_hashes(uint64_t l, uint64_t r) { // hash_utils.rs:13-16
+  uint64_t h = (uint64_t)(17 * 37) + l;
+  return h * 37 + r;
+}
+
+// folds one column into the running per-row hash (hash stays put on NULL)
+template <class T>
+__global__ void fold_fixed_kernel(const T *__restrict__ in, const uint64_t *__restrict__ validity,
+                                  int64_t n, uint64_t tag, int multi, uint64_t *__restrict__ h) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (validity && !((validity[i >> 6] >> (i & 63)) & 1)) return;
+  uint64_t v = mix64((uint64_t)in[i] + tag);
+  h[i] = multi ? combine_hashes(v, h[i]) : v;
+}
+__global__ void fold_bool_kernel(const uint64_t *__restrict__ in, const uint64_t *__restrict__ validity,
+                                 int64_t n, int multi, uint64_t *__restrict__ h) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (validity && !((validity[i >> 6] >> (i & 63)) & 1)) return;
+  uint64_t v = mix64(((in[i >> 6] >> (i & 63)) & 1) ^ 0x0808080808080808ULL);
+  h[i] = multi ? combine_hashes(v, h[i]) : v;
+}
+__global__ void fold_utf8_kernel(const uint8_t *__restrict__ data, const int32_t *__restrict__ off,
+                                 const uint64_t *__restrict__ validity, int64_t n, int multi,
+                                 uint64_t *__restrict__ h) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (validity && !((validity[i >> 6] >> (i & 63)) & 1)) return;
+  uint64_t x = 0xcbf29ce484222325ULL; // FNV-1a over the bytes, then the mixer
+  for (int32_t k = off[i]; k < off[i + 1]; k++) {
+    x ^= data[k];
+    x *= 0x100000001b3ULL;
+  }
+  uint64_t v = mix64(x ^ 0x7575757575757575ULL);
+  h[i] = multi ? combine_hashes(v, h[i]) : v;
+}
+
+NKeys normalize_keys(Ctx *ctx, const std::vector<DCol> &cols_in, int64_t rows) {
+  if (cols_in.empty()) fail(SQLRS_ERR_INTERNAL, "no key columns");
+  std::vector<DCol> cols;
+  for (const DCol &c : cols_in) cols.push_back(c.stride == 0 ? materialize_scalar(ctx, c, rows) : c);
+  NKeys k;
+  k.rows = rows;
+  int64_t n1 = std::max<int64_t>(rows, 1);
+  k.keys = ctx->alloc(8 * (size_t)n1);
+  dim3 g((unsigned)ceil_div(n1, 256)), b(256);
+  ProfScope ps(ctx, "normalize_keys");
+  const DCol &c0 = cols[0];
+  bool fixed = c0.dtype == SQLRS_INT32 || c0.dtype == SQLRS_INT64 || c0.dtype == SQLRS_FLOAT64 ||
+               c0.dtype == SQLRS_BOOLEAN;
+  if (cols.size() == 1 && fixed) {
+    k.exact = true;
+    k.dtype = c0.dtype;
+    if (c0.validity && c0.null_count != 0) {
+      k.validity = c0.validity;
+      k.own_validity = c0.own_validity;
+    }
+    if (rows == 0) return k;
+    switch (c0.dtype) {
+    case SQLRS_INT64:
+    case SQLRS_FLOAT64: // bit pattern: -0.0 != +0.0, NaN payloads distinct (hash_utils.rs:124-131)
+      SQ_HIP(hipMemcpyAsync(k.keys->p, c0.values, 8 * (size_t)rows, hipMemcpyDeviceToDevice,
+                            ctx->stream));
+      break;
+    case SQLRS_INT32:
+      widen_kernel<int32_t><<<g, b, 0, ctx->stream>>>(c0.v<int32_t>(), rows, k.keys->as<uint64_t>());
+      break;
+    default:
+      widen_bool_kernel<<<g, b, 0, ctx->stream>>>(c0.v<uint64_t>(), rows, k.keys->as<uint64_t>());
+    }
+    SQ_HIP(hipGetLastError());
+    return k;
+  }
+  // hash mode: every_rows_hashes = vec![0; n]; create_hashes(...)   (hash_join.rs:169-170)
+  k.exact = false;
+  SQ_HIP(hipMemsetAsync(k.keys->p, 0, 8 * (size_t)n1, ctx->stream));
+  if (rows == 0) return k;
+  int multi = cols.size() > 1;
+  for (const DCol &c : cols) {
+    const uint64_t *v = (c.validity && c.null_count != 0) ? c.validity : nullptr;
+    uint64_t *h = k.keys->as<uint64_t>();
+    switch (c.dtype) {
+    case SQLRS_INT32:
+      fold_fixed_kernel<uint32_t><<<g, b, 0, ctx->stream>>>(c.v<uint32_t>(), v, rows,
+                                                            0x3232323200000000ULL, multi, h);
+      break;
+    case SQLRS_INT64:
+    case SQLRS_FLOAT64:
+      fold_fixed_kernel<uint64_t><<<g, b, 0, ctx->stream>>>(c.v<uint64_t>(), v, rows,
+                                                            0x9e3779b97f4a7c15ULL, multi, h);
+      break;
+    case SQLRS_BOOLEAN:
+      fold_bool_kernel<<<g, b, 0, ctx->stream>>>(c.v<uint64_t>(), v, rows, multi, h);
+      break;
+    case SQLRS_UTF8:
+      fold_utf8_kernel<<<g, b, 0, ctx->stream>>>(c.v<uint8_t>(), c.offsets, v, rows, multi, h);
+      break;
+    default:
+      fail(SQLRS_ERR_INTERNAL, "Unsupported data type in hasher"); // hash_utils.rs:210-216
+    }
+    SQ_HIP(hipGetLastError());
+  }
+  return k;
+}
+
+} // namespace sq

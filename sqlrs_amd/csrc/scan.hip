@@ -1,0 +1,84 @@
+// scan.hip — single-pass exclusive prefix sum (decoupled look-back) over u32 counts.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "prims.hpp"
+
+namespace sq {
+
+// Tile = 4096 elements; wave w owns 1024 contiguous elements read as 4 coalesced chunks of
+// 256 (one uint4 per lane).  HBM traffic: 4 B read + 4/8 B written per element.
+__global__ __launch_bounds__(BLOCK) void scan_u32_kernel(const uint32_t *__restrict__ in, int64_t n,
+                                                         uint64_t *__restrict__ out64,
+                                                         uint32_t *__restrict__ out32,
+                                                         uint64_t *desc, unsigned *ticket,
+                                                         uint64_t *total, int64_t num_tiles) {
+  __shared__ int64_t s_tile;
+  __shared__ uint64_t s_wave[WAVES_PER_BLOCK];
+  __shared__ uint64_t s_excl;
+  if (threadIdx.x == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int64_t tile = s_tile;
+  const int lane = lane_id(), w = wave_id();
+  const int64_t wbase = tile * 4096 + (int64_t)w * 1024;
+  uint32_t v[4][4];
+  uint32_t lane_excl[4]; // exclusive prefix of this lane's uint4 within the wave's 1024
+  uint32_t carry = 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    int64_t i = wbase + c * 256 + lane * 4;
+    if (i + 3 < n) {
+      uint4 x = *reinterpret_cast<const uint4 *>(in + i);
+      v[c][0] = x.x; v[c][1] = x.y; v[c][2] = x.z; v[c][3] = x.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[c][k] = (i + k < n) ? in[i + k] : 0u;
+    }
+    uint32_t s = v[c][0] + v[c][1] + v[c][2] + v[c][3];
+    uint32_t inc = wave_iscan_u32(s);
+    lane_excl[c] = carry + inc - s;
+    carry += (uint32_t)__shfl((int)inc, 63, 64);
+  }
+  if (lane == 0) s_wave[w] = carry;
+  __syncthreads();
+  if (w == 0) {
+    uint64_t agg = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    uint64_t excl = lookback_wave(desc, tile, agg);
+    if (lane == 0) {
+      s_excl = excl;
+      if (tile == num_tiles - 1) *total = excl + agg;
+    }
+  }
+  __syncthreads();
+  uint64_t base = s_excl;
+  for (int k = 0; k < w; k++) base += s_wave[k];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    int64_t i = wbase + c * 256 + lane * 4;
+    uint64_t p = base + lane_excl[c];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (i + k < n) {
+        if (out64) out64[i + k] = p;
+        if (out32) out32[i + k] = (uint32_t)p;
+      }
+      p += v[c][k];
+    }
+  }
+}
+
+void exclusive_scan_u32(Ctx *ctx, const uint32_t *in, int64_t n, uint64_t *out64, uint32_t *out32,
+                        uint64_t *total) {
+  if (n <= 0) {
+    SQ_HIP(hipMemsetAsync(total, 0, 8, ctx->stream));
+    return;
+  }
+  ProfScope ps(ctx, "scan_u32");
+  int64_t tiles = ceil_div(n, 4096);
+  BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 8);
+  unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
+  scan_u32_kernel<<<dim3((unsigned)tiles), dim3(BLOCK), 0, ctx->stream>>>(
+      in, n, out64, out32, desc->as<uint64_t>(), ticket, total, tiles);
+  SQ_HIP(hipGetLastError());
+}
+
+} // namespace sq

@@ -1,0 +1,410 @@
+// select.hip — row selections (bitmaps), order-preserving compaction, and the fused
+// "col OP constant" filter kernel of config C2.
+//
+// Roofline (all HBM-bound, no reuse): the fused filter reads 8 B/row and writes 8 B per
+// kept row (+ 1 bit/row for the selection mask) = the algorithmic 8N + 8sN of SURVEY §8d.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "prims.hpp"
+
+namespace sq {
+
+// ------------------------------------------------------------ bit utilities --
+__global__ void mask_bits_kernel(const uint64_t *__restrict__ values,
+                                 const uint64_t *__restrict__ validity, int invert, int64_t rows,
+                                 int64_t nwords, uint64_t *__restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nwords) return;
+  uint64_t v = values[i];
+  if (invert) v = ~v;
+  if (validity) v &= validity[i];
+  int64_t rem = rows - i * 64;
+  if (rem < 64) v &= (rem <= 0) ? 0ull : ((1ull << rem) - 1);
+  out[i] = v;
+}
+
+// one wave per tile of 64 mask words; writes tile_off[tile] = kept rows before the tile
+__global__ __launch_bounds__(BLOCK) void tile_offsets_kernel(const uint64_t *__restrict__ bits,
+                                                             int64_t nwords, int64_t num_tiles,
+                                                             uint64_t *__restrict__ tile_off,
+                                                             uint64_t *desc, unsigned *ticket,
+                                                             uint64_t *total) {
+  const int lane = lane_id();
+  unsigned t = 0;
+  if (lane == 0) t = atomicAdd(ticket, 1u);
+  int64_t tile = (int64_t)(unsigned)__shfl((int)t, 0, 64);
+  if (tile >= num_tiles) return;
+  int64_t w = tile * TILE_WORDS + lane;
+  uint64_t m = (w < nwords) ? bits[w] : 0ull;
+  uint64_t agg = wave_sum_u64((uint64_t)__popcll(m));
+  uint64_t excl = lookback_wave(desc, tile, agg);
+  if (lane == 0) {
+    tile_off[tile] = excl;
+    if (tile == num_tiles - 1) *total = excl + agg;
+  }
+}
+
+void selection_finish(Ctx *ctx, Selection &s) {
+  int64_t tiles = ceil_div(std::max<int64_t>(s.rows, 1), TILE_ROWS);
+  s.tile_off = ctx->alloc(8 * (size_t)tiles);
+  if (s.rows == 0) {
+    s.count = 0;
+    return;
+  }
+  BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 16);
+  unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
+  uint64_t *total = desc->as<uint64_t>() + tiles + 1;
+  {
+    ProfScope ps(ctx, "tile_offsets");
+    int64_t nwords = ceil_div(s.rows, 64);
+    unsigned blocks = (unsigned)ceil_div(tiles, WAVES_PER_BLOCK);
+    tile_offsets_kernel<<<dim3(blocks), dim3(BLOCK), 0, ctx->stream>>>(
+        s.bits, nwords, tiles, s.tile_off->as<uint64_t>(), desc->as<uint64_t>(), ticket, total);
+    SQ_HIP(hipGetLastError());
+  }
+  s.count = (int64_t)ctx->fetch_value(total);
+}
+
+static Selection selection_from_words(Ctx *ctx, const uint64_t *values, const uint64_t *validity,
+                                      bool invert, int64_t rows) {
+  Selection s;
+  s.rows = rows;
+  int64_t nwords = ceil_div(std::max<int64_t>(rows, 1), 64);
+  s.own_bits = ctx->alloc(8 * (size_t)nwords);
+  s.bits = s.own_bits->as<uint64_t>();
+  if (rows > 0) {
+    ProfScope ps(ctx, "mask_bits");
+    mask_bits_kernel<<<dim3((unsigned)ceil_div(nwords, 256)), dim3(256), 0, ctx->stream>>>(
+        values, validity, invert ? 1 : 0, rows, nwords, s.own_bits->as<uint64_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  selection_finish(ctx, s);
+  return s;
+}
+
+Selection selection_from_mask(Ctx *ctx, const DCol &mask) {
+  if (mask.dtype != SQLRS_BOOLEAN)
+    fail(SQLRS_ERR_INTERNAL, "filter executor expected evaluate boolean array");
+  if (mask.stride == 0) {
+    DCol m = materialize_scalar(ctx, mask, mask.length);
+    return selection_from_words(ctx, m.v<uint64_t>(), m.validity, false, m.length);
+  }
+  return selection_from_words(ctx, mask.v<uint64_t>(), mask.validity, false, mask.length);
+}
+Selection selection_from_clear_bits(Ctx *ctx, const uint64_t *bits, int64_t rows) {
+  return selection_from_words(ctx, bits, nullptr, true, rows);
+}
+
+// ------------------------------------------------------------------ compaction --
+// One block per tile.  Every wave loads the tile's 64 mask words (lane l <- word l), scans the
+// popcounts in-register and then streams its own 16 words: no LDS, no barrier.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void compact_kernel(const T *__restrict__ in,
+                                                        const uint64_t *__restrict__ bits,
+                                                        const uint64_t *__restrict__ tile_off,
+                                                        int64_t rows, int64_t nwords,
+                                                        T *__restrict__ out) {
+  const int64_t tile = blockIdx.x;
+  const int lane = lane_id(), w = wave_id();
+  int64_t wi = tile * TILE_WORDS + lane;
+  uint64_t m = (wi < nwords) ? bits[wi] : 0ull;
+  uint32_t pc = (uint32_t)__popcll(m);
+  uint32_t excl = wave_iscan_u32(pc) - pc;
+  const uint64_t base = tile_off[tile];
+#pragma unroll 4
+  for (int j = 0; j < 16; j++) {
+    int W = w * 16 + j;
+    uint64_t mw = shfl_u64(m, W);
+    uint32_t off = (uint32_t)__shfl((int)excl, W, 64);
+    int64_t row = (tile * TILE_WORDS + W) * 64 + lane;
+    if ((mw >> lane) & 1) out[base + off + mbcnt(mw)] = in[row];
+  }
+}
+
+// row ids of the kept rows
+template <class T>
+__global__ __launch_bounds__(BLOCK) void compact_iota_kernel(const uint64_t *__restrict__ bits,
+                                                             const uint64_t *__restrict__ tile_off,
+                                                             int64_t nwords, T *__restrict__ out) {
+  const int64_t tile = blockIdx.x;
+  const int lane = lane_id(), w = wave_id();
+  int64_t wi = tile * TILE_WORDS + lane;
+  uint64_t m = (wi < nwords) ? bits[wi] : 0ull;
+  uint32_t pc = (uint32_t)__popcll(m);
+  uint32_t excl = wave_iscan_u32(pc) - pc;
+  const uint64_t base = tile_off[tile];
+#pragma unroll 4
+  for (int j = 0; j < 16; j++) {
+    int W = w * 16 + j;
+    uint64_t mw = shfl_u64(m, W);
+    uint32_t off = (uint32_t)__shfl((int)excl, W, 64);
+    int64_t row = (tile * TILE_WORDS + W) * 64 + lane;
+    if ((mw >> lane) & 1) out[base + off + mbcnt(mw)] = (T)row;
+  }
+}
+
+// bit column (BOOLEAN values / validity) -> one byte per kept row
+__global__ __launch_bounds__(BLOCK) void compact_bits_to_bytes_kernel(
+    const uint64_t *__restrict__ src_bits, const uint64_t *__restrict__ bits,
+    const uint64_t *__restrict__ tile_off, int64_t nwords, uint8_t *__restrict__ out) {
+  const int64_t tile = blockIdx.x;
+  const int lane = lane_id(), w = wave_id();
+  int64_t wi = tile * TILE_WORDS + lane;
+  uint64_t m = (wi < nwords) ? bits[wi] : 0ull;
+  uint64_t sv = (wi < nwords) ? src_bits[wi] : 0ull;
+  uint32_t pc = (uint32_t)__popcll(m);
+  uint32_t excl = wave_iscan_u32(pc) - pc;
+  const uint64_t base = tile_off[tile];
+  for (int j = 0; j < 16; j++) {
+    int W = w * 16 + j;
+    uint64_t mw = shfl_u64(m, W);
+    uint64_t sw = shfl_u64(sv, W);
+    uint32_t off = (uint32_t)__shfl((int)excl, W, 64);
+    if ((mw >> lane) & 1) out[base + off + mbcnt(mw)] = (uint8_t)((sw >> lane) & 1);
+  }
+}
+
+__global__ void pack_bytes_kernel(const uint8_t *__restrict__ bytes, int64_t n,
+                                  uint64_t *__restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool b = (i < n) && bytes[i];
+  uint64_t m = __ballot(b);
+  if (lane_id() == 0 && (i / 64) * 64 < n) out[i >> 6] = m;
+}
+
+static BufP compact_bits(Ctx *ctx, const uint64_t *src_bits, const Selection &s) {
+  BufP out = ctx->alloc_zero(bitmap_bytes(std::max<int64_t>(s.count, 1)));
+  if (s.count == 0) return out;
+  BufP bytes = ctx->alloc((size_t)s.count);
+  int64_t tiles = ceil_div(s.rows, TILE_ROWS), nwords = ceil_div(s.rows, 64);
+  compact_bits_to_bytes_kernel<<<dim3((unsigned)tiles), dim3(BLOCK), 0, ctx->stream>>>(
+      src_bits, s.bits, s.tile_off->as<uint64_t>(), nwords, bytes->as<uint8_t>());
+  SQ_HIP(hipGetLastError());
+  int64_t n64 = round_up((size_t)s.count, 64);
+  pack_bytes_kernel<<<dim3((unsigned)ceil_div(n64, 256)), dim3(256), 0, ctx->stream>>>(
+      bytes->as<uint8_t>(), s.count, out->as<uint64_t>());
+  SQ_HIP(hipGetLastError());
+  return out;
+}
+
+BufP selection_indices_u32(Ctx *ctx, const Selection &s) {
+  BufP out = ctx->alloc(4 * (size_t)std::max<int64_t>(s.count, 1));
+  if (s.count == 0) return out;
+  ProfScope ps(ctx, "compact_iota");
+  compact_iota_kernel<uint32_t><<<dim3((unsigned)ceil_div(s.rows, TILE_ROWS)), dim3(BLOCK), 0,
+                                  ctx->stream>>>(s.bits, s.tile_off->as<uint64_t>(),
+                                                 ceil_div(s.rows, 64), out->as<uint32_t>());
+  SQ_HIP(hipGetLastError());
+  return out;
+}
+BufP selection_indices_u64(Ctx *ctx, const Selection &s) {
+  BufP out = ctx->alloc(8 * (size_t)std::max<int64_t>(s.count, 1));
+  if (s.count == 0) return out;
+  ProfScope ps(ctx, "compact_iota");
+  compact_iota_kernel<uint64_t><<<dim3((unsigned)ceil_div(s.rows, TILE_ROWS)), dim3(BLOCK), 0,
+                                  ctx->stream>>>(s.bits, s.tile_off->as<uint64_t>(),
+                                                 ceil_div(s.rows, 64), out->as<uint64_t>());
+  SQ_HIP(hipGetLastError());
+  return out;
+}
+
+DCol compact_column(Ctx *ctx, const DCol &cin, const Selection &s) {
+  DCol c = cin.stride == 0 ? materialize_scalar(ctx, cin, s.rows) : cin;
+  if (c.length != s.rows) fail(SQLRS_ERR_INTERNAL, "compact: length mismatch");
+  if (c.dtype == SQLRS_UTF8) { // variable width: gather by row id
+    BufP idx = selection_indices_u32(ctx, s);
+    return gather_column(ctx, c, idx->p, false, nullptr, s.count);
+  }
+  DCol o;
+  o.dtype = c.dtype;
+  o.length = s.count;
+  int64_t tiles = ceil_div(std::max<int64_t>(s.rows, 1), TILE_ROWS), nwords = ceil_div(s.rows, 64);
+  if (c.has_nulls() || (c.validity && c.null_count < 0)) {
+    o.own_validity = compact_bits(ctx, c.validity, s);
+    o.validity = o.own_validity->as<uint64_t>();
+    o.null_count = -1;
+  }
+  if (c.dtype == SQLRS_BOOLEAN) {
+    o.own_values = compact_bits(ctx, c.v<uint64_t>(), s);
+    o.values = o.own_values->p;
+    return o;
+  }
+  size_t w = width_of(c.dtype);
+  o.own_values = ctx->alloc(w * (size_t)std::max<int64_t>(s.count, 1) + 16);
+  o.values = o.own_values->p;
+  if (s.count == 0 || s.rows == 0) return o;
+  ProfScope ps(ctx, "compact");
+  if (w == 8)
+    compact_kernel<uint64_t><<<dim3((unsigned)tiles), dim3(BLOCK), 0, ctx->stream>>>(
+        c.v<uint64_t>(), s.bits, s.tile_off->as<uint64_t>(), s.rows, nwords,
+        o.own_values->as<uint64_t>());
+  else
+    compact_kernel<uint32_t><<<dim3((unsigned)tiles), dim3(BLOCK), 0, ctx->stream>>>(
+        c.v<uint32_t>(), s.bits, s.tile_off->as<uint64_t>(), s.rows, nwords,
+        o.own_values->as<uint32_t>());
+  SQ_HIP(hipGetLastError());
+  return o;
+}
+
+// ---------------------------------------------------- fused filter (config C2) --
+enum { CMP_GT = 0, CMP_LT, CMP_GE, CMP_LE, CMP_EQ, CMP_NE };
+
+template <class T> struct CmpKey; // total-order key so that f64 compares like the oracle
+template <> struct CmpKey<int64_t> {
+  static __device__ __forceinline__ int64_t key(int64_t v) { return v; }
+};
+template <> struct CmpKey<int32_t> {
+  static __device__ __forceinline__ int32_t key(int32_t v) { return v; }
+};
+template <> struct CmpKey<double> {
+  static __device__ __forceinline__ uint64_t key(double v) { return f64_to_ordered(v); }
+};
+
+template <int OP, class K> __device__ __forceinline__ bool cmp_op(K a, K b) {
+  if (OP == CMP_GT) return a > b;
+  if (OP == CMP_LT) return a < b;
+  if (OP == CMP_GE) return a >= b;
+  if (OP == CMP_LE) return a <= b;
+  if (OP == CMP_EQ) return a == b;
+  return a != b;
+}
+
+// Tile = 4096 rows, one block (4 waves) per tile; wave w owns 16 chunks of 64 rows, so each
+// ballot IS one word of the selection mask.  Loads are issued for all 16 chunks up front
+// (16 x 512 B per wave in flight), ranks come from popcounts, the tile's global offset from
+// the decoupled look-back, and kept values are written contiguously per wave.
+template <class T, int OP>
+__global__ __launch_bounds__(BLOCK) void filter_cmp_const_kernel(
+    const T *__restrict__ in, const uint64_t *__restrict__ validity, T k, int64_t rows,
+    int64_t num_tiles, T *__restrict__ out, uint64_t *__restrict__ sel_bits,
+    uint64_t *__restrict__ tile_off, uint64_t *desc, unsigned *ticket, uint64_t *total) {
+  __shared__ int64_t s_tile;
+  __shared__ uint32_t s_wave[WAVES_PER_BLOCK];
+  __shared__ uint64_t s_excl;
+  if (threadIdx.x == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int64_t tile = s_tile;
+  const int lane = lane_id(), w = wave_id();
+  const int64_t wrow = tile * TILE_ROWS + (int64_t)w * 1024;
+  const int64_t wword = tile * TILE_WORDS + w * 16;
+  const auto kk = CmpKey<T>::key(k);
+  T v[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    int64_t r = wrow + j * 64 + lane;
+    v[j] = (r < rows) ? in[r] : T(0);
+  }
+  uint64_t m[16];
+  uint32_t wave_cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    int64_t r = wrow + j * 64 + lane;
+    bool keep = (r < rows) && cmp_op<OP>(CmpKey<T>::key(v[j]), kk);
+    uint64_t b = __ballot(keep);
+    if (validity) {
+      int64_t nw = (rows + 63) >> 6;
+      uint64_t vw = (wword + j < nw) ? validity[wword + j] : 0ull; // wave-uniform load
+      b &= vw;
+    }
+    m[j] = b;
+    wave_cnt += (uint32_t)__popcll(b);
+  }
+  if (lane == 0) s_wave[w] = wave_cnt;
+  if (sel_bits) {
+    int64_t nw = (rows + 63) >> 6;
+    if (lane < 16 && wword + lane < nw) {
+      uint64_t mine = 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) mine = (lane == j) ? m[j] : mine;
+      sel_bits[wword + lane] = mine;
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    uint64_t agg = (uint64_t)s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    uint64_t excl = lookback_wave(desc, tile, agg);
+    if (lane == 0) {
+      s_excl = excl;
+      if (tile_off) tile_off[tile] = excl;
+      if (tile == num_tiles - 1) *total = excl + agg;
+    }
+  }
+  __syncthreads();
+  uint64_t pos = s_excl;
+  for (int q = 0; q < w; q++) pos += s_wave[q];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    if ((m[j] >> lane) & 1) out[pos + mbcnt(m[j])] = v[j];
+    pos += (uint32_t)__popcll(m[j]);
+  }
+}
+
+template <class T>
+static void launch_filter(Ctx *ctx, int op, const DCol &c, T k, int64_t rows, T *out,
+                          uint64_t *sel_bits, uint64_t *tile_off, uint64_t *desc, unsigned *ticket,
+                          uint64_t *total) {
+  int64_t tiles = ceil_div(rows, TILE_ROWS);
+  dim3 g((unsigned)tiles), b(BLOCK);
+  const T *in = c.v<T>();
+  const uint64_t *val = c.validity;
+#define SQ_LAUNCH(OP)                                                                              \
+  filter_cmp_const_kernel<T, OP><<<g, b, 0, ctx->stream>>>(in, val, k, rows, tiles, out, sel_bits, \
+                                                           tile_off, desc, ticket, total)
+  switch (op) {
+  case CMP_GT: SQ_LAUNCH(CMP_GT); break;
+  case CMP_LT: SQ_LAUNCH(CMP_LT); break;
+  case CMP_GE: SQ_LAUNCH(CMP_GE); break;
+  case CMP_LE: SQ_LAUNCH(CMP_LE); break;
+  case CMP_EQ: SQ_LAUNCH(CMP_EQ); break;
+  default: SQ_LAUNCH(CMP_NE); break;
+  }
+#undef SQ_LAUNCH
+  SQ_HIP(hipGetLastError());
+}
+
+bool filter_fast_path(Ctx *ctx, const Expr &e, const std::function<const DCol &(int)> &col,
+                      int64_t rows, int *col_index, Selection *sel, DCol *out_col) {
+  // pattern: InputRef, Constant, comparison   (e.g. `v1 > k`, evaluator.rs:16-21)
+  if (e.nodes.size() != 3 || rows == 0) return false;
+  const sqlrs_expr_node_t &a = e.nodes[0], &b = e.nodes[1], &o = e.nodes[2];
+  if (a.op != SQLRS_EXPR_INPUT_REF || b.op != SQLRS_EXPR_CONSTANT || b.is_null) return false;
+  if (o.op < SQLRS_EXPR_GT || o.op > SQLRS_EXPR_NOTEQ) return false;
+  const DCol &c = col(a.index);
+  if (c.dtype != b.dtype || c.stride == 0) return false;
+  if (c.dtype != SQLRS_INT64 && c.dtype != SQLRS_FLOAT64 && c.dtype != SQLRS_INT32) return false;
+  int op = o.op - SQLRS_EXPR_GT; // GT, LT, GTEQ, LTEQ, EQ, NOTEQ in header order
+  int64_t tiles = ceil_div(rows, TILE_ROWS), nwords = ceil_div(rows, 64);
+  sel->rows = rows;
+  sel->own_bits = ctx->alloc(8 * (size_t)nwords);
+  sel->bits = sel->own_bits->as<uint64_t>();
+  sel->tile_off = ctx->alloc(8 * (size_t)tiles);
+  BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 16);
+  unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
+  uint64_t *total = desc->as<uint64_t>() + tiles + 1;
+  size_t w = width_of(c.dtype);
+  // worst case every row is kept: output sized for `rows` (288 GB of HBM: no second pass)
+  BufP out = ctx->alloc(w * (size_t)rows + 16);
+  {
+    ProfScope ps(ctx, "filter_cmp_const");
+    uint64_t *sb = sel->own_bits->as<uint64_t>(), *to = sel->tile_off->as<uint64_t>();
+    if (c.dtype == SQLRS_INT64)
+      launch_filter<int64_t>(ctx, op, c, (int64_t)b.i, rows, out->as<int64_t>(), sb, to,
+                             desc->as<uint64_t>(), ticket, total);
+    else if (c.dtype == SQLRS_INT32)
+      launch_filter<int32_t>(ctx, op, c, (int32_t)b.i, rows, out->as<int32_t>(), sb, to,
+                             desc->as<uint64_t>(), ticket, total);
+    else
+      launch_filter<double>(ctx, op, c, b.f, rows, out->as<double>(), sb, to,
+                            desc->as<uint64_t>(), ticket, total);
+  }
+  sel->count = (int64_t)ctx->fetch_value(total);
+  *col_index = a.index;
+  out_col->dtype = c.dtype;
+  out_col->length = sel->count;
+  out_col->null_count = 0; // rows with a NULL predicate input are dropped
+  out_col->own_values = out;
+  out_col->values = out->p;
+  return true;
+}
+
+} // namespace sq

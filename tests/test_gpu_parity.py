@@ -1,0 +1,277 @@
+"""Parity of the HIP path against the CPU oracle on seeded random inputs (MI355X, through
+the C ABI).  Integer / index / order results must be bit-exact; SUM(double) within 1e-9
+relative (north_star tolerance)."""
+import math
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from sqlrs_amd import abi
+from sqlrs_amd.executor import (FilterExecutor, HashAggExecutor, HashJoinExecutor, OrderExecutor,
+                                eval_column)
+from sqlrs_amd.expr import AggFunc, BinaryOp, Constant, InputRef, JoinCondition, OrderBy, TypeCast
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [0, 1, 63, 64, 65, 4095, 4096, 4097, 100_003]
+REL_TOL = 1e-9
+
+
+def col(rng, n, kind, null_frac=0.0, lo=-50, hi=50):
+    if kind == "i64":
+        v = rng.integers(lo, hi, n, dtype=np.int64)
+        t = pa.int64()
+    elif kind == "i32":
+        v = rng.integers(lo, hi, n, dtype=np.int32)
+        t = pa.int32()
+    elif kind == "f64":
+        v = rng.random(n) * (hi - lo) + lo
+        t = pa.float64()
+    elif kind == "bool":
+        v = rng.integers(0, 2, n).astype(bool)
+        t = pa.bool_()
+    else:
+        raise ValueError(kind)
+    mask = rng.random(n) < null_frac if null_frac else None
+    return pa.array(v, type=t, mask=mask)
+
+
+def batch(rng, n, spec):
+    arrays = [col(rng, n, k, nf, *rest) for (k, nf, *rest) in spec]
+    return pa.RecordBatch.from_arrays(arrays, names=[f"c{i}" for i in range(len(arrays))])
+
+
+def rows_of(batches):
+    out = []
+    for b in batches:
+        cols = [b.column(i).to_pylist() for i in range(b.num_columns)]
+        out.extend(zip(*cols) if cols else [])
+    return [tuple(r) for r in out]
+
+
+def assert_same(got, exp, float_cols=()):
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert len(g) == len(e)
+        for i, (x, y) in enumerate(zip(g, e)):
+            if i in float_cols and x is not None and y is not None:
+                assert math.isclose(x, y, rel_tol=REL_TOL, abs_tol=1e-300), (g, e)
+            else:
+                assert x == y or (isinstance(x, float) and isinstance(y, float) and math.isnan(x) and math.isnan(y)), (g, e)
+
+
+# ------------------------------------------------------------------------- filter --
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("kind,const", [("i64", 3), ("f64", 0.5), ("i32", -7)])
+@pytest.mark.parametrize("op", [">", "<", ">=", "<=", "=", "!="])
+def test_filter_cmp_const(hip, oracle, n, kind, const, op):
+    rng = np.random.default_rng(n * 7 + len(op))
+    b = batch(rng, n, [(kind, 0.1), ("i64", 0.2), ("f64", 0.0), ("bool", 0.3), ("i32", 0.0)])
+    dt = {"i64": abi.INT64, "f64": abi.FLOAT64, "i32": abi.INT32}[kind]
+    e = BinaryOp(op, InputRef(0), Constant(const, dt))
+    got = rows_of(FilterExecutor(hip, e, [b]).execute())
+    exp = rows_of(FilterExecutor(oracle, e, [b]).execute())
+    assert_same(got, exp)
+
+
+@pytest.mark.parametrize("n", [0, 1, 64, 1000, 70_001])
+def test_filter_general_expr(hip, oracle, n):
+    rng = np.random.default_rng(n)
+    b = batch(rng, n, [("i64", 0.1), ("i64", 0.1), ("f64", 0.05), ("bool", 0.2), ("i32", 0.1)])
+    exprs = [
+        (InputRef(0) > InputRef(1)) & (InputRef(2) < Constant(10.0, abi.FLOAT64)),
+        (InputRef(0) + InputRef(1) > Constant(5, abi.INT64)) | InputRef(3),
+        BinaryOp("=", TypeCast(InputRef(4), abi.INT64), InputRef(0)),
+        BinaryOp("!=", InputRef(0) * Constant(2, abi.INT64) - InputRef(1), Constant(None, abi.INT64)),
+        InputRef(3) & Constant(None, abi.BOOLEAN),
+        BinaryOp(">=", TypeCast(InputRef(0), abi.FLOAT64), InputRef(2)),
+    ]
+    for e in exprs:
+        got = rows_of(FilterExecutor(hip, e, [b]).execute())
+        exp = rows_of(FilterExecutor(oracle, e, [b]).execute())
+        assert_same(got, exp)
+        if n:
+            g = eval_column(hip, e, b).column(0).to_pylist()
+            x = eval_column(oracle, e, b).column(0).to_pylist()
+            assert g == x
+
+
+def test_filter_device_resident_chain(hip, oracle):
+    rng = np.random.default_rng(5)
+    b = batch(rng, 50_000, [("i64", 0.1), ("f64", 0.0)])
+    e1 = InputRef(0) > Constant(-10, abi.INT64)
+    e2 = InputRef(1) < Constant(20.0, abi.FLOAT64)
+    dev = hip.to_device(b)
+    mid = list(FilterExecutor(hip, e1, [dev], out_mem=abi.MEM_DEVICE).execute())
+    got = rows_of(FilterExecutor(hip, e2, mid).execute())
+    mid_o = list(FilterExecutor(oracle, e1, [b]).execute())
+    exp = rows_of(FilterExecutor(oracle, e2, mid_o).execute())
+    assert_same(got, exp)
+
+
+def test_divide_by_zero_is_arrow_error(hip, oracle):
+    b = pa.RecordBatch.from_arrays([pa.array([4, 6], pa.int64()), pa.array([2, 0], pa.int64())], names=["a", "b"])
+    from sqlrs_amd import ExecutorError
+    for be in (hip, oracle):
+        with pytest.raises(ExecutorError) as ei:
+            eval_column(be, InputRef(0) / InputRef(1), b)
+        assert ei.value.status == abi.ERR_ARROW
+
+
+# --------------------------------------------------------------------------- join --
+def join_schema(lb, rb):
+    return pa.schema([pa.field(f"l.{f.name}", f.type) for f in lb.schema] +
+                     [pa.field(f"r.{f.name}", f.type) for f in rb.schema])
+
+
+@pytest.mark.parametrize("jt", ["inner", "left", "right", "full"])
+@pytest.mark.parametrize("nb,np_,keyrange,nulls", [
+    (0, 10, 5, 0.0), (10, 0, 5, 0.0), (1, 1, 2, 0.0), (100, 1000, 50, 0.1), (1000, 5000, 2000, 0.05),
+    (5000, 70_001, 5000, 0.0), (3000, 20_000, 100, 0.02)])
+@pytest.mark.parametrize("with_filter", [False, True])
+def test_hash_join(hip, oracle, jt, nb, np_, keyrange, nulls, with_filter):
+    rng = np.random.default_rng(nb * 31 + np_)
+    lb = batch(rng, nb, [("i64", nulls, 0, keyrange), ("i64", 0.1), ("f64", 0.0)])
+    rb = batch(rng, np_, [("f64", 0.05), ("i64", nulls, 0, keyrange), ("i64", 0.0)])
+    filt = (InputRef(1) > InputRef(5)) if with_filter else None
+    cond = JoinCondition([(InputRef(0), InputRef(1))], filt)
+    sch = join_schema(lb, rb)
+    # build side in two batches, probe side in three
+    lbs = [lb.slice(0, nb // 2), lb.slice(nb // 2)] if nb > 1 else [lb]
+    rbs = [rb.slice(0, np_ // 3), rb.slice(np_ // 3, np_ // 3), rb.slice(2 * (np_ // 3))] if np_ > 3 else [rb]
+    got = list(HashJoinExecutor(hip, lbs, rbs, jt, cond, sch, lb.num_columns).execute())
+    exp = list(HashJoinExecutor(oracle, lbs, rbs, jt, cond, sch, lb.num_columns).execute())
+    assert [b.num_rows for b in got] == [b.num_rows for b in exp]  # one batch per probe batch + tail
+    assert_same(rows_of(got), rows_of(exp))
+
+
+@pytest.mark.parametrize("jt", ["inner", "right"])
+def test_hash_join_indices(hip, oracle, jt):
+    rng = np.random.default_rng(11)
+    lb = batch(rng, 2000, [("i64", 0.05, 0, 300)])
+    rb = batch(rng, 9000, [("i64", 0.05, 0, 400)])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    got = list(HashJoinExecutor(hip, [lb], [rb], jt, cond, sch, 1).execute(indices_only=True))
+    exp = list(HashJoinExecutor(oracle, [lb], [rb], jt, cond, sch, 1).execute(indices_only=True))
+    assert_same(rows_of(got), rows_of(exp))
+
+
+@pytest.mark.parametrize("kind", ["i32", "f64", "bool"])
+def test_hash_join_key_types(hip, oracle, kind):
+    rng = np.random.default_rng(3)
+    lb = batch(rng, 500, [(kind, 0.1, 0, 40), ("i64", 0.0)])
+    rb = batch(rng, 3000, [(kind, 0.1, 0, 60), ("i64", 0.0)])
+    if kind == "f64":  # make float keys collide
+        lb = lb.set_column(0, "c0", pa.array(np.floor(lb.column(0).to_numpy(zero_copy_only=False)), mask=np.array(lb.column(0).is_null())))
+        rb = rb.set_column(0, "c0", pa.array(np.floor(rb.column(0).to_numpy(zero_copy_only=False)), mask=np.array(rb.column(0).is_null())))
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    for jt in ("inner", "full"):
+        got = list(HashJoinExecutor(hip, [lb], [rb], jt, cond, sch, 2).execute())
+        exp = list(HashJoinExecutor(oracle, [lb], [rb], jt, cond, sch, 2).execute())
+        assert_same(rows_of(got), rows_of(exp))
+
+
+def test_hash_join_two_column_keys(hip, oracle):
+    rng = np.random.default_rng(4)
+    lb = batch(rng, 800, [("i64", 0.05, 0, 20), ("i32", 0.05, 0, 10), ("i64", 0.0)])
+    rb = batch(rng, 4000, [("i64", 0.05, 0, 20), ("i32", 0.05, 0, 10), ("f64", 0.0)])
+    cond = JoinCondition([(InputRef(0), InputRef(0)), (InputRef(1), InputRef(1))])
+    sch = join_schema(lb, rb)
+    for jt in ("inner", "left"):
+        got = list(HashJoinExecutor(hip, [lb], [rb], jt, cond, sch, 3).execute())
+        exp = list(HashJoinExecutor(oracle, [lb], [rb], jt, cond, sch, 3).execute())
+        assert_same(rows_of(got), rows_of(exp))
+
+
+def test_empty_build_side_emits_nothing(hip, oracle):
+    rb = batch(np.random.default_rng(1), 10, [("i64", 0.0)])
+    sch = pa.schema([pa.field("l.c0", pa.int64()), pa.field("r.c0", pa.int64())])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    for jt in ("inner", "right", "full"):
+        assert list(HashJoinExecutor(hip, [], [rb], jt, cond, sch, 1).execute()) == []
+        assert list(HashJoinExecutor(oracle, [], [rb], jt, cond, sch, 1).execute()) == []
+
+
+# ---------------------------------------------------------------------------- agg --
+AGGS = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.INT64),
+        AggFunc("sum", InputRef(2), abi.FLOAT64), AggFunc("count", InputRef(2), abi.INT64),
+        AggFunc("min", InputRef(1), abi.INT64), AggFunc("max", InputRef(2), abi.FLOAT64),
+        AggFunc("max", InputRef(1), abi.INT64), AggFunc("min", InputRef(2), abi.FLOAT64)]
+
+
+@pytest.mark.parametrize("n,groups,nulls", [(1, 1, 0.0), (10, 3, 0.3), (1000, 10, 0.1), (5000, 5000, 0.1),
+                                            (100_003, 1000, 0.05), (200_000, 150_000, 0.0)])
+def test_hash_agg_single_batch(hip, oracle, n, groups, nulls):
+    rng = np.random.default_rng(n + groups)
+    b = batch(rng, n, [("i64", nulls, 0, groups), ("i64", nulls, -1000, 1000), ("f64", nulls, 0, 1)])
+    got = rows_of(HashAggExecutor(hip, AGGS, [InputRef(0)], [b]).execute())
+    exp = rows_of(HashAggExecutor(oracle, AGGS, [InputRef(0)], [b]).execute())
+    assert_same(got, exp, float_cols={3, 6, 8})
+
+
+def test_hash_agg_multi_batch_accumulates(hip, oracle):
+    """COUNT accumulates across batches on the HIP path (SQL semantics); the reference assigns
+    (count.rs:22).  SUM/MIN/MAX must agree with the oracle either way; COUNT agrees with the
+    oracle in its default (accumulating) mode."""
+    rng = np.random.default_rng(9)
+    bs = [batch(rng, n, [("i64", 0.1, 0, 200), ("i64", 0.2, -5, 5), ("f64", 0.0 if i < 2 else 0.3, 0, 1)])
+          for i, n in enumerate([1000, 1, 5000, 0, 3000])]
+    got = rows_of(HashAggExecutor(hip, AGGS, [InputRef(0)], bs).execute())
+    exp = rows_of(HashAggExecutor(oracle, AGGS, [InputRef(0)], bs).execute())
+    assert_same(got, exp, float_cols={3, 6, 8})
+
+
+def test_hash_agg_count_compat_switch_documents_reference_quirk(oracle, oracle_compat):
+    """CPU only in effect: the oracle's compat switch reproduces count.rs:22 (last batch wins)."""
+    b1 = pa.RecordBatch.from_arrays([pa.array([1, 1, 2], pa.int64()), pa.array([1, 1, 1], pa.int64())], names=["k", "v"])
+    b2 = pa.RecordBatch.from_arrays([pa.array([1], pa.int64()), pa.array([1], pa.int64())], names=["k", "v"])
+    aggs = [AggFunc("count", InputRef(1), abi.INT64)]
+    assert rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b1, b2]).execute()) == [(1, 3), (2, 1)]
+    assert rows_of(HashAggExecutor(oracle_compat, aggs, [InputRef(0)], [b1, b2]).execute()) == [(1, 1), (2, 1)]
+
+
+@pytest.mark.parametrize("kind", ["i32", "f64", "bool"])
+def test_hash_agg_key_types(hip, oracle, kind):
+    rng = np.random.default_rng(12)
+    b = batch(rng, 20_000, [(kind, 0.1, 0, 30), ("i64", 0.1), ("f64", 0.1, 0, 1)])
+    if kind == "f64":
+        b = b.set_column(0, "c0", pa.array(np.floor(b.column(0).to_numpy(zero_copy_only=False)), mask=np.array(b.column(0).is_null())))
+    got = rows_of(HashAggExecutor(hip, AGGS, [InputRef(0)], [b]).execute())
+    exp = rows_of(HashAggExecutor(oracle, AGGS, [InputRef(0)], [b]).execute())
+    assert_same(got, exp, float_cols={3, 6, 8})
+
+
+def test_hash_agg_two_keys_and_exprs(hip, oracle):
+    rng = np.random.default_rng(13)
+    b = batch(rng, 30_000, [("i64", 0.05, 0, 20), ("i64", 0.1), ("f64", 0.1, 0, 1), ("i32", 0.05, 0, 7)])
+    aggs = [AggFunc("sum", InputRef(1) + Constant(1, abi.INT64), abi.INT64),
+            AggFunc("sum", TypeCast(InputRef(3), abi.INT64), abi.INT64),
+            AggFunc("count", InputRef(2), abi.INT64)]
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0), InputRef(3)], [b]).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0), InputRef(3)], [b]).execute())
+    assert_same(got, exp)
+
+
+def test_hash_agg_without_input_is_internal_error(hip, oracle):
+    from sqlrs_amd import ExecutorError
+    for be in (hip, oracle):
+        with pytest.raises(ExecutorError) as ei:
+            list(HashAggExecutor(be, AGGS[:1], [InputRef(0)], []).execute())
+        assert ei.value.status == abi.ERR_INTERNAL
+
+
+# -------------------------------------------------------------------------- order --
+@pytest.mark.parametrize("n", [1, 2, 64, 4097, 50_001])
+def test_order(hip, oracle, n):
+    rng = np.random.default_rng(n)
+    b = batch(rng, n, [("i64", 0.1, -20, 20), ("f64", 0.1, -3, 3), ("i32", 0.0, 0, 5), ("bool", 0.2), ("i64", 0.0)])
+    bs = [b.slice(0, n // 2), b.slice(n // 2)] if n > 1 else [b]
+    for ob in ([OrderBy(InputRef(0), True)], [OrderBy(InputRef(0), False)], [OrderBy(InputRef(1), False)],
+               [OrderBy(InputRef(2), True), OrderBy(InputRef(0), False)],
+               [OrderBy(InputRef(3), False), OrderBy(InputRef(2), True), OrderBy(InputRef(1), True)]):
+        got = rows_of(OrderExecutor(hip, ob, bs).execute())
+        exp = rows_of(OrderExecutor(oracle, ob, bs).execute())
+        assert_same(got, exp)
