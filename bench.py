@@ -1,0 +1,359 @@
+#!/usr/bin/env python
+"""bench.py — the hot path of BASELINE.json measured on MI355X through the C ABI.
+
+Workload (config C5, the configuration the metric is quoted on; it fits one GPU):
+
+    SELECT d.key, COUNT(f.val), SUM(f.val)
+    FROM fact f JOIN dim d ON f.key = d.key          -- dim = build (left), fact = probe (right)
+    WHERE f.val > 0.5                                 -- FilterExecutor, selectivity 0.5
+    GROUP BY d.key                                    -- HashAggExecutor, 1e7 groups
+
+fact = 1e9 rows (key int64, val float64), dim = 1e7 rows (key int64), synthetic SplitMix64
+columns generated in HBM.  One "step" = one pass of Filter -> HashJoin(build+probe) -> HashAgg
+over the whole input; inputs are HBM resident when the timed region starts.  `value` is
+fact rows / s summed over all ranks (Mrows/s).
+
+N > 1 (one process per GPU, launched by torch.distributed.run): the TOTAL input is fixed
+("scaling": "strong"); every rank generates a contiguous 1/N slice of fact and dim,
+hash-partitions both on the join key (sqlrs_hash_partition), exchanges the slices with one
+RCCL all-to-all per column over xGMI and runs the same operators on what it receives.  Group
+key = join key, so the per-rank results are disjoint and need no merge.
+
+Output: ONE JSON line on rank 0 (contract in the task description) with `roofline` for the
+dominant kernel (HIP-event time per launch, measured live on the ctx stream) and
+`cpu_baseline` (the CPU oracle, single thread, on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+# --------------------------------------------------------------------------------------
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--rows", type=float, default=float(os.environ.get("SQLRS_BENCH_ROWS", 1e9)),
+                   help="total fact rows over all ranks (C5: 1e9)")
+    p.add_argument("--dim-rows", type=float, default=float(os.environ.get("SQLRS_BENCH_DIM", 1e7)),
+                   help="total dim rows = number of groups (C5: 1e7)")
+    p.add_argument("--threshold", type=float, default=0.5, help="WHERE f.val > threshold")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-rows", type=float, default=0, help="0 = auto (about 10-30 s)")
+    p.add_argument("--operators", action="store_true",
+                   help="also time configs C2/C3/C4 one operator at a time (stderr + 'operators' key)")
+    return p.parse_args()
+
+
+def device_batch(abi, tensors, dtypes):
+    cols = [abi.device_column(dt, t.numel(), t.data_ptr()) for t, dt in zip(tensors, dtypes)]
+    return abi.RawBatch(cols, tensors[0].numel(), keepalive=tensors)
+
+
+class Pipeline:
+    """Filter -> HashJoin -> HashAgg driven through the C ABI on device-resident batches."""
+
+    def __init__(self, be, abi, threshold):
+        from sqlrs_amd.expr import AggFunc, Constant, InputRef, JoinCondition
+        self.be, self.abi = be, abi
+        self.filter_expr = (InputRef(1) > Constant(threshold, abi.FLOAT64)).pack()
+        self.cond = JoinCondition([(InputRef(0), InputRef(0))])
+        self.lk, self._k1 = abi.pack_exprs([InputRef(0)])
+        self.rk, self._k2 = abi.pack_exprs([InputRef(0)])
+        self.right_dtypes = (C.c_int32 * 2)(abi.INT64, abi.FLOAT64)
+        self.gb, self._k3 = abi.pack_exprs([InputRef(0)])  # d.key
+        keep = []
+        self.aggs = (abi.AggFunc * 2)(AggFunc("count", InputRef(2), abi.INT64).abi_struct(keep),
+                                      AggFunc("sum", InputRef(2), abi.FLOAT64).abi_struct(keep))
+        self._keep = keep
+
+    def step(self, dim_b, fact_b):
+        """one pass; returns the device-resident result batch (LibBatch)"""
+        be, abi = self.be, self.abi
+        D = abi.MEM_DEVICE
+        f = C.c_void_p()
+        be.check(be.fn("filter_create")(be.ctx, C.byref(self.filter_expr.abi), C.byref(f)))
+        fo = C.POINTER(abi.Batch)()
+        be.check(be.fn("filter_push")(f, fact_b.ptr, D, C.byref(fo)))
+        be.fn("filter_destroy")(f)
+        filtered = be.wrap(fo)
+        j = C.c_void_p()
+        be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, self.lk, self.rk, None, 2,
+                                           self.right_dtypes, C.byref(j)))
+        be.check(be.fn("hash_join_build_push")(j, dim_b.ptr))
+        be.check(be.fn("hash_join_build_finish")(j))
+        jo = C.POINTER(abi.Batch)()
+        be.check(be.fn("hash_join_probe_push")(j, filtered.ptr, D, C.byref(jo)))
+        joined = be.wrap(jo)
+        filtered.release()
+        be.fn("hash_join_destroy")(j)
+        a = C.c_void_p()
+        be.check(be.fn("hash_agg_create")(be.ctx, 1, self.gb, 2, self.aggs, C.byref(a)))
+        be.check(be.fn("hash_agg_push")(a, joined.ptr))
+        joined.release()
+        ao = C.POINTER(abi.Batch)()
+        be.check(be.fn("hash_agg_finish")(a, D, C.byref(ao)))
+        be.fn("hash_agg_destroy")(a)
+        return be.wrap(ao)
+
+
+# algorithmic HBM bytes per launch of the kernels that can dominate
+def algorithmic_bytes(kernel, w):
+    nP, nB, s, M, G = w["fact_rows"], w["dim_rows"], w["selectivity"], w["matches"], w["groups"]
+    table = {
+        "filter_cmp_const": 8 * nP + 8 * s * nP,            # read predicate column, write kept values
+        "compact": 8 * nP + 8 * s * nP,                     # second column through the same selection
+        "join_probe_count": 8 * s * nP,                     # probe keys read
+        "join_probe_fill": 8 * s * nP + 12 * M,             # probe keys read, (u64,u32) pairs written
+        "gather": 12 * M + 8 * M,                           # index read + gathered column written (per column)
+        "agg_resolve": 8 * M,                               # group keys read
+        "agg_update": 12 * M,                               # group id + value read per row
+        "join_build": 8 * nB,
+        "normalize_keys": 16 * M,
+    }
+    return table.get(kernel)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import sqlrs_amd
+    from sqlrs_amd import abi, datagen
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    be = sqlrs_amd.new_ctx(local_rank)  # raises if the HIP library / GPU is missing: no fallback
+    n_fact_total, n_dim_total = int(args.rows), int(args.dim_rows)
+    # contiguous slice of the global tables owned by this rank
+    f_lo, f_hi = n_fact_total * rank // world, n_fact_total * (rank + 1) // world
+    d_lo, d_hi = n_dim_total * rank // world, n_dim_total * (rank + 1) // world
+    t0 = time.time()
+    fact_key = datagen.fill_chunks(torch.empty(f_hi - f_lo, dtype=torch.int64, device=dev),
+                                   lambda i: datagen.key_t(0xF1, i, n_dim_total), f_lo)
+    fact_val = datagen.fill_chunks(torch.empty(f_hi - f_lo, dtype=torch.float64, device=dev),
+                                   lambda i: datagen.val_t(0xF2, i), f_lo)
+    dim_key = datagen.fill_chunks(torch.empty(d_hi - d_lo, dtype=torch.int64, device=dev),
+                                  lambda i: datagen.dim_key_t(i, n_dim_total), d_lo)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"[bench] generated {f_hi - f_lo:,} fact rows + {d_hi - d_lo:,} dim rows per rank in {time.time() - t0:.1f}s")
+    expected_kept = int((fact_val > args.threshold).sum().item())
+
+    pipe = Pipeline(be, abi, args.threshold)
+    from sqlrs_amd.expr import InputRef
+
+    def exchange(cols, dtypes):
+        """hash-partition on column 0 and all-to-all every column over RCCL; returns tensors"""
+        b = device_batch(abi, cols, dtypes)
+        parts, offs = be.hash_partition(b, InputRef(0), world, abi.MEM_DEVICE)
+        be.synchronize()
+        send_counts = torch.tensor([offs[p + 1] - offs[p] for p in range(world)], dtype=torch.int64, device=dev)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()
+        outs = []
+        for ci, t in enumerate(cols):
+            c = parts.column(ci)
+            src = torch.empty(0, dtype=t.dtype, device=dev) if c.length == 0 else \
+                _tensor_view(torch, c.values, c.length, t.dtype, dev)
+            dst = torch.empty(int(sum(rc)), dtype=t.dtype, device=dev)
+            dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc)
+            outs.append(dst)
+        torch.cuda.synchronize()
+        parts.release()
+        return outs
+
+    def one_step():
+        if world > 1:
+            dk, = exchange([dim_key], [abi.INT64])
+            fk, fv = exchange([fact_key, fact_val], [abi.INT64, abi.FLOAT64])
+        else:
+            dk, fk, fv = dim_key, fact_key, fact_val
+        dim_b = device_batch(abi, [dk], [abi.INT64])
+        fact_b = device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64])
+        out = pipe.step(dim_b, fact_b)
+        be.synchronize()
+        return out
+
+    def barrier():
+        torch.cuda.synchronize()
+        be.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warmup (also validates the result once)
+    out = None
+    for _ in range(max(args.warmup, 1)):
+        if out is not None:
+            out.release()
+        out = one_step()
+    groups_local = out.num_rows
+    cnt = _tensor_view(torch, out.column(1).values, groups_local, torch.int64, dev)
+    sm = _tensor_view(torch, out.column(2).values, groups_local, torch.float64, dev)
+    got_rows = torch.tensor([int(cnt.sum().item())], dtype=torch.int64, device=dev)
+    got_sum = torch.tensor([float(sm.sum().item())], dtype=torch.float64, device=dev)
+    exp_rows = torch.tensor([expected_kept], dtype=torch.int64, device=dev)
+    exp_sum = torch.tensor([float(fact_val[fact_val > args.threshold].sum().item())], dtype=torch.float64, device=dev)
+    ngroups = torch.tensor([groups_local], dtype=torch.int64, device=dev)
+    if world > 1:
+        for t in (got_rows, got_sum, exp_rows, exp_sum, ngroups):
+            dist.all_reduce(t)
+    ok = (got_rows.item() == exp_rows.item()) and abs(got_sum.item() - exp_sum.item()) <= 1e-9 * abs(exp_sum.item())
+    if rank == 0:
+        log(f"[bench] check: rows through join+agg {got_rows.item():,} (expected {exp_rows.item():,}), "
+            f"sum {got_sum.item():.6f} vs {exp_sum.item():.6f}, groups {ngroups.item():,} -> {'OK' if ok else 'MISMATCH'}")
+    if not ok:
+        raise SystemExit("bench result check failed")
+    out.release()
+
+    # ---- timed region: exactly K steps between barriers
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        one_step().release()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_fact_total / (elapsed / args.steps) / 1e6
+
+    # ---- per-kernel device time (HIP events on the ctx stream), separate profiled steps
+    be.profile(True)
+    for _ in range(2):
+        one_step().release()
+    prof = be.profile_read()
+    be.profile(False)
+    workload = {"fact_rows": f_hi - f_lo, "dim_rows": d_hi - d_lo, "selectivity": expected_kept / max(f_hi - f_lo, 1),
+                "matches": expected_kept, "groups": groups_local}
+    if world > 1:  # after the exchange every rank holds about 1/N of everything
+        workload = {"fact_rows": n_fact_total // world, "dim_rows": n_dim_total // world,
+                    "selectivity": exp_rows.item() / n_fact_total, "matches": exp_rows.item() // world,
+                    "groups": ngroups.item() // world}
+    roofline = None
+    if rank == 0:
+        rows = sorted(prof.items(), key=lambda kv: -kv[1][0])
+        tot = sum(v[0] for _, v in rows) or 1.0
+        log("[bench] device time per kernel class (2 profiled steps):")
+        for name, (ms, launches) in rows:
+            ab = algorithmic_bytes(name, workload)
+            extra = f"  {ab / (ms / launches) / 1e6:8.0f} GB/s algorithmic" if (ab and launches) else ""
+            log(f"    {name:22s} {ms / 2:9.3f} ms/step  {launches // 2:4d} launches/step  {100 * ms / tot:5.1f}%{extra}")
+        for name, (ms, launches) in rows:
+            ab = algorithmic_bytes(name, workload)
+            if ab and launches:
+                per_launch_ms = ms / launches
+                ach = ab / per_launch_ms / 1e6
+                roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                            "ms_per_launch": round(per_launch_ms, 4), "algorithmic_bytes": int(ab)}
+                break
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, abi, datagen, n_dim_total)
+
+    if rank == 0:
+        line = {
+            "metric": "Mrows/sec for filter->hash-join->group-by pipeline; achieved HBM GB/s vs peak",
+            "value": round(value, 1), "unit": "Mrows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int64 keys / f64 sum", "data": "synthetic",
+            "config": {"workload": "C5 filter(val>0.5) -> hash-join(fact x dim on int64 key) -> group-by(key) COUNT,SUM(f64)",
+                       "fact_rows": n_fact_total, "dim_rows": n_dim_total, "groups": int(ngroups.item()),
+                       "selectivity": round(exp_rows.item() / n_fact_total, 4),
+                       "parallelism": f"hash-partition x{world} + RCCL all-to-all" if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _tensor_view(torch, ptr, n, dtype, dev):
+    """zero-copy torch view over a library-owned device buffer"""
+    if n == 0:
+        return torch.empty(0, dtype=dtype, device=dev)
+    itemsize = torch.empty(0, dtype=dtype).element_size()
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": {torch.int64: "<i8", torch.float64: "<f8"}[dtype],
+                                  "data": (int(ptr), False), "version": 2, "strides": (itemsize,)}
+    return torch.as_tensor(h, device=dev)
+
+
+def cpu_baseline(args, abi, datagen, n_dim_total):
+    """The CPU oracle (C++ restatement of the reference, 1 thread — the reference never
+    spawns one) on a bounded sample of the same workload.  Test/bench infrastructure only."""
+    import pyarrow as pa
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import load_oracle
+    from sqlrs_amd.executor import FilterExecutor, HashAggExecutor, HashJoinExecutor
+    from sqlrs_amd.expr import AggFunc, Constant, InputRef, JoinCondition
+
+    oracle = load_oracle()
+    n_dim = min(n_dim_total, 1_000_000)
+
+    def run(n_fact):
+        idx = np.arange(n_fact, dtype=np.int64)
+        fact = pa.RecordBatch.from_arrays([pa.array(datagen.key_np(0xF1, idx, n_dim)), pa.array(datagen.val_np(0xF2, idx))],
+                                          names=["key", "val"])
+        dim = pa.RecordBatch.from_arrays([pa.array(datagen.dim_key_np(np.arange(n_dim, dtype=np.int64), n_dim))], names=["key"])
+        schema = pa.schema([("d.key", pa.int64()), ("f.key", pa.int64()), ("f.val", pa.float64())])
+        t = time.perf_counter()
+        filt = FilterExecutor(oracle, InputRef(1) > Constant(args.threshold, abi.FLOAT64), [fact])
+        join = HashJoinExecutor(oracle, [dim], filt.execute(), "inner", JoinCondition([(InputRef(0), InputRef(0))]), schema, 1)
+        agg = HashAggExecutor(oracle, [AggFunc("count", InputRef(2), abi.INT64), AggFunc("sum", InputRef(2), abi.FLOAT64)],
+                              [InputRef(0)], join.execute())
+        (out,) = list(agg.execute())
+        return time.perf_counter() - t, out.num_rows
+
+    n = int(args.cpu_sample_rows) or 1_000_000
+    dt, groups = run(n)
+    if not args.cpu_sample_rows and dt < 8.0:  # scale the sample to roughly 15 s of CPU work
+        n = int(min(n * 15.0 / max(dt, 1e-3), 64_000_000))
+        dt, groups = run(n)
+    val = n / dt / 1e6
+    log(f"[bench] cpu_baseline: {n:,} fact rows x {n_dim:,} dim rows in {dt:.1f}s on 1 thread = {val:.3f} Mrows/s")
+    return {"value": round(val, 4), "unit": "Mrows/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} fact rows x {n_dim} dim rows, single batch, same query, oracle/libsqlrs_oracle.so (1 thread, {os.cpu_count()} host cores present)"}
+
+
+if __name__ == "__main__":
+    main()

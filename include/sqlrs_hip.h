@@ -250,6 +250,17 @@ int sqlrs_order_push(sqlrs_order_t *o, const sqlrs_batch_t *in);
 int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out);
 void sqlrs_order_destroy(sqlrs_order_t *o);
 
+/* --------------------------------------------------------------- exchange -- */
+/* Hash-partitions a batch on one key expression for the multi-GPU partitioned join /
+ * group-by (no reference analogue: sqlrs is single process).  The output batch
+ * holds the input rows permuted so that partition p = rows [offsets[p], offsets[p+1]), input
+ * order preserved inside a partition; `offsets` (host, num_parts + 1 entries) is filled by the
+ * call.  Rows with equal keys always land in the same partition; NULL keys go to partition 0.
+ * The caller exchanges the slices (RCCL all-to-all over xGMI) and feeds what it receives to
+ * the ordinary operators above. */
+int sqlrs_hash_partition(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, const sqlrs_expr_t *key,
+                         int num_parts, int out_mem, sqlrs_batch_t **out, int64_t *offsets);
+
 /* ------------------------------------------------- timing of device work -- */
 /* HIP-event timing on the ctx stream (bench.py measures the dominant kernel
  * with these: torch.cuda.Event only sees torch's own stream). */

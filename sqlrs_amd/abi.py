@@ -299,6 +299,7 @@ class Backend:
             "ctx_pool_bytes": (C.c_int64, [vp]),
             "ctx_pool_trim": (None, [vp]),
             "batch_copy": (i, [vp, pb, i, ppb]),
+            "hash_partition": (i, [vp, pb, pe, i, i, ppb, C.POINTER(C.c_int64)]),
             "timer_create": (i, [vp, pvp]),
             "timer_start": (i, [vp]),
             "timer_stop": (i, [vp]),
@@ -346,6 +347,16 @@ class Backend:
 
     def to_host(self, batch) -> LibBatch:
         return self.copy(batch, MEM_HOST)
+
+    def hash_partition(self, batch, key_expr, num_parts: int, out_mem: int = MEM_DEVICE):
+        """-> (LibBatch permuted by partition, offsets list of num_parts + 1 ints)"""
+        b = as_batch(batch)
+        packed = key_expr.pack()
+        out = C.POINTER(Batch)()
+        offs = (C.c_int64 * (num_parts + 1))()
+        self.check(self.fn("hash_partition")(self.ctx, b.ptr, C.byref(packed.abi), num_parts, out_mem,
+                                             C.byref(out), offs))
+        return self.wrap(out), list(offs)
 
     def profile(self, on: bool = True):
         self.check(self.fn("ctx_profile_enable")(self.ctx, int(on)))
