@@ -126,6 +126,10 @@ def algorithmic_bytes(kernel, w):
         "agg_resolve": 8 * M,                               # group keys read
         "agg_update": 12 * M,                               # group id + value read per row
         "join_build": 8 * nB,
+        "join_probe_unique": 8 * s * nP + 12 * M,           # one pass: keys read, pairs written
+        "rp_scatter": 38 * M,                               # (key, val[, row id]) read + (key, val, row id) written
+        "rp_hist": 8 * M,
+        "lds_agg": 20 * M + 32 * G,                         # partitioned rows read, groups written
         "normalize_keys": 16 * M,
     }
     return table.get(kernel)
@@ -282,6 +286,13 @@ def main():
                             "ms_per_launch": round(per_launch_ms, 4), "algorithmic_bytes": int(ab)}
                 break
 
+    operators = None
+    if rank == 0 and args.operators and world == 1:
+        del fact_key, fact_val, dim_key
+        be.fn("ctx_pool_trim")(be.ctx)
+        torch.cuda.empty_cache()
+        operators = bench_operators(be, abi, datagen, torch, dev)
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, abi, datagen, n_dim_total)
@@ -298,9 +309,133 @@ def main():
                        "parallelism": f"hash-partition x{world} + RCCL all-to-all" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if operators:
+            line["operators"] = operators
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_operators(be, abi, datagen, torch, dev, reps=3):
+    """Configs C2 / C3 / C4 of BASELINE.json, one operator at a time, HBM-resident inputs,
+    timed with HIP events on the ctx stream.  GB/s = algorithmic bytes of SURVEY.md §8d / time."""
+    from sqlrs_amd.expr import AggFunc, Constant, InputRef
+
+    def profile_of(fn, label):
+        be.profile(True)
+        fn()
+        pr = be.profile_read()
+        be.profile(False)
+        rows = sorted(pr.items(), key=lambda kv: -kv[1][0])
+        log(f"[bench]   {label} kernel classes: " + ", ".join(f"{k} {v[0]:.3f}ms x{v[1]}" for k, v in rows if v[0] > 0.01))
+
+    def timed(fn):
+        fn()  # warm-up (also warms the memory pool)
+        t = C.c_void_p()
+        be.check(be.fn("timer_create")(be.ctx, C.byref(t)))
+        best = 1e30
+        for _ in range(reps):
+            be.check(be.fn("timer_start")(t))
+            fn()
+            be.check(be.fn("timer_stop")(t))
+            ms = C.c_double()
+            be.check(be.fn("timer_elapsed_ms")(t, C.byref(ms)))
+            best = min(best, ms.value)
+        be.fn("timer_destroy")(t)
+        return best
+
+    res = {}
+    D = abi.MEM_DEVICE
+    # ---- C2: SELECT v1 FROM t WHERE v1 > k, 1e8 int64 rows, selectivity 0.5
+    n = 100_000_000
+    v1 = datagen.fill_chunks(torch.empty(n, dtype=torch.int64, device=dev),
+                             lambda i: datagen._lsr(datagen.splitmix64_t(0xC2, i), 33))  # mod 2^31
+    torch.cuda.synchronize()  # inputs are produced on torch's stream, consumed on the ctx stream
+    for sel, k in ((0.5, 1 << 30), (0.01, int((1 << 31) * 0.99)), (0.99, int((1 << 31) * 0.01))):
+        e = (InputRef(0) > Constant(k, abi.INT64)).pack()
+        b = device_batch(abi, [v1], [abi.INT64])
+        kept = [0]
+
+        def run():
+            f = C.c_void_p()
+            be.check(be.fn("filter_create")(be.ctx, C.byref(e.abi), C.byref(f)))
+            o = C.POINTER(abi.Batch)()
+            be.check(be.fn("filter_push")(f, b.ptr, D, C.byref(o)))
+            kept[0] = o.contents.num_rows
+            be.fn("batch_release")(o)
+            be.fn("filter_destroy")(f)
+        ms = timed(run)
+        by = 8 * n + 8 * kept[0]
+        res[f"C2_filter_s{sel}"] = {"rows": n, "kept": kept[0], "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
+                                    "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    del v1
+    # ---- C3: 1e8 fact JOIN 1e6 dim on int64 key (Inner, index-pair output)
+    nP, nB = 100_000_000, 1_000_000
+    dim_key = datagen.fill_chunks(torch.empty(nB, dtype=torch.int64, device=dev), lambda i: datagen.dim_key_t(i, nB))
+    for hit, mod in (("all_hit", nB), ("half_hit", 2 * nB)):
+        fk = datagen.fill_chunks(torch.empty(nP, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF1, i, mod))
+        torch.cuda.synchronize()
+        db, fb = device_batch(abi, [dim_key], [abi.INT64]), device_batch(abi, [fk], [abi.INT64])
+        lk, _k1 = abi.pack_exprs([InputRef(0)])
+        rk, _k2 = abi.pack_exprs([InputRef(0)])
+        rd = (C.c_int32 * 1)(abi.INT64)
+        m = [0]
+        j = C.c_void_p()
+
+        def build():
+            be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, lk, rk, None, 1, rd, C.byref(j)))
+            be.check(be.fn("hash_join_build_push")(j, db.ptr))
+            be.check(be.fn("hash_join_build_finish")(j))
+
+        def probe():
+            o = C.POINTER(abi.Batch)()
+            be.check(be.fn("hash_join_probe_indices")(j, fb.ptr, D, C.byref(o)))
+            m[0] = o.contents.num_rows
+            be.fn("batch_release")(o)
+
+        def both():
+            build()
+            probe()
+            be.fn("hash_join_destroy")(j)
+        ms_all = timed(both)
+        build()
+        ms_probe = timed(probe)
+        profile_of(probe, f"C3 probe {hit}")
+        be.fn("hash_join_destroy")(j)
+        by = 8 * nB + 8 * nP + 12 * m[0]
+        res[f"C3_join_{hit}"] = {"probe_rows": nP, "build_rows": nB, "pairs": m[0], "ms_build_probe": round(ms_all, 3),
+                                 "ms_probe": round(ms_probe, 3), "probe_Mrows_s": round(nP / ms_probe / 1e3, 1),
+                                 "GBps": round(by / ms_all / 1e6, 1), "frac": round(by / ms_all / 1e6 / HBM_PEAK_GBPS, 4)}
+        del fk
+    # ---- C4: 2e8 rows, 1e6 int64 groups, COUNT(val), SUM(val) f64
+    n, G = 200_000_000, 1_000_000
+    key = datagen.fill_chunks(torch.empty(n, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xA1, i, G))
+    val = datagen.fill_chunks(torch.empty(n, dtype=torch.float64, device=dev), lambda i: datagen.val_t(0xF2, i))
+    torch.cuda.synchronize()
+    b = device_batch(abi, [key, val], [abi.INT64, abi.FLOAT64])
+    gb, _k3 = abi.pack_exprs([InputRef(0)])
+    keep = []
+    aggs = (abi.AggFunc * 2)(AggFunc("count", InputRef(1), abi.INT64).abi_struct(keep),
+                             AggFunc("sum", InputRef(1), abi.FLOAT64).abi_struct(keep))
+    groups = [0]
+
+    def run_agg():
+        a = C.c_void_p()
+        be.check(be.fn("hash_agg_create")(be.ctx, 1, gb, 2, aggs, C.byref(a)))
+        be.check(be.fn("hash_agg_push")(a, b.ptr))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("hash_agg_finish")(a, D, C.byref(o)))
+        groups[0] = o.contents.num_rows
+        be.fn("batch_release")(o)
+        be.fn("hash_agg_destroy")(a)
+    ms = timed(run_agg)
+    profile_of(run_agg, "C4 agg")
+    by = 16 * n + 24 * groups[0]
+    res["C4_agg"] = {"rows": n, "groups": groups[0], "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
+                     "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    for k_, v_ in res.items():
+        log(f"[bench] {k_}: {v_}")
+    return res
 
 
 def _tensor_view(torch, ptr, n, dtype, dev):

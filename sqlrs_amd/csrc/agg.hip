@@ -156,7 +156,8 @@ __global__ __launch_bounds__(BLOCK) void agg_minmax_kernel(const uint32_t *__res
   uint64_t u;
   if (KIND == 0) u = i64_to_ordered(((const int64_t *)vals)[r]);
   else if (KIND == 1) u = f64_to_ordered(((const double *)vals)[r]);
-  else u = i64_to_ordered((int64_t)((const int32_t *)vals)[r]);
+  else if (KIND == 2) u = i64_to_ordered((int64_t)((const int32_t *)vals)[r]);
+  else u = ((const uint64_t *)vals)[r]; // already an order-preserving image (partial MIN/MAX)
   unsigned long long *p = &acc[row_gid[r]];
   unsigned long long cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (IS_MIN) {
@@ -380,12 +381,17 @@ void agg_update_minmax(Ctx *ctx, GrowBuf &acc, int32_t dtype, bool is_min, const
   if (dtype == SQLRS_INT64) SQ_MM(0);
   else if (dtype == SQLRS_FLOAT64) SQ_MM(1);
   else if (dtype == SQLRS_INT32) SQ_MM(2);
+  else if (dtype == SQLRS_UINT64) SQ_MM(3);
   else fail(SQLRS_ERR_INTERNAL, "unsupported min/max type"); // min_max.rs:41
 #undef SQ_MM
   SQ_HIP(hipGetLastError());
 }
 
 DCol agg_finalize_values(Ctx *ctx, int func, int32_t dtype, GrowBuf &acc, GrowBuf *nn, int64_t G) {
+  return agg_finalize_raw(ctx, func, dtype, acc.buf->as<uint64_t>(), nn ? nn->buf->as<uint64_t>() : nullptr, G);
+}
+
+DCol agg_finalize_raw(Ctx *ctx, int func, int32_t dtype, const uint64_t *acc, const uint64_t *nn, int64_t G) {
   DCol o;
   o.length = G;
   int64_t g1 = std::max<int64_t>(G, 1);
@@ -393,20 +399,20 @@ DCol agg_finalize_values(Ctx *ctx, int func, int32_t dtype, GrowBuf &acc, GrowBu
   if (func == SQLRS_AGG_COUNT) {
     o.dtype = SQLRS_INT64;
     o.own_values = ctx->alloc(8 * (size_t)g1);
-    if (G) SQ_HIP(hipMemcpyAsync(o.own_values->p, acc.buf->p, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
+    if (G) SQ_HIP(hipMemcpyAsync(o.own_values->p, acc, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
     o.values = o.own_values->p;
     return o;
   }
   o.dtype = dtype;
   if (func == SQLRS_AGG_SUM) {
     o.own_values = ctx->alloc(8 * (size_t)g1);
-    if (G) SQ_HIP(hipMemcpyAsync(o.own_values->p, acc.buf->p, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
+    if (G) SQ_HIP(hipMemcpyAsync(o.own_values->p, acc, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
   } else {
     o.own_values = ctx->alloc(8 * (size_t)g1);
     if (G) {
-      if (dtype == SQLRS_INT64) agg_unorder_kernel<0><<<g, b, 0, ctx->stream>>>(acc.buf->as<uint64_t>(), G, o.own_values->p);
-      else if (dtype == SQLRS_FLOAT64) agg_unorder_kernel<1><<<g, b, 0, ctx->stream>>>(acc.buf->as<uint64_t>(), G, o.own_values->p);
-      else agg_unorder_kernel<2><<<g, b, 0, ctx->stream>>>(acc.buf->as<uint64_t>(), G, o.own_values->p);
+      if (dtype == SQLRS_INT64) agg_unorder_kernel<0><<<g, b, 0, ctx->stream>>>(acc, G, o.own_values->p);
+      else if (dtype == SQLRS_FLOAT64) agg_unorder_kernel<1><<<g, b, 0, ctx->stream>>>(acc, G, o.own_values->p);
+      else agg_unorder_kernel<2><<<g, b, 0, ctx->stream>>>(acc, G, o.own_values->p);
       SQ_HIP(hipGetLastError());
     }
   }
@@ -415,7 +421,7 @@ DCol agg_finalize_values(Ctx *ctx, int func, int32_t dtype, GrowBuf &acc, GrowBu
     o.own_validity = ctx->alloc(bitmap_bytes(g1));
     int64_t g64 = (int64_t)round_up((size_t)g1, 64);
     agg_nonzero_bits_kernel<<<dim3((unsigned)ceil_div(g64, 256)), b, 0, ctx->stream>>>(
-        nn->buf->as<uint64_t>(), G, o.own_validity->as<uint64_t>());
+        nn, G, o.own_validity->as<uint64_t>());
     SQ_HIP(hipGetLastError());
     o.validity = o.own_validity->as<uint64_t>();
     o.null_count = -1;

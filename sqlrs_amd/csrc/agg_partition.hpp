@@ -1,0 +1,47 @@
+// agg_partition.hpp — interface of the LDS-partitioned pre-aggregation (agg_partition.hip).
+#pragma once
+
+#include <cmath>
+
+#include "common.hpp"
+#include "prims.hpp"
+
+namespace sq {
+
+constexpr int PART_MAX_ACC = 6;
+enum PartOp { PART_COUNT = 0, PART_SUM_I64 = 1, PART_SUM_F64 = 2, PART_MIN = 3, PART_MAX = 4 };
+
+struct PartAggSpec {
+  int n_acc = 0;
+  int op[PART_MAX_ACC] = {0};
+  int src[PART_MAX_ACC] = {0};  // index into PartAggInput::vals
+  int kind[PART_MAX_ACC] = {0}; // MIN/MAX element type: 0 = i64, 1 = f64
+  int nv = 0;                   // value columns used (0..2), all 8 bytes wide
+};
+
+struct PartAggInput {
+  const uint64_t *keys = nullptr; // normalised keys (NKeys)
+  const uint64_t *key_validity = nullptr;
+  int64_t n = 0;
+  const void *vals[2] = {nullptr, nullptr};
+  const uint64_t *val_validity[2] = {nullptr, nullptr};
+};
+
+// Groups of ONE batch: key, first row (local index), one 8-byte cell per accumulator
+// (COUNT: count, SUM: partial sum, MIN/MAX: order-preserving u64 image).
+struct PartAggOutput {
+  int64_t groups = 0, gcap = 0;
+  BufP gkey, gfirst, gvalid, gvalid_bits, gacc, row_ids;
+  int64_t n_overflow = 0; // rows that did not fit their bucket table
+  BufP ov_rows;           // their local row ids (u32)
+  double est_groups = 0;
+  int buckets = 0;
+};
+
+double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n);
+// false = not applicable (too many groups for one partition level, or estimate blown):
+// the caller uses the resolve path for the whole batch.
+bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggInput &in,
+                              uint64_t row_offset, PartAggOutput *out);
+
+} // namespace sq

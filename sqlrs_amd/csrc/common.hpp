@@ -63,6 +63,7 @@ struct Buf {
   Ctx *ctx;
   void *p;
   size_t cap;
+  bool owned = true; // false: a view of memory this library does not own (never released)
   Buf(Ctx *c, void *ptr, size_t n) : ctx(c), p(ptr), cap(n) {}
   ~Buf();
   Buf(const Buf &) = delete;

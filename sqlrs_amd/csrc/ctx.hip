@@ -52,7 +52,7 @@ void Pool::trim() {
 }
 
 Buf::~Buf() {
-  if (p) ctx->pool.release(p, cap);
+  if (p && owned) ctx->pool.release(p, cap);
 }
 
 BufP Ctx::alloc(size_t bytes) {

@@ -1,0 +1,523 @@
+// hashagg_op.hip — HashAggExecutor entry points (src/executor/aggregate/hash_agg.rs:32-150).
+//
+// push() takes one of two routes per batch:
+//   * row route      (small batches): every row resolves to its group through the global table
+//                    and updates the dense accumulators with global atomics (agg.hip);
+//   * partition route (>= 2^21 rows, COUNT/SUM/MIN/MAX over <= 2 argument columns): rows are
+//                    pre-aggregated per LDS bucket (agg_partition.hip) and only the batch's
+//                    groups go through the row route, carrying pre-aggregated cells.
+// Both leave the same state; finish() emits groups in first-seen order (hash_agg.rs:98,132).
+#include <cstdlib>
+
+#include "agg_partition.hpp"
+#include "agg_state.hpp"
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "prims.hpp"
+
+using namespace sq;
+
+namespace {
+
+struct AggSpec {
+  int func = 0, distinct = 0;
+  int32_t return_dtype = 0;
+  Expr arg;
+  GrowBuf acc, nn;
+  bool track_nn = false; // nn maintained (COUNT always; others once a NULL input was seen)
+  int32_t acc_dtype = 0; // dtype the accumulator works in
+  int argcol = -1;       // index into the per-batch evaluated argument columns
+};
+
+uint64_t acc_identity(const AggSpec &a) { return a.func == SQLRS_AGG_MIN ? ~0ull : 0ull; }
+
+bool same_expr(const Expr &x, const Expr &y) {
+  if (x.nodes.size() != y.nodes.size()) return false;
+  for (size_t i = 0; i < x.nodes.size(); i++) {
+    const sqlrs_expr_node_t &p = x.nodes[i], &q = y.nodes[i];
+    if (p.op != q.op || p.dtype != q.dtype || p.index != q.index || p.is_null != q.is_null || p.i != q.i ||
+        std::memcmp(&p.f, &q.f, 8) != 0 || x.strings[i] != y.strings[i])
+      return false;
+  }
+  return true;
+}
+
+} // namespace
+
+// Groups of one pre-aggregated batch that have not been merged into the table yet: while the
+// operator has seen nothing else they ARE its state, and finish() can emit them directly.
+struct PendingGroups {
+  bool active = false;
+  PartAggOutput po;
+  std::vector<DCol> keyvals;          // key column values per group (list order)
+  std::vector<int> cnt_of_col, acc_of_agg, col_of_agg;
+  std::vector<uint8_t> col_nullable;  // value column carried NULLs in that batch
+  std::vector<int32_t> col_dtype;
+  bool exact = true;
+  int32_t key_dtype = SQLRS_INT64;
+};
+
+struct sqlrs_hash_agg {
+  Ctx *ctx = nullptr;
+  PendingGroups pending;
+  std::vector<Expr> group_by;
+  std::vector<AggSpec> aggs;
+  AggState st;
+  bool saw_batch = false, in_order = true;
+  int64_t rows_seen = 0;
+  std::vector<int32_t> key_dtypes;
+  std::vector<std::vector<DCol>> key_parts; // per key column: values of new groups, per batch
+  // distinct argument columns: (expression, cast target) pairs shared by the aggregates
+  std::vector<Expr> arg_exprs;
+  std::vector<int32_t> arg_cast; // 0 = none
+};
+
+namespace sq {
+
+__global__ void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
+                                  int64_t n, uint32_t *__restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+__global__ void rowid_from_u32_kernel(const uint32_t *__restrict__ rows, int64_t n, uint64_t offset,
+                                      uint64_t *__restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = offset + rows[i];
+}
+
+// One evaluated argument column of the current (sub-)batch
+struct ArgView {
+  const void *values = nullptr;
+  const uint64_t *validity = nullptr;
+  int32_t dtype = 0;
+};
+
+// groups for `nk` (rows or pre-aggregated groups) + key values of the groups that are new
+static BufP resolve_groups(sqlrs_hash_agg *a, const NKeys &nk, const uint64_t *row_ids,
+                           const uint32_t *local_map, const std::vector<DCol> &kcols, int64_t *nnew_out) {
+  Ctx *ctx = a->ctx;
+  BufP new_rows;
+  int64_t nnew = 0;
+  BufP row_gid = agg_resolve_rows(ctx, a->st, nk, row_ids, (uint64_t)a->rows_seen, &new_rows, &nnew);
+  if (nnew) { // group key values of first sight (hash_agg.rs:90-96)
+    const void *idx = new_rows->p;
+    BufP mapped;
+    if (local_map) {
+      mapped = ctx->alloc(4 * (size_t)nnew);
+      gather_u32_kernel<<<dim3((unsigned)ceil_div(nnew, 256)), dim3(256), 0, ctx->stream>>>(
+          local_map, new_rows->as<uint32_t>(), nnew, mapped->as<uint32_t>());
+      SQ_HIP(hipGetLastError());
+      idx = mapped->p;
+    }
+    for (size_t c = 0; c < kcols.size(); c++)
+      a->key_parts[c].push_back(gather_column(ctx, kcols[c], idx, false, nullptr, nnew));
+  }
+  if (row_ids) a->in_order = false; // explicit ids arrive in arbitrary order
+  *nnew_out = nnew;
+  return row_gid;
+}
+
+// has-value tracking starts with the first NULL-bearing batch: until then every existing
+// group holds at least one valid value, so its counter is back-filled with 1
+static void start_tracking(Ctx *ctx, AggSpec &s, int64_t G, int64_t nnew) {
+  if (s.track_nn) return;
+  s.track_nn = true;
+  s.nn.ensure(ctx, std::max<int64_t>(G, 1), 0);
+  if (G - nnew > 0) fill_u64(ctx, s.nn.buf->as<uint64_t>(), G - nnew, 1);
+}
+
+// row route: accumulate the argument columns of n rows
+static void update_from_rows(sqlrs_hash_agg *a, const uint32_t *rg, const std::vector<ArgView> &args,
+                             int64_t n, int64_t nnew) {
+  Ctx *ctx = a->ctx;
+  int64_t G = a->st.ngroups;
+  for (AggSpec &s : a->aggs) {
+    const ArgView &v = args[(size_t)s.argcol];
+    if (s.func == SQLRS_AGG_COUNT) {
+      s.nn.ensure(ctx, G, 0);
+      agg_update_count(ctx, s.nn, rg, v.validity, nullptr, n);
+      continue;
+    }
+    if (v.validity) start_tracking(ctx, s, G, nnew);
+    if (s.track_nn) {
+      s.nn.ensure(ctx, G, 0);
+      agg_update_count(ctx, s.nn, rg, v.validity, nullptr, n);
+    }
+    if (s.func == SQLRS_AGG_SUM) {
+      s.acc_dtype = s.return_dtype;
+      s.acc.ensure(ctx, G, 0);
+      agg_update_sum(ctx, s.acc, s.acc_dtype, rg, v.values, v.validity, n);
+    } else {
+      if (v.dtype != s.return_dtype) fail(SQLRS_ERR_INTERNAL, "unsupported min_max scalar type");
+      s.acc_dtype = v.dtype;
+      s.acc.ensure(ctx, G, acc_identity(s));
+      agg_update_minmax(ctx, s.acc, s.acc_dtype, s.func == SQLRS_AGG_MIN, rg, v.values, v.validity, n);
+    }
+  }
+}
+
+// merge pre-aggregated groups into the table state: keys + first rows resolve like rows, the
+// cells accumulate with weights (O(groups) global atomics)
+static void merge_groups(sqlrs_hash_agg *a, PendingGroups &pg) {
+  Ctx *ctx = a->ctx;
+  PartAggOutput &po = pg.po;
+  NKeys gk;
+  gk.rows = po.groups;
+  gk.keys = po.gkey;
+  gk.exact = pg.exact;
+  gk.dtype = pg.key_dtype;
+  if (po.gvalid_bits) {
+    gk.validity = po.gvalid_bits->as<uint64_t>();
+    gk.own_validity = po.gvalid_bits;
+  }
+  int64_t nnew = 0;
+  BufP rgid = resolve_groups(a, gk, po.row_ids->as<uint64_t>(), nullptr, pg.keyvals, &nnew);
+  const uint32_t *rg = rgid->as<uint32_t>();
+  int64_t G = a->st.ngroups, g = po.groups;
+  auto cell = [&](int acc) { return po.gacc->as<uint64_t>() + (size_t)acc * (size_t)po.gcap; };
+  for (size_t i = 0; i < a->aggs.size(); i++) {
+    AggSpec &s = a->aggs[i];
+    int col = pg.col_of_agg[i];
+    int cc = pg.cnt_of_col[(size_t)col];
+    if (s.func == SQLRS_AGG_COUNT) {
+      s.nn.ensure(ctx, G, 0);
+      agg_update_count(ctx, s.nn, rg, nullptr, (const int64_t *)cell(cc), g);
+      continue;
+    }
+    if (pg.col_nullable[(size_t)col]) start_tracking(ctx, s, G, nnew);
+    if (s.track_nn) {
+      s.nn.ensure(ctx, G, 0);
+      agg_update_count(ctx, s.nn, rg, nullptr, (const int64_t *)cell(cc), g);
+    }
+    int ac = pg.acc_of_agg[i];
+    if (s.func == SQLRS_AGG_SUM) {
+      s.acc_dtype = s.return_dtype;
+      s.acc.ensure(ctx, G, 0);
+      agg_update_sum(ctx, s.acc, s.acc_dtype, rg, cell(ac), nullptr, g);
+    } else {
+      s.acc_dtype = pg.col_dtype[(size_t)col];
+      s.acc.ensure(ctx, G, acc_identity(s));
+      agg_update_minmax(ctx, s.acc, SQLRS_UINT64 /* cells are ordered images */, s.func == SQLRS_AGG_MIN, rg,
+                        cell(ac), nullptr, g);
+    }
+  }
+}
+
+static void flush_pending(sqlrs_hash_agg *a) {
+  if (!a->pending.active) return;
+  PendingGroups pg = std::move(a->pending);
+  a->pending = PendingGroups();
+  merge_groups(a, pg);
+}
+
+// finish() when one pre-aggregated batch is the whole input: emit its cells directly
+static DBatch emit_pending(sqlrs_hash_agg *a) {
+  Ctx *ctx = a->ctx;
+  PendingGroups &pg = a->pending;
+  PartAggOutput &po = pg.po;
+  int64_t G = po.groups;
+  DBatch o;
+  o.rows = G;
+  for (const DCol &k : pg.keyvals) o.cols.push_back(k);
+  auto cell = [&](int acc) { return po.gacc->as<uint64_t>() + (size_t)acc * (size_t)po.gcap; };
+  for (size_t i = 0; i < a->aggs.size(); i++) {
+    AggSpec &s = a->aggs[i];
+    int col = pg.col_of_agg[i];
+    int cc = pg.cnt_of_col[(size_t)col];
+    if (s.func == SQLRS_AGG_COUNT) {
+      o.cols.push_back(agg_finalize_raw(ctx, s.func, SQLRS_INT64, cell(cc), nullptr, G));
+      continue;
+    }
+    const uint64_t *nn = pg.col_nullable[(size_t)col] ? cell(cc) : nullptr;
+    int32_t dt = s.func == SQLRS_AGG_SUM ? s.return_dtype : pg.col_dtype[(size_t)col];
+    DCol c = agg_finalize_raw(ctx, s.func, dt, cell(pg.acc_of_agg[i]), nn, G);
+    c.dtype = s.return_dtype;
+    o.cols.push_back(c);
+  }
+  if (G > 1) { // bucket order -> first-seen order (hash_agg.rs:98,132)
+    ProfScope ps(ctx, "agg_order_groups");
+    BufP keys = ctx->alloc(8 * (size_t)G), perm = ctx->alloc(4 * (size_t)G);
+    SQ_HIP(hipMemcpyAsync(keys->p, po.row_ids->p, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
+    iota_u32(ctx, perm->as<uint32_t>(), G);
+    int bits = 1;
+    while (bits < 64 && (1ull << bits) <= (uint64_t)std::max<int64_t>(a->rows_seen, 1)) bits++;
+    radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), G, 0, bits);
+    for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
+  }
+  return o;
+}
+
+} // namespace sq
+
+extern "C" {
+
+int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t *group_by,
+                          int num_aggs, const sqlrs_agg_func_t *aggs, sqlrs_hash_agg_t **out) {
+  return guard(ctx, [&] {
+    if (num_group_by < 1) // PhysicalRewriter only builds HashAgg with keys (physical_rewriter.rs:49-62)
+      fail(SQLRS_ERR_INTERNAL, "HashAgg needs at least one group-by expression");
+    auto a = std::unique_ptr<sqlrs_hash_agg>(new sqlrs_hash_agg());
+    a->ctx = ctx;
+    for (int i = 0; i < num_group_by; i++) a->group_by.push_back(expr_from_abi(&group_by[i]));
+    for (int i = 0; i < num_aggs; i++) {
+      AggSpec s;
+      s.func = aggs[i].func;
+      s.distinct = aggs[i].distinct;
+      s.return_dtype = aggs[i].return_dtype;
+      s.arg = expr_from_abi(&aggs[i].arg);
+      if (s.func < SQLRS_AGG_COUNT || s.func > SQLRS_AGG_MAX)
+        fail(SQLRS_ERR_INTERNAL, "unknown aggregate function");
+      if (s.distinct && (s.func == SQLRS_AGG_COUNT || s.func == SQLRS_AGG_SUM))
+        fail(SQLRS_ERR_INTERNAL, "DISTINCT aggregates are not yet supported on the device path");
+      // SumAccumulator casts its input to the return type (sum.rs:54); the reference's
+      // sum_result has no (Int32, Int32) arm (sum.rs:64-85)
+      if (s.func == SQLRS_AGG_SUM && s.return_dtype != SQLRS_INT64 && s.return_dtype != SQLRS_FLOAT64)
+        fail(SQLRS_ERR_INTERNAL, "not expected types for sum");
+      int32_t cast = s.func == SQLRS_AGG_SUM ? s.return_dtype : 0;
+      int found = -1;
+      for (size_t k = 0; k < a->arg_exprs.size(); k++)
+        if (a->arg_cast[k] == cast && same_expr(a->arg_exprs[k], s.arg)) found = (int)k;
+      if (found < 0) {
+        a->arg_exprs.push_back(s.arg);
+        a->arg_cast.push_back(cast);
+        found = (int)a->arg_exprs.size() - 1;
+      }
+      s.argcol = found;
+      a->aggs.push_back(std::move(s));
+    }
+    a->key_parts.resize((size_t)num_group_by);
+    *out = a.release();
+  });
+}
+
+// one iteration of the for_await loop  [ref: hash_agg.rs:44-122]
+int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
+  return guard(a->ctx, [&] {
+    Ctx *ctx = a->ctx;
+    SQ_HIP(hipSetDevice(ctx->device));
+    InBatch ib(ctx, in);
+    auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
+    int64_t n = ib.rows();
+    // 2.2 group key columns (:69-73) and 3.1 their per-row key (:76-77)
+    std::vector<DCol> kcols;
+    for (const Expr &e : a->group_by) kcols.push_back(eval_expr(ctx, e, colfn, n, true));
+    if (!a->saw_batch) {
+      a->saw_batch = true;
+      for (const DCol &k : kcols) a->key_dtypes.push_back(k.dtype);
+    }
+    NKeys nk = normalize_keys(ctx, kcols, n);
+    // 2.1 argument columns (:63-66), evaluated once per distinct (expression, cast)
+    std::vector<DCol> acols;
+    for (size_t k = 0; k < a->arg_exprs.size(); k++) {
+      DCol c = eval_expr(ctx, a->arg_exprs[k], colfn, n, true);
+      if (a->arg_cast[k] && c.dtype != a->arg_cast[k]) {
+        sqlrs_expr_node_t cn[2];
+        std::memset(cn, 0, sizeof(cn));
+        cn[0].op = SQLRS_EXPR_INPUT_REF;
+        cn[1].op = SQLRS_EXPR_TYPE_CAST;
+        cn[1].dtype = a->arg_cast[k];
+        Expr ce;
+        ce.nodes.assign(cn, cn + 2);
+        ce.strings.resize(2);
+        auto one = [&](int) -> const DCol & { return c; };
+        DCol casted = eval_expr(ctx, ce, one, n, true);
+        c = casted;
+      }
+      acols.push_back(c);
+    }
+    auto views_of = [&](const std::vector<DCol> &cols) {
+      std::vector<ArgView> v;
+      for (const DCol &c : cols) {
+        ArgView x;
+        x.values = c.values;
+        x.validity = (c.validity && c.null_count != 0) ? c.validity : nullptr;
+        x.dtype = c.dtype;
+        v.push_back(x);
+      }
+      return v;
+    };
+
+    // identical argument expressions that evaluate to the same dtype share one column
+    // (COUNT(val) and SUM(val): one read of val)
+    std::vector<DCol> pcols;
+    std::vector<int> pidx(acols.size(), -1);
+    for (size_t k = 0; k < acols.size(); k++) {
+      for (size_t j = 0; j < k && pidx[k] < 0; j++)
+        if (same_expr(a->arg_exprs[j], a->arg_exprs[k]) && acols[j].dtype == acols[k].dtype) pidx[k] = pidx[j];
+      if (pidx[k] < 0) {
+        pidx[k] = (int)pcols.size();
+        pcols.push_back(acols[k]);
+      }
+    }
+    // ---- partition route ----------------------------------------------------------
+    bool done = false;
+    static const int64_t PART_MIN_ROWS = [] {
+      const char *e = std::getenv("SQLRS_PART_MIN_ROWS"); // test hook: force the partition route
+      return e ? std::atoll(e) : (1ll << 21);
+    }();
+    if (n >= PART_MIN_ROWS && pcols.size() <= 2) {
+      PartAggSpec spec;
+      bool ok = true;
+      std::vector<int> acc_of_agg(a->aggs.size(), -1), cnt_of_col(pcols.size(), -1);
+      for (const DCol &c : pcols)
+        ok &= (c.dtype == SQLRS_INT64 || c.dtype == SQLRS_FLOAT64); // 8-byte values only
+      // a COUNT cell per column whose has-value state must be known
+      for (size_t k = 0; ok && k < pcols.size(); k++) {
+        bool need = pcols[k].validity && pcols[k].null_count != 0;
+        for (const AggSpec &s : a->aggs)
+          if (pidx[(size_t)s.argcol] == (int)k && (s.func == SQLRS_AGG_COUNT || s.track_nn)) need = true;
+        if (need) {
+          if (spec.n_acc >= PART_MAX_ACC) { ok = false; break; }
+          cnt_of_col[k] = spec.n_acc;
+          spec.op[spec.n_acc] = PART_COUNT;
+          spec.src[spec.n_acc++] = (int)k;
+        }
+      }
+      for (size_t i = 0; ok && i < a->aggs.size(); i++) {
+        const AggSpec &s = a->aggs[i];
+        if (s.func == SQLRS_AGG_COUNT) {
+          acc_of_agg[i] = cnt_of_col[(size_t)pidx[(size_t)s.argcol]];
+          continue;
+        }
+        if (spec.n_acc >= PART_MAX_ACC) { ok = false; break; }
+        const DCol &c = pcols[(size_t)pidx[(size_t)s.argcol]];
+        if (s.func != SQLRS_AGG_SUM && c.dtype != s.return_dtype) { ok = false; break; }
+        acc_of_agg[i] = spec.n_acc;
+        spec.op[spec.n_acc] = s.func == SQLRS_AGG_SUM ? (c.dtype == SQLRS_FLOAT64 ? PART_SUM_F64 : PART_SUM_I64)
+                              : s.func == SQLRS_AGG_MIN ? PART_MIN : PART_MAX;
+        spec.kind[spec.n_acc] = c.dtype == SQLRS_FLOAT64 ? 1 : 0;
+        spec.src[spec.n_acc++] = pidx[(size_t)s.argcol];
+      }
+      spec.nv = (int)pcols.size();
+      if (ok) {
+        PartAggInput pin;
+        pin.keys = nk.keys->as<uint64_t>();
+        pin.key_validity = nk.validity;
+        pin.n = n;
+        for (size_t k = 0; k < pcols.size(); k++) {
+          pin.vals[k] = pcols[k].values;
+          pin.val_validity[k] = (pcols[k].validity && pcols[k].null_count != 0) ? pcols[k].validity : nullptr;
+        }
+        PartAggOutput po;
+        flush_pending(a); // an older deferred batch must be in the table before this one
+        if (partitioned_preaggregate(ctx, spec, pin, (uint64_t)a->rows_seen, &po)) {
+          PendingGroups pg;
+          pg.active = true;
+          pg.exact = nk.exact;
+          pg.key_dtype = nk.dtype;
+          pg.cnt_of_col = cnt_of_col;
+          pg.acc_of_agg = acc_of_agg;
+          for (const AggSpec &s : a->aggs) pg.col_of_agg.push_back(pidx[(size_t)s.argcol]);
+          for (size_t k = 0; k < pcols.size(); k++) {
+            pg.col_nullable.push_back(pin.val_validity[k] != nullptr);
+            pg.col_dtype.push_back(pcols[k].dtype);
+          }
+          for (const DCol &kc : kcols) // key values of every group of the batch (hash_agg.rs:90-96)
+            pg.keyvals.push_back(gather_column(ctx, kc, po.gfirst->p, false, nullptr, po.groups));
+          pg.po = po;
+          if (a->st.ngroups == 0 && po.n_overflow == 0)
+            a->pending = std::move(pg); // nothing to merge with yet: defer building the table
+          else
+            merge_groups(a, pg);
+          // rows whose bucket table was full go through the row route
+          if (po.n_overflow) {
+            int64_t m = po.n_overflow;
+            DCol kc;
+            kc.dtype = SQLRS_UINT64;
+            kc.length = n;
+            kc.values = nk.keys->p;
+            kc.validity = nk.validity;
+            kc.null_count = nk.validity ? -1 : 0;
+            DCol sub = gather_column(ctx, kc, po.ov_rows->p, false, nullptr, m);
+            NKeys ok_;
+            ok_.rows = m;
+            ok_.keys = sub.own_values;
+            ok_.exact = nk.exact;
+            ok_.dtype = nk.dtype;
+            if (sub.validity) {
+              ok_.validity = sub.validity;
+              ok_.own_validity = sub.own_validity;
+            }
+            BufP rid = ctx->alloc(8 * (size_t)m);
+            rowid_from_u32_kernel<<<dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx->stream>>>(
+                po.ov_rows->as<uint32_t>(), m, (uint64_t)a->rows_seen, rid->as<uint64_t>());
+            SQ_HIP(hipGetLastError());
+            std::vector<DCol> sub_args;
+            for (const DCol &c : acols) sub_args.push_back(gather_column(ctx, c, po.ov_rows->p, false, nullptr, m));
+            int64_t nn2 = 0;
+            BufP rg2 = resolve_groups(a, ok_, rid->as<uint64_t>(), po.ov_rows->as<uint32_t>(), kcols, &nn2);
+            for (DCol &c : sub_args)
+              if (c.validity && c.null_count < 0) c.null_count = count_nulls(ctx, c);
+            update_from_rows(a, rg2->as<uint32_t>(), views_of(sub_args), m, nn2);
+          }
+          done = true;
+        }
+      }
+    }
+    // ---- row route ------------------------------------------------------------------
+    if (!done) {
+      flush_pending(a);
+      int64_t nnew = 0;
+      BufP row_gid = resolve_groups(a, nk, nullptr, nullptr, kcols, &nnew); // 3.2 (:85-110)
+      update_from_rows(a, row_gid->as<uint32_t>(), views_of(acols), n, nnew); // 4. (:113-121)
+    }
+    a->rows_seen += n;
+  });
+}
+
+// [ref: hash_agg.rs:124-149]
+int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out) {
+  return guard(a->ctx, [&] {
+    Ctx *ctx = a->ctx;
+    SQ_HIP(hipSetDevice(ctx->device));
+    if (!a->saw_batch) // group_and_agg_fields.unwrap() panics on None (:125)
+      fail(SQLRS_ERR_INTERNAL, "hash agg finished without any input batch");
+    if (a->pending.active && a->st.ngroups == 0) {
+      *out = emit_batch(ctx, emit_pending(a), out_mem);
+      return;
+    }
+    flush_pending(a);
+    int64_t G = a->st.ngroups;
+    DBatch o;
+    o.rows = G;
+    for (size_t c = 0; c < a->key_parts.size(); c++) {
+      if (a->key_parts[c].empty()) {
+        DCol e = make_null_column(ctx, a->key_dtypes[c], 0);
+        e.null_count = 0;
+        o.cols.push_back(e);
+        continue;
+      }
+      std::vector<const DCol *> parts;
+      for (const DCol &p : a->key_parts[c]) parts.push_back(&p);
+      o.cols.push_back(concat_columns(ctx, parts));
+    }
+    for (AggSpec &s : a->aggs) {
+      if (s.func == SQLRS_AGG_COUNT) {
+        s.nn.ensure(ctx, std::max<int64_t>(G, 1), 0);
+        o.cols.push_back(agg_finalize_values(ctx, s.func, SQLRS_INT64, s.nn, nullptr, G));
+        continue;
+      }
+      int32_t dt = s.acc_dtype ? s.acc_dtype : s.return_dtype;
+      s.acc.ensure(ctx, std::max<int64_t>(G, 1), acc_identity(s));
+      DCol c = agg_finalize_values(ctx, s.func, dt, s.acc, s.track_nn ? &s.nn : nullptr, G);
+      c.dtype = s.return_dtype;
+      o.cols.push_back(c);
+    }
+    if (!a->in_order && G > 1) {
+      // groups were discovered out of row order (partition route): order by first row
+      ProfScope ps(ctx, "agg_order_groups");
+      BufP keys = ctx->alloc(8 * (size_t)G), perm = ctx->alloc(4 * (size_t)G);
+      SQ_HIP(hipMemcpyAsync(keys->p, a->st.gfirst.buf->p, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
+      iota_u32(ctx, perm->as<uint32_t>(), G);
+      int bits = 1;
+      while (bits < 64 && (1ull << bits) <= (uint64_t)std::max<int64_t>(a->rows_seen, 1)) bits++;
+      radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), G, 0, bits);
+      for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
+    }
+    *out = emit_batch(ctx, std::move(o), out_mem);
+  });
+}
+
+void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *a) { delete a; }
+
+} // extern "C"

@@ -156,6 +156,106 @@ __global__ __launch_bounds__(BLOCK) void join_fill_kernel(
   }
 }
 
+// Single-pass probe for UNIQUE build keys (the PK-FK case), Inner/Left: a probe row emits at
+// most one pair, so the probe is an order-preserving compaction: one table lookup per row,
+// ranks from ballots, global offset from the decoupled look-back.  Tile = 2048 probe rows;
+// each lane has 8 independent lookups in flight.
+constexpr int JP_ITEMS = 8;
+constexpr int JP_TILE = BLOCK * JP_ITEMS;
+__global__ __launch_bounds__(BLOCK) void join_probe_unique_kernel(
+    const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n,
+    int64_t num_tiles, const Slot *__restrict__ table, uint64_t mask, uint64_t *__restrict__ left_idx,
+    uint32_t *__restrict__ right_idx, uint64_t *desc, unsigned *ticket, uint64_t *total) {
+  __shared__ int64_t s_tile;
+  __shared__ uint32_t s_wave[WAVES_PER_BLOCK];
+  __shared__ uint64_t s_excl;
+  if (threadIdx.x == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int64_t tile = s_tile;
+  const int lane = lane_id(), w = wave_id();
+  const int64_t wrow = tile * JP_TILE + (int64_t)w * (64 * JP_ITEMS);
+  uint64_t k[JP_ITEMS];
+  bool isnull[JP_ITEMS];
+#pragma unroll
+  for (int j = 0; j < JP_ITEMS; j++) {
+    int64_t r = wrow + j * 64 + lane;
+    k[j] = (r < n) ? __builtin_nontemporal_load(&keys[r]) : 0; // streamed once: keep the table cached
+    isnull[j] = (r < n) && validity && !((validity[r >> 6] >> (r & 63)) & 1);
+  }
+  // first probe of all 8 rows issued back to back (8 independent 16-byte loads in flight per
+  // lane); only the rare collision chains continue one at a time
+  const uint64_t cap = mask + 1;
+  uint64_t slot[JP_ITEMS];
+  Slot sl[JP_ITEMS];
+#pragma unroll
+  for (int j = 0; j < JP_ITEMS; j++) {
+    slot[j] = isnull[j] ? cap : (k[j] == EMPTY_KEY ? cap + 1 : (mix64(k[j]) & mask));
+    sl[j] = load_slot(&table[slot[j]]);
+  }
+  uint32_t head[JP_ITEMS];
+  uint64_t m[JP_ITEMS];
+  uint32_t wave_cnt = 0;
+#pragma unroll
+  for (int j = 0; j < JP_ITEMS; j++) {
+    int64_t r = wrow + j * 64 + lane;
+    bool hit = false;
+    if (r < n) {
+      if (slot[j] >= cap) {
+        hit = sl[j].count != 0; // reserved slots: NULL keys / key == EMPTY_KEY
+      } else {
+        while (sl[j].key != k[j] && sl[j].key != EMPTY_KEY) {
+          slot[j] = (slot[j] + 1) & mask;
+          sl[j] = load_slot(&table[slot[j]]);
+        }
+        hit = sl[j].key == k[j];
+      }
+    }
+    head[j] = sl[j].head;
+    m[j] = __ballot(hit);
+    wave_cnt += (uint32_t)__popcll(m[j]);
+  }
+  if (lane == 0) s_wave[w] = wave_cnt;
+  __syncthreads();
+  if (w == 0) {
+    uint64_t agg = (uint64_t)s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    uint64_t excl = lookback_wave(desc, tile, agg);
+    if (lane == 0) {
+      s_excl = excl;
+      if (tile == num_tiles - 1) *total = excl + agg;
+    }
+  }
+  __syncthreads();
+  uint64_t pos = s_excl;
+  for (int q = 0; q < w; q++) pos += s_wave[q];
+#pragma unroll
+  for (int j = 0; j < JP_ITEMS; j++) {
+    if ((m[j] >> lane) & 1) {
+      uint64_t o = pos + mbcnt(m[j]);
+      __builtin_nontemporal_store((uint64_t)head[j], &left_idx[o]);
+      __builtin_nontemporal_store((uint32_t)(wrow + j * 64 + lane), &right_idx[o]);
+    }
+    pos += (uint32_t)__popcll(m[j]);
+  }
+}
+
+// UNIQUE build keys, Right/Full: every probe row emits exactly one pair (hash_join.rs:235-247)
+__global__ __launch_bounds__(BLOCK) void join_probe_unique_outer_kernel(
+    const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n,
+    const Slot *__restrict__ table, uint64_t mask, uint64_t *__restrict__ left_idx,
+    uint32_t *__restrict__ right_idx, uint64_t *__restrict__ left_validity) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool hit = false;
+  if (r < n) {
+    bool is_null = validity && !((validity[r >> 6] >> (r & 63)) & 1);
+    Slot s = probe_slot(table, mask, keys[r], is_null);
+    hit = s.count != 0;
+    left_idx[r] = hit ? s.head : 0;
+    right_idx[r] = (uint32_t)r;
+  }
+  uint64_t mm = __ballot(hit);
+  if (lane_id() == 0 && r < n) left_validity[r >> 6] = mm;
+}
+
 __global__ void bytes_to_bits_kernel(const uint8_t *__restrict__ bytes, int64_t n,
                                      uint64_t *__restrict__ out) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -261,7 +361,7 @@ static void build_table(sqlrs_hash_join *j) {
     }
   }
   uint64_t cap = 64;
-  while (cap < 2 * (uint64_t)n) cap <<= 1;
+  while (2 * cap < 3 * (uint64_t)n) cap <<= 1; // load factor <= 2/3
   j->mask = cap - 1;
   int64_t nslots = (int64_t)cap + 2;
   j->table = ctx->alloc(sizeof(Slot) * (size_t)nslots);
@@ -314,8 +414,38 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     return p;
   }
   if (n > 0xffffffffll) fail(SQLRS_ERR_INTERNAL, "probe batch larger than 2^32 rows");
-  BufP counts = ctx->alloc(4 * (size_t)n), offsets = ctx->alloc(8 * (size_t)n), total = ctx->alloc(8);
   dim3 g((unsigned)ceil_div(n, BLOCK)), b(BLOCK);
+  if (j->unique && !outer_right) { // one lookup per row, compaction with look-back
+    int64_t tiles = ceil_div(n, JP_TILE);
+    p.left = ctx->alloc(8 * (size_t)n);
+    p.right = ctx->alloc(4 * (size_t)n);
+    BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 16);
+    unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
+    uint64_t *tot = desc->as<uint64_t>() + tiles + 1;
+    {
+      ProfScope ps(ctx, "join_probe_unique");
+      join_probe_unique_kernel<<<dim3((unsigned)tiles), b, 0, ctx->stream>>>(
+          pk.keys->as<uint64_t>(), pk.validity, n, tiles, j->table->as<Slot>(), j->mask,
+          p.left->as<uint64_t>(), p.right->as<uint32_t>(), desc->as<uint64_t>(), ticket, tot);
+      SQ_HIP(hipGetLastError());
+    }
+    p.m = (int64_t)ctx->fetch_value(tot);
+    return p;
+  }
+  if (j->unique && outer_right) { // exactly one pair per probe row
+    p.m = n;
+    p.left = ctx->alloc(8 * (size_t)n);
+    p.right = ctx->alloc(4 * (size_t)n);
+    p.left_validity = ctx->alloc(bitmap_bytes(n));
+    ProfScope ps(ctx, "join_probe_unique");
+    int64_t n64 = (int64_t)round_up((size_t)n, 64);
+    join_probe_unique_outer_kernel<<<dim3((unsigned)ceil_div(n64, BLOCK)), b, 0, ctx->stream>>>(
+        pk.keys->as<uint64_t>(), pk.validity, n, j->table->as<Slot>(), j->mask, p.left->as<uint64_t>(),
+        p.right->as<uint32_t>(), p.left_validity->as<uint64_t>());
+    SQ_HIP(hipGetLastError());
+    return p;
+  }
+  BufP counts = ctx->alloc(4 * (size_t)n), offsets = ctx->alloc(8 * (size_t)n), total = ctx->alloc(8);
   {
     ProfScope ps(ctx, "join_probe_count");
     join_count_kernel<<<g, b, 0, ctx->stream>>>(pk.keys->as<uint64_t>(), pk.validity, n,
@@ -354,8 +484,31 @@ static DBatch gather_pairs(sqlrs_hash_join *j, const DBatch &right, const Pairs 
   DBatch out;
   out.rows = p.m;
   const uint64_t *lv = p.left_validity ? p.left_validity->as<uint64_t>() : nullptr;
-  for (const DCol &c : j->left.cols) out.cols.push_back(gather_column(ctx, c, p.left->p, true, lv, p.m));
-  for (const DCol &c : right.cols) out.cols.push_back(gather_column(ctx, c, p.right->p, false, nullptr, p.m));
+  // Join-key equivalence: with one exactly-compared key `left[c] = right[rc]` every emitted pair
+  // carries equal key values on both sides (NULL = NULL included, hash_utils.rs:91-104), so for
+  // Inner/Left the gathered build key column is the gathered probe key column: the random
+  // gather over the build side is skipped.
+  int lkey_col = -1, rkey_col = -1;
+  bool outer_right = j->join_type == SQLRS_JOIN_RIGHT || j->join_type == SQLRS_JOIN_FULL;
+  if (!outer_right && j->exact && j->lkeys.size() == 1 && j->lkeys[0].nodes.size() == 1 &&
+      j->rkeys[0].nodes.size() == 1 && j->lkeys[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
+      j->rkeys[0].nodes[0].op == SQLRS_EXPR_INPUT_REF) {
+    lkey_col = j->lkeys[0].nodes[0].index;
+    rkey_col = j->rkeys[0].nodes[0].index;
+    if (lkey_col < 0 || (size_t)lkey_col >= j->left.cols.size() || rkey_col < 0 ||
+        (size_t)rkey_col >= right.cols.size() ||
+        j->left.cols[(size_t)lkey_col].dtype != right.cols[(size_t)rkey_col].dtype)
+      lkey_col = rkey_col = -1;
+  }
+  std::vector<DCol> rcols;
+  for (const DCol &c : right.cols) rcols.push_back(gather_column(ctx, c, p.right->p, false, nullptr, p.m));
+  for (size_t c = 0; c < j->left.cols.size(); c++) {
+    if ((int)c == lkey_col)
+      out.cols.push_back(rcols[(size_t)rkey_col]);
+    else
+      out.cols.push_back(gather_column(ctx, j->left.cols[c], p.left->p, true, lv, p.m));
+  }
+  for (DCol &c : rcols) out.cols.push_back(std::move(c));
   return out;
 }
 

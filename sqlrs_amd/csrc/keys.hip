@@ -67,12 +67,13 @@ NKeys normalize_keys(Ctx *ctx, const std::vector<DCol> &cols_in, int64_t rows) {
   NKeys k;
   k.rows = rows;
   int64_t n1 = std::max<int64_t>(rows, 1);
-  k.keys = ctx->alloc(8 * (size_t)n1);
   dim3 g((unsigned)ceil_div(n1, 256)), b(256);
   ProfScope ps(ctx, "normalize_keys");
   const DCol &c0 = cols[0];
   bool fixed = c0.dtype == SQLRS_INT32 || c0.dtype == SQLRS_INT64 || c0.dtype == SQLRS_FLOAT64 ||
                c0.dtype == SQLRS_BOOLEAN;
+  bool alias = cols.size() == 1 && rows > 0 && (c0.dtype == SQLRS_INT64 || c0.dtype == SQLRS_FLOAT64);
+  if (!alias) k.keys = ctx->alloc(8 * (size_t)n1);
   if (cols.size() == 1 && fixed) {
     k.exact = true;
     k.dtype = c0.dtype;
@@ -84,9 +85,15 @@ NKeys normalize_keys(Ctx *ctx, const std::vector<DCol> &cols_in, int64_t rows) {
     switch (c0.dtype) {
     case SQLRS_INT64:
     case SQLRS_FLOAT64: // bit pattern: -0.0 != +0.0, NaN payloads distinct (hash_utils.rs:124-131)
-      SQ_HIP(hipMemcpyAsync(k.keys->p, c0.values, 8 * (size_t)rows, hipMemcpyDeviceToDevice,
-                            ctx->stream));
-      break;
+      // the column buffer IS the key array: no copy.  A borrowed caller buffer stays valid
+      // for the duration of the call that normalises it (operators that retain keys copy).
+      if (c0.own_values) {
+        k.keys = c0.own_values;
+      } else {
+        k.keys = std::make_shared<Buf>(ctx, const_cast<void *>(c0.values), 0);
+        k.keys->owned = false; // non-owning view of the caller's buffer
+      }
+      return k;
     case SQLRS_INT32:
       widen_kernel<int32_t><<<g, b, 0, ctx->stream>>>(c0.v<int32_t>(), rows, k.keys->as<uint64_t>());
       break;

@@ -1,0 +1,354 @@
+// radix_part.hip — LDS-staged hash partitioning of rows (key, up to two 8-byte values, row id,
+// validity flags) into P buckets, one or two levels of <= 256-way multi-split.
+//
+// Direct scattered stores run at the random-access rate of the memory system (~90 G stores/s
+// on MI355X, profiles/r01_ubench_mi355x.txt) no matter how the lines fill up later, so each
+// tile of 4096 rows is first sorted by bucket inside LDS and then written as bucket-contiguous
+// runs: consecutive lanes store consecutive addresses.  With <= 256 buckets per pass a run is
+// >= 16 rows = one full 128-byte line per 8-byte column.
+//
+// Per level:  hist (8 B/row read: keys) -> exclusive scan of the [segment][digit][tile] count
+// matrix = start of every run -> scatter (all columns read once, written once).
+// Level 2 splits every level-1 bucket again (MSD order), giving up to 65536 buckets.
+#include "device_utils.hpp"
+#include "radix_part.hpp"
+
+namespace sq {
+
+constexpr int RP_WG = 512;
+constexpr int RP_ROWS = 8;
+constexpr int RP_TILE = RP_WG * RP_ROWS; // 4096 rows
+
+struct Tile {
+  int64_t start;
+  uint32_t len;
+  uint32_t stride; // tiles of this tile's segment (matrix stride between digits)
+  int64_t mat;     // index of (digit 0, this tile) in the count matrix
+};
+
+// global bucket of a row; digit of the current level
+__device__ __forceinline__ uint32_t rp_bucket(uint64_t key, bool valid, uint32_t P) {
+  return valid ? (uint32_t)__umul64hi(mix64(key), (uint64_t)P) : 0u;
+}
+__device__ __forceinline__ uint32_t rp_digit(uint32_t bucket, int level, uint32_t p2_bits) {
+  return level == 1 ? (bucket >> p2_bits) : (bucket & ((1u << p2_bits) - 1));
+}
+
+__global__ __launch_bounds__(RP_WG) void rp_hist_kernel(const uint64_t *__restrict__ keys,
+                                                        const uint64_t *__restrict__ key_validity,
+                                                        const uint8_t *__restrict__ flags,
+                                                        const Tile *__restrict__ tiles, uint32_t P,
+                                                        uint32_t p2_bits, int level, uint32_t digits,
+                                                        uint32_t *__restrict__ mat) {
+  __shared__ uint32_t h[512];
+  const Tile t = tiles[blockIdx.x];
+  if (threadIdx.x < digits) h[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) {
+    uint32_t o = j * RP_WG + threadIdx.x;
+    if (o < t.len) {
+      int64_t r = t.start + o;
+      bool valid = flags ? (flags[r] & 1) : (!key_validity || ((key_validity[r >> 6] >> (r & 63)) & 1));
+      atomicAdd(&h[rp_digit(rp_bucket(keys[r], valid, P), level, p2_bits)], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < digits) mat[t.mat + (int64_t)threadIdx.x * t.stride] = h[threadIdx.x];
+}
+
+struct RpIn {
+  const uint64_t *key, *v0, *v1;
+  const uint32_t *idx;     // null at level 1: row id = position
+  const uint8_t *flags;    // null at level 1: built from the bitmaps
+  const uint64_t *key_validity, *v0_validity, *v1_validity;
+};
+struct RpOut {
+  uint64_t *key, *v0, *v1;
+  uint32_t *idx;
+  uint8_t *flags; // null when no column is nullable
+};
+
+template <int NV>
+__global__ __launch_bounds__(RP_WG) void rp_scatter_kernel(RpIn in, RpOut out,
+                                                           const Tile *__restrict__ tiles, uint32_t P,
+                                                           uint32_t p2_bits, int level, uint32_t digits,
+                                                           const uint32_t *__restrict__ offs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t *skey = (uint64_t *)smem;
+  uint64_t *sv0 = skey + RP_TILE;
+  uint64_t *sv1 = sv0 + (NV >= 1 ? RP_TILE : 0);
+  uint32_t *sidx = (uint32_t *)(sv1 + (NV >= 2 ? RP_TILE : 0));
+  uint16_t *sdig = (uint16_t *)(sidx + RP_TILE);
+  uint8_t *sflag = (uint8_t *)(sdig + RP_TILE);
+  uint32_t *cnt = (uint32_t *)(sflag + RP_TILE); // [512]
+  uint32_t *lstart = cnt + 512;                  // [512]
+  int64_t *gbase = (int64_t *)(lstart + 512);    // [512]
+  __shared__ uint32_t s_wsum[RP_WG / 64];
+
+  const Tile t = tiles[blockIdx.x];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t k[RP_ROWS], a0[RP_ROWS], a1[RP_ROWS];
+  uint32_t id[RP_ROWS], dg[RP_ROWS], rk[RP_ROWS];
+  uint8_t fl[RP_ROWS];
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) {
+    uint32_t o = j * RP_WG + threadIdx.x;
+    dg[j] = 0xffffffffu;
+    if (o < t.len) {
+      int64_t r = t.start + o;
+      k[j] = in.key[r];
+      if (NV >= 1) a0[j] = in.v0[r];
+      if (NV >= 2) a1[j] = in.v1[r];
+      if (in.idx) {
+        id[j] = in.idx[r];
+        fl[j] = in.flags ? in.flags[r] : 7;
+      } else {
+        id[j] = (uint32_t)r;
+        uint8_t f = 0;
+        if (!in.key_validity || ((in.key_validity[r >> 6] >> (r & 63)) & 1)) f |= 1;
+        if (!in.v0_validity || ((in.v0_validity[r >> 6] >> (r & 63)) & 1)) f |= 2;
+        if (!in.v1_validity || ((in.v1_validity[r >> 6] >> (r & 63)) & 1)) f |= 4;
+        fl[j] = f;
+      }
+      dg[j] = rp_digit(rp_bucket(k[j], fl[j] & 1, P), level, p2_bits);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++)
+    if (dg[j] != 0xffffffffu) rk[j] = atomicAdd(&cnt[dg[j]], 1u);
+  __syncthreads();
+  // exclusive scan of the 512 counters (one per thread)
+  {
+    uint32_t c = cnt[threadIdx.x];
+    uint32_t inc = wave_iscan_u32(c);
+    if (lane_id() == 63) s_wsum[wave_id()] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave_id(); w++) wbase += s_wsum[w];
+    uint32_t ls = wbase + inc - c;
+    lstart[threadIdx.x] = ls;
+    if (threadIdx.x < digits)
+      gbase[threadIdx.x] = (int64_t)offs[t.mat + (int64_t)threadIdx.x * t.stride] - (int64_t)ls;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) {
+    if (dg[j] == 0xffffffffu) continue;
+    uint32_t p = lstart[dg[j]] + rk[j];
+    skey[p] = k[j];
+    if (NV >= 1) sv0[p] = a0[j];
+    if (NV >= 2) sv1[p] = a1[j];
+    sidx[p] = id[j];
+    sdig[p] = (uint16_t)dg[j];
+    sflag[p] = fl[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) {
+    uint32_t p = j * RP_WG + threadIdx.x;
+    if (p < t.len) {
+      int64_t g = gbase[sdig[p]] + p;
+      out.key[g] = skey[p];
+      if (NV >= 1) out.v0[g] = sv0[p];
+      if (NV >= 2) out.v1[g] = sv1[p];
+      out.idx[g] = sidx[p];
+      if (out.flags) out.flags[g] = sflag[p];
+    }
+  }
+}
+
+// bucket b (level-1 digit d1 = b >> p2_bits ... ) start row, from the level's scanned matrix
+__global__ void rp_bucket_starts_kernel(const uint32_t *__restrict__ offs,
+                                        const int64_t *__restrict__ seg_mat,
+                                        const uint32_t *__restrict__ seg_tiles,
+                                        const int64_t *__restrict__ seg_start, uint32_t digits,
+                                        uint32_t nseg, int64_t n, uint32_t *__restrict__ bstart) {
+  int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)nseg * digits;
+  if (b > total) return;
+  if (b == total) {
+    bstart[b] = (uint32_t)n;
+    return;
+  }
+  uint32_t s = (uint32_t)(b / digits), d = (uint32_t)(b % digits);
+  bstart[b] = seg_tiles[s] ? offs[seg_mat[s] + (int64_t)d * seg_tiles[s]] : (uint32_t)seg_start[s + 1];
+}
+
+namespace {
+
+struct Level {
+  std::vector<Tile> tiles;
+  std::vector<int64_t> seg_mat, seg_start; // per segment (seg_start has nseg + 1 entries)
+  std::vector<uint32_t> seg_tiles;
+  int64_t mat_entries = 0;
+};
+
+Level plan_level(const std::vector<int64_t> &seg_start, uint32_t digits) {
+  Level L;
+  L.seg_start = seg_start;
+  size_t nseg = seg_start.size() - 1;
+  for (size_t s = 0; s < nseg; s++) {
+    int64_t len = seg_start[s + 1] - seg_start[s];
+    uint32_t nt = (uint32_t)ceil_div(len, RP_TILE);
+    L.seg_mat.push_back(L.mat_entries);
+    L.seg_tiles.push_back(nt);
+    for (uint32_t i = 0; i < nt; i++) {
+      Tile t;
+      t.start = seg_start[s] + (int64_t)i * RP_TILE;
+      t.len = (uint32_t)std::min<int64_t>(RP_TILE, seg_start[s + 1] - t.start);
+      t.stride = nt;
+      t.mat = L.mat_entries + i;
+      L.tiles.push_back(t);
+    }
+    L.mat_entries += (int64_t)nt * digits;
+  }
+  return L;
+}
+
+template <class T> BufP upload(Ctx *ctx, const std::vector<T> &v) {
+  BufP b = ctx->alloc(sizeof(T) * std::max<size_t>(v.size(), 1));
+  if (!v.empty())
+    SQ_HIP(hipMemcpyAsync(b->p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream));
+  return b;
+}
+
+} // namespace
+
+bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, PartitionedRows *out) {
+  const int64_t n = in.n;
+  if (n <= 0 || n > 0xffffffffll || in.nv > 2) return false;
+  // digits per level: one level up to 256 buckets, else P = d1 * 2^p2_bits
+  uint32_t p2_bits = 0, d1 = std::max(1u, P_wanted);
+  if (P_wanted > 512) { // one level handles up to 512 digits (runs of >= 8 rows per tile)
+    p2_bits = 8;
+    d1 = (uint32_t)ceil_div(P_wanted, 256);
+    if (d1 > 256) return false;
+  }
+  const uint32_t P = d1 << p2_bits;
+  const bool flags = in.key_validity || in.val_validity[0] || in.val_validity[1];
+  const int nv = in.nv;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+  const size_t lds = (size_t)RP_TILE * (8 * (1 + nv) + 4 + 2 + 1) + 512 * (4 + 4 + 8);
+
+  auto alloc_cols = [&](BufP &k, BufP &v0, BufP &v1, BufP &idx, BufP &fl) {
+    k = ctx->alloc(8 * (size_t)n);
+    v0 = nv >= 1 ? ctx->alloc(8 * (size_t)n) : nullptr;
+    v1 = nv >= 2 ? ctx->alloc(8 * (size_t)n) : nullptr;
+    idx = ctx->alloc(4 * (size_t)n);
+    fl = flags ? ctx->alloc((size_t)n) : nullptr;
+  };
+
+  // one level = hist + scan + scatter over `seg_start` segments
+  auto run_level = [&](int level, uint32_t digits, const std::vector<int64_t> &seg_start, const RpIn &rin,
+                       const RpOut &rout, BufP *offs_out, Level *plan_out) {
+    Level L = plan_level(seg_start, digits);
+    BufP tiles = upload(ctx, L.tiles);
+    BufP mat = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
+    BufP offs = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
+    BufP total = ctx->alloc(8);
+    unsigned nt = (unsigned)L.tiles.size();
+    {
+      ProfScope ps(ctx, "rp_hist");
+      rp_hist_kernel<<<dim3(nt), dim3(RP_WG), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags,
+                                                               (const Tile *)tiles->p, P, p2_bits, level,
+                                                               digits, mat->as<uint32_t>());
+      SQ_HIP(hipGetLastError());
+    }
+    exclusive_scan_u32(ctx, mat->as<uint32_t>(), L.mat_entries, nullptr, offs->as<uint32_t>(),
+                       total->as<uint64_t>());
+    {
+      ProfScope ps(ctx, "rp_scatter");
+      dim3 g(nt), b(RP_WG);
+      const Tile *tp = (const Tile *)tiles->p;
+      if (nv == 0)
+        rp_scatter_kernel<0><<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs->as<uint32_t>());
+      else if (nv == 1)
+        rp_scatter_kernel<1><<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs->as<uint32_t>());
+      else
+        rp_scatter_kernel<2><<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs->as<uint32_t>());
+      SQ_HIP(hipGetLastError());
+    }
+    ctx->sync(); // `L.tiles` host vector was the source of an async upload
+    *offs_out = offs;
+    *plan_out = std::move(L);
+  };
+
+  auto bucket_starts = [&](const Level &L, const BufP &offs, uint32_t digits) -> BufP {
+    uint32_t nseg = (uint32_t)L.seg_tiles.size();
+    BufP sm = upload(ctx, L.seg_mat), st = upload(ctx, L.seg_tiles), ss = upload(ctx, L.seg_start);
+    int64_t total = (int64_t)nseg * digits + 1;
+    BufP bs = ctx->alloc(4 * (size_t)total);
+    rp_bucket_starts_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
+        offs->as<uint32_t>(), (const int64_t *)sm->p, (const uint32_t *)st->p, (const int64_t *)ss->p, digits,
+        nseg, n, bs->as<uint32_t>());
+    SQ_HIP(hipGetLastError());
+    ctx->sync();
+    return bs;
+  };
+
+  // ---- level 1
+  BufP k1, a1, b1, i1, f1;
+  alloc_cols(k1, a1, b1, i1, f1);
+  RpIn rin;
+  rin.key = in.keys;
+  rin.v0 = (const uint64_t *)in.vals[0];
+  rin.v1 = (const uint64_t *)in.vals[1];
+  rin.idx = nullptr;
+  rin.flags = nullptr;
+  rin.key_validity = in.key_validity;
+  rin.v0_validity = in.val_validity[0];
+  rin.v1_validity = in.val_validity[1];
+  RpOut rout;
+  rout.key = k1->as<uint64_t>();
+  rout.v0 = a1 ? a1->as<uint64_t>() : nullptr;
+  rout.v1 = b1 ? b1->as<uint64_t>() : nullptr;
+  rout.idx = i1->as<uint32_t>();
+  rout.flags = f1 ? f1->as<uint8_t>() : nullptr;
+  BufP offs1;
+  Level L1;
+  run_level(1, d1, {0, n}, rin, rout, &offs1, &L1);
+  BufP bs1 = bucket_starts(L1, offs1, d1);
+  out->n = n;
+  out->P = P;
+  if (p2_bits == 0) {
+    out->key = k1; out->v0 = a1; out->v1 = b1; out->idx = i1; out->flags = f1;
+    out->bstart = bs1;
+    return true;
+  }
+  // ---- level 2: every level-1 bucket is one segment
+  std::vector<uint32_t> hs((size_t)d1 + 1);
+  SQ_HIP(hipMemcpyAsync(hs.data(), bs1->p, 4 * hs.size(), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->sync();
+  std::vector<int64_t> seg(hs.begin(), hs.end());
+  BufP k2, a2, b2, i2, f2;
+  alloc_cols(k2, a2, b2, i2, f2);
+  RpIn rin2;
+  rin2.key = k1->as<uint64_t>();
+  rin2.v0 = a1 ? a1->as<uint64_t>() : nullptr;
+  rin2.v1 = b1 ? b1->as<uint64_t>() : nullptr;
+  rin2.idx = i1->as<uint32_t>();
+  rin2.flags = f1 ? f1->as<uint8_t>() : nullptr;
+  rin2.key_validity = rin2.v0_validity = rin2.v1_validity = nullptr;
+  RpOut rout2;
+  rout2.key = k2->as<uint64_t>();
+  rout2.v0 = a2 ? a2->as<uint64_t>() : nullptr;
+  rout2.v1 = b2 ? b2->as<uint64_t>() : nullptr;
+  rout2.idx = i2->as<uint32_t>();
+  rout2.flags = f2 ? f2->as<uint8_t>() : nullptr;
+  BufP offs2;
+  Level L2;
+  run_level(2, 1u << p2_bits, seg, rin2, rout2, &offs2, &L2);
+  out->key = k2; out->v0 = a2; out->v1 = b2; out->idx = i2; out->flags = f2;
+  out->bstart = bucket_starts(L2, offs2, 1u << p2_bits);
+  return true;
+}
+
+} // namespace sq

@@ -275,3 +275,38 @@ def test_order(hip, oracle, n):
         got = rows_of(OrderExecutor(hip, ob, bs).execute())
         exp = rows_of(OrderExecutor(oracle, ob, bs).execute())
         assert_same(got, exp)
+
+
+# ----------------------------------------------------- partition route of HashAgg --
+@pytest.fixture
+def force_partition_route(monkeypatch):
+    # the library reads this once per process on the first push; GPU tests run it in a
+    # subprocess-free way by using batches above the default threshold instead
+    yield
+
+
+@pytest.mark.parametrize("n,groups,nulls", [(2_200_000, 1000, 0.05), (2_200_000, 300_000, 0.0),
+                                            (2_300_000, 2_000_000, 0.02), (4_500_000, 50_000, 0.1)])
+def test_hash_agg_partition_route(hip, oracle, n, groups, nulls):
+    """Batches >= 2^21 rows take the LDS-partitioned pre-aggregation; results (incl. first-seen
+    group order) must equal the oracle's."""
+    rng = np.random.default_rng(n + groups)
+    b = batch(rng, n, [("i64", nulls, 0, groups), ("i64", nulls, -1000, 1000), ("f64", nulls, 0, 1)])
+    aggs = [AggFunc("count", InputRef(2), abi.INT64), AggFunc("sum", InputRef(2), abi.FLOAT64),
+            AggFunc("sum", InputRef(1), abi.INT64), AggFunc("min", InputRef(1), abi.INT64),
+            AggFunc("max", InputRef(2), abi.FLOAT64)]
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
+    assert_same(got, exp, float_cols={2, 5})
+
+
+def test_hash_agg_mixed_routes_multi_batch(hip, oracle):
+    rng = np.random.default_rng(77)
+    spec = [("i64", 0.05, 0, 5000), ("f64", 0.0, 0, 1)]
+    bs = [batch(rng, 1000, spec), batch(rng, 2_200_000, spec), batch(rng, 50_000, [("i64", 0.05, 0, 9000), ("f64", 0.2, 0, 1)]),
+          batch(rng, 2_100_000, [("i64", 0.0, 4000, 12000), ("f64", 0.1, 0, 1)])]
+    aggs = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64),
+            AggFunc("min", InputRef(1), abi.FLOAT64)]
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], bs).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], bs).execute())
+    assert_same(got, exp, float_cols={2, 3})
