@@ -178,21 +178,13 @@ def main():
 
     def exchange(cols, dtypes):
         """hash-partition on column 0 and all-to-all every column over RCCL; returns tensors"""
+        from sqlrs_amd import distributed as D
         b = device_batch(abi, cols, dtypes)
         parts, offs = be.hash_partition(b, InputRef(0), world, abi.MEM_DEVICE)
         be.synchronize()
-        send_counts = torch.tensor([offs[p + 1] - offs[p] for p in range(world)], dtype=torch.int64, device=dev)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()
-        outs = []
-        for ci, t in enumerate(cols):
-            c = parts.column(ci)
-            src = torch.empty(0, dtype=t.dtype, device=dev) if c.length == 0 else \
-                _tensor_view(torch, c.values, c.length, t.dtype, dev)
-            dst = torch.empty(int(sum(rc)), dtype=t.dtype, device=dev)
-            dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc)
-            outs.append(dst)
+        views = [_tensor_view(torch, parts.column(ci).values, parts.column(ci).length, t.dtype, dev)
+                 for ci, t in enumerate(cols)]
+        outs = D.all_to_all_columns(dist, views, offs, world, torch)  # same code as the gloo CPU test
         torch.cuda.synchronize()
         parts.release()
         return outs

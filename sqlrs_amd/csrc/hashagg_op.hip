@@ -64,13 +64,32 @@ struct sqlrs_hash_agg {
   std::vector<AggSpec> aggs;
   AggState st;
   bool saw_batch = false, in_order = true;
+  bool strong_keys = false; // internal de-dup stage of a DISTINCT aggregate
   int64_t rows_seen = 0;
   std::vector<int32_t> key_dtypes;
   std::vector<std::vector<DCol>> key_parts; // per key column: values of new groups, per batch
   // distinct argument columns: (expression, cast target) pairs shared by the aggregates
   std::vector<Expr> arg_exprs;
   std::vector<int32_t> arg_cast; // 0 = none
+  // DISTINCT aggregates (count.rs:31-58, sum.rs:99-132): one de-duplicating sub-aggregation per
+  // aggregate, grouped by (group keys..., argument); re-aggregated per group at finish()
+  struct DistinctAgg {
+    int func = 0;
+    int32_t return_dtype = 0;
+    sqlrs_hash_agg *dedup = nullptr;
+  };
+  std::vector<DistinctAgg> distinct_aggs;
+  std::vector<std::pair<int, int>> out_order; // (0 = plain | 1 = distinct, index) per output aggregate
+  ~sqlrs_hash_agg() {
+    for (auto &d : distinct_aggs) delete d.dedup;
+  }
 };
+
+extern "C" int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in);
+extern "C" int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out);
+extern "C" int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t *group_by, int num_aggs,
+                                     const sqlrs_agg_func_t *aggs, sqlrs_hash_agg_t **out);
+extern "C" void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *a);
 
 namespace sq {
 
@@ -247,6 +266,90 @@ static DBatch emit_pending(sqlrs_hash_agg *a) {
   return o;
 }
 
+// DISTINCT aggregates: distinct (keys..., arg) rows -> COUNT(*) / SUM(arg) per key group.  Both
+// stages emit groups in first-seen order, so the column lines up with the main aggregation.
+// DistinctCountAccumulator keeps NULL as one of the distinct values (count.rs:44-52); a distinct
+// SUM skips it (sum.rs:64-85 via sum_result).
+static DCol distinct_column(sqlrs_hash_agg *a, sqlrs_hash_agg::DistinctAgg &d, int64_t G) {
+  Ctx *ctx = a->ctx;
+  sqlrs_batch_t *dd = nullptr, *res = nullptr;
+  int st = sqlrs_hash_agg_finish(d.dedup, SQLRS_MEM_DEVICE, &dd);
+  if (st != SQLRS_OK) fail(st, ctx->last_error);
+  const int nk = (int)a->group_by.size();
+  std::vector<sqlrs_expr_node_t> nodes((size_t)nk + 1);
+  std::vector<sqlrs_expr_t> gb((size_t)nk);
+  std::memset(nodes.data(), 0, sizeof(sqlrs_expr_node_t) * nodes.size());
+  for (int i = 0; i < nk; i++) {
+    nodes[(size_t)i].op = SQLRS_EXPR_INPUT_REF;
+    nodes[(size_t)i].index = i;
+    gb[(size_t)i].nodes = &nodes[(size_t)i];
+    gb[(size_t)i].num_nodes = 1;
+    gb[(size_t)i].reserved = 0;
+  }
+  sqlrs_agg_func_t af;
+  std::memset(&af, 0, sizeof(af));
+  if (d.func == SQLRS_AGG_COUNT) {
+    nodes[(size_t)nk].op = SQLRS_EXPR_CONSTANT; // COUNT of a never-NULL constant = number of distinct values
+    nodes[(size_t)nk].dtype = SQLRS_INT64;
+    nodes[(size_t)nk].i = 1;
+    af.func = SQLRS_AGG_COUNT;
+    af.return_dtype = SQLRS_INT64;
+  } else {
+    nodes[(size_t)nk].op = SQLRS_EXPR_INPUT_REF;
+    nodes[(size_t)nk].index = nk;
+    af.func = SQLRS_AGG_SUM;
+    af.return_dtype = d.return_dtype;
+  }
+  af.arg.nodes = &nodes[(size_t)nk];
+  af.arg.num_nodes = 1;
+  sqlrs_hash_agg_t *b = nullptr;
+  st = sqlrs_hash_agg_create((sqlrs_ctx_t *)ctx, nk, gb.data(), 1, &af, &b);
+  if (st == SQLRS_OK) st = sqlrs_hash_agg_push(b, dd);
+  if (st == SQLRS_OK) st = sqlrs_hash_agg_finish(b, SQLRS_MEM_DEVICE, &res);
+  std::string err = ctx->last_error;
+  if (b) sqlrs_hash_agg_destroy(b);
+  DCol out;
+  if (st == SQLRS_OK) {
+    if (res->num_rows != G) {
+      st = SQLRS_ERR_INTERNAL;
+      err = "distinct aggregate produced a different number of groups";
+    } else {
+      const sqlrs_column_t &c = res->columns[nk];
+      out.dtype = c.dtype;
+      out.length = G;
+      size_t w = width_of(c.dtype);
+      out.own_values = ctx->alloc(w * (size_t)std::max<int64_t>(G, 1));
+      out.values = out.own_values->p;
+      if (G) SQ_HIP(hipMemcpyAsync(out.own_values->p, c.values, w * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
+      if (c.validity && c.null_count != 0) {
+        out.own_validity = ctx->alloc(bitmap_bytes(std::max<int64_t>(G, 1)));
+        SQ_HIP(hipMemcpyAsync(out.own_validity->p, c.validity, bitmap_bytes(G), hipMemcpyDeviceToDevice, ctx->stream));
+        out.validity = out.own_validity->as<uint64_t>();
+        out.null_count = c.null_count;
+      }
+      ctx->sync();
+    }
+  }
+  if (dd) sqlrs_batch_release(dd);
+  if (res) sqlrs_batch_release(res);
+  if (st != SQLRS_OK) fail(st, err);
+  return out;
+}
+
+// [keys..., plain aggregates...] -> [keys..., aggregates in declaration order]
+static void place_aggregate_columns(sqlrs_hash_agg *a, DBatch &o) {
+  if (a->distinct_aggs.empty()) return;
+  const size_t nk = a->group_by.size();
+  std::vector<DCol> cols(o.cols.begin(), o.cols.begin() + (long)nk);
+  for (auto &e : a->out_order) {
+    if (e.first == 0)
+      cols.push_back(o.cols[nk + (size_t)e.second]);
+    else
+      cols.push_back(distinct_column(a, a->distinct_aggs[(size_t)e.second], o.rows));
+  }
+  o.cols = std::move(cols);
+}
+
 } // namespace sq
 
 extern "C" {
@@ -267,8 +370,23 @@ int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t
       s.arg = expr_from_abi(&aggs[i].arg);
       if (s.func < SQLRS_AGG_COUNT || s.func > SQLRS_AGG_MAX)
         fail(SQLRS_ERR_INTERNAL, "unknown aggregate function");
-      if (s.distinct && (s.func == SQLRS_AGG_COUNT || s.func == SQLRS_AGG_SUM))
-        fail(SQLRS_ERR_INTERNAL, "DISTINCT aggregates are not yet supported on the device path");
+      if (s.distinct && (s.func == SQLRS_AGG_COUNT || s.func == SQLRS_AGG_SUM)) {
+        if (s.func == SQLRS_AGG_SUM && s.return_dtype != SQLRS_INT64 && s.return_dtype != SQLRS_FLOAT64)
+          fail(SQLRS_ERR_INTERNAL, "not expected types for sum");
+        sqlrs_hash_agg::DistinctAgg d;
+        d.func = s.func;
+        d.return_dtype = s.return_dtype;
+        d.dedup = new sqlrs_hash_agg();
+        d.dedup->ctx = ctx;
+        d.dedup->strong_keys = true;
+        d.dedup->group_by = a->group_by;
+        d.dedup->group_by.push_back(s.arg);
+        d.dedup->key_parts.resize(d.dedup->group_by.size());
+        a->out_order.emplace_back(1, (int)a->distinct_aggs.size());
+        a->distinct_aggs.push_back(d);
+        continue;
+      }
+      a->out_order.emplace_back(0, (int)a->aggs.size());
       // SumAccumulator casts its input to the return type (sum.rs:54); the reference's
       // sum_result has no (Int32, Int32) arm (sum.rs:64-85)
       if (s.func == SQLRS_AGG_SUM && s.return_dtype != SQLRS_INT64 && s.return_dtype != SQLRS_FLOAT64)
@@ -305,7 +423,7 @@ int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
       a->saw_batch = true;
       for (const DCol &k : kcols) a->key_dtypes.push_back(k.dtype);
     }
-    NKeys nk = normalize_keys(ctx, kcols, n);
+    NKeys nk = a->strong_keys ? normalize_keys_strong(ctx, kcols, n) : normalize_keys(ctx, kcols, n);
     // 2.1 argument columns (:63-66), evaluated once per distinct (expression, cast)
     std::vector<DCol> acols;
     for (size_t k = 0; k < a->arg_exprs.size(); k++) {
@@ -462,6 +580,10 @@ int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
       update_from_rows(a, row_gid->as<uint32_t>(), views_of(acols), n, nnew); // 4. (:113-121)
     }
     a->rows_seen += n;
+    for (auto &d : a->distinct_aggs) {
+      int st = sqlrs_hash_agg_push(d.dedup, in);
+      if (st != SQLRS_OK) fail(st, ctx->last_error);
+    }
   });
 }
 
@@ -473,7 +595,9 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
     if (!a->saw_batch) // group_and_agg_fields.unwrap() panics on None (:125)
       fail(SQLRS_ERR_INTERNAL, "hash agg finished without any input batch");
     if (a->pending.active && a->st.ngroups == 0) {
-      *out = emit_batch(ctx, emit_pending(a), out_mem);
+      DBatch pb = emit_pending(a);
+      place_aggregate_columns(a, pb);
+      *out = emit_batch(ctx, std::move(pb), out_mem);
       return;
     }
     flush_pending(a);
@@ -514,6 +638,7 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
       radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), G, 0, bits);
       for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
     }
+    place_aggregate_columns(a, o);
     *out = emit_batch(ctx, std::move(o), out_mem);
   });
 }

@@ -60,6 +60,75 @@ __global__ void fold_utf8_kernel(const uint8_t *__restrict__ data, const int32_t
   h[i] = multi ? combine_hashes(v, h[i]) : v;
 }
 
+// Strong (asymmetric, position-dependent) 64-bit fold for library-internal de-duplication keys
+// such as (group key..., DISTINCT argument): unlike combine_hashes, (a, b) and (b, a) differ and
+// a NULL is a value of its own.  mode: 0 = fixed 8 B, 1 = fixed 4 B, 2 = bool bits, 3 = utf8
+template <int MODE>
+__global__ void fold_strong_kernel(const void *__restrict__ data, const int32_t *__restrict__ off,
+                                   const uint64_t *__restrict__ validity, int64_t n, uint64_t salt,
+                                   uint64_t *__restrict__ h) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t v;
+  if (validity && !((validity[i >> 6] >> (i & 63)) & 1))
+    v = 0x6e756c6c6e756c6cULL; // "nullnull"
+  else if (MODE == 0)
+    v = mix64(((const uint64_t *)data)[i] + 0x9e3779b97f4a7c15ULL);
+  else if (MODE == 1)
+    v = mix64((uint64_t)((const uint32_t *)data)[i] ^ 0x3232323200000000ULL);
+  else if (MODE == 2)
+    v = mix64(((((const uint64_t *)data)[i >> 6] >> (i & 63)) & 1) ^ 0x0808080808080808ULL);
+  else {
+    uint64_t x = 0xcbf29ce484222325ULL;
+    const uint8_t *b = (const uint8_t *)data;
+    for (int32_t k = off[i]; k < off[i + 1]; k++) {
+      x ^= b[k];
+      x *= 0x100000001b3ULL;
+    }
+    v = mix64(x ^ 0x7575757575757575ULL);
+  }
+  h[i] = mix64((h[i] ^ salt) * 0x9e3779b97f4a7c15ULL + v);
+}
+
+NKeys normalize_keys_strong(Ctx *ctx, const std::vector<DCol> &cols_in, int64_t rows) {
+  if (cols_in.empty()) fail(SQLRS_ERR_INTERNAL, "no key columns");
+  NKeys k;
+  k.rows = rows;
+  k.exact = false;
+  int64_t n1 = std::max<int64_t>(rows, 1);
+  k.keys = ctx->alloc(8 * (size_t)n1);
+  SQ_HIP(hipMemsetAsync(k.keys->p, 0, 8 * (size_t)n1, ctx->stream));
+  if (rows == 0) return k;
+  dim3 g((unsigned)ceil_div(n1, 256)), b(256);
+  ProfScope ps(ctx, "normalize_keys");
+  uint64_t salt = 0x1234567;
+  for (const DCol &cin : cols_in) {
+    DCol c = cin.stride == 0 ? materialize_scalar(ctx, cin, rows) : cin;
+    const uint64_t *v = (c.validity && c.null_count != 0) ? c.validity : nullptr;
+    uint64_t *h = k.keys->as<uint64_t>();
+    salt = salt * 6364136223846793005ULL + 1442695040888963407ULL;
+    switch (c.dtype) {
+    case SQLRS_INT64:
+    case SQLRS_FLOAT64:
+      fold_strong_kernel<0><<<g, b, 0, ctx->stream>>>(c.values, nullptr, v, rows, salt, h);
+      break;
+    case SQLRS_INT32:
+      fold_strong_kernel<1><<<g, b, 0, ctx->stream>>>(c.values, nullptr, v, rows, salt, h);
+      break;
+    case SQLRS_BOOLEAN:
+      fold_strong_kernel<2><<<g, b, 0, ctx->stream>>>(c.values, nullptr, v, rows, salt, h);
+      break;
+    case SQLRS_UTF8:
+      fold_strong_kernel<3><<<g, b, 0, ctx->stream>>>(c.values, c.offsets, v, rows, salt, h);
+      break;
+    default:
+      fail(SQLRS_ERR_INTERNAL, "Unsupported data type in hasher");
+    }
+    SQ_HIP(hipGetLastError());
+  }
+  return k;
+}
+
 NKeys normalize_keys(Ctx *ctx, const std::vector<DCol> &cols_in, int64_t rows) {
   if (cols_in.empty()) fail(SQLRS_ERR_INTERNAL, "no key columns");
   std::vector<DCol> cols;

@@ -70,6 +70,8 @@ struct NKeys {
   int32_t dtype = SQLRS_INT64;        // exact mode: dtype of the single key column
 };
 NKeys normalize_keys(Ctx *ctx, const std::vector<DCol> &cols, int64_t rows);
+// library-internal de-duplication keys: asymmetric strong hash, NULL is a value (keys.hip)
+NKeys normalize_keys_strong(Ctx *ctx, const std::vector<DCol> &cols, int64_t rows);
 
 // ---- radix sort (sort.hip) ----------------------------------------------------------
 // Stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit).

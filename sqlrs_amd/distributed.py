@@ -1,0 +1,74 @@
+"""Multi-GPU exchange for the partitioned hash join / group-by.
+
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI).  Equi-join and
+group-by couple rows only through equal keys, so the path shards with ONE exchange step:
+
+    1. every rank hash-partitions its slice on the key   (device: ``sqlrs_hash_partition``)
+    2. slices are exchanged with one all-to-all per column (xGMI is a full mesh: every pairwise
+       slice rides its own link, so an all-to-all is the topology's best case)
+    3. every rank runs the ordinary operators on what it received; with group key = join key the
+       per-rank results are disjoint and the global result is their concatenation.
+
+``partition_of`` restates the device partition function in numpy so that the exchange logic is
+testable on CPU (``gloo``, world_size 2) and so that tests can check device and host agree.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_MASK = (1 << 64) - 1
+
+
+def mix64_np(x: np.ndarray) -> np.ndarray:
+    """device_utils.hpp mix64 (murmur3 finaliser), vectorised on uint64"""
+    with np.errstate(over="ignore"):
+        x = x.astype(np.uint64)
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xFF51AFD7ED558CCD)
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xC4CEB9FE1A85EC53)
+        x ^= x >> np.uint64(33)
+        return x
+
+
+def partition_of(keys: np.ndarray, parts: int, valid: Optional[np.ndarray] = None) -> np.ndarray:
+    """partition.hip part_of(): p = ((mix64(key ^ C) >> 32) * parts) >> 32; NULL keys -> 0"""
+    h = mix64_np(keys.view(np.uint64) ^ np.uint64(0x5851F42D4C957F2D))
+    p = (((h >> np.uint64(32)) * np.uint64(parts)) >> np.uint64(32)).astype(np.uint32)
+    if valid is not None:
+        p = np.where(valid, p, np.uint32(0))
+    return p
+
+
+def partition_numpy(columns: Sequence[np.ndarray], parts: int, valid: Optional[np.ndarray] = None):
+    """Host restatement of sqlrs_hash_partition on column 0: rows permuted so that partition p is
+    contiguous (input order kept inside a partition) + the parts+1 offsets."""
+    p = partition_of(columns[0], parts, valid)
+    order = np.argsort(p, kind="stable")
+    counts = np.bincount(p, minlength=parts)
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return [c[order] for c in columns], offsets.tolist()
+
+
+def all_to_all_columns(dist, columns, offsets: Sequence[int], world: int, torch):
+    """Exchanges partitioned columns: slice p of every column goes to rank p.  ``columns`` are
+    torch tensors (device or CPU) already in partition order with ``offsets`` (world+1 ints).
+    Returns the received columns (concatenation of every rank's slice for this rank)."""
+    dev = columns[0].device
+    send = torch.tensor([offsets[p + 1] - offsets[p] for p in range(world)], dtype=torch.int64, device=dev)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send)
+    sc, rc = send.tolist(), recv.tolist()
+    outs = []
+    for t in columns:
+        dst = torch.empty(int(sum(rc)), dtype=t.dtype, device=dev)
+        dist.all_to_all_single(dst, t.contiguous(), output_split_sizes=rc, input_split_sizes=sc)
+        outs.append(dst)
+    return outs
+
+
+def shard_bounds(total: int, rank: int, world: int):
+    """contiguous slice [lo, hi) of a table owned by ``rank`` before the exchange"""
+    return total * rank // world, total * (rank + 1) // world

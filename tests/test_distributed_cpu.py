@@ -1,0 +1,117 @@
+"""The N>1 path on CPU: world_size 2, gloo.  Every rank hash-partitions its slice of fact and
+dim with the numpy restatement of the device partition function, exchanges the slices with
+the same all_to_all code the GPU bench uses, runs the local filter -> join -> group-by on the
+CPU oracle, and rank 0 checks that the concatenated per-rank results equal the single-process
+result (group key = join key => disjoint results)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_FACT, N_DIM = 20_000, 500
+
+
+def make_tables():
+    from sqlrs_amd import datagen
+    fi, di = np.arange(N_FACT, dtype=np.int64), np.arange(N_DIM, dtype=np.int64)
+    fact_key = datagen.key_np(0xF1, fi, 2 * N_DIM)  # half of the fact keys have no partner
+    fact_val = datagen.val_np(0xF2, fi)
+    dim_key = datagen.dim_key_np(di, N_DIM)
+    return fact_key, fact_val, dim_key
+
+
+def local_pipeline(oracle, dim_key, fact_key, fact_val):
+    import pyarrow as pa
+    from sqlrs_amd import abi
+    from sqlrs_amd.executor import FilterExecutor, HashAggExecutor, HashJoinExecutor
+    from sqlrs_amd.expr import AggFunc, Constant, InputRef, JoinCondition
+    dim = pa.RecordBatch.from_arrays([pa.array(dim_key)], names=["key"])
+    fact = pa.RecordBatch.from_arrays([pa.array(fact_key), pa.array(fact_val)], names=["key", "val"])
+    schema = pa.schema([("d.key", pa.int64()), ("f.key", pa.int64()), ("f.val", pa.float64())])
+    filt = FilterExecutor(oracle, InputRef(1) > Constant(0.5, abi.FLOAT64), [fact])
+    join = HashJoinExecutor(oracle, [dim], filt.execute(), "inner", JoinCondition([(InputRef(0), InputRef(0))]), schema, 1)
+    agg = HashAggExecutor(oracle, [AggFunc("count", InputRef(2), abi.INT64), AggFunc("sum", InputRef(2), abi.FLOAT64)],
+                          [InputRef(0)], join.execute())
+    outs = list(agg.execute())
+    if not outs:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0)
+    o = outs[0]
+    return (np.array(o.column(0).to_pylist(), dtype=np.int64), np.array(o.column(1).to_pylist(), dtype=np.int64),
+            np.array(o.column(2).to_pylist(), dtype=np.float64))
+
+
+def worker(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle_backend import load_oracle
+    from sqlrs_amd import distributed as D
+    oracle = load_oracle()
+    fact_key, fact_val, dim_key = make_tables()
+    f_lo, f_hi = D.shard_bounds(N_FACT, rank, world)
+    d_lo, d_hi = D.shard_bounds(N_DIM, rank, world)
+
+    def exchange(cols):
+        parts, offs = D.partition_numpy(cols, world)
+        outs = D.all_to_all_columns(dist, [torch.from_numpy(np.ascontiguousarray(c)) for c in parts], offs, world, torch)
+        return [o.numpy() for o in outs]
+
+    (dk,) = exchange([dim_key[d_lo:d_hi]])
+    fk, fv = exchange([fact_key[f_lo:f_hi], fact_val[f_lo:f_hi]])
+    # every key this rank received belongs to this rank's partition
+    assert (D.partition_of(dk, world) == rank).all() and (D.partition_of(fk, world) == rank).all()
+    keys, cnt, sm = local_pipeline(oracle, dk, fk, fv)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (keys, cnt, sm, len(fk), len(dk)))
+    if rank == 0:
+        all_keys = np.concatenate([g[0] for g in gathered])
+        all_cnt = np.concatenate([g[1] for g in gathered])
+        all_sum = np.concatenate([g[2] for g in gathered])
+        assert sum(g[3] for g in gathered) == N_FACT and sum(g[4] for g in gathered) == N_DIM
+        assert len(np.unique(all_keys)) == len(all_keys), "per-rank results must be disjoint"
+        ek, ec, es = local_pipeline(oracle, dim_key, fact_key, fact_val)  # single process
+        o1, o2 = np.argsort(all_keys), np.argsort(ek)
+        assert (all_keys[o1] == ek[o2]).all()
+        assert (all_cnt[o1] == ec[o2]).all()
+        assert np.allclose(all_sum[o1], es[o2], rtol=1e-9, atol=0)
+        with open(result_path, "w") as f:
+            f.write(f"ok {len(ek)}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_partitioned_join_groupby_world2_gloo(tmp_path):
+    result = tmp_path / "result.txt"
+    mp.spawn(worker, args=(2, free_port(), str(result)), nprocs=2, join=True)
+    assert result.read_text().startswith("ok")
+
+
+def test_partition_function_is_balanced_and_total():
+    from sqlrs_amd import distributed as D
+    keys = np.arange(100_000, dtype=np.int64)
+    for parts in (1, 2, 3, 8):
+        p = D.partition_of(keys, parts)
+        assert p.min() >= 0 and p.max() < parts
+        counts = np.bincount(p, minlength=parts)
+        assert counts.min() > 0.9 * len(keys) / parts
+    cols, offs = D.partition_numpy([keys, keys * 2], 8)
+    assert offs[0] == 0 and offs[-1] == len(keys)
+    for p in range(8):  # stable inside a partition
+        seg = cols[0][offs[p]:offs[p + 1]]
+        assert (np.diff(seg) > 0).all() and (D.partition_of(seg, 8) == p).all()
+    assert (cols[1] == cols[0] * 2).all()

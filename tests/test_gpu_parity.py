@@ -310,3 +310,38 @@ def test_hash_agg_mixed_routes_multi_batch(hip, oracle):
     got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], bs).execute())
     exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], bs).execute())
     assert_same(got, exp, float_cols={2, 3})
+
+
+# -------------------------------------------------------------- exchange primitive --
+@pytest.mark.parametrize("parts", [1, 2, 8])
+def test_hash_partition_matches_host_restatement(hip, parts):
+    from sqlrs_amd import distributed as D
+    rng = np.random.default_rng(parts)
+    n = 100_003
+    keys = rng.integers(-10**12, 10**12, n, dtype=np.int64)
+    vals = rng.random(n)
+    mask = rng.random(n) < 0.05
+    b = pa.RecordBatch.from_arrays([pa.array(keys, mask=mask), pa.array(vals)], names=["k", "v"])
+    out, offs = hip.hash_partition(b, InputRef(0), parts, abi.MEM_DEVICE)
+    got = hip.to_host(out).to_arrow(["k", "v"])
+    exp_cols, exp_offs = D.partition_numpy([keys, vals], parts, valid=~mask)
+    assert offs == exp_offs
+    gk = got.column(0).to_numpy(zero_copy_only=False)
+    ek = np.where(~mask, keys, 0)[np.argsort(D.partition_of(keys, parts, ~mask), kind="stable")]
+    assert (np.nan_to_num(gk.astype(float), nan=0.0) == ek.astype(float)).all()
+    assert (got.column(1).to_numpy() == exp_cols[1]).all()
+
+
+# ---------------------------------------------------------------- DISTINCT aggregates --
+@pytest.mark.parametrize("n,groups,nulls", [(10, 3, 0.3), (5000, 40, 0.1), (60_000, 3000, 0.05)])
+def test_hash_agg_distinct(hip, oracle, n, groups, nulls):
+    """count(distinct x) / sum(distinct x) (count.rs:31-58, sum.rs:99-132), mixed with plain
+    aggregates; a NULL counts as one distinct value for COUNT, is skipped by SUM."""
+    rng = np.random.default_rng(n)
+    b = batch(rng, n, [("i64", nulls, 0, groups), ("i64", nulls, 0, 12), ("f64", nulls, 0, 1)])
+    bs = [b.slice(0, n // 2), b.slice(n // 2)]
+    aggs = [AggFunc("count", InputRef(1), abi.INT64, distinct=True), AggFunc("sum", InputRef(2), abi.FLOAT64),
+            AggFunc("sum", InputRef(1), abi.INT64, distinct=True), AggFunc("count", InputRef(2), abi.INT64)]
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], bs).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], bs).execute())
+    assert_same(got, exp, float_cols={2})
