@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--threshold", type=float, default=0.5, help="WHERE f.val > threshold")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=float, default=0, help="0 = auto (about 10-30 s)")
+    p.add_argument("--unfused", action="store_true",
+                   help="run HashJoin and HashAgg as two operators (joined batch materialised in HBM)")
     p.add_argument("--operators", action="store_true",
                    help="also time configs C2/C3/C4 one operator at a time (stderr + 'operators' key)")
     return p.parse_args()
@@ -70,9 +72,9 @@ def device_batch(abi, tensors, dtypes):
 class Pipeline:
     """Filter -> HashJoin -> HashAgg driven through the C ABI on device-resident batches."""
 
-    def __init__(self, be, abi, threshold):
+    def __init__(self, be, abi, threshold, fused=True):
         from sqlrs_amd.expr import AggFunc, Constant, InputRef, JoinCondition
-        self.be, self.abi = be, abi
+        self.be, self.abi, self.fused, self.fused_batches = be, abi, fused, 0
         self.filter_expr = (InputRef(1) > Constant(threshold, abi.FLOAT64)).pack()
         self.cond = JoinCondition([(InputRef(0), InputRef(0))])
         self.lk, self._k1 = abi.pack_exprs([InputRef(0)])
@@ -94,6 +96,21 @@ class Pipeline:
         be.check(be.fn("filter_push")(f, fact_b.ptr, D, C.byref(fo)))
         be.fn("filter_destroy")(f)
         filtered = be.wrap(fo)
+        if self.fused:
+            # HashAgg directly over the Inner HashJoin (sqlrs_join_agg_*): same result, the joined
+            # batch is not materialised when the library's fused route applies
+            ja = C.c_void_p()
+            be.check(be.fn("join_agg_create")(be.ctx, 1, self.lk, self.rk, 1, 2, self.right_dtypes, 1, self.gb, 2,
+                                              self.aggs, C.byref(ja)))
+            be.check(be.fn("join_agg_build_push")(ja, dim_b.ptr))
+            be.check(be.fn("join_agg_build_finish")(ja))
+            be.check(be.fn("join_agg_probe_push")(ja, filtered.ptr))
+            filtered.release()
+            ao = C.POINTER(abi.Batch)()
+            be.check(be.fn("join_agg_finish")(ja, D, C.byref(ao)))
+            self.fused_batches = be.fn("join_agg_fused_batches")(ja)
+            be.fn("join_agg_destroy")(ja)
+            return be.wrap(ao)
         j = C.c_void_p()
         be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, self.lk, self.rk, None, 2,
                                            self.right_dtypes, C.byref(j)))
@@ -173,7 +190,7 @@ def main():
         log(f"[bench] generated {f_hi - f_lo:,} fact rows + {d_hi - d_lo:,} dim rows per rank in {time.time() - t0:.1f}s")
     expected_kept = int((fact_val > args.threshold).sum().item())
 
-    pipe = Pipeline(be, abi, args.threshold)
+    pipe = Pipeline(be, abi, args.threshold, fused=not args.unfused)
     from sqlrs_amd.expr import InputRef
 
     def exchange(cols, dtypes):
@@ -298,6 +315,8 @@ def main():
             "config": {"workload": "C5 filter(val>0.5) -> hash-join(fact x dim on int64 key) -> group-by(key) COUNT,SUM(f64)",
                        "fact_rows": n_fact_total, "dim_rows": n_dim_total, "groups": int(ngroups.item()),
                        "selectivity": round(exp_rows.item() / n_fact_total, 4),
+                       "operators": "Filter -> HashJoin -> HashAgg (3 operators)" if args.unfused else
+                       "Filter -> HashJoinAgg (HashAgg fused over the Inner HashJoin)",
                        "parallelism": f"hash-partition x{world} + RCCL all-to-all" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

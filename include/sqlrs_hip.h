@@ -250,6 +250,29 @@ int sqlrs_order_push(sqlrs_order_t *o, const sqlrs_batch_t *in);
 int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out);
 void sqlrs_order_destroy(sqlrs_order_t *o);
 
+/* ---------------------------------------------------- HashJoin + HashAgg fused -- */
+/* A HashAggExecutor sitting directly on an Inner HashJoinExecutor without join filter
+ * [ref: hash_agg.rs:32-150 consuming hash_join.rs:146-323] — what a physical rewrite of
+ * PhysicalHashAgg(PhysicalHashJoin(left, right)) instantiates.  Results are identical to running
+ * the two operators back to back: group_by / aggregate argument expressions index the JOIN
+ * OUTPUT schema (left columns, then right columns), groups come out in first-seen order of the
+ * join output.  When the join has one exactly-compared key with unique build keys, the group key
+ * is that key and the aggregate arguments only read probe-side columns, the joined batch is never
+ * materialised (probe rows are partitioned once, each LDS bucket table is pre-filled with the
+ * build keys); otherwise the library composes the two operators on the device itself. */
+typedef struct sqlrs_join_agg sqlrs_join_agg_t;
+int sqlrs_join_agg_create(sqlrs_ctx_t *ctx, int num_keys, const sqlrs_expr_t *left_keys,
+                          const sqlrs_expr_t *right_keys, int num_left_columns, int num_right_columns,
+                          const int32_t *right_dtypes, int num_group_by, const sqlrs_expr_t *group_by,
+                          int num_aggs, const sqlrs_agg_func_t *aggs, sqlrs_join_agg_t **out);
+int sqlrs_join_agg_build_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *left);
+int sqlrs_join_agg_build_finish(sqlrs_join_agg_t *ja);
+int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right);
+int sqlrs_join_agg_finish(sqlrs_join_agg_t *ja, int out_mem, sqlrs_batch_t **out);
+/* probe batches that took the non-materialising route so far */
+int64_t sqlrs_join_agg_fused_batches(const sqlrs_join_agg_t *ja);
+void sqlrs_join_agg_destroy(sqlrs_join_agg_t *ja);
+
 /* --------------------------------------------------------------- exchange -- */
 /* Hash-partitions a batch on one key expression for the multi-GPU partitioned join /
  * group-by (no reference analogue: sqlrs is single process).  The output batch

@@ -300,6 +300,13 @@ class Backend:
             "ctx_pool_trim": (None, [vp]),
             "batch_copy": (i, [vp, pb, i, ppb]),
             "hash_partition": (i, [vp, pb, pe, i, i, ppb, C.POINTER(C.c_int64)]),
+            "join_agg_create": (i, [vp, i, pe, pe, i, i, C.POINTER(C.c_int32), i, pe, i, C.POINTER(AggFunc), pvp]),
+            "join_agg_build_push": (i, [vp, pb]),
+            "join_agg_build_finish": (i, [vp]),
+            "join_agg_probe_push": (i, [vp, pb]),
+            "join_agg_finish": (i, [vp, i, ppb]),
+            "join_agg_fused_batches": (C.c_int64, [vp]),
+            "join_agg_destroy": (None, [vp]),
             "timer_create": (i, [vp, pvp]),
             "timer_start": (i, [vp]),
             "timer_stop": (i, [vp]),

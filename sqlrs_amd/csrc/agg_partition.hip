@@ -93,7 +93,9 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     const uint8_t *__restrict__ pf, const uint32_t *__restrict__ bstart, uint32_t P,
     int64_t n, unsigned long long *out_count, uint64_t *__restrict__ gkey,
     uint32_t *__restrict__ gfirst, uint8_t *__restrict__ gvalid, uint64_t *__restrict__ gacc,
-    int64_t gcap, unsigned long long *ov_count, uint32_t *__restrict__ ov_rows) {
+    int64_t gcap, unsigned long long *ov_count, uint32_t *__restrict__ ov_rows,
+    const uint64_t *__restrict__ bk, const uint8_t *__restrict__ bf, const uint32_t *__restrict__ bbstart,
+    int join_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
   __shared__ unsigned int s_cnt;
   __shared__ unsigned long long s_base;
@@ -108,6 +110,33 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
   }
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
+  if (join_mode) {
+    // fused inner join: the bucket's BUILD keys are inserted first; probe rows then only
+    // accumulate into slots that exist (a probe key without a build partner is dropped)
+    const int64_t blo = bbstart[b], bhi = bbstart[b + 1];
+    for (int64_t i = blo + threadIdx.x; i < bhi; i += PART_WG) {
+      uint64_t key = bk[i];
+      bool valid = bf ? (bf[i] & 1) : true;
+      if (!valid) {
+        tab[(size_t)cap * cells] = 1; // NULL build key present (NULL = NULL matches)
+      } else if (key == LDS_EMPTY) {
+        tab[(size_t)(cap + 1) * cells] = 1;
+      } else {
+        uint32_t s = (uint32_t)(mix64(key) >> 7) & mask;
+        uint32_t probes = 0;
+        while (true) {
+          unsigned long long prev = atomicCAS(&tab[(size_t)s * cells], LDS_EMPTY, (unsigned long long)key);
+          if (prev == LDS_EMPTY || prev == key) break;
+          s = (s + 1) & mask;
+          if (++probes >= cap) {
+            atomicExch(ov_count + 1, 1ull); // table too small for the build side: caller falls back
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
   const int64_t lo = bstart[b];
   const int64_t hi = bstart[b + 1];
   // 4 rows per thread per trip, all loads issued before the first dependent LDS op
@@ -133,11 +162,27 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     uint8_t f = f4[u];
     uint32_t s;
     bool ok = true;
-    if (!(f & 1))
+    if (!(f & 1)) {
       s = cap; // NULL keys: one group
-    else if (key == LDS_EMPTY)
+      if (join_mode && tab[(size_t)s * cells] == LDS_EMPTY) continue;
+    } else if (key == LDS_EMPTY) {
       s = cap + 1;
-    else {
+      if (join_mode && tab[(size_t)s * cells] == LDS_EMPTY) continue;
+    } else if (join_mode) {
+      s = (uint32_t)(mix64(key) >> 7) & mask;
+      uint32_t probes = 0;
+      bool found = false;
+      while (probes++ < cap) {
+        unsigned long long cur = tab[(size_t)s * cells];
+        if (cur == key) {
+          found = true;
+          break;
+        }
+        if (cur == LDS_EMPTY) break;
+        s = (s + 1) & mask;
+      }
+      if (!found) continue;
+    } else {
       s = (uint32_t)(mix64(key) >> 7) & mask;
       uint32_t probes = 0;
       while (true) {
@@ -185,7 +230,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
   unsigned int mine = 0;
   for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) {
     const unsigned long long *c = tab + (size_t)s * cells;
-    bool occ = s < cap ? c[0] != LDS_EMPTY : (unsigned int)c[1] != 0xffffffffu;
+    bool occ = (unsigned int)c[1] != 0xffffffffu;
     mine += occ;
   }
   unsigned int my_off = atomicAdd(&s_cnt, mine);
@@ -195,7 +240,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
   unsigned long long base = s_base + my_off;
   for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) {
     const unsigned long long *c = tab + (size_t)s * cells;
-    bool occ = s < cap ? c[0] != LDS_EMPTY : (unsigned int)c[1] != 0xffffffffu;
+    bool occ = (unsigned int)c[1] != 0xffffffffu;
     if (!occ) continue;
     if ((int64_t)base < gcap) {
       gkey[base] = s == cap + 1 ? LDS_EMPTY : c[0];
@@ -223,8 +268,9 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
                               uint64_t row_offset, PartAggOutput *out) {
   const int64_t n = in.n;
   if (n > 0xffffffffll || spec.n_acc > PART_MAX_ACC || spec.nv > 2) return false;
-  // 1. how many groups?  -> bucket count
-  double est = estimate_distinct(ctx, in.keys, in.key_validity, n);
+  // 1. how many groups?  -> bucket count.  Fused join: every build key needs a slot.
+  const bool join_mode = in.join_keys != nullptr;
+  double est = join_mode ? (double)in.join_n : estimate_distinct(ctx, in.keys, in.key_validity, n);
   const int cells = 2 + spec.n_acc;
   // LDS budget per workgroup: 36 KiB tables let four 512-thread workgroups share a CU
   static const size_t lds_budget = [] {
@@ -235,7 +281,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   while ((size_t)(cap * 2 + 2) * cells * 8 <= lds_budget) cap *= 2;
   const double groups_per_table = cap * 0.55;
   double want = est * 1.15 / groups_per_table;
-  if (want > 65536.0 || est > 0.5 * (double)n) return false; // too many groups: resolve path
+  if (want > 65536.0 || (!join_mode && est > 0.5 * (double)n)) return false; // too many groups: resolve path
   uint32_t P = (uint32_t)std::max(1.0, std::ceil(want));
   out->est_groups = est;
   // 2./3. rows in bucket order (LDS-staged multi-split, radix_part.hip)
@@ -253,6 +299,22 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   P = pr.P;
   out->buckets = (int)P;
   BufP pk = pr.key, pi = pr.idx, pv0 = pr.v0, pv1 = pr.v1, pf = pr.flags;
+  PartitionedRows local_build;
+  const PartitionedRows *bp = nullptr;
+  if (join_mode) { // the build keys through the same bucket function (cached across probe batches)
+    if (in.join_cache && in.join_cache->P == P && in.join_cache->n == in.join_n) {
+      bp = in.join_cache;
+    } else {
+      PartitionInput bin;
+      bin.keys = in.join_keys;
+      bin.key_validity = in.join_validity;
+      bin.n = in.join_n;
+      bin.nv = 0;
+      PartitionedRows *dst = in.join_cache ? in.join_cache : &local_build;
+      if (!partition_rows(ctx, bin, P, dst) || dst->P != P) return false;
+      bp = dst;
+    }
+  }
   // 4. LDS aggregation, one workgroup per bucket
   LdsAggParams prm;
   prm.n_acc = spec.n_acc;
@@ -270,7 +332,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   out->gacc = ctx->alloc(8 * (size_t)gcap * (size_t)std::max(spec.n_acc, 1));
   out->gcap = gcap;
   out->ov_rows = ctx->alloc(4 * (size_t)n);
-  BufP ctr = ctx->alloc_zero(16);
+  BufP ctr = ctx->alloc_zero(24);
   size_t lds = (size_t)(cap + 2) * cells * 8;
   static bool attr_set = false;
   if (!attr_set) {
@@ -285,12 +347,15 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
         pv1 ? pv1->as<uint64_t>() : nullptr, pf ? pf->as<uint8_t>() : nullptr, pr.bstart->as<uint32_t>(), P,
         n, ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(),
         out->gvalid ? out->gvalid->as<uint8_t>() : nullptr, out->gacc->as<uint64_t>(), gcap,
-        ctr->as<unsigned long long>() + 1, out->ov_rows->as<uint32_t>());
+        ctr->as<unsigned long long>() + 1, out->ov_rows->as<uint32_t>(),
+        bp ? bp->key->as<uint64_t>() : nullptr, (bp && bp->flags) ? bp->flags->as<uint8_t>() : nullptr,
+        bp ? bp->bstart->as<uint32_t>() : nullptr, join_mode ? 1 : 0);
     SQ_HIP(hipGetLastError());
   }
-  const uint64_t *h = (const uint64_t *)ctx->fetch(ctr->p, 16);
+  const uint64_t *h = (const uint64_t *)ctx->fetch(ctr->p, 24);
   out->groups = (int64_t)h[0];
   out->n_overflow = (int64_t)h[1];
+  if (join_mode && h[2]) return false; // a bucket table could not hold its build keys
   if (out->groups > gcap) return false; // estimate far too low: caller falls back to the resolve path
   // first-row ids as global row numbers + NULL-key bitmap for the merge
   int64_t g1 = std::max<int64_t>(out->groups, 1);

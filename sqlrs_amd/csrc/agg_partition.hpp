@@ -5,6 +5,7 @@
 
 #include "common.hpp"
 #include "prims.hpp"
+#include "radix_part.hpp"
 
 namespace sq {
 
@@ -25,6 +26,12 @@ struct PartAggInput {
   int64_t n = 0;
   const void *vals[2] = {nullptr, nullptr};
   const uint64_t *val_validity[2] = {nullptr, nullptr};
+  // fused inner join (optional): normalised build keys; rows whose key has no build partner
+  // are dropped, groups exist only for keys that have one
+  const uint64_t *join_keys = nullptr;
+  const uint64_t *join_validity = nullptr;
+  int64_t join_n = 0;
+  struct PartitionedRows *join_cache = nullptr; // build side in bucket order, reused across batches
 };
 
 // Groups of ONE batch: key, first row (local index), one 8-byte cell per accumulator

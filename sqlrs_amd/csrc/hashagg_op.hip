@@ -350,6 +350,195 @@ static void place_aggregate_columns(sqlrs_hash_agg *a, DBatch &o) {
   o.cols = std::move(cols);
 }
 
+// evaluates the distinct (expression, cast) argument columns of the aggregates; `shift` is
+// subtracted from every InputRef (fused join: join-output index -> probe batch index)
+static std::vector<DCol> eval_arg_columns(sqlrs_hash_agg *a, const std::function<const DCol &(int)> &colfn,
+                                          int64_t n, int shift) {
+  Ctx *ctx = a->ctx;
+  std::vector<DCol> acols;
+  for (size_t k = 0; k < a->arg_exprs.size(); k++) {
+    Expr e = a->arg_exprs[k];
+    if (shift)
+      for (auto &nd : e.nodes)
+        if (nd.op == SQLRS_EXPR_INPUT_REF) nd.index -= shift;
+    DCol c = eval_expr(ctx, e, colfn, n, true);
+    if (a->arg_cast[k] && c.dtype != a->arg_cast[k]) { // SumAccumulator casts first (sum.rs:54)
+      sqlrs_expr_node_t cn[2];
+      std::memset(cn, 0, sizeof(cn));
+      cn[0].op = SQLRS_EXPR_INPUT_REF;
+      cn[1].op = SQLRS_EXPR_TYPE_CAST;
+      cn[1].dtype = a->arg_cast[k];
+      Expr ce;
+      ce.nodes.assign(cn, cn + 2);
+      ce.strings.resize(2);
+      auto one = [&](int) -> const DCol & { return c; };
+      DCol casted = eval_expr(ctx, ce, one, n, true);
+      c = casted;
+    }
+    acols.push_back(c);
+  }
+  return acols;
+}
+
+struct JoinSide {
+  const uint64_t *keys;     // normalised build keys of an Inner join with unique build keys
+  const uint64_t *validity;
+  int64_t n;
+  PartitionedRows *cache;
+};
+
+// Consumes one batch given its evaluated key / argument columns: partition route when it
+// applies, else the row route.  With `js` (fused join) only rows whose key has a build partner
+// count; returns false if the fused route is not applicable (nothing has been consumed then).
+static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &kcols, const NKeys &nk,
+                        const std::vector<DCol> &acols, const JoinSide *js) {
+  Ctx *ctx = a->ctx;
+    auto views_of = [&](const std::vector<DCol> &cols) {
+      std::vector<ArgView> v;
+      for (const DCol &c : cols) {
+        ArgView x;
+        x.values = c.values;
+        x.validity = (c.validity && c.null_count != 0) ? c.validity : nullptr;
+        x.dtype = c.dtype;
+        v.push_back(x);
+      }
+      return v;
+    };
+
+    // identical argument expressions that evaluate to the same dtype share one column
+    // (COUNT(val) and SUM(val): one read of val)
+    std::vector<DCol> pcols;
+    std::vector<int> pidx(acols.size(), -1);
+    for (size_t k = 0; k < acols.size(); k++) {
+      for (size_t j = 0; j < k && pidx[k] < 0; j++)
+        if (same_expr(a->arg_exprs[j], a->arg_exprs[k]) && acols[j].dtype == acols[k].dtype) pidx[k] = pidx[j];
+      if (pidx[k] < 0) {
+        pidx[k] = (int)pcols.size();
+        pcols.push_back(acols[k]);
+      }
+    }
+    // ---- partition route ----------------------------------------------------------
+    bool done = false;
+    static const int64_t PART_MIN_ROWS = [] {
+      const char *e = std::getenv("SQLRS_PART_MIN_ROWS"); // test hook: force the partition route
+      return e ? std::atoll(e) : (1ll << 21);
+    }();
+    if ((n >= PART_MIN_ROWS || js) && pcols.size() <= 2) {
+      PartAggSpec spec;
+      bool ok = true;
+      std::vector<int> acc_of_agg(a->aggs.size(), -1), cnt_of_col(pcols.size(), -1);
+      for (const DCol &c : pcols)
+        ok &= (c.dtype == SQLRS_INT64 || c.dtype == SQLRS_FLOAT64); // 8-byte values only
+      // a COUNT cell per column whose has-value state must be known
+      for (size_t k = 0; ok && k < pcols.size(); k++) {
+        bool need = pcols[k].validity && pcols[k].null_count != 0;
+        for (const AggSpec &s : a->aggs)
+          if (pidx[(size_t)s.argcol] == (int)k && (s.func == SQLRS_AGG_COUNT || s.track_nn)) need = true;
+        if (need) {
+          if (spec.n_acc >= PART_MAX_ACC) { ok = false; break; }
+          cnt_of_col[k] = spec.n_acc;
+          spec.op[spec.n_acc] = PART_COUNT;
+          spec.src[spec.n_acc++] = (int)k;
+        }
+      }
+      for (size_t i = 0; ok && i < a->aggs.size(); i++) {
+        const AggSpec &s = a->aggs[i];
+        if (s.func == SQLRS_AGG_COUNT) {
+          acc_of_agg[i] = cnt_of_col[(size_t)pidx[(size_t)s.argcol]];
+          continue;
+        }
+        if (spec.n_acc >= PART_MAX_ACC) { ok = false; break; }
+        const DCol &c = pcols[(size_t)pidx[(size_t)s.argcol]];
+        if (s.func != SQLRS_AGG_SUM && c.dtype != s.return_dtype) { ok = false; break; }
+        acc_of_agg[i] = spec.n_acc;
+        spec.op[spec.n_acc] = s.func == SQLRS_AGG_SUM ? (c.dtype == SQLRS_FLOAT64 ? PART_SUM_F64 : PART_SUM_I64)
+                              : s.func == SQLRS_AGG_MIN ? PART_MIN : PART_MAX;
+        spec.kind[spec.n_acc] = c.dtype == SQLRS_FLOAT64 ? 1 : 0;
+        spec.src[spec.n_acc++] = pidx[(size_t)s.argcol];
+      }
+      spec.nv = (int)pcols.size();
+      if (ok) {
+        PartAggInput pin;
+        pin.keys = nk.keys->as<uint64_t>();
+        pin.key_validity = nk.validity;
+        pin.n = n;
+        for (size_t k = 0; k < pcols.size(); k++) {
+          pin.vals[k] = pcols[k].values;
+          pin.val_validity[k] = (pcols[k].validity && pcols[k].null_count != 0) ? pcols[k].validity : nullptr;
+        }
+        if (js) {
+          pin.join_keys = js->keys;
+          pin.join_validity = js->validity;
+          pin.join_n = js->n;
+          pin.join_cache = js->cache;
+        }
+        PartAggOutput po;
+        flush_pending(a); // an older deferred batch must be in the table before this one
+        if (partitioned_preaggregate(ctx, spec, pin, (uint64_t)a->rows_seen, &po)) {
+          PendingGroups pg;
+          pg.active = true;
+          pg.exact = nk.exact;
+          pg.key_dtype = nk.dtype;
+          pg.cnt_of_col = cnt_of_col;
+          pg.acc_of_agg = acc_of_agg;
+          for (const AggSpec &s : a->aggs) pg.col_of_agg.push_back(pidx[(size_t)s.argcol]);
+          for (size_t k = 0; k < pcols.size(); k++) {
+            pg.col_nullable.push_back(pin.val_validity[k] != nullptr);
+            pg.col_dtype.push_back(pcols[k].dtype);
+          }
+          for (const DCol &kc : kcols) // key values of every group of the batch (hash_agg.rs:90-96)
+            pg.keyvals.push_back(gather_column(ctx, kc, po.gfirst->p, false, nullptr, po.groups));
+          pg.po = po;
+          if (a->st.ngroups == 0 && po.n_overflow == 0)
+            a->pending = std::move(pg); // nothing to merge with yet: defer building the table
+          else
+            merge_groups(a, pg);
+          // rows whose bucket table was full go through the row route
+          if (po.n_overflow) {
+            int64_t m = po.n_overflow;
+            DCol kc;
+            kc.dtype = SQLRS_UINT64;
+            kc.length = n;
+            kc.values = nk.keys->p;
+            kc.validity = nk.validity;
+            kc.null_count = nk.validity ? -1 : 0;
+            DCol sub = gather_column(ctx, kc, po.ov_rows->p, false, nullptr, m);
+            NKeys ok_;
+            ok_.rows = m;
+            ok_.keys = sub.own_values;
+            ok_.exact = nk.exact;
+            ok_.dtype = nk.dtype;
+            if (sub.validity) {
+              ok_.validity = sub.validity;
+              ok_.own_validity = sub.own_validity;
+            }
+            BufP rid = ctx->alloc(8 * (size_t)m);
+            rowid_from_u32_kernel<<<dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx->stream>>>(
+                po.ov_rows->as<uint32_t>(), m, (uint64_t)a->rows_seen, rid->as<uint64_t>());
+            SQ_HIP(hipGetLastError());
+            std::vector<DCol> sub_args;
+            for (const DCol &c : acols) sub_args.push_back(gather_column(ctx, c, po.ov_rows->p, false, nullptr, m));
+            int64_t nn2 = 0;
+            BufP rg2 = resolve_groups(a, ok_, rid->as<uint64_t>(), po.ov_rows->as<uint32_t>(), kcols, &nn2);
+            for (DCol &c : sub_args)
+              if (c.validity && c.null_count < 0) c.null_count = count_nulls(ctx, c);
+            update_from_rows(a, rg2->as<uint32_t>(), views_of(sub_args), m, nn2);
+          }
+          done = true;
+        }
+      }
+    }
+    // ---- row route ------------------------------------------------------------------
+    if (!done && js) return false; // fused join: the caller composes join + aggregate instead
+    if (!done) {
+      flush_pending(a);
+      int64_t nnew = 0;
+      BufP row_gid = resolve_groups(a, nk, nullptr, nullptr, kcols, &nnew); // 3.2 (:85-110)
+      update_from_rows(a, row_gid->as<uint32_t>(), views_of(acols), n, nnew); // 4. (:113-121)
+    }
+    return true;
+}
+
 } // namespace sq
 
 extern "C" {
@@ -425,160 +614,8 @@ int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
     }
     NKeys nk = a->strong_keys ? normalize_keys_strong(ctx, kcols, n) : normalize_keys(ctx, kcols, n);
     // 2.1 argument columns (:63-66), evaluated once per distinct (expression, cast)
-    std::vector<DCol> acols;
-    for (size_t k = 0; k < a->arg_exprs.size(); k++) {
-      DCol c = eval_expr(ctx, a->arg_exprs[k], colfn, n, true);
-      if (a->arg_cast[k] && c.dtype != a->arg_cast[k]) {
-        sqlrs_expr_node_t cn[2];
-        std::memset(cn, 0, sizeof(cn));
-        cn[0].op = SQLRS_EXPR_INPUT_REF;
-        cn[1].op = SQLRS_EXPR_TYPE_CAST;
-        cn[1].dtype = a->arg_cast[k];
-        Expr ce;
-        ce.nodes.assign(cn, cn + 2);
-        ce.strings.resize(2);
-        auto one = [&](int) -> const DCol & { return c; };
-        DCol casted = eval_expr(ctx, ce, one, n, true);
-        c = casted;
-      }
-      acols.push_back(c);
-    }
-    auto views_of = [&](const std::vector<DCol> &cols) {
-      std::vector<ArgView> v;
-      for (const DCol &c : cols) {
-        ArgView x;
-        x.values = c.values;
-        x.validity = (c.validity && c.null_count != 0) ? c.validity : nullptr;
-        x.dtype = c.dtype;
-        v.push_back(x);
-      }
-      return v;
-    };
-
-    // identical argument expressions that evaluate to the same dtype share one column
-    // (COUNT(val) and SUM(val): one read of val)
-    std::vector<DCol> pcols;
-    std::vector<int> pidx(acols.size(), -1);
-    for (size_t k = 0; k < acols.size(); k++) {
-      for (size_t j = 0; j < k && pidx[k] < 0; j++)
-        if (same_expr(a->arg_exprs[j], a->arg_exprs[k]) && acols[j].dtype == acols[k].dtype) pidx[k] = pidx[j];
-      if (pidx[k] < 0) {
-        pidx[k] = (int)pcols.size();
-        pcols.push_back(acols[k]);
-      }
-    }
-    // ---- partition route ----------------------------------------------------------
-    bool done = false;
-    static const int64_t PART_MIN_ROWS = [] {
-      const char *e = std::getenv("SQLRS_PART_MIN_ROWS"); // test hook: force the partition route
-      return e ? std::atoll(e) : (1ll << 21);
-    }();
-    if (n >= PART_MIN_ROWS && pcols.size() <= 2) {
-      PartAggSpec spec;
-      bool ok = true;
-      std::vector<int> acc_of_agg(a->aggs.size(), -1), cnt_of_col(pcols.size(), -1);
-      for (const DCol &c : pcols)
-        ok &= (c.dtype == SQLRS_INT64 || c.dtype == SQLRS_FLOAT64); // 8-byte values only
-      // a COUNT cell per column whose has-value state must be known
-      for (size_t k = 0; ok && k < pcols.size(); k++) {
-        bool need = pcols[k].validity && pcols[k].null_count != 0;
-        for (const AggSpec &s : a->aggs)
-          if (pidx[(size_t)s.argcol] == (int)k && (s.func == SQLRS_AGG_COUNT || s.track_nn)) need = true;
-        if (need) {
-          if (spec.n_acc >= PART_MAX_ACC) { ok = false; break; }
-          cnt_of_col[k] = spec.n_acc;
-          spec.op[spec.n_acc] = PART_COUNT;
-          spec.src[spec.n_acc++] = (int)k;
-        }
-      }
-      for (size_t i = 0; ok && i < a->aggs.size(); i++) {
-        const AggSpec &s = a->aggs[i];
-        if (s.func == SQLRS_AGG_COUNT) {
-          acc_of_agg[i] = cnt_of_col[(size_t)pidx[(size_t)s.argcol]];
-          continue;
-        }
-        if (spec.n_acc >= PART_MAX_ACC) { ok = false; break; }
-        const DCol &c = pcols[(size_t)pidx[(size_t)s.argcol]];
-        if (s.func != SQLRS_AGG_SUM && c.dtype != s.return_dtype) { ok = false; break; }
-        acc_of_agg[i] = spec.n_acc;
-        spec.op[spec.n_acc] = s.func == SQLRS_AGG_SUM ? (c.dtype == SQLRS_FLOAT64 ? PART_SUM_F64 : PART_SUM_I64)
-                              : s.func == SQLRS_AGG_MIN ? PART_MIN : PART_MAX;
-        spec.kind[spec.n_acc] = c.dtype == SQLRS_FLOAT64 ? 1 : 0;
-        spec.src[spec.n_acc++] = pidx[(size_t)s.argcol];
-      }
-      spec.nv = (int)pcols.size();
-      if (ok) {
-        PartAggInput pin;
-        pin.keys = nk.keys->as<uint64_t>();
-        pin.key_validity = nk.validity;
-        pin.n = n;
-        for (size_t k = 0; k < pcols.size(); k++) {
-          pin.vals[k] = pcols[k].values;
-          pin.val_validity[k] = (pcols[k].validity && pcols[k].null_count != 0) ? pcols[k].validity : nullptr;
-        }
-        PartAggOutput po;
-        flush_pending(a); // an older deferred batch must be in the table before this one
-        if (partitioned_preaggregate(ctx, spec, pin, (uint64_t)a->rows_seen, &po)) {
-          PendingGroups pg;
-          pg.active = true;
-          pg.exact = nk.exact;
-          pg.key_dtype = nk.dtype;
-          pg.cnt_of_col = cnt_of_col;
-          pg.acc_of_agg = acc_of_agg;
-          for (const AggSpec &s : a->aggs) pg.col_of_agg.push_back(pidx[(size_t)s.argcol]);
-          for (size_t k = 0; k < pcols.size(); k++) {
-            pg.col_nullable.push_back(pin.val_validity[k] != nullptr);
-            pg.col_dtype.push_back(pcols[k].dtype);
-          }
-          for (const DCol &kc : kcols) // key values of every group of the batch (hash_agg.rs:90-96)
-            pg.keyvals.push_back(gather_column(ctx, kc, po.gfirst->p, false, nullptr, po.groups));
-          pg.po = po;
-          if (a->st.ngroups == 0 && po.n_overflow == 0)
-            a->pending = std::move(pg); // nothing to merge with yet: defer building the table
-          else
-            merge_groups(a, pg);
-          // rows whose bucket table was full go through the row route
-          if (po.n_overflow) {
-            int64_t m = po.n_overflow;
-            DCol kc;
-            kc.dtype = SQLRS_UINT64;
-            kc.length = n;
-            kc.values = nk.keys->p;
-            kc.validity = nk.validity;
-            kc.null_count = nk.validity ? -1 : 0;
-            DCol sub = gather_column(ctx, kc, po.ov_rows->p, false, nullptr, m);
-            NKeys ok_;
-            ok_.rows = m;
-            ok_.keys = sub.own_values;
-            ok_.exact = nk.exact;
-            ok_.dtype = nk.dtype;
-            if (sub.validity) {
-              ok_.validity = sub.validity;
-              ok_.own_validity = sub.own_validity;
-            }
-            BufP rid = ctx->alloc(8 * (size_t)m);
-            rowid_from_u32_kernel<<<dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx->stream>>>(
-                po.ov_rows->as<uint32_t>(), m, (uint64_t)a->rows_seen, rid->as<uint64_t>());
-            SQ_HIP(hipGetLastError());
-            std::vector<DCol> sub_args;
-            for (const DCol &c : acols) sub_args.push_back(gather_column(ctx, c, po.ov_rows->p, false, nullptr, m));
-            int64_t nn2 = 0;
-            BufP rg2 = resolve_groups(a, ok_, rid->as<uint64_t>(), po.ov_rows->as<uint32_t>(), kcols, &nn2);
-            for (DCol &c : sub_args)
-              if (c.validity && c.null_count < 0) c.null_count = count_nulls(ctx, c);
-            update_from_rows(a, rg2->as<uint32_t>(), views_of(sub_args), m, nn2);
-          }
-          done = true;
-        }
-      }
-    }
-    // ---- row route ------------------------------------------------------------------
-    if (!done) {
-      flush_pending(a);
-      int64_t nnew = 0;
-      BufP row_gid = resolve_groups(a, nk, nullptr, nullptr, kcols, &nnew); // 3.2 (:85-110)
-      update_from_rows(a, row_gid->as<uint32_t>(), views_of(acols), n, nnew); // 4. (:113-121)
-    }
+    std::vector<DCol> acols = eval_arg_columns(a, colfn, n, 0);
+    agg_consume(a, n, kcols, nk, acols, nullptr);
     a->rows_seen += n;
     for (auto &d : a->distinct_aggs) {
       int st = sqlrs_hash_agg_push(d.dedup, in);
@@ -644,5 +681,127 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
 }
 
 void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *a) { delete a; }
+
+} // extern "C"
+
+// ============================================================ HashJoin + HashAgg fused ==
+#include "join_state.hpp"
+
+extern "C" {
+int sqlrs_hash_join_create(sqlrs_ctx_t *, int, int, const sqlrs_expr_t *, const sqlrs_expr_t *, const sqlrs_expr_t *,
+                           int, const int32_t *, sqlrs_hash_join_t **);
+int sqlrs_hash_join_build_push(sqlrs_hash_join_t *, const sqlrs_batch_t *);
+int sqlrs_hash_join_build_finish(sqlrs_hash_join_t *);
+int sqlrs_hash_join_probe_push(sqlrs_hash_join_t *, const sqlrs_batch_t *, int, sqlrs_batch_t **);
+void sqlrs_hash_join_destroy(sqlrs_hash_join_t *);
+void sqlrs_batch_release(sqlrs_batch_t *);
+}
+
+struct sqlrs_join_agg {
+  Ctx *ctx = nullptr;
+  sqlrs_hash_join *join = nullptr;
+  sqlrs_hash_agg *agg = nullptr;
+  int nleft = 0;
+  PartitionedRows build_parts; // build keys in bucket order (cache for the fused route)
+  int64_t fused_batches = 0, composed_batches = 0;
+  ~sqlrs_join_agg() {
+    if (join) sqlrs_hash_join_destroy(join);
+    delete agg;
+  }
+};
+
+extern "C" {
+
+int sqlrs_join_agg_create(sqlrs_ctx_t *ctx, int num_keys, const sqlrs_expr_t *left_keys,
+                          const sqlrs_expr_t *right_keys, int num_left_columns, int num_right_columns,
+                          const int32_t *right_dtypes, int num_group_by, const sqlrs_expr_t *group_by,
+                          int num_aggs, const sqlrs_agg_func_t *aggs, sqlrs_join_agg_t **out) {
+  return guard(ctx, [&] {
+    auto ja = std::unique_ptr<sqlrs_join_agg>(new sqlrs_join_agg());
+    ja->ctx = ctx;
+    ja->nleft = num_left_columns;
+    int st = sqlrs_hash_join_create(ctx, SQLRS_JOIN_INNER, num_keys, left_keys, right_keys, nullptr,
+                                    num_right_columns, right_dtypes, &ja->join);
+    if (st != SQLRS_OK) fail(st, ctx->last_error);
+    st = sqlrs_hash_agg_create(ctx, num_group_by, group_by, num_aggs, aggs, &ja->agg);
+    if (st != SQLRS_OK) fail(st, ctx->last_error);
+    *out = ja.release();
+  });
+}
+
+int sqlrs_join_agg_build_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *left) {
+  return sqlrs_hash_join_build_push(ja->join, left);
+}
+int sqlrs_join_agg_build_finish(sqlrs_join_agg_t *ja) { return sqlrs_hash_join_build_finish(ja->join); }
+
+// one probe batch: HashJoin probe (hash_join.rs:207-292) feeding HashAgg push (hash_agg.rs:44-122)
+int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
+  return guard(ja->ctx, [&] {
+    Ctx *ctx = ja->ctx;
+    SQ_HIP(hipSetDevice(ctx->device));
+    sqlrs_hash_join *j = ja->join;
+    sqlrs_hash_agg *a = ja->agg;
+    if (!j->finished) fail(SQLRS_ERR_INTERNAL, "probe before build_finish");
+    if (j->empty_build) return; // the join emits nothing (hash_join.rs:183-185)
+    // Fused route: Inner join on ONE exactly-compared key with unique build keys, grouped by
+    // that key, aggregate arguments taken from the probe side only.  Then every probe row
+    // yields at most one joined row and Agg(Join(build, probe)) = Agg(probe rows whose key
+    // has a build partner): the joined batch is never materialised.
+    bool eligible = j->unique && j->exact && j->lkeys.size() == 1 && j->lkeys[0].nodes.size() == 1 &&
+                    j->rkeys[0].nodes.size() == 1 && j->lkeys[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
+                    j->rkeys[0].nodes[0].op == SQLRS_EXPR_INPUT_REF && a->group_by.size() == 1 &&
+                    a->group_by[0].nodes.size() == 1 && a->group_by[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
+                    a->distinct_aggs.empty() && !a->strong_keys && right->num_rows >= (1ll << 16);
+    if (eligible) {
+      int lc = j->lkeys[0].nodes[0].index, rc = j->rkeys[0].nodes[0].index, g = a->group_by[0].nodes[0].index;
+      eligible = (g == lc || g == ja->nleft + rc);
+      for (const Expr &e : a->arg_exprs)
+        for (const auto &nd : e.nodes)
+          if (nd.op == SQLRS_EXPR_INPUT_REF && nd.index < ja->nleft) eligible = false;
+    }
+    if (eligible) {
+      InBatch ib(ctx, right);
+      auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
+      int64_t n = ib.rows();
+      std::vector<DCol> kcols{eval_expr(ctx, j->rkeys[0], colfn, n, true)};
+      NKeys nk = normalize_keys(ctx, kcols, n);
+      if (nk.exact && nk.dtype == j->key_dtype) {
+        if (!a->saw_batch) {
+          a->saw_batch = true;
+          a->key_dtypes.push_back(kcols[0].dtype);
+        }
+        std::vector<DCol> acols = eval_arg_columns(a, colfn, n, ja->nleft);
+        JoinSide js;
+        js.keys = j->bkeys->as<uint64_t>();
+        js.validity = j->bkeys_validity ? j->bkeys_validity->as<uint64_t>() : nullptr;
+        js.n = j->nB;
+        js.cache = &ja->build_parts;
+        if (agg_consume(a, n, kcols, nk, acols, &js)) {
+          a->rows_seen += n;
+          ja->fused_batches++;
+          return;
+        }
+      }
+    }
+    // composed route: materialise the joined batch on the device and aggregate it
+    sqlrs_batch_t *joined = nullptr;
+    int st = sqlrs_hash_join_probe_push(j, right, SQLRS_MEM_DEVICE, &joined);
+    if (st != SQLRS_OK) fail(st, ctx->last_error);
+    if (joined) {
+      st = sqlrs_hash_agg_push(a, joined);
+      std::string err = ctx->last_error;
+      sqlrs_batch_release(joined);
+      if (st != SQLRS_OK) fail(st, err);
+    }
+    ja->composed_batches++;
+  });
+}
+
+int sqlrs_join_agg_finish(sqlrs_join_agg_t *ja, int out_mem, sqlrs_batch_t **out) {
+  return sqlrs_hash_agg_finish(ja->agg, out_mem, out);
+}
+// number of probe batches that took the fused route (diagnostics / tests)
+int64_t sqlrs_join_agg_fused_batches(const sqlrs_join_agg_t *ja) { return ja->fused_batches; }
+void sqlrs_join_agg_destroy(sqlrs_join_agg_t *ja) { delete ja; }
 
 } // extern "C"

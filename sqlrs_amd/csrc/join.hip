@@ -279,26 +279,7 @@ __global__ void mark_bits_kernel(const I *__restrict__ idx, const uint64_t *__re
 
 using namespace sq;
 
-struct sqlrs_hash_join {
-  Ctx *ctx = nullptr;
-  int join_type = 0;
-  std::vector<Expr> lkeys, rkeys;
-  bool has_filter = false;
-  Expr filter;
-  std::vector<int32_t> right_dtypes;
-  // build
-  std::vector<DBatch> left_batches;
-  std::vector<NKeys> left_key_parts;
-  bool finished = false, empty_build = true;
-  DBatch left;
-  int64_t nB = 0;
-  BufP table;
-  uint64_t mask = 0;
-  bool unique = true, exact = true;
-  int32_t key_dtype = SQLRS_INT64;
-  BufP rows_by_slot;
-  BufP visited; // bit per build row
-};
+#include "join_state.hpp"
 
 namespace sq {
 
@@ -378,6 +359,8 @@ static void build_table(sqlrs_hash_join *j) {
     SQ_HIP(hipGetLastError());
   }
   j->unique = ctx->fetch_value(dup->as<int>()) == 0;
+  j->bkeys = keys; // kept for the fused join+aggregate route (hashagg_op.hip)
+  j->bkeys_validity = validity;
   if (!j->unique) {
     // CSR: head = exclusive scan of counts in slot order; rows stably sorted by slot
     ProfScope ps(ctx, "join_build_csr");

@@ -1,0 +1,29 @@
+// join_state.hpp — state of one HashJoinExecutor (join.hip); shared with the fused
+// join + aggregate operator in hashagg_op.hip.
+#pragma once
+
+#include "common.hpp"
+#include "prims.hpp"
+
+struct sqlrs_hash_join {
+  sq::Ctx *ctx = nullptr;
+  int join_type = 0;
+  std::vector<sq::Expr> lkeys, rkeys;
+  bool has_filter = false;
+  sq::Expr filter;
+  std::vector<int32_t> right_dtypes;
+  // build
+  std::vector<sq::DBatch> left_batches;
+  std::vector<sq::NKeys> left_key_parts;
+  bool finished = false, empty_build = true;
+  sq::DBatch left;
+  int64_t nB = 0;
+  sq::BufP table;
+  uint64_t mask = 0;
+  bool unique = true, exact = true;
+  int32_t key_dtype = SQLRS_INT64;
+  sq::BufP rows_by_slot;
+  sq::BufP visited; // bit per build row
+  sq::BufP bkeys, bkeys_validity; // normalised build keys (u64[nB]) and their validity bitmap
+};
+

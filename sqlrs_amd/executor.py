@@ -164,6 +164,55 @@ class HashAggExecutor:
             be.fn("hash_agg_destroy")(h)
 
 
+class HashJoinAggExecutor:
+    """``HashAggExecutor`` directly over an Inner ``HashJoinExecutor`` without join filter — the
+    physical rewrite of ``PhysicalHashAgg(PhysicalHashJoin(left, right))`` (hash_agg.rs:32-150
+    consuming hash_join.rs:146-323).  Same result as running the two operators back to back;
+    ``group_by`` / aggregate arguments index the join output schema (left columns, then right
+    columns).  HIP library only (the oracle composes the two operators)."""
+
+    def __init__(self, backend: abi.Backend, left_child: Iterable, right_child: Iterable,
+                 join_condition: JoinCondition, join_output_schema: pa.Schema, num_left_columns: int,
+                 agg_funcs: List[AggFunc], group_by: List[BoundExpr], out_mem: int = abi.MEM_HOST,
+                 output_names: Optional[Sequence[str]] = None):
+        self.backend = backend
+        self.left_child, self.right_child = left_child, right_child
+        self.join_condition, self.join_output_schema = join_condition, join_output_schema
+        self.num_left_columns = num_left_columns
+        self.agg_funcs, self.group_by = agg_funcs, group_by
+        self.out_mem, self.output_names = out_mem, output_names
+        self.fused_batches = 0
+
+    def execute(self):
+        be = self.backend
+        keep = []
+        lk, k1 = abi.pack_exprs([l for l, _ in self.join_condition.on])
+        rk, k2 = abi.pack_exprs([r for _, r in self.join_condition.on])
+        gb, k3 = abi.pack_exprs(self.group_by)
+        keep += [lk, rk, gb, k1, k2, k3]
+        aggs = (abi.AggFunc * max(len(self.agg_funcs), 1))(*[a.abi_struct(keep) for a in self.agg_funcs])
+        right_fields = list(self.join_output_schema)[self.num_left_columns:]
+        rd = (C.c_int32 * max(len(right_fields), 1))(*[abi.dtype_of(f.type) for f in right_fields])
+        h = C.c_void_p()
+        be.check(be.fn("join_agg_create")(be.ctx, len(self.join_condition.on), lk, rk, self.num_left_columns,
+                                          len(right_fields), rd, len(self.group_by), gb, len(self.agg_funcs),
+                                          aggs, C.byref(h)))
+        try:
+            for batch in self.left_child:
+                b = abi.as_batch(batch)  # keep the marshalled batch alive across the call
+                be.check(be.fn("join_agg_build_push")(h, b.ptr))
+            be.check(be.fn("join_agg_build_finish")(h))
+            for batch in self.right_child:
+                b = abi.as_batch(batch)
+                be.check(be.fn("join_agg_probe_push")(h, b.ptr))
+            out = C.POINTER(abi.Batch)()
+            be.check(be.fn("join_agg_finish")(h, self.out_mem, C.byref(out)))
+            self.fused_batches = be.fn("join_agg_fused_batches")(h)
+            yield _emit(be, out, self.out_mem, self.output_names)
+        finally:
+            be.fn("join_agg_destroy")(h)
+
+
 class OrderExecutor:
     """``OrderExecutor { order_by, child }`` (order.rs:8-11)."""
 

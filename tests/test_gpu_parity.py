@@ -345,3 +345,52 @@ def test_hash_agg_distinct(hip, oracle, n, groups, nulls):
     got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], bs).execute())
     exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], bs).execute())
     assert_same(got, exp, float_cols={2})
+
+
+# ------------------------------------------------------------ fused HashJoin + HashAgg --
+def _join_agg_reference(oracle, lbs, rbs, cond, sch, nleft, aggs, gb):
+    join = HashJoinExecutor(oracle, lbs, rbs, "inner", cond, sch, nleft)
+    return rows_of(HashAggExecutor(oracle, aggs, gb, join.execute()).execute())
+
+
+@pytest.mark.parametrize("nb,np_,keyrange,nulls,group_on_left", [
+    (1000, 140_000, 1500, 0.0, True), (5000, 200_000, 5000, 0.05, False), (300, 2_200_000, 600, 0.02, True),
+    (50_000, 300_000, 80_000, 0.0, True)])
+def test_join_agg_fused_route(hip, oracle, nb, np_, keyrange, nulls, group_on_left):
+    """Unique build keys, group by the join key, arguments from the probe side: the joined batch is
+    never materialised; result must equal HashAgg(HashJoin(..)) on the oracle incl. group order."""
+    from sqlrs_amd.executor import HashJoinAggExecutor
+    rng = np.random.default_rng(nb + np_)
+    lkeys = rng.permutation(keyrange)[:nb].astype(np.int64)
+    lmask = np.zeros(nb, bool)
+    if nulls:
+        lmask[0] = True  # one NULL build key: NULL = NULL matches (hash_utils.rs:91-104)
+    lb = pa.RecordBatch.from_arrays([pa.array(lkeys, mask=lmask), pa.array(rng.random(nb))], names=["c0", "c1"])
+    rb = batch(rng, np_, [("f64", nulls, 0, 1), ("i64", nulls, 0, keyrange), ("i64", nulls, -100, 100)])
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    sch = join_schema(lb, rb)
+    gb = [InputRef(0)] if group_on_left else [InputRef(2 + 1)]
+    aggs = [AggFunc("count", InputRef(2), abi.INT64), AggFunc("sum", InputRef(2), abi.FLOAT64),
+            AggFunc("max", InputRef(4), abi.INT64), AggFunc("min", InputRef(2), abi.FLOAT64)]
+    rbs = [rb.slice(0, np_ // 2), rb.slice(np_ // 2)]
+    ex = HashJoinAggExecutor(hip, [lb], rbs, cond, sch, 2, aggs, gb)
+    got = rows_of(ex.execute())
+    assert ex.fused_batches == 2
+    exp = _join_agg_reference(oracle, [lb], rbs, cond, sch, 2, aggs, gb)
+    assert_same(got, exp, float_cols={2, 4})
+
+
+def test_join_agg_composed_route(hip, oracle):
+    """Duplicate build keys / arguments from the build side: the library composes join + agg."""
+    from sqlrs_amd.executor import HashJoinAggExecutor
+    rng = np.random.default_rng(5)
+    lb = batch(rng, 3000, [("i64", 0.02, 0, 500), ("i64", 0.0, 0, 9)])
+    rb = batch(rng, 100_000, [("i64", 0.02, 0, 700), ("f64", 0.05, 0, 1)])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(1), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64)]
+    ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
+    got = rows_of(ex.execute())
+    assert ex.fused_batches == 0
+    exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
+    assert_same(got, exp, float_cols={3})
