@@ -310,6 +310,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
       bin.key_validity = in.join_validity;
       bin.n = in.join_n;
       bin.nv = 0;
+      bin.build_side = true;
       PartitionedRows *dst = in.join_cache ? in.join_cache : &local_build;
       if (!partition_rows(ctx, bin, P, dst) || dst->P != P) return false;
       bp = dst;

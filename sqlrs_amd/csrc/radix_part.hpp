@@ -13,6 +13,7 @@ struct PartitionInput {
   int nv = 0; // 8-byte value columns carried along (0..2)
   const void *vals[2] = {nullptr, nullptr};
   const uint64_t *val_validity[2] = {nullptr, nullptr};
+  bool build_side = false; // profiling label only
 };
 
 // Rows in bucket order: bucket b = rows [bstart[b], bstart[b+1]).  `idx` = original row,
