@@ -291,7 +291,8 @@ def main():
                 per_launch_ms = ms / launches
                 ach = ab / per_launch_ms / 1e6
                 roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
-                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                            "traffic": pmc_traffic(name, n_fact_total, n_dim_total, world, args),
                             "ms_per_launch": round(per_launch_ms, 4), "algorithmic_bytes": int(ab)}
                 break
 
@@ -325,6 +326,20 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, n_fact, n_dim, world, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01b_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc runs of this very
+    command).  Only valid for the default workload; otherwise null."""
+    if not (n_fact == 1_000_000_000 and n_dim == 10_000_000 and world == 1 and args.threshold == 0.5
+            and not args.unfused):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def bench_operators(be, abi, datagen, torch, dev, reps=3):
