@@ -162,98 +162,175 @@ __global__ __launch_bounds__(BLOCK) void join_fill_kernel(
 // each lane has 8 independent lookups in flight.
 constexpr int JP_ITEMS = 8;
 constexpr int JP_TILE = BLOCK * JP_ITEMS;
+constexpr uint32_t DENSE_EMPTY = 0xffffffffu;
+
+// Direct-address table for build keys that are unique and cover a small integer range (the
+// dense surrogate keys of a dimension table): heads[key - kmin] = build row.  4 bytes per
+// possible key instead of a 16-byte hash slot at load factor <= 2/3: a 1e6-key dimension needs
+// 4 MiB, which one XCD's L2 holds (265 G lookups/s instead of 66 G/s, profiles/r01_ubench).
+struct DenseTable {
+  const uint32_t *heads;
+  uint64_t kmin, range;
+  uint32_t null_head; // build row whose key is NULL (NULL = NULL matches) or DENSE_EMPTY
+};
+
+template <bool DENSE>
 __global__ __launch_bounds__(BLOCK) void join_probe_unique_kernel(
     const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n,
-    int64_t num_tiles, const Slot *__restrict__ table, uint64_t mask, uint64_t *__restrict__ left_idx,
-    uint32_t *__restrict__ right_idx, uint64_t *desc, unsigned *ticket, uint64_t *total) {
+    int64_t num_tiles, const Slot *__restrict__ table, uint64_t mask, DenseTable dt,
+    uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx, uint64_t *desc, unsigned *ticket,
+    uint64_t *total, int use_ticket) {
+  unsigned *timeout = use_ticket ? nullptr : ticket + 1;
   __shared__ int64_t s_tile;
   __shared__ uint32_t s_wave[WAVES_PER_BLOCK];
   __shared__ uint64_t s_excl;
-  if (threadIdx.x == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);
+  // one ticket buys LB_TILES_PER_TICKET consecutive tiles (a single atomic counter sustains only
+  // ~88 tickets/us: a ticket per 2048-row tile would cost >= 0.55 ms per 1e8 probe rows)
+  if (threadIdx.x == 0) s_tile = use_ticket ? (int64_t)atomicAdd(ticket, 1u) : (int64_t)blockIdx.x;
   __syncthreads();
-  const int64_t tile = s_tile;
+  const int64_t tile0 = s_tile;
   const int lane = lane_id(), w = wave_id();
-  const int64_t wrow = tile * JP_TILE + (int64_t)w * (64 * JP_ITEMS);
-  uint64_t k[JP_ITEMS];
-  bool isnull[JP_ITEMS];
-#pragma unroll
-  for (int j = 0; j < JP_ITEMS; j++) {
-    int64_t r = wrow + j * 64 + lane;
-    k[j] = (r < n) ? __builtin_nontemporal_load(&keys[r]) : 0; // streamed once: keep the table cached
-    isnull[j] = (r < n) && validity && !((validity[r >> 6] >> (r & 63)) & 1);
-  }
-  // first probe of all 8 rows issued back to back (8 independent 16-byte loads in flight per
-  // lane); only the rare collision chains continue one at a time
   const uint64_t cap = mask + 1;
-  uint64_t slot[JP_ITEMS];
-  Slot sl[JP_ITEMS];
+  for (int sub = 0; sub < LB_TILES_PER_TICKET; sub++) {
+    const int64_t tile = tile0 + sub;
+    if (tile >= num_tiles) break;
+    const int64_t wrow = tile * JP_TILE + (int64_t)w * (64 * JP_ITEMS);
+    uint64_t k[JP_ITEMS];
+    bool isnull[JP_ITEMS];
 #pragma unroll
-  for (int j = 0; j < JP_ITEMS; j++) {
-    slot[j] = isnull[j] ? cap : (k[j] == EMPTY_KEY ? cap + 1 : (mix64(k[j]) & mask));
-    sl[j] = load_slot(&table[slot[j]]);
-  }
-  uint32_t head[JP_ITEMS];
-  uint64_t m[JP_ITEMS];
-  uint32_t wave_cnt = 0;
+    for (int j = 0; j < JP_ITEMS; j++) {
+      int64_t r = wrow + j * 64 + lane;
+      k[j] = (r < n) ? __builtin_nontemporal_load(&keys[r]) : 0; // streamed once: keep the table cached
+      isnull[j] = (r < n) && validity && !((validity[r >> 6] >> (r & 63)) & 1);
+    }
+    uint32_t head[JP_ITEMS];
+    uint64_t m[JP_ITEMS];
+    uint32_t wave_cnt = 0;
+    if (DENSE) {
 #pragma unroll
-  for (int j = 0; j < JP_ITEMS; j++) {
-    int64_t r = wrow + j * 64 + lane;
-    bool hit = false;
-    if (r < n) {
-      if (slot[j] >= cap) {
-        hit = sl[j].count != 0; // reserved slots: NULL keys / key == EMPTY_KEY
-      } else {
-        while (sl[j].key != k[j] && sl[j].key != EMPTY_KEY) {
-          slot[j] = (slot[j] + 1) & mask;
-          sl[j] = load_slot(&table[slot[j]]);
+      for (int j = 0; j < JP_ITEMS; j++) { // 8 independent 4-byte loads in flight per lane
+        int64_t r = wrow + j * 64 + lane;
+        uint64_t d = k[j] - dt.kmin;
+        head[j] = DENSE_EMPTY;
+        if (r < n) head[j] = isnull[j] ? dt.null_head : (d < dt.range ? dt.heads[d] : DENSE_EMPTY);
+      }
+#pragma unroll
+      for (int j = 0; j < JP_ITEMS; j++) {
+        m[j] = __ballot(head[j] != DENSE_EMPTY);
+        wave_cnt += (uint32_t)__popcll(m[j]);
+      }
+    } else {
+      // first probe of all 8 rows issued back to back (8 independent 16-byte loads in flight per
+      // lane); only the rare collision chains continue one at a time
+      uint64_t slot[JP_ITEMS];
+      Slot sl[JP_ITEMS];
+#pragma unroll
+      for (int j = 0; j < JP_ITEMS; j++) {
+        slot[j] = isnull[j] ? cap : (k[j] == EMPTY_KEY ? cap + 1 : (mix64(k[j]) & mask));
+        sl[j] = load_slot(&table[slot[j]]);
+      }
+#pragma unroll
+      for (int j = 0; j < JP_ITEMS; j++) {
+        int64_t r = wrow + j * 64 + lane;
+        bool hit = false;
+        if (r < n) {
+          if (slot[j] >= cap) {
+            hit = sl[j].count != 0; // reserved slots: NULL keys / key == EMPTY_KEY
+          } else {
+            while (sl[j].key != k[j] && sl[j].key != EMPTY_KEY) {
+              slot[j] = (slot[j] + 1) & mask;
+              sl[j] = load_slot(&table[slot[j]]);
+            }
+            hit = sl[j].key == k[j];
+          }
         }
-        hit = sl[j].key == k[j];
+        head[j] = sl[j].head;
+        m[j] = __ballot(hit);
+        wave_cnt += (uint32_t)__popcll(m[j]);
       }
     }
-    head[j] = sl[j].head;
-    m[j] = __ballot(hit);
-    wave_cnt += (uint32_t)__popcll(m[j]);
-  }
-  if (lane == 0) s_wave[w] = wave_cnt;
-  __syncthreads();
-  if (w == 0) {
-    uint64_t agg = (uint64_t)s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    uint64_t excl = lookback_wave(desc, tile, agg);
-    if (lane == 0) {
-      s_excl = excl;
-      if (tile == num_tiles - 1) *total = excl + agg;
+    if (lane == 0) s_wave[w] = wave_cnt;
+    __syncthreads();
+    if (w == 0) {
+      uint64_t agg = (uint64_t)s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+      uint64_t excl = lookback_wave(desc, tile, agg, timeout);
+      if (lane == 0) {
+        s_excl = excl;
+        if (tile == num_tiles - 1) *total = excl + agg;
+      }
     }
-  }
-  __syncthreads();
-  uint64_t pos = s_excl;
-  for (int q = 0; q < w; q++) pos += s_wave[q];
+    __syncthreads();
+    uint64_t pos = s_excl;
+    for (int q = 0; q < w; q++) pos += s_wave[q];
 #pragma unroll
-  for (int j = 0; j < JP_ITEMS; j++) {
-    if ((m[j] >> lane) & 1) {
-      uint64_t o = pos + mbcnt(m[j]);
-      __builtin_nontemporal_store((uint64_t)head[j], &left_idx[o]);
-      __builtin_nontemporal_store((uint32_t)(wrow + j * 64 + lane), &right_idx[o]);
+    for (int j = 0; j < JP_ITEMS; j++) {
+      if ((m[j] >> lane) & 1) {
+        uint64_t o = pos + mbcnt(m[j]);
+        __builtin_nontemporal_store((uint64_t)head[j], &left_idx[o]);
+        __builtin_nontemporal_store((uint32_t)(wrow + j * 64 + lane), &right_idx[o]);
+      }
+      pos += (uint32_t)__popcll(m[j]);
     }
-    pos += (uint32_t)__popcll(m[j]);
+    __syncthreads(); // s_wave / s_excl are reused by the next tile
   }
 }
 
 // UNIQUE build keys, Right/Full: every probe row emits exactly one pair (hash_join.rs:235-247)
+template <bool DENSE>
 __global__ __launch_bounds__(BLOCK) void join_probe_unique_outer_kernel(
     const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n,
-    const Slot *__restrict__ table, uint64_t mask, uint64_t *__restrict__ left_idx,
+    const Slot *__restrict__ table, uint64_t mask, DenseTable dt, uint64_t *__restrict__ left_idx,
     uint32_t *__restrict__ right_idx, uint64_t *__restrict__ left_validity) {
   int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   bool hit = false;
   if (r < n) {
     bool is_null = validity && !((validity[r >> 6] >> (r & 63)) & 1);
-    Slot s = probe_slot(table, mask, keys[r], is_null);
-    hit = s.count != 0;
-    left_idx[r] = hit ? s.head : 0;
+    uint32_t h;
+    if (DENSE) {
+      uint64_t d = keys[r] - dt.kmin;
+      h = is_null ? dt.null_head : (d < dt.range ? dt.heads[d] : DENSE_EMPTY);
+      hit = h != DENSE_EMPTY;
+    } else {
+      Slot s = probe_slot(table, mask, keys[r], is_null);
+      hit = s.count != 0;
+      h = s.head;
+    }
+    left_idx[r] = hit ? h : 0;
     right_idx[r] = (uint32_t)r;
   }
   uint64_t mm = __ballot(hit);
   if (lane_id() == 0 && r < n) left_validity[r >> 6] = mm;
+}
+
+// min / max of the valid build keys as signed integers (dense-range detection)
+__global__ void key_minmax_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
+                                  int64_t n, unsigned long long *mn, unsigned long long *mx) {
+  unsigned long long lo = ~0ull, hi = 0;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+    if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) continue;
+    unsigned long long u = i64_to_ordered((int64_t)keys[r]);
+    lo = u < lo ? u : lo;
+    hi = u > hi ? u : hi;
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    unsigned long long a = shfl_xor_u64(lo, m), b = shfl_xor_u64(hi, m);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  if (lane_id() == 0) {
+    atomicMin(mn, lo);
+    atomicMax(mx, hi);
+  }
+}
+__global__ void dense_fill_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
+                                  int64_t n, uint64_t kmin, uint32_t *__restrict__ heads, uint32_t *null_head) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) {
+    *null_head = (uint32_t)r; // unique build keys: at most one NULL row
+    return;
+  }
+  heads[keys[r] - kmin] = (uint32_t)r;
 }
 
 __global__ void bytes_to_bits_kernel(const uint8_t *__restrict__ bytes, int64_t n,
@@ -361,6 +438,36 @@ static void build_table(sqlrs_hash_join *j) {
   j->unique = ctx->fetch_value(dup->as<int>()) == 0;
   j->bkeys = keys; // kept for the fused join+aggregate route (hashagg_op.hip)
   j->bkeys_validity = validity;
+  if (j->unique && j->exact && n > 0 && j->key_dtype != SQLRS_FLOAT64) {
+    // dense surrogate keys?  (range <= 4 x rows and < 2^31)  -> direct-address table
+    BufP mm = ctx->alloc(16);
+    uint64_t init[2] = {~0ull, 0ull};
+    SQ_HIP(hipMemcpyAsync(mm->p, init, 16, hipMemcpyHostToDevice, ctx->stream));
+    ctx->sync();
+    const uint64_t *vp = validity ? validity->as<uint64_t>() : nullptr;
+    unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256), 1024);
+    key_minmax_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n,
+                                                                  mm->as<unsigned long long>(),
+                                                                  mm->as<unsigned long long>() + 1);
+    SQ_HIP(hipGetLastError());
+    const uint64_t *h = (const uint64_t *)ctx->fetch(mm->p, 16);
+    uint64_t lo = h[0], hi = h[1];
+    if (lo <= hi) {
+      uint64_t range = hi - lo + 1; // ordered images differ like the signed values
+      if (range <= 4 * (uint64_t)n + 1024 && range < (1ull << 31)) {
+        ProfScope ps(ctx, "join_build_dense");
+        j->dense = ctx->alloc(4 * (size_t)range + 8);
+        SQ_HIP(hipMemsetAsync(j->dense->p, 0xff, 4 * (size_t)range + 8, ctx->stream));
+        j->dense_min = lo ^ (1ull << 63); // back from the ordered image to the two's complement bits
+        j->dense_range = range;
+        uint32_t *null_head = j->dense->as<uint32_t>() + range; // spare slot after the table
+        dense_fill_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
+            keys->as<uint64_t>(), vp, n, j->dense_min, j->dense->as<uint32_t>(), null_head);
+        SQ_HIP(hipGetLastError());
+        j->dense_null_head = ctx->fetch_value(null_head);
+      }
+    }
+  }
   if (!j->unique) {
     // CSR: head = exclusive scan of counts in slot order; rows stably sorted by slot
     ProfScope ps(ctx, "join_build_csr");
@@ -405,14 +512,26 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 16);
     unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
     uint64_t *tot = desc->as<uint64_t>() + tiles + 1;
-    {
-      ProfScope ps(ctx, "join_probe_unique");
-      join_probe_unique_kernel<<<dim3((unsigned)tiles), b, 0, ctx->stream>>>(
-          pk.keys->as<uint64_t>(), pk.validity, n, tiles, j->table->as<Slot>(), j->mask,
-          p.left->as<uint64_t>(), p.right->as<uint32_t>(), desc->as<uint64_t>(), ticket, tot);
-      SQ_HIP(hipGetLastError());
+    for (int use_ticket = 0; use_ticket < 2; use_ticket++) {
+      if (use_ticket) SQ_HIP(hipMemsetAsync(desc->p, 0, 8 * (size_t)tiles + 16, ctx->stream));
+      {
+        ProfScope ps(ctx, j->dense ? "join_probe_dense" : "join_probe_unique");
+        dim3 gt((unsigned)tiles);
+        DenseTable dt{j->dense ? j->dense->as<uint32_t>() : nullptr, j->dense_min, j->dense_range, j->dense_null_head};
+        if (j->dense)
+          join_probe_unique_kernel<true><<<gt, b, 0, ctx->stream>>>(
+              pk.keys->as<uint64_t>(), pk.validity, n, tiles, j->table->as<Slot>(), j->mask, dt,
+              p.left->as<uint64_t>(), p.right->as<uint32_t>(), desc->as<uint64_t>(), ticket, tot, use_ticket);
+        else
+          join_probe_unique_kernel<false><<<gt, b, 0, ctx->stream>>>(
+              pk.keys->as<uint64_t>(), pk.validity, n, tiles, j->table->as<Slot>(), j->mask, dt,
+              p.left->as<uint64_t>(), p.right->as<uint32_t>(), desc->as<uint64_t>(), ticket, tot, use_ticket);
+        SQ_HIP(hipGetLastError());
+      }
+      const uint64_t *h = (const uint64_t *)ctx->fetch(ticket, 16); // {ticket|timeout, total}
+      p.m = (int64_t)h[1];
+      if (use_ticket || (h[0] >> 32) == 0) break;
     }
-    p.m = (int64_t)ctx->fetch_value(tot);
     return p;
   }
   if (j->unique && outer_right) { // exactly one pair per probe row
@@ -422,9 +541,15 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     p.left_validity = ctx->alloc(bitmap_bytes(n));
     ProfScope ps(ctx, "join_probe_unique");
     int64_t n64 = (int64_t)round_up((size_t)n, 64);
-    join_probe_unique_outer_kernel<<<dim3((unsigned)ceil_div(n64, BLOCK)), b, 0, ctx->stream>>>(
-        pk.keys->as<uint64_t>(), pk.validity, n, j->table->as<Slot>(), j->mask, p.left->as<uint64_t>(),
-        p.right->as<uint32_t>(), p.left_validity->as<uint64_t>());
+    DenseTable dt{j->dense ? j->dense->as<uint32_t>() : nullptr, j->dense_min, j->dense_range, j->dense_null_head};
+    if (j->dense)
+      join_probe_unique_outer_kernel<true><<<dim3((unsigned)ceil_div(n64, BLOCK)), b, 0, ctx->stream>>>(
+          pk.keys->as<uint64_t>(), pk.validity, n, j->table->as<Slot>(), j->mask, dt, p.left->as<uint64_t>(),
+          p.right->as<uint32_t>(), p.left_validity->as<uint64_t>());
+    else
+      join_probe_unique_outer_kernel<false><<<dim3((unsigned)ceil_div(n64, BLOCK)), b, 0, ctx->stream>>>(
+          pk.keys->as<uint64_t>(), pk.validity, n, j->table->as<Slot>(), j->mask, dt, p.left->as<uint64_t>(),
+          p.right->as<uint32_t>(), p.left_validity->as<uint64_t>());
     SQ_HIP(hipGetLastError());
     return p;
   }

@@ -24,6 +24,9 @@ struct sqlrs_hash_join {
   int32_t key_dtype = SQLRS_INT64;
   sq::BufP rows_by_slot;
   sq::BufP visited; // bit per build row
+  sq::BufP dense;              // direct-address table (u32 build row per key - dense_min) or null
+  uint64_t dense_min = 0, dense_range = 0;
+  uint32_t dense_null_head = 0xffffffffu;
   sq::BufP bkeys, bkeys_validity; // normalised build keys (u64[nB]) and their validity bitmap
 };
 

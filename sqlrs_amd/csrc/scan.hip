@@ -15,10 +15,15 @@ __global__ __launch_bounds__(BLOCK) void scan_u32_kernel(const uint32_t *__restr
   __shared__ int64_t s_tile;
   __shared__ uint64_t s_wave[WAVES_PER_BLOCK];
   __shared__ uint64_t s_excl;
-  if (threadIdx.x == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);
+  // one ticket per LB_TILES_PER_TICKET consecutive tiles (a single atomic counter sustains only
+  // ~88 tickets/us on MI355X)
+  if (threadIdx.x == 0) s_tile = (int64_t)atomicAdd(ticket, 1u) * LB_TILES_PER_TICKET;
   __syncthreads();
-  const int64_t tile = s_tile;
+  const int64_t tile0 = s_tile;
   const int lane = lane_id(), w = wave_id();
+  for (int sub = 0; sub < LB_TILES_PER_TICKET; sub++) {
+  const int64_t tile = tile0 + sub;
+  if (tile >= num_tiles) break;
   const int64_t wbase = tile * 4096 + (int64_t)w * 1024;
   uint32_t v[4][4];
   uint32_t lane_excl[4]; // exclusive prefix of this lane's uint4 within the wave's 1024
@@ -64,6 +69,8 @@ __global__ __launch_bounds__(BLOCK) void scan_u32_kernel(const uint32_t *__restr
       p += v[c][k];
     }
   }
+  __syncthreads(); // s_wave / s_excl are reused by the next tile
+  } // sub
 }
 
 void exclusive_scan_u32(Ctx *ctx, const uint32_t *in, int64_t n, uint64_t *out64, uint32_t *out32,
@@ -76,7 +83,7 @@ void exclusive_scan_u32(Ctx *ctx, const uint32_t *in, int64_t n, uint64_t *out64
   int64_t tiles = ceil_div(n, 4096);
   BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 8);
   unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
-  scan_u32_kernel<<<dim3((unsigned)tiles), dim3(BLOCK), 0, ctx->stream>>>(
+  scan_u32_kernel<<<dim3((unsigned)ceil_div(tiles, LB_TILES_PER_TICKET)), dim3(BLOCK), 0, ctx->stream>>>(
       in, n, out64, out32, desc->as<uint64_t>(), ticket, total, tiles);
   SQ_HIP(hipGetLastError());
 }

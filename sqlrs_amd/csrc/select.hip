@@ -31,16 +31,24 @@ __global__ __launch_bounds__(BLOCK) void tile_offsets_kernel(const uint64_t *__r
                                                              uint64_t *total) {
   const int lane = lane_id();
   unsigned t = 0;
-  if (lane == 0) t = atomicAdd(ticket, 1u);
-  int64_t tile = (int64_t)(unsigned)__shfl((int)t, 0, 64);
-  if (tile >= num_tiles) return;
-  int64_t w = tile * TILE_WORDS + lane;
-  uint64_t m = (w < nwords) ? bits[w] : 0ull;
-  uint64_t agg = wave_sum_u64((uint64_t)__popcll(m));
-  uint64_t excl = lookback_wave(desc, tile, agg);
-  if (lane == 0) {
-    tile_off[tile] = excl;
-    if (tile == num_tiles - 1) *total = excl + agg;
+  if (lane == 0) t = atomicAdd(ticket, 1u); // one ticket per wave buys 8 consecutive tiles
+  int64_t tile0 = (int64_t)(unsigned)__shfl((int)t, 0, 64) * LB_TILES_PER_TICKET;
+  uint64_t m[LB_TILES_PER_TICKET];
+#pragma unroll
+  for (int sub = 0; sub < LB_TILES_PER_TICKET; sub++) {
+    int64_t w = (tile0 + sub) * TILE_WORDS + lane;
+    m[sub] = (w < nwords) ? bits[w] : 0ull;
+  }
+#pragma unroll
+  for (int sub = 0; sub < LB_TILES_PER_TICKET; sub++) {
+    int64_t tile = tile0 + sub;
+    if (tile >= num_tiles) return;
+    uint64_t agg = wave_sum_u64((uint64_t)__popcll(m[sub]));
+    uint64_t excl = lookback_wave(desc, tile, agg);
+    if (lane == 0) {
+      tile_off[tile] = excl;
+      if (tile == num_tiles - 1) *total = excl + agg;
+    }
   }
 }
 
@@ -57,7 +65,7 @@ void selection_finish(Ctx *ctx, Selection &s) {
   {
     ProfScope ps(ctx, "tile_offsets");
     int64_t nwords = ceil_div(s.rows, 64);
-    unsigned blocks = (unsigned)ceil_div(tiles, WAVES_PER_BLOCK);
+    unsigned blocks = (unsigned)ceil_div(ceil_div(tiles, LB_TILES_PER_TICKET), WAVES_PER_BLOCK);
     tile_offsets_kernel<<<dim3(blocks), dim3(BLOCK), 0, ctx->stream>>>(
         s.bits, nwords, tiles, s.tile_off->as<uint64_t>(), desc->as<uint64_t>(), ticket, total);
     SQ_HIP(hipGetLastError());
@@ -277,17 +285,24 @@ template <class T, int OP>
 __global__ __launch_bounds__(BLOCK) void filter_cmp_const_kernel(
     const T *__restrict__ in, const uint64_t *__restrict__ validity, T k, int64_t rows,
     int64_t num_tiles, T *__restrict__ out, uint64_t *__restrict__ sel_bits,
-    uint64_t *__restrict__ tile_off, uint64_t *desc, unsigned *ticket, uint64_t *total) {
+    uint64_t *__restrict__ tile_off, uint64_t *desc, unsigned *ticket, uint64_t *total, int use_ticket) {
   __shared__ int64_t s_tile;
   __shared__ uint32_t s_wave[WAVES_PER_BLOCK];
   __shared__ uint64_t s_excl;
-  if (threadIdx.x == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);
+  unsigned *timeout = use_ticket ? nullptr : ticket + 1; // word after the ticket counter
+  // One atomic ticket buys LB_TILES_PER_TICKET consecutive tiles: a single counter sustains
+  // only ~88 tickets/us on MI355X (MI355X_MICROARCH.md "dequeue"), so a ticket per 4096-row
+  // tile would cap a 1e8-row filter at ~0.28 ms by itself.
+  if (threadIdx.x == 0) s_tile = use_ticket ? (int64_t)atomicAdd(ticket, 1u) : (int64_t)blockIdx.x;
   __syncthreads();
-  const int64_t tile = s_tile;
+  const int64_t tile0 = s_tile;
   const int lane = lane_id(), w = wave_id();
+  const auto kk = CmpKey<T>::key(k);
+  for (int sub = 0; sub < LB_TILES_PER_TICKET; sub++) {
+  const int64_t tile = tile0 + sub;
+  if (tile >= num_tiles) break;
   const int64_t wrow = tile * TILE_ROWS + (int64_t)w * 1024;
   const int64_t wword = tile * TILE_WORDS + w * 16;
-  const auto kk = CmpKey<T>::key(k);
   T v[16];
 #pragma unroll
   for (int j = 0; j < 16; j++) {
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(BLOCK) void filter_cmp_const_kernel(
   __syncthreads();
   if (w == 0) {
     uint64_t agg = (uint64_t)s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    uint64_t excl = lookback_wave(desc, tile, agg);
+    uint64_t excl = lookback_wave(desc, tile, agg, timeout);
     if (lane == 0) {
       s_excl = excl;
       if (tile_off) tile_off[tile] = excl;
@@ -337,19 +352,21 @@ __global__ __launch_bounds__(BLOCK) void filter_cmp_const_kernel(
     if ((m[j] >> lane) & 1) out[pos + mbcnt(m[j])] = v[j];
     pos += (uint32_t)__popcll(m[j]);
   }
+  __syncthreads(); // s_wave / s_excl are reused by the next tile
+  } // sub
 }
 
 template <class T>
 static void launch_filter(Ctx *ctx, int op, const DCol &c, T k, int64_t rows, T *out,
                           uint64_t *sel_bits, uint64_t *tile_off, uint64_t *desc, unsigned *ticket,
-                          uint64_t *total) {
+                          uint64_t *total, int use_ticket) {
   int64_t tiles = ceil_div(rows, TILE_ROWS);
-  dim3 g((unsigned)tiles), b(BLOCK);
+  dim3 g((unsigned)ceil_div(tiles, LB_TILES_PER_TICKET)), b(BLOCK);
   const T *in = c.v<T>();
   const uint64_t *val = c.validity;
 #define SQ_LAUNCH(OP)                                                                              \
   filter_cmp_const_kernel<T, OP><<<g, b, 0, ctx->stream>>>(in, val, k, rows, tiles, out, sel_bits, \
-                                                           tile_off, desc, ticket, total)
+                                                           tile_off, desc, ticket, total, use_ticket)
   switch (op) {
   case CMP_GT: SQ_LAUNCH(CMP_GT); break;
   case CMP_LT: SQ_LAUNCH(CMP_LT); break;
@@ -384,20 +401,26 @@ bool filter_fast_path(Ctx *ctx, const Expr &e, const std::function<const DCol &(
   size_t w = width_of(c.dtype);
   // worst case every row is kept: output sized for `rows` (288 GB of HBM: no second pass)
   BufP out = ctx->alloc(w * (size_t)rows + 16);
-  {
-    ProfScope ps(ctx, "filter_cmp_const");
-    uint64_t *sb = sel->own_bits->as<uint64_t>(), *to = sel->tile_off->as<uint64_t>();
-    if (c.dtype == SQLRS_INT64)
-      launch_filter<int64_t>(ctx, op, c, (int64_t)b.i, rows, out->as<int64_t>(), sb, to,
-                             desc->as<uint64_t>(), ticket, total);
-    else if (c.dtype == SQLRS_INT32)
-      launch_filter<int32_t>(ctx, op, c, (int32_t)b.i, rows, out->as<int32_t>(), sb, to,
-                             desc->as<uint64_t>(), ticket, total);
-    else
-      launch_filter<double>(ctx, op, c, b.f, rows, out->as<double>(), sb, to,
-                            desc->as<uint64_t>(), ticket, total);
+  // desc layout: [tiles descriptors][ticket u32, timeout u32][total u64]
+  for (int use_ticket = 0; use_ticket < 2; use_ticket++) {
+    if (use_ticket) SQ_HIP(hipMemsetAsync(desc->p, 0, 8 * (size_t)tiles + 16, ctx->stream));
+    {
+      ProfScope ps(ctx, "filter_cmp_const");
+      uint64_t *sb = sel->own_bits->as<uint64_t>(), *to = sel->tile_off->as<uint64_t>();
+      if (c.dtype == SQLRS_INT64)
+        launch_filter<int64_t>(ctx, op, c, (int64_t)b.i, rows, out->as<int64_t>(), sb, to,
+                               desc->as<uint64_t>(), ticket, total, use_ticket);
+      else if (c.dtype == SQLRS_INT32)
+        launch_filter<int32_t>(ctx, op, c, (int32_t)b.i, rows, out->as<int32_t>(), sb, to,
+                               desc->as<uint64_t>(), ticket, total, use_ticket);
+      else
+        launch_filter<double>(ctx, op, c, b.f, rows, out->as<double>(), sb, to,
+                              desc->as<uint64_t>(), ticket, total, use_ticket);
+    }
+    const uint64_t *h = (const uint64_t *)ctx->fetch(ticket, 16); // {ticket|timeout, total}
+    sel->count = (int64_t)h[1];
+    if (use_ticket || (h[0] >> 32) == 0) break; // no look-back timeout: done
   }
-  sel->count = (int64_t)ctx->fetch_value(total);
   *col_index = a.index;
   out_col->dtype = c.dtype;
   out_col->length = sel->count;
