@@ -10,6 +10,8 @@
 // Per level:  hist (8 B/row read: keys) -> exclusive scan of the [segment][digit][tile] count
 // matrix = start of every run -> scatter (all columns read once, written once).
 // Level 2 splits every level-1 bucket again (MSD order), giving up to 65536 buckets.
+#include <cstdlib>
+
 #include "device_utils.hpp"
 #include "radix_part.hpp"
 
@@ -82,11 +84,50 @@ struct RpOut {
   uint8_t *flags; // null when no column is nullable
 };
 
+// rows of one tile held in registers (one struct per pipeline stage)
+template <int NV, int RP_ROWS> struct TileRegs {
+  uint64_t k[RP_ROWS], a0[NV >= 1 ? RP_ROWS : 1], a1[NV >= 2 ? RP_ROWS : 1];
+  uint32_t id[RP_ROWS];
+  uint8_t fl[RP_ROWS]; // 0xff = no row
+};
+
+template <int NV, int RP_WG, int RP_ROWS>
+__device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, TileRegs<NV, RP_ROWS> &r) {
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) {
+    uint32_t o = j * RP_WG + threadIdx.x;
+    r.fl[j] = 0xff;
+    if (o < t.len) {
+      int64_t row = t.start + o;
+      r.k[j] = in.key[row];
+      if (NV >= 1) r.a0[j] = in.v0[row];
+      if (NV >= 2) r.a1[j] = in.v1[row];
+      if (in.idx) {
+        r.id[j] = in.idx[row];
+        r.fl[j] = in.flags ? in.flags[row] : 7;
+      } else {
+        r.id[j] = (uint32_t)row;
+        uint8_t f = 0;
+        if (!in.key_validity || ((in.key_validity[row >> 6] >> (row & 63)) & 1)) f |= 1;
+        if (!in.v0_validity || ((in.v0_validity[row >> 6] >> (row & 63)) & 1)) f |= 2;
+        if (!in.v1_validity || ((in.v1_validity[row >> 6] >> (row & 63)) & 1)) f |= 4;
+        r.fl[j] = f;
+      }
+    }
+  }
+}
+
+// Persistent workgroups: workgroup b owns the CONTIGUOUS tile range [b*tpw, (b+1)*tpw) (so the
+// partial cache lines shared by neighbouring tiles' runs meet in one L2) and software-pipelines
+// it: the rows of tile i+1 are loaded into a second register set before tile i goes through its
+// LDS phases (rank with LDS atomics -> scan -> stage sorted -> coalesced stores), which hides the
+// HBM latency that a 150 KiB-LDS kernel (one workgroup per CU) cannot hide with occupancy.
 template <int NV, int RP_WG, int RP_ROWS>
 __global__ __launch_bounds__(RP_WG) void rp_scatter_kernel(RpIn in, RpOut out,
                                                            const Tile *__restrict__ tiles, uint32_t P,
                                                            uint32_t p2_bits, int level, uint32_t digits,
-                                                           const uint32_t *__restrict__ offs) {
+                                                           const uint32_t *__restrict__ offs,
+                                                           uint32_t num_tiles, uint32_t tiles_per_wg) {
   constexpr int RP_TILE = RP_WG * RP_ROWS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t *skey = (uint64_t *)smem;
@@ -100,76 +141,70 @@ __global__ __launch_bounds__(RP_WG) void rp_scatter_kernel(RpIn in, RpOut out,
   int64_t *gbase = (int64_t *)(lstart + RP_WG);  // [RP_WG]
   __shared__ uint32_t s_wsum[RP_WG / 64];
 
-  const Tile t = tiles[xcd_tile(blockIdx.x, gridDim.x)];
-  cnt[threadIdx.x] = 0;
-  __syncthreads();
-  uint64_t k[RP_ROWS], a0[RP_ROWS], a1[RP_ROWS];
-  uint32_t id[RP_ROWS], dg[RP_ROWS], rk[RP_ROWS];
-  uint8_t fl[RP_ROWS];
-#pragma unroll
-  for (int j = 0; j < RP_ROWS; j++) {
-    uint32_t o = j * RP_WG + threadIdx.x;
-    dg[j] = 0xffffffffu;
-    if (o < t.len) {
-      int64_t r = t.start + o;
-      k[j] = in.key[r];
-      if (NV >= 1) a0[j] = in.v0[r];
-      if (NV >= 2) a1[j] = in.v1[r];
-      if (in.idx) {
-        id[j] = in.idx[r];
-        fl[j] = in.flags ? in.flags[r] : 7;
-      } else {
-        id[j] = (uint32_t)r;
-        uint8_t f = 0;
-        if (!in.key_validity || ((in.key_validity[r >> 6] >> (r & 63)) & 1)) f |= 1;
-        if (!in.v0_validity || ((in.v0_validity[r >> 6] >> (r & 63)) & 1)) f |= 2;
-        if (!in.v1_validity || ((in.v1_validity[r >> 6] >> (r & 63)) & 1)) f |= 4;
-        fl[j] = f;
-      }
-      dg[j] = rp_digit(rp_bucket(k[j], fl[j] & 1, P), level, p2_bits);
+  const uint32_t t0 = blockIdx.x * tiles_per_wg;
+  const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
+  if (t0 >= t1) return;
+  TileRegs<NV, RP_ROWS> cur, nxt;
+  Tile t = tiles[t0];
+  rp_load_tile<NV, RP_WG, RP_ROWS>(in, t, cur);
+  for (uint32_t ti = t0; ti < t1; ti++) {
+    Tile tn = t;
+    if (ti + 1 < t1) { // prefetch the next tile (loads stay in flight during the LDS phases)
+      tn = tiles[ti + 1];
+      rp_load_tile<NV, RP_WG, RP_ROWS>(in, tn, nxt);
     }
-  }
-#pragma unroll
-  for (int j = 0; j < RP_ROWS; j++)
-    if (dg[j] != 0xffffffffu) rk[j] = atomicAdd(&cnt[dg[j]], 1u);
-  __syncthreads();
-  // exclusive scan of the 512 counters (one per thread)
-  {
-    uint32_t c = cnt[threadIdx.x];
-    uint32_t inc = wave_iscan_u32(c);
-    if (lane_id() == 63) s_wsum[wave_id()] = inc;
+    cnt[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wave_id(); w++) wbase += s_wsum[w];
-    uint32_t ls = wbase + inc - c;
-    lstart[threadIdx.x] = ls;
-    if (threadIdx.x < digits)
-      gbase[threadIdx.x] = (int64_t)offs[t.mat + (int64_t)threadIdx.x * t.stride] - (int64_t)ls;
-  }
-  __syncthreads();
+    uint32_t dg[RP_ROWS], rk[RP_ROWS];
 #pragma unroll
-  for (int j = 0; j < RP_ROWS; j++) {
-    if (dg[j] == 0xffffffffu) continue;
-    uint32_t p = lstart[dg[j]] + rk[j];
-    skey[p] = k[j];
-    if (NV >= 1) sv0[p] = a0[j];
-    if (NV >= 2) sv1[p] = a1[j];
-    sidx[p] = id[j];
-    sdig[p] = (uint16_t)dg[j];
-    sflag[p] = fl[j];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < RP_ROWS; j++) {
-    uint32_t p = j * RP_WG + threadIdx.x;
-    if (p < t.len) {
-      int64_t g = gbase[sdig[p]] + p;
-      out.key[g] = skey[p];
-      if (NV >= 1) out.v0[g] = sv0[p];
-      if (NV >= 2) out.v1[g] = sv1[p];
-      out.idx[g] = sidx[p];
-      if (out.flags) out.flags[g] = sflag[p];
+    for (int j = 0; j < RP_ROWS; j++) {
+      dg[j] = 0xffffffffu;
+      if (cur.fl[j] != 0xff) {
+        dg[j] = rp_digit(rp_bucket(cur.k[j], cur.fl[j] & 1, P), level, p2_bits);
+        rk[j] = atomicAdd(&cnt[dg[j]], 1u);
+      }
     }
+    __syncthreads();
+    { // exclusive scan of the RP_WG counters (one per thread)
+      uint32_t c = cnt[threadIdx.x];
+      uint32_t inc = wave_iscan_u32(c);
+      if (lane_id() == 63) s_wsum[wave_id()] = inc;
+      __syncthreads();
+      uint32_t wbase = 0;
+      for (int w = 0; w < wave_id(); w++) wbase += s_wsum[w];
+      uint32_t ls = wbase + inc - c;
+      lstart[threadIdx.x] = ls;
+      if (threadIdx.x < digits)
+        gbase[threadIdx.x] = (int64_t)offs[t.mat + (int64_t)threadIdx.x * t.stride] - (int64_t)ls;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      if (dg[j] == 0xffffffffu) continue;
+      uint32_t p = lstart[dg[j]] + rk[j];
+      skey[p] = cur.k[j];
+      if (NV >= 1) sv0[p] = cur.a0[j];
+      if (NV >= 2) sv1[p] = cur.a1[j];
+      sidx[p] = cur.id[j];
+      sdig[p] = (uint16_t)dg[j];
+      sflag[p] = cur.fl[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      uint32_t p = j * RP_WG + threadIdx.x;
+      if (p < t.len) {
+        int64_t g = gbase[sdig[p]] + p;
+        out.key[g] = skey[p];
+        if (NV >= 1) out.v0[g] = sv0[p];
+        if (NV >= 2) out.v1[g] = sv1[p];
+        out.idx[g] = sidx[p];
+        if (out.flags) out.flags[g] = sflag[p];
+      }
+    }
+    __syncthreads(); // the staging area and the counters are reused by the next tile
+    cur = nxt;
+    t = tn;
   }
 }
 
@@ -248,10 +283,23 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<0, 512, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<1, 512, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<2, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<0, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<1, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<0, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<1, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<2, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
   const int WG = 512;
-  const int ROWS = nv <= 1 ? 12 : 8; // 6144-row tiles when the staging area fits (<= 150 KiB)
+  // rows per thread: 12 -> 6144-row tiles (one workgroup per CU), 8 -> 4096, 6 -> 3072-row tiles
+  // (two workgroups per CU).  Measured on MI355X (C5, two passes over 5e8 rows): 12.8 / 13.4 /
+  // 13.6 ms — the pass moves 36-40 B/row at ~3.3 TB/s, ~70 % of the 4.9 TB/s copy ceiling, so tile
+  // shape is no longer the lever.  SQLRS_RP_ROWS overrides (tuning only).
+  static const int rows_env = [] {
+    const char *e = std::getenv("SQLRS_RP_ROWS");
+    return e ? std::atoi(e) : 0;
+  }();
+  const int ROWS = rows_env == 6 ? 6 : ((rows_env == 8 || nv > 1) ? 8 : 12);
   const int RP_TILE = WG * ROWS;
   const size_t lds = (size_t)RP_TILE * (8 * (1 + nv) + 4 + 2 + 1) + (size_t)WG * (4 + 4 + 8);
 
@@ -274,24 +322,25 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     unsigned nt = (unsigned)L.tiles.size();
     {
       ProfScope ps(ctx, in.build_side ? "rp_hist_build" : "rp_hist");
-      if (ROWS == 12)
-        rp_hist_kernel<512, 12><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags,
-                                                                        (const Tile *)tiles->p, P, p2_bits, level,
-                                                                        digits, mat->as<uint32_t>());
-      else
-        rp_hist_kernel<512, 8><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags,
-                                                                       (const Tile *)tiles->p, P, p2_bits, level,
-                                                                       digits, mat->as<uint32_t>());
+#define SQ_RH(R) rp_hist_kernel<512, R><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, (const Tile *)tiles->p, P, p2_bits, level, digits, mat->as<uint32_t>())
+      if (ROWS == 12) SQ_RH(12); else if (ROWS == 8) SQ_RH(8); else SQ_RH(6);
+#undef SQ_RH
       SQ_HIP(hipGetLastError());
     }
     exclusive_scan_u32(ctx, mat->as<uint32_t>(), L.mat_entries, nullptr, offs->as<uint32_t>(),
                        total->as<uint64_t>());
     {
       ProfScope ps(ctx, in.build_side ? "rp_scatter_build" : "rp_scatter");
-      dim3 g(nt), b((unsigned)WG);
+      // one workgroup per CU slot; contiguous tile ranges (8 per workgroup at least)
+      uint32_t wgs = std::min<uint32_t>(nt, (uint32_t)ctx->num_cus * (ROWS <= 6 ? 2 : 1));
+      uint32_t tpw = (uint32_t)ceil_div(nt, wgs);
+      wgs = (uint32_t)ceil_div(nt, tpw);
+      dim3 g(wgs), b((unsigned)WG);
       const Tile *tp = (const Tile *)tiles->p;
-#define SQ_RP(NV, R) rp_scatter_kernel<NV, 512, R><<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs->as<uint32_t>())
-      if (nv == 0) SQ_RP(0, 12); else if (nv == 1) SQ_RP(1, 12); else SQ_RP(2, 8);
+#define SQ_RP(NV, R) rp_scatter_kernel<NV, 512, R><<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs->as<uint32_t>(), nt, tpw)
+      if (ROWS == 12) { if (nv == 0) SQ_RP(0, 12); else SQ_RP(1, 12); }
+      else if (ROWS == 8) { if (nv == 0) SQ_RP(0, 8); else if (nv == 1) SQ_RP(1, 8); else SQ_RP(2, 8); }
+      else { if (nv == 0) SQ_RP(0, 6); else if (nv == 1) SQ_RP(1, 6); else SQ_RP(2, 6); }
 #undef SQ_RP
       SQ_HIP(hipGetLastError());
     }
