@@ -69,6 +69,30 @@ __global__ __launch_bounds__(BLOCK) void cmp_kernel(const T *__restrict__ a, int
   if (lane_id() == 0 && i < n) out[i >> 6] = m;
 }
 
+// Utf8 comparison: byte-wise lexicographic (arrow string order), one row per lane; a stride-0
+// operand is a constant (row 0 of its buffers).
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void cmp_utf8_kernel(const uint8_t *__restrict__ ad,
+                                                         const int32_t *__restrict__ ao, int sa,
+                                                         const uint8_t *__restrict__ bd,
+                                                         const int32_t *__restrict__ bo, int sb, int64_t n,
+                                                         uint64_t *__restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool r = false;
+  if (i < n) {
+    int64_t ia = sa ? i : 0, ib = sb ? i : 0;
+    int32_t a0 = ao[ia], la = ao[ia + 1] - a0, b0 = bo[ib], lb = bo[ib + 1] - b0;
+    int32_t m = la < lb ? la : lb;
+    int c = 0;
+    for (int32_t k = 0; k < m && c == 0; k++) c = (int)ad[a0 + k] - (int)bd[b0 + k];
+    if (c == 0) c = (la > lb) - (la < lb);
+    r = OP == CMP_GT ? c > 0 : OP == CMP_LT ? c < 0 : OP == CMP_GE ? c >= 0
+        : OP == CMP_LE ? c <= 0 : OP == CMP_EQ ? c == 0 : c != 0;
+  }
+  uint64_t mm = __ballot(r);
+  if (lane_id() == 0 && i < n) out[i >> 6] = mm;
+}
+
 // boolean compare / Kleene logic on whole words.  mode: 0..5 = CMP_*, 6 = AND, 7 = OR
 __global__ void bool_words_kernel(const uint64_t *__restrict__ a, int sa,
                                   const uint64_t *__restrict__ av, int sav,
@@ -140,20 +164,37 @@ __global__ void cast_bool_kernel(const uint64_t *__restrict__ in, int64_t n, D *
 }
 
 // ------------------------------------------------------------------ host side --
-static DCol make_scalar(Ctx *ctx, const sqlrs_expr_node_t &n, int64_t rows) {
+static DCol make_scalar(Ctx *ctx, const sqlrs_expr_node_t &n, const std::string &str, int64_t rows) {
   DCol c;
   c.dtype = n.dtype;
   c.length = rows;
   c.stride = 0;
   c.scalar_null = n.is_null != 0;
+  if (n.dtype == SQLRS_UTF8) { // one string: bytes + offsets {0, len}; validity word after them
+    size_t len = c.scalar_null ? 0 : str.size();
+    size_t off_at = round_up(len + 1, 8);
+    std::vector<uint8_t> host(off_at + 16, 0);
+    std::memcpy(host.data(), str.data(), len);
+    int32_t offs[2] = {0, (int32_t)len};
+    std::memcpy(host.data() + off_at, offs, 8);
+    uint64_t vword = c.scalar_null ? 0ull : ~0ull;
+    std::memcpy(host.data() + off_at + 8, &vword, 8);
+    c.own_values = ctx->alloc(host.size());
+    SQ_HIP(hipMemcpyAsync(c.own_values->p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+    ctx->sync();
+    c.values = c.own_values->p;
+    c.offsets = (const int32_t *)(c.own_values->as<uint8_t>() + off_at);
+    c.data_bytes = (int64_t)len;
+    c.null_count = c.scalar_null ? rows : 0;
+    if (c.scalar_null) c.validity = (const uint64_t *)(c.own_values->as<uint8_t>() + off_at + 8);
+    return c;
+  }
   uint64_t bits = 0;
   switch (n.dtype) {
   case SQLRS_INT64: bits = (uint64_t)n.i; break;
   case SQLRS_INT32: bits = (uint64_t)(uint32_t)(int32_t)n.i; break;
   case SQLRS_FLOAT64: std::memcpy(&bits, &n.f, 8); break;
   case SQLRS_BOOLEAN: bits = n.i ? ~0ull : 0ull; break;
-  case SQLRS_UTF8:
-    fail(SQLRS_ERR_INTERNAL, "utf8 constants are not supported on the device path");
   default:
     fail(SQLRS_ERR_INTERNAL, "constant of unsupported dtype");
   }
@@ -275,8 +316,23 @@ static DCol binary_op(Ctx *ctx, const DCol &l, const DCol &r, int op, int64_t ro
     case SQLRS_INT64: launch_cmp<int64_t>(ctx, cop, l, r, rows, o.own_values->as<uint64_t>()); break;
     case SQLRS_INT32: launch_cmp<int32_t>(ctx, cop, l, r, rows, o.own_values->as<uint64_t>()); break;
     case SQLRS_FLOAT64: launch_cmp<double>(ctx, cop, l, r, rows, o.own_values->as<uint64_t>()); break;
-    case SQLRS_UTF8:
-      fail(SQLRS_ERR_INTERNAL, "utf8 comparison is not supported on the device path");
+    case SQLRS_UTF8: {
+      int64_t n64 = (int64_t)round_up((size_t)rows, 64);
+      dim3 g((unsigned)ceil_div(n64, BLOCK)), b(BLOCK);
+      uint64_t *ob = o.own_values->as<uint64_t>();
+#define SQ_U8(OP) cmp_utf8_kernel<OP><<<g, b, 0, ctx->stream>>>(l.v<uint8_t>(), l.offsets, l.stride, r.v<uint8_t>(), r.offsets, r.stride, rows, ob)
+      switch (cop) {
+      case CMP_GT: SQ_U8(CMP_GT); break;
+      case CMP_LT: SQ_U8(CMP_LT); break;
+      case CMP_GE: SQ_U8(CMP_GE); break;
+      case CMP_LE: SQ_U8(CMP_LE); break;
+      case CMP_EQ: SQ_U8(CMP_EQ); break;
+      default: SQ_U8(CMP_NE); break;
+      }
+#undef SQ_U8
+      SQ_HIP(hipGetLastError());
+      break;
+    }
     default:
       fail(SQLRS_ERR_ARROW, "comparison of unsupported type");
     }
@@ -373,7 +429,7 @@ DCol eval_expr(Ctx *ctx, const Expr &e, const std::function<const DCol &(int)> &
     }
     case SQLRS_EXPR_CONSTANT:
       if (n.dtype == SQLRS_NULLTYPE) fail(SQLRS_ERR_INTERNAL, "Null-typed constant array");
-      st.push_back(make_scalar(ctx, n, rows));
+      st.push_back(make_scalar(ctx, n, e.strings[k], rows));
       break;
     case SQLRS_EXPR_TYPE_CAST: {
       if (st.empty()) fail(SQLRS_ERR_INTERNAL, "malformed expression");

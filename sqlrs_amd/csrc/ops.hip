@@ -99,6 +99,50 @@ __global__ void sort_key_kernel(const void *__restrict__ vals, const uint64_t *_
   else u = (((const uint64_t *)vals)[r >> 6] >> (r & 63)) & 1;
   keys[i] = desc ? ~u : u;
 }
+// Utf8 sort keys: LSD over 8-byte big-endian chunks of the strings (zero padded), preceded by a
+// pass on the length so that a string sorts before its zero-extended twin (byte-wise
+// lexicographic order, like arrow's).  NULL rows get key 0 (they tie; the validity pass places them).
+__global__ void utf8_maxlen_kernel(const int32_t *__restrict__ off, int64_t n, unsigned int *mx) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  unsigned int l = i < n ? (unsigned int)(off[i + 1] - off[i]) : 0u;
+  for (int m = 32; m >= 1; m >>= 1) {
+    unsigned int o = (unsigned int)__shfl_xor((int)l, m, 64);
+    l = o > l ? o : l;
+  }
+  if (lane_id() == 0 && l) atomicMax(mx, l);
+}
+// chunk < 0: key = string length
+__global__ void utf8_chunk_key_kernel(const uint8_t *__restrict__ data, const int32_t *__restrict__ off,
+                                      const uint64_t *__restrict__ validity,
+                                      const uint32_t *__restrict__ perm, int64_t n, int chunk, int desc,
+                                      uint64_t *__restrict__ keys) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  uint64_t u = 0;
+  if (i < n) {
+    uint32_t r = perm[i];
+    if (!validity || ((validity[r >> 6] >> (r & 63)) & 1)) {
+      int32_t a = off[r], len = off[r + 1] - a;
+      if (chunk < 0) {
+        u = (uint64_t)(uint32_t)len;
+      } else {
+        for (int k = 0; k < 8; k++) {
+          int32_t p = chunk * 8 + k;
+          u = (u << 8) | (p < len ? (uint64_t)data[a + p] : 0ull);
+        }
+      }
+      if (desc) u = ~u;
+    }
+    keys[i] = u;
+  }
+}
+// OR of (key ^ key[0]) over all rows: the bit positions on which the keys differ at all
+__global__ void keys_diff_kernel(const uint64_t *__restrict__ keys, int64_t n, unsigned long long *diff_or) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  uint64_t d = (i < n) ? (keys[i] ^ keys[0]) : 0;
+  for (int m = 32; m >= 1; m >>= 1) d |= shfl_xor_u64(d, m);
+  if (lane_id() == 0 && d) atomicOr(diff_or, (unsigned long long)d);
+}
+
 __global__ void sort_valid_key_kernel(const uint64_t *__restrict__ validity,
                                       const uint32_t *__restrict__ perm, int64_t n,
                                       uint64_t *__restrict__ keys) {
@@ -189,13 +233,35 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
       case SQLRS_BOOLEAN:
         sort_key_kernel<3><<<g, b, 0, ctx->stream>>>(c.values, valid, perm->as<uint32_t>(), n, desc, keys->as<uint64_t>());
         break;
-      case SQLRS_UTF8:
-        fail(SQLRS_ERR_INTERNAL, "utf8 sort keys are not supported on the device path");
+      case SQLRS_UTF8: {
+        BufP mx = ctx->alloc_zero(8);
+        int64_t n64 = (int64_t)round_up((size_t)n, 64);
+        dim3 g64((unsigned)ceil_div(n64, 256));
+        utf8_maxlen_kernel<<<g64, b, 0, ctx->stream>>>(c.offsets, n, mx->as<unsigned int>());
+        SQ_HIP(hipGetLastError());
+        int max_len = (int)ctx->fetch_value(mx->as<unsigned int>());
+        int chunks = (max_len + 7) / 8;
+        BufP diff = ctx->alloc(16);
+        for (int ch = -1; ch < chunks; ch++) { // length first (least significant), then chunks
+          int chunk = ch < 0 ? -1 : chunks - 1 - ch; // last chunk -> first chunk
+          SQ_HIP(hipMemsetAsync(diff->p, 0, 16, ctx->stream));
+          utf8_chunk_key_kernel<<<g64, b, 0, ctx->stream>>>(c.v<uint8_t>(), c.offsets, valid, perm->as<uint32_t>(),
+                                                            n, chunk, desc, keys->as<uint64_t>());
+          keys_diff_kernel<<<g64, b, 0, ctx->stream>>>(keys->as<uint64_t>(), n, diff->as<unsigned long long>());
+          SQ_HIP(hipGetLastError());
+          uint64_t d = ctx->fetch_value(diff->as<uint64_t>());
+          if (!d) continue; // every key equal in this chunk: nothing to sort
+          int lo = __builtin_ctzll(d) & ~7, hi = 64 - __builtin_clzll(d);
+          radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), n, lo, hi);
+        }
+        bits = 0; // sorted above
+        break;
+      }
       default:
         fail(SQLRS_ERR_INTERNAL, "unsupported sort key type");
       }
       SQ_HIP(hipGetLastError());
-      radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), n, 0, bits);
+      if (bits) radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), n, 0, bits);
       if (valid) { // nulls_first = true regardless of direction (order.rs:37-40)
         sort_valid_key_kernel<<<g, b, 0, ctx->stream>>>(valid, perm->as<uint32_t>(), n, keys->as<uint64_t>());
         SQ_HIP(hipGetLastError());

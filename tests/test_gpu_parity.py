@@ -394,3 +394,46 @@ def test_join_agg_composed_route(hip, oracle):
     assert ex.fused_batches == 0
     exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
     assert_same(got, exp, float_cols={3})
+
+
+# ------------------------------------------------------------------------- Utf8 paths --
+def _strings(rng, n, null_frac=0.1):
+    alphabet = ["a", "ab", "abc", "b", "", "zz", "abcdefgh", "abcdefghi", "abcdefgh\x00", "Colorado", "CA", "CO", "été"]
+    vals = [alphabet[i] + ("" if rng.random() < 0.7 else str(rng.integers(0, 50))) for i in rng.integers(0, len(alphabet), n)]
+    mask = rng.random(n) < null_frac
+    return pa.array(vals, type=pa.string(), mask=mask)
+
+
+@pytest.mark.parametrize("n", [1, 65, 5000])
+def test_utf8_comparisons_and_filter(hip, oracle, n):
+    rng = np.random.default_rng(n)
+    b = pa.RecordBatch.from_arrays([_strings(rng, n), _strings(rng, n), pa.array(rng.integers(0, 9, n))], names=["s", "t", "v"])
+    for e in (BinaryOp("!=", InputRef(0), Constant("CO", abi.UTF8)), BinaryOp("=", InputRef(0), Constant("abcdefgh", abi.UTF8)),
+              BinaryOp(">", InputRef(0), InputRef(1)), BinaryOp("<=", InputRef(0), InputRef(1)),
+              BinaryOp(">=", InputRef(0), Constant("ab", abi.UTF8)), BinaryOp("<", InputRef(1), Constant(None, abi.UTF8))):
+        assert eval_column(hip, e, b).column(0).to_pylist() == eval_column(oracle, e, b).column(0).to_pylist()
+        got = rows_of(FilterExecutor(hip, e, [b]).execute())
+        assert got == rows_of(FilterExecutor(oracle, e, [b]).execute())
+
+
+@pytest.mark.parametrize("n", [2, 300, 20_000])
+def test_order_by_utf8(hip, oracle, n):
+    rng = np.random.default_rng(n)
+    b = pa.RecordBatch.from_arrays([_strings(rng, n), pa.array(rng.integers(0, 5, n)), pa.array(np.arange(n))], names=["s", "k", "i"])
+    for ob in ([OrderBy(InputRef(0), True)], [OrderBy(InputRef(0), False)],
+               [OrderBy(InputRef(1), True), OrderBy(InputRef(0), False)], [OrderBy(InputRef(0), True), OrderBy(InputRef(1), False)]):
+        assert rows_of(OrderExecutor(hip, ob, [b]).execute()) == rows_of(OrderExecutor(oracle, ob, [b]).execute())
+
+
+def test_utf8_keys_join_and_agg(hip, oracle):
+    rng = np.random.default_rng(8)
+    lb = pa.RecordBatch.from_arrays([_strings(rng, 400, 0.05), pa.array(rng.integers(0, 100, 400))], names=["s", "x"])
+    rb = pa.RecordBatch.from_arrays([pa.array(rng.random(3000)), _strings(rng, 3000, 0.05)], names=["v", "s"])
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    sch = join_schema(lb, rb)
+    for jt in ("inner", "full"):
+        got = rows_of(HashJoinExecutor(hip, [lb], [rb], jt, cond, sch, 2).execute())
+        assert_same(got, rows_of(HashJoinExecutor(oracle, [lb], [rb], jt, cond, sch, 2).execute()))
+    aggs = [AggFunc("count", InputRef(0), abi.INT64), AggFunc("sum", InputRef(0), abi.FLOAT64)]
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(1)], [rb]).execute())
+    assert_same(got, rows_of(HashAggExecutor(oracle, aggs, [InputRef(1)], [rb]).execute()), float_cols={2})
