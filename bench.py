@@ -508,7 +508,7 @@ def cpu_baseline(args, abi, datagen, n_dim_total):
     n = int(args.cpu_sample_rows) or 1_000_000
     dt, groups = run(n)
     if not args.cpu_sample_rows and dt < 8.0:  # scale the sample to roughly 15 s of CPU work
-        n = int(min(n * 15.0 / max(dt, 1e-3), 64_000_000))
+        n = int(min(n * 25.0 / max(dt, 1e-3), 64_000_000))
         dt, groups = run(n)
     val = n / dt / 1e6
     log(f"[bench] cpu_baseline: {n:,} fact rows x {n_dim:,} dim rows in {dt:.1f}s on 1 thread = {val:.3f} Mrows/s")
