@@ -1,0 +1,495 @@
+// sqlrs_executor.hpp — C++ host-side mirror of the sqlrs v1 operator interface over the C ABI
+// of include/sqlrs_hip.h.
+//
+// The reference is Rust; no Rust toolchain exists in the build image, so the layer a sqlrs
+// maintainer would write in Rust above the FFI is written here in C++ with
+// the reference's names, argument meaning and error behaviour:
+//
+//   BoxedExecutor          = BoxStream<Result<RecordBatch, ExecutorError>>   src/executor/mod.rs:34
+//   try_collect            src/executor/mod.rs:58-64
+//   ExecutorError          src/executor/mod.rs:67-85
+//   FilterExecutor{expr, child}                                              src/executor/filter.rs:7-25
+//   HashJoinExecutor{left_child, right_child, join_type, join_condition,
+//                    join_output_schema}                                     src/executor/join/hash_join.rs:16-23
+//   HashAggExecutor{agg_funcs, group_by, child}                              src/executor/aggregate/hash_agg.rs:15-19
+//   OrderExecutor{order_by, child}                                           src/executor/order.rs:8-11
+//   BoundExpr / BoundAggFunc / BoundOrderBy / JoinCondition / JoinType /
+//   ColumnCatalog, build_bound_input_ref                                     src/binder/**, src/catalog/mod.rs
+//   pretty_format_batches                                                    arrow::util::pretty (used by the tests)
+//
+// Each operator is a struct with public fields and `execute()` returning a pull stream; the only
+// addition is the `HipCtx` handle (the reference has no device).  Header only, C++17.
+#pragma once
+
+#include <cstring>
+#include <memory>
+#include <optional>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../include/sqlrs_hip.h"
+
+namespace sqlrs {
+
+// ------------------------------------------------------------------ errors --
+struct ExecutorError : std::runtime_error { // executor/mod.rs:67-85
+  enum Kind { Storage, Arrow, InternalError } kind;
+  ExecutorError(Kind k, const std::string &m) : std::runtime_error(m), kind(k) {}
+};
+
+// ------------------------------------------------------------------- arrays --
+enum class DataType { Int32 = SQLRS_INT32, Int64 = SQLRS_INT64, Float64 = SQLRS_FLOAT64,
+                      Boolean = SQLRS_BOOLEAN, Utf8 = SQLRS_UTF8 };
+
+struct Array {
+  DataType type;
+  int64_t len = 0;
+  std::vector<uint8_t> values;   // fixed width data / bitmap / utf8 bytes
+  std::vector<uint8_t> validity; // empty = no nulls (Arrow bitmap otherwise)
+  std::vector<int32_t> offsets;  // Utf8
+  bool is_valid(int64_t i) const { return validity.empty() || ((validity[i >> 3] >> (i & 7)) & 1); }
+  int64_t null_count() const {
+    int64_t n = 0;
+    for (int64_t i = 0; i < len; i++) n += !is_valid(i);
+    return n;
+  }
+  std::string value_to_string(int64_t i) const {
+    if (!is_valid(i)) return "";
+    switch (type) {
+    case DataType::Int32: { int32_t v; std::memcpy(&v, values.data() + 4 * i, 4); return std::to_string(v); }
+    case DataType::Int64: { int64_t v; std::memcpy(&v, values.data() + 8 * i, 8); return std::to_string(v); }
+    case DataType::Float64: { double v; std::memcpy(&v, values.data() + 8 * i, 8); std::ostringstream o; o << v; return o.str(); }
+    case DataType::Boolean: return ((values[i >> 3] >> (i & 7)) & 1) ? "true" : "false";
+    case DataType::Utf8: return std::string((const char *)values.data() + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
+    }
+    return "";
+  }
+};
+using ArrayRef = std::shared_ptr<Array>;
+
+template <class T> ArrayRef make_primitive(DataType t, const std::vector<std::optional<T>> &v) {
+  auto a = std::make_shared<Array>();
+  a->type = t;
+  a->len = (int64_t)v.size();
+  a->values.resize(sizeof(T) * v.size());
+  bool any_null = false;
+  for (size_t i = 0; i < v.size(); i++) {
+    T x = v[i].value_or(T());
+    std::memcpy(a->values.data() + sizeof(T) * i, &x, sizeof(T));
+    any_null |= !v[i].has_value();
+  }
+  if (any_null) {
+    a->validity.assign((v.size() + 7) / 8, 0);
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i]) a->validity[i >> 3] |= (uint8_t)(1u << (i & 7));
+  }
+  return a;
+}
+inline ArrayRef Int32Array(const std::vector<int32_t> &v) {
+  return make_primitive<int32_t>(DataType::Int32, std::vector<std::optional<int32_t>>(v.begin(), v.end()));
+}
+inline ArrayRef Int64Array(const std::vector<int64_t> &v) {
+  return make_primitive<int64_t>(DataType::Int64, std::vector<std::optional<int64_t>>(v.begin(), v.end()));
+}
+inline ArrayRef Int64ArrayOpt(const std::vector<std::optional<int64_t>> &v) { return make_primitive<int64_t>(DataType::Int64, v); }
+inline ArrayRef Float64Array(const std::vector<double> &v) {
+  return make_primitive<double>(DataType::Float64, std::vector<std::optional<double>>(v.begin(), v.end()));
+}
+inline ArrayRef StringArray(const std::vector<std::string> &v) {
+  auto a = std::make_shared<Array>();
+  a->type = DataType::Utf8;
+  a->len = (int64_t)v.size();
+  a->offsets.push_back(0);
+  for (auto &s : v) {
+    a->values.insert(a->values.end(), s.begin(), s.end());
+    a->offsets.push_back((int32_t)a->values.size());
+  }
+  return a;
+}
+
+struct Field {
+  std::string name;
+  DataType data_type;
+  bool nullable;
+};
+using Schema = std::vector<Field>;
+using SchemaRef = std::shared_ptr<Schema>;
+
+struct RecordBatch {
+  SchemaRef schema;
+  std::vector<ArrayRef> columns;
+  int64_t num_rows() const { return columns.empty() ? rows_ : columns[0]->len; }
+  int64_t rows_ = 0;
+  static RecordBatch try_new(SchemaRef schema, std::vector<ArrayRef> columns) {
+    if (schema->size() != columns.size()) throw ExecutorError(ExecutorError::Arrow, "number of columns must match schema");
+    for (auto &c : columns)
+      if (c->len != columns[0]->len) throw ExecutorError(ExecutorError::Arrow, "all columns must have the same length");
+    RecordBatch b;
+    b.schema = std::move(schema);
+    b.columns = std::move(columns);
+    return b;
+  }
+};
+
+// arrow::util::pretty::pretty_format_batches (the format the reference's tests assert on)
+inline std::string pretty_format_batches(const std::vector<RecordBatch> &batches) {
+  if (batches.empty()) return "";
+  const Schema &schema = *batches[0].schema;
+  std::vector<std::vector<std::string>> rows;
+  std::vector<size_t> width(schema.size());
+  for (size_t c = 0; c < schema.size(); c++) width[c] = schema[c].name.size();
+  for (const RecordBatch &b : batches)
+    for (int64_t r = 0; r < b.num_rows(); r++) {
+      std::vector<std::string> row;
+      for (size_t c = 0; c < schema.size(); c++) {
+        row.push_back(b.columns[c]->value_to_string(r));
+        width[c] = std::max(width[c], row.back().size());
+      }
+      rows.push_back(std::move(row));
+    }
+  auto border = [&] {
+    std::string s = "+";
+    for (size_t w : width) s += std::string(w + 2, '-') + "+";
+    return s + "\n";
+  };
+  auto line = [&](const std::vector<std::string> &cells) {
+    std::string s = "|";
+    for (size_t c = 0; c < cells.size(); c++) s += " " + cells[c] + std::string(width[c] - cells[c].size(), ' ') + " |";
+    return s + "\n";
+  };
+  std::vector<std::string> header;
+  for (auto &f : schema) header.push_back(f.name);
+  std::string out = border() + line(header) + border();
+  for (auto &r : rows) out += line(r);
+  out += border();
+  out.pop_back();
+  return out;
+}
+
+// -------------------------------------------------------------- bound exprs --
+enum class BinaryOperator { Plus = SQLRS_EXPR_PLUS, Minus, Multiply, Divide, Gt, Lt, GtEq, LtEq, Eq, NotEq, And, Or };
+
+struct ScalarValue { // src/types/mod.rs:23-36
+  DataType type = DataType::Int64;
+  bool is_null = false;
+  int64_t i = 0;
+  double f = 0;
+  std::string s;
+  static ScalarValue Int64(std::optional<int64_t> v) { ScalarValue x; x.type = DataType::Int64; x.is_null = !v; x.i = v.value_or(0); return x; }
+  static ScalarValue Int32(std::optional<int32_t> v) { ScalarValue x; x.type = DataType::Int32; x.is_null = !v; x.i = v.value_or(0); return x; }
+  static ScalarValue Float64(std::optional<double> v) { ScalarValue x; x.type = DataType::Float64; x.is_null = !v; x.f = v.value_or(0); return x; }
+  static ScalarValue Boolean(std::optional<bool> v) { ScalarValue x; x.type = DataType::Boolean; x.is_null = !v; x.i = v.value_or(false); return x; }
+  static ScalarValue String(std::optional<std::string> v) { ScalarValue x; x.type = DataType::Utf8; x.is_null = !v; x.s = v.value_or(""); return x; }
+};
+
+struct BoundExpr { // src/binder/expression/mod.rs:18-27 (the variants evaluated on this path)
+  enum Kind { InputRef, Constant, BinaryOp, TypeCast, Alias } kind = InputRef;
+  size_t index = 0;                       // BoundInputRef.index
+  ScalarValue value;                      // Constant
+  BinaryOperator op = BinaryOperator::Eq; // BoundBinaryOp.op
+  DataType cast_type = DataType::Int64;   // BoundTypeCast.cast_type
+  std::vector<BoundExpr> children;        // BinaryOp: left, right; TypeCast / Alias: inner
+
+  static BoundExpr input_ref(size_t i) { BoundExpr e; e.kind = InputRef; e.index = i; return e; }
+  static BoundExpr constant(ScalarValue v) { BoundExpr e; e.kind = Constant; e.value = std::move(v); return e; }
+  static BoundExpr binary_op(BinaryOperator op, BoundExpr l, BoundExpr r) {
+    BoundExpr e; e.kind = BinaryOp; e.op = op; e.children = {std::move(l), std::move(r)}; return e;
+  }
+  static BoundExpr type_cast(BoundExpr inner, DataType t) { BoundExpr e; e.kind = TypeCast; e.cast_type = t; e.children = {std::move(inner)}; return e; }
+};
+inline BoundExpr build_bound_input_ref(size_t index) { return BoundExpr::input_ref(index); } // binder/mod.rs:400-413
+
+enum class JoinType { Inner = SQLRS_JOIN_INNER, Left = SQLRS_JOIN_LEFT, Right = SQLRS_JOIN_RIGHT, Full = SQLRS_JOIN_FULL };
+struct JoinCondition { // JoinCondition::On { on, filter }   src/binder/table/join.rs:40-48
+  std::vector<std::pair<BoundExpr, BoundExpr>> on;
+  std::optional<BoundExpr> filter;
+};
+struct ColumnDesc { std::string name; DataType data_type; };
+struct ColumnCatalog { // src/catalog/mod.rs
+  std::string table_id, column_id;
+  bool nullable;
+  ColumnDesc desc;
+  Field to_arrow_field() const { return Field{table_id + "." + column_id, desc.data_type, nullable}; } // catalog/mod.rs:131-137
+};
+enum class AggFunc { Count = SQLRS_AGG_COUNT, Sum = SQLRS_AGG_SUM, Min = SQLRS_AGG_MIN, Max = SQLRS_AGG_MAX };
+struct BoundAggFunc { // src/binder/expression/agg_func.rs:29-34
+  AggFunc func;
+  std::vector<BoundExpr> exprs;
+  DataType return_type;
+  bool distinct = false;
+};
+struct BoundOrderBy { BoundExpr expr; bool asc; }; // src/binder/statement/mod.rs:26-29
+
+// ------------------------------------------------------------------ streams --
+struct Executor { // one BoxStream: next() = poll; nullopt = end of stream; errors are thrown
+  virtual ~Executor() {}
+  virtual std::optional<RecordBatch> next() = 0;
+};
+using BoxedExecutor = std::unique_ptr<Executor>;
+
+struct IterExecutor : Executor { // futures::stream::iter(vec).boxed()  (hash_join.rs:407-414)
+  std::vector<RecordBatch> batches;
+  size_t pos = 0;
+  explicit IterExecutor(std::vector<RecordBatch> b) : batches(std::move(b)) {}
+  std::optional<RecordBatch> next() override {
+    if (pos >= batches.size()) return std::nullopt;
+    return batches[pos++];
+  }
+};
+inline BoxedExecutor stream_iter(std::vector<RecordBatch> b) { return BoxedExecutor(new IterExecutor(std::move(b))); }
+inline std::vector<RecordBatch> try_collect(BoxedExecutor e) { // executor/mod.rs:58-64
+  std::vector<RecordBatch> out;
+  while (auto b = e->next()) out.push_back(std::move(*b));
+  return out;
+}
+
+// ------------------------------------------------------------- HIP plumbing --
+struct HipCtx {
+  sqlrs_ctx_t *raw = nullptr;
+  explicit HipCtx(int device_id = 0) {
+    if (sqlrs_ctx_create(device_id, &raw) != SQLRS_OK)
+      throw ExecutorError(ExecutorError::InternalError, "no usable gfx950 device (libsqlrs_hip has no CPU fallback)");
+  }
+  ~HipCtx() { if (raw) sqlrs_ctx_destroy(raw); }
+  HipCtx(const HipCtx &) = delete;
+  void check(int status) const {
+    if (status == SQLRS_OK) return;
+    std::string msg = sqlrs_last_error(raw);
+    throw ExecutorError(status == SQLRS_ERR_ARROW ? ExecutorError::Arrow : ExecutorError::InternalError, msg);
+  }
+};
+using HipCtxRef = std::shared_ptr<HipCtx>;
+
+namespace detail {
+
+struct Lowered { // BoundExpr -> postfix sqlrs_expr_t
+  std::vector<sqlrs_expr_node_t> nodes;
+  std::vector<std::unique_ptr<std::string>> strings;
+  sqlrs_expr_t abi() const { return sqlrs_expr_t{nodes.data(), (int32_t)nodes.size(), 0}; }
+  void push(const BoundExpr &e) {
+    sqlrs_expr_node_t n;
+    std::memset(&n, 0, sizeof(n));
+    switch (e.kind) {
+    case BoundExpr::InputRef: n.op = SQLRS_EXPR_INPUT_REF; n.index = (int32_t)e.index; nodes.push_back(n); break;
+    case BoundExpr::Constant:
+      n.op = SQLRS_EXPR_CONSTANT; n.dtype = (int32_t)e.value.type; n.is_null = e.value.is_null; n.i = e.value.i; n.f = e.value.f;
+      if (e.value.type == DataType::Utf8) { strings.emplace_back(new std::string(e.value.s)); n.s = strings.back()->c_str(); }
+      nodes.push_back(n);
+      break;
+    case BoundExpr::BinaryOp: push(e.children[0]); push(e.children[1]); n.op = (int32_t)e.op; nodes.push_back(n); break;
+    case BoundExpr::TypeCast: push(e.children[0]); n.op = SQLRS_EXPR_TYPE_CAST; n.dtype = (int32_t)e.cast_type; nodes.push_back(n); break;
+    case BoundExpr::Alias: push(e.children[0]); break; // evaluator.rs:25
+    }
+  }
+};
+inline Lowered lower(const BoundExpr &e) { Lowered l; l.push(e); return l; }
+
+struct AbiBatch { // zero-copy view of a RecordBatch
+  std::vector<sqlrs_column_t> cols;
+  sqlrs_batch_t b;
+  explicit AbiBatch(const RecordBatch &rb) {
+    for (auto &a : rb.columns) {
+      sqlrs_column_t c;
+      c.dtype = (int32_t)a->type; c.mem = SQLRS_MEM_HOST; c.length = a->len; c.null_count = a->null_count();
+      c.values = a->values.data(); c.validity = a->validity.empty() ? nullptr : a->validity.data();
+      c.offsets = a->type == DataType::Utf8 ? a->offsets.data() : nullptr;
+      cols.push_back(c);
+    }
+    b.num_rows = rb.num_rows(); b.num_columns = (int32_t)cols.size(); b.reserved = 0; b.columns = cols.data(); b.owner = nullptr;
+  }
+};
+
+inline RecordBatch import_batch(sqlrs_batch_t *out, SchemaRef schema) { // copies, then releases the library batch
+  std::vector<ArrayRef> cols;
+  for (int i = 0; i < out->num_columns; i++) {
+    const sqlrs_column_t &c = out->columns[i];
+    auto a = std::make_shared<Array>();
+    a->type = (DataType)c.dtype; a->len = c.length;
+    size_t nb = (size_t)((c.length + 7) / 8);
+    if (c.validity && c.null_count != 0) a->validity.assign(c.validity, c.validity + nb);
+    if (a->type == DataType::Utf8) {
+      a->offsets.assign(c.offsets, c.offsets + c.length + 1);
+      a->values.assign((const uint8_t *)c.values, (const uint8_t *)c.values + a->offsets.back());
+    } else if (a->type == DataType::Boolean) {
+      a->values.assign((const uint8_t *)c.values, (const uint8_t *)c.values + nb);
+    } else {
+      size_t w = a->type == DataType::Int32 ? 4 : 8;
+      a->values.assign((const uint8_t *)c.values, (const uint8_t *)c.values + w * (size_t)c.length);
+    }
+    cols.push_back(a);
+  }
+  RecordBatch rb;
+  rb.rows_ = out->num_rows;
+  sqlrs_batch_release(out);
+  if (!schema) { // derive a schema from the columns
+    auto s = std::make_shared<Schema>();
+    for (size_t i = 0; i < cols.size(); i++) s->push_back(Field{"c" + std::to_string(i), cols[i]->type, true});
+    schema = s;
+  }
+  rb.schema = schema;
+  rb.columns = std::move(cols);
+  return rb;
+}
+
+} // namespace detail
+
+// ---------------------------------------------------------------- operators --
+struct FilterExecutor { // filter.rs:7-10
+  HipCtxRef ctx;
+  BoundExpr expr;
+  BoxedExecutor child;
+  BoxedExecutor execute() {
+    struct S : Executor {
+      HipCtxRef ctx; BoxedExecutor child; sqlrs_filter_t *f = nullptr; detail::Lowered low;
+      ~S() override { if (f) sqlrs_filter_destroy(f); }
+      std::optional<RecordBatch> next() override { // filter.rs:15-24
+        auto batch = child->next();
+        if (!batch) return std::nullopt;
+        detail::AbiBatch in(*batch);
+        sqlrs_batch_t *out = nullptr;
+        ctx->check(sqlrs_filter_push(f, &in.b, SQLRS_MEM_HOST, &out));
+        return detail::import_batch(out, batch->schema);
+      }
+    };
+    auto s = std::make_unique<S>();
+    s->ctx = ctx; s->child = std::move(child); s->low = detail::lower(expr);
+    sqlrs_expr_t e = s->low.abi();
+    ctx->check(sqlrs_filter_create(ctx->raw, &e, &s->f));
+    return s;
+  }
+};
+
+struct HashJoinExecutor { // hash_join.rs:16-23
+  HipCtxRef ctx;
+  BoxedExecutor left_child, right_child;
+  JoinType join_type;
+  JoinCondition join_condition;
+  std::vector<ColumnCatalog> join_output_schema;
+  size_t num_left_columns; // where the right part of join_output_schema starts
+
+  BoxedExecutor execute() {
+    struct S : Executor {
+      HipCtxRef ctx; BoxedExecutor left, right; sqlrs_hash_join_t *j = nullptr; SchemaRef schema;
+      int phase = 0; // 0 build, 1 probe, 2 tail, 3 done
+      ~S() override { if (j) sqlrs_hash_join_destroy(j); }
+      std::optional<RecordBatch> next() override {
+        if (phase == 0) { // build phase (hash_join.rs:161-187)
+          while (auto b = left->next()) { detail::AbiBatch in(*b); ctx->check(sqlrs_hash_join_build_push(j, &in.b)); }
+          ctx->check(sqlrs_hash_join_build_finish(j));
+          phase = 1;
+        }
+        while (phase == 1) { // probe phase (:207-292)
+          auto b = right->next();
+          if (!b) { phase = 2; break; }
+          detail::AbiBatch in(*b);
+          sqlrs_batch_t *out = nullptr;
+          ctx->check(sqlrs_hash_join_probe_push(j, &in.b, SQLRS_MEM_HOST, &out));
+          if (out) return detail::import_batch(out, schema);
+        }
+        if (phase == 2) { // unvisited-left tail (:296-322)
+          phase = 3;
+          sqlrs_batch_t *out = nullptr;
+          ctx->check(sqlrs_hash_join_finish(j, SQLRS_MEM_HOST, &out));
+          if (out) return detail::import_batch(out, schema);
+        }
+        return std::nullopt;
+      }
+    };
+    auto s = std::make_unique<S>();
+    s->ctx = ctx; s->left = std::move(left_child); s->right = std::move(right_child);
+    auto sch = std::make_shared<Schema>(); // join_output_arrow_schema (hash_join.rs:136-143)
+    for (auto &c : join_output_schema) sch->push_back(c.to_arrow_field());
+    s->schema = sch;
+    std::vector<detail::Lowered> lk, rk;
+    std::vector<sqlrs_expr_t> lke, rke;
+    for (auto &p : join_condition.on) { lk.push_back(detail::lower(p.first)); rk.push_back(detail::lower(p.second)); }
+    for (auto &l : lk) lke.push_back(l.abi());
+    for (auto &r : rk) rke.push_back(r.abi());
+    detail::Lowered flt;
+    sqlrs_expr_t fe{nullptr, 0, 0};
+    if (join_condition.filter) { flt = detail::lower(*join_condition.filter); fe = flt.abi(); }
+    std::vector<int32_t> right_dtypes;
+    for (size_t i = num_left_columns; i < join_output_schema.size(); i++) right_dtypes.push_back((int32_t)join_output_schema[i].desc.data_type);
+    if (join_condition.on.empty()) throw ExecutorError(ExecutorError::InternalError, "HashJoin must has on condition");
+    ctx->check(sqlrs_hash_join_create(ctx->raw, (int)join_type, (int)lke.size(), lke.data(), rke.data(),
+                                      join_condition.filter ? &fe : nullptr, (int)right_dtypes.size(), right_dtypes.data(), &s->j));
+    return s;
+  }
+};
+
+struct HashAggExecutor { // hash_agg.rs:15-19
+  HipCtxRef ctx;
+  std::vector<BoundAggFunc> agg_funcs;
+  std::vector<BoundExpr> group_by;
+  BoxedExecutor child;
+  std::vector<std::string> output_names; // eval_field names, e.g. "a", "Sum(b)" (evaluator.rs:30-64)
+
+  BoxedExecutor execute() {
+    struct S : Executor {
+      HipCtxRef ctx; BoxedExecutor child; sqlrs_hash_agg_t *a = nullptr; std::vector<std::string> names; bool done = false;
+      ~S() override { if (a) sqlrs_hash_agg_destroy(a); }
+      std::optional<RecordBatch> next() override {
+        if (done) return std::nullopt;
+        done = true;
+        while (auto b = child->next()) { detail::AbiBatch in(*b); ctx->check(sqlrs_hash_agg_push(a, &in.b)); } // :44-122
+        sqlrs_batch_t *out = nullptr;
+        ctx->check(sqlrs_hash_agg_finish(a, SQLRS_MEM_HOST, &out)); // :124-149
+        RecordBatch rb = detail::import_batch(out, nullptr);
+        auto sch = std::make_shared<Schema>(*rb.schema);
+        for (size_t i = 0; i < sch->size() && i < names.size(); i++) (*sch)[i].name = names[i];
+        rb.schema = sch;
+        return rb;
+      }
+    };
+    auto s = std::make_unique<S>();
+    s->ctx = ctx; s->child = std::move(child); s->names = output_names;
+    std::vector<detail::Lowered> gl, al;
+    std::vector<sqlrs_expr_t> ge;
+    std::vector<sqlrs_agg_func_t> af;
+    for (auto &g : group_by) gl.push_back(detail::lower(g));
+    for (auto &g : gl) ge.push_back(g.abi());
+    for (auto &f : agg_funcs) al.push_back(detail::lower(f.exprs.at(0))); // only exprs[0] is read (hash_agg.rs:65)
+    for (size_t i = 0; i < agg_funcs.size(); i++)
+      af.push_back(sqlrs_agg_func_t{(int32_t)agg_funcs[i].func, agg_funcs[i].distinct, (int32_t)agg_funcs[i].return_type, 0, al[i].abi()});
+    ctx->check(sqlrs_hash_agg_create(ctx->raw, (int)ge.size(), ge.data(), (int)af.size(), af.data(), &s->a));
+    return s;
+  }
+};
+
+struct OrderExecutor { // order.rs:8-11
+  HipCtxRef ctx;
+  std::vector<BoundOrderBy> order_by;
+  BoxedExecutor child;
+  BoxedExecutor execute() {
+    struct S : Executor {
+      HipCtxRef ctx; BoxedExecutor child; sqlrs_order_t *o = nullptr; bool done = false;
+      ~S() override { if (o) sqlrs_order_destroy(o); }
+      std::optional<RecordBatch> next() override {
+        if (done) return std::nullopt;
+        done = true;
+        SchemaRef schema;
+        while (auto b = child->next()) { // order.rs:19-26
+          if (!schema) schema = b->schema;
+          detail::AbiBatch in(*b);
+          ctx->check(sqlrs_order_push(o, &in.b));
+        }
+        sqlrs_batch_t *out = nullptr;
+        ctx->check(sqlrs_order_finish(o, SQLRS_MEM_HOST, &out));
+        return detail::import_batch(out, schema);
+      }
+    };
+    auto s = std::make_unique<S>();
+    s->ctx = ctx; s->child = std::move(child);
+    std::vector<detail::Lowered> low;
+    std::vector<sqlrs_order_by_t> ob;
+    for (auto &x : order_by) low.push_back(detail::lower(x.expr));
+    for (size_t i = 0; i < order_by.size(); i++) ob.push_back(sqlrs_order_by_t{low[i].abi(), order_by[i].asc, 0});
+    ctx->check(sqlrs_order_create(ctx->raw, (int)ob.size(), ob.data(), &s->o));
+    return s;
+  }
+};
+
+} // namespace sqlrs
