@@ -57,6 +57,11 @@ def parse():
     p.add_argument("--threshold", type=float, default=0.5, help="WHERE f.val > threshold")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=float, default=0, help="0 = auto (about 10-30 s)")
+    p.add_argument("--exchange", choices=["auto", "partition", "broadcast"], default="auto",
+                   help="N>1: 'partition' = hash-partition fact AND dim on the join key + all-to-all (partitioned "
+                        "hash join); 'broadcast' = all-gather the dim keys, aggregate the local fact slice, then "
+                        "hash-partition + all-to-all only the partial aggregates and merge; 'auto' = broadcast when "
+                        "the dim is at least 16x smaller than the fact table")
     p.add_argument("--unfused", action="store_true",
                    help="run HashJoin and HashAgg as two operators (joined batch materialised in HBM)")
     p.add_argument("--operators", action="store_true",
@@ -166,12 +171,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    # test hook: all ranks on GPU 0 with a gloo process group (exchange staged through the host) so
+    # that the multi-rank logic can be exercised on a one-GPU box; never used for reported numbers
+    single_dev = os.environ.get("SQLRS_BENCH_SINGLE_DEVICE") == "1"
+    if single_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if single_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     be = sqlrs_amd.new_ctx(local_rank)  # raises if the HIP library / GPU is missing: no fallback
     n_fact_total, n_dim_total = int(args.rows), int(args.dim_rows)
@@ -191,6 +204,9 @@ def main():
     expected_kept = int((fact_val > args.threshold).sum().item())
 
     pipe = Pipeline(be, abi, args.threshold, fused=not args.unfused)
+
+    def D_shard(total, r, w):
+        return total * (r + 1) // w - total * r // w
     from sqlrs_amd.expr import InputRef
 
     def exchange(cols, dtypes):
@@ -201,12 +217,56 @@ def main():
         be.synchronize()
         views = [_tensor_view(torch, parts.column(ci).values, parts.column(ci).length, t.dtype, dev)
                  for ci, t in enumerate(cols)]
-        outs = D.all_to_all_columns(dist, views, offs, world, torch)  # same code as the gloo CPU test
+        if single_dev:  # gloo moves host tensors
+            outs = [o.to(dev) for o in D.all_to_all_columns(dist, [v.cpu() for v in views], offs, world, torch)]
+        else:
+            outs = D.all_to_all_columns(dist, views, offs, world, torch)  # same code as the gloo CPU test
         torch.cuda.synchronize()
         parts.release()
         return outs
 
+    strategy = args.exchange
+    if strategy == "auto":
+        strategy = "broadcast" if n_dim_total * 16 <= n_fact_total else "partition"
+    dim_sizes = [D_shard(n_dim_total, r, world) for r in range(world)]
+    merge_gb, _mk = abi.pack_exprs([InputRef(0)])
+    _mkeep = []
+    from sqlrs_amd.expr import AggFunc as _AggFunc
+    merge_aggs = (abi.AggFunc * 2)(_AggFunc("sum", InputRef(1), abi.INT64).abi_struct(_mkeep),
+                                   _AggFunc("sum", InputRef(2), abi.FLOAT64).abi_struct(_mkeep))
+
+    def gather_dim():
+        """all-gather of the dim keys (every rank ends up with the whole build side)"""
+        if single_dev:
+            parts = [torch.empty(n, dtype=torch.int64) for n in dim_sizes]
+            dist.all_gather(parts, dim_key.cpu())
+            return torch.cat(parts).to(dev)
+        parts = [torch.empty(n, dtype=torch.int64, device=dev) for n in dim_sizes]
+        dist.all_gather(parts, dim_key)
+        return torch.cat(parts)
+
     def one_step():
+        if world > 1 and strategy == "broadcast":
+            # 1. replicate the small build side  2. local Filter -> HashJoinAgg = PARTIAL aggregates
+            dk = gather_dim()
+            part = pipe.step(device_batch(abi, [dk], [abi.INT64]),
+                             device_batch(abi, [fact_key, fact_val], [abi.INT64, abi.FLOAT64]))
+            be.synchronize()
+            g = part.num_rows
+            cols = [_tensor_view(torch, part.column(i).values, g, t, dev)
+                    for i, t in enumerate((torch.int64, torch.int64, torch.float64))]
+            # 3. exchange the partial aggregates by key  4. merge: SUM(count), SUM(sum) per key
+            rk, rc, rs = exchange(cols, [abi.INT64, abi.INT64, abi.FLOAT64])
+            part.release()
+            a = C.c_void_p()
+            be.check(be.fn("hash_agg_create")(be.ctx, 1, merge_gb, 2, merge_aggs, C.byref(a)))
+            mb = device_batch(abi, [rk, rc, rs], [abi.INT64, abi.INT64, abi.FLOAT64])
+            be.check(be.fn("hash_agg_push")(a, mb.ptr))
+            ao = C.POINTER(abi.Batch)()
+            be.check(be.fn("hash_agg_finish")(a, abi.MEM_DEVICE, C.byref(ao)))
+            be.fn("hash_agg_destroy")(a)
+            be.synchronize()
+            return be.wrap(ao)
         if world > 1:
             dk, = exchange([dim_key], [abi.INT64])
             fk, fv = exchange([fact_key, fact_val], [abi.INT64, abi.FLOAT64])
@@ -318,7 +378,10 @@ def main():
                        "selectivity": round(exp_rows.item() / n_fact_total, 4),
                        "operators": "Filter -> HashJoin -> HashAgg (3 operators)" if args.unfused else
                        "Filter -> HashJoinAgg (HashAgg fused over the Inner HashJoin)",
-                       "parallelism": f"hash-partition x{world} + RCCL all-to-all" if world > 1 else "single GPU"},
+                       "parallelism": ("single GPU" if world == 1 else
+                                       f"x{world}: all-gather dim, local partial aggregation, all-to-all of partial aggregates, merge"
+                                       if strategy == "broadcast" else
+                                       f"x{world}: hash-partition fact+dim on the join key, all-to-all, local join+aggregate")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if operators:

@@ -49,7 +49,22 @@ def local_pipeline(oracle, dim_key, fact_key, fact_val):
             np.array(o.column(2).to_pylist(), dtype=np.float64))
 
 
-def worker(rank, world, port, result_path):
+def merge_partials(oracle, keys, cnt, sm):
+    """final merge of exchanged partial aggregates: SUM(count), SUM(sum) per key"""
+    import pyarrow as pa
+    from sqlrs_amd import abi
+    from sqlrs_amd.executor import HashAggExecutor
+    from sqlrs_amd.expr import AggFunc, InputRef
+    if len(keys) == 0:
+        return keys, cnt, sm
+    b = pa.RecordBatch.from_arrays([pa.array(keys), pa.array(cnt), pa.array(sm)], names=["k", "c", "s"])
+    (o,) = list(HashAggExecutor(oracle, [AggFunc("sum", InputRef(1), abi.INT64), AggFunc("sum", InputRef(2), abi.FLOAT64)],
+                                [InputRef(0)], [b]).execute())
+    return (np.array(o.column(0).to_pylist(), dtype=np.int64), np.array(o.column(1).to_pylist(), dtype=np.int64),
+            np.array(o.column(2).to_pylist(), dtype=np.float64))
+
+
+def worker(rank, world, port, result_path, strategy="partition"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -65,11 +80,25 @@ def worker(rank, world, port, result_path):
         outs = D.all_to_all_columns(dist, [torch.from_numpy(np.ascontiguousarray(c)) for c in parts], offs, world, torch)
         return [o.numpy() for o in outs]
 
-    (dk,) = exchange([dim_key[d_lo:d_hi]])
-    fk, fv = exchange([fact_key[f_lo:f_hi], fact_val[f_lo:f_hi]])
-    # every key this rank received belongs to this rank's partition
-    assert (D.partition_of(dk, world) == rank).all() and (D.partition_of(fk, world) == rank).all()
-    keys, cnt, sm = local_pipeline(oracle, dk, fk, fv)
+    if strategy == "broadcast":
+        # all-gather the dim, aggregate the local fact slice, exchange + merge partial aggregates
+        parts = [torch.empty(D.shard_bounds(N_DIM, r, world)[1] - D.shard_bounds(N_DIM, r, world)[0], dtype=torch.int64)
+                 for r in range(world)]
+        dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(dim_key[d_lo:d_hi])))
+        dk = torch.cat(parts).numpy()
+        assert (dk == dim_key).all()
+        pk, pc, ps = local_pipeline(oracle, dk, fact_key[f_lo:f_hi], fact_val[f_lo:f_hi])
+        rk, rc, rs = exchange([pk, pc, ps])
+        assert (D.partition_of(rk, world) == rank).all()
+        keys, cnt, sm = merge_partials(oracle, rk, rc, rs)
+        fk = fact_key[f_lo:f_hi]
+        dk = dim_key[d_lo:d_hi]
+    else:
+        (dk,) = exchange([dim_key[d_lo:d_hi]])
+        fk, fv = exchange([fact_key[f_lo:f_hi], fact_val[f_lo:f_hi]])
+        # every key this rank received belongs to this rank's partition
+        assert (D.partition_of(dk, world) == rank).all() and (D.partition_of(fk, world) == rank).all()
+        keys, cnt, sm = local_pipeline(oracle, dk, fk, fv)
     gathered = [None] * world
     dist.all_gather_object(gathered, (keys, cnt, sm, len(fk), len(dk)))
     if rank == 0:
@@ -95,9 +124,10 @@ def free_port():
         return s.getsockname()[1]
 
 
-def test_partitioned_join_groupby_world2_gloo(tmp_path):
+@pytest.mark.parametrize("strategy", ["partition", "broadcast"])
+def test_partitioned_join_groupby_world2_gloo(tmp_path, strategy):
     result = tmp_path / "result.txt"
-    mp.spawn(worker, args=(2, free_port(), str(result)), nprocs=2, join=True)
+    mp.spawn(worker, args=(2, free_port(), str(result), strategy), nprocs=2, join=True)
     assert result.read_text().startswith("ok")
 
 
