@@ -90,7 +90,7 @@ __device__ __forceinline__ uint64_t acc_identity_cell(int op) { return op == PAR
 __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     LdsAggParams prm, const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pi,
     const uint64_t *__restrict__ pv0, const uint64_t *__restrict__ pv1,
-    const uint8_t *__restrict__ pf, const uint32_t *__restrict__ bstart, uint32_t P,
+    const uint8_t *__restrict__ pf, const uint32_t *__restrict__ work /* {bucket, lo, hi} triples */, uint32_t P,
     int64_t n, unsigned long long *out_count, uint64_t *__restrict__ gkey,
     uint32_t *__restrict__ gfirst, uint8_t *__restrict__ gvalid, uint64_t *__restrict__ gacc,
     int64_t gcap, unsigned long long *ov_count, uint32_t *__restrict__ ov_rows,
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
   __shared__ unsigned int s_cnt;
   __shared__ unsigned long long s_base;
-  const uint32_t b = blockIdx.x;
+  // one work item = one bucket, or one chunk of an oversized (skewed) bucket
+  const uint32_t b = work[3 * blockIdx.x];
   const int cells = prm.cells;
   const uint32_t cap = prm.cap, mask = cap - 1, nslots = cap + 2;
   for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) {
@@ -137,8 +138,8 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     }
     __syncthreads();
   }
-  const int64_t lo = bstart[b];
-  const int64_t hi = bstart[b + 1];
+  const int64_t lo = work[3 * blockIdx.x + 1];
+  const int64_t hi = work[3 * blockIdx.x + 2];
   // 4 rows per thread per trip, all loads issued before the first dependent LDS op
   for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * PART_WG) {
     uint64_t keys4[4], v04[4], v14[4];
@@ -327,12 +328,6 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   prm.cells = cells;
   prm.cap = cap;
   int64_t gcap = (int64_t)std::min<double>((double)n, est * 1.5 + 65536.0 + 2.0 * P);
-  out->gkey = ctx->alloc(8 * (size_t)gcap);
-  out->gfirst = ctx->alloc(4 * (size_t)gcap);
-  out->gvalid = in.key_validity ? ctx->alloc((size_t)gcap) : nullptr;
-  out->gacc = ctx->alloc(8 * (size_t)gcap * (size_t)std::max(spec.n_acc, 1));
-  out->gcap = gcap;
-  out->ov_rows = ctx->alloc(4 * (size_t)n);
   BufP ctr = ctx->alloc_zero(24);
   size_t lds = (size_t)(cap + 2) * cells * 8;
   static bool attr_set = false;
@@ -341,11 +336,40 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
                                150 * 1024));
     attr_set = true;
   }
+  // work list: buckets larger than `chunk` rows (key skew) are split so that no workgroup streams
+  // more than `chunk` rows; the same key may then appear in several chunks (out->may_dup) and the
+  // caller merges the groups instead of adopting them as they are
+  std::vector<uint32_t> hb((size_t)P + 1);
+  SQ_HIP(hipMemcpyAsync(hb.data(), pr.bstart->p, 4 * hb.size(), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->sync();
+  const uint32_t chunk = (uint32_t)std::max<int64_t>(65536, 8 * (n / std::max<uint32_t>(P, 1)));
+  std::vector<uint32_t> work;
+  work.reserve(3 * ((size_t)P + 64));
+  out->may_dup = false;
+  for (uint32_t bkt = 0; bkt < P; bkt++) {
+    uint32_t lo = hb[bkt], hi = hb[bkt + 1];
+    if (hi - lo <= chunk) {
+      work.insert(work.end(), {bkt, lo, hi});
+    } else {
+      out->may_dup = true;
+      for (uint32_t c0 = lo; c0 < hi; c0 += chunk) work.insert(work.end(), {bkt, c0, std::min(hi, c0 + chunk)});
+    }
+  }
+  const uint32_t nwork = (uint32_t)(work.size() / 3);
+  BufP dwork = ctx->alloc(4 * work.size() + 16);
+  SQ_HIP(hipMemcpyAsync(dwork->p, work.data(), 4 * work.size(), hipMemcpyHostToDevice, ctx->stream));
+  gcap += (int64_t)(nwork - P) * (int64_t)(cap + 2); // every extra chunk can add a table's worth of partials
+  out->gkey = ctx->alloc(8 * (size_t)gcap);
+  out->gfirst = ctx->alloc(4 * (size_t)gcap);
+  out->gvalid = in.key_validity ? ctx->alloc((size_t)gcap) : nullptr;
+  out->gacc = ctx->alloc(8 * (size_t)gcap * (size_t)std::max(spec.n_acc, 1));
+  out->gcap = gcap;
+  out->ov_rows = ctx->alloc(4 * (size_t)n);
   {
     ProfScope ps(ctx, "lds_agg");
-    lds_agg_kernel<<<dim3(P), dim3(PART_WG), lds, ctx->stream>>>(
+    lds_agg_kernel<<<dim3(nwork), dim3(PART_WG), lds, ctx->stream>>>(
         prm, pk->as<uint64_t>(), pi->as<uint32_t>(), pv0 ? pv0->as<uint64_t>() : nullptr,
-        pv1 ? pv1->as<uint64_t>() : nullptr, pf ? pf->as<uint8_t>() : nullptr, pr.bstart->as<uint32_t>(), P,
+        pv1 ? pv1->as<uint64_t>() : nullptr, pf ? pf->as<uint8_t>() : nullptr, dwork->as<uint32_t>(), P,
         n, ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(),
         out->gvalid ? out->gvalid->as<uint8_t>() : nullptr, out->gacc->as<uint64_t>(), gcap,
         ctr->as<unsigned long long>() + 1, out->ov_rows->as<uint32_t>(),
@@ -353,6 +377,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
         bp ? bp->bstart->as<uint32_t>() : nullptr, join_mode ? 1 : 0);
     SQ_HIP(hipGetLastError());
   }
+  ctx->sync(); // `work` (host) was the source of an async upload
   const uint64_t *h = (const uint64_t *)ctx->fetch(ctr->p, 24);
   out->groups = (int64_t)h[0];
   out->n_overflow = (int64_t)h[1];

@@ -41,6 +41,7 @@ struct PartAggOutput {
   BufP gkey, gfirst, gvalid, gvalid_bits, gacc, row_ids;
   int64_t n_overflow = 0; // rows that did not fit their bucket table
   BufP ov_rows;           // their local row ids (u32)
+  bool may_dup = false;   // a skewed bucket was split: the same key can appear more than once
   double est_groups = 0;
   int buckets = 0;
 };

@@ -489,7 +489,7 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
           for (const DCol &kc : kcols) // key values of every group of the batch (hash_agg.rs:90-96)
             pg.keyvals.push_back(gather_column(ctx, kc, po.gfirst->p, false, nullptr, po.groups));
           pg.po = po;
-          if (a->st.ngroups == 0 && po.n_overflow == 0)
+          if (a->st.ngroups == 0 && po.n_overflow == 0 && !po.may_dup)
             a->pending = std::move(pg); // nothing to merge with yet: defer building the table
           else
             merge_groups(a, pg);

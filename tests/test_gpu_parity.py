@@ -437,3 +437,19 @@ def test_utf8_keys_join_and_agg(hip, oracle):
     aggs = [AggFunc("count", InputRef(0), abi.INT64), AggFunc("sum", InputRef(0), abi.FLOAT64)]
     got = rows_of(HashAggExecutor(hip, aggs, [InputRef(1)], [rb]).execute())
     assert_same(got, rows_of(HashAggExecutor(oracle, aggs, [InputRef(1)], [rb]).execute()), float_cols={2})
+
+
+def test_hash_agg_partition_route_with_key_skew(hip, oracle):
+    """A heavy-hitter key fills one LDS bucket beyond the chunk limit: the bucket is split over
+    several workgroups and the duplicate partial groups are merged (agg_partition.hip)."""
+    rng = np.random.default_rng(21)
+    n = 2_400_000
+    keys = rng.integers(0, 20_000, n, dtype=np.int64)
+    keys[rng.random(n) < 0.6] = 7  # 60 % of the rows share one key
+    b = pa.RecordBatch.from_arrays([pa.array(keys), pa.array(rng.random(n)), pa.array(rng.integers(-9, 9, n, dtype=np.int64))],
+                                   names=["k", "v", "w"])
+    aggs = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64),
+            AggFunc("min", InputRef(2), abi.INT64), AggFunc("sum", InputRef(2), abi.INT64)]
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
+    assert_same(got, exp, float_cols={2})
