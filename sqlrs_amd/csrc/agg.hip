@@ -216,6 +216,23 @@ __global__ void agg_rehash_kernel(const AggSlot *__restrict__ old_t, const uint3
   new_gid[d] = old_gid[i];
 }
 
+// gfirst[gid] = first_row of the group's slot (the slot keeps the running minimum; gfirst is
+// written when the group is created and goes stale if an earlier row arrives in a later call)
+__global__ void agg_refresh_gfirst_kernel(const AggSlot *__restrict__ t, const uint32_t *__restrict__ slot_gid,
+                                          int64_t nslots, uint64_t *__restrict__ gfirst) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nslots) return;
+  uint32_t g = slot_gid[i];
+  if (g != 0xffffffffu) gfirst[g] = t[i].first_row;
+}
+void agg_refresh_gfirst(Ctx *ctx, AggState &st) {
+  if (!st.table || st.ngroups == 0) return;
+  int64_t nslots = (int64_t)st.mask + 3;
+  agg_refresh_gfirst_kernel<<<dim3((unsigned)ceil_div(nslots, 256)), dim3(256), 0, ctx->stream>>>(
+      st.table->as<AggSlot>(), st.slot_gid->as<uint32_t>(), nslots, st.gfirst.buf->as<uint64_t>());
+  SQ_HIP(hipGetLastError());
+}
+
 void fill_u64(Ctx *ctx, uint64_t *p, int64_t n, uint64_t v) {
   if (n <= 0) return;
   fill_u64_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(p, n, v);

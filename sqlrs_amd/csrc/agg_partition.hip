@@ -272,6 +272,11 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   // 1. how many groups?  -> bucket count.  Fused join: every build key needs a slot.
   const bool join_mode = in.join_keys != nullptr;
   double est = join_mode ? (double)in.join_n : estimate_distinct(ctx, in.keys, in.key_validity, n);
+  static const double est_scale = [] { // test hook: mis-scale the estimate to force the overflow path
+    const char *e = std::getenv("SQLRS_EST_SCALE");
+    return e ? std::atof(e) : 1.0;
+  }();
+  if (!join_mode) est = std::max(1.0, est * est_scale);
   const int cells = 2 + spec.n_acc;
   // LDS budget per workgroup: 36 KiB tables let four 512-thread workgroups share a CU
   static const size_t lds_budget = [] {

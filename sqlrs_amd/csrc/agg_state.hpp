@@ -33,6 +33,7 @@ struct AggState {
 };
 
 void fill_u64(Ctx *ctx, uint64_t *p, int64_t n, uint64_t v);
+void agg_refresh_gfirst(Ctx *ctx, AggState &st);
 void agg_table_alloc(Ctx *ctx, AggState &st, uint64_t cap);
 BufP agg_resolve_rows(Ctx *ctx, AggState &st, const NKeys &k, const uint64_t *row_ids,
                       uint64_t offset, BufP *new_rows_out, int64_t *nnew_out);

@@ -667,6 +667,7 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
     if (!a->in_order && G > 1) {
       // groups were discovered out of row order (partition route): order by first row
       ProfScope ps(ctx, "agg_order_groups");
+      agg_refresh_gfirst(ctx, a->st);
       BufP keys = ctx->alloc(8 * (size_t)G), perm = ctx->alloc(4 * (size_t)G);
       SQ_HIP(hipMemcpyAsync(keys->p, a->st.gfirst.buf->p, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
       iota_u32(ctx, perm->as<uint32_t>(), G);

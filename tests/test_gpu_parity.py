@@ -453,3 +453,20 @@ def test_hash_agg_partition_route_with_key_skew(hip, oracle):
     got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
     exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
     assert_same(got, exp, float_cols={2})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", ["0.3", "0.05"])
+def test_hash_agg_partition_route_with_forced_table_overflow(scale):
+    """SQLRS_EST_SCALE shrinks the HyperLogLog group estimate, so the per-bucket LDS tables
+    overflow and rows take the overflow -> global-table path; group order and values must not
+    change (the hook is read once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SQLRS_EST_SCALE=scale)
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "(partition_route or mixed_routes or join_agg) and not forced"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
