@@ -84,35 +84,57 @@ struct RpOut {
   uint8_t *flags; // null when no column is nullable
 };
 
+// How a level reads its rows (template parameter of the scatter kernel, so the unrolled load
+// sequence has no branches: with run-time `if (in.idx)` / bitmap tests inside it the compiler put
+// an s_waitcnt vmcnt(0) after every row's loads and the 12 rows of a thread were fetched one
+// HBM latency after the other — 20 us per tile, i.e. the whole kernel):
+//   RP_L1      level 1, no nullable column: row id = position, flags = 7
+//   RP_L1_NULL level 1 with validity bitmaps (flags built from the bitmaps)
+//   RP_LN      level >= 2: row id column, no flags column
+//   RP_LN_FLAG level >= 2: row id column + flags column
+#ifdef RP_TIMING
+__device__ unsigned long long rp_timing[8];
+#define RP_T(i) do { if (threadIdx.x == 0) { long long now_ = clock64(); tacc[i] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define RP_T(i) do {} while (0)
+#endif
+enum { RP_L1 = 0, RP_L1_NULL = 1, RP_LN = 2, RP_LN_FLAG = 3 };
+
 // rows of one tile held in registers (one struct per pipeline stage)
 template <int NV, int RP_ROWS> struct TileRegs {
   uint64_t k[RP_ROWS], a0[NV >= 1 ? RP_ROWS : 1], a1[NV >= 2 ? RP_ROWS : 1];
   uint32_t id[RP_ROWS];
-  uint8_t fl[RP_ROWS]; // 0xff = no row
+  uint8_t fl[RP_ROWS];
+  uint32_t goff; // offs[] entry of (digit threadIdx.x, this tile)
 };
 
-template <int NV, int RP_WG, int RP_ROWS>
-__device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, TileRegs<NV, RP_ROWS> &r) {
+template <int NV, int RP_WG, int RP_ROWS, int MODE>
+__device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, const uint32_t *__restrict__ offs,
+                                             uint32_t digits, TileRegs<NV, RP_ROWS> &r) {
+  // every lane loads (rows past the end of a ragged tile re-read its last row), so the loads of
+  // all RP_ROWS rows are issued back to back
 #pragma unroll
   for (int j = 0; j < RP_ROWS; j++) {
-    uint32_t o = j * RP_WG + threadIdx.x;
-    r.fl[j] = 0xff;
-    if (o < t.len) {
-      int64_t row = t.start + o;
-      r.k[j] = in.key[row];
-      if (NV >= 1) r.a0[j] = in.v0[row];
-      if (NV >= 2) r.a1[j] = in.v1[row];
-      if (in.idx) {
-        r.id[j] = in.idx[row];
-        r.fl[j] = in.flags ? in.flags[row] : 7;
-      } else {
-        r.id[j] = (uint32_t)row;
-        uint8_t f = 0;
-        if (!in.key_validity || ((in.key_validity[row >> 6] >> (row & 63)) & 1)) f |= 1;
-        if (!in.v0_validity || ((in.v0_validity[row >> 6] >> (row & 63)) & 1)) f |= 2;
-        if (!in.v1_validity || ((in.v1_validity[row >> 6] >> (row & 63)) & 1)) f |= 4;
-        r.fl[j] = f;
-      }
+    uint32_t o = min((uint32_t)(j * RP_WG) + threadIdx.x, t.len - 1);
+    int64_t row = t.start + o;
+    r.k[j] = __builtin_nontemporal_load(in.key + row);
+    if (NV >= 1) r.a0[j] = __builtin_nontemporal_load(in.v0 + row);
+    if (NV >= 2) r.a1[j] = __builtin_nontemporal_load(in.v1 + row);
+    if (MODE == RP_LN || MODE == RP_LN_FLAG) r.id[j] = __builtin_nontemporal_load(in.idx + row);
+    else r.id[j] = (uint32_t)row;
+    if (MODE == RP_LN_FLAG) r.fl[j] = in.flags[row];
+    else r.fl[j] = 7;
+  }
+  r.goff = offs[t.mat + (int64_t)min(threadIdx.x, digits - 1) * t.stride];
+  if (MODE == RP_L1_NULL) {
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      int64_t row = t.start + min((uint32_t)(j * RP_WG) + threadIdx.x, t.len - 1);
+      uint8_t f = 0;
+      if (!in.key_validity || ((in.key_validity[row >> 6] >> (row & 63)) & 1)) f |= 1;
+      if (!in.v0_validity || ((in.v0_validity[row >> 6] >> (row & 63)) & 1)) f |= 2;
+      if (!in.v1_validity || ((in.v1_validity[row >> 6] >> (row & 63)) & 1)) f |= 4;
+      r.fl[j] = f;
     }
   }
 }
@@ -122,13 +144,20 @@ __device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, Tile
 // it: the rows of tile i+1 are loaded into a second register set before tile i goes through its
 // LDS phases (rank with LDS atomics -> scan -> stage sorted -> coalesced stores), which hides the
 // HBM latency that a 150 KiB-LDS kernel (one workgroup per CU) cannot hide with occupancy.
-template <int NV, int RP_WG, int RP_ROWS>
-__global__ __launch_bounds__(RP_WG) void rp_scatter_kernel(RpIn in, RpOut out,
+template <int NV, int RP_WG, int RP_ROWS, int MODE>
+__global__ __launch_bounds__(RP_WG, RP_ROWS <= 6 ? 2 : 1) void rp_scatter_kernel(RpIn in, RpOut out,
                                                            const Tile *__restrict__ tiles, uint32_t P,
                                                            uint32_t p2_bits, int level, uint32_t digits,
                                                            const uint32_t *__restrict__ offs,
-                                                           uint32_t num_tiles, uint32_t tiles_per_wg) {
+                                                           uint32_t num_tiles, uint32_t tiles_per_wg,
+                                                           int64_t sink) {
   constexpr int RP_TILE = RP_WG * RP_ROWS;
+  constexpr bool FLAGS = MODE == RP_L1_NULL || MODE == RP_LN_FLAG;
+#ifdef RP_NO_DRAIN
+  constexpr bool DRAIN = false;
+#else
+  constexpr bool DRAIN = true;
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t *skey = (uint64_t *)smem;
   uint64_t *sv0 = skey + RP_TILE;
@@ -144,27 +173,40 @@ __global__ __launch_bounds__(RP_WG) void rp_scatter_kernel(RpIn in, RpOut out,
   const uint32_t t0 = blockIdx.x * tiles_per_wg;
   const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
   if (t0 >= t1) return;
+  // Software pipeline: the rows of tile i+1 are loaded into a second register set before tile i
+  // goes through its LDS phases.  Everything that would make the compiler wait early is kept
+  // out of the loop (s_waitcnt vmcnt counts loads and stores together on gfx9, and at a join of
+  // two paths the compiler assumes the one with FEWER younger operations):
+  //  * loads are unconditional — ragged tiles re-read their last row, the last iteration
+  //    re-reads its own tile;
+  //  * stores are unconditional — the lanes past the end of a ragged tile write to the
+  //    `sink` rows behind the output columns;
+  //  * the first tile is complete before the loop, like every later tile on the back edge.
+  // With that the only wait in the loop is vmcnt(stores of this tile) before `cur = nxt`.
   TileRegs<NV, RP_ROWS> cur, nxt;
   Tile t = tiles[t0];
-  rp_load_tile<NV, RP_WG, RP_ROWS>(in, t, cur);
+  rp_load_tile<NV, RP_WG, RP_ROWS, MODE>(in, t, offs, digits, cur);
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+#ifdef RP_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
   for (uint32_t ti = t0; ti < t1; ti++) {
-    Tile tn = t;
-    if (ti + 1 < t1) { // prefetch the next tile (loads stay in flight during the LDS phases)
-      tn = tiles[ti + 1];
-      rp_load_tile<NV, RP_WG, RP_ROWS>(in, tn, nxt);
-    }
+    Tile tn = tiles[min(ti + 1, t1 - 1)];
+    rp_load_tile<NV, RP_WG, RP_ROWS, MODE>(in, tn, offs, digits, nxt);
     cnt[threadIdx.x] = 0;
     __syncthreads();
+    RP_T(0);
     uint32_t dg[RP_ROWS], rk[RP_ROWS];
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
       dg[j] = 0xffffffffu;
-      if (cur.fl[j] != 0xff) {
+      if ((uint32_t)(j * RP_WG) + threadIdx.x < t.len) {
         dg[j] = rp_digit(rp_bucket(cur.k[j], cur.fl[j] & 1, P), level, p2_bits);
         rk[j] = atomicAdd(&cnt[dg[j]], 1u);
       }
     }
     __syncthreads();
+    RP_T(1);
     { // exclusive scan of the RP_WG counters (one per thread)
       uint32_t c = cnt[threadIdx.x];
       uint32_t inc = wave_iscan_u32(c);
@@ -174,10 +216,10 @@ __global__ __launch_bounds__(RP_WG) void rp_scatter_kernel(RpIn in, RpOut out,
       for (int w = 0; w < wave_id(); w++) wbase += s_wsum[w];
       uint32_t ls = wbase + inc - c;
       lstart[threadIdx.x] = ls;
-      if (threadIdx.x < digits)
-        gbase[threadIdx.x] = (int64_t)offs[t.mat + (int64_t)threadIdx.x * t.stride] - (int64_t)ls;
+      gbase[threadIdx.x] = (int64_t)cur.goff - (int64_t)ls;
     }
     __syncthreads();
+    RP_T(2);
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
       if (dg[j] == 0xffffffffu) continue;
@@ -187,25 +229,32 @@ __global__ __launch_bounds__(RP_WG) void rp_scatter_kernel(RpIn in, RpOut out,
       if (NV >= 2) sv1[p] = cur.a1[j];
       sidx[p] = cur.id[j];
       sdig[p] = (uint16_t)dg[j];
-      sflag[p] = cur.fl[j];
+      if (FLAGS) sflag[p] = cur.fl[j];
     }
     __syncthreads();
+    RP_T(3);
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
       uint32_t p = j * RP_WG + threadIdx.x;
-      if (p < t.len) {
-        int64_t g = gbase[sdig[p]] + p;
-        out.key[g] = skey[p];
-        if (NV >= 1) out.v0[g] = sv0[p];
-        if (NV >= 2) out.v1[g] = sv1[p];
-        out.idx[g] = sidx[p];
-        if (out.flags) out.flags[g] = sflag[p];
-      }
+      int64_t g = gbase[sdig[p] & (RP_WG - 1)] + p;
+      if (p >= t.len) g = sink + threadIdx.x;
+      out.key[g] = skey[p];
+      if (NV >= 1) out.v0[g] = sv0[p];
+      if (NV >= 2) out.v1[g] = sv1[p];
+      out.idx[g] = sidx[p];
+      if (FLAGS) out.flags[g] = sflag[p];
     }
+    if (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads(); // the staging area and the counters are reused by the next tile
+    RP_T(4);
     cur = nxt;
     t = tn;
+    RP_T(5);
   }
+#ifdef RP_TIMING
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 6; i++) atomicAdd(&rp_timing[i], (unsigned long long)tacc[i]);
+#endif
 }
 
 // bucket b (level-1 digit d1 = b >> p2_bits ... ) start row, from the level's scanned matrix
@@ -278,37 +327,24 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   const uint32_t P = d1 << p2_bits;
   const bool flags = in.key_validity || in.val_validity[0] || in.val_validity[1];
   const int nv = in.nv;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<0, 512, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<1, 512, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<2, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<0, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<1, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<0, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<1, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    SQ_HIP(hipFuncSetAttribute((const void *)rp_scatter_kernel<2, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
-  }
   const int WG = 512;
-  // rows per thread: 12 -> 6144-row tiles (one workgroup per CU), 8 -> 4096, 6 -> 3072-row tiles
-  // (two workgroups per CU).  Measured on MI355X (C5, two passes over 5e8 rows): 12.8 / 13.4 /
-  // 13.6 ms — the pass moves 36-40 B/row at ~3.3 TB/s, ~70 % of the 4.9 TB/s copy ceiling, so tile
-  // shape is no longer the lever.  SQLRS_RP_ROWS overrides (tuning only).
-  static const int rows_env = [] {
+  // rows per thread: 12 -> 6144-row tiles, 8 -> 4096-row tiles (two value columns); one
+  // workgroup per CU either way (the staging area is ~140 KiB)
+  static const int rows_env = [] { // tuning only
     const char *e = std::getenv("SQLRS_RP_ROWS");
     return e ? std::atoi(e) : 0;
   }();
-  const int ROWS = rows_env == 6 ? 6 : ((rows_env == 8 || nv > 1) ? 8 : 12);
+  const int ROWS = nv > 1 ? 8 : (rows_env == 6 ? 6 : 12);
   const int RP_TILE = WG * ROWS;
   const size_t lds = (size_t)RP_TILE * (8 * (1 + nv) + 4 + 2 + 1) + (size_t)WG * (4 + 4 + 8);
 
   auto alloc_cols = [&](BufP &k, BufP &v0, BufP &v1, BufP &idx, BufP &fl) {
-    k = ctx->alloc(8 * (size_t)n);
-    v0 = nv >= 1 ? ctx->alloc(8 * (size_t)n) : nullptr;
-    v1 = nv >= 2 ? ctx->alloc(8 * (size_t)n) : nullptr;
-    idx = ctx->alloc(4 * (size_t)n);
-    fl = flags ? ctx->alloc((size_t)n) : nullptr;
+    const size_t np = (size_t)n + WG; // + the sink rows of rp_scatter_kernel
+    k = ctx->alloc(8 * np);
+    v0 = nv >= 1 ? ctx->alloc(8 * np) : nullptr;
+    v1 = nv >= 2 ? ctx->alloc(8 * np) : nullptr;
+    idx = ctx->alloc(4 * np);
+    fl = flags ? ctx->alloc(np) : nullptr;
   };
 
   // one level = hist + scan + scatter over `seg_start` segments
@@ -332,17 +368,45 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     {
       ProfScope ps(ctx, in.build_side ? "rp_scatter_build" : "rp_scatter");
       // one workgroup per CU slot; contiguous tile ranges (8 per workgroup at least)
-      uint32_t wgs = std::min<uint32_t>(nt, (uint32_t)ctx->num_cus * (ROWS <= 6 ? 2 : 1));
+      uint32_t wgs = std::min<uint32_t>(nt, (uint32_t)ctx->num_cus * (ROWS == 6 ? 2 : 1));
       uint32_t tpw = (uint32_t)ceil_div(nt, wgs);
       wgs = (uint32_t)ceil_div(nt, tpw);
       dim3 g(wgs), b((unsigned)WG);
       const Tile *tp = (const Tile *)tiles->p;
-#define SQ_RP(NV, R) rp_scatter_kernel<NV, 512, R><<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs->as<uint32_t>(), nt, tpw)
-      if (ROWS == 12) { if (nv == 0) SQ_RP(0, 12); else SQ_RP(1, 12); }
-      else if (ROWS == 8) { if (nv == 0) SQ_RP(0, 8); else if (nv == 1) SQ_RP(1, 8); else SQ_RP(2, 8); }
-      else { if (nv == 0) SQ_RP(0, 6); else if (nv == 1) SQ_RP(1, 6); else SQ_RP(2, 6); }
+      const int mode = level == 1 ? (flags ? RP_L1_NULL : RP_L1) : (flags ? RP_LN_FLAG : RP_LN);
+#define SQ_RP1(NV, R, M)                                                                                      \
+  do {                                                                                                        \
+    auto kfn = rp_scatter_kernel<NV, 512, R, M>;                                                              \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      SQ_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    kfn<<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs->as<uint32_t>(), nt, tpw, n); \
+  } while (0)
+#define SQ_RP(NV, R)                                                                                          \
+  do {                                                                                                        \
+    if (mode == RP_L1) SQ_RP1(NV, R, RP_L1);                                                                  \
+    else if (mode == RP_L1_NULL) SQ_RP1(NV, R, RP_L1_NULL);                                                   \
+    else if (mode == RP_LN) SQ_RP1(NV, R, RP_LN);                                                             \
+    else SQ_RP1(NV, R, RP_LN_FLAG);                                                                           \
+  } while (0)
+      if (nv == 2) SQ_RP(2, 8);
+      else if (ROWS == 6) { if (nv == 0) SQ_RP(0, 6); else SQ_RP(1, 6); }
+      else { if (nv == 0) SQ_RP(0, 12); else SQ_RP(1, 12); }
+#undef SQ_RP1
 #undef SQ_RP
       SQ_HIP(hipGetLastError());
+#ifdef RP_TIMING
+      {
+        unsigned long long h[8], z[8] = {0};
+        SQ_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(rp_timing), sizeof(h)));
+        SQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rp_timing), z, sizeof(z)));
+        if (nt > 1000)
+          fprintf(stderr, "[rp_timing] level %d digits %u tiles %u wgs %u: cycles/tile prefetch+zero %.0f rank %.0f scan %.0f stage %.0f store %.0f copywait %.0f\n",
+                  level, digits, nt, wgs, (double)h[0] / nt, (double)h[1] / nt, (double)h[2] / nt, (double)h[3] / nt, (double)h[4] / nt, (double)h[5] / nt);
+      }
+#endif
     }
     ctx->sync(); // `L.tiles` host vector was the source of an async upload
     *offs_out = offs;
