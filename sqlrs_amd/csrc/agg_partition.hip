@@ -76,17 +76,77 @@ double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validit
 }
 
 // ----------------------------------------------------------------- LDS aggregate --
+// accumulator code = kind | (value column << 3)
+enum AccKind { AK_COUNT = 0, AK_SUM_I64 = 1, AK_SUM_F64 = 2, AK_MIN_I64 = 3, AK_MIN_F64 = 4, AK_MAX_I64 = 5, AK_MAX_F64 = 6 };
+
 struct LdsAggParams {
   int n_acc;
-  int op[PART_MAX_ACC];   // PartOp
-  int src[PART_MAX_ACC];  // value column
-  int kind[PART_MAX_ACC]; // MIN/MAX: 0 i64, 1 f64
-  int cells;              // 8-byte cells per slot = 2 + n_acc
+  int code[PART_MAX_ACC]; // AccKind | src << 3
   uint32_t cap;           // slots (power of two); +2 reserved slots follow
 };
 
-__device__ __forceinline__ uint64_t acc_identity_cell(int op) { return op == PART_MIN ? ~0ull : 0ull; }
+__device__ __forceinline__ uint64_t acc_identity_cell(int kind) {
+  return (kind == AK_MIN_I64 || kind == AK_MIN_F64) ? ~0ull : 0ull;
+}
 
+// slot hash inside a bucket.  The bucket itself is chosen by the high bits of mix64(key), so any
+// cheap function of the key is independent of it; two 32-bit multiplies instead of mix64's two
+// 64-bit ones (the kernel is bound by instruction issue, not by LDS or HBM).
+__device__ __forceinline__ uint32_t slot_hash(uint64_t key) {
+  uint32_t x = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85ebca6bu);
+  x *= 0x9e3779b1u;
+  return x ^ (x >> 15);
+}
+
+__device__ __forceinline__ void acc_apply(int kind, unsigned long long *c, uint64_t v) {
+  switch (kind) {
+  case AK_COUNT: atomicAdd(c, 1ull); break;
+  case AK_SUM_I64: atomicAdd(c, (unsigned long long)v); break;
+  case AK_SUM_F64: unsafeAtomicAdd((double *)c, __longlong_as_double((long long)v)); break;
+  case AK_MIN_I64: atomicMin(c, (unsigned long long)i64_to_ordered((int64_t)v)); break;
+  case AK_MIN_F64: atomicMin(c, (unsigned long long)f64_to_ordered(__longlong_as_double((long long)v))); break;
+  case AK_MAX_I64: atomicMax(c, (unsigned long long)i64_to_ordered((int64_t)v)); break;
+  default: atomicMax(c, (unsigned long long)f64_to_ordered(__longlong_as_double((long long)v)));
+  }
+}
+
+// rows of one trip (LDS_U rows per thread) held in registers
+constexpr int LDS_U = 4;
+template <int NV> struct AggRows {
+  uint64_t k[LDS_U], v0[NV >= 1 ? LDS_U : 1], v1[NV >= 2 ? LDS_U : 1];
+  uint32_t id[LDS_U];
+  uint8_t f[LDS_U];
+};
+
+// every lane loads (rows past `hi` re-read row hi-1), so all loads of a trip issue back to back
+template <int NV, bool FLAGS>
+__device__ __forceinline__ void lds_agg_load(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pi,
+                                             const uint64_t *__restrict__ pv0, const uint64_t *__restrict__ pv1,
+                                             const uint8_t *__restrict__ pf, int64_t i0, int64_t hi,
+                                             AggRows<NV> &r) {
+#pragma unroll
+  for (int u = 0; u < LDS_U; u++) {
+    int64_t i = min(i0 + (int64_t)u * PART_WG, hi - 1);
+    r.k[u] = __builtin_nontemporal_load(pk + i);
+    r.id[u] = __builtin_nontemporal_load(pi + i);
+    if (NV >= 1) r.v0[u] = __builtin_nontemporal_load(pv0 + i);
+    if (NV >= 2) r.v1[u] = __builtin_nontemporal_load(pv1 + i);
+    r.f[u] = FLAGS ? pf[i] : 7;
+  }
+}
+
+// One workgroup per work item (a bucket, or a chunk of a skewed bucket).
+//
+// Table layout in LDS (structure of arrays, nslots = cap + 2; slot cap = NULL key, cap + 1 = the
+// key whose value is the EMPTY marker):  key[nslots] u64 | acc[n_acc][nslots] u64 | first[nslots] u32.
+// 64 lanes probing random slots touch 32 different bank pairs this way; with 32-byte
+// array-of-struct slots they fell on 8 (SQ_LDS_BANK_CONFLICT was 60 % of the LDS cycles).
+//
+// NACC >= 0: the accumulator list is a compile-time constant (C0, C1 = codes of accumulators
+// 0 and 1), which removes the per-row interpreter (loop + switch over prm.code); NACC < 0 reads
+// it from `prm`.  JOIN: fused inner join, the bucket's build keys are inserted first and probe
+// rows only accumulate into slots that exist.
+template <int NV, bool FLAGS, bool JOIN, int NACC, int C0, int C1>
 __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     LdsAggParams prm, const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pi,
     const uint64_t *__restrict__ pv0, const uint64_t *__restrict__ pv1,
@@ -94,39 +154,46 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     int64_t n, unsigned long long *out_count, uint64_t *__restrict__ gkey,
     uint32_t *__restrict__ gfirst, uint8_t *__restrict__ gvalid, uint64_t *__restrict__ gacc,
     int64_t gcap, unsigned long long *ov_count, uint32_t *__restrict__ ov_rows,
-    const uint64_t *__restrict__ bk, const uint8_t *__restrict__ bf, const uint32_t *__restrict__ bbstart,
-    int join_mode) {
+    const uint64_t *__restrict__ bk, const uint8_t *__restrict__ bf, const uint32_t *__restrict__ bbstart) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
   __shared__ unsigned int s_cnt;
   __shared__ unsigned long long s_base;
-  // one work item = one bucket, or one chunk of an oversized (skewed) bucket
   const uint32_t b = work[3 * blockIdx.x];
-  const int cells = prm.cells;
+  const int64_t lo = work[3 * blockIdx.x + 1];
+  const int64_t hi = work[3 * blockIdx.x + 2];
   const uint32_t cap = prm.cap, mask = cap - 1, nslots = cap + 2;
+  const int n_acc = NACC >= 0 ? NACC : prm.n_acc;
+  auto code_of = [&](int a) { return NACC >= 0 ? (a == 0 ? C0 : C1) : prm.code[a]; };
+  unsigned long long *tkey = tab;
+  unsigned long long *tacc = tab + nslots;
+  unsigned int *tfirst = (unsigned int *)(tacc + (size_t)n_acc * nslots);
+  AggRows<NV> cur, nxt;
+  if (lo < hi) lds_agg_load<NV, FLAGS>(pk, pi, pv0, pv1, pf, lo + threadIdx.x, hi, cur); // in flight during the set-up
   for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) {
-    unsigned long long *c = tab + (size_t)s * cells;
-    c[0] = LDS_EMPTY;
-    c[1] = ~0ull; // first row (low 32 bits used)
-    for (int a = 0; a < prm.n_acc; a++) c[2 + a] = acc_identity_cell(prm.op[a]);
+    tkey[s] = LDS_EMPTY;
+    tfirst[s] = 0xffffffffu;
+#pragma unroll
+    for (int a = 0; a < PART_MAX_ACC; a++) {
+      if (a >= n_acc) break;
+      tacc[(size_t)a * nslots + s] = acc_identity_cell(code_of(a) & 7);
+    }
   }
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
-  if (join_mode) {
-    // fused inner join: the bucket's BUILD keys are inserted first; probe rows then only
-    // accumulate into slots that exist (a probe key without a build partner is dropped)
+  if (JOIN) {
     const int64_t blo = bbstart[b], bhi = bbstart[b + 1];
     for (int64_t i = blo + threadIdx.x; i < bhi; i += PART_WG) {
       uint64_t key = bk[i];
       bool valid = bf ? (bf[i] & 1) : true;
       if (!valid) {
-        tab[(size_t)cap * cells] = 1; // NULL build key present (NULL = NULL matches)
+        tkey[cap] = 1; // NULL build key present (NULL = NULL matches)
       } else if (key == LDS_EMPTY) {
-        tab[(size_t)(cap + 1) * cells] = 1;
+        tkey[cap + 1] = 1;
       } else {
-        uint32_t s = (uint32_t)(mix64(key) >> 7) & mask;
+        uint32_t s = slot_hash(key) & mask;
         uint32_t probes = 0;
         while (true) {
-          unsigned long long prev = atomicCAS(&tab[(size_t)s * cells], LDS_EMPTY, (unsigned long long)key);
+          unsigned long long prev = atomicCAS(&tkey[s], LDS_EMPTY, (unsigned long long)key);
           if (prev == LDS_EMPTY || prev == key) break;
           s = (s + 1) & mask;
           if (++probes >= cap) {
@@ -138,116 +205,93 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     }
     __syncthreads();
   }
-  const int64_t lo = work[3 * blockIdx.x + 1];
-  const int64_t hi = work[3 * blockIdx.x + 2];
-  // 4 rows per thread per trip, all loads issued before the first dependent LDS op
-  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * PART_WG) {
-    uint64_t keys4[4], v04[4], v14[4];
-    uint32_t idx4[4];
-    uint8_t f4[4];
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
+  for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {
+    const int64_t i0 = base + threadIdx.x;
+    // next trip's rows (the last trip re-reads the last rows of the bucket)
+    lds_agg_load<NV, FLAGS>(pk, pi, pv0, pv1, pf, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
+    // first probe of all LDS_U rows: the table reads are independent and issue together
+    uint32_t slot[LDS_U];
+    unsigned long long seen[LDS_U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int64_t i = i0 + (int64_t)u * PART_WG;
-      bool in = i < hi;
-      keys4[u] = in ? pk[i] : 0;
-      idx4[u] = in ? pi[i] : 0;
-      f4[u] = in ? (pf ? pf[i] : 7) : 0xff;
-      v04[u] = (in && pv0) ? pv0[i] : 0;
-      v14[u] = (in && pv1) ? pv1[i] : 0;
+    for (int u = 0; u < LDS_U; u++) {
+      uint32_t s = slot_hash(cur.k[u]) & mask;
+      if (FLAGS && !(cur.f[u] & 1)) s = cap;            // NULL keys: one group
+      else if (cur.k[u] == LDS_EMPTY) s = cap + 1;
+      slot[u] = s;
+      seen[u] = tkey[s];
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-    if (f4[u] == 0xff) continue;
-    uint64_t key = keys4[u];
-    uint32_t idx = idx4[u];
-    uint8_t f = f4[u];
-    uint32_t s;
-    bool ok = true;
-    if (!(f & 1)) {
-      s = cap; // NULL keys: one group
-      if (join_mode && tab[(size_t)s * cells] == LDS_EMPTY) continue;
-    } else if (key == LDS_EMPTY) {
-      s = cap + 1;
-      if (join_mode && tab[(size_t)s * cells] == LDS_EMPTY) continue;
-    } else if (join_mode) {
-      s = (uint32_t)(mix64(key) >> 7) & mask;
-      uint32_t probes = 0;
-      bool found = false;
-      while (probes++ < cap) {
-        unsigned long long cur = tab[(size_t)s * cells];
-        if (cur == key) {
-          found = true;
-          break;
+    for (int u = 0; u < LDS_U; u++) {
+      if (i0 + (int64_t)u * PART_WG >= hi) continue;
+      const uint64_t key = cur.k[u];
+      uint32_t s = slot[u];
+      unsigned long long c = seen[u];
+      bool ok = true;
+      if (s >= cap) { // reserved slots: no probing
+        if (JOIN && c == LDS_EMPTY) continue;
+      } else if (JOIN) {
+        uint32_t probes = 0;
+        while (c != key && c != LDS_EMPTY && ++probes < cap) {
+          s = (s + 1) & mask;
+          c = tkey[s];
         }
-        if (cur == LDS_EMPTY) break;
-        s = (s + 1) & mask;
-      }
-      if (!found) continue;
-    } else {
-      s = (uint32_t)(mix64(key) >> 7) & mask;
-      uint32_t probes = 0;
-      while (true) {
-        unsigned long long cur = tab[(size_t)s * cells];
-        if (cur == key) break;
-        if (cur == LDS_EMPTY) {
-          unsigned long long prev = atomicCAS(&tab[(size_t)s * cells], LDS_EMPTY, (unsigned long long)key);
-          if (prev == LDS_EMPTY || prev == key) break;
-        }
-        s = (s + 1) & mask;
-        if (++probes >= cap) { // table full: hand the row back to the caller
-          ok = false;
-          break;
+        if (c != key) continue; // no build partner
+      } else {
+        uint32_t probes = 0;
+        while (true) {
+          if (c == key) break;
+          if (c == LDS_EMPTY) {
+            unsigned long long prev = atomicCAS(&tkey[s], LDS_EMPTY, (unsigned long long)key);
+            if (prev == LDS_EMPTY || prev == key) break;
+          }
+          s = (s + 1) & mask;
+          if (++probes >= cap) { // table full: hand the row back to the caller
+            ok = false;
+            break;
+          }
+          c = tkey[s];
         }
       }
-    }
-    if (!ok) {
-      unsigned long long o = atomicAdd(ov_count, 1ull);
-      ov_rows[o] = idx;
-      continue;
-    }
-    unsigned long long *c = tab + (size_t)s * cells;
-    atomicMin((unsigned int *)&c[1], idx);
-    for (int a = 0; a < prm.n_acc; a++) {
-      int src = prm.src[a];
-      if (!(f & (2 << src))) continue; // NULL input is skipped by every accumulator
-      uint64_t v = src ? v14[u] : v04[u];
-      switch (prm.op[a]) {
-      case PART_COUNT: atomicAdd(&c[2 + a], 1ull); break;
-      case PART_SUM_I64: atomicAdd(&c[2 + a], (unsigned long long)v); break;
-      case PART_SUM_F64: unsafeAtomicAdd((double *)&c[2 + a], __longlong_as_double((long long)v)); break;
-      case PART_MIN:
-        atomicMin(&c[2 + a], (unsigned long long)(prm.kind[a] ? f64_to_ordered(__longlong_as_double((long long)v))
-                                                               : i64_to_ordered((int64_t)v)));
-        break;
-      default:
-        atomicMax(&c[2 + a], (unsigned long long)(prm.kind[a] ? f64_to_ordered(__longlong_as_double((long long)v))
-                                                               : i64_to_ordered((int64_t)v)));
+      if (!ok) {
+        unsigned long long o = atomicAdd(ov_count, 1ull);
+        ov_rows[o] = cur.id[u];
+        continue;
+      }
+      atomicMin(&tfirst[s], cur.id[u]);
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        const int code = code_of(a);
+        const int src = code >> 3;
+        if (FLAGS && !(cur.f[u] & (2 << src))) continue; // NULL input is skipped by every accumulator
+        uint64_t v = (NV >= 2 && src) ? cur.v1[u] : cur.v0[u];
+        acc_apply(code & 7, tacc + (size_t)a * nslots + s, v);
       }
     }
-    } // u
+    cur = nxt;
   }
   __syncthreads();
   // compact the occupied slots of this bucket into the global group list
   unsigned int mine = 0;
-  for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) {
-    const unsigned long long *c = tab + (size_t)s * cells;
-    bool occ = (unsigned int)c[1] != 0xffffffffu;
-    mine += occ;
-  }
+  for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) mine += tfirst[s] != 0xffffffffu;
   unsigned int my_off = atomicAdd(&s_cnt, mine);
   __syncthreads();
   if (threadIdx.x == 0) s_base = atomicAdd(out_count, (unsigned long long)s_cnt);
   __syncthreads();
   unsigned long long base = s_base + my_off;
   for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) {
-    const unsigned long long *c = tab + (size_t)s * cells;
-    bool occ = (unsigned int)c[1] != 0xffffffffu;
-    if (!occ) continue;
+    unsigned int first = tfirst[s];
+    if (first == 0xffffffffu) continue;
     if ((int64_t)base < gcap) {
-      gkey[base] = s == cap + 1 ? LDS_EMPTY : c[0];
-      gfirst[base] = (unsigned int)c[1];
+      gkey[base] = s == cap + 1 ? LDS_EMPTY : tkey[s];
+      gfirst[base] = first;
       if (gvalid) gvalid[base] = s == cap ? 0 : 1;
-      for (int a = 0; a < prm.n_acc; a++) gacc[(size_t)a * gcap + base] = c[2 + a];
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        gacc[(size_t)a * gcap + base] = tacc[(size_t)a * nslots + s];
+      }
     }
     base++;
   }
@@ -277,15 +321,23 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     return e ? std::atof(e) : 1.0;
   }();
   if (!join_mode) est = std::max(1.0, est * est_scale);
-  const int cells = 2 + spec.n_acc;
-  // LDS budget per workgroup: 36 KiB tables let four 512-thread workgroups share a CU
+  // LDS budget per workgroup and fill target.  72 KiB (two 512-thread workgroups per CU) filled
+  // to 27 %: the probe loops of a wave run as long as its unluckiest lane, and at 55 % fill
+  // (36 KiB tables, four workgroups per CU) that was ~5 trips per row instead of ~2:
+  // 3.7 ms vs 3.0 ms for the C5 bucket pass.  Fewer groups per table would need more buckets,
+  // which costs more in the partition passes than it saves here.
   static const size_t lds_budget = [] {
     const char *e = std::getenv("SQLRS_LDS_AGG_KB");
-    return (size_t)(e ? std::atoi(e) : 36) * 1024;
+    return (size_t)(e ? std::atoi(e) : 72) * 1024;
   }();
+  const size_t slot_bytes = 8 + 8 * (size_t)spec.n_acc + 4; // key, accumulators, first row
   uint32_t cap = 1;
-  while ((size_t)(cap * 2 + 2) * cells * 8 <= lds_budget) cap *= 2;
-  const double groups_per_table = cap * 0.55;
+  while ((size_t)(cap * 2 + 2) * slot_bytes <= lds_budget) cap *= 2;
+  static const double load_factor = [] { // tuning hook
+    const char *e = std::getenv("SQLRS_LDS_LOAD");
+    return e ? std::atof(e) : 0.275;
+  }();
+  const double groups_per_table = cap * load_factor;
   double want = est * 1.15 / groups_per_table;
   if (want > 65536.0 || (!join_mode && est > 0.5 * (double)n)) return false; // too many groups: resolve path
   uint32_t P = (uint32_t)std::max(1.0, std::ceil(want));
@@ -326,21 +378,22 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   LdsAggParams prm;
   prm.n_acc = spec.n_acc;
   for (int a = 0; a < PART_MAX_ACC; a++) {
-    prm.op[a] = a < spec.n_acc ? spec.op[a] : 0;
-    prm.src[a] = a < spec.n_acc ? spec.src[a] : 0;
-    prm.kind[a] = a < spec.n_acc ? spec.kind[a] : 0;
+    int kind = AK_COUNT;
+    if (a < spec.n_acc) {
+      switch (spec.op[a]) {
+      case PART_COUNT: kind = AK_COUNT; break;
+      case PART_SUM_I64: kind = AK_SUM_I64; break;
+      case PART_SUM_F64: kind = AK_SUM_F64; break;
+      case PART_MIN: kind = spec.kind[a] ? AK_MIN_F64 : AK_MIN_I64; break;
+      default: kind = spec.kind[a] ? AK_MAX_F64 : AK_MAX_I64;
+      }
+    }
+    prm.code[a] = a < spec.n_acc ? (kind | (spec.src[a] << 3)) : 0;
   }
-  prm.cells = cells;
   prm.cap = cap;
   int64_t gcap = (int64_t)std::min<double>((double)n, est * 1.5 + 65536.0 + 2.0 * P);
   BufP ctr = ctx->alloc_zero(24);
-  size_t lds = (size_t)(cap + 2) * cells * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SQ_HIP(hipFuncSetAttribute((const void *)lds_agg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               150 * 1024));
-    attr_set = true;
-  }
+  size_t lds = round_up((size_t)(cap + 2) * slot_bytes, 16);
   // work list: buckets larger than `chunk` rows (key skew) are split so that no workgroup streams
   // more than `chunk` rows; the same key may then appear in several chunks (out->may_dup) and the
   // caller merges the groups instead of adopting them as they are
@@ -372,14 +425,50 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   out->ov_rows = ctx->alloc(4 * (size_t)n);
   {
     ProfScope ps(ctx, "lds_agg");
-    lds_agg_kernel<<<dim3(nwork), dim3(PART_WG), lds, ctx->stream>>>(
-        prm, pk->as<uint64_t>(), pi->as<uint32_t>(), pv0 ? pv0->as<uint64_t>() : nullptr,
-        pv1 ? pv1->as<uint64_t>() : nullptr, pf ? pf->as<uint8_t>() : nullptr, dwork->as<uint32_t>(), P,
-        n, ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(),
-        out->gvalid ? out->gvalid->as<uint8_t>() : nullptr, out->gacc->as<uint64_t>(), gcap,
-        ctr->as<unsigned long long>() + 1, out->ov_rows->as<uint32_t>(),
-        bp ? bp->key->as<uint64_t>() : nullptr, (bp && bp->flags) ? bp->flags->as<uint8_t>() : nullptr,
-        bp ? bp->bstart->as<uint32_t>() : nullptr, join_mode ? 1 : 0);
+#define SQ_LA(NV, FL, JN, NA, C0, C1)                                                                          \
+  do {                                                                                                         \
+    auto kfn = lds_agg_kernel<NV, FL, JN, NA, C0, C1>;                                                         \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                           \
+      SQ_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));  \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    kfn<<<dim3(nwork), dim3(PART_WG), lds, ctx->stream>>>(                                                     \
+        prm, pk->as<uint64_t>(), pi->as<uint32_t>(), pv0 ? pv0->as<uint64_t>() : nullptr,                      \
+        pv1 ? pv1->as<uint64_t>() : nullptr, pf ? pf->as<uint8_t>() : nullptr, dwork->as<uint32_t>(), P, n,    \
+        ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(),                 \
+        out->gvalid ? out->gvalid->as<uint8_t>() : nullptr, out->gacc->as<uint64_t>(), gcap,                   \
+        ctr->as<unsigned long long>() + 1, out->ov_rows->as<uint32_t>(),                                       \
+        bp ? bp->key->as<uint64_t>() : nullptr, (bp && bp->flags) ? bp->flags->as<uint8_t>() : nullptr,        \
+        bp ? bp->bstart->as<uint32_t>() : nullptr);                                                            \
+    launched = true;                                                                                           \
+  } while (0)
+#define SQ_LA_J(NV, FL, NA, C0, C1)                                                                            \
+  do {                                                                                                         \
+    if (join_mode) SQ_LA(NV, FL, true, NA, C0, C1);                                                            \
+    else SQ_LA(NV, FL, false, NA, C0, C1);                                                                     \
+  } while (0)
+    const int nvu = pv1 ? 2 : (pv0 ? 1 : 0);
+    bool launched = false;
+    // specialised kernels: no nullable column, one value column, the usual accumulator lists
+    if (!pf && nvu == 1 && spec.n_acc <= 2) {
+      const int c0 = prm.code[0], c1 = spec.n_acc == 2 ? prm.code[1] : -1;
+#define SQ_SIG1(K) if (!launched && spec.n_acc == 1 && c0 == K) SQ_LA_J(1, false, 1, K, 0)
+#define SQ_SIG2(K0, K1) if (!launched && spec.n_acc == 2 && c0 == K0 && c1 == K1) SQ_LA_J(1, false, 2, K0, K1)
+      SQ_SIG1(AK_COUNT); SQ_SIG1(AK_SUM_I64); SQ_SIG1(AK_SUM_F64); SQ_SIG1(AK_MIN_I64); SQ_SIG1(AK_MIN_F64);
+      SQ_SIG1(AK_MAX_I64); SQ_SIG1(AK_MAX_F64);
+      SQ_SIG2(AK_COUNT, AK_SUM_F64); SQ_SIG2(AK_SUM_F64, AK_COUNT);
+      SQ_SIG2(AK_COUNT, AK_SUM_I64); SQ_SIG2(AK_SUM_I64, AK_COUNT);
+      SQ_SIG2(AK_MIN_F64, AK_MAX_F64); SQ_SIG2(AK_MIN_I64, AK_MAX_I64);
+#undef SQ_SIG1
+#undef SQ_SIG2
+    }
+    if (!launched) { // generic: the accumulator list is interpreted per row
+      if (pf) { if (nvu == 0) SQ_LA_J(0, true, -1, 0, 0); else if (nvu == 1) SQ_LA_J(1, true, -1, 0, 0); else SQ_LA_J(2, true, -1, 0, 0); }
+      else { if (nvu == 0) SQ_LA_J(0, false, -1, 0, 0); else if (nvu == 1) SQ_LA_J(1, false, -1, 0, 0); else SQ_LA_J(2, false, -1, 0, 0); }
+    }
+#undef SQ_LA_J
+#undef SQ_LA
     SQ_HIP(hipGetLastError());
   }
   ctx->sync(); // `work` (host) was the source of an async upload
