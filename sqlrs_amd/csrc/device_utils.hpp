@@ -104,7 +104,15 @@ __device__ __forceinline__ void lb_store(uint64_t *p, uint64_t v) {
 }
 
 // Called by ALL 64 lanes of ONE wave.  Publishes this tile's aggregate, walks back over
-// predecessor descriptors 64 at a time and returns the tile's exclusive prefix.
+// predecessor descriptors 64 * LB_LOADS at a time and returns the tile's exclusive prefix.
+//
+// Throughput limit of the chained scan: when tiles start at rate R (tiles/us) and one descriptor
+// read costs L us (agent-scope, ~1-2 us under load), the nearest finished prefix is R*L' tiles
+// back, where L' is the look-back time itself — it only stays short while R * L / window < 1.
+// 4096-row tiles at 290 Grows/s are R = 70 tiles/us: the 64-wide window was saturated and the
+// filter ran at the look-back's pace, not HBM's.  The cure is fewer, larger tiles (select.hip),
+// not a wider window: LB_LOADS = 4 was measured slower (the descriptor polling traffic grows).
+template <int LB_LOADS = 1>
 __device__ __forceinline__ uint64_t lookback_wave(uint64_t *desc, int64_t tile, uint64_t aggregate,
                                                   unsigned *timeout = nullptr) {
   const int lane = lane_id();
@@ -116,27 +124,38 @@ __device__ __forceinline__ uint64_t lookback_wave(uint64_t *desc, int64_t tile, 
   uint64_t excl = 0;
   int64_t base = tile - 1;
   unsigned spins = 0;
-  while (true) {
-    int64_t t = base - lane;
-    uint64_t d = (t >= 0) ? lb_load(&desc[t]) : LB_PFX; // virtual tiles < 0: prefix 0
-    uint64_t status = d >> 62;
-    uint64_t invalid = __ballot(status == 0);
-    uint64_t pfx = __ballot(status == 2);
-    int first_pfx = pfx ? __builtin_ctzll(pfx) : 64;
-    uint64_t need = first_pfx == 64 ? ~0ull : ((1ull << first_pfx) - 1);
-    if (invalid & need) {
+  bool done = false;
+  while (!done) {
+    uint64_t d[LB_LOADS];
+#pragma unroll
+    for (int q = 0; q < LB_LOADS; q++) {
+      int64_t t = base - lane - 64 * q;
+      d[q] = (t >= 0) ? lb_load(&desc[t]) : LB_PFX; // virtual tiles < 0: prefix 0
+    }
+    int consumed = 0; // 64-descriptor groups of this window that were complete
+#pragma unroll
+    for (int q = 0; q < LB_LOADS; q++) {
+      if (done || consumed != q) continue;
+      uint64_t status = d[q] >> 62;
+      uint64_t invalid = __ballot(status == 0);
+      uint64_t pfx = __ballot(status == 2);
+      int first_pfx = pfx ? __builtin_ctzll(pfx) : 64;
+      uint64_t need = first_pfx == 64 ? ~0ull : ((1ull << first_pfx) - 1);
+      if (invalid & need) continue; // a predecessor has not published yet: re-read from here
+      uint64_t v = (lane <= first_pfx) ? (d[q] & LB_VAL) : 0;
+      excl += wave_sum_u64(v);
+      consumed = q + 1;
+      if (first_pfx < 64) done = true;
+    }
+    base -= 64 * consumed;
+    if (!done && consumed < LB_LOADS) {
       if (timeout && (++spins > LB_SPIN_LIMIT ||
                       __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
         if (lane == 0) __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break; // the host discards this launch and reruns it with tickets
       }
       __builtin_amdgcn_s_sleep(2);
-      continue;
     }
-    uint64_t v = (lane <= first_pfx) ? (d & LB_VAL) : 0;
-    excl += wave_sum_u64(v);
-    if (first_pfx < 64) break;
-    base -= 64;
   }
   if (lane == 0) lb_store(&desc[tile], LB_PFX | (excl + aggregate));
   return excl;

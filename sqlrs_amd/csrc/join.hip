@@ -333,6 +333,18 @@ __global__ void dense_fill_kernel(const uint64_t *__restrict__ keys, const uint6
   heads[keys[r] - kmin] = (uint32_t)r;
 }
 
+// after dense_fill_kernel (last writer wins): a row that does not find itself was overwritten by
+// a duplicate of its key; two NULL keys are duplicates too (NULL = NULL matches)
+__global__ void dense_verify_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
+                                    int64_t n, uint64_t kmin, const uint32_t *__restrict__ heads,
+                                    const uint32_t *null_head, int *dup) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  bool null_key = validity && !((validity[r >> 6] >> (r & 63)) & 1);
+  uint32_t h = null_key ? *null_head : heads[keys[r] - kmin];
+  if (h != (uint32_t)r) *dup = 1;
+}
+
 __global__ void bytes_to_bits_kernel(const uint8_t *__restrict__ bytes, int64_t n,
                                      uint64_t *__restrict__ out) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -418,28 +430,12 @@ static void build_table(sqlrs_hash_join *j) {
         validity = c.own_validity;
     }
   }
-  uint64_t cap = 64;
-  while (2 * cap < 3 * (uint64_t)n) cap <<= 1; // load factor <= 2/3
-  j->mask = cap - 1;
-  int64_t nslots = (int64_t)cap + 2;
-  j->table = ctx->alloc(sizeof(Slot) * (size_t)nslots);
-  BufP row_slot = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
-  BufP dup = ctx->alloc_zero(8);
-  {
-    ProfScope ps(ctx, "join_build");
-    table_init_kernel<<<dim3((unsigned)ceil_div(nslots, 256)), dim3(256), 0, ctx->stream>>>(
-        j->table->as<Slot>(), nslots);
-    if (n)
-      join_insert_kernel<<<dim3((unsigned)ceil_div(n, BLOCK)), dim3(BLOCK), 0, ctx->stream>>>(
-          keys->as<uint64_t>(), validity ? validity->as<uint64_t>() : nullptr, n,
-          j->table->as<Slot>(), j->mask, row_slot->as<uint32_t>(), dup->as<int>());
-    SQ_HIP(hipGetLastError());
-  }
-  j->unique = ctx->fetch_value(dup->as<int>()) == 0;
   j->bkeys = keys; // kept for the fused join+aggregate route (hashagg_op.hip)
   j->bkeys_validity = validity;
-  if (j->unique && j->exact && n > 0 && j->key_dtype != SQLRS_FLOAT64) {
-    // dense surrogate keys?  (range <= 4 x rows and < 2^31)  -> direct-address table
+  // 1. dense surrogate keys (range <= 4 x rows and < 2^31) -> direct-address table.  It is tried
+  //    first: when the build keys turn out unique nothing else is needed, and the 16-byte-slot
+  //    hash table (1.1 ms for 1e7 keys) is never built.
+  if (j->exact && n > 0 && j->key_dtype != SQLRS_FLOAT64) {
     BufP mm = ctx->alloc(16);
     uint64_t init[2] = {~0ull, 0ull};
     SQ_HIP(hipMemcpyAsync(mm->p, init, 16, hipMemcpyHostToDevice, ctx->stream));
@@ -456,29 +452,57 @@ static void build_table(sqlrs_hash_join *j) {
       uint64_t range = hi - lo + 1; // ordered images differ like the signed values
       if (range <= 4 * (uint64_t)n + 1024 && range < (1ull << 31)) {
         ProfScope ps(ctx, "join_build_dense");
-        j->dense = ctx->alloc(4 * (size_t)range + 8);
-        SQ_HIP(hipMemsetAsync(j->dense->p, 0xff, 4 * (size_t)range + 8, ctx->stream));
-        j->dense_min = lo ^ (1ull << 63); // back from the ordered image to the two's complement bits
-        j->dense_range = range;
-        uint32_t *null_head = j->dense->as<uint32_t>() + range; // spare slot after the table
+        BufP dense = ctx->alloc(4 * (size_t)range + 8);
+        SQ_HIP(hipMemsetAsync(dense->p, 0xff, 4 * (size_t)range + 8, ctx->stream));
+        uint64_t dmin = lo ^ (1ull << 63); // back from the ordered image to the two's complement bits
+        uint32_t *null_head = dense->as<uint32_t>() + range; // spare slot after the table
+        BufP dup = ctx->alloc_zero(8);
         dense_fill_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
-            keys->as<uint64_t>(), vp, n, j->dense_min, j->dense->as<uint32_t>(), null_head);
+            keys->as<uint64_t>(), vp, n, dmin, dense->as<uint32_t>(), null_head);
+        dense_verify_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
+            keys->as<uint64_t>(), vp, n, dmin, dense->as<uint32_t>(), null_head, dup->as<int>());
         SQ_HIP(hipGetLastError());
-        j->dense_null_head = ctx->fetch_value(null_head);
+        if (ctx->fetch_value(dup->as<int>()) == 0) {
+          j->unique = true;
+          j->dense = dense;
+          j->dense_min = dmin;
+          j->dense_range = range;
+          j->dense_null_head = ctx->fetch_value(null_head);
+          return;
+        }
       }
     }
   }
+  // 2. open-addressing table over the key hash (any key type, duplicates allowed)
+  uint64_t cap = 64;
+  while (2 * cap < 3 * (uint64_t)n) cap <<= 1; // load factor <= 2/3
+  j->mask = cap - 1;
+  int64_t nslots = (int64_t)cap + 2;
+  j->table = ctx->alloc(sizeof(Slot) * (size_t)nslots);
+  BufP row_slot = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
+  BufP dup = ctx->alloc_zero(8);
+  {
+    ProfScope ps(ctx, "join_build");
+    table_init_kernel<<<dim3((unsigned)ceil_div(nslots, 256)), dim3(256), 0, ctx->stream>>>(
+        (j->table ? j->table->as<Slot>() : nullptr), nslots);
+    if (n)
+      join_insert_kernel<<<dim3((unsigned)ceil_div(n, BLOCK)), dim3(BLOCK), 0, ctx->stream>>>(
+          keys->as<uint64_t>(), validity ? validity->as<uint64_t>() : nullptr, n,
+          (j->table ? j->table->as<Slot>() : nullptr), j->mask, row_slot->as<uint32_t>(), dup->as<int>());
+    SQ_HIP(hipGetLastError());
+  }
+  j->unique = ctx->fetch_value(dup->as<int>()) == 0;
   if (!j->unique) {
     // CSR: head = exclusive scan of counts in slot order; rows stably sorted by slot
     ProfScope ps(ctx, "join_build_csr");
     BufP counts = ctx->alloc(4 * (size_t)nslots), heads = ctx->alloc(4 * (size_t)nslots);
     BufP total = ctx->alloc(8);
     slot_counts_kernel<<<dim3((unsigned)ceil_div(nslots, 256)), dim3(256), 0, ctx->stream>>>(
-        j->table->as<Slot>(), nslots, counts->as<uint32_t>());
+        (j->table ? j->table->as<Slot>() : nullptr), nslots, counts->as<uint32_t>());
     exclusive_scan_u32(ctx, counts->as<uint32_t>(), nslots, nullptr, heads->as<uint32_t>(),
                        total->as<uint64_t>());
     slot_heads_kernel<<<dim3((unsigned)ceil_div(nslots, 256)), dim3(256), 0, ctx->stream>>>(
-        j->table->as<Slot>(), nslots, heads->as<uint32_t>());
+        (j->table ? j->table->as<Slot>() : nullptr), nslots, heads->as<uint32_t>());
     BufP k64 = ctx->alloc(8 * (size_t)n);
     j->rows_by_slot = ctx->alloc(4 * (size_t)n);
     u32_to_u64_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
@@ -520,11 +544,11 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
         DenseTable dt{j->dense ? j->dense->as<uint32_t>() : nullptr, j->dense_min, j->dense_range, j->dense_null_head};
         if (j->dense)
           join_probe_unique_kernel<true><<<gt, b, 0, ctx->stream>>>(
-              pk.keys->as<uint64_t>(), pk.validity, n, tiles, j->table->as<Slot>(), j->mask, dt,
+              pk.keys->as<uint64_t>(), pk.validity, n, tiles, (j->table ? j->table->as<Slot>() : nullptr), j->mask, dt,
               p.left->as<uint64_t>(), p.right->as<uint32_t>(), desc->as<uint64_t>(), ticket, tot, use_ticket);
         else
           join_probe_unique_kernel<false><<<gt, b, 0, ctx->stream>>>(
-              pk.keys->as<uint64_t>(), pk.validity, n, tiles, j->table->as<Slot>(), j->mask, dt,
+              pk.keys->as<uint64_t>(), pk.validity, n, tiles, (j->table ? j->table->as<Slot>() : nullptr), j->mask, dt,
               p.left->as<uint64_t>(), p.right->as<uint32_t>(), desc->as<uint64_t>(), ticket, tot, use_ticket);
         SQ_HIP(hipGetLastError());
       }
@@ -544,11 +568,11 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     DenseTable dt{j->dense ? j->dense->as<uint32_t>() : nullptr, j->dense_min, j->dense_range, j->dense_null_head};
     if (j->dense)
       join_probe_unique_outer_kernel<true><<<dim3((unsigned)ceil_div(n64, BLOCK)), b, 0, ctx->stream>>>(
-          pk.keys->as<uint64_t>(), pk.validity, n, j->table->as<Slot>(), j->mask, dt, p.left->as<uint64_t>(),
+          pk.keys->as<uint64_t>(), pk.validity, n, (j->table ? j->table->as<Slot>() : nullptr), j->mask, dt, p.left->as<uint64_t>(),
           p.right->as<uint32_t>(), p.left_validity->as<uint64_t>());
     else
       join_probe_unique_outer_kernel<false><<<dim3((unsigned)ceil_div(n64, BLOCK)), b, 0, ctx->stream>>>(
-          pk.keys->as<uint64_t>(), pk.validity, n, j->table->as<Slot>(), j->mask, dt, p.left->as<uint64_t>(),
+          pk.keys->as<uint64_t>(), pk.validity, n, (j->table ? j->table->as<Slot>() : nullptr), j->mask, dt, p.left->as<uint64_t>(),
           p.right->as<uint32_t>(), p.left_validity->as<uint64_t>());
     SQ_HIP(hipGetLastError());
     return p;
@@ -557,7 +581,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   {
     ProfScope ps(ctx, "join_probe_count");
     join_count_kernel<<<g, b, 0, ctx->stream>>>(pk.keys->as<uint64_t>(), pk.validity, n,
-                                                j->table->as<Slot>(), j->mask, outer_right,
+                                                (j->table ? j->table->as<Slot>() : nullptr), j->mask, outer_right,
                                                 counts->as<uint32_t>());
     SQ_HIP(hipGetLastError());
   }
@@ -572,7 +596,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   if (p.m) {
     ProfScope ps(ctx, "join_probe_fill");
     join_fill_kernel<<<g, b, 0, ctx->stream>>>(
-        pk.keys->as<uint64_t>(), pk.validity, n, j->table->as<Slot>(), j->mask, j->unique ? 1 : 0,
+        pk.keys->as<uint64_t>(), pk.validity, n, (j->table ? j->table->as<Slot>() : nullptr), j->mask, j->unique ? 1 : 0,
         j->rows_by_slot ? j->rows_by_slot->as<uint32_t>() : nullptr, offsets->as<uint64_t>(),
         p.left->as<uint64_t>(), p.right->as<uint32_t>(), lvb ? lvb->as<uint8_t>() : nullptr);
     SQ_HIP(hipGetLastError());

@@ -277,96 +277,250 @@ template <int OP, class K> __device__ __forceinline__ bool cmp_op(K a, K b) {
   return a != b;
 }
 
-// Tile = 4096 rows, one block (4 waves) per tile; wave w owns 16 chunks of 64 rows, so each
-// ballot IS one word of the selection mask.  Loads are issued for all 16 chunks up front
-// (16 x 512 B per wave in flight), ranks come from popcounts, the tile's global offset from
-// the decoupled look-back, and kept values are written contiguously per wave.
-template <class T, int OP>
-__global__ __launch_bounds__(BLOCK) void filter_cmp_const_kernel(
+// One block = FILTER_WAVES worker waves + 1 scan wave per FILTER tile of 16384 rows (four of the
+// 4096-row tiles that `tile_off` and the other compaction kernels use).  Worker wave w owns 32
+// chunks of 64 rows, so each ballot IS one word of the selection mask; all 32 loads of a wave are
+// issued up front (16 KiB per wave in flight).  Ranks come from popcounts, the tile's global
+// offset from the decoupled look-back, and kept values are written contiguously per wave.
+//
+// Why 16384 rows: the chained scan only keeps up while (tiles started per us) x (descriptor read
+// latency) stays well below the 64-descriptor look-back window (device_utils.hpp).  With
+// 4096-row tiles that ratio was ~1 and a tile spent 80 % of its life waiting for its prefix
+// (42 K of 55 K cycles): 3.4 ms per 1e9 rows no matter how the loads and stores were scheduled.
+//
+// The scan wave owns the look-back so that its spinning descriptor reads (s_waitcnt vmcnt(0))
+// never sit in front of a worker's data loads in the in-order vmcnt queue.
+#ifdef FILTER_TIMING // phase timers (tools only): -DFILTER_TIMING via SQLRS_EXTRA_CFLAGS
+__device__ unsigned long long filter_timing[8];
+#define FT(i) do { if (threadIdx.x == 0) { long long now_ = clock64(); atomicAdd(&filter_timing[i], (unsigned long long)(now_ - tlast)); tlast = now_; } } while (0)
+#define FT_INIT long long tlast = clock64()
+#else
+#define FT(i) do {} while (0)
+#define FT_INIT do {} while (0)
+#endif
+constexpr int FILTER_WAVES = 8;
+constexpr int FILTER_CHUNKS = 32;                                // 64-row chunks per worker wave
+constexpr int FILTER_TILE_ROWS = FILTER_WAVES * FILTER_CHUNKS * 64; // 16384
+constexpr int FILTER_SUB = FILTER_TILE_ROWS / TILE_ROWS;           // 4096-row tiles per filter tile
+constexpr int FILTER_BLOCK = (FILTER_WAVES + 1) * 64;
+static_assert(FILTER_CHUNKS <= 64 && FILTER_SUB * 2 == FILTER_WAVES, "tile_off mapping assumes 2 waves per 4096 rows");
+
+template <class T, int OP, bool HASV>
+__global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_kernel(
     const T *__restrict__ in, const uint64_t *__restrict__ validity, T k, int64_t rows,
     int64_t num_tiles, T *__restrict__ out, uint64_t *__restrict__ sel_bits,
     uint64_t *__restrict__ tile_off, uint64_t *desc, unsigned *ticket, uint64_t *total, int use_ticket) {
   __shared__ int64_t s_tile;
-  __shared__ uint32_t s_wave[WAVES_PER_BLOCK];
+  __shared__ uint32_t s_wave[FILTER_WAVES];
   __shared__ uint64_t s_excl;
   unsigned *timeout = use_ticket ? nullptr : ticket + 1; // word after the ticket counter
-  // One atomic ticket buys LB_TILES_PER_TICKET consecutive tiles: a single counter sustains
-  // only ~88 tickets/us on MI355X (MI355X_MICROARCH.md "dequeue"), so a ticket per 4096-row
-  // tile would cap a 1e8-row filter at ~0.28 ms by itself.
-  if (threadIdx.x == 0) s_tile = use_ticket ? (int64_t)atomicAdd(ticket, 1u) : (int64_t)blockIdx.x;
-  __syncthreads();
-  const int64_t tile0 = s_tile;
-  const int lane = lane_id(), w = wave_id();
-  const auto kk = CmpKey<T>::key(k);
-  for (int sub = 0; sub < LB_TILES_PER_TICKET; sub++) {
-  const int64_t tile = tile0 + sub;
-  if (tile >= num_tiles) break;
-  const int64_t wrow = tile * TILE_ROWS + (int64_t)w * 1024;
-  const int64_t wword = tile * TILE_WORDS + w * 16;
-  T v[16];
-#pragma unroll
-  for (int j = 0; j < 16; j++) {
-    int64_t r = wrow + j * 64 + lane;
-    v[j] = (r < rows) ? in[r] : T(0);
+  // tile order: blockIdx (workgroups are dispatched in index order, so a tile's predecessors are
+  // running or done; the look-back spin is bounded and the host reruns the launch with tickets if
+  // it ever times out), or one atomic ticket per tile in that fallback launch.
+  int64_t tile = blockIdx.x;
+  if (use_ticket) {
+    if (threadIdx.x == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);
+    __syncthreads();
+    tile = s_tile;
   }
-  uint64_t m[16];
+  const int lane = lane_id(), w = wave_id();
+  const int64_t nw = (rows + 63) >> 6;
+  if (w == FILTER_WAVES) { // ---- scan wave
+#ifdef FILTER_TIMING
+    long long tl0 = clock64();
+#endif
+    __syncthreads(); // (1) the workers' counts are in s_wave
+#ifdef FILTER_TIMING
+    long long tl1 = clock64();
+#endif
+    uint32_t c = lane < FILTER_WAVES ? s_wave[lane] : 0;
+    uint32_t inc = wave_iscan_u32(c);
+    uint64_t agg = (uint32_t)__shfl((int)inc, 63, 64);
+    uint64_t excl = lookback_wave(desc, tile, agg, timeout);
+    // kept rows before each 4096-row tile = before waves 0, 2, 4, 6
+    if (lane < FILTER_WAVES && (lane & 1) == 0 && tile_off) {
+      int64_t t4 = tile * FILTER_SUB + (lane >> 1);
+      if (t4 * TILE_ROWS < rows) tile_off[t4] = excl + (inc - c);
+    }
+    if (lane == 0) {
+      s_excl = excl;
+      if (tile == num_tiles - 1) *total = excl + agg;
+    }
+#ifdef FILTER_TIMING
+    if (lane == 0) { atomicAdd(&filter_timing[5], (unsigned long long)(tl1 - tl0)); atomicAdd(&filter_timing[6], (unsigned long long)(clock64() - tl1)); }
+#endif
+    __syncthreads(); // (2)
+    return;
+  }
+  // ---- worker waves
+  FT_INIT;
+  const auto kk = CmpKey<T>::key(k);
+  const int64_t wrow = tile * FILTER_TILE_ROWS + (int64_t)w * (FILTER_CHUNKS * 64) + lane;
+  const int64_t wword = (tile * FILTER_WAVES + w) * FILTER_CHUNKS;
+  T v[FILTER_CHUNKS];
+#pragma unroll
+  for (int j = 0; j < FILTER_CHUNKS; j++) v[j] = __builtin_nontemporal_load(in + min(wrow + j * 64, rows - 1));
+  FT(0);
+  uint64_t mine = 0; // lane j keeps the mask word of chunk j
   uint32_t wave_cnt = 0;
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    int64_t r = wrow + j * 64 + lane;
-    bool keep = (r < rows) && cmp_op<OP>(CmpKey<T>::key(v[j]), kk);
+  for (int j = 0; j < FILTER_CHUNKS; j++) {
+    bool keep = (wrow + j * 64 < rows) && cmp_op<OP>(CmpKey<T>::key(v[j]), kk);
     uint64_t b = __ballot(keep);
-    if (validity) {
-      int64_t nw = (rows + 63) >> 6;
-      uint64_t vw = (wword + j < nw) ? validity[wword + j] : 0ull; // wave-uniform load
-      b &= vw;
-    }
-    m[j] = b;
+    if (HASV) b &= validity[min(wword + j, nw - 1)]; // wave-uniform load (rows past the end are not kept)
+    mine = (lane == j) ? b : mine;
     wave_cnt += (uint32_t)__popcll(b);
   }
   if (lane == 0) s_wave[w] = wave_cnt;
-  if (sel_bits) {
-    int64_t nw = (rows + 63) >> 6;
-    if (lane < 16 && wword + lane < nw) {
-      uint64_t mine = 0;
-#pragma unroll
-      for (int j = 0; j < 16; j++) mine = (lane == j) ? m[j] : mine;
-      sel_bits[wword + lane] = mine;
-    }
-  }
-  __syncthreads();
-  if (w == 0) {
-    uint64_t agg = (uint64_t)s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    uint64_t excl = lookback_wave(desc, tile, agg, timeout);
-    if (lane == 0) {
-      s_excl = excl;
-      if (tile_off) tile_off[tile] = excl;
-      if (tile == num_tiles - 1) *total = excl + agg;
-    }
-  }
-  __syncthreads();
+  if (sel_bits && lane < FILTER_CHUNKS && wword + lane < nw) sel_bits[wword + lane] = mine;
+  FT(1);
+  __syncthreads(); // (1)
+  FT(2);
+  __syncthreads(); // (2) the scan wave has published the tile's offset
+  FT(3);
   uint64_t pos = s_excl;
   for (int q = 0; q < w; q++) pos += s_wave[q];
+  const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    if ((m[j] >> lane) & 1) out[pos + mbcnt(m[j])] = v[j];
-    pos += (uint32_t)__popcll(m[j]);
+  for (int j = 0; j < FILTER_CHUNKS; j++) {
+    uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j) << 32) |
+                 (uint32_t)__builtin_amdgcn_readlane((int)mlo, j);
+    if ((m >> lane) & 1) out[pos + mbcnt(m)] = v[j];
+    pos += (uint32_t)__popcll(m);
   }
-  __syncthreads(); // s_wave / s_excl are reused by the next tile
-  } // sub
+  FT(4);
+}
+
+// Persistent, software-pipelined variant (the default launch): block b takes tiles b, b + G, ...
+// and keeps TWO tiles in registers — the 32 loads of tile i+1 are issued before tile i's ballots,
+// look-back wait and stores, so the ~6 us a tile waits for its prefix are spent streaming the
+// next tile instead of idling the memory pipe.  The loop body is written twice (va/vb swap
+// roles) instead of copying registers, loads are unconditional, and s_wave / s_excl are
+// double-buffered by tile parity (no third barrier).  Without tickets a tile's predecessors are
+// only guaranteed to be running if all G blocks are resident: the host sizes G by occupancy,
+// the look-back spin is bounded, and on a timeout the launch is redone by the ticketed
+// one-tile-per-block kernel above.
+template <class T>
+__device__ __forceinline__ void filter_load_tile(const T *__restrict__ in, int64_t rows, int64_t tile,
+                                                 T (&v)[FILTER_CHUNKS]) {
+  const int64_t wrow = tile * FILTER_TILE_ROWS + (int64_t)wave_id() * (FILTER_CHUNKS * 64) + lane_id();
+#pragma unroll
+  for (int j = 0; j < FILTER_CHUNKS; j++) v[j] = __builtin_nontemporal_load(in + min(wrow + j * 64, rows - 1));
+}
+
+template <class T, int OP, bool HASV, class KK>
+__device__ __forceinline__ void filter_tile(const T (&v)[FILTER_CHUNKS], KK kk,
+                                            const uint64_t *__restrict__ validity, int64_t rows, int64_t tile,
+                                            T *__restrict__ out, uint64_t *__restrict__ sel_bits,
+                                            uint32_t *s_wave, const uint64_t *s_excl) {
+  const int lane = lane_id(), w = wave_id();
+  const int64_t nw = (rows + 63) >> 6;
+  const int64_t wrow = tile * FILTER_TILE_ROWS + (int64_t)w * (FILTER_CHUNKS * 64) + lane;
+  const int64_t wword = (tile * FILTER_WAVES + w) * FILTER_CHUNKS;
+  uint64_t mine = 0; // lane j keeps the mask word of chunk j
+  uint32_t wave_cnt = 0;
+#pragma unroll
+  for (int j = 0; j < FILTER_CHUNKS; j++) {
+    bool keep = (wrow + j * 64 < rows) && cmp_op<OP>(CmpKey<T>::key(v[j]), kk);
+    uint64_t b = __ballot(keep);
+    if (HASV) b &= validity[min(wword + j, nw - 1)];
+    mine = (lane == j) ? b : mine;
+    wave_cnt += (uint32_t)__popcll(b);
+  }
+  if (lane == 0) s_wave[w] = wave_cnt;
+  if (sel_bits && lane < FILTER_CHUNKS && wword + lane < nw) sel_bits[wword + lane] = mine;
+  __syncthreads(); // (1)
+  __syncthreads(); // (2) the scan wave has published the tile's offset
+  uint64_t pos = *s_excl;
+  for (int q = 0; q < w; q++) pos += s_wave[q];
+  const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+#pragma unroll
+  for (int j = 0; j < FILTER_CHUNKS; j++) {
+    uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j) << 32) |
+                 (uint32_t)__builtin_amdgcn_readlane((int)mlo, j);
+    if ((m >> lane) & 1) out[pos + mbcnt(m)] = v[j];
+    pos += (uint32_t)__popcll(m);
+  }
+}
+
+template <class T, int OP, bool HASV>
+__global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_persistent_kernel(
+    const T *__restrict__ in, const uint64_t *__restrict__ validity, T k, int64_t rows,
+    int64_t num_tiles, T *__restrict__ out, uint64_t *__restrict__ sel_bits,
+    uint64_t *__restrict__ tile_off, uint64_t *desc, unsigned *timeout, uint64_t *total) {
+  __shared__ uint32_t s_wave[2][FILTER_WAVES];
+  __shared__ uint64_t s_excl[2];
+  const int64_t G = gridDim.x;
+  int64_t tile = blockIdx.x; // G <= num_tiles: every block has a first tile
+  if (wave_id() == FILTER_WAVES) { // ---- scan wave
+    const int lane = lane_id();
+    for (int p = 0; tile < num_tiles; tile += G, p ^= 1) {
+      __syncthreads(); // (1) the workers' counts are in s_wave[p]
+      uint32_t c = lane < FILTER_WAVES ? s_wave[p][lane] : 0;
+      uint32_t inc = wave_iscan_u32(c);
+      uint64_t agg = (uint32_t)__shfl((int)inc, 63, 64);
+      uint64_t excl = lookback_wave(desc, tile, agg, timeout);
+      if (lane < FILTER_WAVES && (lane & 1) == 0 && tile_off) {
+        int64_t t4 = tile * FILTER_SUB + (lane >> 1);
+        if (t4 * TILE_ROWS < rows) tile_off[t4] = excl + (inc - c);
+      }
+      if (lane == 0) {
+        s_excl[p] = excl;
+        if (tile == num_tiles - 1) *total = excl + agg;
+      }
+      __syncthreads(); // (2)
+    }
+    return;
+  }
+  // ---- worker waves
+  const auto kk = CmpKey<T>::key(k);
+  T va[FILTER_CHUNKS], vb[FILTER_CHUNKS];
+  filter_load_tile(in, rows, tile, va);
+  while (true) {
+    int64_t nt = tile + G;
+    filter_load_tile(in, rows, min(nt, num_tiles - 1), vb);
+    filter_tile<T, OP, HASV>(va, kk, validity, rows, tile, out, sel_bits, s_wave[0], &s_excl[0]);
+    if (nt >= num_tiles) break;
+    tile = nt;
+    nt = tile + G;
+    filter_load_tile(in, rows, min(nt, num_tiles - 1), va);
+    filter_tile<T, OP, HASV>(vb, kk, validity, rows, tile, out, sel_bits, s_wave[1], &s_excl[1]);
+    if (nt >= num_tiles) break;
+    tile = nt;
+  }
 }
 
 template <class T>
 static void launch_filter(Ctx *ctx, int op, const DCol &c, T k, int64_t rows, T *out,
                           uint64_t *sel_bits, uint64_t *tile_off, uint64_t *desc, unsigned *ticket,
                           uint64_t *total, int use_ticket) {
-  int64_t tiles = ceil_div(rows, TILE_ROWS);
-  dim3 g((unsigned)ceil_div(tiles, LB_TILES_PER_TICKET)), b(BLOCK);
+  int64_t tiles = ceil_div(rows, FILTER_TILE_ROWS);
   const T *in = c.v<T>();
   const uint64_t *val = c.validity;
-#define SQ_LAUNCH(OP)                                                                              \
-  filter_cmp_const_kernel<T, OP><<<g, b, 0, ctx->stream>>>(in, val, k, rows, tiles, out, sel_bits, \
-                                                           tile_off, desc, ticket, total, use_ticket)
+  // use_ticket = 0: persistent pipelined kernel, as many blocks as are resident at once;
+  // use_ticket = 1: one block per tile, tile ids from an atomic ticket (safe under any dispatch order)
+#define SQ_LAUNCH1(OP, HV)                                                                                       \
+  do {                                                                                                           \
+    if (use_ticket) {                                                                                            \
+      filter_cmp_const_kernel<T, OP, HV><<<dim3((unsigned)tiles), dim3(FILTER_BLOCK), 0, ctx->stream>>>(         \
+          in, val, k, rows, tiles, out, sel_bits, tile_off, desc, ticket, total, 1);                             \
+    } else {                                                                                                     \
+      static int occ = 0;                                                                                        \
+      if (!occ) {                                                                                                \
+        SQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, filter_cmp_const_persistent_kernel<T, OP, HV>, \
+                                                            FILTER_BLOCK, 0));                                   \
+        occ = std::max(1, std::min(occ, 2));                                                                     \
+      }                                                                                                          \
+      unsigned g = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->num_cus * occ);                              \
+      filter_cmp_const_persistent_kernel<T, OP, HV><<<dim3(g), dim3(FILTER_BLOCK), 0, ctx->stream>>>(            \
+          in, val, k, rows, tiles, out, sel_bits, tile_off, desc, ticket + 1, total);                            \
+    }                                                                                                            \
+  } while (0)
+#define SQ_LAUNCH(OP)                                                                                            \
+  do {                                                                                                           \
+    if (val) SQ_LAUNCH1(OP, true);                                                                               \
+    else SQ_LAUNCH1(OP, false);                                                                                  \
+  } while (0)
   switch (op) {
   case CMP_GT: SQ_LAUNCH(CMP_GT); break;
   case CMP_LT: SQ_LAUNCH(CMP_LT); break;
@@ -376,6 +530,7 @@ static void launch_filter(Ctx *ctx, int op, const DCol &c, T k, int64_t rows, T 
   default: SQ_LAUNCH(CMP_NE); break;
   }
 #undef SQ_LAUNCH
+#undef SQ_LAUNCH1
   SQ_HIP(hipGetLastError());
 }
 
@@ -390,11 +545,11 @@ bool filter_fast_path(Ctx *ctx, const Expr &e, const std::function<const DCol &(
   if (c.dtype != b.dtype || c.stride == 0) return false;
   if (c.dtype != SQLRS_INT64 && c.dtype != SQLRS_FLOAT64 && c.dtype != SQLRS_INT32) return false;
   int op = o.op - SQLRS_EXPR_GT; // GT, LT, GTEQ, LTEQ, EQ, NOTEQ in header order
-  int64_t tiles = ceil_div(rows, TILE_ROWS), nwords = ceil_div(rows, 64);
+  int64_t tiles = ceil_div(rows, FILTER_TILE_ROWS), nwords = ceil_div(rows, 64);
   sel->rows = rows;
   sel->own_bits = ctx->alloc(8 * (size_t)nwords);
   sel->bits = sel->own_bits->as<uint64_t>();
-  sel->tile_off = ctx->alloc(8 * (size_t)tiles);
+  sel->tile_off = ctx->alloc(8 * (size_t)ceil_div(rows, TILE_ROWS));
   BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 16);
   unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
   uint64_t *total = desc->as<uint64_t>() + tiles + 1;
@@ -417,6 +572,17 @@ bool filter_fast_path(Ctx *ctx, const Expr &e, const std::function<const DCol &(
         launch_filter<double>(ctx, op, c, b.f, rows, out->as<double>(), sb, to,
                               desc->as<uint64_t>(), ticket, total, use_ticket);
     }
+#ifdef FILTER_TIMING
+    {
+      ctx->sync();
+      unsigned long long h[8], z[8] = {0};
+      SQ_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(filter_timing), sizeof(h)));
+      SQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(filter_timing), z, sizeof(z)));
+      if (tiles > 1000)
+        fprintf(stderr, "[filter_timing] tiles %lld: cycles/tile issue-loads %.0f ballots(load wait) %.0f bar1 %.0f bar2(lookback) %.0f stores-issue %.0f | scan wave: wait-bar1 %.0f lookback %.0f\n",
+                (long long)tiles, (double)h[0] / tiles, (double)h[1] / tiles, (double)h[2] / tiles, (double)h[3] / tiles, (double)h[4] / tiles, (double)h[5] / tiles, (double)h[6] / tiles);
+    }
+#endif
     const uint64_t *h = (const uint64_t *)ctx->fetch(ticket, 16); // {ticket|timeout, total}
     sel->count = (int64_t)h[1];
     if (use_ticket || (h[0] >> 32) == 0) break; // no look-back timeout: done
