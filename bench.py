@@ -149,9 +149,9 @@ def algorithmic_bytes(kernel, w):
         "agg_update": 12 * M,                               # group id + value read per row
         "join_build": 8 * nB,
         "join_probe_unique": 8 * s * nP + 12 * M,           # one pass: keys read, pairs written
-        "rp_scatter": 38 * M,                               # (key, val[, row id]) read + (key, val, row id) written
+        "rp_scatter": 32 * M,                               # packed (key|row, val) 16 B read + 16 B written
         "rp_hist": 8 * M,
-        "lds_agg": 20 * M + 32 * G,                         # partitioned rows read, groups written
+        "lds_agg": 16 * M + 28 * G,                         # partitioned rows read, groups written
         "normalize_keys": 16 * M,
     }
     return table.get(kernel)

@@ -18,6 +18,7 @@
 // Rows whose bucket table overflows (estimate too low) are returned to the caller and take
 // the resolve path directly, so the result never depends on the estimate.
 #include <cstdlib>
+#include <cstring>
 
 #include "agg_partition.hpp"
 #include "device_utils.hpp"
@@ -33,14 +34,19 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t h, uint32_t P) {
 }
 
 // ---------------------------------------------------------------- key statistics --
+// HyperLogLog registers + min / max of the keys' signed-order image (hll[4096..4099] as two u64)
 __global__ __launch_bounds__(PART_WG) void key_stats_kernel(const uint64_t *__restrict__ keys,
                                                             const uint64_t *__restrict__ validity,
                                                             int64_t n, unsigned int *__restrict__ hll) {
   __shared__ unsigned int reg[4096];
   for (int i = threadIdx.x; i < 4096; i += PART_WG) reg[i] = 0;
   __syncthreads();
+  uint64_t kmin = ~0ull, kmax = 0;
   for (int64_t r = blockIdx.x * (int64_t)PART_WG + threadIdx.x; r < n; r += (int64_t)gridDim.x * PART_WG) {
     if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) continue;
+    const uint64_t o = keys[r] ^ (1ull << 63);
+    kmin = min(kmin, o);
+    kmax = max(kmax, o);
     uint64_t h = mix64(keys[r] ^ 0x2545f4914f6cdd1dULL);
     unsigned idx = (unsigned)(h >> 52);
     unsigned rank = (unsigned)__builtin_clzll((h << 12) | (1ull << 11)) + 1;
@@ -49,10 +55,19 @@ __global__ __launch_bounds__(PART_WG) void key_stats_kernel(const uint64_t *__re
   __syncthreads();
   for (int i = threadIdx.x; i < 4096; i += PART_WG)
     if (reg[i]) atomicMax(&hll[i], reg[i]);
+  kmin = wave_min_u64(kmin);
+  kmax = wave_max_u64(kmax);
+  if (lane_id() == 0) {
+    unsigned long long *mm = (unsigned long long *)(hll + 4096);
+    atomicMin(mm, (unsigned long long)kmin);
+    atomicMax(mm + 1, (unsigned long long)kmax);
+  }
 }
 
-double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n) {
-  BufP hll = ctx->alloc_zero(4096 * 4);
+double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n,
+                         uint64_t *omin, uint64_t *omax) {
+  BufP hll = ctx->alloc_zero(4096 * 4 + 16);
+  SQ_HIP(hipMemsetAsync(hll->as<uint8_t>() + 4096 * 4, 0xff, 8, ctx->stream)); // min starts at ~0
   {
     ProfScope ps(ctx, "key_stats");
     unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, PART_WG * 16), 2048);
@@ -60,9 +75,12 @@ double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validit
                                                                                   hll->as<unsigned int>());
     SQ_HIP(hipGetLastError());
   }
-  std::vector<unsigned int> reg(4096);
-  SQ_HIP(hipMemcpyAsync(reg.data(), hll->p, 4096 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<unsigned int> reg(4096 + 4);
+  SQ_HIP(hipMemcpyAsync(reg.data(), hll->p, 4096 * 4 + 16, hipMemcpyDeviceToHost, ctx->stream));
   ctx->sync();
+  if (omin) std::memcpy(omin, &reg[4096], 8);
+  if (omax) std::memcpy(omax, &reg[4098], 8);
+  reg.resize(4096);
   const double m = 4096.0;
   double sum = 0;
   int zeros = 0;
@@ -119,7 +137,7 @@ template <int NV> struct AggRows {
 };
 
 // every lane loads (rows past `hi` re-read row hi-1), so all loads of a trip issue back to back
-template <int NV, bool FLAGS>
+template <int NV, bool FLAGS, bool PACK>
 __device__ __forceinline__ void lds_agg_load(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pi,
                                              const uint64_t *__restrict__ pv0, const uint64_t *__restrict__ pv1,
                                              const uint8_t *__restrict__ pf, int64_t i0, int64_t hi,
@@ -128,7 +146,7 @@ __device__ __forceinline__ void lds_agg_load(const uint64_t *__restrict__ pk, co
   for (int u = 0; u < LDS_U; u++) {
     int64_t i = min(i0 + (int64_t)u * PART_WG, hi - 1);
     r.k[u] = __builtin_nontemporal_load(pk + i);
-    r.id[u] = __builtin_nontemporal_load(pi + i);
+    if (!PACK) r.id[u] = __builtin_nontemporal_load(pi + i);
     if (NV >= 1) r.v0[u] = __builtin_nontemporal_load(pv0 + i);
     if (NV >= 2) r.v1[u] = __builtin_nontemporal_load(pv1 + i);
     r.f[u] = FLAGS ? pf[i] : 7;
@@ -146,7 +164,8 @@ __device__ __forceinline__ void lds_agg_load(const uint64_t *__restrict__ pk, co
 // 0 and 1), which removes the per-row interpreter (loop + switch over prm.code); NACC < 0 reads
 // it from `prm`.  JOIN: fused inner join, the bucket's build keys are inserted first and probe
 // rows only accumulate into slots that exist.
-template <int NV, bool FLAGS, bool JOIN, int NACC, int C0, int C1>
+// PACK: `pk` holds packed (key, row) words (radix_part.hpp KeyPack) and there is no `pi` column.
+template <int NV, bool FLAGS, bool JOIN, int NACC, int C0, int C1, bool PACK>
 __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     LdsAggParams prm, const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pi,
     const uint64_t *__restrict__ pv0, const uint64_t *__restrict__ pv1,
@@ -154,7 +173,8 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     int64_t n, unsigned long long *out_count, uint64_t *__restrict__ gkey,
     uint32_t *__restrict__ gfirst, uint8_t *__restrict__ gvalid, uint64_t *__restrict__ gacc,
     int64_t gcap, unsigned long long *ov_count, uint32_t *__restrict__ ov_rows,
-    const uint64_t *__restrict__ bk, const uint8_t *__restrict__ bf, const uint32_t *__restrict__ bbstart) {
+    const uint64_t *__restrict__ bk, const uint8_t *__restrict__ bf, const uint32_t *__restrict__ bbstart,
+    KeyPack kp) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
   __shared__ unsigned int s_cnt;
   __shared__ unsigned long long s_base;
@@ -168,7 +188,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
   unsigned long long *tacc = tab + nslots;
   unsigned int *tfirst = (unsigned int *)(tacc + (size_t)n_acc * nslots);
   AggRows<NV> cur, nxt;
-  if (lo < hi) lds_agg_load<NV, FLAGS>(pk, pi, pv0, pv1, pf, lo + threadIdx.x, hi, cur); // in flight during the set-up
+  if (lo < hi) lds_agg_load<NV, FLAGS, PACK>(pk, pi, pv0, pv1, pf, lo + threadIdx.x, hi, cur); // in flight during the set-up
   for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) {
     tkey[s] = LDS_EMPTY;
     tfirst[s] = 0xffffffffu;
@@ -209,10 +229,17 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
   for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {
     const int64_t i0 = base + threadIdx.x;
     // next trip's rows (the last trip re-reads the last rows of the bucket)
-    lds_agg_load<NV, FLAGS>(pk, pi, pv0, pv1, pf, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
+    lds_agg_load<NV, FLAGS, PACK>(pk, pi, pv0, pv1, pf, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
     // first probe of all LDS_U rows: the table reads are independent and issue together
     uint32_t slot[LDS_U];
     unsigned long long seen[LDS_U];
+    if (PACK) {
+#pragma unroll
+      for (int u = 0; u < LDS_U; u++) {
+        cur.id[u] = packed_row(kp, cur.k[u]);
+        cur.k[u] = packed_key(kp, cur.k[u]);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
       uint32_t s = slot_hash(cur.k[u]) & mask;
@@ -309,13 +336,30 @@ __global__ void bytes_pack_kernel(const uint8_t *__restrict__ bytes, int64_t n, 
   if (lane_id() == 0 && i < n) out[i >> 6] = m;
 }
 
+// min / max of the signed-order image of `keys` (all valid)
+__global__ void key_range_kernel(const uint64_t *__restrict__ keys, int64_t n, unsigned long long *mm) {
+  uint64_t kmin = ~0ull, kmax = 0;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t o = keys[r] ^ (1ull << 63);
+    kmin = min(kmin, o);
+    kmax = max(kmax, o);
+  }
+  kmin = wave_min_u64(kmin);
+  kmax = wave_max_u64(kmax);
+  if (lane_id() == 0) {
+    atomicMin(mm, (unsigned long long)kmin);
+    atomicMax(mm + 1, (unsigned long long)kmax);
+  }
+}
+
 bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggInput &in,
                               uint64_t row_offset, PartAggOutput *out) {
   const int64_t n = in.n;
   if (n > 0xffffffffll || spec.n_acc > PART_MAX_ACC || spec.nv > 2) return false;
   // 1. how many groups?  -> bucket count.  Fused join: every build key needs a slot.
   const bool join_mode = in.join_keys != nullptr;
-  double est = join_mode ? (double)in.join_n : estimate_distinct(ctx, in.keys, in.key_validity, n);
+  uint64_t omin = ~0ull, omax = 0; // signed-order image of the smallest / largest key of interest
+  double est = join_mode ? (double)in.join_n : estimate_distinct(ctx, in.keys, in.key_validity, n, &omin, &omax);
   static const double est_scale = [] { // test hook: mis-scale the estimate to force the overflow path
     const char *e = std::getenv("SQLRS_EST_SCALE");
     return e ? std::atof(e) : 1.0;
@@ -343,7 +387,39 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   uint32_t P = (uint32_t)std::max(1.0, std::ceil(want));
   out->est_groups = est;
   // 2./3. rows in bucket order (LDS-staged multi-split, radix_part.hip)
+  // (key, row) packing: the keys of interest are the batch's own keys, or the build keys of the
+  // fused join (a probe key outside their range cannot have a partner)
+  KeyPack kp;
+  const bool nullable = in.key_validity || in.val_validity[0] || in.val_validity[1];
+  if (!nullable && spec.nv <= 1 && !(join_mode && in.join_validity)) {
+    if (join_mode) {
+      BufP mm = ctx->alloc(16);
+      uint64_t init[2] = {~0ull, 0ull};
+      SQ_HIP(hipMemcpyAsync(mm->p, init, 16, hipMemcpyHostToDevice, ctx->stream));
+      ctx->sync();
+      unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(in.join_n, 1024), 1024);
+      key_range_kernel<<<dim3(std::max(blocks, 1u)), dim3(256), 0, ctx->stream>>>(
+          in.join_keys, in.join_n, mm->as<unsigned long long>());
+      SQ_HIP(hipGetLastError());
+      const uint64_t *h = (const uint64_t *)ctx->fetch(mm->p, 16);
+      omin = h[0];
+      omax = h[1];
+    }
+    if (omin <= omax) {
+      uint64_t range = omax - omin; // offsets 0..range; sentinel offset = kmask > range
+      uint32_t kbits = 1;
+      while (kbits < 64 && ((1ull << kbits) - 1) <= range) kbits++;
+      int rowbits = 1;
+      while (rowbits < 32 && (1ll << rowbits) < n) rowbits++;
+      if (kbits + rowbits <= 64) {
+        kp.kbits = kbits;
+        kp.kmask = (1ull << kbits) - 1;
+        kp.kmin = omin ^ (1ull << 63);
+      }
+    }
+  }
   PartitionInput pin;
+  pin.pack = kp;
   pin.keys = in.keys;
   pin.key_validity = in.key_validity;
   pin.n = n;
@@ -425,28 +501,33 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   out->ov_rows = ctx->alloc(4 * (size_t)n);
   {
     ProfScope ps(ctx, "lds_agg");
-#define SQ_LA(NV, FL, JN, NA, C0, C1)                                                                          \
+#define SQ_LA(NV, FL, JN, NA, C0, C1, PK)                                                                        \
   do {                                                                                                         \
-    auto kfn = lds_agg_kernel<NV, FL, JN, NA, C0, C1>;                                                         \
+    auto kfn = lds_agg_kernel<NV, FL, JN, NA, C0, C1, PK>;                                                      \
     static bool attr_set = false;                                                                              \
     if (!attr_set) {                                                                                           \
       SQ_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));  \
       attr_set = true;                                                                                         \
     }                                                                                                          \
     kfn<<<dim3(nwork), dim3(PART_WG), lds, ctx->stream>>>(                                                     \
-        prm, pk->as<uint64_t>(), pi->as<uint32_t>(), pv0 ? pv0->as<uint64_t>() : nullptr,                      \
+        prm, pk->as<uint64_t>(), pi ? pi->as<uint32_t>() : nullptr, pv0 ? pv0->as<uint64_t>() : nullptr,       \
         pv1 ? pv1->as<uint64_t>() : nullptr, pf ? pf->as<uint8_t>() : nullptr, dwork->as<uint32_t>(), P, n,    \
         ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(),                 \
         out->gvalid ? out->gvalid->as<uint8_t>() : nullptr, out->gacc->as<uint64_t>(), gcap,                   \
         ctr->as<unsigned long long>() + 1, out->ov_rows->as<uint32_t>(),                                       \
         bp ? bp->key->as<uint64_t>() : nullptr, (bp && bp->flags) ? bp->flags->as<uint8_t>() : nullptr,        \
-        bp ? bp->bstart->as<uint32_t>() : nullptr);                                                            \
+        bp ? bp->bstart->as<uint32_t>() : nullptr, pr.pack);                                                   \
     launched = true;                                                                                           \
   } while (0)
 #define SQ_LA_J(NV, FL, NA, C0, C1)                                                                            \
   do {                                                                                                         \
-    if (join_mode) SQ_LA(NV, FL, true, NA, C0, C1);                                                            \
-    else SQ_LA(NV, FL, false, NA, C0, C1);                                                                     \
+    if (pr.pack.kbits) {                                                                                       \
+      if (join_mode) SQ_LA(NV, FL, true, NA, C0, C1, true);                                                    \
+      else SQ_LA(NV, FL, false, NA, C0, C1, true);                                                             \
+    } else {                                                                                                   \
+      if (join_mode) SQ_LA(NV, FL, true, NA, C0, C1, false);                                                   \
+      else SQ_LA(NV, FL, false, NA, C0, C1, false);                                                            \
+    }                                                                                                          \
   } while (0)
     const int nvu = pv1 ? 2 : (pv0 ? 1 : 0);
     bool launched = false;

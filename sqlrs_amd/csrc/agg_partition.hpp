@@ -46,7 +46,9 @@ struct PartAggOutput {
   int buckets = 0;
 };
 
-double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n);
+// also returns min / max of the valid keys' signed-order image (key ^ 1 << 63) when asked
+double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n,
+                         uint64_t *omin = nullptr, uint64_t *omax = nullptr);
 // false = not applicable (too many groups for one partition level, or estimate blown):
 // the caller uses the resolve path for the whole batch.
 bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggInput &in,

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(RP_WG) void rp_hist_kernel(const uint64_t *__restri
                                                         const uint8_t *__restrict__ flags,
                                                         const Tile *__restrict__ tiles, uint32_t P,
                                                         uint32_t p2_bits, int level, uint32_t digits,
-                                                        uint32_t *__restrict__ mat) {
+                                                        uint32_t *__restrict__ mat, KeyPack kp) {
   __shared__ uint32_t h[512];
   const Tile t = tiles[xcd_tile(blockIdx.x, gridDim.x)];
   if (threadIdx.x < digits) h[threadIdx.x] = 0;
@@ -65,7 +65,9 @@ __global__ __launch_bounds__(RP_WG) void rp_hist_kernel(const uint64_t *__restri
     if (o < t.len) {
       int64_t r = t.start + o;
       bool valid = flags ? (flags[r] & 1) : (!key_validity || ((key_validity[r >> 6] >> (r & 63)) & 1));
-      atomicAdd(&h[rp_digit(rp_bucket(keys[r], valid, P), level, p2_bits)], 1u);
+      uint64_t key = keys[r];
+      if (kp.kbits) key = packed_key(kp, key); // level >= 2 of a packed partition
+      atomicAdd(&h[rp_digit(rp_bucket(key, valid, P), level, p2_bits)], 1u);
     }
   }
   __syncthreads();
@@ -108,7 +110,7 @@ template <int NV, int RP_ROWS> struct TileRegs {
   uint32_t goff; // offs[] entry of (digit threadIdx.x, this tile)
 };
 
-template <int NV, int RP_WG, int RP_ROWS, int MODE>
+template <int NV, int RP_WG, int RP_ROWS, int MODE, bool PACK>
 __device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, const uint32_t *__restrict__ offs,
                                              uint32_t digits, TileRegs<NV, RP_ROWS> &r) {
   // every lane loads (rows past the end of a ragged tile re-read its last row), so the loads of
@@ -120,7 +122,8 @@ __device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, cons
     r.k[j] = __builtin_nontemporal_load(in.key + row);
     if (NV >= 1) r.a0[j] = __builtin_nontemporal_load(in.v0 + row);
     if (NV >= 2) r.a1[j] = __builtin_nontemporal_load(in.v1 + row);
-    if (MODE == RP_LN || MODE == RP_LN_FLAG) r.id[j] = __builtin_nontemporal_load(in.idx + row);
+    if (PACK) r.id[j] = (uint32_t)row; // level 1: packed at staging time; level >= 2: unused
+    else if (MODE == RP_LN || MODE == RP_LN_FLAG) r.id[j] = __builtin_nontemporal_load(in.idx + row);
     else r.id[j] = (uint32_t)row;
     if (MODE == RP_LN_FLAG) r.fl[j] = in.flags[row];
     else r.fl[j] = 7;
@@ -144,13 +147,13 @@ __device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, cons
 // it: the rows of tile i+1 are loaded into a second register set before tile i goes through its
 // LDS phases (rank with LDS atomics -> scan -> stage sorted -> coalesced stores), which hides the
 // HBM latency that a 150 KiB-LDS kernel (one workgroup per CU) cannot hide with occupancy.
-template <int NV, int RP_WG, int RP_ROWS, int MODE>
+template <int NV, int RP_WG, int RP_ROWS, int MODE, bool PACK>
 __global__ __launch_bounds__(RP_WG, RP_ROWS <= 6 ? 2 : 1) void rp_scatter_kernel(RpIn in, RpOut out,
                                                            const Tile *__restrict__ tiles, uint32_t P,
                                                            uint32_t p2_bits, int level, uint32_t digits,
                                                            const uint32_t *__restrict__ offs,
                                                            uint32_t num_tiles, uint32_t tiles_per_wg,
-                                                           int64_t sink) {
+                                                           int64_t sink, KeyPack kp) {
   constexpr int RP_TILE = RP_WG * RP_ROWS;
   constexpr bool FLAGS = MODE == RP_L1_NULL || MODE == RP_LN_FLAG;
 #ifdef RP_NO_DRAIN
@@ -185,14 +188,14 @@ __global__ __launch_bounds__(RP_WG, RP_ROWS <= 6 ? 2 : 1) void rp_scatter_kernel
   // With that the only wait in the loop is vmcnt(stores of this tile) before `cur = nxt`.
   TileRegs<NV, RP_ROWS> cur, nxt;
   Tile t = tiles[t0];
-  rp_load_tile<NV, RP_WG, RP_ROWS, MODE>(in, t, offs, digits, cur);
+  rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, t, offs, digits, cur);
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
 #ifdef RP_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #endif
   for (uint32_t ti = t0; ti < t1; ti++) {
     Tile tn = tiles[min(ti + 1, t1 - 1)];
-    rp_load_tile<NV, RP_WG, RP_ROWS, MODE>(in, tn, offs, digits, nxt);
+    rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, tn, offs, digits, nxt);
     cnt[threadIdx.x] = 0;
     __syncthreads();
     RP_T(0);
@@ -201,7 +204,8 @@ __global__ __launch_bounds__(RP_WG, RP_ROWS <= 6 ? 2 : 1) void rp_scatter_kernel
     for (int j = 0; j < RP_ROWS; j++) {
       dg[j] = 0xffffffffu;
       if ((uint32_t)(j * RP_WG) + threadIdx.x < t.len) {
-        dg[j] = rp_digit(rp_bucket(cur.k[j], cur.fl[j] & 1, P), level, p2_bits);
+        const uint64_t key = (PACK && MODE == RP_LN) ? packed_key(kp, cur.k[j]) : cur.k[j];
+        dg[j] = rp_digit(rp_bucket(key, cur.fl[j] & 1, P), level, p2_bits);
         rk[j] = atomicAdd(&cnt[dg[j]], 1u);
       }
     }
@@ -224,10 +228,10 @@ __global__ __launch_bounds__(RP_WG, RP_ROWS <= 6 ? 2 : 1) void rp_scatter_kernel
     for (int j = 0; j < RP_ROWS; j++) {
       if (dg[j] == 0xffffffffu) continue;
       uint32_t p = lstart[dg[j]] + rk[j];
-      skey[p] = cur.k[j];
+      skey[p] = (PACK && MODE == RP_L1) ? pack_key_row(kp, cur.k[j], cur.id[j]) : cur.k[j];
       if (NV >= 1) sv0[p] = cur.a0[j];
       if (NV >= 2) sv1[p] = cur.a1[j];
-      sidx[p] = cur.id[j];
+      if (!PACK) sidx[p] = cur.id[j];
       sdig[p] = (uint16_t)dg[j];
       if (FLAGS) sflag[p] = cur.fl[j];
     }
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(RP_WG, RP_ROWS <= 6 ? 2 : 1) void rp_scatter_kernel
       out.key[g] = skey[p];
       if (NV >= 1) out.v0[g] = sv0[p];
       if (NV >= 2) out.v1[g] = sv1[p];
-      out.idx[g] = sidx[p];
+      if (!PACK) out.idx[g] = sidx[p];
       if (FLAGS) out.flags[g] = sflag[p];
     }
     if (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -327,6 +331,11 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   const uint32_t P = d1 << p2_bits;
   const bool flags = in.key_validity || in.val_validity[0] || in.val_validity[1];
   const int nv = in.nv;
+  int rowbits = 1;
+  while (rowbits < 32 && (1ll << rowbits) < n) rowbits++;
+  const bool pack = !flags && nv <= 1 && in.pack.kbits != 0 && in.pack.kbits + rowbits <= 64;
+  const KeyPack kp = pack ? in.pack : KeyPack();
+  out->pack = kp;
   const int WG = 512;
   // rows per thread: 12 -> 6144-row tiles, 8 -> 4096-row tiles (two value columns); one
   // workgroup per CU either way (the staging area is ~140 KiB)
@@ -343,7 +352,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     k = ctx->alloc(8 * np);
     v0 = nv >= 1 ? ctx->alloc(8 * np) : nullptr;
     v1 = nv >= 2 ? ctx->alloc(8 * np) : nullptr;
-    idx = ctx->alloc(4 * np);
+    idx = pack ? nullptr : ctx->alloc(4 * np);
     fl = flags ? ctx->alloc(np) : nullptr;
   };
 
@@ -358,7 +367,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     unsigned nt = (unsigned)L.tiles.size();
     {
       ProfScope ps(ctx, in.build_side ? "rp_hist_build" : "rp_hist");
-#define SQ_RH(R) rp_hist_kernel<512, R><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, (const Tile *)tiles->p, P, p2_bits, level, digits, mat->as<uint32_t>())
+#define SQ_RH(R) rp_hist_kernel<512, R><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, (const Tile *)tiles->p, P, p2_bits, level, digits, mat->as<uint32_t>(), level == 1 ? KeyPack() : kp)
       if (ROWS == 12) SQ_RH(12); else if (ROWS == 8) SQ_RH(8); else SQ_RH(6);
 #undef SQ_RH
       SQ_HIP(hipGetLastError());
@@ -374,22 +383,23 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       dim3 g(wgs), b((unsigned)WG);
       const Tile *tp = (const Tile *)tiles->p;
       const int mode = level == 1 ? (flags ? RP_L1_NULL : RP_L1) : (flags ? RP_LN_FLAG : RP_LN);
-#define SQ_RP1(NV, R, M)                                                                                      \
+#define SQ_RP1(NV, R, M, PK)                                                                                  \
   do {                                                                                                        \
-    auto kfn = rp_scatter_kernel<NV, 512, R, M>;                                                              \
+    auto kfn = rp_scatter_kernel<NV, 512, R, M, PK>;                                                          \
     static bool attr_set = false;                                                                             \
     if (!attr_set) {                                                                                          \
       SQ_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
       attr_set = true;                                                                                        \
     }                                                                                                         \
-    kfn<<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs->as<uint32_t>(), nt, tpw, n); \
+    kfn<<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs->as<uint32_t>(), nt, tpw,  \
+                                    n, kp);                                                                   \
   } while (0)
 #define SQ_RP(NV, R)                                                                                          \
   do {                                                                                                        \
-    if (mode == RP_L1) SQ_RP1(NV, R, RP_L1);                                                                  \
-    else if (mode == RP_L1_NULL) SQ_RP1(NV, R, RP_L1_NULL);                                                   \
-    else if (mode == RP_LN) SQ_RP1(NV, R, RP_LN);                                                             \
-    else SQ_RP1(NV, R, RP_LN_FLAG);                                                                           \
+    if (mode == RP_L1) { if (pack) SQ_RP1(NV, R, RP_L1, true); else SQ_RP1(NV, R, RP_L1, false); }            \
+    else if (mode == RP_L1_NULL) SQ_RP1(NV, R, RP_L1_NULL, false);                                            \
+    else if (mode == RP_LN) { if (pack) SQ_RP1(NV, R, RP_LN, true); else SQ_RP1(NV, R, RP_LN, false); }       \
+    else SQ_RP1(NV, R, RP_LN_FLAG, false);                                                                    \
   } while (0)
       if (nv == 2) SQ_RP(2, 8);
       else if (ROWS == 6) { if (nv == 0) SQ_RP(0, 6); else SQ_RP(1, 6); }
@@ -442,7 +452,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   rout.key = k1->as<uint64_t>();
   rout.v0 = a1 ? a1->as<uint64_t>() : nullptr;
   rout.v1 = b1 ? b1->as<uint64_t>() : nullptr;
-  rout.idx = i1->as<uint32_t>();
+  rout.idx = i1 ? i1->as<uint32_t>() : nullptr;
   rout.flags = f1 ? f1->as<uint8_t>() : nullptr;
   BufP offs1;
   Level L1;
@@ -466,14 +476,14 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   rin2.key = k1->as<uint64_t>();
   rin2.v0 = a1 ? a1->as<uint64_t>() : nullptr;
   rin2.v1 = b1 ? b1->as<uint64_t>() : nullptr;
-  rin2.idx = i1->as<uint32_t>();
+  rin2.idx = i1 ? i1->as<uint32_t>() : nullptr;
   rin2.flags = f1 ? f1->as<uint8_t>() : nullptr;
   rin2.key_validity = rin2.v0_validity = rin2.v1_validity = nullptr;
   RpOut rout2;
   rout2.key = k2->as<uint64_t>();
   rout2.v0 = a2 ? a2->as<uint64_t>() : nullptr;
   rout2.v1 = b2 ? b2->as<uint64_t>() : nullptr;
-  rout2.idx = i2->as<uint32_t>();
+  rout2.idx = i2 ? i2->as<uint32_t>() : nullptr;
   rout2.flags = f2 ? f2->as<uint8_t>() : nullptr;
   BufP offs2;
   Level L2;

@@ -6,6 +6,23 @@
 
 namespace sq {
 
+// Optional packing of (key, row id) into one 8-byte word: word = min(key - kmin, kmask) | row << kbits.
+// Applies when the keys of interest span a known range [kmin, kmin + kmask) and kbits + bits(rows)
+// <= 64; a key outside the range is stored as the sentinel offset kmask (no key of interest has
+// it).  Saves the 4-byte row-id column in every partition pass and in the bucket pass.
+struct KeyPack {
+  uint64_t kmin = 0, kmask = 0;
+  uint32_t kbits = 0; // 0 = not packed
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint64_t pack_key_row(const KeyPack &kp, uint64_t key, uint32_t row) {
+  uint64_t off = key - kp.kmin;
+  return (off < kp.kmask ? off : kp.kmask) | ((uint64_t)row << kp.kbits);
+}
+__device__ __forceinline__ uint64_t packed_key(const KeyPack &kp, uint64_t w) { return (w & kp.kmask) + kp.kmin; }
+__device__ __forceinline__ uint32_t packed_row(const KeyPack &kp, uint64_t w) { return (uint32_t)(w >> kp.kbits); }
+#endif
+
 struct PartitionInput {
   const uint64_t *keys = nullptr; // normalised keys (NKeys)
   const uint64_t *key_validity = nullptr;
@@ -14,6 +31,7 @@ struct PartitionInput {
   const void *vals[2] = {nullptr, nullptr};
   const uint64_t *val_validity[2] = {nullptr, nullptr};
   bool build_side = false; // profiling label only
+  KeyPack pack;            // used only when no column is nullable
 };
 
 // Rows in bucket order: bucket b = rows [bstart[b], bstart[b+1]).  `idx` = original row,
@@ -24,6 +42,7 @@ struct PartitionedRows {
   uint32_t P = 0;
   BufP key, v0, v1, idx, flags;
   BufP bstart; // u32[P + 1]
+  KeyPack pack; // kbits != 0: `key` holds packed (key, row) words and `idx` is null
 };
 
 // P_wanted <= 65536; the actual bucket count (>= P_wanted) is returned in out->P.
