@@ -48,8 +48,8 @@ def log(*a):
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--rows", type=float, default=float(os.environ.get("SQLRS_BENCH_ROWS", 1e9)),
                    help="total fact rows over all ranks (C5: 1e9)")
     p.add_argument("--dim-rows", type=float, default=float(os.environ.get("SQLRS_BENCH_DIM", 1e7)),

@@ -148,7 +148,7 @@ __device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, cons
 // LDS phases (rank with LDS atomics -> scan -> stage sorted -> coalesced stores), which hides the
 // HBM latency that a 150 KiB-LDS kernel (one workgroup per CU) cannot hide with occupancy.
 template <int NV, int RP_WG, int RP_ROWS, int MODE, bool PACK>
-__global__ __launch_bounds__(RP_WG, RP_ROWS <= 6 ? 2 : 1) void rp_scatter_kernel(RpIn in, RpOut out,
+__global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV <= 1)) ? 2 : 1) void rp_scatter_kernel(RpIn in, RpOut out,
                                                            const Tile *__restrict__ tiles, uint32_t P,
                                                            uint32_t p2_bits, int level, uint32_t digits,
                                                            const uint32_t *__restrict__ offs,
@@ -162,13 +162,15 @@ __global__ __launch_bounds__(RP_WG, RP_ROWS <= 6 ? 2 : 1) void rp_scatter_kernel
   constexpr bool DRAIN = true;
 #endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // staging area: key | v0 | v1 | row id | digit | flags  (packed mode: key|row words and values only,
+  // the digit is recomputed from the key when the tile is written out)
   uint64_t *skey = (uint64_t *)smem;
   uint64_t *sv0 = skey + RP_TILE;
   uint64_t *sv1 = sv0 + (NV >= 1 ? RP_TILE : 0);
   uint32_t *sidx = (uint32_t *)(sv1 + (NV >= 2 ? RP_TILE : 0));
-  uint16_t *sdig = (uint16_t *)(sidx + RP_TILE);
-  uint8_t *sflag = (uint8_t *)(sdig + RP_TILE);
-  uint32_t *cnt = (uint32_t *)(sflag + RP_TILE); // [RP_WG]
+  uint16_t *sdig = (uint16_t *)(sidx + (PACK ? 0 : RP_TILE));
+  uint8_t *sflag = (uint8_t *)(sdig + (PACK ? 0 : RP_TILE));
+  uint32_t *cnt = (uint32_t *)(sflag + (PACK ? 0 : RP_TILE)); // [RP_WG]
   uint32_t *lstart = cnt + RP_WG;                // [RP_WG]
   int64_t *gbase = (int64_t *)(lstart + RP_WG);  // [RP_WG]
   __shared__ uint32_t s_wsum[RP_WG / 64];
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(RP_WG, RP_ROWS <= 6 ? 2 : 1) void rp_scatter_kernel
       if (NV >= 1) sv0[p] = cur.a0[j];
       if (NV >= 2) sv1[p] = cur.a1[j];
       if (!PACK) sidx[p] = cur.id[j];
-      sdig[p] = (uint16_t)dg[j];
+      if (!PACK) sdig[p] = (uint16_t)dg[j];
       if (FLAGS) sflag[p] = cur.fl[j];
     }
     __syncthreads();
@@ -240,9 +242,11 @@ __global__ __launch_bounds__(RP_WG, RP_ROWS <= 6 ? 2 : 1) void rp_scatter_kernel
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
       uint32_t p = j * RP_WG + threadIdx.x;
-      int64_t g = gbase[sdig[p] & (RP_WG - 1)] + p;
+      const uint64_t kw = skey[p];
+      const uint32_t d = PACK ? rp_digit(rp_bucket(packed_key(kp, kw), true, P), level, p2_bits) : sdig[p];
+      int64_t g = gbase[d & (RP_WG - 1)] + p;
       if (p >= t.len) g = sink + threadIdx.x;
-      out.key[g] = skey[p];
+      out.key[g] = kw;
       if (NV >= 1) out.v0[g] = sv0[p];
       if (NV >= 2) out.v1[g] = sv1[p];
       if (!PACK) out.idx[g] = sidx[p];
@@ -343,9 +347,9 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     const char *e = std::getenv("SQLRS_RP_ROWS");
     return e ? std::atoi(e) : 0;
   }();
-  const int ROWS = nv > 1 ? 8 : (rows_env == 6 ? 6 : 12);
+  const int ROWS = nv > 1 ? 8 : (rows_env == 6 ? 6 : ((rows_env == 8 && pack) ? 8 : 12));
   const int RP_TILE = WG * ROWS;
-  const size_t lds = (size_t)RP_TILE * (8 * (1 + nv) + 4 + 2 + 1) + (size_t)WG * (4 + 4 + 8);
+  const size_t lds = (size_t)RP_TILE * (pack ? 8 * (1 + nv) : 8 * (1 + nv) + 4 + 2 + 1) + (size_t)WG * (4 + 4 + 8);
 
   auto alloc_cols = [&](BufP &k, BufP &v0, BufP &v1, BufP &idx, BufP &fl) {
     const size_t np = (size_t)n + WG; // + the sink rows of rp_scatter_kernel
@@ -377,7 +381,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     {
       ProfScope ps(ctx, in.build_side ? "rp_scatter_build" : "rp_scatter");
       // one workgroup per CU slot; contiguous tile ranges (8 per workgroup at least)
-      uint32_t wgs = std::min<uint32_t>(nt, (uint32_t)ctx->num_cus * (ROWS == 6 ? 2 : 1));
+      uint32_t wgs = std::min<uint32_t>(nt, (uint32_t)ctx->num_cus * ((ROWS == 6 || (ROWS == 8 && pack)) ? 2 : 1));
       uint32_t tpw = (uint32_t)ceil_div(nt, wgs);
       wgs = (uint32_t)ceil_div(nt, tpw);
       dim3 g(wgs), b((unsigned)WG);
@@ -403,6 +407,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   } while (0)
       if (nv == 2) SQ_RP(2, 8);
       else if (ROWS == 6) { if (nv == 0) SQ_RP(0, 6); else SQ_RP(1, 6); }
+      else if (ROWS == 8) { if (nv == 0) SQ_RP(0, 8); else SQ_RP(1, 8); }
       else { if (nv == 0) SQ_RP(0, 12); else SQ_RP(1, 12); }
 #undef SQ_RP1
 #undef SQ_RP
