@@ -48,7 +48,9 @@ __device__ __forceinline__ uint32_t rp_digit(uint32_t bucket, int level, uint32_
   return level == 1 ? (bucket >> p2_bits) : (bucket & ((1u << p2_bits) - 1));
 }
 
-template <int RP_WG, int RP_ROWS>
+// PLAIN: no nullable key (no bitmap, no flags column) — every lane loads unconditionally (rows
+// past the end of a ragged tile re-read its last row), so the RP_ROWS loads issue back to back.
+template <int RP_WG, int RP_ROWS, bool PLAIN>
 __global__ __launch_bounds__(RP_WG) void rp_hist_kernel(const uint64_t *__restrict__ keys,
                                                         const uint64_t *__restrict__ key_validity,
                                                         const uint8_t *__restrict__ flags,
@@ -57,6 +59,12 @@ __global__ __launch_bounds__(RP_WG) void rp_hist_kernel(const uint64_t *__restri
                                                         uint32_t *__restrict__ mat, KeyPack kp) {
   __shared__ uint32_t h[512];
   const Tile t = tiles[xcd_tile(blockIdx.x, gridDim.x)];
+  uint64_t k[RP_ROWS];
+  if (PLAIN) {
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++)
+      k[j] = __builtin_nontemporal_load(keys + t.start + min((uint32_t)(j * RP_WG) + threadIdx.x, t.len - 1));
+  }
   if (threadIdx.x < digits) h[threadIdx.x] = 0;
   __syncthreads();
 #pragma unroll
@@ -64,8 +72,8 @@ __global__ __launch_bounds__(RP_WG) void rp_hist_kernel(const uint64_t *__restri
     uint32_t o = j * RP_WG + threadIdx.x;
     if (o < t.len) {
       int64_t r = t.start + o;
-      bool valid = flags ? (flags[r] & 1) : (!key_validity || ((key_validity[r >> 6] >> (r & 63)) & 1));
-      uint64_t key = keys[r];
+      bool valid = PLAIN ? true : (flags ? (flags[r] & 1) : (!key_validity || ((key_validity[r >> 6] >> (r & 63)) & 1)));
+      uint64_t key = PLAIN ? k[j] : keys[r];
       if (kp.kbits) key = packed_key(kp, key); // level >= 2 of a packed partition
       atomicAdd(&h[rp_digit(rp_bucket(key, valid, P), level, p2_bits)], 1u);
     }
@@ -371,9 +379,11 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     unsigned nt = (unsigned)L.tiles.size();
     {
       ProfScope ps(ctx, in.build_side ? "rp_hist_build" : "rp_hist");
-#define SQ_RH(R) rp_hist_kernel<512, R><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, (const Tile *)tiles->p, P, p2_bits, level, digits, mat->as<uint32_t>(), level == 1 ? KeyPack() : kp)
+#define SQ_RH1(R, PL) rp_hist_kernel<512, R, PL><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, (const Tile *)tiles->p, P, p2_bits, level, digits, mat->as<uint32_t>(), level == 1 ? KeyPack() : kp)
+#define SQ_RH(R) do { if (!rin.key_validity && !rin.flags) SQ_RH1(R, true); else SQ_RH1(R, false); } while (0)
       if (ROWS == 12) SQ_RH(12); else if (ROWS == 8) SQ_RH(8); else SQ_RH(6);
 #undef SQ_RH
+#undef SQ_RH1
       SQ_HIP(hipGetLastError());
     }
     exclusive_scan_u32(ctx, mat->as<uint32_t>(), L.mat_entries, nullptr, offs->as<uint32_t>(),
