@@ -275,6 +275,91 @@ __global__ __launch_bounds__(BLOCK) void join_probe_unique_kernel(
   }
 }
 
+// Direct-address probe with large tiles: 8 worker waves x 32 rows per lane = 16384 probe rows per
+// block, plus a scan wave that owns the decoupled look-back (same structure and same reason as
+// filter_cmp_const_kernel, select.hip: with 2048-row tiles the probe ran at the look-back's pace,
+// ~47 tiles/us = 97 Grows/s, not at the memory system's).
+constexpr int JD_WAVES = 8;
+constexpr int JD_ITEMS = 32;
+constexpr int JD_TILE = JD_WAVES * JD_ITEMS * 64;
+constexpr int JD_BLOCK = (JD_WAVES + 1) * 64;
+
+template <bool HASV>
+__global__ __launch_bounds__(JD_BLOCK, 2) void join_probe_dense_kernel(
+    const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n, int64_t num_tiles,
+    DenseTable dt, uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx, uint64_t *desc,
+    unsigned *ticket, uint64_t *total, int use_ticket) {
+  unsigned *timeout = use_ticket ? nullptr : ticket + 1;
+  __shared__ int64_t s_tile;
+  __shared__ uint32_t s_wave[JD_WAVES];
+  __shared__ uint64_t s_excl;
+  int64_t tile = blockIdx.x;
+  if (use_ticket) {
+    if (threadIdx.x == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);
+    __syncthreads();
+    tile = s_tile;
+  }
+  const int lane = lane_id(), w = wave_id();
+  if (w == JD_WAVES) { // ---- scan wave
+    __syncthreads(); // (1) the workers' counts are in s_wave
+    uint32_t c = lane < JD_WAVES ? s_wave[lane] : 0;
+    uint64_t agg = wave_sum_u32(c);
+    uint64_t excl = lookback_wave(desc, tile, agg, timeout);
+    if (lane == 0) {
+      s_excl = excl;
+      if (tile == num_tiles - 1) *total = excl + agg;
+    }
+    __syncthreads(); // (2)
+    return;
+  }
+  // ---- worker waves
+  const int64_t wrow = tile * JD_TILE + (int64_t)w * (JD_ITEMS * 64) + lane;
+  uint64_t k[JD_ITEMS];
+#pragma unroll
+  for (int j = 0; j < JD_ITEMS; j++) // streamed once: keep the table cached
+    k[j] = __builtin_nontemporal_load(keys + min(wrow + j * 64, n - 1));
+  uint32_t head[JD_ITEMS];
+#pragma unroll
+  for (int j = 0; j < JD_ITEMS; j++) { // independent 4-byte table loads, all in flight together
+    const int64_t r = wrow + j * 64;
+    const uint64_t d = k[j] - dt.kmin;
+    bool isnull = false;
+    if (HASV) {
+      const int64_t rc = min(r, n - 1);
+      isnull = !((validity[rc >> 6] >> (rc & 63)) & 1);
+    }
+    uint32_t h = DENSE_EMPTY;
+    if (r < n && !isnull && d < dt.range) h = dt.heads[d];
+    if (HASV && r < n && isnull) h = dt.null_head;
+    head[j] = h;
+  }
+  uint64_t mine = 0; // lane j keeps the hit mask of chunk j
+  uint32_t wave_cnt = 0;
+#pragma unroll
+  for (int j = 0; j < JD_ITEMS; j++) {
+    uint64_t b = __ballot(head[j] != DENSE_EMPTY);
+    mine = (lane == j) ? b : mine;
+    wave_cnt += (uint32_t)__popcll(b);
+  }
+  if (lane == 0) s_wave[w] = wave_cnt;
+  __syncthreads(); // (1)
+  __syncthreads(); // (2) the scan wave has published the tile's offset
+  uint64_t pos = s_excl;
+  for (int q = 0; q < w; q++) pos += s_wave[q];
+  const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+#pragma unroll
+  for (int j = 0; j < JD_ITEMS; j++) {
+    uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j) << 32) |
+                 (uint32_t)__builtin_amdgcn_readlane((int)mlo, j);
+    if ((m >> lane) & 1) {
+      uint64_t o = pos + mbcnt(m);
+      __builtin_nontemporal_store((uint64_t)head[j], &left_idx[o]);
+      __builtin_nontemporal_store((uint32_t)(wrow + j * 64), &right_idx[o]);
+    }
+    pos += (uint32_t)__popcll(m);
+  }
+}
+
 // UNIQUE build keys, Right/Full: every probe row emits exactly one pair (hash_join.rs:235-247)
 template <bool DENSE>
 __global__ __launch_bounds__(BLOCK) void join_probe_unique_outer_kernel(
@@ -530,7 +615,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   if (n > 0xffffffffll) fail(SQLRS_ERR_INTERNAL, "probe batch larger than 2^32 rows");
   dim3 g((unsigned)ceil_div(n, BLOCK)), b(BLOCK);
   if (j->unique && !outer_right) { // one lookup per row, compaction with look-back
-    int64_t tiles = ceil_div(n, JP_TILE);
+    int64_t tiles = ceil_div(n, j->dense ? JD_TILE : JP_TILE);
     p.left = ctx->alloc(8 * (size_t)n);
     p.right = ctx->alloc(4 * (size_t)n);
     BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 16);
@@ -542,10 +627,14 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
         ProfScope ps(ctx, j->dense ? "join_probe_dense" : "join_probe_unique");
         dim3 gt((unsigned)tiles);
         DenseTable dt{j->dense ? j->dense->as<uint32_t>() : nullptr, j->dense_min, j->dense_range, j->dense_null_head};
-        if (j->dense)
-          join_probe_unique_kernel<true><<<gt, b, 0, ctx->stream>>>(
-              pk.keys->as<uint64_t>(), pk.validity, n, tiles, (j->table ? j->table->as<Slot>() : nullptr), j->mask, dt,
-              p.left->as<uint64_t>(), p.right->as<uint32_t>(), desc->as<uint64_t>(), ticket, tot, use_ticket);
+        if (j->dense && pk.validity)
+          join_probe_dense_kernel<true><<<gt, dim3(JD_BLOCK), 0, ctx->stream>>>(
+              pk.keys->as<uint64_t>(), pk.validity, n, tiles, dt, p.left->as<uint64_t>(), p.right->as<uint32_t>(),
+              desc->as<uint64_t>(), ticket, tot, use_ticket);
+        else if (j->dense)
+          join_probe_dense_kernel<false><<<gt, dim3(JD_BLOCK), 0, ctx->stream>>>(
+              pk.keys->as<uint64_t>(), pk.validity, n, tiles, dt, p.left->as<uint64_t>(), p.right->as<uint32_t>(),
+              desc->as<uint64_t>(), ticket, tot, use_ticket);
         else
           join_probe_unique_kernel<false><<<gt, b, 0, ctx->stream>>>(
               pk.keys->as<uint64_t>(), pk.validity, n, tiles, (j->table ? j->table->as<Slot>() : nullptr), j->mask, dt,
