@@ -79,7 +79,39 @@ __global__ __launch_bounds__(RP_WG) void rp_hist_kernel(const uint64_t *__restri
     }
   }
   __syncthreads();
-  if (threadIdx.x < digits) mat[t.mat + (int64_t)threadIdx.x * t.stride] = h[threadIdx.x];
+  // tile-major: the tile's `digits` counts are one contiguous run (rp_transpose_kernel turns the
+  // matrix digit-major for the scan; 256 scattered 4-byte writes per tile were a third of this
+  // kernel's time at level 2)
+  if (threadIdx.x < digits) mat[(int64_t)xcd_tile(blockIdx.x, gridDim.x) * digits + threadIdx.x] = h[threadIdx.x];
+}
+
+// count / offset matrix between its two layouts, 16 tiles at a time through LDS:
+//   tile-major  T[g * digits + d]                (what one tile reads or writes: contiguous)
+//   digit-major M[tiles[g].mat + d * tiles[g].stride]  (the order the exclusive scan must run in:
+//                                                  all tiles of digit 0, then digit 1, ... per segment)
+constexpr int RP_TB = 16;
+template <bool TO_TILE_MAJOR>
+__global__ __launch_bounds__(256) void rp_transpose_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                           const Tile *__restrict__ tiles, uint32_t num_tiles,
+                                                           uint32_t digits) {
+  extern __shared__ uint32_t tbuf[]; // [RP_TB][digits + 1]
+  const uint32_t g0 = blockIdx.x * RP_TB, pitch = digits + 1;
+  for (uint32_t i = threadIdx.x; i < RP_TB * digits; i += 256) {
+    uint32_t tl, d;
+    if (TO_TILE_MAJOR) { d = i / RP_TB; tl = i % RP_TB; } else { tl = i / digits; d = i % digits; }
+    uint32_t g = g0 + tl;
+    if (g >= num_tiles) continue;
+    tbuf[tl * pitch + d] = TO_TILE_MAJOR ? src[tiles[g].mat + (int64_t)d * tiles[g].stride] : src[(int64_t)g * digits + d];
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < RP_TB * digits; i += 256) {
+    uint32_t tl, d;
+    if (TO_TILE_MAJOR) { tl = i / digits; d = i % digits; } else { d = i / RP_TB; tl = i % RP_TB; }
+    uint32_t g = g0 + tl;
+    if (g >= num_tiles) continue;
+    if (TO_TILE_MAJOR) dst[(int64_t)g * digits + d] = tbuf[tl * pitch + d];
+    else dst[tiles[g].mat + (int64_t)d * tiles[g].stride] = tbuf[tl * pitch + d];
+  }
 }
 
 struct RpIn {
@@ -119,8 +151,9 @@ template <int NV, int RP_ROWS> struct TileRegs {
 };
 
 template <int NV, int RP_WG, int RP_ROWS, int MODE, bool PACK>
-__device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, const uint32_t *__restrict__ offs,
-                                             uint32_t digits, TileRegs<NV, RP_ROWS> &r) {
+__device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, uint32_t tile_index,
+                                             const uint32_t *__restrict__ offs, uint32_t digits,
+                                             TileRegs<NV, RP_ROWS> &r) {
   // every lane loads (rows past the end of a ragged tile re-read its last row), so the loads of
   // all RP_ROWS rows are issued back to back
 #pragma unroll
@@ -136,7 +169,7 @@ __device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, cons
     if (MODE == RP_LN_FLAG) r.fl[j] = in.flags[row];
     else r.fl[j] = 7;
   }
-  r.goff = offs[t.mat + (int64_t)min(threadIdx.x, digits - 1) * t.stride];
+  r.goff = offs[(int64_t)tile_index * digits + min(threadIdx.x, digits - 1)]; // tile-major offsets
   if (MODE == RP_L1_NULL) {
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
@@ -198,14 +231,14 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
   // With that the only wait in the loop is vmcnt(stores of this tile) before `cur = nxt`.
   TileRegs<NV, RP_ROWS> cur, nxt;
   Tile t = tiles[t0];
-  rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, t, offs, digits, cur);
+  rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, t, t0, offs, digits, cur);
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
 #ifdef RP_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #endif
   for (uint32_t ti = t0; ti < t1; ti++) {
     Tile tn = tiles[min(ti + 1, t1 - 1)];
-    rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, tn, offs, digits, nxt);
+    rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, tn, min(ti + 1, t1 - 1), offs, digits, nxt);
     cnt[threadIdx.x] = 0;
     __syncthreads();
     RP_T(0);
@@ -386,8 +419,18 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
 #undef SQ_RH1
       SQ_HIP(hipGetLastError());
     }
-    exclusive_scan_u32(ctx, mat->as<uint32_t>(), L.mat_entries, nullptr, offs->as<uint32_t>(),
+    // tile-major counts -> digit-major, scan, digit-major offsets -> tile-major for the scatter
+    BufP mat_dm = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
+    BufP offs_tm = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
+    const size_t tlds = (size_t)RP_TB * (digits + 1) * 4;
+    const unsigned tblocks = (unsigned)ceil_div(nt, RP_TB);
+    rp_transpose_kernel<false><<<dim3(tblocks), dim3(256), tlds, ctx->stream>>>(
+        mat->as<uint32_t>(), mat_dm->as<uint32_t>(), (const Tile *)tiles->p, nt, digits);
+    exclusive_scan_u32(ctx, mat_dm->as<uint32_t>(), L.mat_entries, nullptr, offs->as<uint32_t>(),
                        total->as<uint64_t>());
+    rp_transpose_kernel<true><<<dim3(tblocks), dim3(256), tlds, ctx->stream>>>(
+        offs->as<uint32_t>(), offs_tm->as<uint32_t>(), (const Tile *)tiles->p, nt, digits);
+    SQ_HIP(hipGetLastError());
     {
       ProfScope ps(ctx, in.build_side ? "rp_scatter_build" : "rp_scatter");
       // one workgroup per CU slot; contiguous tile ranges (8 per workgroup at least)
@@ -405,7 +448,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       SQ_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
       attr_set = true;                                                                                        \
     }                                                                                                         \
-    kfn<<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs->as<uint32_t>(), nt, tpw,  \
+    kfn<<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs_tm->as<uint32_t>(), nt, tpw, \
                                     n, kp);                                                                   \
   } while (0)
 #define SQ_RP(NV, R)                                                                                          \
