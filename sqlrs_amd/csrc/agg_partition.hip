@@ -34,23 +34,38 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t h, uint32_t P) {
 }
 
 // ---------------------------------------------------------------- key statistics --
-// HyperLogLog registers + min / max of the keys' signed-order image (hll[4096..4099] as two u64)
+// HyperLogLog registers + min / max of the keys' signed-order image (hll[4096..4099] as two u64).
+// Min / max see every row; the HyperLogLog registers only every 2^sample_shift-th 64-row group
+// (the hash + LDS atomic per row is what made this kernel slower than a plain read).
 __global__ __launch_bounds__(PART_WG) void key_stats_kernel(const uint64_t *__restrict__ keys,
                                                             const uint64_t *__restrict__ validity,
-                                                            int64_t n, unsigned int *__restrict__ hll) {
+                                                            int64_t n, int sample_shift,
+                                                            unsigned int *__restrict__ hll) {
   __shared__ unsigned int reg[4096];
   for (int i = threadIdx.x; i < 4096; i += PART_WG) reg[i] = 0;
   __syncthreads();
   uint64_t kmin = ~0ull, kmax = 0;
-  for (int64_t r = blockIdx.x * (int64_t)PART_WG + threadIdx.x; r < n; r += (int64_t)gridDim.x * PART_WG) {
-    if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) continue;
-    const uint64_t o = keys[r] ^ (1ull << 63);
-    kmin = min(kmin, o);
-    kmax = max(kmax, o);
-    uint64_t h = mix64(keys[r] ^ 0x2545f4914f6cdd1dULL);
-    unsigned idx = (unsigned)(h >> 52);
-    unsigned rank = (unsigned)__builtin_clzll((h << 12) | (1ull << 11)) + 1;
-    if (reg[idx] < rank) atomicMax(&reg[idx], rank);
+  const int64_t smask = (1ll << sample_shift) - 1;
+  constexpr int KU = 12; // loads in flight per lane (the loaded HBM latency needs ~100 KiB per CU)
+  for (int64_t base = blockIdx.x * (int64_t)(PART_WG * KU) + threadIdx.x; base < n;
+       base += (int64_t)gridDim.x * (PART_WG * KU)) {
+    uint64_t k[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) k[u] = __builtin_nontemporal_load(keys + min(base + u * PART_WG, n - 1));
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      const int64_t r = base + u * PART_WG;
+      if (r >= n) continue;
+      if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) continue;
+      const uint64_t o = k[u] ^ (1ull << 63);
+      kmin = min(kmin, o);
+      kmax = max(kmax, o);
+      if (((r >> 6) & smask) != 0) continue; // wave-uniform
+      uint64_t h = mix64(k[u] ^ 0x2545f4914f6cdd1dULL);
+      unsigned idx = (unsigned)(h >> 52);
+      unsigned rank = (unsigned)__builtin_clzll((h << 12) | (1ull << 11)) + 1;
+      if (reg[idx] < rank) atomicMax(&reg[idx], rank);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 4096; i += PART_WG)
@@ -64,14 +79,16 @@ __global__ __launch_bounds__(PART_WG) void key_stats_kernel(const uint64_t *__re
   }
 }
 
-double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n,
-                         uint64_t *omin, uint64_t *omax) {
+static double hll_pass(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n, int sample_shift,
+                       uint64_t *omin, uint64_t *omax) {
   BufP hll = ctx->alloc_zero(4096 * 4 + 16);
   SQ_HIP(hipMemsetAsync(hll->as<uint8_t>() + 4096 * 4, 0xff, 8, ctx->stream)); // min starts at ~0
   {
     ProfScope ps(ctx, "key_stats");
-    unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, PART_WG * 16), 2048);
-    key_stats_kernel<<<dim3(std::max(blocks, 1u)), dim3(PART_WG), 0, ctx->stream>>>(keys, validity, n,
+    // two blocks per CU: every block ends with up to 4096 global atomicMax (24 G/s on MI355X), so
+    // 2048 blocks spent 0.33 ms merging their registers — more than reading 1.6 GB of keys
+    unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, PART_WG * 16), 2 * (int64_t)ctx->num_cus);
+    key_stats_kernel<<<dim3(std::max(blocks, 1u)), dim3(PART_WG), 0, ctx->stream>>>(keys, validity, n, sample_shift,
                                                                                   hll->as<unsigned int>());
     SQ_HIP(hipGetLastError());
   }
@@ -90,6 +107,18 @@ double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validit
   }
   double e = (0.7213 / (1.0 + 1.079 / m)) * m * m / sum;
   if (e <= 2.5 * m && zeros) e = m * std::log(m / zeros);
+  return e;
+}
+
+// Distinct keys of the batch.  A 1/8 sample (every eighth 64-row group) is enough while every
+// group is seen several times in it; when the sample looks like mostly distinct keys the full
+// pass decides (the partition route is then usually rejected anyway).  A low estimate is not a
+// correctness problem: rows that do not fit their bucket table take the overflow path.
+double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n,
+                         uint64_t *omin, uint64_t *omax) {
+  const int shift = n >= (1ll << 22) ? 3 : 0;
+  double e = hll_pass(ctx, keys, validity, n, shift, omin, omax);
+  if (shift && e > 0.2 * (double)(n >> shift)) e = hll_pass(ctx, keys, validity, n, 0, omin, omax);
   return e;
 }
 
