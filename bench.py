@@ -392,16 +392,18 @@ def main():
 
 
 def pmc_traffic(kernel, n_fact, n_dim, world, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r01b_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc runs of this very
-    command).  Only valid for the default workload; otherwise null."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (the newest
+    profiles/*_pmc_traffic.json, written by tools/profile_round.sh: 2*FETCH_SIZE + WRITE_SIZE, separate
+    --pmc runs of this very command).  Only valid for the default workload; otherwise null."""
     if not (n_fact == 1_000_000_000 and n_dim == 10_000_000 and world == 1 and args.threshold == 0.5
             and not args.unfused):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")) as f:
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+        with open(newest) as f:
             return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, IndexError):
         return None
 
 
