@@ -524,6 +524,68 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     by = 16 * n + 24 * groups[0]
     res["C4_agg"] = {"rows": n, "groups": groups[0], "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
                      "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    # ---- C4 with Zipf(1.1) keys over the same 1e6 groups (hot groups: contention / bucket skew)
+    import numpy as _np
+    w = _np.arange(1, G + 1, dtype=_np.float64) ** -1.1
+    cdf = torch.from_numpy(_np.cumsum(w) / w.sum()).to(dev)
+    perm_a = datagen._coprime_multiplier(G)
+    key = datagen.fill_chunks(key, lambda i: (torch.searchsorted(cdf, datagen.val_t(0xA7, i)).clamp_(max=G - 1) * perm_a + 7) % G)
+    torch.cuda.synchronize()
+    del cdf
+    ms = timed(run_agg)
+    profile_of(run_agg, "C4 agg zipf")
+    by = 16 * n + 24 * groups[0]
+    res["C4_agg_zipf1.1"] = {"rows": n, "groups": groups[0], "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
+                             "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    del key, val, b
+    # ---- C2 with 10 % NULLs in the predicate column (validity bitmap read, NULL rows dropped)
+    n = 100_000_000
+    v1 = datagen.fill_chunks(torch.empty(n, dtype=torch.int64, device=dev),
+                             lambda i: datagen._lsr(datagen.splitmix64_t(0xC2, i), 33))
+    nwords = (n + 63) // 64
+    bits = torch.zeros(nwords, dtype=torch.int64, device=dev)
+    for bit in range(64):  # bit set = valid with probability 0.9
+        r = datagen.val_t(0xC3 + bit, torch.arange(nwords, dtype=torch.int64, device=dev)) < 0.9
+        bits |= r.to(torch.int64) << bit
+    torch.cuda.synchronize()
+    col = abi.device_column(abi.INT64, n, v1.data_ptr(), validity_ptr=bits.data_ptr(), null_count=-1)
+    bnull = abi.RawBatch([col], n, keepalive=[v1, bits])
+    e = (InputRef(0) > Constant(1 << 30, abi.INT64)).pack()
+    kept = [0]
+
+    def run_null():
+        f = C.c_void_p()
+        be.check(be.fn("filter_create")(be.ctx, C.byref(e.abi), C.byref(f)))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("filter_push")(f, bnull.ptr, D, C.byref(o)))
+        kept[0] = o.contents.num_rows
+        be.fn("batch_release")(o)
+        be.fn("filter_destroy")(f)
+    ms = timed(run_null)
+    by = 8 * n + n // 8 + 8 * kept[0]
+    res["C2_filter_s0.5_null10"] = {"rows": n, "kept": kept[0], "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
+                                    "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    del bnull, bits
+    # ---- Order: ORDER BY v1 (int64, 31 significant bits) carrying one f64 column, 1e8 rows
+    val = datagen.fill_chunks(torch.empty(n, dtype=torch.float64, device=dev), lambda i: datagen.val_t(0xF2, i))
+    torch.cuda.synchronize()
+    bo = device_batch(abi, [v1, val], [abi.INT64, abi.FLOAT64])
+    pk = InputRef(0).pack()
+    obs = (abi.OrderBy * 1)(abi.OrderBy(pk.abi, 1, 0))
+
+    def run_order():
+        h = C.c_void_p()
+        be.check(be.fn("order_create")(be.ctx, 1, obs, C.byref(h)))
+        be.check(be.fn("order_push")(h, bo.ptr))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("order_finish")(h, D, C.byref(o)))
+        be.fn("batch_release")(o)
+        be.fn("order_destroy")(h)
+    ms = timed(run_order)
+    profile_of(run_order, "Order")
+    by = 16 * n + 16 * n  # read key + carried column, write both permuted (SURVEY.md §8d minimum)
+    res["Order_int64_1col"] = {"rows": n, "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
+                               "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
     for k_, v_ in res.items():
         log(f"[bench] {k_}: {v_}")
     return res

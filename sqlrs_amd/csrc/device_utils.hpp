@@ -38,6 +38,13 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// 64-bit value of lane `src` (a compile-time constant after unrolling) broadcast to the wave
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);

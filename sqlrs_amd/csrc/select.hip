@@ -360,6 +360,8 @@ __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_kernel(
   T v[FILTER_CHUNKS];
 #pragma unroll
   for (int j = 0; j < FILTER_CHUNKS; j++) v[j] = __builtin_nontemporal_load(in + min(wrow + j * 64, rows - 1));
+  // the wave's 32 validity words in one coalesced load: lane j holds the word of chunk j
+  const uint64_t vw = HASV ? validity[min(wword + (lane & (FILTER_CHUNKS - 1)), nw - 1)] : ~0ull;
   FT(0);
   uint64_t mine = 0; // lane j keeps the mask word of chunk j
   uint32_t wave_cnt = 0;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_kernel(
   for (int j = 0; j < FILTER_CHUNKS; j++) {
     bool keep = (wrow + j * 64 < rows) && cmp_op<OP>(CmpKey<T>::key(v[j]), kk);
     uint64_t b = __ballot(keep);
-    if (HASV) b &= validity[min(wword + j, nw - 1)]; // wave-uniform load (rows past the end are not kept)
+    if (HASV) b &= readlane_u64(vw, j); // rows past the end are not kept (keep is false there)
     mine = (lane == j) ? b : mine;
     wave_cnt += (uint32_t)__popcll(b);
   }
@@ -400,17 +402,20 @@ __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_kernel(
 // only guaranteed to be running if all G blocks are resident: the host sizes G by occupancy,
 // the look-back spin is bounded, and on a timeout the launch is redone by the ticketed
 // one-tile-per-block kernel above.
-template <class T>
-__device__ __forceinline__ void filter_load_tile(const T *__restrict__ in, int64_t rows, int64_t tile,
-                                                 T (&v)[FILTER_CHUNKS]) {
+template <class T, bool HASV>
+__device__ __forceinline__ void filter_load_tile(const T *__restrict__ in, const uint64_t *__restrict__ validity,
+                                                 int64_t rows, int64_t tile, T (&v)[FILTER_CHUNKS], uint64_t &vw) {
   const int64_t wrow = tile * FILTER_TILE_ROWS + (int64_t)wave_id() * (FILTER_CHUNKS * 64) + lane_id();
 #pragma unroll
   for (int j = 0; j < FILTER_CHUNKS; j++) v[j] = __builtin_nontemporal_load(in + min(wrow + j * 64, rows - 1));
+  // the wave's 32 validity words in one coalesced load: lane j holds the word of chunk j
+  const int64_t wword = (tile * FILTER_WAVES + wave_id()) * FILTER_CHUNKS;
+  vw = HASV ? validity[min(wword + (lane_id() & (FILTER_CHUNKS - 1)), ((rows + 63) >> 6) - 1)] : ~0ull;
 }
 
 template <class T, int OP, bool HASV, class KK>
-__device__ __forceinline__ void filter_tile(const T (&v)[FILTER_CHUNKS], KK kk,
-                                            const uint64_t *__restrict__ validity, int64_t rows, int64_t tile,
+__device__ __forceinline__ void filter_tile(const T (&v)[FILTER_CHUNKS], const uint64_t vw, KK kk, int64_t rows,
+                                            int64_t tile,
                                             T *__restrict__ out, uint64_t *__restrict__ sel_bits,
                                             uint32_t *s_wave, const uint64_t *s_excl) {
   const int lane = lane_id(), w = wave_id();
@@ -423,7 +428,7 @@ __device__ __forceinline__ void filter_tile(const T (&v)[FILTER_CHUNKS], KK kk,
   for (int j = 0; j < FILTER_CHUNKS; j++) {
     bool keep = (wrow + j * 64 < rows) && cmp_op<OP>(CmpKey<T>::key(v[j]), kk);
     uint64_t b = __ballot(keep);
-    if (HASV) b &= validity[min(wword + j, nw - 1)];
+    if (HASV) b &= readlane_u64(vw, j);
     mine = (lane == j) ? b : mine;
     wave_cnt += (uint32_t)__popcll(b);
   }
@@ -475,16 +480,17 @@ __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_persistent_kern
   // ---- worker waves
   const auto kk = CmpKey<T>::key(k);
   T va[FILTER_CHUNKS], vb[FILTER_CHUNKS];
-  filter_load_tile(in, rows, tile, va);
+  uint64_t wa, wb;
+  filter_load_tile<T, HASV>(in, validity, rows, tile, va, wa);
   while (true) {
     int64_t nt = tile + G;
-    filter_load_tile(in, rows, min(nt, num_tiles - 1), vb);
-    filter_tile<T, OP, HASV>(va, kk, validity, rows, tile, out, sel_bits, s_wave[0], &s_excl[0]);
+    filter_load_tile<T, HASV>(in, validity, rows, min(nt, num_tiles - 1), vb, wb);
+    filter_tile<T, OP, HASV>(va, wa, kk, rows, tile, out, sel_bits, s_wave[0], &s_excl[0]);
     if (nt >= num_tiles) break;
     tile = nt;
     nt = tile + G;
-    filter_load_tile(in, rows, min(nt, num_tiles - 1), va);
-    filter_tile<T, OP, HASV>(vb, kk, validity, rows, tile, out, sel_bits, s_wave[1], &s_excl[1]);
+    filter_load_tile<T, HASV>(in, validity, rows, min(nt, num_tiles - 1), va, wa);
+    filter_tile<T, OP, HASV>(vb, wb, kk, rows, tile, out, sel_bits, s_wave[1], &s_excl[1]);
     if (nt >= num_tiles) break;
     tile = nt;
   }

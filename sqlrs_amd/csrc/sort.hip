@@ -3,7 +3,7 @@
 // Used by OrderExecutor (order.rs:45 lexsort_to_indices), by the agg finalize (groups in
 // first-seen order, hash_agg.rs:98,132) and by the join build when a key repeats (rows of one
 // key in insertion order, hash_join.rs:172-177).  Per pass: per-tile digit histogram ->
-// exclusive scan over (digit, tile) -> stable scatter.  HBM traffic per pass:
+// exclusive scan over (digit, tile) -> stable LDS-staged scatter.  HBM traffic per pass:
 // hist reads 8 B/key, scatter reads 12 B and writes 12 B per key.
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -11,76 +11,124 @@
 
 namespace sq {
 
-constexpr int RS_ITEMS = 16;
-constexpr int RS_TILE = BLOCK * RS_ITEMS; // 4096 keys per block
+// Tile = 512 threads x RS_ITEMS rows.  Row order inside a tile is (wave, chunk, lane): wave w owns
+// the RS_ITEMS * 64 consecutive rows [w * RS_ITEMS * 64, ...), chunk j of it is 64 consecutive rows.
+constexpr int RS_WG = 512;
+constexpr int RS_WAVES = RS_WG / 64;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_WG * RS_ITEMS; // 4096 keys per block: 56 KiB of LDS, two blocks per CU
 
-__global__ __launch_bounds__(BLOCK) void rs_hist_kernel(const uint64_t *__restrict__ keys, int64_t n,
+__global__ __launch_bounds__(RS_WG) void rs_hist_kernel(const uint64_t *__restrict__ keys, int64_t n,
                                                         int shift, int64_t nblocks,
                                                         uint32_t *__restrict__ hist) {
   __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
+  if (threadIdx.x < 256) h[threadIdx.x] = 0;
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE + threadIdx.x;
+  uint64_t k[RS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) k[r] = __builtin_nontemporal_load(keys + min(base + r * RS_WG, n - 1));
   __syncthreads();
-  int64_t base = (int64_t)blockIdx.x * RS_TILE;
-#pragma unroll 4
-  for (int r = 0; r < RS_ITEMS; r++) {
-    int64_t i = base + r * BLOCK + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1u);
-  }
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++)
+    if (base + r * RS_WG < n) atomicAdd(&h[(k[r] >> shift) & 255], 1u);
   __syncthreads();
-  hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+  if (threadIdx.x < 256) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ __launch_bounds__(BLOCK) void rs_scatter_kernel(
+// Stable scatter of one tile, staged through LDS so that every digit's rows leave as one
+// contiguous run (direct per-row stores ran at the random-store rate: 0.8 TB/s per pass).
+//   1. per wave, chunk by chunk: lanes with the same digit find each other with 8 ballots; the
+//      first of them bumps the wave's own counter of that digit (no atomics: one writer per digit
+//      and chunk, chunks in order) -> rank of the row among the wave's rows of that digit
+//   2. per digit: exclusive prefix of the 8 wave counters, exclusive scan over the 256 digits
+//   3. rows are written to their tile-local position in LDS (digit-major, row order inside a digit)
+//   4. the tile is copied out; position p of digit d goes to offsets[d][tile] + (p - start[d])
+__global__ __launch_bounds__(RS_WG) void rs_scatter_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t n, int shift,
     int64_t nblocks, const uint32_t *__restrict__ offsets, uint64_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out) {
-  __shared__ uint32_t base[256];
-  __shared__ uint32_t wcnt[WAVES_PER_BLOCK][256];
-  base[threadIdx.x] = offsets[(int64_t)threadIdx.x * nblocks + blockIdx.x];
-#pragma unroll
-  for (int w = 0; w < WAVES_PER_BLOCK; w++) wcnt[w][threadIdx.x] = 0;
-  __syncthreads();
-  const int w = wave_id();
+  __shared__ uint64_t skey[RS_TILE];
+  __shared__ uint32_t sval[RS_TILE];
+  __shared__ uint32_t wcnt[RS_WAVES][256];
+  __shared__ uint32_t dstart[256];
+  __shared__ int64_t gbase[256];
+  __shared__ uint32_t s_wsum[4];
+  const int w = wave_id(), lane = lane_id();
   const int64_t tbase = (int64_t)blockIdx.x * RS_TILE;
-  for (int r = 0; r < RS_ITEMS; r++) {
-    int64_t i = tbase + r * BLOCK + threadIdx.x;
-    bool valid = i < n;
-    uint64_t k = valid ? keys[i] : 0;
-    uint32_t v = valid ? vals[i] : 0;
-    uint32_t d = (uint32_t)(k >> shift) & 255u;
-    // lanes of this wave holding the same digit
+  const int64_t wrow = tbase + (int64_t)w * (RS_ITEMS * 64) + lane;
+  uint64_t k[RS_ITEMS];
+  uint32_t v[RS_ITEMS];
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const int64_t i = min(wrow + j * 64, n - 1);
+    k[j] = __builtin_nontemporal_load(keys + i);
+    v[j] = __builtin_nontemporal_load(vals + i);
+  }
+  uint32_t goff = threadIdx.x < 256 ? offsets[(int64_t)threadIdx.x * nblocks + blockIdx.x] : 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) wcnt[w][lane + 64 * q] = 0;
+  uint32_t rnk[RS_ITEMS];
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const bool valid = wrow + j * 64 < n;
+    const uint32_t d = (uint32_t)(k[j] >> shift) & 255u;
     uint64_t peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-      bool bit = (d >> b) & 1;
-      uint64_t bm = __ballot(bit);
+      const bool bit = (d >> b) & 1;
+      const uint64_t bm = __ballot(bit);
       peers &= bit ? bm : ~bm;
     }
-    uint32_t rank = (uint32_t)mbcnt(peers);
-    uint32_t cnt = (uint32_t)__popcll(peers);
-    bool leader = valid && rank == 0;
-    if (leader) wcnt[w][d] = cnt;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-    if (valid) {
+    const uint32_t r = (uint32_t)mbcnt(peers);
+    uint32_t old = 0;
+    if (valid && r == 0) { // first lane of the digit in this chunk
+      old = wcnt[w][d];
+      wcnt[w][d] = old + (uint32_t)__popcll(peers);
+    }
+    old = (uint32_t)__shfl((int)old, valid ? __builtin_ctzll(peers) : 0, 64);
+    rnk[j] = old + r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) { // digit d = threadIdx.x: wave counters -> exclusive prefix over the waves
+    uint32_t acc = 0;
 #pragma unroll
-      for (int q = 0; q < WAVES_PER_BLOCK; q++) {
-        uint32_t c = wcnt[q][d];
-        before += (q < w) ? c : 0;
-        total += c;
-      }
+    for (int q = 0; q < RS_WAVES; q++) {
+      uint32_t c = wcnt[q][threadIdx.x];
+      wcnt[q][threadIdx.x] = acc;
+      acc += c;
     }
-    uint32_t pos = valid ? base[d] + before + rank : 0;
-    __syncthreads();
-    if (leader) {
-      wcnt[w][d] = 0;
-      if (before == 0) base[d] += total; // the lowest wave holding this digit advances it
+    uint32_t inc = wave_iscan_u32(acc);
+    if (lane == 63) s_wsum[w] = inc;
+    dstart[threadIdx.x] = inc - acc; // wave-local for now
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    uint32_t wb = 0;
+    for (int q = 0; q < w; q++) wb += s_wsum[q];
+    uint32_t ds = dstart[threadIdx.x] + wb;
+    dstart[threadIdx.x] = ds;
+    gbase[threadIdx.x] = (int64_t)goff - (int64_t)ds;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    if (wrow + j * 64 >= n) continue;
+    const uint32_t d = (uint32_t)(k[j] >> shift) & 255u;
+    const uint32_t p = dstart[d] + wcnt[w][d] + rnk[j];
+    skey[p] = k[j];
+    sval[p] = v[j];
+  }
+  __syncthreads();
+  const uint32_t len = (uint32_t)min<int64_t>(RS_TILE, n - tbase);
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const uint32_t p = j * RS_WG + threadIdx.x;
+    if (p < len) {
+      const uint64_t kk = skey[p];
+      const int64_t g = gbase[(uint32_t)(kk >> shift) & 255u] + p;
+      keys_out[g] = kk;
+      vals_out[g] = sval[p];
     }
-    if (valid) {
-      keys_out[pos] = k;
-      vals_out[pos] = v;
-    }
-    __syncthreads();
   }
 }
 
@@ -96,12 +144,12 @@ void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int b
   uint64_t *ka = keys, *kb = k2->as<uint64_t>();
   uint32_t *va = vals, *vb = v2->as<uint32_t>();
   for (int shift = begin_bit; shift < end_bit; shift += 8) {
-    rs_hist_kernel<<<dim3((unsigned)nblocks), dim3(BLOCK), 0, ctx->stream>>>(ka, n, shift, nblocks,
+    rs_hist_kernel<<<dim3((unsigned)nblocks), dim3(RS_WG), 0, ctx->stream>>>(ka, n, shift, nblocks,
                                                                             hist->as<uint32_t>());
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(),
                        total->as<uint64_t>());
-    rs_scatter_kernel<<<dim3((unsigned)nblocks), dim3(BLOCK), 0, ctx->stream>>>(
+    rs_scatter_kernel<<<dim3((unsigned)nblocks), dim3(RS_WG), 0, ctx->stream>>>(
         ka, va, n, shift, nblocks, offs->as<uint32_t>(), kb, vb);
     SQ_HIP(hipGetLastError());
     std::swap(ka, kb);
