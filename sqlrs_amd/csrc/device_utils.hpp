@@ -60,6 +60,17 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
   for (int m = 32; m >= 1; m >>= 1) v = max(v, shfl_xor_u64(v, m));
   return v;
 }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+    v += __longlong_as_double((long long)shfl_xor_u64((uint64_t)__double_as_longlong(v), m));
+  return v;
+}
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
