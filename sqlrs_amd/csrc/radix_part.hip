@@ -323,15 +323,34 @@ __global__ void rp_bucket_starts_kernel(const uint32_t *__restrict__ offs,
   bstart[b] = seg_tiles[s] ? offs[seg_mat[s] + (int64_t)d * seg_tiles[s]] : (uint32_t)seg_start[s + 1];
 }
 
+// one block per segment: tile i of segment s
+__global__ void rp_make_tiles_kernel(const int64_t *__restrict__ seg_start, const int64_t *__restrict__ seg_mat,
+                                     const uint32_t *__restrict__ seg_tiles, const uint32_t *__restrict__ seg_tile_base,
+                                     int rp_tile, Tile *__restrict__ tiles) {
+  const uint32_t s = blockIdx.x, nt = seg_tiles[s], base = seg_tile_base[s];
+  const int64_t start = seg_start[s], end = seg_start[s + 1], mat = seg_mat[s];
+  for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) {
+    Tile t;
+    t.start = start + (int64_t)i * rp_tile;
+    t.len = (uint32_t)min((int64_t)rp_tile, end - t.start);
+    t.stride = nt;
+    t.mat = mat + i;
+    tiles[base + i] = t;
+  }
+}
+
 namespace {
 
 struct Level {
-  std::vector<Tile> tiles;
   std::vector<int64_t> seg_mat, seg_start; // per segment (seg_start has nseg + 1 entries)
-  std::vector<uint32_t> seg_tiles;
+  std::vector<uint32_t> seg_tiles, seg_tile_base;
   int64_t mat_entries = 0;
+  uint32_t num_tiles = 0;
 };
 
+// per-segment geometry only (<= 513 entries); the Tile descriptors themselves are filled on the
+// device (rp_make_tiles_kernel): building and uploading 81 K of them on the host left the GPU
+// idle for 0.2 ms per level
 Level plan_level(const std::vector<int64_t> &seg_start, uint32_t digits, int RP_TILE) {
   Level L;
   L.seg_start = seg_start;
@@ -341,14 +360,8 @@ Level plan_level(const std::vector<int64_t> &seg_start, uint32_t digits, int RP_
     uint32_t nt = (uint32_t)ceil_div(len, RP_TILE);
     L.seg_mat.push_back(L.mat_entries);
     L.seg_tiles.push_back(nt);
-    for (uint32_t i = 0; i < nt; i++) {
-      Tile t;
-      t.start = seg_start[s] + (int64_t)i * RP_TILE;
-      t.len = (uint32_t)std::min<int64_t>(RP_TILE, seg_start[s + 1] - t.start);
-      t.stride = nt;
-      t.mat = L.mat_entries + i;
-      L.tiles.push_back(t);
-    }
+    L.seg_tile_base.push_back(L.num_tiles);
+    L.num_tiles += nt;
     L.mat_entries += (int64_t)nt * digits;
   }
   return L;
@@ -405,11 +418,19 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   auto run_level = [&](int level, uint32_t digits, const std::vector<int64_t> &seg_start, const RpIn &rin,
                        const RpOut &rout, BufP *offs_out, Level *plan_out) {
     Level L = plan_level(seg_start, digits, RP_TILE);
-    BufP tiles = upload(ctx, L.tiles);
+    BufP tiles = ctx->alloc(sizeof(Tile) * (size_t)std::max<uint32_t>(L.num_tiles, 1));
+    {
+      BufP ss = upload(ctx, L.seg_start), sm = upload(ctx, L.seg_mat), st = upload(ctx, L.seg_tiles),
+           sb = upload(ctx, L.seg_tile_base);
+      rp_make_tiles_kernel<<<dim3((unsigned)L.seg_tiles.size()), dim3(256), 0, ctx->stream>>>(
+          (const int64_t *)ss->p, (const int64_t *)sm->p, (const uint32_t *)st->p, (const uint32_t *)sb->p,
+          RP_TILE, (Tile *)tiles->p);
+      SQ_HIP(hipGetLastError());
+    }
     BufP mat = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
     BufP offs = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
     BufP total = ctx->alloc(8);
-    unsigned nt = (unsigned)L.tiles.size();
+    unsigned nt = L.num_tiles;
     {
       ProfScope ps(ctx, in.build_side ? "rp_hist_build" : "rp_hist");
 #define SQ_RH1(R, PL) rp_hist_kernel<512, R, PL><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, (const Tile *)tiles->p, P, p2_bits, level, digits, mat->as<uint32_t>(), level == 1 ? KeyPack() : kp)
@@ -476,7 +497,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       }
 #endif
     }
-    ctx->sync(); // `L.tiles` host vector was the source of an async upload
+    ctx->sync(); // the host vectors of `L` were the source of async uploads
     *offs_out = offs;
     *plan_out = std::move(L);
   };
