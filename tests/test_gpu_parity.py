@@ -470,3 +470,115 @@ def test_hash_agg_partition_route_with_forced_table_overflow(scale):
                         "-k", "(partition_route or mixed_routes or join_agg) and not forced"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------- code paths added with the round-1 kernel rework --
+@pytest.mark.parametrize("keys_kind", ["negative", "offset_2p40", "with_minus_one", "extremes", "wide_random"])
+@pytest.mark.parametrize("aggs_kind", ["count_sum_f64", "sum_i64_count", "min_max_f64", "min_i64", "count", "max_i64_generic3"])
+def test_hash_agg_partition_route_packed_and_specialised(hip, oracle, keys_kind, aggs_kind):
+    """No NULLs + one value column: (key,row) packing when the key range allows it, and the
+    compile-time accumulator signatures of lds_agg_kernel; key sets chosen around the packing
+    conditions (negative keys, large offsets, the key whose bit pattern is the LDS EMPTY marker,
+    INT64 extremes = range too wide to pack, random 64-bit keys)."""
+    n = 2_150_000
+    rng = np.random.default_rng(hash((keys_kind, aggs_kind)) % (2**32))
+    if keys_kind == "negative":
+        keys = rng.integers(-40_000, 40_000, n, dtype=np.int64)
+    elif keys_kind == "offset_2p40":
+        keys = (1 << 40) + rng.integers(0, 200_000, n, dtype=np.int64) * 3
+    elif keys_kind == "with_minus_one":
+        keys = rng.integers(-3, 5_000, n, dtype=np.int64)  # -1 == ~0ull, the EMPTY marker
+    elif keys_kind == "extremes":
+        keys = rng.integers(0, 1000, n, dtype=np.int64)
+        keys[rng.random(n) < 0.01] = np.iinfo(np.int64).min
+        keys[rng.random(n) < 0.01] = np.iinfo(np.int64).max
+    else:
+        keys = rng.integers(np.iinfo(np.int64).min, np.iinfo(np.int64).max, 60_000, dtype=np.int64)[rng.integers(0, 60_000, n)]
+    vi = rng.integers(-10**6, 10**6, n, dtype=np.int64)
+    vf = rng.random(n) * 2 - 1
+    if aggs_kind == "count_sum_f64":
+        vals, aggs, fl = vf, [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64)], {2}
+    elif aggs_kind == "sum_i64_count":
+        vals, aggs, fl = vi, [AggFunc("sum", InputRef(1), abi.INT64), AggFunc("count", InputRef(1), abi.INT64)], set()
+    elif aggs_kind == "min_max_f64":
+        vals, aggs, fl = vf, [AggFunc("min", InputRef(1), abi.FLOAT64), AggFunc("max", InputRef(1), abi.FLOAT64)], set()
+    elif aggs_kind == "min_i64":
+        vals, aggs, fl = vi, [AggFunc("min", InputRef(1), abi.INT64)], set()
+    elif aggs_kind == "count":
+        vals, aggs, fl = vf, [AggFunc("count", InputRef(1), abi.INT64)], set()
+    else:  # three accumulators: the interpreted (generic) kernel on the packed path
+        vals, aggs, fl = vi, [AggFunc("max", InputRef(1), abi.INT64), AggFunc("count", InputRef(1), abi.INT64),
+                              AggFunc("sum", InputRef(1), abi.INT64)], set()
+    b = pa.RecordBatch.from_arrays([pa.array(keys), pa.array(vals)], names=["k", "v"])
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
+    assert_same(got, exp, float_cols=fl)
+
+
+@pytest.mark.parametrize("n", [16_383, 16_384, 16_385, 5 * 16_384 + 17, 300_001])
+@pytest.mark.parametrize("nulls", [0.0, 0.1])
+def test_filter_large_tiles(hip, oracle, n, nulls):
+    """filter_cmp_const: 16384-row tiles (8 worker waves + scan wave), ragged ends, validity words."""
+    rng = np.random.default_rng(n)
+    b = batch(rng, n, [("f64", nulls, 0, 1), ("i64", 0.05, -5, 5), ("i32", 0.0, 0, 100)])
+    for e in (InputRef(0) > Constant(0.5, abi.FLOAT64), InputRef(0) <= Constant(0.01, abi.FLOAT64),
+              BinaryOp("!=", InputRef(2), Constant(7, abi.INT32))):
+        got = rows_of(FilterExecutor(hip, e, [b]).execute())
+        exp = rows_of(FilterExecutor(oracle, e, [b]).execute())
+        assert_same(got, exp)
+
+
+@pytest.mark.parametrize("jt", ["inner", "left"])
+@pytest.mark.parametrize("np_", [16_383, 16_385, 70_000])
+@pytest.mark.parametrize("build", ["dense_unique", "dense_unique_null", "dense_dup", "dense_two_nulls"])
+def test_hash_join_direct_address_table(hip, oracle, jt, np_, build):
+    """Build keys in a small integer range: direct-address table when unique (incl. one NULL
+    build key, NULL = NULL matches), hash table when the verify pass finds a duplicate (a repeated
+    key or two NULL keys); probe through the 16384-row tile kernel."""
+    rng = np.random.default_rng(np_ + len(build))
+    nb = 3000
+    keys = rng.permutation(4000)[:nb].astype(np.int64) - 500
+    mask = np.zeros(nb, dtype=bool)
+    if build == "dense_dup":
+        keys[17] = keys[2900]
+    if build in ("dense_unique_null", "dense_two_nulls"):
+        mask[5] = True
+    if build == "dense_two_nulls":
+        mask[77] = True
+    lb = pa.RecordBatch.from_arrays([pa.array(keys, mask=mask), pa.array(rng.random(nb))], names=["k", "x"])
+    pk = rng.integers(-600, 3600, np_, dtype=np.int64)
+    pmask = rng.random(np_) < 0.03
+    rb = pa.RecordBatch.from_arrays([pa.array(rng.random(np_)), pa.array(pk, mask=pmask)], names=["v", "k"])
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    sch = join_schema(lb, rb)
+    got = list(HashJoinExecutor(hip, [lb], [rb], jt, cond, sch, lb.num_columns).execute())
+    exp = list(HashJoinExecutor(oracle, [lb], [rb], jt, cond, sch, lb.num_columns).execute())
+    assert [b.num_rows for b in got] == [b.num_rows for b in exp]
+    assert_same(rows_of(got), rows_of(exp))
+
+
+@pytest.mark.parametrize("kind", ["i64_31bit", "i64_negative", "f64", "i64_const"])
+@pytest.mark.parametrize("asc", [True, False])
+def test_order_large_with_ties(hip, oracle, kind, asc):
+    """300k rows: radix passes over constant bytes are skipped, the leading key column is rebuilt
+    from the sorted keys, ties keep their input order (stable, like the oracle)."""
+    n = 300_007
+    rng = np.random.default_rng(5)
+    if kind == "i64_31bit":
+        k = pa.array(rng.integers(0, 1 << 31, n, dtype=np.int64) & ~0xff)  # low byte constant too
+    elif kind == "i64_negative":
+        k = pa.array(rng.integers(-1000, 1000, n, dtype=np.int64))
+    elif kind == "f64":
+        v = np.round(rng.random(n) * 200 - 100, 1)
+        v[::97] = -0.0
+        v[::89] = 0.0
+        k = pa.array(v)
+    else:
+        k = pa.array(np.full(n, 42, dtype=np.int64))
+    b = pa.RecordBatch.from_arrays([k, pa.array(np.arange(n)), pa.array(rng.random(n))], names=["k", "i", "v"])
+    ob = [OrderBy(InputRef(0), asc)]
+    got = rows_of(OrderExecutor(hip, ob, [b.slice(0, 100_000), b.slice(100_000)]).execute())
+    exp = rows_of(OrderExecutor(oracle, ob, [b.slice(0, 100_000), b.slice(100_000)]).execute())
+    assert [math.copysign(1, r[0]) if isinstance(r[0], float) else 0 for r in got] == \
+           [math.copysign(1, r[0]) if isinstance(r[0], float) else 0 for r in exp]  # -0.0 vs 0.0 kept apart
+    assert_same(got, exp)
