@@ -77,9 +77,12 @@ def device_batch(abi, tensors, dtypes):
 class Pipeline:
     """Filter -> HashJoin -> HashAgg driven through the C ABI on device-resident batches."""
 
-    def __init__(self, be, abi, threshold, fused=True):
+    def __init__(self, be, abi, threshold, fused=True, partial=False):
         from sqlrs_amd.expr import AggFunc, Constant, InputRef, JoinCondition
         self.be, self.abi, self.fused, self.fused_batches = be, abi, fused, 0
+        # partial = the groups are exchanged and merged again (multi-GPU broadcast strategy): their
+        # order is irrelevant, so the first-seen ordering of the local result is skipped
+        self.partial = partial
         self.filter_expr = (InputRef(1) > Constant(threshold, abi.FLOAT64)).pack()
         self.cond = JoinCondition([(InputRef(0), InputRef(0))])
         self.lk, self._k1 = abi.pack_exprs([InputRef(0)])
@@ -107,6 +110,8 @@ class Pipeline:
             ja = C.c_void_p()
             be.check(be.fn("join_agg_create")(be.ctx, 1, self.lk, self.rk, 1, 2, self.right_dtypes, 1, self.gb, 2,
                                               self.aggs, C.byref(ja)))
+            if self.partial:
+                be.check(be.fn("join_agg_set_group_order")(ja, abi.GROUP_ORDER_ANY))
             be.check(be.fn("join_agg_build_push")(ja, dim_b.ptr))
             be.check(be.fn("join_agg_build_finish")(ja))
             be.check(be.fn("join_agg_probe_push")(ja, filtered.ptr))
@@ -128,6 +133,8 @@ class Pipeline:
         be.fn("hash_join_destroy")(j)
         a = C.c_void_p()
         be.check(be.fn("hash_agg_create")(be.ctx, 1, self.gb, 2, self.aggs, C.byref(a)))
+        if self.partial:
+            be.check(be.fn("hash_agg_set_group_order")(a, abi.GROUP_ORDER_ANY))
         be.check(be.fn("hash_agg_push")(a, joined.ptr))
         joined.release()
         ao = C.POINTER(abi.Batch)()
@@ -228,6 +235,7 @@ def main():
     strategy = args.exchange
     if strategy == "auto":
         strategy = "broadcast" if n_dim_total * 16 <= n_fact_total else "partition"
+    pipe.partial = world > 1 and strategy == "broadcast"
     dim_sizes = [D_shard(n_dim_total, r, world) for r in range(world)]
     merge_gb, _mk = abi.pack_exprs([InputRef(0)])
     _mkeep = []

@@ -238,6 +238,13 @@ int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in);
 /* [ref: hash_agg.rs:124-149]; with no pushed batch the reference panics (:125):
  * here that is SQLRS_ERR_INTERNAL. */
 int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out);
+/* Group order of the output batch.  SQLRS_GROUP_ORDER_FIRST_SEEN (default) is the reference's
+ * (hash_agg.rs:98,132).  SQLRS_GROUP_ORDER_ANY is for PARTIAL aggregates that are exchanged and
+ * merged again (multi-GPU): the sort of the groups by first row and the gathers
+ * that follow it are skipped; the set of groups and every value are unchanged. */
+#define SQLRS_GROUP_ORDER_FIRST_SEEN 0
+#define SQLRS_GROUP_ORDER_ANY 1
+int sqlrs_hash_agg_set_group_order(sqlrs_hash_agg_t *a, int group_order);
 void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *a);
 
 /* ------------------------------------------------------------------ Order -- */
@@ -269,6 +276,7 @@ int sqlrs_join_agg_build_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *left);
 int sqlrs_join_agg_build_finish(sqlrs_join_agg_t *ja);
 int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right);
 int sqlrs_join_agg_finish(sqlrs_join_agg_t *ja, int out_mem, sqlrs_batch_t **out);
+int sqlrs_join_agg_set_group_order(sqlrs_join_agg_t *ja, int group_order); /* see sqlrs_hash_agg_set_group_order */
 /* probe batches that took the non-materialising route so far */
 int64_t sqlrs_join_agg_fused_batches(const sqlrs_join_agg_t *ja);
 void sqlrs_join_agg_destroy(sqlrs_join_agg_t *ja);

@@ -19,6 +19,7 @@ import pyarrow as pa
 OK, ERR_ARROW, ERR_INTERNAL, ERR_STORAGE, ERR_DEVICE = 0, 1, 2, 3, 4
 NULLTYPE, INT32, INT64, FLOAT64, BOOLEAN, UTF8, UINT32, UINT64 = range(8)
 MEM_HOST, MEM_DEVICE = 0, 1
+GROUP_ORDER_FIRST_SEEN, GROUP_ORDER_ANY = 0, 1
 JOIN_INNER, JOIN_LEFT, JOIN_RIGHT, JOIN_FULL = 0, 1, 2, 3
 AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX = 0, 1, 2, 3
 
@@ -306,6 +307,8 @@ class Backend:
             "join_agg_probe_push": (i, [vp, pb]),
             "join_agg_finish": (i, [vp, i, ppb]),
             "join_agg_fused_batches": (C.c_int64, [vp]),
+            "join_agg_set_group_order": (i, [vp, i]),
+            "hash_agg_set_group_order": (i, [vp, i]),
             "join_agg_destroy": (None, [vp]),
             "timer_create": (i, [vp, pvp]),
             "timer_start": (i, [vp]),

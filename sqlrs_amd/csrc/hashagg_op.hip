@@ -64,6 +64,7 @@ struct sqlrs_hash_agg {
   std::vector<AggSpec> aggs;
   AggState st;
   bool saw_batch = false, in_order = true;
+  bool any_order = false; // SQLRS_GROUP_ORDER_ANY: partial aggregates, no first-seen ordering at finish
   bool strong_keys = false; // internal de-dup stage of a DISTINCT aggregate
   int64_t rows_seen = 0;
   std::vector<int32_t> key_dtypes;
@@ -253,7 +254,7 @@ static DBatch emit_pending(sqlrs_hash_agg *a) {
     c.dtype = s.return_dtype;
     o.cols.push_back(c);
   }
-  if (G > 1) { // bucket order -> first-seen order (hash_agg.rs:98,132)
+  if (G > 1 && !a->any_order) { // bucket order -> first-seen order (hash_agg.rs:98,132)
     ProfScope ps(ctx, "agg_order_groups");
     BufP keys = ctx->alloc(8 * (size_t)G), perm = ctx->alloc(4 * (size_t)G);
     SQ_HIP(hipMemcpyAsync(keys->p, po.row_ids->p, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
@@ -664,7 +665,7 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
       c.dtype = s.return_dtype;
       o.cols.push_back(c);
     }
-    if (!a->in_order && G > 1) {
+    if (!a->in_order && G > 1 && !a->any_order) {
       // groups were discovered out of row order (partition route): order by first row
       ProfScope ps(ctx, "agg_order_groups");
       agg_refresh_gfirst(ctx, a->st);
@@ -678,6 +679,16 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
     }
     place_aggregate_columns(a, o);
     *out = emit_batch(ctx, std::move(o), out_mem);
+  });
+}
+
+int sqlrs_hash_agg_set_group_order(sqlrs_hash_agg_t *a, int group_order) {
+  return guard(a->ctx, [&] {
+    if (group_order != SQLRS_GROUP_ORDER_FIRST_SEEN && group_order != SQLRS_GROUP_ORDER_ANY)
+      fail(SQLRS_ERR_INTERNAL, "unknown group order");
+    if (!a->distinct_aggs.empty() && group_order == SQLRS_GROUP_ORDER_ANY)
+      fail(SQLRS_ERR_INTERNAL, "DISTINCT aggregates line up by first-seen order: SQLRS_GROUP_ORDER_ANY not supported");
+    a->any_order = group_order == SQLRS_GROUP_ORDER_ANY;
   });
 }
 
@@ -800,6 +811,9 @@ int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) 
 
 int sqlrs_join_agg_finish(sqlrs_join_agg_t *ja, int out_mem, sqlrs_batch_t **out) {
   return sqlrs_hash_agg_finish(ja->agg, out_mem, out);
+}
+int sqlrs_join_agg_set_group_order(sqlrs_join_agg_t *ja, int group_order) {
+  return sqlrs_hash_agg_set_group_order(ja->agg, group_order);
 }
 // number of probe batches that took the fused route (diagnostics / tests)
 int64_t sqlrs_join_agg_fused_batches(const sqlrs_join_agg_t *ja) { return ja->fused_batches; }

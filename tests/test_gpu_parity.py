@@ -582,3 +582,34 @@ def test_order_large_with_ties(hip, oracle, kind, asc):
     assert [math.copysign(1, r[0]) if isinstance(r[0], float) else 0 for r in got] == \
            [math.copysign(1, r[0]) if isinstance(r[0], float) else 0 for r in exp]  # -0.0 vs 0.0 kept apart
     assert_same(got, exp)
+
+
+def test_group_order_any_keeps_groups_and_values(hip, oracle):
+    """SQLRS_GROUP_ORDER_ANY (partial aggregates for the exchange): same groups, same values, only
+    the order is unspecified; DISTINCT aggregates refuse it."""
+    import ctypes as C
+    rng = np.random.default_rng(31)
+    n = 2_200_000
+    b = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 70_000, n, dtype=np.int64)), pa.array(rng.random(n))],
+                                   names=["k", "v"])
+    aggs = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64)]
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
+    keep = []
+    arr = (abi.AggFunc * 2)(*[a.abi_struct(keep) for a in aggs])
+    gb, _k = abi.pack_exprs([InputRef(0)])
+    a = C.c_void_p()
+    hip.check(hip.fn("hash_agg_create")(hip.ctx, 1, gb, 2, arr, C.byref(a)))
+    hip.check(hip.fn("hash_agg_set_group_order")(a, abi.GROUP_ORDER_ANY))
+    hb = abi.as_batch(b)
+    hip.check(hip.fn("hash_agg_push")(a, hb.ptr))
+    out = C.POINTER(abi.Batch)()
+    hip.check(hip.fn("hash_agg_finish")(a, abi.MEM_HOST, C.byref(out)))
+    got = rows_of([hip.wrap(out).to_arrow(["k", "c", "s"])])
+    hip.fn("hash_agg_destroy")(a)
+    assert len(got) == len(exp)
+    assert_same(sorted(got), sorted(exp), float_cols={2})
+    d = C.c_void_p()
+    darr = (abi.AggFunc * 1)(AggFunc("count", InputRef(1), abi.INT64, distinct=True).abi_struct(keep))
+    hip.check(hip.fn("hash_agg_create")(hip.ctx, 1, gb, 1, darr, C.byref(d)))
+    assert hip.fn("hash_agg_set_group_order")(d, abi.GROUP_ORDER_ANY) != 0
+    hip.fn("hash_agg_destroy")(d)
