@@ -382,9 +382,21 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // digits per level: one level up to 256 buckets, else P = d1 * 2^p2_bits
   uint32_t p2_bits = 0, d1 = std::max(1u, P_wanted);
   if (P_wanted > 512) { // one level handles up to 512 digits (runs of >= 8 rows per tile)
-    p2_bits = 8;
-    d1 = (uint32_t)ceil_div(P_wanted, 256);
-    if (d1 > 256) return false;
+    // split the digits evenly between the two levels: 2^p2_bits second-level digits with
+    // 2^p2_bits >= sqrt(P) (runs get longer as a level's digit count drops)
+    static const int p2_env = [] { // tuning hook
+      const char *e = std::getenv("SQLRS_RP_P2BITS");
+      return e ? std::atoi(e) : 0;
+    }();
+    p2_bits = 5;
+    while (p2_bits < 8 && (1u << (2 * p2_bits)) < P_wanted) p2_bits++;
+    if (p2_env >= 4 && p2_env <= 9) p2_bits = (uint32_t)p2_env;
+    d1 = (uint32_t)ceil_div(P_wanted, 1u << p2_bits);
+    if (d1 > 512) {
+      p2_bits = 8;
+      d1 = (uint32_t)ceil_div(P_wanted, 256);
+    }
+    if (d1 > 256 && p2_bits == 8) return false;
   }
   const uint32_t P = d1 << p2_bits;
   const bool flags = in.key_validity || in.val_validity[0] || in.val_validity[1];
