@@ -27,6 +27,14 @@ struct AggSpec {
   bool track_nn = false; // nn maintained (COUNT always; others once a NULL input was seen)
   int32_t acc_dtype = 0; // dtype the accumulator works in
   int argcol = -1;       // index into the per-batch evaluated argument columns
+  // MIN/MAX over Utf8 (min_max.rs:21-29 min_string/max_string): the strings of every pushed batch
+  // and their rows' group ids are kept; finish ranks all strings once and reduces ranks per group
+  struct StrBatch {
+    DCol col;
+    BufP gid;
+    int64_t n;
+  };
+  std::vector<StrBatch> strs;
 };
 
 uint64_t acc_identity(const AggSpec &a) { return a.func == SQLRS_AGG_MIN ? ~0ull : 0ull; }
@@ -110,6 +118,7 @@ struct ArgView {
   const void *values = nullptr;
   const uint64_t *validity = nullptr;
   int32_t dtype = 0;
+  const DCol *col = nullptr;
 };
 
 // groups for `nk` (rows or pre-aggregated groups) + key values of the groups that are new
@@ -147,12 +156,87 @@ static void start_tracking(Ctx *ctx, AggSpec &s, int64_t G, int64_t nnew) {
 }
 
 // row route: accumulate the argument columns of n rows
-static void update_from_rows(sqlrs_hash_agg *a, const uint32_t *rg, const std::vector<ArgView> &args,
+// ---- MIN / MAX over Utf8 -----------------------------------------------------------------
+__global__ void rank_of_perm_kernel(const uint32_t *__restrict__ perm, int64_t n, uint32_t *__restrict__ rank) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) rank[perm[i]] = (uint32_t)i;
+}
+// best[g] = min or max over the group's non-NULL rows of (rank + 1); 0 / ~0 = no value yet
+__global__ void best_rank_kernel(const uint32_t *__restrict__ gid, const uint32_t *__restrict__ rank,
+                                 const uint64_t *__restrict__ validity, int64_t n, int is_min,
+                                 uint32_t *__restrict__ best) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (validity && !((validity[i >> 6] >> (i & 63)) & 1)) return;
+  if (is_min) atomicMin(&best[gid[i]], rank[i] + 1);
+  else atomicMax(&best[gid[i]], rank[i] + 1);
+}
+// winner row of every group (index into the concatenated strings) + whether the group has one
+__global__ void winner_row_kernel(const uint32_t *__restrict__ best, const uint32_t *__restrict__ perm, int64_t G,
+                                  int is_min, uint32_t *__restrict__ row, uint64_t *__restrict__ has) {
+  int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  uint32_t b = g < G ? best[g] : 0;
+  bool ok = g < G && b != (is_min ? 0xffffffffu : 0u);
+  if (g < G) row[g] = ok ? perm[b - 1] : 0;
+  uint64_t m = __ballot(ok);
+  if (lane_id() == 0 && g < G) has[g >> 6] = m;
+}
+
+static DCol finalize_utf8_minmax(Ctx *ctx, AggSpec &s, int64_t G) {
+  const int is_min = s.func == SQLRS_AGG_MIN;
+  int64_t G1 = std::max<int64_t>(G, 1);
+  // all retained strings as one column, their group ids as one array
+  std::vector<const DCol *> parts;
+  int64_t N = 0;
+  for (auto &sb : s.strs) {
+    parts.push_back(&sb.col);
+    N += sb.n;
+  }
+  if (parts.empty() || N == 0) return make_null_column(ctx, SQLRS_UTF8, G);
+  if (N > 0xfffffffell) fail(SQLRS_ERR_INTERNAL, "utf8 min/max: more than 2^32 rows");
+  DCol all = concat_columns(ctx, parts);
+  BufP gid = ctx->alloc(4 * (size_t)N);
+  size_t off = 0;
+  for (auto &sb : s.strs) {
+    if (sb.n) SQ_HIP(hipMemcpyAsync(gid->as<uint8_t>() + off, sb.gid->p, 4 * (size_t)sb.n, hipMemcpyDeviceToDevice, ctx->stream));
+    off += 4 * (size_t)sb.n;
+  }
+  const uint64_t *valid = (all.validity && all.null_count != 0) ? all.validity : nullptr;
+  BufP perm = ctx->alloc(4 * (size_t)N), keys = ctx->alloc(8 * (size_t)N), rank = ctx->alloc(4 * (size_t)N);
+  iota_u32(ctx, perm->as<uint32_t>(), N);
+  sort_perm_by_utf8(ctx, all, valid, 0, perm->as<uint32_t>(), keys->as<uint64_t>(), N);
+  dim3 b(256), gn((unsigned)ceil_div(N, 256));
+  rank_of_perm_kernel<<<gn, b, 0, ctx->stream>>>(perm->as<uint32_t>(), N, rank->as<uint32_t>());
+  BufP best = ctx->alloc(4 * (size_t)G1);
+  SQ_HIP(hipMemsetAsync(best->p, is_min ? 0xff : 0, 4 * (size_t)G1, ctx->stream));
+  best_rank_kernel<<<gn, b, 0, ctx->stream>>>(gid->as<uint32_t>(), rank->as<uint32_t>(), valid, N, is_min,
+                                               best->as<uint32_t>());
+  BufP row = ctx->alloc(4 * (size_t)G1), has = ctx->alloc_zero(bitmap_bytes(G1));
+  int64_t G64 = (int64_t)round_up((size_t)G1, 64);
+  winner_row_kernel<<<dim3((unsigned)ceil_div(G64, 256)), b, 0, ctx->stream>>>(
+      best->as<uint32_t>(), perm->as<uint32_t>(), G, is_min, row->as<uint32_t>(), has->as<uint64_t>());
+  SQ_HIP(hipGetLastError());
+  DCol out = gather_column(ctx, all, row->p, false, has->as<uint64_t>(), G);
+  out.dtype = SQLRS_UTF8;
+  return out;
+}
+
+static void update_from_rows(sqlrs_hash_agg *a, const BufP &rgbuf, const std::vector<ArgView> &args,
                              int64_t n, int64_t nnew) {
   Ctx *ctx = a->ctx;
   int64_t G = a->st.ngroups;
+  const uint32_t *rg = rgbuf->as<uint32_t>();
   for (AggSpec &s : a->aggs) {
     const ArgView &v = args[(size_t)s.argcol];
+    if (v.dtype == SQLRS_UTF8 && (s.func == SQLRS_AGG_MIN || s.func == SQLRS_AGG_MAX)) {
+      if (s.return_dtype != SQLRS_UTF8 || !v.col) fail(SQLRS_ERR_INTERNAL, "unsupported min_max scalar type");
+      AggSpec::StrBatch sb;
+      sb.col = concat_columns(ctx, {v.col}); // private copy: the caller's batch may go away
+      sb.gid = rgbuf;
+      sb.n = n;
+      s.strs.push_back(std::move(sb));
+      continue;
+    }
     if (s.func == SQLRS_AGG_COUNT) {
       s.nn.ensure(ctx, G, 0);
       agg_update_count(ctx, s.nn, rg, v.validity, nullptr, n);
@@ -401,6 +485,7 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
         x.values = c.values;
         x.validity = (c.validity && c.null_count != 0) ? c.validity : nullptr;
         x.dtype = c.dtype;
+        x.col = &c;
         v.push_back(x);
       }
       return v;
@@ -523,7 +608,7 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
             BufP rg2 = resolve_groups(a, ok_, rid->as<uint64_t>(), po.ov_rows->as<uint32_t>(), kcols, &nn2);
             for (DCol &c : sub_args)
               if (c.validity && c.null_count < 0) c.null_count = count_nulls(ctx, c);
-            update_from_rows(a, rg2->as<uint32_t>(), views_of(sub_args), m, nn2);
+            update_from_rows(a, rg2, views_of(sub_args), m, nn2);
           }
           done = true;
         }
@@ -535,7 +620,7 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
       flush_pending(a);
       int64_t nnew = 0;
       BufP row_gid = resolve_groups(a, nk, nullptr, nullptr, kcols, &nnew); // 3.2 (:85-110)
-      update_from_rows(a, row_gid->as<uint32_t>(), views_of(acols), n, nnew); // 4. (:113-121)
+      update_from_rows(a, row_gid, views_of(acols), n, nnew); // 4. (:113-121)
     }
     return true;
 }
@@ -657,6 +742,10 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
       if (s.func == SQLRS_AGG_COUNT) {
         s.nn.ensure(ctx, std::max<int64_t>(G, 1), 0);
         o.cols.push_back(agg_finalize_values(ctx, s.func, SQLRS_INT64, s.nn, nullptr, G));
+        continue;
+      }
+      if (!s.strs.empty() || s.return_dtype == SQLRS_UTF8) {
+        o.cols.push_back(finalize_utf8_minmax(ctx, s, G));
         continue;
       }
       int32_t dt = s.acc_dtype ? s.acc_dtype : s.return_dtype;

@@ -161,6 +161,35 @@ __global__ void sort_valid_key_kernel(const uint64_t *__restrict__ validity,
   keys[i] = (validity[r >> 6] >> (r & 63)) & 1; // NULL (0) first
 }
 
+
+// Stable sort of the rows `perm` refers to by the Utf8 column `c` (byte-wise lexicographic, like
+// arrow): LSD over the length and the strings' 8-byte big-endian chunks, chunks on which no two
+// keys differ skipped.  NULL rows tie (key 0).  `keys` is n-element scratch.
+void sort_perm_by_utf8(Ctx *ctx, const DCol &c, const uint64_t *valid, int desc, uint32_t *perm, uint64_t *keys,
+                       int64_t n) {
+  if (n <= 1) return;
+  dim3 b(256);
+  BufP mx = ctx->alloc_zero(8);
+  int64_t n64 = (int64_t)round_up((size_t)n, 64);
+  dim3 g64((unsigned)ceil_div(n64, 256));
+  utf8_maxlen_kernel<<<g64, b, 0, ctx->stream>>>(c.offsets, n, mx->as<unsigned int>());
+  SQ_HIP(hipGetLastError());
+  int max_len = (int)ctx->fetch_value(mx->as<unsigned int>());
+  int chunks = (max_len + 7) / 8;
+  BufP diff = ctx->alloc(16);
+  for (int ch = -1; ch < chunks; ch++) { // length first (least significant), then chunks
+    int chunk = ch < 0 ? -1 : chunks - 1 - ch; // last chunk -> first chunk
+    SQ_HIP(hipMemsetAsync(diff->p, 0, 16, ctx->stream));
+    utf8_chunk_key_kernel<<<g64, b, 0, ctx->stream>>>(c.v<uint8_t>(), c.offsets, valid, perm, n, chunk, desc, keys);
+    keys_diff_kernel<<<g64, b, 0, ctx->stream>>>(keys, n, diff->as<unsigned long long>());
+    SQ_HIP(hipGetLastError());
+    uint64_t d = ctx->fetch_value(diff->as<uint64_t>());
+    if (!d) continue; // every key equal in this chunk: nothing to sort
+    int lo = __builtin_ctzll(d) & ~7, hi = 64 - __builtin_clzll(d);
+    radix_sort_pairs(ctx, keys, perm, n, lo, hi);
+  }
+}
+
 } // namespace sq
 
 struct sqlrs_order {
@@ -252,26 +281,7 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
         sort_key_kernel<3><<<g, b, 0, ctx->stream>>>(c.values, valid, perm->as<uint32_t>(), n, desc, keys->as<uint64_t>());
         break;
       case SQLRS_UTF8: {
-        BufP mx = ctx->alloc_zero(8);
-        int64_t n64 = (int64_t)round_up((size_t)n, 64);
-        dim3 g64((unsigned)ceil_div(n64, 256));
-        utf8_maxlen_kernel<<<g64, b, 0, ctx->stream>>>(c.offsets, n, mx->as<unsigned int>());
-        SQ_HIP(hipGetLastError());
-        int max_len = (int)ctx->fetch_value(mx->as<unsigned int>());
-        int chunks = (max_len + 7) / 8;
-        BufP diff = ctx->alloc(16);
-        for (int ch = -1; ch < chunks; ch++) { // length first (least significant), then chunks
-          int chunk = ch < 0 ? -1 : chunks - 1 - ch; // last chunk -> first chunk
-          SQ_HIP(hipMemsetAsync(diff->p, 0, 16, ctx->stream));
-          utf8_chunk_key_kernel<<<g64, b, 0, ctx->stream>>>(c.v<uint8_t>(), c.offsets, valid, perm->as<uint32_t>(),
-                                                            n, chunk, desc, keys->as<uint64_t>());
-          keys_diff_kernel<<<g64, b, 0, ctx->stream>>>(keys->as<uint64_t>(), n, diff->as<unsigned long long>());
-          SQ_HIP(hipGetLastError());
-          uint64_t d = ctx->fetch_value(diff->as<uint64_t>());
-          if (!d) continue; // every key equal in this chunk: nothing to sort
-          int lo = __builtin_ctzll(d) & ~7, hi = 64 - __builtin_clzll(d);
-          radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), n, lo, hi);
-        }
+        sort_perm_by_utf8(ctx, c, valid, desc, perm->as<uint32_t>(), keys->as<uint64_t>(), n);
         bits = 0; // sorted above
         break;
       }

@@ -45,6 +45,9 @@ bool filter_fast_path(Ctx *ctx, const Expr &e, const std::function<const DCol &(
 DCol gather_column(Ctx *ctx, const DCol &src, const void *idx, bool idx_is_u64,
                    const uint64_t *idx_validity, int64_t n);
 DCol concat_columns(Ctx *ctx, const std::vector<const DCol *> &parts);
+// ops.hip: stable sort of the rows in `perm` by a Utf8 column (NULL rows tie); keys = n-element scratch
+void sort_perm_by_utf8(Ctx *ctx, const DCol &c, const uint64_t *valid, int desc, uint32_t *perm, uint64_t *keys,
+                       int64_t n);
 DCol materialize_scalar(Ctx *ctx, const DCol &c, int64_t rows);
 // number of clear validity bits among the first `rows` rows
 int64_t count_clear_bits(Ctx *ctx, const uint64_t *bits, int64_t rows);

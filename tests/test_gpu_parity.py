@@ -613,3 +613,20 @@ def test_group_order_any_keeps_groups_and_values(hip, oracle):
     hip.check(hip.fn("hash_agg_create")(hip.ctx, 1, gb, 1, darr, C.byref(d)))
     assert hip.fn("hash_agg_set_group_order")(d, abi.GROUP_ORDER_ANY) != 0
     hip.fn("hash_agg_destroy")(d)
+
+
+@pytest.mark.parametrize("n,groups,nulls", [(1, 1, 0.0), (50, 4, 0.3), (3000, 40, 0.1), (40_000, 3000, 0.05)])
+def test_hash_agg_min_max_utf8(hip, oracle, n, groups, nulls):
+    """MIN / MAX over Utf8 (min_max.rs:21-29): byte-wise lexicographic, NULLs skipped, all-NULL
+    group -> NULL; several batches, mixed with numeric aggregates."""
+    rng = np.random.default_rng(n)
+    keys = pa.array(rng.integers(0, groups, n, dtype=np.int64))
+    strs = _strings(rng, n, nulls)
+    nums = pa.array(rng.integers(-100, 100, n, dtype=np.int64))
+    b = pa.RecordBatch.from_arrays([keys, strs, nums], names=["k", "s", "x"])
+    bs = [b.slice(0, n // 3), b.slice(n // 3)] if n > 3 else [b]
+    aggs = [AggFunc("min", InputRef(1), abi.UTF8), AggFunc("count", InputRef(1), abi.INT64),
+            AggFunc("max", InputRef(1), abi.UTF8), AggFunc("sum", InputRef(2), abi.INT64)]
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], bs).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], bs).execute())
+    assert_same(got, exp)
