@@ -72,6 +72,16 @@ struct sqlrs_hash_agg {
   std::vector<AggSpec> aggs;
   AggState st;
   bool saw_batch = false, in_order = true;
+  // Batches wait here (evaluated key + argument columns, private copies) and are aggregated as ONE
+  // batch: HashAgg is a blocking operator, and pre-aggregating every pushed batch on its own means
+  // merging its groups into the global table with ~24 G atomics/s (4 batches of 5e7 rows with 1e7
+  // groups: 35 ms, against 7.7 ms for the same rows as one batch).
+  struct Staged {
+    std::vector<DCol> kcols, acols;
+    int64_t n = 0;
+  };
+  std::vector<Staged> staged;
+  int64_t staged_rows = 0;
   bool any_order = false; // SQLRS_GROUP_ORDER_ANY: partial aggregates, no first-seen ordering at finish
   bool strong_keys = false; // internal de-dup stage of a DISTINCT aggregate
   int64_t rows_seen = 0;
@@ -625,6 +635,45 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
     return true;
 }
 
+constexpr int64_t STAGE_DIRECT_ROWS = 1ll << 26; // a first batch this large is aggregated in place
+constexpr int64_t STAGE_FLUSH_ROWS = 1ll << 28;  // staged rows that trigger an aggregation before finish
+
+// a column the operator may keep after the call returns: scalars materialised, borrowed buffers copied
+static DCol own_column(Ctx *ctx, const DCol &c, int64_t n) {
+  DCol m = c.stride == 0 ? materialize_scalar(ctx, c, n) : c;
+  bool borrowed = (m.values && !m.own_values) || (m.validity && !m.own_validity) || (m.offsets && !m.own_offsets);
+  return borrowed ? concat_columns(ctx, {&m}) : m;
+}
+
+// aggregate everything that is staged as one batch (arrival order = row order)
+static void flush_staged(sqlrs_hash_agg *a) {
+  if (a->staged.empty()) return;
+  Ctx *ctx = a->ctx;
+  std::vector<sqlrs_hash_agg::Staged> st = std::move(a->staged);
+  a->staged.clear();
+  int64_t n = a->staged_rows;
+  a->staged_rows = 0;
+  std::vector<DCol> kcols, acols;
+  if (st.size() == 1) {
+    kcols = std::move(st[0].kcols);
+    acols = std::move(st[0].acols);
+  } else {
+    for (size_t c = 0; c < st[0].kcols.size(); c++) {
+      std::vector<const DCol *> parts;
+      for (auto &b : st) parts.push_back(&b.kcols[c]);
+      kcols.push_back(concat_columns(ctx, parts));
+    }
+    for (size_t c = 0; c < st[0].acols.size(); c++) {
+      std::vector<const DCol *> parts;
+      for (auto &b : st) parts.push_back(&b.acols[c]);
+      acols.push_back(concat_columns(ctx, parts));
+    }
+  }
+  NKeys nk = a->strong_keys ? normalize_keys_strong(ctx, kcols, n) : normalize_keys(ctx, kcols, n);
+  agg_consume(a, n, kcols, nk, acols, nullptr);
+  a->rows_seen += n;
+}
+
 } // namespace sq
 
 extern "C" {
@@ -698,11 +747,23 @@ int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
       a->saw_batch = true;
       for (const DCol &k : kcols) a->key_dtypes.push_back(k.dtype);
     }
-    NKeys nk = a->strong_keys ? normalize_keys_strong(ctx, kcols, n) : normalize_keys(ctx, kcols, n);
     // 2.1 argument columns (:63-66), evaluated once per distinct (expression, cast)
     std::vector<DCol> acols = eval_arg_columns(a, colfn, n, 0);
-    agg_consume(a, n, kcols, nk, acols, nullptr);
-    a->rows_seen += n;
+    // A first batch that is large by itself is aggregated in place (no copy of 16 B/row); everything
+    // else is staged and aggregated together at finish (or every STAGE_FLUSH_ROWS rows).
+    if (a->staged.empty() && n >= STAGE_DIRECT_ROWS) {
+      NKeys nk = a->strong_keys ? normalize_keys_strong(ctx, kcols, n) : normalize_keys(ctx, kcols, n);
+      agg_consume(a, n, kcols, nk, acols, nullptr);
+      a->rows_seen += n;
+    } else if (n > 0) {
+      sqlrs_hash_agg::Staged sb;
+      sb.n = n;
+      for (const DCol &c : kcols) sb.kcols.push_back(own_column(ctx, c, n));
+      for (const DCol &c : acols) sb.acols.push_back(own_column(ctx, c, n));
+      a->staged.push_back(std::move(sb));
+      a->staged_rows += n;
+      if (a->staged_rows >= STAGE_FLUSH_ROWS) flush_staged(a);
+    }
     for (auto &d : a->distinct_aggs) {
       int st = sqlrs_hash_agg_push(d.dedup, in);
       if (st != SQLRS_OK) fail(st, ctx->last_error);
@@ -717,6 +778,7 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
     SQ_HIP(hipSetDevice(ctx->device));
     if (!a->saw_batch) // group_and_agg_fields.unwrap() panics on None (:125)
       fail(SQLRS_ERR_INTERNAL, "hash agg finished without any input batch");
+    flush_staged(a);
     if (a->pending.active && a->st.ngroups == 0) {
       DBatch pb = emit_pending(a);
       place_aggregate_columns(a, pb);
@@ -877,6 +939,7 @@ int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) 
         js.validity = j->bkeys_validity ? j->bkeys_validity->as<uint64_t>() : nullptr;
         js.n = j->nB;
         js.cache = &ja->build_parts;
+        flush_staged(a); // batches staged by the composed route come first in row order
         if (agg_consume(a, n, kcols, nk, acols, &js)) {
           a->rows_seen += n;
           ja->fused_batches++;
