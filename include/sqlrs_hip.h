@@ -277,7 +277,8 @@ int sqlrs_join_agg_build_finish(sqlrs_join_agg_t *ja);
 int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right);
 int sqlrs_join_agg_finish(sqlrs_join_agg_t *ja, int out_mem, sqlrs_batch_t **out);
 int sqlrs_join_agg_set_group_order(sqlrs_join_agg_t *ja, int group_order); /* see sqlrs_hash_agg_set_group_order */
-/* probe batches that took the non-materialising route so far */
+/* probe inputs that took the non-materialising route so far (small probe batches are staged and
+ * processed together: they count once) */
 int64_t sqlrs_join_agg_fused_batches(const sqlrs_join_agg_t *ja);
 void sqlrs_join_agg_destroy(sqlrs_join_agg_t *ja);
 

@@ -147,7 +147,14 @@ struct InBatch {
   const sqlrs_batch_t *abi;
   std::vector<DCol> cache;
   std::vector<uint8_t> loaded;
+  bool host_upload = false; // an async H2D copy out of the caller's memory was queued
   InBatch(Ctx *c, const sqlrs_batch_t *b);
+  // The caller's buffers are only borrowed for the duration of the call: uploads out of host
+  // memory must have been read before the entry point returns (operators that stage their input
+  // no longer synchronise on their own).
+  ~InBatch();
+  InBatch(const InBatch &) = delete;
+  InBatch &operator=(const InBatch &) = delete;
   int64_t rows() const { return abi->num_rows; }
   int num_columns() const { return abi->num_columns; }
   int32_t dtype(int i) const { return abi->columns[i].dtype; }

@@ -211,9 +211,13 @@ InBatch::InBatch(Ctx *c, const sqlrs_batch_t *b) : ctx(c), abi(b) {
   cache.resize((size_t)b->num_columns);
   loaded.assign((size_t)b->num_columns, 0);
 }
+InBatch::~InBatch() {
+  if (host_upload) (void)hipStreamSynchronize(ctx->stream);
+}
 const DCol &InBatch::col(int i) {
   if (i < 0 || i >= abi->num_columns) fail(SQLRS_ERR_INTERNAL, "input ref out of range");
   if (!loaded[(size_t)i]) {
+    if (abi->columns[i].mem == SQLRS_MEM_HOST && abi->columns[i].length > 0) host_upload = true;
     cache[(size_t)i] = upload_column(ctx, abi->columns[i], false);
     loaded[(size_t)i] = 1;
   }

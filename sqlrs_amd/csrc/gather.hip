@@ -222,6 +222,43 @@ __global__ void rebase_offsets_kernel(const int32_t *__restrict__ src, int64_t n
   if (i <= n) dst[i] = src[i] + add;
 }
 
+// deep copy into buffers owned by the result (operators that keep a caller's column past the call)
+DCol copy_column(Ctx *ctx, const DCol &c_in) {
+  DCol c = c_in.stride == 0 ? materialize_scalar(ctx, c_in, c_in.length) : c_in;
+  DCol o = c;
+  auto dup = [&](const void *src, size_t bytes) -> BufP {
+    BufP b = ctx->alloc(bytes + 16);
+    if (bytes) SQ_HIP(hipMemcpyAsync(b->p, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return b;
+  };
+  // bitmaps: a caller's buffer only has to hold ceil(length / 8) bytes; ours are padded to u64 words
+  auto dup_bits = [&](const void *src) -> BufP {
+    BufP b = ctx->alloc_zero(bitmap_bytes(c.length) + 8);
+    size_t nbytes = (size_t)ceil_div(c.length, 8);
+    if (nbytes) SQ_HIP(hipMemcpyAsync(b->p, src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return b;
+  };
+  if (c.validity && c.null_count != 0) {
+    o.own_validity = dup_bits(c.validity);
+    o.validity = o.own_validity->as<uint64_t>();
+  } else {
+    o.validity = nullptr;
+    o.own_validity.reset();
+    o.null_count = 0;
+  }
+  if (c.dtype == SQLRS_BOOLEAN) {
+    o.own_values = dup_bits(c.values);
+  } else if (c.dtype == SQLRS_UTF8) {
+    o.own_offsets = dup(c.offsets, 4 * (size_t)(c.length + 1));
+    o.offsets = o.own_offsets->as<int32_t>();
+    o.own_values = dup(c.values, (size_t)c.data_bytes);
+  } else {
+    o.own_values = dup(c.values, width_of(c.dtype) * (size_t)c.length);
+  }
+  o.values = o.own_values->p;
+  return o;
+}
+
 DCol concat_columns(Ctx *ctx, const std::vector<const DCol *> &parts_in) {
   if (parts_in.empty()) fail(SQLRS_ERR_INTERNAL, "concat of nothing");
   std::vector<DCol> mat;

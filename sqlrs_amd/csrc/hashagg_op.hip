@@ -241,7 +241,9 @@ static void update_from_rows(sqlrs_hash_agg *a, const BufP &rgbuf, const std::ve
     if (v.dtype == SQLRS_UTF8 && (s.func == SQLRS_AGG_MIN || s.func == SQLRS_AGG_MAX)) {
       if (s.return_dtype != SQLRS_UTF8 || !v.col) fail(SQLRS_ERR_INTERNAL, "unsupported min_max scalar type");
       AggSpec::StrBatch sb;
-      sb.col = concat_columns(ctx, {v.col}); // private copy: the caller's batch may go away
+      bool borrowed = (v.col->values && !v.col->own_values) || (v.col->validity && !v.col->own_validity) ||
+                      (v.col->offsets && !v.col->own_offsets);
+      sb.col = borrowed ? copy_column(ctx, *v.col) : *v.col; // the caller's batch may go away
       sb.gid = rgbuf;
       sb.n = n;
       s.strs.push_back(std::move(sb));
@@ -635,14 +637,22 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
     return true;
 }
 
-constexpr int64_t STAGE_DIRECT_ROWS = 1ll << 26; // a first batch this large is aggregated in place
-constexpr int64_t STAGE_FLUSH_ROWS = 1ll << 28;  // staged rows that trigger an aggregation before finish
+// a first batch this large is aggregated in place; staged rows that trigger an aggregation before
+// finish (SQLRS_STAGE_DIRECT_ROWS / SQLRS_STAGE_FLUSH_ROWS: test hooks, read once)
+static const int64_t STAGE_DIRECT_ROWS = [] {
+  const char *e = std::getenv("SQLRS_STAGE_DIRECT_ROWS");
+  return e ? std::atoll(e) : (1ll << 26);
+}();
+static const int64_t STAGE_FLUSH_ROWS = [] {
+  const char *e = std::getenv("SQLRS_STAGE_FLUSH_ROWS");
+  return e ? std::atoll(e) : (1ll << 28);
+}();
 
 // a column the operator may keep after the call returns: scalars materialised, borrowed buffers copied
 static DCol own_column(Ctx *ctx, const DCol &c, int64_t n) {
   DCol m = c.stride == 0 ? materialize_scalar(ctx, c, n) : c;
   bool borrowed = (m.values && !m.own_values) || (m.validity && !m.own_validity) || (m.offsets && !m.own_offsets);
-  return borrowed ? concat_columns(ctx, {&m}) : m;
+  return borrowed ? copy_column(ctx, m) : m;
 }
 
 // aggregate everything that is staged as one batch (arrival order = row order)
@@ -867,6 +877,11 @@ struct sqlrs_join_agg {
   int nleft = 0;
   PartitionedRows build_parts; // build keys in bucket order (cache for the fused route)
   int64_t fused_batches = 0, composed_batches = 0;
+  // probe batches wait here (private copies) and are processed as one batch, for the same reason
+  // HashAgg stages its input; a first batch of >= 2^26 rows is processed in place
+  std::vector<DBatch> staged;
+  int64_t staged_rows = 0;
+  bool processed_any = false;
   ~sqlrs_join_agg() {
     if (join) sqlrs_hash_join_destroy(join);
     delete agg;
@@ -898,8 +913,9 @@ int sqlrs_join_agg_build_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *left) {
 int sqlrs_join_agg_build_finish(sqlrs_join_agg_t *ja) { return sqlrs_hash_join_build_finish(ja->join); }
 
 // one probe batch: HashJoin probe (hash_join.rs:207-292) feeding HashAgg push (hash_agg.rs:44-122)
-int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
+static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
   return guard(ja->ctx, [&] {
+    ja->processed_any = true;
     Ctx *ctx = ja->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
     sqlrs_hash_join *j = ja->join;
@@ -961,7 +977,50 @@ int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) 
   });
 }
 
+static int join_agg_flush(sqlrs_join_agg_t *ja) {
+  if (ja->staged.empty()) return SQLRS_OK;
+  Ctx *ctx = ja->ctx;
+  sqlrs_batch_t *view = nullptr;
+  int st = guard(ctx, [&] {
+    SQ_HIP(hipSetDevice(ctx->device));
+    std::vector<DBatch> bs = std::move(ja->staged);
+    ja->staged.clear();
+    ja->staged_rows = 0;
+    DBatch all;
+    size_t nc = bs[0].cols.size();
+    for (size_t c = 0; c < nc; c++) {
+      std::vector<const DCol *> parts;
+      for (DBatch &b : bs) {
+        if (b.cols.size() != nc) fail(SQLRS_ERR_ARROW, "concat_batches: schema mismatch");
+        parts.push_back(&b.cols[c]);
+      }
+      all.cols.push_back(bs.size() == 1 ? bs[0].cols[c] : concat_columns(ctx, parts));
+    }
+    for (DBatch &b : bs) all.rows += b.rows;
+    view = emit_batch(ctx, std::move(all), SQLRS_MEM_DEVICE);
+  });
+  if (st != SQLRS_OK) return st;
+  st = join_agg_process(ja, view);
+  sqlrs_batch_release(view);
+  return st;
+}
+
+int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
+  if (ja->staged.empty() && right->num_rows >= STAGE_DIRECT_ROWS) return join_agg_process(ja, right);
+  int st = guard(ja->ctx, [&] {
+    SQ_HIP(hipSetDevice(ja->ctx->device));
+    if (!ja->join->finished) fail(SQLRS_ERR_INTERNAL, "probe before build_finish");
+    InBatch ib(ja->ctx, right);
+    ja->staged.push_back(ib.materialize(true));
+    ja->staged_rows += right->num_rows;
+  });
+  if (st != SQLRS_OK) return st;
+  return ja->staged_rows >= STAGE_FLUSH_ROWS ? join_agg_flush(ja) : SQLRS_OK;
+}
+
 int sqlrs_join_agg_finish(sqlrs_join_agg_t *ja, int out_mem, sqlrs_batch_t **out) {
+  int st = join_agg_flush(ja);
+  if (st != SQLRS_OK) return st;
   return sqlrs_hash_agg_finish(ja->agg, out_mem, out);
 }
 int sqlrs_join_agg_set_group_order(sqlrs_join_agg_t *ja, int group_order) {
