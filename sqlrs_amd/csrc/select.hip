@@ -298,6 +298,9 @@ __device__ unsigned long long filter_timing[8];
 #define FT(i) do {} while (0)
 #define FT_INIT do {} while (0)
 #endif
+#ifndef FILTER_LB_LOADS
+#define FILTER_LB_LOADS 1
+#endif
 constexpr int FILTER_WAVES = 8;
 constexpr int FILTER_CHUNKS = 32;                                // 64-row chunks per worker wave
 constexpr int FILTER_TILE_ROWS = FILTER_WAVES * FILTER_CHUNKS * 64; // 16384
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_kernel(
     uint32_t c = lane < FILTER_WAVES ? s_wave[lane] : 0;
     uint32_t inc = wave_iscan_u32(c);
     uint64_t agg = (uint32_t)__shfl((int)inc, 63, 64);
-    uint64_t excl = lookback_wave(desc, tile, agg, timeout);
+    uint64_t excl = lookback_wave<FILTER_LB_LOADS>(desc, tile, agg, timeout);
     // kept rows before each 4096-row tile = before waves 0, 2, 4, 6
     if (lane < FILTER_WAVES && (lane & 1) == 0 && tile_off) {
       int64_t t4 = tile * FILTER_SUB + (lane >> 1);
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_persistent_kern
       uint32_t c = lane < FILTER_WAVES ? s_wave[p][lane] : 0;
       uint32_t inc = wave_iscan_u32(c);
       uint64_t agg = (uint32_t)__shfl((int)inc, 63, 64);
-      uint64_t excl = lookback_wave(desc, tile, agg, timeout);
+      uint64_t excl = lookback_wave<FILTER_LB_LOADS>(desc, tile, agg, timeout);
       if (lane < FILTER_WAVES && (lane & 1) == 0 && tile_off) {
         int64_t t4 = tile * FILTER_SUB + (lane >> 1);
         if (t4 * TILE_ROWS < rows) tile_off[t4] = excl + (inc - c);
