@@ -158,7 +158,10 @@ __device__ __forceinline__ void acc_apply(int kind, unsigned long long *c, uint6
 }
 
 // rows of one trip (LDS_U rows per thread) held in registers
-constexpr int LDS_U = 4;
+#ifndef LDS_U_ROWS
+#define LDS_U_ROWS 4
+#endif
+constexpr int LDS_U = LDS_U_ROWS;
 template <int NV> struct AggRows {
   uint64_t k[LDS_U], v0[NV >= 1 ? LDS_U : 1], v1[NV >= 2 ? LDS_U : 1];
   uint32_t id[LDS_U];
