@@ -219,6 +219,7 @@ def main():
     def exchange(cols, dtypes):
         """hash-partition on column 0 and all-to-all every column over RCCL; returns tensors"""
         from sqlrs_amd import distributed as D
+        t_x = tick()
         b = device_batch(abi, cols, dtypes)
         parts, offs = be.hash_partition(b, InputRef(0), world, abi.MEM_DEVICE)
         be.synchronize()
@@ -230,6 +231,11 @@ def main():
             outs = D.all_to_all_columns(dist, views, offs, world, torch)  # same code as the gloo CPU test
         torch.cuda.synchronize()
         parts.release()
+        if t_x is not None:
+            xstat["ms"] += (time.perf_counter() - t_x) * 1e3
+            sent = sum(int(v.numel()) * v.element_size() for v in views)
+            own = sum((offs[rank + 1] - offs[rank]) * v.element_size() for v in views)
+            xstat["bytes_off_rank"] += sent - own
         return outs
 
     strategy = args.exchange
@@ -243,15 +249,31 @@ def main():
     merge_aggs = (abi.AggFunc * 2)(_AggFunc("sum", InputRef(1), abi.INT64).abi_struct(_mkeep),
                                    _AggFunc("sum", InputRef(2), abi.FLOAT64).abi_struct(_mkeep))
 
+    xstat = {"on": False, "ms": 0.0, "bytes_off_rank": 0}
+
+    def tick():
+        """start of an exchange phase while profiling (None otherwise: the timed region has no extra syncs)"""
+        if not xstat["on"]:
+            return None
+        torch.cuda.synchronize()
+        be.synchronize()
+        return time.perf_counter()
+
     def gather_dim():
         """all-gather of the dim keys (every rank ends up with the whole build side)"""
         if single_dev:
             parts = [torch.empty(n, dtype=torch.int64) for n in dim_sizes]
             dist.all_gather(parts, dim_key.cpu())
             return torch.cat(parts).to(dev)
+        t_x = tick()
         parts = [torch.empty(n, dtype=torch.int64, device=dev) for n in dim_sizes]
         dist.all_gather(parts, dim_key)
-        return torch.cat(parts)
+        out = torch.cat(parts)
+        if t_x is not None:
+            torch.cuda.synchronize()
+            xstat["ms"] += (time.perf_counter() - t_x) * 1e3
+            xstat["bytes_off_rank"] += 8 * (n_dim_total - dim_sizes[rank])
+        return out
 
     def one_step():
         if world > 1 and strategy == "broadcast":
@@ -334,10 +356,26 @@ def main():
 
     # ---- per-kernel device time (HIP events on the ctx stream), separate profiled steps
     be.profile(True)
+    xstat["on"] = world > 1
+    torch.cuda.synchronize()
+    t_prof = time.perf_counter()
     for _ in range(2):
         one_step().release()
+    torch.cuda.synchronize()
+    be.synchronize()
+    prof_step_ms = (time.perf_counter() - t_prof) * 1e3 / 2
+    xstat["on"] = False
     prof = be.profile_read()
     be.profile(False)
+    exchange_info = None
+    if world > 1:  # SURVEY.md §8e scaling report: exchange vs local time, bytes over xGMI, rate per link
+        x_ms, x_bytes = xstat["ms"] / 2, xstat["bytes_off_rank"] / 2
+        exchange_info = {"strategy": strategy, "step_ms_profiled": round(prof_step_ms, 3), "exchange_ms": round(x_ms, 3),
+                         "local_ms": round(prof_step_ms - x_ms, 3), "bytes_off_rank_per_step": int(x_bytes),
+                         "GBps_per_rank": round(x_bytes / max(x_ms, 1e-9) / 1e6, 1),
+                         "GBps_per_link": round(x_bytes / max(x_ms, 1e-9) / 1e6 / (world - 1), 1),
+                         "note": "rank 0, profiled steps with a sync around every exchange phase (partition kernel + "
+                                 "collective); xGMI link peak 153 GB/s"}
     workload = {"fact_rows": f_hi - f_lo, "dim_rows": d_hi - d_lo, "selectivity": expected_kept / max(f_hi - f_lo, 1),
                 "matches": expected_kept, "groups": groups_local}
     if world > 1:  # after the exchange every rank holds about 1/N of everything
@@ -394,6 +432,8 @@ def main():
         }
         if operators:
             line["operators"] = operators
+        if exchange_info:
+            line["exchange"] = exchange_info
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
