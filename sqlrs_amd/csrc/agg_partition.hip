@@ -185,6 +185,41 @@ __device__ __forceinline__ void lds_agg_load(const uint64_t *__restrict__ pk, co
   }
 }
 
+// global tables of the split (skewed) buckets: nsplit tables of nslots = cap + 2 slots
+struct SplitTables {
+  unsigned long long *key = nullptr;  // [nsplit][nslots], LDS_EMPTY
+  unsigned int *first = nullptr;      // [nsplit][nslots], ~0
+  unsigned long long *acc = nullptr;  // [n_acc][nsplit][nslots], identity
+  uint32_t nsplit = 0;
+};
+
+__global__ void split_init_kernel(SplitTables stb, int64_t total, int n_acc, LdsAggParams prm) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  stb.key[i] = LDS_EMPTY;
+  stb.first[i] = 0xffffffffu;
+  for (int a = 0; a < n_acc; a++) stb.acc[(size_t)a * total + i] = acc_identity_cell(prm.code[a] & 7);
+}
+
+// occupied slots of the split buckets' tables -> group list (same layout as lds_agg_kernel's output)
+__global__ void split_emit_kernel(SplitTables stb, uint32_t nslots, uint32_t cap, int n_acc,
+                                  unsigned long long *out_count, uint64_t *__restrict__ gkey,
+                                  uint32_t *__restrict__ gfirst, uint8_t *__restrict__ gvalid,
+                                  uint64_t *__restrict__ gacc, int64_t gcap) {
+  const int64_t total = (int64_t)stb.nsplit * nslots;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  unsigned int first = stb.first[i];
+  if (first == 0xffffffffu) return;
+  const uint32_t s = (uint32_t)(i % nslots);
+  unsigned long long base = atomicAdd(out_count, 1ull);
+  if ((int64_t)base >= gcap) return;
+  gkey[base] = s == cap + 1 ? LDS_EMPTY : stb.key[i];
+  gfirst[base] = first;
+  if (gvalid) gvalid[base] = s == cap ? 0 : 1;
+  for (int a = 0; a < n_acc; a++) gacc[(size_t)a * gcap + base] = stb.acc[(size_t)a * total + i];
+}
+
 // One workgroup per work item (a bucket, or a chunk of a skewed bucket).
 //
 // Table layout in LDS (structure of arrays, nslots = cap + 2; slot cap = NULL key, cap + 1 = the
@@ -206,13 +241,14 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     uint32_t *__restrict__ gfirst, uint8_t *__restrict__ gvalid, uint64_t *__restrict__ gacc,
     int64_t gcap, unsigned long long *ov_count, uint32_t *__restrict__ ov_rows,
     const uint64_t *__restrict__ bk, const uint8_t *__restrict__ bf, const uint32_t *__restrict__ bbstart,
-    KeyPack kp) {
+    KeyPack kp, SplitTables stb) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
   __shared__ unsigned int s_cnt;
   __shared__ unsigned long long s_base;
-  const uint32_t b = work[3 * blockIdx.x];
-  const int64_t lo = work[3 * blockIdx.x + 1];
-  const int64_t hi = work[3 * blockIdx.x + 2];
+  const uint32_t b = work[4 * blockIdx.x];
+  const int64_t lo = work[4 * blockIdx.x + 1];
+  const int64_t hi = work[4 * blockIdx.x + 2];
+  const uint32_t split = work[4 * blockIdx.x + 3]; // index of the bucket's global table, or ~0: not split
   const uint32_t cap = prm.cap, mask = cap - 1, nslots = cap + 2;
   const int n_acc = NACC >= 0 ? NACC : prm.n_acc;
   auto code_of = [&](int a) { return NACC >= 0 ? (a == 0 ? C0 : C1) : prm.code[a]; };
@@ -375,6 +411,66 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     cur = nxt;
   }
   __syncthreads();
+  if (split != 0xffffffffu) {
+    // chunk of a skewed bucket: its groups are merged into the bucket's small global table (a few
+    // atomics per distinct key of the chunk), which split_emit_kernel appends to the group list once
+    // — the chunks of a bucket never emit the same key twice
+    unsigned long long *gk = stb.key + (size_t)split * nslots;
+    unsigned int *gf = stb.first + (size_t)split * nslots;
+    for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) {
+      unsigned int first = tfirst[s];
+      if (first == 0xffffffffu) continue;
+      uint32_t g = s; // reserved slots keep their place
+      bool placed = true;
+      if (s < cap) {
+        const unsigned long long key = tkey[s];
+        g = slot_hash(key) & mask;
+        uint32_t probes = 0;
+        while (true) {
+          unsigned long long prev = atomicCAS(&gk[g], LDS_EMPTY, key);
+          if (prev == LDS_EMPTY || prev == key) break;
+          g = (g + 1) & mask;
+          if (++probes >= cap) { // more groups in this bucket than a table holds (estimate far too low)
+            placed = false;
+            break;
+          }
+        }
+      }
+      if (!placed) {
+        // emitted as a partial group of its own; the caller is told that keys may repeat
+        // (ov_count[3]) and merges the batch's groups through the global table
+        unsigned long long o = atomicAdd(out_count, 1ull);
+        if ((int64_t)o < gcap) {
+          gkey[o] = tkey[s];
+          gfirst[o] = first;
+          if (gvalid) gvalid[o] = 1;
+#pragma unroll
+          for (int a = 0; a < PART_MAX_ACC; a++) {
+            if (a >= n_acc) break;
+            gacc[(size_t)a * gcap + o] = tacc[(size_t)a * nslots + s];
+          }
+        }
+        atomicExch(ov_count + 2, 1ull);
+        continue;
+      }
+      atomicMin(&gf[g], first);
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        unsigned long long *cell = stb.acc + ((size_t)a * stb.nsplit + split) * nslots + g;
+        const unsigned long long v = tacc[(size_t)a * nslots + s];
+        switch (code_of(a) & 7) {
+        case AK_COUNT:
+        case AK_SUM_I64: atomicAdd(cell, v); break;
+        case AK_SUM_F64: unsafeAtomicAdd((double *)cell, __longlong_as_double((long long)v)); break;
+        case AK_MIN_I64:
+        case AK_MIN_F64: atomicMin(cell, v); break; // cells hold order-preserving images
+        default: atomicMax(cell, v);
+        }
+      }
+    }
+    return;
+  }
   // compact the occupied slots of this bucket into the global group list
   unsigned int mine = 0;
   for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) mine += tfirst[s] != 0xffffffffu;
@@ -544,31 +640,46 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   }
   prm.cap = cap;
   int64_t gcap = (int64_t)std::min<double>((double)n, est * 1.5 + 65536.0 + 2.0 * P);
-  BufP ctr = ctx->alloc_zero(24);
+  BufP ctr = ctx->alloc_zero(32);
   size_t lds = round_up((size_t)(cap + 2) * slot_bytes, 16);
   // work list: buckets larger than `chunk` rows (key skew) are split so that no workgroup streams
-  // more than `chunk` rows; the same key may then appear in several chunks (out->may_dup) and the
-  // caller merges the groups instead of adopting them as they are
+  // more than `chunk` rows.  The chunks of a split bucket merge their tables into one small global
+  // table per bucket (SplitTables), so a key is still emitted exactly once.
   std::vector<uint32_t> hb((size_t)P + 1);
   SQ_HIP(hipMemcpyAsync(hb.data(), pr.bstart->p, 4 * hb.size(), hipMemcpyDeviceToHost, ctx->stream));
   ctx->sync();
-  const uint32_t chunk = (uint32_t)std::max<int64_t>(65536, 8 * (n / std::max<uint32_t>(P, 1)));
+  const uint32_t chunk = (uint32_t)std::max<int64_t>(32768, 2 * (n / std::max<uint32_t>(P, 1)));
   std::vector<uint32_t> work;
-  work.reserve(3 * ((size_t)P + 64));
+  work.reserve(4 * ((size_t)P + 64));
   out->may_dup = false;
+  uint32_t nsplit = 0;
   for (uint32_t bkt = 0; bkt < P; bkt++) {
     uint32_t lo = hb[bkt], hi = hb[bkt + 1];
     if (hi - lo <= chunk) {
-      work.insert(work.end(), {bkt, lo, hi});
+      work.insert(work.end(), {bkt, lo, hi, 0xffffffffu});
     } else {
-      out->may_dup = true;
-      for (uint32_t c0 = lo; c0 < hi; c0 += chunk) work.insert(work.end(), {bkt, c0, std::min(hi, c0 + chunk)});
+      for (uint32_t c0 = lo; c0 < hi; c0 += chunk) work.insert(work.end(), {bkt, c0, std::min(hi, c0 + chunk), nsplit});
+      nsplit++;
     }
   }
-  const uint32_t nwork = (uint32_t)(work.size() / 3);
+  const uint32_t nwork = (uint32_t)(work.size() / 4);
   BufP dwork = ctx->alloc(4 * work.size() + 16);
   SQ_HIP(hipMemcpyAsync(dwork->p, work.data(), 4 * work.size(), hipMemcpyHostToDevice, ctx->stream));
-  gcap += (int64_t)(nwork - P) * (int64_t)(cap + 2); // every extra chunk can add a table's worth of partials
+  const uint32_t nslots_h = cap + 2;
+  SplitTables stb;
+  BufP stb_key, stb_first, stb_acc;
+  if (nsplit) {
+    const int64_t total = (int64_t)nsplit * nslots_h;
+    stb_key = ctx->alloc(8 * (size_t)total);
+    stb_first = ctx->alloc(4 * (size_t)total);
+    stb_acc = ctx->alloc(8 * (size_t)total * (size_t)std::max(spec.n_acc, 1));
+    stb.key = stb_key->as<unsigned long long>();
+    stb.first = stb_first->as<unsigned int>();
+    stb.acc = stb_acc->as<unsigned long long>();
+    stb.nsplit = nsplit;
+    split_init_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(stb, total, spec.n_acc, prm);
+    SQ_HIP(hipGetLastError());
+  }
   out->gkey = ctx->alloc(8 * (size_t)gcap);
   out->gfirst = ctx->alloc(4 * (size_t)gcap);
   out->gvalid = in.key_validity ? ctx->alloc((size_t)gcap) : nullptr;
@@ -592,7 +703,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
         out->gvalid ? out->gvalid->as<uint8_t>() : nullptr, out->gacc->as<uint64_t>(), gcap,                   \
         ctr->as<unsigned long long>() + 1, out->ov_rows->as<uint32_t>(),                                       \
         bp ? bp->key->as<uint64_t>() : nullptr, (bp && bp->flags) ? bp->flags->as<uint8_t>() : nullptr,        \
-        bp ? bp->bstart->as<uint32_t>() : nullptr, pr.pack);                                                   \
+        bp ? bp->bstart->as<uint32_t>() : nullptr, pr.pack, stb);                                              \
     launched = true;                                                                                           \
   } while (0)
 #define SQ_LA_J(NV, FL, NA, C0, C1)                                                                            \
@@ -626,12 +737,20 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     }
 #undef SQ_LA_J
 #undef SQ_LA
+    if (nsplit) {
+      const int64_t total = (int64_t)nsplit * nslots_h;
+      split_emit_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
+          stb, nslots_h, cap, spec.n_acc, ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(),
+          out->gfirst->as<uint32_t>(), out->gvalid ? out->gvalid->as<uint8_t>() : nullptr,
+          out->gacc->as<uint64_t>(), gcap);
+    }
     SQ_HIP(hipGetLastError());
   }
   ctx->sync(); // `work` (host) was the source of an async upload
-  const uint64_t *h = (const uint64_t *)ctx->fetch(ctr->p, 24);
+  const uint64_t *h = (const uint64_t *)ctx->fetch(ctr->p, 32);
   out->groups = (int64_t)h[0];
   out->n_overflow = (int64_t)h[1];
+  out->may_dup = h[3] != 0; // a split bucket's global table was full: some keys were emitted twice
   if (join_mode && h[2]) return false; // a bucket table could not hold its build keys
   if (out->groups > gcap) return false; // estimate far too low: caller falls back to the resolve path
   // first-row ids as global row numbers + NULL-key bitmap for the merge

@@ -468,7 +468,7 @@ def test_hash_agg_partition_route_with_forced_table_overflow(scale):
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "(partition_route or mixed_routes or join_agg) and not forced"],
-                       env=env, capture_output=True, text=True, timeout=900)
+                       env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
