@@ -20,7 +20,7 @@ OBJDIR = os.path.join(CSRC, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
           "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-CFLAGS += os.environ.get("SQLRS_EXTRA_CFLAGS", "").split()  # e.g. -DRP_TIMING (kernel phase timers)
+CFLAGS += os.environ.get("SQLRS_EXTRA_CFLAGS", "").split()  # e.g. -DFILTER_TIMING (kernel phase timers)
 
 
 def sources():

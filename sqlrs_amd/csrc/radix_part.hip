@@ -134,12 +134,6 @@ struct RpOut {
 //   RP_L1_NULL level 1 with validity bitmaps (flags built from the bitmaps)
 //   RP_LN      level >= 2: row id column, no flags column
 //   RP_LN_FLAG level >= 2: row id column + flags column
-#ifdef RP_TIMING
-__device__ unsigned long long rp_timing[8];
-#define RP_T(i) do { if (threadIdx.x == 0) { long long now_ = clock64(); tacc[i] += now_ - tlast; tlast = now_; } } while (0)
-#else
-#define RP_T(i) do {} while (0)
-#endif
 enum { RP_L1 = 0, RP_L1_NULL = 1, RP_LN = 2, RP_LN_FLAG = 3 };
 
 // rows of one tile held in registers (one struct per pipeline stage)
@@ -219,54 +213,40 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
   const uint32_t t0 = blockIdx.x * tiles_per_wg;
   const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
   if (t0 >= t1) return;
-  // Software pipeline: the rows of tile i+1 are loaded into a second register set before tile i
-  // goes through its LDS phases.  Everything that would make the compiler wait early is kept
-  // out of the loop (s_waitcnt vmcnt counts loads and stores together on gfx9, and at a join of
-  // two paths the compiler assumes the one with FEWER younger operations):
-  //  * loads are unconditional — ragged tiles re-read their last row, the last iteration
-  //    re-reads its own tile;
+  // Software pipeline over the workgroup's tiles.  While tile i sits sorted in the LDS staging
+  // area and is written out, tile i+1 (already in registers) is ranked — the LDS atomics of the
+  // rank fill the issue slots the stores leave while the memory pipe pushes back — and tile i+2 is
+  // being loaded into the second register set.  Everything that would make the compiler wait
+  // early is kept out of the loop (s_waitcnt vmcnt counts loads and stores together on gfx9, and
+  // at a join of two paths the compiler assumes the one with FEWER younger operations):
+  //  * loads are unconditional — ragged tiles re-read their last row, the last iterations
+  //    re-read the last tile;
   //  * stores are unconditional — the lanes past the end of a ragged tile write to the
   //    `sink` rows behind the output columns;
   //  * the first tile is complete before the loop, like every later tile on the back edge.
-  // With that the only wait in the loop is vmcnt(stores of this tile) before `cur = nxt`.
+  // A tile's stores are drained before the barrier that follows them (read / write phases per
+  // CU: measured 12.9 -> 10.7 ms per C5 step).
   TileRegs<NV, RP_ROWS> cur, nxt;
-  Tile t = tiles[t0];
-  rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, t, t0, offs, digits, cur);
-  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-#ifdef RP_TIMING
-  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-#endif
-  for (uint32_t ti = t0; ti < t1; ti++) {
-    Tile tn = tiles[min(ti + 1, t1 - 1)];
-    rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, tn, min(ti + 1, t1 - 1), offs, digits, nxt);
-    cnt[threadIdx.x] = 0;
-    __syncthreads();
-    RP_T(0);
-    uint32_t dg[RP_ROWS], rk[RP_ROWS];
-#pragma unroll
-    for (int j = 0; j < RP_ROWS; j++) {
-      dg[j] = 0xffffffffu;
-      if ((uint32_t)(j * RP_WG) + threadIdx.x < t.len) {
-        const uint64_t key = (PACK && MODE == RP_LN) ? packed_key(kp, cur.k[j]) : cur.k[j];
-        dg[j] = rp_digit(rp_bucket(key, cur.fl[j] & 1, P), level, p2_bits);
-        rk[j] = atomicAdd(&cnt[dg[j]], 1u);
-      }
+  uint32_t dg[RP_ROWS], rk[RP_ROWS];
+  auto rank_row = [&](int j, uint32_t len) {
+    dg[j] = 0xffffffffu;
+    if ((uint32_t)(j * RP_WG) + threadIdx.x < len) {
+      const uint64_t key = (PACK && MODE == RP_LN) ? packed_key(kp, cur.k[j]) : cur.k[j];
+      dg[j] = rp_digit(rp_bucket(key, cur.fl[j] & 1, P), level, p2_bits);
+      rk[j] = atomicAdd(&cnt[dg[j]], 1u);
     }
+  };
+  auto scan_and_stage = [&]() { // counters -> run starts; rows of `cur` -> staging area, sorted by digit
+    uint32_t c = cnt[threadIdx.x];
+    uint32_t inc = wave_iscan_u32(c);
+    if (lane_id() == 63) s_wsum[wave_id()] = inc;
     __syncthreads();
-    RP_T(1);
-    { // exclusive scan of the RP_WG counters (one per thread)
-      uint32_t c = cnt[threadIdx.x];
-      uint32_t inc = wave_iscan_u32(c);
-      if (lane_id() == 63) s_wsum[wave_id()] = inc;
-      __syncthreads();
-      uint32_t wbase = 0;
-      for (int w = 0; w < wave_id(); w++) wbase += s_wsum[w];
-      uint32_t ls = wbase + inc - c;
-      lstart[threadIdx.x] = ls;
-      gbase[threadIdx.x] = (int64_t)cur.goff - (int64_t)ls;
-    }
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave_id(); w++) wbase += s_wsum[w];
+    uint32_t ls = wbase + inc - c;
+    lstart[threadIdx.x] = ls;
+    gbase[threadIdx.x] = (int64_t)cur.goff - (int64_t)ls;
     __syncthreads();
-    RP_T(2);
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
       if (dg[j] == 0xffffffffu) continue;
@@ -279,31 +259,57 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
       if (FLAGS) sflag[p] = cur.fl[j];
     }
     __syncthreads();
-    RP_T(3);
+  };
+  auto store_row = [&](int j, uint32_t len) { // row j of the staged tile -> its run in the output
+    uint32_t p = j * RP_WG + threadIdx.x;
+    const uint64_t kw = skey[p];
+    const uint32_t d = PACK ? rp_digit(rp_bucket(packed_key(kp, kw), true, P), level, p2_bits) : sdig[p];
+    int64_t g = gbase[d & (RP_WG - 1)] + p;
+    if (p >= len) g = sink + threadIdx.x;
+    out.key[g] = kw;
+    if (NV >= 1) out.v0[g] = sv0[p];
+    if (NV >= 2) out.v1[g] = sv1[p];
+    if (!PACK) out.idx[g] = sidx[p];
+    if (FLAGS) out.flags[g] = sflag[p];
+  };
+
+  // first tile: rank, scan, stage
+  Tile t = tiles[t0];
+  rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, t, t0, offs, digits, cur);
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) rank_row(j, t.len);
+  __syncthreads();
+  scan_and_stage();
+  uint32_t staged_len = t.len;
+  // second tile into `cur`
+  t = tiles[min(t0 + 1, t1 - 1)];
+  rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, t, min(t0 + 1, t1 - 1), offs, digits, cur);
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the back edge
+  for (uint32_t ti = t0 + 1; ti < t1; ti++) {
+    // staging area: tile ti-1 (sorted);  cur: tile ti;  nxt <- tile ti+1
+    const uint32_t tnext = min(ti + 1, t1 - 1);
+    Tile tn = tiles[tnext];
+    rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, tn, tnext, offs, digits, nxt);
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
-      uint32_t p = j * RP_WG + threadIdx.x;
-      const uint64_t kw = skey[p];
-      const uint32_t d = PACK ? rp_digit(rp_bucket(packed_key(kp, kw), true, P), level, p2_bits) : sdig[p];
-      int64_t g = gbase[d & (RP_WG - 1)] + p;
-      if (p >= t.len) g = sink + threadIdx.x;
-      out.key[g] = kw;
-      if (NV >= 1) out.v0[g] = sv0[p];
-      if (NV >= 2) out.v1[g] = sv1[p];
-      if (!PACK) out.idx[g] = sidx[p];
-      if (FLAGS) out.flags[g] = sflag[p];
+      store_row(j, staged_len);
+      rank_row(j, t.len);
     }
     if (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads(); // the staging area and the counters are reused by the next tile
-    RP_T(4);
+    __syncthreads(); // the staging area is free, the counters are complete
+    scan_and_stage();
+    staged_len = t.len;
     cur = nxt;
     t = tn;
-    RP_T(5);
   }
-#ifdef RP_TIMING
-  if (threadIdx.x == 0)
-    for (int i = 0; i < 6; i++) atomicAdd(&rp_timing[i], (unsigned long long)tacc[i]);
-#endif
+  // last staged tile
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) store_row(j, staged_len);
 }
 
 // bucket b (level-1 digit d1 = b >> p2_bits ... ) start row, from the level's scanned matrix
@@ -498,16 +504,6 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
 #undef SQ_RP1
 #undef SQ_RP
       SQ_HIP(hipGetLastError());
-#ifdef RP_TIMING
-      {
-        unsigned long long h[8], z[8] = {0};
-        SQ_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(rp_timing), sizeof(h)));
-        SQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rp_timing), z, sizeof(z)));
-        if (nt > 1000)
-          fprintf(stderr, "[rp_timing] level %d digits %u tiles %u wgs %u: cycles/tile prefetch+zero %.0f rank %.0f scan %.0f stage %.0f store %.0f copywait %.0f\n",
-                  level, digits, nt, wgs, (double)h[0] / nt, (double)h[1] / nt, (double)h[2] / nt, (double)h[3] / nt, (double)h[4] / nt, (double)h[5] / nt);
-      }
-#endif
     }
     ctx->sync(); // the host vectors of `L` were the source of async uploads
     *offs_out = offs;
