@@ -94,16 +94,24 @@ class Pipeline:
                                       AggFunc("sum", InputRef(2), abi.FLOAT64).abi_struct(keep))
         self._keep = keep
 
-    def step(self, dim_b, fact_b):
-        """one pass; returns the device-resident result batch (LibBatch)"""
+    def filter(self, fact_b):
+        """Filter alone; returns the device-resident kept rows (LibBatch)"""
         be, abi = self.be, self.abi
-        D = abi.MEM_DEVICE
         f = C.c_void_p()
         be.check(be.fn("filter_create")(be.ctx, C.byref(self.filter_expr.abi), C.byref(f)))
         fo = C.POINTER(abi.Batch)()
-        be.check(be.fn("filter_push")(f, fact_b.ptr, D, C.byref(fo)))
+        be.check(be.fn("filter_push")(f, fact_b.ptr, abi.MEM_DEVICE, C.byref(fo)))
         be.fn("filter_destroy")(f)
-        filtered = be.wrap(fo)
+        return be.wrap(fo)
+
+    def step(self, dim_b, fact_b):
+        """one pass; returns the device-resident result batch (LibBatch)"""
+        return self.join_agg(dim_b, self.filter(fact_b))
+
+    def join_agg(self, dim_b, filtered):
+        """HashJoin + HashAgg over already filtered fact rows (`filtered` is released)"""
+        be, abi = self.be, self.abi
+        D = abi.MEM_DEVICE
         if self.fused:
             # HashAgg directly over the Inner HashJoin (sqlrs_join_agg_*): same result, the joined
             # batch is not materialised when the library's fused route applies
@@ -298,13 +306,22 @@ def main():
             be.synchronize()
             return be.wrap(ao)
         if world > 1:
+            # partitioned hash join: the filter runs below the exchange, so only the kept fact rows
+            # cross xGMI; dim and fact are hash-partitioned on the join key, every rank then owns a
+            # disjoint key range and its local result is final
+            kept = pipe.filter(device_batch(abi, [fact_key, fact_val], [abi.INT64, abi.FLOAT64]))
+            be.synchronize()
+            kk = _tensor_view(torch, kept.column(0).values, kept.num_rows, torch.int64, dev)
+            kv = _tensor_view(torch, kept.column(1).values, kept.num_rows, torch.float64, dev)
             dk, = exchange([dim_key], [abi.INT64])
-            fk, fv = exchange([fact_key, fact_val], [abi.INT64, abi.FLOAT64])
-        else:
-            dk, fk, fv = dim_key, fact_key, fact_val
-        dim_b = device_batch(abi, [dk], [abi.INT64])
-        fact_b = device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64])
-        out = pipe.step(dim_b, fact_b)
+            fk, fv = exchange([kk, kv], [abi.INT64, abi.FLOAT64])
+            kept.release()
+            out = pipe.join_agg(device_batch(abi, [dk], [abi.INT64]),
+                                device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64]))
+            be.synchronize()
+            return out
+        out = pipe.step(device_batch(abi, [dim_key], [abi.INT64]),
+                        device_batch(abi, [fact_key, fact_val], [abi.INT64, abi.FLOAT64]))
         be.synchronize()
         return out
 

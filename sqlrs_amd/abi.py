@@ -148,6 +148,10 @@ class RawBatch:
         self.abi = Batch(num_rows, n, 0, C.cast(self.cols, C.POINTER(Column)), None)
         self.keepalive = keepalive
 
+    def release(self):
+        """drops the references that keep the caller's buffers alive (same call as LibBatch.release)"""
+        self.keepalive = None
+
     @property
     def ptr(self):
         return C.byref(self.abi)
