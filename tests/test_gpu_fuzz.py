@@ -109,3 +109,58 @@ def test_fuzz_order(hip, oracle, seed):
     ob = [OrderBy(InputRef(int(c)), bool(rng.random() < 0.5)) for c in rng.permutation(len(kinds))[:nkeys]]
     bs = _split(rng, b)
     assert_same(rows_of(OrderExecutor(hip, ob, bs).execute()), rows_of(OrderExecutor(oracle, ob, bs).execute()))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_hash_agg_partition_route(hip, oracle, seed):
+    """batches above 2^21 rows: LDS-partitioned pre-aggregation (packed and unpacked rows, NULLs,
+    one or two value columns, skewed keys, several batches staged together)"""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([2_100_000, 2_600_000, 3_300_000]))
+    card = int(rng.choice([5, 4000, 200_000, 1_500_000]))
+    nulls = float(rng.choice([0.0, 0.0, 0.03]))
+    lo = int(rng.choice([0, -card // 2, 1 << 35]))
+    keys = rng.integers(lo, lo + card, n, dtype=np.int64)
+    if rng.random() < 0.4:  # heavy hitters
+        keys[rng.random(n) < 0.5] = lo + int(rng.integers(0, card))
+    kmask = (rng.random(n) < nulls) if nulls else None
+    v1 = pa.array(rng.random(n), mask=(rng.random(n) < nulls) if nulls else None)
+    v2 = pa.array(rng.integers(-10**6, 10**6, n, dtype=np.int64), mask=(rng.random(n) < nulls) if nulls else None)
+    b = pa.RecordBatch.from_arrays([pa.array(keys, mask=kmask), v1, v2], names=["k", "a", "b"])
+    pool = [("count", 1, abi.INT64), ("sum", 1, abi.FLOAT64), ("min", 1, abi.FLOAT64), ("max", 1, abi.FLOAT64),
+            ("count", 2, abi.INT64), ("sum", 2, abi.INT64), ("min", 2, abi.INT64), ("max", 2, abi.INT64)]
+    two_cols = rng.random() < 0.5
+    cand = pool if two_cols else pool[:4]
+    picks = [cand[i] for i in rng.choice(len(cand), int(rng.integers(1, 4)), replace=False)]
+    aggs = [AggFunc(f, InputRef(c), t) for f, c, t in picks]
+    fl = {1 + i for i, (f, c, t) in enumerate(picks) if f == "sum" and t == abi.FLOAT64}
+    bs = [b] if rng.random() < 0.5 else [b.slice(0, n // 3), b.slice(n // 3)]
+    assert_same(rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], bs).execute()),
+                rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], bs).execute()), float_cols=fl)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_join_agg(hip, oracle, seed):
+    """HashJoinAgg (fused where it applies, composed otherwise) vs HashAgg(HashJoin) on the oracle"""
+    from sqlrs_amd.executor import HashJoinAggExecutor
+    rng = np.random.default_rng(6000 + seed)
+    nb = int(rng.choice([50, 3000, 40_000]))
+    npb = int(rng.choice([70_000, 400_000, 2_300_000]))
+    card = int(nb * rng.choice([1, 2, 10]))
+    unique = rng.random() < 0.7
+    lkeys = rng.permutation(card)[:nb].astype(np.int64) if unique else rng.integers(0, card, nb, dtype=np.int64)
+    lb = pa.RecordBatch.from_arrays([pa.array(lkeys), pa.array(rng.integers(0, 9, nb, dtype=np.int64))], names=["k", "x"])
+    nulls = float(rng.choice([0.0, 0.04]))
+    rb = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, card, npb, dtype=np.int64), mask=(rng.random(npb) < nulls) if nulls else None),
+                                     pa.array(rng.random(npb), mask=(rng.random(npb) < nulls) if nulls else None)], names=["k", "v"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64)]
+    if rng.random() < 0.3:
+        aggs.append(AggFunc("sum", InputRef(1), abi.INT64))  # build-side argument: composed route
+    gb = [InputRef(0)] if rng.random() < 0.5 else [InputRef(2)]
+    rbs = _split(rng, rb)
+    got = rows_of(HashJoinAggExecutor(hip, [lb], rbs, cond, sch, 2, aggs, gb).execute())
+    join = HashJoinExecutor(oracle, [lb], rbs, "inner", cond, sch, 2)
+    exp = rows_of(HashAggExecutor(oracle, aggs, gb, join.execute()).execute())
+    assert_same(got, exp, float_cols={2})
