@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -180,6 +181,17 @@ template <class F> int guard(Ctx *ctx, F &&f) {
     if (ctx) ctx->last_error = e.what();
     return SQLRS_ERR_INTERNAL;
   }
+}
+
+// Test hook (read once): SQLRS_FORCE_TICKET=1 makes the look-back kernels skip their fast launch
+// (tile id = block index, bounded spin) and use the ticketed fallback launch right away, so the
+// fallback is exercised by the parity tests instead of only by a timeout.
+inline int first_lookback_mode() {
+  static const int forced = [] {
+    const char *e = std::getenv("SQLRS_FORCE_TICKET");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  return forced;
 }
 
 // Expression (postfix) owned copy

@@ -678,3 +678,19 @@ def test_agg_paths_without_staging():
                         "-k", "(hash_agg or join_agg or utf8_keys) and not forced and not without_staging and not packed_and"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_lookback_ticket_fallback_paths():
+    """SQLRS_FORCE_TICKET=1: the single-pass kernels (filter, hash-join probe) use their ticketed
+    fallback launch, which otherwise only runs after a look-back timeout (hook read once per process,
+    hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SQLRS_FORCE_TICKET="1")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "(test_filter or test_hash_join) and not fallback"],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
