@@ -13,6 +13,11 @@ from test_gpu_parity import assert_same, col, join_schema, rows_of
 
 pytestmark = pytest.mark.gpu
 
+import os
+
+# SQLRS_FUZZ_EXTRA=N adds N more seeds per operator for a longer soak (default suite: 40 / 30)
+_EXTRA = int(os.environ.get("SQLRS_FUZZ_EXTRA", "0"))
+
 _DT = {"i64": abi.INT64, "f64": abi.FLOAT64, "i32": abi.INT32}
 
 
@@ -37,7 +42,7 @@ def _rand_batch(rng, n, kinds, key_card):
     return pa.RecordBatch.from_arrays(cols, names=[f"c{i}" for i in range(len(cols))])
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 + _EXTRA))
 def test_fuzz_filter(hip, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([0, 1, 77, 4096, 20_000, 70_000]))
@@ -55,7 +60,7 @@ def test_fuzz_filter(hip, oracle, seed):
     assert_same(rows_of(FilterExecutor(hip, e, bs).execute()), rows_of(FilterExecutor(oracle, e, bs).execute()))
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 + _EXTRA))
 def test_fuzz_hash_agg(hip, oracle, seed):
     rng = np.random.default_rng(2000 + seed)
     n = int(rng.choice([1, 50, 3000, 40_000, 150_000]))
@@ -75,7 +80,7 @@ def test_fuzz_hash_agg(hip, oracle, seed):
                 rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], bs).execute()), float_cols=fl)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 + _EXTRA))
 def test_fuzz_hash_join(hip, oracle, seed):
     rng = np.random.default_rng(3000 + seed)
     nb = int(rng.choice([0, 1, 40, 900, 6000]))
@@ -98,7 +103,7 @@ def test_fuzz_hash_join(hip, oracle, seed):
     assert_same(rows_of(got), rows_of(exp))
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(30 + _EXTRA))
 def test_fuzz_order(hip, oracle, seed):
     rng = np.random.default_rng(4000 + seed)
     n = int(rng.choice([1, 2, 65, 5000, 70_000]))
