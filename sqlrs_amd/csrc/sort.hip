@@ -43,12 +43,18 @@ __global__ __launch_bounds__(RS_WG) void rs_hist_kernel(const uint64_t *__restri
 //   2. per digit: exclusive prefix of the 8 wave counters, exclusive scan over the 256 digits
 //   3. rows are written to their tile-local position in LDS (digit-major, row order inside a digit)
 //   4. the tile is copied out; position p of digit d goes to offsets[d][tile] + (p - start[d])
+// Record formats.  PAIR: (u64 key, u32 row id) in two arrays.  PACKED: one u64 word
+// (key_part << 32) | row id, used between the first and the last pass when the varying key bits
+// fit 32 bits: 8 instead of 12 bytes per row and pass.  IN / OUT select what a pass reads / writes;
+// a PACKED -> PAIR pass rebuilds the key as (word >> 32) << key_lo | key_const.
+enum { RS_PAIR = 0, RS_PACKED = 1 };
+template <int IN, int OUT>
 __global__ __launch_bounds__(RS_WG) void rs_scatter_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t n, int shift,
     int64_t nblocks, const uint32_t *__restrict__ offsets, uint64_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out) {
+    uint32_t *__restrict__ vals_out, int key_lo, uint64_t key_const) {
   __shared__ uint64_t skey[RS_TILE];
-  __shared__ uint32_t sval[RS_TILE];
+  __shared__ uint32_t sval[(IN == RS_PAIR && OUT == RS_PAIR) ? RS_TILE : 1];
   __shared__ uint32_t wcnt[RS_WAVES][256];
   __shared__ uint32_t dstart[256];
   __shared__ int64_t gbase[256];
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(RS_WG) void rs_scatter_kernel(
   for (int j = 0; j < RS_ITEMS; j++) {
     const int64_t i = min(wrow + j * 64, n - 1);
     k[j] = __builtin_nontemporal_load(keys + i);
-    v[j] = __builtin_nontemporal_load(vals + i);
+    v[j] = IN == RS_PAIR ? __builtin_nontemporal_load(vals + i) : 0u;
   }
   uint32_t goff = threadIdx.x < 256 ? offsets[(int64_t)threadIdx.x * nblocks + blockIdx.x] : 0;
 #pragma unroll
@@ -115,8 +121,11 @@ __global__ __launch_bounds__(RS_WG) void rs_scatter_kernel(
     if (wrow + j * 64 >= n) continue;
     const uint32_t d = (uint32_t)(k[j] >> shift) & 255u;
     const uint32_t p = dstart[d] + wcnt[w][d] + rnk[j];
-    skey[p] = k[j];
-    sval[p] = v[j];
+    // a PAIR -> PACKED pass packs here: the digit was taken from the unpacked key at `shift`,
+    // later passes take it from the word at shift - key_lo + 32
+    if (IN == RS_PAIR && OUT == RS_PACKED) skey[p] = ((k[j] >> key_lo) << 32) | v[j];
+    else skey[p] = k[j];
+    if (IN == RS_PAIR && OUT == RS_PAIR) sval[p] = v[j];
   }
   __syncthreads();
   const uint32_t len = (uint32_t)min<int64_t>(RS_TILE, n - tbase);
@@ -125,9 +134,18 @@ __global__ __launch_bounds__(RS_WG) void rs_scatter_kernel(
     const uint32_t p = j * RS_WG + threadIdx.x;
     if (p < len) {
       const uint64_t kk = skey[p];
-      const int64_t g = gbase[(uint32_t)(kk >> shift) & 255u] + p;
-      keys_out[g] = kk;
-      vals_out[g] = sval[p];
+      // digit of the staged record: a freshly packed word carries the key at bit 32 - key_lo
+      const int sh = (IN == RS_PAIR && OUT == RS_PACKED) ? shift - key_lo + 32 : shift;
+      const int64_t g = gbase[(uint32_t)(kk >> sh) & 255u] + p;
+      if (OUT == RS_PACKED) {
+        keys_out[g] = kk;
+      } else if (IN == RS_PACKED) {
+        keys_out[g] = ((kk >> 32) << key_lo) | key_const;
+        vals_out[g] = (uint32_t)kk;
+      } else {
+        keys_out[g] = kk;
+        vals_out[g] = sval[p];
+      }
     }
   }
 }
@@ -146,6 +164,7 @@ __global__ __launch_bounds__(256) void rs_diff_kernel(const uint64_t *__restrict
   }
   for (int m = 32; m >= 1; m >>= 1) d |= shfl_xor_u64(d, m);
   if (lane_id() == 0 && d) atomicOr(diff_or, (unsigned long long)d);
+  if (blockIdx.x == 0 && threadIdx.x == 0) diff_or[1] = k0; // the bits all keys share are read off any key
 }
 
 void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int begin_bit,
@@ -156,13 +175,15 @@ void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int b
   // Passes over bytes on which no two keys differ would be the identity (stable): skip them.
   // One extra read of the keys (8 B/row) against 32 B/row per skipped pass; worth asking when
   // more than two passes are requested (int64 sort keys of a 31-bit column: 8 passes -> 4).
-  uint64_t varying = ~0ull;
+  uint64_t varying = ~0ull, key0 = 0;
   if (end_bit - begin_bit > 16 && n >= (1 << 16)) {
-    BufP diff = ctx->alloc_zero(8);
+    BufP diff = ctx->alloc_zero(16);
     unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 4 * (int64_t)ctx->num_cus);
     rs_diff_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(keys, n, diff->as<unsigned long long>());
     SQ_HIP(hipGetLastError());
-    varying = ctx->fetch_value(diff->as<uint64_t>());
+    const uint64_t *h = (const uint64_t *)ctx->fetch(diff->p, 16);
+    varying = h[0];
+    key0 = h[1];
   }
   int64_t nblocks = ceil_div(n, RS_TILE);
   BufP k2 = ctx->alloc(8 * (size_t)n), v2 = ctx->alloc(4 * (size_t)n);
@@ -170,15 +191,43 @@ void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int b
   BufP total = ctx->alloc(8);
   uint64_t *ka = keys, *kb = k2->as<uint64_t>();
   uint32_t *va = vals, *vb = v2->as<uint32_t>();
-  for (int shift = begin_bit; shift < end_bit; shift += 8) {
-    if (((varying >> shift) & 0xff) == 0) continue;
-    rs_hist_kernel<<<dim3((unsigned)nblocks), dim3(RS_WG), 0, ctx->stream>>>(ka, n, shift, nblocks,
+  std::vector<int> shifts;
+  for (int shift = begin_bit; shift < end_bit; shift += 8)
+    if (((varying >> shift) & 0xff) != 0) shifts.push_back(shift);
+  // packed records between the first and the last pass: the varying key bits (known exactly when
+  // the diff pass ran) must fit 32 bits next to the 32-bit row id
+  int key_lo = 0;
+  uint64_t key_const = 0;
+  bool packed = false;
+  if (varying != ~0ull && varying != 0 && shifts.size() >= 2) {
+    key_lo = shifts.front();
+    int key_hi = 64 - __builtin_clzll(varying);
+    const bool low_bits_constant = key_lo == 0 || (varying & ((1ull << key_lo) - 1)) == 0;
+    if (key_hi - key_lo <= 32 && low_bits_constant) {
+      packed = true;
+      uint64_t k0 = key0; // constant bits come from any key
+      uint64_t span = (key_hi - key_lo == 64) ? ~0ull : (((1ull << (key_hi - key_lo)) - 1) << key_lo);
+      key_const = k0 & ~span;
+    }
+  }
+  for (size_t pi = 0; pi < shifts.size(); pi++) {
+    const int shift = shifts[pi];
+    const bool in_packed = packed && pi > 0, out_packed = packed && pi + 1 < shifts.size();
+    const int eff = in_packed ? shift - key_lo + 32 : shift; // where the digit sits in what this pass reads
+    rs_hist_kernel<<<dim3((unsigned)nblocks), dim3(RS_WG), 0, ctx->stream>>>(ka, n, eff, nblocks,
                                                                             hist->as<uint32_t>());
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(),
                        total->as<uint64_t>());
-    rs_scatter_kernel<<<dim3((unsigned)nblocks), dim3(RS_WG), 0, ctx->stream>>>(
-        ka, va, n, shift, nblocks, offs->as<uint32_t>(), kb, vb);
+    dim3 g((unsigned)nblocks), b(RS_WG);
+    if (!in_packed && !out_packed)
+      rs_scatter_kernel<RS_PAIR, RS_PAIR><<<g, b, 0, ctx->stream>>>(ka, va, n, shift, nblocks, offs->as<uint32_t>(), kb, vb, 0, 0);
+    else if (!in_packed)
+      rs_scatter_kernel<RS_PAIR, RS_PACKED><<<g, b, 0, ctx->stream>>>(ka, va, n, shift, nblocks, offs->as<uint32_t>(), kb, vb, key_lo, key_const);
+    else if (out_packed)
+      rs_scatter_kernel<RS_PACKED, RS_PACKED><<<g, b, 0, ctx->stream>>>(ka, va, n, eff, nblocks, offs->as<uint32_t>(), kb, vb, key_lo, key_const);
+    else
+      rs_scatter_kernel<RS_PACKED, RS_PAIR><<<g, b, 0, ctx->stream>>>(ka, va, n, eff, nblocks, offs->as<uint32_t>(), kb, vb, key_lo, key_const);
     SQ_HIP(hipGetLastError());
     std::swap(ka, kb);
     std::swap(va, vb);
