@@ -280,12 +280,18 @@ __global__ __launch_bounds__(BLOCK) void join_probe_unique_kernel(
 // filter_cmp_const_kernel, select.hip: with 2048-row tiles the probe ran at the look-back's pace,
 // ~47 tiles/us = 97 Grows/s, not at the memory system's).
 constexpr int JD_WAVES = 8;
-constexpr int JD_ITEMS = 32;
+#ifndef JD_ITEMS_N
+#define JD_ITEMS_N 32
+#endif
+#ifndef JD_OCC
+#define JD_OCC 2
+#endif
+constexpr int JD_ITEMS = JD_ITEMS_N;
 constexpr int JD_TILE = JD_WAVES * JD_ITEMS * 64;
 constexpr int JD_BLOCK = (JD_WAVES + 1) * 64;
 
 template <bool HASV>
-__global__ __launch_bounds__(JD_BLOCK, 2) void join_probe_dense_kernel(
+__global__ __launch_bounds__(JD_BLOCK, JD_OCC) void join_probe_dense_kernel(
     const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n, int64_t num_tiles,
     DenseTable dt, uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx, uint64_t *desc,
     unsigned *ticket, uint64_t *total, int use_ticket) {
