@@ -527,10 +527,9 @@ static void build_table(sqlrs_hash_join *j) {
   //    first: when the build keys turn out unique nothing else is needed, and the 16-byte-slot
   //    hash table (1.1 ms for 1e7 keys) is never built.
   if (j->exact && n > 0 && j->key_dtype != SQLRS_FLOAT64) {
-    BufP mm = ctx->alloc(16);
-    uint64_t init[2] = {~0ull, 0ull};
-    SQ_HIP(hipMemcpyAsync(mm->p, init, 16, hipMemcpyHostToDevice, ctx->stream));
-    ctx->sync();
+    BufP mm = ctx->alloc(16); // {min = ~0, max = 0} without a host round trip
+    SQ_HIP(hipMemsetAsync(mm->p, 0xff, 8, ctx->stream));
+    SQ_HIP(hipMemsetAsync(mm->as<uint8_t>() + 8, 0, 8, ctx->stream));
     const uint64_t *vp = validity ? validity->as<uint64_t>() : nullptr;
     unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256), 1024);
     key_minmax_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n,
@@ -547,18 +546,20 @@ static void build_table(sqlrs_hash_join *j) {
         SQ_HIP(hipMemsetAsync(dense->p, 0xff, 4 * (size_t)range + 8, ctx->stream));
         uint64_t dmin = lo ^ (1ull << 63); // back from the ordered image to the two's complement bits
         uint32_t *null_head = dense->as<uint32_t>() + range; // spare slot after the table
-        BufP dup = ctx->alloc_zero(8);
+        BufP dup = ctx->alloc_zero(8); // {duplicate flag (int), copy of the NULL row's head (u32)}
         dense_fill_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
             keys->as<uint64_t>(), vp, n, dmin, dense->as<uint32_t>(), null_head);
         dense_verify_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
             keys->as<uint64_t>(), vp, n, dmin, dense->as<uint32_t>(), null_head, dup->as<int>());
+        SQ_HIP(hipMemcpyAsync(dup->as<uint32_t>() + 1, null_head, 4, hipMemcpyDeviceToDevice, ctx->stream));
         SQ_HIP(hipGetLastError());
-        if (ctx->fetch_value(dup->as<int>()) == 0) {
+        const uint32_t *hd = (const uint32_t *)ctx->fetch(dup->p, 8); // one round trip for both
+        if (hd[0] == 0) {
           j->unique = true;
           j->dense = dense;
           j->dense_min = dmin;
           j->dense_range = range;
-          j->dense_null_head = ctx->fetch_value(null_head);
+          j->dense_null_head = hd[1];
           return;
         }
       }
