@@ -694,3 +694,27 @@ def test_lookback_ticket_fallback_paths():
                         "-k", "(test_filter or test_hash_join) and not fallback"],
                        env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_f64_keys_compare_by_bit_pattern(hip, oracle):
+    """hash_utils.rs:124-131: f64 keys are hashed by their bits, so -0.0 and +0.0 are different keys
+    and NaNs with different payloads are different keys — group-by and join."""
+    import struct
+    nan1 = struct.unpack("<d", struct.pack("<Q", 0x7FF8000000000001))[0]
+    nan2 = struct.unpack("<d", struct.pack("<Q", 0x7FF8000000000002))[0]
+    vals = [0.0, -0.0, nan1, nan2, 1.5, -0.0, nan1, 0.0, nan2, nan2]
+    k = pa.array(np.array(vals, dtype=np.float64))
+    b = pa.RecordBatch.from_arrays([k, pa.array(np.arange(len(vals), dtype=np.int64))], names=["k", "v"])
+    aggs = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.INT64)]
+    got = list(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())[0]
+    exp = list(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())[0]
+    bits = lambda t: [struct.unpack("<Q", struct.pack("<d", x))[0] for x in t.column(0).to_pylist()]
+    assert bits(got) == bits(exp) and len(bits(got)) == 5
+    assert got.column(1).to_pylist() == exp.column(1).to_pylist() == [2, 2, 2, 3, 1]
+    assert got.column(2).to_pylist() == exp.column(2).to_pylist()
+    lb = pa.RecordBatch.from_arrays([pa.array(np.array([0.0, nan1, 2.0])), pa.array([10, 20, 30])], names=["k", "x"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, b)
+    gj = rows_of(HashJoinExecutor(hip, [lb], [b], "inner", cond, sch, 2).execute())
+    ej = rows_of(HashJoinExecutor(oracle, [lb], [b], "inner", cond, sch, 2).execute())
+    assert [(r[1], r[3]) for r in gj] == [(r[1], r[3]) for r in ej] == [(10, 0), (20, 2), (20, 6), (10, 7)]  # +0.0 and nan1 rows only
