@@ -565,10 +565,9 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   const bool nullable = in.key_validity || in.val_validity[0] || in.val_validity[1];
   if (!nullable && spec.nv <= 1 && !(join_mode && in.join_validity)) {
     if (join_mode) {
-      BufP mm = ctx->alloc(16);
-      uint64_t init[2] = {~0ull, 0ull};
-      SQ_HIP(hipMemcpyAsync(mm->p, init, 16, hipMemcpyHostToDevice, ctx->stream));
-      ctx->sync();
+      BufP mm = ctx->alloc(16); // {min = ~0, max = 0}
+      SQ_HIP(hipMemsetAsync(mm->p, 0xff, 8, ctx->stream));
+      SQ_HIP(hipMemsetAsync(mm->as<uint8_t>() + 8, 0, 8, ctx->stream));
       unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(in.join_n, 1024), 1024);
       key_range_kernel<<<dim3(std::max(blocks, 1u)), dim3(256), 0, ctx->stream>>>(
           in.join_keys, in.join_n, mm->as<unsigned long long>());
@@ -746,7 +745,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     }
     SQ_HIP(hipGetLastError());
   }
-  ctx->sync(); // `work` (host) was the source of an async upload
+  // (`work` on the host was the source of an async upload: the fetch below synchronises)
   const uint64_t *h = (const uint64_t *)ctx->fetch(ctr->p, 32);
   out->groups = (int64_t)h[0];
   out->n_overflow = (int64_t)h[1];

@@ -505,7 +505,8 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
 #undef SQ_RP
       SQ_HIP(hipGetLastError());
     }
-    ctx->sync(); // the host vectors of `L` were the source of async uploads
+    // the host vectors of `L` were the source of async uploads: they move (buffers and all) into
+    // the caller's Level, which outlives the bucket_starts() synchronisation that follows
     *offs_out = offs;
     *plan_out = std::move(L);
   };
