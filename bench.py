@@ -298,6 +298,8 @@ def main():
             part.release()
             a = C.c_void_p()
             be.check(be.fn("hash_agg_create")(be.ctx, 1, merge_gb, 2, merge_aggs, C.byref(a)))
+            # a global first-seen order does not exist across ranks: no ordering pass
+            be.check(be.fn("hash_agg_set_group_order")(a, abi.GROUP_ORDER_ANY))
             mb = device_batch(abi, [rk, rc, rs], [abi.INT64, abi.INT64, abi.FLOAT64])
             be.check(be.fn("hash_agg_push")(a, mb.ptr))
             ao = C.POINTER(abi.Batch)()
