@@ -584,8 +584,26 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
             pg.col_nullable.push_back(pin.val_validity[k] != nullptr);
             pg.col_dtype.push_back(pcols[k].dtype);
           }
-          for (const DCol &kc : kcols) // key values of every group of the batch (hash_agg.rs:90-96)
-            pg.keyvals.push_back(gather_column(ctx, kc, po.gfirst->p, false, nullptr, po.groups));
+          // key values of every group of the batch (hash_agg.rs:90-96).  One exactly-compared 8-byte
+          // key column: the normalised key IS the value (int64 / f64 bit pattern), no gather needed
+          // (a random gather of 1e7 keys costs 0.25 ms)
+          if (nk.exact && kcols.size() == 1 && (kcols[0].dtype == SQLRS_INT64 || kcols[0].dtype == SQLRS_FLOAT64) &&
+              kcols[0].dtype == nk.dtype) {
+            DCol kv;
+            kv.dtype = kcols[0].dtype;
+            kv.length = po.groups;
+            kv.values = po.gkey->p;
+            kv.own_values = po.gkey;
+            if (po.gvalid_bits) {
+              kv.validity = po.gvalid_bits->as<uint64_t>();
+              kv.own_validity = po.gvalid_bits;
+              kv.null_count = -1;
+            }
+            pg.keyvals.push_back(kv);
+          } else {
+            for (const DCol &kc : kcols)
+              pg.keyvals.push_back(gather_column(ctx, kc, po.gfirst->p, false, nullptr, po.groups));
+          }
           pg.po = po;
           if (a->st.ngroups == 0 && po.n_overflow == 0 && !po.may_dup)
             a->pending = std::move(pg); // nothing to merge with yet: defer building the table
