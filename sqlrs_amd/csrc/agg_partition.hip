@@ -5,16 +5,17 @@
 // 60x off the HBM roofline.  Rows are therefore radix-partitioned by key hash into P buckets
 // small enough that each bucket's groups fit one workgroup's LDS hash table:
 //
-//   key_stats   : HyperLogLog over the keys -> estimated group count -> P        ( 8 B/row read)
-//   part_hist   : per tile (65536 rows) bucket histogram -> matrix [P][tiles]    ( 8 B/row read)
-//   scan        : exclusive scan of the matrix = every (bucket, tile) run start
-//   part_scatter: rows -> (key, row id, values) in bucket order                  (8+8v read, 12+8v written)
-//   lds_agg     : one workgroup per bucket: open-addressing table in LDS (64-bit ds CAS to
-//                 claim a slot, ds_add/ds_min/ds_max on the accumulator cells), then the
-//                 occupied slots are written out as (key, first row, accumulators)  (12+8v read)
+//   key_stats : HyperLogLog (sampled) + min/max of the keys -> estimated group count -> P,
+//               and whether (key, row id) can be packed into one word               ( 8 B/row read)
+//   partition : radix_part.hip, one or two levels of LDS-staged multi-split: rows -> (key|row,
+//               values) in bucket order                       (per level: 8 B hist + 32 B scatter)
+//   lds_agg   : one workgroup per bucket: open-addressing table in LDS (64-bit ds CAS to claim a
+//               slot, ds_add/ds_min/ds_max on the accumulator cells), then the occupied slots
+//               are written out as (key, first row, accumulators)                  (16 B/row read)
 //
-// The per-batch groups are merged into the operator state by the ordinary resolve path
-// (agg.hip) with explicit first-row ids and pre-aggregated weights: O(groups) atomics.
+// While nothing else has been pushed the batch's groups ARE the operator state (hashagg_op.hip
+// emits them directly); otherwise they are merged into the global table by the ordinary resolve
+// path (agg.hip) with explicit first-row ids and pre-aggregated weights: O(groups) atomics.
 // Rows whose bucket table overflows (estimate too low) are returned to the caller and take
 // the resolve path directly, so the result never depends on the estimate.
 #include <cstdlib>

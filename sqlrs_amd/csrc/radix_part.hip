@@ -1,15 +1,16 @@
 // radix_part.hip — LDS-staged hash partitioning of rows (key, up to two 8-byte values, row id,
-// validity flags) into P buckets, one or two levels of <= 256-way multi-split.
+// validity flags) into P buckets, one or two levels of <= 512-way multi-split.
 //
 // Direct scattered stores run at the random-access rate of the memory system (~90 G stores/s
 // on MI355X, profiles/r01_ubench_mi355x.txt) no matter how the lines fill up later, so each
-// tile of 4096 rows is first sorted by bucket inside LDS and then written as bucket-contiguous
-// runs: consecutive lanes store consecutive addresses.  With <= 256 buckets per pass a run is
-// >= 16 rows = one full 128-byte line per 8-byte column.
+// tile of 6144 rows is first sorted by bucket inside LDS and then written as bucket-contiguous
+// runs: consecutive lanes store consecutive addresses (256 digits: runs of ~24 rows).
 //
 // Per level:  hist (8 B/row read: keys) -> exclusive scan of the [segment][digit][tile] count
 // matrix = start of every run -> scatter (all columns read once, written once).
 // Level 2 splits every level-1 bucket again (MSD order), giving up to 65536 buckets.
+// When the key range is known the row id rides in the key word (KeyPack, radix_part.hpp):
+// 16 instead of 20 bytes per row.
 #include <cstdlib>
 
 #include "device_utils.hpp"
@@ -17,11 +18,10 @@
 
 namespace sq {
 
-// rows per thread are a template parameter: tile = WG * ROWS rows.  Measured on MI355X (C5,
-// 5e8 rows, 256 digits): 2048-row tiles 9.3 ms/pass, 4096-row tiles 6.8 ms/pass — run length
-// (rows per digit per tile) matters more than workgroups per CU.
-// WG = 256 (2048-row tiles, ~51 KiB LDS with one value column: three workgroups per CU) for
-// up to 256 digits; WG = 512 (4096-row tiles) for a single level of up to 512 digits.
+// rows per thread are a template parameter: tile = 512 * ROWS rows.  Run length (rows per digit
+// per tile) matters more than workgroups per CU: 6144-row tiles with one workgroup per CU beat
+// 3072- and 4096-row tiles with two (measured on C5, both before and after the kernel was made
+// branch-free).
 
 struct Tile {
   int64_t start;
