@@ -1,11 +1,13 @@
 // hashagg_op.hip — HashAggExecutor entry points (src/executor/aggregate/hash_agg.rs:32-150).
 //
-// push() takes one of two routes per batch:
-//   * row route      (small batches): every row resolves to its group through the global table
+// push() stages the batch (HashAgg is blocking; a first batch of >= 2^26 rows is taken in place);
+// staged rows are aggregated together at finish() / every 2^28 rows by one of two routes:
+//   * row route      (small inputs): every row resolves to its group through the global table
 //                    and updates the dense accumulators with global atomics (agg.hip);
 //   * partition route (>= 2^21 rows, COUNT/SUM/MIN/MAX over <= 2 argument columns): rows are
-//                    pre-aggregated per LDS bucket (agg_partition.hip) and only the batch's
-//                    groups go through the row route, carrying pre-aggregated cells.
+//                    pre-aggregated per LDS bucket (agg_partition.hip); the resulting groups are
+//                    the operator state as they are, or go through the row route carrying
+//                    pre-aggregated cells when the table already holds groups.
 // Both leave the same state; finish() emits groups in first-seen order (hash_agg.rs:98,132).
 #include <cstdlib>
 

@@ -1,16 +1,21 @@
 // join.hip — HashJoinExecutor on device (src/executor/join/hash_join.rs:146-323).
 //
-// Build (left child): open-addressing table in HBM, 16-byte slots {key, head, count}, linear
-// probing, slots claimed with one 64-bit CAS on the key.  Unique build keys (the PK-FK case,
-// detected during the build) store the build row directly in `head`; otherwise rows of one
-// key are laid out CSR-style in insertion order (stable radix sort by slot), which is what
-// makes the output pair order equal to the reference's Vec<usize> per hash (:172-177).
+// Build (left child): integer keys that cover a small range (a dimension table's surrogate keys)
+// get a direct-address table heads[key - min] = row, verified to be duplicate-free; anything
+// else an open-addressing table in HBM, 16-byte slots {key, head, count}, linear probing, slots
+// claimed with one 64-bit CAS on the key.  Unique build keys (the PK-FK case) store the build
+// row directly; otherwise rows of one key are laid out CSR-style in insertion order (stable
+// radix sort by slot), which is what makes the output pair order equal to the reference's
+// Vec<usize> per hash (:172-177).
 //
-// Probe (right child): count matches per probe row -> exclusive scan -> fill, so pairs come
-// out probe-row major / build-insertion minor exactly like the reference loop (:225-248).
+// Probe (right child): unique build keys -> one lookup per probe row, hits compacted with ballots
+// and a decoupled look-back in a single pass; duplicates -> count matches per probe row ->
+// exclusive scan -> fill.  Either way pairs come out probe-row major / build-insertion minor
+// exactly like the reference loop (:225-248).
 // Algorithmic HBM bytes: 8 B per build row + 8 B per probe row + 12 B per emitted pair.
-// The table (16 B x 2 x build rows) is the random-access working set: at 1 M build rows it is
-// 32 MiB, i.e. L2 + Infinity-Cache resident (profiles/r01_ubench_mi355x.txt: ~66 G lookups/s).
+// The random-access working set is the table: 4 B x key range (direct-address, 4 MiB for 1e6
+// keys = one XCD's L2, ~265 G lookups/s) or 16 B x 2 x build rows (hash table, ~56-66 G
+// lookups/s once it exceeds the L2; profiles/r01_ubench_mi355x.txt).
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "prims.hpp"
