@@ -718,3 +718,26 @@ def test_f64_keys_compare_by_bit_pattern(hip, oracle):
     gj = rows_of(HashJoinExecutor(hip, [lb], [b], "inner", cond, sch, 2).execute())
     ej = rows_of(HashJoinExecutor(oracle, [lb], [b], "inner", cond, sch, 2).execute())
     assert [(r[1], r[3]) for r in gj] == [(r[1], r[3]) for r in ej] == [(10, 0), (20, 2), (20, 6), (10, 7)]  # +0.0 and nan1 rows only
+
+
+@pytest.mark.parametrize("parts", [2, 8, 200])
+@pytest.mark.parametrize("ncols,kcol", [(1, 0), (2, 0), (3, 1), (3, 2)])
+def test_hash_partition_fast_path(hip, parts, ncols, kcol):
+    """up to three 8-byte columns without NULLs: the stable LDS-staged multi-split; partitions, their
+    sizes and the row order inside each must equal the host restatement (stable argsort)."""
+    from sqlrs_amd import distributed as D
+    rng = np.random.default_rng(parts * 10 + ncols + kcol)
+    n = 300_017
+    cols = [rng.integers(-10**12, 10**12, n, dtype=np.int64) if c != 1 else rng.random(n) for c in range(ncols)]
+    if kcol == 1:
+        cols[1] = rng.integers(0, 10**6, n, dtype=np.int64)
+    b = pa.RecordBatch.from_arrays([pa.array(c) for c in cols], names=[f"c{i}" for i in range(ncols)])
+    out, offs = hip.hash_partition(b, InputRef(kcol), parts, abi.MEM_DEVICE)
+    got = hip.to_host(out).to_arrow([f"c{i}" for i in range(ncols)])
+    keys = cols[kcol].astype(np.int64)
+    pid = D.partition_of(keys, parts, np.ones(n, dtype=bool))
+    order = np.argsort(pid, kind="stable")
+    exp_offs = [0] + list(np.cumsum(np.bincount(pid, minlength=parts)))
+    assert [int(x) for x in offs] == [int(x) for x in exp_offs]
+    for c in range(ncols):
+        assert (got.column(c).to_numpy() == cols[c][order]).all()
