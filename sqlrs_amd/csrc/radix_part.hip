@@ -74,7 +74,7 @@ __global__ __launch_bounds__(RP_WG) void rp_hist_kernel(const uint64_t *__restri
       int64_t r = t.start + o;
       bool valid = PLAIN ? true : (flags ? (flags[r] & 1) : (!key_validity || ((key_validity[r >> 6] >> (r & 63)) & 1)));
       uint64_t key = PLAIN ? k[j] : keys[r];
-      if (kp.kbits) key = packed_key(kp, key); // level >= 2 of a packed partition
+      if (kp.kbits) key = level == 1 ? packed_clamp(kp, key) : packed_key(kp, key); // packed partition
       atomicAdd(&h[rp_digit(rp_bucket(key, valid, P), level, p2_bits)], 1u);
     }
   }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
   auto rank_row = [&](int j, uint32_t len) {
     dg[j] = 0xffffffffu;
     if ((uint32_t)(j * RP_WG) + threadIdx.x < len) {
-      const uint64_t key = (PACK && MODE == RP_LN) ? packed_key(kp, cur.k[j]) : cur.k[j];
+      const uint64_t key = !PACK ? cur.k[j] : (MODE == RP_LN ? packed_key(kp, cur.k[j]) : packed_clamp(kp, cur.k[j]));
       dg[j] = rp_digit(rp_bucket(key, cur.fl[j] & 1, P), level, p2_bits);
       rk[j] = atomicAdd(&cnt[dg[j]], 1u);
     }
@@ -451,7 +451,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     unsigned nt = L.num_tiles;
     {
       ProfScope ps(ctx, in.build_side ? "rp_hist_build" : "rp_hist");
-#define SQ_RH1(R, PL) rp_hist_kernel<512, R, PL><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, (const Tile *)tiles->p, P, p2_bits, level, digits, mat->as<uint32_t>(), level == 1 ? KeyPack() : kp)
+#define SQ_RH1(R, PL) rp_hist_kernel<512, R, PL><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, (const Tile *)tiles->p, P, p2_bits, level, digits, mat->as<uint32_t>(), kp)
 #define SQ_RH(R) do { if (!rin.key_validity && !rin.flags) SQ_RH1(R, true); else SQ_RH1(R, false); } while (0)
       if (ROWS == 12) SQ_RH(12); else if (ROWS == 8) SQ_RH(8); else SQ_RH(6);
 #undef SQ_RH

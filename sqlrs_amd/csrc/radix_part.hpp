@@ -20,6 +20,14 @@ __device__ __forceinline__ uint64_t pack_key_row(const KeyPack &kp, uint64_t key
   return (off < kp.kmask ? off : kp.kmask) | ((uint64_t)row << kp.kbits);
 }
 __device__ __forceinline__ uint64_t packed_key(const KeyPack &kp, uint64_t w) { return (w & kp.kmask) + kp.kmin; }
+// the key a row will carry once it is packed (out-of-range keys become the sentinel key): every
+// pass of a packed partition must derive the row's bucket from THIS key, also the passes that
+// still read the unpacked column — otherwise the first level counts and places a row by one key
+// and writes it by another
+__device__ __forceinline__ uint64_t packed_clamp(const KeyPack &kp, uint64_t key) {
+  uint64_t off = key - kp.kmin;
+  return (off < kp.kmask ? off : kp.kmask) + kp.kmin;
+}
 __device__ __forceinline__ uint32_t packed_row(const KeyPack &kp, uint64_t w) { return (uint32_t)(w >> kp.kbits); }
 #endif
 

@@ -116,7 +116,7 @@ def test_fuzz_order(hip, oracle, seed):
     assert_same(rows_of(OrderExecutor(hip, ob, bs).execute()), rows_of(OrderExecutor(oracle, ob, bs).execute()))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 + _EXTRA // 10))
 def test_fuzz_hash_agg_partition_route(hip, oracle, seed):
     """batches above 2^21 rows: LDS-partitioned pre-aggregation (packed and unpacked rows, NULLs,
     one or two value columns, skewed keys, several batches staged together)"""
@@ -144,7 +144,7 @@ def test_fuzz_hash_agg_partition_route(hip, oracle, seed):
                 rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], bs).execute()), float_cols=fl)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 + _EXTRA // 10))
 def test_fuzz_join_agg(hip, oracle, seed):
     """HashJoinAgg (fused where it applies, composed otherwise) vs HashAgg(HashJoin) on the oracle"""
     from sqlrs_amd.executor import HashJoinAggExecutor

@@ -741,3 +741,23 @@ def test_hash_partition_fast_path(hip, parts, ncols, kcol):
     assert [int(x) for x in offs] == [int(x) for x in exp_offs]
     for c in range(ncols):
         assert (got.column(c).to_numpy() == cols[c][order]).all()
+
+
+@pytest.mark.parametrize("npb", [150_000, 2_300_000])
+def test_join_agg_probe_keys_outside_build_range(hip, oracle, npb):
+    """Fused route with (key, row) packing: probe keys below / above every build key are stored as the
+    sentinel key; every pass must place such a row by that same key (a mismatch between the first
+    level's rank and its store once overwrote neighbouring rows)."""
+    from sqlrs_amd.executor import HashJoinAggExecutor
+    rng = np.random.default_rng(npb)
+    lkeys = (1000 + rng.permutation(28_000)[:3000]).astype(np.int64)
+    lb = pa.RecordBatch.from_arrays([pa.array(lkeys), pa.array(rng.integers(0, 9, 3000, dtype=np.int64))], names=["k", "x"])
+    rb = pa.RecordBatch.from_arrays([pa.array(rng.integers(-500, 30_500, npb, dtype=np.int64)), pa.array(rng.random(npb))], names=["k", "v"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64)]
+    ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
+    got = rows_of(ex.execute())
+    assert ex.fused_batches == 1
+    exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
+    assert_same(got, exp, float_cols={2})
