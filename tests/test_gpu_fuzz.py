@@ -169,3 +169,49 @@ def test_fuzz_join_agg(hip, oracle, seed):
     join = HashJoinExecutor(oracle, [lb], rbs, "inner", cond, sch, 2)
     exp = rows_of(HashAggExecutor(oracle, aggs, gb, join.execute()).execute())
     assert_same(got, exp, float_cols={2})
+
+
+@pytest.mark.parametrize("seed", range(8 + _EXTRA // 20))
+def test_fuzz_hash_agg_partition_route_composite_keys(hip, oracle, seed):
+    """large batches whose group key is not one plain int64 column: two key columns (hash-only
+    matching like the reference), f64 keys, i32 keys, a key expression"""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([2_100_000, 2_500_000]))
+    kind = str(rng.choice(["two_cols", "f64", "i32", "expr"]))
+    card = int(rng.choice([50, 3000, 100_000]))
+    nulls = float(rng.choice([0.0, 0.03]))
+    m = lambda: (rng.random(n) < nulls) if nulls else None
+    k1 = pa.array(rng.integers(0, card, n, dtype=np.int64), mask=m())
+    k2 = pa.array(rng.integers(0, 7, n, dtype=np.int32), mask=m())
+    kf = pa.array(np.floor(rng.random(n) * card) - card / 2, mask=m())
+    v = pa.array(rng.random(n), mask=m())
+    b = pa.RecordBatch.from_arrays([k1, k2, kf, v], names=["k1", "k2", "kf", "v"])
+    gb = {"two_cols": [InputRef(0), InputRef(1)], "f64": [InputRef(2)], "i32": [InputRef(1)],
+          "expr": [InputRef(0) + Constant(5, abi.INT64)]}[kind]
+    aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64)]
+    if rng.random() < 0.5:
+        aggs.append(AggFunc("max", InputRef(3), abi.FLOAT64))
+    bs = [b] if rng.random() < 0.5 else [b.slice(0, n // 2), b.slice(n // 2)]
+    nk = len(gb)
+    assert_same(rows_of(HashAggExecutor(hip, aggs, gb, bs).execute()),
+                rows_of(HashAggExecutor(oracle, aggs, gb, bs).execute()), float_cols={nk + 1})
+
+
+@pytest.mark.parametrize("seed", range(8 + _EXTRA // 20))
+def test_fuzz_filter_and_order_large(hip, oracle, seed):
+    rng = np.random.default_rng(8000 + seed)
+    n = int(rng.choice([200_000, 1_000_003]))
+    nulls = float(rng.choice([0.0, 0.1]))
+    a = pa.array(rng.integers(-(1 << int(rng.choice([8, 20, 40]))), 1 << int(rng.choice([8, 20, 40])), n, dtype=np.int64),
+                 mask=(rng.random(n) < nulls) if nulls else None)
+    f = pa.array(rng.normal(0, 100, n), mask=(rng.random(n) < nulls) if nulls else None)
+    b = pa.RecordBatch.from_arrays([a, f, pa.array(np.arange(n))], names=["a", "f", "i"])
+    thr = float(rng.normal(0, 80))
+    e = BinaryOp(str(rng.choice([">", "<=", "!="])), InputRef(1), Constant(thr, abi.FLOAT64))
+    bs = _split(rng, b)
+    assert_same(rows_of(FilterExecutor(hip, e, bs).execute()), rows_of(FilterExecutor(oracle, e, bs).execute()))
+    ob = [OrderBy(InputRef(0), bool(rng.random() < 0.5))]
+    if rng.random() < 0.5:
+        ob.append(OrderBy(InputRef(1), bool(rng.random() < 0.5)))
+    sub = b.slice(0, 300_000)
+    assert_same(rows_of(OrderExecutor(hip, ob, [sub]).execute()), rows_of(OrderExecutor(oracle, ob, [sub]).execute()))
