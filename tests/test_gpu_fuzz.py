@@ -156,7 +156,11 @@ def test_fuzz_join_agg(hip, oracle, seed):
     lkeys = rng.permutation(card)[:nb].astype(np.int64) if unique else rng.integers(0, card, nb, dtype=np.int64)
     lb = pa.RecordBatch.from_arrays([pa.array(lkeys), pa.array(rng.integers(0, 9, nb, dtype=np.int64))], names=["k", "x"])
     nulls = float(rng.choice([0.0, 0.04]))
-    rb = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, card, npb, dtype=np.int64), mask=(rng.random(npb) < nulls) if nulls else None),
+    pk = rng.integers(0, card, npb, dtype=np.int64)
+    if rng.random() < 0.4:  # heavy hitters: skewed buckets are split and merged through the per-bucket global tables
+        pk[rng.random(npb) < 0.6] = lkeys[int(rng.integers(0, nb))] if rng.random() < 0.7 else card + 5
+        pk[rng.random(npb) < 0.1] = lkeys[int(rng.integers(0, nb))]
+    rb = pa.RecordBatch.from_arrays([pa.array(pk, mask=(rng.random(npb) < nulls) if nulls else None),
                                      pa.array(rng.random(npb), mask=(rng.random(npb) < nulls) if nulls else None)], names=["k", "v"])
     cond = JoinCondition([(InputRef(0), InputRef(0))])
     sch = join_schema(lb, rb)
