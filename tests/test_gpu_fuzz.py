@@ -219,3 +219,42 @@ def test_fuzz_filter_and_order_large(hip, oracle, seed):
         ob.append(OrderBy(InputRef(1), bool(rng.random() < 0.5)))
     sub = b.slice(0, 300_000)
     assert_same(rows_of(OrderExecutor(hip, ob, [sub]).execute()), rows_of(OrderExecutor(oracle, ob, [sub]).execute()))
+
+
+@pytest.mark.parametrize("seed", range(6 + _EXTRA // 20))
+def test_fuzz_hash_agg_distinct_and_utf8_keys(hip, oracle, seed):
+    """DISTINCT aggregates (de-duplicating sub-aggregation) and Utf8 group keys (hash-only matching),
+    medium to large inputs, several batches"""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([5_000, 120_000, 2_150_000]))
+    card = int(rng.choice([3, 200, 20_000]))
+    nulls = float(rng.choice([0.0, 0.05]))
+    m = lambda: (rng.random(n) < nulls) if nulls else None
+    ik = pa.array(rng.integers(0, card, n, dtype=np.int64), mask=m())
+    sk = pa.array([f"k{v % 977}" for v in rng.integers(0, card, n)], type=pa.string(), mask=m()) if n <= 120_000 else None
+    v = pa.array(rng.integers(0, 40, n, dtype=np.int64), mask=m())
+    f = pa.array(np.round(rng.random(n) * 8), mask=m())
+    use_utf8 = sk is not None and rng.random() < 0.5
+    b = pa.RecordBatch.from_arrays([sk if use_utf8 else ik, v, f], names=["k", "v", "f"])
+    aggs = [AggFunc("count", InputRef(1), abi.INT64, distinct=True), AggFunc("sum", InputRef(1), abi.INT64, distinct=True),
+            AggFunc("count", InputRef(2), abi.INT64), AggFunc("sum", InputRef(2), abi.FLOAT64, distinct=bool(rng.random() < 0.5))]
+    aggs = [aggs[i] for i in sorted(rng.choice(4, int(rng.integers(1, 5)), replace=False))]
+    bs = _split(rng, b)
+    fl = {1 + i for i, a in enumerate(aggs) if a.return_type == abi.FLOAT64}
+    assert_same(rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], bs).execute()),
+                rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], bs).execute()), float_cols=fl)
+
+
+@pytest.mark.gpu
+def test_fuzz_hash_agg_with_early_flushes():
+    """SQLRS_STAGE_FLUSH_ROWS=600000: staged batches are aggregated several times before finish, so
+    groups of an earlier flush are merged with later ones (deferred groups -> table, table growth);
+    the large-batch fuzz families run under it (hook read once per process, hence the subprocess)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SQLRS_STAGE_FLUSH_ROWS="600000", SQLRS_STAGE_DIRECT_ROWS="1000000000000")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "(partition_route or distinct_and_utf8 or fuzz_hash_agg[) and not early_flushes"],
+                       env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
