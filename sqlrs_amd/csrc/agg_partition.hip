@@ -18,6 +18,7 @@
 // path (agg.hip) with explicit first-row ids and pre-aggregated weights: O(groups) atomics.
 // Rows whose bucket table overflows (estimate too low) are returned to the caller and take
 // the resolve path directly, so the result never depends on the estimate.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -497,6 +498,179 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
   }
 }
 
+// ---------------------------------------------------------- dense (direct-addressed) --
+// Bucket pass of a range partition (KeyPack::dense): bucket b holds the 2^rbits consecutive key
+// offsets [b << rbits, (b + 1) << rbits), so the LDS table is addressed by the low bits of the
+// offset — acc[n_acc][R] u64 | first[R] u32, R = 2^rbits, no key column, no probing, and a slot
+// is a group exactly when a row reached it (first != ~0).  Rows are packed words, nothing is
+// nullable (the pre-conditions of packing).  JOIN: the build keys are the whole range
+// [kmin, kmin + range] (unique and dense, checked by the host), so a probe row has a partner
+// exactly when its offset is in range; no build-side partition is needed.
+//
+// split tables (skewed buckets): same direct addressing, first[nsplit][R] | acc[n_acc][nsplit][R].
+__global__ void split_init_dense_kernel(SplitTables stb, int64_t total, int n_acc, LdsAggParams prm) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  stb.first[i] = 0xffffffffu;
+  for (int a = 0; a < n_acc; a++) stb.acc[(size_t)a * total + i] = acc_identity_cell(prm.code[a] & 7);
+}
+
+__global__ void split_emit_dense_kernel(SplitTables stb, const uint32_t *__restrict__ split_bucket, uint32_t R,
+                                        KeyPack kp, int n_acc, unsigned long long *out_count,
+                                        uint64_t *__restrict__ gkey, uint32_t *__restrict__ gfirst,
+                                        uint64_t *__restrict__ gacc, int64_t gcap) {
+  const int64_t total = (int64_t)stb.nsplit * R;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  unsigned int first = stb.first[i];
+  if (first == 0xffffffffu) return;
+  const uint32_t s = (uint32_t)(i % R), t = (uint32_t)(i / R);
+  unsigned long long base = atomicAdd(out_count, 1ull);
+  if ((int64_t)base >= gcap) return;
+  gkey[base] = kp.kmin + ((uint64_t)split_bucket[t] << kp.rbits) + s;
+  gfirst[base] = first;
+  for (int a = 0; a < n_acc; a++) gacc[(size_t)a * gcap + base] = stb.acc[(size_t)a * total + i];
+}
+
+template <int NV, bool JOIN, int NACC, int C0, int C1>
+__global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
+    LdsAggParams prm, const uint64_t *__restrict__ pk, const uint64_t *__restrict__ pv0,
+    const uint32_t *__restrict__ work, unsigned long long *out_count, uint64_t *__restrict__ gkey,
+    uint32_t *__restrict__ gfirst, uint64_t *__restrict__ gacc, int64_t gcap, KeyPack kp, SplitTables stb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+  __shared__ unsigned int s_cnt;
+  __shared__ unsigned long long s_base;
+  const uint32_t b = work[4 * blockIdx.x];
+  const int64_t lo = work[4 * blockIdx.x + 1];
+  const int64_t hi = work[4 * blockIdx.x + 2];
+  const uint32_t split = work[4 * blockIdx.x + 3];
+  const uint32_t R = prm.cap, mask = R - 1;
+  const int n_acc = NACC >= 0 ? NACC : prm.n_acc;
+  auto code_of = [&](int a) { return NACC >= 0 ? (a == 0 ? C0 : C1) : prm.code[a]; };
+  unsigned long long *tacc = tab;
+  unsigned int *tfirst = (unsigned int *)(tacc + (size_t)n_acc * R);
+  AggRows<NV> cur, nxt;
+  if (lo < hi) lds_agg_load<NV, false, true>(pk, nullptr, pv0, nullptr, nullptr, lo + threadIdx.x, hi, cur);
+  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+    tfirst[s] = 0xffffffffu;
+#pragma unroll
+    for (int a = 0; a < PART_MAX_ACC; a++) {
+      if (a >= n_acc) break;
+      tacc[(size_t)a * R + s] = acc_identity_cell(code_of(a) & 7);
+    }
+  }
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
+  for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {
+    const int64_t i0 = base + threadIdx.x;
+    lds_agg_load<NV, false, true>(pk, nullptr, pv0, nullptr, nullptr, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
+#pragma unroll
+    for (int u = 0; u < LDS_U; u++) {
+      const uint64_t off = packed_off(kp, cur.k[u]);
+      const uint32_t id = packed_row(kp, cur.k[u]);
+      const uint32_t s = (uint32_t)off & mask;
+      bool act = i0 + (int64_t)u * PART_WG < hi;
+      if (JOIN) act = act && off <= kp.range; // outside the build keys' range (or the sentinel): no partner
+      // hot keys: see lds_agg_kernel
+      const uint64_t actm = __ballot(act);
+      if (actm) {
+        const int first = __builtin_ctzll(actm);
+        const uint32_t s0 = (uint32_t)__shfl((int)s, first, 64);
+        const bool hot = act && s == s0;
+        const uint64_t peers = __ballot(hot);
+        if (__popcll(peers) >= 8) {
+          const uint32_t idmin = wave_min_u32(hot ? id : 0xffffffffu);
+          if (lane_id() == first) atomicMin(&tfirst[s0], idmin);
+#pragma unroll
+          for (int a = 0; a < PART_MAX_ACC; a++) {
+            if (a >= n_acc) break;
+            const int kind = code_of(a) & 7;
+            const uint64_t v = NV >= 1 ? cur.v0[u] : 0ull;
+            unsigned long long *cell = tacc + (size_t)a * R + s0;
+            uint64_t red;
+            switch (kind) {
+            case AK_COUNT: red = (uint64_t)__popcll(peers); break;
+            case AK_SUM_I64: red = wave_sum_u64(hot ? v : 0ull); break;
+            case AK_SUM_F64: red = (uint64_t)__double_as_longlong(wave_sum_f64(hot ? __longlong_as_double((long long)v) : 0.0)); break;
+            case AK_MIN_I64: red = wave_min_u64(hot ? i64_to_ordered((int64_t)v) : ~0ull); break;
+            case AK_MIN_F64: red = wave_min_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : ~0ull); break;
+            case AK_MAX_I64: red = wave_max_u64(hot ? i64_to_ordered((int64_t)v) : 0ull); break;
+            default: red = wave_max_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : 0ull);
+            }
+            if (lane_id() == first) {
+              switch (kind) {
+              case AK_COUNT:
+              case AK_SUM_I64: atomicAdd(cell, (unsigned long long)red); break;
+              case AK_SUM_F64: unsafeAtomicAdd((double *)cell, __longlong_as_double((long long)red)); break;
+              case AK_MIN_I64:
+              case AK_MIN_F64: atomicMin(cell, (unsigned long long)red); break;
+              default: atomicMax(cell, (unsigned long long)red);
+              }
+            }
+          }
+          act = act && !hot;
+        }
+      }
+      if (act) {
+        atomicMin(&tfirst[s], id);
+#pragma unroll
+        for (int a = 0; a < PART_MAX_ACC; a++) {
+          if (a >= n_acc) break;
+          acc_apply(code_of(a) & 7, tacc + (size_t)a * R + s, NV >= 1 ? cur.v0[u] : 0ull);
+        }
+      }
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  if (split != 0xffffffffu) { // chunk of a skewed bucket: merge into the bucket's global table, slot for slot
+    unsigned int *gf = stb.first + (size_t)split * R;
+    for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+      unsigned int first = tfirst[s];
+      if (first == 0xffffffffu) continue;
+      atomicMin(&gf[s], first);
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        unsigned long long *cell = stb.acc + ((size_t)a * stb.nsplit + split) * R + s;
+        const unsigned long long v = tacc[(size_t)a * R + s];
+        switch (code_of(a) & 7) {
+        case AK_COUNT:
+        case AK_SUM_I64: atomicAdd(cell, v); break;
+        case AK_SUM_F64: unsafeAtomicAdd((double *)cell, __longlong_as_double((long long)v)); break;
+        case AK_MIN_I64:
+        case AK_MIN_F64: atomicMin(cell, v); break;
+        default: atomicMax(cell, v);
+        }
+      }
+    }
+    return;
+  }
+  unsigned int mine = 0;
+  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) mine += tfirst[s] != 0xffffffffu;
+  unsigned int my_off = atomicAdd(&s_cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = atomicAdd(out_count, (unsigned long long)s_cnt);
+  __syncthreads();
+  unsigned long long base = s_base + my_off;
+  const uint64_t key0 = kp.kmin + ((uint64_t)b << kp.rbits);
+  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+    unsigned int first = tfirst[s];
+    if (first == 0xffffffffu) continue;
+    if ((int64_t)base < gcap) {
+      gkey[base] = key0 + s;
+      gfirst[base] = first;
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        gacc[(size_t)a * gcap + base] = tacc[(size_t)a * R + s];
+      }
+    }
+    base++;
+  }
+}
+
 __global__ void first_to_rowid_kernel(const uint32_t *__restrict__ gfirst, int64_t n, uint64_t offset,
                                       uint64_t *__restrict__ out) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -538,28 +712,6 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     return e ? std::atof(e) : 1.0;
   }();
   if (!join_mode) est = std::max(1.0, est * est_scale);
-  // LDS budget per workgroup and fill target.  72 KiB (two 512-thread workgroups per CU) filled
-  // to 27 %: the probe loops of a wave run as long as its unluckiest lane, and at 55 % fill
-  // (36 KiB tables, four workgroups per CU) that was ~5 trips per row instead of ~2:
-  // 3.7 ms vs 3.0 ms for the C5 bucket pass.  Fewer groups per table would need more buckets,
-  // which costs more in the partition passes than it saves here.
-  static const size_t lds_budget = [] {
-    const char *e = std::getenv("SQLRS_LDS_AGG_KB");
-    return (size_t)(e ? std::atoi(e) : 72) * 1024;
-  }();
-  const size_t slot_bytes = 8 + 8 * (size_t)spec.n_acc + 4; // key, accumulators, first row
-  uint32_t cap = 1;
-  while ((size_t)(cap * 2 + 2) * slot_bytes <= lds_budget) cap *= 2;
-  static const double load_factor = [] { // tuning hook
-    const char *e = std::getenv("SQLRS_LDS_LOAD");
-    return e ? std::atof(e) : 0.275;
-  }();
-  const double groups_per_table = cap * load_factor;
-  double want = est * 1.15 / groups_per_table;
-  if (want > 65536.0 || (!join_mode && est > 0.5 * (double)n)) return false; // too many groups: resolve path
-  uint32_t P = (uint32_t)std::max(1.0, std::ceil(want));
-  out->est_groups = est;
-  // 2./3. rows in bucket order (LDS-staged multi-split, radix_part.hip)
   // (key, row) packing: the keys of interest are the batch's own keys, or the build keys of the
   // fused join (a probe key outside their range cannot have a partner)
   KeyPack kp;
@@ -590,6 +742,57 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
       }
     }
   }
+  // LDS budget per workgroup and fill target.  72 KiB (two 512-thread workgroups per CU) filled
+  // to 27 %: the probe loops of a wave run as long as its unluckiest lane, and at 55 % fill
+  // (36 KiB tables, four workgroups per CU) that was ~5 trips per row instead of ~2:
+  // 3.7 ms vs 3.0 ms for the C5 bucket pass.  Fewer groups per table would need more buckets,
+  // which costs more in the partition passes than it saves here.
+  static const size_t lds_budget = [] {
+    const char *e = std::getenv("SQLRS_LDS_AGG_KB");
+    return (size_t)(e ? std::atoi(e) : 72) * 1024;
+  }();
+  const size_t slot_bytes = 8 + 8 * (size_t)spec.n_acc + 4; // key, accumulators, first row
+  uint32_t cap = 1;
+  while ((size_t)(cap * 2 + 2) * slot_bytes <= lds_budget) cap *= 2;
+  static const double load_factor = [] { // tuning hook
+    const char *e = std::getenv("SQLRS_LDS_LOAD");
+    return e ? std::atof(e) : 0.275;
+  }();
+  const double groups_per_table = cap * load_factor;
+  double want = est * 1.15 / groups_per_table;
+  if (!join_mode && est > 0.5 * (double)n) return false; // mostly distinct keys: resolve path
+  // Dense keys: when the keys of interest fill most of their range (surrogate keys, dimension
+  // primary keys) the partition is by key range and the bucket tables are addressed directly:
+  // R = 2^rbits slots of 8 * n_acc + 4 bytes at 100 % fill instead of cap slots of 8 more bytes
+  // at 27 %, i.e. ~5x fewer buckets (often one partition level instead of two), no probing and,
+  // for the fused join, no build-side partition and no insert phase.
+  static const bool dense_on = [] { // test / tuning hook
+    const char *e = std::getenv("SQLRS_DENSE_AGG");
+    return !(e && e[0] == '0');
+  }();
+  bool dense = false;
+  if (dense_on && kp.kbits) {
+    const uint64_t range = omax - omin;
+    const size_t dslot = 8 * (size_t)spec.n_acc + 4;
+    uint32_t rbits = 8;
+    while (rbits < 14 && ((size_t)2 << rbits) * dslot <= lds_budget) rbits++;
+    const uint64_t pd = (range >> rbits) + 1;
+    // join: unique build keys (the caller's pre-condition) that span exactly join_n values are
+    // every value of the range; otherwise: at most ~4 slots per group
+    const bool fills = join_mode ? (range + 1 == (uint64_t)in.join_n) : ((double)range + 1.0 <= 4.0 * est);
+    if (fills && pd <= 65536 && (double)pd <= 1.5 * std::max(1.0, std::ceil(want))) {
+      dense = true;
+      kp.dense = 1;
+      kp.rbits = rbits;
+      kp.range = range;
+      cap = 1u << rbits;
+      want = (double)pd;
+    }
+  }
+  if (want > 65536.0) return false; // too many groups: resolve path
+  uint32_t P = (uint32_t)std::max(1.0, std::ceil(want));
+  out->est_groups = est;
+  // 2./3. rows in bucket order (LDS-staged multi-split, radix_part.hip)
   PartitionInput pin;
   pin.pack = kp;
   pin.keys = in.keys;
@@ -603,11 +806,12 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   PartitionedRows pr;
   if (!partition_rows(ctx, pin, P, &pr)) return false;
   P = pr.P;
+  if (dense != (pr.pack.dense != 0)) return false;
   out->buckets = (int)P;
   BufP pk = pr.key, pi = pr.idx, pv0 = pr.v0, pv1 = pr.v1, pf = pr.flags;
   PartitionedRows local_build;
   const PartitionedRows *bp = nullptr;
-  if (join_mode) { // the build keys through the same bucket function (cached across probe batches)
+  if (join_mode && !dense) { // the build keys through the same bucket function (cached across probe batches)
     if (in.join_cache && in.join_cache->P == P && in.join_cache->n == in.join_n) {
       bp = in.join_cache;
     } else {
@@ -640,35 +844,68 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   }
   prm.cap = cap;
   int64_t gcap = (int64_t)std::min<double>((double)n, est * 1.5 + 65536.0 + 2.0 * P);
+  if (dense) gcap = (int64_t)std::min<uint64_t>((uint64_t)n, kp.range + 1); // one group per key of the range at most
   BufP ctr = ctx->alloc_zero(32);
-  size_t lds = round_up((size_t)(cap + 2) * slot_bytes, 16);
+  size_t lds = dense ? round_up((size_t)cap * (slot_bytes - 8), 16) : round_up((size_t)(cap + 2) * slot_bytes, 16);
   // work list: buckets larger than `chunk` rows (key skew) are split so that no workgroup streams
   // more than `chunk` rows.  The chunks of a split bucket merge their tables into one small global
   // table per bucket (SplitTables), so a key is still emitted exactly once.
   std::vector<uint32_t> hb((size_t)P + 1);
   SQ_HIP(hipMemcpyAsync(hb.data(), pr.bstart->p, 4 * hb.size(), hipMemcpyDeviceToHost, ctx->stream));
   ctx->sync();
-  const uint32_t chunk = (uint32_t)std::max<int64_t>(32768, 2 * (n / std::max<uint32_t>(P, 1)));
-  std::vector<uint32_t> work;
+  uint32_t chunk = (uint32_t)std::max<int64_t>(32768, 2 * (n / std::max<uint32_t>(P, 1)));
+  uint32_t split_above = chunk;
+  if (dense) {
+    // A range partition has few, large buckets (about one per workgroup slot of the chip for the
+    // 2e8-row C4 batch), so one oversized bucket is a long tail: buckets more than a quarter above
+    // the average are cut into half-average chunks and the work list is sorted by size, largest
+    // first.  Merging a chunk into its bucket's direct-addressed global table is cheap (no probing).
+    const int64_t avg = n / (int64_t)std::max<uint64_t>((kp.range >> kp.rbits) + 1, 1);
+    chunk = (uint32_t)std::max<int64_t>(32768, avg / 2);
+    split_above = (uint32_t)std::max<int64_t>(65536, avg + avg / 4);
+  }
+  std::vector<uint32_t> work, split_bucket;
   work.reserve(4 * ((size_t)P + 64));
   out->may_dup = false;
   uint32_t nsplit = 0;
   for (uint32_t bkt = 0; bkt < P; bkt++) {
     uint32_t lo = hb[bkt], hi = hb[bkt + 1];
-    if (hi - lo <= chunk) {
+    if (dense && lo == hi) continue; // nothing to set up for an empty bucket (no build keys to insert)
+    if (hi - lo <= split_above) {
       work.insert(work.end(), {bkt, lo, hi, 0xffffffffu});
     } else {
       for (uint32_t c0 = lo; c0 < hi; c0 += chunk) work.insert(work.end(), {bkt, c0, std::min(hi, c0 + chunk), nsplit});
+      split_bucket.push_back(bkt);
       nsplit++;
     }
+  }
+  if (dense && nsplit) { // largest work items first
+    std::vector<uint32_t> ord(work.size() / 4), sorted(work.size());
+    for (uint32_t i = 0; i < ord.size(); i++) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+      return work[4 * a + 2] - work[4 * a + 1] > work[4 * b + 2] - work[4 * b + 1];
+    });
+    for (size_t i = 0; i < ord.size(); i++) std::memcpy(&sorted[4 * i], &work[4 * ord[i]], 16);
+    work.swap(sorted);
   }
   const uint32_t nwork = (uint32_t)(work.size() / 4);
   BufP dwork = ctx->alloc(4 * work.size() + 16);
   SQ_HIP(hipMemcpyAsync(dwork->p, work.data(), 4 * work.size(), hipMemcpyHostToDevice, ctx->stream));
-  const uint32_t nslots_h = cap + 2;
+  const uint32_t nslots_h = dense ? cap : cap + 2;
   SplitTables stb;
-  BufP stb_key, stb_first, stb_acc;
-  if (nsplit) {
+  BufP stb_key, stb_first, stb_acc, dsplit;
+  if (nsplit && dense) {
+    const int64_t total = (int64_t)nsplit * nslots_h;
+    stb_first = ctx->alloc(4 * (size_t)total);
+    stb_acc = ctx->alloc(8 * (size_t)total * (size_t)std::max(spec.n_acc, 1));
+    stb.first = stb_first->as<unsigned int>();
+    stb.acc = stb_acc->as<unsigned long long>();
+    stb.nsplit = nsplit;
+    dsplit = ctx->alloc(4 * (size_t)nsplit);
+    SQ_HIP(hipMemcpyAsync(dsplit->p, split_bucket.data(), 4 * (size_t)nsplit, hipMemcpyHostToDevice, ctx->stream));
+    split_init_dense_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(stb, total, spec.n_acc, prm);
+    SQ_HIP(hipGetLastError());
+  } else if (nsplit) {
     const int64_t total = (int64_t)nsplit * nslots_h;
     stb_key = ctx->alloc(8 * (size_t)total);
     stb_first = ctx->alloc(4 * (size_t)total);
@@ -718,8 +955,46 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   } while (0)
     const int nvu = pv1 ? 2 : (pv0 ? 1 : 0);
     bool launched = false;
+    if (dense) { // direct-addressed tables (packed rows, nothing nullable, at most one value column)
+#define SQ_LD(NV, JN, NA, C0, C1)                                                                              \
+  do {                                                                                                         \
+    auto kfn = lds_agg_dense_kernel<NV, JN, NA, C0, C1>;                                                        \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                           \
+      SQ_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));  \
+      attr_set = true;                                                                                         \
+    }                                                                                                          \
+    kfn<<<dim3(nwork), dim3(PART_WG), lds, ctx->stream>>>(                                                     \
+        prm, pk->as<uint64_t>(), pv0 ? pv0->as<uint64_t>() : nullptr, dwork->as<uint32_t>(),                   \
+        ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(),                 \
+        out->gacc->as<uint64_t>(), gcap, pr.pack, stb);                                                        \
+    launched = true;                                                                                           \
+  } while (0)
+#define SQ_LD_J(NV, NA, C0, C1) do { if (join_mode) SQ_LD(NV, true, NA, C0, C1); else SQ_LD(NV, false, NA, C0, C1); } while (0)
+      if (nvu == 1 && spec.n_acc <= 2) {
+        const int c0 = prm.code[0], c1 = spec.n_acc == 2 ? prm.code[1] : -1;
+#define SQ_SIG1(K) if (!launched && spec.n_acc == 1 && c0 == K) SQ_LD_J(1, 1, K, 0)
+#define SQ_SIG2(K0, K1) if (!launched && spec.n_acc == 2 && c0 == K0 && c1 == K1) SQ_LD_J(1, 2, K0, K1)
+        SQ_SIG1(AK_COUNT); SQ_SIG1(AK_SUM_I64); SQ_SIG1(AK_SUM_F64); SQ_SIG1(AK_MIN_I64); SQ_SIG1(AK_MIN_F64);
+        SQ_SIG1(AK_MAX_I64); SQ_SIG1(AK_MAX_F64);
+        SQ_SIG2(AK_COUNT, AK_SUM_F64); SQ_SIG2(AK_SUM_F64, AK_COUNT);
+        SQ_SIG2(AK_COUNT, AK_SUM_I64); SQ_SIG2(AK_SUM_I64, AK_COUNT);
+        SQ_SIG2(AK_MIN_F64, AK_MAX_F64); SQ_SIG2(AK_MIN_I64, AK_MAX_I64);
+#undef SQ_SIG1
+#undef SQ_SIG2
+      }
+      if (!launched) { if (nvu == 0) SQ_LD_J(0, -1, 0, 0); else SQ_LD_J(1, -1, 0, 0); }
+#undef SQ_LD_J
+#undef SQ_LD
+      if (nsplit) {
+        const int64_t total = (int64_t)nsplit * nslots_h;
+        split_emit_dense_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
+            stb, dsplit->as<uint32_t>(), cap, pr.pack, spec.n_acc, ctr->as<unsigned long long>(),
+            out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(), out->gacc->as<uint64_t>(), gcap);
+      }
+    }
     // specialised kernels: no nullable column, one value column, the usual accumulator lists
-    if (!pf && nvu == 1 && spec.n_acc <= 2) {
+    if (!launched && !pf && nvu == 1 && spec.n_acc <= 2) {
       const int c0 = prm.code[0], c1 = spec.n_acc == 2 ? prm.code[1] : -1;
 #define SQ_SIG1(K) if (!launched && spec.n_acc == 1 && c0 == K) SQ_LA_J(1, false, 1, K, 0)
 #define SQ_SIG2(K0, K1) if (!launched && spec.n_acc == 2 && c0 == K0 && c1 == K1) SQ_LA_J(1, false, 2, K0, K1)
@@ -737,7 +1012,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     }
 #undef SQ_LA_J
 #undef SQ_LA
-    if (nsplit) {
+    if (nsplit && !dense) {
       const int64_t total = (int64_t)nsplit * nslots_h;
       split_emit_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
           stb, nslots_h, cap, spec.n_acc, ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(),

@@ -44,6 +44,11 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nb) {
 __device__ __forceinline__ uint32_t rp_bucket(uint64_t key, bool valid, uint32_t P) {
   return valid ? (uint32_t)__umul64hi(mix64(key), (uint64_t)P) : 0u;
 }
+// `key` is the key the row carries after packing (packed_clamp / packed_key); the branch is uniform
+__device__ __forceinline__ uint32_t rp_bucket(const KeyPack &kp, uint64_t key, bool valid, uint32_t P) {
+  if (kp.dense) return (uint32_t)min((key - kp.kmin) >> kp.rbits, (uint64_t)(P - 1));
+  return rp_bucket(key, valid, P);
+}
 __device__ __forceinline__ uint32_t rp_digit(uint32_t bucket, int level, uint32_t p2_bits) {
   return level == 1 ? (bucket >> p2_bits) : (bucket & ((1u << p2_bits) - 1));
 }
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(RP_WG) void rp_hist_kernel(const uint64_t *__restri
       bool valid = PLAIN ? true : (flags ? (flags[r] & 1) : (!key_validity || ((key_validity[r >> 6] >> (r & 63)) & 1)));
       uint64_t key = PLAIN ? k[j] : keys[r];
       if (kp.kbits) key = level == 1 ? packed_clamp(kp, key) : packed_key(kp, key); // packed partition
-      atomicAdd(&h[rp_digit(rp_bucket(key, valid, P), level, p2_bits)], 1u);
+      atomicAdd(&h[rp_digit(rp_bucket(kp, key, valid, P), level, p2_bits)], 1u);
     }
   }
   __syncthreads();
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
     dg[j] = 0xffffffffu;
     if ((uint32_t)(j * RP_WG) + threadIdx.x < len) {
       const uint64_t key = !PACK ? cur.k[j] : (MODE == RP_LN ? packed_key(kp, cur.k[j]) : packed_clamp(kp, cur.k[j]));
-      dg[j] = rp_digit(rp_bucket(key, cur.fl[j] & 1, P), level, p2_bits);
+      dg[j] = rp_digit(rp_bucket(kp, key, cur.fl[j] & 1, P), level, p2_bits);
       rk[j] = atomicAdd(&cnt[dg[j]], 1u);
     }
   };
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
   auto store_row = [&](int j, uint32_t len) { // row j of the staged tile -> its run in the output
     uint32_t p = j * RP_WG + threadIdx.x;
     const uint64_t kw = skey[p];
-    const uint32_t d = PACK ? rp_digit(rp_bucket(packed_key(kp, kw), true, P), level, p2_bits) : sdig[p];
+    const uint32_t d = PACK ? rp_digit(rp_bucket(kp, packed_key(kp, kw), true, P), level, p2_bits) : sdig[p];
     int64_t g = gbase[d & (RP_WG - 1)] + p;
     if (p >= len) g = sink + threadIdx.x;
     out.key[g] = kw;

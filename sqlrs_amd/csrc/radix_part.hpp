@@ -10,9 +10,17 @@ namespace sq {
 // Applies when the keys of interest span a known range [kmin, kmin + kmask) and kbits + bits(rows)
 // <= 64; a key outside the range is stored as the sentinel offset kmask (no key of interest has
 // it).  Saves the 4-byte row-id column in every partition pass and in the bucket pass.
+//
+// Dense keys (`dense` != 0, only together with packing): the keys of interest fill most of
+// [kmin, kmin + range], so the partition is by key RANGE instead of by hash —
+// bucket = min((key - kmin) >> rbits, P - 1) — and bucket b holds exactly the 2^rbits consecutive
+// key offsets [b << rbits, (b + 1) << rbits): the bucket pass can address its LDS table directly
+// by the low rbits of the offset (no key column in the table, no probing, 100 % fill).
 struct KeyPack {
   uint64_t kmin = 0, kmask = 0;
   uint32_t kbits = 0; // 0 = not packed
+  uint32_t dense = 0, rbits = 0;
+  uint64_t range = 0; // dense: largest key offset of interest
 };
 #if defined(__HIPCC__)
 __device__ __forceinline__ uint64_t pack_key_row(const KeyPack &kp, uint64_t key, uint32_t row) {
@@ -28,6 +36,7 @@ __device__ __forceinline__ uint64_t packed_clamp(const KeyPack &kp, uint64_t key
   uint64_t off = key - kp.kmin;
   return (off < kp.kmask ? off : kp.kmask) + kp.kmin;
 }
+__device__ __forceinline__ uint64_t packed_off(const KeyPack &kp, uint64_t w) { return w & kp.kmask; }
 __device__ __forceinline__ uint32_t packed_row(const KeyPack &kp, uint64_t w) { return (uint32_t)(w >> kp.kbits); }
 #endif
 
@@ -44,7 +53,7 @@ struct PartitionInput {
 
 // Rows in bucket order: bucket b = rows [bstart[b], bstart[b+1]).  `idx` = original row,
 // `flags` (null when nothing is nullable) bit0 key valid, bit1 v0 valid, bit2 v1 valid.
-// bucket(key) = mulhi(mix64(key), P); NULL keys -> bucket 0.
+// bucket(key) = mulhi(mix64(key), P); NULL keys -> bucket 0.  (Dense KeyPack: key range, see above.)
 struct PartitionedRows {
   int64_t n = 0;
   uint32_t P = 0;

@@ -761,3 +761,85 @@ def test_join_agg_probe_keys_outside_build_range(hip, oracle, npb):
     assert ex.fused_batches == 1
     exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
     assert_same(got, exp, float_cols={2})
+
+
+# ----------------------------------------- range partition + direct-addressed bucket tables --
+@pytest.mark.parametrize("shape", ["uniform", "sparse_quarter", "clustered", "zipf", "one_hot_bucket", "multi_level"])
+@pytest.mark.parametrize("aggs_kind", ["count_sum_f64", "min_max_i64", "count_only"])
+def test_hash_agg_dense_key_route(hip, oracle, shape, aggs_kind):
+    """Integer keys that fill most of their range are partitioned by key range and aggregated in
+    direct-addressed LDS tables (agg_partition.hip, lds_agg_dense_kernel): uniform keys, a range
+    filled to a quarter, keys clustered in few buckets and heavy hitters (bucket chunks merged
+    through the direct-addressed split tables), and a range wide enough for two partition levels."""
+    n = 2_200_000
+    rng = np.random.default_rng(hash((shape, aggs_kind)) % (2**32))
+    if shape == "uniform":
+        keys = rng.integers(-70_000, 130_000, n, dtype=np.int64)
+    elif shape == "sparse_quarter":
+        keys = (1 << 33) + rng.choice(400_000, 110_000, replace=False)[rng.integers(0, 110_000, n)]
+    elif shape == "clustered":
+        keys = np.where(rng.random(n) < 0.9, rng.integers(5_000, 5_300, n), rng.integers(0, 900_000, n)).astype(np.int64)
+    elif shape == "zipf":
+        keys = np.minimum(rng.zipf(1.1, n), 600_000).astype(np.int64)
+    elif shape == "one_hot_bucket":
+        keys = np.where(rng.random(n) < 0.6, 77_777, rng.integers(0, 300_000, n)).astype(np.int64)
+    else:
+        keys = rng.integers(0, 1_050_000, n, dtype=np.int64) - 7
+    if aggs_kind == "count_sum_f64":
+        v = pa.array(rng.random(n))
+        aggs = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64)]
+        fl = {2}
+    elif aggs_kind == "min_max_i64":
+        v = pa.array(rng.integers(-10**12, 10**12, n, dtype=np.int64))
+        aggs = [AggFunc("min", InputRef(1), abi.INT64), AggFunc("max", InputRef(1), abi.INT64)]
+        fl = set()
+    else:
+        v = pa.array(rng.integers(0, 5, n, dtype=np.int64))
+        aggs = [AggFunc("count", InputRef(1), abi.INT64)]
+        fl = set()
+    b = pa.RecordBatch.from_arrays([pa.array(keys), v], names=["k", "v"])
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
+    assert_same(got, exp, float_cols=fl)
+
+
+@pytest.mark.parametrize("nb,base", [(40_000, 0), (300_000, -1234), (1_100_000, 1 << 35)])
+@pytest.mark.parametrize("hot", [False, True])
+def test_join_agg_dense_build_keys(hip, oracle, nb, base, hot):
+    """Fused join + group-by whose build keys are a permutation of a full integer range (a dimension
+    table's primary key): direct-addressed bucket tables, no build-side partition.  Probe keys reach
+    below and above the range (no partner), optionally with heavy hitters."""
+    from sqlrs_amd.executor import HashJoinAggExecutor
+    npb = 2_300_000
+    rng = np.random.default_rng(nb + hot)
+    lkeys = (base + rng.permutation(nb)).astype(np.int64)
+    lb = pa.RecordBatch.from_arrays([pa.array(lkeys), pa.array(rng.integers(0, 9, nb, dtype=np.int64))], names=["k", "x"])
+    pk = rng.integers(base - nb // 10, base + nb + nb // 10, npb, dtype=np.int64)
+    if hot:
+        pk[rng.random(npb) < 0.5] = base + nb // 3
+        pk[rng.random(npb) < 0.1] = base - 1      # heavy hitter without partner
+    rb = pa.RecordBatch.from_arrays([pa.array(pk), pa.array(rng.random(npb))], names=["k", "v"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64)]
+    ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
+    got = rows_of(ex.execute())
+    assert ex.fused_batches == 1
+    exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
+    assert_same(got, exp, float_cols={2})
+
+
+@pytest.mark.gpu
+def test_agg_paths_without_dense_tables():
+    """SQLRS_DENSE_AGG=0: dense integer keys go through the hashed partition and the probing LDS
+    tables like any other key set, so that path stays covered by the same inputs (hook read once
+    per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SQLRS_DENSE_AGG="0")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "(partition_route or join_agg or dense_key) and not forced and not without"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
