@@ -128,6 +128,9 @@ def test_fuzz_hash_agg_partition_route(hip, oracle, seed):
     keys = rng.integers(lo, lo + card, n, dtype=np.int64)
     if rng.random() < 0.4:  # heavy hitters
         keys[rng.random(n) < 0.5] = lo + int(rng.integers(0, card))
+    # stride 1: dense keys (range partition, direct-addressed tables); 3: a third of the range is
+    # used (still dense enough); 11: sparse keys (hashed partition, probing tables)
+    keys *= int(rng.choice([1, 1, 3, 11]))
     kmask = (rng.random(n) < nulls) if nulls else None
     v1 = pa.array(rng.random(n), mask=(rng.random(n) < nulls) if nulls else None)
     v2 = pa.array(rng.integers(-10**6, 10**6, n, dtype=np.int64), mask=(rng.random(n) < nulls) if nulls else None)
