@@ -717,7 +717,10 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   KeyPack kp;
   const bool nullable = in.key_validity || in.val_validity[0] || in.val_validity[1];
   if (!nullable && spec.nv <= 1 && !(join_mode && in.join_validity)) {
-    if (join_mode) {
+    if (join_mode && in.join_range_known) {
+      omin = in.join_omin;
+      omax = in.join_omax;
+    } else if (join_mode) {
       BufP mm = ctx->alloc(16); // {min = ~0, max = 0}
       SQ_HIP(hipMemsetAsync(mm->p, 0xff, 8, ctx->stream));
       SQ_HIP(hipMemsetAsync(mm->as<uint8_t>() + 8, 0, 8, ctx->stream));
@@ -850,9 +853,8 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   // work list: buckets larger than `chunk` rows (key skew) are split so that no workgroup streams
   // more than `chunk` rows.  The chunks of a split bucket merge their tables into one small global
   // table per bucket (SplitTables), so a key is still emitted exactly once.
-  std::vector<uint32_t> hb((size_t)P + 1);
-  SQ_HIP(hipMemcpyAsync(hb.data(), pr.bstart->p, 4 * hb.size(), hipMemcpyDeviceToHost, ctx->stream));
-  ctx->sync();
+  const std::vector<uint32_t> &hb = pr.bstart_host;
+  if (hb.size() != (size_t)P + 1) return false;
   uint32_t chunk = (uint32_t)std::max<int64_t>(32768, 2 * (n / std::max<uint32_t>(P, 1)));
   uint32_t split_above = chunk;
   if (dense) {

@@ -32,6 +32,10 @@ struct PartAggInput {
   const uint64_t *join_validity = nullptr;
   int64_t join_n = 0;
   struct PartitionedRows *join_cache = nullptr; // build side in bucket order, reused across batches
+  // smallest / largest valid build key (signed-order images) when the caller already knows them
+  // (the join's direct-address table): saves a pass over the build keys and a host round trip
+  bool join_range_known = false;
+  uint64_t join_omin = 0, join_omax = 0;
 };
 
 // Groups of ONE batch: key, first row (local index), one 8-byte cell per accumulator

@@ -484,6 +484,8 @@ struct JoinSide {
   const uint64_t *validity;
   int64_t n;
   PartitionedRows *cache;
+  bool range_known = false; // omin / omax: signed-order images of the smallest / largest valid key
+  uint64_t omin = 0, omax = 0;
 };
 
 // Consumes one batch given its evaluated key / argument columns: partition route when it
@@ -571,6 +573,9 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
           pin.join_validity = js->validity;
           pin.join_n = js->n;
           pin.join_cache = js->cache;
+          pin.join_range_known = js->range_known;
+          pin.join_omin = js->omin;
+          pin.join_omax = js->omax;
         }
         PartAggOutput po;
         flush_pending(a); // an older deferred batch must be in the table before this one
@@ -975,6 +980,11 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
         js.validity = j->bkeys_validity ? j->bkeys_validity->as<uint64_t>() : nullptr;
         js.n = j->nB;
         js.cache = &ja->build_parts;
+        if (j->dense && j->dense_range) { // the direct-address table's key range
+          js.range_known = true;
+          js.omin = j->dense_min ^ (1ull << 63);
+          js.omax = js.omin + (j->dense_range - 1);
+        }
         flush_staged(a); // batches staged by the composed route come first in row order
         if (agg_consume(a, n, kcols, nk, acols, &js)) {
           a->rows_seen += n;

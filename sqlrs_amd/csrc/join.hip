@@ -402,11 +402,20 @@ __global__ __launch_bounds__(BLOCK) void join_probe_unique_outer_kernel(
 __global__ void key_minmax_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
                                   int64_t n, unsigned long long *mn, unsigned long long *mx) {
   unsigned long long lo = ~0ull, hi = 0;
-  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
-    if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) continue;
-    unsigned long long u = i64_to_ordered((int64_t)keys[r]);
-    lo = u < lo ? u : lo;
-    hi = u > hi ? u : hi;
+  constexpr int KU = 8; // independent loads in flight per lane (rows past the end re-read the last row)
+  for (int64_t base = blockIdx.x * (int64_t)(blockDim.x * KU) + threadIdx.x; base < n;
+       base += (int64_t)gridDim.x * (blockDim.x * KU)) {
+    uint64_t k[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) k[u] = __builtin_nontemporal_load(keys + min(base + (int64_t)u * blockDim.x, n - 1));
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      const int64_t r = min(base + (int64_t)u * blockDim.x, n - 1);
+      if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) continue;
+      unsigned long long o = i64_to_ordered((int64_t)k[u]);
+      lo = o < lo ? o : lo;
+      hi = o > hi ? o : hi;
+    }
   }
   for (int m = 32; m >= 1; m >>= 1) {
     unsigned long long a = shfl_xor_u64(lo, m), b = shfl_xor_u64(hi, m);
@@ -536,7 +545,7 @@ static void build_table(sqlrs_hash_join *j) {
     SQ_HIP(hipMemsetAsync(mm->p, 0xff, 8, ctx->stream));
     SQ_HIP(hipMemsetAsync(mm->as<uint8_t>() + 8, 0, 8, ctx->stream));
     const uint64_t *vp = validity ? validity->as<uint64_t>() : nullptr;
-    unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256), 1024);
+    unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 1024);
     key_minmax_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n,
                                                                   mm->as<unsigned long long>(),
                                                                   mm->as<unsigned long long>() + 1);

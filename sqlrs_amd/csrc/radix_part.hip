@@ -516,7 +516,8 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     *plan_out = std::move(L);
   };
 
-  auto bucket_starts = [&](const Level &L, const BufP &offs, uint32_t digits) -> BufP {
+  // `host` receives a copy (the synchronisation that keeps L's upload sources alive pays for it)
+  auto bucket_starts = [&](const Level &L, const BufP &offs, uint32_t digits, std::vector<uint32_t> *host) -> BufP {
     uint32_t nseg = (uint32_t)L.seg_tiles.size();
     BufP sm = upload(ctx, L.seg_mat), st = upload(ctx, L.seg_tiles), ss = upload(ctx, L.seg_start);
     int64_t total = (int64_t)nseg * digits + 1;
@@ -525,6 +526,8 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         offs->as<uint32_t>(), (const int64_t *)sm->p, (const uint32_t *)st->p, (const int64_t *)ss->p, digits,
         nseg, n, bs->as<uint32_t>());
     SQ_HIP(hipGetLastError());
+    host->resize((size_t)total);
+    SQ_HIP(hipMemcpyAsync(host->data(), bs->p, 4 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
     return bs;
   };
@@ -550,18 +553,17 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   BufP offs1;
   Level L1;
   run_level(1, d1, {0, n}, rin, rout, &offs1, &L1);
-  BufP bs1 = bucket_starts(L1, offs1, d1);
+  std::vector<uint32_t> hs;
+  BufP bs1 = bucket_starts(L1, offs1, d1, &hs);
   out->n = n;
   out->P = P;
   if (p2_bits == 0) {
     out->key = k1; out->v0 = a1; out->v1 = b1; out->idx = i1; out->flags = f1;
     out->bstart = bs1;
+    out->bstart_host = std::move(hs);
     return true;
   }
   // ---- level 2: every level-1 bucket is one segment
-  std::vector<uint32_t> hs((size_t)d1 + 1);
-  SQ_HIP(hipMemcpyAsync(hs.data(), bs1->p, 4 * hs.size(), hipMemcpyDeviceToHost, ctx->stream));
-  ctx->sync();
   std::vector<int64_t> seg(hs.begin(), hs.end());
   BufP k2, a2, b2, i2, f2;
   alloc_cols(k2, a2, b2, i2, f2);
@@ -582,7 +584,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   Level L2;
   run_level(2, 1u << p2_bits, seg, rin2, rout2, &offs2, &L2);
   out->key = k2; out->v0 = a2; out->v1 = b2; out->idx = i2; out->flags = f2;
-  out->bstart = bucket_starts(L2, offs2, 1u << p2_bits);
+  out->bstart = bucket_starts(L2, offs2, 1u << p2_bits, &out->bstart_host);
   return true;
 }
 

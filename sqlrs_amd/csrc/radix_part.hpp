@@ -59,6 +59,7 @@ struct PartitionedRows {
   uint32_t P = 0;
   BufP key, v0, v1, idx, flags;
   BufP bstart; // u32[P + 1]
+  std::vector<uint32_t> bstart_host; // the same on the host
   KeyPack pack; // kbits != 0: `key` holds packed (key, row) words and `idx` is null
 };
 
