@@ -684,7 +684,7 @@ __global__ void bytes_pack_kernel(const uint8_t *__restrict__ bytes, int64_t n, 
 }
 
 // min / max of the signed-order image of `keys` (all valid)
-__global__ void key_range_kernel(const uint64_t *__restrict__ keys, int64_t n, unsigned long long *mm) {
+__global__ __launch_bounds__(256) void key_range_kernel(const uint64_t *__restrict__ keys, int64_t n, unsigned long long *mm) {
   uint64_t kmin = ~0ull, kmax = 0;
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t o = keys[r] ^ (1ull << 63);
@@ -693,7 +693,17 @@ __global__ void key_range_kernel(const uint64_t *__restrict__ keys, int64_t n, u
   }
   kmin = wave_min_u64(kmin);
   kmax = wave_max_u64(kmax);
+  __shared__ unsigned long long s_lo[4], s_hi[4]; // 256 threads; one pair of atomics per block
   if (lane_id() == 0) {
+    s_lo[wave_id()] = kmin;
+    s_hi[wave_id()] = kmax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) {
+      kmin = min(kmin, (uint64_t)s_lo[w]);
+      kmax = max(kmax, (uint64_t)s_hi[w]);
+    }
     atomicMin(mm, (unsigned long long)kmin);
     atomicMax(mm + 1, (unsigned long long)kmax);
   }

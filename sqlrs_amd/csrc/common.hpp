@@ -149,6 +149,7 @@ struct InBatch {
   std::vector<DCol> cache;
   std::vector<uint8_t> loaded;
   bool host_upload = false; // an async H2D copy out of the caller's memory was queued
+  const DBatch *shared = nullptr; // the batch is one of this library's own device batches (ctx.hip)
   InBatch(Ctx *c, const sqlrs_batch_t *b);
   // The caller's buffers are only borrowed for the duration of the call: uploads out of host
   // memory must have been read before the entry point returns (operators that stage their input

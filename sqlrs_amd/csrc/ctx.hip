@@ -203,6 +203,35 @@ DCol upload_column(Ctx *ctx, const sqlrs_column_t &c, bool force_copy) {
   return d;
 }
 
+// A batch this library produced (sqlrs_batch_t::owner points here).
+constexpr uint64_t OWNED_BATCH_MAGIC = 0x5351425443483031ull;
+struct OwnedBatch {
+  sqlrs_batch_t abi;
+  std::vector<sqlrs_column_t> descs;
+  DBatch dev;                     // keeps device buffers alive (out_mem == DEVICE)
+  std::vector<void *> host_blocks; // malloc'd (out_mem == HOST)
+  uint64_t magic = OWNED_BATCH_MAGIC;
+  Ctx *ctx = nullptr;
+  int out_mem = SQLRS_MEM_HOST;
+  ~OwnedBatch() {
+    magic = 0;
+    for (void *p : host_blocks) std::free(p);
+  }
+};
+
+// A device batch produced by this library on the same ctx and handed back unchanged: its columns'
+// buffers are reference counted (BufP), so an operator that retains input (join build side,
+// staged aggregation input) shares them instead of taking private copies; the caller's
+// sqlrs_batch_release only drops its own reference.
+static const DBatch *shared_columns_of(Ctx *c, const sqlrs_batch_t *b) {
+  if (!b->owner) return nullptr;
+  const OwnedBatch *o = (const OwnedBatch *)b->owner;
+  if (&o->abi != b || o->magic != OWNED_BATCH_MAGIC || o->ctx != c || o->out_mem != SQLRS_MEM_DEVICE) return nullptr;
+  if (b->columns != o->descs.data() || b->num_columns != (int)o->dev.cols.size() || b->num_rows != o->dev.rows)
+    return nullptr;
+  return &o->dev;
+}
+
 InBatch::InBatch(Ctx *c, const sqlrs_batch_t *b) : ctx(c), abi(b) {
   if (!b) fail(SQLRS_ERR_ARROW, "null batch");
   if (b->num_columns < 0 || (b->num_columns > 0 && !b->columns)) fail(SQLRS_ERR_ARROW, "bad batch");
@@ -210,12 +239,18 @@ InBatch::InBatch(Ctx *c, const sqlrs_batch_t *b) : ctx(c), abi(b) {
     if (b->columns[i].length != b->num_rows) fail(SQLRS_ERR_ARROW, "column length != num_rows");
   cache.resize((size_t)b->num_columns);
   loaded.assign((size_t)b->num_columns, 0);
+  shared = shared_columns_of(c, b);
 }
 InBatch::~InBatch() {
   if (host_upload) (void)hipStreamSynchronize(ctx->stream);
 }
 const DCol &InBatch::col(int i) {
   if (i < 0 || i >= abi->num_columns) fail(SQLRS_ERR_INTERNAL, "input ref out of range");
+  if (!loaded[(size_t)i] && shared && shared->cols[(size_t)i].values == abi->columns[i].values &&
+      shared->cols[(size_t)i].length == abi->columns[i].length) {
+    cache[(size_t)i] = shared->cols[(size_t)i]; // carries the owning BufPs
+    loaded[(size_t)i] = 1;
+  }
   if (!loaded[(size_t)i]) {
     if (abi->columns[i].mem == SQLRS_MEM_HOST && abi->columns[i].length > 0) host_upload = true;
     cache[(size_t)i] = upload_column(ctx, abi->columns[i], false);
@@ -227,10 +262,12 @@ DBatch InBatch::materialize(bool owned) {
   DBatch b;
   b.rows = abi->num_rows;
   for (int i = 0; i < abi->num_columns; i++) {
-    if (owned && abi->columns[i].mem == SQLRS_MEM_DEVICE)
+    const DCol &c = col(i);
+    const bool borrowed = (c.values && !c.own_values) || (c.validity && !c.own_validity) || (c.offsets && !c.own_offsets);
+    if (owned && abi->columns[i].mem == SQLRS_MEM_DEVICE && borrowed)
       b.cols.push_back(upload_column(ctx, abi->columns[i], true));
     else
-      b.cols.push_back(col(i));
+      b.cols.push_back(c);
   }
   return b;
 }
@@ -242,21 +279,13 @@ int64_t count_nulls(Ctx *ctx, const DCol &c) {
 }
 
 // ------------------------------------------------------------ emitting batches --
-struct OwnedBatch {
-  sqlrs_batch_t abi;
-  std::vector<sqlrs_column_t> descs;
-  DBatch dev;                     // keeps device buffers alive (out_mem == DEVICE)
-  std::vector<void *> host_blocks; // malloc'd (out_mem == HOST)
-  ~OwnedBatch() {
-    for (void *p : host_blocks) std::free(p);
-  }
-};
-
 sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem) {
   if (out_mem != SQLRS_MEM_HOST && out_mem != SQLRS_MEM_DEVICE)
     fail(SQLRS_ERR_INTERNAL, "bad out_mem");
   auto o = std::unique_ptr<OwnedBatch>(new OwnedBatch());
   o->dev = std::move(b);
+  o->ctx = ctx;
+  o->out_mem = out_mem;
   DBatch &d = o->dev;
   const int64_t rows = d.rows;
   o->descs.resize(d.cols.size());

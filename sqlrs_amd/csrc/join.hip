@@ -399,7 +399,7 @@ __global__ __launch_bounds__(BLOCK) void join_probe_unique_outer_kernel(
 }
 
 // min / max of the valid build keys as signed integers (dense-range detection)
-__global__ void key_minmax_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
+__global__ __launch_bounds__(256) void key_minmax_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
                                   int64_t n, unsigned long long *mn, unsigned long long *mx) {
   unsigned long long lo = ~0ull, hi = 0;
   constexpr int KU = 8; // independent loads in flight per lane (rows past the end re-read the last row)
@@ -422,7 +422,17 @@ __global__ void key_minmax_kernel(const uint64_t *__restrict__ keys, const uint6
     lo = a < lo ? a : lo;
     hi = b > hi ? b : hi;
   }
+  __shared__ unsigned long long s_lo[4], s_hi[4]; // 256 threads; one pair of atomics per block
   if (lane_id() == 0) {
+    s_lo[wave_id()] = lo;
+    s_hi[wave_id()] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+    }
     atomicMin(mn, lo);
     atomicMax(mx, hi);
   }
@@ -545,7 +555,7 @@ static void build_table(sqlrs_hash_join *j) {
     SQ_HIP(hipMemsetAsync(mm->p, 0xff, 8, ctx->stream));
     SQ_HIP(hipMemsetAsync(mm->as<uint8_t>() + 8, 0, 8, ctx->stream));
     const uint64_t *vp = validity ? validity->as<uint64_t>() : nullptr;
-    unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 1024);
+    unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 4 * (int64_t)ctx->num_cus);
     key_minmax_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n,
                                                                   mm->as<unsigned long long>(),
                                                                   mm->as<unsigned long long>() + 1);

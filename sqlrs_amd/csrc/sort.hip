@@ -163,7 +163,14 @@ __global__ __launch_bounds__(256) void rs_diff_kernel(const uint64_t *__restrict
     for (int u = 0; u < 8; u++) d |= k[u] ^ k0;
   }
   for (int m = 32; m >= 1; m >>= 1) d |= shfl_xor_u64(d, m);
-  if (lane_id() == 0 && d) atomicOr(diff_or, (unsigned long long)d);
+  // one atomic per block: thousands of atomics on one address cost more than the read of the keys
+  __shared__ unsigned long long s_d[4];
+  if (lane_id() == 0) s_d[wave_id()] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    d = s_d[0] | s_d[1] | s_d[2] | s_d[3];
+    if (d) atomicOr(diff_or, (unsigned long long)d);
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) diff_or[1] = k0; // the bits all keys share are read off any key
 }
 
