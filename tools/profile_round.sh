@@ -32,7 +32,7 @@ out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "--warmup 2 --no-cpu-baseline` (C5, 1e9 x 1e7); counter values are KiB; per-launch means over launches "
                "with > 1e5 units; HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts "
                "half of a coalesced streaming read; calibration: filter_cmp_const reads 8.0e9 B)", "kernels": {}}
-short = {"rp_scatter": "sq::rp_scatter_kernel", "lds_agg": "sq::lds_agg_kernel", "filter_cmp_const": "sq::filter_cmp_const",
+short = {"rp_scatter": "sq::rp_scatter_kernel", "lds_agg": "sq::lds_agg", "filter_cmp_const": "sq::filter_cmp_const",
          "compact": "sq::compact_kernel", "rp_hist": "sq::rp_hist_kernel"}
 for k, pref in short.items():
     # both passes run the same command, so launch i of a kernel is the same launch in both; the
