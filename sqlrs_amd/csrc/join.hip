@@ -438,26 +438,38 @@ __global__ __launch_bounds__(256) void key_minmax_kernel(const uint64_t *__restr
   }
 }
 __global__ void dense_fill_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
-                                  int64_t n, uint64_t kmin, uint32_t *__restrict__ heads, uint32_t *null_head) {
+                                  int64_t n, uint64_t kmin, uint32_t *__restrict__ heads, uint32_t *null_head,
+                                  unsigned long long *counts /* [1] += NULL keys */) {
   int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (r >= n) return;
   if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) {
     *null_head = (uint32_t)r; // unique build keys: at most one NULL row
+    atomicAdd(counts + 1, 1ull);
     return;
   }
   heads[keys[r] - kmin] = (uint32_t)r;
 }
 
-// after dense_fill_kernel (last writer wins): a row that does not find itself was overwritten by
-// a duplicate of its key; two NULL keys are duplicates too (NULL = NULL matches)
-__global__ void dense_verify_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
-                                    int64_t n, uint64_t kmin, const uint32_t *__restrict__ heads,
-                                    const uint32_t *null_head, int *dup) {
-  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  bool null_key = validity && !((validity[r >> 6] >> (r & 63)) & 1);
-  uint32_t h = null_key ? *null_head : heads[keys[r] - kmin];
-  if (h != (uint32_t)r) *dup = 1;
+// After dense_fill_kernel (last writer wins): the valid keys are unique exactly when they occupy as
+// many slots as there are valid rows — a streaming count of the table (4 B per possible key)
+// instead of a second random access per build row (0.19 -> 0.02 ms for 1e7 keys).  Two NULL keys
+// are duplicates too (NULL = NULL matches): the host checks counts[1] <= 1.
+__global__ __launch_bounds__(256) void dense_count_kernel(const uint32_t *__restrict__ heads, int64_t range,
+                                                          unsigned long long *counts /* [0] += occupied slots */) {
+  uint32_t c = 0;
+  constexpr int KU = 8;
+  for (int64_t base = blockIdx.x * (int64_t)(256 * KU) + threadIdx.x; base < range; base += (int64_t)gridDim.x * (256 * KU)) {
+    uint32_t h[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) h[u] = heads[min(base + u * 256, range - 1)];
+#pragma unroll
+    for (int u = 0; u < KU; u++) c += (base + u * 256 < range) && h[u] != DENSE_EMPTY;
+  }
+  c = wave_sum_u32(c);
+  __shared__ uint32_t s_c[4];
+  if (lane_id() == 0) s_c[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(counts, (unsigned long long)(s_c[0] + s_c[1] + s_c[2] + s_c[3]));
 }
 
 __global__ void bytes_to_bits_kernel(const uint8_t *__restrict__ bytes, int64_t n,
@@ -570,14 +582,16 @@ static void build_table(sqlrs_hash_join *j) {
         SQ_HIP(hipMemsetAsync(dense->p, 0xff, 4 * (size_t)range + 8, ctx->stream));
         uint64_t dmin = lo ^ (1ull << 63); // back from the ordered image to the two's complement bits
         uint32_t *null_head = dense->as<uint32_t>() + range; // spare slot after the table
-        BufP dup = ctx->alloc_zero(8); // {duplicate flag (int), copy of the NULL row's head (u32)}
+        BufP cnt = ctx->alloc_zero(24); // {occupied slots, NULL keys, copy of the NULL row's head (u32)}
         dense_fill_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
-            keys->as<uint64_t>(), vp, n, dmin, dense->as<uint32_t>(), null_head);
-        dense_verify_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
-            keys->as<uint64_t>(), vp, n, dmin, dense->as<uint32_t>(), null_head, dup->as<int>());
-        SQ_HIP(hipMemcpyAsync(dup->as<uint32_t>() + 1, null_head, 4, hipMemcpyDeviceToDevice, ctx->stream));
+            keys->as<uint64_t>(), vp, n, dmin, dense->as<uint32_t>(), null_head, cnt->as<unsigned long long>());
+        unsigned cblocks = (unsigned)std::min<int64_t>(ceil_div((int64_t)range, 256 * 8), 4 * (int64_t)ctx->num_cus);
+        dense_count_kernel<<<dim3(cblocks), dim3(256), 0, ctx->stream>>>(dense->as<uint32_t>(), (int64_t)range,
+                                                                        cnt->as<unsigned long long>());
+        SQ_HIP(hipMemcpyAsync(cnt->as<uint64_t>() + 2, null_head, 4, hipMemcpyDeviceToDevice, ctx->stream));
         SQ_HIP(hipGetLastError());
-        const uint32_t *hd = (const uint32_t *)ctx->fetch(dup->p, 8); // one round trip for both
+        const uint64_t *hc = (const uint64_t *)ctx->fetch(cnt->p, 24); // one round trip for all three
+        const uint32_t hd[2] = {(hc[1] <= 1 && hc[0] + hc[1] == (uint64_t)n) ? 0u : 1u, (uint32_t)hc[2]};
         if (hd[0] == 0) {
           j->unique = true;
           j->dense = dense;
