@@ -301,7 +301,10 @@ __device__ unsigned long long filter_timing[8];
 #ifndef FILTER_LB_LOADS
 #define FILTER_LB_LOADS 1
 #endif
-constexpr int FILTER_WAVES = 8;
+#ifndef FILTER_WAVES_N
+#define FILTER_WAVES_N 8
+#endif
+constexpr int FILTER_WAVES = FILTER_WAVES_N; // even: two worker waves per 4096-row compaction tile
 constexpr int FILTER_CHUNKS = 32;                                // 64-row chunks per worker wave
 constexpr int FILTER_TILE_ROWS = FILTER_WAVES * FILTER_CHUNKS * 64; // 16384
 constexpr int FILTER_SUB = FILTER_TILE_ROWS / TILE_ROWS;           // 4096-row tiles per filter tile
