@@ -765,7 +765,7 @@ def test_join_agg_probe_keys_outside_build_range(hip, oracle, npb):
 
 # ----------------------------------------- range partition + direct-addressed bucket tables --
 @pytest.mark.parametrize("shape", ["uniform", "sparse_quarter", "clustered", "zipf", "one_hot_bucket", "multi_level"])
-@pytest.mark.parametrize("aggs_kind", ["count_sum_f64", "min_max_i64", "count_only"])
+@pytest.mark.parametrize("aggs_kind", ["count_sum_f64", "min_max_i64", "count_only", "no_aggregates"])
 def test_hash_agg_dense_key_route(hip, oracle, shape, aggs_kind):
     """Integer keys that fill most of their range are partitioned by key range and aggregated in
     direct-addressed LDS tables (agg_partition.hip, lds_agg_dense_kernel): uniform keys, a range
@@ -793,9 +793,13 @@ def test_hash_agg_dense_key_route(hip, oracle, shape, aggs_kind):
         v = pa.array(rng.integers(-10**12, 10**12, n, dtype=np.int64))
         aggs = [AggFunc("min", InputRef(1), abi.INT64), AggFunc("max", InputRef(1), abi.INT64)]
         fl = set()
-    else:
+    elif aggs_kind == "count_only":
         v = pa.array(rng.integers(0, 5, n, dtype=np.int64))
         aggs = [AggFunc("count", InputRef(1), abi.INT64)]
+        fl = set()
+    else:  # SELECT DISTINCT k (planner/select.rs:29-32): group-by without aggregate functions
+        v = pa.array(rng.integers(0, 5, n, dtype=np.int64))
+        aggs = []
         fl = set()
     b = pa.RecordBatch.from_arrays([pa.array(keys), v], names=["k", "v"])
     got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
