@@ -73,7 +73,12 @@ typedef struct sqlrs_column {
 
 /* One RecordBatch.  [ref: arrow::record_batch::RecordBatch, the item type of
  * BoxedExecutor, executor/mod.rs:34].  Batches returned by the library are
- * owned by it until sqlrs_batch_release. */
+ * owned by it until sqlrs_batch_release.  A DEVICE batch returned by the library
+ * may be pushed, unchanged, into another operator of the same ctx: an operator
+ * that retains its input (join build side, HashAgg) then shares the batch's
+ * reference-counted buffers instead of copying them, and sqlrs_batch_release
+ * only drops the caller's reference (the Arc<RecordBatch> clone of the reference).
+ * Buffers of caller-built batches are borrowed for the duration of the call only. */
 typedef struct sqlrs_batch {
   int64_t num_rows;
   int32_t num_columns;
