@@ -1,6 +1,9 @@
 // ctx.hip — ctx lifecycle, device memory pool, ABI <-> HBM column conversion, timers.
 #include <cstdlib>
 
+#include <mutex>
+#include <unordered_set>
+
 #include "common.hpp"
 #include "prims.hpp"
 
@@ -203,8 +206,11 @@ DCol upload_column(Ctx *ctx, const sqlrs_column_t &c, bool force_copy) {
   return d;
 }
 
-// A batch this library produced (sqlrs_batch_t::owner points here).
+// A batch this library produced (sqlrs_batch_t::owner points here).  Live records are registered,
+// so an `owner` field that a caller forgot to clear is never dereferenced.
 constexpr uint64_t OWNED_BATCH_MAGIC = 0x5351425443483031ull;
+static std::mutex g_owned_mu;
+static std::unordered_set<const void *> g_owned;
 struct OwnedBatch {
   sqlrs_batch_t abi;
   std::vector<sqlrs_column_t> descs;
@@ -213,7 +219,15 @@ struct OwnedBatch {
   uint64_t magic = OWNED_BATCH_MAGIC;
   Ctx *ctx = nullptr;
   int out_mem = SQLRS_MEM_HOST;
+  OwnedBatch() {
+    std::lock_guard<std::mutex> lk(g_owned_mu);
+    g_owned.insert(this);
+  }
   ~OwnedBatch() {
+    {
+      std::lock_guard<std::mutex> lk(g_owned_mu);
+      g_owned.erase(this);
+    }
     magic = 0;
     for (void *p : host_blocks) std::free(p);
   }
@@ -225,6 +239,10 @@ struct OwnedBatch {
 // sqlrs_batch_release only drops its own reference.
 static const DBatch *shared_columns_of(Ctx *c, const sqlrs_batch_t *b) {
   if (!b->owner) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_owned_mu);
+    if (!g_owned.count(b->owner)) return nullptr;
+  }
   const OwnedBatch *o = (const OwnedBatch *)b->owner;
   if (&o->abi != b || o->magic != OWNED_BATCH_MAGIC || o->ctx != c || o->out_mem != SQLRS_MEM_DEVICE) return nullptr;
   if (b->columns != o->descs.data() || b->num_columns != (int)o->dev.cols.size() || b->num_rows != o->dev.rows)
@@ -401,7 +419,12 @@ void sqlrs_ctx_pool_trim(sqlrs_ctx_t *ctx) {
 }
 
 void sqlrs_batch_release(sqlrs_batch_t *batch) {
-  if (batch && batch->owner) delete (OwnedBatch *)batch->owner;
+  if (!batch || !batch->owner) return;
+  {
+    std::lock_guard<std::mutex> lk(g_owned_mu);
+    if (!g_owned.count(batch->owner)) return; // not (or no longer) one of ours: released twice, or a stray owner field
+  }
+  delete (OwnedBatch *)batch->owner;
 }
 
 int sqlrs_batch_copy(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out) {
