@@ -398,7 +398,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
         }
       }
       if (act) {
-        atomicMin(&tfirst[s], cur.id[u]);
+        if (cur.id[u] < tfirst[s]) atomicMin(&tfirst[s], cur.id[u]); // (see lds_agg_dense_kernel)
 #pragma unroll
         for (int a = 0; a < PART_MAX_ACC; a++) {
           if (a >= n_acc) break;
@@ -613,7 +613,9 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
         }
       }
       if (act) {
-        atomicMin(&tfirst[s], id);
+        // most rows are not their group's first row: a plain LDS read decides, the atomic (an order
+        // of magnitude more expensive than a read on this LDS) runs for the few that lower the minimum
+        if (id < tfirst[s]) atomicMin(&tfirst[s], id);
 #pragma unroll
         for (int a = 0; a < PART_MAX_ACC; a++) {
           if (a >= n_acc) break;
