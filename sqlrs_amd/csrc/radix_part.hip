@@ -357,6 +357,11 @@ struct Level {
   std::vector<uint32_t> seg_tiles, seg_tile_base;
   int64_t mat_entries = 0;
   uint32_t num_tiles = 0;
+  // the four arrays on the device: ONE upload per level (seven small copies per level before)
+  std::vector<uint8_t> blob; // host source of the upload (must outlive it)
+  BufP dev;
+  const int64_t *d_seg_start = nullptr, *d_seg_mat = nullptr;
+  const uint32_t *d_seg_tiles = nullptr, *d_seg_tile_base = nullptr;
 };
 
 // per-segment geometry only (<= 513 entries); the Tile descriptors themselves are filled on the
@@ -378,11 +383,22 @@ Level plan_level(const std::vector<int64_t> &seg_start, uint32_t digits, int RP_
   return L;
 }
 
-template <class T> BufP upload(Ctx *ctx, const std::vector<T> &v) {
-  BufP b = ctx->alloc(sizeof(T) * std::max<size_t>(v.size(), 1));
-  if (!v.empty())
-    SQ_HIP(hipMemcpyAsync(b->p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream));
-  return b;
+void upload_level(Ctx *ctx, Level &L) {
+  const size_t nseg = L.seg_tiles.size();
+  const size_t o_start = 0, o_mat = o_start + 8 * (nseg + 1), o_tiles = o_mat + 8 * nseg,
+               o_base = o_tiles + round_up(4 * nseg, 8), total = o_base + round_up(4 * nseg, 8);
+  L.blob.resize(total);
+  std::memcpy(L.blob.data() + o_start, L.seg_start.data(), 8 * (nseg + 1));
+  std::memcpy(L.blob.data() + o_mat, L.seg_mat.data(), 8 * nseg);
+  std::memcpy(L.blob.data() + o_tiles, L.seg_tiles.data(), 4 * nseg);
+  std::memcpy(L.blob.data() + o_base, L.seg_tile_base.data(), 4 * nseg);
+  L.dev = ctx->alloc(total);
+  SQ_HIP(hipMemcpyAsync(L.dev->p, L.blob.data(), total, hipMemcpyHostToDevice, ctx->stream));
+  const uint8_t *d = L.dev->as<uint8_t>();
+  L.d_seg_start = (const int64_t *)(d + o_start);
+  L.d_seg_mat = (const int64_t *)(d + o_mat);
+  L.d_seg_tiles = (const uint32_t *)(d + o_tiles);
+  L.d_seg_tile_base = (const uint32_t *)(d + o_base);
 }
 
 } // namespace
@@ -442,14 +458,10 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
                        const RpOut &rout, BufP *offs_out, Level *plan_out) {
     Level L = plan_level(seg_start, digits, RP_TILE);
     BufP tiles = ctx->alloc(sizeof(Tile) * (size_t)std::max<uint32_t>(L.num_tiles, 1));
-    {
-      BufP ss = upload(ctx, L.seg_start), sm = upload(ctx, L.seg_mat), st = upload(ctx, L.seg_tiles),
-           sb = upload(ctx, L.seg_tile_base);
-      rp_make_tiles_kernel<<<dim3((unsigned)L.seg_tiles.size()), dim3(256), 0, ctx->stream>>>(
-          (const int64_t *)ss->p, (const int64_t *)sm->p, (const uint32_t *)st->p, (const uint32_t *)sb->p,
-          RP_TILE, (Tile *)tiles->p);
-      SQ_HIP(hipGetLastError());
-    }
+    upload_level(ctx, L);
+    rp_make_tiles_kernel<<<dim3((unsigned)L.seg_tiles.size()), dim3(256), 0, ctx->stream>>>(
+        L.d_seg_start, L.d_seg_mat, L.d_seg_tiles, L.d_seg_tile_base, RP_TILE, (Tile *)tiles->p);
+    SQ_HIP(hipGetLastError());
     BufP mat = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
     BufP offs = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
     BufP total = ctx->alloc(8);
@@ -519,12 +531,10 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // `host` receives a copy (the synchronisation that keeps L's upload sources alive pays for it)
   auto bucket_starts = [&](const Level &L, const BufP &offs, uint32_t digits, std::vector<uint32_t> *host) -> BufP {
     uint32_t nseg = (uint32_t)L.seg_tiles.size();
-    BufP sm = upload(ctx, L.seg_mat), st = upload(ctx, L.seg_tiles), ss = upload(ctx, L.seg_start);
     int64_t total = (int64_t)nseg * digits + 1;
     BufP bs = ctx->alloc(4 * (size_t)total);
     rp_bucket_starts_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
-        offs->as<uint32_t>(), (const int64_t *)sm->p, (const uint32_t *)st->p, (const int64_t *)ss->p, digits,
-        nseg, n, bs->as<uint32_t>());
+        offs->as<uint32_t>(), L.d_seg_mat, L.d_seg_tiles, L.d_seg_start, digits, nseg, n, bs->as<uint32_t>());
     SQ_HIP(hipGetLastError());
     host->resize((size_t)total);
     SQ_HIP(hipMemcpyAsync(host->data(), bs->p, 4 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
