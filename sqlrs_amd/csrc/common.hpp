@@ -65,6 +65,7 @@ struct Buf {
   void *p;
   size_t cap;
   bool owned = true; // false: a view of memory this library does not own (never released)
+  std::shared_ptr<Buf> parent; // a view into a larger block of this library: keeps that block alive
   Buf(Ctx *c, void *ptr, size_t n) : ctx(c), p(ptr), cap(n) {}
   ~Buf();
   Buf(const Buf &) = delete;
@@ -100,6 +101,10 @@ struct Ctx {
 
   BufP alloc(size_t bytes);
   BufP alloc_zero(size_t bytes);
+  // small zeroed buffers (flags, counters, descriptors) are carved out of a block that was zeroed
+  // with ONE memset: every hipMemsetAsync is a ~5 us device operation of its own
+  BufP zero_block;
+  size_t zero_used = 0;
   void sync() { SQ_HIP(hipStreamSynchronize(stream)); }
   // copies `bytes` from device to the pinned area and synchronises; returns host pointer
   const void *fetch(const void *dptr, size_t bytes);

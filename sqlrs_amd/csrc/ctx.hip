@@ -64,6 +64,20 @@ BufP Ctx::alloc(size_t bytes) {
   return std::make_shared<Buf>(this, p, cap);
 }
 BufP Ctx::alloc_zero(size_t bytes) {
+  constexpr size_t ZERO_BLOCK = 64 * 1024, ZERO_SMALL = 4096;
+  if (bytes <= ZERO_SMALL) {
+    const size_t need = round_up(bytes ? bytes : 8, 256);
+    if (!zero_block || zero_used + need > ZERO_BLOCK) {
+      zero_block = alloc(ZERO_BLOCK); // the old block lives on while views of it do
+      SQ_HIP(hipMemsetAsync(zero_block->p, 0, ZERO_BLOCK, stream));
+      zero_used = 0;
+    }
+    BufP v = std::make_shared<Buf>(this, (uint8_t *)zero_block->p + zero_used, need);
+    v->owned = false;
+    v->parent = zero_block;
+    zero_used += need;
+    return v;
+  }
   BufP b = alloc(bytes);
   SQ_HIP(hipMemsetAsync(b->p, 0, bytes ? bytes : 8, stream));
   return b;
@@ -398,6 +412,7 @@ void sqlrs_ctx_destroy(sqlrs_ctx_t *ctx) {
     (void)hipEventDestroy(p.b);
   }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  ctx->zero_block.reset();
   ctx->pool.trim();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipStreamDestroy(ctx->stream);
@@ -415,6 +430,7 @@ int64_t sqlrs_ctx_pool_bytes(const sqlrs_ctx_t *ctx) {
 }
 void sqlrs_ctx_pool_trim(sqlrs_ctx_t *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
+  ctx->zero_block.reset();
   ctx->pool.trim();
 }
 
