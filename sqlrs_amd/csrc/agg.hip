@@ -408,22 +408,32 @@ DCol agg_finalize_values(Ctx *ctx, int func, int32_t dtype, GrowBuf &acc, GrowBu
   return agg_finalize_raw(ctx, func, dtype, acc.buf->as<uint64_t>(), nn ? nn->buf->as<uint64_t>() : nullptr, G);
 }
 
-DCol agg_finalize_raw(Ctx *ctx, int func, int32_t dtype, const uint64_t *acc, const uint64_t *nn, int64_t G) {
+DCol agg_finalize_raw(Ctx *ctx, int func, int32_t dtype, const uint64_t *acc, const uint64_t *nn, int64_t G,
+                      const BufP &acc_owner) {
   DCol o;
   o.length = G;
   int64_t g1 = std::max<int64_t>(G, 1);
   dim3 g((unsigned)ceil_div(g1, 256)), b(256);
+  const bool view = acc_owner && G > 0;
   if (func == SQLRS_AGG_COUNT) {
     o.dtype = SQLRS_INT64;
-    o.own_values = ctx->alloc(8 * (size_t)g1);
-    if (G) SQ_HIP(hipMemcpyAsync(o.own_values->p, acc, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
+    if (view) {
+      o.own_values = buf_view(acc_owner, acc, 8 * (size_t)G);
+    } else {
+      o.own_values = ctx->alloc(8 * (size_t)g1);
+      if (G) SQ_HIP(hipMemcpyAsync(o.own_values->p, acc, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     o.values = o.own_values->p;
     return o;
   }
   o.dtype = dtype;
   if (func == SQLRS_AGG_SUM) {
-    o.own_values = ctx->alloc(8 * (size_t)g1);
-    if (G) SQ_HIP(hipMemcpyAsync(o.own_values->p, acc, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
+    if (view) {
+      o.own_values = buf_view(acc_owner, acc, 8 * (size_t)G);
+    } else {
+      o.own_values = ctx->alloc(8 * (size_t)g1);
+      if (G) SQ_HIP(hipMemcpyAsync(o.own_values->p, acc, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
+    }
   } else {
     o.own_values = ctx->alloc(8 * (size_t)g1);
     if (G) {

@@ -43,7 +43,10 @@ void agg_update_sum(Ctx *ctx, GrowBuf &acc, int32_t dtype, const uint32_t *row_g
                     const uint64_t *validity, int64_t n);
 void agg_update_minmax(Ctx *ctx, GrowBuf &acc, int32_t dtype, bool is_min, const uint32_t *row_gid,
                        const void *vals, const uint64_t *validity, int64_t n);
-DCol agg_finalize_raw(Ctx *ctx, int func, int32_t dtype, const uint64_t *acc, const uint64_t *nn, int64_t G);
+// `acc_owner` (optional): the buffer `acc` points into; COUNT / SUM columns are then views of it
+// instead of copies (the cells already hold the final values)
+DCol agg_finalize_raw(Ctx *ctx, int func, int32_t dtype, const uint64_t *acc, const uint64_t *nn, int64_t G,
+                      const BufP &acc_owner = nullptr);
 DCol agg_finalize_values(Ctx *ctx, int func, int32_t dtype, GrowBuf &acc, GrowBuf *nn, int64_t G);
 
 } // namespace sq

@@ -73,6 +73,13 @@ struct Buf {
   template <class T> T *as() const { return (T *)p; }
 };
 using BufP = std::shared_ptr<Buf>;
+// `bytes` at `p` inside `parent`, kept alive by it (never released on its own)
+inline BufP buf_view(const BufP &parent, const void *p, size_t bytes) {
+  BufP v = std::make_shared<Buf>(parent->ctx, const_cast<void *>(p), bytes);
+  v->owned = false;
+  v->parent = parent;
+  return v;
+}
 
 struct ProfEntry {
   const char *name;

@@ -343,19 +343,18 @@ static DBatch emit_pending(sqlrs_hash_agg *a) {
     int col = pg.col_of_agg[i];
     int cc = pg.cnt_of_col[(size_t)col];
     if (s.func == SQLRS_AGG_COUNT) {
-      o.cols.push_back(agg_finalize_raw(ctx, s.func, SQLRS_INT64, cell(cc), nullptr, G));
+      o.cols.push_back(agg_finalize_raw(ctx, s.func, SQLRS_INT64, cell(cc), nullptr, G, po.gacc));
       continue;
     }
     const uint64_t *nn = pg.col_nullable[(size_t)col] ? cell(cc) : nullptr;
     int32_t dt = s.func == SQLRS_AGG_SUM ? s.return_dtype : pg.col_dtype[(size_t)col];
-    DCol c = agg_finalize_raw(ctx, s.func, dt, cell(pg.acc_of_agg[i]), nn, G);
+    DCol c = agg_finalize_raw(ctx, s.func, dt, cell(pg.acc_of_agg[i]), nn, G, po.gacc);
     c.dtype = s.return_dtype;
     o.cols.push_back(c);
   }
   if (G > 1 && !a->any_order) { // bucket order -> first-seen order (hash_agg.rs:98,132)
     ProfScope ps(ctx, "agg_order_groups");
-    BufP keys = ctx->alloc(8 * (size_t)G), perm = ctx->alloc(4 * (size_t)G);
-    SQ_HIP(hipMemcpyAsync(keys->p, po.row_ids->p, 8 * (size_t)G, hipMemcpyDeviceToDevice, ctx->stream));
+    BufP keys = po.row_ids, perm = ctx->alloc(4 * (size_t)G); // sorted in place: this is the batch's last use
     iota_u32(ctx, perm->as<uint32_t>(), G);
     int bits = 1;
     while (bits < 64 && (1ull << bits) <= (uint64_t)std::max<int64_t>(a->rows_seen, 1)) bits++;
