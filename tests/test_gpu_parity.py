@@ -847,3 +847,31 @@ def test_agg_paths_without_dense_tables():
                         "-k", "(partition_route or join_agg or dense_key) and not forced and not without"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("shape", ["int64_7_groups", "int64_sparse_40_groups", "utf8_10_groups", "two_columns_12_groups"])
+def test_hash_agg_partition_route_few_groups(hip, oracle, shape):
+    """Few groups on the partition route: the batch is one or a handful of buckets, every bucket is
+    cut into many chunks whose LDS tables merge through the per-bucket global tables (a single
+    workgroup used to stream the whole batch)."""
+    n = 3_000_000
+    rng = np.random.default_rng(len(shape))
+    v = pa.array(rng.random(n))
+    if shape == "int64_7_groups":
+        kc, gb = [pa.array(rng.integers(-3, 4, n, dtype=np.int64))], [InputRef(0)]
+    elif shape == "int64_sparse_40_groups":
+        kc, gb = [pa.array(rng.integers(0, 40, n, dtype=np.int64) * 1_000_003 - 17)], [InputRef(0)]
+    elif shape == "utf8_10_groups":
+        st = ["CA", "CO", "NY", "TX", "WA", "Colorado State", "California State", "", "zz", "abcdefghij"]
+        kc = [pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, len(st), n, dtype=np.int32)), pa.array(st)).cast(pa.string())]
+        gb = [InputRef(0)]
+    else:
+        kc = [pa.array(rng.integers(0, 3, n, dtype=np.int64)), pa.array(rng.integers(10, 14, n, dtype=np.int64))]
+        gb = [InputRef(0), InputRef(1)]
+    b = pa.RecordBatch.from_arrays(kc + [v], names=[f"k{i}" for i in range(len(kc))] + ["v"])
+    vi = len(kc)
+    aggs = [AggFunc("count", InputRef(vi), abi.INT64), AggFunc("sum", InputRef(vi), abi.FLOAT64),
+            AggFunc("min", InputRef(vi), abi.FLOAT64)]
+    got = rows_of(HashAggExecutor(hip, aggs, gb, [b]).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, gb, [b]).execute())
+    assert_same(got, exp, float_cols={len(kc) + 1})
