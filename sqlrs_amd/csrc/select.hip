@@ -502,6 +502,21 @@ __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_persistent_kern
   }
 }
 
+// Workgroups per CU that are resident for sure.  The occupancy API divides the CU's wave slots by
+// the waves of a block, but a block's waves are dealt to the four SIMDs starting at the same one:
+// two 9-wave blocks need 3 + 3 slots on SIMD 0, and at 96 registers (5 waves per SIMD) the second
+// block does NOT fit although 18 <= 20.  The int32 filter (96 registers) was launched with two
+// blocks per CU on the API's word, half of them never became resident and every call waited out
+// the look-back timeout (1.4 s) before the ticketed rerun.
+static int simd_safe_blocks(const void *kernel, int block_threads) {
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) return 1;
+  const int regs = std::max(8, (int)round_up((size_t)std::max(fa.numRegs, 1), 8));
+  const int per_simd = std::min(8, 512 / regs);
+  const int need = (int)ceil_div(ceil_div(block_threads, 64), 4); // waves of one block on its fullest SIMD
+  return std::max(1, per_simd / need);
+}
+
 template <class T>
 static void launch_filter(Ctx *ctx, int op, const DCol &c, T k, int64_t rows, T *out,
                           uint64_t *sel_bits, uint64_t *tile_off, uint64_t *desc, unsigned *ticket,
@@ -521,7 +536,8 @@ static void launch_filter(Ctx *ctx, int op, const DCol &c, T k, int64_t rows, T 
       if (!occ) {                                                                                                \
         SQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, filter_cmp_const_persistent_kernel<T, OP, HV>, \
                                                             FILTER_BLOCK, 0));                                   \
-        occ = std::max(1, std::min(occ, 2));                                                                     \
+        occ = std::max(1, std::min({occ, 2, simd_safe_blocks((const void *)filter_cmp_const_persistent_kernel<T, OP, HV>, \
+                                                              FILTER_BLOCK)}));                                  \
       }                                                                                                          \
       unsigned g = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->num_cus * occ);                              \
       filter_cmp_const_persistent_kernel<T, OP, HV><<<dim3(g), dim3(FILTER_BLOCK), 0, ctx->stream>>>(            \

@@ -875,3 +875,35 @@ def test_hash_agg_partition_route_few_groups(hip, oracle, shape):
     got = rows_of(HashAggExecutor(hip, aggs, gb, [b]).execute())
     exp = rows_of(HashAggExecutor(oracle, aggs, gb, [b]).execute())
     assert_same(got, exp, float_cols={len(kc) + 1})
+
+
+@pytest.mark.parametrize("dtype", ["i32", "i64", "f64"])
+def test_filter_fast_path_large_batch_stays_on_its_first_launch(hip, oracle, dtype):
+    """The persistent filter kernel needs all its workgroups resident.  The int32 variant (96 registers)
+    was launched with two 9-wave workgroups per CU on the occupancy API's word, half of them were not
+    resident, and every call sat out the look-back timeout (1.4 s) before the ticketed rerun: results
+    were right, 15 000x late.  Checked by result and by a (very generous) time bound."""
+    import time
+    n = 6_000_000
+    rng = np.random.default_rng(11)
+    if dtype == "i32":
+        col, k = pa.array(rng.integers(0, 100, n).astype(np.int32)), Constant(7, abi.INT32)
+    elif dtype == "i64":
+        col, k = pa.array(rng.integers(0, 100, n, dtype=np.int64)), Constant(7, abi.INT64)
+    else:
+        col, k = pa.array(rng.random(n)), Constant(0.25, abi.FLOAT64)
+    b = pa.RecordBatch.from_arrays([col, pa.array(np.arange(n, dtype=np.int64))], names=["v", "i"])
+    dev = hip.to_device(b)
+    e = BinaryOp(">", InputRef(0), k)
+    for _ in range(2):  # warm-up: code objects, pool
+        for o in FilterExecutor(hip, e, [dev], out_mem=abi.MEM_DEVICE).execute():
+            o.release()
+    hip.synchronize()
+    t = time.perf_counter()
+    for o in FilterExecutor(hip, e, [dev], out_mem=abi.MEM_DEVICE).execute():
+        o.release()
+    hip.synchronize()
+    dt = time.perf_counter() - t
+    got = rows_of(FilterExecutor(hip, e, [dev]).execute())
+    assert got == rows_of(FilterExecutor(oracle, e, [b]).execute())
+    assert dt < 0.25, f"filter over {n} rows took {dt * 1e3:.1f} ms: look-back timeout + ticketed rerun?"
