@@ -40,7 +40,7 @@ __global__ __launch_bounds__(BLOCK) void agg_resolve_kernel(
   const uint64_t cap = mask + 1;
   uint64_t key = keys[r];
   uint64_t s;
-  bool special = false;
+  bool special = false, created = false;
   if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) {
     s = cap; // NULL keys form one group (hash_utils.rs:91-104, aggregation.slt:21-26)
     special = true;
@@ -57,8 +57,7 @@ __global__ __launch_bounds__(BLOCK) void agg_resolve_kernel(
       if (cur == AGG_EMPTY_KEY) {
         unsigned long long prev = atomicCAS(&table[s].key, AGG_EMPTY_KEY, (unsigned long long)key);
         if (prev == AGG_EMPTY_KEY) { // this thread created the group
-          unsigned long long c = atomicAdd(new_count, 1ull);
-          if (c >= max_new) __hip_atomic_store(overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          created = true;
           break;
         }
         if (prev == key) break;
@@ -71,6 +70,15 @@ __global__ __launch_bounds__(BLOCK) void agg_resolve_kernel(
     }
   }
   (void)special;
+  { // new groups are counted once per wave: one atomic per new group on this single address ran at
+    // 0.65 G/s (1e7 mostly distinct keys: 15 ms in this kernel)
+    const uint64_t cm = __ballot(created);
+    if (cm && lane_id() == __builtin_ctzll(cm)) {
+      const unsigned long long cnt = (unsigned long long)__popcll(cm);
+      unsigned long long c = atomicAdd(new_count, cnt);
+      if (c + cnt > max_new) __hip_atomic_store(overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   uint64_t rid = row_ids ? row_ids[r] : offset + (uint64_t)r;
   // first_row only ever decreases, so a stale larger value just costs one extra atomic
   unsigned long long cur = __hip_atomic_load(&table[s].first_row, __ATOMIC_RELAXED,

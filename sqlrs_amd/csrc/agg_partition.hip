@@ -775,7 +775,14 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   }();
   const double groups_per_table = cap * load_factor;
   double want = est * 1.15 / groups_per_table;
-  if (!join_mode && est > 0.5 * (double)n) return false; // mostly distinct keys: resolve path
+  static const double max_frac = [] { // tuning hook: largest groups / rows ratio taken by this route
+    const char *e = std::getenv("SQLRS_PART_MAX_FRAC");
+    return e ? std::atof(e) : 1.0;
+  }();
+  // (mostly distinct keys used to be sent to the row route, "est > n / 2": 17 ms instead of 1.7 ms
+  // for 1e7 rows with 8e6 groups — the bucket count limit below is the only size limit now)
+  if (!join_mode) est = std::min(est, (double)n);
+  if (!join_mode && est > max_frac * (double)n) return false;
   // Dense keys: when the keys of interest fill most of their range (surrogate keys, dimension
   // primary keys) the partition is by key range and the bucket tables are addressed directly:
   // R = 2^rbits slots of 8 * n_acc + 4 bytes at 100 % fill instead of cap slots of 8 more bytes
