@@ -180,7 +180,7 @@ __device__ __forceinline__ void lds_agg_load(const uint64_t *__restrict__ pk, co
   for (int u = 0; u < LDS_U; u++) {
     int64_t i = min(i0 + (int64_t)u * PART_WG, hi - 1);
     r.k[u] = __builtin_nontemporal_load(pk + i);
-    if (!PACK) r.id[u] = __builtin_nontemporal_load(pi + i);
+    if (!PACK) r.id[u] = pi ? __builtin_nontemporal_load(pi + i) : (uint32_t)i; // no id column: rows in place
     if (NV >= 1) r.v0[u] = __builtin_nontemporal_load(pv0 + i);
     if (NV >= 2) r.v1[u] = __builtin_nontemporal_load(pv1 + i);
     r.f[u] = FLAGS ? pf[i] : 7;
@@ -792,6 +792,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     const char *e = std::getenv("SQLRS_DENSE_AGG");
     return !(e && e[0] == '0');
   }();
+  const double want_hashed = want; // probing tables needed if the bucket pass ran on hashed buckets
   bool dense = false;
   if (dense_on && kp.kbits) {
     const uint64_t range = omax - omin;
@@ -826,7 +827,30 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     pin.val_validity[k] = in.val_validity[k];
   }
   PartitionedRows pr;
-  if (!partition_rows(ctx, pin, P, &pr)) return false;
+  // One bucket (few groups) and nothing nullable: there is nothing to partition — the bucket pass
+  // reads the caller's columns in place (row id = row index), cut into chunks by the few-buckets rule
+  // below.  Saves the histogram and scatter passes: 50 int64 groups over 5e7 rows 1.12 -> 0.6 ms.
+  const bool in_place = P == 1 && !join_mode && !nullable && want_hashed <= 1.0;
+  if (in_place) {
+    dense = false;
+    kp = KeyPack();
+    cap = 1; // (dense mode had set its own)
+    while ((size_t)(cap * 2 + 2) * slot_bytes <= lds_budget) cap *= 2;
+    pr.n = n;
+    pr.P = 1;
+    auto borrowed = [&](const void *p) {
+      BufP b = std::make_shared<Buf>(ctx, const_cast<void *>(p), 0);
+      b->owned = false;
+      return b;
+    };
+    pr.key = borrowed(in.keys);
+    pr.v0 = spec.nv >= 1 ? borrowed(in.vals[0]) : nullptr;
+    pr.v1 = spec.nv >= 2 ? borrowed(in.vals[1]) : nullptr;
+    pr.bstart_host = {0u, (uint32_t)n};
+    pr.bstart = nullptr;
+  } else if (!partition_rows(ctx, pin, P, &pr)) {
+    return false;
+  }
   P = pr.P;
   if (dense != (pr.pack.dense != 0)) return false;
   out->buckets = (int)P;
