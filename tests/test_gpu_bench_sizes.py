@@ -1,0 +1,244 @@
+"""Parity at the benchmark's own inputs and at BASELINE.json's full sizes.
+
+* `test_bench_pipeline_matches_oracle_per_group`: the columns bench.py generates (same generator,
+  same seeds), through bench.py's own `Pipeline` class (device resident, fused route), against the
+  CPU oracle PER GROUP and in the oracle's group order — at a size the oracle finishes in seconds.
+* the `full_size` tests run C2 / C3 / C4 / C5 at the sizes BASELINE.json states and check
+  size-independent properties against plain torch ops on the same columns (torch is only the
+  checker here; nothing of it is on the product path): filter = order-preserving selection,
+  join pairs probe-major with equal keys on both sides, group-by counts = bincount, sums =
+  index_add_ (1e-9 relative), groups in first-seen order.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(hip):
+    import torch
+
+    import bench
+    from sqlrs_amd import abi, datagen
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    return type("Env", (), dict(torch=torch, bench=bench, abi=abi, datagen=datagen, dev=dev, be=hip))
+
+
+def gen_c5(env, n_fact, n_dim, fact_mod=None):
+    t, d = env.torch, env.datagen
+    fk = d.fill_chunks(t.empty(n_fact, dtype=t.int64, device=env.dev), lambda i: d.key_t(0xF1, i, fact_mod or n_dim))
+    fv = d.fill_chunks(t.empty(n_fact, dtype=t.float64, device=env.dev), lambda i: d.val_t(0xF2, i))
+    dk = d.fill_chunks(t.empty(n_dim, dtype=t.int64, device=env.dev), lambda i: d.dim_key_t(i, n_dim))
+    t.cuda.synchronize()
+    return fk, fv, dk
+
+
+def view(env, col, n, dtype):
+    return env.bench._tensor_view(env.torch, col.values, n, dtype, env.dev)
+
+
+def first_seen_rows(env, keys_of_rows, n_keys):
+    """first_row[k] = smallest row index carrying key k (rows given in input order)"""
+    t = env.torch
+    first = t.full((n_keys,), 1 << 62, dtype=t.int64, device=env.dev)
+    for lo in range(0, keys_of_rows.numel(), 1 << 27):
+        k = keys_of_rows[lo:lo + (1 << 27)]
+        first.scatter_reduce_(0, k, t.arange(lo, lo + k.numel(), dtype=t.int64, device=env.dev), reduce="amin")
+    return first
+
+
+# ------------------------------------------------------------------------------------------
+def test_bench_pipeline_matches_oracle_per_group(env, oracle):
+    t, abi, d = env.torch, env.abi, env.datagen
+    n_fact, n_dim = 20_000_000, 1_000_000
+    fk, fv, dk = gen_c5(env, n_fact, n_dim)
+    # the device generator and the numpy generator (what the oracle is fed) agree bit for bit
+    idx = np.arange(n_fact, dtype=np.int64)
+    fk_np, fv_np = d.key_np(0xF1, idx, n_dim), d.val_np(0xF2, idx)
+    dk_np = d.dim_key_np(np.arange(n_dim, dtype=np.int64), n_dim)
+    assert np.array_equal(fk.cpu().numpy(), fk_np) and np.array_equal(fv.cpu().numpy(), fv_np)
+    assert np.array_equal(dk.cpu().numpy(), dk_np)
+
+    pipe = env.bench.Pipeline(env.be, abi, 0.5, fused=True)
+    out = pipe.step(env.bench.device_batch(abi, [dk], [abi.INT64]),
+                    env.bench.device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64]))
+    env.be.synchronize()
+    assert pipe.fused_batches == 1
+    g = out.num_rows
+    gk = view(env, out.column(0), g, t.int64).cpu().numpy()
+    gc = view(env, out.column(1), g, t.int64).cpu().numpy()
+    gs = view(env, out.column(2), g, t.float64).cpu().numpy()
+    out.release()
+
+    from sqlrs_amd.executor import FilterExecutor, HashAggExecutor, HashJoinExecutor
+    from sqlrs_amd.expr import AggFunc, Constant, InputRef, JoinCondition
+    fact = pa.RecordBatch.from_arrays([pa.array(fk_np), pa.array(fv_np)], names=["key", "val"])
+    dim = pa.RecordBatch.from_arrays([pa.array(dk_np)], names=["key"])
+    schema = pa.schema([("d.key", pa.int64()), ("f.key", pa.int64()), ("f.val", pa.float64())])
+    filt = FilterExecutor(oracle, InputRef(1) > Constant(0.5, abi.FLOAT64), [fact])
+    join = HashJoinExecutor(oracle, [dim], filt.execute(), "inner", JoinCondition([(InputRef(0), InputRef(0))]), schema, 1)
+    agg = HashAggExecutor(oracle, [AggFunc("count", InputRef(2), abi.INT64), AggFunc("sum", InputRef(2), abi.FLOAT64)],
+                          [InputRef(0)], join.execute())
+    (exp,) = list(agg.execute())
+    ek = exp.column(0).to_numpy(zero_copy_only=False)
+    ec = exp.column(1).to_numpy(zero_copy_only=False)
+    es = exp.column(2).to_numpy(zero_copy_only=False)
+    assert g == len(ek)
+    assert np.array_equal(gk, ek)  # keys bit-exact AND in the reference's first-seen order
+    assert np.array_equal(gc, ec)  # counts bit-exact
+    assert np.all(np.abs(gs - es) <= 1e-9 * np.maximum(np.abs(es), 1e-300))  # SUM(double): 1e-9 relative
+
+
+# ------------------------------------------------------------------------------ full sizes --
+@pytest.mark.parametrize("sel_k", [("0.5", 1 << 30), ("0.01", int((1 << 31) * 0.99)), ("0.99", int((1 << 31) * 0.01))])
+def test_full_size_c2_filter(env, sel_k):
+    """C2: SELECT v1 FROM t WHERE v1 > k over 1e8 int64 rows = torch's order-preserving masked select"""
+    t, abi, d = env.torch, env.abi, env.datagen
+    from sqlrs_amd.expr import Constant, InputRef
+    n = 100_000_000
+    _, k = sel_k
+    v1 = d.fill_chunks(t.empty(n, dtype=t.int64, device=env.dev), lambda i: d._lsr(d.splitmix64_t(0xC2, i), 33))
+    t.cuda.synchronize()
+    e = (InputRef(0) > Constant(k, abi.INT64)).pack()
+    f = C.c_void_p()
+    env.be.check(env.be.fn("filter_create")(env.be.ctx, C.byref(e.abi), C.byref(f)))
+    o = C.POINTER(abi.Batch)()
+    env.be.check(env.be.fn("filter_push")(f, env.bench.device_batch(abi, [v1], [abi.INT64]).ptr, abi.MEM_DEVICE, C.byref(o)))
+    env.be.fn("filter_destroy")(f)
+    out = env.be.wrap(o)
+    env.be.synchronize()
+    exp = v1[v1 > k]
+    assert out.num_rows == exp.numel()
+    assert t.equal(view(env, out.column(0), out.num_rows, t.int64), exp)
+    out.release()
+
+
+@pytest.mark.parametrize("variant", ["all_hit", "half_hit", "sparse_keys"])
+def test_full_size_c3_join_pairs(env, variant):
+    """C3: 1e8 fact JOIN 1e6 dim (Inner), index-pair form: one pair per probe row that has a partner
+    (unique build keys), probe-major order = right_idx strictly increasing, equal keys on both sides"""
+    t, abi, d = env.torch, env.abi, env.datagen
+    from sqlrs_amd.expr import InputRef
+    nP, nB = 100_000_000, 1_000_000
+    fk, _, dk = gen_c5(env, nP, nB, fact_mod=2 * nB if variant == "half_hit" else nB)
+    if variant == "sparse_keys":
+        A_s = 0x9E3779B97F4A7C15 - (1 << 64)
+        fk.mul_(A_s).add_(12345)
+        dk = dk * A_s + 12345
+        t.cuda.synchronize()
+    be = env.be
+    lk, _k1 = abi.pack_exprs([InputRef(0)])
+    rk, _k2 = abi.pack_exprs([InputRef(0)])
+    rd = (C.c_int32 * 1)(abi.INT64)
+    j = C.c_void_p()
+    be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, lk, rk, None, 1, rd, C.byref(j)))
+    be.check(be.fn("hash_join_build_push")(j, env.bench.device_batch(abi, [dk], [abi.INT64]).ptr))
+    be.check(be.fn("hash_join_build_finish")(j))
+    o = C.POINTER(abi.Batch)()
+    be.check(be.fn("hash_join_probe_indices")(j, env.bench.device_batch(abi, [fk], [abi.INT64]).ptr, abi.MEM_DEVICE, C.byref(o)))
+    out = be.wrap(o)
+    be.fn("hash_join_destroy")(j)
+    be.synchronize()
+    m = out.num_rows
+    left = view(env, out.column(0), m, t.int64)
+    right = view(env, out.column(1), m, t.int32).to(t.int64) & 0xffffffff
+    in_dim = t.zeros(1, dtype=t.bool, device=env.dev)
+    if variant == "half_hit":
+        expected_m = int((fk < nB).sum().item())
+    else:
+        expected_m = nP
+    assert m == expected_m
+    assert bool((right[1:] > right[:-1]).all().item())          # probe-major, one pair per probe row
+    assert bool((dk[left] == fk[right]).all().item())            # the pair joins equal keys
+    if variant == "half_hit":                                    # exactly the probe rows with a partner
+        assert t.equal(right, t.nonzero(fk < nB).flatten())
+    del in_dim
+    out.release()
+
+
+def _run_hash_agg(env, key, val):
+    abi, be = env.abi, env.be
+    from sqlrs_amd.expr import AggFunc, InputRef
+    gb, _k = abi.pack_exprs([InputRef(0)])
+    keep = []
+    aggs = (abi.AggFunc * 2)(AggFunc("count", InputRef(1), abi.INT64).abi_struct(keep),
+                             AggFunc("sum", InputRef(1), abi.FLOAT64).abi_struct(keep))
+    a = C.c_void_p()
+    be.check(be.fn("hash_agg_create")(be.ctx, 1, gb, 2, aggs, C.byref(a)))
+    be.check(be.fn("hash_agg_push")(a, env.bench.device_batch(abi, [key, val], [abi.INT64, abi.FLOAT64]).ptr))
+    o = C.POINTER(abi.Batch)()
+    be.check(be.fn("hash_agg_finish")(a, abi.MEM_DEVICE, C.byref(o)))
+    be.fn("hash_agg_destroy")(a)
+    be.synchronize()
+    return be.wrap(o)
+
+
+@pytest.mark.parametrize("keys", ["uniform", "sparse"])
+def test_full_size_c4_group_by(env, keys):
+    """C4: 2e8 rows, 1e6 int64 groups, COUNT + SUM(f64): counts = bincount (bit-exact), sums =
+    index_add_ (1e-9 relative), every key once, groups in first-seen order (hash_agg.rs:98,132)"""
+    t, d = env.torch, env.datagen
+    n, G = 200_000_000, 1_000_000
+    key = d.fill_chunks(t.empty(n, dtype=t.int64, device=env.dev), lambda i: d.key_t(0xA1, i, G))
+    val = d.fill_chunks(t.empty(n, dtype=t.float64, device=env.dev), lambda i: d.val_t(0xF2, i))
+    t.cuda.synchronize()
+    exp_cnt = t.bincount(key, minlength=G)
+    exp_sum = t.zeros(G, dtype=t.float64, device=env.dev).index_add_(0, key, val)
+    first = first_seen_rows(env, key, G)
+    A_s, A_inv = 0x9E3779B97F4A7C15 - (1 << 64), pow(0x9E3779B97F4A7C15, -1, 1 << 64)
+    A_inv_s = A_inv - (1 << 64) if A_inv >= (1 << 63) else A_inv
+    if keys == "sparse":  # hashed buckets instead of the key-range partition
+        key.mul_(A_s).add_(777)
+        t.cuda.synchronize()
+    out = _run_hash_agg(env, key, val)
+    g = out.num_rows
+    gk = view(env, out.column(0), g, t.int64)
+    if keys == "sparse":
+        gk = (gk - 777) * A_inv_s
+    gc, gs = view(env, out.column(1), g, t.int64), view(env, out.column(2), g, t.float64)
+    assert g == int((exp_cnt > 0).sum().item())
+    assert bool(((gk >= 0) & (gk < G)).all().item())
+    assert int(t.bincount(gk, minlength=G).max().item()) == 1                      # every group once
+    assert t.equal(gc, exp_cnt[gk])                                                # COUNT bit-exact
+    e = exp_sum[gk]
+    assert bool(((gs - e).abs() <= 1e-9 * e.abs().clamp_min(1e-300)).all().item())  # SUM within 1e-9 relative
+    fr = first[gk]
+    assert bool((fr[1:] > fr[:-1]).all().item())                                   # first-seen order
+    out.release()
+
+
+def test_full_size_c5_pipeline(env):
+    """C5 on one GPU at BASELINE.json's size (1e9 fact x 1e7 dim, 1e7 groups), bench.py's Pipeline,
+    every group checked (not just totals) + first-seen order of the groups"""
+    t, abi = env.torch, env.abi
+    n_fact, n_dim = 1_000_000_000, 10_000_000
+    fk, fv, dk = gen_c5(env, n_fact, n_dim)
+    exp_cnt, exp_sum, has_dim, kept = env.bench.expected_groups(t, None, fk, fv, dk, 0.5, n_dim)
+    pipe = env.bench.Pipeline(env.be, abi, 0.5, fused=True)
+    out = pipe.step(env.bench.device_batch(abi, [dk], [abi.INT64]),
+                    env.bench.device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64]))
+    env.be.synchronize()
+    ok, groups, rows, msg = env.bench.check_groups(t, None, env.dev, out, exp_cnt, exp_sum, has_dim)
+    assert ok, msg
+    assert rows == kept
+    # first-seen order over the JOIN OUTPUT = over the kept fact rows in input order
+    first = t.full((n_dim,), 1 << 62, dtype=t.int64, device=env.dev)
+    for lo in range(0, n_fact, 1 << 27):
+        k, v = fk[lo:lo + (1 << 27)], fv[lo:lo + (1 << 27)]
+        m = v > 0.5
+        first.scatter_reduce_(0, k[m], t.arange(lo, lo + k.numel(), dtype=t.int64, device=env.dev)[m], reduce="amin")
+    gk = view(env, out.column(0), out.num_rows, t.int64)
+    fr = first[gk]
+    assert bool((fr[1:] > fr[:-1]).all().item())
+    out.release()
+    env.be.fn("ctx_pool_trim")(env.be.ctx)
