@@ -9,6 +9,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# torch bundles its own HIP runtime (same SONAME as /opt/rocm's libamdhip64.so.7).  Tests that check
+# results with torch ops on the GPU need torch's copy to be the first one the process loads: when
+# libsqlrs_hip.so pulled in /opt/rocm's first, torch found "No HIP GPUs" afterwards (two HSA runtimes).
+try:
+    import torch
+    torch.cuda.is_available()
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
