@@ -64,6 +64,8 @@ def parse():
                         "the dim is at least 16x smaller than the fact table")
     p.add_argument("--unfused", action="store_true",
                    help="run HashJoin and HashAgg as two operators (joined batch materialised in HBM)")
+    p.add_argument("--separate-filter", action="store_true",
+                   help="run the Filter as its own operator in front of the fused HashJoinAgg (round-1 shape)")
     p.add_argument("--operators", action="store_true", help="(default at N=1; kept for old command lines)")
     p.add_argument("--no-operators", action="store_true",
                    help="skip the per-operator configs C2/C3/C4/Order and the C5 variants (sparse keys, three "
@@ -80,9 +82,10 @@ def device_batch(abi, tensors, dtypes):
 class Pipeline:
     """Filter -> HashJoin -> HashAgg driven through the C ABI on device-resident batches."""
 
-    def __init__(self, be, abi, threshold, fused=True, partial=False):
+    def __init__(self, be, abi, threshold, fused=True, partial=False, fuse_filter=True):
         from sqlrs_amd.expr import AggFunc, Constant, InputRef, JoinCondition
         self.be, self.abi, self.fused, self.fused_batches = be, abi, fused, 0
+        self.fuse_filter, self.filter_fused_batches = fuse_filter, 0
         # partial = the groups are exchanged and merged again (multi-GPU broadcast strategy): their
         # order is irrelevant, so the first-seen ordering of the local result is skipped
         self.partial = partial
@@ -109,10 +112,15 @@ class Pipeline:
 
     def step(self, dim_b, fact_b):
         """one pass; returns the device-resident result batch (LibBatch)"""
+        if self.fused and self.fuse_filter:
+            # HashAgg(HashJoin(dim, Filter(fact))) as ONE operator: the Filter is handed to the fused
+            # join+aggregate (sqlrs_join_agg_set_probe_filter), which evaluates it in its first partition pass
+            return self.join_agg(dim_b, fact_b, probe_filter=True)
         return self.join_agg(dim_b, self.filter(fact_b))
 
-    def join_agg(self, dim_b, filtered):
-        """HashJoin + HashAgg over already filtered fact rows (`filtered` is released)"""
+    def join_agg(self, dim_b, filtered, probe_filter=False):
+        """HashJoin + HashAgg over already filtered fact rows (`filtered` is released); with
+        `probe_filter` the rows are unfiltered and the operator applies the Filter itself"""
         be, abi = self.be, self.abi
         D = abi.MEM_DEVICE
         if self.fused:
@@ -123,6 +131,8 @@ class Pipeline:
                                               self.aggs, C.byref(ja)))
             if self.partial:
                 be.check(be.fn("join_agg_set_group_order")(ja, abi.GROUP_ORDER_ANY))
+            if probe_filter:
+                be.check(be.fn("join_agg_set_probe_filter")(ja, C.byref(self.filter_expr.abi)))
             be.check(be.fn("join_agg_build_push")(ja, dim_b.ptr))
             be.check(be.fn("join_agg_build_finish")(ja))
             be.check(be.fn("join_agg_probe_push")(ja, filtered.ptr))
@@ -130,6 +140,7 @@ class Pipeline:
             ao = C.POINTER(abi.Batch)()
             be.check(be.fn("join_agg_finish")(ja, D, C.byref(ao)))
             self.fused_batches = be.fn("join_agg_fused_batches")(ja)
+            self.filter_fused_batches = be.fn("join_agg_filter_fused_batches")(ja)
             be.fn("join_agg_destroy")(ja)
             return be.wrap(ao)
         j = C.c_void_p()
@@ -224,6 +235,8 @@ def algorithmic_bytes(kernel, w):
         "join_build": 8 * nB,
         "join_probe_unique": 8 * s * nP + 12 * M,           # one pass: keys read, pairs written
         "rp_scatter": 32 * M,                               # packed (key|row, val) 16 B read + 16 B written
+        "rp_chunk_scatter_filter": 16 * nP + 16 * M,        # key + val of every row read, kept rows written once
+        "rp_chunk_scatter": 32 * M,
         "rp_hist": 8 * M,
         "lds_agg": 16 * M + 28 * G,                         # partitioned rows read, groups written
         "normalize_keys": 16 * M,
@@ -280,7 +293,7 @@ def main():
     exp_cnt, exp_sum, has_dim, expected_kept = expected_groups(torch, dist if world > 1 else None, fact_key, fact_val,
                                                                dim_key, args.threshold, n_dim_total)
 
-    pipe = Pipeline(be, abi, args.threshold, fused=not args.unfused)
+    pipe = Pipeline(be, abi, args.threshold, fused=not args.unfused, fuse_filter=not args.separate_filter)
 
     def D_shard(total, r, w):
         return total * (r + 1) // w - total * r // w
@@ -507,7 +520,9 @@ def main():
                        "fact_rows": n_fact_total, "dim_rows": n_dim_total, "groups": int(ngroups),
                        "selectivity": round(got_rows / n_fact_total, 4),
                        "operators": "Filter -> HashJoin -> HashAgg (3 operators)" if args.unfused else
-                       "Filter -> HashJoinAgg (HashAgg fused over the Inner HashJoin)",
+                       "Filter -> HashJoinAgg (HashAgg fused over the Inner HashJoin)" if args.separate_filter else
+                       "HashJoinAgg with the probe-side Filter handed to it (sqlrs_join_agg_set_probe_filter): "
+                       f"filter evaluated inside the first partition pass = {bool(pipe.filter_fused_batches)}",
                        "parallelism": ("single GPU" if world == 1 else
                                        f"x{world}: all-gather dim, local partial aggregation, all-to-all of partial aggregates, merge"
                                        if strategy == "broadcast" else

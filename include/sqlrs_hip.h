@@ -285,6 +285,17 @@ int sqlrs_join_agg_set_group_order(sqlrs_join_agg_t *ja, int group_order); /* se
 /* probe inputs that took the non-materialising route so far (small probe batches are staged and
  * processed together: they count once) */
 int64_t sqlrs_join_agg_fused_batches(const sqlrs_join_agg_t *ja);
+/* A FilterExecutor sitting directly below the probe side — PhysicalHashAgg(PhysicalHashJoin(left,
+ * PhysicalFilter(right))), the shape of `... FROM fact JOIN dim ... WHERE fact.col > k GROUP BY ...`
+ * [ref: filter.rs:13-25 feeding hash_join.rs:207].  `filter` indexes the PROBE batch's columns.  Results
+ * are identical to sqlrs_filter_push on every probe batch followed by sqlrs_join_agg_probe_push of its
+ * output; when the predicate is `column OP constant` over an int64 / float64 column without NULLs and the
+ * non-materialising route applies, the first partition pass evaluates it itself (the filtered copies of
+ * the probe columns are never written), otherwise the library runs the Filter operator first.  Must be
+ * called before the first probe batch; NULL / empty removes the filter. */
+int sqlrs_join_agg_set_probe_filter(sqlrs_join_agg_t *ja, const sqlrs_expr_t *filter);
+/* probe batches whose filter was evaluated inside the first partition pass (diagnostics / tests) */
+int64_t sqlrs_join_agg_filter_fused_batches(const sqlrs_join_agg_t *ja);
 void sqlrs_join_agg_destroy(sqlrs_join_agg_t *ja);
 
 /* --------------------------------------------------------------- exchange -- */

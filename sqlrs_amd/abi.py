@@ -311,6 +311,8 @@ class Backend:
             "join_agg_probe_push": (i, [vp, pb]),
             "join_agg_finish": (i, [vp, i, ppb]),
             "join_agg_fused_batches": (C.c_int64, [vp]),
+            "join_agg_set_probe_filter": (i, [vp, pe]),
+            "join_agg_filter_fused_batches": (C.c_int64, [vp]),
             "join_agg_set_group_order": (i, [vp, i]),
             "hash_agg_set_group_order": (i, [vp, i]),
             "join_agg_destroy": (None, [vp]),

@@ -713,8 +713,9 @@ __global__ __launch_bounds__(256) void key_range_kernel(const uint64_t *__restri
 
 bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggInput &in,
                               uint64_t row_offset, PartAggOutput *out) {
-  const int64_t n = in.n;
+  int64_t n = in.n; // rows of the batch; after the partition: rows that passed in.filter
   if (n > 0xffffffffll || spec.n_acc > PART_MAX_ACC || spec.nv > 2) return false;
+  if (in.filter.col && !in.join_keys) return false; // a fused row filter is only taken under the fused join
   // 1. how many groups?  -> bucket count.  Fused join: every build key needs a slot.
   const bool join_mode = in.join_keys != nullptr;
   uint64_t omin = ~0ull, omax = 0; // signed-order image of the smallest / largest key of interest
@@ -818,6 +819,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   // 2./3. rows in bucket order (LDS-staged multi-split, radix_part.hip)
   PartitionInput pin;
   pin.pack = kp;
+  pin.filter = in.filter;
   pin.keys = in.keys;
   pin.key_validity = in.key_validity;
   pin.n = n;
@@ -852,7 +854,19 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     return false;
   }
   P = pr.P;
+  n = pr.n; // (a fused row filter dropped the rest)
   if (dense != (pr.pack.dense != 0)) return false;
+  if (n == 0) { // every row failed the fused filter: no groups
+    out->groups = out->n_overflow = 0;
+    out->gcap = 1;
+    out->buckets = (int)P;
+    out->gkey = ctx->alloc(8);
+    out->gfirst = ctx->alloc(4);
+    out->gacc = ctx->alloc(8 * (size_t)std::max(spec.n_acc, 1));
+    out->ov_rows = ctx->alloc(4);
+    out->row_ids = ctx->alloc(8);
+    return true;
+  }
   out->buckets = (int)P;
   BufP pk = pr.key, pi = pr.idx, pv0 = pr.v0, pv1 = pr.v1, pf = pr.flags;
   PartitionedRows local_build;
@@ -980,17 +994,13 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   out->gvalid = in.key_validity ? ctx->alloc((size_t)gcap) : nullptr;
   out->gacc = ctx->alloc(8 * (size_t)gcap * (size_t)std::max(spec.n_acc, 1));
   out->gcap = gcap;
-  out->ov_rows = ctx->alloc(4 * (size_t)n);
+  out->ov_rows = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
   {
     ProfScope ps(ctx, "lds_agg");
 #define SQ_LA(NV, FL, JN, NA, C0, C1, PK)                                                                        \
   do {                                                                                                         \
     auto kfn = lds_agg_kernel<NV, FL, JN, NA, C0, C1, PK>;                                                      \
-    static bool attr_set = false;                                                                              \
-    if (!attr_set) {                                                                                           \
-      SQ_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));  \
-      attr_set = true;                                                                                         \
-    }                                                                                                          \
+    allow_big_lds(ctx, kfn);                                                                                   \
     kfn<<<dim3(nwork), dim3(PART_WG), lds, ctx->stream>>>(                                                     \
         prm, pk->as<uint64_t>(), pi ? pi->as<uint32_t>() : nullptr, pv0 ? pv0->as<uint64_t>() : nullptr,       \
         pv1 ? pv1->as<uint64_t>() : nullptr, pf ? pf->as<uint8_t>() : nullptr, dwork->as<uint32_t>(), P, n,    \
@@ -1017,11 +1027,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
 #define SQ_LD(NV, JN, NA, C0, C1)                                                                              \
   do {                                                                                                         \
     auto kfn = lds_agg_dense_kernel<NV, JN, NA, C0, C1>;                                                        \
-    static bool attr_set = false;                                                                              \
-    if (!attr_set) {                                                                                           \
-      SQ_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));  \
-      attr_set = true;                                                                                         \
-    }                                                                                                          \
+    allow_big_lds(ctx, kfn);                                                                                   \
     kfn<<<dim3(nwork), dim3(PART_WG), lds, ctx->stream>>>(                                                     \
         prm, pk->as<uint64_t>(), pv0 ? pv0->as<uint64_t>() : nullptr, dwork->as<uint32_t>(),                   \
         ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(),                 \

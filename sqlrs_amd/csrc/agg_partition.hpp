@@ -36,6 +36,10 @@ struct PartAggInput {
   // (the join's direct-address table): saves a pass over the build keys and a host round trip
   bool join_range_known = false;
   uint64_t join_omin = 0, join_omax = 0;
+  // FilterExecutor directly below (fused join only): rows failing `filter` do not exist for the
+  // operator.  Evaluated by the chunked first partition level; when that level does not apply the
+  // call returns false and the caller runs the Filter operator first.
+  RowFilter filter;
 };
 
 // Groups of ONE batch: key, first row (local index), one 8-byte cell per accumulator

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <vector>
@@ -112,6 +113,9 @@ struct Ctx {
   // with ONE memset: every hipMemsetAsync is a ~5 us device operation of its own
   BufP zero_block;
   size_t zero_used = 0;
+  // kernels of this device that were granted > 64 KiB of dynamic LDS (hipFuncSetAttribute is per device)
+  std::set<const void *> big_lds_set;
+  std::map<const void *, int> occ_cache; // resident blocks per CU of the persistent kernels, per kernel
   void sync() { SQ_HIP(hipStreamSynchronize(stream)); }
   // copies `bytes` from device to the pinned area and synchronises; returns host pointer
   const void *fetch(const void *dptr, size_t bytes);
@@ -119,6 +123,15 @@ struct Ctx {
   int prof_entry(const char *name);
   void prof_resolve();
 };
+
+// > 64 KiB of dynamic LDS needs an opt-in per kernel — and per device: remembered in the ctx, not in a
+// function-local static (distinct ctxs may sit on distinct GPUs and threads)
+template <class K> inline void allow_big_lds(Ctx *ctx, K kfn, int bytes = 150 * 1024) {
+  const void *f = (const void *)kfn;
+  if (ctx->big_lds_set.count(f)) return;
+  SQ_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  ctx->big_lds_set.insert(f);
+}
 
 // RAII profiling scope: two event records around a launch group when enabled.
 struct ProfScope {

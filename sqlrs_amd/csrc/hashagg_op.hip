@@ -491,7 +491,7 @@ struct JoinSide {
 // applies, else the row route.  With `js` (fused join) only rows whose key has a build partner
 // count; returns false if the fused route is not applicable (nothing has been consumed then).
 static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &kcols, const NKeys &nk,
-                        const std::vector<DCol> &acols, const JoinSide *js) {
+                        const std::vector<DCol> &acols, const JoinSide *js, const RowFilter *rf = nullptr) {
   Ctx *ctx = a->ctx;
     auto views_of = [&](const std::vector<DCol> &cols) {
       std::vector<ArgView> v;
@@ -575,6 +575,7 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
           pin.join_range_known = js->range_known;
           pin.join_omin = js->omin;
           pin.join_omax = js->omax;
+          if (rf) pin.filter = *rf;
         }
         PartAggOutput po;
         flush_pending(a); // an older deferred batch must be in the table before this one
@@ -651,7 +652,7 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
       }
     }
     // ---- row route ------------------------------------------------------------------
-    if (!done && js) return false; // fused join: the caller composes join + aggregate instead
+    if (!done && (js || rf)) return false; // fused join: the caller composes (filter +) join + aggregate instead
     if (!done) {
       flush_pending(a);
       int64_t nnew = 0;
@@ -892,6 +893,9 @@ int sqlrs_hash_join_build_finish(sqlrs_hash_join_t *);
 int sqlrs_hash_join_probe_push(sqlrs_hash_join_t *, const sqlrs_batch_t *, int, sqlrs_batch_t **);
 void sqlrs_hash_join_destroy(sqlrs_hash_join_t *);
 void sqlrs_batch_release(sqlrs_batch_t *);
+int sqlrs_filter_create(sqlrs_ctx_t *, const sqlrs_expr_t *, sqlrs_filter_t **);
+int sqlrs_filter_push(sqlrs_filter_t *, const sqlrs_batch_t *, int, sqlrs_batch_t **);
+void sqlrs_filter_destroy(sqlrs_filter_t *);
 }
 
 struct sqlrs_join_agg {
@@ -906,6 +910,10 @@ struct sqlrs_join_agg {
   std::vector<DBatch> staged;
   int64_t staged_rows = 0;
   bool processed_any = false;
+  // FilterExecutor directly below the probe side (sqlrs_join_agg_set_probe_filter)
+  bool has_filter = false;
+  Expr probe_filter;
+  int64_t filter_fused_batches = 0;
   ~sqlrs_join_agg() {
     if (join) sqlrs_hash_join_destroy(join);
     delete agg;
@@ -936,9 +944,38 @@ int sqlrs_join_agg_build_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *left) {
 }
 int sqlrs_join_agg_build_finish(sqlrs_join_agg_t *ja) { return sqlrs_hash_join_build_finish(ja->join); }
 
-// one probe batch: HashJoin probe (hash_join.rs:207-292) feeding HashAgg push (hash_agg.rs:44-122)
-static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
-  return guard(ja->ctx, [&] {
+// `col OP constant` over an int64 / float64 column without NULLs -> RowFilter (the shape the first
+// partition level can evaluate itself); anything else is run by the Filter operator
+static bool fusable_row_filter(const Expr &e, InBatch &ib, RowFilter *rf) {
+  if (e.nodes.size() != 3) return false;
+  const sqlrs_expr_node_t &a = e.nodes[0], &b = e.nodes[1], &o = e.nodes[2];
+  if (a.op != SQLRS_EXPR_INPUT_REF || b.op != SQLRS_EXPR_CONSTANT || b.is_null) return false;
+  if (o.op < SQLRS_EXPR_GT || o.op > SQLRS_EXPR_NOTEQ) return false;
+  if (a.index < 0 || a.index >= ib.num_columns()) return false;
+  const DCol &c = ib.col(a.index);
+  if (c.dtype != b.dtype || c.stride == 0) return false;
+  if (c.dtype != SQLRS_INT64 && c.dtype != SQLRS_FLOAT64) return false;
+  if (c.validity && c.null_count != 0) return false;
+  rf->col = c.v<uint64_t>();
+  rf->is_f64 = c.dtype == SQLRS_FLOAT64;
+  if (rf->is_f64) {
+    uint64_t bits;
+    std::memcpy(&bits, &b.f, 8);
+    rf->kord = (bits >> 63) ? ~bits : (bits | (1ull << 63)); // f64_to_ordered
+  } else {
+    rf->kord = (uint64_t)b.i ^ (1ull << 63);
+  }
+  static const uint32_t masks[6] = {4, 1, 6, 3, 2, 5}; // GT, LT, GTEQ, LTEQ, EQ, NOTEQ: keep if {<, ==, >}
+  rf->keep_mask = masks[o.op - SQLRS_EXPR_GT];
+  return true;
+}
+
+// one probe batch: (Filter, filter.rs:13-25, when `with_filter`) -> HashJoin probe (hash_join.rs:207-292)
+// feeding HashAgg push (hash_agg.rs:44-122)
+static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bool with_filter) {
+  if (with_filter && !ja->has_filter) with_filter = false;
+  bool filter_pending = with_filter; // the filter still has to be applied by the composed path below
+  int st0 = guard(ja->ctx, [&] {
     ja->processed_any = true;
     Ctx *ctx = ja->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
@@ -966,9 +1003,16 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
       InBatch ib(ctx, right);
       auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
       int64_t n = ib.rows();
-      std::vector<DCol> kcols{eval_expr(ctx, j->rkeys[0], colfn, n, true)};
-      NKeys nk = normalize_keys(ctx, kcols, n);
-      if (nk.exact && nk.dtype == j->key_dtype) {
+      RowFilter rf;
+      const bool fuse_filter = with_filter && fusable_row_filter(ja->probe_filter, ib, &rf);
+      if (with_filter && !fuse_filter) eligible = false; // Filter operator first, then this function again
+      std::vector<DCol> kcols;
+      NKeys nk;
+      if (eligible) {
+        kcols.push_back(eval_expr(ctx, j->rkeys[0], colfn, n, true));
+        nk = normalize_keys(ctx, kcols, n);
+      }
+      if (eligible && nk.exact && nk.dtype == j->key_dtype) {
         if (!a->saw_batch) {
           a->saw_batch = true;
           a->key_dtypes.push_back(kcols[0].dtype);
@@ -985,13 +1029,16 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
           js.omax = js.omin + (j->dense_range - 1);
         }
         flush_staged(a); // batches staged by the composed route come first in row order
-        if (agg_consume(a, n, kcols, nk, acols, &js)) {
+        if (agg_consume(a, n, kcols, nk, acols, &js, fuse_filter ? &rf : nullptr)) {
           a->rows_seen += n;
           ja->fused_batches++;
+          if (fuse_filter) ja->filter_fused_batches++;
+          filter_pending = false;
           return;
         }
       }
     }
+    if (filter_pending) return; // (handled below: Filter operator, then the unfiltered path)
     // composed route: materialise the joined batch on the device and aggregate it
     sqlrs_batch_t *joined = nullptr;
     int st = sqlrs_hash_join_probe_push(j, right, SQLRS_MEM_DEVICE, &joined);
@@ -1004,6 +1051,22 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
     }
     ja->composed_batches++;
   });
+  if (st0 != SQLRS_OK || !filter_pending) return st0;
+  // the filter was not fused: run the Filter operator on the batch, then process its output
+  Ctx *ctx = ja->ctx;
+  std::vector<sqlrs_expr_node_t> nodes = ja->probe_filter.nodes;
+  for (size_t i = 0; i < nodes.size(); i++) nodes[i].s = ja->probe_filter.strings[i].empty() ? nullptr : ja->probe_filter.strings[i].c_str();
+  sqlrs_expr_t fe{nodes.data(), (int32_t)nodes.size(), 0};
+  sqlrs_filter_t *f = nullptr;
+  int st = sqlrs_filter_create((sqlrs_ctx_t *)ctx, &fe, &f);
+  if (st != SQLRS_OK) return st;
+  sqlrs_batch_t *kept = nullptr;
+  st = sqlrs_filter_push(f, right, SQLRS_MEM_DEVICE, &kept);
+  sqlrs_filter_destroy(f);
+  if (st != SQLRS_OK) return st;
+  st = join_agg_process(ja, kept, false);
+  sqlrs_batch_release(kept);
+  return st;
 }
 
 static int join_agg_flush(sqlrs_join_agg_t *ja) {
@@ -1029,20 +1092,35 @@ static int join_agg_flush(sqlrs_join_agg_t *ja) {
     view = emit_batch(ctx, std::move(all), SQLRS_MEM_DEVICE);
   });
   if (st != SQLRS_OK) return st;
-  st = join_agg_process(ja, view);
+  st = join_agg_process(ja, view, false); // staged batches are already filtered
   sqlrs_batch_release(view);
   return st;
 }
 
 int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
-  if (ja->staged.empty() && right->num_rows >= STAGE_DIRECT_ROWS) return join_agg_process(ja, right);
+  if (ja->staged.empty() && right->num_rows >= STAGE_DIRECT_ROWS) return join_agg_process(ja, right, true);
+  sqlrs_batch_t *kept = nullptr;
+  if (ja->has_filter) { // small batches are filtered on arrival; what is staged is the Filter's output
+    Ctx *ctx = ja->ctx;
+    std::vector<sqlrs_expr_node_t> nodes = ja->probe_filter.nodes;
+    for (size_t i = 0; i < nodes.size(); i++) nodes[i].s = ja->probe_filter.strings[i].empty() ? nullptr : ja->probe_filter.strings[i].c_str();
+    sqlrs_expr_t fe{nodes.data(), (int32_t)nodes.size(), 0};
+    sqlrs_filter_t *f = nullptr;
+    int stf = sqlrs_filter_create((sqlrs_ctx_t *)ctx, &fe, &f);
+    if (stf != SQLRS_OK) return stf;
+    stf = sqlrs_filter_push(f, right, SQLRS_MEM_DEVICE, &kept);
+    sqlrs_filter_destroy(f);
+    if (stf != SQLRS_OK) return stf;
+    right = kept;
+  }
   int st = guard(ja->ctx, [&] {
     SQ_HIP(hipSetDevice(ja->ctx->device));
     if (!ja->join->finished) fail(SQLRS_ERR_INTERNAL, "probe before build_finish");
     InBatch ib(ja->ctx, right);
-    ja->staged.push_back(ib.materialize(true));
+    ja->staged.push_back(ib.materialize(true)); // library-owned device batches are shared, not copied
     ja->staged_rows += right->num_rows;
   });
+  if (kept) sqlrs_batch_release(kept);
   if (st != SQLRS_OK) return st;
   return ja->staged_rows >= STAGE_FLUSH_ROWS ? join_agg_flush(ja) : SQLRS_OK;
 }
@@ -1057,6 +1135,14 @@ int sqlrs_join_agg_set_group_order(sqlrs_join_agg_t *ja, int group_order) {
 }
 // number of probe batches that took the fused route (diagnostics / tests)
 int64_t sqlrs_join_agg_fused_batches(const sqlrs_join_agg_t *ja) { return ja->fused_batches; }
+int sqlrs_join_agg_set_probe_filter(sqlrs_join_agg_t *ja, const sqlrs_expr_t *filter) {
+  return guard(ja->ctx, [&] {
+    if (ja->processed_any || !ja->staged.empty()) fail(SQLRS_ERR_INTERNAL, "set_probe_filter after the first probe batch");
+    ja->has_filter = filter && filter->num_nodes > 0;
+    if (ja->has_filter) ja->probe_filter = expr_from_abi(filter);
+  });
+}
+int64_t sqlrs_join_agg_filter_fused_batches(const sqlrs_join_agg_t *ja) { return ja->filter_fused_batches; }
 void sqlrs_join_agg_destroy(sqlrs_join_agg_t *ja) { delete ja; }
 
 } // extern "C"

@@ -214,11 +214,7 @@ extern "C" int sqlrs_hash_partition(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, c
 #define SQ_SPLIT(NC)                                                                                          \
   do {                                                                                                        \
     auto kfn = split_scatter_kernel<NC>;                                                                      \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      SQ_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024)); \
-      attr_set = true;                                                                                        \
-    }                                                                                                         \
+    allow_big_lds(ctx, kfn, 112 * 1024); /* (this kernel also has ~40 KiB of static LDS) */                   \
     kfn<<<g, b, lds, ctx->stream>>>(inp[0], inp[1], inp[2], kcol, n, (uint32_t)num_parts, ntiles,             \
                                     offs->as<uint32_t>(), outp[0], outp[1], outp[2]);                         \
   } while (0)

@@ -317,6 +317,280 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
   for (int j = 0; j < RP_ROWS; j++) store_row(j, staged_len);
 }
 
+// ------------------------------------------------------------ chunked first level --
+// First level of a two-level partition WITHOUT a histogram pass, with an optional row filter fused in.
+//
+// A counting multi-split needs every (tile, digit) count before the first row can be written: one
+// extra read of the keys, and — when a Filter sits below the operator — a filter pass that writes
+// compacted copies of every column just so that they can be read again (C5: filter 12 + compact 12 +
+// hist 4 + scatter 16 GB).  Here the output of level 1 is not one contiguous run per digit but a list
+// of fixed-size CHUNKS per digit (linked-bucket partitioning): workgroup b appends the rows of digit d
+// to its own current chunk of that digit and takes a fresh chunk from a global counter when it is
+// full, so a row's destination depends on nothing but the workgroup's own history.  One pass: every
+// input column read once (the predicate evaluated on the way), every kept row written once.
+//
+// Level 2 treats every non-empty chunk as one input tile (chunk capacity = its tile size), so only
+// its tile list changes (rp_chunk_plan_kernel); its output is contiguous per bucket as before.
+//
+// Chunk bookkeeping per (workgroup, digit) lives in the registers of thread `digit`: current chunk,
+// fill, and a PRE-FETCHED next chunk (the atomic that allocates it is issued when the previous one is
+// taken into use, a chunk's worth of rows before its result is needed).  Chunks 2*(b*digits+d) and
+// +1 are pre-assigned; chunk ids >= base_chunks come from the counter.  Bound: every allocation
+// beyond the pre-assigned ones follows CAP rows written by that (workgroup, digit), so
+// base_chunks + n / CAP + 1 chunks always suffice.
+// Chunks are laid out RP_CHUNK_SKEW rows apart from a multiple of the tile size: with exact multiples of
+// 48 KiB every workgroup of the next level starts its tile on one of four phases of the HBM channel
+// interleave at the same moment.
+constexpr uint32_t RP_CHUNK_SKEW = 32;
+struct ChunkOut {
+  uint64_t *key, *v0, *v1;
+  uint32_t *idx;        // null when the row id is packed into the key word
+  uint32_t *chunk_len;  // rows in chunk c (written when it is closed / at the end of its workgroup)
+  uint32_t *chunk_dig;  // level-1 digit of chunk c
+  unsigned int *counter; // [0] chunks taken beyond base_chunks, [1] overflow flag
+  uint32_t base_chunks, max_chunks;
+  uint32_t cap; // rows per chunk: a multiple of the tile size
+};
+
+// PSRC: where the predicate's operand comes from: -1 no filter, 1 = value column 0, 3 = its own column
+template <int NV, int RP_ROWS, int PSRC> struct ChunkRegs {
+  uint64_t k[RP_ROWS], a0[NV >= 1 ? RP_ROWS : 1], a1[NV >= 2 ? RP_ROWS : 1], pv[PSRC == 3 ? RP_ROWS : 1];
+};
+
+template <int NV, int RP_WG, int RP_ROWS, int PSRC>
+__device__ __forceinline__ void rp_chunk_load(const uint64_t *__restrict__ key, const uint64_t *__restrict__ v0,
+                                              const uint64_t *__restrict__ v1, const uint64_t *__restrict__ pcol,
+                                              int64_t start, uint32_t len, ChunkRegs<NV, RP_ROWS, PSRC> &r) {
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) { // unconditional: rows past the end of a ragged tile re-read its last row
+    const int64_t row = start + min((uint32_t)(j * RP_WG) + threadIdx.x, len - 1);
+    r.k[j] = __builtin_nontemporal_load(key + row);
+    if (NV >= 1) r.a0[j] = __builtin_nontemporal_load(v0 + row);
+    if (NV >= 2) r.a1[j] = __builtin_nontemporal_load(v1 + row);
+    if (PSRC == 3) r.pv[j] = __builtin_nontemporal_load(pcol + row);
+  }
+}
+
+__device__ __forceinline__ bool row_passes(const RowFilter &f, uint64_t bits) {
+  const uint64_t o = f.is_f64 ? f64_to_ordered(__longlong_as_double((long long)bits)) : (bits ^ (1ull << 63));
+  const uint32_t sel = o < f.kord ? 1u : (o == f.kord ? 2u : 4u);
+  return (f.keep_mask & sel) != 0;
+}
+
+template <int NV, int RP_WG, int RP_ROWS, bool PACK, int PSRC>
+__global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
+    const uint64_t *__restrict__ key, const uint64_t *__restrict__ v0, const uint64_t *__restrict__ v1, RowFilter flt,
+    int64_t n, ChunkOut out, uint32_t P, uint32_t p2_bits, uint32_t digits, uint32_t num_tiles, uint32_t tiles_per_wg,
+    int64_t sink, KeyPack kp) {
+  constexpr uint32_t RP_TILE = RP_WG * RP_ROWS; // (a chunk holds out.cap = k * RP_TILE rows)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t *skey = (uint64_t *)smem;
+  uint64_t *sv0 = skey + RP_TILE;
+  uint64_t *sv1 = sv0 + (NV >= 1 ? RP_TILE : 0);
+  uint32_t *sidx = (uint32_t *)(sv1 + (NV >= 2 ? RP_TILE : 0));
+  uint16_t *sdig = (uint16_t *)(sidx + (PACK ? 0 : RP_TILE));
+  uint32_t *cnt = (uint32_t *)(sdig + (PACK ? 0 : RP_TILE)); // [RP_WG]
+  uint32_t *split = cnt + RP_WG;                              // [RP_WG] tile-local position where a digit's run changes chunk
+  int64_t *gb0 = (int64_t *)(split + RP_WG);                  // [RP_WG] destination of position p: gb0[d] + p below the split,
+  int64_t *gb1 = gb0 + RP_WG;                                 //         gb1[d] + p from it on
+  __shared__ uint32_t s_wsum[RP_WG / 64];
+  __shared__ uint32_t s_total;
+
+  const uint32_t t0 = blockIdx.x * tiles_per_wg;
+  const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
+  // chunk state of digit threadIdx.x
+  uint32_t cur_id = 2u * (blockIdx.x * digits + threadIdx.x), nxt_id = cur_id + 1, cfill = 0;
+  const bool owner = threadIdx.x < digits;
+  auto tile_start = [&](uint32_t t) { return (int64_t)t * RP_TILE; };
+  auto tile_len = [&](uint32_t t) { return (uint32_t)min((int64_t)RP_TILE, n - (int64_t)t * RP_TILE); };
+
+  ChunkRegs<NV, RP_ROWS, PSRC> cur, nxt;
+  uint32_t dg[RP_ROWS], rk[RP_ROWS];
+  int64_t cur_start = 0;
+  auto rank_row = [&](int j, uint32_t len) {
+    dg[j] = 0xffffffffu;
+    bool keep = (uint32_t)(j * RP_WG) + threadIdx.x < len;
+    if (PSRC == 1) keep = keep && row_passes(flt, cur.a0[NV >= 1 ? j : 0]);
+    if (PSRC == 3) keep = keep && row_passes(flt, cur.pv[PSRC == 3 ? j : 0]);
+    if (keep) {
+      const uint64_t k = PACK ? packed_clamp(kp, cur.k[j]) : cur.k[j];
+      dg[j] = rp_digit(rp_bucket(kp, k, true, P), 1, p2_bits);
+      rk[j] = atomicAdd(&cnt[dg[j]], 1u);
+    }
+  };
+  auto scan_and_stage = [&]() { // counters -> tile-local run starts + chunk destinations; rows of `cur` -> staging area
+    const uint32_t c = cnt[threadIdx.x];
+    const uint32_t inc = wave_iscan_u32(c);
+    if (lane_id() == 63) s_wsum[wave_id()] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (int w = 0; w < RP_WG / 64; w++) {
+      if (w < wave_id()) wbase += s_wsum[w];
+      tot += s_wsum[w];
+    }
+    const uint32_t ls = wbase + inc - c;
+    if (threadIdx.x == 0) s_total = tot;
+    // destination of this digit's run: the rest of the current chunk, then the pre-fetched one
+    const uint32_t room = min(c, out.cap - cfill);
+    int64_t g0 = (int64_t)cur_id * (out.cap + RP_CHUNK_SKEW) + cfill, g1 = 0;
+    if (owner && c > room) {
+      out.chunk_len[cur_id] = out.cap; // closed
+      out.chunk_dig[cur_id] = threadIdx.x;
+      cur_id = nxt_id;
+      cfill = c - room;
+      g1 = (int64_t)cur_id * (out.cap + RP_CHUNK_SKEW);
+      const uint32_t o = out.base_chunks + atomicAdd(out.counter, 1u); // needed a chunk's worth of rows from now
+      if (o >= out.max_chunks) out.counter[1] = 1;                     // cannot happen (bound above); never out of bounds
+      nxt_id = min(o, out.max_chunks - 1);
+    } else {
+      cfill += c;
+    }
+    cnt[threadIdx.x] = ls; // run start (rank_row's counters are consumed)
+    split[threadIdx.x] = ls + room;
+    gb0[threadIdx.x] = g0 - (int64_t)ls;
+    gb1[threadIdx.x] = g1 - (int64_t)(ls + room);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      if (dg[j] == 0xffffffffu) continue;
+      const uint32_t p = cnt[dg[j]] + rk[j];
+      const uint32_t row = (uint32_t)(cur_start + (uint32_t)(j * RP_WG) + threadIdx.x);
+      skey[p] = PACK ? pack_key_row(kp, cur.k[j], row) : cur.k[j];
+      if (NV >= 1) sv0[p] = cur.a0[j];
+      if (NV >= 2) sv1[p] = cur.a1[j];
+      if (!PACK) sidx[p] = row;
+      if (!PACK) sdig[p] = (uint16_t)dg[j];
+    }
+    __syncthreads();
+  };
+  auto store_row = [&](int j, uint32_t len) { // position p of the staged tile -> its chunk
+    const uint32_t p = j * RP_WG + threadIdx.x;
+    const uint64_t kw = skey[p];
+    const uint32_t d = (PACK ? rp_digit(rp_bucket(kp, packed_key(kp, kw), true, P), 1, p2_bits) : (uint32_t)sdig[p]) & (RP_WG - 1);
+    int64_t g = (p < split[d] ? gb0[d] : gb1[d]) + p;
+    if (p >= len) g = sink + (int64_t)blockIdx.x * RP_WG + threadIdx.x; // lanes past the staged rows (boundary slot): this workgroup's sink rows
+    out.key[g] = kw;
+    if (NV >= 1) out.v0[g] = sv0[p];
+    if (NV >= 2) out.v1[g] = sv1[p];
+    if (!PACK) out.idx[g] = sidx[p];
+  };
+
+  if (t0 < t1) {
+    // same software pipeline as rp_scatter_kernel: while tile i-1 (staged, sorted) is written out, tile i
+    // (in `cur`) is ranked and tile i+1 is in flight into `nxt`
+    uint32_t len = tile_len(t0);
+    cur_start = tile_start(t0);
+    rp_chunk_load<NV, RP_WG, RP_ROWS, PSRC>(key, v0, v1, flt.col, cur_start, len, cur);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) rank_row(j, len);
+    __syncthreads();
+    scan_and_stage();
+    uint32_t staged_len = s_total;
+    uint32_t tcur = min(t0 + 1, t1 - 1);
+    len = tile_len(tcur);
+    cur_start = tile_start(tcur);
+    rp_chunk_load<NV, RP_WG, RP_ROWS, PSRC>(key, v0, v1, flt.col, cur_start, len, cur);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (uint32_t ti = t0 + 1; ti < t1; ti++) {
+      const uint32_t tnext = min(ti + 1, t1 - 1);
+      const uint32_t nlen = tile_len(tnext);
+      const int64_t nstart = tile_start(tnext);
+      rp_chunk_load<NV, RP_WG, RP_ROWS, PSRC>(key, v0, v1, flt.col, nstart, nlen, nxt);
+      cnt[threadIdx.x] = 0; // (the run starts it held were consumed before scan_and_stage's last barrier)
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RP_ROWS; j++) {
+        // a filter leaves the staged tile partly empty: slots whose 512 positions are all past its end are
+        // skipped (uniform branch), only the boundary slot stores to the sink rows
+        if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);
+        rank_row(j, len);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70); // drain this tile's stores (and the prefetch) before the barrier
+      __syncthreads();
+      scan_and_stage();
+      staged_len = s_total;
+      cur = nxt;
+      len = nlen;
+      cur_start = nstart;
+    }
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++)
+      if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);
+  }
+  if (owner) { // publish what is left open; the pre-fetched chunk stays empty
+    out.chunk_len[cur_id] = cfill;
+    out.chunk_dig[cur_id] = threadIdx.x;
+    out.chunk_len[nxt_id] = 0;
+    out.chunk_dig[nxt_id] = threadIdx.x;
+  }
+}
+
+// Tile list of level 2 from the chunk table: chunk c of digit s contributes ceil(len / tile) tiles to
+// segment s (any order of the chunks inside a segment).  One workgroup; <= a few hundred thousand chunks.
+// (The last tile of every (workgroup, digit) stream is partly filled; giving the level-2 workgroups tile
+// ranges of equal ROW counts instead of equal tile counts was measured SLOWER, 4.24 -> 4.8 ms: a partly
+// filled tile costs the pipeline as much as a full one.)
+__global__ __launch_bounds__(1024) void rp_chunk_plan_kernel(const uint32_t *__restrict__ chunk_len,
+                                                             const uint32_t *__restrict__ chunk_dig,
+                                                             const unsigned int *__restrict__ counter, uint32_t base_chunks,
+                                                             uint32_t max_chunks, uint32_t nseg, uint32_t digits2,
+                                                             uint32_t cap, uint32_t tile, int64_t *__restrict__ seg_start,
+                                                             int64_t *__restrict__ seg_mat, uint32_t *__restrict__ seg_tiles,
+                                                             uint32_t *__restrict__ seg_tile_base, Tile *__restrict__ tiles,
+                                                             uint64_t *__restrict__ totals /* {tiles, rows, overflow} */) {
+  __shared__ uint32_t s_tiles[512], s_base[512], s_cursor[512];
+  __shared__ unsigned long long s_rows[512];
+  const uint32_t nchunks = min(base_chunks + counter[0], max_chunks);
+  for (uint32_t i = threadIdx.x; i < 512; i += 1024) {
+    s_tiles[i] = 0;
+    s_cursor[i] = 0;
+    s_rows[i] = 0;
+  }
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < nchunks; c += 1024) {
+    const uint32_t len = chunk_len[c];
+    if (!len) continue;
+    atomicAdd(&s_tiles[chunk_dig[c]], (len + tile - 1) / tile);
+    atomicAdd(&s_rows[chunk_dig[c]], (unsigned long long)len);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tb = 0;
+    int64_t rows = 0;
+    for (uint32_t s = 0; s < nseg; s++) {
+      seg_start[s] = rows;
+      seg_tile_base[s] = tb;
+      seg_mat[s] = (int64_t)tb * digits2;
+      seg_tiles[s] = s_tiles[s];
+      s_base[s] = tb;
+      tb += s_tiles[s];
+      rows += (int64_t)s_rows[s];
+    }
+    seg_start[nseg] = rows;
+    totals[0] = tb;
+    totals[1] = (uint64_t)rows;
+    totals[2] = counter[1];
+  }
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < nchunks; c += 1024) {
+    const uint32_t len = chunk_len[c];
+    if (!len) continue;
+    const uint32_t s = chunk_dig[c], nt = (len + tile - 1) / tile;
+    const uint32_t i0 = atomicAdd(&s_cursor[s], nt);
+    for (uint32_t q = 0; q < nt; q++) {
+      Tile t;
+      t.start = (int64_t)c * (cap + RP_CHUNK_SKEW) + (int64_t)q * tile;
+      t.len = min(tile, len - q * tile);
+      t.stride = s_tiles[s];
+      t.mat = (int64_t)s_base[s] * digits2 + i0 + q;
+      tiles[s_base[s] + i0 + q] = t;
+    }
+  }
+}
+
 // bucket b (level-1 digit d1 = b >> p2_bits ... ) start row, from the level's scanned matrix
 __global__ void rp_bucket_starts_kernel(const uint32_t *__restrict__ offs,
                                         const int64_t *__restrict__ seg_mat,
@@ -352,14 +626,17 @@ __global__ void rp_make_tiles_kernel(const int64_t *__restrict__ seg_start, cons
 
 namespace {
 
+// Geometry of one level.  Either planned on the host from the segment boundaries (plan_level +
+// upload_level + rp_make_tiles_kernel) or built on the device from the chunk table of a chunked first
+// level (rp_chunk_plan_kernel): the kernels only see the device arrays.
 struct Level {
-  std::vector<int64_t> seg_mat, seg_start; // per segment (seg_start has nseg + 1 entries)
+  std::vector<int64_t> seg_mat, seg_start; // per segment (seg_start has nseg + 1 entries); host plan only
   std::vector<uint32_t> seg_tiles, seg_tile_base;
   int64_t mat_entries = 0;
-  uint32_t num_tiles = 0;
+  uint32_t num_tiles = 0, nseg = 0;
   // the four arrays on the device: ONE upload per level (seven small copies per level before)
   std::vector<uint8_t> blob; // host source of the upload (must outlive it)
-  BufP dev;
+  BufP dev, tiles;
   const int64_t *d_seg_start = nullptr, *d_seg_mat = nullptr;
   const uint32_t *d_seg_tiles = nullptr, *d_seg_tile_base = nullptr;
 };
@@ -371,6 +648,7 @@ Level plan_level(const std::vector<int64_t> &seg_start, uint32_t digits, int RP_
   Level L;
   L.seg_start = seg_start;
   size_t nseg = seg_start.size() - 1;
+  L.nseg = (uint32_t)nseg;
   for (size_t s = 0; s < nseg; s++) {
     int64_t len = seg_start[s + 1] - seg_start[s];
     uint32_t nt = (uint32_t)ceil_div(len, RP_TILE);
@@ -383,22 +661,36 @@ Level plan_level(const std::vector<int64_t> &seg_start, uint32_t digits, int RP_
   return L;
 }
 
+// device layout of the four per-segment arrays inside one block
+struct LevelLayout {
+  size_t o_start, o_mat, o_tiles, o_base, total;
+  explicit LevelLayout(size_t nseg) {
+    o_start = 0;
+    o_mat = o_start + 8 * (nseg + 1);
+    o_tiles = o_mat + 8 * nseg;
+    o_base = o_tiles + round_up(4 * nseg, 8);
+    total = o_base + round_up(4 * nseg, 8);
+  }
+};
+void bind_level(Level &L, const LevelLayout &lay) {
+  const uint8_t *d = L.dev->as<uint8_t>();
+  L.d_seg_start = (const int64_t *)(d + lay.o_start);
+  L.d_seg_mat = (const int64_t *)(d + lay.o_mat);
+  L.d_seg_tiles = (const uint32_t *)(d + lay.o_tiles);
+  L.d_seg_tile_base = (const uint32_t *)(d + lay.o_base);
+}
+
 void upload_level(Ctx *ctx, Level &L) {
   const size_t nseg = L.seg_tiles.size();
-  const size_t o_start = 0, o_mat = o_start + 8 * (nseg + 1), o_tiles = o_mat + 8 * nseg,
-               o_base = o_tiles + round_up(4 * nseg, 8), total = o_base + round_up(4 * nseg, 8);
-  L.blob.resize(total);
-  std::memcpy(L.blob.data() + o_start, L.seg_start.data(), 8 * (nseg + 1));
-  std::memcpy(L.blob.data() + o_mat, L.seg_mat.data(), 8 * nseg);
-  std::memcpy(L.blob.data() + o_tiles, L.seg_tiles.data(), 4 * nseg);
-  std::memcpy(L.blob.data() + o_base, L.seg_tile_base.data(), 4 * nseg);
-  L.dev = ctx->alloc(total);
-  SQ_HIP(hipMemcpyAsync(L.dev->p, L.blob.data(), total, hipMemcpyHostToDevice, ctx->stream));
-  const uint8_t *d = L.dev->as<uint8_t>();
-  L.d_seg_start = (const int64_t *)(d + o_start);
-  L.d_seg_mat = (const int64_t *)(d + o_mat);
-  L.d_seg_tiles = (const uint32_t *)(d + o_tiles);
-  L.d_seg_tile_base = (const uint32_t *)(d + o_base);
+  const LevelLayout lay(nseg);
+  L.blob.resize(lay.total);
+  std::memcpy(L.blob.data() + lay.o_start, L.seg_start.data(), 8 * (nseg + 1));
+  std::memcpy(L.blob.data() + lay.o_mat, L.seg_mat.data(), 8 * nseg);
+  std::memcpy(L.blob.data() + lay.o_tiles, L.seg_tiles.data(), 4 * nseg);
+  std::memcpy(L.blob.data() + lay.o_base, L.seg_tile_base.data(), 4 * nseg);
+  L.dev = ctx->alloc(lay.total);
+  SQ_HIP(hipMemcpyAsync(L.dev->p, L.blob.data(), lay.total, hipMemcpyHostToDevice, ctx->stream));
+  bind_level(L, lay);
 }
 
 } // namespace
@@ -444,31 +736,30 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   const int RP_TILE = WG * ROWS;
   const size_t lds = (size_t)RP_TILE * (pack ? 8 * (1 + nv) : 8 * (1 + nv) + 4 + 2 + 1) + (size_t)WG * (4 + 4 + 8);
 
-  auto alloc_cols = [&](BufP &k, BufP &v0, BufP &v1, BufP &idx, BufP &fl) {
-    const size_t np = (size_t)n + WG; // + the sink rows of rp_scatter_kernel
-    k = ctx->alloc(8 * np);
-    v0 = nv >= 1 ? ctx->alloc(8 * np) : nullptr;
-    v1 = nv >= 2 ? ctx->alloc(8 * np) : nullptr;
-    idx = pack ? nullptr : ctx->alloc(4 * np);
+  // (staggering the columns' start offsets inside their 2 MiB aligned blocks — same row, same HBM channel?
+  //  — changed nothing; the 10-15 % spread of these kernels between processes follows physical placement)
+  auto staggered = [&](size_t bytes, int) { return ctx->alloc(bytes); };
+  auto alloc_cols = [&](int64_t rows, BufP &k, BufP &v0, BufP &v1, BufP &idx, BufP &fl) {
+    const size_t np = (size_t)rows + WG; // + the sink rows of rp_scatter_kernel
+    k = staggered(8 * np, 0);
+    v0 = nv >= 1 ? staggered(8 * np, 1) : nullptr;
+    v1 = nv >= 2 ? staggered(8 * np, 2) : nullptr;
+    idx = pack ? nullptr : staggered(4 * np, 3);
     fl = flags ? ctx->alloc(np) : nullptr;
   };
 
-  // one level = hist + scan + scatter over `seg_start` segments
-  auto run_level = [&](int level, uint32_t digits, const std::vector<int64_t> &seg_start, const RpIn &rin,
-                       const RpOut &rout, BufP *offs_out, Level *plan_out) {
-    Level L = plan_level(seg_start, digits, RP_TILE);
-    BufP tiles = ctx->alloc(sizeof(Tile) * (size_t)std::max<uint32_t>(L.num_tiles, 1));
-    upload_level(ctx, L);
-    rp_make_tiles_kernel<<<dim3((unsigned)L.seg_tiles.size()), dim3(256), 0, ctx->stream>>>(
-        L.d_seg_start, L.d_seg_mat, L.d_seg_tiles, L.d_seg_tile_base, RP_TILE, (Tile *)tiles->p);
-    SQ_HIP(hipGetLastError());
-    BufP mat = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
-    BufP offs = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
+  // one level = hist + scan + scatter over the tiles of `L` (sink = first row behind the output columns)
+  auto exec_level = [&](int level, uint32_t digits, const Level &L, const RpIn &rin, const RpOut &rout, int64_t sink,
+                        BufP *offs_out) {
+    const int64_t entries = std::max<int64_t>(L.mat_entries, 1);
+    BufP mat = ctx->alloc(4 * (size_t)entries);
+    BufP offs = ctx->alloc(4 * (size_t)entries);
     BufP total = ctx->alloc(8);
     unsigned nt = L.num_tiles;
-    {
+    const Tile *tp = (const Tile *)L.tiles->p;
+    if (nt) {
       ProfScope ps(ctx, in.build_side ? "rp_hist_build" : "rp_hist");
-#define SQ_RH1(R, PL) rp_hist_kernel<512, R, PL><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, (const Tile *)tiles->p, P, p2_bits, level, digits, mat->as<uint32_t>(), kp)
+#define SQ_RH1(R, PL) rp_hist_kernel<512, R, PL><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, tp, P, p2_bits, level, digits, mat->as<uint32_t>(), kp)
 #define SQ_RH(R) do { if (!rin.key_validity && !rin.flags) SQ_RH1(R, true); else SQ_RH1(R, false); } while (0)
       if (ROWS == 12) SQ_RH(12); else if (ROWS == 8) SQ_RH(8); else SQ_RH(6);
 #undef SQ_RH
@@ -476,36 +767,33 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       SQ_HIP(hipGetLastError());
     }
     // tile-major counts -> digit-major, scan, digit-major offsets -> tile-major for the scatter
-    BufP mat_dm = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
-    BufP offs_tm = ctx->alloc(4 * (size_t)std::max<int64_t>(L.mat_entries, 1));
+    BufP mat_dm = ctx->alloc(4 * (size_t)entries);
+    BufP offs_tm = ctx->alloc(4 * (size_t)entries);
     const size_t tlds = (size_t)RP_TB * (digits + 1) * 4;
     const unsigned tblocks = (unsigned)ceil_div(nt, RP_TB);
-    rp_transpose_kernel<false><<<dim3(tblocks), dim3(256), tlds, ctx->stream>>>(
-        mat->as<uint32_t>(), mat_dm->as<uint32_t>(), (const Tile *)tiles->p, nt, digits);
+    if (nt)
+      rp_transpose_kernel<false><<<dim3(tblocks), dim3(256), tlds, ctx->stream>>>(
+          mat->as<uint32_t>(), mat_dm->as<uint32_t>(), tp, nt, digits);
     exclusive_scan_u32(ctx, mat_dm->as<uint32_t>(), L.mat_entries, nullptr, offs->as<uint32_t>(),
                        total->as<uint64_t>());
-    rp_transpose_kernel<true><<<dim3(tblocks), dim3(256), tlds, ctx->stream>>>(
-        offs->as<uint32_t>(), offs_tm->as<uint32_t>(), (const Tile *)tiles->p, nt, digits);
+    if (nt)
+      rp_transpose_kernel<true><<<dim3(tblocks), dim3(256), tlds, ctx->stream>>>(
+          offs->as<uint32_t>(), offs_tm->as<uint32_t>(), tp, nt, digits);
     SQ_HIP(hipGetLastError());
-    {
+    if (nt) {
       ProfScope ps(ctx, in.build_side ? "rp_scatter_build" : "rp_scatter");
       // one workgroup per CU slot; contiguous tile ranges (8 per workgroup at least)
       uint32_t wgs = std::min<uint32_t>(nt, (uint32_t)ctx->num_cus * ((ROWS == 6 || (ROWS == 8 && pack)) ? 2 : 1));
       uint32_t tpw = (uint32_t)ceil_div(nt, wgs);
       wgs = (uint32_t)ceil_div(nt, tpw);
       dim3 g(wgs), b((unsigned)WG);
-      const Tile *tp = (const Tile *)tiles->p;
       const int mode = level == 1 ? (flags ? RP_L1_NULL : RP_L1) : (flags ? RP_LN_FLAG : RP_LN);
 #define SQ_RP1(NV, R, M, PK)                                                                                  \
   do {                                                                                                        \
     auto kfn = rp_scatter_kernel<NV, 512, R, M, PK>;                                                          \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      SQ_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
-      attr_set = true;                                                                                        \
-    }                                                                                                         \
+    allow_big_lds(ctx, kfn);                                                                                  \
     kfn<<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs_tm->as<uint32_t>(), nt, tpw, \
-                                    n, kp);                                                                   \
+                                    sink, kp);                                                                \
   } while (0)
 #define SQ_RP(NV, R)                                                                                          \
   do {                                                                                                        \
@@ -522,19 +810,30 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
 #undef SQ_RP
       SQ_HIP(hipGetLastError());
     }
-    // the host vectors of `L` were the source of async uploads: they move (buffers and all) into
-    // the caller's Level, which outlives the bucket_starts() synchronisation that follows
     *offs_out = offs;
-    *plan_out = std::move(L);
+  };
+
+  // host-planned level over `seg_start` segments (the host vectors of `L` are the source of async
+  // uploads: `L` must outlive the bucket_starts() synchronisation that follows)
+  auto run_level = [&](int level, uint32_t digits, const std::vector<int64_t> &seg_start, const RpIn &rin,
+                       const RpOut &rout, BufP *offs_out, Level *L) {
+    *L = plan_level(seg_start, digits, RP_TILE);
+    L->tiles = ctx->alloc(sizeof(Tile) * (size_t)std::max<uint32_t>(L->num_tiles, 1));
+    upload_level(ctx, *L);
+    rp_make_tiles_kernel<<<dim3((unsigned)L->seg_tiles.size()), dim3(256), 0, ctx->stream>>>(
+        L->d_seg_start, L->d_seg_mat, L->d_seg_tiles, L->d_seg_tile_base, RP_TILE, (Tile *)L->tiles->p);
+    SQ_HIP(hipGetLastError());
+    exec_level(level, digits, *L, rin, rout, n, offs_out);
   };
 
   // `host` receives a copy (the synchronisation that keeps L's upload sources alive pays for it)
-  auto bucket_starts = [&](const Level &L, const BufP &offs, uint32_t digits, std::vector<uint32_t> *host) -> BufP {
-    uint32_t nseg = (uint32_t)L.seg_tiles.size();
+  auto bucket_starts = [&](const Level &L, const BufP &offs, uint32_t digits, int64_t rows,
+                           std::vector<uint32_t> *host) -> BufP {
+    uint32_t nseg = L.nseg;
     int64_t total = (int64_t)nseg * digits + 1;
     BufP bs = ctx->alloc(4 * (size_t)total);
     rp_bucket_starts_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
-        offs->as<uint32_t>(), L.d_seg_mat, L.d_seg_tiles, L.d_seg_start, digits, nseg, n, bs->as<uint32_t>());
+        offs->as<uint32_t>(), L.d_seg_mat, L.d_seg_tiles, L.d_seg_start, digits, nseg, rows, bs->as<uint32_t>());
     SQ_HIP(hipGetLastError());
     host->resize((size_t)total);
     SQ_HIP(hipMemcpyAsync(host->data(), bs->p, 4 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
@@ -542,9 +841,126 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     return bs;
   };
 
+  // ---- chunked first level (no histogram pass, optional fused row filter): two-level partitions of
+  // batches large enough that the 2 x workgroups x digits pre-assigned chunks are a fraction of the input
+  static const int chunk_env = [] { // test / tuning hook: 1 = whenever two levels are needed, 0 = never
+    const char *e = std::getenv("SQLRS_RP_CHUNKED");
+    return e ? std::atoi(e) : -1;
+  }();
+  // (3072-row tiles with two workgroups per CU were measured slower for this level too: 6.4 vs 5.7 ms)
+  const uint32_t tiles1 = (uint32_t)ceil_div(n, RP_TILE);
+  uint32_t cwgs = std::min<uint32_t>(tiles1, (uint32_t)ctx->num_cus);
+  const uint32_t ctpw = (uint32_t)ceil_div(tiles1, std::max(cwgs, 1u));
+  cwgs = (uint32_t)ceil_div(tiles1, std::max(ctpw, 1u));
+  const uint64_t base_chunks = 2ull * cwgs * d1;
+  static const int ct_env = [] { // tuning hook: tiles per chunk (1, 4, 8, 16 measured alike: 1 = smallest reservation)
+    const char *e = std::getenv("SQLRS_RP_CHUNK_TILES");
+    return e ? std::max(1, std::min(64, std::atoi(e))) : 1;
+  }();
+  const uint64_t CAP = (uint64_t)RP_TILE * (uint64_t)ct_env;
+  bool chunked = p2_bits != 0 && !flags && chunk_env != 0 && d1 <= (uint32_t)WG &&
+                 (chunk_env == 1 || base_chunks * CAP <= 2 * (uint64_t)n); // (pre-assigned chunks: reserved, mostly never touched)
+  if (in.filter.col && !chunked) return false; // only the chunked first level evaluates a row filter
+  if (chunked) {
+    const uint64_t max_chunks = base_chunks + (uint64_t)n / CAP + 2;
+    if (max_chunks * (CAP + RP_CHUNK_SKEW) + WG * (uint64_t)cwgs > 0xffffffffull) { // Tile::start is 64-bit, rows index u32 math
+      if (in.filter.col) return false;
+      chunked = false;
+    }
+    if (chunked) {
+      const size_t pool_rows = (size_t)max_chunks * (CAP + RP_CHUNK_SKEW) + (size_t)WG * cwgs; // + one sink per workgroup
+      BufP ck = staggered(8 * pool_rows, 0), c0 = nv >= 1 ? staggered(8 * pool_rows, 1) : nullptr,
+           c1 = nv >= 2 ? staggered(8 * pool_rows, 2) : nullptr, ci = pack ? nullptr : staggered(4 * pool_rows, 3);
+      BufP clen = ctx->alloc(4 * (size_t)max_chunks), cdig = ctx->alloc(4 * (size_t)max_chunks);
+      BufP ctr = ctx->alloc_zero(8);
+      ChunkOut co;
+      co.key = ck->as<uint64_t>();
+      co.v0 = c0 ? c0->as<uint64_t>() : nullptr;
+      co.v1 = c1 ? c1->as<uint64_t>() : nullptr;
+      co.idx = ci ? ci->as<uint32_t>() : nullptr;
+      co.chunk_len = clen->as<uint32_t>();
+      co.chunk_dig = cdig->as<uint32_t>();
+      co.counter = ctr->as<unsigned int>();
+      co.base_chunks = (uint32_t)base_chunks;
+      co.max_chunks = (uint32_t)max_chunks;
+      co.cap = (uint32_t)CAP;
+      const int psrc = !in.filter.col ? -1 : ((nv >= 1 && (const void *)in.filter.col == in.vals[0]) ? 1 : 3);
+      const size_t clds = (size_t)RP_TILE * (pack ? 8 * (1 + nv) : 8 * (1 + nv) + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8);
+      {
+        ProfScope ps(ctx, in.filter.col ? "rp_chunk_scatter_filter" : "rp_chunk_scatter");
+        const uint64_t *k = in.keys, *a0 = (const uint64_t *)in.vals[0], *a1 = (const uint64_t *)in.vals[1];
+        const int64_t sink = (int64_t)max_chunks * (CAP + RP_CHUNK_SKEW);
+#define SQ_CS1(NV, R, PK, PS)                                                                                       \
+  do {                                                                                                              \
+    auto kfn = rp_chunk_scatter_kernel<NV, 512, R, PK, PS>;                                                         \
+    allow_big_lds(ctx, kfn);                                                                                        \
+    kfn<<<dim3(cwgs), dim3(512), clds, ctx->stream>>>(k, a0, a1, in.filter, n, co, P, p2_bits, d1, tiles1, ctpw,   \
+                                                      sink, kp);                                                    \
+  } while (0)
+#define SQ_CS(NV, R, PK)                                                                                            \
+  do {                                                                                                              \
+    if (psrc < 0) SQ_CS1(NV, R, PK, -1);                                                                            \
+    else if (psrc == 1 && NV >= 1) SQ_CS1(NV, R, PK, (NV >= 1 ? 1 : 3));                                            \
+    else SQ_CS1(NV, R, PK, 3);                                                                                      \
+  } while (0)
+        if (nv == 2) SQ_CS(2, 8, false);
+        else if (ROWS != 12) { chunked = false; } // tuning shapes (SQLRS_RP_ROWS) keep the counting first level
+        else if (nv == 0) { if (pack) SQ_CS(0, 12, true); else SQ_CS(0, 12, false); }
+        else { if (pack) SQ_CS(1, 12, true); else SQ_CS(1, 12, false); }
+#undef SQ_CS
+#undef SQ_CS1
+        SQ_HIP(hipGetLastError());
+      }
+      if (!chunked && in.filter.col) return false;
+      if (chunked) {
+        // level-2 geometry from the chunk table, on the device; the host only needs three numbers
+        const uint32_t digits2 = 1u << p2_bits;
+        Level L2;
+        L2.nseg = d1;
+        const LevelLayout lay(d1);
+        L2.dev = ctx->alloc(lay.total);
+        bind_level(L2, lay);
+        L2.tiles = ctx->alloc(sizeof(Tile) * (size_t)max_chunks * (size_t)ct_env);
+        BufP totals = ctx->alloc(24);
+        rp_chunk_plan_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(
+            co.chunk_len, co.chunk_dig, co.counter, co.base_chunks, co.max_chunks, d1, digits2, (uint32_t)CAP,
+            (uint32_t)RP_TILE, (int64_t *)L2.d_seg_start, (int64_t *)L2.d_seg_mat, (uint32_t *)L2.d_seg_tiles,
+            (uint32_t *)L2.d_seg_tile_base, (Tile *)L2.tiles->p, totals->as<uint64_t>());
+        SQ_HIP(hipGetLastError());
+        const uint64_t *ht = (const uint64_t *)ctx->fetch(totals->p, 24);
+        const uint64_t ntiles = ht[0], kept = ht[1], overflow = ht[2];
+        if (overflow) return false; // (impossible by the chunk bound; never trusted blindly)
+        L2.num_tiles = (uint32_t)ntiles;
+        L2.mat_entries = (int64_t)ntiles * digits2;
+        out->n = (int64_t)kept;
+        out->P = P;
+        BufP k2, a2, b2, i2, f2;
+        alloc_cols((int64_t)kept, k2, a2, b2, i2, f2);
+        RpIn rin2;
+        rin2.key = ck->as<uint64_t>();
+        rin2.v0 = co.v0;
+        rin2.v1 = co.v1;
+        rin2.idx = co.idx;
+        rin2.flags = nullptr;
+        rin2.key_validity = rin2.v0_validity = rin2.v1_validity = nullptr;
+        RpOut rout2;
+        rout2.key = k2->as<uint64_t>();
+        rout2.v0 = a2 ? a2->as<uint64_t>() : nullptr;
+        rout2.v1 = b2 ? b2->as<uint64_t>() : nullptr;
+        rout2.idx = i2 ? i2->as<uint32_t>() : nullptr;
+        rout2.flags = nullptr;
+        BufP offs2;
+        exec_level(2, digits2, L2, rin2, rout2, (int64_t)kept, &offs2);
+        out->key = k2; out->v0 = a2; out->v1 = b2; out->idx = i2; out->flags = nullptr;
+        out->bstart = bucket_starts(L2, offs2, digits2, (int64_t)kept, &out->bstart_host);
+        return true;
+      }
+    }
+  }
+
   // ---- level 1
   BufP k1, a1, b1, i1, f1;
-  alloc_cols(k1, a1, b1, i1, f1);
+  alloc_cols(n, k1, a1, b1, i1, f1);
   RpIn rin;
   rin.key = in.keys;
   rin.v0 = (const uint64_t *)in.vals[0];
@@ -564,7 +980,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   Level L1;
   run_level(1, d1, {0, n}, rin, rout, &offs1, &L1);
   std::vector<uint32_t> hs;
-  BufP bs1 = bucket_starts(L1, offs1, d1, &hs);
+  BufP bs1 = bucket_starts(L1, offs1, d1, n, &hs);
   out->n = n;
   out->P = P;
   if (p2_bits == 0) {
@@ -576,7 +992,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // ---- level 2: every level-1 bucket is one segment
   std::vector<int64_t> seg(hs.begin(), hs.end());
   BufP k2, a2, b2, i2, f2;
-  alloc_cols(k2, a2, b2, i2, f2);
+  alloc_cols(n, k2, a2, b2, i2, f2);
   RpIn rin2;
   rin2.key = k1->as<uint64_t>();
   rin2.v0 = a1 ? a1->as<uint64_t>() : nullptr;
@@ -594,7 +1010,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   Level L2;
   run_level(2, 1u << p2_bits, seg, rin2, rout2, &offs2, &L2);
   out->key = k2; out->v0 = a2; out->v1 = b2; out->idx = i2; out->flags = f2;
-  out->bstart = bucket_starts(L2, offs2, 1u << p2_bits, &out->bstart_host);
+  out->bstart = bucket_starts(L2, offs2, 1u << p2_bits, n, &out->bstart_host);
   return true;
 }
 

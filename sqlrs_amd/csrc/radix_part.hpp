@@ -40,6 +40,18 @@ __device__ __forceinline__ uint64_t packed_off(const KeyPack &kp, uint64_t w) { 
 __device__ __forceinline__ uint32_t packed_row(const KeyPack &kp, uint64_t w) { return (uint32_t)(w >> kp.kbits); }
 #endif
 
+// A row predicate `col OP constant` evaluated by the FIRST partition pass itself (FilterExecutor
+// directly below the partitioned operator, filter.rs:13-25): rows that fail are neither counted nor
+// moved, so the filter's own read + compacted write of every column never happens.  `col` holds
+// 8-byte values (int64 or float64, no NULLs); both sides are compared through their order-preserving
+// u64 images (f64: IEEE total order, exactly like the stand-alone filter kernel of select.hip).
+struct RowFilter {
+  const uint64_t *col = nullptr; // nullptr = no filter
+  uint32_t is_f64 = 0;
+  uint32_t keep_mask = 7; // bit 0: keep rows with v < k, bit 1: v == k, bit 2: v > k
+  uint64_t kord = 0;      // ordered image of the constant
+};
+
 struct PartitionInput {
   const uint64_t *keys = nullptr; // normalised keys (NKeys)
   const uint64_t *key_validity = nullptr;
@@ -49,13 +61,14 @@ struct PartitionInput {
   const uint64_t *val_validity[2] = {nullptr, nullptr};
   bool build_side = false; // profiling label only
   KeyPack pack;            // used only when no column is nullable
+  RowFilter filter;        // only taken by the chunked first level (partition_rows returns false otherwise)
 };
 
 // Rows in bucket order: bucket b = rows [bstart[b], bstart[b+1]).  `idx` = original row,
 // `flags` (null when nothing is nullable) bit0 key valid, bit1 v0 valid, bit2 v1 valid.
 // bucket(key) = mulhi(mix64(key), P); NULL keys -> bucket 0.  (Dense KeyPack: key range, see above.)
 struct PartitionedRows {
-  int64_t n = 0;
+  int64_t n = 0; // rows in bucket order (= input rows that passed PartitionInput::filter)
   uint32_t P = 0;
   BufP key, v0, v1, idx, flags;
   BufP bstart; // u32[P + 1]

@@ -532,7 +532,7 @@ static void launch_filter(Ctx *ctx, int op, const DCol &c, T k, int64_t rows, T 
       filter_cmp_const_kernel<T, OP, HV><<<dim3((unsigned)tiles), dim3(FILTER_BLOCK), 0, ctx->stream>>>(         \
           in, val, k, rows, tiles, out, sel_bits, tile_off, desc, ticket, total, 1);                             \
     } else {                                                                                                     \
-      static int occ = 0;                                                                                        \
+      int &occ = ctx->occ_cache[(const void *)filter_cmp_const_persistent_kernel<T, OP, HV>];                   \
       if (!occ) {                                                                                                \
         SQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, filter_cmp_const_persistent_kernel<T, OP, HV>, \
                                                             FILTER_BLOCK, 0));                                   \

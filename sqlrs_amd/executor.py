@@ -174,8 +174,12 @@ class HashJoinAggExecutor:
     def __init__(self, backend: abi.Backend, left_child: Iterable, right_child: Iterable,
                  join_condition: JoinCondition, join_output_schema: pa.Schema, num_left_columns: int,
                  agg_funcs: List[AggFunc], group_by: List[BoundExpr], out_mem: int = abi.MEM_HOST,
-                 output_names: Optional[Sequence[str]] = None):
+                 output_names: Optional[Sequence[str]] = None, probe_filter: Optional[BoundExpr] = None):
         self.backend = backend
+        # FilterExecutor{expr = probe_filter, child = right_child} directly below the probe side
+        # (filter.rs:7-25): same result as wrapping right_child in a FilterExecutor
+        self.probe_filter = probe_filter
+        self.filter_fused_batches = 0
         self.left_child, self.right_child = left_child, right_child
         self.join_condition, self.join_output_schema = join_condition, join_output_schema
         self.num_left_columns = num_left_columns
@@ -198,6 +202,10 @@ class HashJoinAggExecutor:
                                           len(right_fields), rd, len(self.group_by), gb, len(self.agg_funcs),
                                           aggs, C.byref(h)))
         try:
+            if self.probe_filter is not None:
+                pf = self.probe_filter.pack()
+                keep.append(pf)
+                be.check(be.fn("join_agg_set_probe_filter")(h, C.byref(pf.abi)))
             for batch in self.left_child:
                 b = abi.as_batch(batch)  # keep the marshalled batch alive across the call
                 be.check(be.fn("join_agg_build_push")(h, b.ptr))
@@ -208,6 +216,7 @@ class HashJoinAggExecutor:
             out = C.POINTER(abi.Batch)()
             be.check(be.fn("join_agg_finish")(h, self.out_mem, C.byref(out)))
             self.fused_batches = be.fn("join_agg_fused_batches")(h)
+            self.filter_fused_batches = be.fn("join_agg_filter_fused_batches")(h)
             yield _emit(be, out, self.out_mem, self.output_names)
         finally:
             be.fn("join_agg_destroy")(h)

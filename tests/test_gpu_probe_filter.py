@@ -1,0 +1,137 @@
+"""HashAgg(HashJoin(left, Filter(right))) through sqlrs_join_agg_set_probe_filter, and the chunked
+(histogram-free) first partition level that evaluates the filter — against the oracle running the
+three operators one after the other (filter.rs:13-25 -> hash_join.rs:146-323 -> hash_agg.rs:32-150).
+
+The chunked level is only taken by large two-level partitions; `test_chunked_first_level_forced`
+re-runs the `chunked` cases in a subprocess with SQLRS_RP_CHUNKED=1 / SQLRS_STAGE_DIRECT_ROWS=1 (both
+hooks are read once per process), where they also assert that the filter really was fused."""
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from sqlrs_amd import abi
+from sqlrs_amd.executor import FilterExecutor, HashAggExecutor, HashJoinAggExecutor, HashJoinExecutor
+from sqlrs_amd.expr import AggFunc, BinaryOp, Constant, InputRef, JoinCondition
+
+pytestmark = pytest.mark.gpu
+FORCED = os.environ.get("SQLRS_RP_CHUNKED") == "1"
+
+
+def rows_of(batches):
+    out = []
+    for b in batches:
+        cols = [b.column(i).to_pylist() for i in range(b.num_columns)]
+        out.extend(zip(*cols) if cols else [])
+    return out
+
+
+def assert_same(got, exp, float_cols=()):
+    assert len(got) == len(exp), f"{len(got)} rows, expected {len(exp)}"
+    for g, e in zip(got, exp):
+        for i, (a, b) in enumerate(zip(g, e)):
+            if i in float_cols and a is not None and b is not None:
+                assert abs(a - b) <= 1e-9 * max(abs(b), 1e-300), (g, e)
+            else:
+                assert a == b, (g, e)
+
+
+def reference(oracle, lb, rbs, cond, sch, nleft, aggs, gb, pred):
+    filt = FilterExecutor(oracle, pred, rbs)
+    join = HashJoinExecutor(oracle, [lb], filt.execute(), "inner", cond, sch, nleft)
+    return rows_of(HashAggExecutor(oracle, aggs, gb, join.execute()).execute())
+
+
+def tables(rng, nb, np_, sparse, probe_extra=0.1):
+    """build: nb unique keys (dense permutation or sparse 64-bit); probe: [val f64, key, other i64]"""
+    bkeys = rng.permutation(nb).astype(np.int64)
+    pk = rng.integers(0, int(nb * (1 + probe_extra)), np_, dtype=np.int64)  # some keys without partner
+    if sparse:
+        A = np.int64(0x9E3779B97F4A7C15 - (1 << 64))
+        with np.errstate(over="ignore"):
+            bkeys, pk = bkeys * A + np.int64(99), pk * A + np.int64(99)
+    lb = pa.RecordBatch.from_arrays([pa.array(bkeys), pa.array(rng.random(nb))], names=["c0", "c1"])
+    rb = pa.RecordBatch.from_arrays([pa.array(rng.random(np_)), pa.array(pk), pa.array(rng.integers(-100, 100, np_, dtype=np.int64))],
+                                    names=["c0", "c1", "c2"])
+    sch = pa.schema([("l.c0", pa.int64()), ("l.c1", pa.float64()), ("r.c0", pa.float64()), ("r.c1", pa.int64()), ("r.c2", pa.int64())])
+    return lb, rb, sch
+
+
+PREDS = {
+    "val_gt_half": InputRef(0) > Constant(0.5, abi.FLOAT64),          # the C5 shape: predicate on the aggregated column
+    "val_le_all": InputRef(0) <= Constant(2.0, abi.FLOAT64),           # keeps everything
+    "val_lt_none": InputRef(0) < Constant(-1.0, abi.FLOAT64),          # keeps nothing
+    "other_ne": BinaryOp("!=", InputRef(2), Constant(7, abi.INT64)),   # predicate on a column the aggregates do not read
+    "other_eq": BinaryOp("=", InputRef(2), Constant(-3, abi.INT64)),   # ~0.5 % selectivity
+    "key_ge": InputRef(1) >= Constant(1000, abi.INT64),                # predicate on the join key itself
+    "general": (InputRef(0) > Constant(0.25, abi.FLOAT64)) & (InputRef(2) < Constant(50, abi.INT64)),  # not fusable
+}
+AGGS = {
+    "count_sum": [AggFunc("count", InputRef(2), abi.INT64), AggFunc("sum", InputRef(2), abi.FLOAT64)],
+    "none": [],
+    "two_columns": [AggFunc("sum", InputRef(2), abi.FLOAT64), AggFunc("max", InputRef(4), abi.INT64), AggFunc("count", InputRef(4), abi.INT64)],
+}
+
+
+@pytest.mark.parametrize("pred", ["val_gt_half", "other_ne", "general"])
+@pytest.mark.parametrize("batches", [1, 3])
+def test_probe_filter_small_batches(hip, oracle, pred, batches):
+    """small probe batches: filtered on arrival, staged, processed together"""
+    rng = np.random.default_rng(len(pred) + batches)
+    lb, rb, sch = tables(rng, 4000, 150_000, sparse=False)
+    rbs = [rb.slice(i * (rb.num_rows // batches), rb.num_rows // batches if i + 1 < batches else rb.num_rows) for i in range(batches)]
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    ex = HashJoinAggExecutor(hip, [lb], rbs, cond, sch, 2, AGGS["count_sum"], [InputRef(0)], probe_filter=PREDS[pred])
+    got = rows_of(ex.execute())
+    exp = reference(oracle, lb, rbs, cond, sch, 2, AGGS["count_sum"], [InputRef(0)], PREDS[pred])
+    assert_same(got, exp, float_cols={2})
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+@pytest.mark.parametrize("pred", ["val_gt_half", "val_le_all", "val_lt_none", "other_ne", "other_eq", "key_ge", "general"])
+@pytest.mark.parametrize("aggs", ["count_sum", "none", "two_columns"])
+def test_probe_filter_chunked(hip, oracle, sparse, pred, aggs):
+    """two-level partitions (dense: 1.2e6 build keys -> 586 range buckets; sparse: hashed buckets)"""
+    if pred == "key_ge" and sparse:
+        pytest.skip("the threshold is meant for the dense key range")
+    if aggs != "count_sum" and pred not in ("val_gt_half", "other_ne"):
+        pytest.skip("aggregate lists are crossed with two predicates only")
+    rng = np.random.default_rng(zlib.crc32(f"{sparse}{pred}{aggs}".encode()))
+    lb, rb, sch = tables(rng, 1_200_000 if not sparse else 400_000, 2_500_000, sparse)
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, AGGS[aggs], [InputRef(0)], probe_filter=PREDS[pred])
+    got = rows_of(ex.execute())
+    if FORCED and aggs != "none":  # (without accumulators a bucket table holds 8x the keys: one level, nothing chunked)
+        assert ex.fused_batches == 1
+        assert ex.filter_fused_batches == (0 if pred == "general" else 1)
+    exp = reference(oracle, lb, [rb], cond, sch, 2, AGGS[aggs], [InputRef(0)], PREDS[pred])
+    assert_same(got, exp, float_cols={2} if aggs == "count_sum" else ({1} if aggs == "two_columns" else ()))
+
+
+@pytest.mark.parametrize("keys", ["dense", "sparse"])
+def test_hash_agg_chunked(hip, oracle, keys):
+    """plain HashAgg whose partition needs two levels (2e6 groups): chunked first level, no filter"""
+    rng = np.random.default_rng(11)
+    n, G = 5_000_000, 2_000_000
+    k = rng.integers(0, G, n, dtype=np.int64)
+    if keys == "sparse":
+        with np.errstate(over="ignore"):
+            k = k * np.int64(0x9E3779B97F4A7C15 - (1 << 64)) + np.int64(5)
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(rng.random(n))], names=["k", "v"])
+    aggs = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64), AggFunc("min", InputRef(1), abi.FLOAT64)]
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
+    assert_same(got, exp, float_cols={2})
+
+
+def test_chunked_first_level_forced():
+    if FORCED:
+        pytest.skip("already inside the forced run")
+    env = dict(os.environ, SQLRS_RP_CHUNKED="1", SQLRS_STAGE_DIRECT_ROWS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "chunked and not forced"], env=env, capture_output=True, text=True, timeout=1700)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
