@@ -298,6 +298,62 @@ int sqlrs_join_agg_set_probe_filter(sqlrs_join_agg_t *ja, const sqlrs_expr_t *fi
 int64_t sqlrs_join_agg_filter_fused_batches(const sqlrs_join_agg_t *ja);
 void sqlrs_join_agg_destroy(sqlrs_join_agg_t *ja);
 
+/* ---------------------------------------- operators either side of the hot path -- */
+/* [ref: src/executor/project.rs:6-29  ProjectExecutor{exprs, child}]  One output batch per input batch,
+ * column i = exprs[i].eval_column(batch). */
+typedef struct sqlrs_project sqlrs_project_t;
+int sqlrs_project_create(sqlrs_ctx_t *ctx, int num_exprs, const sqlrs_expr_t *exprs, sqlrs_project_t **out);
+int sqlrs_project_push(sqlrs_project_t *p, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out);
+void sqlrs_project_destroy(sqlrs_project_t *p);
+
+/* [ref: src/executor/limit.rs:4-81  LimitExecutor{limit, offset, child}]  limit / offset are the constants
+ * of the two BoundExpr::Constant (has_* = 0: None).  One call per child batch, in stream order, with the
+ * reference's arithmetic across batches: *out = NULL when the batch contributes nothing, otherwise the
+ * batch itself or its slice; *done = 1 once no later batch can contribute (the reference `break`s, or
+ * returned before polling the child when limit = 0) — the caller stops pulling the child then. */
+typedef struct sqlrs_limit sqlrs_limit_t;
+int sqlrs_limit_create(sqlrs_ctx_t *ctx, int has_limit, int64_t limit, int has_offset, int64_t offset,
+                       sqlrs_limit_t **out);
+int sqlrs_limit_push(sqlrs_limit_t *l, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out, int *done);
+void sqlrs_limit_destroy(sqlrs_limit_t *l);
+
+/* [ref: src/executor/aggregate/simple_agg.rs:10-66  SimpleAggExecutor{agg_funcs, child}]  Aggregates
+ * without GROUP BY: one accumulator per aggregate over all rows, exactly one output row (COUNT = 0 and
+ * NULL for the others when no row arrived); finish without any pushed batch is SQLRS_ERR_INTERNAL (the
+ * reference unwraps a None, :63). */
+typedef struct sqlrs_simple_agg sqlrs_simple_agg_t;
+int sqlrs_simple_agg_create(sqlrs_ctx_t *ctx, int num_aggs, const sqlrs_agg_func_t *aggs, sqlrs_simple_agg_t **out);
+int sqlrs_simple_agg_push(sqlrs_simple_agg_t *a, const sqlrs_batch_t *in);
+int sqlrs_simple_agg_finish(sqlrs_simple_agg_t *a, int out_mem, sqlrs_batch_t **out);
+void sqlrs_simple_agg_destroy(sqlrs_simple_agg_t *a);
+
+/* [ref: src/util/mod.rs:53-80  record_batch_to_string]  The sqllogictest text form of a batch (host or
+ * device resident): one line per row, one blank between columns, NULL -> "NULL", empty string ->
+ * "(empty)", other values as arrow's array_value_to_string prints them (floats: Rust's Display).
+ * *out is a NUL-terminated string owned by the library until sqlrs_string_free. */
+int sqlrs_batch_to_string(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, char **out);
+void sqlrs_string_free(char *s);
+
+/* CSV ingest [ref: src/storage/csv.rs:92-106 CsvConfig (header, ',', infer over 10 records, batches of
+ * 1024 rows), :124-133 schema inference, :190-241 CsvTransaction::next_batch].  Parsed on the host; with
+ * out_mem = SQLRS_MEM_DEVICE every batch is uploaded once and the scan's output is HBM resident.
+ * Inferred types: INT64, FLOAT64, BOOLEAN, else UTF8 (date-like columns stay UTF8: the path has no date
+ * type); a missing value is NULL in a typed column and the empty string in a UTF8 column. */
+typedef struct sqlrs_csv sqlrs_csv_t;
+int sqlrs_csv_open(sqlrs_ctx_t *ctx, const char *path, int has_header, char delimiter, int64_t batch_size,
+                   int64_t infer_max_records, sqlrs_csv_t **out);
+int sqlrs_csv_num_columns(const sqlrs_csv_t *r);
+const char *sqlrs_csv_column_name(const sqlrs_csv_t *r, int i);
+int sqlrs_csv_column_dtype(const sqlrs_csv_t *r, int i);
+/* Bounds (offset, limit) of the scan over the data records, limit < 0 = none [ref: csv.rs:207-215];
+ * call before the first next_batch */
+int sqlrs_csv_set_bounds(sqlrs_csv_t *r, int64_t offset, int64_t limit);
+/* Projections: indices into the file's columns [ref: csv.rs:224] */
+int sqlrs_csv_set_projection(sqlrs_csv_t *r, int num_columns, const int32_t *columns);
+/* *out = NULL at the end of the scan */
+int sqlrs_csv_next_batch(sqlrs_csv_t *r, int out_mem, sqlrs_batch_t **out);
+void sqlrs_csv_close(sqlrs_csv_t *r);
+
 /* --------------------------------------------------------------- exchange -- */
 /* Hash-partitions a batch on one key expression for the multi-GPU partitioned join /
  * group-by (no reference analogue: sqlrs is single process).  The output batch

@@ -27,6 +27,7 @@
 #include "../include/sqlrs_hip.h"
 
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1311,6 +1312,184 @@ int oracle_order_finish(oracle_order *o, int, sqlrs_batch_t **out) {
   });
 }
 void oracle_order_destroy(oracle_order *o) { delete o; }
+
+// ----------------------------------------------------------------- Project --
+// [ref: src/executor/project.rs:6-29] one output batch per input batch, column i = exprs[i].eval_column
+struct oracle_project {
+  oracle_ctx *ctx;
+  std::vector<Expr> exprs;
+};
+int oracle_project_create(oracle_ctx *ctx, int num_exprs, const sqlrs_expr_t *exprs, oracle_project **out) {
+  return guard(ctx, [&] {
+    auto p = std::unique_ptr<oracle_project>(new oracle_project());
+    p->ctx = ctx;
+    for (int i = 0; i < num_exprs; i++) p->exprs.push_back(expr_from_abi(&exprs[i]));
+    *out = p.release();
+  });
+}
+int oracle_project_push(oracle_project *p, const sqlrs_batch_t *in, int, sqlrs_batch_t **out) {
+  return guard(p->ctx, [&] {
+    Batch batch = batch_from_abi(in);
+    Batch o;
+    o.rows = batch.rows;
+    for (const Expr &e : p->exprs) o.cols.push_back(eval_column(e, batch)); // project.rs:17-21
+    *out = batch_to_abi(std::move(o));
+  });
+}
+void oracle_project_destroy(oracle_project *p) { delete p; }
+
+// ------------------------------------------------------------------- Limit --
+// [ref: src/executor/limit.rs:4-81]
+struct oracle_limit {
+  oracle_ctx *ctx;
+  bool has_limit;
+  uint64_t limit, offset_val;
+  uint64_t returned_count = 0;
+  bool done = false;
+};
+int oracle_limit_create(oracle_ctx *ctx, int has_limit, int64_t limit, int has_offset, int64_t offset, oracle_limit **out) {
+  return guard(ctx, [&] {
+    auto l = std::unique_ptr<oracle_limit>(new oracle_limit());
+    l->ctx = ctx;
+    l->has_limit = has_limit != 0;
+    l->limit = (uint64_t)limit;
+    l->offset_val = has_offset ? (uint64_t)offset : 0; // limit.rs:21-27
+    if (l->has_limit && l->limit == 0) l->done = true;  // limit.rs:29-31: nothing is ever yielded
+    *out = l.release();
+  });
+}
+int oracle_limit_push(oracle_limit *l, const sqlrs_batch_t *in, int, sqlrs_batch_t **out, int *done) {
+  return guard(l->ctx, [&] {
+    *out = nullptr;
+    if (l->done) {
+      *done = 1;
+      return;
+    }
+    Batch batch = batch_from_abi(in);
+    const uint64_t cardinality = (uint64_t)batch.rows;
+    const uint64_t limit_val = l->has_limit ? l->limit : cardinality;                       // :39
+    const uint64_t start = std::max(l->returned_count, l->offset_val) - l->returned_count;   // :41
+    const uint64_t total_end = l->offset_val + limit_val;                                    // :45
+    const uint64_t current_batch_end = l->returned_count + cardinality;                      // :46
+    const uint64_t end = std::min(total_end, current_batch_end) - l->returned_count;         // :49-51
+    l->returned_count += cardinality;                                                        // :54
+    if (start < end) {                                                                       // :61-63
+      if (start == 0 && end == cardinality) {
+        *out = batch_to_abi(std::move(batch));                                               // :65-66
+      } else {
+        std::vector<int64_t> idx;
+        for (uint64_t i = start; i < end; i++) idx.push_back((int64_t)i);
+        Batch o;
+        o.rows = (int64_t)(end - start);
+        for (const Col &c : batch.cols) o.cols.push_back(take(c, idx));                      // batch.slice(start, length)
+        *out = batch_to_abi(std::move(o));
+      }
+      if (l->returned_count >= l->offset_val + limit_val) l->done = true;                    // :76-78
+    }
+    *done = l->done ? 1 : 0;
+  });
+}
+void oracle_limit_destroy(oracle_limit *l) { delete l; }
+
+// --------------------------------------------------------------- SimpleAgg --
+// [ref: src/executor/aggregate/simple_agg.rs:10-66] one accumulator per aggregate over ALL rows,
+// one output row; without any input batch `agg_fileds.unwrap()` panics (:63)
+struct oracle_simple_agg {
+  oracle_ctx *ctx;
+  std::vector<AggSpec> agg_funcs;
+  std::vector<std::unique_ptr<Accumulator>> accs;
+  bool saw_batch = false;
+};
+int oracle_simple_agg_create(oracle_ctx *ctx, int num_aggs, const sqlrs_agg_func_t *aggs, oracle_simple_agg **out) {
+  return guard(ctx, [&] {
+    auto a = std::unique_ptr<oracle_simple_agg>(new oracle_simple_agg());
+    a->ctx = ctx;
+    for (int i = 0; i < num_aggs; i++) {
+      AggSpec s;
+      s.func = aggs[i].func;
+      s.distinct = aggs[i].distinct;
+      s.return_dtype = aggs[i].return_dtype;
+      s.arg = expr_from_abi(&aggs[i].arg);
+      a->accs.push_back(create_accumulator(s, ctx->compat_count_last_batch != 0)); // :29
+      a->agg_funcs.push_back(std::move(s));
+    }
+    *out = a.release();
+  });
+}
+int oracle_simple_agg_push(oracle_simple_agg *a, const sqlrs_batch_t *in) {
+  return guard(a->ctx, [&] {
+    Batch batch = batch_from_abi(in);
+    a->saw_batch = true;
+    for (size_t k = 0; k < a->agg_funcs.size(); k++)
+      a->accs[k]->update_batch(eval_column(a->agg_funcs[k].arg, batch)); // :38-56
+  });
+}
+int oracle_simple_agg_finish(oracle_simple_agg *a, int, sqlrs_batch_t **out) {
+  return guard(a->ctx, [&] {
+    if (!a->saw_batch) fail(SQLRS_ERR_INTERNAL, "simple agg finished without any input batch");
+    Batch o;
+    o.rows = 1;
+    for (size_t k = 0; k < a->accs.size(); k++) {
+      Builder b(a->agg_funcs[k].return_dtype);
+      b.append(a->accs[k]->evaluate()); // build_scalar_value_array(&res, 1)  (:59-62)
+      o.cols.push_back(b.finish());
+    }
+    *out = batch_to_abi(std::move(o));
+  });
+}
+void oracle_simple_agg_destroy(oracle_simple_agg *a) { delete a; }
+
+// ----------------------------------------------------- record_batch_to_string --
+// [ref: src/util/mod.rs:53-80] one line per row, columns separated by one blank, NULL -> "NULL",
+// empty Utf8 -> "(empty)", everything else arrow's array_value_to_string = Rust's Display of the
+// value (floats: shortest digits that round-trip, positional notation, no trailing ".0").
+// Returns a malloc'd NUL-terminated string in *out (caller frees with oracle_string_free).
+int oracle_batch_to_string(oracle_ctx *ctx, const sqlrs_batch_t *in, char **out) {
+  return guard(ctx, [&] {
+    Batch b = batch_from_abi(in);
+    std::string s;
+    for (int64_t row = 0; row < b.rows; row++) {
+      for (size_t c = 0; c < b.cols.size(); c++) {
+        if (c) s.push_back(' ');
+        const Col &col = b.cols[c];
+        if (!col.valid(row)) {
+          s += "NULL";
+          continue;
+        }
+        Scalar v = scalar_at(col, row);
+        switch (col.dtype) {
+        case SQLRS_UTF8:
+          s += v.s.empty() ? std::string("(empty)") : v.s;
+          break;
+        case SQLRS_BOOLEAN:
+          s += v.i ? "true" : "false";
+          break;
+        case SQLRS_FLOAT64: {
+          if (std::isnan(v.f)) s += "NaN";
+          else if (std::isinf(v.f)) s += v.f < 0 ? "-inf" : "inf";
+          else {
+            char buf[400];
+            auto r = std::to_chars(buf, buf + sizeof(buf), v.f, std::chars_format::fixed);
+            s.append(buf, r.ptr);
+          }
+          break;
+        }
+        case SQLRS_UINT64:
+          s += std::to_string((uint64_t)v.i);
+          break;
+        default:
+          s += std::to_string(v.i);
+        }
+      }
+      s.push_back('\n');
+    }
+    char *p = (char *)std::malloc(s.size() + 1);
+    if (!p) fail(SQLRS_ERR_INTERNAL, "allocation failed");
+    std::memcpy(p, s.c_str(), s.size() + 1);
+    *out = p;
+  });
+}
+void oracle_string_free(char *s) { std::free(s); }
 
 const char *oracle_version(void) { return "sqlrs-oracle 0.1 (cpu restatement, test only)"; }
 

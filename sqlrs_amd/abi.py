@@ -316,6 +316,26 @@ class Backend:
             "join_agg_set_group_order": (i, [vp, i]),
             "hash_agg_set_group_order": (i, [vp, i]),
             "join_agg_destroy": (None, [vp]),
+            "project_create": (i, [vp, i, pe, pvp]),
+            "project_push": (i, [vp, pb, i, ppb]),
+            "project_destroy": (None, [vp]),
+            "limit_create": (i, [vp, i, C.c_int64, i, C.c_int64, pvp]),
+            "limit_push": (i, [vp, pb, i, ppb, C.POINTER(C.c_int)]),
+            "limit_destroy": (None, [vp]),
+            "simple_agg_create": (i, [vp, i, C.POINTER(AggFunc), pvp]),
+            "simple_agg_push": (i, [vp, pb]),
+            "simple_agg_finish": (i, [vp, i, ppb]),
+            "simple_agg_destroy": (None, [vp]),
+            "batch_to_string": (i, [vp, pb, C.POINTER(C.c_void_p)]),
+            "string_free": (None, [C.c_void_p]),
+            "csv_open": (i, [vp, C.c_char_p, i, C.c_char, C.c_int64, C.c_int64, pvp]),
+            "csv_num_columns": (i, [vp]),
+            "csv_column_name": (C.c_char_p, [vp, i]),
+            "csv_column_dtype": (i, [vp, i]),
+            "csv_set_bounds": (i, [vp, C.c_int64, C.c_int64]),
+            "csv_set_projection": (i, [vp, i, C.POINTER(C.c_int32)]),
+            "csv_next_batch": (i, [vp, i, ppb]),
+            "csv_close": (None, [vp]),
             "timer_create": (i, [vp, pvp]),
             "timer_start": (i, [vp]),
             "timer_stop": (i, [vp]),
@@ -373,6 +393,16 @@ class Backend:
         self.check(self.fn("hash_partition")(self.ctx, b.ptr, C.byref(packed.abi), num_parts, out_mem,
                                              C.byref(out), offs))
         return self.wrap(out), list(offs)
+
+    def batch_to_string(self, batch) -> str:
+        """``record_batch_to_string`` (util/mod.rs:53-80) of a pyarrow / host / device batch"""
+        b = as_batch(batch)
+        out = C.c_void_p()
+        self.check(self.fn("batch_to_string")(self.ctx, b.ptr, C.byref(out)))
+        try:
+            return C.string_at(out.value).decode("utf-8")
+        finally:
+            self.fn("string_free")(out)
 
     def profile(self, on: bool = True):
         self.check(self.fn("ctx_profile_enable")(self.ctx, int(on)))

@@ -193,6 +193,7 @@ struct InBatch {
 DCol upload_column(Ctx *ctx, const sqlrs_column_t &c, bool force_copy);
 // Device batch -> library-owned ABI batch in `out_mem` (host: D2H into malloc'd buffers).
 sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem);
+sqlrs_batch_t *emit_host_columns(Ctx *ctx, std::vector<sqlrs_column_t> &&cols, int64_t rows); // takes over malloc'd blocks
 DCol make_null_column(Ctx *ctx, int32_t dtype, int64_t n);
 int64_t count_nulls(Ctx *ctx, const DCol &c);
 

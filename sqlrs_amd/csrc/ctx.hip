@@ -373,6 +373,27 @@ sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem) {
   return &o.release()->abi;
 }
 
+// Host columns built by the library itself (CSV ingest) -> library-owned HOST batch.  Every pointer of
+// `cols` is a malloc'd block that the batch takes over.
+sqlrs_batch_t *emit_host_columns(Ctx *ctx, std::vector<sqlrs_column_t> &&cols, int64_t rows) {
+  auto o = std::unique_ptr<OwnedBatch>(new OwnedBatch());
+  o->ctx = ctx;
+  o->out_mem = SQLRS_MEM_HOST;
+  o->descs = std::move(cols);
+  for (sqlrs_column_t &c : o->descs) {
+    c.mem = SQLRS_MEM_HOST;
+    if (c.values) o->host_blocks.push_back(const_cast<void *>(c.values));
+    if (c.validity) o->host_blocks.push_back(const_cast<uint8_t *>(c.validity));
+    if (c.offsets) o->host_blocks.push_back(const_cast<int32_t *>(c.offsets));
+  }
+  o->abi.num_rows = rows;
+  o->abi.num_columns = (int32_t)o->descs.size();
+  o->abi.reserved = 0;
+  o->abi.columns = o->descs.data();
+  o->abi.owner = o.get();
+  return &o.release()->abi;
+}
+
 } // namespace sq
 
 using namespace sq;

@@ -1,0 +1,540 @@
+// plumbing.hip — the operators either side of the hot path: ProjectExecutor,
+// LimitExecutor, SimpleAggExecutor, the sqllogictest text form of a batch, and CSV ingest.
+// None of them is a hot loop in the reference; they exist here so that a whole query plan can
+// stay device resident between the scan and the final rendering, and so that the reference's
+// .slt expectations are compared in the reference's own text form.
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <strings.h>
+
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "prims.hpp"
+
+using namespace sq;
+
+extern "C" {
+int sqlrs_hash_agg_create(sqlrs_ctx_t *, int, const sqlrs_expr_t *, int, const sqlrs_agg_func_t *, sqlrs_hash_agg_t **);
+int sqlrs_hash_agg_push(sqlrs_hash_agg_t *, const sqlrs_batch_t *);
+int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *, int, sqlrs_batch_t **);
+void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *);
+void sqlrs_batch_release(sqlrs_batch_t *);
+}
+
+namespace sq {
+
+__global__ void iota_offset_u32_kernel(uint32_t *out, int64_t n, uint32_t start) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = start + (uint32_t)i;
+}
+__global__ void fill_zero_u64_kernel(uint64_t *out, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 0;
+}
+
+} // namespace sq
+
+// ========================================================================== Project ==
+struct sqlrs_project {
+  Ctx *ctx = nullptr;
+  std::vector<Expr> exprs;
+};
+
+// =========================================================================== Limit ==
+struct sqlrs_limit {
+  Ctx *ctx = nullptr;
+  bool has_limit = false, done = false;
+  uint64_t limit = 0, offset_val = 0, returned_count = 0;
+};
+
+// ======================================================================= SimpleAgg ==
+struct sqlrs_simple_agg {
+  Ctx *ctx = nullptr;
+  sqlrs_hash_agg_t *inner = nullptr; // HashAgg over one constant key: same accumulators, one group
+  std::vector<int32_t> funcs, return_dtypes;
+  bool saw_batch = false;
+  ~sqlrs_simple_agg() {
+    if (inner) sqlrs_hash_agg_destroy(inner);
+  }
+};
+
+// ============================================================================= CSV ==
+namespace {
+
+enum CsvKind { CSV_INT = 1, CSV_FLOAT = 2, CSV_BOOL = 4, CSV_TEXT = 8 };
+
+bool all_digits(const char *p, const char *e) {
+  if (p == e) return false;
+  for (; p < e; p++)
+    if (*p < '0' || *p > '9') return false;
+  return true;
+}
+bool is_int(const std::string &s) {
+  const char *p = s.data(), *e = p + s.size();
+  if (p < e && *p == '-') p++;
+  return all_digits(p, e);
+}
+bool is_float(const std::string &s) { // -?(\d*\.\d+|\d+\.\d*)([eE][-+]?\d+)? | -?\d+[eE][-+]?\d+
+  const char *p = s.data(), *e = p + s.size();
+  if (p < e && *p == '-') p++;
+  const char *d0 = p;
+  while (p < e && *p >= '0' && *p <= '9') p++;
+  int int_digits = (int)(p - d0), frac_digits = 0;
+  bool dot = false;
+  if (p < e && *p == '.') {
+    dot = true;
+    p++;
+    const char *f0 = p;
+    while (p < e && *p >= '0' && *p <= '9') p++;
+    frac_digits = (int)(p - f0);
+  }
+  if (int_digits + frac_digits == 0) return false;
+  bool exp = false;
+  if (p < e && (*p == 'e' || *p == 'E')) {
+    p++;
+    if (p < e && (*p == '-' || *p == '+')) p++;
+    if (!all_digits(p, e)) return false;
+    p = e;
+    exp = true;
+  }
+  return p == e && (dot || exp);
+}
+bool is_bool(const std::string &s) {
+  if (s.size() == 4) return strncasecmp(s.c_str(), "true", 4) == 0;
+  if (s.size() == 5) return strncasecmp(s.c_str(), "false", 5) == 0;
+  return false;
+}
+
+// One CSV record -> fields (RFC 4180 quoting: "..." with "" as an escaped quote; the csv crate's
+// defaults, which arrow-csv 28 uses).  Returns false at end of input.
+bool read_record(std::istream &in, char delim, std::vector<std::string> &fields) {
+  fields.clear();
+  std::string cur;
+  bool in_quotes = false, any = false, was_quoted = false;
+  int ch;
+  while ((ch = in.get()) != EOF) {
+    any = true;
+    char c = (char)ch;
+    if (in_quotes) {
+      if (c == '"') {
+        if (in.peek() == '"') {
+          cur.push_back('"');
+          in.get();
+        } else
+          in_quotes = false;
+      } else
+        cur.push_back(c);
+      continue;
+    }
+    if (c == '"' && cur.empty() && !was_quoted) {
+      in_quotes = true;
+      was_quoted = true;
+    } else if (c == delim) {
+      fields.push_back(cur);
+      cur.clear();
+      was_quoted = false;
+    } else if (c == '\n') {
+      if (!cur.empty() && cur.back() == '\r') cur.pop_back();
+      if (fields.empty() && cur.empty() && !was_quoted) { // blank line: skipped by the csv crate
+        any = false;
+        continue;
+      }
+      fields.push_back(cur);
+      return true;
+    } else
+      cur.push_back(c);
+  }
+  if (!any) return false;
+  if (!cur.empty() && cur.back() == '\r') cur.pop_back();
+  if (fields.empty() && cur.empty() && !was_quoted) return false;
+  fields.push_back(cur);
+  return true;
+}
+
+} // namespace
+
+struct sqlrs_csv {
+  Ctx *ctx = nullptr;
+  std::ifstream file;
+  char delimiter = ',';
+  int64_t batch_size = 1024;
+  std::vector<std::string> names;
+  std::vector<int32_t> dtypes;
+  std::vector<int> projection; // indices into the file's columns
+  uint64_t remaining = ~0ull;  // records still allowed by the bounds
+  uint64_t line = 0;           // for error messages
+};
+
+extern "C" {
+
+// --------------------------------------------------------------------------- Project --
+int sqlrs_project_create(sqlrs_ctx_t *ctx, int num_exprs, const sqlrs_expr_t *exprs, sqlrs_project_t **out) {
+  return guard(ctx, [&] {
+    auto p = std::unique_ptr<sqlrs_project>(new sqlrs_project());
+    p->ctx = ctx;
+    for (int i = 0; i < num_exprs; i++) p->exprs.push_back(expr_from_abi(&exprs[i]));
+    *out = p.release();
+  });
+}
+// [ref: project.rs:14-27] a bare InputRef shares the input column's buffers (the reference clones an Arc)
+int sqlrs_project_push(sqlrs_project_t *p, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out) {
+  return guard(p->ctx, [&] {
+    Ctx *ctx = p->ctx;
+    SQ_HIP(hipSetDevice(ctx->device));
+    InBatch ib(ctx, in);
+    auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
+    DBatch o;
+    o.rows = ib.rows();
+    for (const Expr &e : p->exprs) {
+      DCol c = eval_expr(ctx, e, colfn, ib.rows(), true);
+      c.length = ib.rows();
+      // a column borrowed from a caller-built DEVICE batch must not outlive the call as a view
+      const bool borrowed = (c.values && !c.own_values) || (c.validity && !c.own_validity) || (c.offsets && !c.own_offsets);
+      if (borrowed && out_mem == SQLRS_MEM_DEVICE) c = copy_column(ctx, c);
+      o.cols.push_back(std::move(c));
+    }
+    *out = emit_batch(ctx, std::move(o), out_mem);
+  });
+}
+void sqlrs_project_destroy(sqlrs_project_t *p) { delete p; }
+
+// ----------------------------------------------------------------------------- Limit --
+int sqlrs_limit_create(sqlrs_ctx_t *ctx, int has_limit, int64_t limit, int has_offset, int64_t offset, sqlrs_limit_t **out) {
+  return guard(ctx, [&] {
+    if ((has_limit && limit < 0) || (has_offset && offset < 0)) fail(SQLRS_ERR_INTERNAL, "negative limit / offset");
+    auto l = std::unique_ptr<sqlrs_limit>(new sqlrs_limit());
+    l->ctx = ctx;
+    l->has_limit = has_limit != 0;
+    l->limit = (uint64_t)limit;
+    l->offset_val = has_offset ? (uint64_t)offset : 0; // limit.rs:21-27
+    if (l->has_limit && l->limit == 0) l->done = true;  // limit.rs:29-31
+    *out = l.release();
+  });
+}
+// one iteration of the for_await loop [ref: limit.rs:35-79]; *out = NULL when the batch yields nothing,
+// *done = 1 once no later batch can contribute (the reference `break`s / returned early)
+int sqlrs_limit_push(sqlrs_limit_t *l, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out, int *done) {
+  return guard(l->ctx, [&] {
+    Ctx *ctx = l->ctx;
+    SQ_HIP(hipSetDevice(ctx->device));
+    *out = nullptr;
+    if (l->done) {
+      if (done) *done = 1;
+      return;
+    }
+    InBatch ib(ctx, in);
+    const uint64_t cardinality = (uint64_t)ib.rows();
+    const uint64_t limit_val = l->has_limit ? l->limit : cardinality;
+    const uint64_t start = std::max(l->returned_count, l->offset_val) - l->returned_count;
+    const uint64_t total_end = l->offset_val + limit_val;
+    const uint64_t current_batch_end = l->returned_count + cardinality;
+    const uint64_t end = std::min(total_end, current_batch_end) - l->returned_count;
+    l->returned_count += cardinality;
+    if (start < end) {
+      DBatch o;
+      o.rows = (int64_t)(end - start);
+      if (start == 0 && end == cardinality) {
+        o = ib.materialize(out_mem == SQLRS_MEM_DEVICE); // the batch itself (limit.rs:65-66)
+      } else { // batch.slice(start, length): device bitmaps are word aligned, so a slice is a gather of [start, end)
+        const int64_t m = (int64_t)(end - start);
+        BufP idx = ctx->alloc(4 * (size_t)m);
+        iota_offset_u32_kernel<<<dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx->stream>>>(idx->as<uint32_t>(), m, (uint32_t)start);
+        SQ_HIP(hipGetLastError());
+        for (int c = 0; c < ib.num_columns(); c++) o.cols.push_back(gather_column(ctx, ib.col(c), idx->p, false, nullptr, m));
+      }
+      *out = emit_batch(ctx, std::move(o), out_mem);
+      if (l->returned_count >= l->offset_val + limit_val) l->done = true; // limit.rs:76-78
+    }
+    if (done) *done = l->done ? 1 : 0;
+  });
+}
+void sqlrs_limit_destroy(sqlrs_limit_t *l) { delete l; }
+
+// ------------------------------------------------------------------------- SimpleAgg --
+int sqlrs_simple_agg_create(sqlrs_ctx_t *ctx, int num_aggs, const sqlrs_agg_func_t *aggs, sqlrs_simple_agg_t **out) {
+  return guard(ctx, [&] {
+    auto a = std::unique_ptr<sqlrs_simple_agg>(new sqlrs_simple_agg());
+    a->ctx = ctx;
+    sqlrs_expr_node_t key;
+    std::memset(&key, 0, sizeof(key));
+    key.op = SQLRS_EXPR_CONSTANT;
+    key.dtype = SQLRS_INT64;
+    sqlrs_expr_t gb{&key, 1, 0};
+    int st = sqlrs_hash_agg_create(ctx, 1, &gb, num_aggs, aggs, &a->inner);
+    if (st != SQLRS_OK) fail(st, ctx->last_error);
+    for (int i = 0; i < num_aggs; i++) {
+      a->funcs.push_back(aggs[i].func);
+      a->return_dtypes.push_back(aggs[i].return_dtype);
+    }
+    *out = a.release();
+  });
+}
+int sqlrs_simple_agg_push(sqlrs_simple_agg_t *a, const sqlrs_batch_t *in) {
+  a->saw_batch = true;
+  return sqlrs_hash_agg_push(a->inner, in);
+}
+// [ref: simple_agg.rs:58-64] exactly one row; no input rows at all: COUNT = 0, everything else NULL
+int sqlrs_simple_agg_finish(sqlrs_simple_agg_t *a, int out_mem, sqlrs_batch_t **out) {
+  sqlrs_batch_t *g = nullptr;
+  if (!a->saw_batch) return guard(a->ctx, [&] { fail(SQLRS_ERR_INTERNAL, "simple agg finished without any input batch"); });
+  int st = sqlrs_hash_agg_finish(a->inner, SQLRS_MEM_DEVICE, &g);
+  if (st != SQLRS_OK) return st;
+  st = guard(a->ctx, [&] {
+    Ctx *ctx = a->ctx;
+    DBatch o;
+    o.rows = 1;
+    if (g->num_rows == 1) {
+      InBatch ib(ctx, g); // library-owned: columns are shared, not copied
+      for (int c = 1; c < ib.num_columns(); c++) o.cols.push_back(ib.col(c));
+    } else if (g->num_rows == 0) {
+      for (size_t i = 0; i < a->funcs.size(); i++) {
+        if (a->funcs[i] == SQLRS_AGG_COUNT) {
+          DCol z;
+          z.dtype = SQLRS_INT64;
+          z.length = 1;
+          z.own_values = ctx->alloc_zero(8);
+          z.values = z.own_values->p;
+          o.cols.push_back(std::move(z));
+        } else
+          o.cols.push_back(make_null_column(ctx, a->return_dtypes[i], 1));
+      }
+    } else
+      fail(SQLRS_ERR_INTERNAL, "simple agg produced more than one group");
+    *out = emit_batch(ctx, std::move(o), out_mem);
+  });
+  sqlrs_batch_release(g);
+  return st;
+}
+void sqlrs_simple_agg_destroy(sqlrs_simple_agg_t *a) { delete a; }
+
+// ------------------------------------------------------------- record_batch_to_string --
+// [ref: src/util/mod.rs:53-80]
+int sqlrs_batch_to_string(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, char **out) {
+  return guard(ctx, [&] {
+    SQ_HIP(hipSetDevice(ctx->device));
+    sqlrs_batch_t *host = nullptr;
+    const sqlrs_batch_t *b = in;
+    bool device = false;
+    for (int c = 0; c < in->num_columns; c++) device |= in->columns[c].mem == SQLRS_MEM_DEVICE;
+    if (device) {
+      InBatch ib(ctx, in);
+      host = emit_batch(ctx, ib.materialize(false), SQLRS_MEM_HOST);
+      b = host;
+    }
+    std::string s;
+    for (int64_t row = 0; row < b->num_rows; row++) {
+      for (int c = 0; c < b->num_columns; c++) {
+        if (c) s.push_back(' ');
+        const sqlrs_column_t &col = b->columns[c];
+        if (col.validity && col.null_count != 0 && !((col.validity[row >> 3] >> (row & 7)) & 1)) {
+          s += "NULL";
+          continue;
+        }
+        switch (col.dtype) {
+        case SQLRS_UTF8: {
+          const int32_t lo = col.offsets[row], hi = col.offsets[row + 1];
+          if (lo == hi) s += "(empty)";
+          else s.append((const char *)col.values + lo, (size_t)(hi - lo));
+          break;
+        }
+        case SQLRS_BOOLEAN:
+          s += ((((const uint8_t *)col.values)[row >> 3] >> (row & 7)) & 1) ? "true" : "false";
+          break;
+        case SQLRS_FLOAT64: { // Rust's Display: shortest digits that round-trip, positional notation
+          const double v = ((const double *)col.values)[row];
+          if (std::isnan(v)) s += "NaN";
+          else if (std::isinf(v)) s += v < 0 ? "-inf" : "inf";
+          else {
+            char buf[400];
+            auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::fixed);
+            s.append(buf, r.ptr);
+          }
+          break;
+        }
+        case SQLRS_INT32: s += std::to_string(((const int32_t *)col.values)[row]); break;
+        case SQLRS_UINT32: s += std::to_string(((const uint32_t *)col.values)[row]); break;
+        case SQLRS_INT64: s += std::to_string(((const int64_t *)col.values)[row]); break;
+        case SQLRS_UINT64: s += std::to_string(((const uint64_t *)col.values)[row]); break;
+        default:
+          if (host) sqlrs_batch_release(host);
+          fail(SQLRS_ERR_INTERNAL, "unsupported column type in record_batch_to_string");
+        }
+      }
+      s.push_back('\n');
+    }
+    if (host) sqlrs_batch_release(host);
+    char *p = (char *)std::malloc(s.size() + 1);
+    if (!p) fail(SQLRS_ERR_INTERNAL, "allocation failed");
+    std::memcpy(p, s.c_str(), s.size() + 1);
+    *out = p;
+  });
+}
+void sqlrs_string_free(char *s) { std::free(s); }
+
+// ------------------------------------------------------------------------------- CSV --
+// [ref: src/storage/csv.rs:92-106 CsvConfig defaults, :124-133 infer_arrow_schema, :190-241 reader]
+int sqlrs_csv_open(sqlrs_ctx_t *ctx, const char *path, int has_header, char delimiter, int64_t batch_size,
+                   int64_t infer_max_records, sqlrs_csv_t **out) {
+  return guard(ctx, [&] {
+    auto r = std::unique_ptr<sqlrs_csv>(new sqlrs_csv());
+    r->ctx = ctx;
+    r->delimiter = delimiter ? delimiter : ',';
+    r->batch_size = batch_size > 0 ? batch_size : 1024;
+    // pass 1: header + type inference over the first records (arrow-csv infer_reader_schema)
+    std::ifstream probe(path, std::ios::binary);
+    if (!probe) fail(SQLRS_ERR_STORAGE, std::string("cannot open ") + path);
+    std::vector<std::string> f;
+    if (has_header) {
+      if (!read_record(probe, r->delimiter, f)) fail(SQLRS_ERR_STORAGE, "empty csv file");
+      r->names = f;
+    }
+    std::vector<int> kinds;
+    int64_t seen = 0;
+    while ((infer_max_records <= 0 || seen < infer_max_records) && read_record(probe, r->delimiter, f)) {
+      if (r->names.empty())
+        for (size_t i = 0; i < f.size(); i++) r->names.push_back("column_" + std::to_string(i + 1));
+      kinds.resize(r->names.size(), 0);
+      for (size_t i = 0; i < f.size() && i < kinds.size(); i++) {
+        if (f[i].empty()) continue; // a missing value says nothing about the type
+        kinds[i] |= is_bool(f[i]) ? CSV_BOOL : is_int(f[i]) ? CSV_INT : is_float(f[i]) ? CSV_FLOAT : CSV_TEXT;
+      }
+      seen++;
+    }
+    kinds.resize(r->names.size(), 0);
+    for (int k : kinds) {
+      int32_t dt = SQLRS_UTF8;
+      if (k == CSV_INT) dt = SQLRS_INT64;
+      else if (k == CSV_FLOAT || k == (CSV_INT | CSV_FLOAT)) dt = SQLRS_FLOAT64;
+      else if (k == CSV_BOOL) dt = SQLRS_BOOLEAN;
+      r->dtypes.push_back(dt);
+    }
+    for (size_t i = 0; i < r->names.size(); i++) r->projection.push_back((int)i);
+    // pass 2 starts behind the header
+    r->file.open(path, std::ios::binary);
+    if (!r->file) fail(SQLRS_ERR_STORAGE, std::string("cannot open ") + path);
+    if (has_header) read_record(r->file, r->delimiter, f);
+    *out = r.release();
+  });
+}
+int sqlrs_csv_num_columns(const sqlrs_csv_t *r) { return (int)r->names.size(); }
+const char *sqlrs_csv_column_name(const sqlrs_csv_t *r, int i) { return r->names[(size_t)i].c_str(); }
+int sqlrs_csv_column_dtype(const sqlrs_csv_t *r, int i) { return r->dtypes[(size_t)i]; }
+// Bounds of the scan (offset, limit) over the data records [ref: csv.rs:207-215]; limit < 0 = unbounded
+int sqlrs_csv_set_bounds(sqlrs_csv_t *r, int64_t offset, int64_t limit) {
+  return guard(r->ctx, [&] {
+    std::vector<std::string> f;
+    for (int64_t i = 0; i < offset; i++)
+      if (!read_record(r->file, r->delimiter, f)) break;
+    r->remaining = limit < 0 ? ~0ull : (uint64_t)limit;
+  });
+}
+int sqlrs_csv_set_projection(sqlrs_csv_t *r, int num_columns, const int32_t *columns) {
+  return guard(r->ctx, [&] {
+    r->projection.clear();
+    for (int i = 0; i < num_columns; i++) {
+      if (columns[i] < 0 || (size_t)columns[i] >= r->names.size()) fail(SQLRS_ERR_INTERNAL, "projection out of range");
+      r->projection.push_back(columns[i]);
+    }
+  });
+}
+// next batch of <= batch_size records, *out = NULL at the end of the scan [ref: csv.rs:236-241]
+int sqlrs_csv_next_batch(sqlrs_csv_t *r, int out_mem, sqlrs_batch_t **out) {
+  return guard(r->ctx, [&] {
+    Ctx *ctx = r->ctx;
+    *out = nullptr;
+    const size_t nc = r->projection.size();
+    std::vector<std::vector<uint8_t>> values(nc), valid(nc);
+    std::vector<std::vector<int32_t>> offsets(nc);
+    std::vector<int64_t> nulls(nc, 0);
+    for (size_t c = 0; c < nc; c++)
+      if (r->dtypes[(size_t)r->projection[c]] == SQLRS_UTF8) offsets[c].push_back(0);
+    std::vector<std::string> f;
+    int64_t rows = 0;
+    while (rows < r->batch_size && r->remaining > 0 && read_record(r->file, r->delimiter, f)) {
+      r->line++;
+      if (r->remaining != ~0ull) r->remaining--;
+      for (size_t c = 0; c < nc; c++) {
+        const int src = r->projection[c];
+        const std::string &s = (size_t)src < f.size() ? f[(size_t)src] : std::string();
+        const int32_t dt = r->dtypes[(size_t)src];
+        bool ok = true;
+        if (dt == SQLRS_UTF8) { // an empty field is the empty string, not NULL
+          values[c].insert(values[c].end(), s.begin(), s.end());
+          offsets[c].push_back((int32_t)values[c].size());
+        } else if (s.empty()) { // missing value of a typed column -> NULL
+          ok = false;
+          if (dt == SQLRS_BOOLEAN) {
+            if ((rows & 7) == 0) values[c].push_back(0);
+          } else
+            values[c].resize(values[c].size() + 8, 0);
+        } else if (dt == SQLRS_INT64) {
+          int64_t v = 0;
+          auto pr = std::from_chars(s.data(), s.data() + s.size(), v);
+          if (pr.ec != std::errc() || pr.ptr != s.data() + s.size())
+            fail(SQLRS_ERR_ARROW, "Error while parsing value " + s + " for column " + std::to_string(src) + " at line " + std::to_string(r->line));
+          const uint8_t *p = (const uint8_t *)&v;
+          values[c].insert(values[c].end(), p, p + 8);
+        } else if (dt == SQLRS_FLOAT64) {
+          double v = 0;
+          auto pr = std::from_chars(s.data(), s.data() + s.size(), v);
+          if (pr.ec != std::errc() || pr.ptr != s.data() + s.size())
+            fail(SQLRS_ERR_ARROW, "Error while parsing value " + s + " for column " + std::to_string(src) + " at line " + std::to_string(r->line));
+          const uint8_t *p = (const uint8_t *)&v;
+          values[c].insert(values[c].end(), p, p + 8);
+        } else { // BOOLEAN
+          if (!is_bool(s))
+            fail(SQLRS_ERR_ARROW, "Error while parsing value " + s + " for column " + std::to_string(src) + " at line " + std::to_string(r->line));
+          if ((rows & 7) == 0) values[c].push_back(0);
+          if (s.size() == 4) values[c].back() |= (uint8_t)(1u << (rows & 7));
+        }
+        if ((rows & 7) == 0) valid[c].push_back(0);
+        if (ok) valid[c].back() |= (uint8_t)(1u << (rows & 7));
+        else nulls[c]++;
+      }
+      rows++;
+    }
+    if (rows == 0) return; // end of the scan
+    std::vector<sqlrs_column_t> cols(nc);
+    auto take_bytes = [&](const void *src, size_t bytes) -> void * {
+      void *p = std::malloc(bytes + 64);
+      if (!p) fail(SQLRS_ERR_INTERNAL, "host allocation failed");
+      std::memset(p, 0, bytes + 64);
+      if (bytes) std::memcpy(p, src, bytes);
+      return p;
+    };
+    for (size_t c = 0; c < nc; c++) {
+      sqlrs_column_t &d = cols[c];
+      d.dtype = r->dtypes[(size_t)r->projection[c]];
+      d.mem = SQLRS_MEM_HOST;
+      d.length = rows;
+      d.null_count = nulls[c];
+      d.values = take_bytes(values[c].data(), values[c].size());
+      d.validity = nulls[c] ? (const uint8_t *)take_bytes(valid[c].data(), valid[c].size()) : nullptr;
+      d.offsets = d.dtype == SQLRS_UTF8 ? (const int32_t *)take_bytes(offsets[c].data(), 4 * offsets[c].size()) : nullptr;
+    }
+    sqlrs_batch_t *host = emit_host_columns(ctx, std::move(cols), rows);
+    if (out_mem == SQLRS_MEM_HOST) {
+      *out = host;
+      return;
+    }
+    // straight into HBM: one upload per column, the host copy is dropped
+    SQ_HIP(hipSetDevice(ctx->device));
+    sqlrs_batch_t *dev = nullptr;
+    try {
+      InBatch ib(ctx, host);
+      dev = emit_batch(ctx, ib.materialize(true), SQLRS_MEM_DEVICE);
+    } catch (...) {
+      sqlrs_batch_release(host);
+      throw;
+    }
+    ctx->sync(); // the uploads read the host blocks
+    sqlrs_batch_release(host);
+    *out = dev;
+  });
+}
+void sqlrs_csv_close(sqlrs_csv_t *r) { delete r; }
+
+} // extern "C"

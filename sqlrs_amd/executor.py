@@ -253,6 +253,122 @@ class OrderExecutor:
             be.fn("order_destroy")(h)
 
 
+class ProjectExecutor:
+    """``ProjectExecutor { exprs, child }`` (project.rs:6-9)."""
+
+    def __init__(self, backend: abi.Backend, exprs: List[BoundExpr], child: Iterable, out_mem: int = abi.MEM_HOST,
+                 output_names: Optional[Sequence[str]] = None):
+        self.backend, self.exprs, self.child, self.out_mem, self.output_names = backend, exprs, child, out_mem, output_names
+
+    def execute(self):
+        be = self.backend
+        arr, keep = abi.pack_exprs(self.exprs)
+        h = C.c_void_p()
+        be.check(be.fn("project_create")(be.ctx, len(self.exprs), arr, C.byref(h)))
+        try:
+            for batch in self.child:  # project.rs:14-27
+                b = abi.as_batch(batch)
+                out = C.POINTER(abi.Batch)()
+                be.check(be.fn("project_push")(h, b.ptr, self.out_mem, C.byref(out)))
+                yield _emit(be, out, self.out_mem, self.output_names)
+        finally:
+            be.fn("project_destroy")(h)
+
+
+class LimitExecutor:
+    """``LimitExecutor { limit, offset, child }`` (limit.rs:4-8); ``None`` = no LIMIT / OFFSET clause."""
+
+    def __init__(self, backend: abi.Backend, limit: Optional[int], offset: Optional[int], child: Iterable,
+                 out_mem: int = abi.MEM_HOST):
+        self.backend, self.limit, self.offset, self.child, self.out_mem = backend, limit, offset, child, out_mem
+
+    def execute(self):
+        be = self.backend
+        h = C.c_void_p()
+        be.check(be.fn("limit_create")(be.ctx, int(self.limit is not None), int(self.limit or 0),
+                                       int(self.offset is not None), int(self.offset or 0), C.byref(h)))
+        try:
+            if self.limit is not None and self.limit == 0:
+                return  # limit.rs:29-31: returns before the child is polled
+            for batch in self.child:  # limit.rs:35-79
+                b = abi.as_batch(batch)
+                out = C.POINTER(abi.Batch)()
+                done = C.c_int(0)
+                be.check(be.fn("limit_push")(h, b.ptr, self.out_mem, C.byref(out), C.byref(done)))
+                r = _emit(be, out, self.out_mem, _names_of(batch))
+                if r is not None:
+                    yield r
+                if done.value:
+                    break
+        finally:
+            be.fn("limit_destroy")(h)
+
+
+class SimpleAggExecutor:
+    """``SimpleAggExecutor { agg_funcs, child }`` (simple_agg.rs:10-13)."""
+
+    def __init__(self, backend: abi.Backend, agg_funcs: List[AggFunc], child: Iterable, out_mem: int = abi.MEM_HOST,
+                 output_names: Optional[Sequence[str]] = None):
+        self.backend, self.agg_funcs, self.child, self.out_mem, self.output_names = backend, agg_funcs, child, out_mem, output_names
+
+    def execute(self):
+        be = self.backend
+        keep = []
+        aggs = (abi.AggFunc * max(len(self.agg_funcs), 1))(*[a.abi_struct(keep) for a in self.agg_funcs])
+        h = C.c_void_p()
+        be.check(be.fn("simple_agg_create")(be.ctx, len(self.agg_funcs), aggs, C.byref(h)))
+        try:
+            for batch in self.child:  # simple_agg.rs:35-56
+                b = abi.as_batch(batch)
+                be.check(be.fn("simple_agg_push")(h, b.ptr))
+            out = C.POINTER(abi.Batch)()
+            be.check(be.fn("simple_agg_finish")(h, self.out_mem, C.byref(out)))
+            yield _emit(be, out, self.out_mem, self.output_names)
+        finally:
+            be.fn("simple_agg_destroy")(h)
+
+
+class CsvScan:
+    """``CsvTable`` + ``CsvTransaction`` (storage/csv.rs:108-241): schema inferred from the first records,
+    batches of ``batch_size`` rows; ``bounds = (offset, limit)``, ``projection`` = column indices.
+    HIP library only (CSV ingest is host work that lands in HBM with ``out_mem=MEM_DEVICE``)."""
+
+    def __init__(self, backend: abi.Backend, path: str, has_header: bool = True, delimiter: str = ",",
+                 batch_size: int = 1024, infer_max_records: int = 10, bounds=None, projection=None,
+                 out_mem: int = abi.MEM_HOST):
+        self.backend, self.path, self.out_mem = backend, path, out_mem
+        self.cfg = (has_header, delimiter, batch_size, infer_max_records)
+        self.bounds, self.projection = bounds, projection
+        self.names: List[str] = []
+        self.dtypes: List[int] = []
+
+    def execute(self):
+        be = self.backend
+        h = C.c_void_p()
+        has_header, delim, bs, infer = self.cfg
+        be.check(be.fn("csv_open")(be.ctx, self.path.encode(), int(has_header), delim.encode()[:1], bs, infer, C.byref(h)))
+        try:
+            n = be.fn("csv_num_columns")(h)
+            names = [be.fn("csv_column_name")(h, k).decode().lower() for k in range(n)]  # infer_catalog lowercases (:137)
+            dtypes = [be.fn("csv_column_dtype")(h, k) for k in range(n)]
+            if self.projection is not None:
+                arr = (C.c_int32 * max(len(self.projection), 1))(*self.projection)
+                be.check(be.fn("csv_set_projection")(h, len(self.projection), arr))
+                names = [names[k] for k in self.projection]
+                dtypes = [dtypes[k] for k in self.projection]
+            self.names, self.dtypes = names, dtypes
+            if self.bounds is not None:
+                be.check(be.fn("csv_set_bounds")(h, int(self.bounds[0]), -1 if self.bounds[1] is None else int(self.bounds[1])))
+            while True:
+                out = C.POINTER(abi.Batch)()
+                be.check(be.fn("csv_next_batch")(h, self.out_mem, C.byref(out)))
+                if not out:
+                    break
+                yield _emit(be, out, self.out_mem, names)
+        finally:
+            be.fn("csv_close")(h)
+
+
 def eval_column(backend: abi.Backend, expr: BoundExpr, batch, out_mem: int = abi.MEM_HOST):
     """``BoundExpr::eval_column`` (evaluator.rs:13-28) -> one-column batch."""
     packed = expr.pack()

@@ -2,7 +2,7 @@
 hot path.  CPU only."""
 import pytest
 
-from golden_runner import Runner, load
+from golden_runner import Runner, load, render_rows
 
 FX = load()
 
@@ -11,3 +11,61 @@ FX = load()
 def test_oracle_matches_reference_golden(oracle, case):
     got = Runner(oracle, FX).rows(case["plan"])
     assert got == case["expected"], f"{case['name']} ({case['source']})"
+
+
+@pytest.mark.parametrize("case", FX["cases"], ids=[c["name"] for c in FX["cases"]])
+def test_oracle_text_form_matches_reference_golden(oracle, case):
+    """the same goldens compared in the reference's own text form (record_batch_to_string,
+    util/mod.rs:53-80: NULL / (empty) / Display), as its sqllogictest harness does"""
+    assert Runner(oracle, FX).text(case["plan"]) == render_rows(case["expected"])
+
+
+LIMIT_CASES = [  # limit.rs:93-98 #[test_case(inputs, offset, limit, outputs)]
+    ([(0, 6)], 1, 4, [(1, 5)]),
+    ([(0, 6)], 0, 10, [(0, 6)]),
+    ([(0, 6)], 10, 0, []),
+    ([(0, 2), (2, 4), (4, 6)], 1, 4, [(1, 2), (2, 4), (4, 5)]),
+    ([(0, 2), (2, 4), (4, 6)], 1, 2, [(1, 2), (2, 3)]),
+    ([(0, 2), (2, 4), (4, 6)], 3, 0, []),
+]
+
+
+def limit_case(backend, inputs, offset, limit):
+    import pyarrow as pa
+    from sqlrs_amd.executor import LimitExecutor
+    chunks = [pa.RecordBatch.from_arrays([pa.array(list(range(a, b)), type=pa.int32())], names=["a"]) for a, b in inputs]
+    pulled = []
+
+    def child():
+        for c in chunks:
+            pulled.append(1)
+            yield c
+    out = list(LimitExecutor(backend, limit, offset, child()).execute())
+    return [b.column(0).to_pylist() for b in out], len(pulled)
+
+
+@pytest.mark.parametrize("inputs,offset,limit,outputs", LIMIT_CASES)
+def test_oracle_limit_unit_cases(oracle, inputs, offset, limit, outputs):
+    got, _ = limit_case(oracle, inputs, offset, limit)
+    assert got == [list(range(a, b)) for a, b in outputs]  # one output batch per contributing input batch
+
+
+def test_oracle_limit_stops_pulling_the_child(oracle):
+    got, pulled = limit_case(oracle, [(0, 2), (2, 4), (4, 6)], 1, 2)
+    assert pulled == 2  # limit.rs:76-78 breaks after the batch that reaches offset + limit
+    _, pulled0 = limit_case(oracle, [(0, 2), (2, 4)], 0, 0)
+    assert pulled0 == 0  # limit.rs:29-31 returns before polling the child
+
+
+def test_oracle_simple_agg_edge_cases(oracle):
+    import pyarrow as pa
+    from sqlrs_amd import abi
+    from sqlrs_amd.executor import SimpleAggExecutor
+    from sqlrs_amd.expr import AggFunc, InputRef
+    aggs = [AggFunc("count", InputRef(0), abi.INT64), AggFunc("sum", InputRef(0), abi.INT64),
+            AggFunc("max", InputRef(0), abi.INT64)]
+    empty = pa.RecordBatch.from_arrays([pa.array([], type=pa.int64())], names=["a"])
+    (out,) = list(SimpleAggExecutor(oracle, aggs, [empty]).execute())
+    assert [c.to_pylist() for c in out.columns] == [[0], [None], [None]]
+    with pytest.raises(abi.ExecutorError):
+        list(SimpleAggExecutor(oracle, aggs, []).execute())  # simple_agg.rs:63 unwraps a None
