@@ -78,7 +78,19 @@ typedef struct sqlrs_column {
  * that retains its input (join build side, HashAgg) then shares the batch's
  * reference-counted buffers instead of copying them, and sqlrs_batch_release
  * only drops the caller's reference (the Arc<RecordBatch> clone of the reference).
- * Buffers of caller-built batches are borrowed for the duration of the call only. */
+ *
+ * Borrowing rules for caller-built batches:
+ *   - SQLRS_MEM_HOST columns are read completely before the call returns.
+ *   - SQLRS_MEM_DEVICE columns are used STREAM-ORDERED on the ctx stream: the call queues kernels that read
+ *     them (and operators that retain input queue a private copy) but does not wait for those kernels.
+ *     The buffers must (a) hold their data before the ctx stream reaches the call — data produced on
+ *     another stream: sqlrs_ctx_wait_stream(ctx, that_stream) first, or synchronise that stream — and
+ *     (b) stay valid and unmodified until the work queued by the call has completed:
+ *     sqlrs_ctx_synchronize, or sqlrs_ctx_release_to_stream(ctx, s) before stream s reuses / frees them.
+ *     (A stream-ordered allocator on another stream — e.g. torch's caching allocator — may hand a freed
+ *     block to later work of ITS stream: order that stream behind the ctx with release_to_stream.)
+ *   - Device bitmaps (validity, BOOLEAN values) must be 8-byte aligned and readable up to the next multiple
+ *     of 8 bytes (kernels read whole 64-bit words); host bitmaps have no such requirement. */
 typedef struct sqlrs_batch {
   int64_t num_rows;
   int32_t num_columns;
@@ -165,13 +177,22 @@ typedef struct sqlrs_ctx sqlrs_ctx_t;
  * Replaces nothing in the reference (it has no device); it is the handle a
  * replacement ExecutorBuilder would hold [ref: src/executor/mod.rs:36-56]. */
 int sqlrs_ctx_create(int device_id, sqlrs_ctx_t **out);
+/* Operators (and timers) of the ctx must be destroyed first; batches the ctx returned may be released
+ * before or after (their device blocks then go straight back to the driver). */
 void sqlrs_ctx_destroy(sqlrs_ctx_t *ctx);
 /* Message of the last failed call on this ctx (valid until the next call). */
 const char *sqlrs_last_error(const sqlrs_ctx_t *ctx);
 /* Blocks until all work queued on the ctx stream is done. */
 int sqlrs_ctx_synchronize(sqlrs_ctx_t *ctx);
-/* The hipStream_t of the ctx as an opaque pointer (for event timing by callers). */
+/* The hipStream_t of the ctx as an opaque pointer (event timing, stream ordering by callers). */
 void *sqlrs_ctx_stream(sqlrs_ctx_t *ctx);
+/* Stream-ordered hand-over of DEVICE buffers without blocking the host (`stream` = a hipStream_t):
+ * wait_stream: work queued on the ctx AFTER this call starts only when everything queued on
+ *   `producer_stream` BEFORE it has finished (inputs produced there are complete);
+ * release_to_stream: work queued on `consumer_stream` AFTER this call starts only when everything queued
+ *   on the ctx BEFORE it has finished (borrowed inputs may be reused, outputs may be read there). */
+int sqlrs_ctx_wait_stream(sqlrs_ctx_t *ctx, void *producer_stream);
+int sqlrs_ctx_release_to_stream(sqlrs_ctx_t *ctx, void *consumer_stream);
 /* Bytes currently held by the ctx memory pool (live + cached). */
 int64_t sqlrs_ctx_pool_bytes(const sqlrs_ctx_t *ctx);
 /* Frees cached (not live) pool blocks back to the driver. */

@@ -301,6 +301,8 @@ class Backend:
         optional = {
             "ctx_synchronize": (i, [vp]),
             "ctx_stream": (vp, [vp]),
+            "ctx_wait_stream": (i, [vp, vp]),
+            "ctx_release_to_stream": (i, [vp, vp]),
             "ctx_pool_bytes": (C.c_int64, [vp]),
             "ctx_pool_trim": (None, [vp]),
             "batch_copy": (i, [vp, pb, i, ppb]),

@@ -52,9 +52,14 @@ inline size_t width_of(int32_t dtype) {
 // ------------------------------------------------------------------ memory pool --
 // Stream-ordered caching allocator: every kernel of a ctx runs on ctx->stream, so a block
 // released while work is in flight may be handed to later work on the same stream.
+// The pool outlives its ctx while blocks of it are still referenced (batches released after
+// sqlrs_ctx_destroy): every Buf holds a reference, and a block returned to a closed pool is freed
+// instead of cached.
 struct Pool {
   std::multimap<size_t, void *> free_blocks;
   size_t live_bytes = 0, cached_bytes = 0;
+  bool closed = false; // the ctx is gone: no stream to order reuse on, blocks go straight back to the driver
+  int device = 0;
   void *alloc(size_t bytes, size_t *cap);
   void release(void *p, size_t cap);
   void trim();
@@ -62,12 +67,13 @@ struct Pool {
 
 struct Ctx;
 struct Buf {
-  Ctx *ctx;
+  Ctx *ctx; // only valid while the ctx lives: never dereferenced by the destructor
+  std::shared_ptr<Pool> pool;
   void *p;
   size_t cap;
   bool owned = true; // false: a view of memory this library does not own (never released)
   std::shared_ptr<Buf> parent; // a view into a larger block of this library: keeps that block alive
-  Buf(Ctx *c, void *ptr, size_t n) : ctx(c), p(ptr), cap(n) {}
+  Buf(Ctx *c, void *ptr, size_t n);
   ~Buf();
   Buf(const Buf &) = delete;
   Buf &operator=(const Buf &) = delete;
@@ -96,7 +102,8 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string last_error;
-  Pool pool;
+  std::shared_ptr<Pool> pool_ref = std::make_shared<Pool>();
+  Pool &pool = *pool_ref;
   int num_cus = 256;
   // profiling
   bool prof_on = false;
@@ -115,7 +122,9 @@ struct Ctx {
   size_t zero_used = 0;
   // kernels of this device that were granted > 64 KiB of dynamic LDS (hipFuncSetAttribute is per device)
   std::set<const void *> big_lds_set;
-  std::map<const void *, int> occ_cache; // resident blocks per CU of the persistent kernels, per kernel
+  std::map<const void *, int> occ_cache;
+  int64_t lb_timeouts = 0; // look-back launches that timed out and were redone with tickets
+  int lb_backoff = 0; // resident blocks per CU of the persistent kernels, per kernel
   void sync() { SQ_HIP(hipStreamSynchronize(stream)); }
   // copies `bytes` from device to the pinned area and synchronises; returns host pointer
   const void *fetch(const void *dptr, size_t bytes);
@@ -219,6 +228,25 @@ inline int first_lookback_mode() {
     return (e && e[0] == '1') ? 1 : 0;
   }();
   return forced;
+}
+
+// First launch mode of a look-back kernel on this ctx: 0 = fast (tile id = block index, needs every
+// block resident, bounded spin), 1 = ticketed.  After a spin timeout (another ctx / process / RCCL kernel
+// on the GPU broke residency) the ctx goes straight to tickets for the next LB_BACKOFF_CALLS calls
+// instead of sitting out the timeout again, and the event is counted (sqlrs_ctx_profile_read reports it
+// as "lookback_ticket_reruns").
+constexpr int LB_BACKOFF_CALLS = 64;
+inline int lookback_start_mode(Ctx *ctx) {
+  if (first_lookback_mode()) return 1;
+  if (ctx->lb_backoff > 0) {
+    ctx->lb_backoff--;
+    return 1;
+  }
+  return 0;
+}
+inline void lookback_timed_out(Ctx *ctx) {
+  ctx->lb_timeouts++;
+  ctx->lb_backoff = LB_BACKOFF_CALLS;
 }
 
 // Expression (postfix) owned copy

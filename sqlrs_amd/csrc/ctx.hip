@@ -45,6 +45,14 @@ void *Pool::alloc(size_t bytes, size_t *cap) {
 }
 void Pool::release(void *p, size_t cap) {
   live_bytes -= cap;
+  if (closed) { // the ctx (and its stream) is gone: nothing can be in flight on it any more
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    (void)hipFree(p);
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    return;
+  }
   cached_bytes += cap;
   free_blocks.emplace(cap, p);
 }
@@ -54,8 +62,9 @@ void Pool::trim() {
   cached_bytes = 0;
 }
 
+Buf::Buf(Ctx *c, void *ptr, size_t n) : ctx(c), pool(c->pool_ref), p(ptr), cap(n) {}
 Buf::~Buf() {
-  if (p && owned) ctx->pool.release(p, cap);
+  if (p && owned) pool->release(p, cap);
 }
 
 BufP Ctx::alloc(size_t bytes) {
@@ -166,8 +175,10 @@ DCol upload_column(Ctx *ctx, const sqlrs_column_t &c, bool force_copy) {
   bool copy = force_copy || c.mem == SQLRS_MEM_HOST;
   if (c.mem != SQLRS_MEM_HOST && c.mem != SQLRS_MEM_DEVICE) fail(SQLRS_ERR_ARROW, "bad column mem");
   size_t nbits = (size_t)ceil_div(c.length, 8);
+  // device bitmaps are read as whole u64 words: a misaligned one is copied into a padded buffer
+  const bool val_misaligned = c.validity && ((uintptr_t)c.validity & 7);
   if (c.validity && c.null_count != 0) {
-    if (copy) {
+    if (copy || val_misaligned) {
       d.own_validity = ctx->alloc_zero(bitmap_bytes(c.length));
       copy_in(ctx, d.own_validity->p, c.validity, nbits, c.mem);
       d.validity = d.own_validity->as<uint64_t>();
@@ -176,7 +187,7 @@ DCol upload_column(Ctx *ctx, const sqlrs_column_t &c, bool force_copy) {
   }
   switch (c.dtype) {
   case SQLRS_BOOLEAN:
-    if (copy) {
+    if (copy || ((uintptr_t)c.values & 7)) {
       d.own_values = ctx->alloc_zero(bitmap_bytes(c.length));
       copy_in(ctx, d.own_values->p, c.values, nbits, c.mem);
       d.values = d.own_values->p;
@@ -413,6 +424,7 @@ int sqlrs_ctx_create(int device_id, sqlrs_ctx_t **out) {
   if (hipSetDevice(device_id) != hipSuccess) return SQLRS_ERR_DEVICE;
   auto *c = new sqlrs_ctx();
   c->device = device_id;
+  c->pool.device = device_id;
   c->num_cus = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) {
@@ -435,6 +447,9 @@ void sqlrs_ctx_destroy(sqlrs_ctx_t *ctx) {
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   ctx->zero_block.reset();
   ctx->pool.trim();
+  // batches this ctx produced may be released later: their blocks hold the pool alive and are handed
+  // back to the driver directly from then on (operators must be destroyed BEFORE their ctx)
+  ctx->pool.closed = true;
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -446,6 +461,28 @@ int sqlrs_ctx_synchronize(sqlrs_ctx_t *ctx) {
   return guard(ctx, [&] { ctx->sync(); });
 }
 void *sqlrs_ctx_stream(sqlrs_ctx_t *ctx) { return (void *)ctx->stream; }
+
+// stream-ordered hand-over of DEVICE buffers between the caller's stream and the ctx stream
+static int order_streams(sqlrs_ctx_t *ctx, hipStream_t first, hipStream_t then) {
+  return guard(ctx, [&] {
+    SQ_HIP(hipSetDevice(ctx->device));
+    hipEvent_t e;
+    if (!ctx->event_pool.empty()) {
+      e = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+    } else
+      SQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t r1 = hipEventRecord(e, first), r2 = r1 == hipSuccess ? hipStreamWaitEvent(then, e, 0) : r1;
+    ctx->event_pool.push_back(e); // (a recorded event may be re-recorded once the wait is queued)
+    if (r2 != hipSuccess) fail(SQLRS_ERR_DEVICE, std::string("stream ordering: ") + hipGetErrorString(r2));
+  });
+}
+int sqlrs_ctx_wait_stream(sqlrs_ctx_t *ctx, void *producer_stream) {
+  return order_streams(ctx, (hipStream_t)producer_stream, ctx->stream);
+}
+int sqlrs_ctx_release_to_stream(sqlrs_ctx_t *ctx, void *consumer_stream) {
+  return order_streams(ctx, ctx->stream, (hipStream_t)consumer_stream);
+}
 int64_t sqlrs_ctx_pool_bytes(const sqlrs_ctx_t *ctx) {
   return (int64_t)(ctx->pool.live_bytes + ctx->pool.cached_bytes);
 }
@@ -536,6 +573,14 @@ int sqlrs_ctx_profile_read(sqlrs_ctx_t *ctx, int cap, const char **names, double
       names[n] = e.name;
       total_ms[n] = e.total_ms;
       launches[n] = e.launches;
+    }
+    n++;
+  }
+  if (ctx->lb_timeouts) { // look-back launches redone with tickets since the ctx was created (0 ms: a count)
+    if (n < cap) {
+      names[n] = "lookback_ticket_reruns";
+      total_ms[n] = 0;
+      launches[n] = ctx->lb_timeouts;
     }
     n++;
   }

@@ -119,7 +119,10 @@ constexpr int LB_TILES_PER_TICKET = 1;
 // tile's predecessors are running or done) with a BOUNDED spin: if a predecessor never shows
 // up the wave raises *timeout and gives up, and the host reruns the launch with atomic tickets,
 // which is safe under any dispatch order.
-constexpr unsigned LB_SPIN_LIMIT = 1u << 22;
+// (2^14 polls with s_sleep between them are a few milliseconds: long enough for any predecessor that is
+// merely slow, short enough that a launch whose blocks are not all resident — a second ctx, another
+// process or an RCCL kernel on the GPU — costs milliseconds, not the 1.4 s of the former 2^22)
+constexpr unsigned LB_SPIN_LIMIT = 1u << 14;
 constexpr uint64_t LB_AGG = 1ull << 62;
 constexpr uint64_t LB_PFX = 2ull << 62;
 constexpr uint64_t LB_VAL = (1ull << 62) - 1;

@@ -671,8 +671,8 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 16);
     unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
     uint64_t *tot = desc->as<uint64_t>() + tiles + 1;
-    for (int use_ticket = first_lookback_mode(); use_ticket < 2; use_ticket++) {
-      if (use_ticket && !first_lookback_mode()) SQ_HIP(hipMemsetAsync(desc->p, 0, 8 * (size_t)tiles + 16, ctx->stream));
+    for (int use_ticket = lookback_start_mode(ctx), attempt = 0; use_ticket < 2; use_ticket++, attempt++) {
+      if (attempt) SQ_HIP(hipMemsetAsync(desc->p, 0, 8 * (size_t)tiles + 16, ctx->stream)); // rerun after a timeout
       {
         ProfScope ps(ctx, j->dense ? "join_probe_dense" : "join_probe_unique");
         dim3 gt((unsigned)tiles);
@@ -694,6 +694,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
       const uint64_t *h = (const uint64_t *)ctx->fetch(ticket, 16); // {ticket|timeout, total}
       p.m = (int64_t)h[1];
       if (use_ticket || (h[0] >> 32) == 0) break;
+      lookback_timed_out(ctx);
     }
     return p;
   }

@@ -585,8 +585,8 @@ bool filter_fast_path(Ctx *ctx, const Expr &e, const std::function<const DCol &(
   // worst case every row is kept: output sized for `rows` (288 GB of HBM: no second pass)
   BufP out = ctx->alloc(w * (size_t)rows + 16);
   // desc layout: [tiles descriptors][ticket u32, timeout u32][total u64]
-  for (int use_ticket = first_lookback_mode(); use_ticket < 2; use_ticket++) {
-    if (use_ticket && !first_lookback_mode()) SQ_HIP(hipMemsetAsync(desc->p, 0, 8 * (size_t)tiles + 16, ctx->stream));
+  for (int use_ticket = lookback_start_mode(ctx), attempt = 0; use_ticket < 2; use_ticket++, attempt++) {
+    if (attempt) SQ_HIP(hipMemsetAsync(desc->p, 0, 8 * (size_t)tiles + 16, ctx->stream)); // rerun after a timeout
     {
       ProfScope ps(ctx, "filter_cmp_const");
       uint64_t *sb = sel->own_bits->as<uint64_t>(), *to = sel->tile_off->as<uint64_t>();
@@ -614,6 +614,7 @@ bool filter_fast_path(Ctx *ctx, const Expr &e, const std::function<const DCol &(
     const uint64_t *h = (const uint64_t *)ctx->fetch(ticket, 16); // {ticket|timeout, total}
     sel->count = (int64_t)h[1];
     if (use_ticket || (h[0] >> 32) == 0) break; // no look-back timeout: done
+    lookback_timed_out(ctx);
   }
   *col_index = a.index;
   out_col->dtype = c.dtype;
