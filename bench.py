@@ -273,6 +273,21 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    rank_info = None
+    if world > 1:
+        # self-check: the process group really spans `world` ranks on `world` distinct GPUs over RCCL
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)
+        props = torch.cuda.get_device_properties(dev)
+        ident = f"{os.uname().nodename}:{local_rank}:{getattr(props, 'uuid', '')}"
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        backend = dist.get_backend()
+        if int(one.item()) != world or (not single_dev and (backend != "nccl" or len(set(idents)) != world)):
+            raise SystemExit(f"bench: process group check failed: all_reduce(1) = {int(one.item())}, world {world}, "
+                             f"backend {backend}, devices {idents}")
+        rank_info = {"world": world, "backend": "nccl (RCCL)" if backend == "nccl" else backend,
+                     "distinct_devices": len(set(idents)), "all_reduce_of_ones": int(one.item())}
     be = sqlrs_amd.new_ctx(local_rank)  # raises if the HIP library / GPU is missing: no fallback
     n_fact_total, n_dim_total = int(args.rows), int(args.dim_rows)
     # contiguous slice of the global tables owned by this rank
@@ -297,33 +312,12 @@ def main():
 
     def D_shard(total, r, w):
         return total * (r + 1) // w - total * r // w
+    from sqlrs_amd import distributed as D
     from sqlrs_amd.expr import InputRef
-
-    def exchange(cols, dtypes):
-        """hash-partition on column 0 and all-to-all every column over RCCL; returns tensors"""
-        from sqlrs_amd import distributed as D
-        t_x = tick()
-        b = device_batch(abi, cols, dtypes)
-        parts, offs = be.hash_partition(b, InputRef(0), world, abi.MEM_DEVICE)
-        be.synchronize()
-        views = [_tensor_view(torch, parts.column(ci).values, parts.column(ci).length, t.dtype, dev)
-                 for ci, t in enumerate(cols)]
-        if single_dev:  # gloo moves host tensors
-            outs = [o.to(dev) for o in D.all_to_all_columns(dist, [v.cpu() for v in views], offs, world, torch)]
-        else:
-            outs = D.all_to_all_columns(dist, views, offs, world, torch)  # same code as the gloo CPU test
-        torch.cuda.synchronize()
-        parts.release()
-        if t_x is not None:
-            xstat["ms"] += (time.perf_counter() - t_x) * 1e3
-            sent = sum(int(v.numel()) * v.element_size() for v in views)
-            own = sum((offs[rank + 1] - offs[rank]) * v.element_size() for v in views)
-            xstat["bytes_off_rank"] += sent - own
-        return outs
 
     strategy = args.exchange
     if strategy == "auto":
-        strategy = "broadcast" if n_dim_total * 16 <= n_fact_total else "partition"
+        strategy = "partition"  # north_star: build AND probe side hash-partitioned on the join key, RCCL all-to-all
     pipe.partial = world > 1 and strategy == "broadcast"
     dim_sizes = [D_shard(n_dim_total, r, world) for r in range(world)]
     merge_gb, _mk = abi.pack_exprs([InputRef(0)])
@@ -331,72 +325,119 @@ def main():
     from sqlrs_amd.expr import AggFunc as _AggFunc
     merge_aggs = (abi.AggFunc * 2)(_AggFunc("sum", InputRef(1), abi.INT64).abi_struct(_mkeep),
                                    _AggFunc("sum", InputRef(2), abi.FLOAT64).abi_struct(_mkeep))
+    # split sizes of the all-to-alls travel over a CPU group: the host never waits for a payload collective
+    count_group = dist.new_group(backend="gloo") if world > 1 else None
+    data_group = count_group if single_dev else None  # None = the default (RCCL) group
+    wire_out = (lambda t: t.cpu()) if single_dev else None
+    wire_in = (lambda t: t.to(dev)) if single_dev else None
+    n_chunks = max(1, int(os.environ.get("SQLRS_BENCH_EXCHANGE_CHUNKS", "4")))
+    xstat = {"on": False, "exchange_ms": 0.0, "bytes_off_rank": 0, "steps": 0}
+    T_DT = {abi.INT64: torch.int64, abi.FLOAT64: torch.float64}
 
-    xstat = {"on": False, "ms": 0.0, "bytes_off_rank": 0}
+    def torch_stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def tick():
-        """start of an exchange phase while profiling (None otherwise: the timed region has no extra syncs)"""
-        if not xstat["on"]:
-            return None
-        torch.cuda.synchronize()
-        be.synchronize()
-        return time.perf_counter()
+    def exchange(chunks, dtypes, capacity):
+        """`chunks`: iterable of lists of device columns (column 0 = the join key).  Every chunk is
+        hash-partitioned on the key by the library; its all-to-all (one per column, asynchronous) runs
+        while the next chunk is produced and partitioned.  Returns the received columns (one tensor each)."""
+        ex = D.ChunkedExchange(dist, torch, world, [T_DT[d] for d in dtypes], dev, capacity, data_group=data_group,
+                               count_group=count_group, wire_out=wire_out, wire_in=wire_in)
+        keep = []
+        for cols in chunks:
+            b = device_batch(abi, cols, dtypes)
+            parts, offs = be.hash_partition(b, InputRef(0), world, abi.MEM_DEVICE)
+            # the collectives start behind torch's current stream: order it behind the partition kernels
+            be.check(be.fn("ctx_release_to_stream")(be.ctx, torch_stream()))
+            views = [_tensor_view(torch, parts.column(ci).values, parts.column(ci).length, T_DT[d], dev)
+                     for ci, d in enumerate(dtypes)]
+            ex.send_chunk(views, offs)
+            keep.append((parts, b, cols))
+        outs = ex.finish()  # torch's stream now waits for every collective ...
+        be.check(be.fn("ctx_wait_stream")(be.ctx, torch_stream()))  # ... and the ctx stream for torch's
+        for parts, _, _ in keep:
+            parts.release()  # (pool blocks go to LATER ctx-stream work, i.e. behind the collectives that read them)
+        xstat["bytes_off_rank"] += ex.bytes_off_rank
+        return outs
+
+    def filtered_chunks():
+        """Filter below the exchange (only kept fact rows cross xGMI), chunk by chunk"""
+        nloc = fact_key.numel()
+        for c in range(n_chunks):
+            lo, hi = nloc * c // n_chunks, nloc * (c + 1) // n_chunks
+            if hi == lo:
+                continue
+            kept = pipe.filter(device_batch(abi, [fact_key[lo:hi], fact_val[lo:hi]], [abi.INT64, abi.FLOAT64]))
+            kk = _tensor_view(torch, kept.column(0).values, kept.num_rows, torch.int64, dev)
+            kv = _tensor_view(torch, kept.column(1).values, kept.num_rows, torch.float64, dev)
+            yield [kk, kv]
+            kept.release()  # (its partitioned copy is complete: sqlrs_hash_partition returned the offsets)
 
     def gather_dim():
         """all-gather of the dim keys (every rank ends up with the whole build side)"""
         if single_dev:
             parts = [torch.empty(n, dtype=torch.int64) for n in dim_sizes]
-            dist.all_gather(parts, dim_key.cpu())
+            dist.all_gather(parts, dim_key.cpu(), group=count_group)
             return torch.cat(parts).to(dev)
-        t_x = tick()
         parts = [torch.empty(n, dtype=torch.int64, device=dev) for n in dim_sizes]
         dist.all_gather(parts, dim_key)
         out = torch.cat(parts)
-        if t_x is not None:
-            torch.cuda.synchronize()
-            xstat["ms"] += (time.perf_counter() - t_x) * 1e3
-            xstat["bytes_off_rank"] += 8 * (n_dim_total - dim_sizes[rank])
+        be.check(be.fn("ctx_wait_stream")(be.ctx, torch_stream()))
+        xstat["bytes_off_rank"] += 8 * (n_dim_total - dim_sizes[rank])
         return out
 
+    def step_partition():
+        # partitioned hash join (north_star): dim and kept fact rows are hash-partitioned on the join key and
+        # exchanged; every rank then owns a disjoint key range and its local join + group-by result is final
+        t0 = time.perf_counter()
+        dk, = exchange([[dim_key]], [abi.INT64], D_shard(n_dim_total, rank, world) * 2 + 1024)
+        fk, fv = exchange(filtered_chunks(), [abi.INT64, abi.FLOAT64], int(fact_key.numel() * 0.75) + 1024)
+        if xstat["on"]:
+            torch.cuda.synchronize()
+            be.synchronize()
+            xstat["exchange_ms"] += (time.perf_counter() - t0) * 1e3
+        out = pipe.join_agg(device_batch(abi, [dk], [abi.INT64]),
+                            device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64]))
+        be.synchronize()
+        return out
+
+    def step_broadcast():
+        # 1. replicate the small build side  2. local Filter -> HashJoinAgg = PARTIAL aggregates
+        t0 = time.perf_counter()
+        dk = gather_dim()
+        if xstat["on"]:
+            torch.cuda.synchronize()
+            xstat["exchange_ms"] += (time.perf_counter() - t0) * 1e3
+        part = pipe.step(device_batch(abi, [dk], [abi.INT64]),
+                         device_batch(abi, [fact_key, fact_val], [abi.INT64, abi.FLOAT64]))
+        be.synchronize()
+        g = part.num_rows
+        cols = [_tensor_view(torch, part.column(i).values, g, t, dev)
+                for i, t in enumerate((torch.int64, torch.int64, torch.float64))]
+        # 3. exchange the partial aggregates by key  4. merge: SUM(count), SUM(sum) per key
+        t0 = time.perf_counter()
+        rk, rc, rs = exchange([cols], [abi.INT64, abi.INT64, abi.FLOAT64], g + 1024)
+        if xstat["on"]:
+            torch.cuda.synchronize()
+            be.synchronize()
+            xstat["exchange_ms"] += (time.perf_counter() - t0) * 1e3
+        part.release()
+        a = C.c_void_p()
+        be.check(be.fn("hash_agg_create")(be.ctx, 1, merge_gb, 2, merge_aggs, C.byref(a)))
+        # a global first-seen order does not exist across ranks (SURVEY.md §8e): no ordering pass
+        be.check(be.fn("hash_agg_set_group_order")(a, abi.GROUP_ORDER_ANY))
+        mb = device_batch(abi, [rk, rc, rs], [abi.INT64, abi.INT64, abi.FLOAT64])
+        be.check(be.fn("hash_agg_push")(a, mb.ptr))
+        ao = C.POINTER(abi.Batch)()
+        be.check(be.fn("hash_agg_finish")(a, abi.MEM_DEVICE, C.byref(ao)))
+        be.fn("hash_agg_destroy")(a)
+        be.synchronize()
+        return be.wrap(ao)
+
     def one_step():
-        if world > 1 and strategy == "broadcast":
-            # 1. replicate the small build side  2. local Filter -> HashJoinAgg = PARTIAL aggregates
-            dk = gather_dim()
-            part = pipe.step(device_batch(abi, [dk], [abi.INT64]),
-                             device_batch(abi, [fact_key, fact_val], [abi.INT64, abi.FLOAT64]))
-            be.synchronize()
-            g = part.num_rows
-            cols = [_tensor_view(torch, part.column(i).values, g, t, dev)
-                    for i, t in enumerate((torch.int64, torch.int64, torch.float64))]
-            # 3. exchange the partial aggregates by key  4. merge: SUM(count), SUM(sum) per key
-            rk, rc, rs = exchange(cols, [abi.INT64, abi.INT64, abi.FLOAT64])
-            part.release()
-            a = C.c_void_p()
-            be.check(be.fn("hash_agg_create")(be.ctx, 1, merge_gb, 2, merge_aggs, C.byref(a)))
-            # a global first-seen order does not exist across ranks (SURVEY.md §8e): no ordering pass
-            be.check(be.fn("hash_agg_set_group_order")(a, abi.GROUP_ORDER_ANY))
-            mb = device_batch(abi, [rk, rc, rs], [abi.INT64, abi.INT64, abi.FLOAT64])
-            be.check(be.fn("hash_agg_push")(a, mb.ptr))
-            ao = C.POINTER(abi.Batch)()
-            be.check(be.fn("hash_agg_finish")(a, abi.MEM_DEVICE, C.byref(ao)))
-            be.fn("hash_agg_destroy")(a)
-            be.synchronize()
-            return be.wrap(ao)
         if world > 1:
-            # partitioned hash join: the filter runs below the exchange, so only the kept fact rows
-            # cross xGMI; dim and fact are hash-partitioned on the join key, every rank then owns a
-            # disjoint key range and its local result is final
-            kept = pipe.filter(device_batch(abi, [fact_key, fact_val], [abi.INT64, abi.FLOAT64]))
-            be.synchronize()
-            kk = _tensor_view(torch, kept.column(0).values, kept.num_rows, torch.int64, dev)
-            kv = _tensor_view(torch, kept.column(1).values, kept.num_rows, torch.float64, dev)
-            dk, = exchange([dim_key], [abi.INT64])
-            fk, fv = exchange([kk, kv], [abi.INT64, abi.FLOAT64])
-            kept.release()
-            out = pipe.join_agg(device_batch(abi, [dk], [abi.INT64]),
-                                device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64]))
-            be.synchronize()
-            return out
+            xstat["steps"] += 1
+            return step_broadcast() if strategy == "broadcast" else step_partition()
         out = pipe.step(device_batch(abi, [dim_key], [abi.INT64]),
                         device_batch(abi, [fact_key, fact_val], [abi.INT64, abi.FLOAT64]))
         be.synchronize()
@@ -439,7 +480,7 @@ def main():
 
     # ---- per-kernel device time (HIP events on the ctx stream), separate profiled steps
     be.profile(True)
-    xstat["on"] = world > 1
+    xstat.update(on=world > 1, exchange_ms=0.0, bytes_off_rank=0)
     torch.cuda.synchronize()
     t_prof = time.perf_counter()
     for _ in range(2):
@@ -452,13 +493,38 @@ def main():
     be.profile(False)
     exchange_info = None
     if world > 1:  # SURVEY.md §8e scaling report: exchange vs local time, bytes over xGMI, rate per link
-        x_ms, x_bytes = xstat["ms"] / 2, xstat["bytes_off_rank"] / 2
-        exchange_info = {"strategy": strategy, "step_ms_profiled": round(prof_step_ms, 3), "exchange_ms": round(x_ms, 3),
+        x_ms, x_bytes = xstat["exchange_ms"] / 2, xstat["bytes_off_rank"] / 2
+        exchange_info = {"strategy": strategy, "chunks": n_chunks if strategy == "partition" else 1,
+                         "step_ms_profiled": round(prof_step_ms, 3), "exchange_ms": round(x_ms, 3),
                          "local_ms": round(prof_step_ms - x_ms, 3), "bytes_off_rank_per_step": int(x_bytes),
                          "GBps_per_rank": round(x_bytes / max(x_ms, 1e-9) / 1e6, 1),
                          "GBps_per_link": round(x_bytes / max(x_ms, 1e-9) / 1e6 / (world - 1), 1),
-                         "note": "rank 0, profiled steps with a sync around every exchange phase (partition kernel + "
-                                 "collective); xGMI link peak 153 GB/s"}
+                         "ranks": rank_info,
+                         "note": "rank 0, two profiled steps with a sync behind the exchange phase (filter + partition "
+                                 "kernels + collectives, chunk k's all-to-all overlapping chunk k+1's kernels); split "
+                                 "sizes travel over a gloo side group; xGMI link peak 153 GB/s"}
+        # the other strategy, timed with the same wall clock over fewer steps (never the headline value)
+        alt = "broadcast" if strategy == "partition" else "partition"
+        try:
+            main_strategy, strategy = strategy, alt
+            pipe.partial = strategy == "broadcast"
+            o = one_step()
+            ok_alt, _, _, msg_alt = check_groups(torch, dist, dev, o, exp_cnt, exp_sum, has_dim)
+            o.release()
+            barrier()
+            t_alt = time.perf_counter()
+            for _ in range(max(2, args.steps // 4)):
+                one_step().release()
+            barrier()
+            el_alt = torch.tensor([time.perf_counter() - t_alt], dtype=torch.float64, device=dev)
+            dist.all_reduce(el_alt, op=dist.ReduceOp.MAX)
+            exchange_info["alternative"] = {"strategy": alt, "ms_per_step": round(el_alt.item() / max(2, args.steps // 4) * 1e3, 3),
+                                            "check": "OK" if ok_alt else msg_alt}
+        except Exception as e:  # the alternative is informational: it must never take the headline line down
+            exchange_info["alternative"] = {"strategy": alt, "error": repr(e)[:300]}
+        finally:
+            strategy = main_strategy
+            pipe.partial = strategy == "broadcast"
     workload = {"fact_rows": f_hi - f_lo, "dim_rows": d_hi - d_lo, "selectivity": expected_kept / max(f_hi - f_lo, 1),
                 "matches": expected_kept, "groups": out_groups_local}
     if world > 1:  # after the exchange every rank holds about 1/N of everything
@@ -526,7 +592,8 @@ def main():
                        "parallelism": ("single GPU" if world == 1 else
                                        f"x{world}: all-gather dim, local partial aggregation, all-to-all of partial aggregates, merge"
                                        if strategy == "broadcast" else
-                                       f"x{world}: hash-partition fact+dim on the join key, all-to-all, local join+aggregate")},
+                                       f"x{world}: partitioned hash join — Filter below the exchange, fact + dim hash-partitioned on "
+                                       f"the join key, RCCL all-to-all in {n_chunks} overlapped chunks, local HashJoinAgg")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if operators:

@@ -110,6 +110,7 @@ struct Ctx {
   std::vector<ProfEntry> prof;
   std::vector<ProfPending> prof_pending;
   std::vector<hipEvent_t> event_pool;
+  hipEvent_t order_event = nullptr; // sqlrs_ctx_wait_stream / release_to_stream
   // small pinned staging area for device->host scalars
   void *pinned = nullptr;
   size_t pinned_bytes = 0;

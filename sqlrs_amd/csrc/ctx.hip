@@ -445,6 +445,7 @@ void sqlrs_ctx_destroy(sqlrs_ctx_t *ctx) {
     (void)hipEventDestroy(p.b);
   }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
   ctx->zero_block.reset();
   ctx->pool.trim();
   // batches this ctx produced may be released later: their blocks hold the pool alive and are handed
@@ -466,15 +467,11 @@ void *sqlrs_ctx_stream(sqlrs_ctx_t *ctx) { return (void *)ctx->stream; }
 static int order_streams(sqlrs_ctx_t *ctx, hipStream_t first, hipStream_t then) {
   return guard(ctx, [&] {
     SQ_HIP(hipSetDevice(ctx->device));
-    hipEvent_t e;
-    if (!ctx->event_pool.empty()) {
-      e = ctx->event_pool.back();
-      ctx->event_pool.pop_back();
-    } else
-      SQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipError_t r1 = hipEventRecord(e, first), r2 = r1 == hipSuccess ? hipStreamWaitEvent(then, e, 0) : r1;
-    ctx->event_pool.push_back(e); // (a recorded event may be re-recorded once the wait is queued)
-    if (r2 != hipSuccess) fail(SQLRS_ERR_DEVICE, std::string("stream ordering: ") + hipGetErrorString(r2));
+    // one dedicated event (no timing; NOT from the profiling pool, whose events are read with
+    // hipEventElapsedTime); a recorded event may be re-recorded once the wait on it is queued
+    if (!ctx->order_event) SQ_HIP(hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
+    SQ_HIP(hipEventRecord(ctx->order_event, first));
+    SQ_HIP(hipStreamWaitEvent(then, ctx->order_event, 0));
   });
 }
 int sqlrs_ctx_wait_stream(sqlrs_ctx_t *ctx, void *producer_stream) {

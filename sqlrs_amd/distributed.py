@@ -69,6 +69,84 @@ def all_to_all_columns(dist, columns, offsets: Sequence[int], world: int, torch)
     return outs
 
 
+class ChunkedExchange:
+    """All-to-all of hash-partitioned column chunks with the exchange of chunk k overlapping the
+    partitioning of chunk k+1.
+
+    * the per-chunk split sizes travel over ``count_group`` (a CPU / gloo group): the host learns how
+      much it will receive without touching the device stream, so the payload collectives are never
+      waited for inside the loop;
+    * payload columns go through ``dist.all_to_all_single(..., async_op=True)`` on ``data_group``
+      (RCCL over xGMI on the GPU box) straight into slices of ONE receive buffer per column, so the
+      operators downstream see a single batch (no concatenation copy);
+    * ``finish()`` waits for the collectives and returns the received columns.
+
+    ``wire_out`` / ``wire_in`` adapt tensors for the data group (identity on RCCL; ``.cpu()`` / ``.to(dev)``
+    when a test drives GPU tensors through gloo)."""
+
+    def __init__(self, dist, torch, world: int, dtypes, device, capacity_rows: int, data_group=None, count_group=None,
+                 wire_out=None, wire_in=None):
+        self.dist, self.torch, self.world = dist, torch, world
+        self.data_group, self.count_group = data_group, count_group
+        self.wire_out = wire_out or (lambda t: t)
+        self.wire_in = wire_in or (lambda t: t)
+        self.device = device
+        self.dtypes = list(dtypes)
+        self.cap = max(int(capacity_rows), 1)
+        self.bufs = [torch.empty(self.cap, dtype=dt, device=device) for dt in self.dtypes]
+        self.filled = 0
+        self.pending = []   # (work, keepalive, staged) per payload collective
+        self.bytes_off_rank = 0
+        self.rank = dist.get_rank()
+
+    def _grow(self, need: int):
+        self._wait()  # the old buffers are targets of in-flight collectives
+        new_cap = max(need, self.cap * 2)
+        nb = [self.torch.empty(new_cap, dtype=dt, device=self.device) for dt in self.dtypes]
+        for o, n in zip(self.bufs, nb):
+            n[:self.filled].copy_(o[:self.filled])
+        self.bufs, self.cap = nb, new_cap
+
+    def _wait(self):
+        for work, keep, staged in self.pending:
+            work.wait()
+            if staged is not None:  # the data group moved host tensors: land them in the receive buffer
+                dst, src = staged
+                dst.copy_(self.wire_in(src))
+        self.pending = []
+
+    def send_chunk(self, columns, offsets):
+        """columns: tensors of one chunk in partition order, offsets: world + 1 row offsets (host ints)"""
+        torch, dist, W = self.torch, self.dist, self.world
+        sc = [int(offsets[p + 1] - offsets[p]) for p in range(W)]
+        send = torch.tensor(sc, dtype=torch.int64)
+        recv = torch.empty(W, dtype=torch.int64)
+        dist.all_to_all_single(recv, send, group=self.count_group)  # CPU group: no device synchronisation
+        rc = [int(x) for x in recv.tolist()]
+        total = sum(rc)
+        if self.filled + total > self.cap:
+            self._grow(self.filled + total)
+        for ci, col in enumerate(columns):
+            dst = self.bufs[ci][self.filled:self.filled + total]
+            src = self.wire_out(col.contiguous())
+            if src.device == dst.device:
+                work = dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=self.data_group,
+                                              async_op=True)
+                self.pending.append((work, (src, col), None))
+            else:
+                tmp = torch.empty(total, dtype=src.dtype, device=src.device)
+                work = dist.all_to_all_single(tmp, src, output_split_sizes=rc, input_split_sizes=sc, group=self.data_group,
+                                              async_op=True)
+                self.pending.append((work, (src, col), (dst, tmp)))
+            self.bytes_off_rank += (sum(sc) - sc[self.rank]) * col.element_size()
+        self.filled += total
+
+    def finish(self):
+        """-> received columns (views of the receive buffers), valid on the current stream"""
+        self._wait()
+        return [b[:self.filled] for b in self.bufs]
+
+
 def shard_bounds(total: int, rank: int, world: int):
     """contiguous slice [lo, hi) of a table owned by ``rank`` before the exchange"""
     return total * rank // world, total * (rank + 1) // world

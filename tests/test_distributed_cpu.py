@@ -75,10 +75,22 @@ def worker(rank, world, port, result_path, strategy="partition"):
     f_lo, f_hi = D.shard_bounds(N_FACT, rank, world)
     d_lo, d_hi = D.shard_bounds(N_DIM, rank, world)
 
-    def exchange(cols):
-        parts, offs = D.partition_numpy(cols, world)
-        outs = D.all_to_all_columns(dist, [torch.from_numpy(np.ascontiguousarray(c)) for c in parts], offs, world, torch)
-        return [o.numpy() for o in outs]
+    def exchange(cols, chunks=1):
+        """the bench's exchange: ChunkedExchange (split sizes over a side group, asynchronous payload
+        collectives into one receive buffer), the local rows cut into `chunks` chunks"""
+        n = len(cols[0])
+        dts = [torch.from_numpy(c[:0].copy()).dtype for c in cols]
+        ex = D.ChunkedExchange(dist, torch, world, dts, torch.device("cpu"), max(n // 3, 1), count_group=count_group)
+        for c in range(chunks):
+            lo, hi = n * c // chunks, n * (c + 1) // chunks
+            parts, offs = D.partition_numpy([x[lo:hi] for x in cols], world)
+            ex.send_chunk([torch.from_numpy(np.ascontiguousarray(p)) for p in parts], offs)
+        outs = [o.numpy().copy() for o in ex.finish()]
+        sent_off_rank.append(ex.bytes_off_rank)
+        return outs
+
+    count_group = dist.new_group(backend="gloo")
+    sent_off_rank = []
 
     if strategy == "broadcast":
         # all-gather the dim, aggregate the local fact slice, exchange + merge partial aggregates
@@ -95,7 +107,8 @@ def worker(rank, world, port, result_path, strategy="partition"):
         dk = dim_key[d_lo:d_hi]
     else:
         (dk,) = exchange([dim_key[d_lo:d_hi]])
-        fk, fv = exchange([fact_key[f_lo:f_hi], fact_val[f_lo:f_hi]])
+        fk, fv = exchange([fact_key[f_lo:f_hi], fact_val[f_lo:f_hi]], chunks=3)  # receive buffer grows on the way
+        assert sent_off_rank[-1] > 0
         # every key this rank received belongs to this rank's partition
         assert (D.partition_of(dk, world) == rank).all() and (D.partition_of(fk, world) == rank).all()
         keys, cnt, sm = local_pipeline(oracle, dk, fk, fv)
