@@ -7,7 +7,7 @@
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-operators"
 rm -rf /tmp/prof_kt /tmp/prof_fetch /tmp/prof_write
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $CMD > gpurun_out/${TAG}_kt.log 2>&1 < /dev/null
 f=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)
@@ -29,10 +29,10 @@ def per_kernel(d, counter):
     return acc
 fe, wr = per_kernel("/tmp/prof_fetch", "FETCH_SIZE"), per_kernel("/tmp/prof_write", "WRITE_SIZE")
 out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 3 "
-               "--warmup 2 --no-cpu-baseline` (C5, 1e9 x 1e7); counter values are KiB; per-launch means over launches "
+               "--warmup 2 --no-cpu-baseline --no-operators` (C5, 1e9 x 1e7); counter values are KiB; per-launch means over launches "
                "with > 1e5 units; HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts "
                "half of a coalesced streaming read; calibration: filter_cmp_const reads 8.0e9 B)", "kernels": {}}
-short = {"rp_scatter": "sq::rp_scatter_kernel", "lds_agg": "sq::lds_agg", "filter_cmp_const": "sq::filter_cmp_const",
+short = {"rp_chunk_scatter_filter": "sq::rp_chunk_scatter_kernel", "rp_scatter": "sq::rp_scatter_kernel", "lds_agg": "sq::lds_agg", "filter_cmp_const": "sq::filter_cmp_const",
          "compact": "sq::compact_kernel", "rp_hist": "sq::rp_hist_kernel"}
 for k, pref in short.items():
     # both passes run the same command, so launch i of a kernel is the same launch in both; the
