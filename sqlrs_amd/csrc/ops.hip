@@ -1,5 +1,7 @@
 // ops.hip — C entry points of FilterExecutor, eval_column, HashAggExecutor and OrderExecutor
 // (the join lives in join.hip).  Each entry point cites the reference lines it replaces.
+#include <cstdlib>
+
 #include "agg_state.hpp"
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -248,6 +250,32 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
       return all.cols[(size_t)i];
     };
     int64_t n1 = std::max<int64_t>(n, 1);
+    // ---- fast route: one plain key column without NULLs (order_fast.hip)
+    static const bool fast_on = [] { const char *e = std::getenv("SQLRS_ORDER_FAST"); return !(e && e[0] == '0'); }(); // test hook
+    if (fast_on && o->exprs.size() == 1 && o->exprs[0].nodes.size() == 1 && o->exprs[0].nodes[0].op == SQLRS_EXPR_INPUT_REF) {
+      const int kc = o->exprs[0].nodes[0].index;
+      if (kc >= 0 && (size_t)kc < all.cols.size()) {
+        int cc = -1; // one other 8-byte column without NULLs travels with the rows; the rest is gathered
+        for (size_t ci = 0; ci < all.cols.size() && cc < 0; ci++) {
+          const DCol &c = all.cols[ci];
+          if ((int)ci != kc && width_of(c.dtype) == 8 && c.stride != 0 && !(c.validity && c.null_count != 0)) cc = (int)ci;
+        }
+        const bool want_perm = all.cols.size() > (size_t)(cc >= 0 ? 2 : 1);
+        DCol ko, co;
+        BufP fperm;
+        if (order_fast(ctx, all.cols[(size_t)kc], o->asc[0] ? 0 : 1, cc >= 0 ? &all.cols[(size_t)cc] : nullptr, n, &ko, &co, &fperm, want_perm)) {
+          DBatch r;
+          r.rows = n;
+          for (size_t ci = 0; ci < all.cols.size(); ci++) {
+            if ((int)ci == kc) r.cols.push_back(ko);
+            else if ((int)ci == cc) r.cols.push_back(co);
+            else r.cols.push_back(gather_column(ctx, all.cols[ci], fperm->p, false, nullptr, n));
+          }
+          *out = emit_batch(ctx, std::move(r), out_mem);
+          return;
+        }
+      }
+    }
     BufP perm = ctx->alloc(4 * (size_t)n1), keys = ctx->alloc(8 * (size_t)n1);
     iota_u32(ctx, perm->as<uint32_t>(), n);
     dim3 g((unsigned)ceil_div(n1, 256)), b(256);

@@ -1,0 +1,480 @@
+// order_fast.hip — ORDER BY on ONE fixed-width key without NULLs, carrying one 8-byte column
+// (order.rs:15-67 for the common `ORDER BY k` shape; everything else takes the general path of ops.hip).
+//
+// The general path is an LSD radix sort of (u64 key, u32 row id) pairs, 8 bits per pass over HBM, followed
+// by one gather per column — and a random gather of 8-byte elements fetches a 128-byte line per element
+// (12.8 GB for 1e8 rows).  Here the rows themselves travel, and only the TOP bits are sorted through HBM:
+//
+//   0. min / max of the keys' order-preserving image  -> off = image - min < 2^kbits (kbits <= 32)
+//   1. <= 2 stable 8-bit multi-split passes over HBM on the TOP (kbits - rbits <= 16) bits of `off`; a row is
+//      the word  off << 32 | row id  plus its carried column (16 B per row and pass; the first pass reads
+//      the raw column and builds the word in registers)                                     [LSD order]
+//      => rows are grouped by their top bits, in input order inside a group
+//   2. group boundaries (suffix minimum over a 2^16 + 1 entry table)
+//   3. one workgroup per group: the group (<= FIN_CAP rows) is sorted on the remaining rbits INSIDE LDS
+//      (<= 2 stable 8-bit passes, same ballot ranking as the HBM passes), then key column, carried column
+//      and row id (the permutation for any further column) leave in final order.
+//
+// HBM traffic for 1e8 rows, 31 key bits, one carried column: 0.8 (min/max) + 2 x (0.8 + 3.2) + 0.8
+// (boundaries) + 3.6 = 13.2 GB, against 9.6 GB of sort passes + 12.8 GB of gather fetches before.
+// Stability (ties in input order, like the general path) holds because every pass is stable.
+// A group larger than FIN_CAP (heavily repeated keys with many low bits) sends the call back to the
+// general path; rbits = 0 (all key bits sorted in HBM) has no such limit.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "prims.hpp"
+
+namespace sq {
+
+enum { OKIND_I64 = 0, OKIND_F64 = 1, OKIND_I32 = 2 };
+
+template <int KIND> __device__ __forceinline__ uint64_t order_image(const void *__restrict__ vals, int64_t i, int desc) {
+  uint64_t u;
+  if (KIND == OKIND_I64) u = i64_to_ordered(((const int64_t *)vals)[i]);
+  else if (KIND == OKIND_F64) u = f64_to_ordered(((const double *)vals)[i]);
+  else u = i64_to_ordered((int64_t)((const int32_t *)vals)[i]);
+  return desc ? ~u : u;
+}
+template <int KIND> __device__ __forceinline__ uint64_t order_unimage(uint64_t u, int desc) { // bits of the original value
+  if (desc) u = ~u;
+  if (KIND == OKIND_F64) return (uint64_t)__double_as_longlong(ordered_to_f64(u));
+  return (uint64_t)ordered_to_i64(u);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void order_minmax_kernel(const void *__restrict__ vals, int64_t n, int desc,
+                                                           unsigned long long *mm) {
+  uint64_t lo = ~0ull, hi = 0;
+  constexpr int KU = 8;
+  for (int64_t base = blockIdx.x * (int64_t)(256 * KU) + threadIdx.x; base < n; base += (int64_t)gridDim.x * (256 * KU)) {
+    uint64_t k[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) k[u] = order_image<KIND>(vals, min(base + u * 256, n - 1), desc);
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      lo = min(lo, k[u]);
+      hi = max(hi, k[u]);
+    }
+  }
+  lo = wave_min_u64(lo);
+  hi = wave_max_u64(hi);
+  __shared__ unsigned long long s_lo[4], s_hi[4];
+  if (lane_id() == 0) {
+    s_lo[wave_id()] = lo;
+    s_hi[wave_id()] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) {
+      lo = min(lo, (uint64_t)s_lo[w]);
+      hi = max(hi, (uint64_t)s_hi[w]);
+    }
+    atomicMin(mm, (unsigned long long)lo);
+    atomicMax(mm + 1, (unsigned long long)hi);
+  }
+}
+
+// ---- stable 8-bit multi-split over HBM, rows = (word, carried column) -------------------------------
+constexpr int OW_WG = 512, OW_WAVES = OW_WG / 64, OW_ITEMS = 8, OW_TILE = OW_WG * OW_ITEMS;
+
+// RAW: the pass reads the raw key column (row id = position) and builds  off << 32 | row  in registers
+template <int KIND, bool RAW>
+__device__ __forceinline__ uint64_t ow_word(const void *__restrict__ src, int64_t i, int desc, uint64_t imin) {
+  if (RAW) return ((order_image<KIND>(src, i, desc) - imin) << 32) | (uint64_t)(uint32_t)i;
+  return __builtin_nontemporal_load((const uint64_t *)src + i);
+}
+
+template <int KIND, bool RAW>
+__global__ __launch_bounds__(OW_WG) void ow_hist_kernel(const void *__restrict__ src, int64_t n, int desc, uint64_t imin,
+                                                        int shift, int64_t nblocks, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t h[256];
+  if (threadIdx.x < 256) h[threadIdx.x] = 0;
+  const int64_t base = (int64_t)blockIdx.x * OW_TILE + threadIdx.x;
+  uint64_t k[OW_ITEMS];
+#pragma unroll
+  for (int r = 0; r < OW_ITEMS; r++) k[r] = ow_word<KIND, RAW>(src, min(base + r * OW_WG, n - 1), desc, imin);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < OW_ITEMS; r++)
+    if (base + r * OW_WG < n) atomicAdd(&h[(k[r] >> shift) & 255], 1u);
+  __syncthreads();
+  if (threadIdx.x < 256) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// rank of every row among the rows of the same digit in its wave, in row order (wave w owns ITEMS chunks of
+// 64 consecutive rows): lanes with the same digit find each other with 8 ballots, the first of them bumps the
+// wave's own counter of that digit (one writer per digit and chunk, chunks in order: no atomics)
+template <int ITEMS>
+__device__ __forceinline__ void stable_wave_ranks(const uint32_t (&dig)[ITEMS], const bool (&valid)[ITEMS],
+                                                  uint32_t *__restrict__ wcnt_w /* [256] of this wave */,
+                                                  uint32_t (&rnk)[ITEMS]) {
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    uint64_t peers = __ballot(valid[j]);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (dig[j] >> b) & 1;
+      const uint64_t bm = __ballot(bit);
+      peers &= bit ? bm : ~bm;
+    }
+    const uint32_t r = (uint32_t)mbcnt(peers);
+    uint32_t old = 0;
+    if (valid[j] && r == 0) {
+      old = wcnt_w[dig[j]];
+      wcnt_w[dig[j]] = old + (uint32_t)__popcll(peers);
+    }
+    old = (uint32_t)__shfl((int)old, valid[j] ? __builtin_ctzll(peers) : 0, 64);
+    rnk[j] = old + r;
+  }
+}
+
+template <int KIND, bool RAW, int NPAY>
+__global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay,
+                                                           int64_t n, int desc, uint64_t imin, int shift, int64_t nblocks,
+                                                           const uint32_t *__restrict__ offsets,
+                                                           uint64_t *__restrict__ words_out, uint64_t *__restrict__ pay_out) {
+  __shared__ uint64_t sword[OW_TILE];
+  __shared__ uint64_t spay[NPAY ? OW_TILE : 1];
+  __shared__ uint32_t wcnt[OW_WAVES][256];
+  __shared__ uint32_t dstart[256];
+  __shared__ int64_t gbase[256];
+  __shared__ uint32_t s_wsum[4];
+  const int w = wave_id(), lane = lane_id();
+  const int64_t tbase = (int64_t)blockIdx.x * OW_TILE;
+  const int64_t wrow = tbase + (int64_t)w * (OW_ITEMS * 64) + lane;
+  uint64_t k[OW_ITEMS], v[NPAY ? OW_ITEMS : 1];
+#pragma unroll
+  for (int j = 0; j < OW_ITEMS; j++) {
+    const int64_t i = min(wrow + j * 64, n - 1);
+    k[j] = ow_word<KIND, RAW>(src, i, desc, imin);
+    if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
+  }
+  const uint32_t goff = threadIdx.x < 256 ? offsets[(int64_t)threadIdx.x * nblocks + blockIdx.x] : 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) wcnt[w][lane + 64 * q] = 0;
+  uint32_t dig[OW_ITEMS], rnk[OW_ITEMS];
+  bool valid[OW_ITEMS];
+#pragma unroll
+  for (int j = 0; j < OW_ITEMS; j++) {
+    valid[j] = wrow + j * 64 < n;
+    dig[j] = (uint32_t)(k[j] >> shift) & 255u;
+  }
+  stable_wave_ranks<OW_ITEMS>(dig, valid, wcnt[w], rnk);
+  __syncthreads();
+  if (threadIdx.x < 256) { // wave counters -> exclusive prefix over the waves; scan over the digits
+    uint32_t acc = 0;
+#pragma unroll
+    for (int q = 0; q < OW_WAVES; q++) {
+      uint32_t c = wcnt[q][threadIdx.x];
+      wcnt[q][threadIdx.x] = acc;
+      acc += c;
+    }
+    uint32_t inc = wave_iscan_u32(acc);
+    if (lane == 63) s_wsum[w] = inc;
+    dstart[threadIdx.x] = inc - acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    uint32_t wb = 0;
+    for (int q = 0; q < w; q++) wb += s_wsum[q];
+    const uint32_t ds = dstart[threadIdx.x] + wb;
+    dstart[threadIdx.x] = ds;
+    gbase[threadIdx.x] = (int64_t)goff - (int64_t)ds;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < OW_ITEMS; j++) {
+    if (!valid[j]) continue;
+    const uint32_t p = dstart[dig[j]] + wcnt[w][dig[j]] + rnk[j];
+    sword[p] = k[j];
+    if (NPAY) spay[p] = v[j];
+  }
+  __syncthreads();
+  const uint32_t len = (uint32_t)min<int64_t>(OW_TILE, n - tbase);
+#pragma unroll
+  for (int j = 0; j < OW_ITEMS; j++) {
+    const uint32_t p = j * OW_WG + threadIdx.x;
+    if (p < len) {
+      const uint64_t kk = sword[p];
+      const int64_t g = gbase[(uint32_t)(kk >> shift) & 255u] + p;
+      words_out[g] = kk;
+      if (NPAY) pay_out[g] = spay[p];
+    }
+  }
+}
+
+// ---- group boundaries ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ow_group_first_kernel(const uint64_t *__restrict__ words, int64_t n, int gshift,
+                                                             uint32_t *__restrict__ gstart) {
+  constexpr int KU = 8; // independent loads in flight per lane
+  for (int64_t base = blockIdx.x * (int64_t)(256 * KU) + threadIdx.x; base < n; base += (int64_t)gridDim.x * (256 * KU)) {
+    uint64_t cur[KU], prev[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      const int64_t i = min(base + u * 256, n - 1);
+      cur[u] = __builtin_nontemporal_load(words + i);
+      prev[u] = words[max<int64_t>(i - 1, 0)]; // (the neighbouring lane's element: served by the same lines)
+    }
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      const int64_t i = base + u * 256;
+      const uint32_t g = (uint32_t)(cur[u] >> gshift);
+      if (i < n && (i == 0 || (uint32_t)(prev[u] >> gshift) != g)) gstart[g] = (uint32_t)i;
+    }
+  }
+}
+// gstart[g] = first row of the first non-empty group >= g (suffix minimum; gstart[G] = n); also the
+// largest group.  One workgroup of 1024 threads, G <= 65536.
+__global__ __launch_bounds__(1024) void ow_group_fill_kernel(uint32_t *__restrict__ gstart, uint32_t G, uint32_t n,
+                                                             uint32_t *__restrict__ max_group) {
+  __shared__ uint32_t s_min[1024];
+  const uint32_t per = (G + 1023) / 1024, lo = threadIdx.x * per, hi = min(G, lo + per);
+  uint32_t m = 0xffffffffu;
+  for (uint32_t g = lo; g < hi; g++) m = min(m, gstart[g]);
+  s_min[threadIdx.x] = m;
+  __syncthreads();
+  uint32_t run = n; // minimum over everything behind this thread's slice
+  for (uint32_t t = threadIdx.x + 1; t < 1024; t++) run = min(run, s_min[t]);
+  uint32_t mx = 0;
+  for (uint32_t g = hi; g-- > lo;) { // backwards: suffix minimum inside the slice
+    const uint32_t next = run;
+    run = min(run, gstart[g]);
+    gstart[g] = run;
+    mx = max(mx, next - run);
+  }
+  if (threadIdx.x == 0) gstart[G] = n;
+  for (int k = 32; k >= 1; k >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, k, 64));
+  if (lane_id() == 0 && mx) atomicMax(max_group, mx);
+}
+
+// ---- finish: sort every group on its low bits inside LDS, write the final columns ----------------------
+constexpr int FIN_WG = 256, FIN_WAVES = FIN_WG / 64;
+template <int KIND, int NPAY, int R>
+__global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pay,
+                                                           const uint32_t *__restrict__ gstart, int rbits, int desc,
+                                                           uint64_t imin, void *__restrict__ key_out,
+                                                           uint64_t *__restrict__ pay_out, uint32_t *__restrict__ perm_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lo = gstart[blockIdx.x], hi = gstart[blockIdx.x + 1];
+  if (lo >= hi) return;
+  const uint32_t m = hi - lo;
+  uint64_t *sword = (uint64_t *)smem;                       // [R * FIN_WG]
+  uint64_t *spay = sword + (size_t)R * FIN_WG;              // [NPAY ? R * FIN_WG : 0]
+  uint32_t *wcnt = (uint32_t *)(spay + (NPAY ? (size_t)R * FIN_WG : 0)); // [FIN_WAVES][256]
+  uint32_t *dstart = wcnt + FIN_WAVES * 256;                // [256]
+  __shared__ uint32_t s_wsum[FIN_WAVES];
+  const int w = wave_id(), lane = lane_id();
+  // element e = (w * R + j) * 64 + lane: wave w owns R chunks of 64 consecutive rows
+  uint64_t k[R], v[NPAY ? R : 1];
+  bool valid[R];
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    const uint32_t e = (uint32_t)(w * R + j) * 64 + lane;
+    valid[j] = e < m;
+    const uint32_t i = lo + min(e, m - 1);
+    k[j] = __builtin_nontemporal_load(words + i);
+    if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
+  }
+  for (int shift = 32; shift < 32 + rbits; shift += 8) { // stable LSD passes over the low key bits, all in LDS
+    for (int q = lane; q < 256; q += 64) wcnt[w * 256 + q] = 0;
+    uint32_t dig[R], rnk[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      // the last pass may cover fewer than 8 bits: bits >= 32 + rbits are equal inside the group
+      dig[j] = (uint32_t)(k[j] >> shift) & 255u & ((shift + 8 > 32 + rbits) ? ((1u << (32 + rbits - shift)) - 1) : 255u);
+    }
+    stable_wave_ranks<R>(dig, valid, wcnt + w * 256, rnk);
+    __syncthreads();
+    { // FIN_WG == 256: one thread per digit
+      uint32_t acc = 0;
+#pragma unroll
+      for (int q = 0; q < FIN_WAVES; q++) {
+        const uint32_t c = wcnt[q * 256 + threadIdx.x];
+        wcnt[q * 256 + threadIdx.x] = acc;
+        acc += c;
+      }
+      const uint32_t inc = wave_iscan_u32(acc);
+      if (lane == 63) s_wsum[w] = inc;
+      dstart[threadIdx.x] = inc - acc;
+    }
+    __syncthreads();
+    {
+      uint32_t wb = 0;
+      for (int q = 0; q < w; q++) wb += s_wsum[q];
+      dstart[threadIdx.x] += wb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      if (!valid[j]) continue;
+      const uint32_t p = dstart[dig[j]] + wcnt[w * 256 + dig[j]] + rnk[j];
+      sword[p] = k[j];
+      if (NPAY) spay[p] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const uint32_t e = min((uint32_t)(w * R + j) * 64 + lane, m - 1);
+      k[j] = sword[e];
+      if (NPAY) v[j] = spay[e];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    if (!valid[j]) continue;
+    const uint32_t i = lo + (uint32_t)(w * R + j) * 64 + lane;
+    const uint64_t val = order_unimage<KIND>((k[j] >> 32) + imin, desc);
+    if (KIND == OKIND_I32) ((int32_t *)key_out)[i] = (int32_t)(int64_t)val;
+    else ((uint64_t *)key_out)[i] = val;
+    if (NPAY) pay_out[i] = v[j];
+    if (perm_out) perm_out[i] = (uint32_t)k[j];
+  }
+}
+
+// rbits == 0: everything was sorted in HBM, the finish is a streaming unpack
+template <int KIND, int NPAY>
+__global__ void ow_unpack_kernel(const uint64_t *__restrict__ words, int64_t n, int desc, uint64_t imin,
+                                 void *__restrict__ key_out, uint32_t *__restrict__ perm_out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t kw = words[i];
+  const uint64_t val = order_unimage<KIND>((kw >> 32) + imin, desc);
+  if (KIND == OKIND_I32) ((int32_t *)key_out)[i] = (int32_t)(int64_t)val;
+  else ((uint64_t *)key_out)[i] = val;
+  if (perm_out) perm_out[i] = (uint32_t)kw;
+}
+
+constexpr uint32_t FIN_CAP = 6144; // rows of the largest group the in-LDS finish takes (R = 24)
+
+template <int KIND, int NPAY>
+static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, DCol *key_out, DCol *carry_out,
+                            BufP *perm_out, bool want_perm) {
+  // 0. key range
+  BufP mm = ctx->alloc(16);
+  SQ_HIP(hipMemsetAsync(mm->p, 0xff, 8, ctx->stream));
+  SQ_HIP(hipMemsetAsync(mm->as<uint8_t>() + 8, 0, 8, ctx->stream));
+  {
+    ProfScope ps(ctx, "order_minmax");
+    unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 8 * (int64_t)ctx->num_cus);
+    order_minmax_kernel<KIND><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(key.values, n, desc, mm->as<unsigned long long>());
+    SQ_HIP(hipGetLastError());
+  }
+  const uint64_t *h = (const uint64_t *)ctx->fetch(mm->p, 16);
+  const uint64_t imin = h[0], range = h[1] - h[0];
+  if (range > 0xffffffffull) return false; // more than 32 varying key bits: general path
+  int kbits = 1;
+  while (kbits < 32 && (1ull << kbits) <= range) kbits++;
+  const int rbits = std::max(0, kbits - 16), top = kbits - rbits; // top <= 16 bits through HBM
+  // 1. stable multi-split passes on bits [32 + rbits, 32 + kbits) of the word, LSD order
+  const int64_t nblocks = ceil_div(n, OW_TILE);
+  BufP wa = ctx->alloc(8 * (size_t)n), wb = ctx->alloc(8 * (size_t)n);
+  BufP pa = NPAY ? ctx->alloc(8 * (size_t)n) : nullptr, pb = NPAY ? ctx->alloc(8 * (size_t)n) : nullptr;
+  BufP hist = ctx->alloc(4 * (size_t)(256 * nblocks)), offs = ctx->alloc(4 * (size_t)(256 * nblocks)), total = ctx->alloc(8);
+  const void *src = key.values;
+  const uint64_t *psrc = NPAY ? carry->v<uint64_t>() : nullptr;
+  uint64_t *wdst = wa->as<uint64_t>(), *walt = wb->as<uint64_t>();
+  uint64_t *pdst = NPAY ? pa->as<uint64_t>() : nullptr, *palt = NPAY ? pb->as<uint64_t>() : nullptr;
+  bool raw = true;
+  dim3 g((unsigned)nblocks), b(OW_WG);
+  auto one_pass = [&](int shift) {
+    ProfScope ps(ctx, "order_split");
+    if (raw) ow_hist_kernel<KIND, true><<<g, b, 0, ctx->stream>>>(src, n, desc, imin, shift, nblocks, hist->as<uint32_t>());
+    else ow_hist_kernel<KIND, false><<<g, b, 0, ctx->stream>>>(src, n, desc, imin, shift, nblocks, hist->as<uint32_t>());
+    SQ_HIP(hipGetLastError());
+    exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(), total->as<uint64_t>());
+    if (raw) ow_scatter_kernel<KIND, true, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst);
+    else ow_scatter_kernel<KIND, false, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst);
+    SQ_HIP(hipGetLastError());
+    src = wdst;
+    psrc = pdst;
+    std::swap(wdst, walt);
+    std::swap(pdst, palt);
+    raw = false;
+  };
+  for (int shift = 32 + rbits; shift < 32 + kbits || raw; shift += 8) one_pass(shift); // (>= 1 pass: the words must exist)
+  const uint64_t *words = (const uint64_t *)src;
+  const uint64_t *pays = psrc;
+  // outputs
+  key_out->dtype = key.dtype;
+  key_out->length = n;
+  key_out->null_count = 0;
+  key_out->own_values = ctx->alloc((KIND == OKIND_I32 ? 4 : 8) * (size_t)n + 16);
+  key_out->values = key_out->own_values->p;
+  if (want_perm) *perm_out = ctx->alloc(4 * (size_t)n);
+  uint32_t *perm = want_perm ? (*perm_out)->as<uint32_t>() : nullptr;
+  if (rbits == 0) {
+    ProfScope ps(ctx, "order_finish");
+    ow_unpack_kernel<KIND, NPAY><<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(words, n, desc, imin,
+                                                                                               key_out->own_values->p, perm);
+    SQ_HIP(hipGetLastError());
+    if (NPAY) { // the carried column is already in final order: adopt the buffer it sits in
+      carry_out->dtype = carry->dtype;
+      carry_out->length = n;
+      carry_out->null_count = 0;
+      carry_out->own_values = (pays == pa->as<uint64_t>()) ? pa : pb;
+      carry_out->values = carry_out->own_values->p;
+    }
+    return true;
+  }
+  // 2. groups = distinct values of the top bits
+  const uint32_t G = 1u << top;
+  BufP gstart = ctx->alloc(4 * ((size_t)G + 2));
+  SQ_HIP(hipMemsetAsync(gstart->p, 0xff, 4 * ((size_t)G + 1), ctx->stream));
+  SQ_HIP(hipMemsetAsync(gstart->as<uint32_t>() + G + 1, 0, 4, ctx->stream)); // [G + 1] = largest group
+  {
+    ProfScope ps(ctx, "order_groups");
+    ow_group_first_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 16 * (int64_t)ctx->num_cus)), dim3(256), 0, ctx->stream>>>(
+        words, n, 32 + rbits, gstart->as<uint32_t>());
+    ow_group_fill_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(gstart->as<uint32_t>(), G, (uint32_t)n, gstart->as<uint32_t>() + G + 1);
+    SQ_HIP(hipGetLastError());
+  }
+  const uint32_t max_group = ctx->fetch_value(gstart->as<uint32_t>() + G + 1);
+  if (max_group > FIN_CAP) return false; // heavily repeated top bits: general path
+  if (NPAY) {
+    carry_out->dtype = carry->dtype;
+    carry_out->length = n;
+    carry_out->null_count = 0;
+    carry_out->own_values = ctx->alloc(8 * (size_t)n + 16);
+    carry_out->values = carry_out->own_values->p;
+  }
+  {
+    ProfScope ps(ctx, "order_finish");
+    uint64_t *po = NPAY ? carry_out->own_values->as<uint64_t>() : nullptr;
+#define SQ_FIN(RR)                                                                                                   \
+  do {                                                                                                               \
+    auto kfn = ow_finish_kernel<KIND, NPAY, RR>;                                                                     \
+    const size_t lds = (size_t)RR * FIN_WG * 8 * (1 + NPAY) + 4 * (FIN_WAVES * 256 + 256);                           \
+    if (lds > 64 * 1024) allow_big_lds(ctx, kfn);                                                                    \
+    kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(words, pays, gstart->as<uint32_t>(), rbits, desc, imin,         \
+                                                     key_out->own_values->p, po, perm);                              \
+  } while (0)
+    if (max_group <= 8 * FIN_WG) SQ_FIN(8);
+    else if (max_group <= 16 * FIN_WG) SQ_FIN(16);
+    else SQ_FIN(24);
+#undef SQ_FIN
+    SQ_HIP(hipGetLastError());
+  }
+  return true;
+}
+
+// ORDER BY one key column (int64 / float64 / int32, no NULLs) of >= 2^20 rows, optionally carrying one
+// 8-byte column without NULLs; `perm` (row ids in output order) is produced when asked for.  Returns false
+// when the shape or the data do not fit (nothing has been produced then).
+bool order_fast(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, DCol *key_out, DCol *carry_out,
+                BufP *perm, bool want_perm) {
+  if (n < (1 << 20) || n > 0xffffffffll || key.stride == 0 || (key.validity && key.null_count != 0)) return false;
+  if (carry && (width_of(carry->dtype) != 8 || carry->stride == 0 || (carry->validity && carry->null_count != 0))) return false;
+#define SQ_OF(K)                                                                                                     \
+  return carry ? order_fast_impl<K, 1>(ctx, key, desc, carry, n, key_out, carry_out, perm, want_perm)                \
+               : order_fast_impl<K, 0>(ctx, key, desc, nullptr, n, key_out, carry_out, perm, want_perm)
+  switch (key.dtype) {
+  case SQLRS_INT64: SQ_OF(OKIND_I64);
+  case SQLRS_FLOAT64: SQ_OF(OKIND_F64);
+  case SQLRS_INT32: SQ_OF(OKIND_I32);
+  default: return false;
+  }
+#undef SQ_OF
+}
+
+} // namespace sq

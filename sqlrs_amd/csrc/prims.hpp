@@ -83,5 +83,9 @@ NKeys normalize_keys_strong(Ctx *ctx, const std::vector<DCol> &cols, int64_t row
 void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int begin_bit,
                       int end_bit);
 void iota_u32(Ctx *ctx, uint32_t *out, int64_t n);
+// order_fast.hip: ORDER BY one fixed-width key without NULLs, rows (key, one carried 8-byte column, row id)
+// travel through <= 2 HBM passes + an in-LDS finish; false = shape / data do not fit (general path)
+bool order_fast(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, DCol *key_out, DCol *carry_out,
+                BufP *perm, bool want_perm);
 
 } // namespace sq

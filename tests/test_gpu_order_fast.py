@@ -1,0 +1,67 @@
+"""ORDER BY one key column on the fast route of order_fast.hip (rows travel through <= 2 HBM passes on the
+top key bits + an in-LDS finish) against the oracle (order.rs:15-67), including the shapes that must fall
+back to the general path.  A row-id column makes tie order (stable, like the general path) visible."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from sqlrs_amd import abi
+from sqlrs_amd.executor import OrderExecutor
+from sqlrs_amd.expr import InputRef, OrderBy
+
+pytestmark = pytest.mark.gpu
+N = 1_300_000
+
+
+def keys_of(rng, shape):
+    if shape == "i64_31bit":
+        return rng.integers(0, 1 << 31, N, dtype=np.int64)
+    if shape == "i64_negative_20bit":
+        return rng.integers(-(1 << 19), 1 << 19, N, dtype=np.int64)
+    if shape == "i64_10bit_many_ties":       # all key bits sorted in HBM (rbits = 0), groups of ~1300 equal keys
+        return rng.integers(-500, 500, N, dtype=np.int64)
+    if shape == "i64_offset_2p40":
+        return (1 << 40) + rng.integers(0, 1 << 24, N, dtype=np.int64)
+    if shape == "i64_wide":                  # > 32 varying bits: general path
+        return rng.integers(-(1 << 62), 1 << 62, N, dtype=np.int64)
+    if shape == "i64_heavy_groups":          # 50 distinct keys spread over 2^26: a group exceeds the LDS finish -> general path
+        return rng.choice(rng.integers(0, 1 << 26, 50, dtype=np.int64), N)
+    if shape == "i64_constant":
+        return np.full(N, 7, dtype=np.int64)
+    if shape == "f64_unit":                  # doubles in [0, 1): 52 varying bits -> general path
+        return rng.random(N)
+    if shape == "f64_few":                   # doubles from a small set over a narrow bit range
+        return (rng.integers(0, 4096, N) / 4096.0 + 1.0)
+    if shape == "i32":
+        return rng.integers(-(1 << 20), 1 << 20, N).astype(np.int32)
+    raise ValueError(shape)
+
+
+@pytest.mark.parametrize("shape", ["i64_31bit", "i64_negative_20bit", "i64_10bit_many_ties", "i64_offset_2p40", "i64_wide",
+                                   "i64_heavy_groups", "i64_constant", "f64_unit", "f64_few", "i32"])
+@pytest.mark.parametrize("asc", [True, False])
+@pytest.mark.parametrize("extra", ["none", "carry", "carry_and_more"])
+def test_order_fast_route(hip, oracle, shape, asc, extra):
+    if extra != "carry" and shape not in ("i64_31bit", "i64_10bit_many_ties", "i32", "f64_few"):
+        pytest.skip("column mixes are crossed with four key shapes only")
+    rng = np.random.default_rng(abs(hash_seed(shape, asc, extra)))
+    k = keys_of(rng, shape)
+    cols, names = [pa.array(k)], ["k"]
+    if extra != "none":
+        cols.append(pa.array(np.arange(N, dtype=np.int64)))          # row id: carried, shows the tie order
+        names.append("row")
+    if extra == "carry_and_more":
+        cols += [pa.array(rng.random(N), mask=rng.random(N) < 0.1), pa.array(rng.integers(0, 100, N).astype(np.int32)),
+                 pa.array([None if i % 11 == 0 else f"s{i % 97}" for i in range(N)])]
+        names += ["f", "i", "s"]
+    b = pa.RecordBatch.from_arrays(cols, names=names)
+    bs = [b.slice(0, N // 3), b.slice(N // 3)]
+    (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(0), asc=asc)], bs).execute())
+    (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=asc)], bs).execute())
+    for i in range(b.num_columns):
+        assert got.column(i).equals(exp.column(i)), names[i]
+
+
+def hash_seed(*parts):
+    import zlib
+    return zlib.crc32("|".join(str(p) for p in parts).encode())
