@@ -10,7 +10,7 @@
 //      the word  off << 32 | row id  plus its carried column (16 B per row and pass; the first pass reads
 //      the raw column and builds the word in registers)                                     [LSD order]
 //      => rows are grouped by their top bits, in input order inside a group
-//   2. group boundaries (suffix minimum over a 2^16 + 1 entry table)
+//   2. group boundaries (a row whose predecessor has other top bits opens its group and closes the previous one)
 //   3. one workgroup per group: the group (<= FIN_CAP rows) is sorted on the remaining rbits INSIDE LDS
 //      (<= 2 stable 8-bit passes, same ballot ranking as the HBM passes), then key column, carried column
 //      and row id (the permutation for any further column) leave in final order.
@@ -204,8 +204,10 @@ __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restric
 }
 
 // ---- group boundaries ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ow_group_first_kernel(const uint64_t *__restrict__ words, int64_t n, int gshift,
-                                                             uint32_t *__restrict__ gstart) {
+// rows are grouped by their top bits: a row whose predecessor belongs to another group opens its group and
+// closes the predecessor's (gstart / gend start as ~0 / 0: an absent group keeps gstart = ~0)
+__global__ __launch_bounds__(256) void ow_group_bounds_kernel(const uint64_t *__restrict__ words, int64_t n, int gshift,
+                                                              uint32_t *__restrict__ gstart, uint32_t *__restrict__ gend) {
   constexpr int KU = 8; // independent loads in flight per lane
   for (int64_t base = blockIdx.x * (int64_t)(256 * KU) + threadIdx.x; base < n; base += (int64_t)gridDim.x * (256 * KU)) {
     uint64_t cur[KU], prev[KU];
@@ -213,50 +215,40 @@ __global__ __launch_bounds__(256) void ow_group_first_kernel(const uint64_t *__r
     for (int u = 0; u < KU; u++) {
       const int64_t i = min(base + u * 256, n - 1);
       cur[u] = __builtin_nontemporal_load(words + i);
-      prev[u] = words[max<int64_t>(i - 1, 0)]; // (the neighbouring lane's element: served by the same lines)
+      prev[u] = words[i > 0 ? i - 1 : 0]; // (the neighbouring lane's element: served by the same lines)
     }
 #pragma unroll
     for (int u = 0; u < KU; u++) {
       const int64_t i = base + u * 256;
-      const uint32_t g = (uint32_t)(cur[u] >> gshift);
-      if (i < n && (i == 0 || (uint32_t)(prev[u] >> gshift) != g)) gstart[g] = (uint32_t)i;
+      if (i >= n) continue;
+      const uint32_t g = (uint32_t)(cur[u] >> gshift), gp = (uint32_t)(prev[u] >> gshift);
+      if (i == 0 || gp != g) {
+        gstart[g] = (uint32_t)i;
+        if (i) gend[gp] = (uint32_t)i;
+      }
+      if (i == n - 1) gend[g] = (uint32_t)n;
     }
   }
 }
-// gstart[g] = first row of the first non-empty group >= g (suffix minimum; gstart[G] = n); also the
-// largest group.  One workgroup of 1024 threads, G <= 65536.
-__global__ __launch_bounds__(1024) void ow_group_fill_kernel(uint32_t *__restrict__ gstart, uint32_t G, uint32_t n,
-                                                             uint32_t *__restrict__ max_group) {
-  __shared__ uint32_t s_min[1024];
-  const uint32_t per = (G + 1023) / 1024, lo = threadIdx.x * per, hi = min(G, lo + per);
-  uint32_t m = 0xffffffffu;
-  for (uint32_t g = lo; g < hi; g++) m = min(m, gstart[g]);
-  s_min[threadIdx.x] = m;
-  __syncthreads();
-  uint32_t run = n; // minimum over everything behind this thread's slice
-  for (uint32_t t = threadIdx.x + 1; t < 1024; t++) run = min(run, s_min[t]);
-  uint32_t mx = 0;
-  for (uint32_t g = hi; g-- > lo;) { // backwards: suffix minimum inside the slice
-    const uint32_t next = run;
-    run = min(run, gstart[g]);
-    gstart[g] = run;
-    mx = max(mx, next - run);
-  }
-  if (threadIdx.x == 0) gstart[G] = n;
-  for (int k = 32; k >= 1; k >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, k, 64));
-  if (lane_id() == 0 && mx) atomicMax(max_group, mx);
+__global__ void ow_group_max_kernel(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gend, uint32_t G,
+                                    uint32_t *__restrict__ max_group) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t sz = (g < G && gstart[g] != 0xffffffffu) ? gend[g] - gstart[g] : 0;
+  for (int k = 32; k >= 1; k >>= 1) sz = max(sz, (uint32_t)__shfl_xor((int)sz, k, 64));
+  if (lane_id() == 0 && sz) atomicMax(max_group, sz);
 }
 
 // ---- finish: sort every group on its low bits inside LDS, write the final columns ----------------------
 constexpr int FIN_WG = 256, FIN_WAVES = FIN_WG / 64;
 template <int KIND, int NPAY, int R>
 __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pay,
-                                                           const uint32_t *__restrict__ gstart, int rbits, int desc,
+                                                           const uint32_t *__restrict__ gstart,
+                                                           const uint32_t *__restrict__ gend, int rbits, int desc,
                                                            uint64_t imin, void *__restrict__ key_out,
                                                            uint64_t *__restrict__ pay_out, uint32_t *__restrict__ perm_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t lo = gstart[blockIdx.x], hi = gstart[blockIdx.x + 1];
-  if (lo >= hi) return;
+  const uint32_t lo = gstart[blockIdx.x], hi = gend[blockIdx.x];
+  if (lo == 0xffffffffu || lo >= hi) return; // no row carries these top bits
   const uint32_t m = hi - lo;
   uint64_t *sword = (uint64_t *)smem;                       // [R * FIN_WG]
   uint64_t *spay = sword + (size_t)R * FIN_WG;              // [NPAY ? R * FIN_WG : 0]
@@ -419,17 +411,18 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   }
   // 2. groups = distinct values of the top bits
   const uint32_t G = 1u << top;
-  BufP gstart = ctx->alloc(4 * ((size_t)G + 2));
-  SQ_HIP(hipMemsetAsync(gstart->p, 0xff, 4 * ((size_t)G + 1), ctx->stream));
-  SQ_HIP(hipMemsetAsync(gstart->as<uint32_t>() + G + 1, 0, 4, ctx->stream)); // [G + 1] = largest group
+  BufP gstart = ctx->alloc(4 * (size_t)G), gend = ctx->alloc(4 * ((size_t)G + 1)); // gend[G] = largest group
+  SQ_HIP(hipMemsetAsync(gstart->p, 0xff, 4 * (size_t)G, ctx->stream));
+  SQ_HIP(hipMemsetAsync(gend->p, 0, 4 * ((size_t)G + 1), ctx->stream));
   {
     ProfScope ps(ctx, "order_groups");
-    ow_group_first_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 16 * (int64_t)ctx->num_cus)), dim3(256), 0, ctx->stream>>>(
-        words, n, 32 + rbits, gstart->as<uint32_t>());
-    ow_group_fill_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(gstart->as<uint32_t>(), G, (uint32_t)n, gstart->as<uint32_t>() + G + 1);
+    ow_group_bounds_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 16 * (int64_t)ctx->num_cus)), dim3(256), 0, ctx->stream>>>(
+        words, n, 32 + rbits, gstart->as<uint32_t>(), gend->as<uint32_t>());
+    ow_group_max_kernel<<<dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, ctx->stream>>>(gstart->as<uint32_t>(), gend->as<uint32_t>(), G,
+                                                                                      gend->as<uint32_t>() + G);
     SQ_HIP(hipGetLastError());
   }
-  const uint32_t max_group = ctx->fetch_value(gstart->as<uint32_t>() + G + 1);
+  const uint32_t max_group = ctx->fetch_value(gend->as<uint32_t>() + G);
   if (max_group > FIN_CAP) return false; // heavily repeated top bits: general path
   if (NPAY) {
     carry_out->dtype = carry->dtype;
@@ -446,7 +439,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     auto kfn = ow_finish_kernel<KIND, NPAY, RR>;                                                                     \
     const size_t lds = (size_t)RR * FIN_WG * 8 * (1 + NPAY) + 4 * (FIN_WAVES * 256 + 256);                           \
     if (lds > 64 * 1024) allow_big_lds(ctx, kfn);                                                                    \
-    kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(words, pays, gstart->as<uint32_t>(), rbits, desc, imin,         \
+    kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(words, pays, gstart->as<uint32_t>(), gend->as<uint32_t>(), rbits, desc, imin, \
                                                      key_out->own_values->p, po, perm);                              \
   } while (0)
     if (max_group <= 8 * FIN_WG) SQ_FIN(8);
