@@ -33,6 +33,25 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(const T *__restrict__ src
   }
 }
 
+// Nothing nullable (the join's and the sort's common case): GU rows per lane, all index loads first, then
+// all (independent) source loads, then the stores — one row per lane left a single random load in flight
+// per lane and relied on occupancy alone to cover the L2 / HBM latency.
+constexpr int GU = 8;
+template <class T, class I>
+__global__ __launch_bounds__(BLOCK) void gather_plain_kernel(const T *__restrict__ src, const I *__restrict__ idx, int64_t n,
+                                                             T *__restrict__ out) {
+  const int64_t base = blockIdx.x * (int64_t)(BLOCK * GU) + threadIdx.x;
+  I s[GU];
+#pragma unroll
+  for (int u = 0; u < GU; u++) s[u] = __builtin_nontemporal_load(idx + min(base + u * BLOCK, n - 1));
+  T v[GU];
+#pragma unroll
+  for (int u = 0; u < GU; u++) v[u] = src[s[u]];
+#pragma unroll
+  for (int u = 0; u < GU; u++)
+    if (base + u * BLOCK < n) __builtin_nontemporal_store(v[u], out + base + u * BLOCK);
+}
+
 // BOOLEAN values: gather single bits
 template <class I>
 __global__ __launch_bounds__(BLOCK) void gather_bits_kernel(const uint64_t *__restrict__ src,
@@ -158,6 +177,13 @@ static DCol gather_impl(Ctx *ctx, const DCol &src, const I *idx, const uint64_t 
   o.own_values = ctx->alloc(w * (size_t)std::max<int64_t>(n, 1) + 16);
   o.values = o.own_values->p;
   if (n == 0) return o;
+  if (!nullable) {
+    dim3 gp((unsigned)ceil_div(n, BLOCK * GU));
+    if (w == 8) gather_plain_kernel<uint64_t, I><<<gp, b, 0, ctx->stream>>>(src.v<uint64_t>(), idx, n, o.own_values->as<uint64_t>());
+    else gather_plain_kernel<uint32_t, I><<<gp, b, 0, ctx->stream>>>(src.v<uint32_t>(), idx, n, o.own_values->as<uint32_t>());
+    SQ_HIP(hipGetLastError());
+    return o;
+  }
   if (w == 8)
     gather_kernel<uint64_t, I><<<g, b, 0, ctx->stream>>>(src.v<uint64_t>(), sv, idx, idx_validity, n,
                                                          o.own_values->as<uint64_t>(), ov);

@@ -118,46 +118,58 @@ __global__ __launch_bounds__(BLOCK) void join_count_kernel(const uint64_t *__res
                                                            const uint64_t *__restrict__ validity,
                                                            int64_t n, const Slot *__restrict__ table,
                                                            uint64_t mask, int outer_right,
-                                                           uint32_t *__restrict__ counts) {
+                                                           uint32_t *__restrict__ counts, uint2 *__restrict__ match) {
   int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (r >= n) return;
   bool is_null = validity && !((validity[r >> 6] >> (r & 63)) & 1);
   Slot s = probe_slot(table, mask, keys[r], is_null);
   uint32_t c = s.count;
+  match[r] = make_uint2(s.head, c); // what the fill pass needs: no second probe
   if (outer_right && c == 0) c = 1;
   counts[r] = c;
 }
 
-// pass 2: write the pairs at their scanned offsets
-__global__ __launch_bounds__(BLOCK) void join_fill_kernel(
-    const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n,
-    const Slot *__restrict__ table, uint64_t mask, int unique,
-    const uint32_t *__restrict__ rows_by_slot, const uint64_t *__restrict__ offsets,
-    uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx,
+// pass 2, wave-cooperative: a wave owns 64 consecutive probe rows and writes THEIR pairs as one contiguous
+// range of output positions, 64 at a time — lane t of a step finds the row that owns output t by a 6-step
+// search over the wave's inclusive scan of the per-row counts (shuffles), so consecutive lanes store
+// consecutive pairs.  (One lane per probe row, each walking its own run of `count` pairs, stored at the
+// random-store rate: 1.8 ms for 8e7 pairs; this form: see DESIGN.md.)
+__global__ __launch_bounds__(BLOCK) void join_fill_expand_kernel(
+    const uint2 *__restrict__ match, int64_t n, int unique, int outer_right, const uint32_t *__restrict__ rows_by_slot,
+    const uint64_t *__restrict__ offsets, uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx,
     uint8_t *__restrict__ left_valid_bytes) {
-  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  bool is_null = validity && !((validity[r >> 6] >> (r & 63)) & 1);
-  Slot s = probe_slot(table, mask, keys[r], is_null);
-  uint64_t o = offsets[r];
-  if (s.count == 0) {
-    if (left_valid_bytes) { // Right/Full: (NULL, row)   hash_join.rs:241-246
-      left_idx[o] = 0;
-      right_idx[o] = (uint32_t)r;
-      left_valid_bytes[o] = 0;
+  const int lane = lane_id();
+  const int64_t wbase = (blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_id()) * 64;
+  if (wbase >= n) return;
+  const int64_t r = wbase + lane;
+  uint2 m = r < n ? match[r] : make_uint2(0u, 0u);
+  const bool hit = m.y != 0;
+  uint32_t cnt = m.y;
+  if (outer_right && r < n && cnt == 0) cnt = 1; // (NULL, row)  hash_join.rs:241-246
+  const uint32_t incl = wave_iscan_u32(cnt), excl = incl - cnt;
+  const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+  const uint64_t obase = offsets[wbase];
+  for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+    const uint32_t t = t0 + lane;
+    // owner of output t = number of rows of the wave whose inclusive scan is <= t
+    int pos = 0;
+#pragma unroll
+    for (int sstep = 32; sstep >= 1; sstep >>= 1) {
+      const uint32_t v = (uint32_t)__shfl((int)incl, pos + sstep - 1, 64);
+      if (v <= t) pos += sstep;
     }
-    return;
-  }
-  if (unique) {
-    left_idx[o] = s.head;
-    right_idx[o] = (uint32_t)r;
-    if (left_valid_bytes) left_valid_bytes[o] = 1;
-    return;
-  }
-  for (uint32_t j = 0; j < s.count; j++) {
-    left_idx[o + j] = rows_by_slot[s.head + j];
-    right_idx[o + j] = (uint32_t)r;
-    if (left_valid_bytes) left_valid_bytes[o + j] = 1;
+    pos = min(pos, 63);
+    const uint32_t j = t - (uint32_t)__shfl((int)excl, pos, 64);
+    const uint32_t head = (uint32_t)__shfl((int)m.x, pos, 64);
+    const bool phit = __shfl((int)hit, pos, 64) != 0;
+    if (t < total) {
+      const uint64_t o = obase + t;
+      uint64_t l = 0;
+      if (phit) l = unique ? head : rows_by_slot[head + j];
+      left_idx[o] = l;
+      right_idx[o] = (uint32_t)(wbase + pos);
+      if (left_valid_bytes) left_valid_bytes[o] = phit ? 1 : 0;
+    }
   }
 }
 
@@ -718,11 +730,12 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     return p;
   }
   BufP counts = ctx->alloc(4 * (size_t)n), offsets = ctx->alloc(8 * (size_t)n), total = ctx->alloc(8);
+  BufP match = ctx->alloc(8 * (size_t)n);
   {
     ProfScope ps(ctx, "join_probe_count");
     join_count_kernel<<<g, b, 0, ctx->stream>>>(pk.keys->as<uint64_t>(), pk.validity, n,
                                                 (j->table ? j->table->as<Slot>() : nullptr), j->mask, outer_right,
-                                                counts->as<uint32_t>());
+                                                counts->as<uint32_t>(), match->as<uint2>());
     SQ_HIP(hipGetLastError());
   }
   exclusive_scan_u32(ctx, counts->as<uint32_t>(), n, offsets->as<uint64_t>(), nullptr,
@@ -735,10 +748,9 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   if (outer_right) lvb = ctx->alloc((size_t)m1);
   if (p.m) {
     ProfScope ps(ctx, "join_probe_fill");
-    join_fill_kernel<<<g, b, 0, ctx->stream>>>(
-        pk.keys->as<uint64_t>(), pk.validity, n, (j->table ? j->table->as<Slot>() : nullptr), j->mask, j->unique ? 1 : 0,
-        j->rows_by_slot ? j->rows_by_slot->as<uint32_t>() : nullptr, offsets->as<uint64_t>(),
-        p.left->as<uint64_t>(), p.right->as<uint32_t>(), lvb ? lvb->as<uint8_t>() : nullptr);
+    join_fill_expand_kernel<<<dim3((unsigned)ceil_div(n, BLOCK)), b, 0, ctx->stream>>>(
+        match->as<uint2>(), n, j->unique ? 1 : 0, outer_right, j->rows_by_slot ? j->rows_by_slot->as<uint32_t>() : nullptr,
+        offsets->as<uint64_t>(), p.left->as<uint64_t>(), p.right->as<uint32_t>(), lvb ? lvb->as<uint8_t>() : nullptr);
     SQ_HIP(hipGetLastError());
   }
   if (outer_right) {
