@@ -16,6 +16,8 @@
 // The random-access working set is the table: 4 B x key range (direct-address, 4 MiB for 1e6
 // keys = one XCD's L2, ~265 G lookups/s) or 16 B x 2 x build rows (hash table, ~56-66 G
 // lookups/s once it exceeds the L2; profiles/r01_ubench_mi355x.txt).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "prims.hpp"
@@ -383,6 +385,11 @@ __global__ __launch_bounds__(JD_BLOCK, JD_OCC) void join_probe_dense_kernel(
   }
 }
 
+// (The dense probe's block shape — 8 worker waves x 16 slot loads per lane + scan wave, 8192-row tiles — was
+// tried for the general hash table too and measured SLOWER than join_probe_unique_kernel's 4 waves x 8 loads,
+// 3.27 vs 2.56 ms per 1e8 probe rows on a 32 MiB table: the probe is bound by the random-access rate of a
+// table beyond one XCD's L2 (65 G 16-byte loads/s = 1.5 ms, profiles/r01_ubench_mi355x.txt) plus its key stream
+// and pair stores, and many small blocks keep more of those lookups in flight than few large ones.)
 // UNIQUE build keys, Right/Full: every probe row emits exactly one pair (hash_join.rs:235-247)
 template <bool DENSE>
 __global__ __launch_bounds__(BLOCK) void join_probe_unique_outer_kernel(
