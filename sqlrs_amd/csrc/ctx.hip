@@ -5,6 +5,7 @@
 #include <unordered_set>
 
 #include "common.hpp"
+#include "host_stage.hpp"
 #include "prims.hpp"
 
 namespace sq {
@@ -382,6 +383,79 @@ sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem) {
   o->abi.columns = o->descs.data();
   o->abi.owner = o.get();
   return &o.release()->abi;
+}
+
+// --------------------------------------------------------------- host staging --
+bool HostStage::accepts(const sqlrs_batch_t *b) const {
+  if (!b || b->num_columns <= 0 || b->num_rows > HOST_STAGE_MAX_BATCH) return false;
+  if (has_schema && (size_t)b->num_columns != cols.size()) return false;
+  for (int i = 0; i < b->num_columns; i++) {
+    const sqlrs_column_t &c = b->columns[i];
+    if (c.mem != SQLRS_MEM_HOST || !width_of(c.dtype) || c.length != b->num_rows) return false;
+    if (has_schema && cols[(size_t)i].dtype != c.dtype) return false;
+  }
+  return true;
+}
+
+void HostStage::append(const sqlrs_batch_t *b) {
+  if (!has_schema) {
+    cols.resize((size_t)b->num_columns);
+    for (int i = 0; i < b->num_columns; i++) cols[(size_t)i].dtype = b->columns[i].dtype;
+    has_schema = true;
+  }
+  const int64_t n = b->num_rows;
+  for (int i = 0; i < b->num_columns && n > 0; i++) {
+    const sqlrs_column_t &c = b->columns[i];
+    Col &d = cols[(size_t)i];
+    const size_t w = width_of(c.dtype);
+    const uint8_t *src = (const uint8_t *)c.values;
+    d.vals.insert(d.vals.end(), src, src + w * (size_t)n);
+    const bool nullable = c.validity && c.null_count != 0;
+    if (nullable || !d.valid.empty()) {
+      const size_t words = (size_t)ceil_div(rows + n, 64);
+      if (d.valid.empty()) { // first NULL-bearing batch: everything before it was valid
+        d.valid.assign((size_t)ceil_div(rows, 64), ~0ull);
+        if (rows & 63) d.valid.back() &= (1ull << (rows & 63)) - 1;
+      }
+      d.valid.resize(words, 0);
+      for (int64_t r = 0; r < n; r++) {
+        const bool v = !nullable || ((c.validity[r >> 3] >> (r & 7)) & 1);
+        if (v) d.valid[(size_t)((rows + r) >> 6)] |= 1ull << ((rows + r) & 63);
+        else d.nulls++;
+      }
+    }
+  }
+  rows += n;
+}
+
+sqlrs_batch_t *HostStage::take() {
+  if (!has_schema) return nullptr;
+  std::vector<sqlrs_column_t> descs(cols.size());
+  for (size_t i = 0; i < cols.size(); i++) {
+    sqlrs_column_t &d = descs[i];
+    d.dtype = cols[i].dtype;
+    d.mem = SQLRS_MEM_HOST;
+    d.length = rows;
+    d.null_count = cols[i].nulls;
+    d.values = cols[i].vals.data();
+    d.validity = cols[i].nulls ? (const uint8_t *)cols[i].valid.data() : nullptr;
+    d.offsets = nullptr;
+  }
+  sqlrs_batch_t hb;
+  hb.num_rows = rows;
+  hb.num_columns = (int32_t)descs.size();
+  hb.reserved = 0;
+  hb.columns = descs.data();
+  hb.owner = nullptr;
+  sqlrs_batch_t *dev = nullptr;
+  {
+    InBatch ib(ctx, &hb);
+    dev = emit_batch(ctx, ib.materialize(true), SQLRS_MEM_DEVICE);
+  } // (~InBatch waits for the uploads: the vectors may go now)
+  cols.clear();
+  has_schema = false;
+  rows = 0;
+  return dev;
 }
 
 // Host columns built by the library itself (CSV ingest) -> library-owned HOST batch.  Every pointer of

@@ -15,6 +15,7 @@
 #include "agg_state.hpp"
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "host_stage.hpp"
 #include "prims.hpp"
 
 using namespace sq;
@@ -69,6 +70,7 @@ struct PendingGroups {
 
 struct sqlrs_hash_agg {
   Ctx *ctx = nullptr;
+  HostStage hstage; // small HOST batches wait here and are uploaded together (host_stage.hpp)
   PendingGroups pending;
   std::vector<Expr> group_by;
   std::vector<AggSpec> aggs;
@@ -111,6 +113,7 @@ extern "C" int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_bat
 extern "C" int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t *group_by, int num_aggs,
                                      const sqlrs_agg_func_t *aggs, sqlrs_hash_agg_t **out);
 extern "C" void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *a);
+extern "C" void sqlrs_batch_release(sqlrs_batch_t *batch);
 
 namespace sq {
 
@@ -767,8 +770,34 @@ int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t
   });
 }
 
+static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in);
+// what is staged on the host -> one device batch -> the operator
+static int hash_agg_flush_host(sqlrs_hash_agg_t *a) {
+  if (!a->hstage.has_schema) return SQLRS_OK;
+  sqlrs_batch_t *dev = nullptr;
+  int st = guard(a->ctx, [&] {
+    SQ_HIP(hipSetDevice(a->ctx->device));
+    dev = a->hstage.take();
+  });
+  if (st != SQLRS_OK) return st;
+  st = hash_agg_push_device(a, dev);
+  sqlrs_batch_release(dev);
+  return st;
+}
+
 // one iteration of the for_await loop  [ref: hash_agg.rs:44-122]
 int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
+  a->hstage.ctx = a->ctx;
+  if (a->hstage.accepts(in)) {
+    int st = guard(a->ctx, [&] { a->hstage.append(in); });
+    if (st != SQLRS_OK || a->hstage.rows < HOST_STAGE_FLUSH_ROWS) return st;
+    return hash_agg_flush_host(a);
+  }
+  int st = hash_agg_flush_host(a); // keeps the arrival order of the rows
+  return st != SQLRS_OK ? st : hash_agg_push_device(a, in);
+}
+
+static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
   return guard(a->ctx, [&] {
     Ctx *ctx = a->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
@@ -808,6 +837,8 @@ int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
 
 // [ref: hash_agg.rs:124-149]
 int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out) {
+  int stf = hash_agg_flush_host(a);
+  if (stf != SQLRS_OK) return stf;
   return guard(a->ctx, [&] {
     Ctx *ctx = a->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
@@ -914,6 +945,7 @@ struct sqlrs_join_agg {
   bool has_filter = false;
   Expr probe_filter;
   int64_t filter_fused_batches = 0;
+  HostStage hstage; // small HOST probe batches (raw, unfiltered) until enough rows for one upload
   ~sqlrs_join_agg() {
     if (join) sqlrs_hash_join_destroy(join);
     delete agg;
@@ -1097,7 +1129,36 @@ static int join_agg_flush(sqlrs_join_agg_t *ja) {
   return st;
 }
 
+static int join_agg_probe_push_device(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right);
+static int join_agg_flush_host(sqlrs_join_agg_t *ja) {
+  if (!ja->hstage.has_schema) return SQLRS_OK;
+  sqlrs_batch_t *dev = nullptr;
+  int st = guard(ja->ctx, [&] {
+    SQ_HIP(hipSetDevice(ja->ctx->device));
+    dev = ja->hstage.take();
+  });
+  if (st != SQLRS_OK) return st;
+  st = join_agg_probe_push_device(ja, dev);
+  sqlrs_batch_release(dev);
+  return st;
+}
+
 int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
+  ja->hstage.ctx = ja->ctx;
+  if (ja->hstage.accepts(right)) {
+    int st = guard(ja->ctx, [&] {
+      if (!ja->join->finished) fail(SQLRS_ERR_INTERNAL, "probe before build_finish");
+      ja->hstage.append(right);
+    });
+    // (flushed in units large enough for the in-place route: the Filter is then evaluated by the first partition pass)
+    if (st != SQLRS_OK || ja->hstage.rows < std::max(HOST_STAGE_FLUSH_ROWS, STAGE_DIRECT_ROWS)) return st;
+    return join_agg_flush_host(ja);
+  }
+  int st = join_agg_flush_host(ja);
+  return st != SQLRS_OK ? st : join_agg_probe_push_device(ja, right);
+}
+
+static int join_agg_probe_push_device(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) {
   if (ja->staged.empty() && right->num_rows >= STAGE_DIRECT_ROWS) return join_agg_process(ja, right, true);
   sqlrs_batch_t *kept = nullptr;
   if (ja->has_filter) { // small batches are filtered on arrival; what is staged is the Filter's output
@@ -1126,7 +1187,9 @@ int sqlrs_join_agg_probe_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right) 
 }
 
 int sqlrs_join_agg_finish(sqlrs_join_agg_t *ja, int out_mem, sqlrs_batch_t **out) {
-  int st = join_agg_flush(ja);
+  int st = join_agg_flush_host(ja);
+  if (st != SQLRS_OK) return st;
+  st = join_agg_flush(ja);
   if (st != SQLRS_OK) return st;
   return sqlrs_hash_agg_finish(ja->agg, out_mem, out);
 }
@@ -1137,7 +1200,8 @@ int sqlrs_join_agg_set_group_order(sqlrs_join_agg_t *ja, int group_order) {
 int64_t sqlrs_join_agg_fused_batches(const sqlrs_join_agg_t *ja) { return ja->fused_batches; }
 int sqlrs_join_agg_set_probe_filter(sqlrs_join_agg_t *ja, const sqlrs_expr_t *filter) {
   return guard(ja->ctx, [&] {
-    if (ja->processed_any || !ja->staged.empty()) fail(SQLRS_ERR_INTERNAL, "set_probe_filter after the first probe batch");
+    if (ja->processed_any || !ja->staged.empty() || ja->hstage.has_schema)
+      fail(SQLRS_ERR_INTERNAL, "set_probe_filter after the first probe batch");
     ja->has_filter = filter && filter->num_nodes > 0;
     if (ja->has_filter) ja->probe_filter = expr_from_abi(filter);
   });

@@ -521,6 +521,8 @@ using namespace sq;
 
 #include "join_state.hpp"
 
+extern "C" void sqlrs_batch_release(sqlrs_batch_t *batch);
+
 namespace sq {
 
 struct Pairs {
@@ -910,7 +912,30 @@ int sqlrs_hash_join_create(sqlrs_ctx_t *ctx, int join_type, int num_keys,
   });
 }
 
+static int hash_join_build_push_device(sqlrs_hash_join_t *j, const sqlrs_batch_t *left);
+static int hash_join_flush_host(sqlrs_hash_join_t *j) {
+  if (!j->hstage.has_schema) return SQLRS_OK;
+  sqlrs_batch_t *dev = nullptr;
+  int st = guard(j->ctx, [&] {
+    SQ_HIP(hipSetDevice(j->ctx->device));
+    dev = j->hstage.take();
+  });
+  if (st != SQLRS_OK) return st;
+  st = hash_join_build_push_device(j, dev);
+  sqlrs_batch_release(dev);
+  return st;
+}
 int sqlrs_hash_join_build_push(sqlrs_hash_join_t *j, const sqlrs_batch_t *left) {
+  j->hstage.ctx = j->ctx;
+  if (!j->finished && j->hstage.accepts(left)) {
+    int st = guard(j->ctx, [&] { j->hstage.append(left); });
+    if (st != SQLRS_OK || j->hstage.rows < HOST_STAGE_FLUSH_ROWS) return st;
+    return hash_join_flush_host(j);
+  }
+  int st = hash_join_flush_host(j);
+  return st != SQLRS_OK ? st : hash_join_build_push_device(j, left);
+}
+static int hash_join_build_push_device(sqlrs_hash_join_t *j, const sqlrs_batch_t *left) {
   return guard(j->ctx, [&] {
     SQ_HIP(hipSetDevice(j->ctx->device));
     if (j->finished) fail(SQLRS_ERR_INTERNAL, "build_push after build_finish");
@@ -927,6 +952,8 @@ int sqlrs_hash_join_build_push(sqlrs_hash_join_t *j, const sqlrs_batch_t *left) 
 }
 
 int sqlrs_hash_join_build_finish(sqlrs_hash_join_t *j) {
+  int stf = hash_join_flush_host(j);
+  if (stf != SQLRS_OK) return stf;
   return guard(j->ctx, [&] {
     SQ_HIP(hipSetDevice(j->ctx->device));
     if (j->finished) return;

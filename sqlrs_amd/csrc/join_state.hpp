@@ -3,10 +3,12 @@
 #pragma once
 
 #include "common.hpp"
+#include "host_stage.hpp"
 #include "prims.hpp"
 
 struct sqlrs_hash_join {
   sq::Ctx *ctx = nullptr;
+  sq::HostStage hstage; // small HOST build batches until one upload (host_stage.hpp)
   int join_type = 0;
   std::vector<sq::Expr> lkeys, rkeys;
   bool has_filter = false;

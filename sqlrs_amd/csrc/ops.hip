@@ -5,9 +5,12 @@
 #include "agg_state.hpp"
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "host_stage.hpp"
 #include "prims.hpp"
 
 using namespace sq;
+
+extern "C" void sqlrs_batch_release(sqlrs_batch_t *batch);
 
 // =========================================================================== Filter ==
 struct sqlrs_filter {
@@ -196,6 +199,7 @@ void sort_perm_by_utf8(Ctx *ctx, const DCol &c, const uint64_t *valid, int desc,
 
 struct sqlrs_order {
   Ctx *ctx = nullptr;
+  HostStage hstage; // small HOST batches until one upload (host_stage.hpp)
   std::vector<Expr> exprs;
   std::vector<int> asc;
   std::vector<DBatch> batches;
@@ -216,17 +220,41 @@ int sqlrs_order_create(sqlrs_ctx_t *ctx, int num_keys, const sqlrs_order_by_t *o
   });
 }
 
-// [ref: order.rs:19-26]
-int sqlrs_order_push(sqlrs_order_t *o, const sqlrs_batch_t *in) {
+static int order_push_device(sqlrs_order_t *o, const sqlrs_batch_t *in) {
   return guard(o->ctx, [&] {
     SQ_HIP(hipSetDevice(o->ctx->device));
     InBatch ib(o->ctx, in);
     o->batches.push_back(ib.materialize(true));
   });
 }
+static int order_flush_host(sqlrs_order_t *o) {
+  if (!o->hstage.has_schema) return SQLRS_OK;
+  sqlrs_batch_t *dev = nullptr;
+  int st = guard(o->ctx, [&] {
+    SQ_HIP(hipSetDevice(o->ctx->device));
+    dev = o->hstage.take();
+  });
+  if (st != SQLRS_OK) return st;
+  st = order_push_device(o, dev);
+  sqlrs_batch_release(dev);
+  return st;
+}
+// [ref: order.rs:19-26]
+int sqlrs_order_push(sqlrs_order_t *o, const sqlrs_batch_t *in) {
+  o->hstage.ctx = o->ctx;
+  if (o->hstage.accepts(in)) {
+    int st = guard(o->ctx, [&] { o->hstage.append(in); });
+    if (st != SQLRS_OK || o->hstage.rows < HOST_STAGE_FLUSH_ROWS) return st;
+    return order_flush_host(o);
+  }
+  int st = order_flush_host(o);
+  return st != SQLRS_OK ? st : order_push_device(o, in);
+}
 
 // [ref: order.rs:27-66] concat -> lexsort_to_indices (nulls first, stable) -> take
 int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
+  int stf = order_flush_host(o);
+  if (stf != SQLRS_OK) return stf;
   return guard(o->ctx, [&] {
     Ctx *ctx = o->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
