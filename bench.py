@@ -11,17 +11,22 @@ Workload (config C5, the configuration the metric is quoted on; it fits one GPU)
 fact = 1e9 rows (key int64, val float64), dim = 1e7 rows (key int64), synthetic SplitMix64
 columns generated in HBM.  One "step" = one pass of Filter -> HashJoin(build+probe) -> HashAgg
 over the whole input; inputs are HBM resident when the timed region starts.  `value` is
-fact rows / s summed over all ranks (Mrows/s).
+fact rows / s summed over all ranks (Mrows/s).  The plan shape is HashAgg(HashJoin(dim, Filter(fact))):
+the fused HashJoinAgg operator with the Filter handed to it (sqlrs_join_agg_set_probe_filter).
 
 N > 1 (one process per GPU, launched by torch.distributed.run): the TOTAL input is fixed
-("scaling": "strong"); every rank generates a contiguous 1/N slice of fact and dim,
-hash-partitions both on the join key (sqlrs_hash_partition), exchanges the slices with one
-RCCL all-to-all per column over xGMI and runs the same operators on what it receives.  Group
-key = join key, so the per-rank results are disjoint and need no merge.
+("scaling": "strong"); every rank generates a contiguous 1/N slice of fact and dim.  Default
+strategy = north_star's partitioned hash join: Filter below the exchange, dim and kept fact rows
+hash-partitioned on the join key (sqlrs_hash_partition) and exchanged with RCCL all-to-alls in
+overlapped chunks (sqlrs_amd/distributed.py), local HashJoinAgg on what arrives (group key = join key,
+so the per-rank results are disjoint).  `--exchange broadcast` = all-gather the dim, aggregate locally,
+exchange + merge the partial aggregates; the line times the other strategy too (`exchange.alternative`).
 
-Output: ONE JSON line on rank 0 (contract in the task description) with `roofline` for the
-dominant kernel (HIP-event time per launch, measured live on the ctx stream) and
-`cpu_baseline` (the CPU oracle, single thread, on a bounded sample of the same workload).
+Output: ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel:
+HIP-event time per launch measured live on the ctx stream; and the operator-level pipeline figure),
+`cpu_baseline` (all-core CPU port + the single-threaded restatement of the reference, on bounded samples),
+and at N = 1 `c5_variants` (sparse keys, three operators) and `operators` (C2 / C3 / C4 / Order).
+Every result is checked per group before it is timed.
 """
 from __future__ import annotations
 

@@ -104,3 +104,9 @@ def test_hip_text_form_matches_oracle(hip, oracle):
     assert exp.splitlines()[2].startswith("1000000000000000000000 NULL NULL NULL 3")
     assert hip.batch_to_string(b) == exp
     assert hip.batch_to_string(hip.to_device(b)) == exp
+
+
+@pytest.mark.gpu
+def test_two_column_keys_inherit_symmetric_combine(hip, oracle):
+    from test_oracle_golden import symmetric_combine_case
+    assert symmetric_combine_case(hip) == symmetric_combine_case(oracle)

@@ -69,3 +69,29 @@ def test_oracle_simple_agg_edge_cases(oracle):
     assert [c.to_pylist() for c in out.columns] == [[0], [None], [None]]
     with pytest.raises(abi.ExecutorError):
         list(SimpleAggExecutor(oracle, aggs, []).execute())  # simple_agg.rs:63 unwraps a None
+
+
+def symmetric_combine_case(backend):
+    """create_hashes folds the key columns with combine_hashes (hash_utils.rs:13-16): for two columns of the
+    same type the fold is symmetric — (a, b) and (b, a) get the same row hash — and the join / group-by match
+    on the hash alone (hash_join.rs:222-224, hash_agg.rs:87).  So (1, 2) joins (2, 1) and both fall into one
+    group.  Pinned here so that nobody "fixes" it on one side only."""
+    import pyarrow as pa
+    from sqlrs_amd import abi
+    from sqlrs_amd.executor import HashAggExecutor, HashJoinExecutor
+    from sqlrs_amd.expr import AggFunc, InputRef, JoinCondition
+    lb = pa.RecordBatch.from_arrays([pa.array([1, 5], type=pa.int64()), pa.array([2, 6], type=pa.int64())], names=["a", "b"])
+    rb = pa.RecordBatch.from_arrays([pa.array([2, 5, 7], type=pa.int64()), pa.array([1, 6, 7], type=pa.int64())], names=["a", "b"])
+    sch = pa.schema([("l.a", pa.int64()), ("l.b", pa.int64()), ("r.a", pa.int64()), ("r.b", pa.int64())])
+    cond = JoinCondition([(InputRef(0), InputRef(0)), (InputRef(1), InputRef(1))])
+    joined = [tuple(c.to_pylist() for c in b.columns) for b in HashJoinExecutor(backend, [lb], [rb], "inner", cond, sch, 2).execute()]
+    both = pa.RecordBatch.from_arrays([pa.array([1, 2, 9], type=pa.int64()), pa.array([2, 1, 9], type=pa.int64()),
+                                       pa.array([10, 20, 30], type=pa.int64())], names=["a", "b", "v"])
+    (g,) = list(HashAggExecutor(backend, [AggFunc("sum", InputRef(2), abi.INT64)], [InputRef(0), InputRef(1)], [both]).execute())
+    return joined, [c.to_pylist() for c in g.columns]
+
+
+def test_two_column_keys_inherit_symmetric_combine(oracle):
+    joined, groups = symmetric_combine_case(oracle)
+    assert joined == [([1, 5], [2, 6], [2, 5], [1, 6])]   # (1,2) x (2,1) match by hash; (5,6) x (5,6) by value
+    assert groups == [[1, 9], [2, 9], [30, 30]]           # (1,2) and (2,1) are ONE group, keyed by its first row
