@@ -542,7 +542,9 @@ static void build_table(sqlrs_hash_join *j) {
   Ctx *ctx = j->ctx;
   // concat key parts
   int64_t n = j->nB;
-  BufP keys = ctx->alloc(8 * (size_t)std::max<int64_t>(n, 1));
+  // one build batch (the usual case): its normalised keys ARE the key array, no concat copy
+  const bool single = j->left_key_parts.size() == 1 && j->left_key_parts[0].keys && j->left_key_parts[0].keys->owned;
+  BufP keys = single ? j->left_key_parts[0].keys : ctx->alloc(8 * (size_t)std::max<int64_t>(n, 1));
   BufP validity;
   bool any_null = false;
   for (const NKeys &p : j->left_key_parts) any_null |= (p.validity != nullptr);
@@ -554,7 +556,7 @@ static void build_table(sqlrs_hash_join *j) {
     for (const NKeys &p : j->left_key_parts) {
       if (p.exact != j->exact || p.dtype != j->key_dtype)
         fail(SQLRS_ERR_ARROW, "join key type changed between build batches");
-      if (p.rows)
+      if (p.rows && !single)
         SQ_HIP(hipMemcpyAsync(keys->as<uint8_t>() + off, p.keys->p, 8 * (size_t)p.rows,
                               hipMemcpyDeviceToDevice, ctx->stream));
       off += 8 * (size_t)p.rows;

@@ -529,64 +529,82 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
 }
 
 // Tile list of level 2 from the chunk table: chunk c of digit s contributes ceil(len / tile) tiles to
-// segment s (any order of the chunks inside a segment).  One workgroup; <= a few hundred thousand chunks.
+// segment s (any order of the chunks inside a segment).  Three small launches (count per digit -> prefix
+// over <= 512 digits -> assign), <= a few hundred thousand chunks; a single workgroup doing all three took
+// 165 us per C5 step.
 // (The last tile of every (workgroup, digit) stream is partly filled; giving the level-2 workgroups tile
 // ranges of equal ROW counts instead of equal tile counts was measured SLOWER, 4.24 -> 4.8 ms: a partly
 // filled tile costs the pipeline as much as a full one.)
-__global__ __launch_bounds__(1024) void rp_chunk_plan_kernel(const uint32_t *__restrict__ chunk_len,
+struct ChunkPlan {            // device scratch, zeroed before the count kernel
+  uint32_t seg_tiles[512];    // tiles per digit
+  uint32_t cursor[512];       // assign kernel: next free tile slot of the digit
+  unsigned long long seg_rows[512];
+};
+__global__ __launch_bounds__(256) void rp_chunk_count_kernel(const uint32_t *__restrict__ chunk_len,
                                                              const uint32_t *__restrict__ chunk_dig,
                                                              const unsigned int *__restrict__ counter, uint32_t base_chunks,
-                                                             uint32_t max_chunks, uint32_t nseg, uint32_t digits2,
-                                                             uint32_t cap, uint32_t tile, int64_t *__restrict__ seg_start,
-                                                             int64_t *__restrict__ seg_mat, uint32_t *__restrict__ seg_tiles,
-                                                             uint32_t *__restrict__ seg_tile_base, Tile *__restrict__ tiles,
-                                                             uint64_t *__restrict__ totals /* {tiles, rows, overflow} */) {
-  __shared__ uint32_t s_tiles[512], s_base[512], s_cursor[512];
+                                                             uint32_t max_chunks, uint32_t tile, ChunkPlan *plan) {
+  __shared__ uint32_t s_tiles[512];
   __shared__ unsigned long long s_rows[512];
-  const uint32_t nchunks = min(base_chunks + counter[0], max_chunks);
-  for (uint32_t i = threadIdx.x; i < 512; i += 1024) {
+  for (uint32_t i = threadIdx.x; i < 512; i += 256) {
     s_tiles[i] = 0;
-    s_cursor[i] = 0;
     s_rows[i] = 0;
   }
   __syncthreads();
-  for (uint32_t c = threadIdx.x; c < nchunks; c += 1024) {
+  const uint32_t nchunks = min(base_chunks + counter[0], max_chunks);
+  for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nchunks; c += gridDim.x * 256) {
     const uint32_t len = chunk_len[c];
     if (!len) continue;
     atomicAdd(&s_tiles[chunk_dig[c]], (len + tile - 1) / tile);
     atomicAdd(&s_rows[chunk_dig[c]], (unsigned long long)len);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tb = 0;
-    int64_t rows = 0;
-    for (uint32_t s = 0; s < nseg; s++) {
-      seg_start[s] = rows;
-      seg_tile_base[s] = tb;
-      seg_mat[s] = (int64_t)tb * digits2;
-      seg_tiles[s] = s_tiles[s];
-      s_base[s] = tb;
-      tb += s_tiles[s];
-      rows += (int64_t)s_rows[s];
-    }
-    seg_start[nseg] = rows;
-    totals[0] = tb;
-    totals[1] = (uint64_t)rows;
-    totals[2] = counter[1];
+  for (uint32_t i = threadIdx.x; i < 512; i += 256) {
+    if (s_tiles[i]) atomicAdd(&plan->seg_tiles[i], s_tiles[i]);
+    if (s_rows[i]) atomicAdd(&plan->seg_rows[i], s_rows[i]);
   }
-  __syncthreads();
-  for (uint32_t c = threadIdx.x; c < nchunks; c += 1024) {
+}
+__global__ __launch_bounds__(64) void rp_chunk_prefix_kernel(const ChunkPlan *plan, const unsigned int *__restrict__ counter,
+                                                             uint32_t nseg, uint32_t digits2, int64_t *__restrict__ seg_start,
+                                                             int64_t *__restrict__ seg_mat, uint32_t *__restrict__ seg_tiles,
+                                                             uint32_t *__restrict__ seg_tile_base,
+                                                             uint64_t *__restrict__ totals /* {tiles, rows, overflow} */) {
+  if (threadIdx.x != 0) return;
+  uint32_t tb = 0;
+  int64_t rows = 0;
+  for (uint32_t s = 0; s < nseg; s++) {
+    seg_start[s] = rows;
+    seg_tile_base[s] = tb;
+    seg_mat[s] = (int64_t)tb * digits2;
+    seg_tiles[s] = plan->seg_tiles[s];
+    tb += plan->seg_tiles[s];
+    rows += (int64_t)plan->seg_rows[s];
+  }
+  seg_start[nseg] = rows;
+  totals[0] = tb;
+  totals[1] = (uint64_t)rows;
+  totals[2] = counter[1];
+}
+__global__ __launch_bounds__(256) void rp_chunk_assign_kernel(const uint32_t *__restrict__ chunk_len,
+                                                              const uint32_t *__restrict__ chunk_dig,
+                                                              const unsigned int *__restrict__ counter, uint32_t base_chunks,
+                                                              uint32_t max_chunks, uint32_t digits2, uint32_t cap, uint32_t tile,
+                                                              const uint32_t *__restrict__ seg_tiles,
+                                                              const uint32_t *__restrict__ seg_tile_base, ChunkPlan *plan,
+                                                              Tile *__restrict__ tiles) {
+  const uint32_t nchunks = min(base_chunks + counter[0], max_chunks);
+  for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nchunks; c += gridDim.x * 256) {
     const uint32_t len = chunk_len[c];
     if (!len) continue;
-    const uint32_t s = chunk_dig[c], nt = (len + tile - 1) / tile;
-    const uint32_t i0 = atomicAdd(&s_cursor[s], nt);
+    const uint32_t s = chunk_dig[c], nt = (len + tile - 1) / tile, base = seg_tile_base[s];
+    const uint32_t i0 = atomicAdd(&plan->cursor[s], nt);
     for (uint32_t q = 0; q < nt; q++) {
       Tile t;
       t.start = (int64_t)c * (cap + RP_CHUNK_SKEW) + (int64_t)q * tile;
       t.len = min(tile, len - q * tile);
-      t.stride = s_tiles[s];
-      t.mat = (int64_t)s_base[s] * digits2 + i0 + q;
-      tiles[s_base[s] + i0 + q] = t;
+      t.stride = seg_tiles[s];
+      t.mat = (int64_t)base * digits2 + i0 + q;
+      tiles[base + i0 + q] = t;
     }
   }
 }
@@ -922,10 +940,17 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         bind_level(L2, lay);
         L2.tiles = ctx->alloc(sizeof(Tile) * (size_t)max_chunks * (size_t)ct_env);
         BufP totals = ctx->alloc(24);
-        rp_chunk_plan_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(
-            co.chunk_len, co.chunk_dig, co.counter, co.base_chunks, co.max_chunks, d1, digits2, (uint32_t)CAP,
-            (uint32_t)RP_TILE, (int64_t *)L2.d_seg_start, (int64_t *)L2.d_seg_mat, (uint32_t *)L2.d_seg_tiles,
-            (uint32_t *)L2.d_seg_tile_base, (Tile *)L2.tiles->p, totals->as<uint64_t>());
+        BufP plan = ctx->alloc(sizeof(ChunkPlan));
+        SQ_HIP(hipMemsetAsync(plan->p, 0, sizeof(ChunkPlan), ctx->stream));
+        const unsigned pblocks = (unsigned)std::min<uint64_t>(ceil_div((int64_t)max_chunks, 256 * 8), 128);
+        rp_chunk_count_kernel<<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(co.chunk_len, co.chunk_dig, co.counter, co.base_chunks,
+                                                                          co.max_chunks, (uint32_t)RP_TILE, plan->as<ChunkPlan>());
+        rp_chunk_prefix_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(
+            plan->as<ChunkPlan>(), co.counter, d1, digits2, (int64_t *)L2.d_seg_start, (int64_t *)L2.d_seg_mat,
+            (uint32_t *)L2.d_seg_tiles, (uint32_t *)L2.d_seg_tile_base, totals->as<uint64_t>());
+        rp_chunk_assign_kernel<<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(
+            co.chunk_len, co.chunk_dig, co.counter, co.base_chunks, co.max_chunks, digits2, (uint32_t)CAP, (uint32_t)RP_TILE,
+            L2.d_seg_tiles, L2.d_seg_tile_base, plan->as<ChunkPlan>(), (Tile *)L2.tiles->p);
         SQ_HIP(hipGetLastError());
         const uint64_t *ht = (const uint64_t *)ctx->fetch(totals->p, 24);
         const uint64_t ntiles = ht[0], kept = ht[1], overflow = ht[2];

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf /tmp/tl
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-operators > /dev/null 2>&1 < /dev/null
 python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/tl/**/*kernel_trace.csv", recursive=True)[0]
@@ -13,8 +13,8 @@ if mc:
     for r in csv.DictReader(open(mc[0])):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "memcpy " + r.get("Direction", "")))
 rows.sort()
-# steps are delimited by filter_cmp_const launches; take the last three
-starts = [i for i, r in enumerate(rows) if "persistent_kernel" in r[2]]
+# steps are delimited by the join build's key_minmax_kernel; take the last three
+starts = [i for i, r in enumerate(rows) if "key_minmax_kernel" in r[2]]
 for si in range(len(starts) - 3, len(starts) - 1):
     seg = rows[starts[si]:starts[si + 1]]
     span = (seg[-1][1] - seg[0][0]) / 1e6

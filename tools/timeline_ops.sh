@@ -4,13 +4,13 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf /tmp/tl
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-operators > /dev/null 2>&1 < /dev/null
 python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/tl/**/*kernel_trace.csv", recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-60:], r.get("Grid_Size_X", "")) for r in csv.DictReader(open(f))]
 rows.sort()
-starts = [i for i, r in enumerate(rows) if "persistent_kernel" in r[2]]
+starts = [i for i, r in enumerate(rows) if "key_minmax_kernel" in r[2]]
 seg = rows[starts[-2]:starts[-1]]
 prev = seg[0][0]
 for s, e, name, grid in seg:
