@@ -60,6 +60,10 @@ struct Pool {
   size_t live_bytes = 0, cached_bytes = 0;
   bool closed = false; // the ctx is gone: no stream to order reuse on, blocks go straight back to the driver
   int device = 0;
+  // optional arena (SQLRS_POOL_RESERVE_GB): ONE hipMalloc at ctx creation that new blocks are carved from
+  uint8_t *arena = nullptr;
+  size_t arena_bytes = 0, arena_used = 0;
+  bool in_arena(const void *p) const { return arena && (const uint8_t *)p >= arena && (const uint8_t *)p < arena + arena_bytes; }
   void *alloc(size_t bytes, size_t *cap);
   void release(void *p, size_t cap);
   void trim();

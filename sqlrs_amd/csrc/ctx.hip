@@ -33,6 +33,13 @@ void *Pool::alloc(size_t bytes, size_t *cap) {
     return p;
   }
   void *p = nullptr;
+  if (arena && arena_used + want <= arena_bytes) { // carve from the reserved arena
+    p = arena + arena_used;
+    arena_used += want;
+    *cap = want;
+    live_bytes += want;
+    return p;
+  }
   hipError_t e = hipMalloc(&p, want);
   if (e != hipSuccess) {
     trim();
@@ -47,6 +54,7 @@ void *Pool::alloc(size_t bytes, size_t *cap) {
 void Pool::release(void *p, size_t cap) {
   live_bytes -= cap;
   if (closed) { // the ctx (and its stream) is gone: nothing can be in flight on it any more
+    if (in_arena(p)) return; // (the arena itself is leaked with a closed pool: only when batches outlive their ctx)
     int cur = -1;
     (void)hipGetDevice(&cur);
     if (cur != device) (void)hipSetDevice(device);
@@ -58,9 +66,17 @@ void Pool::release(void *p, size_t cap) {
   free_blocks.emplace(cap, p);
 }
 void Pool::trim() {
-  for (auto &kv : free_blocks) (void)hipFree(kv.second);
-  free_blocks.clear();
-  cached_bytes = 0;
+  size_t kept = 0;
+  std::multimap<size_t, void *> keep;
+  for (auto &kv : free_blocks) {
+    if (in_arena(kv.second)) { // arena blocks cannot go back to the driver one by one: they stay cached
+      keep.emplace(kv.first, kv.second);
+      kept += kv.first;
+    } else
+      (void)hipFree(kv.second);
+  }
+  free_blocks.swap(keep);
+  cached_bytes = kept;
 }
 
 Buf::Buf(Ctx *c, void *ptr, size_t n) : ctx(c), pool(c->pool_ref), p(ptr), cap(n) {}
@@ -506,6 +522,14 @@ int sqlrs_ctx_create(int device_id, sqlrs_ctx_t **out) {
     return SQLRS_ERR_DEVICE;
   }
   c->pinned_bytes = 4096;
+  if (const char *e = std::getenv("SQLRS_POOL_RESERVE_GB")) { // experiment / deployment knob: one up-front allocation
+    const size_t bytes = (size_t)std::atof(e) * (1ull << 30);
+    void *p = nullptr;
+    if (bytes && hipMalloc(&p, bytes) == hipSuccess) {
+      c->pool.arena = (uint8_t *)p;
+      c->pool.arena_bytes = bytes;
+    }
+  }
   *out = c;
   return SQLRS_OK;
 }
@@ -524,6 +548,11 @@ void sqlrs_ctx_destroy(sqlrs_ctx_t *ctx) {
   ctx->pool.trim();
   // batches this ctx produced may be released later: their blocks hold the pool alive and are handed
   // back to the driver directly from then on (operators must be destroyed BEFORE their ctx)
+  if (ctx->pool.arena && ctx->pool.live_bytes == 0) { // nothing outlives the ctx: the arena goes back
+    ctx->pool.free_blocks.clear();
+    (void)hipFree(ctx->pool.arena);
+    ctx->pool.arena = nullptr;
+  }
   ctx->pool.closed = true;
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipStreamDestroy(ctx->stream);

@@ -18,7 +18,7 @@ pipe = bench.Pipeline(be, abi, 0.5)
 def step():
     pipe.step(bench.device_batch(abi, [dk], [abi.INT64]), bench.device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64])).release()
 VAR = os.environ.get("VAR", "SQLRS_RP_CHUNK_TILES")  # a hook the library reads per call
-for rep in range(3):
+for rep in range(int(os.environ.get("REPS", 3))):
     for st in os.environ.get("VALUES", "1").split(","):
         os.environ[VAR] = st
         step(); be.synchronize()
