@@ -792,7 +792,11 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
         by = 8 * nB + 8 * nP + 12 * m[0]
         res[f"C3_join_{hit}"] = {"probe_rows": nP, "build_rows": nB, "pairs": m[0], "ms_build_probe": round(ms_all, 3),
                                  "ms_probe": round(ms_probe, 3), "probe_Mrows_s": round(nP / ms_probe / 1e3, 1),
-                                 "GBps": round(by / ms_all / 1e6, 1), "frac": round(by / ms_all / 1e6 / HBM_PEAK_GBPS, 4)}
+                                 "GBps": round(by / ms_all / 1e6, 1), "frac": round(by / ms_all / 1e6 / HBM_PEAK_GBPS, 4),
+                                 # what bounds the probe: random 16-byte table reads, not the HBM stream
+                                 "bound": ("L1 (TCP) request concurrency x L2 latency: 64 table reads in flight per CU, "
+                                           "TCP_PENDING_STALL 77 % (profiles/r02_probe_pmc_ta.txt)" if not sparse else
+                                           "random 16-byte reads of a 32 MB hash table: 65 G reads/s beyond the 4 MB L2 of one XCD")}
         del fk
     # ---- C4: 2e8 rows, 1e6 int64 groups, COUNT(val), SUM(val) f64
     n, G = 200_000_000, 1_000_000

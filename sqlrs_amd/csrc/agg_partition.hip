@@ -187,6 +187,20 @@ __device__ __forceinline__ void lds_agg_load(const uint64_t *__restrict__ pk, co
   }
 }
 
+// the same from {key|row word, value 0} records (radix_part.hpp PartitionedRows::rec): one 16-byte load per row
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+template <int NV>
+__device__ __forceinline__ void lds_agg_load_rec(const uint64_t *__restrict__ prec, int64_t i0, int64_t hi, AggRows<NV> &r) {
+#pragma unroll
+  for (int u = 0; u < LDS_U; u++) {
+    int64_t i = min(i0 + (int64_t)u * PART_WG, hi - 1);
+    const u64x2 t = __builtin_nontemporal_load((const u64x2 *)prec + i);
+    r.k[u] = t.x;
+    r.v0[0 + (NV >= 1 ? u : 0)] = t.y;
+    r.f[u] = 7;
+  }
+}
+
 // global tables of the split (skewed) buckets: nsplit tables of nslots = cap + 2 slots
 struct SplitTables {
   unsigned long long *key = nullptr;  // [nsplit][nslots], LDS_EMPTY
@@ -234,7 +248,8 @@ __global__ void split_emit_kernel(SplitTables stb, uint32_t nslots, uint32_t cap
 // it from `prm`.  JOIN: fused inner join, the bucket's build keys are inserted first and probe
 // rows only accumulate into slots that exist.
 // PACK: `pk` holds packed (key, row) words (radix_part.hpp KeyPack) and there is no `pi` column.
-template <int NV, bool FLAGS, bool JOIN, int NACC, int C0, int C1, bool PACK>
+// REC (PACK, one value column, nothing nullable): `pk` holds {key|row word, value} records, pv0 is unused.
+template <int NV, bool FLAGS, bool JOIN, int NACC, int C0, int C1, bool PACK, bool REC = false>
 __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     LdsAggParams prm, const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pi,
     const uint64_t *__restrict__ pv0, const uint64_t *__restrict__ pv1,
@@ -258,7 +273,10 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
   unsigned long long *tacc = tab + nslots;
   unsigned int *tfirst = (unsigned int *)(tacc + (size_t)n_acc * nslots);
   AggRows<NV> cur, nxt;
-  if (lo < hi) lds_agg_load<NV, FLAGS, PACK>(pk, pi, pv0, pv1, pf, lo + threadIdx.x, hi, cur); // in flight during the set-up
+  if (lo < hi) { // in flight during the set-up
+    if (REC) lds_agg_load_rec<NV>(pk, lo + threadIdx.x, hi, cur);
+    else lds_agg_load<NV, FLAGS, PACK>(pk, pi, pv0, pv1, pf, lo + threadIdx.x, hi, cur);
+  }
   for (uint32_t s = threadIdx.x; s < nslots; s += PART_WG) {
     tkey[s] = LDS_EMPTY;
     tfirst[s] = 0xffffffffu;
@@ -299,7 +317,8 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
   for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {
     const int64_t i0 = base + threadIdx.x;
     // next trip's rows (the last trip re-reads the last rows of the bucket)
-    lds_agg_load<NV, FLAGS, PACK>(pk, pi, pv0, pv1, pf, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
+    if (REC) lds_agg_load_rec<NV>(pk, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
+    else lds_agg_load<NV, FLAGS, PACK>(pk, pi, pv0, pv1, pf, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
     // first probe of all LDS_U rows: the table reads are independent and issue together
     uint32_t slot[LDS_U];
     unsigned long long seen[LDS_U];
@@ -532,7 +551,7 @@ __global__ void split_emit_dense_kernel(SplitTables stb, const uint32_t *__restr
   for (int a = 0; a < n_acc; a++) gacc[(size_t)a * gcap + base] = stb.acc[(size_t)a * total + i];
 }
 
-template <int NV, bool JOIN, int NACC, int C0, int C1>
+template <int NV, bool JOIN, int NACC, int C0, int C1, bool REC = false>
 __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
     LdsAggParams prm, const uint64_t *__restrict__ pk, const uint64_t *__restrict__ pv0,
     const uint32_t *__restrict__ work, unsigned long long *out_count, uint64_t *__restrict__ gkey,
@@ -550,7 +569,10 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
   unsigned long long *tacc = tab;
   unsigned int *tfirst = (unsigned int *)(tacc + (size_t)n_acc * R);
   AggRows<NV> cur, nxt;
-  if (lo < hi) lds_agg_load<NV, false, true>(pk, nullptr, pv0, nullptr, nullptr, lo + threadIdx.x, hi, cur);
+  if (lo < hi) {
+    if (REC) lds_agg_load_rec<NV>(pk, lo + threadIdx.x, hi, cur);
+    else lds_agg_load<NV, false, true>(pk, nullptr, pv0, nullptr, nullptr, lo + threadIdx.x, hi, cur);
+  }
   for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
     tfirst[s] = 0xffffffffu;
 #pragma unroll
@@ -564,7 +586,8 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
   for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {
     const int64_t i0 = base + threadIdx.x;
-    lds_agg_load<NV, false, true>(pk, nullptr, pv0, nullptr, nullptr, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
+    if (REC) lds_agg_load_rec<NV>(pk, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
+    else lds_agg_load<NV, false, true>(pk, nullptr, pv0, nullptr, nullptr, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
       const uint64_t off = packed_off(kp, cur.k[u]);
@@ -1000,9 +1023,12 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
 #define SQ_LA(NV, FL, JN, NA, C0, C1, PK)                                                                        \
   do {                                                                                                         \
     auto kfn = lds_agg_kernel<NV, FL, JN, NA, C0, C1, PK>;                                                      \
+    constexpr bool can_rec = NV == 1 && PK && !FL;                                                             \
+    if (can_rec && pr.rec) kfn = lds_agg_kernel<NV, FL, JN, NA, C0, C1, PK, can_rec>;                          \
+    else if (pr.rec) fail(SQLRS_ERR_INTERNAL, "record-form partition in a column-form bucket pass");           \
     allow_big_lds(ctx, kfn);                                                                                   \
     kfn<<<dim3(nwork), dim3(PART_WG), lds, ctx->stream>>>(                                                     \
-        prm, pk->as<uint64_t>(), pi ? pi->as<uint32_t>() : nullptr, pv0 ? pv0->as<uint64_t>() : nullptr,       \
+        prm, pr.rec ? pr.rec->as<uint64_t>() : pk->as<uint64_t>(), pi ? pi->as<uint32_t>() : nullptr, pv0 ? pv0->as<uint64_t>() : nullptr,       \
         pv1 ? pv1->as<uint64_t>() : nullptr, pf ? pf->as<uint8_t>() : nullptr, dwork->as<uint32_t>(), P, n,    \
         ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(),                 \
         out->gvalid ? out->gvalid->as<uint8_t>() : nullptr, out->gacc->as<uint64_t>(), gcap,                   \
@@ -1021,15 +1047,16 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
       else SQ_LA(NV, FL, false, NA, C0, C1, false);                                                            \
     }                                                                                                          \
   } while (0)
-    const int nvu = pv1 ? 2 : (pv0 ? 1 : 0);
+    const int nvu = pv1 ? 2 : ((pv0 || pr.rec) ? 1 : 0);
     bool launched = false;
     if (dense) { // direct-addressed tables (packed rows, nothing nullable, at most one value column)
 #define SQ_LD(NV, JN, NA, C0, C1)                                                                              \
   do {                                                                                                         \
     auto kfn = lds_agg_dense_kernel<NV, JN, NA, C0, C1>;                                                        \
+    if (NV == 1 && pr.rec) kfn = lds_agg_dense_kernel<NV, JN, NA, C0, C1, NV == 1>;                            \
     allow_big_lds(ctx, kfn);                                                                                   \
     kfn<<<dim3(nwork), dim3(PART_WG), lds, ctx->stream>>>(                                                     \
-        prm, pk->as<uint64_t>(), pv0 ? pv0->as<uint64_t>() : nullptr, dwork->as<uint32_t>(),                   \
+        prm, pr.rec ? pr.rec->as<uint64_t>() : pk->as<uint64_t>(), pv0 ? pv0->as<uint64_t>() : nullptr, dwork->as<uint32_t>(), \
         ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(),                 \
         out->gacc->as<uint64_t>(), gcap, pr.pack, stb);                                                        \
     launched = true;                                                                                           \

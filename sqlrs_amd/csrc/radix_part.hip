@@ -125,10 +125,12 @@ struct RpIn {
   const uint8_t *flags;    // null at level 1: built from the bitmaps
   const uint64_t *key_validity, *v0_validity, *v1_validity;
 };
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 struct RpOut {
   uint64_t *key, *v0, *v1;
   uint32_t *idx;
   uint8_t *flags; // null when no column is nullable
+  u64x2 *rec = nullptr; // REC kernels: {packed key|row word, value 0} records instead of key / v0
 };
 
 // How a level reads its rows (template parameter of the scatter kernel, so the unrolled load
@@ -187,7 +189,7 @@ __device__ __forceinline__ void rp_load_tile(const RpIn &in, const Tile &t, uint
 // it: the rows of tile i+1 are loaded into a second register set before tile i goes through its
 // LDS phases (rank with LDS atomics -> scan -> stage sorted -> coalesced stores), which hides the
 // HBM latency that a 150 KiB-LDS kernel (one workgroup per CU) cannot hide with occupancy.
-template <int NV, int RP_WG, int RP_ROWS, int MODE, bool PACK>
+template <int NV, int RP_WG, int RP_ROWS, int MODE, bool PACK, bool REC = false>
 __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV <= 1)) ? 2 : 1) void rp_scatter_kernel(RpIn in, RpOut out,
                                                            const Tile *__restrict__ tiles, uint32_t P,
                                                            uint32_t p2_bits, int level, uint32_t digits,
@@ -271,6 +273,13 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
     const uint32_t d = PACK ? rp_digit(rp_bucket(kp, packed_key(kp, kw), true, P), level, p2_bits) : sdig[p];
     int64_t g = gbase[d & (RP_WG - 1)] + p;
     if (p >= len) g = sink + threadIdx.x;
+    if (REC) {
+      u64x2 rec;
+      rec.x = kw;
+      rec.y = sv0[NV >= 1 ? p : 0];
+      out.rec[g] = rec;
+      return;
+    }
     out.key[g] = kw;
     if (NV >= 1) out.v0[g] = sv0[p];
     if (NV >= 2) out.v1[g] = sv1[p];
@@ -743,6 +752,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   const bool pack = !flags && nv <= 1 && in.pack.kbits != 0 && in.pack.kbits + rowbits <= 64;
   const KeyPack kp = pack ? in.pack : KeyPack();
   out->pack = kp;
+  out->rec = nullptr;
   const int WG = 512;
   // rows per thread: 12 -> 6144-row tiles, 8 -> 4096-row tiles (two value columns); one
   // workgroup per CU either way (the staging area is ~140 KiB)
@@ -757,15 +767,37 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // (staggering the columns' start offsets inside their 2 MiB aligned blocks — same row, same HBM channel?
   //  — changed nothing; the 10-15 % spread of these kernels between processes follows physical placement)
   auto staggered = [&](size_t bytes, int) { return ctx->alloc(bytes); };
-  auto alloc_cols = [&](int64_t rows, BufP &k, BufP &v0, BufP &v1, BufP &idx, BufP &fl) {
-    const size_t np = (size_t)rows + WG; // + the sink rows of rp_scatter_kernel
-    k = staggered(8 * np, 0);
-    v0 = nv >= 1 ? staggered(8 * np, 1) : nullptr;
-    v1 = nv >= 2 ? staggered(8 * np, 2) : nullptr;
-    idx = pack ? nullptr : staggered(4 * np, 3);
-    fl = flags ? ctx->alloc(np) : nullptr;
+  // final level of a packed partition with one value column: 16-byte {key|row word, value} records instead of
+  // two 8-byte columns — one store per row here, one load per row in the bucket pass, and a (tile, digit) run
+  // of ~24 rows covers three cache lines instead of 2 x 1.5 (C5: level 2 4.93 -> 4.26 ms, bucket pass 1.81 ->
+  // 1.67 ms in one process)
+  const char *rec_e = std::getenv("SQLRS_RP_REC"); // read per call: 0 = column form (in-process A/B, tools/ab_in_process.py)
+  const bool use_rec = pack && nv == 1 && ROWS == 12 && !(rec_e && std::atoi(rec_e) == 0);
+  struct Cols {
+    BufP k, v0, v1, idx, fl, rec;
   };
-
+  auto alloc_cols = [&](int64_t rows, bool final_level, Cols &c, RpOut &ro) {
+    const size_t np = (size_t)rows + WG; // + the sink rows of rp_scatter_kernel
+    c = Cols();
+    if (final_level && use_rec) {
+      c.rec = ctx->alloc(16 * np);
+    } else {
+      c.k = staggered(8 * np, 0);
+      c.v0 = nv >= 1 ? staggered(8 * np, 1) : nullptr;
+    }
+    c.v1 = nv >= 2 ? staggered(8 * np, 2) : nullptr;
+    c.idx = pack ? nullptr : staggered(4 * np, 3);
+    c.fl = flags ? ctx->alloc(np) : nullptr;
+    ro.key = c.k ? c.k->as<uint64_t>() : nullptr;
+    ro.v0 = c.v0 ? c.v0->as<uint64_t>() : nullptr;
+    ro.v1 = c.v1 ? c.v1->as<uint64_t>() : nullptr;
+    ro.idx = c.idx ? c.idx->as<uint32_t>() : nullptr;
+    ro.flags = c.fl ? c.fl->as<uint8_t>() : nullptr;
+    ro.rec = c.rec ? (u64x2 *)c.rec->p : nullptr;
+  };
+  auto publish = [&](const Cols &c) {
+    out->key = c.k; out->v0 = c.v0; out->v1 = c.v1; out->idx = c.idx; out->flags = c.fl; out->rec = c.rec;
+  };
   // one level = hist + scan + scatter over the tiles of `L` (sink = first row behind the output columns)
   auto exec_level = [&](int level, uint32_t digits, const Level &L, const RpIn &rin, const RpOut &rout, int64_t sink,
                         BufP *offs_out) {
@@ -808,10 +840,12 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       const int mode = level == 1 ? (flags ? RP_L1_NULL : RP_L1) : (flags ? RP_LN_FLAG : RP_LN);
 #define SQ_RP1(NV, R, M, PK)                                                                                  \
   do {                                                                                                        \
+    constexpr bool can_rec = NV == 1 && PK && R == 12;                                                        \
     auto kfn = rp_scatter_kernel<NV, 512, R, M, PK>;                                                          \
+    if (can_rec && rout.rec) kfn = rp_scatter_kernel<NV, 512, R, M, PK, can_rec>;                             \
     allow_big_lds(ctx, kfn);                                                                                  \
     kfn<<<g, b, lds, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs_tm->as<uint32_t>(), nt, tpw, \
-                                    sink, kp);                                                                \
+                                    sink, kp);                                                                  \
   } while (0)
 #define SQ_RP(NV, R)                                                                                          \
   do {                                                                                                        \
@@ -959,8 +993,6 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         L2.mat_entries = (int64_t)ntiles * digits2;
         out->n = (int64_t)kept;
         out->P = P;
-        BufP k2, a2, b2, i2, f2;
-        alloc_cols((int64_t)kept, k2, a2, b2, i2, f2);
         RpIn rin2;
         rin2.key = ck->as<uint64_t>();
         rin2.v0 = co.v0;
@@ -968,15 +1000,12 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         rin2.idx = co.idx;
         rin2.flags = nullptr;
         rin2.key_validity = rin2.v0_validity = rin2.v1_validity = nullptr;
+        Cols c2;
         RpOut rout2;
-        rout2.key = k2->as<uint64_t>();
-        rout2.v0 = a2 ? a2->as<uint64_t>() : nullptr;
-        rout2.v1 = b2 ? b2->as<uint64_t>() : nullptr;
-        rout2.idx = i2 ? i2->as<uint32_t>() : nullptr;
-        rout2.flags = nullptr;
+        alloc_cols((int64_t)kept, true, c2, rout2);
         BufP offs2;
         exec_level(2, digits2, L2, rin2, rout2, (int64_t)kept, &offs2);
-        out->key = k2; out->v0 = a2; out->v1 = b2; out->idx = i2; out->flags = nullptr;
+        publish(c2);
         out->bstart = bucket_starts(L2, offs2, digits2, (int64_t)kept, &out->bstart_host);
         return true;
       }
@@ -984,8 +1013,9 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   }
 
   // ---- level 1
-  BufP k1, a1, b1, i1, f1;
-  alloc_cols(n, k1, a1, b1, i1, f1);
+  Cols c1;
+  RpOut rout;
+  alloc_cols(n, p2_bits == 0, c1, rout);
   RpIn rin;
   rin.key = in.keys;
   rin.v0 = (const uint64_t *)in.vals[0];
@@ -995,12 +1025,6 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   rin.key_validity = in.key_validity;
   rin.v0_validity = in.val_validity[0];
   rin.v1_validity = in.val_validity[1];
-  RpOut rout;
-  rout.key = k1->as<uint64_t>();
-  rout.v0 = a1 ? a1->as<uint64_t>() : nullptr;
-  rout.v1 = b1 ? b1->as<uint64_t>() : nullptr;
-  rout.idx = i1 ? i1->as<uint32_t>() : nullptr;
-  rout.flags = f1 ? f1->as<uint8_t>() : nullptr;
   BufP offs1;
   Level L1;
   run_level(1, d1, {0, n}, rin, rout, &offs1, &L1);
@@ -1009,32 +1033,27 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   out->n = n;
   out->P = P;
   if (p2_bits == 0) {
-    out->key = k1; out->v0 = a1; out->v1 = b1; out->idx = i1; out->flags = f1;
+    publish(c1);
     out->bstart = bs1;
     out->bstart_host = std::move(hs);
     return true;
   }
   // ---- level 2: every level-1 bucket is one segment
   std::vector<int64_t> seg(hs.begin(), hs.end());
-  BufP k2, a2, b2, i2, f2;
-  alloc_cols(n, k2, a2, b2, i2, f2);
-  RpIn rin2;
-  rin2.key = k1->as<uint64_t>();
-  rin2.v0 = a1 ? a1->as<uint64_t>() : nullptr;
-  rin2.v1 = b1 ? b1->as<uint64_t>() : nullptr;
-  rin2.idx = i1 ? i1->as<uint32_t>() : nullptr;
-  rin2.flags = f1 ? f1->as<uint8_t>() : nullptr;
-  rin2.key_validity = rin2.v0_validity = rin2.v1_validity = nullptr;
+  Cols c2;
   RpOut rout2;
-  rout2.key = k2->as<uint64_t>();
-  rout2.v0 = a2 ? a2->as<uint64_t>() : nullptr;
-  rout2.v1 = b2 ? b2->as<uint64_t>() : nullptr;
-  rout2.idx = i2 ? i2->as<uint32_t>() : nullptr;
-  rout2.flags = f2 ? f2->as<uint8_t>() : nullptr;
+  alloc_cols(n, true, c2, rout2);
+  RpIn rin2;
+  rin2.key = rout.key;
+  rin2.v0 = rout.v0;
+  rin2.v1 = rout.v1;
+  rin2.idx = rout.idx;
+  rin2.flags = rout.flags;
+  rin2.key_validity = rin2.v0_validity = rin2.v1_validity = nullptr;
   BufP offs2;
   Level L2;
   run_level(2, 1u << p2_bits, seg, rin2, rout2, &offs2, &L2);
-  out->key = k2; out->v0 = a2; out->v1 = b2; out->idx = i2; out->flags = f2;
+  publish(c2);
   out->bstart = bucket_starts(L2, offs2, 1u << p2_bits, n, &out->bstart_host);
   return true;
 }

@@ -71,6 +71,7 @@ struct PartitionedRows {
   int64_t n = 0; // rows in bucket order (= input rows that passed PartitionInput::filter)
   uint32_t P = 0;
   BufP key, v0, v1, idx, flags;
+  BufP rec;    // packed dense partitions with one value column: {key|row word, value} records; key / v0 are null then
   BufP bstart; // u32[P + 1]
   std::vector<uint32_t> bstart_host; // the same on the host
   KeyPack pack; // kbits != 0: `key` holds packed (key, row) words and `idx` is null

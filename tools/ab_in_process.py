@@ -29,4 +29,4 @@ for rep in range(int(os.environ.get("REPS", 3))):
         be.synchronize()
         ms = (time.perf_counter() - t) / 5 * 1e3
         pr = be.profile_read(); be.profile(False)
-        print(f"{VAR}={st:>6}: step {ms:6.2f} ms | " + " ".join(f"{k} {v[0]/max(v[1],1):.2f}" for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])[:4]), flush=True)
+        print(f"{VAR}={st:>6}: step {ms:6.2f} ms | " + " ".join(f"{k} {v[0]/max(v[1],1):.2f}" for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get('TOP', 4))]), flush=True)
