@@ -876,7 +876,7 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     def run_order():
         h = C.c_void_p()
         be.check(be.fn("order_create")(be.ctx, 1, obs, C.byref(h)))
-        be.check(be.fn("order_push")(h, bo.ptr))
+        be.check(be.fn("order_push_retained")(h, bo.ptr))  # `bo` outlives the sort (order.rs:19-26 keeps Arcs)
         o = C.POINTER(abi.Batch)()
         be.check(be.fn("order_finish")(h, D, C.byref(o)))
         be.fn("batch_release")(o)

@@ -303,6 +303,7 @@ class Backend:
             "ctx_stream": (vp, [vp]),
             "ctx_wait_stream": (i, [vp, vp]),
             "ctx_release_to_stream": (i, [vp, vp]),
+            "order_push_retained": (i, [vp, pb]),
             "ctx_pool_bytes": (C.c_int64, [vp]),
             "ctx_pool_trim": (None, [vp]),
             "batch_copy": (i, [vp, pb, i, ppb]),

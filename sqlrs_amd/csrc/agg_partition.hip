@@ -188,7 +188,6 @@ __device__ __forceinline__ void lds_agg_load(const uint64_t *__restrict__ pk, co
 }
 
 // the same from {key|row word, value 0} records (radix_part.hpp PartitionedRows::rec): one 16-byte load per row
-typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 template <int NV>
 __device__ __forceinline__ void lds_agg_load_rec(const uint64_t *__restrict__ prec, int64_t i0, int64_t hi, AggRows<NV> &r) {
 #pragma unroll

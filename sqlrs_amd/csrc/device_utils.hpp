@@ -7,6 +7,9 @@
 
 namespace sq {
 
+// two 8-byte words moved with one 16-byte load / store (a {key|row word, value} record)
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;          // 4 waves
 constexpr int WAVES_PER_BLOCK = 4;

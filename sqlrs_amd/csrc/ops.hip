@@ -220,11 +220,11 @@ int sqlrs_order_create(sqlrs_ctx_t *ctx, int num_keys, const sqlrs_order_by_t *o
   });
 }
 
-static int order_push_device(sqlrs_order_t *o, const sqlrs_batch_t *in) {
+static int order_push_device(sqlrs_order_t *o, const sqlrs_batch_t *in, bool retained = false) {
   return guard(o->ctx, [&] {
     SQ_HIP(hipSetDevice(o->ctx->device));
     InBatch ib(o->ctx, in);
-    o->batches.push_back(ib.materialize(true));
+    o->batches.push_back(ib.materialize(!retained)); // retained: borrowed device columns stay where they are
   });
 }
 static int order_flush_host(sqlrs_order_t *o) {
@@ -252,6 +252,13 @@ int sqlrs_order_push(sqlrs_order_t *o, const sqlrs_batch_t *in) {
 }
 
 // [ref: order.rs:27-66] concat -> lexsort_to_indices (nulls first, stable) -> take
+// [ref: order.rs:19-26 pushes the child's batches — Arc'd arrays — into a Vec: nothing is copied]
+int sqlrs_order_push_retained(sqlrs_order_t *o, const sqlrs_batch_t *in) {
+  o->hstage.ctx = o->ctx;
+  int st = order_flush_host(o);
+  return st != SQLRS_OK ? st : order_push_device(o, in, true);
+}
+
 int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
   int stf = order_flush_host(o);
   if (stf != SQLRS_OK) return stf;

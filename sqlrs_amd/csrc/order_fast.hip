@@ -84,19 +84,43 @@ __device__ __forceinline__ uint64_t ow_word(const void *__restrict__ src, int64_
   return __builtin_nontemporal_load((const uint64_t *)src + i);
 }
 
-template <int KIND, bool RAW>
+// TILED: the pass runs over the tile list `tiles` (tiles aligned to the digit segments of the previous pass, see
+// ow_tile_plan_kernel) instead of over fixed 4096-row blocks; a list entry of length 0 is a spare slot.
+struct OwTile {
+  int64_t start;
+  uint32_t len, pad;
+};
+template <bool TILED>
+__device__ __forceinline__ void ow_tile_of(const OwTile *__restrict__ tiles, int64_t n, int64_t &t0, uint32_t &tl) {
+  if (TILED) {
+    t0 = tiles[blockIdx.x].start;
+    tl = tiles[blockIdx.x].len;
+  } else {
+    t0 = (int64_t)blockIdx.x * OW_TILE;
+    tl = (uint32_t)min<int64_t>(OW_TILE, n - t0);
+  }
+}
+
+template <int KIND, bool RAW, bool TILED = false>
 __global__ __launch_bounds__(OW_WG) void ow_hist_kernel(const void *__restrict__ src, int64_t n, int desc, uint64_t imin,
-                                                        int shift, int64_t nblocks, uint32_t *__restrict__ hist) {
+                                                        int shift, int64_t nblocks, uint32_t *__restrict__ hist,
+                                                        const OwTile *__restrict__ tiles) {
   __shared__ uint32_t h[256];
+  int64_t t0;
+  uint32_t tl;
+  ow_tile_of<TILED>(tiles, n, t0, tl);
+  if (TILED && tl == 0) {
+    if (threadIdx.x < 256) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = 0;
+    return;
+  }
   if (threadIdx.x < 256) h[threadIdx.x] = 0;
-  const int64_t base = (int64_t)blockIdx.x * OW_TILE + threadIdx.x;
   uint64_t k[OW_ITEMS];
 #pragma unroll
-  for (int r = 0; r < OW_ITEMS; r++) k[r] = ow_word<KIND, RAW>(src, min(base + r * OW_WG, n - 1), desc, imin);
+  for (int r = 0; r < OW_ITEMS; r++) k[r] = ow_word<KIND, RAW>(src, t0 + min((uint32_t)(threadIdx.x + r * OW_WG), tl - 1), desc, imin);
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < OW_ITEMS; r++)
-    if (base + r * OW_WG < n) atomicAdd(&h[(k[r] >> shift) & 255], 1u);
+    if ((uint32_t)(threadIdx.x + r * OW_WG) < tl) atomicAdd(&h[(k[r] >> shift) & 255], 1u);
   __syncthreads();
   if (threadIdx.x < 256) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
@@ -128,11 +152,14 @@ __device__ __forceinline__ void stable_wave_ranks(const uint32_t (&dig)[ITEMS], 
   }
 }
 
-template <int KIND, bool RAW, int NPAY>
+// REC (NPAY == 1): the pass writes {word, carried value} records into `words_out` (16 B per row) — what the
+// in-LDS finish reads; a (tile, digit) run of 16 rows is one 256-byte piece instead of 128 B in each of two columns
+template <int KIND, bool RAW, int NPAY, bool TILED = false, bool REC = false>
 __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay,
                                                            int64_t n, int desc, uint64_t imin, int shift, int64_t nblocks,
                                                            const uint32_t *__restrict__ offsets,
-                                                           uint64_t *__restrict__ words_out, uint64_t *__restrict__ pay_out) {
+                                                           uint64_t *__restrict__ words_out, uint64_t *__restrict__ pay_out,
+                                                           const OwTile *__restrict__ tiles) {
   __shared__ uint64_t sword[OW_TILE];
   __shared__ uint64_t spay[NPAY ? OW_TILE : 1];
   __shared__ uint32_t wcnt[OW_WAVES][256];
@@ -140,12 +167,15 @@ __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restric
   __shared__ int64_t gbase[256];
   __shared__ uint32_t s_wsum[4];
   const int w = wave_id(), lane = lane_id();
-  const int64_t tbase = (int64_t)blockIdx.x * OW_TILE;
-  const int64_t wrow = tbase + (int64_t)w * (OW_ITEMS * 64) + lane;
+  int64_t tbase;
+  uint32_t len;
+  ow_tile_of<TILED>(tiles, n, tbase, len);
+  if (TILED && len == 0) return;
+  const uint32_t wrow = (uint32_t)w * (OW_ITEMS * 64) + lane; // element of the tile
   uint64_t k[OW_ITEMS], v[NPAY ? OW_ITEMS : 1];
 #pragma unroll
   for (int j = 0; j < OW_ITEMS; j++) {
-    const int64_t i = min(wrow + j * 64, n - 1);
+    const int64_t i = tbase + min(wrow + j * 64, len - 1);
     k[j] = ow_word<KIND, RAW>(src, i, desc, imin);
     if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
   }
@@ -156,7 +186,7 @@ __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restric
   bool valid[OW_ITEMS];
 #pragma unroll
   for (int j = 0; j < OW_ITEMS; j++) {
-    valid[j] = wrow + j * 64 < n;
+    valid[j] = wrow + j * 64 < len;
     dig[j] = (uint32_t)(k[j] >> shift) & 255u;
   }
   stable_wave_ranks<OW_ITEMS>(dig, valid, wcnt[w], rnk);
@@ -190,17 +220,86 @@ __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restric
     if (NPAY) spay[p] = v[j];
   }
   __syncthreads();
-  const uint32_t len = (uint32_t)min<int64_t>(OW_TILE, n - tbase);
 #pragma unroll
   for (int j = 0; j < OW_ITEMS; j++) {
     const uint32_t p = j * OW_WG + threadIdx.x;
     if (p < len) {
       const uint64_t kk = sword[p];
       const int64_t g = gbase[(uint32_t)(kk >> shift) & 255u] + p;
+      if (REC) {
+        u64x2 rec;
+        rec.x = kk;
+        rec.y = spay[NPAY ? p : 0];
+        ((u64x2 *)words_out)[g] = rec;
+        continue;
+      }
       words_out[g] = kk;
       if (NPAY) pay_out[g] = spay[p];
     }
   }
+}
+
+// ---- segment-aligned tiles for the last HBM pass ---------------------------------------------------------
+// After the first pass the rows are grouped by its digit (segment d = rows [S[d], S[d+1]), S read from the
+// scanned count matrix of that pass).  The last pass runs over tiles that never cross a segment boundary, so
+// the rows of group (hi, lo) — digit `hi` of the last pass, digit `lo` of the first — are exactly the rows the
+// tiles of segment `lo` send to digit `hi`: their position range falls out of the last pass's own scanned
+// count matrix (ow_group_table_kernel) and the sorted rows need not be read again to find the boundaries.
+__global__ __launch_bounds__(256) void ow_tile_plan_kernel(const uint32_t *__restrict__ offs1, int64_t nblocks1, int64_t n,
+                                                           uint32_t *__restrict__ firsttile /* [257] */,
+                                                           int64_t *__restrict__ segstart /* [257] */) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t d = threadIdx.x;
+  const int64_t lo = offs1[(int64_t)d * nblocks1], hi = d == 255 ? n : (int64_t)offs1[(int64_t)(d + 1) * nblocks1];
+  const uint32_t nt = (uint32_t)((hi - lo + OW_TILE - 1) / OW_TILE);
+  const uint32_t inc = wave_iscan_u32(nt);
+  if (lane_id() == 63) s_w[wave_id()] = inc;
+  __syncthreads();
+  uint32_t wb = 0;
+  for (int q = 0; q < wave_id(); q++) wb += s_w[q];
+  firsttile[d] = wb + inc - nt;
+  segstart[d] = lo;
+  if (d == 255) {
+    firsttile[256] = wb + inc;
+    segstart[256] = n;
+  }
+}
+__global__ void ow_tile_fill_kernel(const uint32_t *__restrict__ firsttile, const int64_t *__restrict__ segstart, uint32_t ntmax,
+                                    OwTile *__restrict__ tiles) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntmax) return;
+  OwTile o;
+  o.start = 0;
+  o.len = 0;
+  o.pad = 0;
+  if (t < firsttile[256]) {
+    uint32_t lo = 0, hi = 256; // last segment whose first tile is <= t (segments without tiles share their successor's)
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (firsttile[mid] <= t) lo = mid; else hi = mid;
+    }
+    o.start = segstart[lo] + (int64_t)(t - firsttile[lo]) * OW_TILE;
+    o.len = (uint32_t)min<int64_t>(OW_TILE, segstart[lo + 1] - o.start);
+  }
+  tiles[t] = o;
+}
+// group g = hi << 8 | lo: rows [gstart[g], gend[g]) of the last pass's output; gend[65536] = largest group
+__global__ __launch_bounds__(256) void ow_group_table_kernel(const uint32_t *__restrict__ offs2, int64_t ntmax,
+                                                             const uint32_t *__restrict__ firsttile, int64_t n,
+                                                             uint32_t *__restrict__ gstart, uint32_t *__restrict__ gend) {
+  const uint32_t hi = blockIdx.x, lo = threadIdx.x;
+  // position of the first row that the tiles from `firsttile[lo]` on send to digit hi
+  auto at = [&](uint32_t h, uint32_t t) -> uint32_t {
+    if (t >= (uint32_t)ntmax) { h++; t = 0; }
+    return h >= 256 ? (uint32_t)n : offs2[(int64_t)h * ntmax + t];
+  };
+  const uint32_t a = at(hi, firsttile[lo]);
+  const uint32_t b = lo == 255 ? at(hi + 1, 0) : at(hi, firsttile[lo + 1]);
+  gstart[hi * 256 + lo] = a;
+  gend[hi * 256 + lo] = b;
+  uint32_t sz = b - a;
+  for (int k = 32; k >= 1; k >>= 1) sz = max(sz, (uint32_t)__shfl_xor((int)sz, k, 64));
+  if (lane_id() == 0 && sz) atomicMax(gend + 65536, sz);
 }
 
 // ---- group boundaries ---------------------------------------------------------------------------------
@@ -240,7 +339,7 @@ __global__ void ow_group_max_kernel(const uint32_t *__restrict__ gstart, const u
 
 // ---- finish: sort every group on its low bits inside LDS, write the final columns ----------------------
 constexpr int FIN_WG = 256, FIN_WAVES = FIN_WG / 64;
-template <int KIND, int NPAY, int R>
+template <int KIND, int NPAY, int R, bool REC = false>
 __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pay,
                                                            const uint32_t *__restrict__ gstart,
                                                            const uint32_t *__restrict__ gend, int rbits, int desc,
@@ -264,8 +363,14 @@ __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__res
     const uint32_t e = (uint32_t)(w * R + j) * 64 + lane;
     valid[j] = e < m;
     const uint32_t i = lo + min(e, m - 1);
-    k[j] = __builtin_nontemporal_load(words + i);
-    if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
+    if (REC) {
+      const u64x2 rec = __builtin_nontemporal_load((const u64x2 *)words + i);
+      k[j] = rec.x;
+      v[NPAY ? j : 0] = rec.y;
+    } else {
+      k[j] = __builtin_nontemporal_load(words + i);
+      if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
+    }
   }
   for (int shift = 32; shift < 32 + rbits; shift += 8) { // stable LSD passes over the low key bits, all in LDS
     for (int q = lane; q < 256; q += 64) wcnt[w * 256 + q] = 0;
@@ -369,14 +474,56 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   uint64_t *pdst = NPAY ? pa->as<uint64_t>() : nullptr, *palt = NPAY ? pb->as<uint64_t>() : nullptr;
   bool raw = true;
   dim3 g((unsigned)nblocks), b(OW_WG);
+  // The last of two HBM passes (rbits > 0: an in-LDS finish follows) runs over segment-aligned tiles, which makes
+  // the group boundaries a by-product of its count matrix, and (one carried column) writes 16-byte records.
+  // SQLRS_ORDER_TILED=0 / SQLRS_ORDER_REC=0 (read per call) keep the plain blocks / the column form for A/B runs.
+  const char *tl_e = std::getenv("SQLRS_ORDER_TILED"), *rec_e = std::getenv("SQLRS_ORDER_REC");
+  const bool use_tiled = rbits > 0 && !(tl_e && std::atoi(tl_e) == 0);
+  const bool use_rec = use_tiled && NPAY == 1 && !(rec_e && std::atoi(rec_e) == 0);
+  const int64_t ntmax = nblocks + 256; // tiles of the segment-aligned pass: at most one ragged tile per segment more
+  BufP recbuf = use_rec ? ctx->alloc(16 * (size_t)n) : nullptr;
+  BufP firsttile, segstart, tiles2, hist2, offs2;
+  bool rec_form = false, tiled_done = false;
   auto one_pass = [&](int shift) {
     ProfScope ps(ctx, "order_split");
-    if (raw) ow_hist_kernel<KIND, true><<<g, b, 0, ctx->stream>>>(src, n, desc, imin, shift, nblocks, hist->as<uint32_t>());
-    else ow_hist_kernel<KIND, false><<<g, b, 0, ctx->stream>>>(src, n, desc, imin, shift, nblocks, hist->as<uint32_t>());
+    const bool last = shift + 8 >= 32 + kbits;
+    if (last && use_tiled && !raw) {
+      firsttile = ctx->alloc(4 * 257);
+      segstart = ctx->alloc(8 * 257);
+      tiles2 = ctx->alloc(sizeof(OwTile) * (size_t)ntmax);
+      hist2 = ctx->alloc(4 * (size_t)(256 * ntmax));
+      offs2 = ctx->alloc(4 * (size_t)(256 * ntmax));
+      ow_tile_plan_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(offs->as<uint32_t>(), nblocks, n, firsttile->as<uint32_t>(),
+                                                                segstart->as<int64_t>());
+      ow_tile_fill_kernel<<<dim3((unsigned)ceil_div(ntmax, 256)), dim3(256), 0, ctx->stream>>>(
+          firsttile->as<uint32_t>(), segstart->as<int64_t>(), (uint32_t)ntmax, (OwTile *)tiles2->p);
+      dim3 g2((unsigned)ntmax);
+      const OwTile *tp = (const OwTile *)tiles2->p;
+      ow_hist_kernel<KIND, false, true><<<g2, b, 0, ctx->stream>>>(src, n, desc, imin, shift, ntmax, hist2->as<uint32_t>(), tp);
+      SQ_HIP(hipGetLastError());
+      exclusive_scan_u32(ctx, hist2->as<uint32_t>(), 256 * ntmax, nullptr, offs2->as<uint32_t>(), total->as<uint64_t>());
+      if (use_rec) {
+        ow_scatter_kernel<KIND, false, NPAY, true, NPAY == 1><<<g2, b, 0, ctx->stream>>>(
+            src, psrc, n, desc, imin, shift, ntmax, offs2->as<uint32_t>(), recbuf->as<uint64_t>(), nullptr, tp);
+        src = recbuf->p;
+        psrc = nullptr;
+        rec_form = true;
+      } else {
+        ow_scatter_kernel<KIND, false, NPAY, true, false><<<g2, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, ntmax,
+                                                                                    offs2->as<uint32_t>(), wdst, pdst, tp);
+        src = wdst;
+        psrc = pdst;
+      }
+      SQ_HIP(hipGetLastError());
+      tiled_done = true;
+      return;
+    }
+    if (raw) ow_hist_kernel<KIND, true><<<g, b, 0, ctx->stream>>>(src, n, desc, imin, shift, nblocks, hist->as<uint32_t>(), nullptr);
+    else ow_hist_kernel<KIND, false><<<g, b, 0, ctx->stream>>>(src, n, desc, imin, shift, nblocks, hist->as<uint32_t>(), nullptr);
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(), total->as<uint64_t>());
-    if (raw) ow_scatter_kernel<KIND, true, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst);
-    else ow_scatter_kernel<KIND, false, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst);
+    if (raw) ow_scatter_kernel<KIND, true, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst, nullptr);
+    else ow_scatter_kernel<KIND, false, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst, nullptr);
     SQ_HIP(hipGetLastError());
     src = wdst;
     psrc = pdst;
@@ -416,10 +563,15 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   SQ_HIP(hipMemsetAsync(gend->p, 0, 4 * ((size_t)G + 1), ctx->stream));
   {
     ProfScope ps(ctx, "order_groups");
-    ow_group_bounds_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 16 * (int64_t)ctx->num_cus)), dim3(256), 0, ctx->stream>>>(
-        words, n, 32 + rbits, gstart->as<uint32_t>(), gend->as<uint32_t>());
-    ow_group_max_kernel<<<dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, ctx->stream>>>(gstart->as<uint32_t>(), gend->as<uint32_t>(), G,
-                                                                                      gend->as<uint32_t>() + G);
+    if (tiled_done) { // (G == 65536: two passes of 8 bits)
+      ow_group_table_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(offs2->as<uint32_t>(), ntmax, firsttile->as<uint32_t>(), n,
+                                                                    gstart->as<uint32_t>(), gend->as<uint32_t>());
+    } else {
+      ow_group_bounds_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 16 * (int64_t)ctx->num_cus)), dim3(256), 0, ctx->stream>>>(
+          words, n, 32 + rbits, gstart->as<uint32_t>(), gend->as<uint32_t>());
+      ow_group_max_kernel<<<dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, ctx->stream>>>(gstart->as<uint32_t>(), gend->as<uint32_t>(), G,
+                                                                                        gend->as<uint32_t>() + G);
+    }
     SQ_HIP(hipGetLastError());
   }
   const uint32_t max_group = ctx->fetch_value(gend->as<uint32_t>() + G);
@@ -437,6 +589,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
 #define SQ_FIN(RR)                                                                                                   \
   do {                                                                                                               \
     auto kfn = ow_finish_kernel<KIND, NPAY, RR>;                                                                     \
+    if (NPAY == 1 && rec_form) kfn = ow_finish_kernel<KIND, NPAY, RR, NPAY == 1>;                                    \
     const size_t lds = (size_t)RR * FIN_WG * 8 * (1 + NPAY) + 4 * (FIN_WAVES * 256 + 256);                           \
     if (lds > 64 * 1024) allow_big_lds(ctx, kfn);                                                                    \
     kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(words, pays, gstart->as<uint32_t>(), gend->as<uint32_t>(), rbits, desc, imin, \

@@ -125,7 +125,6 @@ struct RpIn {
   const uint8_t *flags;    // null at level 1: built from the bitmaps
   const uint64_t *key_validity, *v0_validity, *v1_validity;
 };
-typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 struct RpOut {
   uint64_t *key, *v0, *v1;
   uint32_t *idx;

@@ -223,11 +223,14 @@ class HashJoinAggExecutor:
 
 
 class OrderExecutor:
-    """``OrderExecutor { order_by, child }`` (order.rs:8-11)."""
+    """``OrderExecutor { order_by, child }`` (order.rs:8-11).  ``retain_inputs``: the child's DEVICE batches are
+    kept alive by this executor until the sort is done instead of being copied by the library (what the reference
+    does with its Arc'd arrays, order.rs:19-26; ``sqlrs_order_push_retained``)."""
 
     def __init__(self, backend: abi.Backend, order_by: List[OrderBy], child: Iterable,
-                 out_mem: int = abi.MEM_HOST):
+                 out_mem: int = abi.MEM_HOST, retain_inputs: bool = False):
         self.backend, self.order_by, self.child, self.out_mem = backend, order_by, child, out_mem
+        self.retain_inputs = retain_inputs
 
     def execute(self):
         be = self.backend
@@ -245,7 +248,11 @@ class OrderExecutor:
             for batch in self.child:  # order.rs:19-26
                 names = names or _names_of(batch)
                 b = abi.as_batch(batch)
-                be.check(be.fn("order_push")(h, b.ptr))
+                if self.retain_inputs:
+                    keep.append((batch, b))  # alive and unchanged until order_finish has returned
+                    be.check(be.fn("order_push_retained")(h, b.ptr))
+                else:
+                    be.check(be.fn("order_push")(h, b.ptr))
             out = C.POINTER(abi.Batch)()
             be.check(be.fn("order_finish")(h, self.out_mem, C.byref(out)))
             yield _emit(be, out, self.out_mem, names)

@@ -242,3 +242,34 @@ def test_full_size_c5_pipeline(env):
     assert bool((fr[1:] > fr[:-1]).all().item())
     out.release()
     env.be.fn("ctx_pool_trim")(env.be.ctx)
+
+
+@pytest.mark.parametrize("push", ["order_push", "order_push_retained"])
+def test_full_size_order(env, push):
+    """bench's Order shape: ORDER BY v1 (int64, 31 significant bits) carrying one f64 column over 1e8 device rows =
+    torch's stable sort of the key + the gathered column (ties keep input order, order.rs:27-66); the retained push
+    (caller keeps the batch alive, nothing copied) and the copying push give the same batch"""
+    t, abi, d = env.torch, env.abi, env.datagen
+    from sqlrs_amd.expr import InputRef
+    n = 100_000_000
+    v1 = d.fill_chunks(t.empty(n, dtype=t.int64, device=env.dev), lambda i: d._lsr(d.splitmix64_t(0xC2, i), 33))
+    val = d.fill_chunks(t.empty(n, dtype=t.float64, device=env.dev), lambda i: d.val_t(0xF2, i))
+    t.cuda.synchronize()
+    bo = env.bench.device_batch(abi, [v1, val], [abi.INT64, abi.FLOAT64])
+    pk = InputRef(0).pack()
+    obs = (abi.OrderBy * 1)(abi.OrderBy(pk.abi, 1, 0))
+    h = C.c_void_p()
+    env.be.check(env.be.fn("order_create")(env.be.ctx, 1, obs, C.byref(h)))
+    env.be.check(env.be.fn(push)(h, bo.ptr))
+    o = C.POINTER(abi.Batch)()
+    env.be.check(env.be.fn("order_finish")(h, abi.MEM_DEVICE, C.byref(o)))
+    env.be.fn("order_destroy")(h)
+    out = env.be.wrap(o)
+    env.be.synchronize()
+    assert out.num_rows == n
+    gk, gv = view(env, out.column(0), n, t.int64), view(env, out.column(1), n, t.float64)
+    ek, perm = t.sort(v1, stable=True)
+    assert t.equal(gk, ek)
+    del ek
+    assert t.equal(gv, val[perm])  # bit-exact, ties in input order
+    out.release()

@@ -17,7 +17,7 @@ obs = (abi.OrderBy * 1)(abi.OrderBy(pk.abi, 1, 0))
 def run_order():
     h = C.c_void_p()
     be.check(be.fn("order_create")(be.ctx, 1, obs, C.byref(h)))
-    be.check(be.fn("order_push")(h, bo.ptr))
+    be.check(be.fn("order_push_retained")(h, bo.ptr))  # `bo` outlives the sort (order.rs:19-26 keeps Arcs)
     o = C.POINTER(abi.Batch)()
     be.check(be.fn("order_finish")(h, abi.MEM_DEVICE, C.byref(o)))
     be.fn("batch_release")(o)
@@ -26,11 +26,12 @@ VAR = os.environ.get("VAR", "SQLRS_ORDER_VARIANT")
 for st in os.environ.get("VALUES", "0").split(","):
     os.environ[VAR] = st
     run_order(); be.synchronize()
-    be.profile(True)
+    prof = os.environ.get("PROFILE", "1") != "0"
+    be.profile(prof)
     t = time.perf_counter()
     for _ in range(5):
         run_order()
     be.synchronize()
     ms = (time.perf_counter() - t) / 5 * 1e3
-    pr = be.profile_read(); be.profile(False)
+    pr = be.profile_read() if prof else {}; be.profile(False)
     print(f"{VAR}={st}: {ms:.2f} ms | " + " ".join(f"{k} {v[0]/5:.3f}" for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])[:8]), flush=True)
