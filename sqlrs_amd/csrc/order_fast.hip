@@ -152,6 +152,12 @@ __device__ __forceinline__ void stable_wave_ranks(const uint32_t (&dig)[ITEMS], 
   }
 }
 
+// (A persistent, software-pipelined form of this kernel — contiguous tile range per workgroup, the next tile's rows
+// loaded into a second register set, unconditional loads / stores as in rp_scatter_kernel — measured SLOWER: 2.49
+// against 2.35 ms for the two passes of 1e8 rows.  The pass is co-limited by the stable ranking: ~50 VALU
+// instructions per row slot and wave for the 8 ballots, i.e. ~70 % of the SIMD time two resident workgroups have per
+// tile at the HBM rate, so a second register set (128 VGPRs, spills) buys nothing that the second resident
+// workgroup does not already provide.)
 // REC (NPAY == 1): the pass writes {word, carried value} records into `words_out` (16 B per row) — what the
 // in-LDS finish reads; a (tile, digit) run of 16 rows is one 256-byte piece instead of 128 B in each of two columns
 template <int KIND, bool RAW, int NPAY, bool TILED = false, bool REC = false>
