@@ -289,7 +289,8 @@ __global__ void ow_tile_fill_kernel(const uint32_t *__restrict__ firsttile, cons
   }
   tiles[t] = o;
 }
-// group g = hi << 8 | lo: rows [gstart[g], gend[g]) of the last pass's output; gend[65536] = largest group
+// group g = hi << 8 | lo: rows [gstart[g], gend[g]) of the last pass's output; one block per value of `hi`;
+// gend[number of groups] = largest group
 __global__ __launch_bounds__(256) void ow_group_table_kernel(const uint32_t *__restrict__ offs2, int64_t ntmax,
                                                              const uint32_t *__restrict__ firsttile, int64_t n,
                                                              uint32_t *__restrict__ gstart, uint32_t *__restrict__ gend) {
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void ow_group_table_kernel(const uint32_t *__r
   gend[hi * 256 + lo] = b;
   uint32_t sz = b - a;
   for (int k = 32; k >= 1; k >>= 1) sz = max(sz, (uint32_t)__shfl_xor((int)sz, k, 64));
-  if (lane_id() == 0 && sz) atomicMax(gend + 65536, sz);
+  if (lane_id() == 0 && sz) atomicMax(gend + (size_t)gridDim.x * 256, sz);
 }
 
 // ---- group boundaries ---------------------------------------------------------------------------------
@@ -468,7 +469,11 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   if (range > 0xffffffffull) return false; // more than 32 varying key bits: general path
   int kbits = 1;
   while (kbits < 32 && (1ull << kbits) <= range) kbits++;
-  const int rbits = std::max(0, kbits - 16), top = kbits - rbits; // top <= 16 bits through HBM
+  // top <= 16 bits go through HBM — as many as leave groups of ~1-2 K rows for the in-LDS finish (2e6 rows: 10 bits;
+  // with 16 the finish ran 65 536 workgroups of 30 rows each: 0.64 ms of its 1.27 ms)
+  int want = 1;
+  while (want < 16 && (n >> want) > 2048) want++;
+  const int top = std::min(kbits, want), rbits = kbits - top;
   // 1. stable multi-split passes on bits [32 + rbits, 32 + kbits) of the word, LSD order
   const int64_t nblocks = ceil_div(n, OW_TILE);
   BufP wa = ctx->alloc(8 * (size_t)n), wb = ctx->alloc(8 * (size_t)n);
@@ -569,8 +574,8 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   SQ_HIP(hipMemsetAsync(gend->p, 0, 4 * ((size_t)G + 1), ctx->stream));
   {
     ProfScope ps(ctx, "order_groups");
-    if (tiled_done) { // (G == 65536: two passes of 8 bits)
-      ow_group_table_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(offs2->as<uint32_t>(), ntmax, firsttile->as<uint32_t>(), n,
+    if (tiled_done) { // (two passes: 8 bits, then top - 8)
+      ow_group_table_kernel<<<dim3(G >> 8), dim3(256), 0, ctx->stream>>>(offs2->as<uint32_t>(), ntmax, firsttile->as<uint32_t>(), n,
                                                                     gstart->as<uint32_t>(), gend->as<uint32_t>());
     } else {
       ow_group_bounds_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 16 * (int64_t)ctx->num_cus)), dim3(256), 0, ctx->stream>>>(
