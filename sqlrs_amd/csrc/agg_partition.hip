@@ -811,10 +811,8 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   // R = 2^rbits slots of 8 * n_acc + 4 bytes at 100 % fill instead of cap slots of 8 more bytes
   // at 27 %, i.e. ~5x fewer buckets (often one partition level instead of two), no probing and,
   // for the fused join, no build-side partition and no insert phase.
-  static const bool dense_on = [] { // test / tuning hook
-    const char *e = std::getenv("SQLRS_DENSE_AGG");
-    return !(e && e[0] == '0');
-  }();
+  const char *dense_e = std::getenv("SQLRS_DENSE_AGG"); // test / tuning hook, read per call
+  const bool dense_on = !(dense_e && dense_e[0] == '0');
   const double want_hashed = want; // probing tables needed if the bucket pass ran on hashed buckets
   bool dense = false;
   if (dense_on && kp.kbits) {

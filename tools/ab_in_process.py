@@ -12,6 +12,9 @@ n, nd = int(float(os.environ.get("N", 1e9))), int(float(os.environ.get("ND", 1e7
 fk = datagen.fill_chunks(torch.empty(n, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF1, i, nd))
 fv = datagen.fill_chunks(torch.empty(n, dtype=torch.float64, device=dev), lambda i: datagen.val_t(0xF2, i))
 dk = datagen.fill_chunks(torch.empty(nd, dtype=torch.int64, device=dev), lambda i: datagen.dim_key_t(i, nd))
+if os.environ.get("SPARSE"):  # sparse 64-bit keys (k -> k * odd + c on both sides): hash partition + LDS hash tables
+    A_s = 0x9E3779B97F4A7C15 - (1 << 64)
+    fk.mul_(A_s).add_(12345); dk.mul_(A_s).add_(12345)
 torch.cuda.synchronize()
 print("ptrs", hex(fk.data_ptr()), hex(fv.data_ptr()))
 pipe = bench.Pipeline(be, abi, 0.5)
