@@ -128,6 +128,22 @@ def test_hash_agg_chunked(hip, oracle, keys):
     assert_same(got, exp, float_cols={2})
 
 
+@pytest.mark.parametrize("dense", ["1", "0"])
+def test_hash_agg_column_form_hook(hip, oracle, dense, monkeypatch):
+    """SQLRS_RP_REC=0 (read per call): the final partition level writes key / value columns instead of 16-byte
+    records and the bucket pass reads them — the form in-process A/B runs compare against (direct-addressed and
+    probing bucket tables)"""
+    monkeypatch.setenv("SQLRS_RP_REC", "0")
+    monkeypatch.setenv("SQLRS_DENSE_AGG", dense)
+    rng = np.random.default_rng(12)
+    n, G = 3_000_000, 400_000
+    b = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, G, n, dtype=np.int64)), pa.array(rng.random(n))], names=["k", "v"])
+    aggs = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64)]
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
+    assert_same(got, exp, float_cols={2})
+
+
 def test_chunked_first_level_forced():
     if FORCED:
         pytest.skip("already inside the forced run")
