@@ -333,19 +333,20 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
 // compacted copies of every column just so that they can be read again (C5: filter 12 + compact 12 +
 // hist 4 + scatter 16 GB).  Here the output of level 1 is not one contiguous run per digit but a list
 // of fixed-size CHUNKS per digit (linked-bucket partitioning): workgroup b appends the rows of digit d
-// to its own current chunk of that digit and takes a fresh chunk from a global counter when it is
+// to its own current chunk of that digit and takes a fresh chunk of its own arena when it is
 // full, so a row's destination depends on nothing but the workgroup's own history.  One pass: every
 // input column read once (the predicate evaluated on the way), every kept row written once.
 //
 // Level 2 treats every non-empty chunk as one input tile (chunk capacity = its tile size), so only
 // its tile list changes (rp_chunk_plan_kernel); its output is contiguous per bucket as before.
 //
-// Chunk bookkeeping per (workgroup, digit) lives in the registers of thread `digit`: current chunk,
-// fill, and a PRE-FETCHED next chunk (the atomic that allocates it is issued when the previous one is
-// taken into use, a chunk's worth of rows before its result is needed).  Chunks 2*(b*digits+d) and
-// +1 are pre-assigned; chunk ids >= base_chunks come from the counter.  Bound: every allocation
-// beyond the pre-assigned ones follows CAP rows written by that (workgroup, digit), so
-// base_chunks + n / CAP + 1 chunks always suffice.
+// Chunk bookkeeping per (workgroup, digit) lives in the registers of thread `digit`: current chunk and fill.
+// Every workgroup owns an ARENA of consecutive chunks and hands them out in order from a counter in LDS (digit d
+// starts in chunk d of the arena): no global atomic, no overflow possible — a workgroup that reads R rows closes
+// at most R / CAP chunks and leaves at most `digits` partly filled, so arena = ceil(tiles_per_wg / tiles per chunk)
+// + digits + 1 chunks always suffice — and the pool is half the size of the first scheme (two pre-assigned chunks
+// per (workgroup, digit) + a global counter with a pre-fetched next chunk), which it replaced at equal level-1
+// time and slightly better level-2 time (its chunks are read in a more regular order).
 // Chunks are laid out RP_CHUNK_SKEW rows apart from a multiple of the tile size: with exact multiples of
 // 48 KiB every workgroup of the next level starts its tile on one of four phases of the HBM channel
 // interleave at the same moment.
@@ -355,9 +356,10 @@ struct ChunkOut {
   uint32_t *idx;        // null when the row id is packed into the key word
   uint32_t *chunk_len;  // rows in chunk c (written when it is closed / at the end of its workgroup)
   uint32_t *chunk_dig;  // level-1 digit of chunk c
-  unsigned int *counter; // [0] chunks taken beyond base_chunks, [1] overflow flag
-  uint32_t base_chunks, max_chunks;
+  unsigned int *counter; // [1] overflow flag ([0] stays 0: the plan kernels scan base_chunks + counter[0] chunks)
+  uint32_t base_chunks, max_chunks; // both = workgroups * arena
   uint32_t cap; // rows per chunk: a multiple of the tile size
+  uint32_t arena;     // chunks per workgroup: workgroup b takes chunks b * arena, b * arena + 1, ... in this order
 };
 
 // PSRC: where the predicate's operand comes from: -1 no filter, 1 = value column 0, 3 = its own column
@@ -403,11 +405,13 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
   int64_t *gb1 = gb0 + RP_WG;                                 //         gb1[d] + p from it on
   __shared__ uint32_t s_wsum[RP_WG / 64];
   __shared__ uint32_t s_total;
+  __shared__ uint32_t s_next; // arena mode: next free chunk of this workgroup's arena
 
   const uint32_t t0 = blockIdx.x * tiles_per_wg;
   const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
   // chunk state of digit threadIdx.x
-  uint32_t cur_id = 2u * (blockIdx.x * digits + threadIdx.x), nxt_id = cur_id + 1, cfill = 0;
+  uint32_t cur_id = blockIdx.x * out.arena + min(threadIdx.x, digits - 1), cfill = 0;
+  if (threadIdx.x == 0) s_next = digits; // (barriers follow before the first allocation)
   const bool owner = threadIdx.x < digits;
   auto tile_start = [&](uint32_t t) { return (int64_t)t * RP_TILE; };
   auto tile_len = [&](uint32_t t) { return (uint32_t)min((int64_t)RP_TILE, n - (int64_t)t * RP_TILE); };
@@ -444,12 +448,11 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
     if (owner && c > room) {
       out.chunk_len[cur_id] = out.cap; // closed
       out.chunk_dig[cur_id] = threadIdx.x;
-      cur_id = nxt_id;
+      const uint32_t o = atomicAdd(&s_next, 1u); // next chunk of the workgroup's own arena (an LDS counter)
+      if (o >= out.arena) out.counter[1] = 1;    // cannot happen (see the bound above); never out of bounds
+      cur_id = blockIdx.x * out.arena + min(o, out.arena - 1);
       cfill = c - room;
       g1 = (int64_t)cur_id * (out.cap + RP_CHUNK_SKEW);
-      const uint32_t o = out.base_chunks + atomicAdd(out.counter, 1u); // needed a chunk's worth of rows from now
-      if (o >= out.max_chunks) out.counter[1] = 1;                     // cannot happen (bound above); never out of bounds
-      nxt_id = min(o, out.max_chunks - 1);
     } else {
       cfill += c;
     }
@@ -528,11 +531,9 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
     for (int j = 0; j < RP_ROWS; j++)
       if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);
   }
-  if (owner) { // publish what is left open; the pre-fetched chunk stays empty
-    out.chunk_len[cur_id] = cfill;
+  if (owner) { // publish what is left open
+    out.chunk_len[cur_id] = cfill; // (chunks never taken keep the zero length of the table's memset)
     out.chunk_dig[cur_id] = threadIdx.x;
-    out.chunk_len[nxt_id] = 0;
-    out.chunk_dig[nxt_id] = threadIdx.x;
   }
 }
 
@@ -910,17 +911,19 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   uint32_t cwgs = std::min<uint32_t>(tiles1, (uint32_t)ctx->num_cus);
   const uint32_t ctpw = (uint32_t)ceil_div(tiles1, std::max(cwgs, 1u));
   cwgs = (uint32_t)ceil_div(tiles1, std::max(ctpw, 1u));
-  const uint64_t base_chunks = 2ull * cwgs * d1;
+  const uint64_t spare_chunks = (uint64_t)cwgs * (d1 + 1); // chunks that may stay partly filled or unused
   static const int ct_env = [] { // tuning hook: tiles per chunk (1, 4, 8, 16 measured alike: 1 = smallest reservation)
     const char *e = std::getenv("SQLRS_RP_CHUNK_TILES");
     return e ? std::max(1, std::min(64, std::atoi(e))) : 1;
   }();
   const uint64_t CAP = (uint64_t)RP_TILE * (uint64_t)ct_env;
   bool chunked = p2_bits != 0 && !flags && chunk_env != 0 && d1 <= (uint32_t)WG &&
-                 (chunk_env == 1 || base_chunks * CAP <= 2 * (uint64_t)n); // (pre-assigned chunks: reserved, mostly never touched)
+                 (chunk_env == 1 || spare_chunks * CAP <= (uint64_t)n); // (the slack of the arenas is a fraction of the input)
   if (in.filter.col && !chunked) return false; // only the chunked first level evaluates a row filter
   if (chunked) {
-    const uint64_t max_chunks = base_chunks + (uint64_t)n / CAP + 2;
+    // arena mode: a workgroup fills at most ceil(its rows / CAP) chunks completely and leaves <= d1 partly filled
+    const uint64_t arena = (uint64_t)ceil_div((int64_t)ctpw, (int64_t)ct_env) + d1 + 1;
+    const uint64_t max_chunks = arena * cwgs;
     if (max_chunks * (CAP + RP_CHUNK_SKEW) + WG * (uint64_t)cwgs > 0xffffffffull) { // Tile::start is 64-bit, rows index u32 math
       if (in.filter.col) return false;
       chunked = false;
@@ -929,9 +932,11 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       const size_t pool_rows = (size_t)max_chunks * (CAP + RP_CHUNK_SKEW) + (size_t)WG * cwgs; // + one sink per workgroup
       BufP ck = staggered(8 * pool_rows, 0), c0 = nv >= 1 ? staggered(8 * pool_rows, 1) : nullptr,
            c1 = nv >= 2 ? staggered(8 * pool_rows, 2) : nullptr, ci = pack ? nullptr : staggered(4 * pool_rows, 3);
-      BufP clen = ctx->alloc(4 * (size_t)max_chunks), cdig = ctx->alloc(4 * (size_t)max_chunks);
+      BufP clen = ctx->alloc_zero(4 * (size_t)max_chunks);
+      BufP cdig = ctx->alloc(4 * (size_t)max_chunks);
       BufP ctr = ctx->alloc_zero(8);
       ChunkOut co;
+      co.arena = (uint32_t)arena;
       co.key = ck->as<uint64_t>();
       co.v0 = c0 ? c0->as<uint64_t>() : nullptr;
       co.v1 = c1 ? c1->as<uint64_t>() : nullptr;
@@ -939,7 +944,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       co.chunk_len = clen->as<uint32_t>();
       co.chunk_dig = cdig->as<uint32_t>();
       co.counter = ctr->as<unsigned int>();
-      co.base_chunks = (uint32_t)base_chunks;
+      co.base_chunks = (uint32_t)max_chunks;
       co.max_chunks = (uint32_t)max_chunks;
       co.cap = (uint32_t)CAP;
       const int psrc = !in.filter.col ? -1 : ((nv >= 1 && (const void *)in.filter.col == in.vals[0]) ? 1 : 3);
