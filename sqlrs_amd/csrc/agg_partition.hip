@@ -785,10 +785,8 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   // (36 KiB tables, four workgroups per CU) that was ~5 trips per row instead of ~2:
   // 3.7 ms vs 3.0 ms for the C5 bucket pass.  Fewer groups per table would need more buckets,
   // which costs more in the partition passes than it saves here.
-  static const size_t lds_budget = [] {
-    const char *e = std::getenv("SQLRS_LDS_AGG_KB");
-    return (size_t)(e ? std::atoi(e) : 72) * 1024;
-  }();
+  const char *lds_e = std::getenv("SQLRS_LDS_AGG_KB"); // tuning hook, read per call
+  const size_t lds_budget = (size_t)(lds_e ? std::atoi(lds_e) : 72) * 1024;
   const size_t slot_bytes = 8 + 8 * (size_t)spec.n_acc + 4; // key, accumulators, first row
   uint32_t cap = 1;
   while ((size_t)(cap * 2 + 2) * slot_bytes <= lds_budget) cap *= 2;
@@ -817,9 +815,17 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   bool dense = false;
   if (dense_on && kp.kbits) {
     const uint64_t range = omax - omin;
+    // Direct-addressed tables have no fill target to keep and nothing to probe: one table per CU, as large as LDS
+    // allows, halves the bucket count (C5: 4883 -> 2442 buckets of 4096 slots, 39 x 128 -> 39 x 64 digits: level 2
+    // 3.35 -> 3.07 ms, the bucket pass itself 1.63 -> 1.60 ms with one workgroup per CU instead of three; C4: 489 ->
+    // 245 buckets, scatter 2.12 -> 1.52 ms).  8192 slots (first row kept inside the COUNT cell, 16-byte slots) were
+    // measured too: level 1 -0.1 ms, bucket pass +0.13 ms, nothing gained.
+    const char *dk_e = std::getenv("SQLRS_LDS_DENSE_KB"); // tuning hook, read per call
+    const size_t dense_budget = (size_t)(dk_e ? std::atoi(dk_e) : 150) * 1024;
     const size_t dslot = 8 * (size_t)spec.n_acc + 4;
     uint32_t rbits = 8;
-    while (rbits < 14 && ((size_t)2 << rbits) * dslot <= lds_budget) rbits++;
+    while (rbits < 14 && ((size_t)2 << rbits) * dslot <= dense_budget) rbits++;
+    while (rbits > 8 && (range >> (rbits - 1)) == 0) rbits--; // a narrow key range: no larger than it needs (occupancy)
     const uint64_t pd = (range >> rbits) + 1;
     // join: unique build keys (the caller's pre-condition) that span exactly join_n values are
     // every value of the range; otherwise: at most ~4 slots per group
@@ -948,7 +954,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     // a handful of work items — one workgroup streamed 5e7 rows of a 50-group batch alone (26 ms).
     // With fewer non-empty buckets than half the workgroup slots of the chip, every bucket is cut
     // into chunks of 1/(2 x slots) of the batch; their tables merge through the split tables.
-    const uint32_t slots = 2u * (uint32_t)ctx->num_cus;
+    const uint32_t slots = (lds > 80 * 1024 - 64 ? 1u : 2u) * (uint32_t)ctx->num_cus; // (tables of >= 80 KiB: one workgroup per CU)
     uint32_t nonempty = 0;
     for (uint32_t bkt = 0; bkt < P; bkt++) nonempty += hb[bkt + 1] > hb[bkt];
     if (nonempty < slots / 2) {

@@ -95,13 +95,13 @@ def test_probe_filter_small_batches(hip, oracle, pred, batches):
 @pytest.mark.parametrize("pred", ["val_gt_half", "val_le_all", "val_lt_none", "other_ne", "other_eq", "key_ge", "general"])
 @pytest.mark.parametrize("aggs", ["count_sum", "none", "two_columns"])
 def test_probe_filter_chunked(hip, oracle, sparse, pred, aggs):
-    """two-level partitions (dense: 1.2e6 build keys -> 586 range buckets; sparse: hashed buckets)"""
+    """two-level partitions (dense: 2.4e6 build keys -> 586 range buckets of 4096 slots; sparse: hashed buckets)"""
     if pred == "key_ge" and sparse:
         pytest.skip("the threshold is meant for the dense key range")
     if aggs != "count_sum" and pred not in ("val_gt_half", "other_ne"):
         pytest.skip("aggregate lists are crossed with two predicates only")
     rng = np.random.default_rng(zlib.crc32(f"{sparse}{pred}{aggs}".encode()))
-    lb, rb, sch = tables(rng, 1_200_000 if not sparse else 400_000, 2_500_000, sparse)
+    lb, rb, sch = tables(rng, 2_400_000 if not sparse else 400_000, 2_500_000, sparse)
     cond = JoinCondition([(InputRef(0), InputRef(1))])
     ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, AGGS[aggs], [InputRef(0)], probe_filter=PREDS[pred])
     got = rows_of(ex.execute())
@@ -114,9 +114,9 @@ def test_probe_filter_chunked(hip, oracle, sparse, pred, aggs):
 
 @pytest.mark.parametrize("keys", ["dense", "sparse"])
 def test_hash_agg_chunked(hip, oracle, keys):
-    """plain HashAgg whose partition needs two levels (2e6 groups): chunked first level, no filter"""
+    """plain HashAgg whose partition needs two levels (2.6e6 groups, > 512 tables of 4096 slots): chunked first level, no filter"""
     rng = np.random.default_rng(11)
-    n, G = 5_000_000, 2_000_000
+    n, G = 6_000_000, 2_600_000
     k = rng.integers(0, G, n, dtype=np.int64)
     if keys == "sparse":
         with np.errstate(over="ignore"):
