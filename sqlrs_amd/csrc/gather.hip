@@ -201,6 +201,96 @@ DCol gather_column(Ctx *ctx, const DCol &src_in, const void *idx, bool idx_is_u6
   return gather_impl<uint32_t>(ctx, src, (const uint32_t *)idx, idx_validity, n);
 }
 
+// ---- several plain 8-byte columns by the same permutation --------------------------------------------
+// A random gather fetches a whole sector per element whatever its size, so k columns gathered one by one pay k
+// random fetches per row.  Packing the k values of a row side by side first (one streaming pass) makes it one
+// random fetch per row: 1e7 rows x 3 columns 0.60 -> 0.35 ms (the group ordering at the end of C5).
+template <int K>
+__global__ __launch_bounds__(BLOCK) void pack_rows_kernel(const uint64_t *__restrict__ c0, const uint64_t *__restrict__ c1,
+                                                          const uint64_t *__restrict__ c2, const uint64_t *__restrict__ c3,
+                                                          int64_t n, uint64_t *__restrict__ rows) {
+  constexpr int W = K <= 2 ? 2 : 4; // words per packed row (16 or 32 bytes)
+  const int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+  if (i >= n) return;
+  u64x2 a;
+  a.x = c0[i];
+  a.y = c1[i];
+  *(u64x2 *)(rows + (size_t)W * i) = a;
+  if (K > 2) {
+    u64x2 b;
+    b.x = c2[i];
+    b.y = K > 3 ? c3[i] : 0ull;
+    *(u64x2 *)(rows + (size_t)W * i + 2) = b;
+  }
+}
+template <int K>
+__global__ __launch_bounds__(BLOCK) void gather_rows_kernel(const uint64_t *__restrict__ rows, const uint32_t *__restrict__ idx,
+                                                            int64_t n, uint64_t *__restrict__ o0, uint64_t *__restrict__ o1,
+                                                            uint64_t *__restrict__ o2, uint64_t *__restrict__ o3) {
+  constexpr int W = K <= 2 ? 2 : 4, U = 4;
+  const int64_t base = blockIdx.x * (int64_t)(BLOCK * U) + threadIdx.x;
+  uint32_t s[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) s[u] = __builtin_nontemporal_load(idx + min(base + u * BLOCK, n - 1));
+  u64x2 a[U], b[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    a[u] = *(const u64x2 *)(rows + (size_t)W * s[u]);
+    if (K > 2) b[u] = *(const u64x2 *)(rows + (size_t)W * s[u] + 2);
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t i = base + u * BLOCK;
+    if (i >= n) continue;
+    o0[i] = a[u].x;
+    o1[i] = a[u].y;
+    if (K > 2) o2[i] = b[u].x;
+    if (K > 3) o3[i] = b[u].y;
+  }
+}
+
+// `cols` (2..4 plain 8-byte columns of `src_rows` rows, no NULLs) gathered by the u32 permutation `idx`; returns
+// false (nothing done) for any other shape
+bool gather_columns_packed(Ctx *ctx, std::vector<DCol> &cols, int64_t src_rows, const uint32_t *idx, int64_t n) {
+  const int k = (int)cols.size();
+  if (k < 2 || k > 4 || n < (1 << 18)) return false;
+  for (const DCol &c : cols)
+    if (width_of(c.dtype) != 8 || c.stride == 0 || (c.validity && c.null_count != 0) || c.length != src_rows) return false;
+  const int w = k <= 2 ? 2 : 4;
+  BufP rows = ctx->alloc(8 * (size_t)w * (size_t)src_rows);
+  const uint64_t *p[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < k; i++) p[i] = cols[(size_t)i].v<uint64_t>();
+  dim3 b(BLOCK), gp((unsigned)ceil_div(src_rows, BLOCK)), gg((unsigned)ceil_div(n, BLOCK * 4));
+  std::vector<DCol> outs((size_t)k);
+  uint64_t *o[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < k; i++) {
+    DCol &d = outs[(size_t)i];
+    d.dtype = cols[(size_t)i].dtype;
+    d.length = n;
+    d.null_count = 0;
+    d.own_values = ctx->alloc(8 * (size_t)n + 16);
+    d.values = d.own_values->p;
+    o[i] = d.own_values->as<uint64_t>();
+  }
+  uint64_t *r = rows->as<uint64_t>();
+  switch (k) {
+  case 2:
+    pack_rows_kernel<2><<<gp, b, 0, ctx->stream>>>(p[0], p[1], p[2], p[3], src_rows, r);
+    gather_rows_kernel<2><<<gg, b, 0, ctx->stream>>>(r, idx, n, o[0], o[1], o[2], o[3]);
+    break;
+  case 3:
+    pack_rows_kernel<3><<<gp, b, 0, ctx->stream>>>(p[0], p[1], p[2], p[3], src_rows, r);
+    gather_rows_kernel<3><<<gg, b, 0, ctx->stream>>>(r, idx, n, o[0], o[1], o[2], o[3]);
+    break;
+  default:
+    pack_rows_kernel<4><<<gp, b, 0, ctx->stream>>>(p[0], p[1], p[2], p[3], src_rows, r);
+    gather_rows_kernel<4><<<gg, b, 0, ctx->stream>>>(r, idx, n, o[0], o[1], o[2], o[3]);
+  }
+  SQ_HIP(hipGetLastError());
+  cols = std::move(outs);
+  return true;
+}
+
 // ------------------------------------------------------------------ bit helpers --
 __global__ void count_clear_kernel(const uint64_t *__restrict__ bits, int64_t rows, int64_t nwords,
                                    unsigned long long *out) {

@@ -362,7 +362,8 @@ static DBatch emit_pending(sqlrs_hash_agg *a) {
     int bits = 1;
     while (bits < 64 && (1ull << bits) <= (uint64_t)std::max<int64_t>(a->rows_seen, 1)) bits++;
     radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), G, 0, bits);
-    for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
+    if (!gather_columns_packed(ctx, o.cols, G, perm->as<uint32_t>(), G))
+      for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
   }
   return o;
 }
@@ -892,7 +893,8 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
       int bits = 1;
       while (bits < 64 && (1ull << bits) <= (uint64_t)std::max<int64_t>(a->rows_seen, 1)) bits++;
       radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), G, 0, bits);
-      for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
+      if (!gather_columns_packed(ctx, o.cols, G, perm->as<uint32_t>(), G))
+        for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
     }
     place_aggregate_columns(a, o);
     *out = emit_batch(ctx, std::move(o), out_mem);

@@ -44,6 +44,8 @@ bool filter_fast_path(Ctx *ctx, const Expr &e, const std::function<const DCol &(
 // out[i] = src[idx[i]]; NULL index (idx_validity bit clear) or NULL source row => NULL.
 DCol gather_column(Ctx *ctx, const DCol &src, const void *idx, bool idx_is_u64,
                    const uint64_t *idx_validity, int64_t n);
+// 2..4 plain 8-byte columns by one u32 permutation, through packed rows (gather.hip); false = shape not taken
+bool gather_columns_packed(Ctx *ctx, std::vector<DCol> &cols, int64_t src_rows, const uint32_t *idx, int64_t n);
 DCol concat_columns(Ctx *ctx, const std::vector<const DCol *> &parts); // one part: returned as is (no copy)
 DCol copy_column(Ctx *ctx, const DCol &c); // deep copy into buffers owned by the result
 // ops.hip: stable sort of the rows in `perm` by a Utf8 column (NULL rows tie); keys = n-element scratch
