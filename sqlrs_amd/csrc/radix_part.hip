@@ -360,6 +360,7 @@ struct ChunkOut {
   uint32_t base_chunks, max_chunks; // both = workgroups * arena
   uint32_t cap; // rows per chunk: a multiple of the tile size
   uint32_t arena;     // chunks per workgroup: workgroup b takes chunks b * arena, b * arena + 1, ... in this order
+  uint32_t *hist = nullptr; // H2 kernels: [chunk][next level's digits] rows of the chunk per digit of the NEXT level
 };
 
 // PSRC: where the predicate's operand comes from: -1 no filter, 1 = value column 0, 3 = its own column
@@ -387,7 +388,12 @@ __device__ __forceinline__ bool row_passes(const RowFilter &f, uint64_t bits) {
   return (f.keep_mask & sel) != 0;
 }
 
-template <int NV, int RP_WG, int RP_ROWS, bool PACK, int PSRC>
+// H2: the kernel also counts, per chunk, its rows per digit of the NEXT level (the level-2 histogram pass read the
+// key words of every chunk again for exactly these numbers).  Possible when all P buckets have a counter in LDS:
+// h2[bucket] holds two 16-bit counts, low = rows of the digit's CURRENT chunk, high = rows of this tile that spill
+// into its next chunk (rank >= room left); when a chunk is closed its low halves go to out.hist and the high halves
+// take their place.
+template <int NV, int RP_WG, int RP_ROWS, bool PACK, int PSRC, bool H2 = false>
 __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
     const uint64_t *__restrict__ key, const uint64_t *__restrict__ v0, const uint64_t *__restrict__ v1, RowFilter flt,
     int64_t n, ChunkOut out, uint32_t P, uint32_t p2_bits, uint32_t digits, uint32_t num_tiles, uint32_t tiles_per_wg,
@@ -403,9 +409,13 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
   uint32_t *split = cnt + RP_WG;                              // [RP_WG] tile-local position where a digit's run changes chunk
   int64_t *gb0 = (int64_t *)(split + RP_WG);                  // [RP_WG] destination of position p: gb0[d] + p below the split,
   int64_t *gb1 = gb0 + RP_WG;                                 //         gb1[d] + p from it on
+  uint32_t *room_s = (uint32_t *)(gb1 + RP_WG);               // H2: [RP_WG] rows the digit's current chunk can still take
+  uint32_t *close_id = room_s + RP_WG;                        // H2: [RP_WG] chunk the digit closes in this tile, or ~0
+  uint32_t *h2 = close_id + RP_WG;                            // H2: [P]
   __shared__ uint32_t s_wsum[RP_WG / 64];
   __shared__ uint32_t s_total;
-  __shared__ uint32_t s_next; // arena mode: next free chunk of this workgroup's arena
+  __shared__ uint32_t s_next; // next free chunk of this workgroup's arena
+  const uint32_t d2n = 1u << p2_bits; // digits of the next level
 
   const uint32_t t0 = blockIdx.x * tiles_per_wg;
   const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
@@ -413,6 +423,10 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
   uint32_t cur_id = blockIdx.x * out.arena + min(threadIdx.x, digits - 1), cfill = 0;
   if (threadIdx.x == 0) s_next = digits; // (barriers follow before the first allocation)
   const bool owner = threadIdx.x < digits;
+  if (H2) {
+    room_s[threadIdx.x] = out.cap;
+    for (uint32_t i = threadIdx.x; i < digits * d2n; i += RP_WG) h2[i] = 0;
+  }
   auto tile_start = [&](uint32_t t) { return (int64_t)t * RP_TILE; };
   auto tile_len = [&](uint32_t t) { return (uint32_t)min((int64_t)RP_TILE, n - (int64_t)t * RP_TILE); };
 
@@ -426,8 +440,19 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
     if (PSRC == 3) keep = keep && row_passes(flt, cur.pv[PSRC == 3 ? j : 0]);
     if (keep) {
       const uint64_t k = PACK ? packed_clamp(kp, cur.k[j]) : cur.k[j];
-      dg[j] = rp_digit(rp_bucket(kp, k, true, P), 1, p2_bits);
+      const uint32_t bkt = rp_bucket(kp, k, true, P);
+      dg[j] = rp_digit(bkt, 1, p2_bits);
       rk[j] = atomicAdd(&cnt[dg[j]], 1u);
+      if (H2) atomicAdd(&h2[bkt], rk[j] < room_s[dg[j]] ? 1u : 0x10000u);
+    }
+  };
+  auto flush_closed = [&]() { // H2: histograms of the chunks named in close_id[] -> out.hist, spill counts move down
+    for (uint32_t i = threadIdx.x; i < digits * d2n; i += RP_WG) {
+      const uint32_t c = close_id[i >> p2_bits];
+      if (c == 0xffffffffu) continue;
+      const uint32_t v = h2[i];
+      out.hist[(size_t)c * d2n + (i & (d2n - 1))] = v & 0xffffu;
+      h2[i] = v >> 16;
     }
   };
   auto scan_and_stage = [&]() { // counters -> tile-local run starts + chunk destinations; rows of `cur` -> staging area
@@ -445,6 +470,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
     // destination of this digit's run: the rest of the current chunk, then the pre-fetched one
     const uint32_t room = min(c, out.cap - cfill);
     int64_t g0 = (int64_t)cur_id * (out.cap + RP_CHUNK_SKEW) + cfill, g1 = 0;
+    if (H2) close_id[threadIdx.x] = (owner && c > room) ? cur_id : 0xffffffffu;
     if (owner && c > room) {
       out.chunk_len[cur_id] = out.cap; // closed
       out.chunk_dig[cur_id] = threadIdx.x;
@@ -460,7 +486,9 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
     split[threadIdx.x] = ls + room;
     gb0[threadIdx.x] = g0 - (int64_t)ls;
     gb1[threadIdx.x] = g1 - (int64_t)(ls + room);
+    if (H2) room_s[threadIdx.x] = out.cap - cfill; // what the next tile's rows of this digit may still put into its chunk
     __syncthreads();
+    if (H2) flush_closed(); // (this tile's counts are complete, the next tile's start after the barrier below)
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
       if (dg[j] == 0xffffffffu) continue;
@@ -535,6 +563,12 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
     out.chunk_len[cur_id] = cfill; // (chunks never taken keep the zero length of the table's memset)
     out.chunk_dig[cur_id] = threadIdx.x;
   }
+  if (H2) { // ... and the histograms of the open chunks (no spill counts are left after the last tile)
+    __syncthreads();
+    close_id[threadIdx.x] = owner ? cur_id : 0xffffffffu;
+    __syncthreads();
+    flush_closed();
+  }
 }
 
 // Tile list of level 2 from the chunk table: chunk c of digit s contributes ceil(len / tile) tiles to
@@ -600,7 +634,7 @@ __global__ __launch_bounds__(256) void rp_chunk_assign_kernel(const uint32_t *__
                                                               uint32_t max_chunks, uint32_t digits2, uint32_t cap, uint32_t tile,
                                                               const uint32_t *__restrict__ seg_tiles,
                                                               const uint32_t *__restrict__ seg_tile_base, ChunkPlan *plan,
-                                                              Tile *__restrict__ tiles) {
+                                                              Tile *__restrict__ tiles, uint32_t *__restrict__ tile_chunk) {
   const uint32_t nchunks = min(base_chunks + counter[0], max_chunks);
   for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nchunks; c += gridDim.x * 256) {
     const uint32_t len = chunk_len[c];
@@ -614,8 +648,17 @@ __global__ __launch_bounds__(256) void rp_chunk_assign_kernel(const uint32_t *__
       t.stride = seg_tiles[s];
       t.mat = (int64_t)base * digits2 + i0 + q;
       tiles[base + i0 + q] = t;
+      if (tile_chunk) tile_chunk[base + i0 + q] = c; // (one tile per chunk when the chunk histograms are used)
     }
   }
+}
+// count matrix of the next level (tile-major, what rp_hist_kernel writes) from the chunk histograms of an H2 level
+__global__ void rp_hist_from_chunks_kernel(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ tile_chunk,
+                                           int64_t entries, uint32_t digits, uint32_t *__restrict__ mat) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= entries) return;
+  const uint32_t t = (uint32_t)(i / digits), d = (uint32_t)(i % digits);
+  mat[i] = hist[(size_t)tile_chunk[t] * digits + d];
 }
 
 // bucket b (level-1 digit d1 = b >> p2_bits ... ) start row, from the level's scanned matrix
@@ -807,14 +850,14 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   };
   // one level = hist + scan + scatter over the tiles of `L` (sink = first row behind the output columns)
   auto exec_level = [&](int level, uint32_t digits, const Level &L, const RpIn &rin, const RpOut &rout, int64_t sink,
-                        BufP *offs_out) {
+                        BufP *offs_out, BufP premat = nullptr) {
     const int64_t entries = std::max<int64_t>(L.mat_entries, 1);
-    BufP mat = ctx->alloc(4 * (size_t)entries);
+    BufP mat = premat ? premat : ctx->alloc(4 * (size_t)entries);
     BufP offs = ctx->alloc(4 * (size_t)entries);
     BufP total = ctx->alloc(8);
     unsigned nt = L.num_tiles;
     const Tile *tp = (const Tile *)L.tiles->p;
-    if (nt) {
+    if (nt && !premat) {
       ProfScope ps(ctx, in.build_side ? "rp_hist_build" : "rp_hist");
 #define SQ_RH1(R, PL) rp_hist_kernel<512, R, PL><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, tp, P, p2_bits, level, digits, mat->as<uint32_t>(), kp)
 #define SQ_RH(R) do { if (!rin.key_validity && !rin.flags) SQ_RH1(R, true); else SQ_RH1(R, false); } while (0)
@@ -948,7 +991,13 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       co.max_chunks = (uint32_t)max_chunks;
       co.cap = (uint32_t)CAP;
       const int psrc = !in.filter.col ? -1 : ((nv >= 1 && (const void *)in.filter.col == in.vals[0]) ? 1 : 3);
-      const size_t clds = (size_t)RP_TILE * (pack ? 8 * (1 + nv) : 8 * (1 + nv) + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8);
+      // chunk histograms of the next level counted by this kernel (H2): every bucket needs a 4-byte counter in LDS
+      const char *h2_e = std::getenv("SQLRS_RP_H2"); // A/B hook, read per call: 0 = level 2 runs its own histogram pass
+      const bool h2 = pack && nv == 1 && ROWS == 12 && ct_env == 1 && (size_t)P * 4 <= 24 * 1024 && !(h2_e && std::atoi(h2_e) == 0);
+      BufP chist = h2 ? ctx->alloc(4 * (size_t)max_chunks * ((size_t)1 << p2_bits)) : nullptr;
+      co.hist = chist ? chist->as<uint32_t>() : nullptr;
+      const size_t clds = (size_t)RP_TILE * (pack ? 8 * (1 + nv) : 8 * (1 + nv) + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8) +
+                          (h2 ? (size_t)WG * 8 + (size_t)P * 4 : 0);
       {
         ProfScope ps(ctx, in.filter.col ? "rp_chunk_scatter_filter" : "rp_chunk_scatter");
         const uint64_t *k = in.keys, *a0 = (const uint64_t *)in.vals[0], *a1 = (const uint64_t *)in.vals[1];
@@ -956,6 +1005,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
 #define SQ_CS1(NV, R, PK, PS)                                                                                       \
   do {                                                                                                              \
     auto kfn = rp_chunk_scatter_kernel<NV, 512, R, PK, PS>;                                                         \
+    if (NV == 1 && PK && R == 12 && h2) kfn = rp_chunk_scatter_kernel<NV, 512, R, PK, PS, (NV == 1 && PK && R == 12)>; \
     allow_big_lds(ctx, kfn);                                                                                        \
     kfn<<<dim3(cwgs), dim3(512), clds, ctx->stream>>>(k, a0, a1, in.filter, n, co, P, p2_bits, d1, tiles1, ctpw,   \
                                                       sink, kp);                                                    \
@@ -985,6 +1035,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         bind_level(L2, lay);
         L2.tiles = ctx->alloc(sizeof(Tile) * (size_t)max_chunks * (size_t)ct_env);
         BufP totals = ctx->alloc(24);
+        BufP tile_chunk = h2 ? ctx->alloc(4 * (size_t)max_chunks) : nullptr;
         BufP plan = ctx->alloc(sizeof(ChunkPlan));
         SQ_HIP(hipMemsetAsync(plan->p, 0, sizeof(ChunkPlan), ctx->stream));
         const unsigned pblocks = (unsigned)std::min<uint64_t>(ceil_div((int64_t)max_chunks, 256 * 8), 128);
@@ -995,7 +1046,8 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
             (uint32_t *)L2.d_seg_tiles, (uint32_t *)L2.d_seg_tile_base, totals->as<uint64_t>());
         rp_chunk_assign_kernel<<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(
             co.chunk_len, co.chunk_dig, co.counter, co.base_chunks, co.max_chunks, digits2, (uint32_t)CAP, (uint32_t)RP_TILE,
-            L2.d_seg_tiles, L2.d_seg_tile_base, plan->as<ChunkPlan>(), (Tile *)L2.tiles->p);
+            L2.d_seg_tiles, L2.d_seg_tile_base, plan->as<ChunkPlan>(), (Tile *)L2.tiles->p,
+            tile_chunk ? tile_chunk->as<uint32_t>() : nullptr);
         SQ_HIP(hipGetLastError());
         const uint64_t *ht = (const uint64_t *)ctx->fetch(totals->p, 24);
         const uint64_t ntiles = ht[0], kept = ht[1], overflow = ht[2];
@@ -1014,8 +1066,14 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         Cols c2;
         RpOut rout2;
         alloc_cols((int64_t)kept, true, c2, rout2);
-        BufP offs2;
-        exec_level(2, digits2, L2, rin2, rout2, (int64_t)kept, &offs2);
+        BufP offs2, premat;
+        if (h2 && L2.mat_entries) { // the level's count matrix is already known: no histogram pass over the chunks
+          premat = ctx->alloc(4 * (size_t)L2.mat_entries);
+          rp_hist_from_chunks_kernel<<<dim3((unsigned)ceil_div(L2.mat_entries, 256)), dim3(256), 0, ctx->stream>>>(
+              co.hist, tile_chunk->as<uint32_t>(), L2.mat_entries, digits2, premat->as<uint32_t>());
+          SQ_HIP(hipGetLastError());
+        }
+        exec_level(2, digits2, L2, rin2, rout2, (int64_t)kept, &offs2, premat);
         publish(c2);
         out->bstart = bucket_starts(L2, offs2, digits2, (int64_t)kept, &out->bstart_host);
         return true;
