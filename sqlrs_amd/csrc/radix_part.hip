@@ -635,21 +635,34 @@ __global__ __launch_bounds__(256) void rp_chunk_assign_kernel(const uint32_t *__
                                                               const uint32_t *__restrict__ seg_tiles,
                                                               const uint32_t *__restrict__ seg_tile_base, ChunkPlan *plan,
                                                               Tile *__restrict__ tiles, uint32_t *__restrict__ tile_chunk) {
+  // a block claims the tile slots of its chunks with ONE global atomic per digit (its chunks rank themselves with
+  // LDS atomics): one global atomic per chunk on <= 512 addresses took 96 us for the 9e4 chunks of a C5 step
+  __shared__ uint32_t s_need[512], s_base[512];
   const uint32_t nchunks = min(base_chunks + counter[0], max_chunks);
-  for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nchunks; c += gridDim.x * 256) {
-    const uint32_t len = chunk_len[c];
-    if (!len) continue;
-    const uint32_t s = chunk_dig[c], nt = (len + tile - 1) / tile, base = seg_tile_base[s];
-    const uint32_t i0 = atomicAdd(&plan->cursor[s], nt);
-    for (uint32_t q = 0; q < nt; q++) {
-      Tile t;
-      t.start = (int64_t)c * (cap + RP_CHUNK_SKEW) + (int64_t)q * tile;
-      t.len = min(tile, len - q * tile);
-      t.stride = seg_tiles[s];
-      t.mat = (int64_t)base * digits2 + i0 + q;
-      tiles[base + i0 + q] = t;
-      if (tile_chunk) tile_chunk[base + i0 + q] = c; // (one tile per chunk when the chunk histograms are used)
+  for (uint32_t c0 = blockIdx.x * 256; c0 < nchunks; c0 += gridDim.x * 256) {
+    for (uint32_t i = threadIdx.x; i < 512; i += 256) s_need[i] = 0;
+    __syncthreads();
+    const uint32_t c = c0 + threadIdx.x;
+    const uint32_t len = c < nchunks ? chunk_len[c] : 0;
+    const uint32_t s = len ? chunk_dig[c] : 0, nt = (len + tile - 1) / tile;
+    const uint32_t local = len ? atomicAdd(&s_need[s], nt) : 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 512; i += 256)
+      if (s_need[i]) s_base[i] = atomicAdd(&plan->cursor[i], s_need[i]);
+    __syncthreads();
+    if (len) {
+      const uint32_t base = seg_tile_base[s], i0 = s_base[s] + local;
+      for (uint32_t q = 0; q < nt; q++) {
+        Tile t;
+        t.start = (int64_t)c * (cap + RP_CHUNK_SKEW) + (int64_t)q * tile;
+        t.len = min(tile, len - q * tile);
+        t.stride = seg_tiles[s];
+        t.mat = (int64_t)base * digits2 + i0 + q;
+        tiles[base + i0 + q] = t;
+        if (tile_chunk) tile_chunk[base + i0 + q] = c; // (one tile per chunk when the chunk histograms are used)
+      }
     }
+    __syncthreads(); // (s_need / s_base are reused by the next trip)
   }
 }
 // count matrix of the next level (tile-major, what rp_hist_kernel writes) from the chunk histograms of an H2 level
