@@ -112,6 +112,30 @@ def test_probe_filter_chunked(hip, oracle, sparse, pred, aggs):
     assert_same(got, exp, float_cols={2} if aggs == "count_sum" else ({1} if aggs == "two_columns" else ()))
 
 
+@pytest.mark.parametrize("threshold", [0.3, -1.0])
+def test_probe_filter_chunked_hot_digit(hip, oracle, threshold):
+    """chunk close / spill logic at test size: every probe key falls into ONE level-1 digit, so each workgroup's chunk
+    of that digit overflows after one or two tiles (a tile's run is split between the closing chunk and the next
+    one; with `val > -1` every tile fills a chunk exactly and the next tile closes it with no room left) — the
+    per-chunk counts of the level-2 digits that level 1 hands to level 2 must follow every one of those moves"""
+    rng = np.random.default_rng(int(threshold * 10) + 50)
+    nb, np_ = 2_400_000, 6_000_000
+    bkeys = rng.permutation(nb).astype(np.int64)
+    pk = rng.integers(1000, 1000 + nb // 80, np_, dtype=np.int64)  # ~30 K distinct keys: inside the first level-1 digit
+    lb = pa.RecordBatch.from_arrays([pa.array(bkeys), pa.array(rng.random(nb))], names=["c0", "c1"])
+    rb = pa.RecordBatch.from_arrays([pa.array(rng.random(np_)), pa.array(pk), pa.array(rng.integers(-100, 100, np_, dtype=np.int64))],
+                                    names=["c0", "c1", "c2"])
+    sch = pa.schema([("l.c0", pa.int64()), ("l.c1", pa.float64()), ("r.c0", pa.float64()), ("r.c1", pa.int64()), ("r.c2", pa.int64())])
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    pred = InputRef(0) > Constant(threshold, abi.FLOAT64)
+    ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, AGGS["count_sum"], [InputRef(0)], probe_filter=pred)
+    got = rows_of(ex.execute())
+    if FORCED:
+        assert ex.fused_batches == 1 and ex.filter_fused_batches == 1
+    exp = reference(oracle, lb, [rb], cond, sch, 2, AGGS["count_sum"], [InputRef(0)], pred)
+    assert_same(got, exp, float_cols={2})
+
+
 @pytest.mark.parametrize("keys", ["dense", "sparse"])
 def test_hash_agg_chunked(hip, oracle, keys):
     """plain HashAgg whose partition needs two levels (2.6e6 groups, > 512 tables of 4096 slots): chunked first level, no filter"""
