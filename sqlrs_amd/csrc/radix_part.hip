@@ -467,7 +467,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
     }
     const uint32_t ls = wbase + inc - c;
     if (threadIdx.x == 0) s_total = tot;
-    // destination of this digit's run: the rest of the current chunk, then the pre-fetched one
+    // destination of this digit's run: the rest of the current chunk, then the next chunk of the arena
     const uint32_t room = min(c, out.cap - cfill);
     int64_t g0 = (int64_t)cur_id * (out.cap + RP_CHUNK_SKEW) + cfill, g1 = 0;
     if (H2) close_id[threadIdx.x] = (owner && c > room) ? cur_id : 0xffffffffu;
@@ -798,9 +798,9 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     }
     if (d1 > 256 && p2_bits == 8) return false;
     // Very large batches that take the chunked first level: one bit more for level 1 (512 digits) and one less for
-    // level 2.  Level 2 gains more from its longer runs than level 1 loses (C5, same process: 5.30 + 4.77 ->
-    // 5.58 + 4.24 ms); the bucket layout of the result does not depend on the split.  The pre-assigned chunks of
-    // 512 digits must still be a fraction of the input (see `chunked` below).
+    // level 2.  Level 2 gains more from its longer runs than level 1 loses (C5 with sparse keys, same process:
+    // 7.93 + 6.67 -> 7.80 + 6.26 ms); the bucket layout of the result does not depend on the split.  The arena
+    // slack of 512 digits must still be a fraction of the input (see `chunked` below).
     if (!p2_e && p2_bits == 8 && 2 * d1 <= 512 && !in.key_validity && !in.val_validity[0] && !in.val_validity[1] &&
         2ull * std::min<uint64_t>((uint64_t)ceil_div(n, 6144), (uint64_t)ctx->num_cus) * (2 * d1) * 6144ull <= 2 * (uint64_t)n) {
       p2_bits = 7;
@@ -957,7 +957,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   };
 
   // ---- chunked first level (no histogram pass, optional fused row filter): two-level partitions of
-  // batches large enough that the 2 x workgroups x digits pre-assigned chunks are a fraction of the input
+  // batches large enough that the slack of the arenas (workgroups x (digits + 1) chunks) is a fraction of the input
   static const int chunk_env = [] { // test / tuning hook: 1 = whenever two levels are needed, 0 = never
     const char *e = std::getenv("SQLRS_RP_CHUNKED");
     return e ? std::atoi(e) : -1;
