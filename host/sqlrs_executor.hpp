@@ -13,6 +13,9 @@
 //                    join_output_schema}                                     src/executor/join/hash_join.rs:16-23
 //   HashAggExecutor{agg_funcs, group_by, child}                              src/executor/aggregate/hash_agg.rs:15-19
 //   OrderExecutor{order_by, child}                                           src/executor/order.rs:8-11
+//   ProjectExecutor{exprs, child}                                            src/executor/project.rs:6-28
+//   LimitExecutor{limit, offset, child}                                      src/executor/limit.rs:4-81
+//   SimpleAggExecutor{agg_funcs, child}                                      src/executor/aggregate/simple_agg.rs:9-65
 //   BoundExpr / BoundAggFunc / BoundOrderBy / JoinCondition / JoinType /
 //   ColumnCatalog, build_bound_input_ref                                     src/binder/**, src/catalog/mod.rs
 //   pretty_format_batches                                                    arrow::util::pretty (used by the tests)
@@ -488,6 +491,107 @@ struct OrderExecutor { // order.rs:8-11
     for (auto &x : order_by) low.push_back(detail::lower(x.expr));
     for (size_t i = 0; i < order_by.size(); i++) ob.push_back(sqlrs_order_by_t{low[i].abi(), order_by[i].asc, 0});
     ctx->check(sqlrs_order_create(ctx->raw, (int)ob.size(), ob.data(), &s->o));
+    return s;
+  }
+};
+
+// ---- the operators either side of the path, same ABI, same stream shape ----------------
+struct ProjectExecutor { // project.rs:6-9
+  HipCtxRef ctx;
+  std::vector<BoundExpr> exprs;
+  BoxedExecutor child;
+  std::vector<std::string> output_names; // eval_field's names are the caller's business (binder); optional here
+  BoxedExecutor execute() {
+    struct S : Executor {
+      HipCtxRef ctx; BoxedExecutor child; sqlrs_project_t *p = nullptr; std::vector<std::string> names;
+      ~S() override { if (p) sqlrs_project_destroy(p); }
+      std::optional<RecordBatch> next() override { // one output batch per input batch (project.rs:15-27)
+        auto b = child->next();
+        if (!b) return std::nullopt;
+        detail::AbiBatch in(*b);
+        sqlrs_batch_t *out = nullptr;
+        ctx->check(sqlrs_project_push(p, &in.b, SQLRS_MEM_HOST, &out));
+        RecordBatch rb = detail::import_batch(out, nullptr);
+        auto sch = std::make_shared<Schema>(*rb.schema);
+        for (size_t i = 0; i < sch->size() && i < names.size(); i++) (*sch)[i].name = names[i];
+        rb.schema = sch;
+        return rb;
+      }
+    };
+    auto s = std::make_unique<S>();
+    s->ctx = ctx; s->child = std::move(child); s->names = output_names;
+    std::vector<detail::Lowered> low;
+    std::vector<sqlrs_expr_t> ex;
+    for (auto &e : exprs) low.push_back(detail::lower(e));
+    for (auto &l : low) ex.push_back(l.abi());
+    ctx->check(sqlrs_project_create(ctx->raw, (int)ex.size(), ex.data(), &s->p));
+    return s;
+  }
+};
+
+struct LimitExecutor { // limit.rs:4-8; both bounds are Constants in the reference (limit.rs:14-27)
+  HipCtxRef ctx;
+  std::optional<int64_t> limit, offset;
+  BoxedExecutor child;
+  BoxedExecutor execute() {
+    struct S : Executor {
+      HipCtxRef ctx; BoxedExecutor child; sqlrs_limit_t *l = nullptr; bool done = false;
+      ~S() override { if (l) sqlrs_limit_destroy(l); }
+      std::optional<RecordBatch> next() override {
+        while (!done) { // batches that fall before the offset produce nothing (limit.rs:62-64)
+          auto b = child->next();
+          if (!b) return std::nullopt;
+          detail::AbiBatch in(*b);
+          sqlrs_batch_t *out = nullptr;
+          int fin = 0;
+          ctx->check(sqlrs_limit_push(l, &in.b, SQLRS_MEM_HOST, &out, &fin));
+          done = fin != 0; // limit.rs:76-78: stop pulling the child
+          if (out) return detail::import_batch(out, b->schema);
+        }
+        return std::nullopt;
+      }
+    };
+    auto s = std::make_unique<S>();
+    s->ctx = ctx; s->child = std::move(child);
+    ctx->check(sqlrs_limit_create(ctx->raw, limit ? 1 : 0, limit.value_or(0), offset ? 1 : 0, offset.value_or(0), &s->l));
+    if (limit && *limit == 0) s->done = true; // limit.rs:29-31: nothing is pulled at all
+    return s;
+  }
+};
+
+struct SimpleAggExecutor { // simple_agg.rs:9-12: aggregates without GROUP BY, exactly one output row
+  HipCtxRef ctx;
+  std::vector<BoundAggFunc> agg_funcs;
+  BoxedExecutor child;
+  std::vector<std::string> output_names;
+  BoxedExecutor execute() {
+    struct S : Executor {
+      HipCtxRef ctx; BoxedExecutor child; sqlrs_simple_agg_t *a = nullptr; bool done = false; std::vector<std::string> names;
+      ~S() override { if (a) sqlrs_simple_agg_destroy(a); }
+      std::optional<RecordBatch> next() override {
+        if (done) return std::nullopt;
+        done = true;
+        while (auto b = child->next()) { // simple_agg.rs:35-57
+          detail::AbiBatch in(*b);
+          ctx->check(sqlrs_simple_agg_push(a, &in.b));
+        }
+        sqlrs_batch_t *out = nullptr;
+        ctx->check(sqlrs_simple_agg_finish(a, SQLRS_MEM_HOST, &out));
+        RecordBatch rb = detail::import_batch(out, nullptr);
+        auto sch = std::make_shared<Schema>(*rb.schema);
+        for (size_t i = 0; i < sch->size() && i < names.size(); i++) (*sch)[i].name = names[i];
+        rb.schema = sch;
+        return rb;
+      }
+    };
+    auto s = std::make_unique<S>();
+    s->ctx = ctx; s->child = std::move(child); s->names = output_names;
+    std::vector<detail::Lowered> al;
+    std::vector<sqlrs_agg_func_t> af;
+    for (auto &f : agg_funcs) al.push_back(detail::lower(f.exprs.at(0))); // only exprs[0] is read (simple_agg.rs:38-41)
+    for (size_t i = 0; i < agg_funcs.size(); i++)
+      af.push_back(sqlrs_agg_func_t{(int32_t)agg_funcs[i].func, agg_funcs[i].distinct, (int32_t)agg_funcs[i].return_type, 0, al[i].abi()});
+    ctx->check(sqlrs_simple_agg_create(ctx->raw, (int)af.size(), af.data(), &s->a));
     return s;
   }
 };

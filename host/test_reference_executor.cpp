@@ -8,6 +8,7 @@
 //   src/executor/aggregate/hash_agg.rs:182-222 test_hash_agg_with_multiple_chunks
 //   src/executor/mod.rs:309-345                test_executor_hash_agg_works (operator level)
 //   src/executor/mod.rs:264-285,368-395        filter / order, operator level
+//   src/executor/limit.rs:97-117               limit (six cases); project / simple_agg at operator level
 // The expected tables are the reference's golden vectors (data), not its code.
 //
 // Build:  g++ -std=c++17 -Iinclude host/test_reference_executor.cpp -Lsqlrs_amd/csrc -lsqlrs_hip
@@ -240,6 +241,76 @@ int main() {
       if (e.kind != ExecutorError::InternalError) failures++;
       std::printf("ok   hash agg without input -> InternalError(%s)\n", e.what());
     }
+  }
+  // ---- limit.rs:97-117: the six (inputs, offset, limit, outputs) cases of `limit`, as data
+  {
+    struct LimitCase {
+      std::vector<std::pair<int, int>> inputs; // half-open ranges, one chunk each (range_to_chunk, limit.rs:119-123)
+      int64_t offset, limit;
+      std::vector<std::pair<int, int>> outputs;
+    };
+    const std::vector<LimitCase> cases = {
+        {{{0, 6}}, 1, 4, {{1, 5}}},
+        {{{0, 6}}, 0, 10, {{0, 6}}},
+        {{{0, 6}}, 10, 0, {}},
+        {{{0, 2}, {2, 4}, {4, 6}}, 1, 4, {{1, 2}, {2, 4}, {4, 5}}},
+        {{{0, 2}, {2, 4}, {4, 6}}, 1, 2, {{1, 2}, {2, 3}}},
+        {{{0, 2}, {2, 4}, {4, 6}}, 3, 0, {}},
+    };
+    auto schema = std::make_shared<Schema>(Schema{{"a", DataType::Int32, false}});
+    auto chunk = [&](std::pair<int, int> r) {
+      std::vector<int32_t> v;
+      for (int x = r.first; x < r.second; x++) v.push_back(x);
+      return RecordBatch::try_new(schema, {Int32Array(v)});
+    };
+    int ci = 0;
+    for (const LimitCase &c : cases) {
+      std::vector<RecordBatch> in;
+      for (auto r : c.inputs) in.push_back(chunk(r));
+      LimitExecutor ex;
+      ex.ctx = ctx;
+      ex.offset = c.offset;
+      ex.limit = c.limit;
+      ex.child = stream_iter(in);
+      auto out = try_collect(ex.execute());
+      bool same = out.size() == c.outputs.size(); // the reference compares the batches one by one (assert_eq on Vec<RecordBatch>)
+      for (size_t i = 0; same && i < out.size(); i++) {
+        same = out[i].num_rows() == c.outputs[i].second - c.outputs[i].first;
+        for (int64_t r = 0; same && r < out[i].num_rows(); r++)
+          same = out[i].columns[0]->value_to_string(r) == std::to_string(c.outputs[i].first + (int)r);
+      }
+      if (same) std::printf("ok   limit case %d\n", ci);
+      else { failures++; std::printf("FAIL limit case %d\n", ci); }
+      ci++;
+    }
+  }
+  { // select id + 1, salary from employee   (ProjectExecutor, project.rs:13-28: one output batch per input batch)
+    ProjectExecutor ex;
+    ex.ctx = ctx;
+    ex.exprs = {BoundExpr::binary_op(BinaryOperator::Plus, build_bound_input_ref(0), BoundExpr::constant(ScalarValue::Int64(1))),
+                build_bound_input_ref(3)};
+    ex.child = stream_iter({employee, employee});
+    ex.output_names = {"id + 1", "salary"};
+    auto out = try_collect(ex.execute());
+    if (out.size() != 2) { failures++; std::printf("FAIL project: %zu batches for 2 input batches\n", out.size()); }
+    expect_table("project id + 1, salary (two chunks)", out,
+                 {"+--------+--------+", "| id + 1 | salary |", "+--------+--------+", "| 2      | 100    |", "| 3      | 100    |",
+                  "| 4      | 200    |", "| 5      | 400    |", "| 2      | 100    |", "| 3      | 100    |", "| 4      | 200    |",
+                  "| 5      | 400    |", "+--------+--------+"});
+  }
+  { // select count(id), sum(salary), max(salary), min(id) from employee   (SimpleAggExecutor over two chunks: one row)
+    SimpleAggExecutor ex;
+    ex.ctx = ctx;
+    ex.agg_funcs = {BoundAggFunc{AggFunc::Count, {build_bound_input_ref(0)}, DataType::Int64, false},
+                    BoundAggFunc{AggFunc::Sum, {build_bound_input_ref(3)}, DataType::Int64, false},
+                    BoundAggFunc{AggFunc::Max, {build_bound_input_ref(3)}, DataType::Int64, false},
+                    BoundAggFunc{AggFunc::Min, {build_bound_input_ref(0)}, DataType::Int64, false}};
+    ex.child = stream_iter({employee, employee});
+    ex.output_names = {"Count(id)", "Sum(salary)", "Max(salary)", "Min(id)"};
+    expect_table("simple agg over two chunks", try_collect(ex.execute()),
+                 {"+-----------+-------------+-------------+---------+", "| Count(id) | Sum(salary) | Max(salary) | Min(id) |",
+                  "+-----------+-------------+-------------+---------+", "| 8         | 1600        | 400         | 1       |",
+                  "+-----------+-------------+-------------+---------+"});
   }
   std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "PASSED", failures, failures == 1 ? "" : "s");
   return failures ? 1 : 0;
