@@ -17,7 +17,7 @@
  * documented semantics.
  *
  * Pinning: tests/test_oracle_golden.py checks this oracle against every golden
- * table the reference's own tests hold for this path (tests/golden/*.json,
+ * table the reference's own tests hold for this path (tests/golden/ (.json files),
  * transcribed from hash_join.rs:442-749, hash_agg.rs:213-220,
  * executor/mod.rs:271-395, tests/slt/{aggregation,join,join_filter,order,
  * filter,distinct}.slt).
