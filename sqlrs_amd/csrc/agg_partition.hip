@@ -292,15 +292,18 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     for (int64_t i = blo + threadIdx.x; i < bhi; i += PART_WG) {
       uint64_t key = bk[i];
       bool valid = bf ? (bf[i] & 1) : true;
+      // a key seen twice = duplicate build keys: the caller's pre-condition does not hold (it may not have been
+      // established yet, join_state.hpp `unique_known`): flag it, the caller falls back to the composed route
       if (!valid) {
-        tkey[cap] = 1; // NULL build key present (NULL = NULL matches)
+        if (atomicExch(&tkey[cap], 1ull) != LDS_EMPTY) atomicExch(ov_count + 1, 1ull); // NULL build key present (NULL = NULL matches)
       } else if (key == LDS_EMPTY) {
-        tkey[cap + 1] = 1;
+        if (atomicExch(&tkey[cap + 1], 1ull) != LDS_EMPTY) atomicExch(ov_count + 1, 1ull);
       } else {
         uint32_t s = slot_hash(key) & mask;
         uint32_t probes = 0;
         while (true) {
           unsigned long long prev = atomicCAS(&tkey[s], LDS_EMPTY, (unsigned long long)key);
+          if (prev == key) atomicExch(ov_count + 1, 1ull);
           if (prev == LDS_EMPTY || prev == key) break;
           s = (s + 1) & mask;
           if (++probes >= cap) {
@@ -829,7 +832,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     const uint64_t pd = (range >> rbits) + 1;
     // join: unique build keys (the caller's pre-condition) that span exactly join_n values are
     // every value of the range; otherwise: at most ~4 slots per group
-    const bool fills = join_mode ? (range + 1 == (uint64_t)in.join_n) : ((double)range + 1.0 <= 4.0 * est);
+    const bool fills = join_mode ? (in.join_unique_known && range + 1 == (uint64_t)in.join_n) : ((double)range + 1.0 <= 4.0 * est);
     if (fills && pd <= 65536 && (double)pd <= 1.5 * std::max(1.0, std::ceil(want))) {
       dense = true;
       kp.dense = 1;

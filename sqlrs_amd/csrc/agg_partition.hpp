@@ -36,6 +36,10 @@ struct PartAggInput {
   // (the join's direct-address table): saves a pass over the build keys and a host round trip
   bool join_range_known = false;
   uint64_t join_omin = 0, join_omax = 0;
+  // the build keys are KNOWN to be unique (the caller's pre-condition).  false: not established yet — only the route
+  // that inserts the build keys into its bucket tables (and notices a key twice) may run, not the direct-addressed
+  // one, which takes "every key of the range has a partner" from uniqueness
+  bool join_unique_known = true;
   // FilterExecutor directly below (fused join only): rows failing `filter` do not exist for the
   // operator.  Evaluated by the chunked first partition level; when that level does not apply the
   // call returns false and the caller runs the Filter operator first.

@@ -487,6 +487,7 @@ struct JoinSide {
   const uint64_t *validity;
   int64_t n;
   PartitionedRows *cache;
+  bool unique_known = true; // false: uniqueness of the build keys not established yet (agg_partition.hpp)
   bool range_known = false; // omin / omax: signed-order images of the smallest / largest valid key
   uint64_t omin = 0, omax = 0;
 };
@@ -577,6 +578,7 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
           pin.join_n = js->n;
           pin.join_cache = js->cache;
           pin.join_range_known = js->range_known;
+          pin.join_unique_known = js->unique_known;
           pin.join_omin = js->omin;
           pin.join_omax = js->omax;
           if (rf) pin.filter = *rf;
@@ -967,6 +969,7 @@ int sqlrs_join_agg_create(sqlrs_ctx_t *ctx, int num_keys, const sqlrs_expr_t *le
     int st = sqlrs_hash_join_create(ctx, SQLRS_JOIN_INNER, num_keys, left_keys, right_keys, nullptr,
                                     num_right_columns, right_dtypes, &ja->join);
     if (st != SQLRS_OK) fail(st, ctx->last_error);
+    ja->join->lazy_table = true; // (join_state.hpp: built when the composed route first probes it)
     st = sqlrs_hash_agg_create(ctx, num_group_by, group_by, num_aggs, aggs, &ja->agg);
     if (st != SQLRS_OK) fail(st, ctx->last_error);
     *out = ja.release();
@@ -1021,7 +1024,9 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bo
     // that key, aggregate arguments taken from the probe side only.  Then every probe row
     // yields at most one joined row and Agg(Join(build, probe)) = Agg(probe rows whose key
     // has a build partner): the joined batch is never materialised.
-    bool eligible = j->unique && j->exact && j->lkeys.size() == 1 && j->lkeys[0].nodes.size() == 1 &&
+    // (a join whose hash table is still deferred has not established uniqueness: the fused bucket pass inserts the
+    //  build keys itself and reports duplicates — the attempt then fails and the table is built after all)
+    bool eligible = (j->unique || !j->unique_known) && j->exact && j->lkeys.size() == 1 && j->lkeys[0].nodes.size() == 1 &&
                     j->rkeys[0].nodes.size() == 1 && j->lkeys[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
                     j->rkeys[0].nodes[0].op == SQLRS_EXPR_INPUT_REF && a->group_by.size() == 1 &&
                     a->group_by[0].nodes.size() == 1 && a->group_by[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
@@ -1057,6 +1062,7 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bo
         js.validity = j->bkeys_validity ? j->bkeys_validity->as<uint64_t>() : nullptr;
         js.n = j->nB;
         js.cache = &ja->build_parts;
+        js.unique_known = j->unique_known;
         if (j->dense && j->dense_range) { // the direct-address table's key range
           js.range_known = true;
           js.omin = j->dense_min ^ (1ull << 63);
@@ -1071,6 +1077,7 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bo
           return;
         }
       }
+      hash_join_ensure_table(j); // (the attempt may have failed on duplicate build keys: `unique` is a fact from here on)
     }
     if (filter_pending) return; // (handled below: Filter operator, then the unfiltered path)
     // composed route: materialise the joined batch on the device and aggregate it

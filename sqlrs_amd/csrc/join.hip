@@ -538,6 +538,7 @@ static NKeys eval_keys(Ctx *ctx, const std::vector<Expr> &exprs,
   return normalize_keys(ctx, kc, rows);
 }
 
+static void build_hash_table(sqlrs_hash_join *j);
 static void build_table(sqlrs_hash_join *j) {
   Ctx *ctx = j->ctx;
   // concat key parts
@@ -622,6 +623,7 @@ static void build_table(sqlrs_hash_join *j) {
         const uint32_t hd[2] = {(hc[1] <= 1 && hc[0] + hc[1] == (uint64_t)n) ? 0u : 1u, (uint32_t)hc[2]};
         if (hd[0] == 0) {
           j->unique = true;
+          j->unique_known = j->table_built = true;
           j->dense = dense;
           j->dense_min = dmin;
           j->dense_range = range;
@@ -631,7 +633,16 @@ static void build_table(sqlrs_hash_join *j) {
       }
     }
   }
-  // 2. open-addressing table over the key hash (any key type, duplicates allowed)
+  if (j->lazy_table) return; // built by hash_join_ensure_table when something probes it
+  build_hash_table(j);
+}
+
+// 2. open-addressing table over the key hash (any key type, duplicates allowed)
+static void build_hash_table(sqlrs_hash_join *j) {
+  Ctx *ctx = j->ctx;
+  const int64_t n = j->nB;
+  BufP keys = j->bkeys, validity = j->bkeys_validity;
+  j->table_built = j->unique_known = true;
   uint64_t cap = 64;
   while (2 * cap < 3 * (uint64_t)n) cap <<= 1; // load factor <= 2/3
   j->mask = cap - 1;
@@ -673,8 +684,13 @@ static void build_table(sqlrs_hash_join *j) {
   }
 }
 
+void hash_join_ensure_table(sqlrs_hash_join *j) {
+  if (!j->table_built && j->finished && !j->empty_build) build_hash_table(j);
+}
+
 static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   Ctx *ctx = j->ctx;
+  hash_join_ensure_table(j);
   if (pk.exact != j->exact || (pk.exact && pk.dtype != j->key_dtype))
     fail(SQLRS_ERR_INTERNAL, "join keys of different types on the two sides are not supported");
   Pairs p;

@@ -23,6 +23,10 @@ struct sqlrs_hash_join {
   sq::BufP table;
   uint64_t mask = 0;
   bool unique = true, exact = true;
+  // A join owned by a HashJoin+HashAgg (sqlrs_join_agg) defers its general hash table: the fused route never
+  // probes it (its bucket pass inserts the build keys into LDS tables and reports duplicates itself), so the table
+  // (1.1 ms for 1e7 keys) is built on first need only — `unique` is a fact once `unique_known` is set.
+  bool lazy_table = false, table_built = false, unique_known = false;
   int32_t key_dtype = SQLRS_INT64;
   sq::BufP rows_by_slot;
   sq::BufP visited; // bit per build row
@@ -32,3 +36,7 @@ struct sqlrs_hash_join {
   sq::BufP bkeys, bkeys_validity; // normalised build keys (u64[nB]) and their validity bitmap
 };
 
+// builds the deferred hash table of a `lazy_table` join (join.hip); no-op otherwise
+namespace sq {
+void hash_join_ensure_table(sqlrs_hash_join *j);
+}

@@ -396,6 +396,39 @@ def test_join_agg_composed_route(hip, oracle):
     assert_same(got, exp, float_cols={3})
 
 
+@pytest.mark.parametrize("build", ["unique", "one_duplicate", "two_nulls", "many_duplicates"])
+def test_join_agg_deferred_hash_table(hip, oracle, build):
+    """Sparse 64-bit build keys (no direct-address table): a join owned by HashJoinAgg defers its hash table, the
+    fused bucket pass inserts the build keys into its LDS tables and is the one that notices a key twice (or two
+    NULL keys) — the attempt is dropped, the table is built after all and the operators are composed; unique
+    keys never build it.  Fused-eligible shape in every case: group by the join key, arguments from the probe side."""
+    from sqlrs_amd.executor import HashJoinAggExecutor
+    rng = np.random.default_rng(len(build))
+    nb, np_ = 40_000, 300_000
+    A = np.int64(0x9E3779B97F4A7C15 - (1 << 64))
+    with np.errstate(over="ignore"):
+        lkeys = rng.permutation(nb).astype(np.int64) * A + np.int64(17)
+        pkeys = rng.integers(0, int(nb * 1.1), np_, dtype=np.int64) * A + np.int64(17)
+    lmask = np.zeros(nb, bool)
+    if build == "one_duplicate":
+        lkeys[nb - 1] = lkeys[3]
+    elif build == "many_duplicates":
+        lkeys[nb // 2:] = lkeys[:nb - nb // 2]
+    elif build == "two_nulls":
+        lmask[[5, 777]] = True
+    pmask = rng.random(np_) < (0.01 if build == "two_nulls" else 0.0)
+    lb = pa.RecordBatch.from_arrays([pa.array(lkeys, mask=lmask), pa.array(rng.random(nb))], names=["c0", "c1"])
+    rb = pa.RecordBatch.from_arrays([pa.array(pkeys, mask=pmask), pa.array(rng.random(np_))], names=["c0", "c1"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64)]
+    ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
+    got = rows_of(ex.execute())
+    assert (ex.fused_batches >= 1) == (build == "unique")
+    exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
+    assert_same(got, exp, float_cols={2})
+
+
 # ------------------------------------------------------------------------- Utf8 paths --
 def _strings(rng, n, null_frac=0.1):
     alphabet = ["a", "ab", "abc", "b", "", "zz", "abcdefgh", "abcdefghi", "abcdefgh\x00", "Colorado", "CA", "CO", "été"]
