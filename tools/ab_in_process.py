@@ -17,7 +17,7 @@ if os.environ.get("SPARSE"):  # sparse 64-bit keys (k -> k * odd + c on both sid
     fk.mul_(A_s).add_(12345); dk.mul_(A_s).add_(12345)
 torch.cuda.synchronize()
 print("ptrs", hex(fk.data_ptr()), hex(fv.data_ptr()))
-pipe = bench.Pipeline(be, abi, 0.5)
+pipe = bench.Pipeline(be, abi, 0.5, fused=os.environ.get("UNFUSED") != "1")  # UNFUSED=1: Filter, HashJoin, HashAgg as three operators
 def step():
     pipe.step(bench.device_batch(abi, [dk], [abi.INT64]), bench.device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64])).release()
 VAR = os.environ.get("VAR", "SQLRS_RP_CHUNK_TILES")  # a hook the library reads per call
