@@ -65,8 +65,12 @@ def parse():
     p.add_argument("--exchange", choices=["auto", "partition", "broadcast"], default="auto",
                    help="N>1: 'partition' = hash-partition fact AND dim on the join key + all-to-all (partitioned "
                         "hash join); 'broadcast' = all-gather the dim keys, aggregate the local fact slice, then "
-                        "hash-partition + all-to-all only the partial aggregates and merge; 'auto' = broadcast when "
-                        "the dim is at least 16x smaller than the fact table")
+                        "hash-partition + all-to-all only the partial aggregates and merge; 'auto' = partition "
+                        "(north_star's partitioned hash join)")
+    p.add_argument("--force-exchange", action="store_true",
+                   help="N=1 only: run the multi-GPU code path (RCCL process group of ONE rank, fused filter + hash "
+                        "partition, all-to-all, stream hand-over, local HashJoinAgg) instead of the single-GPU step; "
+                        "a hardware smoke of the exchange path, never the headline configuration")
     p.add_argument("--unfused", action="store_true",
                    help="run HashJoin and HashAgg as two operators (joined batch materialised in HBM)")
     p.add_argument("--separate-filter", action="store_true",
@@ -77,6 +81,27 @@ def parse():
                         "operators) that the default N=1 run times after the headline measurement")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = all)")
     return p.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port); rank 0's JSON
+    line is this process's stdout.  Returns the launcher's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] no launcher in the environment: starting", " ".join(cmd))
+    return subprocess.call(cmd, env=env)
 
 
 def device_batch(abi, tensors, dtypes):
@@ -257,12 +282,17 @@ def main():
     import sqlrs_amd
     from sqlrs_amd import abi, datagen
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, same command line)
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, "
+                         f"or run `python bench.py --gpus {args.gpus}` without a launcher)")
+    # multi = the exchange path runs: N > 1, or N = 1 with --force-exchange (RCCL group of one rank)
+    multi = world > 1 or args.force_exchange
     # test hook: all ranks on GPU 0 with a gloo process group (exchange staged through the host) so
     # that the multi-rank logic can be exercised on a one-GPU box; never used for reported numbers
     single_dev = os.environ.get("SQLRS_BENCH_SINGLE_DEVICE") == "1"
@@ -270,16 +300,20 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:  # --force-exchange without a launcher: a rendezvous of one
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if single_dev:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
     rank_info = None
-    if world > 1:
+    if multi:
         # self-check: the process group really spans `world` ranks on `world` distinct GPUs over RCCL
         one = torch.ones(1, dtype=torch.int64, device=dev)
         dist.all_reduce(one)
@@ -310,7 +344,7 @@ def main():
         log(f"[bench] generated {f_hi - f_lo:,} fact rows + {d_hi - d_lo:,} dim rows per rank in {time.time() - t0:.1f}s")
     # expected result per group, computed by torch on the same columns (independent of the library):
     # exp_cnt[k] / exp_sum[k] over the kept fact rows of ALL ranks, has_dim[k] = key k has a build partner
-    exp_cnt, exp_sum, has_dim, expected_kept = expected_groups(torch, dist if world > 1 else None, fact_key, fact_val,
+    exp_cnt, exp_sum, has_dim, expected_kept = expected_groups(torch, dist if multi else None, fact_key, fact_val,
                                                                dim_key, args.threshold, n_dim_total)
 
     pipe = Pipeline(be, abi, args.threshold, fused=not args.unfused, fuse_filter=not args.separate_filter)
@@ -323,7 +357,7 @@ def main():
     strategy = args.exchange
     if strategy == "auto":
         strategy = "partition"  # north_star: build AND probe side hash-partitioned on the join key, RCCL all-to-all
-    pipe.partial = world > 1 and strategy == "broadcast"
+    pipe.partial = multi and strategy == "broadcast"
     dim_sizes = [D_shard(n_dim_total, r, world) for r in range(world)]
     merge_gb, _mk = abi.pack_exprs([InputRef(0)])
     _mkeep = []
@@ -331,7 +365,7 @@ def main():
     merge_aggs = (abi.AggFunc * 2)(_AggFunc("sum", InputRef(1), abi.INT64).abi_struct(_mkeep),
                                    _AggFunc("sum", InputRef(2), abi.FLOAT64).abi_struct(_mkeep))
     # split sizes of the all-to-alls travel over a CPU group: the host never waits for a payload collective
-    count_group = dist.new_group(backend="gloo") if world > 1 else None
+    count_group = dist.new_group(backend="gloo") if multi else None
     data_group = count_group if single_dev else None  # None = the default (RCCL) group
     wire_out = (lambda t: t.cpu()) if single_dev else None
     wire_in = (lambda t: t.to(dev)) if single_dev else None
@@ -362,6 +396,37 @@ def main():
         be.check(be.fn("ctx_wait_stream")(be.ctx, torch_stream()))  # ... and the ctx stream for torch's
         for parts, _, _ in keep:
             parts.release()  # (pool blocks go to LATER ctx-stream work, i.e. behind the collectives that read them)
+        xstat["bytes_off_rank"] += ex.bytes_off_rank
+        return outs
+
+    fused_exchange = os.environ.get("SQLRS_BENCH_EXCHANGE_FUSED", "1") != "0"
+
+    def exchange_filtered_fact():
+        """Filter + hash partition of the local fact slice in ONE pass per chunk (sqlrs_hash_partition_filter: every
+        row read once, every kept row written once into its partition's region), the slices of chunk k travelling
+        (list all-to-all straight out of the regions) while chunk k + 1 is filtered and partitioned."""
+        from sqlrs_amd.expr import Constant
+        dtypes = [abi.INT64, abi.FLOAT64]
+        ex = D.ChunkedExchange(dist, torch, world, [T_DT[d] for d in dtypes], dev, int(fact_key.numel() * 0.75) + 1024,
+                               data_group=data_group, count_group=count_group, wire_out=wire_out, wire_in=wire_in)
+        pred = InputRef(1) > Constant(args.threshold, abi.FLOAT64)
+        keep = []
+        nloc = fact_key.numel()
+        for c in range(n_chunks):
+            lo, hi = nloc * c // n_chunks, nloc * (c + 1) // n_chunks
+            if hi == lo:
+                continue
+            b = device_batch(abi, [fact_key[lo:hi], fact_val[lo:hi]], dtypes)
+            parts, starts, rows = be.hash_partition_filter(b, InputRef(0), pred, world, abi.MEM_DEVICE)
+            be.check(be.fn("ctx_release_to_stream")(be.ctx, torch_stream()))
+            views = [_tensor_view(torch, parts.column(ci).values, parts.column(ci).length, T_DT[d], dev)
+                     for ci, d in enumerate(dtypes)]
+            ex.send_regions(views, starts, rows)
+            keep.append((parts, b))
+        outs = ex.finish()
+        be.check(be.fn("ctx_wait_stream")(be.ctx, torch_stream()))
+        for parts, _ in keep:
+            parts.release()
         xstat["bytes_off_rank"] += ex.bytes_off_rank
         return outs
 
@@ -396,7 +461,10 @@ def main():
         # exchanged; every rank then owns a disjoint key range and its local join + group-by result is final
         t0 = time.perf_counter()
         dk, = exchange([[dim_key]], [abi.INT64], D_shard(n_dim_total, rank, world) * 2 + 1024)
-        fk, fv = exchange(filtered_chunks(), [abi.INT64, abi.FLOAT64], int(fact_key.numel() * 0.75) + 1024)
+        if fused_exchange:
+            fk, fv = exchange_filtered_fact()
+        else:  # SQLRS_BENCH_EXCHANGE_FUSED=0: Filter operator, stable partition, contiguous all_to_all_single
+            fk, fv = exchange(filtered_chunks(), [abi.INT64, abi.FLOAT64], int(fact_key.numel() * 0.75) + 1024)
         if xstat["on"]:
             torch.cuda.synchronize()
             be.synchronize()
@@ -440,7 +508,7 @@ def main():
         return be.wrap(ao)
 
     def one_step():
-        if world > 1:
+        if multi:
             xstat["steps"] += 1
             return step_broadcast() if strategy == "broadcast" else step_partition()
         out = pipe.step(device_batch(abi, [dim_key], [abi.INT64]),
@@ -451,7 +519,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         be.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -462,7 +530,7 @@ def main():
             out.release()
         out = one_step()
     out_groups_local = out.num_rows
-    ok, ngroups, got_rows, msg = check_groups(torch, dist if world > 1 else None, dev, out, exp_cnt, exp_sum, has_dim)
+    ok, ngroups, got_rows, msg = check_groups(torch, dist if multi else None, dev, out, exp_cnt, exp_sum, has_dim)
     if rank == 0:
         log(f"[bench] check (per group: keys, COUNT bit-exact, SUM 1e-9 rel): {msg} -> {'OK' if ok else 'MISMATCH'}")
     if not ok:
@@ -477,7 +545,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     ms_per_step = elapsed / args.steps * 1e3
@@ -485,7 +553,7 @@ def main():
 
     # ---- per-kernel device time (HIP events on the ctx stream), separate profiled steps
     be.profile(True)
-    xstat.update(on=world > 1, exchange_ms=0.0, bytes_off_rank=0)
+    xstat.update(on=multi, exchange_ms=0.0, bytes_off_rank=0)
     torch.cuda.synchronize()
     t_prof = time.perf_counter()
     for _ in range(2):
@@ -497,13 +565,14 @@ def main():
     prof = be.profile_read()
     be.profile(False)
     exchange_info = None
-    if world > 1:  # SURVEY.md §8e scaling report: exchange vs local time, bytes over xGMI, rate per link
+    if multi:  # SURVEY.md §8e scaling report: exchange vs local time, bytes over xGMI, rate per link
         x_ms, x_bytes = xstat["exchange_ms"] / 2, xstat["bytes_off_rank"] / 2
         exchange_info = {"strategy": strategy, "chunks": n_chunks if strategy == "partition" else 1,
+                         "fused_filter_partition": bool(fused_exchange and strategy == "partition"),
                          "step_ms_profiled": round(prof_step_ms, 3), "exchange_ms": round(x_ms, 3),
                          "local_ms": round(prof_step_ms - x_ms, 3), "bytes_off_rank_per_step": int(x_bytes),
                          "GBps_per_rank": round(x_bytes / max(x_ms, 1e-9) / 1e6, 1),
-                         "GBps_per_link": round(x_bytes / max(x_ms, 1e-9) / 1e6 / (world - 1), 1),
+                         "GBps_per_link": round(x_bytes / max(x_ms, 1e-9) / 1e6 / max(world - 1, 1), 1),
                          "ranks": rank_info,
                          "note": "rank 0, two profiled steps with a sync behind the exchange phase (filter + partition "
                                  "kernels + collectives, chunk k's all-to-all overlapping chunk k+1's kernels); split "
@@ -532,7 +601,7 @@ def main():
             pipe.partial = strategy == "broadcast"
     workload = {"fact_rows": f_hi - f_lo, "dim_rows": d_hi - d_lo, "selectivity": expected_kept / max(f_hi - f_lo, 1),
                 "matches": expected_kept, "groups": out_groups_local}
-    if world > 1:  # after the exchange every rank holds about 1/N of everything
+    if multi:  # after the exchange every rank holds about 1/N of everything
         workload = {"fact_rows": n_fact_total // world, "dim_rows": n_dim_total // world,
                     "selectivity": got_rows / n_fact_total, "matches": got_rows // world,
                     "groups": ngroups // world}
@@ -566,19 +635,19 @@ def main():
                 break
 
     variants = None
-    if rank == 0 and world == 1 and not args.no_operators and not args.unfused:
+    if rank == 0 and not multi and not args.no_operators and not args.unfused:
         variants = bench_variants(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim_total,
                                   exp_cnt, exp_sum, has_dim)
 
     operators = None
-    if rank == 0 and not args.no_operators and world == 1:
+    if rank == 0 and not args.no_operators and not multi:
         del fact_key, fact_val, dim_key
         be.fn("ctx_pool_trim")(be.ctx)
         torch.cuda.empty_cache()
         operators = bench_operators(be, abi, datagen, torch, dev)
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and not multi:  # (the CPU leg is an N = 1 figure)
         cpu = cpu_baseline(args, abi, datagen, n_dim_total)
 
     if rank == 0:
@@ -594,11 +663,12 @@ def main():
                        "Filter -> HashJoinAgg (HashAgg fused over the Inner HashJoin)" if args.separate_filter else
                        "HashJoinAgg with the probe-side Filter handed to it (sqlrs_join_agg_set_probe_filter): "
                        f"filter evaluated inside the first partition pass = {bool(pipe.filter_fused_batches)}",
-                       "parallelism": ("single GPU" if world == 1 else
+                       "parallelism": ("single GPU" if not multi else
                                        f"x{world}: all-gather dim, local partial aggregation, all-to-all of partial aggregates, merge"
                                        if strategy == "broadcast" else
                                        f"x{world}: partitioned hash join — Filter below the exchange, fact + dim hash-partitioned on "
-                                       f"the join key, RCCL all-to-all in {n_chunks} overlapped chunks, local HashJoinAgg")},
+                                       f"the join key, RCCL all-to-all in {n_chunks} overlapped chunks, local HashJoinAgg"
+                                       + ("; Filter + partition fused in one pass (sqlrs_hash_partition_filter)" if fused_exchange else ""))},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if operators:
@@ -608,7 +678,7 @@ def main():
         if exchange_info:
             line["exchange"] = exchange_info
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
@@ -618,7 +688,7 @@ def pmc_traffic(kernel, n_fact, n_dim, world, args):
     tools/profile_round.sh (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command,
     HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024).  Only valid for the default workload; otherwise null."""
     if not (n_fact == 1_000_000_000 and n_dim == 10_000_000 and world == 1 and args.threshold == 0.5
-            and not args.unfused):
+            and not args.unfused and not args.force_exchange):
         return None, None
     try:
         import glob

@@ -391,6 +391,20 @@ void sqlrs_csv_close(sqlrs_csv_t *r);
  * the ordinary operators above. */
 int sqlrs_hash_partition(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, const sqlrs_expr_t *key,
                          int num_parts, int out_mem, sqlrs_batch_t **out, int64_t *offsets);
+/* Filter + hash partition in one pass: the rows of `in` that pass `predicate` (FilterExecutor semantics,
+ * [ref: src/executor/filter.rs:13-25]: rows whose mask is false or NULL are dropped; NULL / zero nodes =
+ * no predicate) distributed like sqlrs_hash_partition.  Partition p = rows
+ * [part_start[p], part_start[p] + part_rows[p]) of the output batch (both arrays: host, num_parts
+ * entries, filled by the call); rows outside those ranges are unspecified padding and the row order
+ * inside a partition is unspecified — what the equi-join / group-by exchange needs, nothing more.
+ * `column OP constant` predicates over an int64 / float64 column without NULLs on batches of <= 3
+ * fixed-width 8-byte columns (the filtered fact rows of the partitioned hash join) run as ONE kernel:
+ * every row is read once, every kept row written once, into per-partition regions of num_rows rows each
+ * (num_parts x the input's size of device memory).  Any other shape = sqlrs_filter_* followed by
+ * sqlrs_hash_partition inside the library (same rows per partition). */
+int sqlrs_hash_partition_filter(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, const sqlrs_expr_t *key,
+                                const sqlrs_expr_t *predicate, int num_parts, int out_mem,
+                                sqlrs_batch_t **out, int64_t *part_start, int64_t *part_rows);
 
 /* ------------------------------------------------- timing of device work -- */
 /* HIP-event timing on the ctx stream (bench.py measures the dominant kernel

@@ -308,6 +308,7 @@ class Backend:
             "ctx_pool_trim": (None, [vp]),
             "batch_copy": (i, [vp, pb, i, ppb]),
             "hash_partition": (i, [vp, pb, pe, i, i, ppb, C.POINTER(C.c_int64)]),
+            "hash_partition_filter": (i, [vp, pb, pe, pe, i, i, ppb, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
             "join_agg_create": (i, [vp, i, pe, pe, i, i, C.POINTER(C.c_int32), i, pe, i, C.POINTER(AggFunc), pvp]),
             "join_agg_build_push": (i, [vp, pb]),
             "join_agg_build_finish": (i, [vp]),
@@ -396,6 +397,20 @@ class Backend:
         self.check(self.fn("hash_partition")(self.ctx, b.ptr, C.byref(packed.abi), num_parts, out_mem,
                                              C.byref(out), offs))
         return self.wrap(out), list(offs)
+
+    def hash_partition_filter(self, batch, key_expr, predicate, num_parts: int, out_mem: int = MEM_DEVICE):
+        """Filter + hash partition in one pass -> (LibBatch, part_start list, part_rows list): partition p =
+        rows [part_start[p], part_start[p] + part_rows[p]) of the batch; `predicate` may be None"""
+        b = as_batch(batch)
+        packed = key_expr.pack()
+        pred = predicate.pack() if predicate is not None else None
+        out = C.POINTER(Batch)()
+        starts = (C.c_int64 * num_parts)()
+        rows = (C.c_int64 * num_parts)()
+        self.check(self.fn("hash_partition_filter")(self.ctx, b.ptr, C.byref(packed.abi),
+                                                    C.byref(pred.abi) if pred is not None else None, num_parts,
+                                                    out_mem, C.byref(out), starts, rows))
+        return self.wrap(out), list(starts), list(rows)
 
     def batch_to_string(self, batch) -> str:
         """``record_batch_to_string`` (util/mod.rs:53-80) of a pyarrow / host / device batch"""

@@ -933,6 +933,34 @@ int sqlrs_filter_push(sqlrs_filter_t *, const sqlrs_batch_t *, int, sqlrs_batch_
 void sqlrs_filter_destroy(sqlrs_filter_t *);
 }
 
+namespace sq {
+// `col OP constant` over an int64 / float64 column without NULLs -> RowFilter (the shape the first
+// partition level can evaluate itself); anything else is run by the Filter operator
+bool fusable_row_filter(const Expr &e, InBatch &ib, RowFilter *rf) {
+  if (e.nodes.size() != 3) return false;
+  const sqlrs_expr_node_t &a = e.nodes[0], &b = e.nodes[1], &o = e.nodes[2];
+  if (a.op != SQLRS_EXPR_INPUT_REF || b.op != SQLRS_EXPR_CONSTANT || b.is_null) return false;
+  if (o.op < SQLRS_EXPR_GT || o.op > SQLRS_EXPR_NOTEQ) return false;
+  if (a.index < 0 || a.index >= ib.num_columns()) return false;
+  const DCol &c = ib.col(a.index);
+  if (c.dtype != b.dtype || c.stride == 0) return false;
+  if (c.dtype != SQLRS_INT64 && c.dtype != SQLRS_FLOAT64) return false;
+  if (c.validity && c.null_count != 0) return false;
+  rf->col = c.v<uint64_t>();
+  rf->is_f64 = c.dtype == SQLRS_FLOAT64;
+  if (rf->is_f64) {
+    uint64_t bits;
+    std::memcpy(&bits, &b.f, 8);
+    rf->kord = (bits >> 63) ? ~bits : (bits | (1ull << 63)); // f64_to_ordered
+  } else {
+    rf->kord = (uint64_t)b.i ^ (1ull << 63);
+  }
+  static const uint32_t masks[6] = {4, 1, 6, 3, 2, 5}; // GT, LT, GTEQ, LTEQ, EQ, NOTEQ: keep if {<, ==, >}
+  rf->keep_mask = masks[o.op - SQLRS_EXPR_GT];
+  return true;
+}
+} // namespace sq
+
 struct sqlrs_join_agg {
   Ctx *ctx = nullptr;
   sqlrs_hash_join *join = nullptr;
@@ -981,32 +1009,6 @@ int sqlrs_join_agg_build_push(sqlrs_join_agg_t *ja, const sqlrs_batch_t *left) {
 }
 int sqlrs_join_agg_build_finish(sqlrs_join_agg_t *ja) { return sqlrs_hash_join_build_finish(ja->join); }
 
-// `col OP constant` over an int64 / float64 column without NULLs -> RowFilter (the shape the first
-// partition level can evaluate itself); anything else is run by the Filter operator
-static bool fusable_row_filter(const Expr &e, InBatch &ib, RowFilter *rf) {
-  if (e.nodes.size() != 3) return false;
-  const sqlrs_expr_node_t &a = e.nodes[0], &b = e.nodes[1], &o = e.nodes[2];
-  if (a.op != SQLRS_EXPR_INPUT_REF || b.op != SQLRS_EXPR_CONSTANT || b.is_null) return false;
-  if (o.op < SQLRS_EXPR_GT || o.op > SQLRS_EXPR_NOTEQ) return false;
-  if (a.index < 0 || a.index >= ib.num_columns()) return false;
-  const DCol &c = ib.col(a.index);
-  if (c.dtype != b.dtype || c.stride == 0) return false;
-  if (c.dtype != SQLRS_INT64 && c.dtype != SQLRS_FLOAT64) return false;
-  if (c.validity && c.null_count != 0) return false;
-  rf->col = c.v<uint64_t>();
-  rf->is_f64 = c.dtype == SQLRS_FLOAT64;
-  if (rf->is_f64) {
-    uint64_t bits;
-    std::memcpy(&bits, &b.f, 8);
-    rf->kord = (bits >> 63) ? ~bits : (bits | (1ull << 63)); // f64_to_ordered
-  } else {
-    rf->kord = (uint64_t)b.i ^ (1ull << 63);
-  }
-  static const uint32_t masks[6] = {4, 1, 6, 3, 2, 5}; // GT, LT, GTEQ, LTEQ, EQ, NOTEQ: keep if {<, ==, >}
-  rf->keep_mask = masks[o.op - SQLRS_EXPR_GT];
-  return true;
-}
-
 // one probe batch: (Filter, filter.rs:13-25, when `with_filter`) -> HashJoin probe (hash_join.rs:207-292)
 // feeding HashAgg push (hash_agg.rs:44-122)
 static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bool with_filter) {
@@ -1043,7 +1045,15 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bo
       auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
       int64_t n = ib.rows();
       RowFilter rf;
-      const bool fuse_filter = with_filter && fusable_row_filter(ja->probe_filter, ib, &rf);
+      // The fused filter drops rows INSIDE the first partition pass, i.e. after the aggregate arguments were
+      // evaluated over all n rows: an argument that can raise (integer DIVIDE: "Divide by zero error") would
+      // fail on a row the predicate removes — `SUM(a / b) ... WHERE b > 0` succeeds in the reference
+      // (filter.rs:13-25 runs first).  Such plans take the Filter operator first.
+      bool args_cannot_raise = true;
+      for (const Expr &e : a->arg_exprs)
+        for (const auto &nd : e.nodes)
+          if (nd.op == SQLRS_EXPR_DIVIDE) args_cannot_raise = false;
+      const bool fuse_filter = with_filter && args_cannot_raise && fusable_row_filter(ja->probe_filter, ib, &rf);
       if (with_filter && !fuse_filter) eligible = false; // Filter operator first, then this function again
       std::vector<DCol> kcols;
       NKeys nk;

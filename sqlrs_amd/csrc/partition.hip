@@ -8,9 +8,17 @@
 //    filtered fact rows (key, val)): a stable LDS-staged multi-split that carries the columns
 //    (split_hist / split_scatter below): every column is read once and written once
 //    (1e7 x 3 columns: 0.54 -> 0.2 ms).
+//  * fused path (sqlrs_hash_partition_filter): Filter + compaction + partition in ONE pass.  A counting
+//    multi-split needs every (tile, partition) count before the first row moves, and a FilterExecutor below
+//    it wrote compacted copies first (44 B per input row at selectivity 0.5: filter 24, histogram 4,
+//    scatter 16).  Here every partition owns a REGION of the output (capacity = the input rows) and a tile
+//    claims its run in a region with one returning atomic per (tile, partition): 16 B read per row, 16 B
+//    written per kept row, nothing else.  Tiles land in claim order, so the row order inside a partition is
+//    unspecified (kept inside a tile) — equi-join and group-by do not depend on it.
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "prims.hpp"
+#include "radix_part.hpp"
 
 namespace sq {
 
@@ -158,6 +166,118 @@ __global__ __launch_bounds__(SP_WG) void split_scatter_kernel(
   }
 }
 
+// One-pass Filter + partition (see the header of this file).  Same in-tile ranking and LDS staging as
+// split_scatter_kernel; the (tile, partition) run start comes from an atomic claim on the partition's fill
+// cursor instead of a scanned count matrix, and rows failing the predicate are never ranked nor staged.
+// SEP: the predicate reads a column that is not carried (its own load stream); otherwise column `pc` of the
+// carried ones (pc < 0: no predicate).
+template <int NC, bool SEP>
+__global__ __launch_bounds__(SP_WG) void split_claim_kernel(
+    const uint64_t *__restrict__ c0, const uint64_t *__restrict__ c1, const uint64_t *__restrict__ c2, int kc, int pc,
+    RowFilter flt, int64_t n, uint32_t parts, int64_t cap, unsigned long long *__restrict__ cursor,
+    uint64_t *__restrict__ o0, uint64_t *__restrict__ o1, uint64_t *__restrict__ o2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+  uint64_t *s0 = (uint64_t *)sp_smem;
+  uint64_t *s1 = s0 + SP_TILE;
+  uint64_t *s2 = s1 + (NC >= 2 ? SP_TILE : 0);
+  uint8_t *spart = (uint8_t *)(s2 + (NC >= 3 ? SP_TILE : 0));
+  __shared__ uint32_t wcnt[SP_WAVES][256];
+  __shared__ uint32_t dstart[256];
+  __shared__ int64_t gbase[256];
+  __shared__ uint32_t s_wsum[4];
+  const int w = wave_id(), lane = lane_id();
+  const int64_t tbase = (int64_t)blockIdx.x * SP_TILE;
+  const int64_t wrow = tbase + (int64_t)w * (SP_ITEMS * 64) + lane;
+  uint64_t a[SP_ITEMS], b[NC >= 2 ? SP_ITEMS : 1], c[NC >= 3 ? SP_ITEMS : 1], pv[SEP ? SP_ITEMS : 1];
+#pragma unroll
+  for (int j = 0; j < SP_ITEMS; j++) { // unconditional loads: rows past the end re-read the last row
+    const int64_t i = min(wrow + j * 64, n - 1);
+    a[j] = __builtin_nontemporal_load(c0 + i);
+    if (NC >= 2) b[j] = __builtin_nontemporal_load(c1 + i);
+    if (NC >= 3) c[j] = __builtin_nontemporal_load(c2 + i);
+    if (SEP) pv[j] = __builtin_nontemporal_load(flt.col + i);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) wcnt[w][lane + 64 * q] = 0;
+  uint32_t rnk[SP_ITEMS], prt[SP_ITEMS];
+#pragma unroll
+  for (int j = 0; j < SP_ITEMS; j++) {
+    bool valid = wrow + j * 64 < n;
+    if (SEP) valid = valid && row_passes(flt, pv[SEP ? j : 0]);
+    else if (pc >= 0) valid = valid && row_passes(flt, pc == 0 ? a[j] : (pc == 1 ? b[NC >= 2 ? j : 0] : c[NC >= 3 ? j : 0]));
+    const uint64_t key = kc == 0 ? a[j] : (kc == 1 ? b[NC >= 2 ? j : 0] : c[NC >= 3 ? j : 0]);
+    const uint32_t d = valid ? part_of(key, parts) : 0xffffffffu;
+    prt[j] = d;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+      const bool on = (d >> bit) & 1;
+      const uint64_t bm = __ballot(on);
+      peers &= on ? bm : ~bm;
+    }
+    const uint32_t r = (uint32_t)mbcnt(peers);
+    uint32_t old = 0;
+    if (valid && r == 0) {
+      old = wcnt[w][d];
+      wcnt[w][d] = old + (uint32_t)__popcll(peers);
+    }
+    old = (uint32_t)__shfl((int)old, valid ? __builtin_ctzll(peers) : 0, 64);
+    rnk[j] = old + r;
+  }
+  __syncthreads();
+  uint32_t goff_lo = 0, goff_hi = 0;
+  if (threadIdx.x < 256) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int q = 0; q < SP_WAVES; q++) {
+      uint32_t cnt = wcnt[q][threadIdx.x];
+      wcnt[q][threadIdx.x] = acc;
+      acc += cnt;
+    }
+    // claim this tile's run in the partition's region (one returning atomic per non-empty (tile, partition))
+    if (acc) {
+      const unsigned long long g = atomicAdd(&cursor[threadIdx.x], (unsigned long long)acc);
+      goff_lo = (uint32_t)g;
+      goff_hi = (uint32_t)(g >> 32);
+    }
+    uint32_t inc = wave_iscan_u32(acc);
+    if (lane == 63) s_wsum[w] = inc;
+    dstart[threadIdx.x] = inc - acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    uint32_t wb = 0;
+    for (int q = 0; q < w; q++) wb += s_wsum[q];
+    uint32_t ds = dstart[threadIdx.x] + wb;
+    dstart[threadIdx.x] = ds;
+    const int64_t g = (int64_t)(((uint64_t)goff_hi << 32) | goff_lo);
+    gbase[threadIdx.x] = (int64_t)threadIdx.x * cap + g - (int64_t)ds;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SP_ITEMS; j++) {
+    const uint32_t d = prt[j];
+    if (d == 0xffffffffu) continue;
+    const uint32_t p = dstart[d] + wcnt[w][d] + rnk[j];
+    s0[p] = a[j];
+    if (NC >= 2) s1[p] = b[j];
+    if (NC >= 3) s2[p] = c[j];
+    spart[p] = (uint8_t)d;
+  }
+  __syncthreads();
+  const uint32_t len = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3]; // rows of this tile that passed
+#pragma unroll
+  for (int j = 0; j < SP_ITEMS; j++) {
+    const uint32_t p = j * SP_WG + threadIdx.x;
+    if (p < len) {
+      const int64_t g = gbase[spart[p]] + p;
+      o0[g] = s0[p];
+      if (NC >= 2) o1[g] = s1[p];
+      if (NC >= 3) o2[g] = s2[p];
+    }
+  }
+}
+
 } // namespace sq
 
 using namespace sq;
@@ -257,4 +377,117 @@ extern "C" int sqlrs_hash_partition(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, c
       o.cols.push_back(gather_column(ctx, ib.col(c), perm->p, false, nullptr, n));
     *out = emit_batch(ctx, std::move(o), out_mem);
   });
+}
+
+extern "C" {
+int sqlrs_filter_create(sqlrs_ctx_t *, const sqlrs_expr_t *, sqlrs_filter_t **);
+int sqlrs_filter_push(sqlrs_filter_t *, const sqlrs_batch_t *, int, sqlrs_batch_t **);
+void sqlrs_filter_destroy(sqlrs_filter_t *);
+void sqlrs_batch_release(sqlrs_batch_t *);
+}
+
+extern "C" int sqlrs_hash_partition_filter(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, const sqlrs_expr_t *key,
+                                           const sqlrs_expr_t *predicate, int num_parts, int out_mem,
+                                           sqlrs_batch_t **out, int64_t *part_start, int64_t *part_rows) {
+  const bool has_pred = predicate && predicate->num_nodes > 0;
+  bool done = false;
+  int st = guard(ctx, [&] {
+    SQ_HIP(hipSetDevice(ctx->device));
+    if (num_parts < 1 || num_parts > 256) fail(SQLRS_ERR_INTERNAL, "num_parts must be in [1, 256]");
+    Expr e = expr_from_abi(key);
+    InBatch ib(ctx, in);
+    const int64_t n = ib.rows();
+    const int nc = ib.num_columns();
+    // fused one-pass path: <= 3 carried 8-byte columns without NULLs, the key is one of them, the predicate is
+    // `column OP constant` over an int64 / float64 column without NULLs (any column of the batch)
+    bool fast = n >= (1 << 16) && n <= 0xffffffffll && nc >= 1 && nc <= 3 && e.nodes.size() == 1 &&
+                e.nodes[0].op == SQLRS_EXPR_INPUT_REF && e.nodes[0].index >= 0 && e.nodes[0].index < nc;
+    for (int c = 0; fast && c < nc; c++) {
+      const DCol &col = ib.col(c);
+      fast = width_of(col.dtype) == 8 && !(col.validity && col.null_count != 0) && col.stride != 0 && col.dtype != SQLRS_UTF8;
+    }
+    // (f64 keys are normalised by bit pattern and -0.0 / NaN handling lives in normalize_keys: integers only here)
+    if (fast) fast = ib.col(e.nodes[0].index).dtype == SQLRS_INT64;
+    RowFilter rf;
+    if (fast && has_pred) fast = fusable_row_filter(expr_from_abi(predicate), ib, &rf);
+    // every partition owns a region of `cap` rows (worst case: all rows kept, one partition): sized for 288 GB of HBM,
+    // bounded by an eighth of the device memory
+    const int64_t cap = round_up(std::max<int64_t>(n, 1), 64);
+    if (fast) {
+      size_t free_b = 0, total_b = 0;
+      SQ_HIP(hipMemGetInfo(&free_b, &total_b));
+      const size_t need = (size_t)num_parts * (size_t)cap * 8 * (size_t)nc;
+      if (need > total_b / 8) fast = false; // (of the TOTAL: the choice must not flip as the pool warms up)
+    }
+    if (!fast) return;
+    ProfScope ps(ctx, "hash_partition_filter");
+    const int kcol = e.nodes[0].index;
+    int pcol = -1;
+    bool sep = false;
+    if (has_pred) {
+      for (int c = 0; c < nc; c++)
+        if ((const void *)ib.col(c).v<uint64_t>() == (const void *)rf.col) pcol = c;
+      sep = pcol < 0;
+    }
+    BufP cursor = ctx->alloc_zero(8 * 256);
+    DBatch o;
+    o.rows = (int64_t)num_parts * cap;
+    uint64_t *outp[3] = {nullptr, nullptr, nullptr};
+    const uint64_t *inp[3] = {nullptr, nullptr, nullptr};
+    for (int c = 0; c < nc; c++) {
+      DCol oc;
+      oc.dtype = ib.col(c).dtype;
+      oc.length = o.rows;
+      oc.null_count = 0;
+      oc.own_values = ctx->alloc(8 * (size_t)o.rows + 16);
+      oc.values = oc.own_values->p;
+      outp[c] = oc.own_values->as<uint64_t>();
+      inp[c] = ib.col(c).v<uint64_t>();
+      o.cols.push_back(std::move(oc));
+    }
+    const int64_t ntiles = ceil_div(n, SP_TILE);
+    const size_t lds = (size_t)SP_TILE * (8 * (size_t)nc + 1);
+    dim3 g((unsigned)ntiles), b(SP_WG);
+#define SQ_CLAIM(NC, SEP)                                                                                        \
+  do {                                                                                                            \
+    auto kfn = split_claim_kernel<NC, SEP>;                                                                       \
+    allow_big_lds(ctx, kfn, 112 * 1024);                                                                          \
+    kfn<<<g, b, lds, ctx->stream>>>(inp[0], inp[1], inp[2], kcol, pcol, rf, n, (uint32_t)num_parts, cap,          \
+                                    cursor->as<unsigned long long>(), outp[0], outp[1], outp[2]);                 \
+  } while (0)
+#define SQ_CLAIM_NC(NC) do { if (sep) SQ_CLAIM(NC, true); else SQ_CLAIM(NC, false); } while (0)
+    if (nc == 1) SQ_CLAIM_NC(1); else if (nc == 2) SQ_CLAIM_NC(2); else SQ_CLAIM_NC(3);
+#undef SQ_CLAIM_NC
+#undef SQ_CLAIM
+    SQ_HIP(hipGetLastError());
+    std::vector<uint64_t> hc(256);
+    SQ_HIP(hipMemcpyAsync(hc.data(), cursor->p, 8 * 256, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    for (int p2 = 0; p2 < num_parts; p2++) {
+      part_start[p2] = (int64_t)p2 * cap;
+      part_rows[p2] = (int64_t)hc[(size_t)p2];
+    }
+    *out = emit_batch(ctx, std::move(o), out_mem);
+    done = true;
+  });
+  if (st != SQLRS_OK || done) return st;
+  // composed path (any other shape): Filter operator (filter.rs:13-25), then the stable partition
+  sqlrs_batch_t *kept = nullptr;
+  if (has_pred) {
+    sqlrs_filter_t *f = nullptr;
+    st = sqlrs_filter_create(ctx, predicate, &f);
+    if (st != SQLRS_OK) return st;
+    st = sqlrs_filter_push(f, in, SQLRS_MEM_DEVICE, &kept);
+    sqlrs_filter_destroy(f);
+    if (st != SQLRS_OK) return st;
+  }
+  std::vector<int64_t> offs((size_t)num_parts + 1);
+  st = sqlrs_hash_partition(ctx, kept ? kept : in, key, num_parts, out_mem, out, offs.data());
+  if (kept) sqlrs_batch_release(kept);
+  if (st != SQLRS_OK) return st;
+  for (int p2 = 0; p2 < num_parts; p2++) {
+    part_start[p2] = offs[(size_t)p2];
+    part_rows[p2] = offs[(size_t)p2 + 1] - offs[(size_t)p2];
+  }
+  return SQLRS_OK;
 }

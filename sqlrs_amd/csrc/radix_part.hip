@@ -382,12 +382,6 @@ __device__ __forceinline__ void rp_chunk_load(const uint64_t *__restrict__ key, 
   }
 }
 
-__device__ __forceinline__ bool row_passes(const RowFilter &f, uint64_t bits) {
-  const uint64_t o = f.is_f64 ? f64_to_ordered(__longlong_as_double((long long)bits)) : (bits ^ (1ull << 63));
-  const uint32_t sel = o < f.kord ? 1u : (o == f.kord ? 2u : 4u);
-  return (f.keep_mask & sel) != 0;
-}
-
 // H2: the kernel also counts, per chunk, its rows per digit of the NEXT level (the level-2 histogram pass read the
 // key words of every chunk again for exactly these numbers).  Possible when all P buckets have a counter in LDS:
 // h2[bucket] holds two 16-bit counts, low = rows of the digit's CURRENT chunk, high = rows of this tile that spill

@@ -52,6 +52,20 @@ struct RowFilter {
   uint64_t kord = 0;      // ordered image of the constant
 };
 
+#if defined(__HIPCC__)
+} // namespace sq
+#include "device_utils.hpp"
+namespace sq {
+__device__ __forceinline__ bool row_passes(const RowFilter &f, uint64_t bits) {
+  const uint64_t o = f.is_f64 ? f64_to_ordered(__longlong_as_double((long long)bits)) : (bits ^ (1ull << 63));
+  const uint32_t sel = o < f.kord ? 1u : (o == f.kord ? 2u : 4u);
+  return (f.keep_mask & sel) != 0;
+}
+#endif
+// `col OP constant` over an int64 / float64 column of `ib` without NULLs -> RowFilter; false = not that shape
+// (hashagg_op.hip; shared by the fused join + aggregate and by sqlrs_hash_partition_filter)
+bool fusable_row_filter(const Expr &e, InBatch &ib, RowFilter *rf);
+
 struct PartitionInput {
   const uint64_t *keys = nullptr; // normalised keys (NKeys)
   const uint64_t *key_validity = nullptr;

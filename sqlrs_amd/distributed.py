@@ -52,6 +52,26 @@ def partition_numpy(columns: Sequence[np.ndarray], parts: int, valid: Optional[n
     return [c[order] for c in columns], offsets.tolist()
 
 
+def partition_filter_numpy(columns: Sequence[np.ndarray], parts: int, keep: Optional[np.ndarray] = None):
+    """Host restatement of sqlrs_hash_partition_filter's output layout on column 0: every partition owns a
+    region of ``cap`` = len rows (rounded up to 64), filled from its start with the kept rows of that
+    partition; returns (region columns, part_start, part_rows).  The device fills a region in tile-claim
+    order; here input order is kept (any order inside a partition is a valid output)."""
+    n = len(columns[0])
+    cap = (max(n, 1) + 63) // 64 * 64
+    p = partition_of(columns[0], parts)
+    sel = np.ones(n, dtype=bool) if keep is None else keep.astype(bool)
+    outs = [np.zeros(parts * cap, dtype=c.dtype) for c in columns]
+    starts, rows = [], []
+    for q in range(parts):
+        idx = np.nonzero(sel & (p == q))[0]
+        for o, c in zip(outs, columns):
+            o[q * cap:q * cap + len(idx)] = c[idx]
+        starts.append(q * cap)
+        rows.append(len(idx))
+    return outs, starts, rows
+
+
 def all_to_all_columns(dist, columns, offsets: Sequence[int], world: int, torch):
     """Exchanges partitioned columns: slice p of every column goes to rank p.  ``columns`` are
     torch tensors (device or CPU) already in partition order with ``offsets`` (world+1 ints).
@@ -138,6 +158,51 @@ class ChunkedExchange:
                 work = dist.all_to_all_single(tmp, src, output_split_sizes=rc, input_split_sizes=sc, group=self.data_group,
                                               async_op=True)
                 self.pending.append((work, (src, col), (dst, tmp)))
+            self.bytes_off_rank += (sum(sc) - sc[self.rank]) * col.element_size()
+        self.filled += total
+
+    def send_regions(self, columns, starts, rows):
+        """Like send_chunk for the output of ``sqlrs_hash_partition_filter``: partition p of every column is
+        ``col[starts[p] : starts[p] + rows[p]]`` — regions with padding between them, so the slices travel as
+        a LIST all-to-all (RCCL: one grouped send/recv per peer straight out of the regions and into the
+        receive buffer; gloo has no list all-to-all: the same exchange spelled as isend / irecv pairs)."""
+        torch, dist, W = self.torch, self.dist, self.world
+        sc = [int(r) for r in rows]
+        send = torch.tensor(sc, dtype=torch.int64)
+        recv = torch.empty(W, dtype=torch.int64)
+        dist.all_to_all_single(recv, send, group=self.count_group)  # CPU group: no device synchronisation
+        rc = [int(x) for x in recv.tolist()]
+        total = sum(rc)
+        if self.filled + total > self.cap:
+            self._grow(self.filled + total)
+        backend = dist.get_backend(self.data_group)
+        for ci, col in enumerate(columns):
+            dst = self.bufs[ci][self.filled:self.filled + total]
+            ins = [self.wire_out(col[int(starts[p]):int(starts[p]) + sc[p]]) for p in range(W)]
+            staged = None
+            if ins[0].device == dst.device:
+                outs = list(torch.split(dst, rc))
+            else:  # the data group moves host tensors: land them in the receive buffer afterwards
+                tmp = torch.empty(total, dtype=ins[0].dtype, device=ins[0].device)
+                outs, staged = list(torch.split(tmp, rc)), (dst, tmp)
+            if backend == "nccl":
+                work = dist.all_to_all(outs, ins, group=self.data_group, async_op=True)
+                self.pending.append((work, (ins, outs, col), staged))
+            else:
+                outs[self.rank].copy_(ins[self.rank])
+                ops = []
+                for r in range(W):
+                    if r == self.rank:
+                        continue
+                    if sc[r]:
+                        ops.append(dist.P2POp(dist.isend, ins[r], r, group=self.data_group))
+                    if rc[r]:
+                        ops.append(dist.P2POp(dist.irecv, outs[r], r, group=self.data_group))
+                works = dist.batch_isend_irecv(ops) if ops else []
+                for k, wk in enumerate(works):
+                    self.pending.append((wk, (ins, outs, col), staged if k == len(works) - 1 else None))
+                if not works and staged is not None:
+                    staged[0].copy_(self.wire_in(staged[1]))
             self.bytes_off_rank += (sum(sc) - sc[self.rank]) * col.element_size()
         self.filled += total
 

@@ -70,3 +70,26 @@ def test_product_does_not_reference_oracle():
                     code = line.split("//")[0].split("#")[0] if f.endswith(".py") is False else line
                     if re.search(r"(import|include|CDLL|dlopen).*oracle", code):
                         raise AssertionError(f"{f}: {line.strip()}")
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-runs its own command line as N ranks under
+    torch.distributed.run on 127.0.0.1 (what the driver's N > 1 command relies on)"""
+    import importlib
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -89,6 +89,20 @@ def worker(rank, world, port, result_path, strategy="partition"):
         sent_off_rank.append(ex.bytes_off_rank)
         return outs
 
+    def exchange_filtered(cols, keep, chunks):
+        """the fused form (sqlrs_hash_partition_filter): Filter + partition in one step, per-partition
+        regions with padding, slices sent straight out of the regions (ChunkedExchange.send_regions)"""
+        n = len(cols[0])
+        dts = [torch.from_numpy(c[:0].copy()).dtype for c in cols]
+        ex = D.ChunkedExchange(dist, torch, world, dts, torch.device("cpu"), max(n // 5, 1), count_group=count_group)
+        for c in range(chunks):
+            lo, hi = n * c // chunks, n * (c + 1) // chunks
+            regs, starts, rows = D.partition_filter_numpy([x[lo:hi] for x in cols], world, keep[lo:hi])
+            ex.send_regions([torch.from_numpy(r) for r in regs], starts, rows)
+        outs = [o.numpy().copy() for o in ex.finish()]
+        sent_off_rank.append(ex.bytes_off_rank)
+        return outs
+
     count_group = dist.new_group(backend="gloo")
     sent_off_rank = []
 
@@ -107,7 +121,14 @@ def worker(rank, world, port, result_path, strategy="partition"):
         dk = dim_key[d_lo:d_hi]
     else:
         (dk,) = exchange([dim_key[d_lo:d_hi]])
-        fk, fv = exchange([fact_key[f_lo:f_hi], fact_val[f_lo:f_hi]], chunks=3)  # receive buffer grows on the way
+        if strategy == "partition_fused":  # Filter below the exchange, fused into the partition step
+            fk, fv = exchange_filtered([fact_key[f_lo:f_hi], fact_val[f_lo:f_hi]], fact_val[f_lo:f_hi] > 0.5, chunks=3)
+            assert (fv > 0.5).all()
+            n_kept = torch.tensor([len(fk)])
+            dist.all_reduce(n_kept)
+            assert int(n_kept.item()) == int((fact_val > 0.5).sum())
+        else:
+            fk, fv = exchange([fact_key[f_lo:f_hi], fact_val[f_lo:f_hi]], chunks=3)  # receive buffer grows on the way
         assert sent_off_rank[-1] > 0
         # every key this rank received belongs to this rank's partition
         assert (D.partition_of(dk, world) == rank).all() and (D.partition_of(fk, world) == rank).all()
@@ -118,7 +139,8 @@ def worker(rank, world, port, result_path, strategy="partition"):
         all_keys = np.concatenate([g[0] for g in gathered])
         all_cnt = np.concatenate([g[1] for g in gathered])
         all_sum = np.concatenate([g[2] for g in gathered])
-        assert sum(g[3] for g in gathered) == N_FACT and sum(g[4] for g in gathered) == N_DIM
+        assert sum(g[3] for g in gathered) == (N_FACT if strategy != "partition_fused" else int((fact_val > 0.5).sum()))
+        assert sum(g[4] for g in gathered) == N_DIM
         assert len(np.unique(all_keys)) == len(all_keys), "per-rank results must be disjoint"
         ek, ec, es = local_pipeline(oracle, dim_key, fact_key, fact_val)  # single process
         o1, o2 = np.argsort(all_keys), np.argsort(ek)
@@ -137,7 +159,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("strategy", ["partition", "broadcast"])
+@pytest.mark.parametrize("strategy", ["partition", "partition_fused", "broadcast"])
 def test_partitioned_join_groupby_world2_gloo(tmp_path, strategy):
     result = tmp_path / "result.txt"
     mp.spawn(worker, args=(2, free_port(), str(result), strategy), nprocs=2, join=True)

@@ -136,6 +136,28 @@ def test_probe_filter_chunked_hot_digit(hip, oracle, threshold):
     assert_same(got, exp, float_cols={2})
 
 
+@pytest.mark.parametrize("np_", [150_000, 2_500_000])
+def test_probe_filter_guards_a_raising_argument(hip, oracle, np_):
+    """SUM(1000 / r.c2) ... WHERE r.c2 <> 0 (int64): the reference filters first (filter.rs:13-25), so the division
+    never sees the zero rows.  The fused filter drops rows inside the first partition pass, AFTER the aggregate
+    arguments were evaluated over the whole batch — such plans must take the Filter operator first instead of
+    failing with "Divide by zero error" (small batch: filtered on arrival; large batch: the in-place route)."""
+    rng = np.random.default_rng(77)
+    lb, rb, sch = tables(rng, 2_400_000 if np_ > 1_000_000 else 4000, np_, sparse=False)
+    assert 0 in rb.column(2).to_pylist()[:5000]
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    aggs = [AggFunc("sum", Constant(1000, abi.INT64) / InputRef(4), abi.INT64), AggFunc("count", InputRef(4), abi.INT64)]
+    pred = BinaryOp("!=", InputRef(2), Constant(0, abi.INT64))
+    ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)], probe_filter=pred)
+    got = rows_of(ex.execute())
+    assert ex.filter_fused_batches == 0
+    exp = reference(oracle, lb, [rb], cond, sch, 2, aggs, [InputRef(0)], pred)
+    assert_same(got, exp)
+    # without the guard the same plan is an Arrow error on both backends (array_compute.rs:70-90 -> divide)
+    with pytest.raises(Exception, match="Divide by zero"):
+        rows_of(HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)]).execute())
+
+
 @pytest.mark.parametrize("keys", ["dense", "sparse"])
 def test_hash_agg_chunked(hip, oracle, keys):
     """plain HashAgg whose partition needs two levels (2.6e6 groups, > 512 tables of 4096 slots): chunked first level, no filter"""

@@ -93,6 +93,54 @@ __global__ void k_lds_cas(unsigned long long* out, int iters){
   if(threadIdx.x==0) out[blockIdx.x]=t[5]+acc;
 }
 
+// ---- composite probe: exactly the memory work of the dense hash-join probe
+// (hash_join.rs:207-253 on a direct-address table) and nothing else: stream 8-B probe keys, ONE random 4-B
+// load per key into a table of `slots` entries (3.8 MiB for 1e6 build keys: resident in one XCD's L2),
+// stream the (left_idx u64, right_idx u32) pair out at the key's own position.  No ballot, no look-back,
+// no barrier, no compaction: every key hits.  MODE selects how the table is read:
+//   0 plain load (allocates a 128-B line in the CU's L1 per miss), 1 non-temporal, 2 sc1 (agent scope: L1 bypassed)
+template<int ILP, int MODE>
+__global__ void k_probe_composite(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ heads, uint64_t mask,
+                                  uint64_t* __restrict__ left, uint32_t* __restrict__ right, size_t n){
+  size_t i = blockIdx.x*(size_t)blockDim.x*ILP+threadIdx.x; const size_t s=(size_t)gridDim.x*blockDim.x*ILP;
+  for(; i + (size_t)(ILP-1)*blockDim.x < n; i += s){
+    uint64_t k[ILP]; uint32_t h[ILP];
+    #pragma unroll
+    for(int j=0;j<ILP;j++) k[j]=__builtin_nontemporal_load(keys+i+(size_t)j*blockDim.x);
+    #pragma unroll
+    for(int j=0;j<ILP;j++){
+      const uint32_t* p=heads+(k[j]&mask);
+      h[j] = MODE==0 ? *p : (MODE==1 ? __builtin_nontemporal_load(p) : __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT));
+    }
+    #pragma unroll
+    for(int j=0;j<ILP;j++){
+      __builtin_nontemporal_store((uint64_t)h[j], left+i+(size_t)j*blockDim.x);
+      __builtin_nontemporal_store((uint32_t)(i+(size_t)j*blockDim.x), right+i+(size_t)j*blockDim.x);
+    }
+  }
+}
+// the lookups alone (indices computed, nothing streamed): what the three load flavours sustain into a 4-B table
+template<int ILP, int MODE>
+__global__ void k_rand4(const uint32_t* __restrict__ tab, uint64_t mask, uint64_t* out, size_t n){
+  size_t i = blockIdx.x*(size_t)blockDim.x+threadIdx.x, s=(size_t)gridDim.x*blockDim.x;
+  uint64_t acc=0;
+  for(; i + (ILP-1)*s < n; i += ILP*s){
+    uint32_t v[ILP];
+    #pragma unroll
+    for(int j=0;j<ILP;j++){
+      const uint32_t* p=tab+(mix64(i+j*s)&mask);
+      v[j] = MODE==0 ? *p : (MODE==1 ? __builtin_nontemporal_load(p) : __hip_atomic_load(p,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT));
+    }
+    #pragma unroll
+    for(int j=0;j<ILP;j++) acc+=v[j];
+  }
+  if(acc==0x1234567) out[0]=acc;
+}
+__global__ void k_fill_keys(uint64_t* keys, uint64_t mask, size_t n){
+  size_t i = blockIdx.x*(size_t)blockDim.x+threadIdx.x, s=(size_t)gridDim.x*blockDim.x;
+  for(;i<n;i+=s) keys[i]=mix64(i*0x9E3779B97F4A7C15ull+1)&mask;
+}
+
 template<class F> float timeit(F f, int reps=5){
   hipEvent_t a,b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -100,7 +148,39 @@ template<class F> float timeit(F f, int reps=5){
   for(int r=0;r<reps;r++){ hipEventRecord(a); f(); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms,a,b); if(ms<best)best=ms; }
   return best;
 }
-int main(){
+int probe_composite(){
+  const size_t n=100000000; // C3: 1e8 probe keys against 1e6 build keys
+  uint64_t *keys,*left; uint32_t *right,*heads; uint64_t* out;
+  CK(hipMalloc(&keys,8*n)); CK(hipMalloc(&left,8*n)); CK(hipMalloc(&right,4*n)); CK(hipMalloc(&out,4096));
+  printf("composite probe: %zu keys (8 B in) -> one random 4-B table load each -> (u64,u32) pair out, all hit; algorithmic bytes 8 nP + 12 M = %.1f GB\n", n, 20.0*n/1e9);
+  for(size_t slots: {(size_t)1<<17,(size_t)1<<20,(size_t)1<<21,(size_t)1<<23}){ // 0.5 / 4 / 8 / 32 MiB tables
+    CK(hipMalloc(&heads,4*slots)); CK(hipMemset(heads,1,4*slots));
+    k_fill_keys<<<4096,256>>>(keys,slots-1,n); CK(hipDeviceSynchronize());
+    const char* mname[3]={"plain","nt","sc1"};
+    float best=1e30f;
+    #define RUN(ILP,MODE,G) { float ms=timeit([&]{k_probe_composite<ILP,MODE><<<G,256>>>(keys,heads,slots-1,left,right,n);}); \
+      printf("  table %5.1f MiB  ilp %2d  %-5s grid %5d: %.3f ms  %.0f Gkeys/s  %.0f GB/s algorithmic (%.3f of 8 TB/s)\n", 4.0*slots/1048576, ILP, mname[MODE], G, ms, n/ms/1e6, 20.0*n/ms/1e6, 20.0*n/ms/1e6/8000); if(ms<best)best=ms; }
+    RUN(4,0,8192) RUN(8,0,4096) RUN(8,0,8192) RUN(16,0,2048) RUN(16,0,4096)
+    RUN(8,1,4096) RUN(16,1,4096) RUN(8,2,4096) RUN(16,2,4096) RUN(16,2,2048)
+    #undef RUN
+    for(int mode=0;mode<3;mode++){
+      float ms = mode==0 ? timeit([&]{k_rand4<8,0><<<4096,256>>>(heads,slots-1,out,n);}) :
+                 mode==1 ? timeit([&]{k_rand4<8,1><<<4096,256>>>(heads,slots-1,out,n);}) :
+                           timeit([&]{k_rand4<8,2><<<4096,256>>>(heads,slots-1,out,n);});
+      printf("  table %5.1f MiB  lookups alone (%s): %.3f ms  %.0f G/s\n", 4.0*slots/1048576, mname[mode], ms, n/ms/1e6);
+    }
+    printf("  table %5.1f MiB  best composite %.3f ms = %.3f of the HBM roofline on 8 nP + 12 M bytes\n", 4.0*slots/1048576, best, 20.0*n/best/1e6/8000);
+    CK(hipFree(heads));
+  }
+  { // the streams alone: keys in, pairs out, no lookup
+    float ms=timeit([&]{k_probe_composite<8,0><<<4096,256>>>(keys,(const uint32_t*)left,0,left,right,n);});
+    printf("  streams alone (every key -> slot 0): %.3f ms  %.0f GB/s\n", ms, 20.0*n/ms/1e6);
+  }
+  return 0;
+}
+
+int main(int argc, char** argv){
+  if(argc>1 && argv[1][0]=='p') return probe_composite();
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p,0));
   printf("device %s CUs=%d L2=%d MB clock=%d MHz lds/block=%zu\n", p.name,p.multiProcessorCount,p.l2CacheSize>>20,p.clockRate/1000,p.sharedMemPerBlock);
   const size_t GB=1ull<<30;
