@@ -1,0 +1,364 @@
+//! The executors `ExecutorBuilder` instantiates instead of the CPU ones, and the `visit_physical_*` bodies that do
+//! it (src/executor/mod.rs:87-200).  Same struct fields as the reference operators (filter.rs:7-10,
+//! hash_join.rs:16-23, hash_agg.rs:15-19, order.rs:8-11, project.rs:6-9, limit.rs:4-8, simple_agg.rs:9-12) plus
+//! the `HipCtx` handle; every `execute` yields exactly the batches the CPU operator yields.
+use std::sync::Arc;
+
+use arrow::datatypes::{Field, Schema, SchemaRef};
+use arrow::record_batch::RecordBatch;
+use futures_async_stream::try_stream;
+
+use crate::binder::{AggFunc, BoundAggFunc, BoundExpr, BoundOrderBy, JoinCondition, JoinType};
+use crate::catalog::ColumnCatalog;
+use crate::convert::{dtype_of, import_batch, lower, AbiBatch, HipCtx, Lowered};
+use crate::executor::{BoxedExecutor, ExecutorBuilder, ExecutorError};
+use crate::ffi::*;
+use crate::optimizer::{
+    PhysicalFilter, PhysicalHashAgg, PhysicalHashJoin, PhysicalLimit, PhysicalOrder, PhysicalProject,
+    PhysicalSimpleAgg, PlanRef, PlanTreeNode,
+};
+
+/// destroys the operator handle when the stream is dropped (also on an early error)
+struct Guard<T>(*mut T, unsafe extern "C" fn(*mut T));
+impl<T> Drop for Guard<T> {
+    fn drop(&mut self) { if !self.0.is_null() { unsafe { (self.1)(self.0) } } }
+}
+unsafe impl<T> Send for Guard<T> {}
+
+fn lower_all(exprs: &[BoundExpr]) -> Result<(Vec<Lowered>, Vec<sqlrs_expr_t>), ExecutorError> {
+    let low: Vec<Lowered> = exprs.iter().map(lower).collect::<Result<_, _>>()?;
+    let abi = low.iter().map(|l| l.abi()).collect();
+    Ok((low, abi))
+}
+fn lower_aggs(aggs: &[BoundAggFunc]) -> Result<(Vec<Lowered>, Vec<sqlrs_agg_func_t>), ExecutorError> {
+    // only exprs[0] is read by the reference (hash_agg.rs:65, simple_agg.rs:38-41)
+    let low: Vec<Lowered> = aggs.iter().map(|a| lower(&a.exprs[0])).collect::<Result<_, _>>()?;
+    let mut out = Vec::new();
+    for (a, l) in aggs.iter().zip(&low) {
+        let func = match a.func { AggFunc::Count => SQLRS_AGG_COUNT, AggFunc::Sum => SQLRS_AGG_SUM, AggFunc::Min => SQLRS_AGG_MIN, AggFunc::Max => SQLRS_AGG_MAX };
+        out.push(sqlrs_agg_func_t { func, distinct: a.distinct as i32, return_dtype: dtype_of(&a.return_type)?, reserved: 0, arg: l.abi() });
+    }
+    Ok((low, out))
+}
+/// output schema of an aggregation: eval_field names / types (evaluator.rs:30-64), as the CPU operators build it
+fn agg_schema(group_by: &[BoundExpr], aggs: &[BoundAggFunc], input: &RecordBatch) -> SchemaRef {
+    let mut fields: Vec<Field> = group_by.iter().map(|g| g.eval_field(input)).collect(); // hash_agg.rs:49-60: keys, then aggregates
+    fields.extend(aggs.iter().map(|a| BoundExpr::AggFunc(a.clone()).eval_field(input)));
+    Arc::new(Schema::new(fields))
+}
+
+// ------------------------------------------------------------------ Filter --
+pub struct HipFilterExecutor { pub ctx: Arc<HipCtx>, pub expr: BoundExpr, pub child: BoxedExecutor }
+impl HipFilterExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let expr = lower(&self.expr)?;
+        let mut f = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_filter_create(self.ctx.raw(), &expr.abi(), &mut f) })?;
+        let _g = Guard(f, sqlrs_filter_destroy);
+        #[for_await]
+        for batch in self.child { // filter.rs:15-24: one output batch per input batch, empty ones included
+            let batch = batch?;
+            let inb = AbiBatch::new(&batch)?;
+            let mut out = std::ptr::null_mut();
+            self.ctx.check(unsafe { sqlrs_filter_push(f, &inb.raw, SQLRS_MEM_HOST, &mut out) })?;
+            yield import_batch(batch.schema(), out)?;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- HashJoin --
+pub struct HipHashJoinExecutor {
+    pub ctx: Arc<HipCtx>,
+    pub left_child: BoxedExecutor,
+    pub right_child: BoxedExecutor,
+    pub join_type: JoinType,
+    pub join_condition: JoinCondition,
+    pub join_output_schema: Vec<ColumnCatalog>,
+}
+fn join_keys(cond: &JoinCondition) -> Result<(Vec<BoundExpr>, Vec<BoundExpr>, Option<BoundExpr>), ExecutorError> {
+    match cond { // hash_join.rs:129-134
+        JoinCondition::On { on, filter } => Ok((on.iter().map(|(l, _)| l.clone()).collect(), on.iter().map(|(_, r)| r.clone()).collect(), filter.clone())),
+        JoinCondition::None => Err(ExecutorError::InternalError("HashJoin must has on condition".into())),
+    }
+}
+impl HipHashJoinExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let (lk, rk, filter) = join_keys(&self.join_condition)?;
+        let (_l1, lke) = lower_all(&lk)?;
+        let (_l2, rke) = lower_all(&rk)?;
+        let flt = filter.as_ref().map(lower).transpose()?;
+        let fe = flt.as_ref().map(|f| f.abi());
+        let schema: SchemaRef = Arc::new(Schema::new(self.join_output_schema.iter().map(|c| c.to_arrow_field()).collect::<Vec<_>>())); // :136-143
+        let mut left_batches = 0usize;
+        let mut pending_left: Vec<RecordBatch> = vec![];
+        #[for_await]
+        for batch in self.left_child { pending_left.push(batch?); left_batches += 1; }
+        if left_batches == 0 { return Ok(()); } // hash_join.rs:183-185
+        let nleft = pending_left[0].num_columns();
+        let right_dtypes: Vec<i32> = self.join_output_schema[nleft..].iter().map(|c| dtype_of(&c.desc.data_type)).collect::<Result<_, _>>()?;
+        let mut j = std::ptr::null_mut();
+        self.ctx.check(unsafe {
+            sqlrs_hash_join_create(self.ctx.raw(), self.join_type as i32, lke.len() as i32, lke.as_ptr(), rke.as_ptr(),
+                                   fe.as_ref().map_or(std::ptr::null(), |f| f as *const _), right_dtypes.len() as i32, right_dtypes.as_ptr(), &mut j)
+        })?;
+        let _g = Guard(j, sqlrs_hash_join_destroy);
+        for batch in &pending_left { // build phase (:161-187)
+            let inb = AbiBatch::new(batch)?;
+            self.ctx.check(unsafe { sqlrs_hash_join_build_push(j, &inb.raw) })?;
+        }
+        drop(pending_left);
+        self.ctx.check(unsafe { sqlrs_hash_join_build_finish(j) })?;
+        #[for_await]
+        for batch in self.right_child { // probe phase (:207-292): one joined batch per probe batch
+            let batch = batch?;
+            let inb = AbiBatch::new(&batch)?;
+            let mut out = std::ptr::null_mut();
+            self.ctx.check(unsafe { sqlrs_hash_join_probe_push(j, &inb.raw, SQLRS_MEM_HOST, &mut out) })?;
+            if !out.is_null() { yield import_batch(schema.clone(), out)?; }
+        }
+        let mut tail = std::ptr::null_mut(); // unvisited left rows of Left / Full joins (:296-322)
+        self.ctx.check(unsafe { sqlrs_hash_join_finish(j, SQLRS_MEM_HOST, &mut tail) })?;
+        if !tail.is_null() { yield import_batch(schema, tail)?; }
+    }
+}
+
+// ----------------------------------------------------------------- HashAgg --
+pub struct HipHashAggExecutor { pub ctx: Arc<HipCtx>, pub agg_funcs: Vec<BoundExpr>, pub group_by: Vec<BoundExpr>, pub child: BoxedExecutor }
+fn agg_funcs_of(exprs: &[BoundExpr]) -> Vec<BoundAggFunc> {
+    exprs.iter().filter_map(|e| if let BoundExpr::AggFunc(a) = e { Some(a.clone()) } else { None }).collect() // hash_agg.rs:58-63
+}
+impl HipHashAggExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let aggs = agg_funcs_of(&self.agg_funcs);
+        let (_l1, ge) = lower_all(&self.group_by)?;
+        let (_l2, af) = lower_aggs(&aggs)?;
+        let mut a = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_hash_agg_create(self.ctx.raw(), ge.len() as i32, ge.as_ptr(), af.len() as i32, af.as_ptr(), &mut a) })?;
+        let _g = Guard(a, sqlrs_hash_agg_destroy);
+        let mut schema = None;
+        #[for_await]
+        for batch in self.child { // hash_agg.rs:44-122
+            let batch = batch?;
+            if schema.is_none() { schema = Some(agg_schema(&self.group_by, &aggs, &batch)); }
+            let inb = AbiBatch::new(&batch)?;
+            self.ctx.check(unsafe { sqlrs_hash_agg_push(a, &inb.raw) })?;
+        }
+        let mut out = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_hash_agg_finish(a, SQLRS_MEM_HOST, &mut out) })?; // no input: InternalError (the reference panics, :125)
+        yield import_batch(schema.expect("finish succeeded, so a batch was pushed"), out)?; // :147-149
+    }
+}
+
+// ------------------------------------------------------------------- Order --
+pub struct HipOrderExecutor { pub ctx: Arc<HipCtx>, pub order_by: Vec<BoundOrderBy>, pub child: BoxedExecutor }
+impl HipOrderExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let low: Vec<Lowered> = self.order_by.iter().map(|o| lower(&o.expr)).collect::<Result<_, _>>()?;
+        let ob: Vec<sqlrs_order_by_t> = self.order_by.iter().zip(&low).map(|(o, l)| sqlrs_order_by_t { expr: l.abi(), asc: o.asc as i32, reserved: 0 }).collect();
+        let mut h = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_order_create(self.ctx.raw(), ob.len() as i32, ob.as_ptr(), &mut h) })?;
+        let _g = Guard(h, sqlrs_order_destroy);
+        let mut schema = None;
+        #[for_await]
+        for batch in self.child { // order.rs:19-26
+            let batch = batch?;
+            schema.get_or_insert(batch.schema());
+            let inb = AbiBatch::new(&batch)?;
+            self.ctx.check(unsafe { sqlrs_order_push(h, &inb.raw) })?;
+        }
+        let Some(schema) = schema else { return Ok(()) };
+        let mut out = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_order_finish(h, SQLRS_MEM_HOST, &mut out) })?;
+        yield import_batch(schema, out)?; // order.rs:66
+    }
+}
+
+// -------------------------------------------- Project / Limit / SimpleAgg --
+pub struct HipProjectExecutor { pub ctx: Arc<HipCtx>, pub exprs: Vec<BoundExpr>, pub child: BoxedExecutor }
+impl HipProjectExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let (_l, ex) = lower_all(&self.exprs)?;
+        let mut p = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_project_create(self.ctx.raw(), ex.len() as i32, ex.as_ptr(), &mut p) })?;
+        let _g = Guard(p, sqlrs_project_destroy);
+        #[for_await]
+        for batch in self.child { // project.rs:15-27
+            let batch = batch?;
+            let schema: SchemaRef = Arc::new(Schema::new(self.exprs.iter().map(|e| e.eval_field(&batch)).collect::<Vec<_>>()));
+            let inb = AbiBatch::new(&batch)?;
+            let mut out = std::ptr::null_mut();
+            self.ctx.check(unsafe { sqlrs_project_push(p, &inb.raw, SQLRS_MEM_HOST, &mut out) })?;
+            yield import_batch(schema, out)?;
+        }
+    }
+}
+pub struct HipLimitExecutor { pub ctx: Arc<HipCtx>, pub limit: Option<usize>, pub offset: Option<usize>, pub child: BoxedExecutor }
+impl HipLimitExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        if self.limit == Some(0) { return Ok(()); } // limit.rs:29-31
+        let mut l = std::ptr::null_mut();
+        self.ctx.check(unsafe {
+            sqlrs_limit_create(self.ctx.raw(), self.limit.is_some() as i32, self.limit.unwrap_or(0) as i64,
+                               self.offset.is_some() as i32, self.offset.unwrap_or(0) as i64, &mut l)
+        })?;
+        let _g = Guard(l, sqlrs_limit_destroy);
+        #[for_await]
+        for batch in self.child { // limit.rs:33-79
+            let batch = batch?;
+            let inb = AbiBatch::new(&batch)?;
+            let (mut out, mut done) = (std::ptr::null_mut(), 0);
+            self.ctx.check(unsafe { sqlrs_limit_push(l, &inb.raw, SQLRS_MEM_HOST, &mut out, &mut done) })?;
+            if !out.is_null() { yield import_batch(batch.schema(), out)?; }
+            if done != 0 { break; } // :76-78
+        }
+    }
+}
+pub struct HipSimpleAggExecutor { pub ctx: Arc<HipCtx>, pub agg_funcs: Vec<BoundExpr>, pub child: BoxedExecutor }
+impl HipSimpleAggExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let aggs = agg_funcs_of(&self.agg_funcs);
+        let (_l, af) = lower_aggs(&aggs)?;
+        let mut a = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_simple_agg_create(self.ctx.raw(), af.len() as i32, af.as_ptr(), &mut a) })?;
+        let _g = Guard(a, sqlrs_simple_agg_destroy);
+        let mut schema = None;
+        #[for_await]
+        for batch in self.child { // simple_agg.rs:35-57
+            let batch = batch?;
+            if schema.is_none() { schema = Some(agg_schema(&[], &aggs, &batch)); }
+            let inb = AbiBatch::new(&batch)?;
+            self.ctx.check(unsafe { sqlrs_simple_agg_push(a, &inb.raw) })?;
+        }
+        let mut out = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_simple_agg_finish(a, SQLRS_MEM_HOST, &mut out) })?;
+        let Some(schema) = schema else { unsafe { sqlrs_batch_release(out) }; return Ok(()) };
+        yield import_batch(schema, out)?; // simple_agg.rs:59-65: exactly one row
+    }
+}
+
+// --------------------------- HashAgg directly over an Inner HashJoin (rewrite) --
+/// `PhysicalHashAgg(PhysicalHashJoin[Inner, no join filter](left, PhysicalFilter?(right)))` as ONE operator
+/// (`sqlrs_join_agg_*`): same batches as the three executors back to back; the library takes its fused route
+/// (no joined batch, Filter evaluated inside the first partition pass) when the plan's data allow it.
+pub struct HipHashJoinAggExecutor {
+    pub ctx: Arc<HipCtx>,
+    pub left_child: BoxedExecutor,
+    pub right_child: BoxedExecutor, // the Filter's child when `probe_filter` is set
+    pub join_condition: JoinCondition,
+    pub join_output_schema: Vec<ColumnCatalog>,
+    pub agg_funcs: Vec<BoundExpr>,
+    pub group_by: Vec<BoundExpr>,
+    pub probe_filter: Option<BoundExpr>,
+}
+impl HipHashJoinAggExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let (lk, rk, _) = join_keys(&self.join_condition)?;
+        let (_l1, lke) = lower_all(&lk)?;
+        let (_l2, rke) = lower_all(&rk)?;
+        let aggs = agg_funcs_of(&self.agg_funcs);
+        let (_l3, ge) = lower_all(&self.group_by)?;
+        let (_l4, af) = lower_aggs(&aggs)?;
+        let join_schema: SchemaRef = Arc::new(Schema::new(self.join_output_schema.iter().map(|c| c.to_arrow_field()).collect::<Vec<_>>()));
+        let mut left: Vec<RecordBatch> = vec![];
+        #[for_await]
+        for batch in self.left_child { left.push(batch?); }
+        if left.is_empty() { // the join yields nothing (hash_join.rs:183-185) and HashAgg over nothing panics (hash_agg.rs:125)
+            return Err(ExecutorError::InternalError("HashAgg without input".into()));
+        }
+        let nleft = left[0].num_columns();
+        let right_dtypes: Vec<i32> = self.join_output_schema[nleft..].iter().map(|c| dtype_of(&c.desc.data_type)).collect::<Result<_, _>>()?;
+        let mut ja = std::ptr::null_mut();
+        self.ctx.check(unsafe {
+            sqlrs_join_agg_create(self.ctx.raw(), lke.len() as i32, lke.as_ptr(), rke.as_ptr(), nleft as i32, right_dtypes.len() as i32,
+                                  right_dtypes.as_ptr(), ge.len() as i32, ge.as_ptr(), af.len() as i32, af.as_ptr(), &mut ja)
+        })?;
+        let _g = Guard(ja, sqlrs_join_agg_destroy);
+        if let Some(p) = &self.probe_filter {
+            let low = lower(p)?;
+            self.ctx.check(unsafe { sqlrs_join_agg_set_probe_filter(ja, &low.abi()) })?; // (the library copies the expression)
+        }
+        for batch in &left {
+            let inb = AbiBatch::new(batch)?;
+            self.ctx.check(unsafe { sqlrs_join_agg_build_push(ja, &inb.raw) })?;
+        }
+        drop(left);
+        self.ctx.check(unsafe { sqlrs_join_agg_build_finish(ja) })?;
+        #[for_await]
+        for batch in self.right_child {
+            let batch = batch?;
+            let inb = AbiBatch::new(&batch)?;
+            self.ctx.check(unsafe { sqlrs_join_agg_probe_push(ja, &inb.raw) })?;
+        }
+        let mut out = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_join_agg_finish(ja, SQLRS_MEM_HOST, &mut out) })?;
+        // eval_field only reads the schema of its input: an empty batch of the join's output schema will do
+        let schema = agg_schema(&self.group_by, &aggs, &RecordBatch::new_empty(join_schema));
+        yield import_batch(schema, out)?;
+    }
+}
+
+// ------------------------------------------- the visit_physical_* bodies --
+/// `ExecutorBuilder` gains one field, `hip: Arc<HipCtx>` (src/executor/mod.rs:36-43); these bodies replace the
+/// ones at mod.rs:103-114, 127-137, 139-149, 151-161, 163-174, 176-187, 189-199.
+impl ExecutorBuilder {
+    pub fn hip_visit_physical_filter(&mut self, plan: &PhysicalFilter) -> Option<BoxedExecutor> {
+        Some(HipFilterExecutor { ctx: self.hip.clone(), expr: plan.logical().expr(), child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())
+    }
+    pub fn hip_visit_physical_hash_join(&mut self, plan: &PhysicalHashJoin) -> Option<BoxedExecutor> {
+        Some(HipHashJoinExecutor {
+            ctx: self.hip.clone(),
+            left_child: self.visit(plan.left()).unwrap(),
+            right_child: self.visit(plan.right()).unwrap(),
+            join_type: plan.join_type(),
+            join_condition: plan.join_condition(),
+            join_output_schema: plan.join_output_columns(),
+        }.execute())
+    }
+    /// HashAgg, with the one peephole that reaches the fused operator from a reference-shaped plan
+    pub fn hip_visit_physical_hash_agg(&mut self, plan: &PhysicalHashAgg) -> Option<BoxedExecutor> {
+        let child: PlanRef = plan.children().first().unwrap().clone();
+        if let Some(join) = child.as_physical_hash_join() {
+            if let (JoinType::Inner, JoinCondition::On { filter: None, .. }) = (join.join_type(), join.join_condition()) {
+                let (right_child, probe_filter) = match join.right().as_physical_filter() {
+                    // FilterExecutor directly below the probe side: handed to the operator (filter.rs:13-25)
+                    Some(f) => (self.visit(f.children().first().unwrap().clone()).unwrap(), Some(f.logical().expr())),
+                    None => (self.visit(join.right()).unwrap(), None),
+                };
+                return Some(HipHashJoinAggExecutor {
+                    ctx: self.hip.clone(),
+                    left_child: self.visit(join.left()).unwrap(),
+                    right_child,
+                    join_condition: join.join_condition(),
+                    join_output_schema: join.join_output_columns(),
+                    agg_funcs: plan.logical().agg_funcs(),
+                    group_by: plan.logical().group_by(),
+                    probe_filter,
+                }.execute());
+            }
+        }
+        Some(HipHashAggExecutor { ctx: self.hip.clone(), agg_funcs: plan.logical().agg_funcs(), group_by: plan.logical().group_by(), child: self.visit(child).unwrap() }.execute())
+    }
+    pub fn hip_visit_physical_order(&mut self, plan: &PhysicalOrder) -> Option<BoxedExecutor> {
+        Some(HipOrderExecutor { ctx: self.hip.clone(), order_by: plan.logical().order_by(), child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())
+    }
+    pub fn hip_visit_physical_project(&mut self, plan: &PhysicalProject) -> Option<BoxedExecutor> {
+        Some(HipProjectExecutor { ctx: self.hip.clone(), exprs: plan.logical().exprs(), child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())
+    }
+    pub fn hip_visit_physical_limit(&mut self, plan: &PhysicalLimit) -> Option<BoxedExecutor> {
+        // both bounds are Constants in the reference (limit.rs:14-27); the binder has already folded them
+        let as_usize = |e: Option<BoundExpr>| e.and_then(|e| match e { BoundExpr::Constant(v) => v.as_usize(), e => unreachable!("expr: {:?} not allowed in limit", e) });
+        Some(HipLimitExecutor { ctx: self.hip.clone(), limit: as_usize(plan.logical().limit()), offset: as_usize(plan.logical().offset()),
+                                child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())
+    }
+    pub fn hip_visit_physical_simple_agg(&mut self, plan: &PhysicalSimpleAgg) -> Option<BoxedExecutor> {
+        Some(HipSimpleAggExecutor { ctx: self.hip.clone(), agg_funcs: plan.logical().agg_funcs(), child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())
+    }
+}

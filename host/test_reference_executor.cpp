@@ -312,6 +312,64 @@ int main() {
                   "+-----------+-------------+-------------+---------+", "| 8         | 1600        | 400         | 1       |",
                   "+-----------+-------------+-------------+---------+"});
   }
+  // ---- ExecutorBuilder over plan trees (executor/mod.rs:36-56, 87-200): one executor per node, and the
+  //      PhysicalHashAgg(PhysicalHashJoin[Inner](l, PhysicalFilter?(r))) peephole that reaches sqlrs_join_agg_*
+  { // mod.rs:368-395  select * from employee order by id desc offset 2 limit 1
+    ExecutorBuilder eb{ctx};
+    PlanRef plan = PlanNode::limit_node(1, 2, PlanNode::order({BoundOrderBy{build_bound_input_ref(0), false}}, PlanNode::table_scan({employee})));
+    expect_table("builder: order by id desc offset 2 limit 1", try_collect(eb.build(plan)),
+                 {"+----+------------+-----------+--------+", "| id | first_name | last_name | salary |",
+                  "+----+------------+-----------+--------+", "| 2  | Gregg      | Langford  | 100    |",
+                  "+----+------------+-----------+--------+"});
+  }
+  { // the headline plan shape: select d.k, count(f.v), sum(f.v) from f join d on f.k = d.k where f.v > 5 group by d.k
+    auto dsch = std::make_shared<Schema>(Schema{{"k", DataType::Int64, false}});
+    auto fsch = std::make_shared<Schema>(Schema{{"k", DataType::Int64, false}, {"v", DataType::Int64, false}});
+    auto make_plan = [&](const RecordBatch &dim, const std::vector<RecordBatch> &fact) {
+      std::vector<ColumnCatalog> out = build_table_schema("d", dim, false);
+      for (auto &c : build_table_schema("f", fact[0], false)) out.push_back(c);
+      JoinCondition cond;
+      cond.on = {{build_bound_input_ref(0), build_bound_input_ref(0)}};
+      PlanRef probe = PlanNode::filter(BoundExpr::binary_op(BinaryOperator::Gt, build_bound_input_ref(1), BoundExpr::constant(ScalarValue::Int64(5))),
+                                       PlanNode::table_scan(fact));
+      PlanRef join = PlanNode::hash_join(JoinType::Inner, cond, out, 1, PlanNode::table_scan({dim}), probe);
+      return PlanNode::hash_agg({BoundAggFunc{AggFunc::Count, {build_bound_input_ref(2)}, DataType::Int64, false},
+                                 BoundAggFunc{AggFunc::Sum, {build_bound_input_ref(2)}, DataType::Int64, false}},
+                                {build_bound_input_ref(0)}, join, {"d.k", "Count(f.v)", "Sum(f.v)"});
+    };
+    RecordBatch dim = RecordBatch::try_new(dsch, {Int64Array({3, 1, 2, 9})});
+    RecordBatch f1 = RecordBatch::try_new(fsch, {Int64Array({2, 1, 2, 7, 3}), Int64Array({10, 6, 4, 8, 9})});
+    RecordBatch f2 = RecordBatch::try_new(fsch, {Int64Array({1, 2, 3, 3}), Int64Array({5, 7, 6, 20})});
+    const std::vector<std::string> expected = {"+-----+------------+----------+", "| d.k | Count(f.v) | Sum(f.v) |", "+-----+------------+----------+",
+                                               "| 2   | 2          | 17       |", "| 1   | 1          | 6        |",
+                                               "| 3   | 3          | 35       |", "+-----+------------+----------+"};
+    ExecutorBuilder plain{ctx};
+    plain.fuse_join_agg = false; // Filter, HashJoin, HashAgg: three executors, as executor/mod.rs builds them
+    expect_table("builder: HashAgg(HashJoin(dim, Filter(fact))) as three operators", try_collect(plain.build(make_plan(dim, {f1, f2}))), expected);
+    ExecutorBuilder fused{ctx};
+    expect_table("builder: the same plan through the join_agg peephole", try_collect(fused.build(make_plan(dim, {f1, f2}))), expected);
+    if (plain.rewrites != 0 || fused.rewrites != 1) { failures++; std::printf("FAIL peephole: rewrites %d / %d\n", plain.rewrites, fused.rewrites); }
+    // at a size where the library's fused route applies (unique build keys, group key = join key, probe-side
+    // arguments): both shapes must agree row for row and the rewritten plan must report fused batches
+    const int64_t nd = 3000, nf = 400000;
+    std::vector<int64_t> dk(nd), fk(nf), fv(nf);
+    uint64_t x = 88172645463325252ull;
+    auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (int64_t i = 0; i < nd; i++) dk[i] = (i * 7919) % nd; // a permutation of 0..nd-1 (7919 is coprime to 3000)
+    for (int64_t i = 0; i < nf; i++) { fk[i] = (int64_t)(rnd() % (uint64_t)(nd + 500)); fv[i] = (int64_t)(rnd() % 11); }
+    RecordBatch bigd = RecordBatch::try_new(dsch, {Int64Array(dk)});
+    RecordBatch bigf = RecordBatch::try_new(fsch, {Int64Array(fk), Int64Array(fv)});
+    ExecutorBuilder p2{ctx}, f2b{ctx};
+    p2.fuse_join_agg = false;
+    auto a = try_collect(p2.build(make_plan(bigd, {bigf})));
+    auto b = try_collect(f2b.build(make_plan(bigd, {bigf})));
+    bool same = a.size() == 1 && b.size() == 1 && a[0].num_rows() == b[0].num_rows() && a[0].num_rows() > 0;
+    for (size_t c = 0; same && c < 3; c++)
+      for (int64_t r = 0; same && r < a[0].num_rows(); r++) same = a[0].columns[c]->value_to_string(r) == b[0].columns[c]->value_to_string(r);
+    if (same && f2b.last_fused_batches >= 1) std::printf("ok   builder: 4e5-row plan, three operators == join_agg peephole (%lld groups, fused batches %lld)\n",
+                                                         (long long)a[0].num_rows(), (long long)f2b.last_fused_batches);
+    else { failures++; std::printf("FAIL builder: large plan (same %d, fused batches %lld)\n", (int)same, (long long)f2b.last_fused_batches); }
+  }
   std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "PASSED", failures, failures == 1 ? "" : "s");
   return failures ? 1 : 0;
 }
