@@ -44,6 +44,8 @@ struct PartAggInput {
   // operator.  Evaluated by the chunked first partition level; when that level does not apply the
   // call returns false and the caller runs the Filter operator first.
   RowFilter filter;
+  // true: key statistics from a full pass (the rerun after an optimistic attempt saw a key outside its sampled range)
+  bool exact_stats = false;
 };
 
 // Groups of ONE batch: key, first row (local index), one 8-byte cell per accumulator
@@ -56,11 +58,14 @@ struct PartAggOutput {
   bool may_dup = false;   // a skewed bucket was split: the same key can appear more than once
   double est_groups = 0;
   int buckets = 0;
+  // partitioned_preaggregate returned false because a key lay outside the SAMPLED key range the rows were packed
+  // with: call again with PartAggInput::exact_stats (nothing of this attempt is kept)
+  bool retry_exact = false;
 };
 
 // also returns min / max of the valid keys' signed-order image (key ^ 1 << 63) when asked
 double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n,
-                         uint64_t *omin = nullptr, uint64_t *omax = nullptr);
+                         uint64_t *omin = nullptr, uint64_t *omax = nullptr, bool *sampled = nullptr);
 // false = not applicable (too many groups for one partition level, or estimate blown):
 // the caller uses the resolve path for the whole batch.
 bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggInput &in,

@@ -585,7 +585,13 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
         }
         PartAggOutput po;
         flush_pending(a); // an older deferred batch must be in the table before this one
-        if (partitioned_preaggregate(ctx, spec, pin, (uint64_t)a->rows_seen, &po)) {
+        bool part_ok = partitioned_preaggregate(ctx, spec, pin, (uint64_t)a->rows_seen, &po);
+        if (!part_ok && po.retry_exact) { // optimistic key statistics (sampled range) did not hold: exact pass, once
+          pin.exact_stats = true;
+          po = PartAggOutput();
+          part_ok = partitioned_preaggregate(ctx, spec, pin, (uint64_t)a->rows_seen, &po);
+        }
+        if (part_ok) {
           PendingGroups pg;
           pg.active = true;
           pg.exact = nk.exact;

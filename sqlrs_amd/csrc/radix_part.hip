@@ -813,11 +813,13 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   const int WG = 512;
   // rows per thread: 12 -> 6144-row tiles, 8 -> 4096-row tiles (two value columns); one
   // workgroup per CU either way (the staging area is ~140 KiB)
-  static const int rows_env = [] { // tuning only
-    const char *e = std::getenv("SQLRS_RP_ROWS");
-    return e ? std::atoi(e) : 0;
-  }();
-  const int ROWS = nv > 1 ? 8 : (rows_env == 6 ? 6 : ((rows_env == 8 && pack) ? 8 : 12));
+  const char *rows_e = std::getenv("SQLRS_RP_ROWS"); // tuning only, read per call (in-process A/B)
+  const int rows_env = rows_e ? std::atoi(rows_e) : 0;
+  // 16 = 8192-row tiles (packed rows with one value column only: 128 KiB of staging, 256 VGPRs, no spills): the
+  // default for very large batches — a third fewer barrier rounds per row (C5, one process: level 1 5.50 -> 5.36 ms,
+  // level 2 3.66 -> 3.61 ms); smaller batches keep 6144-row tiles (less arena slack, more tiles per workgroup)
+  const bool big16 = pack && nv == 1 && (rows_env == 16 || (rows_env == 0 && n >= (1ll << 28)));
+  const int ROWS = nv > 1 ? 8 : (rows_env == 6 ? 6 : ((rows_env == 8 && pack) ? 8 : (big16 ? 16 : 12)));
   const int RP_TILE = WG * ROWS;
   const size_t lds = (size_t)RP_TILE * (pack ? 8 * (1 + nv) : 8 * (1 + nv) + 4 + 2 + 1) + (size_t)WG * (4 + 4 + 8);
 
@@ -829,7 +831,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // of ~24 rows covers three cache lines instead of 2 x 1.5 (C5: level 2 4.93 -> 4.26 ms, bucket pass 1.81 ->
   // 1.67 ms in one process)
   const char *rec_e = std::getenv("SQLRS_RP_REC"); // read per call: 0 = column form (in-process A/B, tools/ab_in_process.py)
-  const bool use_rec = pack && nv == 1 && ROWS == 12 && !(rec_e && std::atoi(rec_e) == 0);
+  const bool use_rec = pack && nv == 1 && (ROWS == 12 || ROWS == 16) && !(rec_e && std::atoi(rec_e) == 0);
   struct Cols {
     BufP k, v0, v1, idx, fl, rec;
   };
@@ -868,7 +870,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       ProfScope ps(ctx, in.build_side ? "rp_hist_build" : "rp_hist");
 #define SQ_RH1(R, PL) rp_hist_kernel<512, R, PL><<<dim3(nt), dim3(512), 0, ctx->stream>>>(rin.key, rin.key_validity, rin.flags, tp, P, p2_bits, level, digits, mat->as<uint32_t>(), kp)
 #define SQ_RH(R) do { if (!rin.key_validity && !rin.flags) SQ_RH1(R, true); else SQ_RH1(R, false); } while (0)
-      if (ROWS == 12) SQ_RH(12); else if (ROWS == 8) SQ_RH(8); else SQ_RH(6);
+      if (ROWS == 12) SQ_RH(12); else if (ROWS == 16) SQ_RH(16); else if (ROWS == 8) SQ_RH(8); else SQ_RH(6);
 #undef SQ_RH
 #undef SQ_RH1
       SQ_HIP(hipGetLastError());
@@ -897,7 +899,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       const int mode = level == 1 ? (flags ? RP_L1_NULL : RP_L1) : (flags ? RP_LN_FLAG : RP_LN);
 #define SQ_RP1(NV, R, M, PK)                                                                                  \
   do {                                                                                                        \
-    constexpr bool can_rec = NV == 1 && PK && R == 12;                                                        \
+    constexpr bool can_rec = NV == 1 && PK && (R == 12 || R == 16);                                           \
     auto kfn = rp_scatter_kernel<NV, 512, R, M, PK>;                                                          \
     if (can_rec && rout.rec) kfn = rp_scatter_kernel<NV, 512, R, M, PK, can_rec>;                             \
     allow_big_lds(ctx, kfn);                                                                                  \
@@ -914,6 +916,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       if (nv == 2) SQ_RP(2, 8);
       else if (ROWS == 6) { if (nv == 0) SQ_RP(0, 6); else SQ_RP(1, 6); }
       else if (ROWS == 8) { if (nv == 0) SQ_RP(0, 8); else SQ_RP(1, 8); }
+      else if (ROWS == 16) { if (pack && mode == RP_LN) SQ_RP1(1, 16, RP_LN, true); else SQ_RP1(1, 16, RP_L1, true); }
       else { if (nv == 0) SQ_RP(0, 12); else SQ_RP(1, 12); }
 #undef SQ_RP1
 #undef SQ_RP
@@ -1000,7 +1003,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       const int psrc = !in.filter.col ? -1 : ((nv >= 1 && (const void *)in.filter.col == in.vals[0]) ? 1 : 3);
       // chunk histograms of the next level counted by this kernel (H2): every bucket needs a 4-byte counter in LDS
       const char *h2_e = std::getenv("SQLRS_RP_H2"); // A/B hook, read per call: 0 = level 2 runs its own histogram pass
-      const bool h2 = pack && nv == 1 && ROWS == 12 && ct_env == 1 && (size_t)P * 4 <= 24 * 1024 && !(h2_e && std::atoi(h2_e) == 0);
+      const bool h2 = pack && nv == 1 && (ROWS == 12 || ROWS == 16) && ct_env == 1 && (size_t)P * 4 <= 24 * 1024 && !(h2_e && std::atoi(h2_e) == 0);
       BufP chist = h2 ? ctx->alloc(4 * (size_t)max_chunks * ((size_t)1 << p2_bits)) : nullptr;
       co.hist = chist ? chist->as<uint32_t>() : nullptr;
       const size_t clds = (size_t)RP_TILE * (pack ? 8 * (1 + nv) : 8 * (1 + nv) + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8) +
@@ -1012,7 +1015,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
 #define SQ_CS1(NV, R, PK, PS)                                                                                       \
   do {                                                                                                              \
     auto kfn = rp_chunk_scatter_kernel<NV, 512, R, PK, PS>;                                                         \
-    if (NV == 1 && PK && R == 12 && h2) kfn = rp_chunk_scatter_kernel<NV, 512, R, PK, PS, (NV == 1 && PK && R == 12)>; \
+    if (NV == 1 && PK && (R == 12 || R == 16) && h2) kfn = rp_chunk_scatter_kernel<NV, 512, R, PK, PS, (NV == 1 && PK && (R == 12 || R == 16))>; \
     allow_big_lds(ctx, kfn);                                                                                        \
     kfn<<<dim3(cwgs), dim3(512), clds, ctx->stream>>>(k, a0, a1, in.filter, n, co, P, p2_bits, d1, tiles1, ctpw,   \
                                                       sink, kp);                                                    \
@@ -1024,6 +1027,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     else SQ_CS1(NV, R, PK, 3);                                                                                      \
   } while (0)
         if (nv == 2) SQ_CS(2, 8, false);
+        else if (ROWS == 16) SQ_CS(1, 16, true);
         else if (ROWS != 12) { chunked = false; } // tuning shapes (SQLRS_RP_ROWS) keep the counting first level
         else if (nv == 0) { if (pack) SQ_CS(0, 12, true); else SQ_CS(0, 12, false); }
         else { if (pack) SQ_CS(1, 12, true); else SQ_CS(1, 12, false); }

@@ -21,10 +21,15 @@ struct KeyPack {
   uint32_t kbits = 0; // 0 = not packed
   uint32_t dense = 0, rbits = 0;
   uint64_t range = 0; // dense: largest key offset of interest
+  // Optimistic packing (range taken from a SAMPLE of the keys): the first pass that packs a row sets *oob when its
+  // key lies outside [kmin, kmin + kmask) — the caller then discards the result and reruns with the exact range.
+  // null = out-of-range keys are expected (fused join: no partner) or impossible (exact range).
+  unsigned int *oob = nullptr;
 };
 #if defined(__HIPCC__)
 __device__ __forceinline__ uint64_t pack_key_row(const KeyPack &kp, uint64_t key, uint32_t row) {
   uint64_t off = key - kp.kmin;
+  if (kp.oob && off >= kp.kmask) *kp.oob = 1u; // (uniform null test; a plain store, any number of writers)
   return (off < kp.kmask ? off : kp.kmask) | ((uint64_t)row << kp.kbits);
 }
 __device__ __forceinline__ uint64_t packed_key(const KeyPack &kp, uint64_t w) { return (w & kp.kmask) + kp.kmin; }

@@ -174,6 +174,37 @@ def test_hash_agg_chunked(hip, oracle, keys):
     assert_same(got, exp, float_cols={2})
 
 
+@pytest.mark.parametrize("outliers", ["none", "unsampled_chunk", "last_chunk"])
+def test_hash_agg_optimistic_key_range(hip, outliers):
+    """Large batches take their key statistics from a block SAMPLE (every eighth 6144-row chunk + the first and the
+    last): the rows are packed with the widened sampled range, and a key outside it — here 1e12 among keys below 5e4,
+    hidden in a chunk the sample skips — must be noticed by the first partition pass (KeyPack::oob) and the batch
+    re-run with exact statistics.  Checked against numpy (counts bit-exact, sums 1e-9, groups in first-seen order)."""
+    rng = np.random.default_rng(31)
+    n, G = (1 << 24) + 12345, 50_000
+    k = rng.integers(0, G, n, dtype=np.int64)
+    if outliers == "unsampled_chunk":
+        k[3 * 6144 + 17] = 10**12      # chunk 3: not a multiple of 8
+        k[5 * 6144 + 4000] = -(10**12)
+    elif outliers == "last_chunk":
+        k[n - 5] = 10**12              # the last chunk is always sampled: the range simply becomes wide (no dense tables)
+    v = rng.random(n)
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"])
+    aggs = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64)]
+    got = HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute()
+    (out,) = list(got)
+    uk, first, inv = np.unique(k, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")
+    exp_k = uk[order]
+    exp_c = np.bincount(inv, minlength=len(uk))[order]
+    exp_s = np.bincount(inv, weights=v, minlength=len(uk))[order]
+    assert out.num_rows == len(uk)
+    assert (out.column(0).to_numpy() == exp_k).all()
+    assert (out.column(1).to_numpy() == exp_c).all()
+    gs = out.column(2).to_numpy()
+    assert (np.abs(gs - exp_s) <= 1e-9 * np.abs(exp_s)).all()
+
+
 @pytest.mark.parametrize("dense", ["1", "0"])
 def test_hash_agg_column_form_hook(hip, oracle, dense, monkeypatch):
     """SQLRS_RP_REC=0 (read per call): the final partition level writes key / value columns instead of 16-byte
