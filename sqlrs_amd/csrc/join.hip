@@ -390,6 +390,263 @@ __global__ __launch_bounds__(JD_BLOCK, JD_OCC) void join_probe_dense_kernel(
 // 3.27 vs 2.56 ms per 1e8 probe rows on a 32 MiB table: the probe is bound by the random-access rate of a
 // table beyond one XCD's L2 (65 G 16-byte loads/s = 1.5 ms, profiles/r01_ubench_mi355x.txt) plus its key stream
 // and pair stores, and many small blocks keep more of those lookups in flight than few large ones.)
+// ---- general keys on LDS tables (blocked partitioned join) -------------------------------------------------
+// For build sides too large for an L2-resident table (sparse 64-bit keys: 16-byte slots at load <= 2/3 leave one
+// XCD's 4 MiB L2 at ~1.3e5 keys) the probe of the global table runs at the random-access rate of the memory
+// system behind L2 (56-66 G lookups/s: 2.6 ms per 1e8 probe rows against 1e6 build keys).  Radix-partitioned
+// instead (north_star: LDS-staged open addressing for the partitioned hash join):
+//   build  : the build keys hash-partitioned into P = 512 buckets once (partition_rows, (key, build row) per bucket);
+//   probe 1: the probe keys cut into RANGES of 2^15 consecutive rows, every range hash-partitioned into the same
+//            512 buckets by one workgroup in one pass (lds_join_partition_kernel: (key, row) per (range, bucket),
+//            "slivers" of ~64 rows);
+//   probe 2: one workgroup per (bucket, group of ranges): the bucket's build keys go into an open-addressing table
+//            in LDS (slot claimed with one 32-bit ds CAS on the row word; the keys are unique, so an insert never
+//            compares keys), then every sliver of the bucket is probed there, a wave per sliver, and the build row
+//            (or "none") is stored AT THE ROW'S POSITION IN THE PARTITIONED ORDER: coalesced loads and stores only;
+//   probe 3: one workgroup per range: its 32768 (row, match) entries are contiguous in the partitioned order; they
+//            are un-permuted through a 128 KiB match array in LDS (scattered ds writes) and compacted from there
+//            into (left_idx, right_idx) pairs in probe-row order — the reference's pair order
+//            (hash_join.rs:225-234) — with the decoupled look-back every compaction here uses.
+// The output order is restored by BLOCKING (a range is what one LDS array holds), not by re-sorting: a global
+// scatter of 1e8 row ids runs at the random-store rate (89 G/s), and even confined to 4 MiB windows of a global
+// match array it cost 2.2 ms (measured: partial-line write-backs), more than the direct probe it replaces.
+// 1024-thread workgroups (16 waves share one table, two workgroups per CU): the sliver loop is a chain of dependent
+// latencies (sliver bounds -> keys -> LDS probes -> store), so it runs at the number of waves in flight — with
+// 256-thread workgroups (12 waves per CU next to three 48 KiB tables) the kernel took 1.9 ms, 1.0 of it without any
+// lookup at all.  16-byte slots {key, build row + 1}: one ds_read_b128 per probe step instead of two dependent reads.
+constexpr int LJ_WG = 1024, LJ_WAVES = LJ_WG / 64, LJ_RANGE_LOG2 = 15, LJ_RANGE = 1 << LJ_RANGE_LOG2;
+struct LjSlot {
+  uint64_t key;
+  uint32_t row1, pad; // build row + 1, 0 = empty
+};
+__device__ __forceinline__ uint32_t lj_bucket(uint64_t key, uint32_t P) { // = radix_part's rp_bucket (the build side's)
+  return (uint32_t)__umul64hi(mix64(key), (uint64_t)P);
+}
+
+// probe 1: one workgroup partitions ONE range of 2^15 consecutive probe rows into the P buckets, in one pass.
+// A range's rows occupy exactly rows [range base, + len) of the partitioned order, so nothing depends on another
+// range: no global histogram, no scan, no second read of the keys (a counting multi-split over all ranges cost
+// hist 0.14 + scan 0.06 + scatter 0.84 ms per 1e8 rows — 12-row runs per (tile, bucket)).  The 32 keys of a thread
+// stay in registers; an LDS atomic per row gives its rank inside its bucket, a scan of the P counters the bucket
+// starts (also the sliver table the next two kernels read), and the rows leave through an LDS staging area a
+// quarter of the range at a time, so the stores are contiguous (12 B per row: key + original row).
+constexpr int LP_ROWS = LJ_RANGE / LJ_WG; // 32 rows per thread
+constexpr int LP_STAGE = LJ_RANGE / 4;    // rows staged per round (96 KiB)
+__global__ __launch_bounds__(LJ_WG) void lds_join_partition_kernel(const uint64_t *__restrict__ keys, int64_t n, uint32_t P,
+                                                                   uint64_t *__restrict__ okey, uint32_t *__restrict__ oidx,
+                                                                   uint32_t *__restrict__ pbstart) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lp_smem[];
+  uint64_t *skey = (uint64_t *)lp_smem;            // [LP_STAGE]
+  uint32_t *sidx = (uint32_t *)(skey + LP_STAGE);  // [LP_STAGE]
+  __shared__ uint32_t cnt[512], start[512 + 1];
+  __shared__ uint32_t s_wsum[8];
+  const int64_t rbase = (int64_t)blockIdx.x * LJ_RANGE;
+  const uint32_t len = (uint32_t)min<int64_t>(LJ_RANGE, n - rbase);
+  uint64_t k[LP_ROWS];
+  uint32_t rk2[LP_ROWS / 2]; // two 16-bit values per word: the row's rank inside its bucket, then its position inside
+                             // the range's output (0xffff = no row); the bucket is recomputed from the key (registers)
+#pragma unroll
+  for (int j = 0; j < LP_ROWS; j++) // unconditional loads (rows past the end re-read the last row)
+    k[j] = __builtin_nontemporal_load(keys + rbase + min((uint32_t)(j * LJ_WG) + threadIdx.x, len - 1));
+  if (threadIdx.x < 512) cnt[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < LP_ROWS; j++) {
+    uint32_t r = 0xffffu;
+    if ((uint32_t)(j * LJ_WG) + threadIdx.x < len) r = atomicAdd(&cnt[lj_bucket(k[j], P)], 1u); // (< 2^15: the range's rows)
+    rk2[j >> 1] = (j & 1) ? (rk2[j >> 1] | (r << 16)) : r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 512) { // exclusive scan of the P <= 512 counters (8 waves)
+    const uint32_t c = threadIdx.x < P ? cnt[threadIdx.x] : 0;
+    const uint32_t inc = wave_iscan_u32(c);
+    if (lane_id() == 63) s_wsum[wave_id()] = inc;
+    cnt[threadIdx.x] = inc - c; // (wave-local exclusive prefix)
+  }
+  __syncthreads();
+  if (threadIdx.x < 512) {
+    uint32_t wb = 0;
+    for (int w = 0; w < wave_id(); w++) wb += s_wsum[w];
+    const uint32_t st = cnt[threadIdx.x] + wb;
+    start[threadIdx.x] = st;
+    if (threadIdx.x < P) pbstart[(size_t)blockIdx.x * P + threadIdx.x] = (uint32_t)rbase + st;
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) pbstart[(size_t)gridDim.x * P] = (uint32_t)n;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < LP_ROWS; j++) {
+    const uint32_t r = (rk2[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+    const uint32_t pos = r == 0xffffu ? 0xffffu : start[lj_bucket(k[j], P)] + r; // (< 2^15)
+    rk2[j >> 1] = (j & 1) ? ((rk2[j >> 1] & 0xffffu) | (pos << 16)) : ((rk2[j >> 1] & 0xffff0000u) | pos);
+  }
+  for (uint32_t q0 = 0; q0 < len; q0 += LP_STAGE) { // (uniform trip count)
+#pragma unroll
+    for (int j = 0; j < LP_ROWS; j++) {
+      const uint32_t p = ((rk2[j >> 1] >> ((j & 1) * 16)) & 0xffffu) - q0; // (0xffff - q0 stays >= LP_STAGE)
+      if (p < (uint32_t)LP_STAGE) {
+        skey[p] = k[j];
+        sidx[p] = (uint32_t)rbase + (uint32_t)(j * LJ_WG) + threadIdx.x;
+      }
+    }
+    __syncthreads();
+    const uint32_t m = min((uint32_t)LP_STAGE, len - q0);
+    for (uint32_t p = threadIdx.x; p < m; p += LJ_WG) {
+      __builtin_nontemporal_store(skey[p], okey + rbase + q0 + p);
+      __builtin_nontemporal_store(sidx[p], oidx + rbase + q0 + p);
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(LJ_WG) void lds_join_probe_kernel(
+    const uint64_t *__restrict__ bkey, const uint32_t *__restrict__ brow, const uint32_t *__restrict__ bbstart,
+    const uint64_t *__restrict__ pkey, const uint32_t *__restrict__ pbstart, uint32_t pn, uint32_t P, uint32_t nranges,
+    uint32_t ranges_per_item, uint32_t slots, uint32_t *__restrict__ mpart) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lj_smem[];
+  LjSlot *tab = (LjSlot *)lj_smem;
+  const uint32_t b = blockIdx.x % P, g = blockIdx.x / P, mask = slots - 1;
+  for (uint32_t s = threadIdx.x; s < slots; s += LJ_WG) tab[s].row1 = 0;
+  __syncthreads();
+  {
+    const uint32_t b0 = bbstart[b], b1 = bbstart[b + 1];
+    constexpr int BU = 4; // build rows in flight per lane
+    for (uint32_t base = b0 + threadIdx.x; base < b1; base += LJ_WG * BU) {
+      uint64_t bk[BU];
+      uint32_t br[BU];
+#pragma unroll
+      for (int u = 0; u < BU; u++) {
+        const uint32_t i = min(base + u * LJ_WG, b1 - 1);
+        bk[u] = bkey[i];
+        br[u] = brow[i];
+      }
+#pragma unroll
+      for (int u = 0; u < BU; u++) {
+        if (base + u * LJ_WG >= b1) continue;
+        uint32_t s = (uint32_t)mix64(bk[u]) & mask; // (the bucket was chosen by the HIGH bits of mix64)
+        while (atomicCAS(&tab[s].row1, 0u, br[u] + 1u) != 0u) s = (s + 1) & mask; // (load <= 1/2: terminates)
+        tab[s].key = bk[u];
+      }
+    }
+  }
+  __syncthreads();
+  auto lookup = [&](uint64_t key) {
+    uint32_t s = (uint32_t)mix64(key) & mask;
+    while (true) {
+      const uint4 sl = *(const uint4 *)&tab[s]; // one 16-byte LDS read: key + row word
+      if (!sl.z) return DENSE_EMPTY;
+      if ((((uint64_t)sl.y << 32) | sl.x) == key) return sl.z - 1;
+      s = (s + 1) & mask;
+    }
+  };
+  const int lane = lane_id();
+  const uint32_t r1 = min(nranges, (g + 1) * ranges_per_item);
+  // a wave takes four slivers at a time (their first 64 rows: four independent loads in flight per lane);
+  // the few slivers longer than 64 rows finish in the tail loop
+  for (uint32_t r = g * ranges_per_item + 4 * wave_id(); r < r1; r += 4 * LJ_WAVES) {
+    uint32_t lo[4], hi[4];
+    uint64_t k[8];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t rr = min(r + q, r1 - 1);
+      lo[q] = pbstart[(size_t)rr * P + b];
+      hi[q] = r + q < r1 ? pbstart[(size_t)rr * P + b + 1] : lo[q];
+    }
+    // a sliver has 64 rows on average (Poisson: almost half of them have a few more), so its first 128 rows are
+    // loaded at once — a dependent second load per sliver was 4 extra HBM latencies per trip (2.2 -> 0.x ms)
+#pragma unroll
+    for (int q = 0; q < 8; q++) { // unconditional loads: lanes past the sliver re-read its first row (or row 0)
+      const uint32_t i = lo[q >> 1] + (q & 1) * 64 + lane;
+      k[q] = __builtin_nontemporal_load(pkey + (i < hi[q >> 1] ? i : min(lo[q >> 1], pn - 1)));
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t i = lo[q >> 1] + (q & 1) * 64 + lane;
+      if (i < hi[q >> 1]) __builtin_nontemporal_store(lookup(k[q]), mpart + i);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      for (uint32_t i = lo[q] + 128 + lane; i < hi[q]; i += 64) mpart[i] = lookup(pkey[i]);
+  }
+}
+
+// probe 3: un-permute one range through LDS and compact it (see above).  8 worker waves + the scan wave.
+constexpr int LR_WAVES = 8, LR_BLOCK = (LR_WAVES + 1) * 64, LR_PER_WAVE = LJ_RANGE / LR_WAVES / 64; // 64 chunks of 64 rows per wave
+__global__ __launch_bounds__(LR_BLOCK) void lds_join_restore_kernel(
+    const uint32_t *__restrict__ pidx, const uint32_t *__restrict__ mpart, int64_t n, int64_t num_tiles,
+    uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx, uint64_t *desc, unsigned *ticket, uint64_t *total,
+    int use_ticket) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
+  uint32_t *m = (uint32_t *)lr_smem; // [LJ_RANGE]
+  unsigned *timeout = use_ticket ? nullptr : ticket + 1;
+  __shared__ int64_t s_tile;
+  __shared__ uint32_t s_wave[LR_WAVES];
+  __shared__ uint64_t s_excl;
+  int64_t tile = blockIdx.x;
+  if (use_ticket) {
+    if (threadIdx.x == 0) s_tile = (int64_t)atomicAdd(ticket, 1u);
+    __syncthreads();
+    tile = s_tile;
+  }
+  const int lane = lane_id(), w = wave_id();
+  const int64_t rbase = tile * LJ_RANGE;
+  const uint32_t len = (uint32_t)min<int64_t>(LJ_RANGE, n - rbase);
+  if (w < LR_WAVES) { // the range's entries are rows [rbase, rbase + len) of the partitioned order, in bucket order
+    constexpr int U = 8;
+    for (uint32_t base = w * 64 + lane; base < len; base += LR_WAVES * 64 * U) {
+      uint32_t id[U], mv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t i = min(base + u * LR_WAVES * 64, len - 1);
+        id[u] = __builtin_nontemporal_load(pidx + rbase + i);
+        mv[u] = __builtin_nontemporal_load(mpart + rbase + i);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (base + u * LR_WAVES * 64 < len) m[id[u] - (uint32_t)rbase] = mv[u];
+    }
+  }
+  __syncthreads(); // (0) the match array of the range is complete
+  if (w == LR_WAVES) { // ---- scan wave
+    __syncthreads(); // (1) the workers' counts are in s_wave
+    uint32_t c = lane < LR_WAVES ? s_wave[lane] : 0;
+    uint64_t agg = wave_sum_u32(c);
+    uint64_t excl = lookback_wave(desc, tile, agg, timeout);
+    if (lane == 0) {
+      s_excl = excl;
+      if (tile == num_tiles - 1) *total = excl + agg;
+    }
+    __syncthreads(); // (2)
+    return;
+  }
+  const uint32_t wbase = w * (LR_PER_WAVE * 64);
+  uint64_t mine = 0; // lane j keeps the hit mask of chunk j
+  uint32_t wave_cnt = 0;
+#pragma unroll 8
+  for (int j = 0; j < LR_PER_WAVE; j++) {
+    const uint32_t r = wbase + j * 64 + lane;
+    const uint64_t bm = __ballot(r < len && m[r] != DENSE_EMPTY);
+    mine = (lane == j) ? bm : mine;
+    wave_cnt += (uint32_t)__popcll(bm);
+  }
+  if (lane == 0) s_wave[w] = wave_cnt;
+  __syncthreads(); // (1)
+  __syncthreads(); // (2) the scan wave has published the range's offset
+  uint64_t pos = s_excl;
+  for (int q = 0; q < w; q++) pos += s_wave[q];
+  const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+#pragma unroll 8
+  for (int j = 0; j < LR_PER_WAVE; j++) {
+    const uint64_t bm = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j) << 32) |
+                        (uint32_t)__builtin_amdgcn_readlane((int)mlo, j);
+    const uint32_t r = wbase + j * 64 + lane;
+    if ((bm >> lane) & 1) {
+      const uint64_t o = pos + mbcnt(bm);
+      __builtin_nontemporal_store((uint64_t)m[r], &left_idx[o]);
+      __builtin_nontemporal_store((uint32_t)(rbase + r), &right_idx[o]);
+    }
+    pos += (uint32_t)__popcll(bm);
+  }
+}
+
 // UNIQUE build keys, Right/Full: every probe row emits exactly one pair (hash_join.rs:235-247)
 template <bool DENSE>
 __global__ __launch_bounds__(BLOCK) void join_probe_unique_outer_kernel(
@@ -520,6 +777,7 @@ __global__ void mark_bits_kernel(const I *__restrict__ idx, const uint64_t *__re
 using namespace sq;
 
 #include "join_state.hpp"
+#include "radix_part.hpp"
 
 extern "C" void sqlrs_batch_release(sqlrs_batch_t *batch);
 
@@ -688,6 +946,69 @@ void hash_join_ensure_table(sqlrs_hash_join *j) {
   if (!j->table_built && j->finished && !j->empty_build) build_hash_table(j);
 }
 
+// General keys on LDS tables, probe 1 + 2 (see lds_join_probe_kernel): the probe rows in (range, bucket) order with the
+// build row of every row's key (or DENSE_EMPTY) beside them; `ok` = false: route not taken.  Unique build keys without
+// NULLs, exactly-compared keys, probe keys without NULLs; the build side large enough that its global table has left
+// one XCD's L2 and small enough for 512 LDS tables of <= 8192 slots.
+struct LdsJoinMatch {
+  bool ok = false;
+  BufP idx, mpart; // u32[n] each: original row, build row | DENSE_EMPTY
+};
+static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
+  Ctx *ctx = j->ctx;
+  LdsJoinMatch out;
+  const int64_t n = pk.rows, nB = j->nB;
+  const char *env_e = std::getenv("SQLRS_LDS_JOIN"); // test / tuning hook, read per call: 0 = never, 1 = whenever the shapes allow
+  const int env = env_e ? std::atoi(env_e) : -1;
+  if (env == 0 || !j->exact || pk.validity || j->bkeys_validity || !j->bkeys || nB < 2 || n > 0xffffffffll) return out;
+  if (env != 1 && (nB < (1 << 18) || n < (1 << 22) || n < 8 * nB)) return out;
+  const uint32_t P = 512;
+  if (!j->lds_build) { // build keys in bucket order, once per join
+    auto pr = std::make_shared<PartitionedRows>();
+    PartitionInput bin;
+    bin.keys = j->bkeys->as<uint64_t>();
+    bin.n = nB;
+    bin.nv = 0;
+    bin.build_side = true;
+    j->lds_slots = 0;
+    j->lds_build = pr; // (remembered either way: do not try again)
+    if (!partition_rows(ctx, bin, P, pr.get()) || pr->P != P || !pr->idx || pr->pack.kbits) return out;
+    uint32_t maxb = 0;
+    for (uint32_t bkt = 0; bkt < P; bkt++) maxb = std::max(maxb, pr->bstart_host[bkt + 1] - pr->bstart_host[bkt]);
+    uint32_t slots = 1024;
+    while (slots < 2 * maxb) slots <<= 1; // load <= 1/2 in the fullest bucket
+    j->lds_slots = slots <= 8192 ? slots : 0; // (8192 x 16 B = 128 KiB: one workgroup per CU)
+  }
+  if (!j->lds_slots || !j->lds_build->key) return out;
+  const PartitionedRows &bp = *j->lds_build;
+  const uint32_t nranges = (uint32_t)ceil_div(n, LJ_RANGE);
+  BufP pkey = ctx->alloc(8 * (size_t)n + 16), pbstart = ctx->alloc(4 * ((size_t)nranges * P + 1));
+  out.idx = ctx->alloc(4 * (size_t)n + 16);
+  {
+    ProfScope ps(ctx, "join_partition_lds");
+    allow_big_lds(ctx, lds_join_partition_kernel, 112 * 1024);
+    lds_join_partition_kernel<<<dim3(nranges), dim3(LJ_WG), (size_t)LP_STAGE * 12, ctx->stream>>>(
+        pk.keys->as<uint64_t>(), n, P, pkey->as<uint64_t>(), out.idx->as<uint32_t>(), pbstart->as<uint32_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  // ranges per work item: one LDS table build (~2 K inserts) per rpi x ~64 probe rows
+  const char *rpi_e = std::getenv("SQLRS_LJ_RPI");
+  const uint32_t rpi = rpi_e ? (uint32_t)std::max(1, std::atoi(rpi_e)) : 1024;
+  const uint32_t ngroups = (uint32_t)ceil_div((int64_t)nranges, (int64_t)rpi);
+  out.mpart = ctx->alloc(4 * (size_t)n + 16);
+  {
+    ProfScope ps(ctx, "join_probe_lds");
+    const size_t lds = (size_t)j->lds_slots * sizeof(LjSlot);
+    allow_big_lds(ctx, lds_join_probe_kernel, 112 * 1024);
+    lds_join_probe_kernel<<<dim3(P * ngroups), dim3(LJ_WG), lds, ctx->stream>>>(
+        bp.key->as<uint64_t>(), bp.idx->as<uint32_t>(), bp.bstart->as<uint32_t>(), pkey->as<uint64_t>(),
+        pbstart->as<uint32_t>(), (uint32_t)n, P, nranges, rpi, j->lds_slots, out.mpart->as<uint32_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  out.ok = true;
+  return out;
+}
+
 static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   Ctx *ctx = j->ctx;
   hash_join_ensure_table(j);
@@ -703,8 +1024,11 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   }
   if (n > 0xffffffffll) fail(SQLRS_ERR_INTERNAL, "probe batch larger than 2^32 rows");
   dim3 g((unsigned)ceil_div(n, BLOCK)), b(BLOCK);
+  // general keys, build side beyond an L2-resident table: LDS tables over a blocked partition (see lds_join_probe_kernel)
+  LdsJoinMatch lm;
+  if (j->unique && !outer_right && !j->dense) lm = lds_join_match(j, pk);
   if (j->unique && !outer_right) { // one lookup per row, compaction with look-back
-    int64_t tiles = ceil_div(n, j->dense ? JD_TILE : JP_TILE);
+    int64_t tiles = ceil_div(n, lm.ok ? LJ_RANGE : (j->dense ? JD_TILE : JP_TILE));
     p.left = ctx->alloc(8 * (size_t)n);
     p.right = ctx->alloc(4 * (size_t)n);
     BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 16);
@@ -713,10 +1037,15 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     for (int use_ticket = lookback_start_mode(ctx), attempt = 0; use_ticket < 2; use_ticket++, attempt++) {
       if (attempt) SQ_HIP(hipMemsetAsync(desc->p, 0, 8 * (size_t)tiles + 16, ctx->stream)); // rerun after a timeout
       {
-        ProfScope ps(ctx, j->dense ? "join_probe_dense" : "join_probe_unique");
+        ProfScope ps(ctx, lm.ok ? "join_match_compact" : (j->dense ? "join_probe_dense" : "join_probe_unique"));
         dim3 gt((unsigned)tiles);
         DenseTable dt{j->dense ? j->dense->as<uint32_t>() : nullptr, j->dense_min, j->dense_range, j->dense_null_head};
-        if (j->dense && pk.validity)
+        if (lm.ok) {
+          allow_big_lds(ctx, lds_join_restore_kernel, 4 * LJ_RANGE + 1024);
+          lds_join_restore_kernel<<<gt, dim3(LR_BLOCK), 4 * (size_t)LJ_RANGE, ctx->stream>>>(
+              lm.idx->as<uint32_t>(), lm.mpart->as<uint32_t>(), n, tiles, p.left->as<uint64_t>(), p.right->as<uint32_t>(),
+              desc->as<uint64_t>(), ticket, tot, use_ticket);
+        } else if (j->dense && pk.validity)
           join_probe_dense_kernel<true><<<gt, dim3(JD_BLOCK), 0, ctx->stream>>>(
               pk.keys->as<uint64_t>(), pk.validity, n, tiles, dt, p.left->as<uint64_t>(), p.right->as<uint32_t>(),
               desc->as<uint64_t>(), ticket, tot, use_ticket);

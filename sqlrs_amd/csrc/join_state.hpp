@@ -5,6 +5,7 @@
 #include "common.hpp"
 #include "host_stage.hpp"
 #include "prims.hpp"
+#include "radix_part.hpp"
 
 struct sqlrs_hash_join {
   sq::Ctx *ctx = nullptr;
@@ -34,6 +35,10 @@ struct sqlrs_hash_join {
   uint64_t dense_min = 0, dense_range = 0;
   uint32_t dense_null_head = 0xffffffffu;
   sq::BufP bkeys, bkeys_validity; // normalised build keys (u64[nB]) and their validity bitmap
+  // general keys on LDS tables (join.hip, lds_join_match): the build keys in bucket order, built at the first probe
+  // that takes the route; lds_slots = 0: the route does not apply to this build side
+  std::shared_ptr<sq::PartitionedRows> lds_build;
+  uint32_t lds_slots = 0;
 };
 
 // builds the deferred hash table of a `lazy_table` join (join.hip); no-op otherwise

@@ -158,6 +158,65 @@ def test_hash_join_indices(hip, oracle, jt):
     assert_same(rows_of(got), rows_of(exp))
 
 
+@pytest.mark.parametrize("jt", ["inner", "left"])
+@pytest.mark.parametrize("nb,npr,forced", [(700, 9_000, True), (40_000, 1_200_000, True), (300_000, 4_400_000, False)])
+def test_hash_join_lds_tables_general_keys(hip, oracle, monkeypatch, jt, nb, npr, forced):
+    """General (sparse 64-bit, f64) unique build keys probed through LDS tables over a blocked partition
+    (lds_join_probe_kernel): probed in partitioned order, un-permuted per 2^15-row range through LDS, compacted in probe-row order.  The pairs — and the
+    joined batches — must equal the oracle's bit for bit (hash_join.rs:207-292).  `forced`: SQLRS_LDS_JOIN=1 takes
+    the route at test sizes; the last case takes it by its own size rule (one probe batch >= 2^22 rows)."""
+    if forced:
+        monkeypatch.setenv("SQLRS_LDS_JOIN", "1")
+    rng = np.random.default_rng(nb + len(jt))
+    A = np.int64(0x9E3779B97F4A7C15 - (1 << 64))
+    with np.errstate(over="ignore"):
+        bk = rng.permutation(nb + nb // 3)[:nb].astype(np.int64) * A + np.int64(77)     # sparse, unique
+        pk = rng.integers(0, nb + nb // 2, npr, dtype=np.int64) * A + np.int64(77)      # ~1/3 of the probe keys miss
+    lb = pa.RecordBatch.from_arrays([pa.array(bk), pa.array(rng.integers(0, 1000, nb, dtype=np.int64))], names=["c0", "c1"])
+    rb = pa.RecordBatch.from_arrays([pa.array(pk), pa.array(rng.random(npr))], names=["c0", "c1"])
+    rbs = [rb] if (npr < 100_000 or not forced) else [rb.slice(0, npr // 3), rb.slice(npr // 3)]
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    hip.profile(True)
+    got = list(HashJoinExecutor(hip, [lb], rbs, jt, cond, sch, 2).execute(indices_only=(jt == "inner")))
+    prof = hip.profile_read()
+    hip.profile(False)
+    assert prof.get("join_probe_lds", (0, 0))[1] > 0 and prof.get("join_match_compact", (0, 0))[1] > 0, prof
+    exp = list(HashJoinExecutor(oracle, [lb], rbs, jt, cond, sch, 2).execute(indices_only=(jt == "inner")))
+    assert [b.num_rows for b in got] == [b.num_rows for b in exp]
+    for g, e in zip(got, exp):
+        for c in range(g.num_columns):
+            assert g.column(c).equals(e.column(c)), c
+
+
+def test_hash_join_lds_tables_f64_keys_and_fallbacks(hip, oracle, monkeypatch):
+    """f64 keys compare by bit pattern on the LDS route too; NULL keys on either side, duplicate build keys and
+    Right / Full joins keep the global-table routes (same results)."""
+    monkeypatch.setenv("SQLRS_LDS_JOIN", "1")
+    rng = np.random.default_rng(19)
+    nb, npr = 5000, 60_000
+    bk = rng.permutation(2 * nb)[:nb].astype(np.float64) * 0.37
+    pk = rng.integers(0, 2 * nb, npr).astype(np.float64) * 0.37
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    for variant in ("plain", "probe_nulls", "dup_build", "full"):
+        b2, p2 = bk.copy(), pk
+        lmask = None
+        if variant == "dup_build":
+            b2[10] = b2[11]
+        lb = pa.RecordBatch.from_arrays([pa.array(b2), pa.array(np.arange(nb, dtype=np.int64))], names=["c0", "c1"])
+        rb = pa.RecordBatch.from_arrays([pa.array(p2, mask=(rng.random(npr) < 0.05) if variant == "probe_nulls" else None),
+                                         pa.array(rng.random(npr))], names=["c0", "c1"])
+        sch = join_schema(lb, rb)
+        jt = "full" if variant == "full" else "inner"
+        hip.profile(True)
+        got = list(HashJoinExecutor(hip, [lb], [rb], jt, cond, sch, 2).execute())
+        prof = hip.profile_read()
+        hip.profile(False)
+        assert (prof.get("join_probe_lds", (0, 0))[1] > 0) == (variant == "plain"), (variant, prof)
+        exp = list(HashJoinExecutor(oracle, [lb], [rb], jt, cond, sch, 2).execute())
+        assert_same(rows_of(got), rows_of(exp))
+
+
 @pytest.mark.parametrize("kind", ["i32", "f64", "bool"])
 def test_hash_join_key_types(hip, oracle, kind):
     rng = np.random.default_rng(3)
