@@ -670,6 +670,9 @@ def main():
                                        f"the join key, RCCL all-to-all in {n_chunks} overlapped chunks, local HashJoinAgg"
                                        + ("; Filter + partition fused in one pass (sqlrs_hash_partition_filter)" if fused_exchange else ""))},
             "roofline": roofline, "cpu_baseline": cpu,
+            # probe batches of the last step that took the library's fused join + aggregate route / had the Filter
+            # evaluated inside the first partition pass (0 = the operators were composed: the 2.5x slower form)
+            "fused_batches": int(pipe.fused_batches), "filter_fused_batches": int(pipe.filter_fused_batches),
         }
         if operators:
             line["operators"] = operators
@@ -863,10 +866,16 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
         res[f"C3_join_{hit}"] = {"probe_rows": nP, "build_rows": nB, "pairs": m[0], "ms_build_probe": round(ms_all, 3),
                                  "ms_probe": round(ms_probe, 3), "probe_Mrows_s": round(nP / ms_probe / 1e3, 1),
                                  "GBps": round(by / ms_all / 1e6, 1), "frac": round(by / ms_all / 1e6 / HBM_PEAK_GBPS, 4),
-                                 # what bounds the probe: random 16-byte table reads, not the HBM stream
-                                 "bound": ("L1 (TCP) request concurrency x L2 latency: 64 table reads in flight per CU, "
-                                           "TCP_PENDING_STALL 77 % (profiles/r02_probe_pmc_ta.txt)" if not sparse else
-                                           "random 16-byte reads of a 32 MB hash table: 65 G reads/s beyond the 4 MB L2 of one XCD")}
+                                 # what bounds the probe: one random L2 lookup per row, not the HBM stream
+                                 "bound": ("one random L2 lookup per probe row: key stream + lookups + pair stores are ADDITIVE on "
+                                           "the CU's vector memory path (composite microbenchmark with nothing but that memory work, "
+                                           "no compaction: 0.689 ms per 1e8 rows on a 4 MiB table = ceiling_frac; "
+                                           "profiles/r03_probe_composite.txt, r02_probe_pmc_ta.txt)" if not sparse else
+                                           "general keys: blocked partitioned join on LDS tables (per-range partition -> per-bucket LDS "
+                                           "probe -> per-range LDS un-permute + compaction); each of the three passes is latency- not "
+                                           "bandwidth-bound (5.2 GB moved for 2.0 GB algorithmic)"),
+                                 "ceiling_frac": (round(by / 0.689 / 1e6 / HBM_PEAK_GBPS, 4) if not sparse and hit == "all_hit" else None),
+                                 "ms_probe_composite_ubench": (0.689 if not sparse and hit == "all_hit" else None)}
         del fk
     # ---- C4: 2e8 rows, 1e6 int64 groups, COUNT(val), SUM(val) f64
     n, G = 200_000_000, 1_000_000
@@ -956,9 +965,99 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     by = 16 * n + 16 * n  # read key + carried column, write both permuted (SURVEY.md §8d minimum)
     res["Order_int64_1col"] = {"rows": n, "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
                                "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    del bo, v1, val
+    be.fn("ctx_pool_trim")(be.ctx)
+    torch.cuda.empty_cache()
+    res.update(bench_host_resident(be, abi, datagen, torch, dev))
     for k_, v_ in res.items():
         log(f"[bench] {k_}: {v_}")
     return res
+
+
+def bench_host_resident(be, abi, datagen, torch, dev):
+    """What a drop-in actually feeds (north_star: "Arrow column buffers move to HBM once per pipeline"): HOST-resident
+    inputs, PCIe inclusive, wall clock.  (a) C5_host_1e8: the C5 query over 1e8 fact rows x 1e7 dim rows held in PINNED
+    host memory, handed to the fused operator in 2^24-row batches (each column crosses the link once: 1.76 GB);
+    (b) C4_host_batches_1024: HashAgg fed the reference's CSV batch shape (1024 rows, storage/csv.rs:105) from pageable
+    host memory through the library's host staging.  Never part of `value`."""
+    from sqlrs_amd.expr import AggFunc, Constant, InputRef
+    PCIE_GBPS = 63.0  # MI355X_MICROARCH.md: PCIe Gen5 x16
+    H = abi.MEM_HOST
+    out = {}
+    # ---- (a)
+    nP, nB, step_rows = 100_000_000, 10_000_000, 1 << 24
+    fk = datagen.fill_chunks(torch.empty(nP, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF1, i, nB)).cpu().pin_memory()
+    fv = datagen.fill_chunks(torch.empty(nP, dtype=torch.float64, device=dev), lambda i: datagen.val_t(0xF2, i)).cpu().pin_memory()
+    dk = datagen.fill_chunks(torch.empty(nB, dtype=torch.int64, device=dev), lambda i: datagen.dim_key_t(i, nB)).cpu().pin_memory()
+    torch.cuda.synchronize()
+
+    def host_batch(tensors, dtypes, lo, hi):
+        cols = [abi.Column(dt, H, hi - lo, 0, t.data_ptr() + lo * t.element_size(), None, None) for t, dt in zip(tensors, dtypes)]
+        return abi.RawBatch(cols, hi - lo, keepalive=tensors)
+    lk, _k1 = abi.pack_exprs([InputRef(0)])
+    rk, _k2 = abi.pack_exprs([InputRef(0)])
+    gb, _k3 = abi.pack_exprs([InputRef(0)])
+    keep = []
+    aggs = (abi.AggFunc * 2)(AggFunc("count", InputRef(2), abi.INT64).abi_struct(keep), AggFunc("sum", InputRef(2), abi.FLOAT64).abi_struct(keep))
+    rd = (C.c_int32 * 2)(abi.INT64, abi.FLOAT64)
+    pf = (InputRef(1) > Constant(0.5, abi.FLOAT64)).pack()
+    groups = [0]
+
+    def run_c5_host():
+        ja = C.c_void_p()
+        be.check(be.fn("join_agg_create")(be.ctx, 1, lk, rk, 1, 2, rd, 1, gb, 2, aggs, C.byref(ja)))
+        be.check(be.fn("join_agg_set_probe_filter")(ja, C.byref(pf.abi)))
+        be.check(be.fn("join_agg_build_push")(ja, host_batch([dk], [abi.INT64], 0, nB).ptr))
+        be.check(be.fn("join_agg_build_finish")(ja))
+        for lo in range(0, nP, step_rows):
+            be.check(be.fn("join_agg_probe_push")(ja, host_batch([fk, fv], [abi.INT64, abi.FLOAT64], lo, min(nP, lo + step_rows)).ptr))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("join_agg_finish")(ja, abi.MEM_DEVICE, C.byref(o)))
+        groups[0] = o.contents.num_rows
+        be.fn("batch_release")(o)
+        be.fn("join_agg_destroy")(ja)
+        be.synchronize()
+    run_c5_host()
+    best = 1e30
+    for _ in range(2):
+        t = time.perf_counter()
+        run_c5_host()
+        best = min(best, time.perf_counter() - t)
+    moved = 16 * nP + 8 * nB
+    out["C5_host_1e8"] = {"fact_rows": nP, "dim_rows": nB, "groups": groups[0], "ms": round(best * 1e3, 2),
+                          "Mrows_s": round(nP / best / 1e6, 1), "pcie_GBps": round(moved / best / 1e9, 1),
+                          "pcie_frac_of_63GBps": round(moved / best / 1e9 / PCIE_GBPS, 3),
+                          "note": "pinned host columns -> sqlrs_join_agg_* with the probe Filter, 2^24-row probe batches, result left in HBM; wall clock"}
+    del fk, fv, dk
+    # ---- (b)
+    import pyarrow as pa
+    n, B, G = 20_000_000, 1024, 1_000_000
+    idx = np.arange(n, dtype=np.int64)
+    fact = pa.RecordBatch.from_arrays([pa.array(datagen.key_np(0xA1, idx, G)), pa.array(datagen.val_np(0xF2, idx))], names=["key", "val"])
+    fb = [abi.HostBatch(fact.slice(lo, B)) for lo in range(0, n, B)]  # marshalled once: the binding's cost is not the library's
+    aggs4 = (abi.AggFunc * 2)(AggFunc("count", InputRef(1), abi.INT64).abi_struct(keep), AggFunc("sum", InputRef(1), abi.FLOAT64).abi_struct(keep))
+
+    def run_c4_host():
+        a = C.c_void_p()
+        be.check(be.fn("hash_agg_create")(be.ctx, 1, gb, 2, aggs4, C.byref(a)))
+        push = be.fn("hash_agg_push")
+        for b in fb:
+            be.check(push(a, b.ptr))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("hash_agg_finish")(a, H, C.byref(o)))
+        groups[0] = o.contents.num_rows
+        be.fn("batch_release")(o)
+        be.fn("hash_agg_destroy")(a)
+    run_c4_host()
+    t = time.perf_counter()
+    run_c4_host()
+    dt = time.perf_counter() - t
+    out["C4_host_batches_1024"] = {"rows": n, "batches": len(fb), "groups": groups[0], "ms": round(dt * 1e3, 1),
+                                   "Mrows_s": round(n / dt / 1e6, 1), "pcie_GBps": round(16 * n / dt / 1e9, 2),
+                                   "pcie_frac_of_63GBps": round(16 * n / dt / 1e9 / PCIE_GBPS, 4),
+                                   "note": "19532 pageable 1024-row host batches (storage/csv.rs:105) through sqlrs_hash_agg_push's host "
+                                           "staging (one upload per 2^22 rows), result on the host; wall clock incl. one ctypes call per batch"}
+    return out
 
 
 def _tensor_view(torch, ptr, n, dtype, dev):
