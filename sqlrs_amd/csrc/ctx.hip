@@ -523,7 +523,7 @@ int sqlrs_ctx_create(int device_id, sqlrs_ctx_t **out) {
   }
   c->pinned_bytes = 4096;
   if (const char *e = std::getenv("SQLRS_POOL_RESERVE_GB")) { // experiment / deployment knob: one up-front allocation
-    const size_t bytes = (size_t)std::atof(e) * (1ull << 30);
+    const size_t bytes = (size_t)(std::atof(e) * (double)(1ull << 30)); // (fractions of a GiB count: "0.5", "1.5")
     void *p = nullptr;
     if (bytes && hipMalloc(&p, bytes) == hipSuccess) {
       c->pool.arena = (uint8_t *)p;

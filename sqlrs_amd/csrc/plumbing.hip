@@ -77,7 +77,7 @@ bool is_int(const std::string &s) {
   if (p < e && *p == '-') p++;
   return all_digits(p, e);
 }
-bool is_float(const std::string &s) { // -?(\d*\.\d+|\d+\.\d*)([eE][-+]?\d+)? | -?\d+[eE][-+]?\d+
+bool is_float(const std::string &s) { // -?(\d*\.\d+|\d+\.\d*)([eE]-?\d+)? | -?\d+[eE]-?\d+
   const char *p = s.data(), *e = p + s.size();
   if (p < e && *p == '-') p++;
   const char *d0 = p;
@@ -95,7 +95,7 @@ bool is_float(const std::string &s) { // -?(\d*\.\d+|\d+\.\d*)([eE][-+]?\d+)? | 
   bool exp = false;
   if (p < e && (*p == 'e' || *p == 'E')) {
     p++;
-    if (p < e && (*p == '-' || *p == '+')) p++;
+    if (p < e && *p == '-') p++; // (arrow-csv 28's DECIMAL_RE has [eE]-?\d+: "1e+5" is text, not a float)
     if (!all_digits(p, e)) return false;
     p = e;
     exp = true;
@@ -456,6 +456,11 @@ int sqlrs_csv_next_batch(sqlrs_csv_t *r, int out_mem, sqlrs_batch_t **out) {
     while (rows < r->batch_size && r->remaining > 0 && read_record(r->file, r->delimiter, f)) {
       r->line++;
       if (r->remaining != ~0ull) r->remaining--;
+      // a record with another number of fields than the schema is an error of the csv crate (UnequalLengths), which
+      // arrow-csv surfaces as an ArrowError — not a row padded with NULLs
+      if (f.size() != r->names.size())
+        fail(SQLRS_ERR_ARROW, "Error parsing line " + std::to_string(r->line) + ": found record with " + std::to_string(f.size()) +
+                                  " fields, but the previous record has " + std::to_string(r->names.size()) + " fields");
       for (size_t c = 0; c < nc; c++) {
         const int src = r->projection[c];
         const std::string &s = (size_t)src < f.size() ? f[(size_t)src] : std::string();

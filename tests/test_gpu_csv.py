@@ -56,6 +56,22 @@ def test_csv_dialect_batches_bounds_projection(hip, tmp_path):
     assert hip.batch_to_string(dev[0]).splitlines()[7] == "7 NULL NULL (empty) (empty)"
 
 
+def test_csv_malformed_input_follows_arrow_csv(hip, tmp_path):
+    """a record with another number of fields than the header is an error (the csv crate's UnequalLengths, surfaced
+    by arrow-csv as an ArrowError), not a row padded with NULLs; `1e+5` is text (arrow-csv 28's DECIMAL_RE allows
+    only `[eE]-?\\d+`), `1e-5` and `2E5` are floats"""
+    p = tmp_path / "ragged.csv"
+    p.write_text("a,b,c\n1,2,3\n4,5\n7,8,9\n")
+    with pytest.raises(Exception, match="found record with 2 fields"):
+        read_all(CsvScan(hip, str(p)))
+    q = tmp_path / "exp.csv"
+    q.write_text("x,y\n1e-5,1e+5\n2E5,3\n")
+    scan = CsvScan(hip, str(q))
+    _, got = read_all(scan)
+    assert scan.dtypes == [abi.FLOAT64, abi.UTF8]
+    assert got.column(0).to_pylist() == [1e-5, 2e5] and got.column(1).to_pylist() == ["1e+5", "3"]
+
+
 def test_c1_employee_group_by_state_end_to_end(hip, oracle):
     """BASELINE.json config C1 with the reference's golden (aggregation.slt:30-34 restricted to the three
     columns): CSV -> HBM -> HashAgg -> text, nothing but the file and the final string on the host"""
