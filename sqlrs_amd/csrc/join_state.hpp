@@ -34,6 +34,7 @@ struct sqlrs_hash_join {
   sq::BufP dense;              // direct-address table (u32 build row per key - dense_min) or null
   uint64_t dense_min = 0, dense_range = 0;
   uint32_t dense_null_head = 0xffffffffu;
+  sq::BufP dense_bits; // one bit per possible key of the direct-address table (key-only build side, join.hip)
   sq::BufP bkeys, bkeys_validity; // normalised build keys (u64[nB]) and their validity bitmap
   // general keys on LDS tables (join.hip, lds_join_match): the build keys in bucket order, built at the first probe
   // that takes the route; lds_slots = 0: the route does not apply to this build side

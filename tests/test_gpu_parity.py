@@ -217,6 +217,33 @@ def test_hash_join_lds_tables_f64_keys_and_fallbacks(hip, oracle, monkeypatch):
         assert_same(rows_of(got), rows_of(exp))
 
 
+@pytest.mark.parametrize("hit", ["all", "some", "none"])
+@pytest.mark.parametrize("batches", [1, 2])
+def test_hash_join_key_only_build_side(hip, oracle, hit, batches):
+    """Inner join whose build side is nothing but its unique dense key column (a dimension projected to its key):
+    the probe is an existence test against a bitmap and the joined batch the probe batch restricted to the matching
+    rows (all of them: shared outright) — same batches as the general route (hash_join.rs:207-292)."""
+    rng = np.random.default_rng(len(hit) + batches)
+    nb, npr = 50_000, 400_000
+    bk = (rng.permutation(nb) + 1000).astype(np.int64)
+    lo, hi = {"all": (1000, 1000 + nb), "some": (0, 2000 + nb), "none": (2 * nb + 5000, 3 * nb + 5000)}[hit]
+    lb = pa.RecordBatch.from_arrays([pa.array(bk)], names=["c0"])
+    rb = pa.RecordBatch.from_arrays([pa.array(rng.random(npr)), pa.array(rng.integers(lo, hi, npr, dtype=np.int64))], names=["c0", "c1"])
+    rbs = [rb] if batches == 1 else [rb.slice(0, 150_000), rb.slice(150_000)]
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    sch = join_schema(lb, rb)
+    hip.profile(True)
+    got = list(HashJoinExecutor(hip, [lb], rbs, "inner", cond, sch, 1).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    assert prof.get("join_semi_mask", (0, 0))[1] == batches, prof
+    exp = list(HashJoinExecutor(oracle, [lb], rbs, "inner", cond, sch, 1).execute())
+    assert [b.num_rows for b in got] == [b.num_rows for b in exp]
+    for g, e in zip(got, exp):
+        for c in range(g.num_columns):
+            assert g.column(c).equals(e.column(c)), c
+
+
 @pytest.mark.parametrize("kind", ["i32", "f64", "bool"])
 def test_hash_join_key_types(hip, oracle, kind):
     rng = np.random.default_rng(3)
@@ -548,7 +575,7 @@ def test_hash_agg_partition_route_with_key_skew(hip, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scale", ["0.3", "0.05"])
+@pytest.mark.parametrize("scale", ["0.05"])
 def test_hash_agg_partition_route_with_forced_table_overflow(scale):
     """SQLRS_EST_SCALE shrinks the HyperLogLog group estimate, so the per-bucket LDS tables
     overflow and rows take the overflow -> global-table path; group order and values must not
@@ -559,8 +586,8 @@ def test_hash_agg_partition_route_with_forced_table_overflow(scale):
     env = dict(os.environ, SQLRS_EST_SCALE=scale)
     here = os.path.abspath(__file__)
     # (the milder scale re-runs the partition-route tests only: the driver's GPU suite has a time budget)
-    sel = "(partition_route or mixed_routes or join_agg) and not forced" if scale == "0.05" else \
-          "partition_route and not forced and not packed_and"
+    sel = "((test_hash_agg_partition_route and not packed_and and not few_groups) or mixed_routes or join_agg_fused or " \
+          "join_agg_composed) and not forced"
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", sel],
                        env=env, capture_output=True, text=True, timeout=400)
@@ -770,8 +797,12 @@ def test_agg_paths_without_staging():
     env = dict(os.environ, SQLRS_STAGE_DIRECT_ROWS="0")
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "(hash_agg or join_agg or utf8_keys) and not forced and not without_staging and not packed_and"],
-                       env=env, capture_output=True, text=True, timeout=1500)
+                        # (a representative cut — multi-batch aggregation, both partition routes, the fused join, Utf8 keys —
+                        #  not every aggregation test twice: the driver's GPU suite has a time budget)
+                        "-k", "(mixed_routes or multi_batch or (test_hash_agg_partition_route and not packed_and and not few_groups "
+                              "and not key_skew) or join_agg_fused or join_agg_composed or join_agg_dense or utf8_keys or "
+                              "test_hash_agg_distinct) and not forced and not without"],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
@@ -786,7 +817,9 @@ def test_lookback_ticket_fallback_paths():
     env = dict(os.environ, SQLRS_FORCE_TICKET="1")
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "(test_filter or test_hash_join) and not fallback"],
+                        "-k", "(test_filter_cmp_const or test_filter_large_tiles or test_filter_general_expr or test_hash_join_indices or "
+                              "test_hash_join_direct_address_table or test_hash_join_lds_tables_general_keys or (test_hash_join and inner)) "
+                              "and not fallback"],
                        env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -1000,7 +1033,8 @@ def test_agg_paths_without_dense_tables():
     env = dict(os.environ, SQLRS_DENSE_AGG="0")
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "(dense_key or join_agg) and not forced and not without"],
+                        "-k", "((dense_key_route and (count_sum_f64 or min_max_i64)) or join_agg_dense_build_keys or "
+                              "join_agg_probe_keys_outside or join_agg_fused) and not forced and not without"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
