@@ -764,9 +764,10 @@ __global__ void dense_bits_kernel(const uint32_t *__restrict__ heads, int64_t ra
 constexpr int SM_U = 8; // 64-row chunks per wave and trip
 __global__ __launch_bounds__(BLOCK) void semi_mask_kernel(const uint64_t *__restrict__ keys, int64_t n,
                                                           const uint64_t *__restrict__ bits, uint64_t kmin, uint64_t range,
-                                                          uint64_t *__restrict__ mask) {
+                                                          uint64_t *__restrict__ mask, unsigned long long *__restrict__ hits) {
   const int lane = lane_id();
   const int64_t nchunks = (n + 63) / 64;
+  uint32_t wave_hits = 0;
   for (int64_t c0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id()) * SM_U; c0 < nchunks;
        c0 += (int64_t)gridDim.x * WAVES_PER_BLOCK * SM_U) {
     uint64_t k[SM_U];
@@ -784,9 +785,11 @@ __global__ __launch_bounds__(BLOCK) void semi_mask_kernel(const uint64_t *__rest
       const uint64_t d = k[u] - kmin;
       const uint64_t b = __ballot((c0 + u) * 64 + lane < n && ((wd[u] >> (d & 63)) & 1));
       mine = lane == u ? b : mine;
+      wave_hits += (uint32_t)__popcll(b);
     }
     if (lane < SM_U && c0 + lane < nchunks) mask[c0 + lane] = mine; // one 64-byte store per trip
   }
+  if (lane == 0 && wave_hits) atomicAdd(hits, (unsigned long long)wave_hits); // (one atomic per wave: all rows matched?)
 }
 
 __global__ void bytes_to_bits_kernel(const uint8_t *__restrict__ bytes, int64_t n,
@@ -1281,11 +1284,14 @@ static bool semi_join_probe(sqlrs_hash_join *j, InBatch &ib, const NKeys &pk, DB
   {
     ProfScope ps(ctx, "join_semi_mask");
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(nwords, WAVES_PER_BLOCK * SM_U), 8 * (int64_t)ctx->num_cus);
+    BufP hits = ctx->alloc_zero(8);
     semi_mask_kernel<<<dim3(std::max(blocks, 1u)), dim3(BLOCK), 0, ctx->stream>>>(
-        pk.keys->as<uint64_t>(), n, j->dense_bits->as<uint64_t>(), j->dense_min, j->dense_range, sel.own_bits->as<uint64_t>());
+        pk.keys->as<uint64_t>(), n, j->dense_bits->as<uint64_t>(), j->dense_min, j->dense_range, sel.own_bits->as<uint64_t>(),
+        hits->as<unsigned long long>());
     SQ_HIP(hipGetLastError());
+    sel.count = (int64_t)ctx->fetch_value(hits->as<uint64_t>());
   }
-  selection_finish(ctx, sel);
+  if (sel.count != n) selection_finish(ctx, sel); // (tile offsets are only needed to compact: 1.4 ms per 5e8 rows)
   // (all rows kept: the output SHARES the probe columns — library-owned buffers by reference, a caller's borrowed
   //  device buffers as private copies, since a batch is only borrowed for the call)
   DBatch right = ib.materialize(sel.count == n);
