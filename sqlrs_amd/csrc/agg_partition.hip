@@ -553,28 +553,47 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
 // exactly when its offset is in range; no build-side partition is needed.
 //
 // split tables (skewed buckets): same direct addressing, first[nsplit][R] | acc[n_acc][nsplit][R].
-__global__ void split_init_dense_kernel(SplitTables stb, int64_t total, int n_acc, LdsAggParams prm) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  stb.first[i] = 0xffffffffu;
-  for (int a = 0; a < n_acc; a++) stb.acc[(size_t)a * total + i] = acc_identity_cell(prm.code[a] & 7);
-}
-
-__global__ void split_emit_dense_kernel(SplitTables stb, const uint32_t *__restrict__ split_bucket, uint32_t R,
-                                        KeyPack kp, int n_acc, unsigned long long *out_count,
+// Dense route, split buckets: every chunk of a split bucket STORES its finished LDS table (first[R] | acc[n_acc][R],
+// plain coalesced stores) as table `split` of `stb` (here: nsplit = number of CHUNK tables), and this kernel reduces the
+// tables chunk_lo[t] .. chunk_lo[t + 1] of split bucket t slot by slot and emits the groups.  The first form merged
+// every chunk into one global table per bucket with an atomic per slot and accumulator (12 K global atomics per chunk
+// at 24 G/s): splitting was affordable for a few skewed buckets only, and a batch of Zipf keys — ~245 unequal buckets
+// on 256 CUs, one work item each — ran at the pace of its slowest bucket (C4: bucket pass 1.58 ms against 0.63 for
+// uniform keys).  With stores a chunk costs 80 KB of traffic, so EVERY bucket can be cut into several work items.
+__global__ void split_emit_dense_kernel(SplitTables stb, const uint32_t *__restrict__ split_bucket,
+                                        const uint32_t *__restrict__ chunk_lo, uint32_t nbuckets_split, uint32_t R,
+                                        KeyPack kp, LdsAggParams prm, int n_acc, unsigned long long *out_count,
                                         uint64_t *__restrict__ gkey, uint32_t *__restrict__ gfirst,
                                         uint64_t *__restrict__ gacc, int64_t gcap) {
-  const int64_t total = (int64_t)stb.nsplit * R;
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  unsigned int first = stb.first[i];
-  if (first == 0xffffffffu) return;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)nbuckets_split * R) return;
   const uint32_t s = (uint32_t)(i % R), t = (uint32_t)(i / R);
+  const int64_t total = (int64_t)stb.nsplit * R;
+  unsigned int first = 0xffffffffu;
+  unsigned long long acc[PART_MAX_ACC];
+  for (int a = 0; a < n_acc; a++) acc[a] = acc_identity_cell(prm.code[a] & 7);
+  for (uint32_t c = chunk_lo[t]; c < chunk_lo[t + 1]; c++) {
+    const unsigned int f = stb.first[(size_t)c * R + s];
+    if (f == 0xffffffffu) continue; // (a slot no row of this chunk touched holds identities)
+    first = min(first, f);
+    for (int a = 0; a < n_acc; a++) {
+      const unsigned long long v = stb.acc[(size_t)a * total + (size_t)c * R + s];
+      switch (prm.code[a] & 7) {
+      case AK_COUNT:
+      case AK_SUM_I64: acc[a] += v; break;
+      case AK_SUM_F64: acc[a] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)acc[a]) + __longlong_as_double((long long)v)); break;
+      case AK_MIN_I64:
+      case AK_MIN_F64: acc[a] = min(acc[a], v); break;
+      default: acc[a] = max(acc[a], v);
+      }
+    }
+  }
+  if (first == 0xffffffffu) return;
   unsigned long long base = atomicAdd(out_count, 1ull);
   if ((int64_t)base >= gcap) return;
   gkey[base] = kp.kmin + ((uint64_t)split_bucket[t] << kp.rbits) + s;
   gfirst[base] = first;
-  for (int a = 0; a < n_acc; a++) gacc[(size_t)a * gcap + base] = stb.acc[(size_t)a * total + i];
+  for (int a = 0; a < n_acc; a++) gacc[(size_t)a * gcap + base] = acc[a];
 }
 
 template <int NV, bool JOIN, int NACC, int C0, int C1, bool REC = false>
@@ -677,25 +696,14 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
     cur = nxt;
   }
   __syncthreads();
-  if (split != 0xffffffffu) { // chunk of a skewed bucket: merge into the bucket's global table, slot for slot
+  if (split != 0xffffffffu) { // chunk of a split bucket: its table goes out as chunk table `split` (split_emit_dense_kernel reduces)
     unsigned int *gf = stb.first + (size_t)split * R;
     for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
-      unsigned int first = tfirst[s];
-      if (first == 0xffffffffu) continue;
-      atomicMin(&gf[s], first);
+      gf[s] = tfirst[s];
 #pragma unroll
       for (int a = 0; a < PART_MAX_ACC; a++) {
         if (a >= n_acc) break;
-        unsigned long long *cell = stb.acc + ((size_t)a * stb.nsplit + split) * R + s;
-        const unsigned long long v = tacc[(size_t)a * R + s];
-        switch (code_of(a) & 7) {
-        case AK_COUNT:
-        case AK_SUM_I64: atomicAdd(cell, v); break;
-        case AK_SUM_F64: unsafeAtomicAdd((double *)cell, __longlong_as_double((long long)v)); break;
-        case AK_MIN_I64:
-        case AK_MIN_F64: atomicMin(cell, v); break;
-        default: atomicMax(cell, v);
-        }
+        stb.acc[((size_t)a * stb.nsplit + split) * R + s] = tacc[(size_t)a * R + s];
       }
     }
     return;
@@ -988,8 +996,11 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     int64_t nonempty_d = 0;
     for (uint32_t bkt = 0; bkt < P; bkt++) nonempty_d += hb[bkt + 1] > hb[bkt];
     const int64_t avg = n / std::max<int64_t>(nonempty_d, 1);
-    chunk = (uint32_t)std::max<int64_t>(32768, avg / 2);
-    split_above = (uint32_t)std::max<int64_t>(65536, avg + avg / 4);
+    const char *cd_e = std::getenv("SQLRS_DENSE_CHUNK_DIV"), *sa_e = std::getenv("SQLRS_DENSE_SPLIT_PCT"); // tuning hooks, read per call
+    const int cdiv = cd_e ? std::max(1, std::atoi(cd_e)) : 2;        // chunk = average / this
+    const int sa_pct = sa_e ? std::max(1, std::atoi(sa_e)) : 125;    // buckets above this % of the average are split
+    chunk = (uint32_t)std::max<int64_t>(32768, avg / cdiv);
+    split_above = (uint32_t)std::max<int64_t>(65536, avg * sa_pct / 100);
   }
   {
     // Few buckets (few groups: GROUP BY state, a flag, a date part): without this the whole batch is
@@ -1004,21 +1015,32 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
       split_above = chunk;
     }
   }
-  std::vector<uint32_t> work, split_bucket;
+  std::vector<uint32_t> work, split_bucket, chunk_lo; // dense: chunk_lo[t] = first chunk table of split bucket t
   work.reserve(4 * ((size_t)P + 64));
   out->may_dup = false;
-  uint32_t nsplit = 0;
+  uint32_t nsplit = 0, nchunk_tables = 0;
   for (uint32_t bkt = 0; bkt < P; bkt++) {
     uint32_t lo = hb[bkt], hi = hb[bkt + 1];
     if (dense && lo == hi) continue; // nothing to set up for an empty bucket (no build keys to insert)
     if (hi - lo <= split_above) {
       work.insert(work.end(), {bkt, lo, hi, 0xffffffffu});
+    } else if (dense) { // every chunk stores its own table; the emit kernel reduces them
+      chunk_lo.push_back(nchunk_tables);
+      // (equal chunks: a remainder chunk of a few rows would still cost a whole table)
+      const uint32_t pieces = (uint32_t)ceil_div((int64_t)(hi - lo), (int64_t)chunk);
+      for (uint32_t q = 0; q < pieces; q++) {
+        const uint32_t c0 = lo + (uint32_t)((uint64_t)(hi - lo) * q / pieces), c1 = lo + (uint32_t)((uint64_t)(hi - lo) * (q + 1) / pieces);
+        work.insert(work.end(), {bkt, c0, c1, nchunk_tables++});
+      }
+      split_bucket.push_back(bkt);
+      nsplit++;
     } else {
       for (uint32_t c0 = lo; c0 < hi; c0 += chunk) work.insert(work.end(), {bkt, c0, std::min(hi, c0 + chunk), nsplit});
       split_bucket.push_back(bkt);
       nsplit++;
     }
   }
+  chunk_lo.push_back(nchunk_tables);
   if (nsplit) { // largest work items first
     std::vector<uint32_t> ord(work.size() / 4), sorted(work.size());
     for (uint32_t i = 0; i < ord.size(); i++) ord[i] = i;
@@ -1034,17 +1056,18 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   const uint32_t nslots_h = dense ? cap : cap + 2;
   SplitTables stb;
   BufP stb_key, stb_first, stb_acc, dsplit;
-  if (nsplit && dense) {
-    const int64_t total = (int64_t)nsplit * nslots_h;
+  BufP dchunk_lo;
+  if (nsplit && dense) { // one table per CHUNK (stored whole by its workgroup: nothing to initialise)
+    const int64_t total = (int64_t)nchunk_tables * nslots_h;
     stb_first = ctx->alloc(4 * (size_t)total);
     stb_acc = ctx->alloc(8 * (size_t)total * (size_t)std::max(spec.n_acc, 1));
     stb.first = stb_first->as<unsigned int>();
     stb.acc = stb_acc->as<unsigned long long>();
-    stb.nsplit = nsplit;
+    stb.nsplit = nchunk_tables;
     dsplit = ctx->alloc(4 * (size_t)nsplit);
+    dchunk_lo = ctx->alloc(4 * ((size_t)nsplit + 1));
     SQ_HIP(hipMemcpyAsync(dsplit->p, split_bucket.data(), 4 * (size_t)nsplit, hipMemcpyHostToDevice, ctx->stream));
-    split_init_dense_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(stb, total, spec.n_acc, prm);
-    SQ_HIP(hipGetLastError());
+    SQ_HIP(hipMemcpyAsync(dchunk_lo->p, chunk_lo.data(), 4 * ((size_t)nsplit + 1), hipMemcpyHostToDevice, ctx->stream));
   } else if (nsplit) {
     const int64_t total = (int64_t)nsplit * nslots_h;
     stb_key = ctx->alloc(8 * (size_t)total);
@@ -1125,8 +1148,8 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
       if (nsplit) {
         const int64_t total = (int64_t)nsplit * nslots_h;
         split_emit_dense_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
-            stb, dsplit->as<uint32_t>(), cap, pr.pack, spec.n_acc, ctr->as<unsigned long long>(),
-            out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(), out->gacc->as<uint64_t>(), gcap);
+            stb, dsplit->as<uint32_t>(), dchunk_lo->as<uint32_t>(), nsplit, cap, pr.pack, prm, spec.n_acc,
+            ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(), out->gacc->as<uint64_t>(), gcap);
       }
     }
     // specialised kernels: no nullable column, one value column, the usual accumulator lists
