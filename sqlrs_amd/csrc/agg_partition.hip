@@ -408,7 +408,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
         const bool hot = act && s == s0;
         const uint64_t peers = __ballot(hot);
         if (__popcll(peers) >= 8) {
-          const uint32_t idmin = wave_min_u32(hot ? cur.id[u] : 0xffffffffu);
+          const uint32_t idmin = wave_min_u32_dpp(hot ? cur.id[u] : 0xffffffffu);
           if (lane_id() == first) atomicMin(&tfirst[s0], idmin);
 #pragma unroll
           for (int a = 0; a < PART_MAX_ACC; a++) {
@@ -421,8 +421,8 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
             uint64_t red;
             switch (kind) {
             case AK_COUNT: red = (uint64_t)__popcll(inm); break;
-            case AK_SUM_I64: red = wave_sum_u64(in ? v : 0ull); break;
-            case AK_SUM_F64: red = (uint64_t)__double_as_longlong(wave_sum_f64(in ? __longlong_as_double((long long)v) : 0.0)); break;
+            case AK_SUM_I64: red = wave_sum_u64_dpp(in ? v : 0ull); break;
+            case AK_SUM_F64: red = (uint64_t)__double_as_longlong(wave_sum_f64_dpp(in ? __longlong_as_double((long long)v) : 0.0)); break;
             case AK_MIN_I64: red = wave_min_u64(in ? i64_to_ordered((int64_t)v) : ~0ull); break;
             case AK_MIN_F64: red = wave_min_u64(in ? f64_to_ordered(__longlong_as_double((long long)v)) : ~0ull); break;
             case AK_MAX_I64: red = wave_max_u64(in ? i64_to_ordered((int64_t)v) : 0ull); break;
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
         const bool hot = act && s == s0;
         const uint64_t peers = __ballot(hot);
         if (__popcll(peers) >= 8) {
-          const uint32_t idmin = wave_min_u32(hot ? id : 0xffffffffu);
+          const uint32_t idmin = wave_min_u32_dpp(hot ? id : 0xffffffffu);
           if (lane_id() == first) atomicMin(&tfirst[s0], idmin);
 #pragma unroll
           for (int a = 0; a < PART_MAX_ACC; a++) {
@@ -661,8 +661,8 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
             uint64_t red;
             switch (kind) {
             case AK_COUNT: red = (uint64_t)__popcll(peers); break;
-            case AK_SUM_I64: red = wave_sum_u64(hot ? v : 0ull); break;
-            case AK_SUM_F64: red = (uint64_t)__double_as_longlong(wave_sum_f64(hot ? __longlong_as_double((long long)v) : 0.0)); break;
+            case AK_SUM_I64: red = wave_sum_u64_dpp(hot ? v : 0ull); break;
+            case AK_SUM_F64: red = (uint64_t)__double_as_longlong(wave_sum_f64_dpp(hot ? __longlong_as_double((long long)v) : 0.0)); break;
             case AK_MIN_I64: red = wave_min_u64(hot ? i64_to_ordered((int64_t)v) : ~0ull); break;
             case AK_MIN_F64: red = wave_min_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : ~0ull); break;
             case AK_MAX_I64: red = wave_max_u64(hot ? i64_to_ordered((int64_t)v) : 0ull); break;

@@ -74,6 +74,44 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     v += __longlong_as_double((long long)shfl_xor_u64((uint64_t)__double_as_longlong(v), m));
   return v;
 }
+// ---- DPP reductions (ALL 64 lanes must be active) ----------------------------------------------------------
+// The butterfly above is six dependent ds_bpermute round trips (twelve for a 64-bit value).  Inside a 16-lane row
+// the data-parallel-primitive modifiers move a register without touching the LDS crossbar: xor-1 / xor-2 as quad
+// permutations, then row_half_mirror (lane i <-> 7 - i) and row_mirror (i <-> 15 - i) pair the 4- and 8-lane groups
+// (any pairing of groups that already hold uniform partial results works); the four row results are combined with
+// readlanes.  Used where a reduction sits on the per-row path (hot keys of the LDS bucket passes).
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL> __device__ __forceinline__ uint64_t dpp_mov_u64(uint64_t v) {
+  return ((uint64_t)dpp_mov_u32<CTRL>((uint32_t)(v >> 32)) << 32) | dpp_mov_u32<CTRL>((uint32_t)v);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
+  v += __longlong_as_double((long long)dpp_mov_u64<DPP_XOR1>((uint64_t)__double_as_longlong(v)));
+  v += __longlong_as_double((long long)dpp_mov_u64<DPP_XOR2>((uint64_t)__double_as_longlong(v)));
+  v += __longlong_as_double((long long)dpp_mov_u64<DPP_HALF_MIRROR>((uint64_t)__double_as_longlong(v)));
+  v += __longlong_as_double((long long)dpp_mov_u64<DPP_MIRROR>((uint64_t)__double_as_longlong(v)));
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (__longlong_as_double((long long)readlane_u64(b, 0)) + __longlong_as_double((long long)readlane_u64(b, 16))) +
+         (__longlong_as_double((long long)readlane_u64(b, 32)) + __longlong_as_double((long long)readlane_u64(b, 48)));
+}
+__device__ __forceinline__ uint64_t wave_sum_u64_dpp(uint64_t v) {
+  v += dpp_mov_u64<DPP_XOR1>(v);
+  v += dpp_mov_u64<DPP_XOR2>(v);
+  v += dpp_mov_u64<DPP_HALF_MIRROR>(v);
+  v += dpp_mov_u64<DPP_MIRROR>(v);
+  return (readlane_u64(v, 0) + readlane_u64(v, 16)) + (readlane_u64(v, 32) + readlane_u64(v, 48));
+}
+__device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) {
+  v = min(v, dpp_mov_u32<DPP_XOR1>(v));
+  v = min(v, dpp_mov_u32<DPP_XOR2>(v));
+  v = min(v, dpp_mov_u32<DPP_HALF_MIRROR>(v));
+  v = min(v, dpp_mov_u32<DPP_MIRROR>(v));
+  return min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+             min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
