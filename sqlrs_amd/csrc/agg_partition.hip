@@ -29,6 +29,10 @@
 namespace sq {
 
 constexpr int PART_WG = 512;
+#ifndef HOT_MIN_PEERS_N
+#define HOT_MIN_PEERS_N 8
+#endif
+constexpr int HOT_MIN_PEERS = HOT_MIN_PEERS_N; // lanes of a wave on one slot from which they are reduced across the wave first
 constexpr uint64_t LDS_EMPTY = ~0ull;
 
 __device__ __forceinline__ uint32_t bucket_of(uint64_t h, uint32_t P) {
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
         const uint32_t s0 = (uint32_t)__shfl((int)s, first, 64);
         const bool hot = act && s == s0;
         const uint64_t peers = __ballot(hot);
-        if (__popcll(peers) >= 8) {
+        if (__popcll(peers) >= HOT_MIN_PEERS) {
           const uint32_t idmin = wave_min_u32_dpp(hot ? cur.id[u] : 0xffffffffu);
           if (lane_id() == first) atomicMin(&tfirst[s0], idmin);
 #pragma unroll
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
         const uint32_t s0 = (uint32_t)__shfl((int)s, first, 64);
         const bool hot = act && s == s0;
         const uint64_t peers = __ballot(hot);
-        if (__popcll(peers) >= 8) {
+        if (__popcll(peers) >= HOT_MIN_PEERS) {
           const uint32_t idmin = wave_min_u32_dpp(hot ? id : 0xffffffffu);
           if (lane_id() == first) atomicMin(&tfirst[s0], idmin);
 #pragma unroll
