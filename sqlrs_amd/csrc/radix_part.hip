@@ -23,6 +23,10 @@ namespace sq {
 // 3072- and 4096-row tiles with two (measured on C5, both before and after the kernel was made
 // branch-free).
 
+// s_waitcnt immediate for "at most N vector-memory operations outstanding" (gfx9 encoding: vmcnt[3:0] in bits 3:0,
+// vmcnt[5:4] in bits 15:14; expcnt and lgkmcnt left at their maxima = not waited for)
+constexpr int vmcnt_imm(int n) { return (n & 0xF) | ((n >> 4) << 14) | 0x0F70; }
+
 struct Tile {
   int64_t start;
   uint32_t len;
@@ -300,12 +304,19 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
   // second tile into `cur`
   t = tiles[min(t0 + 1, t1 - 1)];
   rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, t, min(t0 + 1, t1 - 1), offs, digits, cur);
+#ifndef RP_PREFETCH_LATE
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the back edge
+#endif
+  // loads of one rp_load_tile per thread (the prefetch left in flight behind the drained stores, see below)
+  [[maybe_unused]] constexpr int NLOADS = RP_ROWS * (1 + (NV >= 1) + (NV >= 2) + ((!PACK && (MODE == RP_LN || MODE == RP_LN_FLAG)) ? 1 : 0) +
+                                    (MODE == RP_LN_FLAG ? 1 : 0)) + 1;
   for (uint32_t ti = t0 + 1; ti < t1; ti++) {
     // staging area: tile ti-1 (sorted);  cur: tile ti;  nxt <- tile ti+1
     const uint32_t tnext = min(ti + 1, t1 - 1);
     Tile tn = tiles[tnext];
+#ifndef RP_PREFETCH_LATE // (default; -DRP_PREFETCH_LATE = the A/B variant below, tools/ab_two_builds.sh)
     rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, tn, tnext, offs, digits, nxt);
+#endif
     cnt[threadIdx.x] = 0;
     __syncthreads();
 #pragma unroll
@@ -313,7 +324,21 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
       store_row(j, staged_len);
       rank_row(j, t.len);
     }
+    // -DRP_PREFETCH_LATE (measured in round 3, not faster, kept as an A/B build): the next tile's loads issued BEHIND
+    // this tile's stores.  vmcnt is one in-order counter: with the loads in front, every wait of the rank loop — and
+    // the drain — also waits for prefetched rows it does not need yet (the ISA shows vmcnt(62) .. vmcnt(32) down the
+    // unrolled loop: the counter saturates at 63 with 64 loads + stores in flight) and nothing is in flight during
+    // scan_and_stage; behind the stores the drain waits for exactly the stores (the NLOADS youngest operations stay
+    // outstanding) and the rows of tile ti+1 travel while tile ti is scanned and staged.  Two builds in one process
+    // (tools/ab_two_builds.sh), C5: level 1 6.27 / 6.20 / 5.84 ms late vs 6.21 / 5.93 / 5.83 early, level 2 3.80 / 3.18
+    // / 3.72 vs 3.04 / 2.91 / 3.70 — inside the spread that buffer placement alone causes: these loops are not bound by
+    // where their loads sit.
+#ifndef RP_PREFETCH_LATE
     if (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);
+#else
+    rp_load_tile<NV, RP_WG, RP_ROWS, MODE, PACK>(in, tn, tnext, offs, digits, nxt);
+    if (DRAIN) __builtin_amdgcn_s_waitcnt(vmcnt_imm(NLOADS < 63 ? NLOADS : 63));
+#endif
     __syncthreads(); // the staging area is free, the counters are complete
     scan_and_stage();
     staged_len = t.len;
@@ -526,12 +551,17 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
     len = tile_len(tcur);
     cur_start = tile_start(tcur);
     rp_chunk_load<NV, RP_WG, RP_ROWS, PSRC>(key, v0, v1, flt.col, cur_start, len, cur);
+#ifndef RP_PREFETCH_LATE
     __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+    [[maybe_unused]] constexpr int NLOADS = RP_ROWS * (1 + (NV >= 1) + (NV >= 2) + (PSRC == 3)); // loads of one rp_chunk_load per thread
     for (uint32_t ti = t0 + 1; ti < t1; ti++) {
       const uint32_t tnext = min(ti + 1, t1 - 1);
       const uint32_t nlen = tile_len(tnext);
       const int64_t nstart = tile_start(tnext);
+#ifndef RP_PREFETCH_LATE
       rp_chunk_load<NV, RP_WG, RP_ROWS, PSRC>(key, v0, v1, flt.col, nstart, nlen, nxt);
+#endif
       cnt[threadIdx.x] = 0; // (the run starts it held were consumed before scan_and_stage's last barrier)
       __syncthreads();
 #pragma unroll
@@ -541,7 +571,12 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
         if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);
         rank_row(j, len);
       }
-      __builtin_amdgcn_s_waitcnt(0x0F70); // drain this tile's stores (and the prefetch) before the barrier
+#ifndef RP_PREFETCH_LATE
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+#else
+      rp_chunk_load<NV, RP_WG, RP_ROWS, PSRC>(key, v0, v1, flt.col, nstart, nlen, nxt);
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(NLOADS < 63 ? NLOADS : 63));
+#endif
       __syncthreads();
       scan_and_stage();
       staged_len = s_total;
