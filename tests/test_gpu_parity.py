@@ -799,9 +799,9 @@ def test_agg_paths_without_staging():
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         # (a representative cut — multi-batch aggregation, both partition routes, the fused join, Utf8 keys —
                         #  not every aggregation test twice: the driver's GPU suite has a time budget)
-                        "-k", "(mixed_routes or multi_batch or (test_hash_agg_partition_route and not packed_and and not few_groups "
-                              "and not key_skew) or join_agg_fused or join_agg_composed or join_agg_dense or utf8_keys or "
-                              "test_hash_agg_distinct) and not forced and not without"],
+                        "-k", "(mixed_routes or (test_hash_agg_partition_route and not packed_and and not few_groups "
+                              "and not key_skew) or join_agg_fused or join_agg_composed or join_agg_dense or utf8_keys) "
+                              "and not forced and not without"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -1033,8 +1033,8 @@ def test_agg_paths_without_dense_tables():
     env = dict(os.environ, SQLRS_DENSE_AGG="0")
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "((dense_key_route and (count_sum_f64 or min_max_i64)) or join_agg_dense_build_keys or "
-                              "join_agg_probe_keys_outside or join_agg_fused) and not forced and not without"],
+                        "-k", "((dense_key_route and count_sum_f64) or join_agg_dense_build_keys or "
+                              "join_agg_probe_keys_outside) and not forced and not without"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 

@@ -233,13 +233,16 @@ def test_chunked_first_level_forced():
     env = dict(os.environ, SQLRS_RP_CHUNKED="1", SQLRS_STAGE_DIRECT_ROWS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "chunked and not forced and ((count_sum and (val_gt_half or other_ne or key_ge or val_lt_none)) "
-                              "or hot_digit or (hash_agg_chunked and dense))"], env=env, capture_output=True,
+                              "or hot_digit or (hash_agg_chunked and dense) or without_chunk_histograms)"], env=env, capture_output=True,
                        text=True, timeout=1700)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    # the same level with its A/B hook off: level 2 runs its own histogram pass instead of taking the chunk
-    # histograms the first level counted on the way (SQLRS_RP_H2)
-    env["SQLRS_RP_H2"] = "0"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "chunked and not forced and count_sum and val_gt_half"], env=env, capture_output=True,
-                       text=True, timeout=1700)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    # (the same level with SQLRS_RP_H2=0 — level 2 running its own histogram pass — is part of that run:
+    #  test_chunked_level_without_chunk_histograms, the hook is read per call)
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_chunked_level_without_chunk_histograms(hip, oracle, sparse, monkeypatch):
+    """SQLRS_RP_H2=0 (read per call): level 2 runs its own histogram pass instead of taking the chunk histograms the
+    first level counted on the way; only meaningful where the chunked level runs (the forced run, or full-size batches)"""
+    monkeypatch.setenv("SQLRS_RP_H2", "0")
+    test_probe_filter_chunked(hip, oracle, sparse, "val_gt_half", "count_sum")
