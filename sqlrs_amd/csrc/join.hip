@@ -397,8 +397,8 @@ __global__ __launch_bounds__(JD_BLOCK, JD_OCC) void join_probe_dense_kernel(
 // instead (north_star: LDS-staged open addressing for the partitioned hash join):
 //   build  : the build keys hash-partitioned into P = 512 buckets once (partition_rows, (key, build row) per bucket);
 //   probe 1: the probe keys cut into RANGES of 2^15 consecutive rows, every range hash-partitioned into the same
-//            512 buckets by one workgroup (lds_join_partition_kernel: (key, row) per (range, bucket), "slivers" of
-//            ~64 rows);
+//            512 buckets by one workgroup in one pass (lds_join_partition_kernel: (key, row) per (range, bucket),
+//            "slivers" of ~64 rows);
 //   probe 2: one workgroup per (bucket, group of ranges): the bucket's build keys go into an open-addressing table
 //            in LDS (slot claimed with one 32-bit ds CAS on the row word; the keys are unique, so an insert never
 //            compares keys), then every sliver of the bucket is probed there, a wave per sliver, and the build row
@@ -423,64 +423,55 @@ __device__ __forceinline__ uint32_t lj_bucket(uint64_t key, uint32_t P) { // = r
   return (uint32_t)__umul64hi(mix64(key), (uint64_t)P);
 }
 
-// probe 1: one workgroup partitions ONE range of 2^15 consecutive probe rows into the P buckets.
+// probe 1: one workgroup partitions ONE range of 2^15 consecutive probe rows into the P buckets, in one pass.
 // A range's rows occupy exactly rows [range base, + len) of the partitioned order, so nothing depends on another
-// range: no global histogram, no scan (a counting multi-split over all ranges cost hist 0.14 + scan 0.06 + scatter
-// 0.84 ms per 1e8 rows — 12-row runs per (tile, bucket)).  The range's keys (256 KiB) are STREAMED three times, eight
-// loads in flight per lane: (A) from HBM — an LDS atomic per row gives its rank inside its bucket (kept, 16 bits per
-// row); a scan of the P counters gives the bucket starts (also the sliver table the next two kernels read); (B) from
-// L2 — rank -> position inside the range's output; (C) from L2, an eighth of the output at a time — the rows whose
-// position falls into the window are staged in LDS and leave as contiguous stores (12 B per row: key + original row).
-// The first form held all 32 keys of a thread in registers instead: at 1024 threads (128 VGPRs) the compiler spilled
-// 23 of them to scratch right behind their loads — 23 serialised HBM latencies per workgroup, one workgroup per CU,
-// 1.10 ms per 1e8 rows.  This form keeps 32 registers of packed ranks and 48 KiB of staging per 512-thread workgroup:
-// three workgroups per CU overlap their phases.
-constexpr int LP_WG = 512;                // (three workgroups per CU: 24 waves, <= 80 VGPRs, 3 x 52 KiB of LDS)
-constexpr int LP_ROWS = LJ_RANGE / LP_WG; // 64 rows per thread
-constexpr int LP_STAGE = LJ_RANGE / 8;    // rows staged per round (48 KiB)
-constexpr int LP_B = 8;                   // keys in flight per lane
-__global__ __launch_bounds__(LP_WG, 6) void lds_join_partition_kernel(const uint64_t *__restrict__ keys, int64_t n, uint32_t P,
-                                                                      uint64_t *__restrict__ okey, uint32_t *__restrict__ oidx,
-                                                                      uint32_t *__restrict__ pbstart) {
+// range: no global histogram, no scan, no second read of the keys (a counting multi-split over all ranges cost
+// hist 0.14 + scan 0.06 + scatter 0.84 ms per 1e8 rows — 12-row runs per (tile, bucket)).  The 32 keys of a thread
+// stay in registers; an LDS atomic per row gives its rank inside its bucket, a scan of the P counters the bucket
+// starts (also the sliver table the next two kernels read), and the rows leave through an LDS staging area a
+// quarter of the range at a time, so the stores are contiguous (12 B per row: key + original row).
+// 1.10 ms per 1e8 rows — not at bandwidth (2.0 GB): at 1024 threads (128 VGPRs) the compiler spills 23 of the 32 keys
+// right behind their loads, and one workgroup per CU overlaps nothing.  A second form that STREAMS the keys three
+// times instead (ranks, positions, staged output; 512-thread workgroups, 80 VGPRs, three per CU) was built and
+// measured at 1.16 ms: its 64 + 64 + 8 x 64 row steps per thread are a chain of dependent L2 latencies.  (Lesson kept
+// from it: the unrolled phases share their 64 row addresses, which the compiler keeps live from one phase to the next
+// — or hoists out of the staging loop — and spills; an opaque `asm volatile("" : "+v"(tid))` per phase / per group
+// brought 628 bytes of scratch per lane down to 60.)
+constexpr int LP_ROWS = LJ_RANGE / LJ_WG; // 32 rows per thread
+constexpr int LP_STAGE = LJ_RANGE / 4;    // rows staged per round (96 KiB)
+__global__ __launch_bounds__(LJ_WG) void lds_join_partition_kernel(const uint64_t *__restrict__ keys, int64_t n, uint32_t P,
+                                                                   uint64_t *__restrict__ okey, uint32_t *__restrict__ oidx,
+                                                                   uint32_t *__restrict__ pbstart) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lp_smem[];
   uint64_t *skey = (uint64_t *)lp_smem;            // [LP_STAGE]
   uint32_t *sidx = (uint32_t *)(skey + LP_STAGE);  // [LP_STAGE]
-  __shared__ uint32_t cnt[512], start[512];
+  __shared__ uint32_t cnt[512], start[512 + 1];
   __shared__ uint32_t s_wsum[8];
   const int64_t rbase = (int64_t)blockIdx.x * LJ_RANGE;
   const uint32_t len = (uint32_t)min<int64_t>(LJ_RANGE, n - rbase);
-  const uint64_t *__restrict__ kr = keys + rbase;
-  uint32_t rk2[LP_ROWS / 2]; // two 16-bit values per word: a row's rank inside its bucket, later its position in the
-                             // range's output (0xffff = no row)
-  cnt[threadIdx.x] = 0; // (LP_WG = 512 counters)
+  uint64_t k[LP_ROWS];
+  uint32_t rk2[LP_ROWS / 2]; // two 16-bit values per word: the row's rank inside its bucket, then its position inside
+                             // the range's output (0xffff = no row); the bucket is recomputed from the key (registers)
+#pragma unroll
+  for (int j = 0; j < LP_ROWS; j++) // unconditional loads (rows past the end re-read the last row)
+    k[j] = __builtin_nontemporal_load(keys + rbase + min((uint32_t)(j * LJ_WG) + threadIdx.x, len - 1));
+  if (threadIdx.x < 512) cnt[threadIdx.x] = 0;
   __syncthreads();
-  // ---- (A) ranks
-  uint32_t tid_a = threadIdx.x;
 #pragma unroll
-  for (int g = 0; g < LP_ROWS / LP_B; g++) {
-    asm volatile("" : "+v"(tid_a));
-    uint64_t k[LP_B];
-#pragma unroll
-    for (int u = 0; u < LP_B; u++) // unconditional loads (rows past the end re-read the last row)
-      k[u] = __builtin_nontemporal_load(kr + min((uint32_t)((g * LP_B + u) * LP_WG) + tid_a, len - 1));
-#pragma unroll
-    for (int u = 0; u < LP_B; u++) {
-      const int j = g * LP_B + u;
-      uint32_t r = 0xffffu;
-      if ((uint32_t)(j * LP_WG) + tid_a < len) r = atomicAdd(&cnt[lj_bucket(k[u], P)], 1u); // (< 2^15: the range's rows)
-      rk2[j >> 1] = (j & 1) ? (rk2[j >> 1] | (r << 16)) : r;
-    }
-    __builtin_amdgcn_sched_barrier(0); // one group of LP_B rows at a time: the fully unrolled phases otherwise spill
+  for (int j = 0; j < LP_ROWS; j++) {
+    uint32_t r = 0xffffu;
+    if ((uint32_t)(j * LJ_WG) + threadIdx.x < len) r = atomicAdd(&cnt[lj_bucket(k[j], P)], 1u); // (< 2^15: the range's rows)
+    rk2[j >> 1] = (j & 1) ? (rk2[j >> 1] | (r << 16)) : r;
   }
   __syncthreads();
-  { // exclusive scan of the P <= 512 counters (8 waves = the workgroup)
+  if (threadIdx.x < 512) { // exclusive scan of the P <= 512 counters (8 waves)
     const uint32_t c = threadIdx.x < P ? cnt[threadIdx.x] : 0;
     const uint32_t inc = wave_iscan_u32(c);
     if (lane_id() == 63) s_wsum[wave_id()] = inc;
     cnt[threadIdx.x] = inc - c; // (wave-local exclusive prefix)
   }
   __syncthreads();
-  {
+  if (threadIdx.x < 512) {
     uint32_t wb = 0;
     for (int w = 0; w < wave_id(); w++) wb += s_wsum[w];
     const uint32_t st = cnt[threadIdx.x] + wb;
@@ -489,65 +480,30 @@ __global__ __launch_bounds__(LP_WG, 6) void lds_join_partition_kernel(const uint
     if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) pbstart[(size_t)gridDim.x * P] = (uint32_t)n;
   }
   __syncthreads();
-  // ---- (B) rank -> position (the keys come out of L2 / the Infinity Cache now)
-  uint32_t tid_b = threadIdx.x; // (opaque: the 64 clamped row offsets of phase A would otherwise stay live — and spill — until here)
 #pragma unroll
-  for (int g = 0; g < LP_ROWS / LP_B; g++) {
-    asm volatile("" : "+v"(tid_b));
-    uint64_t k[LP_B];
-#pragma unroll
-    for (int u = 0; u < LP_B; u++) k[u] = kr[min((uint32_t)((g * LP_B + u) * LP_WG) + tid_b, len - 1)];
-#pragma unroll
-    for (int u = 0; u < LP_B; u++) {
-      const int j = g * LP_B + u;
-      const uint32_t r = (rk2[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-      const uint32_t pos = r == 0xffffu ? 0xffffu : start[lj_bucket(k[u], P)] + r; // (< 2^15)
-      rk2[j >> 1] = (j & 1) ? ((rk2[j >> 1] & 0xffffu) | (pos << 16)) : ((rk2[j >> 1] & 0xffff0000u) | pos);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  for (int j = 0; j < LP_ROWS; j++) {
+    const uint32_t r = (rk2[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+    const uint32_t pos = r == 0xffffu ? 0xffffu : start[lj_bucket(k[j], P)] + r; // (< 2^15)
+    rk2[j >> 1] = (j & 1) ? ((rk2[j >> 1] & 0xffffu) | (pos << 16)) : ((rk2[j >> 1] & 0xffff0000u) | pos);
   }
-  // ---- (C) the output, an eighth at a time: stage the rows of the window, store them contiguously
   for (uint32_t q0 = 0; q0 < len; q0 += LP_STAGE) { // (uniform trip count)
-    // (the thread id through an opaque asm: otherwise the 64 row addresses of the unrolled body are loop invariants,
-    //  get hoisted out of this loop and spill — 628 bytes of scratch per lane)
-    uint32_t tid = threadIdx.x;
 #pragma unroll
-    for (int g = 0; g < LP_ROWS / LP_B; g++) {
-      asm volatile("" : "+v"(tid)); // (per group: the row addresses of later groups are not computed ahead)
-      uint64_t k[LP_B];
-      uint32_t pw[LP_B / 2]; // (the packed positions through the same kind of barrier: their 64 unpacked halves are loop invariants too)
-#pragma unroll
-      for (int u = 0; u < LP_B / 2; u++) {
-        pw[u] = rk2[g * (LP_B / 2) + u];
-        asm volatile("" : "+v"(pw[u]));
+    for (int j = 0; j < LP_ROWS; j++) {
+      const uint32_t p = ((rk2[j >> 1] >> ((j & 1) * 16)) & 0xffffu) - q0; // (0xffff - q0 stays >= LP_STAGE)
+      if (p < (uint32_t)LP_STAGE) {
+        skey[p] = k[j];
+        sidx[p] = (uint32_t)rbase + (uint32_t)(j * LJ_WG) + threadIdx.x;
       }
-#pragma unroll
-      for (int u = 0; u < LP_B; u++) {
-        const int j = g * LP_B + u;
-        const uint32_t p = ((pw[u >> 1] >> ((u & 1) * 16)) & 0xffffu) - q0; // (0xffff - q0 stays >= LP_STAGE)
-        k[u] = p < (uint32_t)LP_STAGE ? kr[(uint32_t)(j * LP_WG) + tid] : 0; // (only the window's rows are fetched)
-      }
-#pragma unroll
-      for (int u = 0; u < LP_B; u++) {
-        const int j = g * LP_B + u;
-        const uint32_t p = ((pw[u >> 1] >> ((u & 1) * 16)) & 0xffffu) - q0;
-        if (p < (uint32_t)LP_STAGE) {
-          skey[p] = k[u];
-          sidx[p] = (uint32_t)rbase + (uint32_t)(j * LP_WG) + tid;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     const uint32_t m = min((uint32_t)LP_STAGE, len - q0);
-    for (uint32_t p = threadIdx.x; p < m; p += LP_WG) {
+    for (uint32_t p = threadIdx.x; p < m; p += LJ_WG) {
       __builtin_nontemporal_store(skey[p], okey + rbase + q0 + p);
       __builtin_nontemporal_store(sidx[p], oidx + rbase + q0 + p);
     }
     __syncthreads();
   }
 }
-
 __global__ __launch_bounds__(LJ_WG) void lds_join_probe_kernel(
     const uint64_t *__restrict__ bkey, const uint32_t *__restrict__ brow, const uint32_t *__restrict__ bbstart,
     const uint64_t *__restrict__ pkey, const uint32_t *__restrict__ pbstart, uint32_t pn, uint32_t P, uint32_t nranges,
@@ -1082,7 +1038,7 @@ static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
   {
     ProfScope ps(ctx, "join_partition_lds");
     allow_big_lds(ctx, lds_join_partition_kernel, 112 * 1024);
-    lds_join_partition_kernel<<<dim3(nranges), dim3(LP_WG), (size_t)LP_STAGE * 12, ctx->stream>>>(
+    lds_join_partition_kernel<<<dim3(nranges), dim3(LJ_WG), (size_t)LP_STAGE * 12, ctx->stream>>>(
         pk.keys->as<uint64_t>(), n, P, pkey->as<uint64_t>(), out.idx->as<uint32_t>(), pbstart->as<uint32_t>());
     SQ_HIP(hipGetLastError());
   }
