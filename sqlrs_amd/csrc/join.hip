@@ -487,12 +487,18 @@ __global__ __launch_bounds__(LJ_WG) void lds_join_partition_kernel(const uint64_
     rk2[j >> 1] = (j & 1) ? ((rk2[j >> 1] & 0xffffu) | (pos << 16)) : ((rk2[j >> 1] & 0xffff0000u) | pos);
   }
   for (uint32_t q0 = 0; q0 < len; q0 += LP_STAGE) { // (uniform trip count)
+    // (thread id and packed positions through an opaque asm: the 32 row ids and the 32 unpacked positions of the
+    //  unrolled body are loop invariants otherwise, get hoisted out of this loop and push the keys into scratch)
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int j = 0; j < LP_ROWS; j++) {
-      const uint32_t p = ((rk2[j >> 1] >> ((j & 1) * 16)) & 0xffffu) - q0; // (0xffff - q0 stays >= LP_STAGE)
+      uint32_t w = rk2[j >> 1];
+      asm volatile("" : "+v"(w));
+      const uint32_t p = ((w >> ((j & 1) * 16)) & 0xffffu) - q0; // (0xffff - q0 stays >= LP_STAGE)
       if (p < (uint32_t)LP_STAGE) {
         skey[p] = k[j];
-        sidx[p] = (uint32_t)rbase + (uint32_t)(j * LJ_WG) + threadIdx.x;
+        sidx[p] = (uint32_t)rbase + (uint32_t)(j * LJ_WG) + tid;
       }
     }
     __syncthreads();
