@@ -415,6 +415,10 @@ __global__ __launch_bounds__(JD_BLOCK, JD_OCC) void join_probe_dense_kernel(
 // 256-thread workgroups (12 waves per CU next to three 48 KiB tables) the kernel took 1.9 ms, 1.0 of it without any
 // lookup at all.  16-byte slots {key, build row + 1}: one ds_read_b128 per probe step instead of two dependent reads.
 constexpr int LJ_WG = 1024, LJ_WAVES = LJ_WG / 64, LJ_RANGE_LOG2 = 15, LJ_RANGE = 1 << LJ_RANGE_LOG2;
+#ifndef LJ_Q_N
+#define LJ_Q_N 8
+#endif
+constexpr int LJ_Q = LJ_Q_N; // slivers a wave probes at a time
 struct LjSlot {
   uint64_t key;
   uint32_t row1, pad; // build row + 1, 0 = empty
@@ -552,31 +556,31 @@ __global__ __launch_bounds__(LJ_WG) void lds_join_probe_kernel(
   };
   const int lane = lane_id();
   const uint32_t r1 = min(nranges, (g + 1) * ranges_per_item);
-  // a wave takes four slivers at a time (their first 64 rows: four independent loads in flight per lane);
-  // the few slivers longer than 64 rows finish in the tail loop
-  for (uint32_t r = g * ranges_per_item + 4 * wave_id(); r < r1; r += 4 * LJ_WAVES) {
-    uint32_t lo[4], hi[4];
-    uint64_t k[8];
+  // a wave takes LJ_Q slivers at a time (their first 128 rows: 2 x LJ_Q independent loads in flight per lane);
+  // the few slivers longer than 128 rows finish in the tail loop
+  for (uint32_t r = g * ranges_per_item + LJ_Q * wave_id(); r < r1; r += LJ_Q * LJ_WAVES) {
+    uint32_t lo[LJ_Q], hi[LJ_Q];
+    uint64_t k[2 * LJ_Q];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < LJ_Q; q++) {
       const uint32_t rr = min(r + q, r1 - 1);
       lo[q] = pbstart[(size_t)rr * P + b];
       hi[q] = r + q < r1 ? pbstart[(size_t)rr * P + b + 1] : lo[q];
     }
     // a sliver has 64 rows on average (Poisson: almost half of them have a few more), so its first 128 rows are
-    // loaded at once — a dependent second load per sliver was 4 extra HBM latencies per trip (2.2 -> 0.x ms)
+    // loaded at once — a dependent second load per sliver was 4 extra HBM latencies per trip
 #pragma unroll
-    for (int q = 0; q < 8; q++) { // unconditional loads: lanes past the sliver re-read its first row (or row 0)
+    for (int q = 0; q < 2 * LJ_Q; q++) { // unconditional loads: lanes past the sliver re-read its first row (or row 0)
       const uint32_t i = lo[q >> 1] + (q & 1) * 64 + lane;
       k[q] = __builtin_nontemporal_load(pkey + (i < hi[q >> 1] ? i : min(lo[q >> 1], pn - 1)));
     }
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < 2 * LJ_Q; q++) {
       const uint32_t i = lo[q >> 1] + (q & 1) * 64 + lane;
       if (i < hi[q >> 1]) __builtin_nontemporal_store(lookup(k[q]), mpart + i);
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int q = 0; q < LJ_Q; q++)
       for (uint32_t i = lo[q] + 128 + lane; i < hi[q]; i += 64) mpart[i] = lookup(pkey[i]);
   }
 }

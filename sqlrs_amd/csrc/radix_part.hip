@@ -853,7 +853,10 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // 16 = 8192-row tiles (packed rows with one value column only: 128 KiB of staging, 256 VGPRs, no spills): the
   // default for very large batches — a third fewer barrier rounds per row (C5, one process: level 1 5.50 -> 5.36 ms,
   // level 2 3.66 -> 3.61 ms); smaller batches keep 6144-row tiles (less arena slack, more tiles per workgroup)
-  const bool big16 = pack && nv == 1 && (rows_env == 16 || (rows_env == 0 && n >= (1ll << 28)));
+  // (two-level partitions only — the counting single level is slower with them, C4: 1.55 -> 1.96 ms — and not with the
+  //  predicate on a column of its own: that instantiation needs more than 256 VGPRs and spills)
+  const bool big16 = pack && nv == 1 && (rows_env == 16 || (rows_env == 0 && n >= (1ll << 28) && P_wanted > 512 &&
+                                                          (!in.filter.col || (const void *)in.filter.col == in.vals[0])));
   const int ROWS = nv > 1 ? 8 : (rows_env == 6 ? 6 : ((rows_env == 8 && pack) ? 8 : (big16 ? 16 : 12)));
   const int RP_TILE = WG * ROWS;
   const size_t lds = (size_t)RP_TILE * (pack ? 8 * (1 + nv) : 8 * (1 + nv) + 4 + 2 + 1) + (size_t)WG * (4 + 4 + 8);

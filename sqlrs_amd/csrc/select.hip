@@ -411,12 +411,14 @@ __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_kernel(
 template <class T, bool HASV>
 __device__ __forceinline__ void filter_load_tile(const T *__restrict__ in, const uint64_t *__restrict__ validity,
                                                  int64_t rows, int64_t tile, T (&v)[FILTER_CHUNKS], uint64_t &vw) {
-  const int64_t wrow = tile * FILTER_TILE_ROWS + (int64_t)wave_id() * (FILTER_CHUNKS * 64) + lane_id();
+  uint32_t tid = threadIdx.x; // (opaque per tile, see filter_tile)
+  asm volatile("" : "+v"(tid));
+  const int64_t wrow = tile * FILTER_TILE_ROWS + (int64_t)(tid >> 6) * (FILTER_CHUNKS * 64) + (tid & 63);
 #pragma unroll
   for (int j = 0; j < FILTER_CHUNKS; j++) v[j] = __builtin_nontemporal_load(in + min(wrow + j * 64, rows - 1));
   // the wave's 32 validity words in one coalesced load: lane j holds the word of chunk j
-  const int64_t wword = (tile * FILTER_WAVES + wave_id()) * FILTER_CHUNKS;
-  vw = HASV ? validity[min(wword + (lane_id() & (FILTER_CHUNKS - 1)), ((rows + 63) >> 6) - 1)] : ~0ull;
+  const int64_t wword = (tile * FILTER_WAVES + (int64_t)(tid >> 6)) * FILTER_CHUNKS;
+  vw = HASV ? validity[min(wword + (int64_t)(tid & (FILTER_CHUNKS - 1)), ((rows + 63) >> 6) - 1)] : ~0ull;
 }
 
 template <class T, int OP, bool HASV, class KK>
@@ -424,7 +426,15 @@ __device__ __forceinline__ void filter_tile(const T (&v)[FILTER_CHUNKS], const u
                                             int64_t tile,
                                             T *__restrict__ out, uint64_t *__restrict__ sel_bits,
                                             uint32_t *s_wave, const uint64_t *s_excl) {
-  const int lane = lane_id(), w = wave_id();
+  // The thread id goes through an opaque asm per tile (round 3): values derived from it (lane * 4, the wave's word
+  // base, ...) are loop invariants of the persistent kernel, and with two tiles of 64-bit rows in registers (128 of
+  // the 168 VGPRs three waves per SIMD may use) the compiler SPILLED three of them — and every reload inside the
+  // loop is a scratch load behind the 32 prefetched row loads on the in-order vmcnt: `s_waitcnt vmcnt(0)` in the
+  // middle of the pipeline, i.e. the prefetch was waited for as soon as it was issued.  Recomputing them per tile
+  // costs a few VALU operations and leaves no scratch.
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = (int)(tid & 63), w = (int)(tid >> 6);
   const int64_t nw = (rows + 63) >> 6;
   const int64_t wrow = tile * FILTER_TILE_ROWS + (int64_t)w * (FILTER_CHUNKS * 64) + lane;
   const int64_t wword = (tile * FILTER_WAVES + w) * FILTER_CHUNKS;
