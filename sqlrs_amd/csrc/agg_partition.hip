@@ -643,7 +643,9 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
       const uint32_t id = packed_row(kp, cur.k[u]);
       const uint32_t s = (uint32_t)off & mask;
       bool act = i0 + (int64_t)u * PART_WG < hi;
-      if (JOIN) act = act && off <= kp.range; // outside the build keys' range (or the sentinel): no partner
+      // outside the range of the keys of interest: a probe row without partner (fused join), or a sentinel row of a
+      // claimed partition (radix_part.hip; every real row of a plain aggregation lies inside the range)
+      act = act && off <= kp.range;
       // hot keys: see lds_agg_kernel.  (Repeating the test for the next active lane's slot — up to four rounds per
       // row slot, for buckets with several hot keys — was measured SLOWER on Zipf(1.1) keys, 1.5 -> 1.8 ms for the C4
       // batch: a wave reduction costs more than the ~8-20 serialised LDS atomics it replaces.)
@@ -998,7 +1000,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     // (average over the NON-EMPTY buckets: an optimistically widened key range has empty buckets at both ends, and an
     //  average diluted by them made every real bucket look oversized — C4 bucket pass 0.65 -> 0.87 ms)
     int64_t nonempty_d = 0;
-    for (uint32_t bkt = 0; bkt < P; bkt++) nonempty_d += hb[bkt + 1] > hb[bkt];
+    for (uint32_t bkt = 0; bkt < P; bkt++) nonempty_d += pr.bucket_end(bkt) > hb[bkt];
     const int64_t avg = n / std::max<int64_t>(nonempty_d, 1);
     const char *cd_e = std::getenv("SQLRS_DENSE_CHUNK_DIV"), *sa_e = std::getenv("SQLRS_DENSE_SPLIT_PCT"); // tuning hooks, read per call
     const int cdiv = cd_e ? std::max(1, std::atoi(cd_e)) : 2;        // chunk = average / this
@@ -1013,7 +1015,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     // into chunks of 1/(2 x slots) of the batch; their tables merge through the split tables.
     const uint32_t slots = (lds > 80 * 1024 - 64 ? 1u : 2u) * (uint32_t)ctx->num_cus; // (tables of >= 80 KiB: one workgroup per CU)
     uint32_t nonempty = 0;
-    for (uint32_t bkt = 0; bkt < P; bkt++) nonempty += hb[bkt + 1] > hb[bkt];
+    for (uint32_t bkt = 0; bkt < P; bkt++) nonempty += pr.bucket_end(bkt) > hb[bkt];
     if (nonempty < slots / 2) {
       chunk = (uint32_t)std::max<int64_t>(32768, n / (2 * (int64_t)slots));
       split_above = chunk;
@@ -1024,7 +1026,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   out->may_dup = false;
   uint32_t nsplit = 0, nchunk_tables = 0;
   for (uint32_t bkt = 0; bkt < P; bkt++) {
-    uint32_t lo = hb[bkt], hi = hb[bkt + 1];
+    uint32_t lo = hb[bkt], hi = pr.bucket_end(bkt); // (a claimed partition: slots of the bucket's region, sentinel rows included)
     if (dense && lo == hi) continue; // nothing to set up for an empty bucket (no build keys to insert)
     if (hi - lo <= split_above) {
       work.insert(work.end(), {bkt, lo, hi, 0xffffffffu});

@@ -600,6 +600,274 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
   }
 }
 
+// ------------------------------------------------------------ claimed single level --
+// A ONE-level partition (<= 512 buckets) without a histogram pass, with an optional row filter fused in: what the
+// chunked first level is to two-level partitions.  The counting form reads every key twice (histogram, then
+// scatter) and needs the (tile, digit) count matrix scanned in between (C4, 2e8 rows: 0.26 + 0.15 ms of 2.9).
+//
+// Here every bucket owns a REGION sized from a SAMPLE of the batch (rp_sample_hist_kernel: an eighth of every tile,
+// the predicate applied; rp_region_plan_kernel: estimate x 9/8 + slack, prefix sum -> region starts), and a
+// workgroup appends the rows of digit d to its own open BLOCK of that region — B rows, a power of two: every block
+// starts on a cache-line boundary — taking the next block(s) with one atomic add on the region's cursor when the
+// open one is full (`need` rows -> ceil(need / B) consecutive blocks in one claim, so a tile's run of one digit still
+// has at most two destinations: the rest of the open block, then the new claim).  Per-tile claims of exactly the
+// run's length would need no padding, but every run would then start and end inside a cache line shared with a run
+// of another workgroup — another XCD's L2 — and partial lines are written to HBM from both (the 2.2x write
+// amplification round 1 measured when neighbouring runs did not meet in one L2).
+//
+// What a workgroup leaves unfilled of its last block of every digit is filled with SENTINEL rows (all-ones key|row
+// word = the packed form of "key outside the range", which the bucket pass already skips): bucket b = slots
+// [start[b], cursor[b]) with holes of that kind, about wgs * B / 2 per bucket (B is chosen so that this is ~3 % of
+// the rows).  A region that turns out too small (estimate off: clustered input whose clusters the sample missed)
+// raises a flag and sends the rows of that digit to the sink; the caller then runs the counting level.
+struct ClaimOut {
+  uint64_t *key, *v0;    // column form (REC = false)
+  u64x2 *rec;            // record form
+  uint32_t *cursor;      // [P] next free slot of the bucket's region (starts at the region's first slot)
+  const uint32_t *rend;  // [P] first slot behind the region
+  unsigned int *flag;    // [0] set when a region overflowed
+  unsigned long long *kept; // rows that passed the filter
+  uint32_t B;            // block size in rows (power of two)
+};
+
+// est[d] += rows of digit d among the sampled rows that pass the filter; est[P] += sampled rows
+__global__ __launch_bounds__(256) void rp_sample_hist_kernel(const uint64_t *__restrict__ key, RowFilter flt, int64_t n,
+                                                             uint32_t tile_rows, uint32_t num_tiles, uint32_t P, KeyPack kp,
+                                                             uint32_t *__restrict__ est) {
+  __shared__ uint32_t h[512];
+  __shared__ uint32_t s_seen;
+  for (uint32_t i = threadIdx.x; i < 512; i += 256) h[i] = 0;
+  if (threadIdx.x == 0) s_seen = 0;
+  __syncthreads();
+  const uint32_t S = tile_rows / 8; // sampled rows per tile: the (5 t mod 8)-th eighth of tile t
+  const int64_t total = (int64_t)num_tiles * S;
+  uint32_t seen = 0;
+  constexpr int U = 4;
+  for (int64_t i0 = ((int64_t)blockIdx.x * U) * 256 + threadIdx.x; i0 < total; i0 += (int64_t)gridDim.x * U * 256) {
+    uint64_t k[U], f[U];
+    bool in[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = i0 + (int64_t)u * 256;
+      const uint32_t t = (uint32_t)(i / S), o = (uint32_t)(i % S);
+      const int64_t row = (int64_t)t * tile_rows + (int64_t)((t * 5u) & 7u) * S + o;
+      in[u] = i < total && row < n;
+      const int64_t r = in[u] ? row : 0;
+      k[u] = __builtin_nontemporal_load(key + r);
+      f[u] = flt.col ? __builtin_nontemporal_load(flt.col + r) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!in[u]) continue;
+      seen++;
+      if (flt.col && !row_passes(flt, f[u])) continue;
+      atomicAdd(&h[rp_bucket(kp, packed_clamp(kp, k[u]), true, P)], 1u);
+    }
+  }
+  atomicAdd(&s_seen, seen);
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < P; d += 256)
+    if (h[d]) atomicAdd(&est[d], h[d]);
+  if (threadIdx.x == 0 && s_seen) atomicAdd(&est[P], s_seen);
+}
+
+// regions from the sampled counts: cap[d] = est[d] * n / sampled * 9/8 + slack, rounded up to whole blocks
+__global__ __launch_bounds__(512) void rp_region_plan_kernel(const uint32_t *__restrict__ est, uint32_t P, int64_t n, uint32_t slack,
+                                                             uint32_t B, uint32_t *__restrict__ rstart, uint32_t *__restrict__ rend,
+                                                             uint32_t *__restrict__ cursor) {
+  __shared__ uint32_t s_wsum[8];
+  const uint32_t d = threadIdx.x;
+  const uint32_t seen = est[P];
+  uint32_t cap = 0;
+  if (d < P) {
+    const uint64_t scaled = seen ? (uint64_t)((double)est[d] * (double)n / (double)seen) : 0ull;
+    cap = (uint32_t)((scaled + scaled / 8 + slack + B - 1) & ~(uint64_t)(B - 1));
+  }
+  const uint32_t inc = wave_iscan_u32(cap);
+  if (lane_id() == 63) s_wsum[wave_id()] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave_id(); w++) base += s_wsum[w];
+  const uint32_t start = base + inc - cap;
+  if (d < P) {
+    rstart[d] = start;
+    cursor[d] = start;
+    rend[d] = start + cap;
+  }
+}
+
+template <int NV, int RP_WG, int RP_ROWS, int PSRC, bool REC>
+__global__ __launch_bounds__(RP_WG, 1) void rp_claim_scatter_kernel(
+    const uint64_t *__restrict__ key, const uint64_t *__restrict__ v0, RowFilter flt, int64_t n, ClaimOut out, uint32_t P,
+    uint32_t num_tiles, uint32_t tiles_per_wg, int64_t sink, KeyPack kp) {
+  constexpr uint32_t RP_TILE = RP_WG * RP_ROWS;
+  constexpr int64_t DEAD = -(1ll << 40); // destination base of a digit whose region overflowed: g < 0 -> the sink
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t *skey = (uint64_t *)smem;
+  uint64_t *sv0 = skey + RP_TILE;
+  uint32_t *cnt = (uint32_t *)(sv0 + (NV >= 1 ? RP_TILE : 0)); // [RP_WG]
+  uint32_t *split = cnt + RP_WG;                                // [RP_WG] tile-local position where a digit's run changes block
+  int64_t *gb0 = (int64_t *)(split + RP_WG);                    // [RP_WG] destination of position p: gb0[d] + p below the split,
+  int64_t *gb1 = gb0 + RP_WG;                                   //         gb1[d] + p from it on
+  __shared__ uint32_t s_wsum[RP_WG / 64];
+  __shared__ uint32_t s_total;
+
+  const uint32_t t0 = blockIdx.x * tiles_per_wg;
+  const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
+  // open block of digit threadIdx.x: next free slot, slots left
+  const bool owner = threadIdx.x < P;
+  uint32_t pos = 0, room = 0;
+  bool dead = false;
+  const uint32_t my_end = owner ? out.rend[threadIdx.x] : 0u;
+  const uint32_t Bm1 = out.B - 1;
+  unsigned long long kept = 0;
+  auto tile_start = [&](uint32_t t) { return (int64_t)t * RP_TILE; };
+  auto tile_len = [&](uint32_t t) { return (uint32_t)min((int64_t)RP_TILE, n - (int64_t)t * RP_TILE); };
+
+  ChunkRegs<NV, RP_ROWS, PSRC> cur, nxt;
+  uint32_t dg[RP_ROWS], rk[RP_ROWS];
+  int64_t cur_start = 0;
+  auto rank_row = [&](int j, uint32_t len) {
+    dg[j] = 0xffffffffu;
+    bool keep = (uint32_t)(j * RP_WG) + threadIdx.x < len;
+    if (PSRC == 1) keep = keep && row_passes(flt, cur.a0[NV >= 1 ? j : 0]);
+    if (PSRC == 3) keep = keep && row_passes(flt, cur.pv[PSRC == 3 ? j : 0]);
+    if (keep) {
+      dg[j] = rp_bucket(kp, packed_clamp(kp, cur.k[j]), true, P);
+      rk[j] = atomicAdd(&cnt[dg[j]], 1u);
+    }
+  };
+  auto scan_and_stage = [&]() {
+    const uint32_t c = cnt[threadIdx.x];
+    // the claim first: its answer is needed only behind the staging loop
+    const uint32_t used = min(c, room), need = c - used;
+    const bool claim = owner && need > 0;
+    const uint32_t k = (need + Bm1) & ~Bm1;
+    uint32_t got = 0;
+    if (claim && !dead) got = atomicAdd(&out.cursor[threadIdx.x], k);
+    const uint32_t inc = wave_iscan_u32(c);
+    if (lane_id() == 63) s_wsum[wave_id()] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (int w = 0; w < RP_WG / 64; w++) {
+      if (w < wave_id()) wbase += s_wsum[w];
+      tot += s_wsum[w];
+    }
+    const uint32_t ls = wbase + inc - c;
+    if (threadIdx.x == 0) {
+      s_total = tot;
+      kept += tot;
+    }
+    cnt[threadIdx.x] = ls; // run start (rank_row's counters are consumed)
+    split[threadIdx.x] = ls + used;
+    gb0[threadIdx.x] = (int64_t)pos - (int64_t)ls;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      if (dg[j] == 0xffffffffu) continue;
+      const uint32_t p = cnt[dg[j]] + rk[j];
+      const uint32_t row = (uint32_t)(cur_start + (uint32_t)(j * RP_WG) + threadIdx.x);
+      skey[p] = pack_key_row(kp, cur.k[j], row);
+      if (NV >= 1) sv0[p] = cur.a0[j];
+    }
+    int64_t g1 = 0;
+    if (claim) {
+      if (!dead && (uint64_t)got + k > (uint64_t)my_end) {
+        dead = true;
+        *out.flag = 1u;
+      }
+      if (dead) {
+        g1 = DEAD;
+        pos = 0;
+        room = 0;
+      } else {
+        g1 = (int64_t)got - (int64_t)(ls + used);
+        pos = got + need;
+        room = k - need;
+      }
+    } else {
+      pos += c;
+      room -= c;
+    }
+    gb1[threadIdx.x] = g1;
+    __syncthreads();
+  };
+  auto store_row = [&](int j, uint32_t len) { // position p of the staged tile -> its block
+    const uint32_t p = j * RP_WG + threadIdx.x;
+    const uint64_t kw = skey[p];
+    const uint32_t d = rp_bucket(kp, packed_key(kp, kw), true, P) & (RP_WG - 1);
+    int64_t g = (p < split[d] ? gb0[d] : gb1[d]) + p;
+    if (p >= len || g < 0) g = sink + (int64_t)blockIdx.x * RP_WG + threadIdx.x; // past the staged rows / overflowed region: sink rows
+    if (REC) {
+      u64x2 rec;
+      rec.x = kw;
+      rec.y = sv0[NV >= 1 ? p : 0];
+      out.rec[g] = rec;
+      return;
+    }
+    out.key[g] = kw;
+    if (NV >= 1) out.v0[g] = sv0[p];
+  };
+
+  if (t0 < t1) {
+    // the software pipeline of rp_chunk_scatter_kernel: while tile i-1 (staged, sorted) is written out, tile i
+    // (in `cur`) is ranked and tile i+1 is in flight into `nxt`
+    uint32_t len = tile_len(t0);
+    cur_start = tile_start(t0);
+    rp_chunk_load<NV, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, cur_start, len, cur);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) rank_row(j, len);
+    __syncthreads();
+    scan_and_stage();
+    uint32_t staged_len = s_total;
+    uint32_t tcur = min(t0 + 1, t1 - 1);
+    len = tile_len(tcur);
+    cur_start = tile_start(tcur);
+    rp_chunk_load<NV, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, cur_start, len, cur);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (uint32_t ti = t0 + 1; ti < t1; ti++) {
+      const uint32_t tnext = min(ti + 1, t1 - 1);
+      const uint32_t nlen = tile_len(tnext);
+      const int64_t nstart = tile_start(tnext);
+      rp_chunk_load<NV, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, nstart, nlen, nxt);
+      cnt[threadIdx.x] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RP_ROWS; j++) {
+        if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);
+        rank_row(j, len);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      scan_and_stage();
+      staged_len = s_total;
+      cur = nxt;
+      len = nlen;
+      cur_start = nstart;
+    }
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++)
+      if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);
+  }
+  // what is left of every open block: sentinel rows
+  if (owner && !dead) {
+    for (uint32_t i = 0; i < room; i++) {
+      if (REC) {
+        u64x2 rec;
+        rec.x = ~0ull;
+        rec.y = 0;
+        out.rec[pos + i] = rec;
+      } else {
+        out.key[pos + i] = ~0ull;
+      }
+    }
+  }
+  if (threadIdx.x == 0 && kept) atomicAdd(out.kept, kept);
+}
+
 // Tile list of level 2 from the chunk table: chunk c of digit s contributes ceil(len / tile) tiles to
 // segment s (any order of the chunks inside a segment).  Three small launches (count per digit -> prefix
 // over <= 512 digits -> assign), <= a few hundred thousand chunks; a single workgroup doing all three took
@@ -810,6 +1078,7 @@ void upload_level(Ctx *ctx, Level &L) {
 bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, PartitionedRows *out) {
   const int64_t n = in.n;
   if (n <= 0 || n > 0xffffffffll || in.nv > 2) return false;
+  out->bend_host.clear();
   // digits per level: one level up to 256 buckets, else P = d1 * 2^p2_bits
   uint32_t p2_bits = 0, d1 = std::max(1u, P_wanted);
   if (P_wanted > 512) { // one level handles up to 512 digits (runs of >= 8 rows per tile)
@@ -990,6 +1259,99 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     ctx->sync();
     return bs;
   };
+
+  // ---- claimed single level (no histogram pass, optional fused row filter): one-level range partitions of packed
+  // rows; see rp_claim_scatter_kernel.  Hashed buckets keep the counting level (their bucket pass takes a sentinel
+  // row for a key of its own).
+  const char *claim_e = std::getenv("SQLRS_RP_CLAIM"); // test / tuning hook, read per call: 0 = never, 1 = whatever the batch size
+  const int claim_env = claim_e ? std::atoi(claim_e) : -1;
+  const bool claimable = p2_bits == 0 && pack && kp.dense && nv <= 1 && ROWS == 12 && P <= (uint32_t)WG && P >= 2 &&
+                         claim_env != 0 && (claim_env == 1 || n >= (1ll << 22));
+  if (claimable) {
+    const uint32_t tiles1c = (uint32_t)ceil_div(n, RP_TILE);
+    uint32_t wgs = std::min<uint32_t>(tiles1c, (uint32_t)ctx->num_cus);
+    const uint32_t tpw = (uint32_t)ceil_div(tiles1c, std::max(wgs, 1u));
+    wgs = (uint32_t)ceil_div(tiles1c, std::max(tpw, 1u));
+    // block size: the holes (about wgs * B / 2 per bucket) stay near 3 % of the rows; >= 16 rows = 256 bytes
+    uint32_t B = 16;
+    while (B < 256 && (uint64_t)(2 * B) * 16 * wgs * P <= (uint64_t)n) B *= 2;
+    const uint32_t slack = 4096 + wgs * B;
+    const uint64_t slots_max = (uint64_t)n + (uint64_t)n / 8 + (uint64_t)P * ((uint64_t)slack + B) + 64;
+    const uint64_t pool_rows = slots_max + (uint64_t)WG * wgs; // + one sink per workgroup
+    if (pool_rows <= 0xffffffffull) {
+      BufP est = ctx->alloc_zero(4 * ((size_t)P + 1));
+      BufP plan = ctx->alloc(4 * 3 * (size_t)P); // region start | region end | cursor
+      BufP cst = ctx->alloc_zero(16);            // {kept rows (u64), overflow flag}
+      uint32_t *rstart = plan->as<uint32_t>(), *rend = rstart + P, *cursor = rend + P;
+      {
+        ProfScope ps(ctx, "rp_sample_hist");
+        const int64_t samples = (int64_t)tiles1c * (RP_TILE / 8);
+        const unsigned sblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(samples, 256 * 4 * 2), 4096));
+        rp_sample_hist_kernel<<<dim3(sblocks), dim3(256), 0, ctx->stream>>>(in.keys, in.filter, n, (uint32_t)RP_TILE, tiles1c, P, kp,
+                                                                           est->as<uint32_t>());
+        rp_region_plan_kernel<<<dim3(1), dim3(512), 0, ctx->stream>>>(est->as<uint32_t>(), P, n, slack, B, rstart, rend, cursor);
+        SQ_HIP(hipGetLastError());
+      }
+      Cols cc;
+      if (use_rec) cc.rec = ctx->alloc(16 * (size_t)pool_rows);
+      else {
+        cc.k = ctx->alloc(8 * (size_t)pool_rows);
+        cc.v0 = nv >= 1 ? ctx->alloc(8 * (size_t)pool_rows) : nullptr;
+      }
+      ClaimOut co;
+      co.key = cc.k ? cc.k->as<uint64_t>() : nullptr;
+      co.v0 = cc.v0 ? cc.v0->as<uint64_t>() : nullptr;
+      co.rec = cc.rec ? (u64x2 *)cc.rec->p : nullptr;
+      co.cursor = cursor;
+      co.rend = rend;
+      co.kept = cst->as<unsigned long long>();
+      co.flag = (unsigned int *)(cst->as<uint64_t>() + 1);
+      co.B = B;
+      const int psrc = !in.filter.col ? -1 : ((nv >= 1 && (const void *)in.filter.col == in.vals[0]) ? 1 : 3);
+      const size_t clds = (size_t)RP_TILE * 8 * (1 + nv) + (size_t)WG * (4 + 4 + 8 + 8);
+      {
+        ProfScope ps(ctx, in.filter.col ? "rp_claim_scatter_filter" : "rp_claim_scatter");
+        const uint64_t *k = in.keys, *a0 = (const uint64_t *)in.vals[0];
+        const int64_t sink = (int64_t)slots_max;
+#define SQ_CL1(NV, PS, RC)                                                                                          \
+  do {                                                                                                              \
+    auto kfn = rp_claim_scatter_kernel<NV, 512, 12, PS, RC>;                                                        \
+    allow_big_lds(ctx, kfn);                                                                                        \
+    kfn<<<dim3(wgs), dim3(512), clds, ctx->stream>>>(k, a0, in.filter, n, co, P, tiles1c, tpw, sink, kp);           \
+  } while (0)
+#define SQ_CL(NV, RC)                                                                                               \
+  do {                                                                                                              \
+    if (psrc < 0) SQ_CL1(NV, -1, RC);                                                                               \
+    else if (psrc == 1 && NV >= 1) SQ_CL1(NV, (NV >= 1 ? 1 : 3), RC);                                               \
+    else SQ_CL1(NV, 3, RC);                                                                                         \
+  } while (0)
+        if (nv == 0) SQ_CL(0, false);
+        else if (use_rec) SQ_CL(1, true);
+        else SQ_CL(1, false);
+#undef SQ_CL
+#undef SQ_CL1
+        SQ_HIP(hipGetLastError());
+      }
+      // one round trip: region starts, cursors (= region fill) and the two counters
+      std::vector<uint32_t> hp(3 * (size_t)P);
+      uint64_t hc[2];
+      SQ_HIP(hipMemcpyAsync(hp.data(), plan->p, 4 * 3 * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
+      SQ_HIP(hipMemcpyAsync(hc, cst->p, 16, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();
+      if (!(uint32_t)hc[1]) {
+        out->n = (int64_t)hc[0];
+        out->P = P;
+        publish(cc);
+        out->bstart = plan; // (region starts; device consumers of contiguous buckets never see a claimed partition)
+        out->bstart_host.assign(hp.begin(), hp.begin() + P);
+        out->bstart_host.push_back((uint32_t)slots_max);
+        out->bend_host.assign(hp.begin() + 2 * (size_t)P, hp.begin() + 3 * (size_t)P);
+        return true;
+      }
+      // a region overflowed (the sample misjudged a bucket): the counting level below redoes the batch
+    }
+  }
+  if (in.filter.col && p2_bits == 0) return false; // a single level evaluates a row filter only in its claimed form
 
   // ---- chunked first level (no histogram pass, optional fused row filter): two-level partitions of
   // batches large enough that the slack of the arenas (workgroups x (digits + 1) chunks) is a fraction of the input

@@ -29,7 +29,9 @@ struct KeyPack {
 #if defined(__HIPCC__)
 __device__ __forceinline__ uint64_t pack_key_row(const KeyPack &kp, uint64_t key, uint32_t row) {
   uint64_t off = key - kp.kmin;
-  if (kp.oob && off >= kp.kmask) *kp.oob = 1u; // (uniform null test; a plain store, any number of writers)
+  // (uniform null test; a plain store, any number of writers.  Range partitions: an offset between the range and
+  //  the sentinel has no bucket of its own either — it would alias a slot of the last bucket)
+  if (kp.oob && (off >= kp.kmask || (kp.dense && off > kp.range))) *kp.oob = 1u;
   return (off < kp.kmask ? off : kp.kmask) | ((uint64_t)row << kp.kbits);
 }
 __device__ __forceinline__ uint64_t packed_key(const KeyPack &kp, uint64_t w) { return (w & kp.kmask) + kp.kmin; }
@@ -93,6 +95,11 @@ struct PartitionedRows {
   BufP rec;    // packed dense partitions with one value column: {key|row word, value} records; key / v0 are null then
   BufP bstart; // u32[P + 1]
   std::vector<uint32_t> bstart_host; // the same on the host
+  // Claimed single level (radix_part.hip): bucket b = SLOTS [bstart_host[b], bend_host[b]) of its own region — rows
+  // and sentinel rows (all-ones key|row word: a key outside the packed range, skipped by the bucket pass); the
+  // regions are not adjacent.  Empty = the buckets are contiguous runs of rows (bucket b ends where b + 1 starts).
+  std::vector<uint32_t> bend_host;
+  uint32_t bucket_end(uint32_t b) const { return bend_host.empty() ? bstart_host[b + 1] : bend_host[b]; }
   KeyPack pack; // kbits != 0: `key` holds packed (key, row) words and `idx` is null
 };
 

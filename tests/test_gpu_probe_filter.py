@@ -180,7 +180,7 @@ def test_hash_agg_chunked(hip, oracle, keys):
     assert_same(got, exp, float_cols={2})
 
 
-@pytest.mark.parametrize("outliers", ["none", "unsampled_chunk", "last_chunk"])
+@pytest.mark.parametrize("outliers", ["none", "unsampled_chunk", "just_outside", "last_chunk"])
 def test_hash_agg_optimistic_key_range(hip, outliers):
     """Large batches take their key statistics from a block SAMPLE (every eighth 6144-row chunk + the first and the
     last): the rows are packed with the widened sampled range, and a key outside it — here 1e12 among keys below 5e4,
@@ -192,6 +192,11 @@ def test_hash_agg_optimistic_key_range(hip, outliers):
     if outliers == "unsampled_chunk":
         k[3 * 6144 + 17] = 10**12      # chunk 3: not a multiple of 8
         k[5 * 6144 + 4000] = -(10**12)
+    elif outliers == "just_outside":
+        # beyond the widened sampled range [-65536, 5e4 + 65536) but below the next power of two (the packed word's
+        # sentinel offset 2^18 - 1): representable, yet no bucket of the range partition holds it
+        k[3 * 6144 + 17] = 150_000
+        k[11 * 6144 + 1] = 150_001
     elif outliers == "last_chunk":
         k[n - 5] = 10**12              # the last chunk is always sampled: the range simply becomes wide (no dense tables)
     v = rng.random(n)
@@ -246,3 +251,68 @@ def test_chunked_level_without_chunk_histograms(hip, oracle, sparse, monkeypatch
     first level counted on the way; only meaningful where the chunked level runs (the forced run, or full-size batches)"""
     monkeypatch.setenv("SQLRS_RP_H2", "0")
     test_probe_filter_chunked(hip, oracle, sparse, "val_gt_half", "count_sum")
+
+
+def _claimed_case(hip, oracle, k, v, expect_claimed, aggs=None):
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"])
+    aggs = aggs or [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64)]
+    hip.profile(True)
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
+    assert_same(got, exp, float_cols={i + 1 for i, a in enumerate(aggs) if a.return_type == abi.FLOAT64})
+    claimed = prof.get("rp_claim_scatter", (0, 0))[1] > 0
+    counted = prof.get("rp_scatter", (0, 0))[1] > 0
+    assert claimed, prof
+    assert counted == (not expect_claimed), prof  # an overflowed region: the counting level redoes the batch
+
+
+@pytest.mark.parametrize("shape", ["uniform", "zipf", "few_rows_per_bucket", "one_hot_bucket"])
+def test_hash_agg_claimed_single_level(hip, oracle, shape, monkeypatch):
+    """One-level range partitions without a histogram pass (rp_claim_scatter_kernel): bucket regions sized from a
+    sample, blocks claimed with one atomic per (workgroup, digit, block), sentinel rows in what is left of a block.
+    Forced at test size (SQLRS_RP_CLAIM=1, read per call); against the oracle, groups in first-seen order."""
+    monkeypatch.setenv("SQLRS_RP_CLAIM", "1")
+    rng = np.random.default_rng(len(shape))
+    n, G = 3_000_000, 400_000
+    if shape == "uniform":
+        k = rng.integers(0, G, n, dtype=np.int64)
+    elif shape == "zipf":
+        k = (np.minimum(rng.zipf(1.2, n), G) - 1).astype(np.int64)
+        k = (k * 7919 + 13) % G
+    elif shape == "few_rows_per_bucket":
+        n, G = 2_200_000, 2_000_000  # 489 buckets, ~17 rows per (workgroup, bucket): 16-row blocks
+        k = rng.integers(0, G, n, dtype=np.int64)
+    else:  # nine rows in ten fall into the key range of one bucket: its region takes most of the batch
+        k = np.where(rng.random(n) < 0.9, rng.integers(200_000, 203_000, n), rng.integers(0, G, n)).astype(np.int64)
+    _claimed_case(hip, oracle, k, rng.random(n), expect_claimed=True)
+
+
+def test_hash_agg_claimed_level_natural_size(hip, oracle):
+    """>= 2^22 rows take the claimed level on their own (no hook); MIN / MAX over an int64 column"""
+    rng = np.random.default_rng(77)
+    n, G = (1 << 22) + 4321, 600_000
+    k = rng.integers(-300_000, G - 300_000, n, dtype=np.int64)
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(rng.integers(-10**9, 10**9, n, dtype=np.int64))], names=["k", "v"])
+    aggs = [AggFunc("min", InputRef(1), abi.INT64), AggFunc("max", InputRef(1), abi.INT64)]
+    hip.profile(True)
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    assert prof.get("rp_claim_scatter", (0, 0))[1] > 0, prof
+    assert_same(got, rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute()))
+
+
+def test_hash_agg_claimed_level_overflow_falls_back(hip, oracle, monkeypatch):
+    """The sample reads the (5 t mod 8)-th eighth of tile t.  Here exactly those rows carry keys of the lower half of
+    the range and every other row a key of the upper half: the regions of the upper buckets get the minimum size,
+    overflow, and the counting level must redo the batch (same result, both scatter kernels in the profile)."""
+    monkeypatch.setenv("SQLRS_RP_CLAIM", "1")
+    rng = np.random.default_rng(5)
+    n, G, tile = 3_000_000, 400_000, 6144
+    r = np.arange(n)
+    t, o = r // tile, r % tile
+    sampled = (o // (tile // 8)) == ((t * 5) % 8)
+    k = np.where(sampled, rng.integers(0, G // 2, n), rng.integers(G // 2, G, n)).astype(np.int64)
+    _claimed_case(hip, oracle, k, rng.random(n), expect_claimed=False)
