@@ -125,7 +125,15 @@ impl HipHashJoinExecutor {
 }
 
 // ----------------------------------------------------------------- HashAgg --
-pub struct HipHashAggExecutor { pub ctx: Arc<HipCtx>, pub agg_funcs: Vec<BoundExpr>, pub group_by: Vec<BoundExpr>, pub child: BoxedExecutor }
+pub struct HipHashAggExecutor {
+    pub ctx: Arc<HipCtx>,
+    pub agg_funcs: Vec<BoundExpr>,
+    pub group_by: Vec<BoundExpr>,
+    pub child: BoxedExecutor, // the Filter's child when `child_filter` is set
+    /// FilterExecutor{expr, child} directly below the operator (filter.rs:7-25): handed to the library, which evaluates
+    /// `column OP constant` inside its first partition pass and runs the Filter operator itself otherwise
+    pub child_filter: Option<BoundExpr>,
+}
 fn agg_funcs_of(exprs: &[BoundExpr]) -> Vec<BoundAggFunc> {
     exprs.iter().filter_map(|e| if let BoundExpr::AggFunc(a) = e { Some(a.clone()) } else { None }).collect() // hash_agg.rs:58-63
 }
@@ -138,6 +146,10 @@ impl HipHashAggExecutor {
         let mut a = std::ptr::null_mut();
         self.ctx.check(unsafe { sqlrs_hash_agg_create(self.ctx.raw(), ge.len() as i32, ge.as_ptr(), af.len() as i32, af.as_ptr(), &mut a) })?;
         let _g = Guard(a, sqlrs_hash_agg_destroy);
+        if let Some(p) = &self.child_filter {
+            let low = lower(p)?;
+            self.ctx.check(unsafe { sqlrs_hash_agg_set_filter(a, &low.abi()) })?; // (the library copies the expression)
+        }
         let mut schema = None;
         #[for_await]
         for batch in self.child { // hash_agg.rs:44-122
@@ -322,7 +334,8 @@ impl ExecutorBuilder {
             join_output_schema: plan.join_output_columns(),
         }.execute())
     }
-    /// HashAgg, with the one peephole that reaches the fused operator from a reference-shaped plan
+    /// HashAgg, with the two peepholes that reach the fused forms from a reference-shaped plan:
+    /// HashAgg(HashJoin[Inner](l, Filter?(r))) -> sqlrs_join_agg_*, HashAgg(Filter(c)) -> sqlrs_hash_agg_set_filter
     pub fn hip_visit_physical_hash_agg(&mut self, plan: &PhysicalHashAgg) -> Option<BoxedExecutor> {
         let child: PlanRef = plan.children().first().unwrap().clone();
         if let Some(join) = child.as_physical_hash_join() {
@@ -344,7 +357,11 @@ impl ExecutorBuilder {
                 }.execute());
             }
         }
-        Some(HipHashAggExecutor { ctx: self.hip.clone(), agg_funcs: plan.logical().agg_funcs(), group_by: plan.logical().group_by(), child: self.visit(child).unwrap() }.execute())
+        let (child, child_filter) = match child.as_physical_filter() {
+            Some(f) => (self.visit(f.children().first().unwrap().clone()).unwrap(), Some(f.logical().expr())),
+            None => (self.visit(child).unwrap(), None),
+        };
+        Some(HipHashAggExecutor { ctx: self.hip.clone(), agg_funcs: plan.logical().agg_funcs(), group_by: plan.logical().group_by(), child, child_filter }.execute())
     }
     pub fn hip_visit_physical_order(&mut self, plan: &PhysicalOrder) -> Option<BoxedExecutor> {
         Some(HipOrderExecutor { ctx: self.hip.clone(), order_by: plan.logical().order_by(), child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())

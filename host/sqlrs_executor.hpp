@@ -429,10 +429,15 @@ struct HashAggExecutor { // hash_agg.rs:15-19
   std::vector<BoundExpr> group_by;
   BoxedExecutor child;
   std::vector<std::string> output_names; // eval_field names, e.g. "a", "Sum(b)" (evaluator.rs:30-64)
+  // FilterExecutor{expr = child_filter, child} directly below the operator (filter.rs:7-25), handed to the library
+  // (sqlrs_hash_agg_set_filter): same result as wrapping `child` in a FilterExecutor
+  std::optional<BoundExpr> child_filter;
+  int64_t *filter_fused_batches = nullptr; // out (optional): batches whose filter ran inside the first partition pass
 
   BoxedExecutor execute() {
     struct S : Executor {
       HipCtxRef ctx; BoxedExecutor child; sqlrs_hash_agg_t *a = nullptr; std::vector<std::string> names; bool done = false;
+      int64_t *ffused = nullptr;
       ~S() override { if (a) sqlrs_hash_agg_destroy(a); }
       std::optional<RecordBatch> next() override {
         if (done) return std::nullopt;
@@ -440,6 +445,7 @@ struct HashAggExecutor { // hash_agg.rs:15-19
         while (auto b = child->next()) { detail::AbiBatch in(*b); ctx->check(sqlrs_hash_agg_push(a, &in.b)); } // :44-122
         sqlrs_batch_t *out = nullptr;
         ctx->check(sqlrs_hash_agg_finish(a, SQLRS_MEM_HOST, &out)); // :124-149
+        if (ffused) *ffused = sqlrs_hash_agg_filter_fused_batches(a);
         RecordBatch rb = detail::import_batch(out, nullptr);
         auto sch = std::make_shared<Schema>(*rb.schema);
         for (size_t i = 0; i < sch->size() && i < names.size(); i++) (*sch)[i].name = names[i];
@@ -458,6 +464,12 @@ struct HashAggExecutor { // hash_agg.rs:15-19
     for (size_t i = 0; i < agg_funcs.size(); i++)
       af.push_back(sqlrs_agg_func_t{(int32_t)agg_funcs[i].func, agg_funcs[i].distinct, (int32_t)agg_funcs[i].return_type, 0, al[i].abi()});
     ctx->check(sqlrs_hash_agg_create(ctx->raw, (int)ge.size(), ge.data(), (int)af.size(), af.data(), &s->a));
+    if (child_filter) {
+      detail::Lowered low = detail::lower(*child_filter);
+      sqlrs_expr_t fe = low.abi();
+      ctx->check(sqlrs_hash_agg_set_filter(s->a, &fe)); // (the library copies the expression)
+    }
+    s->ffused = filter_fused_batches;
     return s;
   }
 };
@@ -713,14 +725,18 @@ struct PlanNode {
 };
 
 // ExecutorBuilder (src/executor/mod.rs:36-56, PlanVisitor impl :87-200): one visit_physical_* per node, each
-// instantiating the operator struct exactly as the reference does — plus ONE peephole in visit_physical_hash_agg:
+// instantiating the operator struct exactly as the reference does — plus TWO peepholes in visit_physical_hash_agg:
 //
 //   PhysicalHashAgg(PhysicalHashJoin[Inner, no join filter](l, PhysicalFilter?(r)))
 //        -> HashJoinAggExecutor{.., probe_filter = the Filter's expr}     (sqlrs_join_agg_* + set_probe_filter)
 //
+//   PhysicalHashAgg(PhysicalFilter(child))
+//        -> HashAggExecutor{.., child_filter = the Filter's expr}         (sqlrs_hash_agg_set_filter)
+//
 // which is how the bench's headline plan is reached from a reference-shaped plan tree.  The library decides at
-// run time whether its fused route applies (unique build keys, group key = join key, probe-side arguments) and
-// composes the operators itself otherwise, so the rewrite is safe for every plan of that shape.
+// run time whether its fused route applies (unique build keys, group key = join key, probe-side arguments; a
+// predicate the first partition pass can evaluate) and composes the operators itself otherwise, so the rewrites
+// are safe for every plan of those shapes.
 struct ExecutorBuilder {
   HipCtxRef ctx;
   bool fuse_join_agg = true; // false = one executor per node, as the reference builds them
@@ -794,7 +810,15 @@ struct ExecutorBuilder {
       return ex.execute();
     }
     HashAggExecutor ex;
-    ex.ctx = ctx; ex.agg_funcs = plan.agg_funcs; ex.group_by = plan.group_by; ex.child = visit(child); ex.output_names = plan.output_names;
+    ex.ctx = ctx; ex.agg_funcs = plan.agg_funcs; ex.group_by = plan.group_by; ex.output_names = plan.output_names;
+    if (fuse_join_agg && child->kind == PlanNode::PhysicalFilter) { // FilterExecutor directly below: handed to the operator
+      ex.child_filter = child->expr;
+      ex.child = visit(child->children().front());
+      ex.filter_fused_batches = &last_filter_fused_batches;
+      rewrites++;
+    } else {
+      ex.child = visit(child);
+    }
     return ex.execute();
   }
   BoxedExecutor visit_physical_limit(const PlanNode &plan) { // mod.rs:176-187

@@ -370,6 +370,26 @@ int main() {
                                                          (long long)a[0].num_rows(), (long long)f2b.last_fused_batches);
     else { failures++; std::printf("FAIL builder: large plan (same %d, fused batches %lld)\n", (int)same, (long long)f2b.last_fused_batches); }
   }
+  { // PhysicalHashAgg(PhysicalFilter(scan)): select k, count(v), sum(v) from f where v > 5 group by k
+    auto fsch = std::make_shared<Schema>(Schema{{"k", DataType::Int64, false}, {"v", DataType::Int64, false}});
+    auto make_plan = [&](const std::vector<RecordBatch> &fact) {
+      PlanRef flt = PlanNode::filter(BoundExpr::binary_op(BinaryOperator::Gt, build_bound_input_ref(1), BoundExpr::constant(ScalarValue::Int64(5))),
+                                     PlanNode::table_scan(fact));
+      return PlanNode::hash_agg({BoundAggFunc{AggFunc::Count, {build_bound_input_ref(1)}, DataType::Int64, false},
+                                 BoundAggFunc{AggFunc::Sum, {build_bound_input_ref(1)}, DataType::Int64, false}},
+                                {build_bound_input_ref(0)}, flt, {"k", "Count(v)", "Sum(v)"});
+    };
+    RecordBatch f1 = RecordBatch::try_new(fsch, {Int64Array({2, 1, 2, 7, 3}), Int64Array({10, 6, 4, 8, 9})});
+    RecordBatch f2 = RecordBatch::try_new(fsch, {Int64Array({1, 2, 3, 3}), Int64Array({5, 7, 6, 20})});
+    const std::vector<std::string> expected = {"+---+----------+--------+", "| k | Count(v) | Sum(v) |", "+---+----------+--------+",
+                                               "| 2 | 2        | 17     |", "| 1 | 1        | 6      |", "| 7 | 1        | 8      |",
+                                               "| 3 | 3        | 35     |", "+---+----------+--------+"};
+    ExecutorBuilder plain{ctx}, fused{ctx};
+    plain.fuse_join_agg = false;
+    expect_table("builder: HashAgg(Filter(scan)) as two operators", try_collect(plain.build(make_plan({f1, f2}))), expected);
+    expect_table("builder: the same plan with the filter handed to the aggregate", try_collect(fused.build(make_plan({f1, f2}))), expected);
+    if (plain.rewrites != 0 || fused.rewrites != 1) { failures++; std::printf("FAIL agg-filter peephole: rewrites %d / %d\n", plain.rewrites, fused.rewrites); }
+  }
   std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "PASSED", failures, failures == 1 ? "" : "s");
   return failures ? 1 : 0;
 }

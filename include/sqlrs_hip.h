@@ -271,6 +271,17 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
 #define SQLRS_GROUP_ORDER_FIRST_SEEN 0
 #define SQLRS_GROUP_ORDER_ANY 1
 int sqlrs_hash_agg_set_group_order(sqlrs_hash_agg_t *a, int group_order);
+/* A FilterExecutor sitting directly below the operator — PhysicalHashAgg(PhysicalFilter(child)), the shape of
+ * `SELECT k, sum(v) FROM t WHERE t.col > c GROUP BY k` [ref: filter.rs:13-25 feeding hash_agg.rs:44].  `filter`
+ * indexes the columns of the pushed batches.  Results are identical to sqlrs_filter_push on every batch followed
+ * by sqlrs_hash_agg_push of its output (groups in first-seen order of the FILTERED rows).  When the predicate is
+ * `column OP constant` over an int64 / float64 column without NULLs, the batch is one that is aggregated in
+ * place (>= 2^26 rows, first batch) and neither the keys nor the aggregate arguments contain a division, the
+ * first partition pass evaluates the predicate itself (no filtered copy of any column is written); otherwise
+ * the library runs the Filter operator first.  Must be called before the first batch; NULL / empty = none. */
+int sqlrs_hash_agg_set_filter(sqlrs_hash_agg_t *a, const sqlrs_expr_t *filter);
+/* batches whose filter was evaluated inside the first partition pass (diagnostics / tests) */
+int64_t sqlrs_hash_agg_filter_fused_batches(const sqlrs_hash_agg_t *a);
 void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *a);
 
 /* ------------------------------------------------------------------ Order -- */

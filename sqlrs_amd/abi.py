@@ -319,6 +319,8 @@ class Backend:
             "join_agg_filter_fused_batches": (C.c_int64, [vp]),
             "join_agg_set_group_order": (i, [vp, i]),
             "hash_agg_set_group_order": (i, [vp, i]),
+            "hash_agg_set_filter": (i, [vp, pe]),
+            "hash_agg_filter_fused_batches": (C.c_int64, [vp]),
             "join_agg_destroy": (None, [vp]),
             "project_create": (i, [vp, i, pe, pvp]),
             "project_push": (i, [vp, pb, i, ppb]),

@@ -103,6 +103,10 @@ struct sqlrs_hash_agg {
   };
   std::vector<DistinctAgg> distinct_aggs;
   std::vector<std::pair<int, int>> out_order; // (0 = plain | 1 = distinct, index) per output aggregate
+  // FilterExecutor directly below the operator (sqlrs_hash_agg_set_filter)
+  bool has_filter = false;
+  Expr filter;
+  int64_t filter_fused_batches = 0;
   ~sqlrs_hash_agg() {
     for (auto &d : distinct_aggs) delete d.dedup;
   }
@@ -114,8 +118,12 @@ extern "C" int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const s
                                      const sqlrs_agg_func_t *aggs, sqlrs_hash_agg_t **out);
 extern "C" void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *a);
 extern "C" void sqlrs_batch_release(sqlrs_batch_t *batch);
+extern "C" int sqlrs_filter_create(sqlrs_ctx_t *, const sqlrs_expr_t *, sqlrs_filter_t **);
+extern "C" int sqlrs_filter_push(sqlrs_filter_t *, const sqlrs_batch_t *, int, sqlrs_batch_t **);
+extern "C" void sqlrs_filter_destroy(sqlrs_filter_t *);
 
 namespace sq {
+bool fusable_row_filter(const Expr &e, InBatch &ib, RowFilter *rf);
 
 __global__ void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
                                   int64_t n, uint32_t *__restrict__ out) {
@@ -581,8 +589,8 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
           pin.join_unique_known = js->unique_known;
           pin.join_omin = js->omin;
           pin.join_omax = js->omax;
-          if (rf) pin.filter = *rf;
         }
+        if (rf) pin.filter = *rf;
         PartAggOutput po;
         flush_pending(a); // an older deferred batch must be in the table before this one
         bool part_ok = partitioned_preaggregate(ctx, spec, pin, (uint64_t)a->rows_seen, &po);
@@ -806,8 +814,59 @@ int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
   return st != SQLRS_OK ? st : hash_agg_push_device(a, in);
 }
 
-static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
-  return guard(a->ctx, [&] {
+// A filter that the first partition pass can evaluate (col OP constant, radix_part.hpp) on a batch that is aggregated
+// in place: keys and arguments are evaluated on the UNFILTERED batch, so nothing among them may raise for a row the
+// filter would have dropped (a division: ADVICE r2) — then the Filter operator runs first.
+static bool hash_agg_try_fused_filter(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
+  Ctx *ctx = a->ctx;
+  const int64_t n = in->num_rows;
+  if (!a->staged.empty() || n < STAGE_DIRECT_ROWS || !a->distinct_aggs.empty()) return false;
+  for (const Expr &e : a->group_by)
+    for (const sqlrs_expr_node_t &nd : e.nodes)
+      if (nd.op == SQLRS_EXPR_DIVIDE) return false;
+  for (const Expr &e : a->arg_exprs)
+    for (const sqlrs_expr_node_t &nd : e.nodes)
+      if (nd.op == SQLRS_EXPR_DIVIDE) return false;
+  InBatch ib(ctx, in);
+  RowFilter rf;
+  if (!fusable_row_filter(a->filter, ib, &rf)) return false;
+  auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
+  std::vector<DCol> kcols;
+  for (const Expr &e : a->group_by) kcols.push_back(eval_expr(ctx, e, colfn, n, true));
+  std::vector<DCol> acols = eval_arg_columns(a, colfn, n, 0);
+  NKeys nk = a->strong_keys ? normalize_keys_strong(ctx, kcols, n) : normalize_keys(ctx, kcols, n);
+  if (!agg_consume(a, n, kcols, nk, acols, nullptr, &rf)) return false; // (nothing consumed)
+  if (!a->saw_batch) {
+    a->saw_batch = true;
+    for (const DCol &k : kcols) a->key_dtypes.push_back(k.dtype);
+  }
+  a->rows_seen += n;
+  a->filter_fused_batches++;
+  return true;
+}
+
+static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in0) {
+  const sqlrs_batch_t *in = in0;
+  sqlrs_batch_t *kept = nullptr;
+  if (a->has_filter) { // [ref: filter.rs:13-25 feeding hash_agg.rs:44]
+    bool fused = false;
+    int st = guard(a->ctx, [&] {
+      SQ_HIP(hipSetDevice(a->ctx->device));
+      fused = hash_agg_try_fused_filter(a, in0);
+    });
+    if (st != SQLRS_OK || fused) return st;
+    std::vector<sqlrs_expr_node_t> nodes = a->filter.nodes;
+    for (size_t i = 0; i < nodes.size(); i++) nodes[i].s = a->filter.strings[i].empty() ? nullptr : a->filter.strings[i].c_str();
+    sqlrs_expr_t fe{nodes.data(), (int32_t)nodes.size(), 0};
+    sqlrs_filter_t *f = nullptr;
+    st = sqlrs_filter_create((sqlrs_ctx_t *)a->ctx, &fe, &f);
+    if (st != SQLRS_OK) return st;
+    st = sqlrs_filter_push(f, in0, SQLRS_MEM_DEVICE, &kept);
+    sqlrs_filter_destroy(f);
+    if (st != SQLRS_OK) return st;
+    in = kept;
+  }
+  int rc = guard(a->ctx, [&] {
     Ctx *ctx = a->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
     InBatch ib(ctx, in);
@@ -842,6 +901,8 @@ static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
       if (st != SQLRS_OK) fail(st, ctx->last_error);
     }
   });
+  if (kept) sqlrs_batch_release(kept);
+  return rc;
 }
 
 // [ref: hash_agg.rs:124-149]
@@ -918,6 +979,16 @@ int sqlrs_hash_agg_set_group_order(sqlrs_hash_agg_t *a, int group_order) {
     a->any_order = group_order == SQLRS_GROUP_ORDER_ANY;
   });
 }
+
+int sqlrs_hash_agg_set_filter(sqlrs_hash_agg_t *a, const sqlrs_expr_t *filter) {
+  return guard(a->ctx, [&] {
+    if (a->saw_batch || !a->staged.empty() || a->hstage.has_schema)
+      fail(SQLRS_ERR_INTERNAL, "set_filter after the first batch");
+    a->has_filter = filter && filter->num_nodes > 0;
+    if (a->has_filter) a->filter = expr_from_abi(filter);
+  });
+}
+int64_t sqlrs_hash_agg_filter_fused_batches(const sqlrs_hash_agg_t *a) { return a->filter_fused_batches; }
 
 void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *a) { delete a; }
 

@@ -139,9 +139,13 @@ class HashAggExecutor:
 
     def __init__(self, backend: abi.Backend, agg_funcs: List[AggFunc], group_by: List[BoundExpr],
                  child: Iterable, out_mem: int = abi.MEM_HOST,
-                 output_names: Optional[Sequence[str]] = None):
+                 output_names: Optional[Sequence[str]] = None, child_filter: Optional[BoundExpr] = None):
         self.backend, self.agg_funcs, self.group_by = backend, agg_funcs, group_by
         self.child, self.out_mem, self.output_names = child, out_mem, output_names
+        # FilterExecutor{expr = child_filter, child} directly below the operator (filter.rs:7-25), handed to the
+        # library (sqlrs_hash_agg_set_filter; HIP library only): same result as wrapping `child` in a FilterExecutor
+        self.child_filter = child_filter
+        self.filter_fused_batches = 0
 
     def execute(self):
         be = self.backend
@@ -154,11 +158,17 @@ class HashAggExecutor:
         be.check(be.fn("hash_agg_create")(be.ctx, len(self.group_by), gb, len(self.agg_funcs), aggs,
                                           C.byref(h)))
         try:
+            if self.child_filter is not None:
+                pf = self.child_filter.pack()
+                keep.append(pf)
+                be.check(be.fn("hash_agg_set_filter")(h, C.byref(pf.abi)))
             for batch in self.child:  # hash_agg.rs:44-122
                 b = abi.as_batch(batch)
                 be.check(be.fn("hash_agg_push")(h, b.ptr))
             out = C.POINTER(abi.Batch)()  # hash_agg.rs:124-149: exactly one output batch
             be.check(be.fn("hash_agg_finish")(h, self.out_mem, C.byref(out)))
+            if self.child_filter is not None:
+                self.filter_fused_batches = be.fn("hash_agg_filter_fused_batches")(h)
             yield _emit(be, out, self.out_mem, self.output_names)
         finally:
             be.fn("hash_agg_destroy")(h)

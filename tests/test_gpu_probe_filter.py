@@ -237,8 +237,8 @@ def test_chunked_first_level_forced():
         pytest.skip("already inside the forced run")
     env = dict(os.environ, SQLRS_RP_CHUNKED="1", SQLRS_STAGE_DIRECT_ROWS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "chunked and not forced and ((count_sum and (val_gt_half or other_ne or key_ge or val_lt_none)) "
-                              "or hot_digit or (hash_agg_chunked and dense) or without_chunk_histograms)"], env=env, capture_output=True,
+                        "-k", "(chunked and not forced and ((count_sum and (val_gt_half or other_ne or key_ge or val_lt_none)) "
+                              "or hot_digit or (hash_agg_chunked and dense) or without_chunk_histograms)) or child_filter"], env=env, capture_output=True,
                        text=True, timeout=1700)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     # (the same level with SQLRS_RP_H2=0 — level 2 running its own histogram pass — is part of that run:
@@ -316,3 +316,63 @@ def test_hash_agg_claimed_level_overflow_falls_back(hip, oracle, monkeypatch):
     sampled = (o // (tile // 8)) == ((t * 5) % 8)
     k = np.where(sampled, rng.integers(0, G // 2, n), rng.integers(G // 2, G, n)).astype(np.int64)
     _claimed_case(hip, oracle, k, rng.random(n), expect_claimed=False)
+
+
+AGG_PREDS = {
+    "val_gt_half": InputRef(1) > Constant(0.5, abi.FLOAT64),           # predicate on the aggregated column
+    "other_ne": BinaryOp("!=", InputRef(2), Constant(7, abi.INT64)),    # on a column the aggregates do not read
+    "key_ge": InputRef(0) >= Constant(1000, abi.INT64),                 # on the group key itself
+    "val_lt_none": InputRef(1) < Constant(-1.0, abi.FLOAT64),           # keeps nothing
+    "general": (InputRef(1) > Constant(0.25, abi.FLOAT64)) & (InputRef(2) < Constant(50, abi.INT64)),  # not fusable
+}
+
+
+@pytest.mark.parametrize("shape", ["dense_one_level", "dense_two_level", "sparse"])
+@pytest.mark.parametrize("pred", ["val_gt_half", "other_ne", "key_ge", "val_lt_none", "general"])
+def test_hash_agg_child_filter(hip, oracle, shape, pred, monkeypatch):
+    """HashAgg(Filter(child)) with the filter handed to the aggregate (sqlrs_hash_agg_set_filter) against the oracle
+    running FilterExecutor -> HashAggExecutor (filter.rs:13-25 feeding hash_agg.rs:44); groups in first-seen order of
+    the FILTERED rows.  At test size the library runs its Filter operator first; in the forced run (batches aggregated
+    in place, see test_chunked_first_level_forced) `col OP constant` predicates must be evaluated by the first
+    partition pass: the claimed single level (range partitions of <= 512 buckets) or the chunked first level."""
+    if shape != "dense_one_level" and pred in ("key_ge", "val_lt_none"):
+        pytest.skip("crossed with the one-level shape only")
+    monkeypatch.setenv("SQLRS_RP_CLAIM", "1")
+    rng = np.random.default_rng(zlib.crc32(f"{shape}{pred}".encode()))
+    n = 3_000_000
+    G = {"dense_one_level": 400_000, "dense_two_level": 2_600_000, "sparse": 300_000}[shape]
+    k = rng.integers(0, G, n, dtype=np.int64)
+    if shape == "sparse":
+        with np.errstate(over="ignore"):
+            k = k * np.int64(0x9E3779B97F4A7C15 - (1 << 64)) + np.int64(99)
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(rng.random(n)), pa.array(rng.integers(-100, 100, n, dtype=np.int64))],
+                                   names=["k", "v", "c"])
+    aggs = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64)]
+    ex = HashAggExecutor(hip, aggs, [InputRef(0)], [b], child_filter=AGG_PREDS[pred])
+    got = rows_of(ex.execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], FilterExecutor(oracle, AGG_PREDS[pred], [b]).execute()).execute())
+    if exp is not None and exp.num_rows == 0:
+        exp = None
+    if got is not None and got.num_rows == 0:
+        got = None
+    assert_same(got, exp, float_cols={2})
+    if FORCED:
+        # (sparse: 3e5 hashed groups need 612 probing tables — two levels, the chunked first level takes the filter)
+        assert ex.filter_fused_batches == (1 if pred != "general" else 0)
+
+
+def test_hash_agg_child_filter_batches_and_raising_argument(hip, oracle):
+    """several small batches (filtered on arrival, staged, aggregated together) and an aggregate argument that
+    divides by a column which is zero only in rows the filter removes: must not raise (the argument is evaluated
+    behind the filter, as in the reference), DISTINCT aggregate included"""
+    rng = np.random.default_rng(3)
+    n = 200_000
+    c = rng.integers(0, 5, n, dtype=np.int64)
+    b = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 1000, n, dtype=np.int64)), pa.array(rng.integers(1, 100, n, dtype=np.int64)), pa.array(c)],
+                                   names=["k", "v", "c"])
+    bs = [b.slice(i * 50_000, 50_000) for i in range(4)]
+    pred = InputRef(2) > Constant(0, abi.INT64)
+    aggs = [AggFunc("sum", BinaryOp("/", InputRef(1), InputRef(2)), abi.INT64), AggFunc("count", InputRef(1), abi.INT64, distinct=True)]
+    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], bs, child_filter=pred).execute())
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], FilterExecutor(oracle, pred, bs).execute()).execute())
+    assert_same(got, exp)

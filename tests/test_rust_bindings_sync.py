@@ -108,5 +108,5 @@ def test_shim_calls_name_declared_functions_with_the_declared_number_of_argument
         core = {n for n in fam_fns if n.rsplit("_", 1)[-1] in ("create", "push", "finish", "destroy") or n.endswith(("build_push", "build_finish", "probe_push"))}
         assert core <= used, (fam, sorted(core - used))
     for s in ("hip_visit_physical_filter", "hip_visit_physical_hash_join", "hip_visit_physical_hash_agg", "hip_visit_physical_order",
-              "as_physical_hash_join", "as_physical_filter", "sqlrs_join_agg_set_probe_filter"):
+              "as_physical_hash_join", "as_physical_filter", "sqlrs_join_agg_set_probe_filter", "sqlrs_hash_agg_set_filter"):
         assert s in open(os.path.join(RUST, "executors.rs")).read()
