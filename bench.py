@@ -903,6 +903,43 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     by = 16 * n + 24 * groups[0]
     res["C4_agg"] = {"rows": n, "groups": groups[0], "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
                      "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    # ---- C4 with a WHERE: HashAgg(Filter(scan)), val > 0.5 — the filter handed to the aggregate (sqlrs_hash_agg_set_filter:
+    #      evaluated by the partition pass) against the same plan as two operators (filter.rs:13-25 feeding hash_agg.rs:44)
+    pred = (InputRef(1) > Constant(0.5, abi.FLOAT64)).pack()
+    kept = [0]
+
+    def run_agg_where(fused):
+        a = C.c_void_p()
+        be.check(be.fn("hash_agg_create")(be.ctx, 1, gb, 2, aggs, C.byref(a)))
+        fo = None
+        if fused:
+            be.check(be.fn("hash_agg_set_filter")(a, C.byref(pred.abi)))
+            be.check(be.fn("hash_agg_push")(a, b.ptr))
+        else:
+            f = C.c_void_p()
+            be.check(be.fn("filter_create")(be.ctx, C.byref(pred.abi), C.byref(f)))
+            fo = C.POINTER(abi.Batch)()
+            be.check(be.fn("filter_push")(f, b.ptr, D, C.byref(fo)))
+            be.fn("filter_destroy")(f)
+            kept[0] = fo.contents.num_rows
+            be.check(be.fn("hash_agg_push")(a, fo))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("hash_agg_finish")(a, D, C.byref(o)))
+        groups[0] = o.contents.num_rows
+        ff = be.fn("hash_agg_filter_fused_batches")(a)
+        be.fn("batch_release")(o)
+        if fo is not None:
+            be.fn("batch_release")(fo)
+        be.fn("hash_agg_destroy")(a)
+        return ff
+    ms_two = timed(lambda: run_agg_where(False))
+    ms_fused = timed(lambda: run_agg_where(True))
+    ff = run_agg_where(True)
+    profile_of(lambda: run_agg_where(True), "C4 agg where")
+    by = 16 * n + 24 * groups[0]
+    res["C4_agg_where"] = {"rows": n, "kept": kept[0], "groups": groups[0], "ms": round(ms_fused, 3), "ms_two_operators": round(ms_two, 3),
+                           "filter_fused_batches": int(ff), "Mrows_s": round(n / ms_fused / 1e3, 1),
+                           "GBps": round(by / ms_fused / 1e6, 1), "frac": round(by / ms_fused / 1e6 / HBM_PEAK_GBPS, 4)}
     # ---- C4 with Zipf(1.1) keys over the same 1e6 groups (hot groups: contention / bucket skew)
     import numpy as _np
     w = _np.arange(1, G + 1, dtype=_np.float64) ** -1.1

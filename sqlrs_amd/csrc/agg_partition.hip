@@ -46,12 +46,15 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t h, uint32_t P) {
 // block_stride > 1: only every block_stride-th chunk of PART_WG * KU rows is read at all (plus the first and the
 // last chunk: sorted / clustered keys have their extremes there) — min / max are then a SAMPLE's, see
 // estimate_distinct.
+// hll_bits: log2 of the number of registers in use (<= 12).  The block-sampled pass uses 1024: every block merges its
+// registers with one global atomicMax each (24 G/s), and 512 blocks x 4096 registers cost more than reading the sample.
 __global__ __launch_bounds__(PART_WG) void key_stats_kernel(const uint64_t *__restrict__ keys,
                                                             const uint64_t *__restrict__ validity,
-                                                            int64_t n, int sample_shift, int block_stride,
+                                                            int64_t n, int sample_shift, int block_stride, int hll_bits,
                                                             unsigned int *__restrict__ hll) {
   __shared__ unsigned int reg[4096];
-  for (int i = threadIdx.x; i < 4096; i += PART_WG) reg[i] = 0;
+  const int nreg = 1 << hll_bits;
+  for (int i = threadIdx.x; i < nreg; i += PART_WG) reg[i] = 0;
   __syncthreads();
   uint64_t kmin = ~0ull, kmax = 0;
   const int64_t smask = (1ll << sample_shift) - 1;
@@ -74,17 +77,29 @@ __global__ __launch_bounds__(PART_WG) void key_stats_kernel(const uint64_t *__re
       kmax = max(kmax, o);
       if (((r >> 6) & smask) != 0) continue; // wave-uniform
       uint64_t h = mix64(k[u] ^ 0x2545f4914f6cdd1dULL);
-      unsigned idx = (unsigned)(h >> 52);
-      unsigned rank = (unsigned)__builtin_clzll((h << 12) | (1ull << 11)) + 1;
+      unsigned idx = (unsigned)(h >> (64 - hll_bits));
+      unsigned rank = (unsigned)__builtin_clzll((h << hll_bits) | (1ull << (hll_bits - 1))) + 1;
       if (reg[idx] < rank) atomicMax(&reg[idx], rank);
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 4096; i += PART_WG)
+  for (int i = threadIdx.x; i < nreg; i += PART_WG)
     if (reg[i]) atomicMax(&hll[i], reg[i]);
+  // one atomic pair per BLOCK: atomics on one address are serialised in L2, and a pair per wave (8192 of them on two
+  // addresses) was most of the sampled pass's 0.125 ms
+  __shared__ unsigned long long s_mm[2][PART_WG / 64];
   kmin = wave_min_u64(kmin);
   kmax = wave_max_u64(kmax);
   if (lane_id() == 0) {
+    s_mm[0][wave_id()] = kmin;
+    s_mm[1][wave_id()] = kmax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < PART_WG / 64; w++) {
+      kmin = min(kmin, (uint64_t)s_mm[0][w]);
+      kmax = max(kmax, (uint64_t)s_mm[1][w]);
+    }
     unsigned long long *mm = (unsigned long long *)(hll + 4096);
     atomicMin(mm, (unsigned long long)kmin);
     atomicMax(mm + 1, (unsigned long long)kmax);
@@ -93,6 +108,7 @@ __global__ __launch_bounds__(PART_WG) void key_stats_kernel(const uint64_t *__re
 
 static double hll_pass(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n, int sample_shift,
                        uint64_t *omin, uint64_t *omax, int block_stride = 1) {
+  const int hll_bits = block_stride > 1 ? 10 : 12; // (1024 registers: 3 % standard error, the estimate only sizes tables)
   BufP hll = ctx->alloc_zero(4096 * 4 + 16);
   SQ_HIP(hipMemsetAsync(hll->as<uint8_t>() + 4096 * 4, 0xff, 8, ctx->stream)); // min starts at ~0
   {
@@ -101,16 +117,16 @@ static double hll_pass(Ctx *ctx, const uint64_t *keys, const uint64_t *validity,
     // 2048 blocks spent 0.33 ms merging their registers — more than reading 1.6 GB of keys
     unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, (int64_t)PART_WG * 16 * block_stride), 2 * (int64_t)ctx->num_cus);
     key_stats_kernel<<<dim3(std::max(blocks, 1u)), dim3(PART_WG), 0, ctx->stream>>>(keys, validity, n, sample_shift,
-                                                                                  block_stride, hll->as<unsigned int>());
+                                                                                  block_stride, hll_bits, hll->as<unsigned int>());
     SQ_HIP(hipGetLastError());
   }
-  std::vector<unsigned int> reg(4096 + 4);
-  SQ_HIP(hipMemcpyAsync(reg.data(), hll->p, 4096 * 4 + 16, hipMemcpyDeviceToHost, ctx->stream));
-  ctx->sync();
+  // (through the pinned staging buffer: a copy into pageable memory cost ~50 us of host time before the partition)
+  const unsigned int *hreg = (const unsigned int *)ctx->fetch(hll->p, 4096 * 4 + 16);
+  std::vector<unsigned int> reg(hreg, hreg + 4096 + 4);
   if (omin) std::memcpy(omin, &reg[4096], 8);
   if (omax) std::memcpy(omax, &reg[4098], 8);
-  reg.resize(4096);
-  const double m = 4096.0;
+  reg.resize((size_t)1 << hll_bits);
+  const double m = (double)(1 << hll_bits);
   double sum = 0;
   int zeros = 0;
   for (unsigned r : reg) {

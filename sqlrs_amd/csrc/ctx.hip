@@ -517,11 +517,11 @@ int sqlrs_ctx_create(int device_id, sqlrs_ctx_t **out) {
   c->pool.device = device_id;
   c->num_cus = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc(&c->pinned, 65536, hipHostMallocDefault) != hipSuccess) {
     delete c;
     return SQLRS_ERR_DEVICE;
   }
-  c->pinned_bytes = 4096;
+  c->pinned_bytes = 65536;
   if (const char *e = std::getenv("SQLRS_POOL_RESERVE_GB")) { // experiment / deployment knob: one up-front allocation
     const size_t bytes = (size_t)(std::atof(e) * (double)(1ull << 30)); // (fractions of a GiB count: "0.5", "1.5")
     void *p = nullptr;

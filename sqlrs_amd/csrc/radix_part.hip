@@ -1254,6 +1254,11 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     rp_bucket_starts_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
         offs->as<uint32_t>(), L.d_seg_mat, L.d_seg_tiles, L.d_seg_start, digits, nseg, rows, bs->as<uint32_t>());
     SQ_HIP(hipGetLastError());
+    if (4 * (size_t)total <= ctx->pinned_bytes) { // (pinned staging buffer: a copy into pageable memory costs tens of us of host time)
+      const uint32_t *h = (const uint32_t *)ctx->fetch(bs->p, 4 * (size_t)total);
+      host->assign(h, h + total);
+      return bs;
+    }
     host->resize((size_t)total);
     SQ_HIP(hipMemcpyAsync(host->data(), bs->p, 4 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
@@ -1280,13 +1285,18 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     const uint64_t pool_rows = slots_max + (uint64_t)WG * wgs; // + one sink per workgroup
     if (pool_rows <= 0xffffffffull) {
       BufP est = ctx->alloc_zero(4 * ((size_t)P + 1));
-      BufP plan = ctx->alloc(4 * 3 * (size_t)P); // region start | region end | cursor
-      BufP cst = ctx->alloc_zero(16);            // {kept rows (u64), overflow flag}
+      // region start | region end | cursor | {kept rows (u64), overflow flag (u64)}: one buffer, one fetch
+      const size_t plan_words = 3 * (size_t)P + (P & 1), plan_bytes = 4 * plan_words + 16;
+      BufP plan = ctx->alloc(plan_bytes);
+      SQ_HIP(hipMemsetAsync(plan->as<uint8_t>() + 4 * plan_words, 0, 16, ctx->stream));
       uint32_t *rstart = plan->as<uint32_t>(), *rend = rstart + P, *cursor = rend + P;
+      uint64_t *cst = (uint64_t *)(plan->as<uint32_t>() + plan_words);
       {
         ProfScope ps(ctx, "rp_sample_hist");
         const int64_t samples = (int64_t)tiles1c * (RP_TILE / 8);
-        const unsigned sblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(samples, 256 * 4 * 2), 4096));
+        // (four blocks per CU: every block ends with up to P global atomics — 4096 blocks spent more time on those than
+        //  on reading the sample)
+        const unsigned sblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(samples, 256 * 4 * 2), 4 * (int64_t)ctx->num_cus));
         rp_sample_hist_kernel<<<dim3(sblocks), dim3(256), 0, ctx->stream>>>(in.keys, in.filter, n, (uint32_t)RP_TILE, tiles1c, P, kp,
                                                                            est->as<uint32_t>());
         rp_region_plan_kernel<<<dim3(1), dim3(512), 0, ctx->stream>>>(est->as<uint32_t>(), P, n, slack, B, rstart, rend, cursor);
@@ -1304,8 +1314,8 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       co.rec = cc.rec ? (u64x2 *)cc.rec->p : nullptr;
       co.cursor = cursor;
       co.rend = rend;
-      co.kept = cst->as<unsigned long long>();
-      co.flag = (unsigned int *)(cst->as<uint64_t>() + 1);
+      co.kept = (unsigned long long *)cst;
+      co.flag = (unsigned int *)(cst + 1);
       co.B = B;
       const int psrc = !in.filter.col ? -1 : ((nv >= 1 && (const void *)in.filter.col == in.vals[0]) ? 1 : 3);
       const size_t clds = (size_t)RP_TILE * 8 * (1 + nv) + (size_t)WG * (4 + 4 + 8 + 8);
@@ -1333,19 +1343,17 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         SQ_HIP(hipGetLastError());
       }
       // one round trip: region starts, cursors (= region fill) and the two counters
-      std::vector<uint32_t> hp(3 * (size_t)P);
+      const uint32_t *hp = (const uint32_t *)ctx->fetch(plan->p, plan_bytes); // (pinned staging buffer: <= 6.2 KiB)
       uint64_t hc[2];
-      SQ_HIP(hipMemcpyAsync(hp.data(), plan->p, 4 * 3 * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
-      SQ_HIP(hipMemcpyAsync(hc, cst->p, 16, hipMemcpyDeviceToHost, ctx->stream));
-      ctx->sync();
+      std::memcpy(hc, hp + plan_words, 16);
       if (!(uint32_t)hc[1]) {
         out->n = (int64_t)hc[0];
         out->P = P;
         publish(cc);
         out->bstart = plan; // (region starts; device consumers of contiguous buckets never see a claimed partition)
-        out->bstart_host.assign(hp.begin(), hp.begin() + P);
+        out->bstart_host.assign(hp, hp + P);
         out->bstart_host.push_back((uint32_t)slots_max);
-        out->bend_host.assign(hp.begin() + 2 * (size_t)P, hp.begin() + 3 * (size_t)P);
+        out->bend_host.assign(hp + 2 * (size_t)P, hp + 3 * (size_t)P);
         return true;
       }
       // a region overflowed (the sample misjudged a bucket): the counting level below redoes the batch

@@ -183,7 +183,9 @@ void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int b
   // One extra read of the keys (8 B/row) against 32 B/row per skipped pass; worth asking when
   // more than two passes are requested (int64 sort keys of a 31-bit column: 8 passes -> 4).
   uint64_t varying = ~0ull, key0 = 0;
-  if (end_bit - begin_bit > 16 && n >= (1 << 16)) {
+  // (below 2^22 rows a pass is launch-bound, ~35 us: the same as this question — kernel + host round trip — costs,
+  //  and callers that know their keys' width pass it as end_bit)
+  if (end_bit - begin_bit > 16 && n >= (1 << 22)) {
     BufP diff = ctx->alloc_zero(16);
     unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 4 * (int64_t)ctx->num_cus);
     rs_diff_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(keys, n, diff->as<unsigned long long>());
