@@ -176,6 +176,9 @@ struct LdsAggParams {
   int n_acc;
   int code[PART_MAX_ACC]; // AccKind | src << 3
   uint32_t cap;           // slots (power of two); +2 reserved slots follow
+  // dense (direct-addressed) fused join whose build keys do not cover their whole range: bit (key offset) = the key
+  // has a build partner; null = every key of the range has one
+  const unsigned long long *partner_bits;
 };
 
 __device__ __forceinline__ uint64_t acc_identity_cell(int kind) {
@@ -718,6 +721,14 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
     cur = nxt;
   }
   __syncthreads();
+  if (JOIN && prm.partner_bits) { // build keys with gaps: a slot whose key has no build partner is not a group
+    const uint64_t off0 = (uint64_t)b << kp.rbits; // (a multiple of 64 or R < 64: rbits >= 8)
+    for (uint32_t s = threadIdx.x; s < R; s += PART_WG) { // (the slots this thread stores / counts below)
+      if (tfirst[s] == 0xffffffffu) continue;
+      const uint64_t o = off0 + s;
+      if (!((prm.partner_bits[o >> 6] >> (o & 63)) & 1ull)) tfirst[s] = 0xffffffffu;
+    }
+  }
   if (split != 0xffffffffu) { // chunk of a split bucket: its table goes out as chunk table `split` (split_emit_dense_kernel reduces)
     unsigned int *gf = stb.first + (size_t)split * R;
     for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
@@ -879,6 +890,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   // for the fused join, no build-side partition and no insert phase.
   const char *dense_e = std::getenv("SQLRS_DENSE_AGG"); // test / tuning hook, read per call
   const bool dense_on = !(dense_e && dense_e[0] == '0');
+  const uint64_t *partner_bits = nullptr; // dense fused join over build keys with gaps (PartAggInput::join_bits)
   const double want_hashed = want; // probing tables needed if the bucket pass ran on hashed buckets
   bool dense = false;
   if (dense_on && kp.kbits) {
@@ -897,7 +909,11 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     const uint64_t pd = (range >> rbits) + 1;
     // join: unique build keys (the caller's pre-condition) that span exactly join_n values are
     // every value of the range; otherwise: at most ~4 slots per group
-    const bool fills = join_mode ? (in.join_unique_known && range + 1 == (uint64_t)in.join_n) : ((double)range + 1.0 <= 4.0 * est);
+    // (with the existence bitmap of the range — the join's direct-address table — gaps are fine: <= 16 slots per key)
+    const bool fills = join_mode ? (in.join_unique_known && (range + 1 == (uint64_t)in.join_n ||
+                                                             (in.join_bits && in.join_range_known && range / 16 <= (uint64_t)in.join_n)))
+                                 : ((double)range + 1.0 <= 4.0 * est);
+    partner_bits = (join_mode && fills && range + 1 != (uint64_t)in.join_n) ? in.join_bits : nullptr;
     if (fills && pd <= 65536 && (double)pd <= 1.5 * std::max(1.0, std::ceil(want))) {
       dense = true;
       kp.dense = 1;
@@ -997,8 +1013,9 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     prm.code[a] = a < spec.n_acc ? (kind | (spec.src[a] << 3)) : 0;
   }
   prm.cap = cap;
+  prm.partner_bits = dense ? (const unsigned long long *)partner_bits : nullptr;
   int64_t gcap = (int64_t)std::min<double>((double)n, est * 1.5 + 65536.0 + 2.0 * P);
-  if (dense) gcap = (int64_t)std::min<uint64_t>((uint64_t)n, kp.range + 1); // one group per key of the range at most
+  if (dense) gcap = (int64_t)std::min<uint64_t>((uint64_t)n, join_mode ? (uint64_t)in.join_n : kp.range + 1); // one group per key of the range (build key) at most
   size_t lds = dense ? round_up((size_t)cap * (slot_bytes - 8), 16) : round_up((size_t)(cap + 2) * slot_bytes, 16);
   // work list: buckets larger than `chunk` rows (key skew) are split so that no workgroup streams
   // more than `chunk` rows.  The chunks of a split bucket merge their tables into one small global

@@ -40,6 +40,10 @@ struct PartAggInput {
   // that inserts the build keys into its bucket tables (and notices a key twice) may run, not the direct-addressed
   // one, which takes "every key of the range has a partner" from uniqueness
   bool join_unique_known = true;
+  // existence bitmap of the build keys over [join_omin, join_omax] (bit = key offset; the join's direct-address
+  // table, join_state.hpp): lets the direct-addressed route run when the unique build keys do NOT cover their whole
+  // range — a slot is a group only where the bit is set.  Requires join_range_known and join_unique_known.
+  const uint64_t *join_bits = nullptr;
   // FilterExecutor directly below (fused join only): rows failing `filter` do not exist for the
   // operator.  Evaluated by the chunked first partition level; when that level does not apply the
   // call returns false and the caller runs the Filter operator first.

@@ -498,6 +498,7 @@ struct JoinSide {
   bool unique_known = true; // false: uniqueness of the build keys not established yet (agg_partition.hpp)
   bool range_known = false; // omin / omax: signed-order images of the smallest / largest valid key
   uint64_t omin = 0, omax = 0;
+  const uint64_t *bits = nullptr; // existence bitmap over [omin, omax] (PartAggInput::join_bits)
 };
 
 // Consumes one batch given its evaluated key / argument columns: partition route when it
@@ -589,6 +590,7 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
           pin.join_unique_known = js->unique_known;
           pin.join_omin = js->omin;
           pin.join_omax = js->omax;
+          pin.join_bits = js->bits;
         }
         if (rf) pin.filter = *rf;
         PartAggOutput po;
@@ -1154,6 +1156,7 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bo
           js.range_known = true;
           js.omin = j->dense_min ^ (1ull << 63);
           js.omax = js.omin + (j->dense_range - 1);
+          if (j->dense_range != (uint64_t)j->nB && !js.validity) js.bits = hash_join_dense_bits(j); // keys with gaps
         }
         flush_staged(a); // batches staged by the composed route come first in row order
         if (agg_consume(a, n, kcols, nk, acols, &js, fuse_filter ? &rf : nullptr)) {

@@ -691,6 +691,10 @@ __global__ __launch_bounds__(BLOCK) void join_probe_unique_outer_kernel(
   if (lane_id() == 0 && r < n) left_validity[r >> 6] = mm;
 }
 
+static uint64_t dense_slots_per_key_owned() {
+  const char *e = std::getenv("SQLRS_DENSE_JOIN_SLOTS"); // test / tuning hook, read per call
+  return e ? (uint64_t)std::max(1, std::atoi(e)) : 16;
+}
 // min / max of the valid build keys as signed integers (dense-range detection)
 __global__ __launch_bounds__(256) void key_minmax_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
                                   int64_t n, unsigned long long *mn, unsigned long long *mx) {
@@ -907,7 +911,7 @@ static void build_table(sqlrs_hash_join *j) {
   }
   j->bkeys = keys; // kept for the fused join+aggregate route (hashagg_op.hip)
   j->bkeys_validity = validity;
-  // 1. dense surrogate keys (range <= 4 x rows and < 2^31) -> direct-address table.  It is tried
+  // 1. dense surrogate keys (range <= 4 x rows — 16 x for a join+aggregate's join — and < 2^31) -> direct-address table.  It is tried
   //    first: when the build keys turn out unique nothing else is needed, and the 16-byte-slot
   //    hash table (1.1 ms for 1e7 keys) is never built.
   if (j->exact && n > 0 && j->key_dtype != SQLRS_FLOAT64) {
@@ -924,7 +928,11 @@ static void build_table(sqlrs_hash_join *j) {
     uint64_t lo = h[0], hi = h[1];
     if (lo <= hi) {
       uint64_t range = hi - lo + 1; // ordered images differ like the signed values
-      if (range <= 4 * (uint64_t)n + 1024 && range < (1ull << 31)) {
+      // (a join owned by a HashJoin+HashAgg takes the table up to 16 slots per key: its fused route then partitions
+      //  by key range and needs only the existence bitmap of the range — a filtered dimension, or the hash-partitioned
+      //  shard of one that a rank of the multi-GPU plan receives, 1/8 of the keys of the range for 8 ranks)
+      const uint64_t slots_per_key = j->lazy_table ? dense_slots_per_key_owned() : 4;
+      if (range <= slots_per_key * (uint64_t)n + 1024 && range < (1ull << 31)) {
         ProfScope ps(ctx, "join_build_dense");
         BufP dense = ctx->alloc(4 * (size_t)range + 8);
         SQ_HIP(hipMemsetAsync(dense->p, 0xff, 4 * (size_t)range + 8, ctx->stream));
@@ -1272,6 +1280,19 @@ static void apply_filter(sqlrs_hash_join *j, const DBatch &right, Pairs &p) {
   if (!p.left_validity && unv.count == 0 && lf.own_validity) p.left_validity = lf.own_validity;
 }
 
+const uint64_t *hash_join_dense_bits(sqlrs_hash_join *j) {
+  if (!j->dense || !j->dense_range) return nullptr;
+  if (!j->dense_bits) {
+    Ctx *ctx = j->ctx;
+    const int64_t words = ceil_div((int64_t)j->dense_range, 64);
+    j->dense_bits = ctx->alloc(8 * (size_t)words + 8);
+    dense_bits_kernel<<<dim3((unsigned)ceil_div(words * 64, 256)), dim3(256), 0, ctx->stream>>>(
+        j->dense->as<uint32_t>(), (int64_t)j->dense_range, j->dense_bits->as<uint64_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  return j->dense_bits->as<uint64_t>();
+}
+
 // Key-only build side (see dense_bits_kernel): true = `out` holds the joined batch
 static bool semi_join_probe(sqlrs_hash_join *j, InBatch &ib, const NKeys &pk, DBatch *out) {
   Ctx *ctx = j->ctx;
@@ -1286,13 +1307,7 @@ static bool semi_join_probe(sqlrs_hash_join *j, InBatch &ib, const NKeys &pk, DB
   const int64_t n = ib.rows();
   if (rkey_col < 0 || rkey_col >= ib.num_columns() || n < (1 << 16)) return false;
   if (j->left.cols[0].dtype != ib.col(rkey_col).dtype) return false;
-  if (!j->dense_bits) {
-    const int64_t words = ceil_div((int64_t)j->dense_range, 64);
-    j->dense_bits = ctx->alloc(8 * (size_t)words + 8);
-    dense_bits_kernel<<<dim3((unsigned)ceil_div(words * 64, 256)), dim3(256), 0, ctx->stream>>>(
-        j->dense->as<uint32_t>(), (int64_t)j->dense_range, j->dense_bits->as<uint64_t>());
-    SQ_HIP(hipGetLastError());
-  }
+  hash_join_dense_bits(j);
   Selection sel;
   sel.rows = n;
   const int64_t nwords = ceil_div(n, 64);

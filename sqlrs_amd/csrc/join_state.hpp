@@ -45,4 +45,7 @@ struct sqlrs_hash_join {
 // builds the deferred hash table of a `lazy_table` join (join.hip); no-op otherwise
 namespace sq {
 void hash_join_ensure_table(sqlrs_hash_join *j);
+// existence bitmap of a direct-address (`dense`) join: bit (key - dense_min) is set when the key has a build row
+// (join.hip, dense_bits_kernel); built once, on first need
+const uint64_t *hash_join_dense_bits(sqlrs_hash_join *j);
 }

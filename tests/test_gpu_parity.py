@@ -2,6 +2,7 @@
 the C ABI).  Integer / index / order results must be bit-exact; SUM(double) within 1e-9
 relative (north_star tolerance)."""
 import math
+import os
 
 import numpy as np
 import pyarrow as pa
@@ -1018,6 +1019,42 @@ def test_join_agg_dense_build_keys(hip, oracle, nb, base, hot):
     ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
     got = rows_of(ex.execute())
     assert ex.fused_batches == 1
+    exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
+    assert_same(got, exp, float_cols={2})
+
+
+@pytest.mark.parametrize("keep_one_in", [2, 8, 24])
+@pytest.mark.parametrize("hot", [False, True])
+def test_join_agg_build_keys_with_gaps(hip, oracle, keep_one_in, hot):
+    """Fused join + group-by whose unique build keys cover only PART of their range — a filtered dimension, or the
+    hash-partitioned shard of one that a rank of the multi-GPU plan receives: up to 16 slots per key the join keeps
+    its direct-address table and the group-by its direct-addressed bucket tables, and a slot is a group only where
+    the existence bitmap of the range has its bit (probe keys in a gap have no partner).  1 key in 24: hashed
+    buckets, as before.  `hot`: heavy hitters with and without partner (split buckets store their chunk tables)."""
+    from sqlrs_amd.executor import HashJoinAggExecutor
+    nrange, npb, base = 1_600_000, 2_300_000, -777
+    rng = np.random.default_rng(keep_one_in + hot)
+    present = rng.random(nrange) < 1.0 / keep_one_in
+    present[0] = present[-1] = True
+    lkeys = rng.permutation(base + np.nonzero(present)[0]).astype(np.int64)
+    lb = pa.RecordBatch.from_arrays([pa.array(lkeys), pa.array(rng.integers(0, 9, len(lkeys), dtype=np.int64))], names=["k", "x"])
+    pk = rng.integers(base - 1000, base + nrange + 1000, npb, dtype=np.int64)
+    if hot:
+        pk[rng.random(npb) < 0.4] = lkeys[7]                                   # heavy hitter with a partner
+        pk[rng.random(npb) < 0.2] = base + int(np.nonzero(~present)[0][5])     # ... and one inside a gap
+    rb = pa.RecordBatch.from_arrays([pa.array(pk), pa.array(rng.random(npb))], names=["k", "v"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64)]
+    hip.profile(True)
+    ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
+    got = rows_of(ex.execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    assert ex.fused_batches == 1
+    direct = prof.get("join_build_dense", (0, 0))[1] > 0 and prof.get("rp_scatter_build", (0, 0))[1] == 0
+    if os.environ.get("SQLRS_DENSE_AGG") != "0":
+        assert direct == (keep_one_in <= 16), prof
     exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
     assert_same(got, exp, float_cols={2})
 

@@ -18,13 +18,16 @@ worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 fact_key = datagen.fill_chunks(torch.empty(n_fact, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF1, i, n_dim))
 fact_val = datagen.fill_chunks(torch.empty(n_fact, dtype=torch.float64, device=dev), lambda i: datagen.val_t(0xF2, i))
 dim_key = datagen.fill_chunks(torch.empty(n_dim, dtype=torch.int64, device=dev), lambda i: datagen.dim_key_t(i, n_dim))
+torch.cuda.synchronize()  # the library reads the columns on its own stream
 pred = InputRef(1) > Constant(0.5, abi.FLOAT64)
 T = {abi.INT64: torch.int64, abi.FLOAT64: torch.float64}
 res = {}
 for W in worlds:
     # partition 0 of the dim keys
     parts, offs = be.hash_partition(bench.device_batch(abi, [dim_key], [abi.INT64]), InputRef(0), W, abi.MEM_DEVICE)
+    be.synchronize()  # (the library works on its own stream; torch reads the result on torch's)
     dk = bench._tensor_view(torch, parts.column(0).values, parts.column(0).length, torch.int64, dev)[offs[0]:offs[1]].clone()
+    torch.cuda.synchronize()
     parts.release()
     # partition 0 of the kept fact rows, slice by slice as the W source ranks would send them
     fk = torch.empty(int(n_fact * 0.55 / W) + 4096, dtype=torch.int64, device=dev)
@@ -47,8 +50,11 @@ for W in worlds:
         out = pipe.join_agg(bench.device_batch(abi, [dk], [abi.INT64]), bench.device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64]))
         be.synchronize()
         return out
+    print(f"W={W}: {dk.numel():,} dim keys, {got:,} kept fact rows received", file=sys.stderr, flush=True)
     out = step()
     groups = out.num_rows
+    rng = (int(dk.min()), int(dk.max()), int(fk.min()), int(fk.max()))
+    assert rng[0] >= 0 and rng[1] < n_dim and rng[2] >= 0 and rng[3] < n_dim, rng
     # check against torch on the same received rows
     exp_cnt = torch.bincount(fk, minlength=n_dim)
     has = torch.zeros(n_dim, dtype=torch.bool, device=dev)
