@@ -25,7 +25,7 @@ exchange + merge the partial aggregates; the line times the other strategy too (
 Output: ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel:
 HIP-event time per launch measured live on the ctx stream; and the operator-level pipeline figure),
 `cpu_baseline` (all-core CPU port + the single-threaded restatement of the reference, on bounded samples),
-and at N = 1 `c5_variants` (sparse keys, three operators) and `operators` (C2 / C3 / C4 / Order).
+and at N = 1 `c5_variants` (sparse keys, three operators, GROUP BY a dim attribute) and `operators` (C2 / C3 / C4 / Order).
 Every result is checked per group before it is timed.
 """
 from __future__ import annotations
@@ -737,6 +737,10 @@ def bench_variants(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim
     ms = timed(pipe, db, fb, 3, 1)
     res["three_operators"] = {"ms_per_step": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1), "check": "OK" if ok else msg}
     be.fn("ctx_pool_trim")(be.ctx)
+    # ---- GROUP BY a dim ATTRIBUTE: SELECT d.region, COUNT(f.val), SUM(f.val) ... GROUP BY d.region (region = key mod 1000)
+    res["group_by_dim_attribute"] = bench_group_by_attribute(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim,
+                                                             exp_cnt, exp_sum, has_dim)
+    be.fn("ctx_pool_trim")(be.ctx)
     # ---- sparse keys: k -> k * A + B in place (wrapping int64 arithmetic), inverse for the check
     A, B = 0x9E3779B97F4A7C15, 0x632BE59BD9B4E019
     A_s = A - (1 << 64)
@@ -769,6 +773,84 @@ def bench_variants(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim
     if any(v["check"] != "OK" for v in res.values()):
         raise SystemExit("bench variant result check failed")
     return res
+
+
+def bench_group_by_attribute(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim, exp_cnt, exp_sum, has_dim, regions=1000):
+    """The headline query grouped by a column of the DIM side instead of the join key — the usual star-join shape:
+    HashAgg[group_by = d.region](HashJoin(dim[key, region], Filter(fact))) through sqlrs_join_agg_*.  The operator
+    groups by join key first and re-aggregates the per-key rows by region (eager aggregation, include/sqlrs_hip.h:
+    sqlrs_join_agg_eager_groups); `ms_composed` is the same plan with that route switched off (SQLRS_EAGER_AGG=0,
+    read at operator creation): the joined batch is materialised and aggregated.  Checked per region against torch."""
+    from sqlrs_amd.expr import AggFunc, Constant, InputRef
+    region = dim_key % regions
+    lk, _k1 = abi.pack_exprs([InputRef(0)])
+    rk, _k2 = abi.pack_exprs([InputRef(0)])
+    gb, _k3 = abi.pack_exprs([InputRef(1)])  # d.region
+    keep = []
+    aggs = (abi.AggFunc * 2)(AggFunc("count", InputRef(3), abi.INT64).abi_struct(keep),
+                             AggFunc("sum", InputRef(3), abi.FLOAT64).abi_struct(keep))
+    right_dtypes = (C.c_int32 * 2)(abi.INT64, abi.FLOAT64)
+    pred = (InputRef(1) > Constant(args.threshold, abi.FLOAT64)).pack()
+    # expectation per region from the per-key expectation
+    joined = (has_dim > 0)
+    e_cnt = torch.zeros(regions, dtype=torch.int64, device=dev).index_add_(0, torch.arange(n_dim, device=dev) % regions, exp_cnt * joined)
+    e_sum = torch.zeros(regions, dtype=torch.float64, device=dev).index_add_(0, torch.arange(n_dim, device=dev) % regions,
+                                                                              exp_sum * joined.to(torch.float64))
+    torch.cuda.synchronize()  # (`region` was produced on torch's stream; the library reads it on its own)
+
+    def step():
+        ja = C.c_void_p()
+        be.check(be.fn("join_agg_create")(be.ctx, 1, lk, rk, 2, 2, right_dtypes, 1, gb, 2, aggs, C.byref(ja)))
+        be.check(be.fn("join_agg_set_probe_filter")(ja, C.byref(pred.abi)))
+        db = device_batch(abi, [dim_key, region], [abi.INT64, abi.INT64])
+        fb = device_batch(abi, [fact_key, fact_val], [abi.INT64, abi.FLOAT64])
+        be.check(be.fn("join_agg_build_push")(ja, db.ptr))
+        be.check(be.fn("join_agg_build_finish")(ja))
+        be.check(be.fn("join_agg_probe_push")(ja, fb.ptr))
+        ao = C.POINTER(abi.Batch)()
+        be.check(be.fn("join_agg_finish")(ja, abi.MEM_DEVICE, C.byref(ao)))
+        eg = be.fn("join_agg_eager_groups")(ja)
+        be.fn("join_agg_destroy")(ja)
+        be.synchronize()
+        return be.wrap(ao), eg
+
+    def check(out):
+        g = out.num_rows
+        r = _tensor_view(torch, out.column(0).values, g, torch.int64, dev)
+        c = _tensor_view(torch, out.column(1).values, g, torch.int64, dev)
+        sm = _tensor_view(torch, out.column(2).values, g, torch.float64, dev)
+        ok = g == int((e_cnt > 0).sum().item()) and bool((torch.bincount(r, minlength=regions) <= 1).all().item())
+        ok = ok and bool((c == e_cnt[r]).all().item()) and bool(((sm - e_sum[r]).abs() <= 1e-9 * e_sum[r].abs().clamp_min(1e-300)).all().item())
+        return ok, g
+
+    def timed(steps=3):
+        step()[0].release()
+        be.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            step()[0].release()
+        be.synchronize()
+        return (time.perf_counter() - t) / steps * 1e3
+
+    out, eg = step()
+    ok, groups = check(out)
+    out.release()
+    ms = timed()
+    old = os.environ.get("SQLRS_EAGER_AGG")
+    os.environ["SQLRS_EAGER_AGG"] = "0"
+    try:
+        out, _ = step()
+        ok2, _g = check(out)
+        out.release()
+        ms_c = timed(2)
+    finally:
+        if old is None:
+            del os.environ["SQLRS_EAGER_AGG"]
+        else:
+            os.environ["SQLRS_EAGER_AGG"] = old
+    n = fact_key.numel()
+    return {"ms_per_step": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1), "groups": groups, "eager_groups": int(eg),
+            "ms_composed": round(ms_c, 3), "check": "OK" if (ok and ok2) else f"mismatch (eager {ok}, composed {ok2})"}
 
 
 def bench_operators(be, abi, datagen, torch, dev, reps=3):

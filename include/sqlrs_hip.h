@@ -334,6 +334,15 @@ int64_t sqlrs_join_agg_fused_batches(const sqlrs_join_agg_t *ja);
 int sqlrs_join_agg_set_probe_filter(sqlrs_join_agg_t *ja, const sqlrs_expr_t *filter);
 /* probe batches whose filter was evaluated inside the first partition pass (diagnostics / tests) */
 int64_t sqlrs_join_agg_filter_fused_batches(const sqlrs_join_agg_t *ja);
+/* GROUP BY over columns of the BUILD side (`... FROM fact JOIN dim ON fact.k = dim.k GROUP BY dim.region`,
+ * PhysicalHashAgg over PhysicalHashJoin with group_by = InputRefs below num_left_columns) with unique build keys:
+ * every build column is a function of the join key, so the operator groups the probe rows by JOIN KEY first (its
+ * non-materialising route), finds the build row of every distinct key once, and re-aggregates those partial rows by
+ * the requested columns (COUNT -> sum of counts; SUM / MIN / MAX of partials).  Same groups, same first-seen group
+ * order [ref: hash_agg.rs:98] and the same aggregates as HashAgg over the materialised join [ref: hash_join.rs:284-291
+ * feeding hash_agg.rs:44-122]; SUM(double) within the summation-order tolerance.  Returns the number of partial
+ * groups (distinct join keys) the last finish re-aggregated; 0 = the route did not run (diagnostics / tests). */
+int64_t sqlrs_join_agg_eager_groups(const sqlrs_join_agg_t *ja);
 void sqlrs_join_agg_destroy(sqlrs_join_agg_t *ja);
 
 /* ---------------------------------------- operators either side of the hot path -- */

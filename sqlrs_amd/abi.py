@@ -317,6 +317,7 @@ class Backend:
             "join_agg_fused_batches": (C.c_int64, [vp]),
             "join_agg_set_probe_filter": (i, [vp, pe]),
             "join_agg_filter_fused_batches": (C.c_int64, [vp]),
+            "join_agg_eager_groups": (C.c_int64, [vp]),
             "join_agg_set_group_order": (i, [vp, i]),
             "hash_agg_set_group_order": (i, [vp, i]),
             "hash_agg_set_filter": (i, [vp, pe]),

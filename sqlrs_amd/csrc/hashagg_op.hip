@@ -1005,6 +1005,7 @@ int sqlrs_hash_join_create(sqlrs_ctx_t *, int, int, const sqlrs_expr_t *, const 
 int sqlrs_hash_join_build_push(sqlrs_hash_join_t *, const sqlrs_batch_t *);
 int sqlrs_hash_join_build_finish(sqlrs_hash_join_t *);
 int sqlrs_hash_join_probe_push(sqlrs_hash_join_t *, const sqlrs_batch_t *, int, sqlrs_batch_t **);
+int sqlrs_hash_join_probe_indices(sqlrs_hash_join_t *, const sqlrs_batch_t *, int, sqlrs_batch_t **);
 void sqlrs_hash_join_destroy(sqlrs_hash_join_t *);
 void sqlrs_batch_release(sqlrs_batch_t *);
 int sqlrs_filter_create(sqlrs_ctx_t *, const sqlrs_expr_t *, sqlrs_filter_t **);
@@ -1057,11 +1058,74 @@ struct sqlrs_join_agg {
   Expr probe_filter;
   int64_t filter_fused_batches = 0;
   HostStage hstage; // small HOST probe batches (raw, unfiltered) until enough rows for one upload
+  // Eager aggregation (GROUP BY columns of the BUILD side, e.g. `GROUP BY d.region` over fact JOIN dim): when the build
+  // keys are unique every build column is a function of the join key, so the rows are first grouped by the probe-side
+  // JOIN KEY (`inner`: the fused route of join_agg_process, groups in first-seen order), each of those groups finds
+  // its build row once (one probe of the join per distinct key instead of one per row), and `outer` re-aggregates
+  // the partial rows by the requested columns: COUNT -> SUM of the counts, SUM / MIN / MAX of the partials.  `outer`
+  // sees the partial groups in first-seen order, so its own first-seen order is the operator's (hash_agg.rs:98).
+  bool eager_possible = false, eager_decided = false, eager = false;
+  sqlrs_hash_agg *inner = nullptr, *outer = nullptr;
+  std::vector<int> group_cols; // build-side column of each GROUP BY expression
+  int64_t eager_groups = 0;    // partial groups (distinct join keys) the last finish() re-aggregated
   ~sqlrs_join_agg() {
     if (join) sqlrs_hash_join_destroy(join);
     delete agg;
+    delete inner;
+    delete outer;
   }
 };
+
+// GROUP BY over build-side columns only (and not just the join key itself, which the fused route takes directly), one
+// INPUT_REF key pair, plain aggregates whose arguments read the probe side: sets up `inner` and `outer`
+static void join_agg_plan_eager(sqlrs_join_agg *ja, int num_keys, const sqlrs_expr_t *left_keys, const sqlrs_expr_t *right_keys,
+                                int num_group_by, const sqlrs_expr_t *group_by, int num_aggs, const sqlrs_agg_func_t *aggs) {
+  const char *env = std::getenv("SQLRS_EAGER_AGG"); // test / tuning hook: 0 = never
+  if (env && std::atoi(env) == 0) return;
+  if (num_keys != 1 || num_group_by < 1 || left_keys[0].num_nodes != 1 || right_keys[0].num_nodes != 1 ||
+      left_keys[0].nodes[0].op != SQLRS_EXPR_INPUT_REF || right_keys[0].nodes[0].op != SQLRS_EXPR_INPUT_REF)
+    return;
+  const int lc = left_keys[0].nodes[0].index, rc = right_keys[0].nodes[0].index;
+  for (int g = 0; g < num_group_by; g++) {
+    if (group_by[g].num_nodes != 1 || group_by[g].nodes[0].op != SQLRS_EXPR_INPUT_REF) return;
+    const int idx = group_by[g].nodes[0].index;
+    if (idx < 0 || idx >= ja->nleft) return;
+    ja->group_cols.push_back(idx);
+  }
+  if (num_group_by == 1 && ja->group_cols[0] == lc) return; // the fused route's own shape
+  for (int i = 0; i < num_aggs; i++) {
+    if (aggs[i].distinct || aggs[i].return_dtype == SQLRS_UTF8) return;
+    if (aggs[i].func < SQLRS_AGG_COUNT || aggs[i].func > SQLRS_AGG_MAX) return;
+    for (int k = 0; k < aggs[i].arg.num_nodes; k++)
+      if (aggs[i].arg.nodes[k].op == SQLRS_EXPR_INPUT_REF && aggs[i].arg.nodes[k].index < ja->nleft) return;
+  }
+  // inner: GROUP BY the probe-side join key (joined-schema index), the caller's aggregates as they are
+  sqlrs_expr_node_t kn = right_keys[0].nodes[0];
+  kn.index = ja->nleft + rc;
+  sqlrs_expr_t ke{&kn, 1, 0};
+  int st = sqlrs_hash_agg_create((sqlrs_ctx_t *)ja->ctx, 1, &ke, num_aggs, aggs, &ja->inner);
+  if (st != SQLRS_OK) fail(st, ja->ctx->last_error);
+  // outer: input = [group columns..., partial aggregates...]
+  std::vector<sqlrs_expr_node_t> nodes((size_t)(num_group_by + num_aggs));
+  std::vector<sqlrs_expr_t> gb((size_t)num_group_by);
+  std::vector<sqlrs_agg_func_t> fin((size_t)std::max(num_aggs, 1));
+  for (int c = 0; c < num_group_by + num_aggs; c++) {
+    nodes[(size_t)c] = sqlrs_expr_node_t{};
+    nodes[(size_t)c].op = SQLRS_EXPR_INPUT_REF;
+    nodes[(size_t)c].index = c;
+  }
+  for (int g = 0; g < num_group_by; g++) gb[(size_t)g] = sqlrs_expr_t{&nodes[(size_t)g], 1, 0};
+  for (int i = 0; i < num_aggs; i++) {
+    sqlrs_agg_func_t f{};
+    f.func = aggs[i].func == SQLRS_AGG_COUNT ? SQLRS_AGG_SUM : aggs[i].func; // counts add up (count.rs:17-23 per batch)
+    f.return_dtype = aggs[i].func == SQLRS_AGG_COUNT ? SQLRS_INT64 : aggs[i].return_dtype;
+    f.arg = sqlrs_expr_t{&nodes[(size_t)(num_group_by + i)], 1, 0};
+    fin[(size_t)i] = f;
+  }
+  st = sqlrs_hash_agg_create((sqlrs_ctx_t *)ja->ctx, num_group_by, gb.data(), num_aggs, fin.data(), &ja->outer);
+  if (st != SQLRS_OK) fail(st, ja->ctx->last_error);
+  ja->eager_possible = true;
+}
 
 extern "C" {
 
@@ -1079,6 +1143,7 @@ int sqlrs_join_agg_create(sqlrs_ctx_t *ctx, int num_keys, const sqlrs_expr_t *le
     ja->join->lazy_table = true; // (join_state.hpp: built when the composed route first probes it)
     st = sqlrs_hash_agg_create(ctx, num_group_by, group_by, num_aggs, aggs, &ja->agg);
     if (st != SQLRS_OK) fail(st, ctx->last_error);
+    join_agg_plan_eager(ja.get(), num_keys, left_keys, right_keys, num_group_by, group_by, num_aggs, aggs);
     *out = ja.release();
   });
 }
@@ -1098,9 +1163,16 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bo
     Ctx *ctx = ja->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
     sqlrs_hash_join *j = ja->join;
-    sqlrs_hash_agg *a = ja->agg;
     if (!j->finished) fail(SQLRS_ERR_INTERNAL, "probe before build_finish");
     if (j->empty_build) return; // the join emits nothing (hash_join.rs:183-185)
+    if (!ja->eager_decided) { // once, at the first batch: eager aggregation needs unique, exactly compared build keys
+      ja->eager_decided = true;
+      if (ja->eager_possible && j->exact && right->num_rows >= (1ll << 16)) {
+        hash_join_ensure_table(j); // (establishes `unique` when the direct-address table did not)
+        ja->eager = j->unique && j->unique_known;
+      }
+    }
+    sqlrs_hash_agg *a = ja->eager ? ja->inner : ja->agg;
     // Fused route: Inner join on ONE exactly-compared key with unique build keys, grouped by
     // that key, aggregate arguments taken from the probe side only.  Then every probe row
     // yields at most one joined row and Agg(Join(build, probe)) = Agg(probe rows whose key
@@ -1290,11 +1362,54 @@ int sqlrs_join_agg_finish(sqlrs_join_agg_t *ja, int out_mem, sqlrs_batch_t **out
   if (st != SQLRS_OK) return st;
   st = join_agg_flush(ja);
   if (st != SQLRS_OK) return st;
-  return sqlrs_hash_agg_finish(ja->agg, out_mem, out);
+  if (!ja->eager || !ja->inner->saw_batch) return sqlrs_hash_agg_finish(ja->agg, out_mem, out);
+  // eager aggregation: partial groups by join key -> their build rows -> re-aggregation by the GROUP BY columns
+  sqlrs_batch_t *part = nullptr, *fake = nullptr, *pairs = nullptr, *fin = nullptr;
+  st = sqlrs_hash_agg_finish(ja->inner, SQLRS_MEM_DEVICE, &part);
+  if (st == SQLRS_OK)
+    st = guard(ja->ctx, [&] {
+      Ctx *ctx = ja->ctx;
+      SQ_HIP(hipSetDevice(ctx->device));
+      sqlrs_hash_join *j = ja->join;
+      InBatch pb(ctx, part);
+      const int64_t G = pb.rows();
+      ja->eager_groups = G;
+      const int rc = j->rkeys[0].nodes[0].index;
+      DBatch f;
+      f.rows = G;
+      if (G > 0) {
+        // the partial keys as a probe batch of the join (every column is the key column: only column rc is read)
+        DBatch fk;
+        fk.rows = G;
+        for (int c = 0; c <= rc; c++) fk.cols.push_back(pb.col(0));
+        fake = emit_batch(ctx, std::move(fk), SQLRS_MEM_DEVICE);
+        int s2 = sqlrs_hash_join_probe_indices(j, fake, SQLRS_MEM_DEVICE, &pairs);
+        if (s2 != SQLRS_OK) fail(s2, ctx->last_error);
+        // unique build keys, and a partial group exists only for a key with a partner: exactly one pair per partial
+        // group, in probe-row order (hash_join.rs:207-253) — pair i belongs to partial group i
+        if (!pairs || pairs->num_rows != G) fail(SQLRS_ERR_INTERNAL, "eager aggregation: a partial group without exactly one build row");
+        InBatch pr(ctx, pairs);
+        for (int gc : ja->group_cols) f.cols.push_back(gather_column(ctx, j->left.cols[(size_t)gc], pr.col(0).values, true, nullptr, G));
+      } else {
+        for (int gc : ja->group_cols) f.cols.push_back(make_null_column(ctx, j->left.cols[(size_t)gc].dtype, 0));
+      }
+      for (int c = 1; c < pb.num_columns(); c++) f.cols.push_back(pb.col(c));
+      fin = emit_batch(ctx, std::move(f), SQLRS_MEM_DEVICE);
+    });
+  if (st == SQLRS_OK) st = sqlrs_hash_agg_push(ja->outer, fin);
+  if (st == SQLRS_OK) st = sqlrs_hash_agg_finish(ja->outer, out_mem, out);
+  for (sqlrs_batch_t *b : {part, fake, pairs, fin})
+    if (b) sqlrs_batch_release(b);
+  return st;
 }
 int sqlrs_join_agg_set_group_order(sqlrs_join_agg_t *ja, int group_order) {
-  return sqlrs_hash_agg_set_group_order(ja->agg, group_order);
+  int st = sqlrs_hash_agg_set_group_order(ja->agg, group_order);
+  if (st == SQLRS_OK && ja->outer) st = sqlrs_hash_agg_set_group_order(ja->outer, group_order); // (`inner` stays in first-seen order)
+  return st;
 }
+// partial groups (distinct join keys) that the last finish() re-aggregated by build-side GROUP BY columns; 0 = the
+// eager-aggregation route did not run (diagnostics / tests)
+int64_t sqlrs_join_agg_eager_groups(const sqlrs_join_agg_t *ja) { return ja->eager_groups; }
 // number of probe batches that took the fused route (diagnostics / tests)
 int64_t sqlrs_join_agg_fused_batches(const sqlrs_join_agg_t *ja) { return ja->fused_batches; }
 int sqlrs_join_agg_set_probe_filter(sqlrs_join_agg_t *ja, const sqlrs_expr_t *filter) {

@@ -196,6 +196,7 @@ class HashJoinAggExecutor:
         self.agg_funcs, self.group_by = agg_funcs, group_by
         self.out_mem, self.output_names = out_mem, output_names
         self.fused_batches = 0
+        self.eager_groups = 0  # partial groups re-aggregated by build-side GROUP BY columns (0 = route not taken)
 
     def execute(self):
         be = self.backend
@@ -227,6 +228,7 @@ class HashJoinAggExecutor:
             be.check(be.fn("join_agg_finish")(h, self.out_mem, C.byref(out)))
             self.fused_batches = be.fn("join_agg_fused_batches")(h)
             self.filter_fused_batches = be.fn("join_agg_filter_fused_batches")(h)
+            self.eager_groups = be.fn("join_agg_eager_groups")(h)
             yield _emit(be, out, self.out_mem, self.output_names)
         finally:
             be.fn("join_agg_destroy")(h)

@@ -1023,6 +1023,54 @@ def test_join_agg_dense_build_keys(hip, oracle, nb, base, hot):
     assert_same(got, exp, float_cols={2})
 
 
+@pytest.mark.parametrize("shape", ["dense_dim_region", "sparse_dim_two_columns", "nullable", "key_and_attribute",
+                                   "small_batches", "duplicate_build_keys", "no_match"])
+def test_join_agg_group_by_build_columns(hip, oracle, shape):
+    """`... FROM fact JOIN dim ON fact.k = dim.k [WHERE ...] GROUP BY dim.region`: eager aggregation — the probe rows are
+    grouped by JOIN KEY first (non-materialising route), every distinct key finds its build row once, the partial rows are
+    re-aggregated by the build-side columns.  Same groups in the same first-seen order and the same aggregates as
+    HashAgg(HashJoin(..)) on the oracle; duplicate build keys (a key no longer determines its build row) and batches
+    below the route's size keep the composed route."""
+    from sqlrs_amd.executor import HashJoinAggExecutor
+    rng = np.random.default_rng(len(shape))
+    nb, npb = 300_000, 2_400_000
+    if shape == "sparse_dim_two_columns":
+        lkeys = (rng.permutation(nb).astype(np.int64) * 1_000_003 + 17)
+    else:
+        lkeys = rng.permutation(nb).astype(np.int64) - 5000
+    if shape == "duplicate_build_keys":
+        lkeys[:1000] = lkeys[1000:2000]
+    region = rng.integers(0, 37, nb, dtype=np.int64)
+    tier = rng.integers(0, 3, nb).astype(np.int32)
+    rmask = (rng.random(nb) < 0.03) if shape == "nullable" else None
+    lb = pa.RecordBatch.from_arrays([pa.array(lkeys), pa.array(region, mask=rmask), pa.array(tier)], names=["k", "region", "tier"])
+    pk = lkeys[rng.integers(0, nb, npb)]
+    miss = rng.random(npb) < (1.0 if shape == "no_match" else 0.1)
+    pk = np.where(miss, np.int64(-7_000_000) - rng.integers(0, 1000, npb), pk)  # rows without partner
+    vmask = (rng.random(npb) < 0.05) if shape == "nullable" else None
+    rb = pa.RecordBatch.from_arrays([pa.array(rng.random(npb), mask=vmask), pa.array(pk), pa.array(rng.integers(-50, 50, npb, dtype=np.int64))],
+                                    names=["v", "k", "w"])
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    sch = join_schema(lb, rb)
+    gb = {"sparse_dim_two_columns": [InputRef(1), InputRef(2)], "key_and_attribute": [InputRef(0), InputRef(1)]}.get(shape, [InputRef(1)])
+    aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64),
+            AggFunc("sum", InputRef(5), abi.INT64), AggFunc("min", InputRef(3), abi.FLOAT64), AggFunc("max", InputRef(5), abi.INT64)]
+    if shape == "small_batches":
+        rbs = [rb.slice(o, 30_000) for o in range(0, 240_000, 30_000)]  # staged, flushed as one batch below the route's size
+    else:
+        rbs = [rb.slice(0, npb // 3), rb.slice(npb // 3)]
+    pf = (InputRef(0) > Constant(0.25, abi.FLOAT64)) if shape in ("dense_dim_region", "key_and_attribute") else None
+    ex = HashJoinAggExecutor(hip, [lb], rbs, cond, sch, 3, aggs, gb, probe_filter=pf)
+    got = rows_of(ex.execute())
+    if shape == "duplicate_build_keys":
+        assert ex.eager_groups == 0
+    elif shape not in ("small_batches", "no_match") and os.environ.get("SQLRS_EAGER_AGG") != "0":
+        assert ex.eager_groups > 0 and ex.fused_batches >= 1
+    kept = list(FilterExecutor(oracle, pf, rbs).execute()) if pf is not None else rbs
+    exp = _join_agg_reference(oracle, [lb], kept, cond, sch, 3, aggs, gb)
+    assert_same(got, exp, float_cols={len(gb) + 1, len(gb) + 3})
+
+
 @pytest.mark.parametrize("keep_one_in", [2, 8, 24])
 @pytest.mark.parametrize("hot", [False, True])
 def test_join_agg_build_keys_with_gaps(hip, oracle, keep_one_in, hot):
