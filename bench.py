@@ -1022,6 +1022,55 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     res["C4_agg_where"] = {"rows": n, "kept": kept[0], "groups": groups[0], "ms": round(ms_fused, 3), "ms_two_operators": round(ms_two, 3),
                            "filter_fused_batches": int(ff), "Mrows_s": round(n / ms_fused / 1e3, 1),
                            "GBps": round(by / ms_fused / 1e6, 1), "frac": round(by / ms_fused / 1e6 / HBM_PEAK_GBPS, 4)}
+    # ---- C4 with a WIDE aggregate list (three argument columns, six aggregates: the TPC-H Q1 shape): run as parts of
+    #      <= 2 argument columns each (hashagg_op.hip); `ms_unsplit` = the same operator as ONE part (SQLRS_AGG_SPLIT=0,
+    #      read at operator creation), whose rows take the row route's global atomics
+    val2 = datagen.fill_chunks(torch.empty(n, dtype=torch.float64, device=dev), lambda i: datagen.val_t(0xF3, i))
+    qty = datagen.fill_chunks(torch.empty(n, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF4, i, 50))
+    torch.cuda.synchronize()
+    bw = device_batch(abi, [key, val, val2, qty], [abi.INT64, abi.FLOAT64, abi.FLOAT64, abi.INT64])
+    keep_w = []
+    aggs_w = (abi.AggFunc * 6)(AggFunc("count", InputRef(1), abi.INT64).abi_struct(keep_w), AggFunc("sum", InputRef(1), abi.FLOAT64).abi_struct(keep_w),
+                               AggFunc("sum", InputRef(2), abi.FLOAT64).abi_struct(keep_w), AggFunc("sum", InputRef(3), abi.INT64).abi_struct(keep_w),
+                               AggFunc("min", InputRef(2), abi.FLOAT64).abi_struct(keep_w), AggFunc("max", InputRef(3), abi.INT64).abi_struct(keep_w))
+    chk = [None]
+
+    def run_agg_wide():
+        a = C.c_void_p()
+        be.check(be.fn("hash_agg_create")(be.ctx, 1, gb, 6, aggs_w, C.byref(a)))
+        be.check(be.fn("hash_agg_push")(a, bw.ptr))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("hash_agg_finish")(a, D, C.byref(o)))
+        groups[0] = o.contents.num_rows
+        if chk[0] is None:  # once: SUM(qty) and COUNT(val) over all groups against torch (bit exact), group count
+            be.synchronize()
+            w_ = be.wrap(o)
+            cnt = _tensor_view(torch, w_.column(1).values, groups[0], torch.int64, dev)
+            sq = _tensor_view(torch, w_.column(4).values, groups[0], torch.int64, dev)
+            chk[0] = bool(int(cnt.sum().item()) == n and int(sq.sum().item()) == int(qty.sum().item()))
+            w_.release()
+        else:
+            be.fn("batch_release")(o)
+        be.fn("hash_agg_destroy")(a)
+    ms_w = timed(run_agg_wide)
+    profile_of(run_agg_wide, "C4 agg wide")
+    g_w, ok_w = groups[0], chk[0]
+    os.environ["SQLRS_AGG_SPLIT"] = "0"
+    try:
+        chk[0] = True
+        run_agg_wide()
+        be.synchronize()
+        t0 = time.perf_counter()
+        run_agg_wide()
+        be.synchronize()
+        ms_u = (time.perf_counter() - t0) * 1e3
+    finally:
+        del os.environ["SQLRS_AGG_SPLIT"]
+    by = 32 * n + 56 * g_w
+    res["C4_agg_wide_3cols_6aggs"] = {"rows": n, "groups": g_w, "ms": round(ms_w, 3), "ms_unsplit": round(ms_u, 3), "Mrows_s": round(n / ms_w / 1e3, 1),
+                                      "GBps": round(by / ms_w / 1e6, 1), "frac": round(by / ms_w / 1e6 / HBM_PEAK_GBPS, 4),
+                                      "check": "OK" if ok_w and g_w == G else "mismatch"}
+    del val2, qty, bw
     # ---- C4 with Zipf(1.1) keys over the same 1e6 groups (hot groups: contention / bucket skew)
     import numpy as _np
     w = _np.arange(1, G + 1, dtype=_np.float64) ** -1.1

@@ -107,8 +107,17 @@ struct sqlrs_hash_agg {
   bool has_filter = false;
   Expr filter;
   int64_t filter_fused_batches = 0;
+  // Wide aggregate lists: the partition route carries at most two 8-byte argument columns and PART_MAX_ACC
+  // accumulator cells per bucket-table slot; an operator asking for more (SUM(a), SUM(b), SUM(c), COUNT(*) ...) used to
+  // fall to the row route — one global atomic per row and accumulator, 24 G/s.  Such an operator is instead run as
+  // several PARTS with the same GROUP BY and disjoint subsets of the aggregates (each within those limits): every
+  // part sees every batch, all of them find the same groups in the same first-seen order (hash_agg.rs:98: the order
+  // depends on the key columns alone), and finish() puts their aggregate columns side by side.
+  std::vector<sqlrs_hash_agg *> parts;
+  std::vector<std::pair<int, int>> part_col; // per aggregate, output order: (part, aggregate index inside the part)
   ~sqlrs_hash_agg() {
     for (auto &d : distinct_aggs) delete d.dedup;
+    for (auto *p : parts) delete p;
   }
 };
 
@@ -735,8 +744,74 @@ static void flush_staged(sqlrs_hash_agg *a) {
 
 extern "C" {
 
+static int hash_agg_create_impl(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t *group_by, int num_aggs,
+                                const sqlrs_agg_func_t *aggs, bool allow_split, sqlrs_hash_agg_t **out);
 int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t *group_by,
                           int num_aggs, const sqlrs_agg_func_t *aggs, sqlrs_hash_agg_t **out) {
+  return hash_agg_create_impl(ctx, num_group_by, group_by, num_aggs, aggs, true, out);
+}
+
+// Parts of a wide aggregate list (sqlrs_hash_agg::parts): the aggregates of ONE argument expression per part (first
+// fit, at most PART_MAX_ACC cells: a COUNT cell — the column may turn out nullable — plus one per SUM / MIN / MAX).
+// One column, not two: a part with a single 8-byte argument travels as 16-byte packed records through a one-level
+// claimed partition when its keys are dense integers (C4 with three argument columns: parts of 2 + 1 columns 10.0 ms,
+// the two-column part alone 7 ms of two-level column-form passes).
+static void hash_agg_plan_parts(sqlrs_hash_agg *a, sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t *group_by,
+                                const sqlrs_agg_func_t *aggs) {
+  const char *env = std::getenv("SQLRS_AGG_SPLIT"); // test / tuning hook, read per create: 0 = never
+  if (env && std::atoi(env) == 0) return;
+  if (!a->distinct_aggs.empty() || a->aggs.size() < 3) return;
+  std::vector<int> col_of((size_t)a->aggs.size(), -1); // distinct argument expression of every aggregate (casts aside)
+  int ncols = 0;
+  for (size_t i = 0; i < a->aggs.size(); i++) {
+    if (a->aggs[i].return_dtype == SQLRS_UTF8) return; // (string MIN / MAX keeps its batches: row route anyway)
+    for (size_t k = 0; k < i && col_of[i] < 0; k++)
+      if (same_expr(a->aggs[k].arg, a->aggs[i].arg)) col_of[i] = col_of[k];
+    if (col_of[i] < 0) col_of[i] = ncols++;
+  }
+  struct Part {
+    std::vector<int> cols, aggs;
+    int cells = 0;
+  };
+  std::vector<Part> plan;
+  for (size_t i = 0; i < a->aggs.size(); i++) {
+    const int c = col_of[i], own = a->aggs[i].func != SQLRS_AGG_COUNT ? 1 : 0;
+    size_t at = plan.size();
+    for (size_t q = 0; q < plan.size() && at == plan.size(); q++) {
+      const bool has = std::find(plan[q].cols.begin(), plan[q].cols.end(), c) != plan[q].cols.end();
+      if (has && plan[q].cells + own <= PART_MAX_ACC) at = q;
+    }
+    if (at == plan.size()) plan.emplace_back();
+    Part &pt = plan[at];
+    if (std::find(pt.cols.begin(), pt.cols.end(), c) == pt.cols.end()) {
+      pt.cols.push_back(c);
+      pt.cells++;
+    }
+    pt.cells += own;
+    pt.aggs.push_back((int)i);
+  }
+  if (plan.size() < 2) return;
+  if (ncols <= 2) { // two argument columns within PART_MAX_ACC cells fit one partition-route operator as they are
+    int cells = ncols;
+    for (const AggSpec &sp : a->aggs) cells += sp.func != SQLRS_AGG_COUNT ? 1 : 0;
+    if (cells <= PART_MAX_ACC) return;
+  }
+  a->part_col.assign(a->aggs.size(), {0, 0});
+  for (size_t q = 0; q < plan.size(); q++) {
+    std::vector<sqlrs_agg_func_t> sub;
+    for (size_t k = 0; k < plan[q].aggs.size(); k++) {
+      sub.push_back(aggs[plan[q].aggs[k]]); // (no DISTINCT aggregate here: aggregate i of `a->aggs` is aggs[i])
+      a->part_col[(size_t)plan[q].aggs[k]] = {(int)q, (int)k};
+    }
+    sqlrs_hash_agg_t *p = nullptr;
+    int st = hash_agg_create_impl(ctx, num_group_by, group_by, (int)sub.size(), sub.data(), false, &p);
+    if (st != SQLRS_OK) fail(st, ctx->last_error);
+    a->parts.push_back(p);
+  }
+}
+
+static int hash_agg_create_impl(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t *group_by, int num_aggs,
+                                const sqlrs_agg_func_t *aggs, bool allow_split, sqlrs_hash_agg_t **out) {
   return guard(ctx, [&] {
     if (num_group_by < 1) // PhysicalRewriter only builds HashAgg with keys (physical_rewriter.rs:49-62)
       fail(SQLRS_ERR_INTERNAL, "HashAgg needs at least one group-by expression");
@@ -785,6 +860,7 @@ int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t
       a->aggs.push_back(std::move(s));
     }
     a->key_parts.resize((size_t)num_group_by);
+    if (allow_split) hash_agg_plan_parts(a.get(), ctx, num_group_by, group_by, aggs);
     *out = a.release();
   });
 }
@@ -806,6 +882,14 @@ static int hash_agg_flush_host(sqlrs_hash_agg_t *a) {
 
 // one iteration of the for_await loop  [ref: hash_agg.rs:44-122]
 int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
+  if (!a->parts.empty()) { // wide aggregate list: every part sees every batch
+    a->saw_batch = true;
+    for (sqlrs_hash_agg *p : a->parts) {
+      int st = sqlrs_hash_agg_push(p, in);
+      if (st != SQLRS_OK) return st;
+    }
+    return SQLRS_OK;
+  }
   a->hstage.ctx = a->ctx;
   if (a->hstage.accepts(in)) {
     int st = guard(a->ctx, [&] { a->hstage.append(in); });
@@ -908,20 +992,47 @@ static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in0) {
 }
 
 // [ref: hash_agg.rs:124-149]
+static DBatch hash_agg_finish_device(sqlrs_hash_agg_t *a);
 int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out) {
+  if (!a->parts.empty()) { // the parts' group columns are identical (same keys, same first-seen order): side by side
+    for (sqlrs_hash_agg *p : a->parts) {
+      int stp = hash_agg_flush_host(p);
+      if (stp != SQLRS_OK) return stp;
+    }
+    return guard(a->ctx, [&] {
+      Ctx *ctx = a->ctx;
+      SQ_HIP(hipSetDevice(ctx->device));
+      std::vector<DBatch> outs;
+      for (sqlrs_hash_agg *p : a->parts) {
+        outs.push_back(hash_agg_finish_device(p));
+        if (outs.back().rows != outs[0].rows) fail(SQLRS_ERR_INTERNAL, "parts of a wide aggregate list disagree on the groups");
+      }
+      const size_t nk = a->group_by.size();
+      DBatch o;
+      o.rows = outs[0].rows;
+      for (size_t c = 0; c < nk; c++) o.cols.push_back(outs[0].cols[c]);
+      for (const auto &pc : a->part_col) o.cols.push_back(outs[(size_t)pc.first].cols[nk + (size_t)pc.second]);
+      *out = emit_batch(ctx, std::move(o), out_mem);
+    });
+  }
   int stf = hash_agg_flush_host(a);
   if (stf != SQLRS_OK) return stf;
   return guard(a->ctx, [&] {
+    SQ_HIP(hipSetDevice(a->ctx->device));
+    *out = emit_batch(a->ctx, hash_agg_finish_device(a), out_mem);
+  });
+}
+// (host-staged batches are flushed by the caller; throws)
+static DBatch hash_agg_finish_device(sqlrs_hash_agg_t *a) {
+  {
     Ctx *ctx = a->ctx;
-    SQ_HIP(hipSetDevice(ctx->device));
     if (!a->saw_batch) // group_and_agg_fields.unwrap() panics on None (:125)
       fail(SQLRS_ERR_INTERNAL, "hash agg finished without any input batch");
     flush_staged(a);
     if (a->pending.active && a->st.ngroups == 0) {
       DBatch pb = emit_pending(a);
       place_aggregate_columns(a, pb);
-      *out = emit_batch(ctx, std::move(pb), out_mem);
-      return;
+      return pb;
     }
     flush_pending(a);
     int64_t G = a->st.ngroups;
@@ -968,8 +1079,8 @@ int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out)
         for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
     }
     place_aggregate_columns(a, o);
-    *out = emit_batch(ctx, std::move(o), out_mem);
-  });
+    return o;
+  }
 }
 
 int sqlrs_hash_agg_set_group_order(sqlrs_hash_agg_t *a, int group_order) {
@@ -978,7 +1089,7 @@ int sqlrs_hash_agg_set_group_order(sqlrs_hash_agg_t *a, int group_order) {
       fail(SQLRS_ERR_INTERNAL, "unknown group order");
     if (!a->distinct_aggs.empty() && group_order == SQLRS_GROUP_ORDER_ANY)
       fail(SQLRS_ERR_INTERNAL, "DISTINCT aggregates line up by first-seen order: SQLRS_GROUP_ORDER_ANY not supported");
-    a->any_order = group_order == SQLRS_GROUP_ORDER_ANY;
+    a->any_order = group_order == SQLRS_GROUP_ORDER_ANY; // (parts stay in first-seen order: their columns line up by it)
   });
 }
 
@@ -988,9 +1099,15 @@ int sqlrs_hash_agg_set_filter(sqlrs_hash_agg_t *a, const sqlrs_expr_t *filter) {
       fail(SQLRS_ERR_INTERNAL, "set_filter after the first batch");
     a->has_filter = filter && filter->num_nodes > 0;
     if (a->has_filter) a->filter = expr_from_abi(filter);
+    for (sqlrs_hash_agg *p : a->parts) {
+      int st = sqlrs_hash_agg_set_filter(p, filter);
+      if (st != SQLRS_OK) fail(st, a->ctx->last_error);
+    }
   });
 }
-int64_t sqlrs_hash_agg_filter_fused_batches(const sqlrs_hash_agg_t *a) { return a->filter_fused_batches; }
+int64_t sqlrs_hash_agg_filter_fused_batches(const sqlrs_hash_agg_t *a) {
+  return a->parts.empty() ? a->filter_fused_batches : a->parts[0]->filter_fused_batches;
+}
 
 void sqlrs_hash_agg_destroy(sqlrs_hash_agg_t *a) { delete a; }
 
@@ -1183,7 +1300,7 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bo
                     j->rkeys[0].nodes.size() == 1 && j->lkeys[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
                     j->rkeys[0].nodes[0].op == SQLRS_EXPR_INPUT_REF && a->group_by.size() == 1 &&
                     a->group_by[0].nodes.size() == 1 && a->group_by[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
-                    a->distinct_aggs.empty() && !a->strong_keys && right->num_rows >= (1ll << 16);
+                    a->distinct_aggs.empty() && a->parts.empty() && !a->strong_keys && right->num_rows >= (1ll << 16);
     if (eligible) {
       int lc = j->lkeys[0].nodes[0].index, rc = j->rkeys[0].nodes[0].index, g = a->group_by[0].nodes[0].index;
       eligible = (g == lc || g == ja->nleft + rc);

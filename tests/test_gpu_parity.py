@@ -387,6 +387,36 @@ def test_hash_agg_partition_route(hip, oracle, n, groups, nulls):
     assert_same(got, exp, float_cols={2, 5})
 
 
+@pytest.mark.parametrize("shape", ["one_batch", "batches", "with_filter"])
+def test_hash_agg_wide_aggregate_list(hip, oracle, shape):
+    """More than two argument columns / more accumulator cells than one partition-route operator carries (TPC-H Q1's
+    SUM(a), SUM(b), SUM(c), AVG parts, COUNT(*) ...): the operator runs as several parts with the same GROUP BY and
+    disjoint aggregates, whose columns line up by first-seen order — no row of it takes the row route's global
+    atomics.  Against the oracle, column for column in the order the aggregates were given."""
+    rng = np.random.default_rng(len(shape))
+    n, groups = 2_400_000, 40_000
+    spec = [("i64", 0.02, 0, groups), ("f64", 0.05, 0, 1), ("i64", 0.0, -1000, 1000), ("f64", 0.0, -5, 5), ("i64", 0.1, 0, 50)]
+    aggs = [AggFunc("sum", InputRef(1), abi.FLOAT64), AggFunc("count", InputRef(4), abi.INT64), AggFunc("sum", InputRef(2), abi.INT64),
+            AggFunc("min", InputRef(3), abi.FLOAT64), AggFunc("max", InputRef(3), abi.FLOAT64), AggFunc("sum", InputRef(3), abi.FLOAT64),
+            AggFunc("count", InputRef(1), abi.INT64), AggFunc("max", InputRef(4), abi.INT64), AggFunc("min", InputRef(2), abi.INT64),
+            AggFunc("sum", InputRef(4), abi.INT64)]
+    if shape == "batches":
+        bs = [batch(rng, 3000, spec), batch(rng, n, spec), batch(rng, 70_000, spec)]
+    else:
+        bs = [batch(rng, n, spec)]
+    pf = (InputRef(3) > Constant(-1.0, abi.FLOAT64)) if shape == "with_filter" else None
+    hip.profile(True)
+    ex = HashAggExecutor(hip, aggs, [InputRef(0)], bs, child_filter=pf)
+    got = rows_of(ex.execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    if os.environ.get("SQLRS_AGG_SPLIT") != "0" and shape == "one_batch":  # (the other shapes stage / filter below the route's size)
+        assert prof.get("lds_agg", (0, 0))[1] >= 2 and prof.get("agg_update", (0, 0))[1] == 0, prof
+    kept = list(FilterExecutor(oracle, pf, bs).execute()) if pf is not None else bs
+    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], kept).execute())
+    assert_same(got, exp, float_cols={1, 4, 5, 6})
+
+
 def test_hash_agg_mixed_routes_multi_batch(hip, oracle):
     rng = np.random.default_rng(77)
     spec = [("i64", 0.05, 0, 5000), ("f64", 0.0, 0, 1)]
