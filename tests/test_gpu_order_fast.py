@@ -79,3 +79,28 @@ def test_order_fast_route_ab_hooks(hip, oracle, hooks, monkeypatch):
     (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(0), asc=True)], [b]).execute())
     (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=True)], [b]).execute())
     assert got.equals(exp)
+
+
+@pytest.mark.parametrize("shape", ["sample_holds", "outlier_low", "outlier_high", "sorted"])
+@pytest.mark.parametrize("asc", [True, False])
+def test_order_fast_optimistic_key_range(hip, oracle, shape, asc, monkeypatch):
+    """Columns of >= 2^24 rows take their key range from a SAMPLE (every 16th chunk of 2048 rows + the last rows) and the
+    first split pass tests every key against it; forced at test size by SQLRS_ORDER_SAMPLE=1 (read per call).  An outlier
+    in a chunk the sample does not read must send the call through the exact pass once (two order_minmax launches)."""
+    monkeypatch.setenv("SQLRS_ORDER_SAMPLE", "1")
+    rng = np.random.default_rng(len(shape) + asc)
+    k = rng.integers(1 << 20, 1 << 30, N, dtype=np.int64)
+    if shape == "outlier_low":
+        k[2048 * 3 + 7] = -5
+    elif shape == "outlier_high":
+        k[2048 * 21 + 100] = (1 << 31) + 12345
+    elif shape == "sorted":
+        k = np.sort(k)
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(np.arange(N, dtype=np.int64))], names=["k", "row"])
+    hip.profile(True)
+    (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
+    assert got.column(0).equals(exp.column(0)) and got.column(1).equals(exp.column(1))
+    assert prof.get("order_minmax", (0, 0))[1] == (2 if shape.startswith("outlier") else 1), prof
