@@ -306,7 +306,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     const uint64_t *__restrict__ bk, const uint8_t *__restrict__ bf, const uint32_t *__restrict__ bbstart,
     KeyPack kp, SplitTables stb) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
-  __shared__ unsigned int s_cnt;
+  __shared__ unsigned int s_cnt, s_join_fail;
   __shared__ unsigned long long s_base;
   const uint32_t b = work[4 * blockIdx.x];
   const int64_t lo = work[4 * blockIdx.x + 1];
@@ -332,9 +332,14 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
       tacc[(size_t)a * nslots + s] = acc_identity_cell(code_of(a) & 7);
     }
   }
-  if (threadIdx.x == 0) s_cnt = 0;
+  if (threadIdx.x == 0) {
+    s_cnt = 0;
+    s_join_fail = 0;
+  }
   __syncthreads();
   if (JOIN) {
+    // (a failed attempt is abandoned as a whole: once any workgroup has reported, the rest return at once)
+    if (*(volatile unsigned long long *)(ov_count + 1) != 0) return;
     const int64_t blo = bbstart[b], bhi = bbstart[b + 1];
     for (int64_t i = blo + threadIdx.x; i < bhi; i += PART_WG) {
       uint64_t key = bk[i];
@@ -342,25 +347,31 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
       // a key seen twice = duplicate build keys: the caller's pre-condition does not hold (it may not have been
       // established yet, join_state.hpp `unique_known`): flag it, the caller falls back to the composed route
       if (!valid) {
-        if (atomicExch(&tkey[cap], 1ull) != LDS_EMPTY) atomicExch(ov_count + 1, 1ull); // NULL build key present (NULL = NULL matches)
+        if (atomicExch(&tkey[cap], 1ull) != LDS_EMPTY) s_join_fail = 1; // NULL build key present (NULL = NULL matches)
       } else if (key == LDS_EMPTY) {
-        if (atomicExch(&tkey[cap + 1], 1ull) != LDS_EMPTY) atomicExch(ov_count + 1, 1ull);
+        if (atomicExch(&tkey[cap + 1], 1ull) != LDS_EMPTY) s_join_fail = 1;
       } else {
         uint32_t s = slot_hash(key) & mask;
         uint32_t probes = 0;
         while (true) {
           unsigned long long prev = atomicCAS(&tkey[s], LDS_EMPTY, (unsigned long long)key);
-          if (prev == key) atomicExch(ov_count + 1, 1ull);
+          if (prev == key) s_join_fail = 1;
           if (prev == LDS_EMPTY || prev == key) break;
           s = (s + 1) & mask;
           if (++probes >= cap) {
-            atomicExch(ov_count + 1, 1ull); // table too small for the build side: caller falls back
+            s_join_fail = 1; // table too small for the build side: caller falls back
             break;
           }
         }
       }
     }
     __syncthreads();
+    // one report per workgroup (every duplicate used to exchange the global flag itself: 5e5 duplicate keys = 6 ms of
+    // same-address atomics in an attempt that was going to be thrown away), and nothing more to do for this bucket
+    if (s_join_fail) {
+      if (threadIdx.x == 0) atomicExch(ov_count + 1, 1ull);
+      return;
+    }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
   for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {

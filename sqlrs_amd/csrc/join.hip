@@ -957,6 +957,10 @@ static void build_table(sqlrs_hash_join *j) {
           j->dense_null_head = hd[1];
           return;
         }
+        // fewer occupied slots than valid keys (or several NULL keys, which match each other): the build keys are NOT
+        // unique — a fact the fused join+aggregate need not discover again by inserting them into its bucket tables
+        j->unique = false;
+        j->unique_known = true;
       }
     }
   }
