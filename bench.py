@@ -276,6 +276,9 @@ def algorithmic_bytes(kernel, w):
 
 def main():
     args = parse()
+    # (read when the HSA runtime starts, i.e. before the first HIP call of this process and of the ranks it launches:
+    #  the host driver only supports dmabuf IPC, RCCL's peer buffers fail with the legacy mode)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
