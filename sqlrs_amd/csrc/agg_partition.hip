@@ -179,7 +179,20 @@ struct LdsAggParams {
   // dense (direct-addressed) fused join whose build keys do not cover their whole range: bit (key offset) = the key
   // has a build partner; null = every key of the range has one
   const unsigned long long *partner_bits;
+  // dense fused join over DUPLICATE build keys: build rows per key offset (0 = no partner); COUNT / SUM cells of a slot
+  // are multiplied by it when the slot is emitted
+  const unsigned int *partner_mult;
 };
+
+// cell of accumulator `kind` for a key that has `m` build rows (every probe row = m joined rows)
+__device__ __forceinline__ unsigned long long acc_times(int kind, unsigned long long cell, unsigned int m) {
+  switch (kind) {
+  case 0 /* AK_COUNT */:
+  case 1 /* AK_SUM_I64 */: return cell * (unsigned long long)m; // (wrapping, like m additions)
+  case 2 /* AK_SUM_F64 */: return (unsigned long long)__double_as_longlong(__longlong_as_double((long long)cell) * (double)m);
+  default: return cell;
+  }
+}
 
 __device__ __forceinline__ uint64_t acc_identity_cell(int kind) {
   return (kind == AK_MIN_I64 || kind == AK_MIN_F64) ? ~0ull : 0ull;
@@ -623,11 +636,13 @@ __global__ void split_emit_dense_kernel(SplitTables stb, const uint32_t *__restr
     }
   }
   if (first == 0xffffffffu) return;
+  unsigned int mlt = 1;
+  if (prm.partner_mult) mlt = prm.partner_mult[((uint64_t)split_bucket[t] << kp.rbits) + s]; // (> 0: the chunk tables hold partners only)
   unsigned long long base = atomicAdd(out_count, 1ull);
   if ((int64_t)base >= gcap) return;
   gkey[base] = kp.kmin + ((uint64_t)split_bucket[t] << kp.rbits) + s;
   gfirst[base] = first;
-  for (int a = 0; a < n_acc; a++) gacc[(size_t)a * gcap + base] = acc[a];
+  for (int a = 0; a < n_acc; a++) gacc[(size_t)a * gcap + base] = prm.partner_mult ? acc_times(prm.code[a] & 7, acc[a], mlt) : acc[a];
 }
 
 template <int NV, bool JOIN, int NACC, int C0, int C1, bool REC = false>
@@ -732,12 +747,13 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
     cur = nxt;
   }
   __syncthreads();
-  if (JOIN && prm.partner_bits) { // build keys with gaps: a slot whose key has no build partner is not a group
+  if (JOIN && (prm.partner_bits || prm.partner_mult)) { // build keys with gaps: a slot whose key has no build partner is not a group
     const uint64_t off0 = (uint64_t)b << kp.rbits; // (a multiple of 64 or R < 64: rbits >= 8)
     for (uint32_t s = threadIdx.x; s < R; s += PART_WG) { // (the slots this thread stores / counts below)
       if (tfirst[s] == 0xffffffffu) continue;
       const uint64_t o = off0 + s;
-      if (!((prm.partner_bits[o >> 6] >> (o & 63)) & 1ull)) tfirst[s] = 0xffffffffu;
+      const bool partner = prm.partner_mult ? prm.partner_mult[o] != 0 : (((prm.partner_bits[o >> 6] >> (o & 63)) & 1ull) != 0);
+      if (!partner) tfirst[s] = 0xffffffffu;
     }
   }
   if (split != 0xffffffffu) { // chunk of a split bucket: its table goes out as chunk table `split` (split_emit_dense_kernel reduces)
@@ -766,10 +782,12 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
     if ((int64_t)base < gcap) {
       gkey[base] = key0 + s;
       gfirst[base] = first;
+      const unsigned int mlt = (JOIN && prm.partner_mult) ? prm.partner_mult[((uint64_t)b << kp.rbits) + s] : 1u;
 #pragma unroll
       for (int a = 0; a < PART_MAX_ACC; a++) {
         if (a >= n_acc) break;
-        gacc[(size_t)a * gcap + base] = tacc[(size_t)a * R + s];
+        const unsigned long long cell = tacc[(size_t)a * R + s];
+        gacc[(size_t)a * gcap + base] = (JOIN && prm.partner_mult) ? acc_times(code_of(a) & 7, cell, mlt) : cell;
       }
     }
     base++;
@@ -922,9 +940,9 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     // every value of the range; otherwise: at most ~4 slots per group
     // (with the existence bitmap of the range — the join's direct-address table — gaps are fine: <= 16 slots per key)
     const bool fills = join_mode ? (in.join_unique_known && (range + 1 == (uint64_t)in.join_n ||
-                                                             (in.join_bits && in.join_range_known && range / 16 <= (uint64_t)in.join_n)))
+                                                             ((in.join_bits || in.join_mult) && in.join_range_known && range / 16 <= (uint64_t)in.join_n)))
                                  : ((double)range + 1.0 <= 4.0 * est);
-    partner_bits = (join_mode && fills && range + 1 != (uint64_t)in.join_n) ? in.join_bits : nullptr;
+    partner_bits = (join_mode && fills && !in.join_mult && range + 1 != (uint64_t)in.join_n) ? in.join_bits : nullptr;
     if (fills && pd <= 65536 && (double)pd <= 1.5 * std::max(1.0, std::ceil(want))) {
       dense = true;
       kp.dense = 1;
@@ -934,6 +952,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
       want = (double)pd;
     }
   }
+  if (join_mode && in.join_mult && !dense) return false; // duplicate build keys: the direct-addressed route or nothing
   if (want > 65536.0) return false; // too many groups: resolve path
   uint32_t P = (uint32_t)std::max(1.0, std::ceil(want));
   out->est_groups = est;
@@ -1025,6 +1044,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   }
   prm.cap = cap;
   prm.partner_bits = dense ? (const unsigned long long *)partner_bits : nullptr;
+  prm.partner_mult = (dense && join_mode) ? in.join_mult : nullptr;
   int64_t gcap = (int64_t)std::min<double>((double)n, est * 1.5 + 65536.0 + 2.0 * P);
   if (dense) gcap = (int64_t)std::min<uint64_t>((uint64_t)n, join_mode ? (uint64_t)in.join_n : kp.range + 1); // one group per key of the range (build key) at most
   size_t lds = dense ? round_up((size_t)cap * (slot_bytes - 8), 16) : round_up((size_t)(cap + 2) * slot_bytes, 16);

@@ -44,6 +44,11 @@ struct PartAggInput {
   // table, join_state.hpp): lets the direct-addressed route run when the unique build keys do NOT cover their whole
   // range — a slot is a group only where the bit is set.  Requires join_range_known and join_unique_known.
   const uint64_t *join_bits = nullptr;
+  // DUPLICATE build keys over [join_omin, join_omax] (no NULL key): build rows per key offset (u32, 0 = none).  Every
+  // probe row then stands for that many joined rows: the direct-addressed route aggregates the probe rows as usual and
+  // multiplies COUNT / SUM cells by the key's multiplicity when a slot is emitted (MIN / MAX are unaffected; the
+  // first-seen order is the probe rows').  Only that route: the call returns false when it does not apply.
+  const uint32_t *join_mult = nullptr;
   // FilterExecutor directly below (fused join only): rows failing `filter` do not exist for the
   // operator.  Evaluated by the chunked first partition level; when that level does not apply the
   // call returns false and the caller runs the Filter operator first.

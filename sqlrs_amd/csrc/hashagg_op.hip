@@ -508,6 +508,7 @@ struct JoinSide {
   bool range_known = false; // omin / omax: signed-order images of the smallest / largest valid key
   uint64_t omin = 0, omax = 0;
   const uint64_t *bits = nullptr; // existence bitmap over [omin, omax] (PartAggInput::join_bits)
+  const uint32_t *mult = nullptr; // duplicate build keys: build rows per key of [omin, omax] (PartAggInput::join_mult)
 };
 
 // Consumes one batch given its evaluated key / argument columns: partition route when it
@@ -600,6 +601,7 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
           pin.join_omin = js->omin;
           pin.join_omax = js->omax;
           pin.join_bits = js->bits;
+          pin.join_mult = js->mult;
         }
         if (rf) pin.filter = *rf;
         PartAggOutput po;
@@ -1296,7 +1298,9 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bo
     // has a build partner): the joined batch is never materialised.
     // (a join whose hash table is still deferred has not established uniqueness: the fused bucket pass inserts the
     //  build keys itself and reports duplicates — the attempt then fails and the table is built after all)
-    bool eligible = (j->unique || !j->unique_known) && j->exact && j->lkeys.size() == 1 && j->lkeys[0].nodes.size() == 1 &&
+    // (duplicate build keys over a dense range: the direct-addressed route takes a multiplicity per key)
+    const bool dup_dense = j->unique_known && !j->unique && j->dup_range && !j->bkeys_validity;
+    bool eligible = (j->unique || !j->unique_known || dup_dense) && j->exact && j->lkeys.size() == 1 && j->lkeys[0].nodes.size() == 1 &&
                     j->rkeys[0].nodes.size() == 1 && j->lkeys[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
                     j->rkeys[0].nodes[0].op == SQLRS_EXPR_INPUT_REF && a->group_by.size() == 1 &&
                     a->group_by[0].nodes.size() == 1 && a->group_by[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
@@ -1341,7 +1345,14 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bo
         js.n = j->nB;
         js.cache = &ja->build_parts;
         js.unique_known = j->unique_known;
-        if (j->dense && j->dense_range) { // the direct-address table's key range
+        if (dup_dense) {
+          js.mult = hash_join_dup_mult(j);
+          js.unique_known = true; // (what the route needs of uniqueness — one slot per key — the multiplicities restore)
+          js.range_known = js.mult != nullptr;
+          js.omin = j->dup_min ^ (1ull << 63);
+          js.omax = js.omin + (j->dup_range - 1);
+          js.cache = nullptr; // (no build-side partition on this route)
+        } else if (j->dense && j->dense_range) { // the direct-address table's key range
           js.range_known = true;
           js.omin = j->dense_min ^ (1ull << 63);
           js.omax = js.omin + (j->dense_range - 1);

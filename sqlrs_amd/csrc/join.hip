@@ -961,6 +961,10 @@ static void build_table(sqlrs_hash_join *j) {
         // unique — a fact the fused join+aggregate need not discover again by inserting them into its bucket tables
         j->unique = false;
         j->unique_known = true;
+        if (hc[1] == 0 && !validity) { // (no NULL key: the fused join+aggregate can take multiplicities per key, hash_join_dup_mult)
+          j->dup_min = dmin;
+          j->dup_range = range;
+        }
       }
     }
   }
@@ -1282,6 +1286,22 @@ static void apply_filter(sqlrs_hash_join *j, const DBatch &right, Pairs &p) {
   p.right = r2.own_values;
   p.left_validity = l2.own_validity;
   if (!p.left_validity && unv.count == 0 && lf.own_validity) p.left_validity = lf.own_validity;
+}
+
+__global__ void dup_mult_kernel(const uint64_t *__restrict__ keys, int64_t n, uint64_t kmin, uint32_t *__restrict__ mult) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r < n) atomicAdd(&mult[keys[r] - kmin], 1u);
+}
+const uint32_t *hash_join_dup_mult(sqlrs_hash_join *j) {
+  if (!j->dup_range || !j->bkeys || j->bkeys_validity) return nullptr;
+  if (!j->dup_mult) {
+    Ctx *ctx = j->ctx;
+    j->dup_mult = ctx->alloc_zero(4 * (size_t)j->dup_range + 8);
+    dup_mult_kernel<<<dim3((unsigned)ceil_div(j->nB, 256)), dim3(256), 0, ctx->stream>>>(j->bkeys->as<uint64_t>(), j->nB, j->dup_min,
+                                                                                      j->dup_mult->as<uint32_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  return j->dup_mult->as<uint32_t>();
 }
 
 const uint64_t *hash_join_dense_bits(sqlrs_hash_join *j) {

@@ -35,6 +35,10 @@ struct sqlrs_hash_join {
   uint64_t dense_min = 0, dense_range = 0;
   uint32_t dense_null_head = 0xffffffffu;
   sq::BufP dense_bits; // one bit per possible key of the direct-address table (key-only build side, join.hip)
+  // duplicate build keys over a dense range (no NULL key): the range the direct-address build found, and — on first
+  // need of the fused join+aggregate — how many build rows carry each key of it (u32 per key, 0 = none)
+  uint64_t dup_min = 0, dup_range = 0;
+  sq::BufP dup_mult;
   sq::BufP bkeys, bkeys_validity; // normalised build keys (u64[nB]) and their validity bitmap
   // general keys on LDS tables (join.hip, lds_join_match): the build keys in bucket order, built at the first probe
   // that takes the route; lds_slots = 0: the route does not apply to this build side
@@ -48,4 +52,7 @@ void hash_join_ensure_table(sqlrs_hash_join *j);
 // existence bitmap of a direct-address (`dense`) join: bit (key - dense_min) is set when the key has a build row
 // (join.hip, dense_bits_kernel); built once, on first need
 const uint64_t *hash_join_dense_bits(sqlrs_hash_join *j);
+// build rows per key of [dup_min, dup_min + dup_range) of a join with duplicate build keys over a dense range
+// (join.hip); null when the build side has no such range
+const uint32_t *hash_join_dup_mult(sqlrs_hash_join *j);
 }

@@ -1101,6 +1101,43 @@ def test_join_agg_group_by_build_columns(hip, oracle, shape):
     assert_same(got, exp, float_cols={len(gb) + 1, len(gb) + 3})
 
 
+@pytest.mark.parametrize("shape", ["pairs", "mixed_multiplicities_with_gaps", "hot", "with_filter", "sparse_range"])
+def test_join_agg_duplicate_build_keys(hip, oracle, shape):
+    """Join + group-by on the join key with DUPLICATE build keys over a dense range: every probe row stands for m joined rows
+    (m = build rows with its key), so the direct-addressed route aggregates the probe rows as for unique keys and multiplies
+    COUNT / SUM cells by m when a slot is emitted (MIN / MAX unaffected, first-seen order = the probe rows').  Must equal
+    HashAgg(HashJoin(..)) on the oracle.  `sparse_range` (1 key in 40 of the range): no dense range, composed route."""
+    from sqlrs_amd.executor import HashJoinAggExecutor
+    rng = np.random.default_rng(len(shape))
+    nkeys, npb, base = 400_000, 2_300_000, 1 << 33
+    if shape == "pairs":
+        mult = np.full(nkeys, 2)
+    else:
+        mult = rng.integers(0, 4, nkeys)  # 0 = a gap in the range
+        mult[0] = mult[-1] = 1
+    stride = 40 if shape == "sparse_range" else 1
+    lkeys = rng.permutation(np.repeat(base + np.arange(nkeys, dtype=np.int64) * stride, mult))
+    lb = pa.RecordBatch.from_arrays([pa.array(lkeys), pa.array(rng.integers(0, 9, len(lkeys), dtype=np.int64))], names=["k", "x"])
+    pk = base + rng.integers(-500, nkeys + 500, npb, dtype=np.int64) * stride
+    if shape == "hot":
+        pk[rng.random(npb) < 0.4] = lkeys[3]
+        pk[rng.random(npb) < 0.1] = base + int(np.nonzero(mult == 0)[0][2])  # heavy hitter inside a gap
+    rb = pa.RecordBatch.from_arrays([pa.array(pk), pa.array(rng.random(npb)), pa.array(rng.integers(-9, 9, npb, dtype=np.int64))], names=["k", "v", "w"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64), AggFunc("min", InputRef(3), abi.FLOAT64)]
+    aggs2 = [AggFunc("sum", InputRef(4), abi.INT64), AggFunc("max", InputRef(4), abi.INT64)]
+    pf = (InputRef(1) > Constant(0.3, abi.FLOAT64)) if shape == "with_filter" else None
+    kept = list(FilterExecutor(oracle, pf, [rb]).execute()) if pf is not None else [rb]
+    for ag, fl in ((aggs, {2, 3}), (aggs2, set())):
+        ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, ag, [InputRef(0)], probe_filter=pf)
+        got = rows_of(ex.execute())
+        if os.environ.get("SQLRS_DENSE_AGG") != "0":
+            assert ex.fused_batches == (0 if shape == "sparse_range" else 1)
+        exp = _join_agg_reference(oracle, [lb], kept, cond, sch, 2, ag, [InputRef(0)])
+        assert_same(got, exp, float_cols=fl)
+
+
 @pytest.mark.parametrize("keep_one_in", [2, 8, 24])
 @pytest.mark.parametrize("hot", [False, True])
 def test_join_agg_build_keys_with_gaps(hip, oracle, keep_one_in, hot):

@@ -137,7 +137,7 @@ def sweep3():
     for label, lk, rk, gb in (("join_agg dense unique keys, group by join key (fused)", dimk, pk, [InputRef(0)]),
                               ("join_agg sparse unique keys (fused, hashed buckets)", dimk * 1_000_003, pk * 1_000_003, [InputRef(0)]),
                               ("join_agg group by build payload (eager aggregation)", dimk, pk, [InputRef(1)]),
-                              ("join_agg duplicate build keys (composed)", dimk // 2, pk // 2, [InputRef(0)])):
+                              ("join_agg duplicate build keys (fused, multiplicities)", dimk // 2, pk // 2, [InputRef(0)])):
         lb, rb = dev([lk, (lk % 1000)]), dev([rk, pv])
         timed(label, lambda: HashJoinAggExecutor(be, [lb], [rb], on, sch, 2, aggs, gb, out_mem=D).execute(), n)
         lb.release(); rb.release()
