@@ -25,7 +25,7 @@ exchange + merge the partial aggregates; the line times the other strategy too (
 Output: ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel:
 HIP-event time per launch measured live on the ctx stream; and the operator-level pipeline figure),
 `cpu_baseline` (all-core CPU port + the single-threaded restatement of the reference, on bounded samples),
-and at N = 1 `c5_variants` (sparse keys, three operators, GROUP BY a dim attribute) and `operators` (C2 / C3 / C4 / Order).
+and at N = 1 `c5_variants` (sparse keys, three operators, duplicate build keys, GROUP BY a dim attribute) and `operators` (C2 / C3 / C4 / Order).
 Every result is checked per group before it is timed.
 """
 from __future__ import annotations
@@ -739,6 +739,21 @@ def bench_variants(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim
     out.release()
     ms = timed(pipe, db, fb, 3, 1)
     res["three_operators"] = {"ms_per_step": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1), "check": "OK" if ok else msg}
+    be.fn("ctx_pool_trim")(be.ctx)
+    # ---- duplicate build keys: half of the dim keys appear twice (1.5e7 build rows, a many-to-many join grouped by its key)
+    dim2 = torch.cat([dim_key, dim_key[: n_dim // 2]])
+    has2 = torch.bincount(dim2, minlength=n_dim)
+    torch.cuda.synchronize()
+    pipe = Pipeline(be, abi, args.threshold, fused=True)
+    db, fb = batches(dim2, fact_key, fact_val)
+    out = pipe.step(db(), fb())
+    be.synchronize()
+    ok, groups, rows, msg = check_groups(torch, None, dev, out, exp_cnt, exp_sum, has2)
+    out.release()
+    ms = timed(pipe, db, fb, 3, 1)
+    res["duplicate_build_keys"] = {"ms_per_step": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1), "build_rows": int(dim2.numel()),
+                                   "joined_rows": rows, "fused_route": bool(pipe.fused_batches), "check": "OK" if ok else msg}
+    del dim2, has2
     be.fn("ctx_pool_trim")(be.ctx)
     # ---- GROUP BY a dim ATTRIBUTE: SELECT d.region, COUNT(f.val), SUM(f.val) ... GROUP BY d.region (region = key mod 1000)
     res["group_by_dim_attribute"] = bench_group_by_attribute(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim,
