@@ -16,11 +16,14 @@ the fused HashJoinAgg operator with the Filter handed to it (sqlrs_join_agg_set_
 
 N > 1 (one process per GPU, launched by torch.distributed.run): the TOTAL input is fixed
 ("scaling": "strong"); every rank generates a contiguous 1/N slice of fact and dim.  Default
-strategy = north_star's partitioned hash join: Filter below the exchange, dim and kept fact rows
-hash-partitioned on the join key (sqlrs_hash_partition) and exchanged with RCCL all-to-alls in
-overlapped chunks (sqlrs_amd/distributed.py), local HashJoinAgg on what arrives (group key = join key,
-so the per-rank results are disjoint).  `--exchange broadcast` = all-gather the dim, aggregate locally,
-exchange + merge the partial aggregates; the line times the other strategy too (`exchange.alternative`).
+strategy (`combine`) = north_star's partitioned hash join with the partial aggregation below the exchange: the dim
+is hash-partitioned on the join key (sqlrs_hash_partition) and exchanged with an RCCL all-to-all, every rank
+pre-aggregates its fact slice by key (HashAgg with the Filter handed to it), the partial aggregates are
+hash-partitioned + exchanged the same way and merged by HashJoinAgg(dim partition, partials) on the owning
+rank (group key = join key, so the per-rank results are disjoint).  `--exchange partition` = the row form (Filter
+below the exchange, kept fact ROWS partitioned and exchanged in overlapped chunks, local HashJoinAgg);
+`--exchange broadcast` = all-gather the dim, aggregate locally, exchange + merge the partial aggregates; the line
+times the other two strategies too (`exchange.alternative`, `exchange.alternative2`).
 
 Output: ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel:
 HIP-event time per launch measured live on the ctx stream; and the operator-level pipeline figure),
@@ -62,11 +65,14 @@ def parse():
     p.add_argument("--threshold", type=float, default=0.5, help="WHERE f.val > threshold")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=float, default=0, help="0 = auto (about 10-30 s)")
-    p.add_argument("--exchange", choices=["auto", "partition", "broadcast"], default="auto",
-                   help="N>1: 'partition' = hash-partition fact AND dim on the join key + all-to-all (partitioned "
-                        "hash join); 'broadcast' = all-gather the dim keys, aggregate the local fact slice, then "
-                        "hash-partition + all-to-all only the partial aggregates and merge; 'auto' = partition "
-                        "(north_star's partitioned hash join)")
+    p.add_argument("--exchange", choices=["auto", "combine", "partition", "broadcast"], default="auto",
+                   help="N>1: 'partition' = hash-partition the kept fact ROWS and the dim on the join key + all-to-all "
+                        "(partitioned hash join, every kept row crosses xGMI); 'combine' = the same partitioned join with the "
+                        "group-by's partial aggregation pushed below the exchange: the dim is hash-partitioned + exchanged, "
+                        "every rank pre-aggregates its fact slice by key (Filter fused), the partial aggregates are "
+                        "hash-partitioned + exchanged and merged by the join on the owning rank; 'broadcast' = all-gather the "
+                        "dim keys instead of partitioning them, join + aggregate the local fact slice, exchange + merge the "
+                        "partial aggregates; 'auto' = combine")
     p.add_argument("--force-exchange", action="store_true",
                    help="N=1 only: run the multi-GPU code path (RCCL process group of ONE rank, fused filter + hash "
                         "partition, all-to-all, stream hand-over, local HashJoinAgg) instead of the single-GPU step; "
@@ -303,7 +309,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    json_fd = None
     if multi:
+        # RCCL prints its version banner on STDOUT when the first communicator comes up: rank 0's stdout must hold the
+        # JSON line and nothing else, so file descriptor 1 points at stderr from here on and the line goes to a copy
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:  # --force-exchange without a launcher: a rendezvous of one
@@ -359,7 +371,10 @@ def main():
 
     strategy = args.exchange
     if strategy == "auto":
-        strategy = "partition"  # north_star: build AND probe side hash-partitioned on the join key, RCCL all-to-all
+        # north_star: build AND probe side hash-partitioned on the join key, RCCL all-to-all — with the probe side
+        # pre-aggregated by key below the exchange (1e7 partial groups per rank instead of 5e8 / N kept rows: at
+        # N = 2 the row form moves 2 GB per rank over ONE xGMI link, several times the local work)
+        strategy = "combine"
     pipe.partial = multi and strategy == "broadcast"
     dim_sizes = [D_shard(n_dim_total, r, world) for r in range(world)]
     merge_gb, _mk = abi.pack_exprs([InputRef(0)])
@@ -477,6 +492,69 @@ def main():
         be.synchronize()
         return out
 
+    # partial aggregation of a rank's fact slice: HashAgg[GROUP BY key; COUNT(val), SUM(val)](Filter(fact)), any group order
+    from sqlrs_amd.expr import Constant as _Constant
+    _part_pred = (InputRef(1) > _Constant(args.threshold, abi.FLOAT64)).pack()
+    _part_gb, _pk1 = abi.pack_exprs([InputRef(0)])
+    _pkeep = []
+    _part_aggs = (abi.AggFunc * 2)(_AggFunc("count", InputRef(1), abi.INT64).abi_struct(_pkeep),
+                                   _AggFunc("sum", InputRef(1), abi.FLOAT64).abi_struct(_pkeep))
+    # merge on the owning rank: HashJoinAgg(dim partition, partials) GROUP BY d.key; SUM(count), SUM(sum) — the Inner
+    # join drops the keys without a build partner (joined schema: d.key | p.key, p.count, p.sum)
+    _m_lk, _mk1 = abi.pack_exprs([InputRef(0)])
+    _m_rk, _mk2 = abi.pack_exprs([InputRef(0)])
+    _m_gb, _mk3 = abi.pack_exprs([InputRef(0)])
+    _m_rd = (C.c_int32 * 3)(abi.INT64, abi.INT64, abi.FLOAT64)
+    _mkeep2 = []
+    _m_aggs = (abi.AggFunc * 2)(_AggFunc("sum", InputRef(2), abi.INT64).abi_struct(_mkeep2),
+                                _AggFunc("sum", InputRef(3), abi.FLOAT64).abi_struct(_mkeep2))
+
+    def step_combine():
+        # partitioned hash join, the group-by's partial aggregation below the exchange (eager aggregation across ranks):
+        # 1. dim keys hash-partitioned + exchanged  2. local HashAgg(Filter(fact slice)) by key = partial aggregates
+        # 3. partials hash-partitioned + exchanged  4. HashJoinAgg(dim partition, partials) merges and joins them
+        t0 = time.perf_counter()
+        dk, = exchange([[dim_key]], [abi.INT64], D_shard(n_dim_total, rank, world) * 2 + 1024)
+        if xstat["on"]:
+            torch.cuda.synchronize()
+            be.synchronize()
+            xstat["exchange_ms"] += (time.perf_counter() - t0) * 1e3
+        a = C.c_void_p()
+        be.check(be.fn("hash_agg_create")(be.ctx, 1, _part_gb, 2, _part_aggs, C.byref(a)))
+        be.check(be.fn("hash_agg_set_group_order")(a, abi.GROUP_ORDER_ANY))
+        be.check(be.fn("hash_agg_set_filter")(a, C.byref(_part_pred.abi)))
+        fb = device_batch(abi, [fact_key, fact_val], [abi.INT64, abi.FLOAT64])
+        be.check(be.fn("hash_agg_push")(a, fb.ptr))
+        po = C.POINTER(abi.Batch)()
+        be.check(be.fn("hash_agg_finish")(a, abi.MEM_DEVICE, C.byref(po)))
+        be.fn("hash_agg_destroy")(a)
+        part = be.wrap(po)
+        g = part.num_rows
+        cols = [_tensor_view(torch, part.column(i).values, g, t, dev)
+                for i, t in enumerate((torch.int64, torch.int64, torch.float64))]
+        t0 = time.perf_counter()
+        rk, rc, rs = exchange([cols], [abi.INT64, abi.INT64, abi.FLOAT64], g + 1024)
+        if xstat["on"]:
+            torch.cuda.synchronize()
+            be.synchronize()
+            xstat["exchange_ms"] += (time.perf_counter() - t0) * 1e3
+        part.release()
+        ja = C.c_void_p()
+        be.check(be.fn("join_agg_create")(be.ctx, 1, _m_lk, _m_rk, 1, 3, _m_rd, 1, _m_gb, 2, _m_aggs, C.byref(ja)))
+        # a global first-seen order does not exist across ranks: no ordering pass
+        be.check(be.fn("join_agg_set_group_order")(ja, abi.GROUP_ORDER_ANY))
+        db = device_batch(abi, [dk], [abi.INT64])
+        mb = device_batch(abi, [rk, rc, rs], [abi.INT64, abi.INT64, abi.FLOAT64])
+        be.check(be.fn("join_agg_build_push")(ja, db.ptr))
+        be.check(be.fn("join_agg_build_finish")(ja))
+        be.check(be.fn("join_agg_probe_push")(ja, mb.ptr))
+        ao = C.POINTER(abi.Batch)()
+        be.check(be.fn("join_agg_finish")(ja, abi.MEM_DEVICE, C.byref(ao)))
+        pipe.fused_batches = be.fn("join_agg_fused_batches")(ja)
+        be.fn("join_agg_destroy")(ja)
+        be.synchronize()
+        return be.wrap(ao)
+
     def step_broadcast():
         # 1. replicate the small build side  2. local Filter -> HashJoinAgg = PARTIAL aggregates
         t0 = time.perf_counter()
@@ -513,7 +591,7 @@ def main():
     def one_step():
         if multi:
             xstat["steps"] += 1
-            return step_broadcast() if strategy == "broadcast" else step_partition()
+            return step_broadcast() if strategy == "broadcast" else step_combine() if strategy == "combine" else step_partition()
         out = pipe.step(device_batch(abi, [dim_key], [abi.INT64]),
                         device_batch(abi, [fact_key, fact_val], [abi.INT64, abi.FLOAT64]))
         be.synchronize()
@@ -580,28 +658,29 @@ def main():
                          "note": "rank 0, two profiled steps with a sync behind the exchange phase (filter + partition "
                                  "kernels + collectives, chunk k's all-to-all overlapping chunk k+1's kernels); split "
                                  "sizes travel over a gloo side group; xGMI link peak 153 GB/s"}
-        # the other strategy, timed with the same wall clock over fewer steps (never the headline value)
-        alt = "broadcast" if strategy == "partition" else "partition"
-        try:
-            main_strategy, strategy = strategy, alt
-            pipe.partial = strategy == "broadcast"
-            o = one_step()
-            ok_alt, _, _, msg_alt = check_groups(torch, dist, dev, o, exp_cnt, exp_sum, has_dim)
-            o.release()
-            barrier()
-            t_alt = time.perf_counter()
-            for _ in range(max(2, args.steps // 4)):
-                one_step().release()
-            barrier()
-            el_alt = torch.tensor([time.perf_counter() - t_alt], dtype=torch.float64, device=dev)
-            dist.all_reduce(el_alt, op=dist.ReduceOp.MAX)
-            exchange_info["alternative"] = {"strategy": alt, "ms_per_step": round(el_alt.item() / max(2, args.steps // 4) * 1e3, 3),
-                                            "check": "OK" if ok_alt else msg_alt}
-        except Exception as e:  # the alternative is informational: it must never take the headline line down
-            exchange_info["alternative"] = {"strategy": alt, "error": repr(e)[:300]}
-        finally:
-            strategy = main_strategy
-            pipe.partial = strategy == "broadcast"
+        # the other strategies, timed with the same wall clock over fewer steps (never the headline value)
+        main_strategy = strategy
+        for slot, alt in zip(("alternative", "alternative2"), [x for x in ("partition", "broadcast", "combine") if x != main_strategy]):
+            try:
+                strategy = alt
+                pipe.partial = strategy == "broadcast"
+                o = one_step()
+                ok_alt, _, _, msg_alt = check_groups(torch, dist, dev, o, exp_cnt, exp_sum, has_dim)
+                o.release()
+                barrier()
+                t_alt = time.perf_counter()
+                for _ in range(max(2, args.steps // 4)):
+                    one_step().release()
+                barrier()
+                el_alt = torch.tensor([time.perf_counter() - t_alt], dtype=torch.float64, device=dev)
+                dist.all_reduce(el_alt, op=dist.ReduceOp.MAX)
+                exchange_info[slot] = {"strategy": alt, "ms_per_step": round(el_alt.item() / max(2, args.steps // 4) * 1e3, 3),
+                                       "check": "OK" if ok_alt else msg_alt}
+            except Exception as e:  # the alternatives are informational: they must never take the headline line down
+                exchange_info[slot] = {"strategy": alt, "error": repr(e)[:300]}
+            finally:
+                strategy = main_strategy
+                pipe.partial = strategy == "broadcast"
     workload = {"fact_rows": f_hi - f_lo, "dim_rows": d_hi - d_lo, "selectivity": expected_kept / max(f_hi - f_lo, 1),
                 "matches": expected_kept, "groups": out_groups_local}
     if multi:  # after the exchange every rank holds about 1/N of everything
@@ -669,6 +748,10 @@ def main():
                        "parallelism": ("single GPU" if not multi else
                                        f"x{world}: all-gather dim, local partial aggregation, all-to-all of partial aggregates, merge"
                                        if strategy == "broadcast" else
+                                       f"x{world}: partitioned hash join, partial aggregation below the exchange — dim hash-partitioned on the "
+                                       "join key + RCCL all-to-all; HashAgg(Filter(fact slice)) by key on every rank; partial aggregates "
+                                       "hash-partitioned + RCCL all-to-all; HashJoinAgg(dim partition, partials) on the owning rank"
+                                       if strategy == "combine" else
                                        f"x{world}: partitioned hash join — Filter below the exchange, fact + dim hash-partitioned on "
                                        f"the join key, RCCL all-to-all in {n_chunks} overlapped chunks, local HashJoinAgg"
                                        + ("; Filter + partition fused in one pass (sqlrs_hash_partition_filter)" if fused_exchange else ""))},
@@ -683,7 +766,11 @@ def main():
             line["c5_variants"] = variants
         if exchange_info:
             line["exchange"] = exchange_info
-        print(json.dumps(line), flush=True)
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line), flush=True)
     if multi:
         dist.destroy_process_group()
 

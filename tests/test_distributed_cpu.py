@@ -64,6 +64,42 @@ def merge_partials(oracle, keys, cnt, sm):
             np.array(o.column(2).to_pylist(), dtype=np.float64))
 
 
+def local_partials(oracle, fact_key, fact_val):
+    """a rank's partial aggregation below the exchange: HashAgg[GROUP BY key; COUNT(val), SUM(val)](Filter(fact slice))"""
+    import pyarrow as pa
+    from sqlrs_amd import abi
+    from sqlrs_amd.executor import FilterExecutor, HashAggExecutor
+    from sqlrs_amd.expr import AggFunc, Constant, InputRef
+    fact = pa.RecordBatch.from_arrays([pa.array(fact_key), pa.array(fact_val)], names=["key", "val"])
+    filt = FilterExecutor(oracle, InputRef(1) > Constant(0.5, abi.FLOAT64), [fact])
+    outs = list(HashAggExecutor(oracle, [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64)],
+                                [InputRef(0)], filt.execute()).execute())
+    if not outs:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0)
+    o = outs[0]
+    return (np.array(o.column(0).to_pylist(), dtype=np.int64), np.array(o.column(1).to_pylist(), dtype=np.int64),
+            np.array(o.column(2).to_pylist(), dtype=np.float64))
+
+
+def merge_join(oracle, dim_key, keys, cnt, sm):
+    """the owning rank's merge: HashAgg[GROUP BY d.key; SUM(count), SUM(sum)](HashJoin(dim partition, partials))"""
+    import pyarrow as pa
+    from sqlrs_amd import abi
+    from sqlrs_amd.executor import HashAggExecutor, HashJoinExecutor
+    from sqlrs_amd.expr import AggFunc, InputRef, JoinCondition
+    dim = pa.RecordBatch.from_arrays([pa.array(dim_key)], names=["key"])
+    part = pa.RecordBatch.from_arrays([pa.array(keys), pa.array(cnt), pa.array(sm)], names=["k", "c", "s"])
+    schema = pa.schema([("d.key", pa.int64()), ("p.k", pa.int64()), ("p.c", pa.int64()), ("p.s", pa.float64())])
+    join = HashJoinExecutor(oracle, [dim], [part], "inner", JoinCondition([(InputRef(0), InputRef(0))]), schema, 1)
+    outs = list(HashAggExecutor(oracle, [AggFunc("sum", InputRef(2), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64)],
+                                [InputRef(0)], join.execute()).execute())
+    if not outs:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0)
+    o = outs[0]
+    return (np.array(o.column(0).to_pylist(), dtype=np.int64), np.array(o.column(1).to_pylist(), dtype=np.int64),
+            np.array(o.column(2).to_pylist(), dtype=np.float64))
+
+
 def worker(rank, world, port, result_path, strategy="partition"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -119,6 +155,13 @@ def worker(rank, world, port, result_path, strategy="partition"):
         keys, cnt, sm = merge_partials(oracle, rk, rc, rs)
         fk = fact_key[f_lo:f_hi]
         dk = dim_key[d_lo:d_hi]
+    elif strategy == "combine":
+        # partitioned join with the partial aggregation below the exchange (bench.py: step_combine)
+        (dk,) = exchange([dim_key[d_lo:d_hi]])
+        pk, pc, ps = local_partials(oracle, fact_key[f_lo:f_hi], fact_val[f_lo:f_hi])
+        fk, rc, rs = exchange([pk, pc, ps], chunks=2)
+        assert (D.partition_of(dk, world) == rank).all() and (D.partition_of(fk, world) == rank).all()
+        keys, cnt, sm = merge_join(oracle, dk, fk, rc, rs)
     else:
         (dk,) = exchange([dim_key[d_lo:d_hi]])
         if strategy == "partition_fused":  # Filter below the exchange, fused into the partition step
@@ -139,7 +182,8 @@ def worker(rank, world, port, result_path, strategy="partition"):
         all_keys = np.concatenate([g[0] for g in gathered])
         all_cnt = np.concatenate([g[1] for g in gathered])
         all_sum = np.concatenate([g[2] for g in gathered])
-        assert sum(g[3] for g in gathered) == (N_FACT if strategy != "partition_fused" else int((fact_val > 0.5).sum()))
+        if strategy != "combine":  # (combine exchanges partial groups, not rows)
+            assert sum(g[3] for g in gathered) == (N_FACT if strategy != "partition_fused" else int((fact_val > 0.5).sum()))
         assert sum(g[4] for g in gathered) == N_DIM
         assert len(np.unique(all_keys)) == len(all_keys), "per-rank results must be disjoint"
         ek, ec, es = local_pipeline(oracle, dim_key, fact_key, fact_val)  # single process
@@ -159,7 +203,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("strategy", ["partition", "partition_fused", "broadcast"])
+@pytest.mark.parametrize("strategy", ["partition", "partition_fused", "broadcast", "combine"])
 def test_partitioned_join_groupby_world2_gloo(tmp_path, strategy):
     result = tmp_path / "result.txt"
     mp.spawn(worker, args=(2, free_port(), str(result), strategy), nprocs=2, join=True)
