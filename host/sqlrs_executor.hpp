@@ -624,11 +624,12 @@ struct HashJoinAggExecutor {
   std::optional<BoundExpr> probe_filter; // indexes the right child's schema
   std::vector<std::string> output_names;
   int64_t *fused_batches = nullptr, *filter_fused_batches = nullptr; // diagnostics, filled after the stream ends
+  int64_t *eager_groups = nullptr; // partial groups re-aggregated by build-side GROUP BY columns (0 = route not taken)
 
   BoxedExecutor execute() {
     struct S : Executor {
       HipCtxRef ctx; BoxedExecutor left, right; sqlrs_join_agg_t *ja = nullptr; std::vector<std::string> names; bool done = false;
-      int64_t *fused = nullptr, *ffused = nullptr;
+      int64_t *fused = nullptr, *ffused = nullptr, *eager = nullptr;
       ~S() override { if (ja) sqlrs_join_agg_destroy(ja); }
       std::optional<RecordBatch> next() override {
         if (done) return std::nullopt;
@@ -640,6 +641,7 @@ struct HashJoinAggExecutor {
         ctx->check(sqlrs_join_agg_finish(ja, SQLRS_MEM_HOST, &out)); // hash_agg.rs:124-149
         if (fused) *fused = sqlrs_join_agg_fused_batches(ja);
         if (ffused) *ffused = sqlrs_join_agg_filter_fused_batches(ja);
+        if (eager) *eager = sqlrs_join_agg_eager_groups(ja);
         RecordBatch rb = detail::import_batch(out, nullptr);
         auto sch = std::make_shared<Schema>(*rb.schema);
         for (size_t i = 0; i < sch->size() && i < names.size(); i++) (*sch)[i].name = names[i];
@@ -649,7 +651,7 @@ struct HashJoinAggExecutor {
     };
     auto s = std::make_unique<S>();
     s->ctx = ctx; s->left = std::move(left_child); s->right = std::move(right_child); s->names = output_names;
-    s->fused = fused_batches; s->ffused = filter_fused_batches;
+    s->fused = fused_batches; s->ffused = filter_fused_batches; s->eager = eager_groups;
     if (join_condition.on.empty()) throw ExecutorError(ExecutorError::InternalError, "HashJoin must has on condition");
     std::vector<detail::Lowered> lk, rk, gl, al;
     std::vector<sqlrs_expr_t> lke, rke, ge;
