@@ -259,7 +259,16 @@ void sqlrs_hash_join_destroy(sqlrs_hash_join_t *j);
 typedef struct sqlrs_hash_agg sqlrs_hash_agg_t;
 int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t *group_by,
                           int num_aggs, const sqlrs_agg_func_t *aggs, sqlrs_hash_agg_t **out);
-/* [ref: hash_agg.rs:44-122] */
+/* [ref: hash_agg.rs:44-122]
+ * BLOCKING operators (this one, sqlrs_join_agg_probe_push, sqlrs_order_push, sqlrs_hash_join_build_push) decide when
+ * to work: small HOST batches of fixed-width columns — the reference's 1024-row CSV batches — are appended to a host
+ * staging area (one memcpy) and uploaded together once per 2^22 rows or at *_finish; device batches are staged by
+ * reference.  Consequence for error reporting: an error that only the evaluation of a batch reveals (an expression
+ * over a column of the wrong type, "Divide by zero error", a schema that differs from the first batch's) is returned
+ * by the call that works on the staged rows — a LATER push or *_finish — not necessarily by the push that delivered
+ * the batch; the operator is unusable after an error either way (destroy it), exactly like the reference's stream,
+ * which ends at its first Err.  A wide aggregate list (more than two argument columns) runs as several internal
+ * operators that each see every batch. */
 int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in);
 /* [ref: hash_agg.rs:124-149]; with no pushed batch the reference panics (:125):
  * here that is SQLRS_ERR_INTERNAL. */
@@ -392,8 +401,9 @@ int sqlrs_csv_open(sqlrs_ctx_t *ctx, const char *path, int has_header, char deli
 int sqlrs_csv_num_columns(const sqlrs_csv_t *r);
 const char *sqlrs_csv_column_name(const sqlrs_csv_t *r, int i);
 int sqlrs_csv_column_dtype(const sqlrs_csv_t *r, int i);
-/* Bounds (offset, limit) of the scan over the data records, limit < 0 = none [ref: csv.rs:207-215];
- * call before the first next_batch */
+/* Bounds (offset, limit) of the scan over the data records, limit < 0 = none [ref: csv.rs:207-223]; a file
+ * WITHOUT a header yields limit + 1 records, as the reference does (its (offset, offset + limit + 1) line bounds meet
+ * arrow-csv's line counter, which starts one later only when there is a header); call before the first next_batch */
 int sqlrs_csv_set_bounds(sqlrs_csv_t *r, int64_t offset, int64_t limit);
 /* Projections: indices into the file's columns [ref: csv.rs:224] */
 int sqlrs_csv_set_projection(sqlrs_csv_t *r, int num_columns, const int32_t *columns);

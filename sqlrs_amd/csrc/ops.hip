@@ -298,7 +298,19 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
         const bool want_perm = all.cols.size() > (size_t)(cc >= 0 ? 2 : 1);
         DCol ko, co;
         BufP fperm;
-        if (order_fast(ctx, all.cols[(size_t)kc], o->asc[0] ? 0 : 1, cc >= 0 ? &all.cols[(size_t)cc] : nullptr, n, &ko, &co, &fperm, want_perm)) {
+        // (the fast route holds ~48 B of scratch per row, the general path ~24: when the pool cannot give the former,
+        //  the ORDER still runs — an allocation failure of the attempt is "route not taken", nothing was produced)
+        bool fast = false;
+        try {
+          fast = order_fast(ctx, all.cols[(size_t)kc], o->asc[0] ? 0 : 1, cc >= 0 ? &all.cols[(size_t)cc] : nullptr, n, &ko, &co, &fperm, want_perm);
+        } catch (const Error &e) {
+          if (e.status != SQLRS_ERR_DEVICE || e.msg.rfind("hipMalloc(", 0) != 0) throw;
+          (void)hipGetLastError(); // (clears the sticky out-of-memory error code)
+          ko = DCol();
+          co = DCol();
+          fperm = nullptr;
+        }
+        if (fast) {
           DBatch r;
           r.rows = n;
           for (size_t ci = 0; ci < all.cols.size(); ci++) {

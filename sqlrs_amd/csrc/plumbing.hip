@@ -166,6 +166,7 @@ struct sqlrs_csv {
   std::vector<int> projection; // indices into the file's columns
   uint64_t remaining = ~0ull;  // records still allowed by the bounds
   uint64_t line = 0;           // for error messages
+  bool has_header = true;
 };
 
 extern "C" {
@@ -382,6 +383,7 @@ int sqlrs_csv_open(sqlrs_ctx_t *ctx, const char *path, int has_header, char deli
     auto r = std::unique_ptr<sqlrs_csv>(new sqlrs_csv());
     r->ctx = ctx;
     r->delimiter = delimiter ? delimiter : ',';
+    r->has_header = has_header != 0;
     r->batch_size = batch_size > 0 ? batch_size : 1024;
     // pass 1: header + type inference over the first records (arrow-csv infer_reader_schema)
     std::ifstream probe(path, std::ios::binary);
@@ -428,7 +430,10 @@ int sqlrs_csv_set_bounds(sqlrs_csv_t *r, int64_t offset, int64_t limit) {
     std::vector<std::string> f;
     for (int64_t i = 0; i < offset; i++)
       if (!read_record(r->file, r->delimiter, f)) break;
-    r->remaining = limit < 0 ? ~0ull : (uint64_t)limit;
+    // csv.rs:216-223 turns (offset, limit) into arrow-csv's line bounds (offset, offset + limit + 1), and arrow-csv 28
+    // starts its line counter at offset + 1 only when the file has a header: a headerless scan yields limit + 1
+    // records (the LimitExecutor above trims the batch either way)
+    r->remaining = limit < 0 ? ~0ull : (uint64_t)limit + (r->has_header ? 0 : 1);
   });
 }
 int sqlrs_csv_set_projection(sqlrs_csv_t *r, int num_columns, const int32_t *columns) {

@@ -50,6 +50,12 @@ def test_csv_dialect_batches_bounds_projection(hip, tmp_path):
     # bounds = (offset, limit) over the records, projection = column indices (csv.rs:207-224)
     _, part = read_all(CsvScan(hip, str(p), bounds=(1000, 30), projection=[3, 0]))
     assert part.column(1).to_pylist() == list(range(1000, 1030)) and part.column(0)[0].as_py() == "s,1000"
+    # a file WITHOUT a header yields limit + 1 records: csv.rs:216-223 hands arrow-csv the line bounds
+    # (offset, offset + limit + 1) and arrow-csv 28 starts its line counter one later only when there is a header
+    q = tmp_path / "nohdr.csv"
+    q.write_text("\n".join(f"{i},{i * 2}" for i in range(100)) + "\n")
+    _, nh = read_all(CsvScan(hip, str(q), has_header=False, bounds=(10, 5)))
+    assert nh.column(0).to_pylist() == list(range(10, 16))
     # straight into HBM
     dev = list(CsvScan(hip, str(p), out_mem=abi.MEM_DEVICE).execute())
     assert [d.num_rows for d in dev] == [1024, 1024, 452]
