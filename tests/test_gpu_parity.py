@@ -51,6 +51,30 @@ def rows_of(batches):
     return [tuple(r) for r in out]
 
 
+def table_of(batches):
+    """the batches concatenated into one pyarrow Table, for `assert_same_table` (tests with millions of groups: row tuples
+    in Python were most of their run time)"""
+    batches = list(batches)
+    return pa.Table.from_batches(batches) if batches else None
+
+
+def assert_same_table(got, exp, float_cols=()):
+    if got is None or exp is None:
+        assert (got is None or got.num_rows == 0) and (exp is None or exp.num_rows == 0)
+        return
+    assert got.num_rows == exp.num_rows, f"{got.num_rows} rows, expected {exp.num_rows}"
+    assert got.num_columns == exp.num_columns
+    for i in range(got.num_columns):
+        g, e = got.column(i).combine_chunks(), exp.column(i).combine_chunks()
+        if i in float_cols:
+            assert g.is_null().equals(e.is_null()), i
+            a, b = g.fill_null(0).to_numpy(zero_copy_only=False), e.fill_null(0).to_numpy(zero_copy_only=False)
+            bad = np.abs(a - b) > REL_TOL * np.maximum(np.abs(b), 1e-300)
+            assert not bad.any(), (i, int(bad.argmax()), a[bad.argmax()], b[bad.argmax()])  # SUM(double): 1e-9 relative
+        else:
+            assert g.equals(e), i
+
+
 def assert_same(got, exp, float_cols=()):
     assert len(got) == len(exp)
     for g, e in zip(got, exp):
@@ -382,9 +406,9 @@ def test_hash_agg_partition_route(hip, oracle, n, groups, nulls):
     aggs = [AggFunc("count", InputRef(2), abi.INT64), AggFunc("sum", InputRef(2), abi.FLOAT64),
             AggFunc("sum", InputRef(1), abi.INT64), AggFunc("min", InputRef(1), abi.INT64),
             AggFunc("max", InputRef(2), abi.FLOAT64)]
-    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
-    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
-    assert_same(got, exp, float_cols={2, 5})
+    got = table_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
+    exp = table_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
+    assert_same_table(got, exp, float_cols={2, 5})
 
 
 @pytest.mark.parametrize("shape", ["one_batch", "batches", "with_filter"])
@@ -407,14 +431,14 @@ def test_hash_agg_wide_aggregate_list(hip, oracle, shape):
     pf = (InputRef(3) > Constant(-1.0, abi.FLOAT64)) if shape == "with_filter" else None
     hip.profile(True)
     ex = HashAggExecutor(hip, aggs, [InputRef(0)], bs, child_filter=pf)
-    got = rows_of(ex.execute())
+    got = table_of(ex.execute())
     prof = hip.profile_read()
     hip.profile(False)
     if os.environ.get("SQLRS_AGG_SPLIT") != "0" and shape == "one_batch":  # (the other shapes stage / filter below the route's size)
         assert prof.get("lds_agg", (0, 0))[1] >= 2 and prof.get("agg_update", (0, 0))[1] == 0, prof
     kept = list(FilterExecutor(oracle, pf, bs).execute()) if pf is not None else bs
-    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], kept).execute())
-    assert_same(got, exp, float_cols={1, 4, 5, 6})
+    exp = table_of(HashAggExecutor(oracle, aggs, [InputRef(0)], kept).execute())
+    assert_same_table(got, exp, float_cols={1, 4, 5, 6})
 
 
 def test_hash_agg_mixed_routes_multi_batch(hip, oracle):
@@ -465,9 +489,9 @@ def test_hash_agg_distinct(hip, oracle, n, groups, nulls):
 
 
 # ------------------------------------------------------------ fused HashJoin + HashAgg --
-def _join_agg_reference(oracle, lbs, rbs, cond, sch, nleft, aggs, gb):
+def _join_agg_reference(oracle, lbs, rbs, cond, sch, nleft, aggs, gb, as_table=False):
     join = HashJoinExecutor(oracle, lbs, rbs, "inner", cond, sch, nleft)
-    return rows_of(HashAggExecutor(oracle, aggs, gb, join.execute()).execute())
+    return (table_of if as_table else rows_of)(HashAggExecutor(oracle, aggs, gb, join.execute()).execute())
 
 
 @pytest.mark.parametrize("nb,np_,keyrange,nulls,group_on_left", [
@@ -1022,9 +1046,9 @@ def test_hash_agg_dense_key_route(hip, oracle, shape, aggs_kind):
         aggs = []
         fl = set()
     b = pa.RecordBatch.from_arrays([pa.array(keys), v], names=["k", "v"])
-    got = rows_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
-    exp = rows_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
-    assert_same(got, exp, float_cols=fl)
+    got = table_of(HashAggExecutor(hip, aggs, [InputRef(0)], [b]).execute())
+    exp = table_of(HashAggExecutor(oracle, aggs, [InputRef(0)], [b]).execute())
+    assert_same_table(got, exp, float_cols=fl)
 
 
 @pytest.mark.parametrize("nb,base", [(40_000, 0), (300_000, -1234), (1_100_000, 1 << 35)])
@@ -1047,10 +1071,10 @@ def test_join_agg_dense_build_keys(hip, oracle, nb, base, hot):
     sch = join_schema(lb, rb)
     aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64)]
     ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
-    got = rows_of(ex.execute())
+    got = table_of(ex.execute())
     assert ex.fused_batches == 1
-    exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
-    assert_same(got, exp, float_cols={2})
+    exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)], as_table=True)
+    assert_same_table(got, exp, float_cols={2})
 
 
 @pytest.mark.parametrize("shape", ["dense_dim_region", "sparse_dim_two_columns", "nullable", "key_and_attribute",
@@ -1063,7 +1087,7 @@ def test_join_agg_group_by_build_columns(hip, oracle, shape):
     below the route's size keep the composed route."""
     from sqlrs_amd.executor import HashJoinAggExecutor
     rng = np.random.default_rng(len(shape))
-    nb, npb = 300_000, 2_400_000
+    nb, npb = 300_000, 900_000
     if shape == "sparse_dim_two_columns":
         lkeys = (rng.permutation(nb).astype(np.int64) * 1_000_003 + 17)
     else:
@@ -1091,14 +1115,14 @@ def test_join_agg_group_by_build_columns(hip, oracle, shape):
         rbs = [rb.slice(0, npb // 3), rb.slice(npb // 3)]
     pf = (InputRef(0) > Constant(0.25, abi.FLOAT64)) if shape in ("dense_dim_region", "key_and_attribute") else None
     ex = HashJoinAggExecutor(hip, [lb], rbs, cond, sch, 3, aggs, gb, probe_filter=pf)
-    got = rows_of(ex.execute())
+    got = table_of(ex.execute())
     if shape == "duplicate_build_keys":
         assert ex.eager_groups == 0
     elif shape not in ("small_batches", "no_match") and os.environ.get("SQLRS_EAGER_AGG") != "0":
         assert ex.eager_groups > 0 and ex.fused_batches >= 1
     kept = list(FilterExecutor(oracle, pf, rbs).execute()) if pf is not None else rbs
-    exp = _join_agg_reference(oracle, [lb], kept, cond, sch, 3, aggs, gb)
-    assert_same(got, exp, float_cols={len(gb) + 1, len(gb) + 3})
+    exp = _join_agg_reference(oracle, [lb], kept, cond, sch, 3, aggs, gb, as_table=True)
+    assert_same_table(got, exp, float_cols={len(gb) + 1, len(gb) + 3})
 
 
 @pytest.mark.parametrize("shape", ["pairs", "mixed_multiplicities_with_gaps", "hot", "with_filter", "sparse_range"])
@@ -1109,7 +1133,7 @@ def test_join_agg_duplicate_build_keys(hip, oracle, shape):
     HashAgg(HashJoin(..)) on the oracle.  `sparse_range` (1 key in 40 of the range): no dense range, composed route."""
     from sqlrs_amd.executor import HashJoinAggExecutor
     rng = np.random.default_rng(len(shape))
-    nkeys, npb, base = 400_000, 2_300_000, 1 << 33
+    nkeys, npb, base = 150_000, 700_000, 1 << 33
     if shape == "pairs":
         mult = np.full(nkeys, 2)
     else:
@@ -1131,11 +1155,11 @@ def test_join_agg_duplicate_build_keys(hip, oracle, shape):
     kept = list(FilterExecutor(oracle, pf, [rb]).execute()) if pf is not None else [rb]
     for ag, fl in ((aggs, {2, 3}), (aggs2, set())):
         ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, ag, [InputRef(0)], probe_filter=pf)
-        got = rows_of(ex.execute())
+        got = table_of(ex.execute())
         if os.environ.get("SQLRS_DENSE_AGG") != "0":
             assert ex.fused_batches == (0 if shape == "sparse_range" else 1)
-        exp = _join_agg_reference(oracle, [lb], kept, cond, sch, 2, ag, [InputRef(0)])
-        assert_same(got, exp, float_cols=fl)
+        exp = _join_agg_reference(oracle, [lb], kept, cond, sch, 2, ag, [InputRef(0)], as_table=True)
+        assert_same_table(got, exp, float_cols=fl)
 
 
 @pytest.mark.parametrize("keep_one_in", [2, 8, 24])
@@ -1147,7 +1171,7 @@ def test_join_agg_build_keys_with_gaps(hip, oracle, keep_one_in, hot):
     the existence bitmap of the range has its bit (probe keys in a gap have no partner).  1 key in 24: hashed
     buckets, as before.  `hot`: heavy hitters with and without partner (split buckets store their chunk tables)."""
     from sqlrs_amd.executor import HashJoinAggExecutor
-    nrange, npb, base = 1_600_000, 2_300_000, -777
+    nrange, npb, base = 1_600_000, 800_000, -777
     rng = np.random.default_rng(keep_one_in + hot)
     present = rng.random(nrange) < 1.0 / keep_one_in
     present[0] = present[-1] = True
@@ -1163,15 +1187,15 @@ def test_join_agg_build_keys_with_gaps(hip, oracle, keep_one_in, hot):
     aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64)]
     hip.profile(True)
     ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
-    got = rows_of(ex.execute())
+    got = table_of(ex.execute())
     prof = hip.profile_read()
     hip.profile(False)
     assert ex.fused_batches == 1
     direct = prof.get("join_build_dense", (0, 0))[1] > 0 and prof.get("rp_scatter_build", (0, 0))[1] == 0
     if os.environ.get("SQLRS_DENSE_AGG") != "0":
         assert direct == (keep_one_in <= 16), prof
-    exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)])
-    assert_same(got, exp, float_cols={2})
+    exp = _join_agg_reference(oracle, [lb], [rb], cond, sch, 2, aggs, [InputRef(0)], as_table=True)
+    assert_same_table(got, exp, float_cols={2})
 
 
 @pytest.mark.gpu

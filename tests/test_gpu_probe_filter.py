@@ -237,9 +237,9 @@ def test_chunked_first_level_forced():
         pytest.skip("already inside the forced run")
     env = dict(os.environ, SQLRS_RP_CHUNKED="1", SQLRS_STAGE_DIRECT_ROWS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "(chunked and not forced and ((count_sum and (val_gt_half or ((other_ne or key_ge or val_lt_none) and False))) "
-                              "or hot_digit or (hash_agg_chunked and dense) or without_chunk_histograms)) "
-                              "or (child_filter and (val_gt_half or key_ge) and (dense_two_level or sparse))"], env=env, capture_output=True,
+                        "-k", "(chunked and not forced and ((count_sum and (val_gt_half or (key_ge and False))) "
+                              "or (hot_digit and 0.3) or (hash_agg_chunked and dense) or (without_chunk_histograms and False))) "
+                              "or (child_filter and val_gt_half and (dense_two_level or sparse))"], env=env, capture_output=True,
                        text=True, timeout=1700)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     # (the same level with SQLRS_RP_H2=0 — level 2 running its own histogram pass — is part of that run:
