@@ -309,11 +309,72 @@ constexpr int JD_ITEMS = JD_ITEMS_N;
 constexpr int JD_TILE = JD_WAVES * JD_ITEMS * 64;
 constexpr int JD_BLOCK = (JD_WAVES + 1) * 64;
 
+// ---- every probe row has a partner (the PK-FK join): no compaction ---------------------------------------------
+// Pair i of an Inner join whose probe rows ALL match unique build keys is (heads[key[i] - kmin], i): the output
+// position is the row number, so the tile counts, the look-back chain and the two barriers of the kernel below
+// have nothing to decide.  This kernel does exactly the memory work of the probe — the key stream, one table
+// lookup per key, the pair stores (what tools/ubench.hip's composite measures: 0.689 ms per 1e8 rows on a 3.8 MiB
+// table, the floor of §4.2) — OPTIMISTICALLY: a row without partner raises `miss`, and join_probe_dense_kernel
+// (launched right behind, a no-op while the flag is clear) redoes the batch with compaction.  A sample of ~16 K rows
+// is tested first, so a probe with many misses costs two empty launches, not an attempt; one with a rare miss pays
+// for the attempt (0.7 of the compacting kernel's time) once.
+constexpr int JA_ILP = 16; // independent table loads in flight per lane
+// rows `every` apart (a sample of the batch): a probe with many misses is recognised before the attempt starts
+__global__ void join_probe_dense_sample_kernel(const uint64_t *__restrict__ keys, int64_t n, int64_t every, DenseTable dt,
+                                               unsigned int *__restrict__ miss) {
+  const int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * every;
+  if (r >= n) return;
+  const uint64_t d = keys[r] - dt.kmin;
+  if (dt.heads[min(d, dt.range + 1)] == DENSE_EMPTY) atomicOr(miss, 1u); // (heads[range + 1]: padding, always empty)
+}
+// thread t of the grid takes rows t, t + S, t + 2 S, ... (S = threads of the grid), JA_ILP of them per trip: the shape of
+// the composite micro-benchmark (per-wave contiguous chunks with clamped tails measured 9 % slower, 0.755 vs 0.69 ms)
+template <bool SC1>
+__global__ __launch_bounds__(256) void join_probe_dense_allhit_kernel(const uint64_t *__restrict__ keys, int64_t n, DenseTable dt,
+                                                                      uint64_t *__restrict__ left_idx,
+                                                                      uint32_t *__restrict__ right_idx,
+                                                                      unsigned int *__restrict__ miss) {
+  if (*(volatile unsigned int *)miss) return; // (the sample met a row without partner: no attempt)
+  const int64_t S = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool bad = false;
+  for (; i + (JA_ILP - 1) * S < n; i += JA_ILP * S) {
+    uint64_t k[JA_ILP];
+#pragma unroll
+    for (int u = 0; u < JA_ILP; u++) k[u] = __builtin_nontemporal_load(keys + i + u * S);
+    uint32_t h[JA_ILP];
+#pragma unroll
+    for (int u = 0; u < JA_ILP; u++) { // (unconditional: heads[range + 1] is empty; SC1: agent-scope loads bypass the L1)
+      const uint32_t *hp = dt.heads + min(k[u] - dt.kmin, dt.range + 1);
+      h[u] = SC1 ? __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *hp;
+    }
+#pragma unroll
+    for (int u = 0; u < JA_ILP; u++) {
+      bad |= h[u] == DENSE_EMPTY;
+      __builtin_nontemporal_store((uint64_t)h[u], &left_idx[i + u * S]);
+      __builtin_nontemporal_store((uint32_t)(i + u * S), &right_idx[i + u * S]);
+    }
+  }
+  for (; i < n; i += S) { // the last, partial trip
+    const uint32_t h = dt.heads[min(keys[i] - dt.kmin, dt.range + 1)];
+    bad |= h == DENSE_EMPTY;
+    left_idx[i] = h;
+    right_idx[i] = (uint32_t)i;
+  }
+  if (__ballot(bad) && lane_id() == 0) atomicOr(miss, 1u);
+}
+
+// `skip_unless` (optional): the optimistic kernel above ran first — while its flag is clear every pair is in place
+// and this launch only publishes the total
 template <bool HASV>
 __global__ __launch_bounds__(JD_BLOCK, JD_OCC) void join_probe_dense_kernel(
     const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n, int64_t num_tiles,
     DenseTable dt, uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx, uint64_t *desc,
-    unsigned *ticket, uint64_t *total, int use_ticket) {
+    unsigned *ticket, uint64_t *total, int use_ticket, const unsigned int *__restrict__ skip_unless = nullptr) {
+  if (skip_unless && *skip_unless == 0) { // (uniform over the grid: read before any barrier or ticket)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total = (uint64_t)n;
+    return;
+  }
   unsigned *timeout = use_ticket ? nullptr : ticket + 1;
   __shared__ int64_t s_tile;
   __shared__ uint32_t s_wave[JD_WAVES];
@@ -1108,9 +1169,40 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     int64_t tiles = ceil_div(n, lm.ok ? LJ_RANGE : (j->dense ? JD_TILE : JP_TILE));
     p.left = ctx->alloc(8 * (size_t)n);
     p.right = ctx->alloc(4 * (size_t)n);
-    BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 16);
+    BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 24);
     unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
     uint64_t *tot = desc->as<uint64_t>() + tiles + 1;
+    // optimistic all-hit attempt of the direct-address probe (join_probe_dense_allhit_kernel); its miss flag sits behind
+    // the descriptors and is NOT cleared by a look-back rerun.  SQLRS_PROBE_ALLHIT=0 (read per call): never.
+    unsigned int *miss = nullptr;
+    {
+      const char *ah_e = std::getenv("SQLRS_PROBE_ALLHIT");
+      if (j->dense && !lm.ok && !pk.validity && n >= (1 << 16) && !j->probe_miss_seen && !(ah_e && std::atoi(ah_e) == 0)) {
+        miss = (unsigned int *)(desc->as<uint64_t>() + tiles + 2);
+        ProfScope ps(ctx, "join_probe_dense");
+        DenseTable dt{j->dense->as<uint32_t>(), j->dense_min, j->dense_range, j->dense_null_head};
+        const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * JA_ILP), 16 * (int64_t)ctx->num_cus);
+        const int64_t every = std::max<int64_t>(1, n >> 14); // ~16 K sampled rows
+        join_probe_dense_sample_kernel<<<dim3((unsigned)ceil_div(ceil_div(n, every), 256)), dim3(256), 0, ctx->stream>>>(
+            pk.keys->as<uint64_t>(), n, every, dt, miss);
+        const char *sc_e = std::getenv("SQLRS_PROBE_ALLHIT_SC1"); // A/B hook, read per call
+        if (sc_e && std::atoi(sc_e) == 1)
+          join_probe_dense_allhit_kernel<true><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, dt, p.left->as<uint64_t>(),
+                                                                                          p.right->as<uint32_t>(), miss);
+        else
+          join_probe_dense_allhit_kernel<false><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, dt, p.left->as<uint64_t>(),
+                                                                                           p.right->as<uint32_t>(), miss);
+        SQ_HIP(hipGetLastError());
+        const char *hc_e = std::getenv("SQLRS_PROBE_ALLHIT_HOSTCHECK"); // A/B hook, read per call (default on)
+        if (!(hc_e && std::atoi(hc_e) == 0)) {
+          if (ctx->fetch_value(miss) == 0) { // every pair is in place
+            p.m = n;
+            return p;
+          }
+          j->probe_miss_seen = true; // (later batches of this join go straight to the compacting kernel)
+        }
+      }
+    }
     for (int use_ticket = lookback_start_mode(ctx), attempt = 0; use_ticket < 2; use_ticket++, attempt++) {
       if (attempt) SQ_HIP(hipMemsetAsync(desc->p, 0, 8 * (size_t)tiles + 16, ctx->stream)); // rerun after a timeout
       {
@@ -1129,7 +1221,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
         else if (j->dense)
           join_probe_dense_kernel<false><<<gt, dim3(JD_BLOCK), 0, ctx->stream>>>(
               pk.keys->as<uint64_t>(), pk.validity, n, tiles, dt, p.left->as<uint64_t>(), p.right->as<uint32_t>(),
-              desc->as<uint64_t>(), ticket, tot, use_ticket);
+              desc->as<uint64_t>(), ticket, tot, use_ticket, miss);
         else
           join_probe_unique_kernel<false><<<gt, b, 0, ctx->stream>>>(
               pk.keys->as<uint64_t>(), pk.validity, n, tiles, (j->table ? j->table->as<Slot>() : nullptr), j->mask, dt,

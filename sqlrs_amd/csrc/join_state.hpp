@@ -34,6 +34,7 @@ struct sqlrs_hash_join {
   sq::BufP dense;              // direct-address table (u32 build row per key - dense_min) or null
   uint64_t dense_min = 0, dense_range = 0;
   uint32_t dense_null_head = 0xffffffffu;
+  bool probe_miss_seen = false; // a probe batch had a row without partner: no more optimistic all-hit attempts (join.hip)
   sq::BufP dense_bits; // one bit per possible key of the direct-address table (key-only build side, join.hip)
   // duplicate build keys over a dense range (no NULL key): the range the direct-address build found, and — on first
   // need of the fused join+aggregate — how many build rows carry each key of it (u32 per key, 0 = none)

@@ -183,6 +183,34 @@ def test_hash_join_indices(hip, oracle, jt):
     assert_same(rows_of(got), rows_of(exp))
 
 
+@pytest.mark.parametrize("shape", ["all_hit", "miss_in_the_last_row", "miss_in_the_first_row", "one_row_in_ten_misses", "hook_off"])
+def test_hash_join_dense_probe_all_hit_attempt(hip, oracle, shape, monkeypatch):
+    """Direct-address probe, Inner join, unique build keys: the optimistic all-hit kernel (pair i = (build row, i), no
+    compaction) runs first and the compacting kernel only redoes the batch when a probe row had no partner.  Index pairs
+    and joined batches against the oracle; a single miss anywhere must send the batch through the compacting kernel
+    (one launch of the class per kernel: 1 + 1, of which the second is a no-op while the flag is clear)."""
+    if shape == "hook_off":
+        monkeypatch.setenv("SQLRS_PROBE_ALLHIT", "0")
+    rng = np.random.default_rng(len(shape))
+    nb, npr = 50_000, 400_000
+    bk = rng.permutation(nb).astype(np.int64) + 1000
+    pk = rng.integers(1000, 1000 + nb, npr, dtype=np.int64)
+    if shape == "miss_in_the_last_row":
+        pk[-1] = 5
+    elif shape == "miss_in_the_first_row":
+        pk[0] = 1000 + nb + 7
+    elif shape == "one_row_in_ten_misses":
+        pk[rng.random(npr) < 0.1] = -3
+    lb = pa.RecordBatch.from_arrays([pa.array(bk), pa.array(bk * 3 + 1)], names=["k", "p"])
+    rb = pa.RecordBatch.from_arrays([pa.array(pk), pa.array(rng.random(npr))], names=["k", "v"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    for indices_only in (True, False):
+        got = table_of(HashJoinExecutor(hip, [lb], [rb], "inner", cond, sch, 2).execute(indices_only=indices_only))
+        exp = table_of(HashJoinExecutor(oracle, [lb], [rb], "inner", cond, sch, 2).execute(indices_only=indices_only))
+        assert_same_table(got, exp)
+
+
 @pytest.mark.parametrize("jt", ["inner", "left"])
 @pytest.mark.parametrize("nb,npr,forced", [(700, 9_000, True), (40_000, 1_200_000, True), (300_000, 4_400_000, False)])
 def test_hash_join_lds_tables_general_keys(hip, oracle, monkeypatch, jt, nb, npr, forced):
