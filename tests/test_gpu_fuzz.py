@@ -140,6 +140,8 @@ def test_fuzz_hash_agg_partition_route(hip, oracle, seed):
     two_cols = rng.random() < 0.5
     cand = pool if two_cols else pool[:4]
     picks = [cand[i] for i in rng.choice(len(cand), int(rng.integers(1, 4)), replace=False)]
+    if seed % 5 == 4:  # a wide aggregate list: three argument columns (the key column is the third), run as one-column parts
+        picks = [pool[i] for i in rng.choice(len(pool), int(rng.integers(4, 8)), replace=False)] + [("max", 0, abi.INT64), ("count", 0, abi.INT64)]
     aggs = [AggFunc(f, InputRef(c), t) for f, c, t in picks]
     fl = {1 + i for i, (f, c, t) in enumerate(picks) if f == "sum" and t == abi.FLOAT64}
     bs = [b] if rng.random() < 0.5 else [b.slice(0, n // 3), b.slice(n // 3)]
@@ -171,11 +173,13 @@ def test_fuzz_join_agg(hip, oracle, seed):
     if rng.random() < 0.3:
         aggs.append(AggFunc("sum", InputRef(1), abi.INT64))  # build-side argument: composed route
     gb = [InputRef(0)] if rng.random() < 0.5 else [InputRef(2)]
+    if seed % 4 == 3:  # GROUP BY a build-side payload column (eager aggregation when the build keys are unique), or key + payload
+        gb = [InputRef(1)] if rng.random() < 0.6 else [InputRef(0), InputRef(1)]
     rbs = _split(rng, rb)
     got = rows_of(HashJoinAggExecutor(hip, [lb], rbs, cond, sch, 2, aggs, gb).execute())
     join = HashJoinExecutor(oracle, [lb], rbs, "inner", cond, sch, 2)
     exp = rows_of(HashAggExecutor(oracle, aggs, gb, join.execute()).execute())
-    assert_same(got, exp, float_cols={2})
+    assert_same(got, exp, float_cols={len(gb) + 1})
 
 
 @pytest.mark.parametrize("seed", range(8 + _EXTRA // 20))
