@@ -378,7 +378,7 @@ static DBatch emit_pending(sqlrs_hash_agg *a) {
     iota_u32(ctx, perm->as<uint32_t>(), G);
     int bits = 1;
     while (bits < 64 && (1ull << bits) <= (uint64_t)std::max<int64_t>(a->rows_seen, 1)) bits++;
-    radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), G, 0, bits);
+    radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), G, 0, bits, true); // (first rows < rows_seen < 2^bits)
     if (!gather_columns_packed(ctx, o.cols, G, perm->as<uint32_t>(), G))
       for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
   }
@@ -1076,7 +1076,7 @@ static DBatch hash_agg_finish_device(sqlrs_hash_agg_t *a) {
       iota_u32(ctx, perm->as<uint32_t>(), G);
       int bits = 1;
       while (bits < 64 && (1ull << bits) <= (uint64_t)std::max<int64_t>(a->rows_seen, 1)) bits++;
-      radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), G, 0, bits);
+      radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), G, 0, bits, true); // (first rows < rows_seen < 2^bits)
       if (!gather_columns_packed(ctx, o.cols, G, perm->as<uint32_t>(), G))
         for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
     }

@@ -81,9 +81,11 @@ NKeys normalize_keys_strong(Ctx *ctx, const std::vector<DCol> &cols, int64_t row
 
 // ---- radix sort (sort.hip) ----------------------------------------------------------
 // Stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit).
-// Results are left in keys/vals (temporaries come from the pool).
+// Results are left in keys/vals (temporaries come from the pool).  `keys_below_end_bit`: the caller guarantees that no
+// key has a bit at or above end_bit set (row numbers below a known count) — the question "on which bytes do the keys
+// differ" (a pass over the keys + a host round trip) is then not asked: every byte of [begin_bit, end_bit) is sorted.
 void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int begin_bit,
-                      int end_bit);
+                      int end_bit, bool keys_below_end_bit = false);
 void iota_u32(Ctx *ctx, uint32_t *out, int64_t n);
 // order_fast.hip: ORDER BY one fixed-width key without NULLs, rows (key, one carried 8-byte column, row id)
 // travel through <= 2 HBM passes + an in-LDS finish; false = shape / data do not fit (general path)

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void rs_diff_kernel(const uint64_t *__restrict
 }
 
 void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int begin_bit,
-                      int end_bit) {
+                      int end_bit, bool keys_below_end_bit) {
   if (n <= 1 || end_bit <= begin_bit) return;
   if (n > 0xffffffffll) fail(SQLRS_ERR_INTERNAL, "radix sort: more than 2^32 rows");
   ProfScope ps(ctx, "radix_sort");
@@ -185,7 +185,10 @@ void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int b
   uint64_t varying = ~0ull, key0 = 0;
   // (below 2^22 rows a pass is launch-bound, ~35 us: the same as this question — kernel + host round trip — costs,
   //  and callers that know their keys' width pass it as end_bit)
-  if (end_bit - begin_bit > 16 && n >= (1 << 22)) {
+  if (keys_below_end_bit && begin_bit == 0 && end_bit <= 32) {
+    varying = (1ull << end_bit) - 1; // (all of it sorted, nothing above it: the packed form applies without asking)
+    key0 = 0;
+  } else if (end_bit - begin_bit > 16 && n >= (1 << 22)) {
     BufP diff = ctx->alloc_zero(16);
     unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 4 * (int64_t)ctx->num_cus);
     rs_diff_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(keys, n, diff->as<unsigned long long>());
