@@ -913,6 +913,9 @@ struct Pairs {
   int64_t m = 0;
   BufP left, right;   // u64[m], u32[m]
   BufP left_validity; // bitmap or null (Right/Full only)
+  // pair i = (some build row, probe row i) for EVERY probe row (the all-hit attempt succeeded): the probe side of the
+  // joined batch is the probe batch itself, nothing to gather
+  bool right_identity = false;
 };
 
 static NKeys eval_keys(Ctx *ctx, const std::vector<Expr> &exprs,
@@ -1197,6 +1200,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
         if (!(hc_e && std::atoi(hc_e) == 0)) {
           if (ctx->fetch_value(miss) == 0) { // every pair is in place
             p.m = n;
+            p.right_identity = true;
             return p;
           }
           j->probe_miss_seen = true; // (later batches of this join go straight to the compacting kernel)
@@ -1237,6 +1241,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   }
   if (j->unique && outer_right) { // exactly one pair per probe row
     p.m = n;
+    p.right_identity = true; // (pair i = (build row | NULL, probe row i))
     p.left = ctx->alloc(8 * (size_t)n);
     p.right = ctx->alloc(4 * (size_t)n);
     p.left_validity = ctx->alloc(bitmap_bytes(n));
@@ -1310,7 +1315,8 @@ static DBatch gather_pairs(sqlrs_hash_join *j, const DBatch &right, const Pairs 
       lkey_col = rkey_col = -1;
   }
   std::vector<DCol> rcols;
-  for (const DCol &c : right.cols) rcols.push_back(gather_column(ctx, c, p.right->p, false, nullptr, p.m));
+  for (const DCol &c : right.cols)
+    rcols.push_back(p.right_identity ? c : gather_column(ctx, c, p.right->p, false, nullptr, p.m));
   for (size_t c = 0; c < j->left.cols.size(); c++) {
     if ((int)c == lkey_col)
       out.cols.push_back(rcols[(size_t)rkey_col]);
@@ -1468,7 +1474,10 @@ static DBatch probe_batch(sqlrs_hash_join *j, InBatch &ib, Pairs *pairs_only) {
     *pairs_only = p;
     return DBatch();
   }
-  DBatch right = ib.materialize(false);
+  if (j->has_filter) p.right_identity = false; // (the join filter selects among the pairs)
+  // every probe row matched exactly once: the joined batch takes the probe columns as they are — shared when they
+  // are this library's own buffers (an upstream operator's output), copied once when the caller only lent them
+  DBatch right = ib.materialize(p.right_identity);
   if (j->has_filter) apply_filter(j, right, p);
   if ((j->join_type == SQLRS_JOIN_LEFT || j->join_type == SQLRS_JOIN_FULL) && p.m) {
     mark_bits_kernel<uint64_t><<<dim3((unsigned)ceil_div(p.m, 256)), dim3(256), 0, ctx->stream>>>(
