@@ -52,9 +52,16 @@ int sqlrs_filter_push(sqlrs_filter_t *f, const sqlrs_batch_t *in, int out_mem, s
     }
     DBatch o;
     o.rows = sel.count;
+    // every row passed: the output is the input (filter_record_batch of an all-true mask) — its columns are shared
+    // when they are this library's own buffers and copied once when the caller only lent them, not compacted
+    DBatch whole;
+    const bool keep_all = sel.count == rows && rows > 0;
+    if (keep_all) whole = ib.materialize(true);
     for (int i = 0; i < ib.num_columns(); i++) {
       if (i == fast_idx)
         o.cols.push_back(fast_col);
+      else if (keep_all)
+        o.cols.push_back(whole.cols[(size_t)i]);
       else
         o.cols.push_back(compact_column(ctx, ib.col(i), sel));
     }
