@@ -309,7 +309,18 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
         //  the ORDER still runs — an allocation failure of the attempt is "route not taken", nothing was produced)
         bool fast = false;
         try {
-          fast = order_fast(ctx, all.cols[(size_t)kc], o->asc[0] ? 0 : 1, cc >= 0 ? &all.cols[(size_t)cc] : nullptr, n, &ko, &co, &fperm, want_perm);
+          bool in_order = false;
+          fast = order_fast(ctx, all.cols[(size_t)kc], o->asc[0] ? 0 : 1, cc >= 0 ? &all.cols[(size_t)cc] : nullptr, n, &ko, &co, &fperm, want_perm,
+                            &in_order);
+          if (in_order) { // the rows arrived in the requested order (ties included: a stable sort is the identity)
+            for (DCol &c : all.cols) { // (columns of a retained push are only lent until this call returns: one copy)
+              if (c.stride == 0) c = materialize_scalar(ctx, c, n);
+              const bool borrowed = (c.values && !c.own_values) || (c.validity && !c.own_validity) || (c.offsets && !c.own_offsets);
+              if (borrowed) c = copy_column(ctx, c);
+            }
+            *out = emit_batch(ctx, std::move(all), out_mem);
+            return;
+          }
         } catch (const Error &e) {
           if (e.status != SQLRS_ERR_DEVICE || e.msg.rfind("hipMalloc(", 0) != 0) throw;
           (void)hipGetLastError(); // (clears the sticky out-of-memory error code)

@@ -90,6 +90,6 @@ void iota_u32(Ctx *ctx, uint32_t *out, int64_t n);
 // order_fast.hip: ORDER BY one fixed-width key without NULLs, rows (key, one carried 8-byte column, row id)
 // travel through <= 2 HBM passes + an in-LDS finish; false = shape / data do not fit (general path)
 bool order_fast(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, DCol *key_out, DCol *carry_out,
-                BufP *perm, bool want_perm);
+                BufP *perm, bool want_perm, bool *in_order = nullptr);
 
 } // namespace sq

@@ -103,4 +103,31 @@ def test_order_fast_optimistic_key_range(hip, oracle, shape, asc, monkeypatch):
     hip.profile(False)
     (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
     assert got.column(0).equals(exp.column(0)) and got.column(1).equals(exp.column(1))
-    assert prof.get("order_minmax", (0, 0))[1] == (2 if shape.startswith("outlier") else 1), prof
+    # (ascending keys ordered ascending: the sampled neighbour pairs show no inversion, the full test — a second scope of
+    #  the class — finds the rows in order and nothing is sorted: test_order_rows_already_in_order)
+    assert prof.get("order_minmax", (0, 0))[1] == (2 if shape.startswith("outlier") or (shape == "sorted" and asc) else 1), prof
+
+
+@pytest.mark.parametrize("shape", ["ascending_with_ties", "descending", "one_inversion_at_the_end", "one_inversion_between_samples"])
+def test_order_rows_already_in_order(hip, oracle, shape):
+    """ORDER BY over rows that arrive in the requested order is the identity (ties included): sampled neighbour pairs, then
+    every pair; a single inversion anywhere must send the rows through the sort (no order_split launch otherwise)."""
+    rng = np.random.default_rng(len(shape))
+    k = np.sort(rng.integers(0, 1 << 20, N, dtype=np.int64))   # ~1.3 rows per value: ties
+    asc = shape != "descending"
+    if not asc:
+        k = k[::-1].copy()
+    if shape == "one_inversion_at_the_end":
+        k[-1] = k[-2] - 1
+    elif shape == "one_inversion_between_samples":
+        k[700_003], k[700_004] = k[700_004] + 5, k[700_003]
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(np.arange(N, dtype=np.int64)), pa.array(rng.random(N))], names=["k", "row", "x"])
+    hip.profile(True)
+    (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(0), asc=asc)], [b.slice(0, N // 2), b.slice(N // 2)]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
+    for i in range(3):
+        assert got.column(i).equals(exp.column(i)), i
+    sorted_anyway = prof.get("order_split", (0, 0))[1] > 0 or prof.get("radix_sort", (0, 0))[1] > 0
+    assert sorted_anyway == shape.startswith("one_inversion"), prof
