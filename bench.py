@@ -1238,6 +1238,39 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     by = 16 * n + 16 * n  # read key + carried column, write both permuted (SURVEY.md §8d minimum)
     res["Order_int64_1col"] = {"rows": n, "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
                                "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    # ---- ORDER BY v1 LIMIT 100 — PhysicalLimit(PhysicalOrder(scan)): offset + limit handed to the sort (sqlrs_order_set_limit),
+    #      which sorts the candidates below a sampled threshold only; checked against torch.topk on the same column
+    K = 100
+    first = [None]
+
+    def run_order_limit():
+        h = C.c_void_p()
+        be.check(be.fn("order_create")(be.ctx, 1, obs, C.byref(h)))
+        be.check(be.fn("order_set_limit")(h, K))
+        be.check(be.fn("order_push_retained")(h, bo.ptr))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("order_finish")(h, D, C.byref(o)))
+        lim = C.c_void_p()
+        be.check(be.fn("limit_create")(be.ctx, 1, K, 0, 0, C.byref(lim)))
+        lo = C.POINTER(abi.Batch)()
+        fin = C.c_int()
+        be.check(be.fn("limit_push")(lim, o, D, C.byref(lo), C.byref(fin)))
+        if first[0] is None:
+            be.synchronize()
+            w_ = be.wrap(lo)
+            got_k = _tensor_view(torch, w_.column(0).values, w_.num_rows, torch.int64, dev).clone()
+            exp_k = torch.topk(v1, K, largest=False, sorted=True).values
+            first[0] = (bool(w_.num_rows == K and torch.equal(got_k, exp_k)), int(be.fn("order_topk_candidates")(h)))
+            w_.release()
+        else:
+            be.fn("batch_release")(lo)
+        be.fn("limit_destroy")(lim)
+        be.fn("batch_release")(o)
+        be.fn("order_destroy")(h)
+    ms_k = timed(run_order_limit)
+    profile_of(run_order_limit, "Order limit")
+    res["Order_int64_limit100"] = {"rows": n, "limit": K, "ms": round(ms_k, 3), "ms_full_sort": round(ms, 3), "candidates": first[0][1],
+                                   "Mrows_s": round(n / ms_k / 1e3, 1), "check": "OK" if first[0][0] else "mismatch"}
     del bo, v1, val
     be.fn("ctx_pool_trim")(be.ctx)
     torch.cuda.empty_cache()

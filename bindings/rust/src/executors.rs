@@ -165,7 +165,9 @@ impl HipHashAggExecutor {
 }
 
 // ------------------------------------------------------------------- Order --
-pub struct HipOrderExecutor { pub ctx: Arc<HipCtx>, pub order_by: Vec<BoundOrderBy>, pub child: BoxedExecutor }
+/// `limit_hint`: a LimitExecutor sits directly above (PhysicalLimit(PhysicalOrder(child))) and reads only the first
+/// offset + limit rows: the operator may return a prefix of the sorted result (sqlrs_order_set_limit); 0 = no hint
+pub struct HipOrderExecutor { pub ctx: Arc<HipCtx>, pub order_by: Vec<BoundOrderBy>, pub child: BoxedExecutor, pub limit_hint: i64 }
 impl HipOrderExecutor {
     #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
     pub async fn execute(self) {
@@ -174,6 +176,7 @@ impl HipOrderExecutor {
         let mut h = std::ptr::null_mut();
         self.ctx.check(unsafe { sqlrs_order_create(self.ctx.raw(), ob.len() as i32, ob.as_ptr(), &mut h) })?;
         let _g = Guard(h, sqlrs_order_destroy);
+        if self.limit_hint > 0 { self.ctx.check(unsafe { sqlrs_order_set_limit(h, self.limit_hint) })?; }
         let mut schema = None;
         #[for_await]
         for batch in self.child { // order.rs:19-26
@@ -364,7 +367,7 @@ impl ExecutorBuilder {
         Some(HipHashAggExecutor { ctx: self.hip.clone(), agg_funcs: plan.logical().agg_funcs(), group_by: plan.logical().group_by(), child, child_filter }.execute())
     }
     pub fn hip_visit_physical_order(&mut self, plan: &PhysicalOrder) -> Option<BoxedExecutor> {
-        Some(HipOrderExecutor { ctx: self.hip.clone(), order_by: plan.logical().order_by(), child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())
+        Some(HipOrderExecutor { ctx: self.hip.clone(), order_by: plan.logical().order_by(), child: self.visit(plan.children().first().unwrap().clone()).unwrap(), limit_hint: 0 }.execute())
     }
     pub fn hip_visit_physical_project(&mut self, plan: &PhysicalProject) -> Option<BoxedExecutor> {
         Some(HipProjectExecutor { ctx: self.hip.clone(), exprs: plan.logical().exprs(), child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())
@@ -372,8 +375,16 @@ impl ExecutorBuilder {
     pub fn hip_visit_physical_limit(&mut self, plan: &PhysicalLimit) -> Option<BoxedExecutor> {
         // both bounds are Constants in the reference (limit.rs:14-27); the binder has already folded them
         let as_usize = |e: Option<BoundExpr>| e.and_then(|e| match e { BoundExpr::Constant(v) => v.as_usize(), e => unreachable!("expr: {:?} not allowed in limit", e) });
-        Some(HipLimitExecutor { ctx: self.hip.clone(), limit: as_usize(plan.logical().limit()), offset: as_usize(plan.logical().offset()),
-                                child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())
+        let (limit, offset) = (as_usize(plan.logical().limit()), as_usize(plan.logical().offset()));
+        let below = plan.children().first().unwrap().clone();
+        // peephole: PhysicalLimit(PhysicalOrder(x)) hands offset + limit down to the sort (ORDER BY ... LIMIT k)
+        let child = match (below.as_physical_order(), limit) {
+            (Ok(order), Some(l)) => HipOrderExecutor { ctx: self.hip.clone(), order_by: order.logical().order_by(),
+                                                      child: self.visit(order.children().first().unwrap().clone()).unwrap(),
+                                                      limit_hint: (l + offset.unwrap_or(0)) as i64 }.execute(),
+            _ => self.visit(below).unwrap(),
+        };
+        Some(HipLimitExecutor { ctx: self.hip.clone(), limit, offset, child }.execute())
     }
     pub fn hip_visit_physical_simple_agg(&mut self, plan: &PhysicalSimpleAgg) -> Option<BoxedExecutor> {
         Some(HipSimpleAggExecutor { ctx: self.hip.clone(), agg_funcs: plan.logical().agg_funcs(), child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())

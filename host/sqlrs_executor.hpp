@@ -478,6 +478,9 @@ struct OrderExecutor { // order.rs:8-11
   HipCtxRef ctx;
   std::vector<BoundOrderBy> order_by;
   BoxedExecutor child;
+  // LimitExecutor directly above (PhysicalLimit(PhysicalOrder(child))): only the first offset + limit rows will be
+  // read, the operator may return a prefix of the sorted result (sqlrs_order_set_limit); 0 = no hint
+  int64_t limit_hint = 0;
   BoxedExecutor execute() {
     struct S : Executor {
       HipCtxRef ctx; BoxedExecutor child; sqlrs_order_t *o = nullptr; bool done = false;
@@ -503,6 +506,7 @@ struct OrderExecutor { // order.rs:8-11
     for (auto &x : order_by) low.push_back(detail::lower(x.expr));
     for (size_t i = 0; i < order_by.size(); i++) ob.push_back(sqlrs_order_by_t{low[i].abi(), order_by[i].asc, 0});
     ctx->check(sqlrs_order_create(ctx->raw, (int)ob.size(), ob.data(), &s->o));
+    if (limit_hint > 0) ctx->check(sqlrs_order_set_limit(s->o, limit_hint));
     return s;
   }
 };
@@ -727,7 +731,8 @@ struct PlanNode {
 };
 
 // ExecutorBuilder (src/executor/mod.rs:36-56, PlanVisitor impl :87-200): one visit_physical_* per node, each
-// instantiating the operator struct exactly as the reference does — plus TWO peepholes in visit_physical_hash_agg:
+// instantiating the operator struct exactly as the reference does — plus TWO peepholes in visit_physical_hash_agg
+// and one in visit_physical_limit (PhysicalLimit(PhysicalOrder(child)) -> OrderExecutor{.., limit_hint = offset + limit}):
 //
 //   PhysicalHashAgg(PhysicalHashJoin[Inner, no join filter](l, PhysicalFilter?(r)))
 //        -> HashJoinAggExecutor{.., probe_filter = the Filter's expr}     (sqlrs_join_agg_* + set_probe_filter)
@@ -823,9 +828,19 @@ struct ExecutorBuilder {
     }
     return ex.execute();
   }
-  BoxedExecutor visit_physical_limit(const PlanNode &plan) { // mod.rs:176-187
+  BoxedExecutor visit_physical_limit(const PlanNode &plan) { // mod.rs:176-187 + the ORDER BY ... LIMIT k peephole
     LimitExecutor ex;
-    ex.ctx = ctx; ex.limit = plan.limit; ex.offset = plan.offset; ex.child = visit(plan.children().front());
+    ex.ctx = ctx; ex.limit = plan.limit; ex.offset = plan.offset;
+    const PlanRef &child = plan.children().front();
+    if (fuse_join_agg && child->kind == PlanNode::PhysicalOrder && plan.limit) { // PhysicalLimit(PhysicalOrder(x)): hand offset + limit down
+      OrderExecutor ord;
+      ord.ctx = ctx; ord.order_by = child->order_by; ord.child = visit(child->children().front());
+      ord.limit_hint = (int64_t)(*plan.limit + (plan.offset ? *plan.offset : 0));
+      ex.child = ord.execute();
+      rewrites++;
+    } else {
+      ex.child = visit(child);
+    }
     return ex.execute();
   }
   BoxedExecutor visit_physical_order(const PlanNode &plan) { // mod.rs:189-199

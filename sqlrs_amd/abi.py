@@ -304,6 +304,8 @@ class Backend:
             "ctx_wait_stream": (i, [vp, vp]),
             "ctx_release_to_stream": (i, [vp, vp]),
             "order_push_retained": (i, [vp, pb]),
+            "order_set_limit": (i, [vp, C.c_int64]),
+            "order_topk_candidates": (C.c_int64, [vp]),
             "ctx_pool_bytes": (C.c_int64, [vp]),
             "ctx_pool_trim": (None, [vp]),
             "batch_copy": (i, [vp, pb, i, ppb]),

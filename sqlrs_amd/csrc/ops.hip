@@ -210,7 +210,122 @@ struct sqlrs_order {
   std::vector<Expr> exprs;
   std::vector<int> asc;
   std::vector<DBatch> batches;
+  int64_t limit_hint = 0;      // sqlrs_order_set_limit: only the first `limit_hint` rows of the result will be read
+  int64_t topk_candidates = 0; // rows the last finish() sorted because of the hint (0 = everything)
 };
+
+namespace sq {
+// ---- ORDER BY ... LIMIT k: sort the candidates only -------------------------------------------------------------
+// PhysicalLimit(PhysicalOrder(child)) reads the first offset + limit rows of the sorted result; the reference sorts
+// everything (order.rs:27-66) and slices (limit.rs:12-80).  With the hint the operator picks a threshold T from a sample
+// of the keys (65 536 evenly spaced rows, sorted; the sample's quantile at twice the wanted fraction plus a margin), keeps
+// the rows with key <= T with the Filter operator's own one-pass compaction (ties at T included: every row that can be
+// among the first k is kept), and sorts those — the sorted candidates ARE a prefix of the full result, stable ties and
+// all.  Fewer candidates than k (the sample misjudged the column): the hint is ignored and everything is sorted.
+template <int KIND>
+__global__ void topk_sample_kernel(const void *__restrict__ vals, int64_t n, int64_t step, int64_t S, int desc,
+                                   uint64_t *__restrict__ out) {
+  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int64_t i = min(s * step, n - 1);
+  uint64_t u;
+  if (KIND == 0) u = i64_to_ordered(((const int64_t *)vals)[i]);
+  else if (KIND == 1) u = f64_to_ordered(((const double *)vals)[i]);
+  else u = i64_to_ordered((int64_t)((const int32_t *)vals)[i]);
+  out[s] = desc ? ~u : u;
+}
+} // namespace sq
+
+extern "C" {
+int sqlrs_order_create(sqlrs_ctx_t *ctx, int num_keys, const sqlrs_order_by_t *order_by, sqlrs_order_t **out);
+int sqlrs_order_push(sqlrs_order_t *o, const sqlrs_batch_t *in);
+int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out);
+void sqlrs_order_destroy(sqlrs_order_t *o);
+}
+
+// true = `out` holds the sorted candidates (a prefix of the full result with at least limit_hint rows)
+static bool order_topk(sqlrs_order *o, DBatch &all, int kc, int out_mem, sqlrs_batch_t **out) {
+  Ctx *ctx = o->ctx;
+  const int64_t n = all.rows, L = o->limit_hint;
+  const DCol &key = all.cols[(size_t)kc];
+  const int desc = o->asc[0] ? 0 : 1;
+  const int kind = key.dtype == SQLRS_INT64 ? 0 : key.dtype == SQLRS_FLOAT64 ? 1 : 2;
+  // 1. threshold from a sorted sample
+  const int64_t S = 65536, step = n / S;
+  BufP sk = ctx->alloc(8 * (size_t)S), sv = ctx->alloc(4 * (size_t)S);
+  {
+    ProfScope ps(ctx, "order_topk_sample");
+    dim3 g((unsigned)ceil_div(S, 256)), b(256);
+    if (kind == 0) topk_sample_kernel<0><<<g, b, 0, ctx->stream>>>(key.values, n, step, S, desc, sk->as<uint64_t>());
+    else if (kind == 1) topk_sample_kernel<1><<<g, b, 0, ctx->stream>>>(key.values, n, step, S, desc, sk->as<uint64_t>());
+    else topk_sample_kernel<2><<<g, b, 0, ctx->stream>>>(key.values, n, step, S, desc, sk->as<uint64_t>());
+    SQ_HIP(hipGetLastError());
+    iota_u32(ctx, sv->as<uint32_t>(), S);
+    radix_sort_pairs(ctx, sk->as<uint64_t>(), sv->as<uint32_t>(), S, 0, 64);
+  }
+  const int64_t q = std::min<int64_t>(S - 1, (int64_t)std::ceil((double)L * (double)S / (double)n * 2.0) + 256);
+  uint64_t T = ctx->fetch_value(sk->as<uint64_t>() + q);
+  if (desc) T = ~T; // back to the ascending image: the candidates of a descending order are the rows with image >= T
+  // 2. the candidates: Filter(key <= value(T))  (>= for DESC), the operator's own fast path
+  sqlrs_expr_node_t nodes[3];
+  std::memset(nodes, 0, sizeof(nodes));
+  nodes[0].op = SQLRS_EXPR_INPUT_REF;
+  nodes[0].index = kc;
+  nodes[1].op = SQLRS_EXPR_CONSTANT;
+  nodes[1].dtype = key.dtype;
+  if (kind == 1) { // (host forms of device_utils.hpp's ordered_to_f64 / ordered_to_i64)
+    const uint64_t bits = (T >> 63) ? (T & ~(1ull << 63)) : ~T;
+    std::memcpy(&nodes[1].f, &bits, 8);
+  } else
+    nodes[1].i = (int64_t)(T ^ (1ull << 63));
+  nodes[2].op = desc ? SQLRS_EXPR_GTEQ : SQLRS_EXPR_LTEQ;
+  sqlrs_expr_t fe{nodes, 3, 0};
+  sqlrs_filter_t *f = nullptr;
+  sqlrs_batch_t *view = nullptr, *kept = nullptr;
+  sqlrs_order_t *tmp = nullptr;
+  auto cleanup = [&] {
+    if (tmp) sqlrs_order_destroy(tmp);
+    if (f) sqlrs_filter_destroy(f);
+    if (kept) sqlrs_batch_release(kept);
+    if (view) sqlrs_batch_release(view);
+  };
+  bool done = false;
+  try {
+    DBatch copy = all; // (columns share their buffers; lent ones stay lent for the duration of this call)
+    view = emit_batch(ctx, std::move(copy), SQLRS_MEM_DEVICE);
+    int st = sqlrs_filter_create((sqlrs_ctx_t *)ctx, &fe, &f);
+    if (st == SQLRS_OK) st = sqlrs_filter_push(f, view, SQLRS_MEM_DEVICE, &kept);
+    if (st != SQLRS_OK) fail(st, ctx->last_error);
+    if (kept && kept->num_rows >= L) {
+      // 3. sort the candidates (same keys, same directions, no hint)
+      std::vector<std::vector<sqlrs_expr_node_t>> kn;
+      std::vector<sqlrs_order_by_t> ob;
+      for (size_t k = 0; k < o->exprs.size(); k++) {
+        kn.push_back(o->exprs[k].nodes);
+        for (size_t q2 = 0; q2 < kn.back().size(); q2++)
+          kn.back()[q2].s = o->exprs[k].strings[q2].empty() ? nullptr : o->exprs[k].strings[q2].c_str();
+      }
+      for (size_t k = 0; k < o->exprs.size(); k++) {
+        sqlrs_order_by_t e;
+        e.expr = sqlrs_expr_t{kn[k].data(), (int32_t)kn[k].size(), 0};
+        e.asc = o->asc[k];
+        e.reserved = 0;
+        ob.push_back(e);
+      }
+      st = sqlrs_order_create((sqlrs_ctx_t *)ctx, (int)ob.size(), ob.data(), &tmp);
+      if (st == SQLRS_OK) st = sqlrs_order_push(tmp, kept);
+      if (st == SQLRS_OK) st = sqlrs_order_finish(tmp, out_mem, out);
+      if (st != SQLRS_OK) fail(st, ctx->last_error);
+      o->topk_candidates = kept->num_rows;
+      done = true;
+    }
+  } catch (...) {
+    cleanup();
+    throw;
+  }
+  cleanup();
+  return done;
+}
 
 extern "C" {
 
@@ -292,6 +407,22 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
       return all.cols[(size_t)i];
     };
     int64_t n1 = std::max<int64_t>(n, 1);
+    // ---- ORDER BY ... LIMIT k (sqlrs_order_set_limit): one plain fixed-width key column without NULLs, k a small part of the rows
+    o->topk_candidates = 0;
+    {
+      const char *tk_e = std::getenv("SQLRS_ORDER_TOPK"); // test / tuning hook, read per call: 0 = ignore the hint, 1 = whatever the sizes
+      const int tk = tk_e ? std::atoi(tk_e) : -1;
+      if (o->limit_hint > 0 && tk != 0 && o->exprs.size() == 1 && o->exprs[0].nodes.size() == 1 && o->exprs[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
+          (tk == 1 ? n >= (1 << 17) : (n >= (1 << 20) && o->limit_hint <= n / 16))) {
+        const int kc0 = o->exprs[0].nodes[0].index;
+        if (kc0 >= 0 && (size_t)kc0 < all.cols.size()) {
+          const DCol &kcol = all.cols[(size_t)kc0];
+          const bool plain = (kcol.dtype == SQLRS_INT64 || kcol.dtype == SQLRS_FLOAT64 || kcol.dtype == SQLRS_INT32) && kcol.stride != 0 &&
+                             !(kcol.validity && kcol.null_count != 0);
+          if (plain && order_topk(o, all, kc0, out_mem, out)) return;
+        }
+      }
+    }
     // ---- fast route: one plain key column without NULLs (order_fast.hip)
     static const bool fast_on = [] { const char *e = std::getenv("SQLRS_ORDER_FAST"); return !(e && e[0] == '0'); }(); // test hook
     if (fast_on && o->exprs.size() == 1 && o->exprs[0].nodes.size() == 1 && o->exprs[0].nodes[0].op == SQLRS_EXPR_INPUT_REF) {
@@ -412,6 +543,13 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
   });
 }
 
+int sqlrs_order_set_limit(sqlrs_order_t *o, int64_t rows) {
+  return guard(o->ctx, [&] {
+    if (rows < 0) fail(SQLRS_ERR_INTERNAL, "order limit hint must be >= 0");
+    o->limit_hint = rows;
+  });
+}
+int64_t sqlrs_order_topk_candidates(const sqlrs_order_t *o) { return o->topk_candidates; }
 void sqlrs_order_destroy(sqlrs_order_t *o) { delete o; }
 
 } // extern "C"

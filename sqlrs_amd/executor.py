@@ -240,9 +240,13 @@ class OrderExecutor:
     does with its Arc'd arrays, order.rs:19-26; ``sqlrs_order_push_retained``)."""
 
     def __init__(self, backend: abi.Backend, order_by: List[OrderBy], child: Iterable,
-                 out_mem: int = abi.MEM_HOST, retain_inputs: bool = False):
+                 out_mem: int = abi.MEM_HOST, retain_inputs: bool = False, limit_hint: Optional[int] = None):
         self.backend, self.order_by, self.child, self.out_mem = backend, order_by, child, out_mem
         self.retain_inputs = retain_inputs
+        # LimitExecutor{offset, limit} directly above (PhysicalLimit(PhysicalOrder(child))): only the first
+        # offset + limit rows will be read — the operator may return a prefix of the sorted result (sqlrs_order_set_limit)
+        self.limit_hint = limit_hint
+        self.topk_candidates = 0  # rows the sort actually took because of the hint (0 = all of them)
 
     def execute(self):
         be = self.backend
@@ -256,7 +260,10 @@ class OrderExecutor:
         h = C.c_void_p()
         be.check(be.fn("order_create")(be.ctx, len(obs), arr, C.byref(h)))
         names = None
+        hinted = self.limit_hint is not None and hasattr(be.lib, be.prefix + "order_set_limit")  # (HIP library only)
         try:
+            if hinted:
+                be.check(be.fn("order_set_limit")(h, int(self.limit_hint)))
             for batch in self.child:  # order.rs:19-26
                 names = names or _names_of(batch)
                 b = abi.as_batch(batch)
@@ -267,6 +274,8 @@ class OrderExecutor:
                     be.check(be.fn("order_push")(h, b.ptr))
             out = C.POINTER(abi.Batch)()
             be.check(be.fn("order_finish")(h, self.out_mem, C.byref(out)))
+            if hinted:
+                self.topk_candidates = be.fn("order_topk_candidates")(h)
             yield _emit(be, out, self.out_mem, names)
         finally:
             be.fn("order_destroy")(h)

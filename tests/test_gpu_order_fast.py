@@ -6,7 +6,7 @@ import pyarrow as pa
 import pytest
 
 from sqlrs_amd import abi
-from sqlrs_amd.executor import OrderExecutor
+from sqlrs_amd.executor import LimitExecutor, OrderExecutor
 from sqlrs_amd.expr import InputRef, OrderBy
 
 pytestmark = pytest.mark.gpu
@@ -131,3 +131,43 @@ def test_order_rows_already_in_order(hip, oracle, shape):
         assert got.column(i).equals(exp.column(i)), i
     sorted_anyway = prof.get("order_split", (0, 0))[1] > 0 or prof.get("radix_sort", (0, 0))[1] > 0
     assert sorted_anyway == shape.startswith("one_inversion"), prof
+
+
+@pytest.mark.parametrize("shape", ["i64_random", "i64_many_ties", "f64", "i32_desc", "threshold_too_low", "two_payload_columns_desc"])
+def test_order_by_limit_sorts_only_the_candidates(hip, oracle, shape, monkeypatch):
+    """PhysicalLimit(PhysicalOrder(child)): with sqlrs_order_set_limit(offset + limit) the operator keeps the rows that can
+    be among the first k (threshold from a sorted sample, ties included), sorts those and returns a prefix of the full
+    result; LimitExecutor slices it.  Same rows as Limit(Order(..)) on the oracle, ties in input order.  `threshold_too_low`:
+    the first rows of the column dominate the sample badly enough that fewer than k rows pass — the hint must be ignored."""
+    monkeypatch.setenv("SQLRS_ORDER_TOPK", "1")  # (the size rule wants >= 2^20 rows and k <= rows / 16: forced at test size)
+    rng = np.random.default_rng(len(shape))
+    n, k, off = N, 1000, 37
+    asc = "desc" not in shape
+    if shape == "i64_many_ties":
+        key = rng.integers(0, 50, n, dtype=np.int64)          # k-th row deep inside a run of equal keys
+    elif shape == "f64":
+        key = rng.standard_normal(n)
+    elif shape == "i32_desc":
+        key = rng.integers(-(1 << 30), 1 << 30, n).astype(np.int32)
+    elif shape == "threshold_too_low":
+        key = rng.integers(1 << 20, 1 << 30, n, dtype=np.int64)
+        key[::max(1, n // 65536)] = -5                         # every sampled row is tiny, almost no other row is
+        k = 200_000
+    else:
+        key = rng.integers(-(1 << 40), 1 << 40, n, dtype=np.int64)
+    cols, names = [pa.array(key), pa.array(np.arange(n, dtype=np.int64))], ["k", "row"]
+    if shape == "two_payload_columns_desc":
+        cols.append(pa.array(rng.random(n), mask=rng.random(n) < 0.1))
+        names.append("x")
+    b = pa.RecordBatch.from_arrays(cols, names=names)
+    ob = [OrderBy(InputRef(0), asc=asc)]
+    ex = OrderExecutor(hip, ob, [b.slice(0, n // 3), b.slice(n // 3)], limit_hint=off + k)
+    got = pa.Table.from_batches(list(LimitExecutor(hip, k, off, ex.execute()).execute()))
+    exp = pa.Table.from_batches(list(LimitExecutor(oracle, k, off, OrderExecutor(oracle, ob, [b]).execute()).execute()))
+    assert got.num_rows == k
+    for i in range(len(names)):
+        assert got.column(i).combine_chunks().equals(exp.column(i).combine_chunks()), names[i]
+    if shape == "threshold_too_low":
+        assert ex.topk_candidates == 0
+    elif shape != "i64_many_ties":
+        assert 0 < ex.topk_candidates < n // 4, ex.topk_candidates
