@@ -1363,6 +1363,15 @@ def bench_host_resident(be, abi, datagen, torch, dev):
                                    "pcie_frac_of_63GBps": round(16 * n / dt / 1e9 / PCIE_GBPS, 4),
                                    "note": "19532 pageable 1024-row host batches (storage/csv.rs:105) through sqlrs_hash_agg_push's host "
                                            "staging (one upload per 2^22 rows), result on the host; wall clock incl. one ctypes call per batch"}
+    # the same leg from a NATIVE caller (host/bench_host_batches.cpp: a C call per batch, what a Rust drop-in pays)
+    exe = os.path.join(ROOT, "host", "bench_host_batches")
+    if os.path.exists(exe):
+        try:
+            import subprocess
+            r = subprocess.run([exe, str(n), "1000000", "1024"], capture_output=True, text=True, timeout=300)
+            out["C4_host_batches_1024_native"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:  # informational leg: never takes the line down
+            out["C4_host_batches_1024_native"] = {"error": repr(e)[:200]}
     return out
 
 

@@ -415,7 +415,12 @@ bool HostStage::accepts(const sqlrs_batch_t *b) const {
 
 void HostStage::append(const sqlrs_batch_t *b) {
   if (!has_schema) {
-    cols.resize((size_t)b->num_columns);
+    if (cols.size() != (size_t)b->num_columns) { // (column slots keep their pinned block across flushes of one schema)
+      for (Col &c : cols)
+        if (c.pin) (void)hipHostFree(c.pin);
+      cols.clear();
+      cols.resize((size_t)b->num_columns);
+    }
     for (int i = 0; i < b->num_columns; i++) cols[(size_t)i].dtype = b->columns[i].dtype;
     has_schema = true;
   }
@@ -425,7 +430,31 @@ void HostStage::append(const sqlrs_batch_t *b) {
     Col &d = cols[(size_t)i];
     const size_t w = width_of(c.dtype);
     const uint8_t *src = (const uint8_t *)c.values;
-    d.vals.insert(d.vals.end(), src, src + w * (size_t)n);
+    const size_t add = w * (size_t)n;
+    if (!d.pin && rows + n < HOST_STAGE_PIN_ROWS) {
+      d.vals.insert(d.vals.end(), src, src + add);
+    } else {
+      const size_t have = d.pin ? d.pin_size : d.vals.size();
+      if (have + add > d.pin_cap) { // grow (doubling, at least 2^20 rows' worth): pinned blocks are kept across flushes
+        size_t cap = std::max<size_t>(d.pin_cap * 2, w << 20);
+        while (cap < have + add) cap *= 2;
+        void *np = nullptr;
+        SQ_HIP(hipHostMalloc(&np, cap, hipHostMallocDefault));
+        if (have) std::memcpy(np, d.pin ? d.pin : d.vals.data(), have);
+        if (d.pin) SQ_HIP(hipHostFree(d.pin));
+        d.pin = (uint8_t *)np;
+        d.pin_cap = cap;
+        d.pin_size = have;
+        d.vals.clear();
+        d.vals.shrink_to_fit();
+      } else if (!d.pin_size && !d.vals.empty()) { // (a kept buffer, values still in the vector: cannot happen, kept for safety)
+        std::memcpy(d.pin, d.vals.data(), d.vals.size());
+        d.pin_size = d.vals.size();
+        d.vals.clear();
+      }
+      std::memcpy(d.pin + d.pin_size, src, add);
+      d.pin_size += add;
+    }
     const bool nullable = c.validity && c.null_count != 0;
     if (nullable || !d.valid.empty()) {
       const size_t words = (size_t)ceil_div(rows + n, 64);
@@ -453,7 +482,7 @@ sqlrs_batch_t *HostStage::take() {
     d.mem = SQLRS_MEM_HOST;
     d.length = rows;
     d.null_count = cols[i].nulls;
-    d.values = cols[i].vals.data();
+    d.values = cols[i].pin_size ? (const void *)cols[i].pin : (const void *)cols[i].vals.data();
     d.validity = cols[i].nulls ? (const uint8_t *)cols[i].valid.data() : nullptr;
     d.offsets = nullptr;
   }
@@ -467,11 +496,22 @@ sqlrs_batch_t *HostStage::take() {
   {
     InBatch ib(ctx, &hb);
     dev = emit_batch(ctx, ib.materialize(true), SQLRS_MEM_DEVICE);
-  } // (~InBatch waits for the uploads: the vectors may go now)
-  cols.clear();
+  } // (~InBatch waits for the uploads: the staged values may go now)
+  // the pinned blocks stay with their column slot for the next flush (same schema); everything else is dropped
+  for (Col &c : cols) {
+    c.vals.clear();
+    c.valid.clear();
+    c.pin_size = 0;
+    c.nulls = 0;
+  }
   has_schema = false;
   rows = 0;
   return dev;
+}
+
+HostStage::~HostStage() {
+  for (Col &c : cols)
+    if (c.pin) (void)hipHostFree(c.pin);
 }
 
 // Host columns built by the library itself (CSV ingest) -> library-owned HOST batch.  Every pointer of
