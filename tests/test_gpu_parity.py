@@ -469,6 +469,26 @@ def test_hash_agg_wide_aggregate_list(hip, oracle, shape):
     assert_same_table(got, exp, float_cols={1, 4, 5, 6})
 
 
+def test_host_batches_cross_the_pinned_staging_threshold(hip, oracle):
+    """150 HOST batches of 1000 rows (the reference's CSV batch shape) into the blocking operators: the staging area starts as
+    a vector and moves to pinned memory when 2^16 rows have arrived (host_stage.hpp) — values, NULL bitmaps and row order
+    must survive the move; HashAgg, Order and the join's build side against the oracle."""
+    rng = np.random.default_rng(150)
+    n = 150_000
+    b = batch(rng, n, [("i64", 0.03, 0, 5000), ("f64", 0.05, 0, 1), ("i64", 0.0, -100, 100)])
+    bs = [b.slice(o, 1000) for o in range(0, n, 1000)]
+    aggs = [AggFunc("count", InputRef(1), abi.INT64), AggFunc("sum", InputRef(1), abi.FLOAT64), AggFunc("max", InputRef(2), abi.INT64)]
+    assert_same_table(table_of(HashAggExecutor(hip, aggs, [InputRef(0)], bs).execute()),
+                      table_of(HashAggExecutor(oracle, aggs, [InputRef(0)], bs).execute()), float_cols={2})
+    ob = [OrderBy(InputRef(2), asc=False), OrderBy(InputRef(0), asc=True)]
+    assert_same_table(table_of(OrderExecutor(hip, ob, bs).execute()), table_of(OrderExecutor(oracle, ob, bs).execute()))
+    probe = batch(rng, 20_000, [("i64", 0.0, 0, 6000), ("f64", 0.0, 0, 1)])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(b, probe)
+    assert_same_table(table_of(HashJoinExecutor(hip, bs, [probe], "inner", cond, sch, 3).execute()),
+                      table_of(HashJoinExecutor(oracle, bs, [probe], "inner", cond, sch, 3).execute()))
+
+
 def test_hash_agg_mixed_routes_multi_batch(hip, oracle):
     rng = np.random.default_rng(77)
     spec = [("i64", 0.05, 0, 5000), ("f64", 0.0, 0, 1)]
