@@ -103,6 +103,55 @@ def test_fuzz_hash_join(hip, oracle, seed):
     assert_same(rows_of(got), rows_of(exp))
 
 
+@pytest.mark.parametrize("seed", range(10 + _EXTRA // 10))
+def test_fuzz_order_fast_route_shortcuts(hip, oracle, seed, monkeypatch):
+    """ORDER BY one plain key of >= 2^20 rows with the shortcuts of round 3 forced at test size: key range from a sample
+    (SQLRS_ORDER_SAMPLE=1), rows already in order, and — every other seed — a LimitExecutor above whose offset + limit is
+    handed to the sort (SQLRS_ORDER_TOPK=1); random key types, ranges, directions, tie densities, nearly sorted inputs."""
+    from sqlrs_amd.executor import LimitExecutor
+    monkeypatch.setenv("SQLRS_ORDER_SAMPLE", "1")
+    monkeypatch.setenv("SQLRS_ORDER_TOPK", "1")
+    rng = np.random.default_rng(4500 + seed)
+    n = int(rng.choice([1_100_000, 1_400_000]))
+    kind = str(rng.choice(["i64", "i64_ties", "f64", "i32", "i64_offset"]))
+    if kind == "i64":
+        k = rng.integers(-(1 << 31), 1 << 31, n, dtype=np.int64) >> int(rng.integers(0, 12))
+    elif kind == "i64_ties":
+        k = rng.integers(0, int(rng.choice([3, 100, 40_000])), n, dtype=np.int64)
+    elif kind == "f64":
+        k = np.round(rng.standard_normal(n), int(rng.integers(1, 6))) + 0.0  # (+ 0.0: no negative zeros — their order against +0.0 is arrow's business)
+    elif kind == "i32":
+        k = rng.integers(-(1 << 24), 1 << 24, n).astype(np.int32)
+    else:
+        k = (1 << 45) + rng.integers(0, 1 << 28, n, dtype=np.int64)
+    shape = str(rng.choice(["random", "random", "sorted", "sorted_desc", "nearly_sorted"]))
+    if shape != "random":
+        k = np.sort(k, kind="stable")
+        if shape == "sorted_desc":
+            k = k[::-1].copy()
+        if shape == "nearly_sorted":
+            i = int(rng.integers(1, n - 1))
+            k[i], k[i - 1] = k[i - 1], k[i]
+    asc = bool(rng.random() < 0.5)
+    cols, names = [pa.array(k), pa.array(np.arange(n, dtype=np.int64))], ["k", "row"]
+    if rng.random() < 0.5:
+        cols.append(pa.array(rng.random(n), mask=rng.random(n) < 0.05))
+        names.append("x")
+    b = pa.RecordBatch.from_arrays(cols, names=names)
+    bs = _split(rng, b)
+    ob = [OrderBy(InputRef(0), asc)]
+    if seed % 2:
+        kk, off = int(rng.choice([1, 100, 20_000, n // 17])), int(rng.choice([0, 0, 13]))
+        got = pa.Table.from_batches(list(LimitExecutor(hip, kk, off, OrderExecutor(hip, ob, bs, limit_hint=kk + off).execute()).execute()))
+        exp = pa.Table.from_batches(list(LimitExecutor(oracle, kk, off, OrderExecutor(oracle, ob, bs).execute()).execute()))
+    else:
+        got = pa.Table.from_batches(list(OrderExecutor(hip, ob, bs).execute()))
+        exp = pa.Table.from_batches(list(OrderExecutor(oracle, ob, bs).execute()))
+    assert got.num_rows == exp.num_rows
+    for i in range(len(names)):
+        assert got.column(i).combine_chunks().equals(exp.column(i).combine_chunks()), (names[i], kind, shape, asc)
+
+
 @pytest.mark.parametrize("seed", range(30 + _EXTRA))
 def test_fuzz_order(hip, oracle, seed):
     rng = np.random.default_rng(4000 + seed)
