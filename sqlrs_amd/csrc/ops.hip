@@ -7,6 +7,7 @@
 #include "device_utils.hpp"
 #include "host_stage.hpp"
 #include "prims.hpp"
+#include "radix_part.hpp"
 
 using namespace sq;
 
@@ -17,6 +18,76 @@ struct sqlrs_filter {
   Ctx *ctx;
   Expr expr;
 };
+
+// ---- conjunctions of `column OP constant` ------------------------------------------------------------------------
+// `a > x AND b < y [AND ...]` (TPC-H Q6 has three range terms) used to go term by term through the expression
+// evaluator: a comparison kernel and a BOOLEAN array per term, an AND kernel per pair, the mask conversion, then tile
+// offsets and compaction.  For up to four terms over int64 / float64 columns without NULLs one kernel reads the predicate
+// columns once and writes the selection's mask words directly (ballot = one word per wave trip); tile offsets and the
+// compaction of the columns follow as for any mask.  2e7 rows, three carried columns, two terms: 0.38 -> 0.30 ms.
+namespace sq {
+constexpr int CONJ_MAX = 4;
+struct ConjTerms {
+  RowFilter t[CONJ_MAX];
+  int n = 0;
+};
+__global__ __launch_bounds__(256) void filter_conj_mask_kernel(ConjTerms ct, int64_t rows, uint64_t *__restrict__ bits) {
+  const int lane = lane_id();
+  const int64_t nwords = (rows + 63) / 64;
+  constexpr int KU = 4; // words per wave and trip: independent loads in flight
+  for (int64_t w0 = ((int64_t)blockIdx.x * 4 + wave_id()) * KU; w0 < nwords; w0 += (int64_t)gridDim.x * 4 * KU) {
+    uint64_t v[CONJ_MAX][KU];
+#pragma unroll
+    for (int q = 0; q < CONJ_MAX; q++) {
+      if (q >= ct.n) break;
+#pragma unroll
+      for (int u = 0; u < KU; u++) v[q][u] = __builtin_nontemporal_load(ct.t[q].col + min((w0 + u) * 64 + lane, rows - 1));
+    }
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      const int64_t r = (w0 + u) * 64 + lane;
+      bool keep = r < rows;
+#pragma unroll
+      for (int q = 0; q < CONJ_MAX; q++) {
+        if (q >= ct.n) break;
+        keep = keep && row_passes(ct.t[q], v[q][u]);
+      }
+      const uint64_t m = __ballot(keep);
+      if (lane == 0 && w0 + u < nwords) bits[w0 + u] = m;
+    }
+  }
+}
+// true = `sel` is the selection of the conjunction `e` over `ib`
+static bool filter_conjunction_fast_path(Ctx *ctx, const Expr &e, InBatch &ib, int64_t rows, Selection *sel) {
+  // postfix of t1 AND t2 AND ... : t1 t2 AND t3 AND ...   (every term = INPUT_REF CONSTANT CMP)
+  const size_t nn = e.nodes.size();
+  if (rows < (1 << 16) || nn < 7 || (nn - 3) % 4 != 0) return false;
+  const size_t nterms = 1 + (nn - 3) / 4;
+  if (nterms > (size_t)CONJ_MAX) return false;
+  ConjTerms ct;
+  for (size_t k = 0; k < nterms; k++) {
+    const size_t at = k == 0 ? 0 : 3 + (k - 1) * 4;
+    if (k > 0 && e.nodes[at + 3].op != SQLRS_EXPR_AND) return false;
+    Expr term;
+    term.nodes.assign(e.nodes.begin() + (long)at, e.nodes.begin() + (long)at + 3);
+    term.strings.assign(e.strings.begin() + (long)at, e.strings.begin() + (long)at + 3);
+    if (!fusable_row_filter(term, ib, &ct.t[k])) return false;
+  }
+  ct.n = (int)nterms;
+  const int64_t nwords = ceil_div(rows, 64);
+  sel->rows = rows;
+  sel->own_bits = ctx->alloc(8 * (size_t)nwords + 8);
+  sel->bits = sel->own_bits->as<uint64_t>();
+  {
+    ProfScope ps(ctx, "filter_conj_mask");
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nwords, 16), 8 * (int64_t)ctx->num_cus));
+    filter_conj_mask_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(ct, rows, sel->own_bits->as<uint64_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  selection_finish(ctx, *sel);
+  return true;
+}
+} // namespace sq
 
 extern "C" {
 
@@ -45,7 +116,8 @@ int sqlrs_filter_push(sqlrs_filter_t *f, const sqlrs_batch_t *in, int out_mem, s
     Selection sel;
     DCol fast_col;
     int fast_idx = -1;
-    if (!filter_fast_path(ctx, f->expr, colfn, rows, &fast_idx, &sel, &fast_col)) {
+    if (!filter_fast_path(ctx, f->expr, colfn, rows, &fast_idx, &sel, &fast_col) &&
+        !filter_conjunction_fast_path(ctx, f->expr, ib, rows, &sel)) {
       DCol mask = eval_expr(ctx, f->expr, colfn, rows, false);
       mask.length = rows;
       sel = selection_from_mask(ctx, mask);

@@ -100,6 +100,34 @@ def test_filter_cmp_const(hip, oracle, n, kind, const, op):
     assert_same(got, exp)
 
 
+@pytest.mark.parametrize("shape", ["two_terms", "three_terms_q6", "four_terms", "five_terms_general", "null_column_general", "or_general", "nothing_passes"])
+def test_filter_conjunction_of_comparisons(hip, oracle, shape):
+    """`a > x AND b < y [AND ...]` over int64 / float64 columns without NULLs: one kernel writes the selection mask of up to
+    four terms (filter_conj_mask_kernel); more terms, a nullable column or an OR take the expression evaluator.  Same rows in
+    the same order as the oracle either way; the class of the run says which route it was."""
+    rng = np.random.default_rng(len(shape))
+    n = 300_000
+    nulls = 0.05 if shape == "null_column_general" else 0.0
+    b = batch(rng, n, [("i64", 0.0, 0, 1000), ("f64", nulls, 0, 1), ("i64", 0.0, -50, 50), ("f64", 0.0, 0, 1), ("i32", 0.1, 0, 9)])
+    t = [BinaryOp(">", InputRef(0), Constant(200, abi.INT64)), BinaryOp("<", InputRef(1), Constant(0.6, abi.FLOAT64)),
+         BinaryOp(">=", InputRef(2), Constant(-20, abi.INT64)), BinaryOp("!=", InputRef(3), Constant(0.5, abi.FLOAT64)),
+         BinaryOp("<=", InputRef(0), Constant(900, abi.INT64))]
+    k = {"two_terms": 2, "three_terms_q6": 3, "four_terms": 4, "five_terms_general": 5, "null_column_general": 2, "or_general": 2,
+         "nothing_passes": 2}[shape]
+    e = t[0]
+    for x in t[1:k]:
+        e = BinaryOp("or" if shape == "or_general" else "and", e, x)
+    if shape == "nothing_passes":
+        e = BinaryOp("and", BinaryOp(">", InputRef(0), Constant(5000, abi.INT64)), t[1])
+    hip.profile(True)
+    got = table_of(FilterExecutor(hip, e, [b]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    exp = table_of(FilterExecutor(oracle, e, [b]).execute())
+    assert_same_table(got, exp)
+    assert (prof.get("filter_conj_mask", (0, 0))[1] > 0) == (not shape.endswith("general")), prof
+
+
 @pytest.mark.parametrize("n", [0, 1, 64, 1000, 70_001])
 def test_filter_general_expr(hip, oracle, n):
     rng = np.random.default_rng(n)
