@@ -16,6 +16,13 @@
 #include "device_utils.hpp"
 #include "radix_part.hpp"
 
+// stores of the partition passes: plain by default; -DRP_NT_STORES = non-temporal (A/B: tools/ab_two_builds.sh)
+#ifdef RP_NT_STORES
+#define RP_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define RP_ST(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace sq {
 
 // rows per thread are a template parameter: tile = 512 * ROWS rows.  Run length (rows per digit
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
       u64x2 rec;
       rec.x = kw;
       rec.y = sv0[NV >= 1 ? p : 0];
-      out.rec[g] = rec;
+      RP_ST(&out.rec[g], rec);
       return;
     }
     out.key[g] = kw;
@@ -527,9 +534,9 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
     const uint32_t d = (PACK ? rp_digit(rp_bucket(kp, packed_key(kp, kw), true, P), 1, p2_bits) : (uint32_t)sdig[p]) & (RP_WG - 1);
     int64_t g = (p < split[d] ? gb0[d] : gb1[d]) + p;
     if (p >= len) g = sink + (int64_t)blockIdx.x * RP_WG + threadIdx.x; // lanes past the staged rows (boundary slot): this workgroup's sink rows
-    out.key[g] = kw;
-    if (NV >= 1) out.v0[g] = sv0[p];
-    if (NV >= 2) out.v1[g] = sv1[p];
+    RP_ST(&out.key[g], kw);
+    if (NV >= 1) RP_ST(&out.v0[g], sv0[p]);
+    if (NV >= 2) RP_ST(&out.v1[g], sv1[p]);
     if (!PACK) out.idx[g] = sidx[p];
   };
 
@@ -802,7 +809,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_claim_scatter_kernel(
       u64x2 rec;
       rec.x = kw;
       rec.y = sv0[NV >= 1 ? p : 0];
-      out.rec[g] = rec;
+      RP_ST(&out.rec[g], rec);
       return;
     }
     out.key[g] = kw;
