@@ -1207,7 +1207,8 @@ static void join_agg_plan_eager(sqlrs_join_agg *ja, int num_keys, const sqlrs_ex
   const int lc = left_keys[0].nodes[0].index, rc = right_keys[0].nodes[0].index;
   for (int g = 0; g < num_group_by; g++) {
     if (group_by[g].num_nodes != 1 || group_by[g].nodes[0].op != SQLRS_EXPR_INPUT_REF) return;
-    const int idx = group_by[g].nodes[0].index;
+    int idx = group_by[g].nodes[0].index;
+    if (idx == ja->nleft + rc) idx = lc; // the probe-side join key: equal to the build side's in every joined row (exactly compared)
     if (idx < 0 || idx >= ja->nleft) return;
     ja->group_cols.push_back(idx);
   }

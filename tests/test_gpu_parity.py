@@ -1153,7 +1153,7 @@ def test_join_agg_dense_build_keys(hip, oracle, nb, base, hot):
     assert_same_table(got, exp, float_cols={2})
 
 
-@pytest.mark.parametrize("shape", ["dense_dim_region", "sparse_dim_two_columns", "nullable", "key_and_attribute",
+@pytest.mark.parametrize("shape", ["dense_dim_region", "sparse_dim_two_columns", "nullable", "key_and_attribute", "probe_key_and_attribute",
                                    "small_batches", "duplicate_build_keys", "no_match"])
 def test_join_agg_group_by_build_columns(hip, oracle, shape):
     """`... FROM fact JOIN dim ON fact.k = dim.k [WHERE ...] GROUP BY dim.region`: eager aggregation — the probe rows are
@@ -1182,7 +1182,8 @@ def test_join_agg_group_by_build_columns(hip, oracle, shape):
                                     names=["v", "k", "w"])
     cond = JoinCondition([(InputRef(0), InputRef(1))])
     sch = join_schema(lb, rb)
-    gb = {"sparse_dim_two_columns": [InputRef(1), InputRef(2)], "key_and_attribute": [InputRef(0), InputRef(1)]}.get(shape, [InputRef(1)])
+    gb = {"sparse_dim_two_columns": [InputRef(1), InputRef(2)], "key_and_attribute": [InputRef(0), InputRef(1)],
+          "probe_key_and_attribute": [InputRef(2), InputRef(3 + 1)]}.get(shape, [InputRef(1)])  # (InputRef(4) = f.k, the probe-side join key)
     aggs = [AggFunc("count", InputRef(3), abi.INT64), AggFunc("sum", InputRef(3), abi.FLOAT64),
             AggFunc("sum", InputRef(5), abi.INT64), AggFunc("min", InputRef(3), abi.FLOAT64), AggFunc("max", InputRef(5), abi.INT64)]
     if shape == "small_batches":
