@@ -995,7 +995,8 @@ static void build_table(sqlrs_hash_join *j) {
       // (a join owned by a HashJoin+HashAgg takes the table up to 16 slots per key: its fused route then partitions
       //  by key range and needs only the existence bitmap of the range — a filtered dimension, or the hash-partitioned
       //  shard of one that a rank of the multi-GPU plan receives, 1/8 of the keys of the range for 8 ranks)
-      const uint64_t slots_per_key = j->lazy_table ? dense_slots_per_key_owned() : 4;
+      const char *pj_e = std::getenv("SQLRS_DENSE_JOIN_SLOTS_PLAIN"); // tuning hook, read per call
+      const uint64_t slots_per_key = j->lazy_table ? dense_slots_per_key_owned() : (pj_e ? (uint64_t)std::max(1, std::atoi(pj_e)) : 4);
       if (range <= slots_per_key * (uint64_t)n + 1024 && range < (1ull << 31)) {
         ProfScope ps(ctx, "join_build_dense");
         BufP dense = ctx->alloc(4 * (size_t)range + 8);
@@ -1237,6 +1238,8 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
       if (use_ticket || (h[0] >> 32) == 0) break;
       lookback_timed_out(ctx);
     }
+    // unique build keys, pairs in probe-row order: as many pairs as probe rows = every row matched once = pair i is (.., i)
+    p.right_identity = p.m == n;
     return p;
   }
   if (j->unique && outer_right) { // exactly one pair per probe row
