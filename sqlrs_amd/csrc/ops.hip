@@ -335,7 +335,9 @@ static bool order_topk(sqlrs_order *o, DBatch &all, int kc, int out_mem, sqlrs_b
     iota_u32(ctx, sv->as<uint32_t>(), S);
     radix_sort_pairs(ctx, sk->as<uint64_t>(), sv->as<uint32_t>(), S, 0, 64);
   }
-  const int64_t q = std::min<int64_t>(S - 1, (int64_t)std::ceil((double)L * (double)S / (double)n * 2.0) + 256);
+  // (rows below the q-th of S sampled keys: q n / S on average with a deviation of sqrt(q) n / S — twice the wanted
+  //  fraction plus 64 sample ranks is >= 8 deviations above k for every k)
+  const int64_t q = std::min<int64_t>(S - 1, (int64_t)std::ceil((double)L * (double)S / (double)n * 2.0) + 64);
   uint64_t T = ctx->fetch_value(sk->as<uint64_t>() + q);
   if (desc) T = ~T; // back to the ascending image: the candidates of a descending order are the rows with image >= T
   // 2. the candidates: Filter(key <= value(T))  (>= for DESC), the operator's own fast path
