@@ -311,8 +311,9 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out);
  * the caller promises to read only the first `rows` (= offset + limit) rows of the result.  sqlrs_order_finish may then
  * return a PREFIX of the sorted result with at least `rows` rows (or everything): it keeps the rows whose key cannot be
  * beyond position `rows` — a threshold from a sample of the keys, ties at the threshold included — and sorts only those,
- * so the prefix is exactly what the full sort would put first, stable ties and all.  Applies to one plain fixed-width key
- * without NULLs when `rows` is a small part of the input; ignored otherwise (0 = no hint).  The LimitExecutor above
+ * so the prefix is exactly what the full sort would put first, stable ties and all.  Applies when the FIRST key is a plain
+ * fixed-width column without NULLs (the threshold is taken on it; further keys only order the candidates) and `rows` is a
+ * small part of the input; ignored otherwise (0 = no hint).  The LimitExecutor above
  * slices either result the same way. */
 int sqlrs_order_set_limit(sqlrs_order_t *o, int64_t rows);
 /* rows the last finish sorted because of the hint; 0 = the hint did not apply (diagnostics / tests) */

@@ -481,12 +481,14 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
       return all.cols[(size_t)i];
     };
     int64_t n1 = std::max<int64_t>(n, 1);
-    // ---- ORDER BY ... LIMIT k (sqlrs_order_set_limit): one plain fixed-width key column without NULLs, k a small part of the rows
+    // ---- ORDER BY ... LIMIT k (sqlrs_order_set_limit): the first key a plain fixed-width column without NULLs, k a small part of the rows
     o->topk_candidates = 0;
     {
       const char *tk_e = std::getenv("SQLRS_ORDER_TOPK"); // test / tuning hook, read per call: 0 = ignore the hint, 1 = whatever the sizes
       const int tk = tk_e ? std::atoi(tk_e) : -1;
-      if (o->limit_hint > 0 && tk != 0 && o->exprs.size() == 1 && o->exprs[0].nodes.size() == 1 && o->exprs[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
+      // (several keys: the threshold is taken on the FIRST one — a row whose first key lies beyond k rows' first keys
+      //  cannot be among the first k whatever the other keys say; the candidates are sorted on all of them)
+      if (o->limit_hint > 0 && tk != 0 && !o->exprs.empty() && o->exprs[0].nodes.size() == 1 && o->exprs[0].nodes[0].op == SQLRS_EXPR_INPUT_REF &&
           (tk == 1 ? n >= (1 << 17) : (n >= (1 << 20) && o->limit_hint <= n / 16))) {
         const int kc0 = o->exprs[0].nodes[0].index;
         if (kc0 >= 0 && (size_t)kc0 < all.cols.size()) {

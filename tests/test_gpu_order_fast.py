@@ -133,7 +133,7 @@ def test_order_rows_already_in_order(hip, oracle, shape):
     assert sorted_anyway == shape.startswith("one_inversion"), prof
 
 
-@pytest.mark.parametrize("shape", ["i64_random", "i64_many_ties", "f64", "i32_desc", "threshold_too_low", "two_payload_columns_desc"])
+@pytest.mark.parametrize("shape", ["i64_random", "i64_many_ties", "f64", "i32_desc", "threshold_too_low", "two_payload_columns_desc", "two_keys"])
 def test_order_by_limit_sorts_only_the_candidates(hip, oracle, shape, monkeypatch):
     """PhysicalLimit(PhysicalOrder(child)): with sqlrs_order_set_limit(offset + limit) the operator keeps the rows that can
     be among the first k (threshold from a sorted sample, ties included), sorts those and returns a prefix of the full
@@ -161,6 +161,10 @@ def test_order_by_limit_sorts_only_the_candidates(hip, oracle, shape, monkeypatc
         names.append("x")
     b = pa.RecordBatch.from_arrays(cols, names=names)
     ob = [OrderBy(InputRef(0), asc=asc)]
+    if shape == "two_keys":  # ORDER BY k, row DESC LIMIT ..: threshold on the first key, the candidates sorted on both
+        key = rng.integers(0, 2000, n, dtype=np.int64)
+        b = pa.RecordBatch.from_arrays([pa.array(key), pa.array(np.arange(n, dtype=np.int64))], names=names)
+        ob = [OrderBy(InputRef(0), asc=True), OrderBy(InputRef(1), asc=False)]
     ex = OrderExecutor(hip, ob, [b.slice(0, n // 3), b.slice(n // 3)], limit_hint=off + k)
     got = pa.Table.from_batches(list(LimitExecutor(hip, k, off, ex.execute()).execute()))
     exp = pa.Table.from_batches(list(LimitExecutor(oracle, k, off, OrderExecutor(oracle, ob, [b]).execute()).execute()))
