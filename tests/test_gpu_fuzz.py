@@ -140,6 +140,8 @@ def test_fuzz_order_fast_route_shortcuts(hip, oracle, seed, monkeypatch):
     b = pa.RecordBatch.from_arrays(cols, names=names)
     bs = _split(rng, b)
     ob = [OrderBy(InputRef(0), asc)]
+    if seed % 3 == 2:  # a second key: the top-k threshold is taken on the first key only, the fast route steps aside
+        ob.append(OrderBy(InputRef(1), bool(rng.random() < 0.5)))
     if seed % 2:
         kk, off = int(rng.choice([1, 100, 20_000, n // 17])), int(rng.choice([0, 0, 13]))
         got = pa.Table.from_batches(list(LimitExecutor(hip, kk, off, OrderExecutor(hip, ob, bs, limit_hint=kk + off).execute()).execute()))
