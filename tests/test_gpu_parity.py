@@ -211,7 +211,8 @@ def test_hash_join_indices(hip, oracle, jt):
     assert_same(rows_of(got), rows_of(exp))
 
 
-@pytest.mark.parametrize("shape", ["all_hit", "miss_in_the_last_row", "miss_in_the_first_row", "one_row_in_ten_misses", "hook_off"])
+@pytest.mark.parametrize("shape", ["all_hit", "miss_in_the_last_row", "miss_in_the_first_row", "one_row_in_ten_misses", "hook_off",
+                                   "null_build_key_and_max_plus_one"])
 def test_hash_join_dense_probe_all_hit_attempt(hip, oracle, shape, monkeypatch):
     """Direct-address probe, Inner join, unique build keys: the optimistic all-hit kernel (pair i = (build row, i), no
     compaction) runs first and the compacting kernel only redoes the batch when a probe row had no partner.  Index pairs
@@ -229,7 +230,19 @@ def test_hash_join_dense_probe_all_hit_attempt(hip, oracle, shape, monkeypatch):
         pk[0] = 1000 + nb + 7
     elif shape == "one_row_in_ten_misses":
         pk[rng.random(npr) < 0.1] = -3
-    lb = pa.RecordBatch.from_arrays([pa.array(bk), pa.array(bk * 3 + 1)], names=["k", "p"])
+    bka = pa.array(bk)
+    if shape == "null_build_key_and_max_plus_one":
+        # one NULL build key: its row sits in the table slot right behind the key range.  A non-NULL probe key equal to
+        # max build key + 1 addresses exactly that slot and must NOT match (a NULL key only matches a NULL key,
+        # hash_utils.rs:91-104); every other probe row matches, so the all-hit attempt is what runs.
+        mask = np.zeros(nb, dtype=bool)
+        mask[17] = True  # (that row's key value disappears from the build side: no probe row may ask for it)
+        gone = bk[17]
+        bka = pa.array(bk, mask=mask)
+        pk[pk == gone] = bk[18]
+        pk[12345] = bk.max() + 1
+        pk[npr - 2] = bk.max() + 1
+    lb = pa.RecordBatch.from_arrays([bka, pa.array(bk * 3 + 1)], names=["k", "p"])
     rb = pa.RecordBatch.from_arrays([pa.array(pk), pa.array(rng.random(npr))], names=["k", "v"])
     cond = JoinCondition([(InputRef(0), InputRef(0))])
     sch = join_schema(lb, rb)
