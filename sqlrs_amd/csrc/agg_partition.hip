@@ -794,6 +794,228 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
   }
 }
 
+// Bucket pass over SLIM rows (radix_part.hpp PartitionedRows::Slim; radix_part.hip "slim records"): value + 32-bit word
+// {slot | row inside its level-1 tile << rbits | tile delta << (rbits + 13)} per row, 12 instead of 16 bytes.  The word
+// no longer holds the row id — only the first-seen order of the groups needs it (hash_agg.rs:87-99) — so it is rebuilt:
+// row = (base tile of the run the row sits in + delta) * tile + row inside the tile.  The bucket is the concatenation
+// of its non-empty RUNS (one per level-2 input tile that sent it rows) whose starts / base tiles rp_slim_runs_kernel
+// listed; the prologue turns the starts inside this work item's range into one bit per position + a prefix count per
+// 64-position group (LDS), and a row at position p finds its run with two wave-uniform LDS reads and a popcount.  The
+// base tile is then ONE 4-byte load per row from a list a wave reads 1-3 consecutive entries of; it depends on the
+// position only, so it is issued together with the prefetch of the row itself.
+struct SlimBucketIn {
+  const uint64_t *val;
+  const uint32_t *word;
+  const uint32_t *nzstart, *nzbt, *nzcount, *bcol;
+  uint32_t tile;   // rows per level-1 tile
+  uint32_t groups; // 64-position groups the LDS arrays hold (>= those of the largest work item)
+};
+struct SlimRows {
+  uint64_t v[LDS_U];
+  uint32_t w[LDS_U], bt[LDS_U];
+};
+
+template <bool JOIN, int NACC, int C0, int C1>
+__global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
+    LdsAggParams prm, SlimBucketIn in, const uint32_t *__restrict__ work, unsigned long long *out_count,
+    uint64_t *__restrict__ gkey, uint32_t *__restrict__ gfirst, uint64_t *__restrict__ gacc, int64_t gcap, KeyPack kp,
+    SplitTables stb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+  __shared__ unsigned int s_cnt, s_before;
+  __shared__ unsigned long long s_base;
+  __shared__ uint32_t s_wsum[PART_WG / 64];
+  const uint32_t b = work[4 * blockIdx.x];
+  const int64_t lo = work[4 * blockIdx.x + 1];
+  const int64_t hi = work[4 * blockIdx.x + 2];
+  const uint32_t split = work[4 * blockIdx.x + 3];
+  const uint32_t R = prm.cap, mask = R - 1;
+  const int n_acc = NACC >= 0 ? NACC : prm.n_acc;
+  auto code_of = [&](int a) { return NACC >= 0 ? (a == 0 ? C0 : C1) : prm.code[a]; };
+  unsigned long long *tacc = tab;
+  unsigned int *tfirst = (unsigned int *)(tacc + (size_t)n_acc * R);
+  unsigned long long *gmask = (unsigned long long *)(tfirst + R); // [groups] bit = a run starts at this position (> lo)
+  uint32_t *gpre = (uint32_t *)(gmask + in.groups);              // [groups] index of the run holding the group's first row
+  const uint32_t col = in.bcol[b], nruns = in.nzcount[b];
+  const uint32_t ngroups = (uint32_t)((hi - lo + 63) >> 6);
+  const uint64_t le_mask = (2ull << lane_id()) - 1ull;
+  const uint32_t rbits = kp.rbits, lmask = (1u << 13) - 1u;
+
+  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+    tfirst[s] = 0xffffffffu;
+#pragma unroll
+    for (int a = 0; a < PART_MAX_ACC; a++) {
+      if (a >= n_acc) break;
+      tacc[(size_t)a * R + s] = acc_identity_cell(code_of(a) & 7);
+    }
+  }
+  for (uint32_t g = threadIdx.x; g < ngroups; g += PART_WG) gmask[g] = 0;
+  if (threadIdx.x == 0) {
+    s_cnt = 0;
+    s_before = 0;
+  }
+  __syncthreads();
+  { // runs of the bucket: how many start at or before lo, one bit for every start inside (lo, hi)
+    uint32_t before = 0;
+    for (uint32_t k = threadIdx.x; k < nruns; k += PART_WG) {
+      const int64_t st = in.nzstart[col + k];
+      if (st <= lo) before++;
+      else if (st < hi) atomicOr(&gmask[(st - lo) >> 6], 1ull << ((st - lo) & 63));
+    }
+    before = wave_sum_u32(before);
+    if (lane_id() == 0 && before) atomicAdd(&s_before, before);
+  }
+  __syncthreads();
+  { // gpre[g] = (runs starting at or before lo) - 1 + bits of the groups before g
+    constexpr uint32_t GPT = 8; // groups per thread per round
+    uint32_t carry = s_before - 1u; // (the bucket's first run starts at its first row <= lo: s_before >= 1)
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += PART_WG * GPT) {
+      const uint32_t gb = g0 + threadIdx.x * GPT;
+      uint32_t pc[GPT], sum = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < GPT; i++) {
+        pc[i] = gb + i < ngroups ? (uint32_t)__popcll(gmask[gb + i]) : 0u;
+        sum += pc[i];
+      }
+      const uint32_t inc = wave_iscan_u32(sum);
+      if (lane_id() == 63) s_wsum[wave_id()] = inc;
+      __syncthreads();
+      uint32_t wbase = 0, tot = 0;
+      for (int w = 0; w < PART_WG / 64; w++) {
+        if (w < wave_id()) wbase += s_wsum[w];
+        tot += s_wsum[w];
+      }
+      uint32_t run = carry + wbase + inc - sum;
+#pragma unroll
+      for (uint32_t i = 0; i < GPT; i++) {
+        if (gb + i < ngroups) gpre[gb + i] = run;
+        run += pc[i];
+      }
+      carry += tot;
+      __syncthreads();
+    }
+  }
+  // rows [i0, i0 + LDS_U * PART_WG) step PART_WG of this thread: value, word, and the base tile of their run
+  auto load = [&](int64_t i0, SlimRows &r) {
+#pragma unroll
+    for (int u = 0; u < LDS_U; u++) {
+      const int64_t i = min(i0 + (int64_t)u * PART_WG, hi - 1);
+      r.v[u] = __builtin_nontemporal_load(in.val + i);
+      r.w[u] = __builtin_nontemporal_load(in.word + i);
+      const uint32_t g = (uint32_t)((i - lo) >> 6);
+      const uint32_t k = gpre[g] + (uint32_t)__popcll(gmask[g] & le_mask);
+      r.bt[u] = in.nzbt[col + min(k, nruns - 1)];
+    }
+  };
+  SlimRows cur, nxt;
+  if (lo < hi) load(lo + threadIdx.x, cur);
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
+  for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {
+    const int64_t i0 = base + threadIdx.x;
+    load(i0 + (int64_t)LDS_U * PART_WG, nxt);
+#pragma unroll
+    for (int u = 0; u < LDS_U; u++) {
+      const uint32_t w = cur.w[u];
+      const uint32_t s = w & mask;
+      const uint32_t id = (cur.bt[u] + (w >> (rbits + 13))) * in.tile + ((w >> rbits) & lmask);
+      bool act = i0 + (int64_t)u * PART_WG < hi;
+      const uint64_t actm = __ballot(act);
+      if (actm) { // hot keys: see lds_agg_kernel
+        const int first = __builtin_ctzll(actm);
+        const uint32_t s0 = (uint32_t)__shfl((int)s, first, 64);
+        const bool hot = act && s == s0;
+        const uint64_t peers = __ballot(hot);
+        if (__popcll(peers) >= HOT_MIN_PEERS) {
+          const uint32_t idmin = wave_min_u32_dpp(hot ? id : 0xffffffffu);
+          if (lane_id() == first) atomicMin(&tfirst[s0], idmin);
+#pragma unroll
+          for (int a = 0; a < PART_MAX_ACC; a++) {
+            if (a >= n_acc) break;
+            const int kind = code_of(a) & 7;
+            const uint64_t v = cur.v[u];
+            unsigned long long *cell = tacc + (size_t)a * R + s0;
+            uint64_t red;
+            switch (kind) {
+            case AK_COUNT: red = (uint64_t)__popcll(peers); break;
+            case AK_SUM_I64: red = wave_sum_u64_dpp(hot ? v : 0ull); break;
+            case AK_SUM_F64: red = (uint64_t)__double_as_longlong(wave_sum_f64_dpp(hot ? __longlong_as_double((long long)v) : 0.0)); break;
+            case AK_MIN_I64: red = wave_min_u64(hot ? i64_to_ordered((int64_t)v) : ~0ull); break;
+            case AK_MIN_F64: red = wave_min_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : ~0ull); break;
+            case AK_MAX_I64: red = wave_max_u64(hot ? i64_to_ordered((int64_t)v) : 0ull); break;
+            default: red = wave_max_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : 0ull);
+            }
+            if (lane_id() == first) {
+              switch (kind) {
+              case AK_COUNT:
+              case AK_SUM_I64: atomicAdd(cell, (unsigned long long)red); break;
+              case AK_SUM_F64: unsafeAtomicAdd((double *)cell, __longlong_as_double((long long)red)); break;
+              case AK_MIN_I64:
+              case AK_MIN_F64: atomicMin(cell, (unsigned long long)red); break;
+              default: atomicMax(cell, (unsigned long long)red);
+              }
+            }
+          }
+          act = act && !hot;
+        }
+      }
+      if (act) {
+        if (id < tfirst[s]) atomicMin(&tfirst[s], id);
+#pragma unroll
+        for (int a = 0; a < PART_MAX_ACC; a++) {
+          if (a >= n_acc) break;
+          acc_apply(code_of(a) & 7, tacc + (size_t)a * R + s, cur.v[u]);
+        }
+      }
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  if (JOIN && (prm.partner_bits || prm.partner_mult)) { // build keys with gaps: a slot whose key has no build partner is not a group
+    const uint64_t off0 = (uint64_t)b << kp.rbits;
+    for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+      if (tfirst[s] == 0xffffffffu) continue;
+      const uint64_t o = off0 + s;
+      const bool partner = prm.partner_mult ? prm.partner_mult[o] != 0 : (((prm.partner_bits[o >> 6] >> (o & 63)) & 1ull) != 0);
+      if (!partner) tfirst[s] = 0xffffffffu;
+    }
+  }
+  if (split != 0xffffffffu) { // chunk of a split bucket: its table goes out as chunk table `split` (split_emit_dense_kernel reduces)
+    unsigned int *gf = stb.first + (size_t)split * R;
+    for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+      gf[s] = tfirst[s];
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        stb.acc[((size_t)a * stb.nsplit + split) * R + s] = tacc[(size_t)a * R + s];
+      }
+    }
+    return;
+  }
+  unsigned int mine = 0;
+  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) mine += tfirst[s] != 0xffffffffu;
+  unsigned int my_off = atomicAdd(&s_cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = atomicAdd(out_count, (unsigned long long)s_cnt);
+  __syncthreads();
+  unsigned long long obase = s_base + my_off;
+  const uint64_t key0 = kp.kmin + ((uint64_t)b << kp.rbits);
+  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+    unsigned int first = tfirst[s];
+    if (first == 0xffffffffu) continue;
+    if ((int64_t)obase < gcap) {
+      gkey[obase] = key0 + s;
+      gfirst[obase] = first;
+      const unsigned int mlt = (JOIN && prm.partner_mult) ? prm.partner_mult[((uint64_t)b << kp.rbits) + s] : 1u;
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        const unsigned long long cell = tacc[(size_t)a * R + s];
+        gacc[(size_t)a * gcap + obase] = (JOIN && prm.partner_mult) ? acc_times(code_of(a) & 7, cell, mlt) : cell;
+      }
+    }
+    obase++;
+  }
+}
+
 __global__ void first_to_rowid_kernel(const uint32_t *__restrict__ gfirst, int64_t n, uint64_t offset,
                                       uint64_t *__restrict__ out) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1084,6 +1306,14 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
       split_above = chunk;
     }
   }
+  if (pr.slim.on) { // slim rows: a work item's run bits live in LDS next to its table (12 bytes per 64 rows)
+    const size_t table = round_up((size_t)cap * (slot_bytes - 8), 16);
+    const size_t room = 159 * 1024 > table ? 159 * 1024 - table : 0; // (160 KiB per workgroup, static LDS of the kernel included)
+    const uint32_t item_rows = (uint32_t)std::min<size_t>(1u << 18, (room / 12 > 2 ? room / 12 - 2 : 0) * 64);
+    if (item_rows < 16384) return false; // (cannot happen: direct-addressed tables take <= 150 KiB)
+    chunk = std::min(chunk, item_rows);
+    split_above = std::min(split_above, item_rows);
+  }
   std::vector<uint32_t> work, split_bucket, chunk_lo; // dense: chunk_lo[t] = first chunk table of split bucket t
   work.reserve(4 * ((size_t)P + 64));
   out->may_dup = false;
@@ -1186,7 +1416,44 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   } while (0)
     const int nvu = pv1 ? 2 : ((pv0 || pr.rec) ? 1 : 0);
     bool launched = false;
-    if (dense) { // direct-addressed tables (packed rows, nothing nullable, at most one value column)
+    if (dense && pr.slim.on) { // slim rows (radix_part.hpp): value + 32-bit word, row ids rebuilt from the runs
+      uint32_t max_item = 64;
+      for (uint32_t i = 0; i < nwork; i++) max_item = std::max(max_item, work[4 * i + 2] - work[4 * i + 1]);
+      SlimBucketIn sb;
+      sb.val = pr.slim.val->as<uint64_t>();
+      sb.word = pr.slim.word->as<uint32_t>();
+      sb.nzstart = pr.slim.nzstart->as<uint32_t>();
+      sb.nzbt = pr.slim.nzbt->as<uint32_t>();
+      sb.nzcount = pr.slim.nzcount->as<uint32_t>();
+      sb.bcol = pr.slim.bcol->as<uint32_t>();
+      sb.tile = pr.slim.tile;
+      sb.groups = (uint32_t)ceil_div((int64_t)max_item, 64) + 1;
+      const size_t slds = round_up((size_t)cap * (slot_bytes - 8), 16) + 12 * (size_t)sb.groups;
+#define SQ_LS(JN, NA, C0, C1)                                                                                  \
+  do {                                                                                                         \
+    auto kfn = lds_agg_dense_slim_kernel<JN, NA, C0, C1>;                                                       \
+    allow_big_lds(ctx, kfn, 159 * 1024);                                                                                 \
+    kfn<<<dim3(nwork), dim3(PART_WG), slds, ctx->stream>>>(prm, sb, dwork->as<uint32_t>(), ctr->as<unsigned long long>(), \
+                                                           out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(), \
+                                                           out->gacc->as<uint64_t>(), gcap, pr.pack, stb);        \
+    launched = true;                                                                                           \
+  } while (0)
+#define SQ_LS_J(NA, C0, C1) do { if (join_mode) SQ_LS(true, NA, C0, C1); else SQ_LS(false, NA, C0, C1); } while (0)
+      const int c0 = prm.code[0], c1 = spec.n_acc == 2 ? prm.code[1] : -1;
+      if (spec.n_acc == 2 && c0 == AK_COUNT && c1 == AK_SUM_F64) SQ_LS_J(2, AK_COUNT, AK_SUM_F64);
+      else if (spec.n_acc == 2 && c0 == AK_SUM_F64 && c1 == AK_COUNT) SQ_LS_J(2, AK_SUM_F64, AK_COUNT);
+      else if (spec.n_acc == 1 && c0 == AK_SUM_F64) SQ_LS_J(1, AK_SUM_F64, 0);
+      else if (spec.n_acc == 1 && c0 == AK_COUNT) SQ_LS_J(1, AK_COUNT, 0);
+      else SQ_LS_J(-1, 0, 0);
+#undef SQ_LS_J
+#undef SQ_LS
+      if (nsplit) {
+        const int64_t total = (int64_t)nsplit * nslots_h;
+        split_emit_dense_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
+            stb, dsplit->as<uint32_t>(), dchunk_lo->as<uint32_t>(), nsplit, cap, pr.pack, prm, spec.n_acc,
+            ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(), out->gacc->as<uint64_t>(), gcap);
+      }
+    } else if (dense) { // direct-addressed tables (packed rows, nothing nullable, at most one value column)
 #define SQ_LD(NV, JN, NA, C0, C1)                                                                              \
   do {                                                                                                         \
     auto kfn = lds_agg_dense_kernel<NV, JN, NA, C0, C1>;                                                        \

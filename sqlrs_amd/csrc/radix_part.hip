@@ -607,6 +607,465 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
   }
 }
 
+// ------------------------------------------------------------ slim records (12 bytes per row) --
+// The packed two-level partition above moves {key|row word, value} = 16 bytes per kept row through level 1, level 2
+// and the bucket pass: 4 x 16 B.  The row id (30 bits at C5) is only there for the first-seen order of the groups
+// (hash_agg.rs:87-99), and the key bits a level has already consumed travel on for nothing.  The slim form carries
+//   level 1 -> level 2:  value (8 B) + u32 { key offset inside the level-1 digit | row inside its level-1 TILE << kshift }
+//   level 2 -> buckets:  value (8 B) + u32 { slot inside the bucket | row inside its tile << rbits | tile DELTA << (rbits + 13) }
+// and rebuilds the row id where it is needed: row = (base tile of the chunk + tile delta) * TILE + row inside the tile.
+//  * Level 1: workgroup b reads CONSECUTIVE tiles and appends digit d's rows to its open chunk of d, so a chunk is a
+//    sequence of runs, one per tile: the owner thread of the digit writes cstart[chunk][tile - base tile] = fill at the
+//    start of the run (a 2-byte store per tile and digit) and base[chunk].  A chunk is closed early when the next tile
+//    would be more than 127 tiles after its base (the delta has 7 bits).
+//  * Level 2 reads a chunk as one input tile: from cstart[] it builds, in LDS, one bit per position where a non-empty
+//    run starts + the prefix count of those bits per 64-position group + the delta of the k-th non-empty run; a row at
+//    position p then finds its delta with two wave-uniform LDS reads, a popcount and one byte read.
+//  * The bucket pass needs the base tile of the CHUNK a row came from: bucket b is the concatenation of the runs
+//    (input tile i of its segment, digit) in tile order, whose starts are the scanned count matrix's column; a small
+//    kernel (rp_slim_runs_kernel) compacts the non-empty runs of every column to {start, base tile} lists, and the
+//    bucket pass does at bucket scale what level 2 does at chunk scale (agg_partition.hip, lds_agg_dense_slim_kernel).
+// Rows whose key lies outside the dense range (fused join: no build partner) are dropped by level 1 instead of
+// travelling to the last bucket.  C5: 48 -> 40 GB per step.
+constexpr uint32_t SLIM_RUNS = 128;      // cstart entries per chunk = largest tile delta + 1
+constexpr uint32_t SLIM_LOCAL_BITS = 13; // row inside a level-1 tile (tiles of <= 8192 rows)
+struct SlimChunkOut {
+  uint64_t *v0;         // values, chunk c = rows [c * (cap + RP_CHUNK_SKEW), + cap)
+  uint32_t *w;          // words
+  uint32_t *chunk_len;  // rows in chunk c (0 = never used)
+  uint32_t *chunk_dig;  // level-1 digit of chunk c
+  uint32_t *chunk_base; // level-1 tile of the chunk's first run
+  uint16_t *cstart;     // [chunk][SLIM_RUNS] fill at the start of the run of tile base + i (0xffff = no such run)
+  unsigned int *counter; // [1] arena overflow flag
+  uint32_t max_chunks, cap, arena;
+  uint32_t *hist;       // [chunk][next level's digits]
+  uint32_t kshift;      // rbits + p2_bits: bits of the key offset inside a level-1 digit
+  uint32_t max_delta;   // a chunk holds runs of tiles base .. base + max_delta (< SLIM_RUNS; smaller only as a test hook)
+};
+
+// rows of the tile being ranked / staged: the key as its 32-bit offset in the dense range, ~0 = the row does not take
+// part (past the end of a ragged tile, fails the predicate, no bucket).  Half the registers of the loaded form, and the
+// predicate is evaluated once, when the prefetched rows become the current ones.
+template <int RP_ROWS> struct SlimCur {
+  uint32_t off[RP_ROWS];
+  uint64_t a0[RP_ROWS];
+};
+
+template <int RP_WG, int RP_ROWS, int PSRC>
+__global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
+    const uint64_t *__restrict__ key, const uint64_t *__restrict__ v0, RowFilter flt, int64_t n, SlimChunkOut out,
+    uint32_t P, uint32_t p2_bits, uint32_t digits, uint32_t num_tiles, uint32_t tiles_per_wg, int64_t sink, KeyPack kp) {
+  constexpr uint32_t RP_TILE = RP_WG * RP_ROWS;
+  static_assert(RP_TILE <= (1u << SLIM_LOCAL_BITS), "row inside a tile must fit SLIM_LOCAL_BITS");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t *sv0 = (uint64_t *)smem;
+  uint32_t *sw = (uint32_t *)(sv0 + RP_TILE);
+  uint16_t *sdig = (uint16_t *)(sw + RP_TILE);
+  uint32_t *cnt = (uint32_t *)(sdig + RP_TILE); // [RP_WG]
+  uint32_t *split = cnt + RP_WG;                // [RP_WG] tile-local position where a digit's run changes chunk
+  int64_t *gb0 = (int64_t *)(split + RP_WG);    // [RP_WG] destination of position p: gb0[d] + p below the split,
+  int64_t *gb1 = gb0 + RP_WG;                   //         gb1[d] + p from it on
+  uint32_t *room_s = (uint32_t *)(gb1 + RP_WG); // [RP_WG] rows the digit's current chunk can still take
+  uint32_t *close_id = room_s + RP_WG;          // [RP_WG] chunk the digit closes in this tile, or ~0
+  uint32_t *h2 = close_id + RP_WG;              // [P] low half: rows of the digit's current chunk, high: spill of this tile
+  __shared__ uint32_t s_wsum[RP_WG / 64];
+  __shared__ uint32_t s_total;
+  __shared__ uint32_t s_next; // next free chunk of this workgroup's arena
+  const uint32_t d2n = 1u << p2_bits;
+  const uint32_t inmask = (1u << out.kshift) - 1u;
+
+  const uint32_t t0 = blockIdx.x * tiles_per_wg;
+  const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
+  // chunk state of digit threadIdx.x
+  uint32_t cur_id = blockIdx.x * out.arena + min(threadIdx.x, digits - 1), cfill = 0, cbase = 0;
+  bool opened = false; // the current chunk has a first run (cbase is its tile)
+  if (threadIdx.x == 0) s_next = digits;
+  const bool owner = threadIdx.x < digits;
+  room_s[threadIdx.x] = out.cap;
+  for (uint32_t i = threadIdx.x; i < digits * d2n; i += RP_WG) h2[i] = 0;
+  auto tile_start = [&](uint32_t t) { return (int64_t)t * RP_TILE; };
+  auto tile_len = [&](uint32_t t) { return (uint32_t)min((int64_t)RP_TILE, n - (int64_t)t * RP_TILE); };
+
+  ChunkRegs<1, RP_ROWS, PSRC> nxt;
+  SlimCur<RP_ROWS> cur;
+  uint32_t dr[RP_ROWS]; // digit << 16 | rank inside the tile's run of that digit; ~0 = row not kept
+  uint32_t cur_tile = 0;
+  auto take_rows = [&](uint32_t len) { // nxt (as loaded) -> cur
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      bool keep = (uint32_t)(j * RP_WG) + threadIdx.x < len;
+      if (PSRC == 1) keep = keep && row_passes(flt, nxt.a0[j]);
+      if (PSRC == 3) keep = keep && row_passes(flt, nxt.pv[PSRC == 3 ? j : 0]);
+      const uint64_t off = nxt.k[j] - kp.kmin;
+      if (keep && off > kp.range) { // no bucket of the range partition holds this key: the row has no group / no partner
+        if (kp.oob) *kp.oob = 1u;   // (optimistically sampled range: the caller reruns with the exact one)
+        keep = false;
+      }
+      cur.off[j] = keep ? (uint32_t)off : 0xffffffffu;
+      cur.a0[j] = nxt.a0[j];
+    }
+  };
+  auto rank_row = [&](int j) {
+    dr[j] = 0xffffffffu;
+    if (cur.off[j] != 0xffffffffu) {
+      const uint32_t bkt = cur.off[j] >> kp.rbits;
+      const uint32_t d = bkt >> p2_bits;
+      const uint32_t r = atomicAdd(&cnt[d], 1u);
+      atomicAdd(&h2[bkt], r < room_s[d] ? 1u : 0x10000u);
+      dr[j] = (d << 16) | r;
+    }
+  };
+  auto flush_closed = [&]() { // histograms of the chunks named in close_id[] -> out.hist, spill counts move down
+    for (uint32_t i = threadIdx.x; i < digits * d2n; i += RP_WG) {
+      const uint32_t c = close_id[i >> p2_bits];
+      if (c == 0xffffffffu) continue;
+      const uint32_t v = h2[i];
+      out.hist[(size_t)c * d2n + (i & (d2n - 1))] = v & 0xffffu;
+      h2[i] = v >> 16;
+    }
+  };
+  auto take_chunk = [&]() { // next chunk of the workgroup's own arena (an LDS counter)
+    const uint32_t o = atomicAdd(&s_next, 1u);
+    if (o >= out.arena) out.counter[1] = 1; // cannot happen (the arena bound counts the early closes); never out of bounds
+    return blockIdx.x * out.arena + min(o, out.arena - 1);
+  };
+  auto scan_and_stage = [&]() {
+    const uint32_t c = cnt[threadIdx.x];
+    const uint32_t inc = wave_iscan_u32(c);
+    if (lane_id() == 63) s_wsum[wave_id()] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (int w = 0; w < RP_WG / 64; w++) {
+      if (w < wave_id()) wbase += s_wsum[w];
+      tot += s_wsum[w];
+    }
+    const uint32_t ls = wbase + inc - c;
+    if (threadIdx.x == 0) s_total = tot;
+    const uint32_t room = min(c, out.cap - cfill);
+    int64_t g0 = (int64_t)cur_id * (out.cap + RP_CHUNK_SKEW) + cfill, g1 = 0;
+    uint32_t closing = 0xffffffffu;
+    if (owner && c > 0) {
+      if (!opened) { // first run of this chunk
+        opened = true;
+        cbase = cur_tile;
+        out.chunk_base[cur_id] = cur_tile;
+      }
+      out.cstart[(size_t)cur_id * SLIM_RUNS + (cur_tile - cbase)] = (uint16_t)cfill; // (delta <= 127: see the early close below)
+    }
+    if (owner && c > room) { // the run spills into the next chunk of the arena
+      out.chunk_len[cur_id] = out.cap;
+      out.chunk_dig[cur_id] = threadIdx.x;
+      closing = cur_id;
+      cur_id = take_chunk();
+      cfill = c - room;
+      cbase = cur_tile;
+      out.chunk_base[cur_id] = cur_tile;
+      out.cstart[(size_t)cur_id * SLIM_RUNS] = 0;
+      g1 = (int64_t)cur_id * (out.cap + RP_CHUNK_SKEW);
+    } else {
+      cfill += c;
+      if (owner && opened && cur_tile + 1 - cbase > out.max_delta) { // the next tile's delta would not fit: close early
+        out.chunk_len[cur_id] = cfill;
+        out.chunk_dig[cur_id] = threadIdx.x;
+        closing = cur_id;
+        cur_id = take_chunk();
+        cfill = 0;
+        opened = false;
+      }
+    }
+    close_id[threadIdx.x] = closing;
+    cnt[threadIdx.x] = ls;
+    split[threadIdx.x] = ls + room;
+    gb0[threadIdx.x] = g0 - (int64_t)ls;
+    gb1[threadIdx.x] = g1 - (int64_t)(ls + room);
+    room_s[threadIdx.x] = out.cap - cfill;
+    __syncthreads();
+    flush_closed();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      if (dr[j] == 0xffffffffu) continue;
+      const uint32_t d = dr[j] >> 16;
+      const uint32_t p = cnt[d] + (dr[j] & 0xffffu);
+      const uint32_t local = (uint32_t)(j * RP_WG) + threadIdx.x;
+      sv0[p] = cur.a0[j];
+      sw[p] = (cur.off[j] & inmask) | (local << out.kshift);
+      sdig[p] = (uint16_t)d;
+    }
+    __syncthreads();
+  };
+  auto store_row = [&](int j, uint32_t len) {
+    const uint32_t p = j * RP_WG + threadIdx.x;
+    const uint32_t d = (uint32_t)sdig[p] & (RP_WG - 1);
+    int64_t g = (p < split[d] ? gb0[d] : gb1[d]) + p;
+    if (p >= len) g = sink + (int64_t)blockIdx.x * RP_WG + threadIdx.x;
+    RP_ST(&out.v0[g], sv0[p]);
+    RP_ST(&out.w[g], sw[p]);
+  };
+
+  if (t0 < t1) {
+    uint32_t len = tile_len(t0);
+    cur_tile = t0;
+    rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(t0), len, nxt);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    take_rows(len);
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) rank_row(j);
+    __syncthreads();
+    scan_and_stage();
+    uint32_t staged_len = s_total;
+    uint32_t tcur = min(t0 + 1, t1 - 1);
+    len = tile_len(tcur);
+    cur_tile = tcur;
+    rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(tcur), len, nxt);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    take_rows(len);
+    for (uint32_t ti = t0 + 1; ti < t1; ti++) {
+      const uint32_t tnext = min(ti + 1, t1 - 1);
+      const uint32_t nlen = tile_len(tnext);
+      rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(tnext), nlen, nxt);
+      cnt[threadIdx.x] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RP_ROWS; j++) {
+        if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);
+        rank_row(j);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      scan_and_stage();
+      staged_len = s_total;
+      take_rows(nlen);
+      cur_tile = tnext;
+    }
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++)
+      if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);
+  }
+  if (owner) { // publish what is left open
+    out.chunk_len[cur_id] = cfill;
+    out.chunk_dig[cur_id] = threadIdx.x;
+  }
+  __syncthreads();
+  close_id[threadIdx.x] = owner ? cur_id : 0xffffffffu;
+  __syncthreads();
+  flush_closed();
+}
+
+// Level 2 of the slim form: input tile = one chunk of level 1 (values + words), output = value / word columns in
+// bucket order.  The pipeline is rp_scatter_kernel's; what is new is the tile-delta lookup (see the section header).
+struct SlimIn {
+  const uint64_t *v0;
+  const uint32_t *w;
+  const uint32_t *tile_chunk;  // input tile -> chunk
+  const uint16_t *cstart;      // [chunk][SLIM_RUNS]
+};
+struct SlimOut {
+  uint64_t *v0;
+  uint32_t *w;
+};
+template <int RP_ROWS> struct SlimRegs {
+  uint64_t a0[RP_ROWS];
+  uint32_t w[RP_ROWS];
+  uint32_t goff;      // offs[] entry of (digit threadIdx.x, this tile)
+  uint16_t cs0, cs1;  // wave 0 only: cstart[lane], cstart[64 + lane] of the tile's chunk
+};
+template <int RP_WG, int RP_ROWS>
+__device__ __forceinline__ void rp_slim_load(const SlimIn &in, const Tile &t, uint32_t tile_index,
+                                             const uint32_t *__restrict__ offs, uint32_t digits, SlimRegs<RP_ROWS> &r) {
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) {
+    const int64_t row = t.start + min((uint32_t)(j * RP_WG) + threadIdx.x, t.len - 1);
+    r.a0[j] = __builtin_nontemporal_load(in.v0 + row);
+    r.w[j] = __builtin_nontemporal_load(in.w + row);
+  }
+  r.goff = offs[(int64_t)tile_index * digits + min(threadIdx.x, digits - 1)];
+  // (every wave loads — uniform control flow keeps the unrolled load sequence free of early waits; only wave 0 uses them)
+  const uint16_t *cs = in.cstart + (size_t)in.tile_chunk[tile_index] * SLIM_RUNS;
+  r.cs0 = cs[lane_id()];
+  r.cs1 = cs[64 + lane_id()];
+}
+
+template <int RP_WG, int RP_ROWS>
+__global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, SlimOut out, const Tile *__restrict__ tiles,
+                                                                  uint32_t p2_bits, uint32_t digits,
+                                                                  const uint32_t *__restrict__ offs, uint32_t num_tiles,
+                                                                  uint32_t tiles_per_wg, int64_t sink, uint32_t kshift,
+                                                                  uint32_t rbits) {
+  constexpr int RP_TILE = RP_WG * RP_ROWS;
+  static_assert(SLIM_RUNS == 128 && RP_TILE / 64 <= 128, "one mask word per 64 positions of a chunk");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t *sv0 = (uint64_t *)smem;
+  unsigned long long *rmask = (unsigned long long *)(sv0 + RP_TILE); // [128] bit = a non-empty run starts at this position
+  int64_t *gbase = (int64_t *)(rmask + 128);                         // [RP_WG]
+  uint32_t *sw = (uint32_t *)(gbase + RP_WG);
+  uint32_t *cnt = sw + RP_TILE;      // [RP_WG]
+  uint32_t *lstart = cnt + RP_WG;    // [RP_WG]
+  uint32_t *rpre = lstart + RP_WG;   // [128] non-empty runs that start before group g
+  uint8_t *sdig = (uint8_t *)(rpre + 128);
+  uint8_t *rdelta = sdig + RP_TILE;  // [128] tile delta of the k-th non-empty run
+  __shared__ uint32_t s_wsum[RP_WG / 64];
+  __shared__ uint32_t s_psum;
+  const uint32_t d2mask = (1u << p2_bits) - 1u, slotmask = (1u << rbits) - 1u;
+  const uint64_t le_mask = (2ull << lane_id()) - 1ull; // bits 0 .. lane
+
+  const uint32_t t0 = blockIdx.x * tiles_per_wg;
+  const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
+  if (t0 >= t1) return;
+  SlimRegs<RP_ROWS> cur, nxt;
+  uint32_t dr[RP_ROWS]; // digit << 16 | rank inside the tile's run of that digit; ~0 = no row
+  auto rank_row = [&](int j, uint32_t len) {
+    dr[j] = 0xffffffffu;
+    if ((uint32_t)(j * RP_WG) + threadIdx.x < len) {
+      const uint32_t d = (cur.w[j] >> rbits) & d2mask;
+      dr[j] = (d << 16) | atomicAdd(&cnt[d], 1u);
+    }
+  };
+  // wave 0: the chunk's run table -> rmask (bits), rdelta (k-th non-empty run -> tile delta).  A written cstart entry
+  // below the chunk's length IS a non-empty run (level 1 writes an entry only for a tile that brings rows).
+  auto build_runs = [&](uint32_t len) {
+    if (wave_id() != 0) return;
+    const bool f0 = cur.cs0 < len, f1 = cur.cs1 < len;
+    const uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
+    const uint64_t lt = le_mask >> 1;
+    if (f0) {
+      rdelta[__popcll(b0 & lt)] = (uint8_t)lane_id();
+      atomicOr(&rmask[cur.cs0 >> 6], 1ull << (cur.cs0 & 63));
+    }
+    if (f1) {
+      rdelta[__popcll(b0) + __popcll(b1 & lt)] = (uint8_t)(64 + lane_id());
+      atomicOr(&rmask[cur.cs1 >> 6], 1ull << (cur.cs1 & 63));
+    }
+  };
+  auto scan_and_stage = [&]() {
+    uint32_t c = cnt[threadIdx.x];
+    uint32_t inc = wave_iscan_u32(c);
+    if (lane_id() == 63) s_wsum[wave_id()] = inc;
+    // prefix count of the run bits per 64-position group (threads 0..127 = waves 0 and 1)
+    uint32_t pc = 0, pinc = 0;
+    if (threadIdx.x < 128) {
+      pc = (uint32_t)__popcll(rmask[threadIdx.x]);
+      pinc = wave_iscan_u32(pc);
+      if (threadIdx.x == 63) s_psum = pinc;
+    }
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave_id(); w++) wbase += s_wsum[w];
+    uint32_t ls = wbase + inc - c;
+    lstart[threadIdx.x] = ls;
+    gbase[threadIdx.x] = (int64_t)cur.goff - (int64_t)ls;
+    if (threadIdx.x < 128) rpre[threadIdx.x] = pinc - pc + (threadIdx.x >= 64 ? s_psum : 0u);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      if (dr[j] == 0xffffffffu) continue;
+      const uint32_t p = lstart[dr[j] >> 16] + (dr[j] & 0xffffu);
+      const uint32_t g = (uint32_t)(j * (RP_WG / 64)) + (uint32_t)wave_id(); // 64-position group of input position j * RP_WG + tid
+      const uint32_t k = rpre[g] + (uint32_t)__popcll(rmask[g] & le_mask) - 1u;
+      const uint32_t delta = rdelta[k & (SLIM_RUNS - 1)];
+      const uint32_t w = cur.w[j];
+      sv0[p] = cur.a0[j];
+      sw[p] = (w & slotmask) | (((w >> kshift) & ((1u << SLIM_LOCAL_BITS) - 1u)) << rbits) | (delta << (rbits + SLIM_LOCAL_BITS));
+      sdig[p] = (uint8_t)(dr[j] >> 16);
+    }
+    __syncthreads();
+  };
+  auto store_row = [&](int j, uint32_t len) {
+    const uint32_t p = j * RP_WG + threadIdx.x;
+    int64_t g = gbase[sdig[p] & d2mask] + p;
+    if (p >= len) g = sink + threadIdx.x;
+    RP_ST(&out.v0[g], sv0[p]);
+    RP_ST(&out.w[g], sw[p]);
+  };
+
+  Tile t = tiles[t0];
+  rp_slim_load<RP_WG, RP_ROWS>(in, t, t0, offs, digits, cur);
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+  cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 128) rmask[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) rank_row(j, t.len);
+  build_runs(t.len);
+  __syncthreads();
+  scan_and_stage();
+  uint32_t staged_len = t.len;
+  t = tiles[min(t0 + 1, t1 - 1)];
+  rp_slim_load<RP_WG, RP_ROWS>(in, t, min(t0 + 1, t1 - 1), offs, digits, cur);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (uint32_t ti = t0 + 1; ti < t1; ti++) {
+    const uint32_t tnext = min(ti + 1, t1 - 1);
+    Tile tn = tiles[tnext];
+    rp_slim_load<RP_WG, RP_ROWS>(in, tn, tnext, offs, digits, nxt);
+    cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 128) rmask[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      store_row(j, staged_len);
+      rank_row(j, t.len);
+    }
+    build_runs(t.len);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    scan_and_stage();
+    staged_len = t.len;
+    cur = nxt;
+    t = tn;
+  }
+#pragma unroll
+  for (int j = 0; j < RP_ROWS; j++) store_row(j, staged_len);
+}
+
+// Non-empty runs of every bucket's column of the scanned (digit-major) count matrix, compacted in place:
+// bucket b = (segment s, digit d) owns entries [col, col + tiles of s), col = seg_mat[s] + d * seg_tiles[s]; run i of the
+// column is the rows input tile i of the segment sent to the bucket, offs[col + i] its first row in the output.
+// nzstart[col + k] / nzbt[col + k] = start and BASE TILE (of the chunk the input tile was) of the column's k-th
+// non-empty run, nzcount[b] their number, bcol[b] = col.  One workgroup per bucket.
+__global__ __launch_bounds__(256) void rp_slim_runs_kernel(const uint32_t *__restrict__ offs, int64_t entries,
+                                                           const uint64_t *__restrict__ total, const int64_t *__restrict__ seg_mat,
+                                                           const uint32_t *__restrict__ seg_tiles,
+                                                           const uint32_t *__restrict__ seg_tile_base,
+                                                           const uint32_t *__restrict__ tile_chunk,
+                                                           const uint32_t *__restrict__ chunk_base, uint32_t digits,
+                                                           uint32_t *__restrict__ nzstart, uint32_t *__restrict__ nzbt,
+                                                           uint32_t *__restrict__ nzcount, uint32_t *__restrict__ bcol) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t b = blockIdx.x, s = b / digits, d = b % digits;
+  const uint32_t nt = seg_tiles[s];
+  const int64_t col = seg_mat[s] + (int64_t)d * nt;
+  uint32_t done = 0;
+  for (uint32_t i0 = 0; i0 < nt; i0 += 256) {
+    const uint32_t i = i0 + threadIdx.x;
+    uint32_t start = 0, next = 0;
+    if (i < nt) {
+      start = offs[col + i];
+      next = col + i + 1 < entries ? offs[col + i + 1] : (uint32_t)*total;
+    }
+    const bool f = i < nt && next > start;
+    const uint64_t bal = __ballot(f);
+    if (lane_id() == 0) s_w[wave_id()] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t before = done, all = 0;
+    for (int w = 0; w < 4; w++) {
+      if (w < wave_id()) before += s_w[w];
+      all += s_w[w];
+    }
+    if (f) {
+      const uint32_t k = before + (uint32_t)mbcnt(bal);
+      nzstart[col + k] = start;
+      nzbt[col + k] = chunk_base[tile_chunk[seg_tile_base[s] + i]];
+    }
+    done += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    nzcount[b] = done;
+    bcol[b] = (uint32_t)col;
+  }
+}
+
 // ------------------------------------------------------------ claimed single level --
 // A ONE-level partition (<= 512 buckets) without a histogram pass, with an optional row filter fused in: what the
 // chunked first level is to two-level partitions.  The counting form reads every key twice (histogram, then
@@ -1086,6 +1545,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   const int64_t n = in.n;
   if (n <= 0 || n > 0xffffffffll || in.nv > 2) return false;
   out->bend_host.clear();
+  out->slim = PartitionedRows::Slim();
   // digits per level: one level up to 256 buckets, else P = d1 * 2^p2_bits
   uint32_t p2_bits = 0, d1 = std::max(1u, P_wanted);
   if (P_wanted > 512) { // one level handles up to 512 digits (runs of >= 8 rows per tile)
@@ -1172,12 +1632,19 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     out->key = c.k; out->v0 = c.v0; out->v1 = c.v1; out->idx = c.idx; out->flags = c.fl; out->rec = c.rec;
   };
   // one level = hist + scan + scatter over the tiles of `L` (sink = first row behind the output columns)
+  struct SlimLaunch { // level 2 of the slim form: rp_scatter_slim_kernel instead of rp_scatter_kernel
+    SlimIn in;
+    SlimOut out;
+    uint32_t kshift, rbits;
+    BufP total; // (out) the scan's grand total, device u64
+  };
   auto exec_level = [&](int level, uint32_t digits, const Level &L, const RpIn &rin, const RpOut &rout, int64_t sink,
-                        BufP *offs_out, BufP premat = nullptr) {
+                        BufP *offs_out, BufP premat = nullptr, SlimLaunch *slim = nullptr) {
     const int64_t entries = std::max<int64_t>(L.mat_entries, 1);
     BufP mat = premat ? premat : ctx->alloc(4 * (size_t)entries);
     BufP offs = ctx->alloc(4 * (size_t)entries);
     BufP total = ctx->alloc(8);
+    if (slim) slim->total = total;
     unsigned nt = L.num_tiles;
     const Tile *tp = (const Tile *)L.tiles->p;
     if (nt && !premat) {
@@ -1211,6 +1678,24 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       wgs = (uint32_t)ceil_div(nt, tpw);
       dim3 g(wgs), b((unsigned)WG);
       const int mode = level == 1 ? (flags ? RP_L1_NULL : RP_L1) : (flags ? RP_LN_FLAG : RP_LN);
+      if (slim) {
+        const size_t slds = (size_t)RP_TILE * 13 + 1024 + (size_t)WG * 16 + 512 + 128;
+        if (ROWS == 16) {
+          auto kfn = rp_scatter_slim_kernel<512, 16>;
+          allow_big_lds(ctx, kfn);
+          kfn<<<g, b, slds, ctx->stream>>>(slim->in, slim->out, tp, p2_bits, digits, offs_tm->as<uint32_t>(), nt, tpw, sink,
+                                          slim->kshift, slim->rbits);
+        } else {
+          auto kfn = rp_scatter_slim_kernel<512, 12>;
+          allow_big_lds(ctx, kfn);
+          kfn<<<g, b, slds, ctx->stream>>>(slim->in, slim->out, tp, p2_bits, digits, offs_tm->as<uint32_t>(), nt, tpw, sink,
+                                          slim->kshift, slim->rbits);
+        }
+        SQ_HIP(hipGetLastError());
+        slim->total = total;
+        *offs_out = offs;
+        return;
+      }
 #define SQ_RP1(NV, R, M, PK)                                                                                  \
   do {                                                                                                        \
     constexpr bool can_rec = NV == 1 && PK && (R == 12 || R == 16);                                           \
@@ -1377,6 +1862,8 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // (3072-row tiles with two workgroups per CU were measured slower for this level too: 6.4 vs 5.7 ms)
   const uint32_t tiles1 = (uint32_t)ceil_div(n, RP_TILE);
   uint32_t cwgs = std::min<uint32_t>(tiles1, (uint32_t)ctx->num_cus);
+  if (const char *wg_e = std::getenv("SQLRS_RP_CHUNK_WGS")) // test hook, read per call: fewer workgroups = longer tile ranges per workgroup
+    cwgs = std::max(1u, std::min<uint32_t>(cwgs, (uint32_t)std::atoi(wg_e)));
   const uint32_t ctpw = (uint32_t)ceil_div(tiles1, std::max(cwgs, 1u));
   cwgs = (uint32_t)ceil_div(tiles1, std::max(ctpw, 1u));
   const uint64_t spare_chunks = (uint64_t)cwgs * (d1 + 1); // chunks that may stay partly filled or unused
@@ -1389,12 +1876,135 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
                  (chunk_env == 1 || spare_chunks * CAP <= (uint64_t)n); // (the slack of the arenas is a fraction of the input)
   if (in.filter.col && !chunked) return false; // only the chunked first level evaluates a row filter
   if (chunked) {
+    // Slim records (12 instead of 16 bytes per row through level 1, level 2 and the bucket pass; see the section
+    // "slim records" above): dense packed rows with one value column whose chunk histograms fit LDS, bucket tables of
+    // <= 4096 slots.  SQLRS_RP_SLIM=0 (read per call) keeps the 16-byte form (in-process A/B, tests).
+    const char *slim_e = std::getenv("SQLRS_RP_SLIM");
+    const bool slim_on = pack && kp.dense && nv == 1 && (ROWS == 12 || ROWS == 16) && ct_env == 1 && (size_t)P * 4 <= 24 * 1024 &&
+                         kp.rbits + SLIM_LOCAL_BITS + 7 <= 32 && kp.rbits + p2_bits + SLIM_LOCAL_BITS <= 32 &&
+                         !(slim_e && std::atoi(slim_e) == 0) && !(std::getenv("SQLRS_RP_H2") && std::atoi(std::getenv("SQLRS_RP_H2")) == 0);
     // arena mode: a workgroup fills at most ceil(its rows / CAP) chunks completely and leaves <= d1 partly filled
-    const uint64_t arena = (uint64_t)ceil_div((int64_t)ctpw, (int64_t)ct_env) + d1 + 1;
+    // (slim: + the chunks closed early because their next run would be more than SLIM_RUNS - 1 tiles after their first)
+    const char *sd_e = std::getenv("SQLRS_RP_SLIM_DELTA"); // test hook, read per call: early closes at test sizes
+    const uint32_t slim_delta = sd_e ? (uint32_t)std::max(1, std::min<int>(std::atoi(sd_e), (int)SLIM_RUNS - 1)) : SLIM_RUNS - 1;
+    const uint64_t arena = (uint64_t)ceil_div((int64_t)ctpw, (int64_t)ct_env) + d1 + 1 +
+                           (slim_on ? (uint64_t)d1 * (uint64_t)ceil_div((int64_t)ctpw, (int64_t)slim_delta + 1) : 0);
     const uint64_t max_chunks = arena * cwgs;
     if (max_chunks * (CAP + RP_CHUNK_SKEW) + WG * (uint64_t)cwgs > 0xffffffffull) { // Tile::start is 64-bit, rows index u32 math
       if (in.filter.col) return false;
       chunked = false;
+    }
+    if (chunked && slim_on) {
+      const size_t pool_rows = (size_t)max_chunks * (CAP + RP_CHUNK_SKEW) + (size_t)WG * cwgs; // + one sink per workgroup
+      const uint32_t digits2 = 1u << p2_bits;
+      BufP cv = ctx->alloc(8 * pool_rows), cw = ctx->alloc(4 * pool_rows);
+      BufP clen = ctx->alloc_zero(4 * (size_t)max_chunks);
+      BufP cdig = ctx->alloc(4 * (size_t)max_chunks), cbase = ctx->alloc(4 * (size_t)max_chunks);
+      BufP cstart = ctx->alloc(2 * (size_t)max_chunks * SLIM_RUNS);
+      SQ_HIP(hipMemsetAsync(cstart->p, 0xff, 2 * (size_t)max_chunks * SLIM_RUNS, ctx->stream));
+      BufP ctr = ctx->alloc_zero(8);
+      BufP chist = ctx->alloc(4 * (size_t)max_chunks * digits2);
+      SlimChunkOut so;
+      so.v0 = cv->as<uint64_t>();
+      so.w = cw->as<uint32_t>();
+      so.chunk_len = clen->as<uint32_t>();
+      so.chunk_dig = cdig->as<uint32_t>();
+      so.chunk_base = cbase->as<uint32_t>();
+      so.cstart = cstart->as<uint16_t>();
+      so.counter = ctr->as<unsigned int>();
+      so.max_chunks = (uint32_t)max_chunks;
+      so.cap = (uint32_t)CAP;
+      so.arena = (uint32_t)arena;
+      so.hist = chist->as<uint32_t>();
+      so.kshift = kp.rbits + p2_bits;
+      so.max_delta = slim_delta;
+      const int psrc = !in.filter.col ? -1 : ((const void *)in.filter.col == in.vals[0] ? 1 : 3);
+      const size_t clds = (size_t)RP_TILE * 14 + (size_t)WG * (4 + 4 + 8 + 8 + 4 + 4) + (size_t)P * 4;
+      {
+        ProfScope ps(ctx, in.filter.col ? "rp_chunk_scatter_filter" : "rp_chunk_scatter");
+        const int64_t sink = (int64_t)max_chunks * (CAP + RP_CHUNK_SKEW);
+#define SQ_SL1(R, PS)                                                                                                \
+  do {                                                                                                              \
+    auto kfn = rp_chunk_scatter_slim_kernel<512, R, PS>;                                                            \
+    allow_big_lds(ctx, kfn);                                                                                        \
+    kfn<<<dim3(cwgs), dim3(512), clds, ctx->stream>>>(in.keys, (const uint64_t *)in.vals[0], in.filter, n, so, P, p2_bits, d1, \
+                                                      tiles1, ctpw, sink, kp);                                      \
+  } while (0)
+#define SQ_SL(R) do { if (psrc < 0) SQ_SL1(R, -1); else if (psrc == 1) SQ_SL1(R, 1); else SQ_SL1(R, 3); } while (0)
+        if (ROWS == 16) SQ_SL(16); else SQ_SL(12);
+#undef SQ_SL
+#undef SQ_SL1
+        SQ_HIP(hipGetLastError());
+      }
+      // level-2 geometry from the chunk table, on the device (as below)
+      Level L2;
+      L2.nseg = d1;
+      const LevelLayout lay(d1);
+      L2.dev = ctx->alloc(lay.total);
+      bind_level(L2, lay);
+      L2.tiles = ctx->alloc(sizeof(Tile) * (size_t)max_chunks);
+      BufP totals = ctx->alloc(24);
+      BufP tile_chunk = ctx->alloc(4 * (size_t)max_chunks);
+      BufP plan = ctx->alloc(sizeof(ChunkPlan));
+      SQ_HIP(hipMemsetAsync(plan->p, 0, sizeof(ChunkPlan), ctx->stream));
+      const unsigned pblocks = (unsigned)std::min<uint64_t>(ceil_div((int64_t)max_chunks, 256 * 8), 128);
+      rp_chunk_count_kernel<<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(so.chunk_len, so.chunk_dig, so.counter, so.max_chunks,
+                                                                        so.max_chunks, (uint32_t)RP_TILE, plan->as<ChunkPlan>());
+      rp_chunk_prefix_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(
+          plan->as<ChunkPlan>(), so.counter, d1, digits2, (int64_t *)L2.d_seg_start, (int64_t *)L2.d_seg_mat,
+          (uint32_t *)L2.d_seg_tiles, (uint32_t *)L2.d_seg_tile_base, totals->as<uint64_t>());
+      rp_chunk_assign_kernel<<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(
+          so.chunk_len, so.chunk_dig, so.counter, so.max_chunks, so.max_chunks, digits2, (uint32_t)CAP, (uint32_t)RP_TILE,
+          L2.d_seg_tiles, L2.d_seg_tile_base, plan->as<ChunkPlan>(), (Tile *)L2.tiles->p, tile_chunk->as<uint32_t>());
+      SQ_HIP(hipGetLastError());
+      const uint64_t *ht = (const uint64_t *)ctx->fetch(totals->p, 24);
+      const uint64_t ntiles = ht[0], kept = ht[1], overflow = ht[2];
+      if (overflow) return false; // (impossible by the chunk bound; never trusted blindly)
+      L2.num_tiles = (uint32_t)ntiles;
+      L2.mat_entries = (int64_t)ntiles * digits2;
+      out->n = (int64_t)kept;
+      out->P = P;
+      if (kept == 0) { // nothing passed the filter: the caller sees an empty partition
+        out->bstart_host.assign((size_t)P + 1, 0u);
+        out->bstart = nullptr;
+        return true;
+      }
+      const size_t np = (size_t)kept + WG; // + the sink rows
+      PartitionedRows::Slim &sl = out->slim;
+      sl = PartitionedRows::Slim();
+      sl.val = ctx->alloc(8 * np);
+      sl.word = ctx->alloc(4 * np);
+      SlimLaunch sln;
+      sln.in.v0 = so.v0;
+      sln.in.w = so.w;
+      sln.in.tile_chunk = tile_chunk->as<uint32_t>();
+      sln.in.cstart = so.cstart;
+      sln.out.v0 = sl.val->as<uint64_t>();
+      sln.out.w = sl.word->as<uint32_t>();
+      sln.kshift = so.kshift;
+      sln.rbits = kp.rbits;
+      BufP offs2;
+      BufP premat = ctx->alloc(4 * (size_t)L2.mat_entries);
+      rp_hist_from_chunks_kernel<<<dim3((unsigned)ceil_div(L2.mat_entries, 256)), dim3(256), 0, ctx->stream>>>(
+          so.hist, tile_chunk->as<uint32_t>(), L2.mat_entries, digits2, premat->as<uint32_t>());
+      SQ_HIP(hipGetLastError());
+      exec_level(2, digits2, L2, RpIn(), RpOut(), (int64_t)kept, &offs2, premat, &sln);
+      // the non-empty runs of every bucket with the base tile of the chunk they came from
+      sl.nzstart = ctx->alloc(4 * (size_t)L2.mat_entries);
+      sl.nzbt = ctx->alloc(4 * (size_t)L2.mat_entries);
+      sl.nzcount = ctx->alloc(4 * (size_t)P);
+      sl.bcol = ctx->alloc(4 * (size_t)P);
+      ProfScope ps_runs(ctx, "rp_slim_runs");
+      rp_slim_runs_kernel<<<dim3(P), dim3(256), 0, ctx->stream>>>(
+          offs2->as<uint32_t>(), L2.mat_entries, sln.total->as<uint64_t>(), L2.d_seg_mat, L2.d_seg_tiles, L2.d_seg_tile_base,
+          tile_chunk->as<uint32_t>(), so.chunk_base, digits2, sl.nzstart->as<uint32_t>(), sl.nzbt->as<uint32_t>(),
+          sl.nzcount->as<uint32_t>(), sl.bcol->as<uint32_t>());
+      SQ_HIP(hipGetLastError());
+      sl.tile = (uint32_t)RP_TILE;
+      sl.on = true;
+      out->key = out->v0 = out->v1 = out->idx = out->flags = out->rec = nullptr;
+      out->bstart = bucket_starts(L2, offs2, digits2, (int64_t)kept, &out->bstart_host);
+      return true;
     }
     if (chunked) {
       const size_t pool_rows = (size_t)max_chunks * (CAP + RP_CHUNK_SKEW) + (size_t)WG * cwgs; // + one sink per workgroup

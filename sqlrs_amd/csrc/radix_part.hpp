@@ -101,6 +101,16 @@ struct PartitionedRows {
   std::vector<uint32_t> bend_host;
   uint32_t bucket_end(uint32_t b) const { return bend_host.empty() ? bstart_host[b + 1] : bend_host[b]; }
   KeyPack pack; // kbits != 0: `key` holds packed (key, row) words and `idx` is null
+  // Slim form (radix_part.hip, "slim records"; dense packed partitions with one value column): 12 bytes per row —
+  // `val` + a 32-bit `word` = slot in the bucket | row inside its level-1 tile << rbits | tile delta << (rbits + 13);
+  // row id = (nzbt of the run the row sits in + tile delta) * tile + row inside the tile.  key / v0 / rec are null.
+  struct Slim {
+    bool on = false;
+    BufP val, word;     // u64 / u32 per row, bucket order
+    BufP nzstart, nzbt; // u32 per run: first row / base tile of the k-th non-empty run of bucket b at [bcol[b] + k]
+    BufP nzcount, bcol; // u32 [P]
+    uint32_t tile = 0;  // rows per level-1 tile
+  } slim;
 };
 
 // P_wanted <= 65536; the actual bucket count (>= P_wanted) is returned in out->P.

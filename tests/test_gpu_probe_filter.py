@@ -232,6 +232,34 @@ def test_hash_agg_column_form_hook(hip, oracle, dense, monkeypatch):
     assert_same(got, exp, float_cols={2})
 
 
+@pytest.mark.parametrize("hooks", ["default", "long_tile_ranges_early_closes", "one_workgroup", "off"])
+@pytest.mark.parametrize("pred", ["val_gt_half", "other_ne", "key_ge"])
+def test_chunked_slim_records(hip, oracle, hooks, pred, monkeypatch):
+    """Slim records (radix_part.hip): 12-byte rows {value, slot | row-in-tile | tile delta} through both partition levels
+    and the bucket pass, row ids rebuilt from the chunk / run tables — the groups' first-seen order (hash_agg.rs:87-99)
+    must be the oracle's bit for bit.  Only where the chunked level runs (the forced run).  Hooks (read per call):
+    few workgroups = long tile ranges per workgroup, a small largest tile delta = chunks closed early; off = the
+    16-byte form on the same input."""
+    if not FORCED:
+        pytest.skip("needs the chunked first level (SQLRS_RP_CHUNKED=1: the forced run)")
+    env = {"default": {}, "long_tile_ranges_early_closes": {"SQLRS_RP_CHUNK_WGS": "3", "SQLRS_RP_SLIM_DELTA": "5"},
+           "one_workgroup": {"SQLRS_RP_CHUNK_WGS": "1", "SQLRS_RP_SLIM_DELTA": "127"}, "off": {"SQLRS_RP_SLIM": "0"}}[hooks]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(zlib.crc32(f"slim{hooks}{pred}".encode()))
+    lb, rb, sch = tables(rng, 2_400_000, 2_500_000, sparse=False)
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    hip.profile(True)
+    ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, AGGS["count_sum"], [InputRef(0)], probe_filter=PREDS[pred])
+    got = rows_of(ex.execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    assert ex.fused_batches == 1 and ex.filter_fused_batches == 1
+    assert (prof.get("rp_slim_runs", (0, 0))[1] > 0) == (hooks != "off"), prof
+    exp = reference(oracle, lb, [rb], cond, sch, 2, AGGS["count_sum"], [InputRef(0)], PREDS[pred])
+    assert_same(got, exp, float_cols={2})
+
+
 def test_chunked_first_level_forced():
     if FORCED:
         pytest.skip("already inside the forced run")
@@ -239,7 +267,7 @@ def test_chunked_first_level_forced():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "(chunked and not forced and ((count_sum and (val_gt_half or (key_ge and False))) "
                               "or (hot_digit and 0.3) or (hash_agg_chunked and dense) or (without_chunk_histograms and False))) "
-                              "or (child_filter and val_gt_half and (dense_two_level or sparse))"], env=env, capture_output=True,
+                              "or (child_filter and val_gt_half and (dense_two_level or sparse)) or slim_records"], env=env, capture_output=True,
                        text=True, timeout=1700)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     # (the same level with SQLRS_RP_H2=0 — level 2 running its own histogram pass — is part of that run:
