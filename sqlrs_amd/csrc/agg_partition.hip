@@ -804,13 +804,12 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
 // base tile is then ONE 4-byte load per row from a list a wave reads 1-3 consecutive entries of; it depends on the
 // position only, so it is issued together with the prefetch of the row itself.
 struct SlimBucketIn {
-  const uint64_t *val;
-  const uint32_t *word;
+  SlimRowsView rows;
   const uint32_t *nzstart, *nzbt, *nzcount, *bcol;
   uint32_t tile;   // rows per level-1 tile
   uint32_t groups; // 64-position groups the LDS arrays hold (>= those of the largest work item)
 };
-struct SlimRows {
+struct SlimAggRows {
   uint64_t v[LDS_U];
   uint32_t w[LDS_U], bt[LDS_U];
 };
@@ -895,18 +894,17 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
     }
   }
   // rows [i0, i0 + LDS_U * PART_WG) step PART_WG of this thread: value, word, and the base tile of their run
-  auto load = [&](int64_t i0, SlimRows &r) {
+  auto load = [&](int64_t i0, SlimAggRows &r) {
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
       const int64_t i = min(i0 + (int64_t)u * PART_WG, hi - 1);
-      r.v[u] = __builtin_nontemporal_load(in.val + i);
-      r.w[u] = __builtin_nontemporal_load(in.word + i);
+      slim_load_nt(in.rows, i, r.w[u], r.v[u]);
       const uint32_t g = (uint32_t)((i - lo) >> 6);
       const uint32_t k = gpre[g] + (uint32_t)__popcll(gmask[g] & le_mask);
       r.bt[u] = in.nzbt[col + min(k, nruns - 1)];
     }
   };
-  SlimRows cur, nxt;
+  SlimAggRows cur, nxt;
   if (lo < hi) load(lo + threadIdx.x, cur);
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
   for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {
@@ -1420,8 +1418,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
       uint32_t max_item = 64;
       for (uint32_t i = 0; i < nwork; i++) max_item = std::max(max_item, work[4 * i + 2] - work[4 * i + 1]);
       SlimBucketIn sb;
-      sb.val = pr.slim.val->as<uint64_t>();
-      sb.word = pr.slim.word->as<uint32_t>();
+      sb.rows = pr.slim.rows;
       sb.nzstart = pr.slim.nzstart->as<uint32_t>();
       sb.nzbt = pr.slim.nzbt->as<uint32_t>();
       sb.nzcount = pr.slim.nzcount->as<uint32_t>();

@@ -11,6 +11,7 @@
 // Level 2 splits every level-1 bucket again (MSD order), giving up to 65536 buckets.
 // When the key range is known the row id rides in the key word (KeyPack, radix_part.hpp):
 // 16 instead of 20 bytes per row.
+#include <cstdio>
 #include <cstdlib>
 
 #include "device_utils.hpp"
@@ -630,8 +631,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
 constexpr uint32_t SLIM_RUNS = 128;      // cstart entries per chunk = largest tile delta + 1
 constexpr uint32_t SLIM_LOCAL_BITS = 13; // row inside a level-1 tile (tiles of <= 8192 rows)
 struct SlimChunkOut {
-  uint64_t *v0;         // values, chunk c = rows [c * (cap + RP_CHUNK_SKEW), + cap)
-  uint32_t *w;          // words
+  SlimRowsView rows;    // chunk c = rows [c * (cap + RP_CHUNK_SKEW), + cap)
   uint32_t *chunk_len;  // rows in chunk c (0 = never used)
   uint32_t *chunk_dig;  // level-1 digit of chunk c
   uint32_t *chunk_base; // level-1 tile of the chunk's first run
@@ -798,8 +798,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
     const uint32_t d = (uint32_t)sdig[p] & (RP_WG - 1);
     int64_t g = (p < split[d] ? gb0[d] : gb1[d]) + p;
     if (p >= len) g = sink + (int64_t)blockIdx.x * RP_WG + threadIdx.x;
-    RP_ST(&out.v0[g], sv0[p]);
-    RP_ST(&out.w[g], sw[p]);
+    slim_store(out.rows, g, sw[p], sv0[p]);
   };
 
   if (t0 < t1) {
@@ -856,14 +855,12 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
 // Level 2 of the slim form: input tile = one chunk of level 1 (values + words), output = value / word columns in
 // bucket order.  The pipeline is rp_scatter_kernel's; what is new is the tile-delta lookup (see the section header).
 struct SlimIn {
-  const uint64_t *v0;
-  const uint32_t *w;
+  SlimRowsView rows;
   const uint32_t *tile_chunk;  // input tile -> chunk
   const uint16_t *cstart;      // [chunk][SLIM_RUNS]
 };
 struct SlimOut {
-  uint64_t *v0;
-  uint32_t *w;
+  SlimRowsView rows;
 };
 template <int RP_ROWS> struct SlimRegs {
   uint64_t a0[RP_ROWS];
@@ -877,8 +874,7 @@ __device__ __forceinline__ void rp_slim_load(const SlimIn &in, const Tile &t, ui
 #pragma unroll
   for (int j = 0; j < RP_ROWS; j++) {
     const int64_t row = t.start + min((uint32_t)(j * RP_WG) + threadIdx.x, t.len - 1);
-    r.a0[j] = __builtin_nontemporal_load(in.v0 + row);
-    r.w[j] = __builtin_nontemporal_load(in.w + row);
+    slim_load_nt(in.rows, row, r.w[j], r.a0[j]);
   }
   r.goff = offs[(int64_t)tile_index * digits + min(threadIdx.x, digits - 1)];
   // (every wave loads — uniform control flow keeps the unrolled load sequence free of early waits; only wave 0 uses them)
@@ -910,9 +906,13 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
   const uint32_t d2mask = (1u << p2_bits) - 1u, slotmask = (1u << rbits) - 1u;
   const uint64_t le_mask = (2ull << lane_id()) - 1ull; // bits 0 .. lane
 
+  // (a segment-synchronous schedule — every workgroup inside the same level-1 segment at any time, 64 instead of ~2400
+  //  bucket regions written concurrently — was measured SLOWER in every one of six placements, 2.66-3.24 against 2.54-3.21 ms:
+  //  the spread of this kernel between allocations is not a TLB-reach effect)
   const uint32_t t0 = blockIdx.x * tiles_per_wg;
   const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
   if (t0 >= t1) return;
+  auto tile_of = [&](uint32_t slot) { return slot; };
   SlimRegs<RP_ROWS> cur, nxt;
   uint32_t dr[RP_ROWS]; // digit << 16 | rank inside the tile's run of that digit; ~0 = no row
   auto rank_row = [&](int j, uint32_t len) {
@@ -975,12 +975,12 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
     const uint32_t p = j * RP_WG + threadIdx.x;
     int64_t g = gbase[sdig[p] & d2mask] + p;
     if (p >= len) g = sink + threadIdx.x;
-    RP_ST(&out.v0[g], sv0[p]);
-    RP_ST(&out.w[g], sw[p]);
+    slim_store(out.rows, g, sw[p], sv0[p]);
   };
 
-  Tile t = tiles[t0];
-  rp_slim_load<RP_WG, RP_ROWS>(in, t, t0, offs, digits, cur);
+  uint32_t tix = tile_of(t0);
+  Tile t = tiles[tix];
+  rp_slim_load<RP_WG, RP_ROWS>(in, t, tix, offs, digits, cur);
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
   cnt[threadIdx.x] = 0;
   if (threadIdx.x < 128) rmask[threadIdx.x] = 0;
@@ -991,11 +991,12 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
   __syncthreads();
   scan_and_stage();
   uint32_t staged_len = t.len;
-  t = tiles[min(t0 + 1, t1 - 1)];
-  rp_slim_load<RP_WG, RP_ROWS>(in, t, min(t0 + 1, t1 - 1), offs, digits, cur);
+  tix = tile_of(min(t0 + 1, t1 - 1));
+  t = tiles[tix];
+  rp_slim_load<RP_WG, RP_ROWS>(in, t, tix, offs, digits, cur);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   for (uint32_t ti = t0 + 1; ti < t1; ti++) {
-    const uint32_t tnext = min(ti + 1, t1 - 1);
+    const uint32_t tnext = tile_of(min(ti + 1, t1 - 1));
     Tile tn = tiles[tnext];
     rp_slim_load<RP_WG, RP_ROWS>(in, tn, tnext, offs, digits, nxt);
     cnt[threadIdx.x] = 0;
@@ -1897,7 +1898,20 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     if (chunked && slim_on) {
       const size_t pool_rows = (size_t)max_chunks * (CAP + RP_CHUNK_SKEW) + (size_t)WG * cwgs; // + one sink per workgroup
       const uint32_t digits2 = 1u << p2_bits;
-      BufP cv = ctx->alloc(8 * pool_rows), cw = ctx->alloc(4 * pool_rows);
+      auto slim_alloc = [&](size_t rows, BufP &b0, BufP &b1) {
+        SlimRowsView v;
+#ifdef SLIM_AOS
+        b0 = ctx->alloc(sizeof(SlimRec) * rows);
+        v.rec = b0->as<SlimRec>();
+#else
+        b0 = ctx->alloc(8 * rows);
+        b1 = ctx->alloc(4 * rows);
+        v.v = b0->as<uint64_t>();
+        v.w = b1->as<uint32_t>();
+#endif
+        return v;
+      };
+      BufP cb0, cb1;
       BufP clen = ctx->alloc_zero(4 * (size_t)max_chunks);
       BufP cdig = ctx->alloc(4 * (size_t)max_chunks), cbase = ctx->alloc(4 * (size_t)max_chunks);
       BufP cstart = ctx->alloc(2 * (size_t)max_chunks * SLIM_RUNS);
@@ -1905,8 +1919,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       BufP ctr = ctx->alloc_zero(8);
       BufP chist = ctx->alloc(4 * (size_t)max_chunks * digits2);
       SlimChunkOut so;
-      so.v0 = cv->as<uint64_t>();
-      so.w = cw->as<uint32_t>();
+      so.rows = slim_alloc(pool_rows, cb0, cb1);
       so.chunk_len = clen->as<uint32_t>();
       so.chunk_dig = cdig->as<uint32_t>();
       so.chunk_base = cbase->as<uint32_t>();
@@ -1972,15 +1985,12 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       const size_t np = (size_t)kept + WG; // + the sink rows
       PartitionedRows::Slim &sl = out->slim;
       sl = PartitionedRows::Slim();
-      sl.val = ctx->alloc(8 * np);
-      sl.word = ctx->alloc(4 * np);
+      sl.rows = slim_alloc(np, sl.buf0, sl.buf1);
       SlimLaunch sln;
-      sln.in.v0 = so.v0;
-      sln.in.w = so.w;
+      sln.in.rows = so.rows;
       sln.in.tile_chunk = tile_chunk->as<uint32_t>();
       sln.in.cstart = so.cstart;
-      sln.out.v0 = sl.val->as<uint64_t>();
-      sln.out.w = sl.word->as<uint32_t>();
+      sln.out.rows = sl.rows;
       sln.kshift = so.kshift;
       sln.rbits = kp.rbits;
       BufP offs2;
@@ -2000,6 +2010,10 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
           tile_chunk->as<uint32_t>(), so.chunk_base, digits2, sl.nzstart->as<uint32_t>(), sl.nzbt->as<uint32_t>(),
           sl.nzcount->as<uint32_t>(), sl.bcol->as<uint32_t>());
       SQ_HIP(hipGetLastError());
+      if (std::getenv("SQLRS_RP_TRACE")) // placement experiments (tools/placement_log.py): where the big buffers sit
+        std::fprintf(stderr, "[rp_slim] keys %p vals %p chunks %p %p rows %p %p kept %llu tiles %u\n", (const void *)in.keys, in.vals[0],
+                     cb0 ? cb0->p : nullptr, cb1 ? cb1->p : nullptr, sl.buf0 ? sl.buf0->p : nullptr, sl.buf1 ? sl.buf1->p : nullptr,
+                     (unsigned long long)kept, L2.num_tiles);
       sl.tile = (uint32_t)RP_TILE;
       sl.on = true;
       out->key = out->v0 = out->v1 = out->idx = out->flags = out->rec = nullptr;

@@ -47,6 +47,42 @@ __device__ __forceinline__ uint64_t packed_off(const KeyPack &kp, uint64_t w) { 
 __device__ __forceinline__ uint32_t packed_row(const KeyPack &kp, uint64_t w) { return (uint32_t)(w >> kp.kbits); }
 #endif
 
+// Rows of the slim form (see PartitionedRows::Slim): a value column + a 32-bit word column by default; -DSLIM_AOS =
+// 12-byte {word, value} records, one dwordx3 access per row (compile-time A/B: tools/ab_two_builds.sh — measured: the
+// partition levels gain 0.2 ms from the longer contiguous runs, the bucket pass loses 0.4 ms to the 12-byte lane stride)
+struct SlimRec {
+  uint32_t w, vlo, vhi;
+};
+struct SlimRowsView {
+#ifdef SLIM_AOS
+  SlimRec *rec = nullptr;
+#else
+  uint64_t *v = nullptr;
+  uint32_t *w = nullptr;
+#endif
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ void slim_store(const SlimRowsView &r, int64_t g, uint32_t w, uint64_t v) {
+#ifdef SLIM_AOS
+  r.rec[g] = SlimRec{w, (uint32_t)v, (uint32_t)(v >> 32)};
+#else
+  r.v[g] = v;
+  r.w[g] = w;
+#endif
+}
+__device__ __forceinline__ void slim_load_nt(const SlimRowsView &r, int64_t i, uint32_t &w, uint64_t &v) {
+#ifdef SLIM_AOS
+  const SlimRec *p = r.rec + i;
+  const uint32_t a = __builtin_nontemporal_load(&p->w), lo = __builtin_nontemporal_load(&p->vlo), hi = __builtin_nontemporal_load(&p->vhi);
+  w = a;
+  v = (uint64_t)lo | ((uint64_t)hi << 32);
+#else
+  v = __builtin_nontemporal_load(r.v + i);
+  w = __builtin_nontemporal_load(r.w + i);
+#endif
+}
+#endif
+
 // A row predicate `col OP constant` evaluated by the FIRST partition pass itself (FilterExecutor
 // directly below the partitioned operator, filter.rs:13-25): rows that fail are neither counted nor
 // moved, so the filter's own read + compacted write of every column never happens.  `col` holds
@@ -102,11 +138,12 @@ struct PartitionedRows {
   uint32_t bucket_end(uint32_t b) const { return bend_host.empty() ? bstart_host[b + 1] : bend_host[b]; }
   KeyPack pack; // kbits != 0: `key` holds packed (key, row) words and `idx` is null
   // Slim form (radix_part.hip, "slim records"; dense packed partitions with one value column): 12 bytes per row —
-  // `val` + a 32-bit `word` = slot in the bucket | row inside its level-1 tile << rbits | tile delta << (rbits + 13);
+  // an 8-byte value + a 32-bit word = slot in the bucket | row inside its level-1 tile << rbits | tile delta << (rbits + 13);
   // row id = (nzbt of the run the row sits in + tile delta) * tile + row inside the tile.  key / v0 / rec are null.
   struct Slim {
     bool on = false;
-    BufP val, word;     // u64 / u32 per row, bucket order
+    BufP buf0, buf1;    // the rows in bucket order (values, words; SLIM_AOS: records, null)
+    SlimRowsView rows;  // device view of buf0 / buf1
     BufP nzstart, nzbt; // u32 per run: first row / base tile of the k-th non-empty run of bucket b at [bcol[b] + k]
     BufP nzcount, bcol; // u32 [P]
     uint32_t tile = 0;  // rows per level-1 tile

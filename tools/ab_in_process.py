@@ -22,6 +22,8 @@ def step():
     pipe.step(bench.device_batch(abi, [dk], [abi.INT64]), bench.device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64])).release()
 VAR = os.environ.get("VAR", "SQLRS_RP_CHUNK_TILES")  # a hook the library reads per call
 for rep in range(int(os.environ.get("REPS", 3))):
+    if os.environ.get("TRIM"):  # fresh pool blocks every round: the variants are compared over several placements
+        be.fn("ctx_pool_trim")(be.ctx)
     for st in os.environ.get("VALUES", "1").split(","):
         os.environ[VAR] = st
         step(); be.synchronize()
