@@ -809,6 +809,7 @@ struct SlimBucketIn {
   uint32_t tile;   // rows per level-1 tile
   uint32_t groups; // 64-position groups the LDS arrays hold (>= those of the largest work item)
 };
+constexpr uint32_t SLIM_BT_CAP = 4096; // base tiles of a work item's runs kept in LDS (16 KiB)
 struct SlimAggRows {
   uint64_t v[LDS_U];
   uint32_t w[LDS_U], bt[LDS_U];
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
     uint64_t *__restrict__ gkey, uint32_t *__restrict__ gfirst, uint64_t *__restrict__ gacc, int64_t gcap, KeyPack kp,
     SplitTables stb) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
-  __shared__ unsigned int s_cnt, s_before;
+  __shared__ unsigned int s_cnt, s_before, s_inside;
   __shared__ unsigned long long s_base;
   __shared__ uint32_t s_wsum[PART_WG / 64];
   const uint32_t b = work[4 * blockIdx.x];
@@ -834,6 +835,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   unsigned int *tfirst = (unsigned int *)(tacc + (size_t)n_acc * R);
   unsigned long long *gmask = (unsigned long long *)(tfirst + R); // [groups] bit = a run starts at this position (> lo)
   uint32_t *gpre = (uint32_t *)(gmask + in.groups);              // [groups] index of the run holding the group's first row
+  uint32_t *gbt = gpre + in.groups;                              // [SLIM_BT_CAP] base tiles of the item's runs (when they fit)
   const uint32_t col = in.bcol[b], nruns = in.nzcount[b];
   const uint32_t ngroups = (uint32_t)((hi - lo + 63) >> 6);
   const uint64_t le_mask = (2ull << lane_id()) - 1ull;
@@ -851,19 +853,31 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   if (threadIdx.x == 0) {
     s_cnt = 0;
     s_before = 0;
+    s_inside = 0;
   }
   __syncthreads();
   { // runs of the bucket: how many start at or before lo, one bit for every start inside (lo, hi)
-    uint32_t before = 0;
+    uint32_t before = 0, inside = 0;
     for (uint32_t k = threadIdx.x; k < nruns; k += PART_WG) {
       const int64_t st = in.nzstart[col + k];
       if (st <= lo) before++;
-      else if (st < hi) atomicOr(&gmask[(st - lo) >> 6], 1ull << ((st - lo) & 63));
+      else if (st < hi) {
+        inside++;
+        atomicOr(&gmask[(st - lo) >> 6], 1ull << ((st - lo) & 63));
+      }
     }
     before = wave_sum_u32(before);
+    inside = wave_sum_u32(inside);
     if (lane_id() == 0 && before) atomicAdd(&s_before, before);
+    if (lane_id() == 0 && inside) atomicAdd(&s_inside, inside);
   }
   __syncthreads();
+  // the base tiles of the runs this item touches (run s_before - 1 holds row lo, then the `inside` runs that start inside
+  // the item) go to LDS when they fit: one LDS read per row instead of a global load (1.59 -> ~1.48 ms per C5 step)
+  const uint32_t k_first = s_before - 1u, k_count = s_inside + 1u;
+  const bool bt_lds = k_count <= SLIM_BT_CAP;
+  if (bt_lds)
+    for (uint32_t k = threadIdx.x; k < k_count; k += PART_WG) gbt[k] = in.nzbt[col + min(k_first + k, nruns - 1)];
   { // gpre[g] = (runs starting at or before lo) - 1 + bits of the groups before g
     constexpr uint32_t GPT = 8; // groups per thread per round
     uint32_t carry = s_before - 1u; // (the bucket's first run starts at its first row <= lo: s_before >= 1)
@@ -901,7 +915,11 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
       slim_load_nt(in.rows, i, r.w[u], r.v[u]);
       const uint32_t g = (uint32_t)((i - lo) >> 6);
       const uint32_t k = gpre[g] + (uint32_t)__popcll(gmask[g] & le_mask);
-      r.bt[u] = in.nzbt[col + min(k, nruns - 1)];
+#if defined(SLIM_DBG) && (SLIM_DBG & 16)
+      r.bt[u] = k; // timing experiment: no base-tile load (row ids wrong)
+#else
+      r.bt[u] = bt_lds ? gbt[min(k - k_first, k_count - 1)] : in.nzbt[col + min(k, nruns - 1)];
+#endif
     }
   };
   SlimAggRows cur, nxt;
@@ -910,20 +928,33 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {
     const int64_t i0 = base + threadIdx.x;
     load(i0 + (int64_t)LDS_U * PART_WG, nxt);
+    // LDS operations complete in order: a read behind an atomic waits for it.  So the trip's reads (the slots' current
+    // first rows) are all issued BEFORE its atomics — a stale (larger) first row only costs a redundant atomicMin —
+    // and the hot-key test takes the first active lane's slot with v_readlane, not with a ds_bpermute shuffle.
+    uint32_t sl[LDS_U], id[LDS_U], tf[LDS_U];
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
       const uint32_t w = cur.w[u];
-      const uint32_t s = w & mask;
-      const uint32_t id = (cur.bt[u] + (w >> (rbits + 13))) * in.tile + ((w >> rbits) & lmask);
+      sl[u] = w & mask;
+      id[u] = (cur.bt[u] + (w >> (rbits + 13))) * in.tile + ((w >> rbits) & lmask);
+      tf[u] = tfirst[sl[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < LDS_U; u++) {
+      const uint32_t s = sl[u];
       bool act = i0 + (int64_t)u * PART_WG < hi;
+#ifdef SLIM_DBG
+      const uint64_t actm = (SLIM_DBG & 1) ? 0ull : __ballot(act); // timing experiments only (results invalid)
+#else
       const uint64_t actm = __ballot(act);
+#endif
       if (actm) { // hot keys: see lds_agg_kernel
         const int first = __builtin_ctzll(actm);
-        const uint32_t s0 = (uint32_t)__shfl((int)s, first, 64);
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)s, first);
         const bool hot = act && s == s0;
         const uint64_t peers = __ballot(hot);
         if (__popcll(peers) >= HOT_MIN_PEERS) {
-          const uint32_t idmin = wave_min_u32_dpp(hot ? id : 0xffffffffu);
+          const uint32_t idmin = wave_min_u32_dpp(hot ? id[u] : 0xffffffffu);
           if (lane_id() == first) atomicMin(&tfirst[s0], idmin);
 #pragma unroll
           for (int a = 0; a < PART_MAX_ACC; a++) {
@@ -956,12 +987,22 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
         }
       }
       if (act) {
-        if (id < tfirst[s]) atomicMin(&tfirst[s], id);
+#ifdef SLIM_DBG
+        if (!(SLIM_DBG & 8) && id[u] < tf[u]) atomicMin(&tfirst[s], id[u]);
+#pragma unroll
+        for (int a = 0; a < PART_MAX_ACC; a++) {
+          if (a >= n_acc) break;
+          if ((SLIM_DBG >> (1 + a)) & 1) continue;
+          acc_apply(code_of(a) & 7, tacc + (size_t)a * R + s, cur.v[u]);
+        }
+#else
+        if (id[u] < tf[u]) atomicMin(&tfirst[s], id[u]);
 #pragma unroll
         for (int a = 0; a < PART_MAX_ACC; a++) {
           if (a >= n_acc) break;
           acc_apply(code_of(a) & 7, tacc + (size_t)a * R + s, cur.v[u]);
         }
+#endif
       }
     }
     cur = nxt;
@@ -1306,7 +1347,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   }
   if (pr.slim.on) { // slim rows: a work item's run bits live in LDS next to its table (12 bytes per 64 rows)
     const size_t table = round_up((size_t)cap * (slot_bytes - 8), 16);
-    const size_t room = 159 * 1024 > table ? 159 * 1024 - table : 0; // (160 KiB per workgroup, static LDS of the kernel included)
+    const size_t room = 159 * 1024 > table + 4 * SLIM_BT_CAP ? 159 * 1024 - table - 4 * SLIM_BT_CAP : 0; // (160 KiB per workgroup, static LDS included)
     const uint32_t item_rows = (uint32_t)std::min<size_t>(1u << 18, (room / 12 > 2 ? room / 12 - 2 : 0) * 64);
     if (item_rows < 16384) return false; // (cannot happen: direct-addressed tables take <= 150 KiB)
     chunk = std::min(chunk, item_rows);
@@ -1425,7 +1466,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
       sb.bcol = pr.slim.bcol->as<uint32_t>();
       sb.tile = pr.slim.tile;
       sb.groups = (uint32_t)ceil_div((int64_t)max_item, 64) + 1;
-      const size_t slds = round_up((size_t)cap * (slot_bytes - 8), 16) + 12 * (size_t)sb.groups;
+      const size_t slds = round_up((size_t)cap * (slot_bytes - 8), 16) + 12 * (size_t)sb.groups + 4 * SLIM_BT_CAP;
 #define SQ_LS(JN, NA, C0, C1)                                                                                  \
   do {                                                                                                         \
     auto kfn = lds_agg_dense_slim_kernel<JN, NA, C0, C1>;                                                       \

@@ -179,8 +179,62 @@ int probe_composite(){
   return 0;
 }
 
+
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+// ---- width sweep: does the streaming rate depend on the bytes a lane loads per instruction? (mode 'w')
+template<class T, int NT> __global__ void k_read_w(const T* __restrict__ a, uint64_t* out, size_t n){
+  size_t i = blockIdx.x*(size_t)blockDim.x+threadIdx.x, s=(size_t)gridDim.x*blockDim.x;
+  uint64_t acc=0;
+  for(; i + 3*s < n; i += 4*s){
+    T v0 = NT ? __builtin_nontemporal_load(a+i) : a[i], v1 = NT ? __builtin_nontemporal_load(a+i+s) : a[i+s];
+    T v2 = NT ? __builtin_nontemporal_load(a+i+2*s) : a[i+2*s], v3 = NT ? __builtin_nontemporal_load(a+i+3*s) : a[i+3*s];
+    acc += (uint64_t)v0 ^ (uint64_t)v1 ^ (uint64_t)v2 ^ (uint64_t)v3;
+  }
+  if(acc==0x1234567) out[0]=acc;
+}
+// one workgroup streams ONE contiguous region (the bucket pass's shape): rows of 8 B + 4 B in two columns, or 16 B in one
+template<int MODE> __global__ __launch_bounds__(512) void k_region(const uint64_t* __restrict__ v, const uint32_t* __restrict__ w, const ulonglong2* __restrict__ r16,
+                                                              uint64_t* out, size_t rows_per_wg){
+  const size_t lo = blockIdx.x * rows_per_wg, hi = lo + rows_per_wg;
+  uint64_t acc = 0;
+  if(MODE!=2) for(size_t i = lo + threadIdx.x; i + 3*512 < hi; i += 4*512){
+    if(MODE==0){ // 8 + 4 bytes per row, two loads
+      #pragma unroll
+      for(int u=0;u<4;u++){ acc += __builtin_nontemporal_load(v+i+u*512) ^ __builtin_nontemporal_load(w+i+u*512); }
+    } else if(MODE==1){ // 16-byte rows, one load
+      #pragma unroll
+      for(int u=0;u<4;u++){ u64x2_t t = __builtin_nontemporal_load((const u64x2_t*)r16+i+u*512); acc += t.x ^ t.y; }
+    }
+  }
+  if(MODE==2){ // 8 + 4 bytes per row, a lane takes TWO consecutive rows: one 16-byte and one 8-byte load per pair
+    for(size_t q = threadIdx.x; q + 512 < rows_per_wg/2; q += 2*512){
+      #pragma unroll
+      for(int u=0;u<2;u++){ const size_t p = lo + 2*(q + u*512);
+        u64x2_t t = __builtin_nontemporal_load((const u64x2_t*)(v+p)); uint64_t ww = __builtin_nontemporal_load((const uint64_t*)(w+p)); acc += t.x ^ t.y ^ ww; }
+    }
+  }
+  if(acc==0x1234567) out[0]=acc;
+}
+int width_sweep(){
+  const size_t GB=1ull<<30; char *A; uint64_t* out; CK(hipMalloc(&A,10*GB)); CK(hipMemset(A,1,10*GB)); CK(hipMalloc(&out,4096));
+  for(int nt=0;nt<2;nt++) for(int g: {2048,8192}){
+    float m4 = nt? timeit([&]{k_read_w<uint32_t,1><<<g,256>>>((uint32_t*)A,out,2*GB/4);}) : timeit([&]{k_read_w<uint32_t,0><<<g,256>>>((uint32_t*)A,out,2*GB/4);});
+    float m8 = nt? timeit([&]{k_read_w<uint64_t,1><<<g,256>>>((uint64_t*)A,out,2*GB/8);}) : timeit([&]{k_read_w<uint64_t,0><<<g,256>>>((uint64_t*)A,out,2*GB/8);});
+    printf("stream read 2 GiB %s grid %d: 4 B/lane %.3f ms %.0f GB/s | 8 B/lane %.3f ms %.0f GB/s\n", nt?"nt":"plain", g, m4, 2.0*GB/m4/1e6, m8, 2.0*GB/m8/1e6);
+  }
+  // the bucket pass's shape: 2442 regions of 204800 rows, one 512-thread workgroup each
+  const size_t rows = 204800, nwg = 2442, n = rows*nwg;
+  float a = timeit([&]{k_region<0><<<nwg,512>>>((const uint64_t*)A,(const uint32_t*)(A+5*GB),nullptr,out,rows);});
+  float b = timeit([&]{k_region<1><<<nwg,512>>>(nullptr,nullptr,(const ulonglong2*)A,out,rows);});
+  float c = timeit([&]{k_region<2><<<nwg,512>>>((const uint64_t*)A,(const uint32_t*)(A+5*GB),nullptr,out,rows);});
+  printf("regions (2442 x 204800 rows, 512 threads, 4 rows per trip): 8+4 B columns %.3f ms %.0f GB/s | 16 B rows %.3f ms %.0f GB/s | 8+4 B, two rows per lane %.3f ms %.0f GB/s\n",
+         a, 12.0*n/a/1e6, b, 16.0*n/b/1e6, c, 12.0*n/c/1e6);
+  return 0;
+}
+
 int main(int argc, char** argv){
   if(argc>1 && argv[1][0]=='p') return probe_composite();
+  if(argc>1 && argv[1][0]=='w') return width_sweep();
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p,0));
   printf("device %s CUs=%d L2=%d MB clock=%d MHz lds/block=%zu\n", p.name,p.multiProcessorCount,p.l2CacheSize>>20,p.clockRate/1000,p.sharedMemPerBlock);
   const size_t GB=1ull<<30;
