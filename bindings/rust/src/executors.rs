@@ -1,6 +1,6 @@
 //! The executors `ExecutorBuilder` instantiates instead of the CPU ones, and the `visit_physical_*` bodies that do
 //! it (src/executor/mod.rs:87-200).  Same struct fields as the reference operators (filter.rs:7-10,
-//! hash_join.rs:16-23, hash_agg.rs:15-19, order.rs:8-11, project.rs:6-9, limit.rs:4-8, simple_agg.rs:9-12) plus
+//! hash_join.rs:16-23, cross_join.rs:8-13, hash_agg.rs:15-19, order.rs:8-11, project.rs:6-9, limit.rs:4-8, simple_agg.rs:9-12) plus
 //! the `HipCtx` handle; every `execute` yields exactly the batches the CPU operator yields.
 use std::sync::Arc;
 
@@ -14,7 +14,7 @@ use crate::convert::{dtype_of, import_batch, lower, AbiBatch, HipCtx, Lowered};
 use crate::executor::{BoxedExecutor, ExecutorBuilder, ExecutorError};
 use crate::ffi::*;
 use crate::optimizer::{
-    PhysicalFilter, PhysicalHashAgg, PhysicalHashJoin, PhysicalLimit, PhysicalOrder, PhysicalProject,
+    PhysicalCrossJoin, PhysicalFilter, PhysicalHashAgg, PhysicalHashJoin, PhysicalLimit, PhysicalOrder, PhysicalProject,
     PhysicalSimpleAgg, PlanRef, PlanTreeNode,
 };
 
@@ -212,6 +212,35 @@ impl HipProjectExecutor {
         }
     }
 }
+/// `CrossJoinExecutor { left_child, right_child, join_output_schema }` (cross_join.rs:8-13): what the binder makes of an
+/// uncorrelated scalar subquery (binder/table/subquery.rs:120-167).
+pub struct HipCrossJoinExecutor { pub ctx: Arc<HipCtx>, pub left_child: BoxedExecutor, pub right_child: BoxedExecutor, pub join_output_schema: Vec<ColumnCatalog> }
+impl HipCrossJoinExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let schema: SchemaRef = Arc::new(Schema::new(self.join_output_schema.iter().map(|c| c.to_arrow_field()).collect::<Vec<_>>())); // cross_join.rs:16-23
+        let mut j = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_cross_join_create(self.ctx.raw(), &mut j) })?;
+        let _g = Guard(j, sqlrs_cross_join_destroy);
+        #[for_await]
+        for batch in self.left_child { // cross_join.rs:30: the whole left side first
+            let inb = AbiBatch::new(&batch?)?;
+            self.ctx.check(unsafe { sqlrs_cross_join_build_push(j, &inb.raw) })?;
+        }
+        #[for_await]
+        for batch in self.right_child { // cross_join.rs:38-56
+            let batch = batch?;
+            let inb = AbiBatch::new(&batch)?;
+            let mut out = std::ptr::null_mut();
+            self.ctx.check(unsafe { sqlrs_cross_join_probe_push(j, &inb.raw, SQLRS_MEM_HOST, &mut out) })?;
+            if out.is_null() { continue; } // no left batch / no left row
+            // the library returns the batches of this right batch as ONE batch, left row major: one slice per left row
+            let whole = import_batch(schema.clone(), out)?;
+            let r = batch.num_rows();
+            for i in 0..(if r == 0 { 0 } else { whole.num_rows() / r }) { yield whole.slice(i * r, r); }
+        }
+    }
+}
 pub struct HipLimitExecutor { pub ctx: Arc<HipCtx>, pub limit: Option<usize>, pub offset: Option<usize>, pub child: BoxedExecutor }
 impl HipLimitExecutor {
     #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
@@ -371,6 +400,10 @@ impl ExecutorBuilder {
     }
     pub fn hip_visit_physical_project(&mut self, plan: &PhysicalProject) -> Option<BoxedExecutor> {
         Some(HipProjectExecutor { ctx: self.hip.clone(), exprs: plan.logical().exprs(), child: self.visit(plan.children().first().unwrap().clone()).unwrap() }.execute())
+    }
+    pub fn hip_visit_physical_cross_join(&mut self, plan: &PhysicalCrossJoin) -> Option<BoxedExecutor> { // executor/mod.rs:116-125
+        Some(HipCrossJoinExecutor { ctx: self.hip.clone(), left_child: self.visit(plan.left()).unwrap(), right_child: self.visit(plan.right()).unwrap(),
+                                    join_output_schema: plan.join_output_columns() }.execute())
     }
     pub fn hip_visit_physical_limit(&mut self, plan: &PhysicalLimit) -> Option<BoxedExecutor> {
         // both bounds are Constants in the reference (limit.rs:14-27); the binder has already folded them

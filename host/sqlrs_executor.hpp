@@ -135,6 +135,44 @@ struct RecordBatch {
     b.columns = std::move(columns);
     return b;
   }
+  // rows [offset, offset + length) as a batch of their own (RecordBatch::slice; copies: these arrays own their bytes)
+  RecordBatch slice(int64_t offset, int64_t length) const {
+    RecordBatch o;
+    o.schema = schema;
+    o.rows_ = length;
+    for (const ArrayRef &c : columns) {
+      auto a = std::make_shared<Array>();
+      a->type = c->type;
+      a->len = length;
+      bool any_null = false;
+      std::vector<uint8_t> valid((size_t)length, 1);
+      for (int64_t i = 0; i < length; i++) {
+        valid[(size_t)i] = c->is_valid(offset + i);
+        any_null |= !valid[(size_t)i];
+      }
+      if (any_null) {
+        a->validity.assign((size_t)(length + 7) / 8, 0);
+        for (int64_t i = 0; i < length; i++)
+          if (valid[(size_t)i]) a->validity[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7));
+      }
+      if (c->type == DataType::Utf8) {
+        a->offsets.push_back(0);
+        for (int64_t i = 0; i < length; i++) {
+          a->values.insert(a->values.end(), c->values.begin() + c->offsets[(size_t)(offset + i)], c->values.begin() + c->offsets[(size_t)(offset + i + 1)]);
+          a->offsets.push_back((int32_t)a->values.size());
+        }
+      } else if (c->type == DataType::Boolean) {
+        a->values.assign((size_t)(length + 7) / 8, 0);
+        for (int64_t i = 0; i < length; i++)
+          if ((c->values[(size_t)(offset + i) >> 3] >> ((offset + i) & 7)) & 1) a->values[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7));
+      } else {
+        const size_t w = c->type == DataType::Int32 ? 4 : 8;
+        a->values.assign(c->values.begin() + w * (size_t)offset, c->values.begin() + w * (size_t)(offset + length));
+      }
+      o.columns.push_back(a);
+    }
+    return o;
+  }
 };
 
 // arrow::util::pretty::pretty_format_batches (the format the reference's tests assert on)
@@ -512,6 +550,48 @@ struct OrderExecutor { // order.rs:8-11
 };
 
 // ---- the operators either side of the path, same ABI, same stream shape ----------------
+struct CrossJoinExecutor { // cross_join.rs:8-13 (the join an uncorrelated scalar subquery is rewritten to)
+  HipCtxRef ctx;
+  BoxedExecutor left_child, right_child;
+  BoxedExecutor execute() {
+    struct S : Executor {
+      HipCtxRef ctx; BoxedExecutor left, right; sqlrs_cross_join_t *j = nullptr; bool built = false;
+      std::optional<RecordBatch> whole; int64_t r = 0, at = 0; // the batches of the current right batch, handed out one per left row
+      ~S() override { if (j) sqlrs_cross_join_destroy(j); }
+      std::optional<RecordBatch> next() override {
+        if (!built) { // cross_join.rs:30: the whole left side first
+          while (auto b = left->next()) {
+            detail::AbiBatch in(*b);
+            ctx->check(sqlrs_cross_join_build_push(j, &in.b));
+          }
+          built = true;
+        }
+        for (;;) {
+          if (whole && r > 0 && at + r <= whole->num_rows()) { // one output batch per (right batch, left row), cross_join.rs:43-55
+            RecordBatch out = whole->slice(at, r);
+            at += r;
+            return out;
+          }
+          whole.reset();
+          auto b = right->next();
+          if (!b) return std::nullopt;
+          detail::AbiBatch in(*b);
+          sqlrs_batch_t *out = nullptr;
+          ctx->check(sqlrs_cross_join_probe_push(j, &in.b, SQLRS_MEM_HOST, &out));
+          if (!out) continue; // no left batch / no left row (cross_join.rs:32-34)
+          whole = detail::import_batch(out, nullptr);
+          r = b->num_rows();
+          at = 0;
+        }
+      }
+    };
+    auto s = std::make_unique<S>();
+    s->ctx = ctx; s->left = std::move(left_child); s->right = std::move(right_child);
+    ctx->check(sqlrs_cross_join_create(ctx->raw, &s->j));
+    return s;
+  }
+};
+
 struct ProjectExecutor { // project.rs:6-9
   HipCtxRef ctx;
   std::vector<BoundExpr> exprs;

@@ -9,6 +9,7 @@
 //   src/executor/mod.rs:309-345                test_executor_hash_agg_works (operator level)
 //   src/executor/mod.rs:264-285,368-395        filter / order, operator level
 //   src/executor/limit.rs:97-117               limit (six cases); project / simple_agg at operator level
+//   tests/slt/subquery.slt:50-57               scalar subquery = CrossJoinExecutor (cross_join.rs:8-58)
 // The expected tables are the reference's golden vectors (data), not its code.
 //
 // Build:  g++ -std=c++17 -Iinclude host/test_reference_executor.cpp -Lsqlrs_amd/csrc -lsqlrs_hip
@@ -177,6 +178,34 @@ int main() {
     ex.output_names = {"a", "Sum(b)"};
     expect_table("test_hash_agg_with_multiple_chunks", try_collect(ex.execute()),
                  {"+---+--------+", "| a | Sum(b) |", "+---+--------+", "| 1 | 4      |", "| 2 | 6      |", "+---+--------+"});
+  }
+
+  // ---- tests/slt/subquery.slt:50-57  select a, (select max(b) from t1) max_b from t1 — the cross join the binder makes of
+  //      the scalar subquery (binder/table/subquery.rs:120-167), executed by CrossJoinExecutor (cross_join.rs:8-58):
+  //      one output batch per (right batch, left row)
+  {
+    auto t1s = std::make_shared<Schema>(Schema{{"a", DataType::Int64, false}, {"b", DataType::Int64, false}, {"c", DataType::Int64, false}});
+    RecordBatch t1 = RecordBatch::try_new(t1s, {Int64Array({0, 1, 2, 2}), Int64Array({4, 5, 7, 8}), Int64Array({7, 8, 9, 1})});
+    SimpleAggExecutor sub;
+    sub.ctx = ctx;
+    sub.agg_funcs = {BoundAggFunc{AggFunc::Max, {build_bound_input_ref(1)}, DataType::Int64, false}};
+    sub.child = stream_iter({t1});
+    CrossJoinExecutor cj;
+    cj.ctx = ctx;
+    cj.left_child = stream_iter({t1.slice(0, 2), t1.slice(2, 2)}); // two left batches: concatenated first (cross_join.rs:36)
+    cj.right_child = sub.execute();
+    std::vector<RecordBatch> batches = try_collect(cj.execute());
+    if (batches.size() != 4) {
+      failures++;
+      std::printf("FAIL cross_join: %zu output batches, expected one per left row (4)\n", batches.size());
+    }
+    ProjectExecutor pr;
+    pr.ctx = ctx;
+    pr.exprs = {build_bound_input_ref(0), build_bound_input_ref(3)};
+    pr.child = stream_iter(batches);
+    pr.output_names = {"a", "max_b"};
+    expect_table("slt_scalar_subquery_alias (cross join)", try_collect(pr.execute()),
+                 {"+---+-------+", "| a | max_b |", "+---+-------+", "| 0 | 8     |", "| 1 | 8     |", "| 2 | 8     |", "| 2 | 8     |", "+---+-------+"});
   }
 
   // ---- executor/mod.rs:221-241 table, operator-level plans of :309-345, :264-285, :368-395

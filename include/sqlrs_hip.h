@@ -384,6 +384,20 @@ int sqlrs_limit_create(sqlrs_ctx_t *ctx, int has_limit, int64_t limit, int has_o
 int sqlrs_limit_push(sqlrs_limit_t *l, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out, int *done);
 void sqlrs_limit_destroy(sqlrs_limit_t *l);
 
+/* [ref: src/executor/join/cross_join.rs:8-58  CrossJoinExecutor{left_child, right_child, join_output_schema};
+ *  instantiated at src/executor/mod.rs:116-125]  What the binder rewrites an uncorrelated scalar subquery to
+ * (src/binder/table/subquery.rs:120-167: base table CROSS JOIN the one-row subquery).  The left child is collected and
+ * concatenated (cross_join.rs:30-36); for every right batch and every LEFT ROW the reference yields one batch = that
+ * row's values repeated right.num_rows times | the right columns (cross_join.rs:39-55).  probe_push returns those
+ * batches of ONE right batch as a single batch in the same row order (left row 0 x right rows, left row 1 x right
+ * rows, ...); the host mirrors slice it back into left_rows batches of right.num_rows rows.  *out = NULL when the left
+ * child yielded no batch (cross_join.rs:32-34) or no row. */
+typedef struct sqlrs_cross_join sqlrs_cross_join_t;
+int sqlrs_cross_join_create(sqlrs_ctx_t *ctx, sqlrs_cross_join_t **out);
+int sqlrs_cross_join_build_push(sqlrs_cross_join_t *j, const sqlrs_batch_t *left);
+int sqlrs_cross_join_probe_push(sqlrs_cross_join_t *j, const sqlrs_batch_t *right, int out_mem, sqlrs_batch_t **out);
+void sqlrs_cross_join_destroy(sqlrs_cross_join_t *j);
+
 /* [ref: src/executor/aggregate/simple_agg.rs:10-66  SimpleAggExecutor{agg_funcs, child}]  Aggregates
  * without GROUP BY: one accumulator per aggregate over all rows, exactly one output row (COUNT = 0 and
  * NULL for the others when no row arrived); finish without any pushed batch is SQLRS_ERR_INTERNAL (the

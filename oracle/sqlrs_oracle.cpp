@@ -1338,6 +1338,45 @@ int oracle_project_push(oracle_project *p, const sqlrs_batch_t *in, int, sqlrs_b
 }
 void oracle_project_destroy(oracle_project *p) { delete p; }
 
+// --------------------------------------------------------------- CrossJoin --
+// [ref: src/executor/join/cross_join.rs:8-58] left child collected + concatenated (:30-36); per right batch and per
+// left ROW one output batch = that row's scalars repeated right.num_rows times | the right columns (:39-55).  The ABI
+// returns the batches of one right batch as ONE batch in the same row order (the host mirror slices it back).
+struct oracle_cross_join {
+  oracle_ctx *ctx;
+  std::vector<Batch> left;
+};
+int oracle_cross_join_create(oracle_ctx *ctx, oracle_cross_join **out) {
+  return guard(ctx, [&] {
+    auto j = std::unique_ptr<oracle_cross_join>(new oracle_cross_join());
+    j->ctx = ctx;
+    *out = j.release();
+  });
+}
+int oracle_cross_join_build_push(oracle_cross_join *j, const sqlrs_batch_t *left) {
+  return guard(j->ctx, [&] { j->left.push_back(batch_from_abi(left)); });
+}
+int oracle_cross_join_probe_push(oracle_cross_join *j, const sqlrs_batch_t *right, int, sqlrs_batch_t **out) {
+  return guard(j->ctx, [&] {
+    *out = nullptr;
+    if (j->left.empty()) return; // cross_join.rs:32-34
+    const Batch left = concat_batches(j->left); // cross_join.rs:36
+    const Batch r = batch_from_abi(right);
+    if (left.rows == 0) return;
+    std::vector<Batch> per_row; // the reference's output stream for this right batch
+    for (int64_t row = 0; row < left.rows; row++) { // cross_join.rs:43
+      Batch o;
+      o.rows = r.rows;
+      const std::vector<int64_t> rep((size_t)r.rows, row); // build_scalar_value_array(scalar, right rows) (:47-50)
+      for (const Col &c : left.cols) o.cols.push_back(take(c, rep));
+      for (const Col &c : r.cols) o.cols.push_back(c); // :53
+      per_row.push_back(std::move(o));
+    }
+    *out = batch_to_abi(concat_batches(per_row));
+  });
+}
+void oracle_cross_join_destroy(oracle_cross_join *j) { delete j; }
+
 // ------------------------------------------------------------------- Limit --
 // [ref: src/executor/limit.rs:4-81]
 struct oracle_limit {

@@ -325,6 +325,10 @@ class Backend:
             "hash_agg_set_filter": (i, [vp, pe]),
             "hash_agg_filter_fused_batches": (C.c_int64, [vp]),
             "join_agg_destroy": (None, [vp]),
+            "cross_join_create": (i, [vp, pvp]),
+            "cross_join_build_push": (i, [vp, pb]),
+            "cross_join_probe_push": (i, [vp, pb, i, ppb]),
+            "cross_join_destroy": (None, [vp]),
             "project_create": (i, [vp, i, pe, pvp]),
             "project_push": (i, [vp, pb, i, ppb]),
             "project_destroy": (None, [vp]),

@@ -30,6 +30,14 @@ __global__ void iota_offset_u32_kernel(uint32_t *out, int64_t n, uint32_t start)
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) out[i] = start + (uint32_t)i;
 }
+// cross join: output row k = (left row k / R, right row k % R)
+__global__ void cross_index_kernel(uint32_t *left_idx, uint32_t *right_idx, int64_t n, uint32_t R) {
+  int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (k < n) {
+    left_idx[k] = (uint32_t)(k / R);
+    right_idx[k] = (uint32_t)(k % R);
+  }
+}
 __global__ void fill_zero_u64_kernel(uint64_t *out, int64_t n) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) out[i] = 0;
@@ -41,6 +49,14 @@ __global__ void fill_zero_u64_kernel(uint64_t *out, int64_t n) {
 struct sqlrs_project {
   Ctx *ctx = nullptr;
   std::vector<Expr> exprs;
+};
+
+// ======================================================================= CrossJoin ==
+struct sqlrs_cross_join {
+  Ctx *ctx = nullptr;
+  std::vector<DBatch> left; // the left child's batches (private copies: the caller's buffers are only lent)
+  DBatch left_all;          // ... concatenated once, at the first probe batch (cross_join.rs:36)
+  bool concatenated = false;
 };
 
 // =========================================================================== Limit ==
@@ -201,6 +217,62 @@ int sqlrs_project_push(sqlrs_project_t *p, const sqlrs_batch_t *in, int out_mem,
   });
 }
 void sqlrs_project_destroy(sqlrs_project_t *p) { delete p; }
+
+// ------------------------------------------------------------------------- CrossJoin --
+int sqlrs_cross_join_create(sqlrs_ctx_t *ctx, sqlrs_cross_join_t **out) {
+  return guard(ctx, [&] {
+    auto j = std::unique_ptr<sqlrs_cross_join>(new sqlrs_cross_join());
+    j->ctx = ctx;
+    *out = j.release();
+  });
+}
+int sqlrs_cross_join_build_push(sqlrs_cross_join_t *j, const sqlrs_batch_t *left) {
+  return guard(j->ctx, [&] {
+    Ctx *ctx = j->ctx;
+    SQ_HIP(hipSetDevice(ctx->device));
+    if (j->concatenated) fail(SQLRS_ERR_INTERNAL, "cross join: build_push after the first probe batch");
+    InBatch ib(ctx, left);
+    j->left.push_back(ib.materialize(true));
+  });
+}
+// [ref: cross_join.rs:38-56] all (left row, right batch) outputs of one right batch, left row major
+int sqlrs_cross_join_probe_push(sqlrs_cross_join_t *j, const sqlrs_batch_t *right, int out_mem, sqlrs_batch_t **out) {
+  return guard(j->ctx, [&] {
+    Ctx *ctx = j->ctx;
+    SQ_HIP(hipSetDevice(ctx->device));
+    *out = nullptr;
+    if (j->left.empty()) return; // cross_join.rs:32-34
+    if (!j->concatenated) {
+      j->left_all.rows = 0;
+      for (const DBatch &b : j->left) j->left_all.rows += b.rows;
+      for (size_t c = 0; c < j->left[0].cols.size(); c++) {
+        std::vector<const DCol *> parts;
+        for (const DBatch &b : j->left) {
+          if (b.cols.size() != j->left[0].cols.size()) fail(SQLRS_ERR_ARROW, "cross join: left batches of different schemas");
+          parts.push_back(&b.cols[c]);
+        }
+        j->left_all.cols.push_back(concat_columns(ctx, parts));
+      }
+      j->concatenated = true;
+    }
+    InBatch ib(ctx, right);
+    const int64_t L = j->left_all.rows, R = ib.rows();
+    if (L == 0) return;
+    if (L * R > 0x7fffffffll) fail(SQLRS_ERR_INTERNAL, "cross join: more than 2^31 output rows per probe batch");
+    const int64_t n = L * R;
+    DBatch o;
+    o.rows = n;
+    BufP li = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1)), ri = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
+    if (n) {
+      cross_index_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(li->as<uint32_t>(), ri->as<uint32_t>(), n, (uint32_t)R);
+      SQ_HIP(hipGetLastError());
+    }
+    for (const DCol &c : j->left_all.cols) o.cols.push_back(gather_column(ctx, c, li->p, false, nullptr, n));
+    for (int c = 0; c < ib.num_columns(); c++) o.cols.push_back(gather_column(ctx, ib.col(c), ri->p, false, nullptr, n));
+    *out = emit_batch(ctx, std::move(o), out_mem);
+  });
+}
+void sqlrs_cross_join_destroy(sqlrs_cross_join_t *j) { delete j; }
 
 // ----------------------------------------------------------------------------- Limit --
 int sqlrs_limit_create(sqlrs_ctx_t *ctx, int has_limit, int64_t limit, int has_offset, int64_t offset, sqlrs_limit_t **out) {

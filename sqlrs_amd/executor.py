@@ -303,6 +303,37 @@ class ProjectExecutor:
             be.fn("project_destroy")(h)
 
 
+class CrossJoinExecutor:
+    """``CrossJoinExecutor { left_child, right_child, join_output_schema }`` (cross_join.rs:8-13): what the binder turns an
+    uncorrelated scalar subquery into (binder/table/subquery.rs:120-167).  One output batch per (right batch, left row)
+    like the reference (cross_join.rs:39-55): the library returns the batches of one right batch as a single batch in
+    the same row order, sliced back here (host output only)."""
+
+    def __init__(self, backend: abi.Backend, left_child: Iterable, right_child: Iterable, join_output_schema: pa.Schema):
+        self.backend, self.left_child, self.right_child, self.schema = backend, left_child, right_child, join_output_schema
+
+    def execute(self):
+        be = self.backend
+        h = C.c_void_p()
+        be.check(be.fn("cross_join_create")(be.ctx, C.byref(h)))
+        try:
+            for batch in self.left_child:  # cross_join.rs:30
+                b = abi.as_batch(batch)
+                be.check(be.fn("cross_join_build_push")(h, b.ptr))
+            for batch in self.right_child:  # cross_join.rs:38-56
+                b = abi.as_batch(batch)
+                out = C.POINTER(abi.Batch)()
+                be.check(be.fn("cross_join_probe_push")(h, b.ptr, abi.MEM_HOST, C.byref(out)))
+                whole = _emit(be, out, abi.MEM_HOST, list(self.schema.names))
+                if whole is None:
+                    continue
+                r = b.abi.num_rows if hasattr(b, "abi") else b.num_rows
+                for i in range(whole.num_rows // r if r else 0):
+                    yield whole.slice(i * r, r)
+        finally:
+            be.fn("cross_join_destroy")(h)
+
+
 class LimitExecutor:
     """``LimitExecutor { limit, offset, child }`` (limit.rs:4-8); ``None`` = no LIMIT / OFFSET clause."""
 

@@ -13,7 +13,7 @@ import os
 import pyarrow as pa
 
 from sqlrs_amd import abi
-from sqlrs_amd.executor import (FilterExecutor, HashAggExecutor, HashJoinExecutor, LimitExecutor, OrderExecutor,
+from sqlrs_amd.executor import (CrossJoinExecutor, FilterExecutor, HashAggExecutor, HashJoinExecutor, LimitExecutor, OrderExecutor,
                                 ProjectExecutor, SimpleAggExecutor)
 from sqlrs_amd.expr import (AggFunc, BinaryOp, BoundExpr, Constant, InputRef, JoinCondition,
                             OrderBy, TypeCast)
@@ -96,6 +96,12 @@ class Runner:
                                  build_expr(node["filter"]) if node.get("filter") else None)
             ex = HashJoinExecutor(be, left, right, node["join_type"], cond, schema, len(ls))
             return list(ex.execute())
+        if op == "cross_join":
+            left, right = self.run(node["left"]), self.run(node["right"])
+            ls = left[0].schema if left else pa.schema([])
+            rs = right[0].schema if right else pa.schema([])
+            schema = pa.schema([pa.field(f"l.{f.name}", f.type) for f in ls] + [pa.field(f"r.{f.name}", f.type) for f in rs])
+            return list(CrossJoinExecutor(be, left, right, schema).execute())
         if op in ("hash_agg", "simple_agg"):
             aggs = [AggFunc(a["func"], build_expr(a["expr"]), _DT[a["return_type"]],
                             bool(a.get("distinct", False))) for a in node["aggs"]]
@@ -111,6 +117,11 @@ class Runner:
     def text(self, node) -> str:
         """the plan's output in the reference's sqllogictest text form"""
         return "".join(self.be.batch_to_string(b) for b in self.run(node))
+
+    def types(self, node):
+        """arrow type names of the output columns (the first output batch's schema)"""
+        bs = self.run(node)
+        return [str(f.type) for f in bs[0].schema] if bs else None
 
     def rows(self, node):
         out = []

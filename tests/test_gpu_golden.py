@@ -13,6 +13,8 @@ def test_hip_matches_reference_golden(hip, oracle, case):
     got = Runner(hip, FX).rows(case["plan"])
     assert got == case["expected"], f"{case['name']} ({case['source']})"
     assert got == Runner(oracle, FX).rows(case["plan"])
+    if "expected_types" in case:
+        assert Runner(hip, FX).types(case["plan"]) == case["expected_types"]
     # and in the reference's own text form (record_batch_to_string, util/mod.rs:53-80)
     assert Runner(hip, FX).text(case["plan"]) == render_rows(case["expected"])
 

@@ -11,6 +11,8 @@ FX = load()
 def test_oracle_matches_reference_golden(oracle, case):
     got = Runner(oracle, FX).rows(case["plan"])
     assert got == case["expected"], f"{case['name']} ({case['source']})"
+    if "expected_types" in case:
+        assert Runner(oracle, FX).types(case["plan"]) == case["expected_types"]
 
 
 @pytest.mark.parametrize("case", FX["cases"], ids=[c["name"] for c in FX["cases"]])

@@ -32,7 +32,7 @@ out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "--warmup 2 --no-cpu-baseline --no-operators` (C5, 1e9 x 1e7); counter values are KiB; per-launch means over launches "
                "with > 1e5 units; HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts "
                "half of a coalesced streaming read; calibration: filter_cmp_const reads 8.0e9 B)", "kernels": {}}
-short = {"rp_chunk_scatter_filter": "sq::rp_chunk_scatter_kernel", "rp_scatter": "sq::rp_scatter_kernel", "lds_agg": "sq::lds_agg", "filter_cmp_const": "sq::filter_cmp_const",
+short = {"rp_chunk_scatter_filter": "sq::rp_chunk_scatter", "rp_scatter": "sq::rp_scatter", "lds_agg": "sq::lds_agg", "filter_cmp_const": "sq::filter_cmp_const",
          "compact": "sq::compact_kernel", "rp_hist": "sq::rp_hist_kernel"}
 for k, pref in short.items():
     # both passes run the same command, so launch i of a kernel is the same launch in both; the
@@ -51,4 +51,43 @@ for k, pref in short.items():
                          "write_size_per_launch": round(wm), "hbm_bytes_per_launch": int((2 * fm + wm) * 1024)}
 json.dump(out, open(f"gpurun_out/{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
+PY
+
+# ---- the per-operator legs (C2 / C3 / C4 / Order of bench.py's `operators` object): kernel trace + the two counter passes of
+#      `python tools/operators_only.py` (the same bench_operators() code, no C5 tables) -> gpurun_out/<tag>_ops_kernel_stats.csv,
+#      gpurun_out/<tag>_ops_pmc_traffic.json (every kernel with > 1e5 KiB fetched or written per launch)
+OCMD="python tools/operators_only.py"
+rm -rf /tmp/prof_okt /tmp/prof_ofetch /tmp/prof_owrite
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_okt -- $OCMD > gpurun_out/${TAG}_ops_kt.log 2>&1 < /dev/null
+f=$(find /tmp/prof_okt -name '*kernel_stats.csv' | head -1)
+test -n "$f" && cp "$f" gpurun_out/${TAG}_ops_kernel_stats.csv && head -14 "$f" | cut -c1-160
+for c in FETCH_SIZE WRITE_SIZE; do
+  d=/tmp/prof_o$(echo $c | tr A-Z a-z | cut -d_ -f1)
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $d -- $OCMD > gpurun_out/${TAG}_ops_pmc_$c.log 2>&1 < /dev/null
+done
+python - "$TAG" <<'PY'
+import csv, glob, json, sys, collections
+tag = sys.argv[1]
+def per_kernel(d, counter):
+    fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    acc = collections.defaultdict(list)
+    if not fs: return acc
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != counter: continue
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return acc
+fe, wr = per_kernel("/tmp/prof_ofetch", "FETCH_SIZE"), per_kernel("/tmp/prof_owrite", "WRITE_SIZE")
+out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python tools/operators_only.py` (bench.py's "
+               "operator legs: C2 1e8 rows, C3 1e8 x 1e6, C4 2e8 rows / 1e6 groups, Order 1e8 rows); counter values are KiB; per kernel: "
+               "launches with > 1e5 KiB moved, their mean; HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction, "
+               "see the C5 file)", "kernels": {}}
+for n, fv in sorted(fe.items()):
+    wv = wr.get(n, [])
+    big = [(v, wv[i] if i < len(wv) else 0.0) for i, v in enumerate(fv) if v + (wv[i] if i < len(wv) else 0.0) > 1e5]
+    if not big: continue
+    fm, wm = sum(b[0] for b in big) / len(big), sum(b[1] for b in big) / len(big)
+    out["kernels"][n[:90]] = {"launches_sampled": len(big), "fetch_size_per_launch": round(fm), "write_size_per_launch": round(wm),
+                              "hbm_bytes_per_launch": int((2 * fm + wm) * 1024)}
+json.dump(out, open(f"gpurun_out/{tag}_ops_pmc_traffic.json", "w"), indent=1)
+print(len(out["kernels"]), "operator kernels with counters")
 PY
