@@ -73,6 +73,11 @@ def parse():
                         "hash-partitioned + exchanged and merged by the join on the owning rank; 'broadcast' = all-gather the "
                         "dim keys instead of partitioning them, join + aggregate the local fact slice, exchange + merge the "
                         "partial aggregates; 'auto' = combine")
+    p.add_argument("--exchange-impl", choices=["abi", "torch"], default="abi",
+                   help="N>1: who carries the single-chunk all-to-alls (the dim keys, the partial aggregates of `combine`, the "
+                        "partials of `broadcast`): 'abi' = sqlrs_exchange_all_to_all (exchange.hip: RCCL on the ctx stream, "
+                        "torch-free; the ncclUniqueId travels over the gloo side group), 'torch' = torch.distributed "
+                        "all_to_all_single.  The chunked, overlapped row exchange of `partition` always uses torch's")
     p.add_argument("--force-exchange", action="store_true",
                    help="N=1 only: run the multi-GPU code path (RCCL process group of ONE rank, fused filter + hash "
                         "partition, all-to-all, stream hand-over, local HashJoinAgg) instead of the single-GPU step; "
@@ -415,10 +420,35 @@ def main():
     def torch_stream():
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    # the exchange behind the C ABI (exchange.hip): one communicator per rank over an id made by rank 0
+    abi_x = {"h": None, "keep": [], "bytes0": 0}
+    if multi and not single_dev and args.exchange_impl == "abi":
+        ids = [be.exchange_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, group=count_group)
+        abi_x["h"] = be.exchange_create(ids[0], rank, world)
+
+    def exchange_abi(cols, dtypes):
+        """one chunk through sqlrs_hash_partition + sqlrs_exchange_all_to_all, all on the ctx stream (no torch stream
+        hand-over: the operators that consume the result run on the same stream)"""
+        for old in abi_x["keep"]:
+            old.release()  # (the previous call's batches: their consumers were queued on the ctx stream long ago)
+        abi_x["keep"] = []
+        b = device_batch(abi, cols, dtypes)
+        be.check(be.fn("ctx_wait_stream")(be.ctx, torch_stream()))  # the columns may come from torch's stream
+        parts, offs = be.hash_partition(b, InputRef(0), world, abi.MEM_DEVICE)
+        got, _ = be.exchange_all_to_all(abi_x["h"], parts, offs[:-1], [offs[p + 1] - offs[p] for p in range(world)])
+        abi_x["keep"] = [parts, got]
+        sent = int(be.fn("exchange_bytes_off_rank")(abi_x["h"]))
+        xstat["bytes_off_rank"] += sent - abi_x["bytes0"]
+        abi_x["bytes0"] = sent
+        return [_tensor_view(torch, got.column(ci).values, got.num_rows, T_DT[d], dev) for ci, d in enumerate(dtypes)]
+
     def exchange(chunks, dtypes, capacity):
         """`chunks`: iterable of lists of device columns (column 0 = the join key).  Every chunk is
         hash-partitioned on the key by the library; its all-to-all (one per column, asynchronous) runs
         while the next chunk is produced and partitioned.  Returns the received columns (one tensor each)."""
+        if abi_x["h"] is not None and isinstance(chunks, list) and len(chunks) == 1:
+            return exchange_abi(chunks[0], dtypes)
         ex = D.ChunkedExchange(dist, torch, world, [T_DT[d] for d in dtypes], dev, capacity, data_group=data_group,
                                count_group=count_group, wire_out=wire_out, wire_in=wire_in)
         keep = []
@@ -670,6 +700,8 @@ def main():
     if multi:  # SURVEY.md §8e scaling report: exchange vs local time, bytes over xGMI, rate per link
         x_ms, x_bytes = xstat["exchange_ms"] / 2, xstat["bytes_off_rank"] / 2
         exchange_info = {"strategy": strategy, "chunks": n_chunks if strategy == "partition" else 1,
+                         "impl": ("sqlrs_exchange_all_to_all (C ABI, RCCL on the ctx stream) for single-chunk exchanges"
+                                  if abi_x["h"] is not None else "torch.distributed"),
                          "fused_filter_partition": bool(fused_exchange and strategy == "partition"),
                          "step_ms_profiled": round(prof_step_ms, 3), "exchange_ms": round(x_ms, 3),
                          "local_ms": round(prof_step_ms - x_ms, 3), "bytes_off_rank_per_step": int(x_bytes),
@@ -808,6 +840,10 @@ def main():
         else:
             print(json.dumps(line), flush=True)
     if multi:
+        if abi_x["h"] is not None:
+            for old in abi_x["keep"]:
+                old.release()
+            be.fn("exchange_destroy")(abi_x["h"])
         dist.destroy_process_group()
 
 

@@ -461,6 +461,29 @@ int sqlrs_hash_partition_filter(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, const
                                 const sqlrs_expr_t *predicate, int num_parts, int out_mem,
                                 sqlrs_batch_t **out, int64_t *part_start, int64_t *part_rows);
 
+/* The exchange itself: an all-to-all of hash partitions over RCCL (xGMI) on the ctx stream, one process per GPU
+ * (no reference analogue: sqlrs is a single process; it slots under the executors the builder instantiates
+ * for a partitioned join / aggregate [ref: src/executor/mod.rs:103-114,163-174]: their children are wrapped in an
+ * exchange of the children's hash partitions).  RCCL is dlopen'ed at the first call; none of this needs torch.
+ *   sqlrs_exchange_unique_id   one rank makes the 128-byte id (ncclGetUniqueId) and hands it to the others out of band;
+ *   sqlrs_exchange_create      collective: every rank calls it with the same id, its rank and the world size;
+ *   sqlrs_exchange_all_to_all  collective: `in` is a DEVICE batch of fixed-width columns without NULLs whose rows
+ *       [part_start[p], part_start[p] + part_rows[p]) go to rank p (what sqlrs_hash_partition / _filter return; host
+ *       arrays of `world` entries); *out = the rows received from rank 0, 1, ... in this order (DEVICE);
+ *       recv_rows (optional, host, `world` entries) = rows received per rank.  `in` is read stream-ordered: keep it alive
+ *       until the ctx stream has passed (sqlrs_ctx_synchronize / release_to_stream), like every borrowed device batch;
+ *   sqlrs_exchange_plan        the receive side's bookkeeping as plain host arithmetic (no device): send_rows_all[q * world
+ *       + p] = rows rank q sends to rank p -> rows / start offsets this rank receives per source rank. */
+#define SQLRS_EXCHANGE_ID_BYTES 128
+typedef struct sqlrs_exchange sqlrs_exchange_t;
+int sqlrs_exchange_unique_id(sqlrs_ctx_t *ctx, void *id_out);
+int sqlrs_exchange_create(sqlrs_ctx_t *ctx, const void *unique_id, int rank, int world, sqlrs_exchange_t **out);
+int sqlrs_exchange_all_to_all(sqlrs_exchange_t *x, const sqlrs_batch_t *in, const int64_t *part_start, const int64_t *part_rows,
+                              sqlrs_batch_t **out, int64_t *recv_rows);
+int sqlrs_exchange_plan(int world, int rank, const int64_t *send_rows_all, int64_t *recv_rows, int64_t *recv_start, int64_t *total);
+int64_t sqlrs_exchange_bytes_off_rank(const sqlrs_exchange_t *x);
+void sqlrs_exchange_destroy(sqlrs_exchange_t *x);
+
 /* ------------------------------------------------- timing of device work -- */
 /* HIP-event timing on the ctx stream (bench.py measures the dominant kernel
  * with these: torch.cuda.Event only sees torch's own stream). */

@@ -309,6 +309,12 @@ class Backend:
             "ctx_pool_bytes": (C.c_int64, [vp]),
             "ctx_pool_trim": (None, [vp]),
             "batch_copy": (i, [vp, pb, i, ppb]),
+            "exchange_unique_id": (i, [vp, vp]),
+            "exchange_create": (i, [vp, vp, i, i, pvp]),
+            "exchange_all_to_all": (i, [vp, pb, C.POINTER(C.c_int64), C.POINTER(C.c_int64), ppb, C.POINTER(C.c_int64)]),
+            "exchange_plan": (i, [i, i, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+            "exchange_bytes_off_rank": (C.c_int64, [vp]),
+            "exchange_destroy": (None, [vp]),
             "hash_partition": (i, [vp, pb, pe, i, i, ppb, C.POINTER(C.c_int64)]),
             "hash_partition_filter": (i, [vp, pb, pe, pe, i, i, ppb, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
             "join_agg_create": (i, [vp, i, pe, pe, i, i, C.POINTER(C.c_int32), i, pe, i, C.POINTER(AggFunc), pvp]),
@@ -420,6 +426,41 @@ class Backend:
                                                     C.byref(pred.abi) if pred is not None else None, num_parts,
                                                     out_mem, C.byref(out), starts, rows))
         return self.wrap(out), list(starts), list(rows)
+
+    # ---- exchange (RCCL all-to-all of hash partitions behind the C ABI; one process per GPU)
+    EXCHANGE_ID_BYTES = 128
+
+    def exchange_unique_id(self) -> bytes:
+        """the 128-byte id ONE rank makes (ncclGetUniqueId) and hands to the others out of band"""
+        buf = C.create_string_buffer(self.EXCHANGE_ID_BYTES)
+        self.check(self.fn("exchange_unique_id")(self.ctx, buf))
+        return buf.raw
+
+    def exchange_create(self, unique_id: bytes, rank: int, world: int):
+        """collective over the ranks that share `unique_id` -> opaque handle (exchange_destroy it)"""
+        assert len(unique_id) == self.EXCHANGE_ID_BYTES
+        h = C.c_void_p()
+        self.check(self.fn("exchange_create")(self.ctx, C.create_string_buffer(unique_id, self.EXCHANGE_ID_BYTES), rank, world, C.byref(h)))
+        return h
+
+    def exchange_all_to_all(self, h, parts, part_start, part_rows):
+        """rows [part_start[p], + part_rows[p]) of the DEVICE batch `parts` go to rank p -> (LibBatch of the rows received
+        from rank 0, 1, ..., rows received per rank)"""
+        b = as_batch(parts)
+        w = len(part_rows)
+        ps, pr, rr = (C.c_int64 * w)(*part_start), (C.c_int64 * w)(*part_rows), (C.c_int64 * w)()
+        out = C.POINTER(Batch)()
+        self.check(self.fn("exchange_all_to_all")(h, b.ptr, ps, pr, C.byref(out), rr))
+        return self.wrap(out), list(rr)
+
+    def exchange_plan(self, world: int, rank: int, send_rows_all):
+        """host arithmetic only: send_rows_all[q][p] = rows rank q sends to rank p -> (recv_rows, recv_start, total)"""
+        flat = (C.c_int64 * (world * world))(*[int(v) for row in send_rows_all for v in row])
+        rr, rs, tot = (C.c_int64 * world)(), (C.c_int64 * world)(), C.c_int64()
+        st = self.fn("exchange_plan")(world, rank, flat, rr, rs, C.byref(tot))
+        if st != OK:
+            raise ExecutorError(st, "exchange_plan: inconsistent arguments")
+        return list(rr), list(rs), tot.value
 
     def batch_to_string(self, batch) -> str:
         """``record_batch_to_string`` (util/mod.rs:53-80) of a pyarrow / host / device batch"""

@@ -1093,6 +1093,19 @@ __global__ __launch_bounds__(256) void key_range_kernel(const uint64_t *__restri
   }
 }
 
+const uint64_t *part_row_ids(Ctx *ctx, PartAggOutput &po) {
+  if (!po.row_ids) {
+    const int64_t g1 = std::max<int64_t>(po.groups, 1);
+    po.row_ids = ctx->alloc(8 * (size_t)g1);
+    if (po.groups) {
+      first_to_rowid_kernel<<<dim3((unsigned)ceil_div(g1, 256)), dim3(256), 0, ctx->stream>>>(
+          po.gfirst->as<uint32_t>(), po.groups, po.row_offset, po.row_ids->as<uint64_t>());
+      SQ_HIP(hipGetLastError());
+    }
+  }
+  return po.row_ids->as<uint64_t>();
+}
+
 bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggInput &in,
                               uint64_t row_offset, PartAggOutput *out) {
   int64_t n = in.n; // rows of the batch; after the partition: rows that passed in.filter
@@ -1265,7 +1278,8 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     out->gfirst = ctx->alloc(4);
     out->gacc = ctx->alloc(8 * (size_t)std::max(spec.n_acc, 1));
     out->ov_rows = ctx->alloc(4);
-    out->row_ids = ctx->alloc(8);
+    out->row_ids = nullptr;
+    out->row_offset = row_offset;
     return true;
   }
   out->buckets = (int)P;
@@ -1565,12 +1579,11 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   out->may_dup = h[3] != 0; // a split bucket's global table was full: some keys were emitted twice
   if (join_mode && h[2]) return false; // a bucket table could not hold its build keys
   if (out->groups > gcap) return false; // estimate far too low: caller falls back to the resolve path
-  // first-row ids as global row numbers + NULL-key bitmap for the merge
+  // NULL-key bitmap for the merge (the first rows as global row numbers are made when a merge asks: part_row_ids)
   int64_t g1 = std::max<int64_t>(out->groups, 1);
-  out->row_ids = ctx->alloc(8 * (size_t)g1);
+  out->row_offset = row_offset;
+  out->row_ids = nullptr;
   if (out->groups) {
-    first_to_rowid_kernel<<<dim3((unsigned)ceil_div(g1, 256)), dim3(256), 0, ctx->stream>>>(
-        out->gfirst->as<uint32_t>(), out->groups, row_offset, out->row_ids->as<uint64_t>());
     if (out->gvalid) {
       out->gvalid_bits = ctx->alloc(bitmap_bytes(g1));
       int64_t g64 = (int64_t)round_up((size_t)g1, 64);

@@ -61,7 +61,9 @@ struct PartAggInput {
 // (COUNT: count, SUM: partial sum, MIN/MAX: order-preserving u64 image).
 struct PartAggOutput {
   int64_t groups = 0, gcap = 0;
-  BufP gkey, gfirst, gvalid, gvalid_bits, gacc, row_ids;
+  BufP gkey, gfirst, gvalid, gvalid_bits, gacc;
+  BufP row_ids;            // gfirst as global row numbers (u64): made on demand, part_row_ids()
+  uint64_t row_offset = 0; // global row number of the batch's row 0
   int64_t n_overflow = 0; // rows that did not fit their bucket table
   BufP ov_rows;           // their local row ids (u32)
   bool may_dup = false;   // a skewed bucket was split: the same key can appear more than once
@@ -72,6 +74,9 @@ struct PartAggOutput {
   bool retry_exact = false;
 };
 
+// first rows of the groups as global row numbers (row_offset + gfirst), made on first use: only a merge into an existing
+// aggregation state needs them; a single batch's groups are ordered by the local u32 first rows as they are
+const uint64_t *part_row_ids(Ctx *ctx, PartAggOutput &po);
 // also returns min / max of the valid keys' signed-order image (key ^ 1 << 63) when asked
 double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n,
                          uint64_t *omin = nullptr, uint64_t *omax = nullptr, bool *sampled = nullptr);

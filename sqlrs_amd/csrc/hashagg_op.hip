@@ -309,7 +309,7 @@ static void merge_groups(sqlrs_hash_agg *a, PendingGroups &pg) {
     gk.own_validity = po.gvalid_bits;
   }
   int64_t nnew = 0;
-  BufP rgid = resolve_groups(a, gk, po.row_ids->as<uint64_t>(), nullptr, pg.keyvals, &nnew);
+  BufP rgid = resolve_groups(a, gk, part_row_ids(ctx, po), nullptr, pg.keyvals, &nnew);
   const uint32_t *rg = rgid->as<uint32_t>();
   int64_t G = a->st.ngroups, g = po.groups;
   auto cell = [&](int acc) { return po.gacc->as<uint64_t>() + (size_t)acc * (size_t)po.gcap; };
@@ -374,11 +374,11 @@ static DBatch emit_pending(sqlrs_hash_agg *a) {
   }
   if (G > 1 && !a->any_order) { // bucket order -> first-seen order (hash_agg.rs:98,132)
     ProfScope ps(ctx, "agg_order_groups");
-    BufP keys = po.row_ids, perm = ctx->alloc(4 * (size_t)G); // sorted in place: this is the batch's last use
-    iota_u32(ctx, perm->as<uint32_t>(), G);
+    // (the groups' first rows as they are — local u32 row numbers of the one batch, all below rows_seen < 2^bits)
+    BufP perm = ctx->alloc(4 * (size_t)G);
     int bits = 1;
-    while (bits < 64 && (1ull << bits) <= (uint64_t)std::max<int64_t>(a->rows_seen, 1)) bits++;
-    radix_sort_pairs(ctx, keys->as<uint64_t>(), perm->as<uint32_t>(), G, 0, bits, true); // (first rows < rows_seen < 2^bits)
+    while (bits < 32 && (1ull << bits) <= (uint64_t)std::max<int64_t>(a->rows_seen, 1)) bits++;
+    radix_sort_index_u32(ctx, po.gfirst->as<uint32_t>(), G, bits, perm->as<uint32_t>());
     if (!gather_columns_packed(ctx, o.cols, G, perm->as<uint32_t>(), G))
       for (DCol &c : o.cols) c = gather_column(ctx, c, perm->p, false, nullptr, G);
   }

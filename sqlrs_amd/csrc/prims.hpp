@@ -86,6 +86,8 @@ NKeys normalize_keys_strong(Ctx *ctx, const std::vector<DCol> &cols, int64_t row
 // differ" (a pass over the keys + a host round trip) is then not asked: every byte of [begin_bit, end_bit) is sorted.
 void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int begin_bit,
                       int end_bit, bool keys_below_end_bit = false);
+// perm[0 .. n) = the indices 0 .. n-1 in the stable order of their u32 keys (all below 2^bits)
+void radix_sort_index_u32(Ctx *ctx, const uint32_t *keys, int64_t n, int bits, uint32_t *perm);
 void iota_u32(Ctx *ctx, uint32_t *out, int64_t n);
 // order_fast.hip: ORDER BY one fixed-width key without NULLs, rows (key, one carried 8-byte column, row id)
 // travel through <= 2 HBM passes + an in-LDS finish; false = shape / data do not fit (general path)

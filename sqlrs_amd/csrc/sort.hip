@@ -18,6 +18,8 @@ constexpr int RS_WAVES = RS_WG / 64;
 constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE = RS_WG * RS_ITEMS; // 4096 keys per block: 56 KiB of LDS, two blocks per CU
 
+// KEY32: `keys` is an array of u32 keys (the first pass of radix_sort_index_u32)
+template <bool KEY32 = false>
 __global__ __launch_bounds__(RS_WG) void rs_hist_kernel(const uint64_t *__restrict__ keys, int64_t n,
                                                         int shift, int64_t nblocks,
                                                         uint32_t *__restrict__ hist) {
@@ -26,7 +28,9 @@ __global__ __launch_bounds__(RS_WG) void rs_hist_kernel(const uint64_t *__restri
   const int64_t base = (int64_t)blockIdx.x * RS_TILE + threadIdx.x;
   uint64_t k[RS_ITEMS];
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) k[r] = __builtin_nontemporal_load(keys + min(base + r * RS_WG, n - 1));
+  for (int r = 0; r < RS_ITEMS; r++)
+    k[r] = KEY32 ? (uint64_t)__builtin_nontemporal_load((const uint32_t *)keys + min(base + r * RS_WG, n - 1))
+                 : __builtin_nontemporal_load(keys + min(base + r * RS_WG, n - 1));
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++)
@@ -47,8 +51,10 @@ __global__ __launch_bounds__(RS_WG) void rs_hist_kernel(const uint64_t *__restri
 // (key_part << 32) | row id, used between the first and the last pass when the varying key bits
 // fit 32 bits: 8 instead of 12 bytes per row and pass.  IN / OUT select what a pass reads / writes;
 // a PACKED -> PAIR pass rebuilds the key as (word >> 32) << key_lo | key_const.
+// KEY32 (with IN = RS_PAIR): `keys` is an array of u32 keys and a row's value is its index (no `vals` array): the first
+// pass of radix_sort_index_u32.  keys_out == nullptr (OUT = RS_PAIR): only the values are written (its last pass).
 enum { RS_PAIR = 0, RS_PACKED = 1 };
-template <int IN, int OUT>
+template <int IN, int OUT, bool KEY32 = false>
 __global__ __launch_bounds__(RS_WG) void rs_scatter_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t n, int shift,
     int64_t nblocks, const uint32_t *__restrict__ offsets, uint64_t *__restrict__ keys_out,
@@ -67,8 +73,8 @@ __global__ __launch_bounds__(RS_WG) void rs_scatter_kernel(
 #pragma unroll
   for (int j = 0; j < RS_ITEMS; j++) {
     const int64_t i = min(wrow + j * 64, n - 1);
-    k[j] = __builtin_nontemporal_load(keys + i);
-    v[j] = IN == RS_PAIR ? __builtin_nontemporal_load(vals + i) : 0u;
+    k[j] = KEY32 ? (uint64_t)__builtin_nontemporal_load((const uint32_t *)keys + i) : __builtin_nontemporal_load(keys + i);
+    v[j] = KEY32 ? (uint32_t)i : (IN == RS_PAIR ? __builtin_nontemporal_load(vals + i) : 0u);
   }
   uint32_t goff = threadIdx.x < 256 ? offsets[(int64_t)threadIdx.x * nblocks + blockIdx.x] : 0;
 #pragma unroll
@@ -140,10 +146,10 @@ __global__ __launch_bounds__(RS_WG) void rs_scatter_kernel(
       if (OUT == RS_PACKED) {
         keys_out[g] = kk;
       } else if (IN == RS_PACKED) {
-        keys_out[g] = ((kk >> 32) << key_lo) | key_const;
+        if (keys_out) keys_out[g] = ((kk >> 32) << key_lo) | key_const;
         vals_out[g] = (uint32_t)kk;
       } else {
-        keys_out[g] = kk;
+        if (keys_out) keys_out[g] = kk;
         vals_out[g] = sval[p];
       }
     }
@@ -226,8 +232,8 @@ void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int b
     const int shift = shifts[pi];
     const bool in_packed = packed && pi > 0, out_packed = packed && pi + 1 < shifts.size();
     const int eff = in_packed ? shift - key_lo + 32 : shift; // where the digit sits in what this pass reads
-    rs_hist_kernel<<<dim3((unsigned)nblocks), dim3(RS_WG), 0, ctx->stream>>>(ka, n, eff, nblocks,
-                                                                            hist->as<uint32_t>());
+    rs_hist_kernel<false><<<dim3((unsigned)nblocks), dim3(RS_WG), 0, ctx->stream>>>(ka, n, eff, nblocks,
+                                                                                   hist->as<uint32_t>());
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(),
                        total->as<uint64_t>());
@@ -247,6 +253,42 @@ void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int b
   if (ka != keys) {
     SQ_HIP(hipMemcpyAsync(keys, ka, 8 * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
     SQ_HIP(hipMemcpyAsync(vals, va, 4 * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+}
+
+// perm = the row indices 0 .. n-1 ordered by their u32 key (stable), keys below 2^bits: the ordering of an aggregation's
+// groups by first row (hash_agg.rs:98) without widening the keys to u64, without an iota array and without sorted keys
+// coming back — the first pass reads the u32 keys and packs (key << 32 | index) words, the last writes the indices only.
+void radix_sort_index_u32(Ctx *ctx, const uint32_t *keys, int64_t n, int bits, uint32_t *perm) {
+  if (n <= 0) return;
+  if (n > 0xffffffffll) fail(SQLRS_ERR_INTERNAL, "radix sort: more than 2^32 rows");
+  ProfScope ps(ctx, "radix_sort");
+  const int passes = std::max(1, (std::min(bits, 32) + 7) / 8);
+  const int64_t nblocks = ceil_div(n, RS_TILE);
+  BufP w0 = ctx->alloc(8 * (size_t)n), w1 = passes > 2 ? ctx->alloc(8 * (size_t)n) : nullptr;
+  BufP hist = ctx->alloc(4 * (size_t)(256 * nblocks)), offs = ctx->alloc(4 * (size_t)(256 * nblocks));
+  BufP total = ctx->alloc(8);
+  dim3 g((unsigned)nblocks), b(RS_WG);
+  const uint64_t *in = (const uint64_t *)keys;
+  uint64_t *out = w0->as<uint64_t>();
+  for (int pi = 0; pi < passes; pi++) {
+    const bool first = pi == 0, last = pi + 1 == passes;
+    const int shift = first ? 0 : 32 + 8 * pi; // the u32 keys themselves, then the key half of the packed words
+    if (first) rs_hist_kernel<true><<<g, b, 0, ctx->stream>>>(in, n, shift, nblocks, hist->as<uint32_t>());
+    else rs_hist_kernel<false><<<g, b, 0, ctx->stream>>>(in, n, shift, nblocks, hist->as<uint32_t>());
+    SQ_HIP(hipGetLastError());
+    exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(), total->as<uint64_t>());
+    if (first && last)
+      rs_scatter_kernel<RS_PAIR, RS_PAIR, true><<<g, b, 0, ctx->stream>>>(in, nullptr, n, shift, nblocks, offs->as<uint32_t>(), nullptr, perm, 0, 0);
+    else if (first)
+      rs_scatter_kernel<RS_PAIR, RS_PACKED, true><<<g, b, 0, ctx->stream>>>(in, nullptr, n, shift, nblocks, offs->as<uint32_t>(), out, nullptr, 0, 0);
+    else if (last)
+      rs_scatter_kernel<RS_PACKED, RS_PAIR><<<g, b, 0, ctx->stream>>>(in, nullptr, n, shift, nblocks, offs->as<uint32_t>(), nullptr, perm, 0, 0);
+    else
+      rs_scatter_kernel<RS_PACKED, RS_PACKED><<<g, b, 0, ctx->stream>>>(in, nullptr, n, shift, nblocks, offs->as<uint32_t>(), out, nullptr, 0, 0);
+    SQ_HIP(hipGetLastError());
+    in = out;
+    out = (out == w0->as<uint64_t>() && w1) ? w1->as<uint64_t>() : w0->as<uint64_t>();
   }
 }
 

@@ -139,6 +139,43 @@ def worker(rank, world, port, result_path, strategy="partition"):
         sent_off_rank.append(ex.bytes_off_rank)
         return outs
 
+    def exchange_abi_plan(cols):
+        """the exchange as the C ABI does it (sqlrs_exchange_all_to_all, exchange.hip) with gloo standing in for RCCL:
+        all-gather of the send counts -> sqlrs_exchange_plan (the library's own host arithmetic, called through
+        ctypes: no device needed) -> per column one send / recv per peer into the planned slices of ONE output"""
+        import ctypes as C
+        from sqlrs_amd import build as B
+        lib = C.CDLL(B.OUT)
+        parts, offs = D.partition_numpy(cols, world)
+        send_rows = torch.tensor([offs[p + 1] - offs[p] for p in range(world)], dtype=torch.int64)
+        allc = [torch.empty(world, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allc, send_rows)  # (ncclAllGather of the counts in the library)
+        flat = (C.c_int64 * (world * world))(*[int(v) for row in allc for v in row.tolist()])
+        rr, rs, tot = (C.c_int64 * world)(), (C.c_int64 * world)(), C.c_int64()
+        lib.sqlrs_exchange_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                            C.POINTER(C.c_int64)]
+        assert lib.sqlrs_exchange_plan(world, rank, flat, rr, rs, C.byref(tot)) == 0
+        assert list(rr) == [int(allc[q][rank]) for q in range(world)] and tot.value == sum(rr)
+        assert lib.sqlrs_exchange_plan(world, world, flat, rr, rs, C.byref(tot)) != 0  # rank outside the world
+        outs = []
+        for col in parts:
+            col = np.ascontiguousarray(col)
+            out = np.empty(tot.value, dtype=col.dtype)
+            sends = [torch.from_numpy(col[offs[p]:offs[p + 1]].copy()) for p in range(world)]
+            recvs = [torch.from_numpy(out[rs[q]:rs[q] + rr[q]]) for q in range(world)]
+            reqs = []
+            for peer in range(world):  # (gloo has no all-to-all-v: isend / irecv pairs, like the grouped ncclSend / ncclRecv)
+                if peer == rank:
+                    recvs[peer].copy_(sends[peer])
+                    continue
+                reqs.append(dist.isend(sends[peer], peer))
+                reqs.append(dist.irecv(recvs[peer], peer))
+            for r in reqs:
+                r.wait()
+            outs.append(out)
+        sent_off_rank.append(sum(int(send_rows[p]) for p in range(world) if p != rank) * sum(c.itemsize for c in parts))
+        return outs
+
     count_group = dist.new_group(backend="gloo")
     sent_off_rank = []
 
@@ -155,11 +192,12 @@ def worker(rank, world, port, result_path, strategy="partition"):
         keys, cnt, sm = merge_partials(oracle, rk, rc, rs)
         fk = fact_key[f_lo:f_hi]
         dk = dim_key[d_lo:d_hi]
-    elif strategy == "combine":
+    elif strategy in ("combine", "combine_abi"):
         # partitioned join with the partial aggregation below the exchange (bench.py: step_combine)
-        (dk,) = exchange([dim_key[d_lo:d_hi]])
+        xchg = exchange_abi_plan if strategy == "combine_abi" else exchange
+        (dk,) = xchg([dim_key[d_lo:d_hi]])
         pk, pc, ps = local_partials(oracle, fact_key[f_lo:f_hi], fact_val[f_lo:f_hi])
-        fk, rc, rs = exchange([pk, pc, ps], chunks=2)
+        fk, rc, rs = xchg([pk, pc, ps]) if strategy == "combine_abi" else exchange([pk, pc, ps], chunks=2)
         assert (D.partition_of(dk, world) == rank).all() and (D.partition_of(fk, world) == rank).all()
         keys, cnt, sm = merge_join(oracle, dk, fk, rc, rs)
     else:
@@ -182,7 +220,7 @@ def worker(rank, world, port, result_path, strategy="partition"):
         all_keys = np.concatenate([g[0] for g in gathered])
         all_cnt = np.concatenate([g[1] for g in gathered])
         all_sum = np.concatenate([g[2] for g in gathered])
-        if strategy != "combine":  # (combine exchanges partial groups, not rows)
+        if not strategy.startswith("combine"):  # (combine exchanges partial groups, not rows)
             assert sum(g[3] for g in gathered) == (N_FACT if strategy != "partition_fused" else int((fact_val > 0.5).sum()))
         assert sum(g[4] for g in gathered) == N_DIM
         assert len(np.unique(all_keys)) == len(all_keys), "per-rank results must be disjoint"
@@ -203,7 +241,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("strategy", ["partition", "partition_fused", "broadcast", "combine"])
+@pytest.mark.parametrize("strategy", ["partition", "partition_fused", "broadcast", "combine", "combine_abi"])
 def test_partitioned_join_groupby_world2_gloo(tmp_path, strategy):
     result = tmp_path / "result.txt"
     mp.spawn(worker, args=(2, free_port(), str(result), strategy), nprocs=2, join=True)

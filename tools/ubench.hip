@@ -232,7 +232,55 @@ int width_sweep(){
   return 0;
 }
 
+// the composite probe with the key stream taken off the VGPR return path: keys land in LDS by LDS-DMA (global_load_lds_dwordx4:
+// 128 keys per wave-instruction, lane l gets keys 2l, 2l+1), each lane then looks its two keys up and writes the pairs with one
+// 16-byte and one 8-byte store.  NG such loads in flight per wave.  (mode 'g')
+template<int NG>
+__global__ __launch_bounds__(256) void k_probe_glds(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ heads, uint64_t mask,
+                                                    uint64_t* __restrict__ left, uint32_t* __restrict__ right, size_t n){
+  __shared__ __attribute__((aligned(16))) uint64_t sk[4][NG][128];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const size_t per = (size_t)NG * 128, stride = (size_t)gridDim.x * 4 * per;
+  for(size_t c = ((size_t)blockIdx.x * 4 + w) * per; c + per <= n; c += stride){
+    #pragma unroll
+    for(int g=0; g<NG; g++)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(keys + c + (size_t)g*128 + 2*l),
+                                       (void __attribute__((address_space(3)))*)&sk[w][g][0], 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    asm volatile("" ::: "memory");
+    uint64_t k[2*NG]; uint32_t h[2*NG];
+    #pragma unroll
+    for(int g=0; g<NG; g++){ k[2*g] = sk[w][g][2*l]; k[2*g+1] = sk[w][g][2*l+1]; }
+    #pragma unroll
+    for(int j=0;j<2*NG;j++) h[j] = heads[k[j]&mask];
+    #pragma unroll
+    for(int g=0; g<NG; g++){
+      const size_t r = c + (size_t)g*128 + 2*l;
+      u64x2_t lv; lv.x = h[2*g]; lv.y = h[2*g+1];
+      __builtin_nontemporal_store(lv, (u64x2_t*)(left + r));
+      __builtin_nontemporal_store(((uint64_t)(uint32_t)(r+1) << 32) | (uint32_t)r, (uint64_t*)(right + r));
+    }
+  }
+}
+int probe_glds(){
+  const size_t n=100000000;
+  uint64_t *keys,*left; uint32_t *right,*heads;
+  CK(hipMalloc(&keys,8*n)); CK(hipMalloc(&left,8*n)); CK(hipMalloc(&right,4*n));
+  for(size_t slots: {(size_t)1<<17,(size_t)1<<20}){
+    CK(hipMalloc(&heads,4*slots)); CK(hipMemset(heads,1,4*slots));
+    k_fill_keys<<<4096,256>>>(keys,slots-1,n); CK(hipDeviceSynchronize());
+    #define RUNG(NG,G) { float ms=timeit([&]{k_probe_glds<NG><<<G,256>>>(keys,heads,slots-1,left,right,n);}); \
+      printf("  table %5.1f MiB  LDS-DMA keys, %d x 128 keys in flight per wave, grid %5d: %.3f ms  %.3f of 8 TB/s on 20 B/key\n", 4.0*slots/1048576, NG, G, ms, 20.0*n/ms/1e6/8000); }
+    RUNG(2,4096) RUNG(4,2048) RUNG(4,4096) RUNG(8,1024) RUNG(8,2048) RUNG(8,4096)
+    float ms=timeit([&]{k_probe_composite<16,0><<<4096,256>>>(keys,heads,slots-1,left,right,n);});
+    printf("  table %5.1f MiB  register composite ilp16: %.3f ms  %.3f\n", 4.0*slots/1048576, ms, 20.0*n/ms/1e6/8000);
+    CK(hipFree(heads));
+  }
+  return 0;
+}
+
 int main(int argc, char** argv){
+  if(argc>1 && argv[1][0]=='g') return probe_glds();
   if(argc>1 && argv[1][0]=='p') return probe_composite();
   if(argc>1 && argv[1][0]=='w') return width_sweep();
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p,0));
