@@ -430,14 +430,11 @@ def main():
     def exchange_abi(cols, dtypes):
         """one chunk through sqlrs_hash_partition + sqlrs_exchange_all_to_all, all on the ctx stream (no torch stream
         hand-over: the operators that consume the result run on the same stream)"""
-        for old in abi_x["keep"]:
-            old.release()  # (the previous call's batches: their consumers were queued on the ctx stream long ago)
-        abi_x["keep"] = []
         b = device_batch(abi, cols, dtypes)
         be.check(be.fn("ctx_wait_stream")(be.ctx, torch_stream()))  # the columns may come from torch's stream
         parts, offs = be.hash_partition(b, InputRef(0), world, abi.MEM_DEVICE)
         got, _ = be.exchange_all_to_all(abi_x["h"], parts, offs[:-1], [offs[p + 1] - offs[p] for p in range(world)])
-        abi_x["keep"] = [parts, got]
+        abi_x["keep"] += [parts, got]  # (alive until the next step starts: the step's operators read the views below)
         sent = int(be.fn("exchange_bytes_off_rank")(abi_x["h"]))
         xstat["bytes_off_rank"] += sent - abi_x["bytes0"]
         abi_x["bytes0"] = sent
@@ -641,6 +638,9 @@ def main():
 
     def one_step():
         if multi:
+            for old in abi_x["keep"]:
+                old.release()  # what the previous step received through the ABI exchange
+            abi_x["keep"] = []
             xstat["steps"] += 1
             return step_broadcast() if strategy == "broadcast" else step_combine() if strategy == "combine" else step_partition()
         out = pipe.step(device_batch(abi, [dim_key], [abi.INT64]),

@@ -241,6 +241,50 @@ impl HipCrossJoinExecutor {
         }
     }
 }
+/// The exchange step of a partitioned plan: hash-partitions every batch of `child` on `key` and trades the partitions
+/// with the other ranks (one process per GPU; `sqlrs_exchange_*`: RCCL all-to-all over xGMI on the ctx stream).  No
+/// reference analogue — sqlrs is a single process — but it slots exactly where the builder instantiates the children
+/// of a join / aggregate (executor/mod.rs:103-114,163-174): `left_child: exchange(visit(plan.left()), left_key)`,
+/// `right_child: exchange(visit(plan.right()), right_key)`; rows with equal keys meet on one rank, so the operators
+/// above run unchanged and their per-rank results are disjoint.  `ExchangeComm` is created once per process from an id
+/// rank 0 made (`sqlrs_exchange_unique_id`) and handed round by whatever launched the ranks.
+pub struct ExchangeComm { pub ctx: Arc<HipCtx>, pub raw: *mut sqlrs_exchange_t, pub world: usize }
+unsafe impl Send for ExchangeComm {}
+unsafe impl Sync for ExchangeComm {}
+impl ExchangeComm {
+    pub fn new(ctx: Arc<HipCtx>, unique_id: &[u8; 128], rank: usize, world: usize) -> Result<Self, ExecutorError> {
+        let mut raw = std::ptr::null_mut();
+        ctx.check(unsafe { sqlrs_exchange_create(ctx.raw(), unique_id.as_ptr() as *const _, rank as i32, world as i32, &mut raw) })?;
+        Ok(ExchangeComm { ctx, raw, world })
+    }
+}
+impl Drop for ExchangeComm { fn drop(&mut self) { unsafe { sqlrs_exchange_destroy(self.raw) } } }
+pub struct HipExchangeExecutor { pub comm: Arc<ExchangeComm>, pub key: BoundExpr, pub child: BoxedExecutor }
+impl HipExchangeExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let ctx = self.comm.ctx.clone();
+        let key = lower(&self.key)?;
+        #[for_await]
+        for batch in self.child {
+            let batch = batch?;
+            let inb = AbiBatch::new(&batch)?;
+            let w = self.comm.world;
+            let (mut parts, mut offs) = (std::ptr::null_mut(), vec![0i64; w + 1]);
+            ctx.check(unsafe { sqlrs_hash_partition(ctx.raw(), &inb.raw, &key.abi(), w as i32, SQLRS_MEM_DEVICE, &mut parts, offs.as_mut_ptr()) })?;
+            let rows: Vec<i64> = (0..w).map(|p| offs[p + 1] - offs[p]).collect();
+            let mut got = std::ptr::null_mut();
+            let st = unsafe { sqlrs_exchange_all_to_all(self.comm.raw, parts, offs.as_ptr(), rows.as_ptr(), &mut got, std::ptr::null_mut()) };
+            unsafe { sqlrs_batch_release(parts) }; // (read stream-ordered: the pool hands the block to LATER work of the same stream)
+            ctx.check(st)?;
+            let mut host = std::ptr::null_mut();
+            let st = unsafe { sqlrs_batch_copy(ctx.raw(), got, SQLRS_MEM_HOST, &mut host) };
+            unsafe { sqlrs_batch_release(got) };
+            ctx.check(st)?;
+            yield import_batch(batch.schema(), host)?; // every rank yields the rows whose key hashes to it
+        }
+    }
+}
 pub struct HipLimitExecutor { pub ctx: Arc<HipCtx>, pub limit: Option<usize>, pub offset: Option<usize>, pub child: BoxedExecutor }
 impl HipLimitExecutor {
     #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
