@@ -3,6 +3,7 @@
 // batch — a C call, no interpreter — next to bench.py's `C4_host_batches_1024`, whose wall clock includes one Python
 // ctypes call per batch.  Prints one JSON object; `bench.py` adds it to the line as `C4_host_batches_1024_native`.
 //   ./bench_host_batches [rows = 2e7] [groups = 1e6] [batch = 1024]
+//   ./bench_host_batches filter ... | probe ...   the streaming operators at the same batch shape (see bench_filter / bench_probe)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,7 +27,185 @@ static uint64_t splitmix64(uint64_t seed, uint64_t i) { // the generator of sqlr
     }                                                                                             \
   } while (0)
 
+static void host_col(sqlrs_column_t &c, int32_t dtype, const void *values, int64_t m) {
+  std::memset(&c, 0, sizeof(c));
+  c.dtype = dtype;
+  c.mem = SQLRS_MEM_HOST;
+  c.length = m;
+  c.values = values;
+}
+
+// ./bench_host_batches filter [rows = 2e7] [batch = 1024] [group = 1024]
+// FilterExecutor (C2's query: SELECT v1 FROM t WHERE v1 > k, selectivity 0.5) fed pageable 1024-row host batches by a native
+// caller, result batches on the host: (a) one sqlrs_filter_push per batch, (b) sqlrs_filter_push_many over groups of batches.
+static int bench_filter(int argc, char **argv) {
+  const int64_t n = argc > 2 ? (int64_t)std::atof(argv[2]) : 20000000, B = argc > 3 ? std::atoll(argv[3]) : 1024;
+  const int group = argc > 4 ? std::atoi(argv[4]) : 1024;
+  sqlrs_ctx_t *ctx = nullptr;
+  if (sqlrs_ctx_create(0, &ctx) != SQLRS_OK) {
+    std::printf("{\"error\": \"no device\"}\n");
+    return 2;
+  }
+  std::vector<int64_t> v((size_t)n);
+  int64_t expect = 0;
+  const int64_t k = (1ll << 30);
+  for (int64_t i = 0; i < n; i++) {
+    v[(size_t)i] = (int64_t)(splitmix64(0xC2, (uint64_t)i) % (1ull << 31));
+    expect += v[(size_t)i] > k;
+  }
+  sqlrs_expr_node_t nodes[3] = {};
+  nodes[0].op = SQLRS_EXPR_INPUT_REF;
+  nodes[0].index = 0;
+  nodes[1].op = SQLRS_EXPR_CONSTANT;
+  nodes[1].dtype = SQLRS_INT64;
+  nodes[1].i = k;
+  nodes[2].op = SQLRS_EXPR_GT;
+  sqlrs_expr_t pred{nodes, 3, 0};
+  const int64_t nb = (n + B - 1) / B;
+  std::vector<sqlrs_column_t> cols((size_t)nb);
+  std::vector<sqlrs_batch_t> batches((size_t)nb);
+  std::vector<const sqlrs_batch_t *> ptrs((size_t)nb);
+  for (int64_t b = 0; b < nb; b++) {
+    const int64_t m = std::min<int64_t>(B, n - b * B);
+    host_col(cols[(size_t)b], SQLRS_INT64, v.data() + b * B, m);
+    std::memset(&batches[(size_t)b], 0, sizeof(sqlrs_batch_t));
+    batches[(size_t)b].num_rows = m;
+    batches[(size_t)b].num_columns = 1;
+    batches[(size_t)b].columns = &cols[(size_t)b];
+    ptrs[(size_t)b] = &batches[(size_t)b];
+  }
+  double best[2] = {1e30, 1e30};
+  int64_t kept[2] = {0, 0};
+  bool order_ok = true;
+  for (int mode = 0; mode < 2; mode++) {
+    for (int rep = 0; rep < 3; rep++) {
+      auto t0 = std::chrono::steady_clock::now();
+      sqlrs_filter_t *f = nullptr;
+      CHECK(sqlrs_filter_create(ctx, &pred, &f));
+      int64_t got = 0;
+      std::vector<sqlrs_batch_t *> outs((size_t)group);
+      if (mode == 0) {
+        for (int64_t b = 0; b < nb; b++) {
+          sqlrs_batch_t *o = nullptr;
+          CHECK(sqlrs_filter_push(f, ptrs[(size_t)b], SQLRS_MEM_HOST, &o));
+          got += o->num_rows;
+          sqlrs_batch_release(o);
+        }
+      } else {
+        for (int64_t b0 = 0; b0 < nb; b0 += group) {
+          const int g = (int)std::min<int64_t>(group, nb - b0);
+          CHECK(sqlrs_filter_push_many(f, g, ptrs.data() + b0, SQLRS_MEM_HOST, outs.data()));
+          for (int i = 0; i < g; i++) {
+            const int64_t m = outs[(size_t)i]->num_rows;
+            if (rep == 0 && m) { // one output batch per input batch, rows in input order
+              const int64_t *ov = (const int64_t *)outs[(size_t)i]->columns[0].values;
+              const int64_t *iv = v.data() + (b0 + i) * B;
+              int64_t j = 0;
+              for (int64_t r = 0; r < batches[(size_t)(b0 + i)].num_rows && j < m; r++)
+                if (iv[r] > k) order_ok = order_ok && ov[j++] == iv[r];
+              order_ok = order_ok && j == m;
+            }
+            got += m;
+            sqlrs_batch_release(outs[(size_t)i]);
+          }
+        }
+      }
+      sqlrs_filter_destroy(f);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      kept[mode] = got;
+      if (rep > 0 && ms < best[mode]) best[mode] = ms;
+    }
+  }
+  const bool ok = kept[0] == expect && kept[1] == expect && order_ok;
+  std::printf("{\"rows\": %lld, \"batches\": %lld, \"batch_rows\": %lld, \"kept\": %lld, \"ms_push\": %.1f, \"Mrows_s_push\": %.1f, "
+              "\"group\": %d, \"ms_push_many\": %.1f, \"Mrows_s_push_many\": %.1f, \"check\": \"%s\", \"note\": \"native caller (C ABI): "
+              "pageable %lld-row host batches, one result batch per input batch on the host; push = sqlrs_filter_push per batch, "
+              "push_many = sqlrs_filter_push_many over groups of batches; best of 2 after a warm-up\"}\n",
+              (long long)n, (long long)nb, (long long)B, (long long)kept[1], best[0], (double)n / best[0] / 1e3, group, best[1],
+              (double)n / best[1] / 1e3, ok ? "OK" : "mismatch", (long long)B);
+  sqlrs_ctx_destroy(ctx);
+  return ok ? 0 : 1;
+}
+
+// ./bench_host_batches probe [rows = 2e7] [build = 1e6] [batch = 1024]
+// HashJoinExecutor (C3's join: fact x dim on an int64 key, Inner, every probe row matches) with the PROBE side fed as pageable
+// 1024-row host batches, joined batches (dim key, dim payload, fact key, fact val) on the host: sqlrs_hash_join_probe_push per batch.
+static int bench_probe(int argc, char **argv) {
+  const int64_t n = argc > 2 ? (int64_t)std::atof(argv[2]) : 20000000, nB = argc > 3 ? (int64_t)std::atof(argv[3]) : 1000000;
+  const int64_t B = argc > 4 ? std::atoll(argv[4]) : 1024;
+  sqlrs_ctx_t *ctx = nullptr;
+  if (sqlrs_ctx_create(0, &ctx) != SQLRS_OK) {
+    std::printf("{\"error\": \"no device\"}\n");
+    return 2;
+  }
+  std::vector<int64_t> dk((size_t)nB), dp((size_t)nB), fk((size_t)n);
+  std::vector<double> fv((size_t)n);
+  for (int64_t i = 0; i < nB; i++) {
+    dk[(size_t)i] = (i * 7919) % nB; // a permutation when gcd(7919, nB) = 1
+    dp[(size_t)i] = dk[(size_t)i] * 3 + 1;
+  }
+  for (int64_t i = 0; i < n; i++) {
+    fk[(size_t)i] = (int64_t)(splitmix64(0xF1, (uint64_t)i) % (uint64_t)nB);
+    fv[(size_t)i] = (double)(splitmix64(0xF2, (uint64_t)i) >> 11) * (1.0 / 9007199254740992.0);
+  }
+  sqlrs_expr_node_t k0{};
+  k0.op = SQLRS_EXPR_INPUT_REF;
+  k0.index = 0;
+  sqlrs_expr_t key{&k0, 1, 0};
+  const int32_t right_dtypes[2] = {SQLRS_INT64, SQLRS_FLOAT64};
+  double best = 1e30;
+  int64_t joined = 0;
+  bool ok = true;
+  for (int rep = 0; rep < 3; rep++) {
+    auto t0 = std::chrono::steady_clock::now();
+    sqlrs_hash_join_t *j = nullptr;
+    CHECK(sqlrs_hash_join_create(ctx, SQLRS_JOIN_INNER, 1, &key, &key, nullptr, 2, right_dtypes, &j));
+    sqlrs_column_t lc[2];
+    host_col(lc[0], SQLRS_INT64, dk.data(), nB);
+    host_col(lc[1], SQLRS_INT64, dp.data(), nB);
+    sqlrs_batch_t lb{};
+    lb.num_rows = nB;
+    lb.num_columns = 2;
+    lb.columns = lc;
+    CHECK(sqlrs_hash_join_build_push(j, &lb));
+    CHECK(sqlrs_hash_join_build_finish(j));
+    joined = 0;
+    for (int64_t lo = 0; lo < n; lo += B) {
+      const int64_t m = std::min<int64_t>(B, n - lo);
+      sqlrs_column_t rc[2];
+      host_col(rc[0], SQLRS_INT64, fk.data() + lo, m);
+      host_col(rc[1], SQLRS_FLOAT64, fv.data() + lo, m);
+      sqlrs_batch_t rb{};
+      rb.num_rows = m;
+      rb.num_columns = 2;
+      rb.columns = rc;
+      sqlrs_batch_t *o = nullptr;
+      CHECK(sqlrs_hash_join_probe_push(j, &rb, SQLRS_MEM_HOST, &o));
+      if (o) {
+        if (rep == 0 && o->num_rows == m) { // PK-FK: one joined row per probe row, probe order; payload = 3 * key + 1
+          const int64_t *k = (const int64_t *)o->columns[0].values, *p = (const int64_t *)o->columns[1].values;
+          for (int64_t r = 0; r < m; r += 97) ok = ok && k[r] == fk[(size_t)(lo + r)] && p[r] == 3 * k[r] + 1;
+        }
+        joined += o->num_rows;
+        sqlrs_batch_release(o);
+      }
+    }
+    sqlrs_hash_join_destroy(j);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rep > 0 && ms < best) best = ms;
+  }
+  ok = ok && joined == n;
+  std::printf("{\"probe_rows\": %lld, \"build_rows\": %lld, \"batch_rows\": %lld, \"joined\": %lld, \"ms\": %.1f, \"Mrows_s\": %.1f, "
+              "\"check\": \"%s\", \"note\": \"native caller (C ABI): build side one host batch, probe side pageable %lld-row host batches "
+              "through sqlrs_hash_join_probe_push, joined batches (4 columns) on the host; build included; best of 2 after a warm-up\"}\n",
+              (long long)n, (long long)nB, (long long)B, (long long)joined, best, (double)n / best / 1e3, ok ? "OK" : "mismatch", (long long)B);
+  sqlrs_ctx_destroy(ctx);
+  return ok ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && std::strcmp(argv[1], "filter") == 0) return bench_filter(argc, argv);
+  if (argc > 1 && std::strcmp(argv[1], "probe") == 0) return bench_probe(argc, argv);
   const int64_t n = argc > 1 ? (int64_t)std::atof(argv[1]) : 20000000, G = argc > 2 ? (int64_t)std::atof(argv[2]) : 1000000;
   const int64_t B = argc > 3 ? std::atoll(argv[3]) : 1024;
   sqlrs_ctx_t *ctx = nullptr;

@@ -211,6 +211,12 @@ int sqlrs_batch_copy(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, int out_mem, sql
 typedef struct sqlrs_filter sqlrs_filter_t;
 int sqlrs_filter_create(sqlrs_ctx_t *ctx, const sqlrs_expr_t *expr, sqlrs_filter_t **out);
 int sqlrs_filter_push(sqlrs_filter_t *f, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out);
+/* n iterations of the loop in ONE call: out[i] (n entries) is what sqlrs_filter_push(in[i]) returns — one output batch
+ * per input batch, in order, empty ones included [ref: filter.rs:15-24] — for the reference's batch shape, 1024-row
+ * HOST batches [ref: src/storage/csv.rs:105]: small HOST batches of fixed-width columns are uploaded together, filtered
+ * by one launch sequence and the kept rows of every input batch handed out as a batch of its own (out_mem = HOST); any
+ * other input runs through sqlrs_filter_push batch by batch.  On error no output batch is left allocated. */
+int sqlrs_filter_push_many(sqlrs_filter_t *f, int n, const sqlrs_batch_t *const *in, int out_mem, sqlrs_batch_t **out);
 void sqlrs_filter_destroy(sqlrs_filter_t *f);
 
 /* Evaluates one expression on a batch -> one-column batch.

@@ -17,6 +17,12 @@ extern "C" void sqlrs_batch_release(sqlrs_batch_t *batch);
 struct sqlrs_filter {
   Ctx *ctx;
   Expr expr;
+  std::unique_ptr<HostStage> stage; // sqlrs_filter_push_many: the calls' small HOST batches, uploaded together
+  void *pin_out = nullptr;          // ... and where their kept rows land (pinned: the copy back runs at the PCIe rate)
+  size_t pin_cap = 0;
+  ~sqlrs_filter() {
+    if (pin_out) (void)hipHostFree(pin_out);
+  }
 };
 
 // ---- conjunctions of `column OP constant` ------------------------------------------------------------------------
@@ -105,39 +111,228 @@ int sqlrs_filter_create(sqlrs_ctx_t *ctx, const sqlrs_expr_t *expr, sqlrs_filter
   });
 }
 
+} // extern "C"
+
+namespace sq {
+// mask = expr.eval_column(batch); filter_record_batch(batch, mask)  [ref: filter.rs:16-24] -> the kept rows; *sel_out
+// (optional) = the selection itself (bits + kept rows before every 4096-row tile)
+static DBatch filter_batch(sqlrs_filter *f, InBatch &ib, Selection *sel_out) {
+  Ctx *ctx = f->ctx;
+  auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
+  int64_t rows = ib.rows();
+  Selection sel;
+  DCol fast_col;
+  int fast_idx = -1;
+  if (!filter_fast_path(ctx, f->expr, colfn, rows, &fast_idx, &sel, &fast_col) &&
+      !filter_conjunction_fast_path(ctx, f->expr, ib, rows, &sel)) {
+    DCol mask = eval_expr(ctx, f->expr, colfn, rows, false);
+    mask.length = rows;
+    sel = selection_from_mask(ctx, mask);
+  }
+  DBatch o;
+  o.rows = sel.count;
+  // every row passed: the output is the input (filter_record_batch of an all-true mask) — its columns are shared
+  // when they are this library's own buffers and copied once when the caller only lent them, not compacted
+  DBatch whole;
+  const bool keep_all = sel.count == rows && rows > 0;
+  if (keep_all) whole = ib.materialize(true);
+  for (int i = 0; i < ib.num_columns(); i++) {
+    if (i == fast_idx)
+      o.cols.push_back(fast_col);
+    else if (keep_all)
+      o.cols.push_back(whole.cols[(size_t)i]);
+    else
+      o.cols.push_back(compact_column(ctx, ib.col(i), sel));
+  }
+  if (sel_out) *sel_out = sel;
+  return o;
+}
+
+// kept[i] = selected rows before row bounds[i] (bounds ascending, <= rows): tile prefix + the bits of the tile up to it
+__global__ void kept_before_kernel(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ tile_off, int64_t rows,
+                                   const int64_t *__restrict__ bounds, int64_t n, int64_t total, int64_t *__restrict__ kept) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t b = bounds[i];
+  if (b >= rows) {
+    kept[i] = total;
+    return;
+  }
+  const int64_t t = b / TILE_ROWS;
+  int64_t k = (int64_t)tile_off[t];
+  for (int64_t w = t * (TILE_ROWS / 64); w < (b >> 6); w++) k += __popcll(bits[w]);
+  if (b & 63) k += __popcll(bits[b >> 6] & ((1ull << (b & 63)) - 1));
+  kept[i] = k;
+}
+
+// rows [lo, hi) of a HOST column image (values / validity of `rows_total` rows) as malloc'd blocks of their own
+static sqlrs_column_t slice_host_column(int32_t dtype, const uint8_t *vals, const uint8_t *validity, int64_t lo, int64_t hi) {
+  sqlrs_column_t c;
+  std::memset(&c, 0, sizeof(c));
+  const size_t w = width_of(dtype);
+  const int64_t n = hi - lo;
+  c.dtype = dtype;
+  c.mem = SQLRS_MEM_HOST;
+  c.length = n;
+  void *v = std::malloc(std::max<size_t>(w * (size_t)n, 8));
+  if (!v) fail(SQLRS_ERR_INTERNAL, "out of host memory");
+  if (n) std::memcpy(v, vals + w * (size_t)lo, w * (size_t)n);
+  c.values = v;
+  if (validity) {
+    int64_t nulls = 0;
+    uint8_t *vb = (uint8_t *)std::calloc((size_t)(n + 7) / 8 + 8, 1);
+    if (!vb) {
+      std::free(v);
+      fail(SQLRS_ERR_INTERNAL, "out of host memory");
+    }
+    for (int64_t r = 0; r < n; r++) {
+      const int64_t s = lo + r;
+      if ((validity[s >> 3] >> (s & 7)) & 1) vb[r >> 3] |= (uint8_t)(1u << (r & 7));
+      else nulls++;
+    }
+    if (nulls) {
+      c.validity = vb;
+      c.null_count = nulls;
+    } else {
+      std::free(vb);
+    }
+  }
+  return c;
+}
+} // namespace sq
+
+extern "C" {
+
 // one iteration of the for_await loop  [ref: filter.rs:16-24]
 int sqlrs_filter_push(sqlrs_filter_t *f, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out) {
   return guard(f->ctx, [&] {
     Ctx *ctx = f->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
     InBatch ib(ctx, in);
-    auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
-    int64_t rows = ib.rows();
+    *out = emit_batch(ctx, filter_batch(f, ib, nullptr), out_mem);
+  });
+}
+
+// n iterations of that loop in one call — out[i] is exactly what sqlrs_filter_push(in[i]) returns (one output batch per
+// input batch, empty ones included, filter.rs:15-24) — for the reference's batch shape: 1024-row HOST batches
+// (storage/csv.rs:105).  One upload + one synchronisation per BATCH and column is ~70 us a call (14.5 Mrows/s); here the
+// batches' fixed-width columns are appended to a pinned staging area, uploaded with one copy per column, filtered by
+// ONE launch sequence, the kept rows come back with one copy per column, and every input batch's share of them (the
+// kept rows before each batch boundary are counted on the device from the selection bits) is handed out as a batch of
+// its own.  Batches the staging area does not take (DEVICE memory, Utf8 / Boolean columns, other out_mem) run through
+// sqlrs_filter_push one by one.
+int sqlrs_filter_push_many(sqlrs_filter_t *f, int n, const sqlrs_batch_t *const *in, int out_mem, sqlrs_batch_t **out) {
+  return guard(f->ctx, [&] {
+    Ctx *ctx = f->ctx;
+    SQ_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    if (n <= 0) return;
+    if (!f->stage) {
+      f->stage.reset(new HostStage());
+      f->stage->ctx = ctx;
+    }
+    HostStage &st = *f->stage;
+    bool stageable = out_mem == SQLRS_MEM_HOST && !st.has_schema && n > 1;
+    int64_t total_rows = 0;
+    for (int i = 0; i < n && stageable; i++) {
+      stageable = st.accepts(in[i]) && in[i]->num_columns == in[0]->num_columns;
+      for (int c = 0; c < in[i]->num_columns && stageable; c++) stageable = in[i]->columns[c].dtype == in[0]->columns[c].dtype;
+      total_rows += in[i] ? in[i]->num_rows : 0;
+    }
+    if (!stageable || total_rows == 0 || total_rows > (1ll << 30)) {
+      int i = 0;
+      try {
+        for (; i < n; i++) {
+          InBatch ib(ctx, in[i]);
+          out[i] = emit_batch(ctx, filter_batch(f, ib, nullptr), out_mem);
+        }
+      } catch (...) {
+        for (int k = 0; k < i; k++) {
+          sqlrs_batch_release(out[k]);
+          out[k] = nullptr;
+        }
+        throw;
+      }
+      return;
+    }
+    std::vector<int64_t> bounds((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) {
+      st.append(in[i]);
+      bounds[(size_t)i + 1] = bounds[(size_t)i] + in[i]->num_rows;
+    }
+    sqlrs_batch_t *dev = st.take(); // one upload per column
+    struct Rel {
+      sqlrs_batch_t *b;
+      ~Rel() { if (b) sqlrs_batch_release(b); }
+    } rel{dev};
     Selection sel;
-    DCol fast_col;
-    int fast_idx = -1;
-    if (!filter_fast_path(ctx, f->expr, colfn, rows, &fast_idx, &sel, &fast_col) &&
-        !filter_conjunction_fast_path(ctx, f->expr, ib, rows, &sel)) {
-      DCol mask = eval_expr(ctx, f->expr, colfn, rows, false);
-      mask.length = rows;
-      sel = selection_from_mask(ctx, mask);
-    }
     DBatch o;
-    o.rows = sel.count;
-    // every row passed: the output is the input (filter_record_batch of an all-true mask) — its columns are shared
-    // when they are this library's own buffers and copied once when the caller only lent them, not compacted
-    DBatch whole;
-    const bool keep_all = sel.count == rows && rows > 0;
-    if (keep_all) whole = ib.materialize(true);
-    for (int i = 0; i < ib.num_columns(); i++) {
-      if (i == fast_idx)
-        o.cols.push_back(fast_col);
-      else if (keep_all)
-        o.cols.push_back(whole.cols[(size_t)i]);
-      else
-        o.cols.push_back(compact_column(ctx, ib.col(i), sel));
+    {
+      InBatch ib(ctx, dev);
+      o = filter_batch(f, ib, &sel);
     }
-    *out = emit_batch(ctx, std::move(o), out_mem);
+    // kept rows before every batch boundary
+    BufP dbounds = ctx->alloc(8 * ((size_t)n + 1)), dkept = ctx->alloc(8 * ((size_t)n + 1));
+    SQ_HIP(hipMemcpyAsync(dbounds->p, bounds.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    kept_before_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, ctx->stream>>>(
+        sel.bits, sel.tile_off->as<uint64_t>(), total_rows, dbounds->as<int64_t>(), n + 1, sel.count, dkept->as<int64_t>());
+    SQ_HIP(hipGetLastError());
+    std::vector<int64_t> kept((size_t)n + 1);
+    SQ_HIP(hipMemcpyAsync(kept.data(), dkept->p, 8 * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->stream));
+    // the kept rows of all batches: one copy per column
+    const int nc = (int)o.cols.size();
+    size_t need = 0;
+    std::vector<size_t> voff((size_t)nc), boff((size_t)nc, (size_t)-1);
+    for (int c = 0; c < nc; c++) {
+      const DCol &col = o.cols[(size_t)c];
+      voff[(size_t)c] = need;
+      need += round_up(std::max<size_t>(width_of(col.dtype) * (size_t)o.rows, 8), 64);
+      if (col.validity && col.null_count != 0) {
+        boff[(size_t)c] = need;
+        need += round_up(bitmap_bytes(o.rows) + 8, 64);
+      }
+    }
+    if (need > f->pin_cap) {
+      if (f->pin_out) SQ_HIP(hipHostFree(f->pin_out));
+      f->pin_out = nullptr;
+      f->pin_cap = 0;
+      SQ_HIP(hipHostMalloc(&f->pin_out, need + need / 4, hipHostMallocDefault));
+      f->pin_cap = need + need / 4;
+    }
+    uint8_t *pin = (uint8_t *)f->pin_out;
+    for (int c = 0; c < nc; c++) {
+      const DCol &col = o.cols[(size_t)c];
+      const size_t w = width_of(col.dtype);
+      if (o.rows) SQ_HIP(hipMemcpyAsync(pin + voff[(size_t)c], col.values, w * (size_t)o.rows, hipMemcpyDeviceToHost, ctx->stream));
+      if (boff[(size_t)c] != (size_t)-1)
+        SQ_HIP(hipMemcpyAsync(pin + boff[(size_t)c], col.validity, bitmap_bytes(o.rows), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ctx->sync();
+    int made = 0;
+    try {
+      for (; made < n; made++) {
+        const int64_t lo = kept[(size_t)made], hi = kept[(size_t)made + 1];
+        std::vector<sqlrs_column_t> cols;
+        try {
+          for (int c = 0; c < nc; c++)
+            cols.push_back(slice_host_column(o.cols[(size_t)c].dtype, pin + voff[(size_t)c],
+                                             boff[(size_t)c] == (size_t)-1 ? nullptr : pin + boff[(size_t)c], lo, hi));
+        } catch (...) {
+          for (sqlrs_column_t &c : cols) {
+            std::free(const_cast<void *>(c.values));
+            std::free(const_cast<uint8_t *>(c.validity));
+          }
+          throw;
+        }
+        out[made] = emit_host_columns(ctx, std::move(cols), hi - lo);
+      }
+    } catch (...) {
+      for (int k = 0; k < made; k++) {
+        sqlrs_batch_release(out[k]);
+        out[k] = nullptr;
+      }
+      throw;
+    }
   });
 }
 

@@ -50,8 +50,30 @@ class FilterExecutor:
     """``FilterExecutor { expr, child }`` (filter.rs:7-10)."""
 
     def __init__(self, backend: abi.Backend, expr: BoundExpr, child: Iterable,
-                 out_mem: int = abi.MEM_HOST):
+                 out_mem: int = abi.MEM_HOST, many: int = 0):
         self.backend, self.expr, self.child, self.out_mem = backend, expr, child, out_mem
+        # many > 1: pull that many batches of the child, hand them to sqlrs_filter_push_many together and yield its
+        # outputs one by one — the same stream of batches (one per input batch, filter.rs:15-24), fewer uploads
+        self.many = many
+
+    def _execute_many(self, be, h):
+        group = []
+
+        def flush():
+            n = len(group)
+            hb = [abi.as_batch(b) for b in group]
+            ins = (C.POINTER(abi.Batch) * n)(*[C.pointer(b.abi) if hasattr(b, "abi") else b.ptr for b in hb])
+            outs = (C.POINTER(abi.Batch) * n)()
+            be.check(be.fn("filter_push_many")(h, n, ins, self.out_mem, outs))
+            res = [_emit(be, outs[i], self.out_mem, _names_of(group[i])) for i in range(n)]
+            group.clear()
+            return res
+        for batch in self.child:
+            group.append(batch)
+            if len(group) == self.many:
+                yield from flush()
+        if group:
+            yield from flush()
 
     def execute(self):
         be = self.backend
@@ -59,6 +81,9 @@ class FilterExecutor:
         h = C.c_void_p()
         be.check(be.fn("filter_create")(be.ctx, C.byref(packed.abi), C.byref(h)))
         try:
+            if self.many > 1 and getattr(be.lib, be.prefix + "filter_push_many", None) is not None:
+                yield from self._execute_many(be, h)
+                return
             for batch in self.child:  # filter.rs:15-24
                 b = abi.as_batch(batch)
                 out = C.POINTER(abi.Batch)()

@@ -1363,3 +1363,34 @@ def test_filter_fast_path_large_batch_stays_on_its_first_launch(hip, oracle, dty
     got = rows_of(FilterExecutor(hip, e, [dev]).execute())
     assert got == rows_of(FilterExecutor(oracle, e, [b]).execute())
     assert dt < 0.25, f"filter over {n} rows took {dt * 1e3:.1f} ms: look-back timeout + ticketed rerun?"
+
+
+@pytest.mark.parametrize("shape", ["col_cmp_const", "general_expr", "with_nulls", "utf8_falls_back"])
+def test_filter_push_many_yields_the_batches_of_push(hip, oracle, shape):
+    """sqlrs_filter_push_many: a group of small HOST batches (the reference's 1024-row CSV batches, csv.rs:105) uploaded and
+    filtered together must come back as exactly the batches sqlrs_filter_push yields one by one — one output batch per
+    input batch, in order, empty ones included (filter.rs:15-24) — across every batch boundary; against the oracle's
+    per-batch Filter."""
+    rng = np.random.default_rng(len(shape))
+    sizes = [0, 1, 63, 64, 65, 1024, 1024, 1, 0, 4095, 4096, 4097, 1024, 7, 20_000, 1024, 0, 3]
+    batches = []
+    for n in sizes:
+        v = rng.integers(-50, 50, n, dtype=np.int64)
+        w = rng.random(n)
+        if shape == "with_nulls":
+            cols = [pa.array(v, mask=rng.random(n) < 0.2), pa.array(w, mask=rng.random(n) < 0.1)]
+        elif shape == "utf8_falls_back":
+            cols = [pa.array(v), pa.array([f"s{int(x * 100)}" for x in w])]
+        else:
+            cols = [pa.array(v), pa.array(w)]
+        batches.append(pa.RecordBatch.from_arrays(cols, names=["v", "w"]))
+    if shape == "general_expr":
+        expr = ((InputRef(0) > Constant(3, abi.INT64)) & (InputRef(1) < Constant(0.7, abi.FLOAT64))) | BinaryOp("=", InputRef(0), Constant(-7, abi.INT64))
+    else:
+        expr = InputRef(0) > Constant(3, abi.INT64)
+    exp = list(FilterExecutor(oracle, expr, batches).execute())
+    for many in (5, 64):
+        got = list(FilterExecutor(hip, expr, batches, many=many).execute())
+        assert [b.num_rows for b in got] == [b.num_rows for b in exp]
+        for g, e in zip(got, exp):
+            assert g.equals(e), (many, g.num_rows)
