@@ -245,6 +245,14 @@ int sqlrs_hash_join_build_finish(sqlrs_hash_join_t *j);
  * [ref: hash_join.rs:207-292] */
 int sqlrs_hash_join_probe_push(sqlrs_hash_join_t *j, const sqlrs_batch_t *right, int out_mem,
                                sqlrs_batch_t **out);
+/* n probe batches in ONE call: out[i] (n entries) is what sqlrs_hash_join_probe_push(right[i]) returns — one joined batch
+ * per probe batch, in order [ref: hash_join.rs:207-292] — for the reference's batch shape, 1024-row HOST batches
+ * [ref: src/storage/csv.rs:105]: Inner / Left joins without a join filter over small HOST batches of fixed-width columns
+ * are probed as one batch (pairs are probe-row major, hash_join.rs:225-234: every input batch's joined rows are one
+ * contiguous range) and cut back into n HOST batches; anything else runs batch by batch.  On error no output batch is
+ * left allocated. */
+int sqlrs_hash_join_probe_push_many(sqlrs_hash_join_t *j, int n, const sqlrs_batch_t *const *right, int out_mem,
+                                    sqlrs_batch_t **out);
 /* The index-pair form of one probe batch, before any gather: 2 columns
  * (UINT64 left index, nullable; UINT32 right index), in the reference's order
  * (probe-row major, build insertion order minor), join filter NOT applied.

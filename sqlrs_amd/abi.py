@@ -332,6 +332,7 @@ class Backend:
             "hash_agg_filter_fused_batches": (C.c_int64, [vp]),
             "join_agg_destroy": (None, [vp]),
             "filter_push_many": (i, [vp, i, C.POINTER(pb), i, C.POINTER(pb)]),
+            "hash_join_probe_push_many": (i, [vp, i, C.POINTER(pb), i, C.POINTER(pb)]),
             "cross_join_create": (i, [vp, pvp]),
             "cross_join_build_push": (i, [vp, pb]),
             "cross_join_probe_push": (i, [vp, pb, i, ppb]),

@@ -208,6 +208,11 @@ DCol upload_column(Ctx *ctx, const sqlrs_column_t &c, bool force_copy);
 // Device batch -> library-owned ABI batch in `out_mem` (host: D2H into malloc'd buffers).
 sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem);
 sqlrs_batch_t *emit_host_columns(Ctx *ctx, std::vector<sqlrs_column_t> &&cols, int64_t rows); // takes over malloc'd blocks
+// *_push_many (small HOST batches handled together): every column fixed width? / rows [cut[i], cut[i + 1]) of a device batch
+// as n library-owned HOST batches through one pinned copy per column (ctx.hip)
+bool all_fixed_width(const DBatch &b);
+void split_rows_to_host(Ctx *ctx, const DBatch &o, const std::vector<int64_t> &cut, void **pin, size_t *pin_cap, int n,
+                        sqlrs_batch_t **out);
 DCol make_null_column(Ctx *ctx, int32_t dtype, int64_t n);
 int64_t count_nulls(Ctx *ctx, const DCol &c);
 

@@ -8,6 +8,7 @@
 #include "host_stage.hpp"
 #include "prims.hpp"
 
+extern "C" void sqlrs_batch_release(sqlrs_batch_t *batch);
 namespace sq {
 
 // ------------------------------------------------------------------------ pool --
@@ -507,6 +508,107 @@ sqlrs_batch_t *HostStage::take() {
   has_schema = false;
   rows = 0;
   return dev;
+}
+
+// rows [lo, hi) of a HOST column image (values / validity bitmap) as malloc'd blocks of their own
+static sqlrs_column_t slice_host_column(int32_t dtype, const uint8_t *vals, const uint8_t *validity, int64_t lo, int64_t hi) {
+  sqlrs_column_t c;
+  std::memset(&c, 0, sizeof(c));
+  const size_t w = width_of(dtype);
+  const int64_t n = hi - lo;
+  c.dtype = dtype;
+  c.mem = SQLRS_MEM_HOST;
+  c.length = n;
+  void *v = std::malloc(std::max<size_t>(w * (size_t)n, 8));
+  if (!v) fail(SQLRS_ERR_INTERNAL, "out of host memory");
+  if (n) std::memcpy(v, vals + w * (size_t)lo, w * (size_t)n);
+  c.values = v;
+  if (validity) {
+    int64_t nulls = 0;
+    uint8_t *vb = (uint8_t *)std::calloc((size_t)(n + 7) / 8 + 8, 1);
+    if (!vb) {
+      std::free(v);
+      fail(SQLRS_ERR_INTERNAL, "out of host memory");
+    }
+    for (int64_t r = 0; r < n; r++) {
+      const int64_t s = lo + r;
+      if ((validity[s >> 3] >> (s & 7)) & 1) vb[r >> 3] |= (uint8_t)(1u << (r & 7));
+      else nulls++;
+    }
+    if (nulls) {
+      c.validity = vb;
+      c.null_count = nulls;
+    } else {
+      std::free(vb);
+    }
+  }
+  return c;
+}
+
+bool all_fixed_width(const DBatch &b) {
+  for (const DCol &c : b.cols)
+    if (!width_of(c.dtype) || c.stride == 0) return false;
+  return true;
+}
+
+// out[i] = rows [cut[i], cut[i + 1]) of the device batch `o` (fixed-width columns) as a library-owned HOST batch, i < n:
+// one device-to-host copy per column into the pinned block *pin (grown on demand, kept by the caller), then one slice per
+// output batch.  Synchronises the ctx stream.  On error no output batch is left allocated.
+void split_rows_to_host(Ctx *ctx, const DBatch &o, const std::vector<int64_t> &cut, void **pin_p, size_t *pin_cap, int n,
+                        sqlrs_batch_t **out) {
+  const int nc = (int)o.cols.size();
+  size_t need = 64;
+  std::vector<size_t> voff((size_t)nc), boff((size_t)nc, (size_t)-1);
+  for (int c = 0; c < nc; c++) {
+    const DCol &col = o.cols[(size_t)c];
+    voff[(size_t)c] = need;
+    need += round_up(std::max<size_t>(width_of(col.dtype) * (size_t)o.rows, 8), 64);
+    if (col.validity && col.null_count != 0) {
+      boff[(size_t)c] = need;
+      need += round_up(bitmap_bytes(o.rows) + 8, 64);
+    }
+  }
+  if (need > *pin_cap) {
+    if (*pin_p) SQ_HIP(hipHostFree(*pin_p));
+    *pin_p = nullptr;
+    *pin_cap = 0;
+    SQ_HIP(hipHostMalloc(pin_p, need + need / 4, hipHostMallocDefault));
+    *pin_cap = need + need / 4;
+  }
+  uint8_t *pin = (uint8_t *)*pin_p;
+  for (int c = 0; c < nc; c++) {
+    const DCol &col = o.cols[(size_t)c];
+    const size_t w = width_of(col.dtype);
+    if (o.rows) SQ_HIP(hipMemcpyAsync(pin + voff[(size_t)c], col.values, w * (size_t)o.rows, hipMemcpyDeviceToHost, ctx->stream));
+    if (boff[(size_t)c] != (size_t)-1)
+      SQ_HIP(hipMemcpyAsync(pin + boff[(size_t)c], col.validity, bitmap_bytes(o.rows), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  ctx->sync();
+  int made = 0;
+  try {
+    for (; made < n; made++) {
+      const int64_t lo = cut[(size_t)made], hi = cut[(size_t)made + 1];
+      std::vector<sqlrs_column_t> cols;
+      try {
+        for (int c = 0; c < nc; c++)
+          cols.push_back(slice_host_column(o.cols[(size_t)c].dtype, pin + voff[(size_t)c],
+                                           boff[(size_t)c] == (size_t)-1 ? nullptr : pin + boff[(size_t)c], lo, hi));
+      } catch (...) {
+        for (sqlrs_column_t &c : cols) {
+          std::free(const_cast<void *>(c.values));
+          std::free(const_cast<uint8_t *>(c.validity));
+        }
+        throw;
+      }
+      out[made] = emit_host_columns(ctx, std::move(cols), hi - lo);
+    }
+  } catch (...) {
+    for (int k = 0; k < made; k++) {
+      sqlrs_batch_release(out[k]);
+      out[k] = nullptr;
+    }
+    throw;
+  }
 }
 
 HostStage::~HostStage() {

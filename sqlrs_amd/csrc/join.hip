@@ -1467,15 +1467,17 @@ static bool semi_join_probe(sqlrs_hash_join *j, InBatch &ib, const NKeys &pk, DB
   return true;
 }
 
-static DBatch probe_batch(sqlrs_hash_join *j, InBatch &ib, Pairs *pairs_only) {
+// `also` (optional): the joined batch AND its pairs (probe_push_many cuts the batch at probe-row boundaries)
+static DBatch probe_batch(sqlrs_hash_join *j, InBatch &ib, Pairs *pairs_only, Pairs *also = nullptr) {
   Ctx *ctx = j->ctx;
   auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
   NKeys pk = eval_keys(ctx, j->rkeys, colfn, ib.rows());
-  if (!pairs_only) {
+  if (!pairs_only && !also) {
     DBatch semi;
     if (semi_join_probe(j, ib, pk, &semi)) return semi;
   }
   Pairs p = probe_pairs(j, pk);
+  if (also) *also = p;
   if (pairs_only) {
     *pairs_only = p;
     return DBatch();
@@ -1600,6 +1602,102 @@ int sqlrs_hash_join_probe_push(sqlrs_hash_join_t *j, const sqlrs_batch_t *right,
     InBatch ib(j->ctx, right);
     DBatch r = probe_batch(j, ib, nullptr);
     *out = emit_batch(j->ctx, std::move(r), out_mem);
+  });
+}
+
+} // extern "C"
+
+namespace sq {
+// cut[i] = pairs whose probe row (right[], ascending: pairs are probe-row major) lies before bounds[i]
+__global__ void pairs_before_kernel(const uint32_t *__restrict__ right, int64_t m, const int64_t *__restrict__ bounds, int64_t n,
+                                    int64_t *__restrict__ cut) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t b = bounds[i];
+  int64_t lo = 0, hi = m; // first pair with right >= b
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)right[mid] < b) lo = mid + 1;
+    else hi = mid;
+  }
+  cut[i] = lo;
+}
+} // namespace sq
+
+extern "C" {
+
+// n probe batches in one call: out[i] is what sqlrs_hash_join_probe_push(right[i]) returns [ref: hash_join.rs:207-292: one
+// joined batch per probe batch] — for the reference's batch shape, 1024-row HOST batches (storage/csv.rs:105), where one
+// upload + probe + download per batch is ~80 us a call (12 Mrows/s).  Inner / Left joins without a join filter whose
+// batches are small HOST batches of fixed-width columns (and whose joined columns are fixed width): the batches are
+// uploaded together and probed as ONE batch — the pairs come out probe-row major (hash_join.rs:225-234), so input batch
+// i's joined rows are one contiguous range, found by searching the pairs' probe rows for the batch boundaries — and
+// every range is handed out as a HOST batch of its own.  Anything else runs batch by batch.
+int sqlrs_hash_join_probe_push_many(sqlrs_hash_join_t *j, int n, const sqlrs_batch_t *const *right, int out_mem,
+                                    sqlrs_batch_t **out) {
+  return guard(j->ctx, [&] {
+    Ctx *ctx = j->ctx;
+    SQ_HIP(hipSetDevice(ctx->device));
+    if (!j->finished) fail(SQLRS_ERR_INTERNAL, "probe before build_finish");
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    if (n <= 0 || j->empty_build) return;
+    if (!j->probe_stage) {
+      j->probe_stage.reset(new HostStage());
+      j->probe_stage->ctx = ctx;
+    }
+    HostStage &st = *j->probe_stage;
+    bool stageable = out_mem == SQLRS_MEM_HOST && n > 1 && !j->has_filter && !st.has_schema &&
+                     (j->join_type == SQLRS_JOIN_INNER || j->join_type == SQLRS_JOIN_LEFT) && all_fixed_width(j->left);
+    int64_t total_rows = 0;
+    for (int i = 0; i < n && stageable; i++) {
+      stageable = st.accepts(right[i]) && right[i]->num_columns == right[0]->num_columns;
+      for (int c = 0; c < right[i]->num_columns && stageable; c++) stageable = right[i]->columns[c].dtype == right[0]->columns[c].dtype;
+      total_rows += right[i] ? right[i]->num_rows : 0;
+    }
+    if (!stageable || total_rows == 0 || total_rows > (1ll << 30)) {
+      int i = 0;
+      try {
+        for (; i < n; i++) {
+          InBatch ib(ctx, right[i]);
+          out[i] = emit_batch(ctx, probe_batch(j, ib, nullptr), out_mem);
+        }
+      } catch (...) {
+        for (int k = 0; k < i; k++) {
+          sqlrs_batch_release(out[k]);
+          out[k] = nullptr;
+        }
+        throw;
+      }
+      return;
+    }
+    std::vector<int64_t> bounds((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) {
+      st.append(right[i]);
+      bounds[(size_t)i + 1] = bounds[(size_t)i] + right[i]->num_rows;
+    }
+    sqlrs_batch_t *dev = st.take();
+    struct Rel {
+      sqlrs_batch_t *b;
+      ~Rel() { if (b) sqlrs_batch_release(b); }
+    } rel{dev};
+    Pairs p;
+    DBatch o;
+    {
+      InBatch ib(ctx, dev);
+      o = probe_batch(j, ib, nullptr, &p);
+    }
+    std::vector<int64_t> cut = bounds; // every probe row matched exactly once: pair i = probe row i
+    if (!p.right_identity) {
+      BufP dbounds = ctx->alloc(8 * ((size_t)n + 1)), dcut = ctx->alloc(8 * ((size_t)n + 1));
+      SQ_HIP(hipMemcpyAsync(dbounds->p, bounds.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+      pairs_before_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, ctx->stream>>>(
+          p.right->as<uint32_t>(), p.m, dbounds->as<int64_t>(), n + 1, dcut->as<int64_t>());
+      SQ_HIP(hipGetLastError());
+      SQ_HIP(hipMemcpyAsync(cut.data(), dcut->p, 8 * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();
+    }
+    if (!all_fixed_width(o)) fail(SQLRS_ERR_INTERNAL, "probe_push_many: joined columns are fixed width");
+    split_rows_to_host(ctx, o, cut, &j->pin_out, &j->pin_cap, n, out);
   });
 }
 

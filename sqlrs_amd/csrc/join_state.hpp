@@ -10,6 +10,12 @@
 struct sqlrs_hash_join {
   sq::Ctx *ctx = nullptr;
   sq::HostStage hstage; // small HOST build batches until one upload (host_stage.hpp)
+  std::unique_ptr<sq::HostStage> probe_stage; // sqlrs_hash_join_probe_push_many: the call's small HOST probe batches
+  void *pin_out = nullptr;                    // ... and where their joined rows land on the host (pinned)
+  size_t pin_cap = 0;
+  ~sqlrs_hash_join() {
+    if (pin_out) (void)hipHostFree(pin_out);
+  }
   int join_type = 0;
   std::vector<sq::Expr> lkeys, rkeys;
   bool has_filter = false;

@@ -165,40 +165,6 @@ __global__ void kept_before_kernel(const uint64_t *__restrict__ bits, const uint
   kept[i] = k;
 }
 
-// rows [lo, hi) of a HOST column image (values / validity of `rows_total` rows) as malloc'd blocks of their own
-static sqlrs_column_t slice_host_column(int32_t dtype, const uint8_t *vals, const uint8_t *validity, int64_t lo, int64_t hi) {
-  sqlrs_column_t c;
-  std::memset(&c, 0, sizeof(c));
-  const size_t w = width_of(dtype);
-  const int64_t n = hi - lo;
-  c.dtype = dtype;
-  c.mem = SQLRS_MEM_HOST;
-  c.length = n;
-  void *v = std::malloc(std::max<size_t>(w * (size_t)n, 8));
-  if (!v) fail(SQLRS_ERR_INTERNAL, "out of host memory");
-  if (n) std::memcpy(v, vals + w * (size_t)lo, w * (size_t)n);
-  c.values = v;
-  if (validity) {
-    int64_t nulls = 0;
-    uint8_t *vb = (uint8_t *)std::calloc((size_t)(n + 7) / 8 + 8, 1);
-    if (!vb) {
-      std::free(v);
-      fail(SQLRS_ERR_INTERNAL, "out of host memory");
-    }
-    for (int64_t r = 0; r < n; r++) {
-      const int64_t s = lo + r;
-      if ((validity[s >> 3] >> (s & 7)) & 1) vb[r >> 3] |= (uint8_t)(1u << (r & 7));
-      else nulls++;
-    }
-    if (nulls) {
-      c.validity = vb;
-      c.null_count = nulls;
-    } else {
-      std::free(vb);
-    }
-  }
-  return c;
-}
 } // namespace sq
 
 extern "C" {
@@ -279,60 +245,9 @@ int sqlrs_filter_push_many(sqlrs_filter_t *f, int n, const sqlrs_batch_t *const 
     SQ_HIP(hipGetLastError());
     std::vector<int64_t> kept((size_t)n + 1);
     SQ_HIP(hipMemcpyAsync(kept.data(), dkept->p, 8 * ((size_t)n + 1), hipMemcpyDeviceToHost, ctx->stream));
-    // the kept rows of all batches: one copy per column
-    const int nc = (int)o.cols.size();
-    size_t need = 0;
-    std::vector<size_t> voff((size_t)nc), boff((size_t)nc, (size_t)-1);
-    for (int c = 0; c < nc; c++) {
-      const DCol &col = o.cols[(size_t)c];
-      voff[(size_t)c] = need;
-      need += round_up(std::max<size_t>(width_of(col.dtype) * (size_t)o.rows, 8), 64);
-      if (col.validity && col.null_count != 0) {
-        boff[(size_t)c] = need;
-        need += round_up(bitmap_bytes(o.rows) + 8, 64);
-      }
-    }
-    if (need > f->pin_cap) {
-      if (f->pin_out) SQ_HIP(hipHostFree(f->pin_out));
-      f->pin_out = nullptr;
-      f->pin_cap = 0;
-      SQ_HIP(hipHostMalloc(&f->pin_out, need + need / 4, hipHostMallocDefault));
-      f->pin_cap = need + need / 4;
-    }
-    uint8_t *pin = (uint8_t *)f->pin_out;
-    for (int c = 0; c < nc; c++) {
-      const DCol &col = o.cols[(size_t)c];
-      const size_t w = width_of(col.dtype);
-      if (o.rows) SQ_HIP(hipMemcpyAsync(pin + voff[(size_t)c], col.values, w * (size_t)o.rows, hipMemcpyDeviceToHost, ctx->stream));
-      if (boff[(size_t)c] != (size_t)-1)
-        SQ_HIP(hipMemcpyAsync(pin + boff[(size_t)c], col.validity, bitmap_bytes(o.rows), hipMemcpyDeviceToHost, ctx->stream));
-    }
     ctx->sync();
-    int made = 0;
-    try {
-      for (; made < n; made++) {
-        const int64_t lo = kept[(size_t)made], hi = kept[(size_t)made + 1];
-        std::vector<sqlrs_column_t> cols;
-        try {
-          for (int c = 0; c < nc; c++)
-            cols.push_back(slice_host_column(o.cols[(size_t)c].dtype, pin + voff[(size_t)c],
-                                             boff[(size_t)c] == (size_t)-1 ? nullptr : pin + boff[(size_t)c], lo, hi));
-        } catch (...) {
-          for (sqlrs_column_t &c : cols) {
-            std::free(const_cast<void *>(c.values));
-            std::free(const_cast<uint8_t *>(c.validity));
-          }
-          throw;
-        }
-        out[made] = emit_host_columns(ctx, std::move(cols), hi - lo);
-      }
-    } catch (...) {
-      for (int k = 0; k < made; k++) {
-        sqlrs_batch_release(out[k]);
-        out[k] = nullptr;
-      }
-      throw;
-    }
+    if (!all_fixed_width(o)) fail(SQLRS_ERR_INTERNAL, "filter_push_many: staged columns are fixed width");
+    split_rows_to_host(ctx, o, kept, &f->pin_out, &f->pin_cap, n, out); // one copy per column, one slice per input batch
   });
 }
 

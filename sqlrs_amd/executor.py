@@ -102,8 +102,10 @@ class HashJoinExecutor:
 
     def __init__(self, backend: abi.Backend, left_child: Iterable, right_child: Iterable,
                  join_type: str, join_condition: JoinCondition, join_output_schema: pa.Schema,
-                 num_left_columns: int, out_mem: int = abi.MEM_HOST):
+                 num_left_columns: int, out_mem: int = abi.MEM_HOST, many: int = 0):
         self.backend = backend
+        # many > 1: that many probe batches go to sqlrs_hash_join_probe_push_many together (same stream of joined batches)
+        self.many = many
         self.left_child, self.right_child = left_child, right_child
         self.join_type, self.join_condition = join_type, join_condition
         self.join_output_schema = join_output_schema
@@ -138,6 +140,29 @@ class HashJoinExecutor:
                 b = abi.as_batch(batch)
                 be.check(be.fn("hash_join_build_push")(h, b.ptr))
             be.check(be.fn("hash_join_build_finish")(h))
+            if self.many > 1 and not indices_only and getattr(be.lib, be.prefix + "hash_join_probe_push_many", None) is not None:
+                group = []
+
+                def flush():
+                    n = len(group)
+                    hb = [abi.as_batch(b) for b in group]
+                    ins = (C.POINTER(abi.Batch) * n)(*[C.pointer(b.abi) if hasattr(b, "abi") else b.ptr for b in hb])
+                    outs = (C.POINTER(abi.Batch) * n)()
+                    be.check(be.fn("hash_join_probe_push_many")(h, n, ins, self.out_mem, outs))
+                    group.clear()
+                    return [r for r in (_emit(be, outs[i], self.out_mem, names) for i in range(n)) if r is not None]
+                for batch in self.right_child:
+                    group.append(batch)
+                    if len(group) == self.many:
+                        yield from flush()
+                if group:
+                    yield from flush()
+                out = C.POINTER(abi.Batch)()  # tail, hash_join.rs:296-322
+                be.check(be.fn("hash_join_finish")(h, self.out_mem, C.byref(out)))
+                r = _emit(be, out, self.out_mem, names)
+                if r is not None:
+                    yield r
+                return
             for batch in self.right_child:  # probe phase, hash_join.rs:207-292
                 b = abi.as_batch(batch)
                 out = C.POINTER(abi.Batch)()

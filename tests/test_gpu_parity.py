@@ -1380,7 +1380,7 @@ def test_filter_push_many_yields_the_batches_of_push(hip, oracle, shape):
         if shape == "with_nulls":
             cols = [pa.array(v, mask=rng.random(n) < 0.2), pa.array(w, mask=rng.random(n) < 0.1)]
         elif shape == "utf8_falls_back":
-            cols = [pa.array(v), pa.array([f"s{int(x * 100)}" for x in w])]
+            cols = [pa.array(v), pa.array([f"s{int(x * 100)}" for x in w], type=pa.string())]
         else:
             cols = [pa.array(v), pa.array(w)]
         batches.append(pa.RecordBatch.from_arrays(cols, names=["v", "w"]))
@@ -1391,6 +1391,31 @@ def test_filter_push_many_yields_the_batches_of_push(hip, oracle, shape):
     exp = list(FilterExecutor(oracle, expr, batches).execute())
     for many in (5, 64):
         got = list(FilterExecutor(hip, expr, batches, many=many).execute())
+        assert [b.num_rows for b in got] == [b.num_rows for b in exp]
+        for g, e in zip(got, exp):
+            assert g.equals(e), (many, g.num_rows)
+
+
+@pytest.mark.parametrize("jt", ["inner", "left", "right"])
+@pytest.mark.parametrize("build", ["unique_all_hit", "unique_some_miss", "duplicates", "with_filter"])
+def test_hash_join_probe_push_many_yields_the_batches_of_probe_push(hip, oracle, jt, build):
+    """sqlrs_hash_join_probe_push_many: small HOST probe batches (csv.rs:105) probed together must come back as exactly
+    the joined batches sqlrs_hash_join_probe_push yields one by one (hash_join.rs:207-292), batch boundaries included —
+    Inner / Left take the grouped route, Right joins and join filters fall back to batch by batch; against the oracle."""
+    rng = np.random.default_rng(len(jt) * 7 + len(build))
+    nb = 3000
+    bk = rng.permutation(nb).astype(np.int64) if build != "duplicates" else rng.integers(0, nb // 3, nb, dtype=np.int64)
+    lb = pa.RecordBatch.from_arrays([pa.array(bk), pa.array(bk * 3 + 1)], names=["k", "p"])
+    sizes = [0, 1, 63, 64, 65, 1024, 1024, 1, 0, 4095, 4097, 1024, 7, 20_000, 1024, 0, 3]
+    hi = nb if build == "unique_all_hit" else int(nb * 1.3)
+    rbs = [pa.RecordBatch.from_arrays([pa.array(rng.integers(0, hi, n, dtype=np.int64)), pa.array(rng.random(n))], names=["k", "v"])
+           for n in sizes]
+    filt = (InputRef(1) > InputRef(2)) if build == "with_filter" else None
+    cond = JoinCondition([(InputRef(0), InputRef(0))], filt)
+    sch = join_schema(lb, rbs[0])
+    exp = list(HashJoinExecutor(oracle, [lb], rbs, jt, cond, sch, 2).execute())
+    for many in (4, 64):
+        got = list(HashJoinExecutor(hip, [lb], rbs, jt, cond, sch, 2, many=many).execute())
         assert [b.num_rows for b in got] == [b.num_rows for b in exp]
         for g, e in zip(got, exp):
             assert g.equals(e), (many, g.num_rows)
