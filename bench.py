@@ -270,6 +270,7 @@ def check_groups(torch, dist, dev, out, exp_cnt, exp_sum, has_dim, key_of=None):
 # algorithmic HBM bytes per launch of the kernels that can dominate
 def algorithmic_bytes(kernel, w):
     nP, nB, s, M, G = w["fact_rows"], w["dim_rows"], w["selectivity"], w["matches"], w["groups"]
+    rec = 16 if os.environ.get("SQLRS_RP_SLIM") == "0" else 12
     table = {
         "filter_cmp_const": 8 * nP + 8 * s * nP,            # read predicate column, write kept values
         "compact": 8 * nP + 8 * s * nP,                     # second column through the same selection
@@ -280,11 +281,12 @@ def algorithmic_bytes(kernel, w):
         "agg_update": 12 * M,                               # group id + value read per row
         "join_build": 8 * nB,
         "join_probe_unique": 8 * s * nP + 12 * M,           # one pass: keys read, pairs written
-        "rp_scatter": 32 * M,                               # packed (key|row, val) 16 B read + 16 B written
-        "rp_chunk_scatter_filter": 16 * nP + 16 * M,        # key + val of every row read, kept rows written once
-        "rp_chunk_scatter": 32 * M,
+        # (rec = bytes of a partitioned row: 12 in the slim form — value + 32-bit word, radix_part.hip — 16 with SQLRS_RP_SLIM=0)
+        "rp_scatter": 2 * rec * M,                          # partitioned rows read + written
+        "rp_chunk_scatter_filter": 16 * nP + rec * M,       # key + val of every row read, kept rows written once
+        "rp_chunk_scatter": 16 * M + rec * M,
         "rp_hist": 8 * M,
-        "lds_agg": 16 * M + 28 * G,                         # partitioned rows read, groups written
+        "lds_agg": rec * M + 28 * G,                        # partitioned rows read, groups written
         "normalize_keys": 16 * M,
     }
     return table.get(kernel)
@@ -879,7 +881,7 @@ def pmc_traffic(kernel, n_fact, n_dim, world, args):
         return None, None
     try:
         import glob
-        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+        newest = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")) if "_ops_" not in f)[-1]
         with open(newest) as f:
             v = json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
         return v, (f"profiles/{os.path.basename(newest)} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
@@ -1270,6 +1272,25 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
                                       "GBps": round(by / ms_w / 1e6, 1), "frac": round(by / ms_w / 1e6 / HBM_PEAK_GBPS, 4),
                                       "check": "OK" if ok_w and g_w == G else "mismatch"}
     del val2, qty, bw
+    # ---- what a MISS of the optimistic key statistics costs (review r03 #9): two keys far outside the range of the others,
+    #      hidden in 6144-row chunks the sample does not read.  They go to the outlier list (row route, radix_part.hpp
+    #      key_out_of_range) instead of failing the attempt; `ms_exact` = the same batch with the statistics from a full pass
+    #      (SQLRS_KEY_STATS_EXACT=1, read per call), `ms_plain` = the batch without the outliers
+    if "C4_agg" in res:
+        saved = key[[3 * 6144 + 17, 11 * 6144 + 5]].clone()
+        key[3 * 6144 + 17] = 10 ** 12
+        key[11 * 6144 + 5] = -(10 ** 12)
+        torch.cuda.synchronize()
+        ms_out = timed(run_agg)
+        g_out = groups[0]
+        os.environ["SQLRS_KEY_STATS_EXACT"] = "1"
+        ms_exact = timed(run_agg)
+        os.environ.pop("SQLRS_KEY_STATS_EXACT", None)
+        key[3 * 6144 + 17], key[11 * 6144 + 5] = saved[0], saved[1]
+        torch.cuda.synchronize()
+        res["C4_agg_outlier_keys"] = {"rows": n, "groups": g_out, "ms": round(ms_out, 3), "ms_exact": round(ms_exact, 3),
+                                      "ms_plain": res["C4_agg"]["ms"], "ratio_to_exact": round(ms_out / ms_exact, 3),
+                                      "check": "OK" if g_out == res["C4_agg"]["groups"] + 2 else f"groups {g_out}"}
     # ---- C4 with Zipf(1.1) keys over the same 1e6 groups (hot groups: contention / bucket skew)
     import numpy as _np
     w = _np.arange(1, G + 1, dtype=_np.float64) ** -1.1
@@ -1332,6 +1353,20 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     by = 16 * n + 16 * n  # read key + carried column, write both permuted (SURVEY.md §8d minimum)
     res["Order_int64_1col"] = {"rows": n, "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
                                "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    # ---- what a MISS of the optimistic key range costs (review r03 #9): one key far outside the sampled range in a chunk the
+    #      sample skips; the raw pass's histogram kernel notices, the split passes behind it return at once, the exact form
+    #      runs.  `ms_exact` = the same column with SQLRS_ORDER_SAMPLE=0 (read per call: key range from a full pass)
+    saved1 = v1[5 * 2048 + 3].clone()
+    v1[5 * 2048 + 3] = (1 << 40) + 5
+    torch.cuda.synchronize()
+    ms_out = timed(run_order)
+    os.environ["SQLRS_ORDER_SAMPLE"] = "0"  # (read per call: the exact min / max pass)
+    ms_exact = timed(run_order)
+    os.environ.pop("SQLRS_ORDER_SAMPLE", None)
+    v1[5 * 2048 + 3] = saved1
+    torch.cuda.synchronize()
+    res["Order_outlier_in_unsampled_chunk"] = {"rows": n, "ms": round(ms_out, 3), "ms_exact": round(ms_exact, 3),
+                                               "ms_plain": res["Order_int64_1col"]["ms"], "ratio_to_exact": round(ms_out / ms_exact, 3)}
     # ---- ORDER BY v1 LIMIT 100 — PhysicalLimit(PhysicalOrder(scan)): offset + limit handed to the sort (sqlrs_order_set_limit),
     #      which sorts the candidates below a sampled threshold only; checked against torch.topk on the same column
     K = 100

@@ -395,9 +395,12 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     // first probe of all LDS_U rows: the table reads are independent and issue together
     uint32_t slot[LDS_U];
     unsigned long long seen[LDS_U];
+    uint32_t sentinel = 0; // bit u: row u carries the sentinel offset (its key lay outside the packed range: an outlier that
+                           // went to the overflow list, radix_part.hpp key_out_of_range) — not a key of this bucket
     if (PACK) {
 #pragma unroll
       for (int u = 0; u < LDS_U; u++) {
+        if (!JOIN && packed_off(kp, cur.k[u]) == kp.kmask) sentinel |= 1u << u;
         cur.id[u] = packed_row(kp, cur.k[u]);
         cur.k[u] = packed_key(kp, cur.k[u]);
       }
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
     }
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
-      bool act = i0 + (int64_t)u * PART_WG < hi; // this lane's row contributes to slot s
+      bool act = i0 + (int64_t)u * PART_WG < hi && !((sentinel >> u) & 1u); // this lane's row contributes to slot s
       const uint64_t key = cur.k[u];
       uint32_t s = slot[u];
       unsigned long long c = seen[u];
@@ -1114,8 +1117,10 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   const bool join_mode = in.join_keys != nullptr;
   uint64_t omin = ~0ull, omax = 0; // signed-order image of the smallest / largest key of interest
   bool sampled = false; // omin / omax are a sample's (widened below): rows are packed optimistically
+  const char *kse = std::getenv("SQLRS_KEY_STATS_EXACT"); // measurement hook, read per call: 1 = key statistics from a full pass
+  const bool stats_exact_env = kse && kse[0] == '1';
   double est = join_mode ? (double)in.join_n
-                         : estimate_distinct(ctx, in.keys, in.key_validity, n, &omin, &omax, in.exact_stats ? nullptr : &sampled);
+                         : estimate_distinct(ctx, in.keys, in.key_validity, n, &omin, &omax, (in.exact_stats || stats_exact_env) ? nullptr : &sampled);
   BufP ctr = ctx->alloc_zero(48); // {groups, overflow rows, join failure, split-table full, key outside the sampled range}
   if (sampled && omin <= omax) {
     // widen the sampled range: an eighth of its width (and at least 64 Ki values) on either side
@@ -1158,7 +1163,13 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
         kp.kbits = kbits;
         kp.kmask = (1ull << kbits) - 1;
         kp.kmin = omin ^ (1ull << 63);
-        if (sampled) kp.oob = (unsigned int *)(ctr->as<uint64_t>() + 4);
+        if (sampled) { // keys outside the sampled range: outlier list (= the overflow rows of the bucket pass), a full list = rerun
+          kp.oob = (unsigned int *)(ctr->as<uint64_t>() + 4);
+          out->ov_rows = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
+          kp.ov_rows = out->ov_rows->as<uint32_t>();
+          kp.ov_count = ctr->as<unsigned long long>() + 1;
+          kp.ov_cap = (uint32_t)std::min<int64_t>(n, std::max<int64_t>(65536, n / 1024));
+        }
       }
     }
   }
@@ -1437,7 +1448,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   out->gvalid = in.key_validity ? ctx->alloc((size_t)gcap) : nullptr;
   out->gacc = ctx->alloc(8 * (size_t)gcap * (size_t)std::max(spec.n_acc, 1));
   out->gcap = gcap;
-  out->ov_rows = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
+  if (!out->ov_rows) out->ov_rows = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1)); // (n: rows that passed the fused filter)
   {
     ProfScope ps(ctx, "lds_agg");
 #define SQ_LA(NV, FL, JN, NA, C0, C1, PK)                                                                        \

@@ -1184,6 +1184,8 @@ struct sqlrs_join_agg {
   // the partial rows by the requested columns: COUNT -> SUM of the counts, SUM / MIN / MAX of the partials.  `outer`
   // sees the partial groups in first-seen order, so its own first-seen order is the operator's (hash_agg.rs:98).
   bool eager_possible = false, eager_decided = false, eager = false;
+  bool remapped_key = false; // a GROUP BY on the probe-side join key was redirected to the build-side key column
+  int lkey_col = -1, rkey_col = -1;
   sqlrs_hash_agg *inner = nullptr, *outer = nullptr;
   std::vector<int> group_cols; // build-side column of each GROUP BY expression
   int64_t eager_groups = 0;    // partial groups (distinct join keys) the last finish() re-aggregated
@@ -1205,10 +1207,15 @@ static void join_agg_plan_eager(sqlrs_join_agg *ja, int num_keys, const sqlrs_ex
       left_keys[0].nodes[0].op != SQLRS_EXPR_INPUT_REF || right_keys[0].nodes[0].op != SQLRS_EXPR_INPUT_REF)
     return;
   const int lc = left_keys[0].nodes[0].index, rc = right_keys[0].nodes[0].index;
+  ja->lkey_col = lc;
+  ja->rkey_col = rc;
   for (int g = 0; g < num_group_by; g++) {
     if (group_by[g].num_nodes != 1 || group_by[g].nodes[0].op != SQLRS_EXPR_INPUT_REF) return;
     int idx = group_by[g].nodes[0].index;
-    if (idx == ja->nleft + rc) idx = lc; // the probe-side join key: equal to the build side's in every joined row (exactly compared)
+    if (idx == ja->nleft + rc) { // the probe-side join key: equal to the build side's in every joined row (exactly compared) —
+      idx = lc;                  // bit for bit only for integer keys of ONE type (checked against the build column at the
+      ja->remapped_key = true;   // first batch; -0.0 / 0.0 and int32 / int64 pairs keep the composed route)
+    }
     if (idx < 0 || idx >= ja->nleft) return;
     ja->group_cols.push_back(idx);
   }
@@ -1287,7 +1294,14 @@ static int join_agg_process(sqlrs_join_agg_t *ja, const sqlrs_batch_t *right, bo
     if (j->empty_build) return; // the join emits nothing (hash_join.rs:183-185)
     if (!ja->eager_decided) { // once, at the first batch: eager aggregation needs unique, exactly compared build keys
       ja->eager_decided = true;
-      if (ja->eager_possible && j->exact && right->num_rows >= (1ll << 16)) {
+      bool same_int_key = true; // (advisor, round 3: the output column would take the build column's type and bits)
+      if (ja->remapped_key) {
+        const int lc = ja->lkey_col, rc = ja->rkey_col;
+        const int32_t ld = (lc >= 0 && lc < (int)j->left.cols.size()) ? j->left.cols[(size_t)lc].dtype : SQLRS_NULLTYPE;
+        const int32_t rd = (rc >= 0 && rc < right->num_columns) ? right->columns[rc].dtype : SQLRS_NULLTYPE;
+        same_int_key = ld == rd && (ld == SQLRS_INT64 || ld == SQLRS_INT32 || ld == SQLRS_UINT64 || ld == SQLRS_UINT32);
+      }
+      if (ja->eager_possible && same_int_key && j->exact && right->num_rows >= (1ll << 16)) {
         hash_join_ensure_table(j); // (establishes `unique` when the direct-address table did not)
         ja->eager = j->unique && j->unique_known;
       }

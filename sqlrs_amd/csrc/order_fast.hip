@@ -226,7 +226,11 @@ __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restric
                                                            int64_t n, int desc, uint64_t imin, int shift, int64_t nblocks,
                                                            const uint32_t *__restrict__ offsets,
                                                            uint64_t *__restrict__ words_out, uint64_t *__restrict__ pay_out,
-                                                           const OwTile *__restrict__ tiles) {
+                                                           const OwTile *__restrict__ tiles,
+                                                           const unsigned int *__restrict__ abort_flag = nullptr) {
+  // (optimistic key range: the raw pass's histogram kernel has already seen every key; once it raised the flag, nothing
+  //  this attempt produces is used — a miss then costs that histogram pass, not the two split passes behind it)
+  if (abort_flag && *abort_flag) return;
   __shared__ uint64_t sword[OW_TILE];
   __shared__ uint64_t spay[NPAY ? OW_TILE : 1];
   __shared__ uint32_t wcnt[OW_WAVES][256];
@@ -618,13 +622,13 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
       exclusive_scan_u32(ctx, hist2->as<uint32_t>(), 256 * ntmax, nullptr, offs2->as<uint32_t>(), total->as<uint64_t>());
       if (use_rec) {
         ow_scatter_kernel<KIND, false, NPAY, true, NPAY == 1><<<g2, b, 0, ctx->stream>>>(
-            src, psrc, n, desc, imin, shift, ntmax, offs2->as<uint32_t>(), recbuf->as<uint64_t>(), nullptr, tp);
+            src, psrc, n, desc, imin, shift, ntmax, offs2->as<uint32_t>(), recbuf->as<uint64_t>(), nullptr, tp, oob);
         src = recbuf->p;
         psrc = nullptr;
         rec_form = true;
       } else {
         ow_scatter_kernel<KIND, false, NPAY, true, false><<<g2, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, ntmax,
-                                                                                    offs2->as<uint32_t>(), wdst, pdst, tp);
+                                                                                    offs2->as<uint32_t>(), wdst, pdst, tp, oob);
         src = wdst;
         psrc = pdst;
       }
@@ -636,8 +640,8 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     else ow_hist_kernel<KIND, false><<<g, b, 0, ctx->stream>>>(src, n, desc, imin, shift, nblocks, hist->as<uint32_t>(), nullptr);
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(), total->as<uint64_t>());
-    if (raw) ow_scatter_kernel<KIND, true, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst, nullptr);
-    else ow_scatter_kernel<KIND, false, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst, nullptr);
+    if (raw) ow_scatter_kernel<KIND, true, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst, nullptr, oob);
+    else ow_scatter_kernel<KIND, false, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst, nullptr, oob);
     SQ_HIP(hipGetLastError());
     src = wdst;
     psrc = pdst;

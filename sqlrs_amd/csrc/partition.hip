@@ -400,7 +400,9 @@ extern "C" int sqlrs_hash_partition_filter(sqlrs_ctx_t *ctx, const sqlrs_batch_t
     const int nc = ib.num_columns();
     // fused one-pass path: <= 3 carried 8-byte columns without NULLs, the key is one of them, the predicate is
     // `column OP constant` over an int64 / float64 column without NULLs (any column of the batch)
-    bool fast = n >= (1 << 16) && n <= 0xffffffffll && nc >= 1 && nc <= 3 && e.nodes.size() == 1 &&
+    // (DEVICE consumers only: the region layout is num_parts x the input's size with uninitialised padding between the
+    //  partitions — a HOST copy would move all of it; HOST output takes Filter + stable partition, contiguous partitions)
+    bool fast = out_mem == SQLRS_MEM_DEVICE && n >= (1 << 16) && n <= 0xffffffffll && nc >= 1 && nc <= 3 && e.nodes.size() == 1 &&
                 e.nodes[0].op == SQLRS_EXPR_INPUT_REF && e.nodes[0].index >= 0 && e.nodes[0].index < nc;
     for (int c = 0; fast && c < nc; c++) {
       const DCol &col = ib.col(c);

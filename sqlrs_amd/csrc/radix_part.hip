@@ -690,7 +690,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
   SlimCur<RP_ROWS> cur;
   uint32_t dr[RP_ROWS]; // digit << 16 | rank inside the tile's run of that digit; ~0 = row not kept
   uint32_t cur_tile = 0;
-  auto take_rows = [&](uint32_t len) { // nxt (as loaded) -> cur
+  auto take_rows = [&](uint32_t len, uint32_t nxt_tile) { // nxt (as loaded: tile `nxt_tile`) -> cur
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
       bool keep = (uint32_t)(j * RP_WG) + threadIdx.x < len;
@@ -698,7 +698,8 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
       if (PSRC == 3) keep = keep && row_passes(flt, nxt.pv[PSRC == 3 ? j : 0]);
       const uint64_t off = nxt.k[j] - kp.kmin;
       if (keep && off > kp.range) { // no bucket of the range partition holds this key: the row has no group / no partner
-        if (kp.oob) *kp.oob = 1u;   // (optimistically sampled range: the caller reruns with the exact one)
+        // (optimistically sampled range: the row goes to the outlier list / the caller reruns with the exact range)
+        if (kp.oob) key_out_of_range(kp, (uint32_t)((int64_t)nxt_tile * RP_TILE + (uint32_t)(j * RP_WG) + threadIdx.x));
         keep = false;
       }
       cur.off[j] = keep ? (uint32_t)off : 0xffffffffu;
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
     cur_tile = t0;
     rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(t0), len, nxt);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-    take_rows(len);
+    take_rows(len, t0);
     cnt[threadIdx.x] = 0;
     __syncthreads();
 #pragma unroll
@@ -819,7 +820,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
     cur_tile = tcur;
     rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(tcur), len, nxt);
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    take_rows(len);
+    take_rows(len, tcur);
     for (uint32_t ti = t0 + 1; ti < t1; ti++) {
       const uint32_t tnext = min(ti + 1, t1 - 1);
       const uint32_t nlen = tile_len(tnext);
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
       __syncthreads();
       scan_and_stage();
       staged_len = s_total;
-      take_rows(nlen);
+      take_rows(nlen, tnext);
       cur_tile = tnext;
     }
 #pragma unroll

@@ -25,13 +25,35 @@ struct KeyPack {
   // key lies outside [kmin, kmin + kmask) — the caller then discards the result and reruns with the exact range.
   // null = out-of-range keys are expected (fused join: no partner) or impossible (exact range).
   unsigned int *oob = nullptr;
+  // ... unless the outliers are few: with `ov_rows` set, a row whose key lies outside the range is appended to that list
+  // (local row ids; *ov_count rows so far, capacity ov_cap) and takes the caller's row route like a row that did not fit
+  // its bucket table — an outlier the sample missed costs its own handling, not a second run; only a list that fills
+  // up raises *oob
+  unsigned long long *ov_count = nullptr;
+  uint32_t *ov_rows = nullptr;
+  uint32_t ov_cap = 0;
 };
 #if defined(__HIPCC__)
+// a row whose key the (sampled) range does not cover: onto the outlier list, one atomic per wave; a full list -> *oob
+__device__ __forceinline__ void key_out_of_range(const KeyPack &kp, uint32_t row) {
+  if (!kp.ov_rows) {
+    *kp.oob = 1u; // (a plain store, any number of writers)
+    return;
+  }
+  const unsigned long long peers = __ballot(1); // the lanes that are here with an outlier of their own
+  const int leader = __builtin_ctzll(peers);
+  unsigned long long base = 0;
+  if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(kp.ov_count, (unsigned long long)__popcll(peers));
+  base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader, 64) << 32) | (unsigned)__shfl((int)base, leader, 64);
+  const unsigned long long at = base + (unsigned long long)__popcll(peers & ((1ull << (threadIdx.x & 63)) - 1ull));
+  if (at < kp.ov_cap) kp.ov_rows[at] = row;
+  else *kp.oob = 1u;
+}
 __device__ __forceinline__ uint64_t pack_key_row(const KeyPack &kp, uint64_t key, uint32_t row) {
   uint64_t off = key - kp.kmin;
-  // (uniform null test; a plain store, any number of writers.  Range partitions: an offset between the range and
-  //  the sentinel has no bucket of its own either — it would alias a slot of the last bucket)
-  if (kp.oob && (off >= kp.kmask || (kp.dense && off > kp.range))) *kp.oob = 1u;
+  // (uniform null test.  Range partitions: an offset between the range and the sentinel has no bucket of its own
+  //  either — it would alias a slot of the last bucket)
+  if (kp.oob && (off >= kp.kmask || (kp.dense && off > kp.range))) key_out_of_range(kp, row);
   return (off < kp.kmask ? off : kp.kmask) | ((uint64_t)row << kp.kbits);
 }
 __device__ __forceinline__ uint64_t packed_key(const KeyPack &kp, uint64_t w) { return (w & kp.kmask) + kp.kmin; }
