@@ -49,6 +49,35 @@ fn agg_schema(group_by: &[BoundExpr], aggs: &[BoundAggFunc], input: &RecordBatch
 
 // ------------------------------------------------------------------ Filter --
 pub struct HipFilterExecutor { pub ctx: Arc<HipCtx>, pub expr: BoundExpr, pub child: BoxedExecutor }
+/// The same operator pulling `group` batches of its child at a time and handing them to `sqlrs_filter_push_many`: the same
+/// stream of output batches (one per input batch, filter.rs:15-24) at one upload / launch sequence / download per GROUP —
+/// 1024-row CSV batches (storage/csv.rs:105): 23 -> 934 Mrows/s from a native caller.
+pub struct HipFilterManyExecutor { pub ctx: Arc<HipCtx>, pub expr: BoundExpr, pub child: BoxedExecutor, pub group: usize }
+impl HipFilterManyExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let expr = lower(&self.expr)?;
+        let mut f = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_filter_create(self.ctx.raw(), &expr.abi(), &mut f) })?;
+        let _g = Guard(f, sqlrs_filter_destroy);
+        let mut pending: Vec<RecordBatch> = Vec::with_capacity(self.group);
+        let mut child = self.child;
+        loop {
+            let next = futures::StreamExt::next(&mut child).await;
+            if let Some(b) = next { pending.push(b?); }
+            let end = pending.len() < self.group || self.group == 0;
+            if pending.len() == self.group.max(1) || (end && !pending.is_empty()) {
+                let views: Vec<AbiBatch> = pending.iter().map(AbiBatch::new).collect::<Result<_, _>>()?;
+                let ins: Vec<*const sqlrs_batch_t> = views.iter().map(|v| &v.raw as *const _).collect();
+                let mut outs: Vec<*mut sqlrs_batch_t> = vec![std::ptr::null_mut(); ins.len()];
+                self.ctx.check(unsafe { sqlrs_filter_push_many(f, ins.len() as i32, ins.as_ptr(), SQLRS_MEM_HOST, outs.as_mut_ptr()) })?;
+                for (b, o) in pending.iter().zip(outs) { yield import_batch(b.schema(), o)?; }
+                pending.clear();
+            }
+            if end { break; }
+        }
+    }
+}
 impl HipFilterExecutor {
     #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
     pub async fn execute(self) {

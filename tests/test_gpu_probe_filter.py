@@ -232,8 +232,9 @@ def test_hash_agg_column_form_hook(hip, oracle, dense, monkeypatch):
     assert_same(got, exp, float_cols={2})
 
 
-@pytest.mark.parametrize("hooks", ["default", "long_tile_ranges_early_closes", "one_workgroup", "off"])
-@pytest.mark.parametrize("pred", ["val_gt_half", "other_ne", "key_ge"])
+@pytest.mark.parametrize("hooks,pred", [("default", "val_gt_half"), ("default", "other_ne"), ("default", "key_ge"),
+                                        ("long_tile_ranges_early_closes", "val_gt_half"), ("long_tile_ranges_early_closes", "key_ge"),
+                                        ("one_workgroup", "other_ne"), ("off", "val_gt_half")])
 def test_chunked_slim_records(hip, oracle, hooks, pred, monkeypatch):
     """Slim records (radix_part.hip): 12-byte rows {value, slot | row-in-tile | tile delta} through both partition levels
     and the bucket pass, row ids rebuilt from the chunk / run tables — the groups' first-seen order (hash_agg.rs:87-99)
