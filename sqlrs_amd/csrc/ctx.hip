@@ -426,6 +426,31 @@ void HostStage::append(const sqlrs_batch_t *b) {
     has_schema = true;
   }
   const int64_t n = b->num_rows;
+  // every column's room first, then the copies: a failed pinned allocation leaves the stage as it was (no column has
+  // taken the batch while `rows` has not advanced; advisor, round 3)
+  for (int i = 0; i < b->num_columns && n > 0; i++) {
+    Col &d = cols[(size_t)i];
+    const size_t w = width_of(b->columns[i].dtype), add = w * (size_t)n;
+    if (!d.pin && rows + n < HOST_STAGE_PIN_ROWS) {
+      d.vals.reserve(d.vals.size() + add);
+      continue;
+    }
+    const size_t have = d.pin ? d.pin_size : d.vals.size();
+    if (have + add > d.pin_cap) { // grow (doubling, at least 2^20 rows' worth): pinned blocks are kept across flushes
+      size_t cap = std::max<size_t>(d.pin_cap * 2, w << 20);
+      while (cap < have + add) cap *= 2;
+      void *np = nullptr;
+      SQ_HIP(hipHostMalloc(&np, cap, hipHostMallocDefault));
+      if (have) std::memcpy(np, d.pin ? d.pin : d.vals.data(), have);
+      uint8_t *old_pin = d.pin;
+      d.pin = (uint8_t *)np;
+      d.pin_cap = cap;
+      d.pin_size = have;
+      d.vals.clear();
+      d.vals.shrink_to_fit();
+      if (old_pin) (void)hipHostFree(old_pin);
+    }
+  }
   for (int i = 0; i < b->num_columns && n > 0; i++) {
     const sqlrs_column_t &c = b->columns[i];
     Col &d = cols[(size_t)i];
@@ -435,20 +460,7 @@ void HostStage::append(const sqlrs_batch_t *b) {
     if (!d.pin && rows + n < HOST_STAGE_PIN_ROWS) {
       d.vals.insert(d.vals.end(), src, src + add);
     } else {
-      const size_t have = d.pin ? d.pin_size : d.vals.size();
-      if (have + add > d.pin_cap) { // grow (doubling, at least 2^20 rows' worth): pinned blocks are kept across flushes
-        size_t cap = std::max<size_t>(d.pin_cap * 2, w << 20);
-        while (cap < have + add) cap *= 2;
-        void *np = nullptr;
-        SQ_HIP(hipHostMalloc(&np, cap, hipHostMallocDefault));
-        if (have) std::memcpy(np, d.pin ? d.pin : d.vals.data(), have);
-        if (d.pin) SQ_HIP(hipHostFree(d.pin));
-        d.pin = (uint8_t *)np;
-        d.pin_cap = cap;
-        d.pin_size = have;
-        d.vals.clear();
-        d.vals.shrink_to_fit();
-      } else if (!d.pin_size && !d.vals.empty()) { // (a kept buffer, values still in the vector: cannot happen, kept for safety)
+      if (!d.pin_size && !d.vals.empty()) { // (a kept buffer, values still in the vector: cannot happen, kept for safety)
         std::memcpy(d.pin, d.vals.data(), d.vals.size());
         d.pin_size = d.vals.size();
         d.vals.clear();
