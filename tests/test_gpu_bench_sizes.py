@@ -244,6 +244,61 @@ def test_full_size_c5_pipeline(env):
     env.be.fn("ctx_pool_trim")(env.be.ctx)
 
 
+@pytest.mark.parametrize("shape", ["sorted_keys", "hot_digit", "skewed", "every_row_passes", "few_rows_pass", "keys_beyond_the_dim"])
+def test_slim_records_at_scale(env, shape):
+    """The slim-record route (radix_part.hip) with the 8192-row tiles it takes from 2^28 rows on, on inputs that bend its
+    bookkeeping: sorted keys (a tile is ONE digit: chunks fill and spill every tile, every other digit's chunk is closed
+    early over and over), one hot digit (most rows in 1/23 of the key range: split bucket work items, long chunk lists),
+    skewed keys (hot slots, split buckets), a predicate that keeps everything / almost nothing (full staging area / runs of a row or two),
+    and probe keys far beyond the build range (dropped by level 1).  Every group against torch (COUNT bit-exact,
+    SUM 1e-9), groups in first-seen order, and the route really is the slim one."""
+    t, abi, d = env.torch, env.abi, env.datagen
+    n_fact, n_dim = (1 << 28) + 12_345, 3_000_000
+    fk, fv, dk = gen_c5(env, n_fact, n_dim)
+    thr = 0.5
+    if shape == "sorted_keys":
+        fk = t.sort(fk).values
+    elif shape == "hot_digit":
+        hot = (fv * 7919.0).frac() < 0.9  # (a second stream of pseudo-random bits: independent of the predicate on fv > 0.5)
+        fk = t.where(hot, 1_000_000 + fk % 100_000, fk)
+    elif shape == "skewed":
+        # key = floor(u^2 * n_dim): density ~ 1 / sqrt(key), the hottest keys carry ~1e5 rows each, the buckets of the low
+        # key range several times the average (split work items).  (Zipf keys are C4's leg: the expectation below — torch
+        # index_add_ of doubles — crawls when 8 % of the rows hit one address)
+        u = d.fill_chunks(t.empty(n_fact, dtype=t.float64, device=env.dev), lambda i: d.val_t(0xA7, i))
+        fk = (u * u * n_dim).to(t.int64).clamp_(max=n_dim - 1)
+        del u
+    elif shape == "every_row_passes":
+        thr = -1.0
+    elif shape == "few_rows_pass":
+        thr = 0.9995
+    elif shape == "keys_beyond_the_dim":
+        fk = fk * 3  # two thirds of the probe rows have no build partner, up to 3x the build key range
+    t.cuda.synchronize()
+    n_keys = int(fk.max().item()) + 1
+    exp_cnt, exp_sum, has_dim, kept = env.bench.expected_groups(t, None, fk, fv, dk, thr, max(n_keys, n_dim))
+    pipe = env.bench.Pipeline(env.be, abi, thr, fused=True)
+    env.be.profile(True)
+    out = pipe.step(env.bench.device_batch(abi, [dk], [abi.INT64]), env.bench.device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64]))
+    env.be.synchronize()
+    prof = env.be.profile_read()
+    env.be.profile(False)
+    assert pipe.fused_batches == 1 and pipe.filter_fused_batches == 1
+    assert prof.get("rp_slim_runs", (0, 0))[1] > 0, prof  # the slim route ran
+    ok, groups, rows, msg = env.bench.check_groups(t, None, env.dev, out, exp_cnt, exp_sum, has_dim)
+    assert ok, msg
+    first = t.full((max(n_keys, n_dim),), 1 << 62, dtype=t.int64, device=env.dev)
+    for lo in range(0, n_fact, 1 << 27):
+        k, v = fk[lo:lo + (1 << 27)], fv[lo:lo + (1 << 27)]
+        m = v > thr
+        first.scatter_reduce_(0, k[m], t.arange(lo, lo + k.numel(), dtype=t.int64, device=env.dev)[m], reduce="amin")
+    gk = view(env, out.column(0), out.num_rows, t.int64)
+    fr = first[gk]
+    assert bool((fr[1:] > fr[:-1]).all().item())  # first-seen order (hash_agg.rs:87-99)
+    out.release()
+    env.be.fn("ctx_pool_trim")(env.be.ctx)
+
+
 @pytest.mark.parametrize("push", ["order_push", "order_push_retained"])
 def test_full_size_order(env, push):
     """bench's Order shape: ORDER BY v1 (int64, 31 significant bits) carrying one f64 column over 1e8 device rows =
