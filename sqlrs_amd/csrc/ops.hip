@@ -650,7 +650,7 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
           r.rows = n;
           for (size_t ci = 0; ci < all.cols.size(); ci++) {
             if ((int)ci == kc) r.cols.push_back(ko);
-            else if ((int)ci == cc) r.cols.push_back(co);
+            else if ((int)ci == cc && co.values) r.cols.push_back(co); // (wide keys + more columns: the row ids travelled instead)
             else r.cols.push_back(gather_column(ctx, all.cols[ci], fperm->p, false, nullptr, n));
           }
           *out = emit_batch(ctx, std::move(r), out_mem);

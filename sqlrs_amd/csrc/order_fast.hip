@@ -189,13 +189,17 @@ __global__ __launch_bounds__(OW_WG) void ow_hist_kernel(const void *__restrict__
 // rank of every row among the rows of the same digit in its wave, in row order (wave w owns ITEMS chunks of
 // 64 consecutive rows): lanes with the same digit find each other with 8 ballots, the first of them bumps the
 // wave's own counter of that digit (one writer per digit and chunk, chunks in order: no atomics)
-template <int ITEMS>
+template <int ITEMS, bool SKIP_EMPTY = false>
 __device__ __forceinline__ void stable_wave_ranks(const uint32_t (&dig)[ITEMS], const bool (&valid)[ITEMS],
                                                   uint32_t *__restrict__ wcnt_w /* [256] of this wave */,
                                                   uint32_t (&rnk)[ITEMS]) {
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
     uint64_t peers = __ballot(valid[j]);
+    if (SKIP_EMPTY && !peers) { // (wave-uniform: a chunk without rows)
+      rnk[j] = 0;
+      continue;
+    }
 #pragma unroll
     for (int b = 0; b < 8; b++) {
       const bool bit = (dig[j] >> b) & 1;
@@ -516,6 +520,512 @@ __global__ void ow_unpack_kernel(const uint64_t *__restrict__ words, int64_t n, 
 
 constexpr uint32_t FIN_CAP = 6144; // rows of the largest group the in-LDS finish takes (R = 24)
 
+// ==== keys with more than 32 varying bits ==========================================================================
+// (random 64-bit ids, nanosecond timestamps over months, float64 measurements: the word `off << 32 | row` cannot hold
+// them, and fixed top bits make groups of wildly different sizes — the image of a float is its exponent first.)
+// Splitters taken from a sorted SAMPLE replace the bits: G = 2^top groups (the same count the narrow route would use),
+// 16 samples per group, sub[g] = sample 16 g (sub[0] = 0).  Group of a row = the last g with sub[g] <= off, found in two
+// levels so that a level fits LDS and the passes stay 256-way multi-splits:
+//   pass 1 (raw column -> word = off, 8 B, + payload): digit k = last TOP splitter (sub[k << 8]) <= off — a binary search
+//          over <= 256 values in LDS;
+//   pass 2 (tiles aligned to the segments of pass 1, so k is uniform per tile): digit d = last of sub[k << 8 | 0..255]
+//          <= off.  MSD order: the counts of this pass are laid out segment after segment, digit-major inside the
+//          segment, so that the one exclusive scan yields the position of every (tile, digit) run AND the group table;
+//   finish (one workgroup per group g = k << 8 | d, <= FIN_CAP rows, balanced by construction whatever the distribution):
+//          rel = off - sub[g] < the group's width; two stable 8-bit passes in LDS on the TOP 16 bits of rel, then the
+//          rows with the same top bits — runs of one or two rows, the group's ~1.5 K rows fall onto 65 536 values — are
+//          put in order by counting: position = run start + #(smaller-or-earlier words in the run).  A run longer than
+//          OWK_WALK rows (heavy duplicates of nearly-equal keys) sends the group through LSD passes over all bits of rel.
+// The payload is the carried column, or the row id when the caller needs the permutation (more columns than two).
+// Stability: passes 1 and 2 are stable and the counting step ranks equal words by position.
+struct OwkTile {
+  int64_t start;
+  uint32_t len, k;   // rows, segment (digit of pass 1)
+  uint32_t nt, tin;  // tiles of the segment, index of this tile among them
+};
+constexpr int OWK_SAMPLES = 16; // per group
+constexpr uint32_t OWK_WALK = 192;
+
+template <int KIND>
+__global__ void owk_sample_kernel(const void *__restrict__ vals, int64_t n, int desc, uint64_t imin, int64_t S, int64_t stride,
+                                  uint64_t *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= S) return;
+  // (a jittered grid: an even stride would alias with periodic data)
+  const int64_t row = min(n - 1, i * stride + (int64_t)(mix64((uint64_t)i) % (uint64_t)stride));
+  out[i] = order_image<KIND>(vals, row, desc) - imin;
+}
+__global__ void owk_knots_kernel(const uint64_t *__restrict__ ss, uint32_t G, uint64_t *__restrict__ sub) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) sub[g] = g ? ss[(size_t)g * OWK_SAMPLES] : 0ull;
+}
+
+// last t < nk with sk[t] <= off (sk[0] <= off by construction), for ITEMS rows at once (independent chains of LDS reads)
+template <int ITEMS>
+__device__ __forceinline__ void knot_digits(const uint64_t *__restrict__ sk, uint32_t nk, const uint64_t (&off)[ITEMS], uint32_t (&dig)[ITEMS]) {
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) dig[j] = 0;
+#pragma unroll
+  for (uint32_t step = 128; step; step >>= 1) {
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+      const uint32_t t = dig[j] + step;
+      if (t < nk && sk[t] <= off[j]) dig[j] = t;
+    }
+  }
+}
+
+// LEVEL 1: fixed blocks over the raw column, count matrix digit-major [d * nblocks + block];
+// LEVEL 2: the tile list, count matrix segment-major [(first tile of the segment) * 256 + d * nt + tin]
+template <int KIND, int LEVEL>
+__global__ __launch_bounds__(OW_WG) void owk_hist_kernel(const void *__restrict__ src, int64_t n, int desc, uint64_t imin,
+                                                         int64_t nblocks, uint32_t *__restrict__ hist,
+                                                         const OwkTile *__restrict__ tiles, const uint64_t *__restrict__ sub, uint32_t nk1) {
+  __shared__ uint32_t h[256];
+  __shared__ uint64_t sk[256];
+  int64_t t0;
+  uint32_t tl, nk = nk1;
+  size_t hbase = 0, hstride = (size_t)nblocks, hcol = blockIdx.x;
+  if (LEVEL == 2) {
+    const OwkTile t = tiles[blockIdx.x];
+    t0 = t.start;
+    tl = t.len;
+    nk = 256;
+    hbase = (size_t)(blockIdx.x - t.tin) * 256;
+    hstride = t.nt;
+    hcol = t.tin;
+    if (tl == 0) {
+      if (threadIdx.x < 256) hist[hbase + threadIdx.x * hstride + hcol] = 0;
+      return;
+    }
+    if (threadIdx.x < 256) sk[threadIdx.x] = sub[(size_t)t.k * 256 + threadIdx.x];
+  } else {
+    t0 = (int64_t)blockIdx.x * OW_TILE;
+    tl = (uint32_t)min<int64_t>(OW_TILE, n - t0);
+    if (threadIdx.x < 256) sk[threadIdx.x] = threadIdx.x < nk1 ? sub[(size_t)threadIdx.x << 8] : ~0ull;
+  }
+  if (threadIdx.x < 256) h[threadIdx.x] = 0;
+  uint64_t k[OW_ITEMS];
+#pragma unroll
+  for (int r = 0; r < OW_ITEMS; r++) {
+    const int64_t i = t0 + min((uint32_t)(threadIdx.x + r * OW_WG), tl - 1);
+    k[r] = LEVEL == 1 ? order_image<KIND>(src, i, desc) - imin : __builtin_nontemporal_load((const uint64_t *)src + i);
+  }
+  __syncthreads();
+  uint32_t dig[OW_ITEMS];
+  knot_digits<OW_ITEMS>(sk, nk, k, dig);
+#pragma unroll
+  for (int r = 0; r < OW_ITEMS; r++)
+    if ((uint32_t)(threadIdx.x + r * OW_WG) < tl) atomicAdd(&h[dig[r]], 1u);
+  __syncthreads();
+  if (threadIdx.x < 256) hist[hbase + threadIdx.x * hstride + hcol] = h[threadIdx.x];
+}
+
+// pay == nullptr with NPAY: the payload is the row id (LEVEL 1 only).  REC: {word, payload} records out (LEVEL 2, NPAY)
+template <int KIND, int LEVEL, int NPAY, bool REC>
+__global__ __launch_bounds__(OW_WG) void owk_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay, int64_t n,
+                                                            int desc, uint64_t imin, int64_t nblocks,
+                                                            const uint32_t *__restrict__ offsets, uint64_t *__restrict__ words_out,
+                                                            uint64_t *__restrict__ pay_out, const OwkTile *__restrict__ tiles,
+                                                            const uint64_t *__restrict__ sub, uint32_t nk1) {
+  __shared__ uint64_t sword[OW_TILE];
+  __shared__ uint64_t spay[NPAY ? OW_TILE : 1];
+  __shared__ uint32_t wcnt[OW_WAVES][256]; // (its first 2 KB hold the splitters until the digits are known)
+  __shared__ uint32_t dstart[256];
+  __shared__ uint32_t gbase[256]; // position of the digit's run in the output minus its start in the tile (mod 2^32)
+  __shared__ uint8_t sdig[OW_TILE];
+  __shared__ uint32_t s_wsum[4];
+  uint64_t *sk = (uint64_t *)&wcnt[0][0];
+  const int w = wave_id(), lane = lane_id();
+  int64_t tbase;
+  uint32_t len, nk = nk1;
+  size_t hbase = 0, hstride = (size_t)nblocks, hcol = blockIdx.x;
+  if (LEVEL == 2) {
+    const OwkTile t = tiles[blockIdx.x];
+    tbase = t.start;
+    len = t.len;
+    nk = 256;
+    hbase = (size_t)(blockIdx.x - t.tin) * 256;
+    hstride = t.nt;
+    hcol = t.tin;
+    if (len == 0) return;
+    if (threadIdx.x < 256) sk[threadIdx.x] = sub[(size_t)t.k * 256 + threadIdx.x];
+  } else {
+    tbase = (int64_t)blockIdx.x * OW_TILE;
+    len = (uint32_t)min<int64_t>(OW_TILE, n - tbase);
+    if (threadIdx.x < 256) sk[threadIdx.x] = threadIdx.x < nk1 ? sub[(size_t)threadIdx.x << 8] : ~0ull;
+  }
+  const uint32_t wrow = (uint32_t)w * (OW_ITEMS * 64) + lane; // element of the tile
+  uint64_t k[OW_ITEMS], v[NPAY ? OW_ITEMS : 1];
+#pragma unroll
+  for (int j = 0; j < OW_ITEMS; j++) {
+    const int64_t i = tbase + min(wrow + j * 64, len - 1);
+    k[j] = LEVEL == 1 ? order_image<KIND>(src, i, desc) - imin : __builtin_nontemporal_load((const uint64_t *)src + i);
+    if (NPAY) v[j] = pay ? __builtin_nontemporal_load(pay + i) : (uint64_t)i;
+  }
+  const uint32_t goff = threadIdx.x < 256 ? offsets[hbase + threadIdx.x * hstride + hcol] : 0;
+  __syncthreads();
+  uint32_t dig[OW_ITEMS], rnk[OW_ITEMS];
+  knot_digits<OW_ITEMS>(sk, nk, k, dig);
+  __syncthreads(); // (the splitters are read: their bytes become the wave counters)
+#pragma unroll
+  for (int q = 0; q < 4; q++) wcnt[w][lane + 64 * q] = 0;
+  bool valid[OW_ITEMS];
+#pragma unroll
+  for (int j = 0; j < OW_ITEMS; j++) valid[j] = wrow + j * 64 < len;
+  stable_wave_ranks<OW_ITEMS>(dig, valid, wcnt[w], rnk);
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int q = 0; q < OW_WAVES; q++) {
+      uint32_t c = wcnt[q][threadIdx.x];
+      wcnt[q][threadIdx.x] = acc;
+      acc += c;
+    }
+    uint32_t inc = wave_iscan_u32(acc);
+    if (lane == 63) s_wsum[w] = inc;
+    dstart[threadIdx.x] = inc - acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    uint32_t wb = 0;
+    for (int q = 0; q < w; q++) wb += s_wsum[q];
+    const uint32_t ds = dstart[threadIdx.x] + wb;
+    dstart[threadIdx.x] = ds;
+    gbase[threadIdx.x] = goff - ds;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < OW_ITEMS; j++) {
+    if (!valid[j]) continue;
+    const uint32_t p = dstart[dig[j]] + wcnt[w][dig[j]] + rnk[j];
+    sword[p] = k[j];
+    sdig[p] = (uint8_t)dig[j];
+    if (NPAY) spay[p] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < OW_ITEMS; j++) {
+    const uint32_t p = j * OW_WG + threadIdx.x;
+    if (p < len) {
+      const uint64_t kk = sword[p];
+      const size_t g = (size_t)(uint32_t)(gbase[sdig[p]] + p);
+      if (REC) {
+        u64x2 rec;
+        rec.x = kk;
+        rec.y = spay[NPAY ? p : 0];
+        ((u64x2 *)words_out)[g] = rec;
+        continue;
+      }
+      words_out[g] = kk;
+      if (NPAY) pay_out[g] = spay[p];
+    }
+  }
+}
+
+__global__ void owk_tile_fill_kernel(const uint32_t *__restrict__ firsttile, const int64_t *__restrict__ segstart, uint32_t ntmax,
+                                     OwkTile *__restrict__ tiles) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntmax) return;
+  OwkTile o;
+  const uint32_t used = firsttile[256];
+  if (t < used) {
+    uint32_t lo = 0, hi = 256; // last segment whose first tile is <= t (segments without tiles share their successor's)
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (firsttile[mid] <= t) lo = mid; else hi = mid;
+    }
+    o.start = segstart[lo] + (int64_t)(t - firsttile[lo]) * OW_TILE;
+    o.len = (uint32_t)min<int64_t>(OW_TILE, segstart[lo + 1] - o.start);
+    o.k = lo;
+    o.nt = firsttile[lo + 1] - firsttile[lo];
+    o.tin = t - firsttile[lo];
+  } else { // spare slots: one more "segment" of empty tiles behind the last
+    o.start = 0;
+    o.len = 0;
+    o.k = 256;
+    o.nt = ntmax - used;
+    o.tin = t - used;
+  }
+  tiles[t] = o;
+}
+// group g = k << 8 | d: rows [gstart[g], gend[g]); one block per segment k; gend[G] = largest group
+__global__ __launch_bounds__(256) void owk_group_table_kernel(const uint32_t *__restrict__ offs2, const uint32_t *__restrict__ firsttile,
+                                                              const int64_t *__restrict__ segstart, uint32_t G,
+                                                              uint32_t *__restrict__ gstart, uint32_t *__restrict__ gend) {
+  const uint32_t k = blockIdx.x, d = threadIdx.x;
+  const uint32_t ft = firsttile[k], nt = firsttile[k + 1] - ft;
+  uint32_t a = 0xffffffffu, b = 0;
+  if (nt) {
+    a = offs2[(size_t)ft * 256 + (size_t)d * nt];
+    b = d == 255 ? (uint32_t)segstart[k + 1] : offs2[(size_t)ft * 256 + (size_t)(d + 1) * nt];
+  }
+  gstart[k * 256 + d] = a;
+  gend[k * 256 + d] = b;
+  uint32_t sz = nt ? b - a : 0;
+  for (int s = 32; s >= 1; s >>= 1) sz = max(sz, (uint32_t)__shfl_xor((int)sz, s, 64));
+  if (lane_id() == 0 && sz) atomicMax(gend + G, sz);
+}
+
+// perm_out != nullptr: the payload is the row id — it leaves as the permutation and there is no carried column
+template <int KIND, int NPAY, int R, bool REC>
+__global__ __launch_bounds__(FIN_WG) void owk_finish_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pay,
+                                                            const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gend,
+                                                            const uint64_t *__restrict__ sub, uint32_t G, uint64_t range, int desc,
+                                                            uint64_t imin, uint64_t *__restrict__ key_out,
+                                                            uint64_t *__restrict__ pay_out, uint32_t *__restrict__ perm_out,
+                                                            uint32_t m_above, uint32_t m_upto) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lo = gstart[blockIdx.x], hi = gend[blockIdx.x];
+  if (lo == 0xffffffffu || lo >= hi) return;
+  const uint32_t m = hi - lo;
+  if (m <= m_above || m > m_upto) return; // (a group of another size class: the launch with the LDS room for it takes it)
+  uint64_t *sword = (uint64_t *)smem;                       // [R * FIN_WG]
+  uint64_t *spay = sword + (size_t)R * FIN_WG;              // [NPAY ? R * FIN_WG : 0]
+  uint32_t *wcnt = (uint32_t *)(spay + (NPAY ? (size_t)R * FIN_WG : 0)); // [FIN_WAVES][256]
+  uint32_t *dstart = wcnt + FIN_WAVES * 256;                // [256]
+  __shared__ uint32_t s_wsum[FIN_WAVES];
+  __shared__ uint32_t s_heavy;
+  const int w = wave_id(), lane = lane_id();
+  // wave w owns chunks [w * cpw, (w + 1) * cpw) of 64 consecutive rows (cpw <= R): all four waves work whatever the group's size
+  const uint32_t cpw = ((m + 63) / 64 + FIN_WAVES - 1) / FIN_WAVES;
+  const uint64_t base = sub[blockIdx.x];
+  const uint64_t relmax = (blockIdx.x + 1 < G ? sub[blockIdx.x + 1] - 1 : range) - base; // (next > base: the group has rows)
+  const int tb = relmax ? 64 - __builtin_clzll(relmax) : 0;
+  const int sh = tb > 16 ? tb - 16 : 0, top = sh + 16; // in-LDS passes on bits [sh, top) of rel, counting below sh
+  if (threadIdx.x == 0) s_heavy = 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    uint64_t k[R], v[NPAY ? R : 1];
+    bool valid[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const uint32_t e = (uint32_t)(w * cpw + j) * 64 + lane;
+      valid[j] = (uint32_t)j < cpw && e < m;
+      const uint32_t i = lo + min(e, m - 1);
+      if (REC) {
+        const u64x2 rec = __builtin_nontemporal_load((const u64x2 *)words + i);
+        k[j] = rec.x - base;
+        v[NPAY ? j : 0] = rec.y;
+      } else {
+        k[j] = __builtin_nontemporal_load(words + i) - base;
+        if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
+      }
+    }
+    for (int shift = attempt ? 0 : sh; shift < top; shift += 8) { // stable LSD passes, all in LDS
+      for (int q = lane; q < 256; q += 64) wcnt[w * 256 + q] = 0;
+      uint32_t dig[R], rnk[R];
+#pragma unroll
+      for (int j = 0; j < R; j++) dig[j] = (uint32_t)(k[j] >> shift) & ((shift + 8 > top) ? ((1u << (top - shift)) - 1) : 255u);
+      stable_wave_ranks<R, true>(dig, valid, wcnt + w * 256, rnk);
+      __syncthreads();
+      {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < FIN_WAVES; q++) {
+          const uint32_t c = wcnt[q * 256 + threadIdx.x];
+          wcnt[q * 256 + threadIdx.x] = acc;
+          acc += c;
+        }
+        const uint32_t inc = wave_iscan_u32(acc);
+        if (lane == 63) s_wsum[w] = inc;
+        dstart[threadIdx.x] = inc - acc;
+      }
+      __syncthreads();
+      {
+        uint32_t wb = 0;
+        for (int q = 0; q < w; q++) wb += s_wsum[q];
+        dstart[threadIdx.x] += wb;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        if (!valid[j]) continue;
+        const uint32_t p = dstart[dig[j]] + wcnt[w * 256 + dig[j]] + rnk[j];
+        sword[p] = k[j];
+        if (NPAY) spay[p] = v[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const uint32_t e = min((uint32_t)(w * cpw + j) * 64 + lane, m - 1);
+        k[j] = sword[e];
+        if (NPAY) v[j] = spay[e];
+      }
+      __syncthreads();
+    }
+    if (attempt || sh == 0) { // every bit of rel has been sorted on: the rows are in place
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        if (!valid[j]) continue;
+        const uint32_t i = lo + (uint32_t)(w * cpw + j) * 64 + lane;
+        key_out[i] = order_unimage<KIND>(k[j] + base + imin, desc);
+        if (perm_out) perm_out[i] = (uint32_t)v[NPAY ? j : 0];
+        else if (NPAY) pay_out[i] = v[j];
+      }
+      return;
+    }
+    // rows with equal bits [sh, ..) form runs; inside a run the words are ranked by counting (sword / spay hold the
+    // rows in the order of the last pass)
+    for (uint32_t e = threadIdx.x; e < m; e += FIN_WG) {
+      const uint64_t me = sword[e], pf = me >> sh;
+      uint32_t before = 0, steps = 0;
+      int64_t q = (int64_t)e - 1;
+      for (; q >= 0 && steps <= OWK_WALK; q--, steps++) {
+        const uint64_t o = sword[q];
+        if ((o >> sh) != pf) break;
+        before += o <= me;
+      }
+      const uint32_t start = (uint32_t)(q + 1);
+      bool heavy = steps > OWK_WALK;
+      steps = 0;
+      for (uint32_t f = e + 1; f < m && steps <= OWK_WALK; f++, steps++) {
+        const uint64_t o = sword[f];
+        if ((o >> sh) != pf) break;
+        before += o < me;
+      }
+      heavy |= steps > OWK_WALK;
+      if (heavy) {
+        s_heavy = 1; // (the whole group is redone below: what the others write meanwhile is overwritten)
+        continue;
+      }
+      const uint32_t i = lo + start + before;
+      key_out[i] = order_unimage<KIND>(me + base + imin, desc);
+      if (perm_out) perm_out[i] = (uint32_t)spay[NPAY ? e : 0];
+      else if (NPAY) pay_out[i] = spay[e];
+    }
+    __syncthreads();
+    if (!s_heavy) return;
+  }
+}
+
+// the wide route; false = not taken (nothing produced that the caller may use).  `imin`, `range`: EXACT extremes of the
+// key image.  want_perm: the row ids travel as the payload and `carry_out` stays empty (the caller gathers that column
+// like the others)
+template <int KIND>
+static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, uint64_t imin, uint64_t range,
+                       DCol *key_out, DCol *carry_out, BufP *perm_out, bool want_perm) {
+  if (const char *e = std::getenv("SQLRS_ORDER_WIDE")) // (A/B hook, read per call: 0 = the general path)
+    if (e[0] == '0') return false;
+  int top = 9;
+  while (top < 16 && (n >> top) > 2048) top++;
+  const uint32_t G = 1u << top, nk1 = G >> 8;
+  const int64_t S = (int64_t)G * OWK_SAMPLES;
+  if (n < S) return false;
+  const int kb = 64 - __builtin_clzll(range);
+  const bool pay_rows = want_perm, has_pay = pay_rows || carry != nullptr;
+  // 0. splitters
+  BufP ss = ctx->alloc(8 * (size_t)S), ssv = ctx->alloc(4 * (size_t)S), sub = ctx->alloc(8 * ((size_t)G + 1));
+  {
+    ProfScope ps(ctx, "order_knots");
+    owk_sample_kernel<KIND><<<dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, ctx->stream>>>(key.values, n, desc, imin, S, n / S, ss->as<uint64_t>());
+    SQ_HIP(hipGetLastError());
+    radix_sort_pairs(ctx, ss->as<uint64_t>(), ssv->as<uint32_t>(), S, 0, kb, true);
+    owk_knots_kernel<<<dim3((unsigned)ceil_div((int64_t)G, 256)), dim3(256), 0, ctx->stream>>>(ss->as<uint64_t>(), G, sub->as<uint64_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  const uint64_t *subp = sub->as<uint64_t>();
+  // 1. pass 1: top-level splitters, raw column -> (word, payload) columns
+  const int64_t nblocks = ceil_div(n, OW_TILE), ntmax = nblocks + 256;
+  BufP w1 = ctx->alloc(8 * (size_t)n), p1 = has_pay ? ctx->alloc(8 * (size_t)n) : nullptr;
+  BufP hist = ctx->alloc(4 * (size_t)(256 * nblocks)), offs = ctx->alloc(4 * (size_t)(256 * nblocks)), total = ctx->alloc(8);
+  const uint64_t *psrc = (carry && !pay_rows) ? carry->v<uint64_t>() : nullptr;
+  dim3 g1((unsigned)nblocks), g2((unsigned)ntmax), b(OW_WG);
+  {
+    ProfScope ps(ctx, "order_split");
+    owk_hist_kernel<KIND, 1><<<g1, b, 0, ctx->stream>>>(key.values, n, desc, imin, nblocks, hist->as<uint32_t>(), nullptr, subp, nk1);
+    SQ_HIP(hipGetLastError());
+    exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(), total->as<uint64_t>());
+    if (has_pay)
+      owk_scatter_kernel<KIND, 1, 1, false><<<g1, b, 0, ctx->stream>>>(key.values, psrc, n, desc, imin, nblocks, offs->as<uint32_t>(),
+                                                                      w1->as<uint64_t>(), p1->as<uint64_t>(), nullptr, subp, nk1);
+    else
+      owk_scatter_kernel<KIND, 1, 0, false><<<g1, b, 0, ctx->stream>>>(key.values, nullptr, n, desc, imin, nblocks, offs->as<uint32_t>(),
+                                                                      w1->as<uint64_t>(), nullptr, nullptr, subp, nk1);
+    SQ_HIP(hipGetLastError());
+  }
+  // 2. pass 2 over segment-aligned tiles: the segment's own 256 splitters; records out when there is a payload
+  BufP firsttile = ctx->alloc(4 * 257), segstart = ctx->alloc(8 * 257), tiles2 = ctx->alloc(sizeof(OwkTile) * (size_t)ntmax);
+  BufP hist2 = ctx->alloc(4 * (size_t)(256 * ntmax)), offs2 = ctx->alloc(4 * (size_t)(256 * ntmax));
+  BufP out2 = ctx->alloc((has_pay ? 16 : 8) * (size_t)n);
+  {
+    ProfScope ps(ctx, "order_split");
+    ow_tile_plan_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(offs->as<uint32_t>(), nblocks, n, firsttile->as<uint32_t>(), segstart->as<int64_t>());
+    owk_tile_fill_kernel<<<dim3((unsigned)ceil_div(ntmax, 256)), dim3(256), 0, ctx->stream>>>(firsttile->as<uint32_t>(), segstart->as<int64_t>(),
+                                                                                             (uint32_t)ntmax, (OwkTile *)tiles2->p);
+    const OwkTile *tp = (const OwkTile *)tiles2->p;
+    owk_hist_kernel<KIND, 2><<<g2, b, 0, ctx->stream>>>(w1->p, n, desc, imin, ntmax, hist2->as<uint32_t>(), tp, subp, nk1);
+    SQ_HIP(hipGetLastError());
+    exclusive_scan_u32(ctx, hist2->as<uint32_t>(), 256 * ntmax, nullptr, offs2->as<uint32_t>(), total->as<uint64_t>());
+    if (has_pay)
+      owk_scatter_kernel<KIND, 2, 1, true><<<g2, b, 0, ctx->stream>>>(w1->p, p1->as<uint64_t>(), n, desc, imin, ntmax, offs2->as<uint32_t>(),
+                                                                     out2->as<uint64_t>(), nullptr, tp, subp, nk1);
+    else
+      owk_scatter_kernel<KIND, 2, 0, false><<<g2, b, 0, ctx->stream>>>(w1->p, nullptr, n, desc, imin, ntmax, offs2->as<uint32_t>(),
+                                                                      out2->as<uint64_t>(), nullptr, tp, subp, nk1);
+    SQ_HIP(hipGetLastError());
+  }
+  // 3. groups
+  BufP gstart = ctx->alloc(4 * (size_t)65536), gend = ctx->alloc(4 * ((size_t)65536 + 1));
+  SQ_HIP(hipMemsetAsync(gend->as<uint32_t>() + G, 0, 4, ctx->stream));
+  {
+    ProfScope ps(ctx, "order_groups");
+    owk_group_table_kernel<<<dim3(nk1), dim3(256), 0, ctx->stream>>>(offs2->as<uint32_t>(), firsttile->as<uint32_t>(), segstart->as<int64_t>(), G,
+                                                                   gstart->as<uint32_t>(), gend->as<uint32_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  const uint32_t max_group = ctx->fetch_value(gend->as<uint32_t>() + G);
+  if (std::getenv("SQLRS_ORDER_TRACE"))
+    std::fprintf(stderr, "[order_wide] n=%lld key bits=%d groups=%u largest group=%u rows\n", (long long)n, kb, G, max_group);
+  if (max_group > FIN_CAP) return false; // one value (or a narrow band of values) repeated thousands of times: general path
+  // 4. finish
+  key_out->dtype = key.dtype;
+  key_out->length = n;
+  key_out->null_count = 0;
+  key_out->own_values = ctx->alloc(8 * (size_t)n + 16);
+  key_out->values = key_out->own_values->p;
+  uint32_t *perm = nullptr;
+  uint64_t *po = nullptr;
+  if (pay_rows) {
+    *perm_out = ctx->alloc(4 * (size_t)n);
+    perm = (*perm_out)->as<uint32_t>();
+  } else if (carry) {
+    carry_out->dtype = carry->dtype;
+    carry_out->length = n;
+    carry_out->null_count = 0;
+    carry_out->own_values = ctx->alloc(8 * (size_t)n + 16);
+    carry_out->values = carry_out->own_values->p;
+    po = carry_out->own_values->as<uint64_t>();
+  }
+  {
+    ProfScope ps(ctx, "order_finish");
+    // The splitters balance the groups only statistically (16 samples per group: sizes spread like a Gamma(16), the largest of
+    // 65 536 is ~2.5x the mean), and the LDS a workgroup asks for decides how many are resident: the groups of up to
+    // 2048 rows (9 in 10) go through a launch of their own with 37 KB each, the rest through one sized for the largest.
+#define SQ_WFIN(NP, RR, ABOVE, UPTO)                                                                                 \
+  do {                                                                                                               \
+    auto kfn = owk_finish_kernel<KIND, NP, RR, NP == 1>;                                                             \
+    const size_t lds = (size_t)RR * FIN_WG * 8 * (1 + NP) + 4 * (FIN_WAVES * 256 + 256);                             \
+    if (lds > 64 * 1024) allow_big_lds(ctx, kfn);                                                                    \
+    kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(out2->as<uint64_t>(), nullptr, gstart->as<uint32_t>(), gend->as<uint32_t>(), subp, G, \
+                                                     range, desc, imin, key_out->own_values->as<uint64_t>(), po, perm,  \
+                                                     (uint32_t)(ABOVE), (uint32_t)(UPTO));                           \
+  } while (0)
+#define SQ_WFIN_R(NP)                                                                                                \
+  do {                                                                                                               \
+    SQ_WFIN(NP, 8, 0, 8 * FIN_WG);                                                                                   \
+    if (max_group > 16 * FIN_WG) SQ_WFIN(NP, 24, 8 * FIN_WG, FIN_CAP);                                               \
+    else if (max_group > 8 * FIN_WG) SQ_WFIN(NP, 16, 8 * FIN_WG, 16 * FIN_WG);                                       \
+  } while (0)
+    if (has_pay) SQ_WFIN_R(1);
+    else SQ_WFIN_R(0);
+#undef SQ_WFIN_R
+#undef SQ_WFIN
+    SQ_HIP(hipGetLastError());
+  }
+  return true;
+}
+
 // `optimistic`: the key range comes from a SAMPLE (every 16th chunk of 2048 rows: 0.19 -> 0.03 ms for 1e8 rows), widened
 // as far as the same number of key bits allows; the first split pass tests every key against it and *retry_exact is set
 // (nothing produced, return false) when one lies outside — the caller runs the exact form once.
@@ -553,7 +1063,17 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     imax = std::max(imax, h[2 * q + 1]);
   }
   uint64_t range = imax - imin;
-  if (imin > imax || range > 0xffffffffull) return false; // more than 32 varying key bits: general path
+  if (imin > imax) return false;
+  if (range > 0xffffffffull) { // more than 32 varying key bits: splitters instead of bits (order_wide), or the general path
+    if constexpr (KIND == OKIND_I32) return false;
+    else {
+      if (optimistic) { // (the sampled extremes are not the extremes)
+        *retry_exact = true;
+        return false;
+      }
+      return order_wide<KIND>(ctx, key, desc, carry, n, imin, range, key_out, carry_out, perm_out, want_perm);
+    }
+  }
   int kbits = 1;
   while (kbits < 32 && (1ull << kbits) <= range) kbits++;
   unsigned int *oob = nullptr;

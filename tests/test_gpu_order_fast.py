@@ -175,3 +175,63 @@ def test_order_by_limit_sorts_only_the_candidates(hip, oracle, shape, monkeypatc
         assert ex.topk_candidates == 0
     elif shape != "i64_many_ties":
         assert 0 < ex.topk_candidates < n // 4, ex.topk_candidates
+
+
+def wide_keys_of(rng, shape, n):
+    if shape == "i64_random":                 # 63 varying bits, about one row per value
+        return rng.integers(-(1 << 62), 1 << 62, n, dtype=np.int64)
+    if shape == "i64_33bit":                  # just beyond what the 32-bit word holds
+        k = rng.integers(0, (1 << 32) + 5, n, dtype=np.int64) - 17
+        k[n // 2], k[n // 3] = -17, (1 << 32) + 4 - 17
+        return k
+    if shape == "i64_ties":                   # 200 000 distinct wide values, ~6 rows each: runs ranked by position
+        return rng.choice(rng.integers(-(1 << 60), 1 << 60, 200_000, dtype=np.int64), n)
+    if shape == "f64_unit":                   # the image of a double is its exponent first: fixed bits would pile half the rows into one binade
+        return rng.random(n)
+    if shape == "f64_normal":
+        return rng.normal(0.0, 1e3, n)
+    if shape == "f64_lognormal_signed":       # 40 orders of magnitude, both signs, zeros of both signs
+        k = np.exp(rng.normal(0.0, 15.0, n)) * rng.choice([-1.0, 1.0], n)
+        k[::1000] = 0.0
+        k[1::1000] = -0.0
+        return k
+    if shape == "f64_clusters":               # ~1000 tight clusters: runs of > OWK_WALK rows inside a group -> LSD over all bits
+        c = rng.choice(rng.normal(0.0, 1e6, 1000), n)
+        return c + rng.integers(0, 1 << 12, n) * 2.0 ** -30
+    if shape == "i64_one_heavy_value":        # a value repeated beyond the LDS finish: general path
+        k = rng.integers(-(1 << 62), 1 << 62, n, dtype=np.int64)
+        k[rng.random(n) < 0.02] = 123456789012345
+        return k
+    raise ValueError(shape)
+
+
+@pytest.mark.parametrize("shape", ["i64_random", "i64_33bit", "i64_ties", "f64_unit", "f64_normal", "f64_lognormal_signed",
+                                   "f64_clusters", "i64_one_heavy_value"])
+@pytest.mark.parametrize("asc", [True, False])
+@pytest.mark.parametrize("extra", ["none", "carry", "carry_and_more"])
+def test_order_wide_keys(hip, oracle, shape, asc, extra):
+    """keys with more than 32 varying bits: splitters from a sorted sample, two multi-split passes, in-LDS finish with the
+    counting step (order_fast.hip, order_wide) — against the oracle, ties in input order; `order_knots` shows the route"""
+    if extra != "carry" and shape not in ("i64_random", "f64_unit", "i64_ties", "f64_clusters"):
+        pytest.skip("column mixes are crossed with four key shapes only")
+    n = N if shape != "f64_normal" else 5_000_000
+    rng = np.random.default_rng(hash_seed("wide", shape, asc, extra))
+    k = wide_keys_of(rng, shape, n)
+    cols, names = [pa.array(k)], ["k"]
+    if extra != "none":
+        cols.append(pa.array(np.arange(n, dtype=np.int64)))
+        names.append("row")
+    if extra == "carry_and_more":
+        cols += [pa.array(rng.random(n), mask=rng.random(n) < 0.1), pa.array(rng.integers(0, 100, n).astype(np.int32))]
+        names += ["f", "i"]
+    b = pa.RecordBatch.from_arrays(cols, names=names)
+    hip.profile(True)
+    (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(0), asc=asc)], [b.slice(0, n // 3), b.slice(n // 3)]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
+    for i in range(b.num_columns):
+        assert got.column(i).equals(exp.column(i)), names[i]
+    assert prof.get("order_knots", (0, 0))[1] == 1, prof
+    finished = prof.get("order_finish", (0, 0))[1] == 1
+    assert finished == (shape != "i64_one_heavy_value"), prof
