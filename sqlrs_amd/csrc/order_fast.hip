@@ -431,13 +431,15 @@ __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__res
   uint32_t *dstart = wcnt + FIN_WAVES * 256;                // [256]
   __shared__ uint32_t s_wsum[FIN_WAVES];
   const int w = wave_id(), lane = lane_id();
-  // element e = (w * R + j) * 64 + lane: wave w owns R chunks of 64 consecutive rows
+  // element e = (w * cpw + j) * 64 + lane: wave w owns cpw <= R chunks of 64 consecutive rows — as many as give all four
+  // waves the same share of THIS group (with R per wave, a group of 1500 rows kept three waves busy and one idle)
+  const uint32_t cpw = ((m + 63) / 64 + FIN_WAVES - 1) / FIN_WAVES;
   uint64_t k[R], v[NPAY ? R : 1];
   bool valid[R];
 #pragma unroll
   for (int j = 0; j < R; j++) {
-    const uint32_t e = (uint32_t)(w * R + j) * 64 + lane;
-    valid[j] = e < m;
+    const uint32_t e = (uint32_t)(w * cpw + j) * 64 + lane;
+    valid[j] = (uint32_t)j < cpw && e < m;
     const uint32_t i = lo + min(e, m - 1);
     if (REC) {
       const u64x2 rec = __builtin_nontemporal_load((const u64x2 *)words + i);
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__res
       // the last pass may cover fewer than 8 bits: bits >= 32 + rbits are equal inside the group
       dig[j] = (uint32_t)(k[j] >> shift) & 255u & ((shift + 8 > 32 + rbits) ? ((1u << (32 + rbits - shift)) - 1) : 255u);
     }
-    stable_wave_ranks<R>(dig, valid, wcnt + w * 256, rnk);
+    stable_wave_ranks<R, true>(dig, valid, wcnt + w * 256, rnk);
     __syncthreads();
     { // FIN_WG == 256: one thread per digit
       uint32_t acc = 0;
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__res
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < R; j++) {
-      const uint32_t e = min((uint32_t)(w * R + j) * 64 + lane, m - 1);
+      const uint32_t e = min((uint32_t)(w * cpw + j) * 64 + lane, m - 1);
       k[j] = sword[e];
       if (NPAY) v[j] = spay[e];
     }
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__res
 #pragma unroll
   for (int j = 0; j < R; j++) {
     if (!valid[j]) continue;
-    const uint32_t i = lo + (uint32_t)(w * R + j) * 64 + lane;
+    const uint32_t i = lo + (uint32_t)(w * cpw + j) * 64 + lane;
     const uint64_t val = order_unimage<KIND>((k[j] >> 32) + imin, desc);
     if (KIND == OKIND_I32) ((int32_t *)key_out)[i] = (int32_t)(int64_t)val;
     else ((uint64_t *)key_out)[i] = val;
@@ -555,9 +557,9 @@ __global__ void owk_sample_kernel(const void *__restrict__ vals, int64_t n, int 
   const int64_t row = min(n - 1, i * stride + (int64_t)(mix64((uint64_t)i) % (uint64_t)stride));
   out[i] = order_image<KIND>(vals, row, desc) - imin;
 }
-__global__ void owk_knots_kernel(const uint64_t *__restrict__ ss, uint32_t G, uint64_t *__restrict__ sub) {
+__global__ void owk_knots_kernel(const uint64_t *__restrict__ ss, uint32_t G, uint32_t per_group, uint64_t *__restrict__ sub) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < G) sub[g] = g ? ss[(size_t)g * OWK_SAMPLES] : 0ull;
+  if (g < G) sub[g] = g ? ss[(size_t)g * per_group] : 0ull;
 }
 
 // last t < nk with sk[t] <= off (sk[0] <= off by construction), for ITEMS rows at once (independent chains of LDS reads)
@@ -772,8 +774,7 @@ __global__ __launch_bounds__(256) void owk_group_table_kernel(const uint32_t *__
 template <int KIND, int NPAY, int R, bool REC>
 __global__ __launch_bounds__(FIN_WG) void owk_finish_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pay,
                                                             const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gend,
-                                                            const uint64_t *__restrict__ sub, uint32_t G, uint64_t range, int desc,
-                                                            uint64_t imin, uint64_t *__restrict__ key_out,
+                                                            int desc, uint64_t imin, uint64_t *__restrict__ key_out,
                                                             uint64_t *__restrict__ pay_out, uint32_t *__restrict__ perm_out,
                                                             uint32_t m_above, uint32_t m_upto) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -790,10 +791,11 @@ __global__ __launch_bounds__(FIN_WG) void owk_finish_kernel(const uint64_t *__re
   const int w = wave_id(), lane = lane_id();
   // wave w owns chunks [w * cpw, (w + 1) * cpw) of 64 consecutive rows (cpw <= R): all four waves work whatever the group's size
   const uint32_t cpw = ((m + 63) / 64 + FIN_WAVES - 1) / FIN_WAVES;
-  const uint64_t base = sub[blockIdx.x];
-  const uint64_t relmax = (blockIdx.x + 1 < G ? sub[blockIdx.x + 1] - 1 : range) - base; // (next > base: the group has rows)
-  const int tb = relmax ? 64 - __builtin_clzll(relmax) : 0;
-  const int sh = tb > 16 ? tb - 16 : 0, top = sh + 16; // in-LDS passes on bits [sh, top) of rel, counting below sh
+  __shared__ uint64_t s_mn[FIN_WAVES], s_mx[FIN_WAVES];
+  // rel = word - smallest word of the group (found below: the splitters bound the group, its own extremes bound it tighter —
+  // and the first / last group, which reach down to 0 / up to the end of the range, are no special case)
+  uint64_t base = 0;
+  int sh = 0, top = 16; // in-LDS passes on bits [sh, top) of rel, counting below sh
   if (threadIdx.x == 0) s_heavy = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
     uint64_t k[R], v[NPAY ? R : 1];
@@ -805,13 +807,40 @@ __global__ __launch_bounds__(FIN_WG) void owk_finish_kernel(const uint64_t *__re
       const uint32_t i = lo + min(e, m - 1);
       if (REC) {
         const u64x2 rec = __builtin_nontemporal_load((const u64x2 *)words + i);
-        k[j] = rec.x - base;
+        k[j] = rec.x;
         v[NPAY ? j : 0] = rec.y;
       } else {
-        k[j] = __builtin_nontemporal_load(words + i) - base;
+        k[j] = __builtin_nontemporal_load(words + i);
         if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
       }
     }
+    if (attempt == 0) { // (rows past the group's end repeat its last row: they do not move the extremes)
+      uint64_t mn = ~0ull, mx = 0;
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        mn = min(mn, k[j]);
+        mx = max(mx, k[j]);
+      }
+      mn = wave_min_u64(mn);
+      mx = wave_max_u64(mx);
+      if (lane == 0) {
+        s_mn[w] = mn;
+        s_mx[w] = mx;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < FIN_WAVES; q++) {
+        mn = min(mn, s_mn[q]);
+        mx = max(mx, s_mx[q]);
+      }
+      base = mn;
+      const uint64_t relmax = mx - mn;
+      const int tb = relmax ? 64 - __builtin_clzll(relmax) : 0;
+      sh = tb > 16 ? tb - 16 : 0;
+      top = sh + 16;
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) k[j] -= base;
     for (int shift = attempt ? 0 : sh; shift < top; shift += 8) { // stable LSD passes, all in LDS
       for (int q = lane; q < 256; q += 64) wcnt[w * 256 + q] = 0;
       uint32_t dig[R], rnk[R];
@@ -910,7 +939,9 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   int top = 9;
   while (top < 16 && (n >> top) > 2048) top++;
   const uint32_t G = 1u << top, nk1 = G >> 8;
-  const int64_t S = (int64_t)G * OWK_SAMPLES;
+  int per_group = OWK_SAMPLES;
+  if (const char *e = std::getenv("SQLRS_ORDER_SAMPLES")) per_group = std::max(1, std::min(256, std::atoi(e))); // (A/B hook, read per call)
+  const int64_t S = (int64_t)G * per_group;
   if (n < S) return false;
   const int kb = 64 - __builtin_clzll(range);
   const bool pay_rows = want_perm, has_pay = pay_rows || carry != nullptr;
@@ -921,7 +952,7 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     owk_sample_kernel<KIND><<<dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, ctx->stream>>>(key.values, n, desc, imin, S, n / S, ss->as<uint64_t>());
     SQ_HIP(hipGetLastError());
     radix_sort_pairs(ctx, ss->as<uint64_t>(), ssv->as<uint32_t>(), S, 0, kb, true);
-    owk_knots_kernel<<<dim3((unsigned)ceil_div((int64_t)G, 256)), dim3(256), 0, ctx->stream>>>(ss->as<uint64_t>(), G, sub->as<uint64_t>());
+    owk_knots_kernel<<<dim3((unsigned)ceil_div((int64_t)G, 256)), dim3(256), 0, ctx->stream>>>(ss->as<uint64_t>(), G, (uint32_t)per_group, sub->as<uint64_t>());
     SQ_HIP(hipGetLastError());
   }
   const uint64_t *subp = sub->as<uint64_t>();
@@ -1007,8 +1038,8 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     auto kfn = owk_finish_kernel<KIND, NP, RR, NP == 1>;                                                             \
     const size_t lds = (size_t)RR * FIN_WG * 8 * (1 + NP) + 4 * (FIN_WAVES * 256 + 256);                             \
     if (lds > 64 * 1024) allow_big_lds(ctx, kfn);                                                                    \
-    kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(out2->as<uint64_t>(), nullptr, gstart->as<uint32_t>(), gend->as<uint32_t>(), subp, G, \
-                                                     range, desc, imin, key_out->own_values->as<uint64_t>(), po, perm,  \
+    kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(out2->as<uint64_t>(), nullptr, gstart->as<uint32_t>(), gend->as<uint32_t>(),      \
+                                                     desc, imin, key_out->own_values->as<uint64_t>(), po, perm,         \
                                                      (uint32_t)(ABOVE), (uint32_t)(UPTO));                           \
   } while (0)
 #define SQ_WFIN_R(NP)                                                                                                \
@@ -1067,9 +1098,17 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   if (range > 0xffffffffull) { // more than 32 varying key bits: splitters instead of bits (order_wide), or the general path
     if constexpr (KIND == OKIND_I32) return false;
     else {
-      if (optimistic) { // (the sampled extremes are not the extremes)
-        *retry_exact = true;
-        return false;
+      // (sampled extremes are not the extremes, and this route does not need them: offsets from 0 over the whole 64-bit
+      //  range do — the first and the last group then span far more values than their rows use, which their workgroups
+      //  notice as one long run of equal top bits and sort on all bits.  SQLRS_ORDER_WIDE_EXACT=1: the exact pass first)
+      if (optimistic) {
+        const char *ex = std::getenv("SQLRS_ORDER_WIDE_EXACT");
+        if (ex && ex[0] == '1') {
+          *retry_exact = true;
+          return false;
+        }
+        imin = 0;
+        range = ~0ull;
       }
       return order_wide<KIND>(ctx, key, desc, carry, n, imin, range, key_out, carry_out, perm_out, want_perm);
     }

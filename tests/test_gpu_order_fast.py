@@ -235,3 +235,27 @@ def test_order_wide_keys(hip, oracle, shape, asc, extra):
     assert prof.get("order_knots", (0, 0))[1] == 1, prof
     finished = prof.get("order_finish", (0, 0))[1] == 1
     assert finished == (shape != "i64_one_heavy_value"), prof
+
+
+@pytest.mark.parametrize("shape", ["i64_random", "f64_unit", "f64_lognormal_signed", "f64_clusters", "i64_33bit"])
+@pytest.mark.parametrize("asc", [True, False])
+def test_order_wide_keys_with_sampled_range(hip, oracle, shape, asc, monkeypatch):
+    """columns of >= 2^24 rows sample their key range (forced here by SQLRS_ORDER_SAMPLE=1): a sampled range of more than
+    32 bits goes to the wide route at once, with offsets from 0 over all 64 bits — no exact min / max pass (one
+    order_minmax launch); a sampled range that fits 32 bits while the keys do not (i64_33bit) is found out by the first
+    split pass and takes the exact pass first (two launches)"""
+    monkeypatch.setenv("SQLRS_ORDER_SAMPLE", "1")
+    rng = np.random.default_rng(hash_seed("wide-sampled", shape, asc))
+    k = wide_keys_of(rng, shape, N)
+    if shape == "i64_33bit":          # the two extremes sit in chunks the sample skips (it reads chunks 0, 16, 32, ... and the last rows)
+        k[N // 2], k[N // 3] = 5, 6
+        k[2048 * 3 + 1], k[2048 * 21 + 9] = -17, (1 << 32) + 4 - 17
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(np.arange(N, dtype=np.int64))], names=["k", "row"])
+    hip.profile(True)
+    (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
+    assert got.column(0).equals(exp.column(0)) and got.column(1).equals(exp.column(1))
+    assert prof.get("order_knots", (0, 0))[1] == 1, prof
+    assert prof.get("order_minmax", (0, 0))[1] == (2 if shape == "i64_33bit" else 1), prof
