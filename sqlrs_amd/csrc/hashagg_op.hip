@@ -867,7 +867,7 @@ static int hash_agg_create_impl(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_
   });
 }
 
-static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in);
+static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in, bool filtered = false);
 // what is staged on the host -> one device batch -> the operator
 static int hash_agg_flush_host(sqlrs_hash_agg_t *a) {
   if (!a->hstage.has_schema) return SQLRS_OK;
@@ -884,14 +884,7 @@ static int hash_agg_flush_host(sqlrs_hash_agg_t *a) {
 
 // one iteration of the for_await loop  [ref: hash_agg.rs:44-122]
 int sqlrs_hash_agg_push(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in) {
-  if (!a->parts.empty()) { // wide aggregate list: every part sees every batch
-    a->saw_batch = true;
-    for (sqlrs_hash_agg *p : a->parts) {
-      int st = sqlrs_hash_agg_push(p, in);
-      if (st != SQLRS_OK) return st;
-    }
-    return SQLRS_OK;
-  }
+  if (!a->parts.empty()) a->saw_batch = true; // (wide aggregate list: staged here, handed to the parts by hash_agg_push_device)
   a->hstage.ctx = a->ctx;
   if (a->hstage.accepts(in)) {
     int st = guard(a->ctx, [&] { a->hstage.append(in); });
@@ -933,10 +926,70 @@ static bool hash_agg_try_fused_filter(sqlrs_hash_agg_t *a, const sqlrs_batch_t *
   return true;
 }
 
-static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in0) {
+// Wide aggregate list: every part sees every batch — ONE device copy of it.  A HOST batch is uploaded here once (the parts
+// would each upload it again), and a filter the parts cannot evaluate inside their first partition pass runs here once,
+// the parts taking the kept rows as they are; a fusable filter stays with the parts (each reads the filter column in the
+// pass that reads its keys anyway: nothing is compacted at all).
+static bool any_host_column(const sqlrs_batch_t *b) {
+  for (int c = 0; c < b->num_columns; c++)
+    if (b->columns[c].mem == SQLRS_MEM_HOST && b->columns[c].length > 0) return true;
+  return false;
+}
+static int hash_agg_push_parts(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in0) {
+  const sqlrs_batch_t *in = in0;
+  sqlrs_batch_t *dev = nullptr, *kept = nullptr;
+  bool filtered = false;
+  int st = SQLRS_OK;
+  if (a->has_filter) {
+    bool fusable = false;
+    st = guard(a->ctx, [&] {
+      SQ_HIP(hipSetDevice(a->ctx->device));
+      if (any_host_column(in0) || in0->num_rows < STAGE_DIRECT_ROWS) return;
+      InBatch ib(a->ctx, in0);
+      RowFilter rf;
+      fusable = fusable_row_filter(a->filter, ib, &rf);
+    });
+    if (st != SQLRS_OK) return st;
+    if (!fusable) {
+      std::vector<sqlrs_expr_node_t> nodes = a->filter.nodes;
+      for (size_t i = 0; i < nodes.size(); i++) nodes[i].s = a->filter.strings[i].empty() ? nullptr : a->filter.strings[i].c_str();
+      sqlrs_expr_t fe{nodes.data(), (int32_t)nodes.size(), 0};
+      sqlrs_filter_t *f = nullptr;
+      st = sqlrs_filter_create((sqlrs_ctx_t *)a->ctx, &fe, &f);
+      if (st != SQLRS_OK) return st;
+      st = sqlrs_filter_push(f, in0, SQLRS_MEM_DEVICE, &kept);
+      sqlrs_filter_destroy(f);
+      if (st != SQLRS_OK) return st;
+      in = kept;
+      filtered = true;
+    }
+  }
+  if (any_host_column(in)) {
+    st = guard(a->ctx, [&] {
+      SQ_HIP(hipSetDevice(a->ctx->device));
+      InBatch ib(a->ctx, in);
+      dev = emit_batch(a->ctx, ib.materialize(true), SQLRS_MEM_DEVICE);
+    });
+    if (st != SQLRS_OK) return st;
+    in = dev;
+  }
+  for (sqlrs_hash_agg *p : a->parts) {
+    st = hash_agg_push_device(p, in, filtered);
+    if (st != SQLRS_OK) {
+      a->ctx->last_error = p->ctx->last_error;
+      break;
+    }
+  }
+  if (kept) sqlrs_batch_release(kept);
+  if (dev) sqlrs_batch_release(dev);
+  return st;
+}
+
+static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in0, bool filtered) {
+  if (!a->parts.empty()) return hash_agg_push_parts(a, in0);
   const sqlrs_batch_t *in = in0;
   sqlrs_batch_t *kept = nullptr;
-  if (a->has_filter) { // [ref: filter.rs:13-25 feeding hash_agg.rs:44]
+  if (a->has_filter && !filtered) { // [ref: filter.rs:13-25 feeding hash_agg.rs:44]
     bool fused = false;
     int st = guard(a->ctx, [&] {
       SQ_HIP(hipSetDevice(a->ctx->device));
@@ -997,10 +1050,8 @@ static int hash_agg_push_device(sqlrs_hash_agg_t *a, const sqlrs_batch_t *in0) {
 static DBatch hash_agg_finish_device(sqlrs_hash_agg_t *a);
 int sqlrs_hash_agg_finish(sqlrs_hash_agg_t *a, int out_mem, sqlrs_batch_t **out) {
   if (!a->parts.empty()) { // the parts' group columns are identical (same keys, same first-seen order): side by side
-    for (sqlrs_hash_agg *p : a->parts) {
-      int stp = hash_agg_flush_host(p);
-      if (stp != SQLRS_OK) return stp;
-    }
+    int stp = hash_agg_flush_host(a); // (small host batches are staged in the parent)
+    if (stp != SQLRS_OK) return stp;
     return guard(a->ctx, [&] {
       Ctx *ctx = a->ctx;
       SQ_HIP(hipSetDevice(ctx->device));

@@ -480,7 +480,7 @@ def test_hash_agg_partition_route(hip, oracle, n, groups, nulls):
     assert_same_table(got, exp, float_cols={2, 5})
 
 
-@pytest.mark.parametrize("shape", ["one_batch", "batches", "with_filter"])
+@pytest.mark.parametrize("shape", ["one_batch", "batches", "with_filter", "small_batches_filter_on_an_expression", "device_batch_filter_on_an_expression"])
 def test_hash_agg_wide_aggregate_list(hip, oracle, shape):
     """More than two argument columns / more accumulator cells than one partition-route operator carries (TPC-H Q1's
     SUM(a), SUM(b), SUM(c), AVG parts, COUNT(*) ...): the operator runs as several parts with the same GROUP BY and
@@ -495,14 +495,23 @@ def test_hash_agg_wide_aggregate_list(hip, oracle, shape):
             AggFunc("sum", InputRef(4), abi.INT64)]
     if shape == "batches":
         bs = [batch(rng, 3000, spec), batch(rng, n, spec), batch(rng, 70_000, spec)]
+    elif shape == "small_batches_filter_on_an_expression":   # staged once in the operator, filtered once, then the parts
+        whole = batch(rng, 200_000, spec)
+        bs = [whole.slice(o, 1000) for o in range(0, 200_000, 1000)]
     else:
         bs = [batch(rng, n, spec)]
     pf = (InputRef(3) > Constant(-1.0, abi.FLOAT64)) if shape == "with_filter" else None
+    if shape.endswith("filter_on_an_expression"):            # not `column OP constant`: the Filter operator runs, once
+        pf = (InputRef(3) + InputRef(1)) > Constant(-1.0, abi.FLOAT64)
+    child = [hip.to_device(bs[0])] if shape.startswith("device_batch") else bs
     hip.profile(True)
-    ex = HashAggExecutor(hip, aggs, [InputRef(0)], bs, child_filter=pf)
+    ex = HashAggExecutor(hip, aggs, [InputRef(0)], child, child_filter=pf)
     got = table_of(ex.execute())
     prof = hip.profile_read()
     hip.profile(False)
+    for c in child:
+        if c is not bs[0] and hasattr(c, "release"):
+            c.release()
     if os.environ.get("SQLRS_AGG_SPLIT") != "0" and shape == "one_batch":  # (the other shapes stage / filter below the route's size)
         assert prof.get("lds_agg", (0, 0))[1] >= 2 and prof.get("agg_update", (0, 0))[1] == 0, prof
     kept = list(FilterExecutor(oracle, pf, bs).execute()) if pf is not None else bs
