@@ -772,11 +772,11 @@ __global__ __launch_bounds__(256) void owk_group_table_kernel(const uint32_t *__
 
 // perm_out != nullptr: the payload is the row id — it leaves as the permutation and there is no carried column
 template <int KIND, int NPAY, int R, bool REC>
-__global__ __launch_bounds__(FIN_WG) void owk_finish_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pay,
+__global__ __launch_bounds__(FIN_WG, R == 8 ? 4 : 1) void owk_finish_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pay,
                                                             const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gend,
-                                                            int desc, uint64_t imin, uint64_t *__restrict__ key_out,
-                                                            uint64_t *__restrict__ pay_out, uint32_t *__restrict__ perm_out,
-                                                            uint32_t m_above, uint32_t m_upto) {
+                                                            const uint64_t *__restrict__ sub, uint32_t G, int desc, uint64_t imin,
+                                                            uint64_t *__restrict__ key_out, uint64_t *__restrict__ pay_out,
+                                                            uint32_t *__restrict__ perm_out, uint32_t m_above, uint32_t m_upto) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lo = gstart[blockIdx.x], hi = gend[blockIdx.x];
   if (lo == 0xffffffffu || lo >= hi) return;
@@ -788,13 +788,16 @@ __global__ __launch_bounds__(FIN_WG) void owk_finish_kernel(const uint64_t *__re
   uint32_t *dstart = wcnt + FIN_WAVES * 256;                // [256]
   __shared__ uint32_t s_wsum[FIN_WAVES];
   __shared__ uint32_t s_heavy;
+  __shared__ uint64_t s_mn[FIN_WAVES], s_mx[FIN_WAVES];
   const int w = wave_id(), lane = lane_id();
   // wave w owns chunks [w * cpw, (w + 1) * cpw) of 64 consecutive rows (cpw <= R): all four waves work whatever the group's size
   const uint32_t cpw = ((m + 63) / 64 + FIN_WAVES - 1) / FIN_WAVES;
-  __shared__ uint64_t s_mn[FIN_WAVES], s_mx[FIN_WAVES];
-  // rel = word - smallest word of the group (found below: the splitters bound the group, its own extremes bound it tighter —
-  // and the first / last group, which reach down to 0 / up to the end of the range, are no special case)
-  uint64_t base = 0;
+  // rel = word - base < 2^tb.  Inner groups: base = the group's splitter, width = the distance to the next one.  The first
+  // and the last group reach down to 0 / up to the end of the 64-bit range, far beyond the values their rows have: they take
+  // their own extremes (a workgroup reduction over the rows just loaded)
+  const bool own_extremes = blockIdx.x == 0 || blockIdx.x + 1 == G;
+  uint64_t base = own_extremes ? 0 : sub[blockIdx.x];
+  uint64_t relmax = own_extremes ? 0 : sub[blockIdx.x + 1] - 1 - base; // (next > base: the group has rows)
   int sh = 0, top = 16; // in-LDS passes on bits [sh, top) of rel, counting below sh
   if (threadIdx.x == 0) s_heavy = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -814,27 +817,29 @@ __global__ __launch_bounds__(FIN_WG) void owk_finish_kernel(const uint64_t *__re
         if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
       }
     }
-    if (attempt == 0) { // (rows past the group's end repeat its last row: they do not move the extremes)
-      uint64_t mn = ~0ull, mx = 0;
+    if (attempt == 0) {
+      if (own_extremes) { // (rows past the group's end repeat its last row: they do not move the extremes)
+        uint64_t mn = ~0ull, mx = 0;
 #pragma unroll
-      for (int j = 0; j < R; j++) {
-        mn = min(mn, k[j]);
-        mx = max(mx, k[j]);
-      }
-      mn = wave_min_u64(mn);
-      mx = wave_max_u64(mx);
-      if (lane == 0) {
-        s_mn[w] = mn;
-        s_mx[w] = mx;
-      }
-      __syncthreads();
+        for (int j = 0; j < R; j++) {
+          mn = min(mn, k[j]);
+          mx = max(mx, k[j]);
+        }
+        mn = wave_min_u64(mn);
+        mx = wave_max_u64(mx);
+        if (lane == 0) {
+          s_mn[w] = mn;
+          s_mx[w] = mx;
+        }
+        __syncthreads();
 #pragma unroll
-      for (int q = 0; q < FIN_WAVES; q++) {
-        mn = min(mn, s_mn[q]);
-        mx = max(mx, s_mx[q]);
+        for (int q = 0; q < FIN_WAVES; q++) {
+          mn = min(mn, s_mn[q]);
+          mx = max(mx, s_mx[q]);
+        }
+        base = mn;
+        relmax = mx - mn;
       }
-      base = mn;
-      const uint64_t relmax = mx - mn;
       const int tb = relmax ? 64 - __builtin_clzll(relmax) : 0;
       sh = tb > 16 ? tb - 16 : 0;
       top = sh + 16;
@@ -875,6 +880,7 @@ __global__ __launch_bounds__(FIN_WG) void owk_finish_kernel(const uint64_t *__re
         if (NPAY) spay[p] = v[j];
       }
       __syncthreads();
+      if (!attempt && sh != 0 && shift + 8 >= top) break; // (the counting step below reads the LDS copy, not the registers)
 #pragma unroll
       for (int j = 0; j < R; j++) {
         const uint32_t e = min((uint32_t)(w * cpw + j) * 64 + lane, m - 1);
@@ -894,34 +900,40 @@ __global__ __launch_bounds__(FIN_WG) void owk_finish_kernel(const uint64_t *__re
       }
       return;
     }
-    // rows with equal bits [sh, ..) form runs; inside a run the words are ranked by counting (sword / spay hold the
-    // rows in the order of the last pass)
+    // Rows with equal bits [sh, ..) form runs — of one row, mostly: the group's ~1.5 K rows fall onto 65 536 values.  A row
+    // whose two neighbours have other bits is in place; a row in a run is ranked inside it by counting.  All from the LDS
+    // copy the last pass left (sword / spay), four independent reads per row.
     for (uint32_t e = threadIdx.x; e < m; e += FIN_WG) {
-      const uint64_t me = sword[e], pf = me >> sh;
-      uint32_t before = 0, steps = 0;
-      int64_t q = (int64_t)e - 1;
-      for (; q >= 0 && steps <= OWK_WALK; q--, steps++) {
-        const uint64_t o = sword[q];
-        if ((o >> sh) != pf) break;
-        before += o <= me;
+      const uint64_t me = sword[e], pw = sword[e ? e - 1 : 0], nw = sword[min(e + 1, m - 1)];
+      const uint64_t pv = spay[NPAY ? e : 0];
+      const uint64_t pf = me >> sh;
+      uint32_t pos = e;
+      if ((e && (pw >> sh) == pf) || (e + 1 < m && (nw >> sh) == pf)) {
+        uint32_t before = 0, steps = 0;
+        int64_t q = (int64_t)e - 1;
+        for (; q >= 0 && steps <= OWK_WALK; q--, steps++) {
+          const uint64_t o = sword[q];
+          if ((o >> sh) != pf) break;
+          before += o <= me; // (an equal word further up stays in front: ties in input order)
+        }
+        bool heavy = steps > OWK_WALK;
+        steps = 0;
+        for (uint32_t f = e + 1; f < m && steps <= OWK_WALK; f++, steps++) {
+          const uint64_t o = sword[f];
+          if ((o >> sh) != pf) break;
+          before += o < me;
+        }
+        heavy |= steps > OWK_WALK;
+        if (heavy) {
+          s_heavy = 1; // (the whole group is redone below: what has been written meanwhile is overwritten)
+          continue;
+        }
+        pos = (uint32_t)(q + 1) + before;
       }
-      const uint32_t start = (uint32_t)(q + 1);
-      bool heavy = steps > OWK_WALK;
-      steps = 0;
-      for (uint32_t f = e + 1; f < m && steps <= OWK_WALK; f++, steps++) {
-        const uint64_t o = sword[f];
-        if ((o >> sh) != pf) break;
-        before += o < me;
-      }
-      heavy |= steps > OWK_WALK;
-      if (heavy) {
-        s_heavy = 1; // (the whole group is redone below: what the others write meanwhile is overwritten)
-        continue;
-      }
-      const uint32_t i = lo + start + before;
+      const uint32_t i = lo + pos;
       key_out[i] = order_unimage<KIND>(me + base + imin, desc);
-      if (perm_out) perm_out[i] = (uint32_t)spay[NPAY ? e : 0];
-      else if (NPAY) pay_out[i] = spay[e];
+      if (perm_out) perm_out[i] = (uint32_t)pv;
+      else if (NPAY) pay_out[i] = pv;
     }
     __syncthreads();
     if (!s_heavy) return;
@@ -1038,7 +1050,7 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     auto kfn = owk_finish_kernel<KIND, NP, RR, NP == 1>;                                                             \
     const size_t lds = (size_t)RR * FIN_WG * 8 * (1 + NP) + 4 * (FIN_WAVES * 256 + 256);                             \
     if (lds > 64 * 1024) allow_big_lds(ctx, kfn);                                                                    \
-    kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(out2->as<uint64_t>(), nullptr, gstart->as<uint32_t>(), gend->as<uint32_t>(),      \
+    kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(out2->as<uint64_t>(), nullptr, gstart->as<uint32_t>(), gend->as<uint32_t>(), subp, G, \
                                                      desc, imin, key_out->own_values->as<uint64_t>(), po, perm,         \
                                                      (uint32_t)(ABOVE), (uint32_t)(UPTO));                           \
   } while (0)

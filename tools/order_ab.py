@@ -21,6 +21,8 @@ g = torch.Generator(device=dev).manual_seed(3)
 keys = {"f64_unit": torch.rand(n, dtype=torch.float64, device=dev, generator=g),
         "i64_63bit": torch.randint(-(1 << 62), 1 << 62, (n,), dtype=torch.int64, device=dev, generator=g),
         "f64_normal": torch.randn(n, dtype=torch.float64, device=dev, generator=g)}
+if os.environ.get("SHAPES"):
+    keys = {k: v for k, v in keys.items() if k in os.environ["SHAPES"].split(",")}
 carry = torch.arange(n, dtype=torch.int64, device=dev)
 D = abi.MEM_DEVICE
 pk = InputRef(0).pack()
