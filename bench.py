@@ -1369,29 +1369,44 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     res["Order_outlier_in_unsampled_chunk"] = {"rows": n, "ms": round(ms_out, 3), "ms_exact": round(ms_exact, 3),
                                                "ms_plain": res["Order_int64_1col"]["ms"], "ratio_to_exact": round(ms_out / ms_exact, 3)}
     # ---- keys with more than 32 varying bits (order_fast.hip, order_wide: splitters from a sorted sample): ORDER BY the f64
-    #      column carrying v1, and ORDER BY a column of random 63-bit integers carrying the f64 column.  `ms_general` = the
-    #      same call with SQLRS_ORDER_WIDE=0 (read per call): LSD radix sort of (key, row id) + gathers
-    bo_f = device_batch(abi, [val, v1], [abi.FLOAT64, abi.INT64])
+    #      column (uniform doubles) carrying v1, and ORDER BY a column of random 63-bit integers carrying the f64 column.
+    #      `ms_general` = the same call with SQLRS_ORDER_WIDE=0 (read per call): LSD radix sort of (key, row id) + gathers.
+    #      `check`: key and carried column against torch.sort(stable=True) of the same column (ties keep input order)
     wide = torch.randint(-(1 << 62), 1 << 62, (n,), dtype=torch.int64, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
-    bo_w = device_batch(abi, [wide, val], [abi.INT64, abi.FLOAT64])
-    for leg, batch in (("Order_f64_1col", bo_f), ("Order_int64_63bit_1col", bo_w)):
-        def run_order_wide(batch=batch):
+    for leg, kcol, ccol, kt, ct in (("Order_f64_random", val, v1, abi.FLOAT64, abi.INT64), ("Order_int64_63bit", wide, val, abi.INT64, abi.FLOAT64)):
+        batch = device_batch(abi, [kcol, ccol], [kt, ct])
+        checked = [None]
+
+        def run_order_wide(batch=batch, kcol=kcol, ccol=ccol):
             h = C.c_void_p()
             be.check(be.fn("order_create")(be.ctx, 1, obs, C.byref(h)))
             be.check(be.fn("order_push_retained")(h, batch.ptr))
             o = C.POINTER(abi.Batch)()
             be.check(be.fn("order_finish")(h, D, C.byref(o)))
-            be.fn("batch_release")(o)
+            if checked[0] is None:
+                be.synchronize()
+                w_ = be.wrap(o)
+                got_k = _tensor_view(torch, w_.column(0).values, n, kcol.dtype, dev)
+                got_c = _tensor_view(torch, w_.column(1).values, n, ccol.dtype, dev)
+                exp_k, perm = torch.sort(kcol, stable=True)
+                checked[0] = bool(w_.num_rows == n and torch.equal(got_k, exp_k) and torch.equal(got_c, ccol[perm]))
+                del exp_k, perm, got_k, got_c
+                w_.release()
+            else:
+                be.fn("batch_release")(o)
             be.fn("order_destroy")(h)
         ms_w = timed(run_order_wide)
-        if leg == "Order_f64_1col":
+        if leg == "Order_f64_random":
             profile_of(run_order_wide, "Order_f64")
         os.environ["SQLRS_ORDER_WIDE"] = "0"
         ms_g = timed(run_order_wide)
         os.environ.pop("SQLRS_ORDER_WIDE", None)
         res[leg] = {"rows": n, "ms": round(ms_w, 3), "Mrows_s": round(n / ms_w / 1e3, 1), "GBps": round(by / ms_w / 1e6, 1),
-                    "frac": round(by / ms_w / 1e6 / HBM_PEAK_GBPS, 4), "ms_general": round(ms_g, 3)}
-    del bo_f, bo_w, wide
+                    "frac": round(by / ms_w / 1e6 / HBM_PEAK_GBPS, 4), "ms_general": round(ms_g, 3),
+                    "check": "OK" if checked[0] else "mismatch"}
+        del batch
+        torch.cuda.empty_cache()
+    del wide
     # ---- ORDER BY v1 LIMIT 100 — PhysicalLimit(PhysicalOrder(scan)): offset + limit handed to the sort (sqlrs_order_set_limit),
     #      which sorts the candidates below a sampled threshold only; checked against torch.topk on the same column
     K = 100

@@ -579,7 +579,7 @@ __device__ __forceinline__ void knot_digits(const uint64_t *__restrict__ sk, uin
 
 // LEVEL 1: fixed blocks over the raw column, count matrix digit-major [d * nblocks + block];
 // LEVEL 2: the tile list, count matrix segment-major [(first tile of the segment) * 256 + d * nt + tin]
-template <int KIND, int LEVEL>
+template <int KIND, int LEVEL, bool REC_IN = false>
 __global__ __launch_bounds__(OW_WG) void owk_hist_kernel(const void *__restrict__ src, int64_t n, int desc, uint64_t imin,
                                                          int64_t nblocks, uint32_t *__restrict__ hist,
                                                          const OwkTile *__restrict__ tiles, const uint64_t *__restrict__ sub, uint32_t nk1) {
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(OW_WG) void owk_hist_kernel(const void *__restrict_
 #pragma unroll
   for (int r = 0; r < OW_ITEMS; r++) {
     const int64_t i = t0 + min((uint32_t)(threadIdx.x + r * OW_WG), tl - 1);
-    k[r] = LEVEL == 1 ? order_image<KIND>(src, i, desc) - imin : __builtin_nontemporal_load((const uint64_t *)src + i);
+    k[r] = LEVEL == 1 ? order_image<KIND>(src, i, desc) - imin : __builtin_nontemporal_load((const uint64_t *)src + (REC_IN ? 2 * i : i));
   }
   __syncthreads();
   uint32_t dig[OW_ITEMS];
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(OW_WG) void owk_hist_kernel(const void *__restrict_
 }
 
 // pay == nullptr with NPAY: the payload is the row id (LEVEL 1 only).  REC: {word, payload} records out (LEVEL 2, NPAY)
-template <int KIND, int LEVEL, int NPAY, bool REC>
+template <int KIND, int LEVEL, int NPAY, bool REC, bool REC_IN = false>
 __global__ __launch_bounds__(OW_WG) void owk_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay, int64_t n,
                                                             int desc, uint64_t imin, int64_t nblocks,
                                                             const uint32_t *__restrict__ offsets, uint64_t *__restrict__ words_out,
@@ -662,6 +662,12 @@ __global__ __launch_bounds__(OW_WG) void owk_scatter_kernel(const void *__restri
 #pragma unroll
   for (int j = 0; j < OW_ITEMS; j++) {
     const int64_t i = tbase + min(wrow + j * 64, len - 1);
+    if (REC_IN) { // (the previous pass wrote {word, payload} records)
+      const u64x2 rec = __builtin_nontemporal_load((const u64x2 *)src + i);
+      k[j] = rec.x;
+      v[NPAY ? j : 0] = rec.y;
+      continue;
+    }
     k[j] = LEVEL == 1 ? order_image<KIND>(src, i, desc) - imin : __builtin_nontemporal_load((const uint64_t *)src + i);
     if (NPAY) v[j] = pay ? __builtin_nontemporal_load(pay + i) : (uint64_t)i;
   }
@@ -970,7 +976,11 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   const uint64_t *subp = sub->as<uint64_t>();
   // 1. pass 1: top-level splitters, raw column -> (word, payload) columns
   const int64_t nblocks = ceil_div(n, OW_TILE), ntmax = nblocks + 256;
-  BufP w1 = ctx->alloc(8 * (size_t)n), p1 = has_pay ? ctx->alloc(8 * (size_t)n) : nullptr;
+  // (with a payload both passes write {word, payload} records: a (tile, digit) run is one piece instead of one per column.
+  //  SQLRS_ORDER_WIDE_REC1=0, read per call: pass 1 writes two columns)
+  const char *rec1_e = std::getenv("SQLRS_ORDER_WIDE_REC1");
+  const bool rec1 = has_pay && !(rec1_e && rec1_e[0] == '0');
+  BufP w1 = ctx->alloc((rec1 ? 16 : 8) * (size_t)n), p1 = has_pay && !rec1 ? ctx->alloc(8 * (size_t)n) : nullptr;
   BufP hist = ctx->alloc(4 * (size_t)(256 * nblocks)), offs = ctx->alloc(4 * (size_t)(256 * nblocks)), total = ctx->alloc(8);
   const uint64_t *psrc = (carry && !pay_rows) ? carry->v<uint64_t>() : nullptr;
   dim3 g1((unsigned)nblocks), g2((unsigned)ntmax), b(OW_WG);
@@ -979,7 +989,10 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     owk_hist_kernel<KIND, 1><<<g1, b, 0, ctx->stream>>>(key.values, n, desc, imin, nblocks, hist->as<uint32_t>(), nullptr, subp, nk1);
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(), total->as<uint64_t>());
-    if (has_pay)
+    if (rec1)
+      owk_scatter_kernel<KIND, 1, 1, true><<<g1, b, 0, ctx->stream>>>(key.values, psrc, n, desc, imin, nblocks, offs->as<uint32_t>(),
+                                                                     w1->as<uint64_t>(), nullptr, nullptr, subp, nk1);
+    else if (has_pay)
       owk_scatter_kernel<KIND, 1, 1, false><<<g1, b, 0, ctx->stream>>>(key.values, psrc, n, desc, imin, nblocks, offs->as<uint32_t>(),
                                                                       w1->as<uint64_t>(), p1->as<uint64_t>(), nullptr, subp, nk1);
     else
@@ -997,10 +1010,14 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     owk_tile_fill_kernel<<<dim3((unsigned)ceil_div(ntmax, 256)), dim3(256), 0, ctx->stream>>>(firsttile->as<uint32_t>(), segstart->as<int64_t>(),
                                                                                              (uint32_t)ntmax, (OwkTile *)tiles2->p);
     const OwkTile *tp = (const OwkTile *)tiles2->p;
-    owk_hist_kernel<KIND, 2><<<g2, b, 0, ctx->stream>>>(w1->p, n, desc, imin, ntmax, hist2->as<uint32_t>(), tp, subp, nk1);
+    if (rec1) owk_hist_kernel<KIND, 2, true><<<g2, b, 0, ctx->stream>>>(w1->p, n, desc, imin, ntmax, hist2->as<uint32_t>(), tp, subp, nk1);
+    else owk_hist_kernel<KIND, 2><<<g2, b, 0, ctx->stream>>>(w1->p, n, desc, imin, ntmax, hist2->as<uint32_t>(), tp, subp, nk1);
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist2->as<uint32_t>(), 256 * ntmax, nullptr, offs2->as<uint32_t>(), total->as<uint64_t>());
-    if (has_pay)
+    if (rec1)
+      owk_scatter_kernel<KIND, 2, 1, true, true><<<g2, b, 0, ctx->stream>>>(w1->p, nullptr, n, desc, imin, ntmax, offs2->as<uint32_t>(),
+                                                                           out2->as<uint64_t>(), nullptr, tp, subp, nk1);
+    else if (has_pay)
       owk_scatter_kernel<KIND, 2, 1, true><<<g2, b, 0, ctx->stream>>>(w1->p, p1->as<uint64_t>(), n, desc, imin, ntmax, offs2->as<uint32_t>(),
                                                                      out2->as<uint64_t>(), nullptr, tp, subp, nk1);
     else
@@ -1044,7 +1061,8 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     ProfScope ps(ctx, "order_finish");
     // The splitters balance the groups only statistically (16 samples per group: sizes spread like a Gamma(16), the largest of
     // 65 536 is ~2.5x the mean), and the LDS a workgroup asks for decides how many are resident: the groups of up to
-    // 2048 rows (9 in 10) go through a launch of their own with 37 KB each, the rest through one sized for the largest.
+    // 2048 rows (9 in 10) go through a launch of their own with 37 KB each, those of up to 4096 through a second, the few
+    // beyond (if any) through a third.
 #define SQ_WFIN(NP, RR, ABOVE, UPTO)                                                                                 \
   do {                                                                                                               \
     auto kfn = owk_finish_kernel<KIND, NP, RR, NP == 1>;                                                             \
@@ -1057,8 +1075,8 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
 #define SQ_WFIN_R(NP)                                                                                                \
   do {                                                                                                               \
     SQ_WFIN(NP, 8, 0, 8 * FIN_WG);                                                                                   \
-    if (max_group > 16 * FIN_WG) SQ_WFIN(NP, 24, 8 * FIN_WG, FIN_CAP);                                               \
-    else if (max_group > 8 * FIN_WG) SQ_WFIN(NP, 16, 8 * FIN_WG, 16 * FIN_WG);                                       \
+    if (max_group > 8 * FIN_WG) SQ_WFIN(NP, 16, 8 * FIN_WG, 16 * FIN_WG);                                            \
+    if (max_group > 16 * FIN_WG) SQ_WFIN(NP, 24, 16 * FIN_WG, FIN_CAP);                                              \
   } while (0)
     if (has_pay) SQ_WFIN_R(1);
     else SQ_WFIN_R(0);
