@@ -1368,6 +1368,27 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     torch.cuda.synchronize()
     res["Order_outlier_in_unsampled_chunk"] = {"rows": n, "ms": round(ms_out, 3), "ms_exact": round(ms_exact, 3),
                                                "ms_plain": res["Order_int64_1col"]["ms"], "ratio_to_exact": round(ms_out / ms_exact, 3)}
+    # ---- few distinct keys spread over many bits (50 values over 2^26): a group of equal top bits is far larger than the
+    #      in-LDS finish takes; the call is redone with all key bits through HBM passes (`ms`), against the general path
+    #      (`ms_general`, SQLRS_ORDER_FAST=0 read per call) it used to fall to after the wasted attempt
+    g50 = torch.Generator(device=dev).manual_seed(50)
+    heavy = torch.randint(0, 1 << 26, (50,), dtype=torch.int64, device=dev, generator=g50)[torch.randint(0, 50, (n,), device=dev, generator=g50)]
+    bo_h = device_batch(abi, [heavy, val], [abi.INT64, abi.FLOAT64])
+
+    def run_order_heavy():
+        h = C.c_void_p()
+        be.check(be.fn("order_create")(be.ctx, 1, obs, C.byref(h)))
+        be.check(be.fn("order_push_retained")(h, bo_h.ptr))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("order_finish")(h, D, C.byref(o)))
+        be.fn("batch_release")(o)
+        be.fn("order_destroy")(h)
+    ms_h = timed(run_order_heavy)
+    os.environ["SQLRS_ORDER_FAST"] = "0"
+    ms_hg = timed(run_order_heavy)
+    os.environ.pop("SQLRS_ORDER_FAST", None)
+    res["Order_50_distinct_keys"] = {"rows": n, "ms": round(ms_h, 3), "ms_general": round(ms_hg, 3), "ms_plain": res["Order_int64_1col"]["ms"]}
+    del bo_h, heavy
     # ---- keys with more than 32 varying bits (order_fast.hip, order_wide: splitters from a sorted sample): ORDER BY the f64
     #      column (uniform doubles) carrying v1, and ORDER BY a column of random 63-bit integers carrying the f64 column.
     #      `ms_general` = the same call with SQLRS_ORDER_WIDE=0 (read per call): LSD radix sort of (key, row id) + gathers.

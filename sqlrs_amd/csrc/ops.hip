@@ -610,7 +610,8 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
       }
     }
     // ---- fast route: one plain key column without NULLs (order_fast.hip)
-    static const bool fast_on = [] { const char *e = std::getenv("SQLRS_ORDER_FAST"); return !(e && e[0] == '0'); }(); // test hook
+    const char *fast_e = std::getenv("SQLRS_ORDER_FAST"); // (test / A-B hook, read per call: 0 = the general path)
+    const bool fast_on = !(fast_e && fast_e[0] == '0');
     if (fast_on && o->exprs.size() == 1 && o->exprs[0].nodes.size() == 1 && o->exprs[0].nodes[0].op == SQLRS_EXPR_INPUT_REF) {
       const int kc = o->exprs[0].nodes[0].index;
       if (kc >= 0 && (size_t)kc < all.cols.size()) {

@@ -1092,7 +1092,8 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
 // (nothing produced, return false) when one lies outside — the caller runs the exact form once.
 template <int KIND, int NPAY>
 static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, DCol *key_out, DCol *carry_out,
-                            BufP *perm_out, bool want_perm, bool optimistic, bool *retry_exact, bool *in_order) {
+                            BufP *perm_out, bool want_perm, bool optimistic, bool *retry_exact, bool *in_order,
+                            bool hbm_only = false, bool *retry_hbm_only = nullptr) {
   // 0. key range
   BufP mm = ctx->alloc(16 * OW_MM_SLOTS + 16); // {min = ~0, max = 0} x OW_MM_SLOTS | out-of-range flag (u32), largest group (u32) | inversion seen (u32)
   constexpr int FLAG_W = 2 * OW_MM_SLOTS;       // index of the flag word (u64)
@@ -1169,7 +1170,9 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   // with 16 the finish ran 65 536 workgroups of 30 rows each: 0.64 ms of its 1.27 ms)
   int want = 1;
   while (want < 16 && (n >> want) > 2048) want++;
-  const int top = std::min(kbits, want), rbits = kbits - top;
+  // (hbm_only: every key bit goes through the HBM passes, <= 4 of them, and the finish is a streaming unpack — the second
+  //  try after a group turned out larger than the in-LDS finish takes: few distinct keys spread over many bits)
+  const int top = hbm_only ? kbits : std::min(kbits, want), rbits = kbits - top;
   // 1. stable multi-split passes on bits [32 + rbits, 32 + kbits) of the word, LSD order
   const int64_t nblocks = ceil_div(n, OW_TILE);
   BufP wa = ctx->alloc(8 * (size_t)n), wb = ctx->alloc(8 * (size_t)n);
@@ -1296,7 +1299,10 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     max_group = hv[1];
   } else
     max_group = ctx->fetch_value(gend->as<uint32_t>() + G);
-  if (max_group > FIN_CAP) return false; // heavily repeated top bits: general path
+  if (max_group > FIN_CAP) { // heavily repeated top bits: all bits through HBM passes instead (no limit on a group there)
+    if (retry_hbm_only) *retry_hbm_only = true;
+    return false;
+  }
   if (NPAY) {
     carry_out->dtype = carry->dtype;
     carry_out->length = n;
@@ -1340,12 +1346,18 @@ bool order_fast(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t 
   const bool optimistic = smp_e ? std::atoi(smp_e) != 0 : n >= (1ll << 24); // (1 = whatever the size: tests)
 #define SQ_OF(K)                                                                                                     \
   do {                                                                                                               \
-    bool retry = false;                                                                                              \
-    bool ok = carry ? order_fast_impl<K, 1>(ctx, key, desc, carry, n, key_out, carry_out, perm, want_perm, optimistic, &retry, in_order) \
-                    : order_fast_impl<K, 0>(ctx, key, desc, nullptr, n, key_out, carry_out, perm, want_perm, optimistic, &retry, in_order); \
-    if (ok || !retry) return ok;                                                                                     \
-    return carry ? order_fast_impl<K, 1>(ctx, key, desc, carry, n, key_out, carry_out, perm, want_perm, false, &retry, nullptr) \
-                 : order_fast_impl<K, 0>(ctx, key, desc, nullptr, n, key_out, carry_out, perm, want_perm, false, &retry, nullptr); \
+    bool retry = false, hbm = false;                                                                                 \
+    bool ok = carry ? order_fast_impl<K, 1>(ctx, key, desc, carry, n, key_out, carry_out, perm, want_perm, optimistic, &retry, in_order, false, &hbm) \
+                    : order_fast_impl<K, 0>(ctx, key, desc, nullptr, n, key_out, carry_out, perm, want_perm, optimistic, &retry, in_order, false, &hbm); \
+    if (ok || (!retry && !hbm)) return ok;                                                                           \
+    if (retry) {                                                                                                     \
+      retry = false;                                                                                                 \
+      ok = carry ? order_fast_impl<K, 1>(ctx, key, desc, carry, n, key_out, carry_out, perm, want_perm, false, &retry, nullptr, false, &hbm) \
+                 : order_fast_impl<K, 0>(ctx, key, desc, nullptr, n, key_out, carry_out, perm, want_perm, false, &retry, nullptr, false, &hbm); \
+      if (ok || !hbm) return ok;                                                                                     \
+    }                                                                                                                \
+    return carry ? order_fast_impl<K, 1>(ctx, key, desc, carry, n, key_out, carry_out, perm, want_perm, false, &retry, nullptr, true) \
+                 : order_fast_impl<K, 0>(ctx, key, desc, nullptr, n, key_out, carry_out, perm, want_perm, false, &retry, nullptr, true); \
   } while (0)
   switch (key.dtype) {
   case SQLRS_INT64: SQ_OF(OKIND_I64);

@@ -259,3 +259,21 @@ def test_order_wide_keys_with_sampled_range(hip, oracle, shape, asc, monkeypatch
     assert got.column(0).equals(exp.column(0)) and got.column(1).equals(exp.column(1))
     assert prof.get("order_knots", (0, 0))[1] == 1, prof
     assert prof.get("order_minmax", (0, 0))[1] == (2 if shape == "i64_33bit" else 1), prof
+
+
+@pytest.mark.parametrize("asc", [True, False])
+def test_order_few_distinct_keys_spread_over_many_bits(hip, oracle, asc):
+    """50 distinct keys over 2^26: a group of equal top bits holds tens of thousands of rows, more than the in-LDS finish
+    takes — the call is redone with every key bit through the HBM passes (four here, then a streaming unpack) instead of
+    falling to the general path: no `radix_sort` scope, six `order_split` launches (2 + 4)"""
+    rng = np.random.default_rng(50 + asc)
+    k = keys_of(rng, "i64_heavy_groups")
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(np.arange(N, dtype=np.int64)), pa.array(rng.random(N))], names=["k", "row", "x"])
+    hip.profile(True)
+    (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
+    for i in range(3):
+        assert got.column(i).equals(exp.column(i)), i
+    assert prof.get("radix_sort", (0, 0))[1] == 0 and prof.get("order_split", (0, 0))[1] == 6, prof
