@@ -18,8 +18,10 @@
 // HBM traffic for 1e8 rows, 31 key bits, one carried column: 0.8 (min/max) + 2 x (0.8 + 3.2) + 0.8
 // (boundaries) + 3.6 = 13.2 GB, against 9.6 GB of sort passes + 12.8 GB of gather fetches before.
 // Stability (ties in input order, like the general path) holds because every pass is stable.
-// A group larger than FIN_CAP (heavily repeated keys with many low bits) sends the call back to the
-// general path; rbits = 0 (all key bits sorted in HBM) has no such limit.
+// A group larger than FIN_CAP (heavily repeated keys with many low bits) sends the call through the same
+// passes with rbits = 0 (all key bits sorted in HBM, <= 4 passes: no limit on a group there).
+// Keys with MORE than 32 varying bits (random doubles, 63-bit ids) cannot ride in that word: `order_wide`
+// below replaces the bits by splitters from a sorted sample and keeps the shape (two passes + in-LDS finish).
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "prims.hpp"
