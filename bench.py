@@ -1428,6 +1428,45 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
         del batch
         torch.cuda.empty_cache()
     del wide
+    # ---- ORDER BY a, b (order.rs:27-66 lexsort): a = 1000 distinct int64 values, b = v1 (31 bits), carrying the f64 column —
+    #      one composite key of 41 bits through the single-key routes, both key columns decoded from the sorted composite
+    #      (order_fast.hip, order_composite); `ms_general` = SQLRS_ORDER_COMPOSITE=0 (read per call): one stable radix sort of
+    #      (key, row id) per key + a gather per column; `check`: against torch's stable sorts composed last key first
+    ka = torch.randint(0, 1000, (n,), dtype=torch.int64, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
+    bo2 = device_batch(abi, [ka, v1, val], [abi.INT64, abi.INT64, abi.FLOAT64])
+    pk0, pk1 = InputRef(0).pack(), InputRef(1).pack()
+    obs2 = (abi.OrderBy * 2)(abi.OrderBy(pk0.abi, 1, 0), abi.OrderBy(pk1.abi, 1, 0))
+    checked2 = [None]
+
+    def run_order2():
+        h = C.c_void_p()
+        be.check(be.fn("order_create")(be.ctx, 2, obs2, C.byref(h)))
+        be.check(be.fn("order_push_retained")(h, bo2.ptr))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("order_finish")(h, D, C.byref(o)))
+        if checked2[0] is None:
+            be.synchronize()
+            w_ = be.wrap(o)
+            got = [_tensor_view(torch, w_.column(i).values, n, t, dev) for i, t in enumerate((torch.int64, torch.int64, torch.float64))]
+            p1 = torch.sort(v1, stable=True).indices
+            perm = p1[torch.sort(ka[p1], stable=True).indices]
+            checked2[0] = bool(w_.num_rows == n and torch.equal(got[0], ka[perm]) and torch.equal(got[1], v1[perm]) and torch.equal(got[2], val[perm]))
+            del got, p1, perm
+            w_.release()
+        else:
+            be.fn("batch_release")(o)
+        be.fn("order_destroy")(h)
+    ms_2 = timed(run_order2)
+    profile_of(run_order2, "Order two keys")
+    os.environ["SQLRS_ORDER_COMPOSITE"] = "0"
+    ms_2g = timed(run_order2)
+    os.environ.pop("SQLRS_ORDER_COMPOSITE", None)
+    by2 = 24 * n + 24 * n
+    res["Order_two_int64_keys"] = {"rows": n, "ms": round(ms_2, 3), "Mrows_s": round(n / ms_2 / 1e3, 1), "GBps": round(by2 / ms_2 / 1e6, 1),
+                                   "frac": round(by2 / ms_2 / 1e6 / HBM_PEAK_GBPS, 4), "ms_general": round(ms_2g, 3),
+                                   "check": "OK" if checked2[0] else "mismatch"}
+    del bo2, ka
+    torch.cuda.empty_cache()
     # ---- ORDER BY v1 LIMIT 100 — PhysicalLimit(PhysicalOrder(scan)): offset + limit handed to the sort (sqlrs_order_set_limit),
     #      which sorts the candidates below a sampled threshold only; checked against torch.topk on the same column
     K = 100

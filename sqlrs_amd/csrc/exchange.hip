@@ -181,8 +181,8 @@ int64_t sqlrs_exchange_bytes_off_rank(const sqlrs_exchange_t *x) { return x->byt
 void sqlrs_exchange_destroy(sqlrs_exchange_t *x) {
   if (!x) return;
   if (x->comm) {
-    hipSetDevice(x->ctx->device);
-    hipStreamSynchronize(x->ctx->stream);
+    (void)hipSetDevice(x->ctx->device);
+    (void)hipStreamSynchronize(x->ctx->stream);
     rccl().CommDestroy(x->comm);
   }
   delete x;

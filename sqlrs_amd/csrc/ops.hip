@@ -659,6 +659,65 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
         }
       }
     }
+    // ---- several plain integer keys whose ranges together fit 64 bits: one composite key through the same routes
+    if (fast_on && o->exprs.size() >= 2 && o->exprs.size() <= 4 && n >= (1 << 20)) {
+      std::vector<int> kcs;
+      for (const Expr &e : o->exprs) {
+        if (e.nodes.size() != 1 || e.nodes[0].op != SQLRS_EXPR_INPUT_REF || e.nodes[0].index < 0 || (size_t)e.nodes[0].index >= all.cols.size()) break;
+        kcs.push_back(e.nodes[0].index);
+      }
+      if (kcs.size() == o->exprs.size()) {
+        auto is_key = [&](size_t ci) { return std::find(kcs.begin(), kcs.end(), (int)ci) != kcs.end(); };
+        int cc = -1, others = 0;
+        for (size_t ci = 0; ci < all.cols.size(); ci++) {
+          if (is_key(ci)) continue;
+          others++;
+          const DCol &c = all.cols[ci];
+          if (cc < 0 && width_of(c.dtype) == 8 && c.stride != 0 && !(c.validity && c.null_count != 0)) cc = (int)ci;
+        }
+        const bool want_perm = others > (cc >= 0 ? 1 : 0);
+        std::vector<const DCol *> kp;
+        std::vector<int> kd;
+        for (size_t k = 0; k < kcs.size(); k++) {
+          kp.push_back(&all.cols[(size_t)kcs[k]]);
+          kd.push_back(o->asc[k] ? 0 : 1);
+        }
+        std::vector<DCol> kout;
+        DCol co;
+        BufP fperm;
+        bool done = false, in_order = false;
+        try {
+          done = order_composite(ctx, kp, kd, cc >= 0 ? &all.cols[(size_t)cc] : nullptr, n, &kout, &co, &fperm, want_perm, &in_order);
+        } catch (const Error &e) { // (an allocation failure of the attempt is "route not taken", as above)
+          if (e.status != SQLRS_ERR_DEVICE || e.msg.rfind("hipMalloc(", 0) != 0) throw;
+          (void)hipGetLastError();
+          kout.clear();
+          co = DCol();
+          fperm = nullptr;
+        }
+        if (in_order) { // the rows arrived in the requested order
+          for (DCol &c : all.cols) {
+            if (c.stride == 0) c = materialize_scalar(ctx, c, n);
+            const bool borrowed = (c.values && !c.own_values) || (c.validity && !c.own_validity) || (c.offsets && !c.own_offsets);
+            if (borrowed) c = copy_column(ctx, c);
+          }
+          *out = emit_batch(ctx, std::move(all), out_mem);
+          return;
+        }
+        if (done) {
+          DBatch r;
+          r.rows = n;
+          for (size_t ci = 0; ci < all.cols.size(); ci++) {
+            const auto at = std::find(kcs.begin(), kcs.end(), (int)ci);
+            if (at != kcs.end()) r.cols.push_back(kout[(size_t)(at - kcs.begin())]);
+            else if ((int)ci == cc && co.values) r.cols.push_back(co);
+            else r.cols.push_back(gather_column(ctx, all.cols[ci], fperm->p, false, nullptr, n));
+          }
+          *out = emit_batch(ctx, std::move(r), out_mem);
+          return;
+        }
+      }
+    }
     BufP perm = ctx->alloc(4 * (size_t)n1), keys = ctx->alloc(8 * (size_t)n1);
     iota_u32(ctx, perm->as<uint32_t>(), n);
     dim3 g((unsigned)ceil_div(n1, 256)), b(256);

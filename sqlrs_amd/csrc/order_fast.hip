@@ -1370,4 +1370,122 @@ bool order_fast(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t 
 #undef SQ_OF
 }
 
+// ==== several integer keys =========================================================================================
+// ORDER BY a, b [, c, d] over plain int64 / int32 columns without NULLs (order.rs:27-66: lexsort over the sort columns): when
+// the keys' ranges together need <= 64 bits, the rows are ordered by ONE composite key
+//     field_c = asc ? value - min_c : max_c - value,   composite = field_0 : field_1 : ...   (most significant first)
+// through the single-key routes above (<= 32 bits: the narrow one; more: the splitter route), and the key columns of the
+// result are decoded from the sorted composite instead of being gathered.  The general path runs one stable radix sort
+// of (key, row id) pairs per key, last key first, and gathers every column.
+struct CompKeys {
+  const void *vals[4];
+  uint64_t imin[4], imax[4];
+  int kind[4], bits[4], desc[4];
+  int nk;
+};
+__device__ __forceinline__ uint64_t comp_image(const CompKeys &ck, int c, int64_t i) {
+  return ck.kind[c] == OKIND_I64 ? order_image<OKIND_I64>(ck.vals[c], i, 0) : order_image<OKIND_I32>(ck.vals[c], i, 0);
+}
+__global__ __launch_bounds__(256) void comp_build_kernel(CompKeys ck, int64_t n, int64_t *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t comp = 0;
+  for (int c = 0; c < ck.nk; c++) {
+    if (ck.bits[c] == 0) continue; // (a constant column; a shift by 64 would also be undefined)
+    const uint64_t img = comp_image(ck, c, i);
+    comp = (ck.bits[c] < 64 ? comp << ck.bits[c] : 0) | (ck.desc[c] ? ck.imax[c] - img : img - ck.imin[c]);
+  }
+  out[i] = (int64_t)(comp ^ (1ull << 63)); // (as int64 whose order-preserving image is the composite itself)
+}
+__global__ __launch_bounds__(256) void comp_decode_kernel(const int64_t *__restrict__ comp, int64_t n, int shift, int bits, int desc,
+                                                          uint64_t imin, uint64_t imax, int kind, void *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t c = (uint64_t)comp[i] ^ (1ull << 63);
+  const uint64_t field = bits == 0 ? 0 : ((c >> shift) & (bits < 64 ? (1ull << bits) - 1 : ~0ull));
+  const int64_t v = ordered_to_i64(desc ? imax - field : imin + field);
+  if (kind == OKIND_I32) ((int32_t *)out)[i] = (int32_t)v;
+  else ((int64_t *)out)[i] = v;
+}
+
+bool order_composite(Ctx *ctx, const std::vector<const DCol *> &keys, const std::vector<int> &desc, const DCol *carry, int64_t n,
+                     std::vector<DCol> *keys_out, DCol *carry_out, BufP *perm, bool want_perm, bool *in_order) {
+  if (in_order) *in_order = false;
+  const int nk = (int)keys.size();
+  if (nk < 2 || nk > 4 || n < (1 << 20) || n > 0xffffffffll) return false;
+  if (const char *e = std::getenv("SQLRS_ORDER_COMPOSITE")) // (A/B hook, read per call: 0 = the general path)
+    if (e[0] == '0') return false;
+  CompKeys ck{};
+  ck.nk = nk;
+  for (int c = 0; c < nk; c++) {
+    const DCol &k = *keys[(size_t)c];
+    if ((k.dtype != SQLRS_INT64 && k.dtype != SQLRS_INT32) || k.stride == 0 || (k.validity && k.null_count != 0)) return false;
+    ck.vals[c] = k.values;
+    ck.kind[c] = k.dtype == SQLRS_INT64 ? OKIND_I64 : OKIND_I32;
+    ck.desc[c] = desc[(size_t)c];
+  }
+  // ranges of the keys: one pass per column, one round trip for all
+  constexpr size_t MM_WORDS = 2 * OW_MM_SLOTS + 2;
+  BufP mm = ctx->alloc(8 * MM_WORDS * (size_t)nk);
+  {
+    ProfScope ps(ctx, "order_minmax");
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, (int64_t)256 * 8), 8 * (int64_t)ctx->num_cus));
+    for (int c = 0; c < nk; c++) {
+      unsigned long long *m = mm->as<unsigned long long>() + MM_WORDS * (size_t)c;
+      order_minmax_init_kernel<<<dim3(1), dim3(128), 0, ctx->stream>>>(m);
+      if (ck.kind[c] == OKIND_I64) order_minmax_kernel<OKIND_I64><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(ck.vals[c], n, 0, m, 1);
+      else order_minmax_kernel<OKIND_I32><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(ck.vals[c], n, 0, m, 1);
+    }
+    SQ_HIP(hipGetLastError());
+  }
+  const uint64_t *h = (const uint64_t *)ctx->fetch(mm->p, 8 * MM_WORDS * (size_t)nk);
+  int total = 0;
+  for (int c = 0; c < nk; c++) {
+    uint64_t lo = ~0ull, hi = 0;
+    for (int q = 0; q < OW_MM_SLOTS; q++) {
+      lo = std::min(lo, h[MM_WORDS * (size_t)c + 2 * q]);
+      hi = std::max(hi, h[MM_WORDS * (size_t)c + 2 * q + 1]);
+    }
+    if (lo > hi) return false;
+    ck.imin[c] = lo;
+    ck.imax[c] = hi;
+    ck.bits[c] = hi == lo ? 0 : 64 - __builtin_clzll(hi - lo);
+    total += ck.bits[c];
+  }
+  if (total > 64) return false; // the composite does not fit one word: general path
+  DCol comp;
+  comp.dtype = SQLRS_INT64;
+  comp.length = n;
+  comp.null_count = 0;
+  comp.own_values = ctx->alloc(8 * (size_t)n + 16);
+  comp.values = comp.own_values->p;
+  {
+    ProfScope ps(ctx, "order_keys");
+    comp_build_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(ck, n, comp.own_values->as<int64_t>());
+    SQ_HIP(hipGetLastError());
+  }
+  DCol sorted;
+  if (!order_fast(ctx, comp, 0, carry, n, &sorted, carry_out, perm, want_perm, in_order)) return false;
+  comp = DCol(); // (its buffer goes back to the pool before the outputs are allocated)
+  {
+    ProfScope ps(ctx, "order_keys");
+    keys_out->clear();
+    int shift = total;
+    for (int c = 0; c < nk; c++) {
+      shift -= ck.bits[c];
+      DCol o;
+      o.dtype = keys[(size_t)c]->dtype;
+      o.length = n;
+      o.null_count = 0;
+      o.own_values = ctx->alloc((ck.kind[c] == OKIND_I32 ? 4 : 8) * (size_t)n + 16);
+      o.values = o.own_values->p;
+      comp_decode_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
+          (const int64_t *)sorted.values, n, shift, ck.bits[c], ck.desc[c], ck.imin[c], ck.imax[c], ck.kind[c], o.own_values->p);
+      keys_out->push_back(o);
+    }
+    SQ_HIP(hipGetLastError());
+  }
+  return true;
+}
+
 } // namespace sq

@@ -277,3 +277,60 @@ def test_order_few_distinct_keys_spread_over_many_bits(hip, oracle, asc):
     for i in range(3):
         assert got.column(i).equals(exp.column(i)), i
     assert prof.get("radix_sort", (0, 0))[1] == 0 and prof.get("order_split", (0, 0))[1] == 6, prof
+
+
+def composite_case(rng, shape, n):
+    """-> (key arrays most significant first, asc flags, composite route expected)"""
+    if shape == "two_small_ranges":          # 10 + 14 bits: the narrow route
+        return [rng.integers(0, 1000, n, dtype=np.int64), rng.integers(-5000, 5000, n, dtype=np.int64)], [True, True], True
+    if shape == "int32_then_wide_int64":     # 7 + 40 bits: the splitter route
+        return [rng.integers(-50, 50, n).astype(np.int32), rng.integers(0, 1 << 40, n, dtype=np.int64)], [False, True], True
+    if shape == "three_keys_mixed_directions":
+        return [rng.integers(0, 12, n).astype(np.int32), rng.integers(1990, 2025, n, dtype=np.int64),
+                rng.integers(-(1 << 30), 1 << 30, n, dtype=np.int64)], [True, False, False], True
+    if shape == "four_keys_with_a_constant":
+        return [rng.integers(0, 3, n, dtype=np.int64), np.full(n, -7, dtype=np.int64), rng.integers(0, 200, n).astype(np.int32),
+                rng.integers(0, 5, n, dtype=np.int64)], [True, True, False, True], True
+    if shape == "ties_on_every_key":         # 40 distinct (a, b) pairs: the row-id column shows the input order inside a pair
+        return [rng.integers(0, 8, n, dtype=np.int64), rng.integers(0, 5, n, dtype=np.int64)], [False, True], True
+    if shape == "ranges_beyond_64_bits":     # 63 + 63 bits: general path
+        return [rng.integers(-(1 << 62), 1 << 62, n, dtype=np.int64), rng.integers(-(1 << 62), 1 << 62, n, dtype=np.int64)], [True, True], False
+    if shape == "exactly_64_bits":           # 32 + 32 bits
+        a = rng.integers(0, 1 << 32, n, dtype=np.int64)
+        b = rng.integers(-(1 << 31), 1 << 31, n, dtype=np.int64)
+        a[0], a[1], b[2], b[3] = 0, (1 << 32) - 1, -(1 << 31), (1 << 31) - 1
+        a[5:5000] = a[5]                     # ... with ties on the first key
+        return [a, b], [True, False], True
+    raise ValueError(shape)
+
+
+@pytest.mark.parametrize("shape", ["two_small_ranges", "int32_then_wide_int64", "three_keys_mixed_directions", "four_keys_with_a_constant",
+                                   "ties_on_every_key", "ranges_beyond_64_bits", "exactly_64_bits"])
+@pytest.mark.parametrize("extra", ["none", "carry", "carry_and_more"])
+def test_order_by_several_integer_keys(hip, oracle, shape, extra):
+    """ORDER BY a, b [, c, d] over plain integer columns: one composite key through the single-key routes, key columns decoded
+    from the sorted composite (order_fast.hip, order_composite) — against the oracle's lexsort (order.rs:27-66), ties in
+    input order; `order_split` launches show the route, `radix_sort` launches beyond the sample's the general path"""
+    rng = np.random.default_rng(hash_seed("composite", shape, extra))
+    keys, asc, composite = composite_case(rng, shape, N)
+    cols = list(keys)
+    names = [f"k{i}" for i in range(len(keys))]
+    if extra != "none":
+        cols.append(np.arange(N, dtype=np.int64))
+        names.append("row")
+    arrays = [pa.array(c) for c in cols]
+    if extra == "carry_and_more":
+        arrays += [pa.array(rng.random(N), mask=rng.random(N) < 0.1), pa.array([None if i % 13 == 0 else f"s{i % 89}" for i in range(N)])]
+        names += ["f", "s"]
+    # (the key columns are not the first columns of the table: k0 last)
+    order = list(range(1, len(arrays))) + [0]
+    b = pa.RecordBatch.from_arrays([arrays[i] for i in order], names=[names[i] for i in order])
+    ob = [OrderBy(InputRef(order.index(i)), asc=asc[i]) for i in range(len(keys))]
+    hip.profile(True)
+    (got,) = list(OrderExecutor(hip, ob, [b.slice(0, N // 4), b.slice(N // 4)]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    (exp,) = list(OrderExecutor(oracle, ob, [b]).execute())
+    for i in range(b.num_columns):
+        assert got.column(i).equals(exp.column(i)), b.schema.names[i]
+    assert (prof.get("order_split", (0, 0))[1] > 0) == composite, prof
