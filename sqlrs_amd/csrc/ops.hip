@@ -660,7 +660,8 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
       }
     }
     // ---- several plain integer keys whose ranges together fit 64 bits: one composite key through the same routes
-    if (fast_on && o->exprs.size() >= 2 && o->exprs.size() <= 4 && n >= (1 << 20)) {
+    // (also ONE integer key with NULLs, which the route above leaves alone: a valid bit in front of the value, NULLs first)
+    if (fast_on && o->exprs.size() >= 1 && o->exprs.size() <= 4 && n >= (1 << 20)) {
       std::vector<int> kcs;
       for (const Expr &e : o->exprs) {
         if (e.nodes.size() != 1 || e.nodes[0].op != SQLRS_EXPR_INPUT_REF || e.nodes[0].index < 0 || (size_t)e.nodes[0].index >= all.cols.size()) break;

@@ -1370,17 +1370,19 @@ bool order_fast(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t 
 #undef SQ_OF
 }
 
-// ==== several integer keys =========================================================================================
-// ORDER BY a, b [, c, d] over plain int64 / int32 columns without NULLs (order.rs:27-66: lexsort over the sort columns): when
-// the keys' ranges together need <= 64 bits, the rows are ordered by ONE composite key
-//     field_c = asc ? value - min_c : max_c - value,   composite = field_0 : field_1 : ...   (most significant first)
+// ==== several integer keys, nullable integer keys ====================================================================
+// ORDER BY a, b [, c, d] over plain int64 / int32 columns (order.rs:27-66: lexsort over the sort columns, NULLs first
+// whatever the direction): when the keys' ranges together need <= 64 bits, the rows are ordered by ONE composite key
+//     field_c = [valid bit, only for a column with NULLs :] asc ? value - min_c : max_c - value      (a NULL: all zero)
+//     composite = field_0 : field_1 : ...   (most significant first)
 // through the single-key routes above (<= 32 bits: the narrow one; more: the splitter route), and the key columns of the
-// result are decoded from the sorted composite instead of being gathered.  The general path runs one stable radix sort
-// of (key, row id) pairs per key, last key first, and gathers every column.
+// result — values and validity — are decoded from the sorted composite instead of being gathered.  The general path runs
+// one stable radix sort of (key, row id) pairs per key, last key first, and gathers every column.
 struct CompKeys {
   const void *vals[4];
+  const uint64_t *valid[4]; // nullptr = no NULLs in this key
   uint64_t imin[4], imax[4];
-  int kind[4], bits[4], desc[4];
+  int kind[4], bits[4], desc[4]; // bits: of the value part (the valid bit sits above it)
   int nk;
 };
 __device__ __forceinline__ uint64_t comp_image(const CompKeys &ck, int c, int64_t i) {
@@ -1391,40 +1393,61 @@ __global__ __launch_bounds__(256) void comp_build_kernel(CompKeys ck, int64_t n,
   if (i >= n) return;
   uint64_t comp = 0;
   for (int c = 0; c < ck.nk; c++) {
-    if (ck.bits[c] == 0) continue; // (a constant column; a shift by 64 would also be undefined)
-    const uint64_t img = comp_image(ck, c, i);
-    comp = (ck.bits[c] < 64 ? comp << ck.bits[c] : 0) | (ck.desc[c] ? ck.imax[c] - img : img - ck.imin[c]);
+    const int fb = ck.bits[c] + (ck.valid[c] ? 1 : 0);
+    if (fb == 0) continue; // (a constant column; a shift by 64 would also be undefined)
+    uint64_t field = 0;
+    if (!ck.valid[c] || ((ck.valid[c][i >> 6] >> (i & 63)) & 1ull)) {
+      const uint64_t img = comp_image(ck, c, i);
+      field = (ck.desc[c] ? ck.imax[c] - img : img - ck.imin[c]) | (ck.valid[c] ? 1ull << ck.bits[c] : 0ull);
+    }
+    comp = (fb < 64 ? comp << fb : 0) | field;
   }
   out[i] = (int64_t)(comp ^ (1ull << 63)); // (as int64 whose order-preserving image is the composite itself)
 }
-__global__ __launch_bounds__(256) void comp_decode_kernel(const int64_t *__restrict__ comp, int64_t n, int shift, int bits, int desc,
-                                                          uint64_t imin, uint64_t imax, int kind, void *__restrict__ out) {
+// one key column out of the sorted composite; out_valid (nullable keys): one word per wave
+__global__ __launch_bounds__(256) void comp_decode_kernel(const int64_t *__restrict__ comp, int64_t n, int shift, int bits, int nullable,
+                                                          int desc, uint64_t imin, uint64_t imax, int kind, void *__restrict__ out,
+                                                          uint64_t *__restrict__ out_valid) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t c = (uint64_t)comp[i] ^ (1ull << 63);
-  const uint64_t field = bits == 0 ? 0 : ((c >> shift) & (bits < 64 ? (1ull << bits) - 1 : ~0ull));
-  const int64_t v = ordered_to_i64(desc ? imax - field : imin + field);
-  if (kind == OKIND_I32) ((int32_t *)out)[i] = (int32_t)v;
-  else ((int64_t *)out)[i] = v;
+  const int fb = bits + nullable;
+  bool valid = false;
+  int64_t v = 0;
+  if (i < n) {
+    const uint64_t c = (uint64_t)comp[i] ^ (1ull << 63);
+    const uint64_t field = fb == 0 ? 0 : ((c >> shift) & (fb < 64 ? (1ull << fb) - 1 : ~0ull));
+    valid = !nullable || ((field >> bits) & 1ull);
+    const uint64_t f = bits == 0 ? 0 : (field & (bits < 64 ? (1ull << bits) - 1 : ~0ull));
+    if (valid) v = ordered_to_i64(desc ? imax - f : imin + f);
+    if (kind == OKIND_I32) ((int32_t *)out)[i] = (int32_t)v;
+    else ((int64_t *)out)[i] = v;
+  }
+  if (out_valid) {
+    const uint64_t m = __ballot(valid);
+    if (lane_id() == 0 && (i >> 6) < (n + 63) / 64) out_valid[i >> 6] = m;
+  }
 }
 
 bool order_composite(Ctx *ctx, const std::vector<const DCol *> &keys, const std::vector<int> &desc, const DCol *carry, int64_t n,
                      std::vector<DCol> *keys_out, DCol *carry_out, BufP *perm, bool want_perm, bool *in_order) {
   if (in_order) *in_order = false;
   const int nk = (int)keys.size();
-  if (nk < 2 || nk > 4 || n < (1 << 20) || n > 0xffffffffll) return false;
+  if (nk < 1 || nk > 4 || n < (1 << 20) || n > 0xffffffffll) return false;
   if (const char *e = std::getenv("SQLRS_ORDER_COMPOSITE")) // (A/B hook, read per call: 0 = the general path)
     if (e[0] == '0') return false;
   CompKeys ck{};
   ck.nk = nk;
+  bool any_nullable = false;
   for (int c = 0; c < nk; c++) {
     const DCol &k = *keys[(size_t)c];
-    if ((k.dtype != SQLRS_INT64 && k.dtype != SQLRS_INT32) || k.stride == 0 || (k.validity && k.null_count != 0)) return false;
+    if ((k.dtype != SQLRS_INT64 && k.dtype != SQLRS_INT32) || k.stride == 0) return false;
     ck.vals[c] = k.values;
+    ck.valid[c] = (k.validity && k.null_count != 0) ? k.validity : nullptr;
+    any_nullable |= ck.valid[c] != nullptr;
     ck.kind[c] = k.dtype == SQLRS_INT64 ? OKIND_I64 : OKIND_I32;
     ck.desc[c] = desc[(size_t)c];
   }
-  // ranges of the keys: one pass per column, one round trip for all
+  if (nk == 1 && !any_nullable) return false; // (the single-key route has had its say)
+  // ranges of the keys (over all rows: what sits under a NULL can only widen them): one pass per column, one round trip for all
   constexpr size_t MM_WORDS = 2 * OW_MM_SLOTS + 2;
   BufP mm = ctx->alloc(8 * MM_WORDS * (size_t)nk);
   {
@@ -1450,9 +1473,12 @@ bool order_composite(Ctx *ctx, const std::vector<const DCol *> &keys, const std:
     ck.imin[c] = lo;
     ck.imax[c] = hi;
     ck.bits[c] = hi == lo ? 0 : 64 - __builtin_clzll(hi - lo);
-    total += ck.bits[c];
+    total += ck.bits[c] + (ck.valid[c] ? 1 : 0);
   }
   if (total > 64) return false; // the composite does not fit one word: general path
+  std::vector<int64_t> nulls((size_t)nk, 0);
+  for (int c = 0; c < nk; c++)
+    if (ck.valid[c]) nulls[(size_t)c] = count_nulls(ctx, *keys[(size_t)c]);
   DCol comp;
   comp.dtype = SQLRS_INT64;
   comp.length = n;
@@ -1472,15 +1498,21 @@ bool order_composite(Ctx *ctx, const std::vector<const DCol *> &keys, const std:
     keys_out->clear();
     int shift = total;
     for (int c = 0; c < nk; c++) {
-      shift -= ck.bits[c];
+      const int nullable = ck.valid[c] ? 1 : 0;
+      shift -= ck.bits[c] + nullable;
       DCol o;
       o.dtype = keys[(size_t)c]->dtype;
       o.length = n;
-      o.null_count = 0;
+      o.null_count = nulls[(size_t)c];
       o.own_values = ctx->alloc((ck.kind[c] == OKIND_I32 ? 4 : 8) * (size_t)n + 16);
       o.values = o.own_values->p;
+      if (nullable) {
+        o.own_validity = ctx->alloc(8 * (size_t)ceil_div(n, 64) + 16);
+        o.validity = o.own_validity->as<uint64_t>();
+      }
       comp_decode_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(
-          (const int64_t *)sorted.values, n, shift, ck.bits[c], ck.desc[c], ck.imin[c], ck.imax[c], ck.kind[c], o.own_values->p);
+          (const int64_t *)sorted.values, n, shift, ck.bits[c], nullable, ck.desc[c], ck.imin[c], ck.imax[c], ck.kind[c], o.own_values->p,
+          nullable ? o.own_validity->as<uint64_t>() : nullptr);
       keys_out->push_back(o);
     }
     SQ_HIP(hipGetLastError());

@@ -93,8 +93,9 @@ void iota_u32(Ctx *ctx, uint32_t *out, int64_t n);
 // travel through <= 2 HBM passes + an in-LDS finish; false = shape / data do not fit (general path)
 bool order_fast(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, DCol *key_out, DCol *carry_out,
                 BufP *perm, bool want_perm, bool *in_order = nullptr);
-// 2..4 plain int64 / int32 key columns without NULLs whose ranges together fit 64 bits: ordered by one composite key through
-// order_fast; keys_out = the key columns in output order (decoded from the sorted composite).  carry_out stays empty when the
+// 2..4 plain int64 / int32 key columns, or 1..4 when one has NULLs (NULLs first: a valid bit in front of the value), whose
+// fields together fit 64 bits: ordered by one composite key through order_fast; keys_out = the key columns in output order
+// (values and validity decoded from the sorted composite).  carry_out stays empty when the
 // row ids travelled instead (want_perm with wide composites): the caller gathers that column like the others
 bool order_composite(Ctx *ctx, const std::vector<const DCol *> &keys, const std::vector<int> &desc, const DCol *carry, int64_t n,
                      std::vector<DCol> *keys_out, DCol *carry_out, BufP *perm, bool want_perm, bool *in_order);

@@ -301,11 +301,25 @@ def composite_case(rng, shape, n):
         a[0], a[1], b[2], b[3] = 0, (1 << 32) - 1, -(1 << 31), (1 << 31) - 1
         a[5:5000] = a[5]                     # ... with ties on the first key
         return [a, b], [True, False], True
+    # a (values, mask) pair = a key with NULLs: NULLs first whatever the direction (order.rs:33-41), a valid bit in front of the value
+    if shape == "one_key_with_nulls":
+        return [(rng.integers(-(1 << 20), 1 << 20, n, dtype=np.int64), rng.random(n) < 0.07)], [True], True
+    if shape == "one_key_with_nulls_desc_63_bits":   # 63 value bits + the valid bit: exactly one word, the splitter route
+        return [(rng.integers(0, 1 << 63, n, dtype=np.int64, endpoint=False), rng.random(n) < 0.3)], [False], True
+    if shape == "two_keys_both_with_nulls":
+        return [(rng.integers(0, 50, n).astype(np.int32), rng.random(n) < 0.1),
+                (rng.integers(-(1 << 33), 1 << 33, n, dtype=np.int64), rng.random(n) < 0.2)], [False, True], True
+    if shape == "key_of_nulls_only_then_a_key":
+        return [(np.zeros(n, dtype=np.int64), np.ones(n, dtype=bool)), rng.integers(0, 1 << 18, n, dtype=np.int64)], [True, False], True
+    if shape == "f64_key_with_nulls":                # not an integer key: general path
+        return [(rng.random(n), rng.random(n) < 0.1)], [True], False
     raise ValueError(shape)
 
 
 @pytest.mark.parametrize("shape", ["two_small_ranges", "int32_then_wide_int64", "three_keys_mixed_directions", "four_keys_with_a_constant",
-                                   "ties_on_every_key", "ranges_beyond_64_bits", "exactly_64_bits"])
+                                   "ties_on_every_key", "ranges_beyond_64_bits", "exactly_64_bits", "one_key_with_nulls",
+                                   "one_key_with_nulls_desc_63_bits", "two_keys_both_with_nulls", "key_of_nulls_only_then_a_key",
+                                   "f64_key_with_nulls"])
 @pytest.mark.parametrize("extra", ["none", "carry", "carry_and_more"])
 def test_order_by_several_integer_keys(hip, oracle, shape, extra):
     """ORDER BY a, b [, c, d] over plain integer columns: one composite key through the single-key routes, key columns decoded
@@ -318,7 +332,7 @@ def test_order_by_several_integer_keys(hip, oracle, shape, extra):
     if extra != "none":
         cols.append(np.arange(N, dtype=np.int64))
         names.append("row")
-    arrays = [pa.array(c) for c in cols]
+    arrays = [pa.array(c[0], mask=c[1]) if isinstance(c, tuple) else pa.array(c) for c in cols]
     if extra == "carry_and_more":
         arrays += [pa.array(rng.random(N), mask=rng.random(N) < 0.1), pa.array([None if i % 13 == 0 else f"s{i % 89}" for i in range(N)])]
         names += ["f", "s"]
