@@ -328,3 +328,67 @@ def test_full_size_order(env, push):
     del ek
     assert t.equal(gv, val[perm])  # bit-exact, ties in input order
     out.release()
+
+
+@pytest.mark.parametrize("shape", ["f64_normal_2p28", "i64_63bit_desc", "two_keys_one_with_nulls"])
+def test_full_size_order_wide_and_composite_keys(env, shape):
+    """the splitter route (keys of more than 32 varying bits) and the composite route (several integer keys, NULLs first) at
+    and beyond bench size, against torch's stable sorts (ties keep input order, order.rs:27-66); 2^28 + 12345 rows: every
+    position of the 32-bit offset arithmetic past 2^28, ragged last tile"""
+    t, abi = env.torch, env.abi
+    from sqlrs_amd.expr import InputRef
+    g = t.Generator(device=env.dev).manual_seed(len(shape))
+    n = (1 << 28) + 12345 if shape == "f64_normal_2p28" else 100_000_000
+    row = t.arange(n, dtype=t.int64, device=env.dev)
+    keep = []
+    if shape == "f64_normal_2p28":
+        k = t.randn(n, dtype=t.float64, device=env.dev, generator=g)
+        cols, types, asc = [k, row], [abi.FLOAT64, abi.INT64], [1]
+        perm = t.sort(k, stable=True).indices
+    elif shape == "i64_63bit_desc":
+        k = t.randint(-(1 << 62), 1 << 62, (n,), dtype=t.int64, device=env.dev, generator=g)
+        k[::7] = k[3]  # ties: a seventh of the rows share one key
+        cols, types, asc = [k, row], [abi.INT64, abi.INT64], [0]
+        perm = t.sort(k, stable=True, descending=True).indices
+    else:
+        a = t.randint(0, 300, (n,), dtype=t.int64, device=env.dev, generator=g)
+        b = t.randint(-(1 << 34), 1 << 34, (n,), dtype=t.int64, device=env.dev, generator=g)
+        a_null = t.rand(n, device=env.dev, generator=g) < 0.05
+        cols, types, asc = [a, b, row], [abi.INT64, abi.INT64, abi.INT64], [0, 1]
+        p1 = t.sort(b, stable=True).indices                       # last key first
+        # a DESC with NULLs first: NULL rows get a key above every value
+        a_key = t.where(a_null, t.full_like(a, 1000), a)[p1]
+        perm = p1[t.sort(a_key, stable=True, descending=True).indices]
+        del p1, a_key
+    rb = env.bench.device_batch(abi, cols, types)
+    if shape == "two_keys_one_with_nulls":  # validity bitmap of `a` (bit set = valid), LSB first
+        bits = (~a_null).view(t.uint8)
+        pad = (-n) % 64
+        if pad:
+            bits = t.cat([bits, t.zeros(pad, dtype=t.uint8, device=env.dev)])
+        w = (bits.view(-1, 8).to(t.int32) << t.arange(8, device=env.dev, dtype=t.int32)).sum(1).to(t.uint8)
+        col0 = abi.device_column(abi.INT64, n, a.data_ptr(), validity_ptr=w.data_ptr(), null_count=int(a_null.sum().item()))
+        rb = abi.RawBatch([col0] + [abi.device_column(abi.INT64, n, c.data_ptr()) for c in cols[1:]], n, keepalive=cols + [w])
+        keep.append(w)
+    packs = [InputRef(i).pack() for i in range(len(asc))]
+    obs = (abi.OrderBy * len(asc))(*[abi.OrderBy(p.abi, a_, 0) for p, a_ in zip(packs, asc)])
+    h = C.c_void_p()
+    env.be.check(env.be.fn("order_create")(env.be.ctx, len(asc), obs, C.byref(h)))
+    env.be.check(env.be.fn("order_push_retained")(h, rb.ptr))
+    o = C.POINTER(abi.Batch)()
+    env.be.check(env.be.fn("order_finish")(h, abi.MEM_DEVICE, C.byref(o)))
+    env.be.fn("order_destroy")(h)
+    out = env.be.wrap(o)
+    env.be.synchronize()
+    assert out.num_rows == n
+    got_row = view(env, out.column(len(cols) - 1), n, t.int64)
+    assert t.equal(got_row, perm)                      # the permutation itself: ties in input order, NULLs first
+    if shape == "two_keys_one_with_nulls":
+        nn = int(a_null.sum().item())
+        assert t.equal(view(env, out.column(1), n, t.int64), b[perm])
+        assert t.equal(view(env, out.column(0), n, t.int64)[nn:], a[perm][nn:]) and bool(a_null[perm][:nn].all().item())
+        assert out.column(0).null_count == nn
+    else:
+        assert t.equal(view(env, out.column(0), n, cols[0].dtype), cols[0][perm])
+    out.release()
+    env.be.fn("ctx_pool_trim")(env.be.ctx)
