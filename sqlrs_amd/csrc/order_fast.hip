@@ -540,6 +540,7 @@ constexpr uint32_t FIN_CAP = 6144; // rows of the largest group the in-LDS finis
 //          rows with the same top bits — runs of one or two rows, the group's ~1.5 K rows fall onto 65 536 values — are
 //          put in order by counting: position = run start + #(smaller-or-earlier words in the run).  A run longer than
 //          OWK_WALK rows (heavy duplicates of nearly-equal keys) sends the group through LSD passes over all bits of rel.
+//   heavy values (a run of equal splitters): a group of their own that is copied, not sorted — owk_topfirst_kernel.
 // The payload is the carried column, or the row id when the caller needs the permutation (more columns than two).
 // Stability: passes 1 and 2 are stable and the counting step ranks equal words by position.
 struct OwkTile {
@@ -563,6 +564,30 @@ __global__ void owk_knots_kernel(const uint64_t *__restrict__ ss, uint32_t G, ui
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < G) sub[g] = g ? ss[(size_t)g * per_group] : 0ull;
 }
+// A value that holds a large share of the rows (zeros, a default, a sentinel) shows up as a RUN of equal splitters.  Rows
+// equal to such a value all go to the FIRST group of the run, which then holds nothing else ("pure": sub[g] == sub[g + 1]) and
+// needs no sorting whatever its size — the stable passes have left its rows in input order; the values between the run and
+// the next splitter go to the run's last group as before, the groups in between stay empty.
+// topfirst[k] = first group whose splitter equals top-level splitter k (pass 1 sends the rows equal to it there).
+__global__ void owk_topfirst_kernel(const uint64_t *__restrict__ sub, uint32_t G, uint32_t nk1, uint32_t *__restrict__ topfirst) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nk1) return;
+  const uint64_t v = sub[(size_t)k << 8];
+  uint32_t lo = 0, hi = k << 8; // first index with sub[index] >= v (sub[hi] == v)
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (sub[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  topfirst[k] = lo;
+}
+// first t with sk[t] >= off, given that some sk[d] == off (a branch-free lower bound over the 256 entries of a level)
+__device__ __forceinline__ uint32_t knot_first_equal(const uint64_t *__restrict__ sk, uint64_t off) {
+  uint32_t pos = 0; // = number of entries < off
+#pragma unroll
+  for (uint32_t step = 128; step; step >>= 1)
+    if (sk[pos + step - 1] < off) pos += step;
+  return pos;
+}
 
 // last t < nk with sk[t] <= off (sk[0] <= off by construction), for ITEMS rows at once (independent chains of LDS reads)
 template <int ITEMS>
@@ -584,9 +609,11 @@ __device__ __forceinline__ void knot_digits(const uint64_t *__restrict__ sk, uin
 template <int KIND, int LEVEL, bool REC_IN = false>
 __global__ __launch_bounds__(OW_WG) void owk_hist_kernel(const void *__restrict__ src, int64_t n, int desc, uint64_t imin,
                                                          int64_t nblocks, uint32_t *__restrict__ hist,
-                                                         const OwkTile *__restrict__ tiles, const uint64_t *__restrict__ sub, uint32_t nk1) {
+                                                         const OwkTile *__restrict__ tiles, const uint64_t *__restrict__ sub, uint32_t nk1,
+                                                         const uint32_t *__restrict__ topfirst) {
   __shared__ uint32_t h[256];
   __shared__ uint64_t sk[256];
+  __shared__ uint32_t sfirst[256]; // LEVEL 1: segment of the rows EQUAL to top-level splitter k
   int64_t t0;
   uint32_t tl, nk = nk1;
   size_t hbase = 0, hstride = (size_t)nblocks, hcol = blockIdx.x;
@@ -606,7 +633,10 @@ __global__ __launch_bounds__(OW_WG) void owk_hist_kernel(const void *__restrict_
   } else {
     t0 = (int64_t)blockIdx.x * OW_TILE;
     tl = (uint32_t)min<int64_t>(OW_TILE, n - t0);
-    if (threadIdx.x < 256) sk[threadIdx.x] = threadIdx.x < nk1 ? sub[(size_t)threadIdx.x << 8] : ~0ull;
+    if (threadIdx.x < 256) {
+      sk[threadIdx.x] = threadIdx.x < nk1 ? sub[(size_t)threadIdx.x << 8] : ~0ull;
+      sfirst[threadIdx.x] = threadIdx.x < nk1 ? topfirst[threadIdx.x] >> 8 : 0;
+    }
   }
   if (threadIdx.x < 256) h[threadIdx.x] = 0;
   uint64_t k[OW_ITEMS];
@@ -618,6 +648,9 @@ __global__ __launch_bounds__(OW_WG) void owk_hist_kernel(const void *__restrict_
   __syncthreads();
   uint32_t dig[OW_ITEMS];
   knot_digits<OW_ITEMS>(sk, nk, k, dig);
+#pragma unroll
+  for (int r = 0; r < OW_ITEMS; r++) // a row equal to its splitter: the first group of the run of equal splitters
+    if (sk[dig[r]] == k[r]) dig[r] = LEVEL == 1 ? sfirst[dig[r]] : knot_first_equal(sk, k[r]);
 #pragma unroll
   for (int r = 0; r < OW_ITEMS; r++)
     if ((uint32_t)(threadIdx.x + r * OW_WG) < tl) atomicAdd(&h[dig[r]], 1u);
@@ -631,7 +664,8 @@ __global__ __launch_bounds__(OW_WG) void owk_scatter_kernel(const void *__restri
                                                             int desc, uint64_t imin, int64_t nblocks,
                                                             const uint32_t *__restrict__ offsets, uint64_t *__restrict__ words_out,
                                                             uint64_t *__restrict__ pay_out, const OwkTile *__restrict__ tiles,
-                                                            const uint64_t *__restrict__ sub, uint32_t nk1) {
+                                                            const uint64_t *__restrict__ sub, uint32_t nk1,
+                                                            const uint32_t *__restrict__ topfirst) {
   __shared__ uint64_t sword[OW_TILE];
   __shared__ uint64_t spay[NPAY ? OW_TILE : 1];
   __shared__ uint32_t wcnt[OW_WAVES][256]; // (its first 2 KB hold the splitters until the digits are known)
@@ -640,6 +674,7 @@ __global__ __launch_bounds__(OW_WG) void owk_scatter_kernel(const void *__restri
   __shared__ uint8_t sdig[OW_TILE];
   __shared__ uint32_t s_wsum[4];
   uint64_t *sk = (uint64_t *)&wcnt[0][0];
+  uint32_t *sfirst = &wcnt[2][0]; // (behind the 2 KB of splitters; LEVEL 1 only)
   const int w = wave_id(), lane = lane_id();
   int64_t tbase;
   uint32_t len, nk = nk1;
@@ -657,7 +692,10 @@ __global__ __launch_bounds__(OW_WG) void owk_scatter_kernel(const void *__restri
   } else {
     tbase = (int64_t)blockIdx.x * OW_TILE;
     len = (uint32_t)min<int64_t>(OW_TILE, n - tbase);
-    if (threadIdx.x < 256) sk[threadIdx.x] = threadIdx.x < nk1 ? sub[(size_t)threadIdx.x << 8] : ~0ull;
+    if (threadIdx.x < 256) {
+      sk[threadIdx.x] = threadIdx.x < nk1 ? sub[(size_t)threadIdx.x << 8] : ~0ull;
+      sfirst[threadIdx.x] = threadIdx.x < nk1 ? topfirst[threadIdx.x] >> 8 : 0;
+    }
   }
   const uint32_t wrow = (uint32_t)w * (OW_ITEMS * 64) + lane; // element of the tile
   uint64_t k[OW_ITEMS], v[NPAY ? OW_ITEMS : 1];
@@ -677,6 +715,9 @@ __global__ __launch_bounds__(OW_WG) void owk_scatter_kernel(const void *__restri
   __syncthreads();
   uint32_t dig[OW_ITEMS], rnk[OW_ITEMS];
   knot_digits<OW_ITEMS>(sk, nk, k, dig);
+#pragma unroll
+  for (int j = 0; j < OW_ITEMS; j++) // a row equal to its splitter: the first group of the run of equal splitters
+    if (sk[dig[j]] == k[j]) dig[j] = LEVEL == 1 ? sfirst[dig[j]] : knot_first_equal(sk, k[j]);
   __syncthreads(); // (the splitters are read: their bytes become the wave counters)
 #pragma unroll
   for (int q = 0; q < 4; q++) wcnt[w][lane + 64 * q] = 0;
@@ -760,22 +801,55 @@ __global__ void owk_tile_fill_kernel(const uint32_t *__restrict__ firsttile, con
   }
   tiles[t] = o;
 }
-// group g = k << 8 | d: rows [gstart[g], gend[g]); one block per segment k; gend[G] = largest group
+// group g = k << 8 | d: rows [gstart[g], gend[g]); one block per segment k; gend[G] = largest group that needs sorting,
+// gend[G + 1] = entries of the work list `pure_items` — {group, chunk of 4096 rows} for every pure group (owk_topfirst_kernel)
+constexpr uint32_t OWK_PURE_CHUNK = 4096;
+__device__ __forceinline__ bool owk_pure(const uint64_t *__restrict__ sub, uint32_t G, uint32_t g) {
+  return g + 1 < G && sub[g] == sub[g + 1];
+}
 __global__ __launch_bounds__(256) void owk_group_table_kernel(const uint32_t *__restrict__ offs2, const uint32_t *__restrict__ firsttile,
-                                                              const int64_t *__restrict__ segstart, uint32_t G,
-                                                              uint32_t *__restrict__ gstart, uint32_t *__restrict__ gend) {
-  const uint32_t k = blockIdx.x, d = threadIdx.x;
+                                                              const int64_t *__restrict__ segstart, const uint64_t *__restrict__ sub,
+                                                              uint32_t G, uint32_t *__restrict__ gstart, uint32_t *__restrict__ gend,
+                                                              uint2 *__restrict__ pure_items) {
+  const uint32_t k = blockIdx.x, d = threadIdx.x, g = k * 256 + d;
   const uint32_t ft = firsttile[k], nt = firsttile[k + 1] - ft;
   uint32_t a = 0xffffffffu, b = 0;
   if (nt) {
     a = offs2[(size_t)ft * 256 + (size_t)d * nt];
     b = d == 255 ? (uint32_t)segstart[k + 1] : offs2[(size_t)ft * 256 + (size_t)(d + 1) * nt];
   }
-  gstart[k * 256 + d] = a;
-  gend[k * 256 + d] = b;
+  gstart[g] = a;
+  gend[g] = b;
   uint32_t sz = nt ? b - a : 0;
+  if (sz && owk_pure(sub, G, g)) { // nothing to sort: its rows are copied out chunk by chunk (owk_pure_copy_kernel)
+    const uint32_t items = (sz + OWK_PURE_CHUNK - 1) / OWK_PURE_CHUNK;
+    const uint32_t at = atomicAdd(gend + G + 1, items);
+    for (uint32_t q = 0; q < items; q++) pure_items[at + q] = make_uint2(g, q);
+    sz = 0;
+  }
   for (int s = 32; s >= 1; s >>= 1) sz = max(sz, (uint32_t)__shfl_xor((int)sz, s, 64));
   if (lane_id() == 0 && sz) atomicMax(gend + G, sz);
+}
+// rows of the pure groups: every row of the group carries the same word, and the stable passes kept them in input order
+template <int KIND, int NPAY, bool REC>
+__global__ __launch_bounds__(256) void owk_pure_copy_kernel(const uint64_t *__restrict__ words, const uint2 *__restrict__ items,
+                                                            const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gend,
+                                                            int desc, uint64_t imin, uint64_t *__restrict__ key_out,
+                                                            uint64_t *__restrict__ pay_out, uint32_t *__restrict__ perm_out) {
+  const uint2 it = items[blockIdx.x];
+  const uint32_t lo = gstart[it.x] + it.y * OWK_PURE_CHUNK, hi = min(gend[it.x], lo + OWK_PURE_CHUNK);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+    uint64_t kw, v = 0;
+    if (REC) {
+      const u64x2 rec = __builtin_nontemporal_load((const u64x2 *)words + i);
+      kw = rec.x;
+      v = rec.y;
+    } else
+      kw = __builtin_nontemporal_load(words + i);
+    key_out[i] = order_unimage<KIND>(kw + imin, desc);
+    if (perm_out) perm_out[i] = (uint32_t)v;
+    else if (NPAY) pay_out[i] = v;
+  }
 }
 
 // perm_out != nullptr: the payload is the row id — it leaves as the permutation and there is no carried column
@@ -790,6 +864,7 @@ __global__ __launch_bounds__(FIN_WG, R == 8 ? 4 : 1) void owk_finish_kernel(cons
   if (lo == 0xffffffffu || lo >= hi) return;
   const uint32_t m = hi - lo;
   if (m <= m_above || m > m_upto) return; // (a group of another size class: the launch with the LDS room for it takes it)
+  if (owk_pure(sub, G, blockIdx.x)) return; // (one value, nothing to sort: owk_pure_copy_kernel)
   uint64_t *sword = (uint64_t *)smem;                       // [R * FIN_WG]
   uint64_t *spay = sword + (size_t)R * FIN_WG;              // [NPAY ? R * FIN_WG : 0]
   uint32_t *wcnt = (uint32_t *)(spay + (NPAY ? (size_t)R * FIN_WG : 0)); // [FIN_WAVES][256]
@@ -967,15 +1042,18 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   const bool pay_rows = want_perm, has_pay = pay_rows || carry != nullptr;
   // 0. splitters
   BufP ss = ctx->alloc(8 * (size_t)S), ssv = ctx->alloc(4 * (size_t)S), sub = ctx->alloc(8 * ((size_t)G + 1));
+  BufP topfirst = ctx->alloc(4 * 256);
   {
     ProfScope ps(ctx, "order_knots");
     owk_sample_kernel<KIND><<<dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, ctx->stream>>>(key.values, n, desc, imin, S, n / S, ss->as<uint64_t>());
     SQ_HIP(hipGetLastError());
     radix_sort_pairs(ctx, ss->as<uint64_t>(), ssv->as<uint32_t>(), S, 0, kb, true);
     owk_knots_kernel<<<dim3((unsigned)ceil_div((int64_t)G, 256)), dim3(256), 0, ctx->stream>>>(ss->as<uint64_t>(), G, (uint32_t)per_group, sub->as<uint64_t>());
+    owk_topfirst_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(sub->as<uint64_t>(), G, nk1, topfirst->as<uint32_t>());
     SQ_HIP(hipGetLastError());
   }
   const uint64_t *subp = sub->as<uint64_t>();
+  const uint32_t *tfp = topfirst->as<uint32_t>();
   // 1. pass 1: top-level splitters, raw column -> (word, payload) columns
   const int64_t nblocks = ceil_div(n, OW_TILE), ntmax = nblocks + 256;
   // (with a payload both passes write {word, payload} records: a (tile, digit) run is one piece instead of one per column.
@@ -988,18 +1066,18 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   dim3 g1((unsigned)nblocks), g2((unsigned)ntmax), b(OW_WG);
   {
     ProfScope ps(ctx, "order_split");
-    owk_hist_kernel<KIND, 1><<<g1, b, 0, ctx->stream>>>(key.values, n, desc, imin, nblocks, hist->as<uint32_t>(), nullptr, subp, nk1);
+    owk_hist_kernel<KIND, 1><<<g1, b, 0, ctx->stream>>>(key.values, n, desc, imin, nblocks, hist->as<uint32_t>(), nullptr, subp, nk1, tfp);
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(), total->as<uint64_t>());
     if (rec1)
       owk_scatter_kernel<KIND, 1, 1, true><<<g1, b, 0, ctx->stream>>>(key.values, psrc, n, desc, imin, nblocks, offs->as<uint32_t>(),
-                                                                     w1->as<uint64_t>(), nullptr, nullptr, subp, nk1);
+                                                                     w1->as<uint64_t>(), nullptr, nullptr, subp, nk1, tfp);
     else if (has_pay)
       owk_scatter_kernel<KIND, 1, 1, false><<<g1, b, 0, ctx->stream>>>(key.values, psrc, n, desc, imin, nblocks, offs->as<uint32_t>(),
-                                                                      w1->as<uint64_t>(), p1->as<uint64_t>(), nullptr, subp, nk1);
+                                                                      w1->as<uint64_t>(), p1->as<uint64_t>(), nullptr, subp, nk1, tfp);
     else
       owk_scatter_kernel<KIND, 1, 0, false><<<g1, b, 0, ctx->stream>>>(key.values, nullptr, n, desc, imin, nblocks, offs->as<uint32_t>(),
-                                                                      w1->as<uint64_t>(), nullptr, nullptr, subp, nk1);
+                                                                      w1->as<uint64_t>(), nullptr, nullptr, subp, nk1, tfp);
     SQ_HIP(hipGetLastError());
   }
   // 2. pass 2 over segment-aligned tiles: the segment's own 256 splitters; records out when there is a payload
@@ -1012,34 +1090,37 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     owk_tile_fill_kernel<<<dim3((unsigned)ceil_div(ntmax, 256)), dim3(256), 0, ctx->stream>>>(firsttile->as<uint32_t>(), segstart->as<int64_t>(),
                                                                                              (uint32_t)ntmax, (OwkTile *)tiles2->p);
     const OwkTile *tp = (const OwkTile *)tiles2->p;
-    if (rec1) owk_hist_kernel<KIND, 2, true><<<g2, b, 0, ctx->stream>>>(w1->p, n, desc, imin, ntmax, hist2->as<uint32_t>(), tp, subp, nk1);
-    else owk_hist_kernel<KIND, 2><<<g2, b, 0, ctx->stream>>>(w1->p, n, desc, imin, ntmax, hist2->as<uint32_t>(), tp, subp, nk1);
+    if (rec1) owk_hist_kernel<KIND, 2, true><<<g2, b, 0, ctx->stream>>>(w1->p, n, desc, imin, ntmax, hist2->as<uint32_t>(), tp, subp, nk1, tfp);
+    else owk_hist_kernel<KIND, 2><<<g2, b, 0, ctx->stream>>>(w1->p, n, desc, imin, ntmax, hist2->as<uint32_t>(), tp, subp, nk1, tfp);
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist2->as<uint32_t>(), 256 * ntmax, nullptr, offs2->as<uint32_t>(), total->as<uint64_t>());
     if (rec1)
       owk_scatter_kernel<KIND, 2, 1, true, true><<<g2, b, 0, ctx->stream>>>(w1->p, nullptr, n, desc, imin, ntmax, offs2->as<uint32_t>(),
-                                                                           out2->as<uint64_t>(), nullptr, tp, subp, nk1);
+                                                                           out2->as<uint64_t>(), nullptr, tp, subp, nk1, tfp);
     else if (has_pay)
       owk_scatter_kernel<KIND, 2, 1, true><<<g2, b, 0, ctx->stream>>>(w1->p, p1->as<uint64_t>(), n, desc, imin, ntmax, offs2->as<uint32_t>(),
-                                                                     out2->as<uint64_t>(), nullptr, tp, subp, nk1);
+                                                                     out2->as<uint64_t>(), nullptr, tp, subp, nk1, tfp);
     else
       owk_scatter_kernel<KIND, 2, 0, false><<<g2, b, 0, ctx->stream>>>(w1->p, nullptr, n, desc, imin, ntmax, offs2->as<uint32_t>(),
-                                                                      out2->as<uint64_t>(), nullptr, tp, subp, nk1);
+                                                                      out2->as<uint64_t>(), nullptr, tp, subp, nk1, tfp);
     SQ_HIP(hipGetLastError());
   }
   // 3. groups
-  BufP gstart = ctx->alloc(4 * (size_t)65536), gend = ctx->alloc(4 * ((size_t)65536 + 1));
-  SQ_HIP(hipMemsetAsync(gend->as<uint32_t>() + G, 0, 4, ctx->stream));
+  BufP gstart = ctx->alloc(4 * (size_t)65536), gend = ctx->alloc(4 * ((size_t)65536 + 2)); // [G]: largest group, [G + 1]: pure chunks
+  BufP pure_items = ctx->alloc(8 * ((size_t)ceil_div(n, (int64_t)OWK_PURE_CHUNK) + G + 1));
+  SQ_HIP(hipMemsetAsync(gend->as<uint32_t>() + G, 0, 8, ctx->stream));
   {
     ProfScope ps(ctx, "order_groups");
-    owk_group_table_kernel<<<dim3(nk1), dim3(256), 0, ctx->stream>>>(offs2->as<uint32_t>(), firsttile->as<uint32_t>(), segstart->as<int64_t>(), G,
-                                                                   gstart->as<uint32_t>(), gend->as<uint32_t>());
+    owk_group_table_kernel<<<dim3(nk1), dim3(256), 0, ctx->stream>>>(offs2->as<uint32_t>(), firsttile->as<uint32_t>(), segstart->as<int64_t>(), subp, G,
+                                                                   gstart->as<uint32_t>(), gend->as<uint32_t>(), (uint2 *)pure_items->p);
     SQ_HIP(hipGetLastError());
   }
-  const uint32_t max_group = ctx->fetch_value(gend->as<uint32_t>() + G);
+  const uint32_t *gh = (const uint32_t *)ctx->fetch(gend->as<uint32_t>() + G, 8);
+  const uint32_t max_group = gh[0], pure_chunks = gh[1];
   if (std::getenv("SQLRS_ORDER_TRACE"))
-    std::fprintf(stderr, "[order_wide] n=%lld key bits=%d groups=%u largest group=%u rows\n", (long long)n, kb, G, max_group);
-  if (max_group > FIN_CAP) return false; // one value (or a narrow band of values) repeated thousands of times: general path
+    std::fprintf(stderr, "[order_wide] n=%lld key bits=%d groups=%u largest group to sort=%u rows, %u chunks of single-value groups\n",
+                 (long long)n, kb, G, max_group, pure_chunks);
+  if (max_group > FIN_CAP) return false; // thousands of distinct keys between two neighbouring samples: general path
   // 4. finish
   key_out->dtype = key.dtype;
   key_out->length = n;
@@ -1084,6 +1165,15 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     else SQ_WFIN_R(0);
 #undef SQ_WFIN_R
 #undef SQ_WFIN
+    if (pure_chunks) { // groups of ONE value (heavy hitters): copied out as they are
+      const uint2 *items = (const uint2 *)pure_items->p;
+      if (has_pay)
+        owk_pure_copy_kernel<KIND, 1, true><<<dim3(pure_chunks), dim3(256), 0, ctx->stream>>>(
+            out2->as<uint64_t>(), items, gstart->as<uint32_t>(), gend->as<uint32_t>(), desc, imin, key_out->own_values->as<uint64_t>(), po, perm);
+      else
+        owk_pure_copy_kernel<KIND, 0, false><<<dim3(pure_chunks), dim3(256), 0, ctx->stream>>>(
+            out2->as<uint64_t>(), items, gstart->as<uint32_t>(), gend->as<uint32_t>(), desc, imin, key_out->own_values->as<uint64_t>(), po, perm);
+    }
     SQ_HIP(hipGetLastError());
   }
   return true;
