@@ -76,6 +76,39 @@ __global__ __launch_bounds__(256) void order_inversion_kernel(const void *__rest
   if (__ballot(bad) && lane_id() == 0) atomicOr(inv, 1u);
 }
 
+// Does ONE VALUE hold a visible share of the rows (zeros, a default, a handful of distinct keys)?  Its group of equal top bits
+// would be far larger than the in-LDS finish takes, and the attempt would be thrown away after both split passes.  2048
+// sampled keys are counted in an LDS table; *out = the largest count (travels with the key range: no round trip of its own).
+constexpr uint32_t OW_HEAVY_SAMPLES = 2048, OW_HEAVY_MIN = 6; // 6 of 2048: a share of ~0.3 %
+template <int KIND>
+__global__ __launch_bounds__(1024) void order_heavy_probe_kernel(const void *__restrict__ vals, int64_t n, int desc, unsigned int *__restrict__ out) {
+  __shared__ unsigned long long skey[2 * OW_HEAVY_SAMPLES];
+  __shared__ uint32_t scnt[2 * OW_HEAVY_SAMPLES];
+  for (uint32_t i = threadIdx.x; i < 2 * OW_HEAVY_SAMPLES; i += 1024) {
+    skey[i] = ~0ull;
+    scnt[i] = 0;
+  }
+  __syncthreads();
+  const int64_t stride = max(n / (int64_t)OW_HEAVY_SAMPLES, (int64_t)1);
+  uint32_t best = 0;
+  for (uint32_t s = threadIdx.x; s < OW_HEAVY_SAMPLES; s += 1024) {
+    const int64_t row = min(n - 1, (int64_t)s * stride + (int64_t)(mix64((uint64_t)s) % (uint64_t)stride));
+    unsigned long long k = order_image<KIND>(vals, row, desc);
+    if (k == ~0ull) k = ~1ull; // (~0 marks a free slot)
+    uint32_t hsh = (uint32_t)mix64(k) & (2 * OW_HEAVY_SAMPLES - 1);
+    for (;;) {
+      const unsigned long long old = atomicCAS(&skey[hsh], ~0ull, k);
+      if (old == ~0ull || old == k) {
+        best = max(best, atomicAdd(&scnt[hsh], 1u) + 1u);
+        break;
+      }
+      hsh = (hsh + 1) & (2 * OW_HEAVY_SAMPLES - 1);
+    }
+  }
+  for (int sft = 32; sft >= 1; sft >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, sft, 64));
+  if (lane_id() == 0) atomicMax(out, best);
+}
+
 constexpr int OW_MM_SLOTS = 32; // {min, max} pairs the blocks spread their atomics over; the host reduces them
 __global__ void order_minmax_init_kernel(unsigned long long *mm) { // [2 * OW_MM_SLOTS + 2]: {~0, 0} pairs, the flag word, the inversion word
   const int i = threadIdx.x;
@@ -1038,7 +1071,7 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   if (const char *e = std::getenv("SQLRS_ORDER_SAMPLES")) per_group = std::max(1, std::min(256, std::atoi(e))); // (A/B hook, read per call)
   const int64_t S = (int64_t)G * per_group;
   if (n < S) return false;
-  const int kb = 64 - __builtin_clzll(range);
+  const int kb = range ? 64 - __builtin_clzll(range) : 1;
   const bool pay_rows = want_perm, has_pay = pay_rows || carry != nullptr;
   // 0. splitters
   BufP ss = ctx->alloc(8 * (size_t)S), ssv = ctx->alloc(4 * (size_t)S), sub = ctx->alloc(8 * ((size_t)G + 1));
@@ -1189,17 +1222,21 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   // 0. key range
   BufP mm = ctx->alloc(16 * OW_MM_SLOTS + 16); // {min = ~0, max = 0} x OW_MM_SLOTS | out-of-range flag (u32), largest group (u32) | inversion seen (u32)
   constexpr int FLAG_W = 2 * OW_MM_SLOTS;       // index of the flag word (u64)
-  unsigned int *inv = (unsigned int *)(mm->as<uint64_t>() + FLAG_W + 1);
+  unsigned int *inv = (unsigned int *)(mm->as<uint64_t>() + FLAG_W + 1); // (its upper half: the heavy-value probe's count)
+  const char *hp_e = std::getenv("SQLRS_ORDER_HEAVY_PROBE"); // (A/B hook, read per call: 0 = no probe)
+  const bool heavy_probe = KIND != OKIND_I32 && !hbm_only && !(hp_e && hp_e[0] == '0');
   {
     ProfScope ps(ctx, "order_minmax");
     order_minmax_init_kernel<<<dim3(1), dim3(128), 0, ctx->stream>>>(mm->as<unsigned long long>());
     if (in_order) order_inversion_kernel<KIND, true><<<dim3(256), dim3(256), 0, ctx->stream>>>(key.values, n, desc, inv);
+    if (heavy_probe) order_heavy_probe_kernel<KIND><<<dim3(1), dim3(1024), 0, ctx->stream>>>(key.values, n, desc, inv + 1);
     const int every = optimistic ? 16 : 1;
     unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, (int64_t)256 * 8 * every), 8 * (int64_t)ctx->num_cus));
     order_minmax_kernel<KIND><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(key.values, n, desc, mm->as<unsigned long long>(), every);
     SQ_HIP(hipGetLastError());
   }
   const uint64_t *h = (const uint64_t *)ctx->fetch(mm->p, 16 * OW_MM_SLOTS + 16);
+  const uint32_t heavy_cnt = (uint32_t)(h[FLAG_W + 1] >> 32);
   if (in_order && (uint32_t)h[FLAG_W + 1] == 0) { // no inversion among the sampled pairs: look at every pair
     ProfScope ps(ctx, "order_minmax");
     const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256 * 8), 8 * (int64_t)ctx->num_cus));
@@ -1235,6 +1272,13 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
       }
       return order_wide<KIND>(ctx, key, desc, carry, n, imin, range, key_out, carry_out, perm_out, want_perm);
     }
+  }
+  if constexpr (KIND != OKIND_I32) {
+    // a value with a visible share of the rows: the splitter route gives it a group of its own that is copied, not sorted
+    // (order_wide works on any range; if it declines, the plan below runs as before)
+    if (heavy_probe && heavy_cnt >= OW_HEAVY_MIN &&
+        order_wide<KIND>(ctx, key, desc, carry, n, optimistic ? 0 : imin, optimistic ? ~0ull : range, key_out, carry_out, perm_out, want_perm))
+      return true;
   }
   int kbits = 1;
   while (kbits < 32 && (1ull << kbits) <= range) kbits++;

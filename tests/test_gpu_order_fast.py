@@ -277,10 +277,16 @@ def test_order_wide_keys_with_sampled_range(hip, oracle, shape, asc, monkeypatch
 
 
 @pytest.mark.parametrize("asc", [True, False])
-def test_order_few_distinct_keys_spread_over_many_bits(hip, oracle, asc):
+@pytest.mark.parametrize("probe", [True, False])
+def test_order_few_distinct_keys_spread_over_many_bits(hip, oracle, asc, probe, monkeypatch):
     """50 distinct keys over 2^26: a group of equal top bits holds tens of thousands of rows, more than the in-LDS finish
-    takes — the call is redone with every key bit through the HBM passes (four here, then a streaming unpack) instead of
-    falling to the general path: no `radix_sort` scope, six `order_split` launches (2 + 4)"""
+    takes.  The heavy-value probe (2048 sampled keys counted in LDS, travels with the key range) sends the call to the
+    splitter route, where every value gets a group of its own that is copied (`order_knots`, two `order_split` launches).
+    Without the probe (SQLRS_ORDER_HEAVY_PROBE=0, or a share too small for it) the attempt is thrown away after both split
+    passes and the call is redone with every key bit through HBM passes (four here, then a streaming unpack): six
+    `order_split` launches, no general path (`gather`) either way"""
+    if not probe:
+        monkeypatch.setenv("SQLRS_ORDER_HEAVY_PROBE", "0")
     rng = np.random.default_rng(50 + asc)
     k = keys_of(rng, "i64_heavy_groups")
     b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(np.arange(N, dtype=np.int64)), pa.array(rng.random(N))], names=["k", "row", "x"])
@@ -291,7 +297,9 @@ def test_order_few_distinct_keys_spread_over_many_bits(hip, oracle, asc):
     (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
     for i in range(3):
         assert got.column(i).equals(exp.column(i)), i
-    assert prof.get("radix_sort", (0, 0))[1] == 0 and prof.get("order_split", (0, 0))[1] == 6, prof
+    # (gathered by the permutation: the third column; on the splitter route the row ids travel, so the second one too)
+    assert prof.get("gather", (0, 0))[1] == (2 if probe else 1), prof
+    assert prof.get("order_knots", (0, 0))[1] == (1 if probe else 0) and prof.get("order_split", (0, 0))[1] == (2 if probe else 6), prof
 
 
 def composite_case(rng, shape, n):
