@@ -1861,7 +1861,9 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     const char *e = std::getenv("SQLRS_RP_CHUNKED");
     return e ? std::atoi(e) : -1;
   }();
-  // (3072-row tiles with two workgroups per CU were measured slower for this level too: 6.4 vs 5.7 ms)
+  // (3072-row tiles with two workgroups per CU were measured slower for this level too: 6.4 vs 5.7 ms; so were 1024-thread
+  //  workgroups with 8 rows per thread over the same 8192-row tiles — twice the waves per CU, but 128 VGPRs and 32 spilled:
+  //  6.65 vs 5.68 ms, round 4)
   const uint32_t tiles1 = (uint32_t)ceil_div(n, RP_TILE);
   uint32_t cwgs = std::min<uint32_t>(tiles1, (uint32_t)ctx->num_cus);
   if (const char *wg_e = std::getenv("SQLRS_RP_CHUNK_WGS")) // test hook, read per call: fewer workgroups = longer tile ranges per workgroup
