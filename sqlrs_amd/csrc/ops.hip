@@ -511,6 +511,65 @@ static bool order_topk(sqlrs_order *o, DBatch &all, int kc, int out_mem, sqlrs_b
   return done;
 }
 
+// ---- ONE key with NULLs that the composite key cannot take (a double; an int64 whose range needs all 64 bits): the NULL rows
+// first, in input order (order.rs:33-41: nulls_first whatever the direction), then the rest ordered by the routes for keys
+// without NULLs.  Both parts are order-preserving compactions of every column (the Filter operator's), the valid part goes
+// through an inner Order on the same key, and the two are concatenated.
+static bool order_null_split(sqlrs_order *o, DBatch &all, int kc, int out_mem, sqlrs_batch_t **out) {
+  Ctx *ctx = o->ctx;
+  const int64_t n = all.rows;
+  const DCol &key = all.cols[(size_t)kc];
+  const int64_t nulls = count_nulls(ctx, key);
+  if (nulls == 0 || n - nulls < (1 << 20)) return false; // (nothing to split off / the rest is small: general path)
+  Selection sv;
+  sv.rows = n;
+  sv.bits = key.validity;
+  selection_finish(ctx, sv);
+  Selection sn = selection_from_clear_bits(ctx, key.validity, n);
+  if (sv.count + sn.count != n) fail(SQLRS_ERR_INTERNAL, "order: NULL / valid rows do not add up");
+  DBatch vb, nb;
+  vb.rows = sv.count;
+  nb.rows = sn.count;
+  for (DCol &c : all.cols) {
+    if (c.stride == 0) c = materialize_scalar(ctx, c, n);
+    vb.cols.push_back(compact_column(ctx, c, sv));
+    nb.cols.push_back(compact_column(ctx, c, sn));
+  }
+  DCol &vk = vb.cols[(size_t)kc];
+  vk.validity = nullptr;
+  vk.own_validity = nullptr;
+  vk.null_count = 0;
+  sqlrs_order_t *tmp = nullptr;
+  sqlrs_batch_t *sorted = nullptr;
+  auto cleanup = [&] {
+    if (sorted) sqlrs_batch_release(sorted);
+    if (tmp) sqlrs_order_destroy(tmp);
+  };
+  try {
+    std::vector<sqlrs_expr_node_t> kn = o->exprs[0].nodes;
+    for (size_t q = 0; q < kn.size(); q++) kn[q].s = o->exprs[0].strings[q].empty() ? nullptr : o->exprs[0].strings[q].c_str();
+    sqlrs_order_by_t ob{sqlrs_expr_t{kn.data(), (int32_t)kn.size(), 0}, o->asc[0], 0};
+    int st = sqlrs_order_create((sqlrs_ctx_t *)ctx, 1, &ob, &tmp);
+    if (st != SQLRS_OK) fail(st, ctx->last_error);
+    tmp->batches.push_back(std::move(vb));
+    st = sqlrs_order_finish(tmp, SQLRS_MEM_DEVICE, &sorted);
+    if (st != SQLRS_OK) fail(st, ctx->last_error);
+    InBatch ib(ctx, sorted);
+    DBatch r;
+    r.rows = n;
+    for (size_t c = 0; c < all.cols.size(); c++) {
+      std::vector<const DCol *> parts{&nb.cols[c], &ib.col((int)c)};
+      r.cols.push_back(concat_columns(ctx, parts));
+    }
+    *out = emit_batch(ctx, std::move(r), out_mem);
+  } catch (...) {
+    cleanup();
+    throw;
+  }
+  cleanup();
+  return true;
+}
+
 extern "C" {
 
 int sqlrs_order_create(sqlrs_ctx_t *ctx, int num_keys, const sqlrs_order_by_t *order_by,
@@ -717,6 +776,15 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
           *out = emit_batch(ctx, std::move(r), out_mem);
           return;
         }
+      }
+    }
+    // ---- one key with NULLs (what the composite key above did not take): NULL rows first, the rest through an inner Order
+    if (fast_on && o->exprs.size() == 1 && o->exprs[0].nodes.size() == 1 && o->exprs[0].nodes[0].op == SQLRS_EXPR_INPUT_REF && n >= (1 << 21)) {
+      const int kc = o->exprs[0].nodes[0].index;
+      if (kc >= 0 && (size_t)kc < all.cols.size()) {
+        const DCol &kcol = all.cols[(size_t)kc];
+        const bool plain = (kcol.dtype == SQLRS_INT64 || kcol.dtype == SQLRS_FLOAT64 || kcol.dtype == SQLRS_INT32) && kcol.stride != 0;
+        if (plain && kcol.validity && kcol.null_count != 0 && order_null_split(o, all, kc, out_mem, out)) return;
       }
     }
     BufP perm = ctx->alloc(4 * (size_t)n1), keys = ctx->alloc(8 * (size_t)n1);

@@ -371,3 +371,34 @@ def test_order_by_several_integer_keys(hip, oracle, shape, extra):
     for i in range(b.num_columns):
         assert got.column(i).equals(exp.column(i)), b.schema.names[i]
     assert (prof.get("order_split", (0, 0))[1] > 0) == composite, prof
+
+
+@pytest.mark.parametrize("shape", ["f64_asc", "f64_desc_more_columns", "i64_full_range", "f64_few_valid_rows"])
+def test_order_one_key_with_nulls_split(hip, oracle, shape):
+    """ORDER BY one key WITH NULLs that the composite key cannot take (a double; an int64 whose values span 64 bits): the NULL
+    rows first in input order, the rest through an inner Order on the compacted rows (ops.hip, order_null_split) — against
+    the oracle (order.rs:33-41: nulls first whatever the direction); `order_split` launches show the inner fast route"""
+    n = 2_600_000
+    rng = np.random.default_rng(hash_seed("nullsplit", shape))
+    asc = shape != "f64_desc_more_columns"
+    if shape == "i64_full_range":
+        k = rng.integers(-(1 << 63), (1 << 63) - 1, n, dtype=np.int64, endpoint=True)
+        k[7], k[8] = -(1 << 63), (1 << 63) - 1
+    else:
+        k = rng.normal(0.0, 100.0, n)
+    mask = rng.random(n) < (0.9 if shape == "f64_few_valid_rows" else 0.15)   # True = NULL
+    arrays = [pa.array(np.arange(n, dtype=np.int64)), pa.array(k, mask=mask)]
+    names = ["row", "k"]
+    if shape == "f64_desc_more_columns":
+        arrays += [pa.array(rng.random(n), mask=rng.random(n) < 0.1), pa.array([None if i % 17 == 0 else f"s{i % 71}" for i in range(n)])]
+        names += ["f", "s"]
+    b = pa.RecordBatch.from_arrays(arrays, names=names)
+    hip.profile(True)
+    (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(1), asc=asc)], [b.slice(0, n // 2), b.slice(n // 2)]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(1), asc=asc)], [b]).execute())
+    for i in range(b.num_columns):
+        assert got.column(i).equals(exp.column(i)), names[i]
+    split = shape != "f64_few_valid_rows"        # (260 000 valid rows: not worth the split, general path)
+    assert (prof.get("order_split", (0, 0))[1] > 0) == split, prof

@@ -34,10 +34,20 @@ pk = InputRef(0).pack()
 obs = (abi.OrderBy * 1)(abi.OrderBy(pk.abi, 1, 0))
 
 
-def batch_of(k):
-    cols = [abi.device_column(abi.FLOAT64 if k.dtype == torch.float64 else abi.INT64, n, k.data_ptr()),
-            abi.device_column(abi.INT64, n, carry.data_ptr())]
-    return abi.RawBatch(cols, n, keepalive=[k, carry])
+valid_bits = None
+if "f64_nulls10" in os.environ.get("SHAPES", ""):   # (only on request: a key column with 10 % NULLs)
+    keys["f64_nulls10"] = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    v8 = (torch.rand(n + (-n) % 64, device=dev, generator=g) >= 0.1).view(-1, 8).to(torch.int32)
+    valid_bits = (v8 << torch.arange(8, device=dev, dtype=torch.int32)).sum(1).to(torch.uint8)
+
+
+def batch_of(k, name=""):
+    kt = abi.FLOAT64 if k.dtype == torch.float64 else abi.INT64
+    if name == "f64_nulls10":
+        c0 = abi.device_column(kt, n, k.data_ptr(), validity_ptr=valid_bits.data_ptr(), null_count=-1)
+    else:
+        c0 = abi.device_column(kt, n, k.data_ptr())
+    return abi.RawBatch([c0, abi.device_column(abi.INT64, n, carry.data_ptr())], n, keepalive=[k, carry])
 
 
 def run(b):
@@ -51,7 +61,7 @@ def run(b):
 
 
 for name, k in keys.items():
-    b = batch_of(k)
+    b = batch_of(k, name)
     for rnd in range(2):
         for v in values:
             os.environ[var] = v
