@@ -921,11 +921,171 @@ struct Pairs {
   bool right_identity = false;
 };
 
-static NKeys eval_keys(Ctx *ctx, const std::vector<Expr> &exprs,
-                       const std::function<const DCol &(int)> &col, int64_t rows) {
+static std::vector<DCol> eval_key_cols(Ctx *ctx, const std::vector<Expr> &exprs, const std::function<const DCol &(int)> &col,
+                                       int64_t rows) {
   std::vector<DCol> kc;
   for (const Expr &e : exprs) kc.push_back(eval_expr(ctx, e, col, rows, true));
-  return normalize_keys(ctx, kc, rows);
+  return kc;
+}
+static NKeys eval_keys(Ctx *ctx, const std::vector<Expr> &exprs,
+                       const std::function<const DCol &(int)> &col, int64_t rows) {
+  return normalize_keys(ctx, eval_key_cols(ctx, exprs, col, rows), rows);
+}
+
+// ---- several integer key columns as ONE exact key (sqlrs_hash_join::Composite) ----------------------------------------
+// The reference hashes the key columns into 64 bits and matches by hash alone (hash_join.rs:161-232) — and its fold of the
+// column hashes collides readily: on a 1000 x 1000 grid of (x, y) build keys, 3e6 probe rows find 3.71e6 partners where
+// 2.96e6 exist.  The default of this library reproduces exactly that (normalize_keys, hash mode: same pairs, same order as the
+// reference, false matches included).  This is the OPT-IN alternative for callers who want the SQL answer: an exact
+// composite key, which also makes dense key grids eligible for the direct-address table and sparse ones for the LDS route.
+// NULL in a key column never matches here; the composite is taken only when no build key is NULL, and a probe row with a NULL
+// key, a value outside the build side's ranges, or a key column of another integer type gets a key that matches nothing.
+struct CompJoinKeys {
+  const void *vals[4];
+  const uint64_t *valid[4];
+  int64_t min[4];
+  uint64_t range[4], stride[4];
+  int is32[4];
+  int nk; // < 0: every row gets the no-match key (key column types differ between the sides)
+};
+constexpr uint64_t COMP_NO_MATCH = ~0ull; // (composites are < 2^62)
+__device__ __forceinline__ int64_t comp_value(const CompJoinKeys &ck, int c, int64_t i) {
+  return ck.is32[c] ? (int64_t)((const int32_t *)ck.vals[c])[i] : ((const int64_t *)ck.vals[c])[i];
+}
+__global__ __launch_bounds__(256) void comp_join_minmax_kernel(const void *__restrict__ vals, int is32, int64_t n, long long *mm) {
+  long long lo = INT64_MAX, hi = INT64_MIN;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const long long v = is32 ? (long long)((const int32_t *)vals)[i] : ((const long long *)vals)[i];
+    lo = min(lo, v);
+    hi = max(hi, v);
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    lo = min(lo, (long long)shfl_xor_u64((uint64_t)lo, m));
+    hi = max(hi, (long long)shfl_xor_u64((uint64_t)hi, m));
+  }
+  if (lane_id() == 0) {
+    atomicMin(mm, lo);
+    atomicMax(mm + 1, hi);
+  }
+}
+__global__ __launch_bounds__(256) void comp_join_keys_kernel(CompJoinKeys ck, int64_t n, uint64_t *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key = 0;
+  bool ok = ck.nk > 0;
+  for (int c = 0; c < ck.nk && ok; c++) {
+    if (ck.valid[c] && !((ck.valid[c][i >> 6] >> (i & 63)) & 1ull)) ok = false;
+    else {
+      const uint64_t d = (uint64_t)comp_value(ck, c, i) - (uint64_t)ck.min[c]; // (wraps to a huge value below the minimum)
+      if (d >= ck.range[c]) ok = false;
+      else key += d * ck.stride[c];
+    }
+  }
+  out[i] = ok ? key : COMP_NO_MATCH;
+}
+// build side: ranges of the key columns over all build batches -> j->comp, and the composite key of every build row
+static BufP composite_build_keys(sqlrs_hash_join *j) {
+  Ctx *ctx = j->ctx;
+  const size_t nk = j->lkeys.size();
+  // OPT-IN (SQLRS_JOIN_COMPOSITE=1, read per build): exact equality is NOT what the reference computes — see the note above
+  const char *e = std::getenv("SQLRS_JOIN_COMPOSITE");
+  if (!e || e[0] != '1') return nullptr;
+  if (nk < 2 || nk > 4 || j->lazy_table || j->nB < 1 || j->left_keycol_parts.size() != j->left_batches.size()) return nullptr;
+  for (const std::vector<DCol> &part : j->left_keycol_parts) {
+    if (part.size() != nk) return nullptr;
+    for (size_t c = 0; c < nk; c++) {
+      const DCol &k = part[c];
+      if ((k.dtype != SQLRS_INT64 && k.dtype != SQLRS_INT32) || k.dtype != j->left_keycol_parts[0][c].dtype || k.stride == 0 ||
+          (k.validity && count_nulls(ctx, k) != 0))
+        return nullptr;
+    }
+  }
+  BufP mm = ctx->alloc(16 * nk);
+  std::vector<long long> init;
+  for (size_t c = 0; c < nk; c++) {
+    init.push_back(INT64_MAX);
+    init.push_back(INT64_MIN);
+  }
+  SQ_HIP(hipMemcpyAsync(mm->p, init.data(), 16 * nk, hipMemcpyHostToDevice, ctx->stream));
+  SQ_HIP(hipStreamSynchronize(ctx->stream)); // (`init` is pageable host memory)
+  for (const std::vector<DCol> &part : j->left_keycol_parts)
+    for (size_t c = 0; c < nk; c++) {
+      const int64_t rows = part[c].length;
+      if (rows == 0) continue;
+      const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(rows, 256), 4 * (int64_t)ctx->num_cus);
+      comp_join_minmax_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(part[c].values, part[c].dtype == SQLRS_INT32, rows,
+                                                                         mm->as<long long>() + 2 * c);
+    }
+  SQ_HIP(hipGetLastError());
+  const long long *h = (const long long *)ctx->fetch(mm->p, 16 * nk);
+  sqlrs_hash_join::Composite cp;
+  cp.nk = (int)nk;
+  unsigned __int128 total = 1;
+  for (size_t c = 0; c < nk; c++) {
+    if (h[2 * c] > h[2 * c + 1]) return nullptr;
+    cp.dtype[c] = j->left_keycol_parts[0][c].dtype;
+    cp.min[c] = h[2 * c];
+    cp.range[c] = (uint64_t)h[2 * c + 1] - (uint64_t)h[2 * c] + 1; // (0 = all 2^64 values: caught by the product below)
+    if (cp.range[c] == 0) return nullptr;
+    total *= cp.range[c];
+    if (total >= ((unsigned __int128)1 << 62)) return nullptr; // the composite does not fit: hashes
+  }
+  uint64_t stride = 1;
+  for (size_t c = nk; c-- > 0;) {
+    cp.stride[c] = stride;
+    stride *= cp.range[c];
+  }
+  cp.on = true;
+  j->comp = cp;
+  BufP keys = ctx->alloc(8 * (size_t)std::max<int64_t>(j->nB, 1));
+  int64_t off = 0;
+  ProfScope ps(ctx, "normalize_keys");
+  for (const std::vector<DCol> &part : j->left_keycol_parts) {
+    const int64_t rows = part[0].length;
+    if (rows == 0) continue;
+    CompJoinKeys ck{};
+    ck.nk = (int)nk;
+    for (size_t c = 0; c < nk; c++) {
+      ck.vals[c] = part[c].values;
+      ck.valid[c] = nullptr;
+      ck.min[c] = cp.min[c];
+      ck.range[c] = cp.range[c];
+      ck.stride[c] = cp.stride[c];
+      ck.is32[c] = cp.dtype[c] == SQLRS_INT32;
+    }
+    comp_join_keys_kernel<<<dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, ctx->stream>>>(ck, rows, keys->as<uint64_t>() + off);
+    off += rows;
+  }
+  SQ_HIP(hipGetLastError());
+  return keys;
+}
+// probe side: the same composite, the no-match key for rows that cannot have a partner
+static NKeys composite_probe_keys(sqlrs_hash_join *j, const std::function<const DCol &(int)> &col, int64_t rows) {
+  Ctx *ctx = j->ctx;
+  std::vector<DCol> kc = eval_key_cols(ctx, j->rkeys, col, rows);
+  NKeys k;
+  k.rows = rows;
+  k.exact = true;
+  k.dtype = SQLRS_INT64;
+  k.keys = ctx->alloc(8 * (size_t)std::max<int64_t>(rows, 1));
+  if (rows == 0) return k;
+  const sqlrs_hash_join::Composite &cp = j->comp;
+  CompJoinKeys ck{};
+  ck.nk = cp.nk;
+  for (int c = 0; c < cp.nk; c++) {
+    const DCol &d = kc[(size_t)c];
+    if (d.dtype != cp.dtype[c]) ck.nk = -1; // (the reference's hashes differ by type: nothing matches)
+    ck.vals[c] = d.values;
+    ck.valid[c] = (d.validity && d.null_count != 0) ? d.validity : nullptr;
+    ck.min[c] = cp.min[c];
+    ck.range[c] = cp.range[c];
+    ck.stride[c] = cp.stride[c];
+    ck.is32[c] = cp.dtype[c] == SQLRS_INT32;
+  }
+  ProfScope ps(ctx, "normalize_keys");
+  comp_join_keys_kernel<<<dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, ctx->stream>>>(ck, rows, k.keys->as<uint64_t>());
+  SQ_HIP(hipGetLastError());
+  return k;
 }
 
 static void build_hash_table(sqlrs_hash_join *j);
@@ -934,14 +1094,16 @@ static void build_table(sqlrs_hash_join *j) {
   // concat key parts
   int64_t n = j->nB;
   // one build batch (the usual case): its normalised keys ARE the key array, no concat copy
-  const bool single = j->left_key_parts.size() == 1 && j->left_key_parts[0].keys && j->left_key_parts[0].keys->owned;
-  BufP keys = single ? j->left_key_parts[0].keys : ctx->alloc(8 * (size_t)std::max<int64_t>(n, 1));
+  BufP ckeys = composite_build_keys(j); // several integer key columns: one exact key (or null: as normalised per batch)
+  j->left_keycol_parts.clear();
+  const bool single = !ckeys && j->left_key_parts.size() == 1 && j->left_key_parts[0].keys && j->left_key_parts[0].keys->owned;
+  BufP keys = ckeys ? ckeys : (single ? j->left_key_parts[0].keys : ctx->alloc(8 * (size_t)std::max<int64_t>(n, 1)));
   BufP validity;
   bool any_null = false;
   for (const NKeys &p : j->left_key_parts) any_null |= (p.validity != nullptr);
-  j->exact = j->left_key_parts[0].exact;
-  j->key_dtype = j->left_key_parts[0].dtype;
-  {
+  j->exact = ckeys ? true : j->left_key_parts[0].exact;
+  j->key_dtype = ckeys ? SQLRS_INT64 : j->left_key_parts[0].dtype;
+  if (!ckeys) {
     size_t off = 0;
     std::vector<DCol> vparts;
     for (const NKeys &p : j->left_key_parts) {
@@ -1471,7 +1633,7 @@ static bool semi_join_probe(sqlrs_hash_join *j, InBatch &ib, const NKeys &pk, DB
 static DBatch probe_batch(sqlrs_hash_join *j, InBatch &ib, Pairs *pairs_only, Pairs *also = nullptr) {
   Ctx *ctx = j->ctx;
   auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
-  NKeys pk = eval_keys(ctx, j->rkeys, colfn, ib.rows());
+  NKeys pk = j->comp.on ? composite_probe_keys(j, colfn, ib.rows()) : eval_keys(ctx, j->rkeys, colfn, ib.rows());
   if (!pairs_only && !also) {
     DBatch semi;
     if (semi_join_probe(j, ib, pk, &semi)) return semi;
@@ -1557,7 +1719,12 @@ static int hash_join_build_push_device(sqlrs_hash_join_t *j, const sqlrs_batch_t
       if (i < 0 || (size_t)i >= b.cols.size()) fail(SQLRS_ERR_INTERNAL, "input ref out of range");
       return b.cols[(size_t)i];
     };
-    j->left_key_parts.push_back(eval_keys(j->ctx, j->lkeys, colfn, b.rows));
+    if (j->lkeys.size() >= 2 && j->lkeys.size() <= 4 && !j->lazy_table) { // (kept for the composite key, build_table)
+      std::vector<DCol> kc = eval_key_cols(j->ctx, j->lkeys, colfn, b.rows);
+      j->left_key_parts.push_back(normalize_keys(j->ctx, kc, b.rows));
+      j->left_keycol_parts.push_back(std::move(kc));
+    } else
+      j->left_key_parts.push_back(eval_keys(j->ctx, j->lkeys, colfn, b.rows));
     j->left_batches.push_back(std::move(b));
     j->empty_build = false;
   });

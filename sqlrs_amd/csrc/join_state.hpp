@@ -24,6 +24,19 @@ struct sqlrs_hash_join {
   // build
   std::vector<sq::DBatch> left_batches;
   std::vector<sq::NKeys> left_key_parts;
+  // Several key columns (ON a.x = b.x AND a.y = b.y), OPT-IN (SQLRS_JOIN_COMPOSITE=1: exact equality instead of the
+  // reference's match-by-hash, whose collisions are part of its results): the evaluated key columns of every build batch are
+  // kept until the build is finished; when they are all integers without NULLs whose ranges multiply to < 2^62, both sides
+  // are joined on ONE exact int64 key, sum_c (v_c - min_c) * stride_c (join.hip, composite_build_keys) — dense ranges then
+  // take the direct-address table, the rest the LDS route
+  std::vector<std::vector<sq::DCol>> left_keycol_parts;
+  struct Composite {
+    bool on = false;
+    int nk = 0;
+    int32_t dtype[4] = {0, 0, 0, 0};
+    int64_t min[4] = {0, 0, 0, 0};
+    uint64_t range[4] = {0, 0, 0, 0}, stride[4] = {0, 0, 0, 0};
+  } comp;
   bool finished = false, empty_build = true;
   sq::DBatch left;
   int64_t nB = 0;
