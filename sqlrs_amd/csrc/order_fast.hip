@@ -1273,13 +1273,6 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
       return order_wide<KIND>(ctx, key, desc, carry, n, imin, range, key_out, carry_out, perm_out, want_perm);
     }
   }
-  if constexpr (KIND != OKIND_I32) {
-    // a value with a visible share of the rows: the splitter route gives it a group of its own that is copied, not sorted
-    // (order_wide works on any range; if it declines, the plan below runs as before)
-    if (heavy_probe && heavy_cnt >= OW_HEAVY_MIN &&
-        order_wide<KIND>(ctx, key, desc, carry, n, optimistic ? 0 : imin, optimistic ? ~0ull : range, key_out, carry_out, perm_out, want_perm))
-      return true;
-  }
   int kbits = 1;
   while (kbits < 32 && (1ull << kbits) <= range) kbits++;
   unsigned int *oob = nullptr;
@@ -1309,6 +1302,14 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   // (hbm_only: every key bit goes through the HBM passes, <= 4 of them, and the finish is a streaming unpack — the second
   //  try after a group turned out larger than the in-LDS finish takes: few distinct keys spread over many bits)
   const int top = hbm_only ? kbits : std::min(kbits, want), rbits = kbits - top;
+  if constexpr (KIND != OKIND_I32) {
+    // a value with a visible share of the rows: the splitter route gives it a group of its own that is copied, not sorted
+    // (order_wide works on any range; if it declines, the plan below runs as before)
+    // (only when low bits are left for the in-LDS finish: with every bit sorted in HBM no group is too large)
+    if (heavy_probe && rbits > 0 && heavy_cnt >= OW_HEAVY_MIN &&
+        order_wide<KIND>(ctx, key, desc, carry, n, optimistic ? 0 : imin, optimistic ? ~0ull : range, key_out, carry_out, perm_out, want_perm))
+      return true;
+  }
   // 1. stable multi-split passes on bits [32 + rbits, 32 + kbits) of the word, LSD order
   const int64_t nblocks = ceil_div(n, OW_TILE);
   BufP wa = ctx->alloc(8 * (size_t)n), wb = ctx->alloc(8 * (size_t)n);

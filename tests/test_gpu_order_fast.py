@@ -402,3 +402,19 @@ def test_order_one_key_with_nulls_split(hip, oracle, shape):
         assert got.column(i).equals(exp.column(i)), names[i]
     split = shape != "f64_few_valid_rows"        # (260 000 valid rows: not worth the split, general path)
     assert (prof.get("order_split", (0, 0))[1] > 0) == split, prof
+
+
+def test_order_heavy_values_with_all_bits_in_hbm_stay_on_the_narrow_route(hip, oracle):
+    """1001 distinct keys over 10 bits, ~1300 rows each: every key bit goes through the HBM passes (no in-LDS finish, no limit on
+    a group), so the heavy-value probe — which does see values with a visible share here — must not divert the call"""
+    rng = np.random.default_rng(1001)
+    k = keys_of(rng, "i64_10bit_many_ties")
+    k[: N // 4] = 77                           # a quarter of the rows carry one value
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(np.arange(N, dtype=np.int64))], names=["k", "row"])
+    hip.profile(True)
+    (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(0), asc=True)], [b]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=True)], [b]).execute())
+    assert got.equals(exp)
+    assert prof.get("order_knots", (0, 0))[1] == 0 and prof.get("order_split", (0, 0))[1] == 2, prof
