@@ -418,3 +418,60 @@ def test_order_heavy_values_with_all_bits_in_hbm_stay_on_the_narrow_route(hip, o
     (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=True)], [b]).execute())
     assert got.equals(exp)
     assert prof.get("order_knots", (0, 0))[1] == 0 and prof.get("order_split", (0, 0))[1] == 2, prof
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_order_routes(hip, oracle, seed, monkeypatch):
+    """random key type / width / distribution / heavy values / NULLs / key count / directions / column mix at sizes where the
+    fast routes run (narrow, splitters, composite, NULL split, their fallbacks and the general path) — against the oracle"""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(1 << 20, 3 << 20))
+    if rng.random() < 0.5:
+        monkeypatch.setenv("SQLRS_ORDER_SAMPLE", "1")       # key range from a sample, as for >= 2^24 rows
+
+    def key_column():
+        kind = rng.choice(["i64", "i32", "f64"])
+        bits = int(rng.integers(1, 64 if kind != "i32" else 32))
+        if kind == "f64":
+            v = rng.choice([rng.normal(0, 10.0 ** rng.integers(-3, 9), n), rng.random(n), np.exp(rng.normal(0, 12, n)) * rng.choice([-1.0, 1.0], n)])
+        else:
+            lo = int(rng.integers(-(1 << 62), 1 << 61)) if kind == "i64" else int(rng.integers(-(1 << 30), 1 << 29))
+            hi = lo + (1 << bits) - 1
+            cap = (1 << 63) - 1 if kind == "i64" else (1 << 31) - 1
+            v = rng.integers(lo, min(hi, cap), n, dtype=np.int64, endpoint=True)
+            v = v.astype(np.int32) if kind == "i32" else v
+        shape = rng.choice(["random", "sorted", "reversed", "nearly_sorted"], p=[0.7, 0.1, 0.1, 0.1])
+        if shape == "sorted":
+            v = np.sort(v)
+        elif shape == "reversed":
+            v = np.sort(v)[::-1].copy()
+        elif shape == "nearly_sorted":
+            v = np.sort(v)
+            i = rng.integers(0, n - 1, 5)
+            v[i], v[i + 1] = v[i + 1].copy(), v[i].copy()
+        for _ in range(int(rng.integers(0, 4))):             # heavy values
+            v[rng.random(n) < rng.choice([0.001, 0.02, 0.3])] = v[int(rng.integers(0, n))]
+        mask = (rng.random(n) < rng.choice([0.01, 0.2])) if rng.random() < 0.3 else None
+        return pa.array(v, mask=mask)
+
+    nk = int(rng.choice([1, 1, 1, 2, 3]))
+    arrays = [key_column() for _ in range(nk)]
+    names = [f"k{i}" for i in range(nk)]
+    extra = int(rng.integers(0, 4))
+    if extra >= 1:
+        arrays.append(pa.array(np.arange(n, dtype=np.int64)))
+        names.append("row")
+    if extra >= 2:
+        arrays.append(pa.array(rng.random(n), mask=(rng.random(n) < 0.1) if rng.random() < 0.5 else None))
+        names.append("f")
+    if extra >= 3:
+        arrays.append(pa.array(rng.integers(0, 1000, n).astype(np.int32)))
+        names.append("i")
+    order = list(rng.permutation(len(arrays)))               # the key columns anywhere in the table
+    b = pa.RecordBatch.from_arrays([arrays[i] for i in order], names=[names[i] for i in order])
+    ob = [OrderBy(InputRef(order.index(i)), asc=bool(rng.random() < 0.5)) for i in range(nk)]
+    cut = int(rng.integers(1, n - 1))
+    (got,) = list(OrderExecutor(hip, ob, [b.slice(0, cut), b.slice(cut)]).execute())
+    (exp,) = list(OrderExecutor(oracle, ob, [b]).execute())
+    for i in range(b.num_columns):
+        assert got.column(i).equals(exp.column(i)), (seed, b.schema.names[i])
