@@ -8,6 +8,7 @@ TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-operators"
+if [ -z "$ONLY_OPS" ]; then   # (ONLY_OPS=1: the operator legs only)
 rm -rf /tmp/prof_kt /tmp/prof_fetch /tmp/prof_write
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $CMD > gpurun_out/${TAG}_kt.log 2>&1 < /dev/null
 f=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)
@@ -52,6 +53,7 @@ for k, pref in short.items():
 json.dump(out, open(f"gpurun_out/{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
 PY
+fi
 
 # ---- the per-operator legs (C2 / C3 / C4 / Order of bench.py's `operators` object): kernel trace + the two counter passes of
 #      `python tools/operators_only.py` (the same bench_operators() code, no C5 tables) -> gpurun_out/<tag>_ops_kernel_stats.csv,
@@ -59,7 +61,8 @@ PY
 OCMD="python tools/operators_only.py"
 rm -rf /tmp/prof_okt /tmp/prof_ofetch /tmp/prof_owrite
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_okt -- $OCMD > gpurun_out/${TAG}_ops_kt.log 2>&1 < /dev/null
-f=$(find /tmp/prof_okt -name '*kernel_stats.csv' | head -1)
+# (the legs fed by the native caller start child processes, each with output files of its own: the largest is the python process's)
+f=$(find /tmp/prof_okt -name '*kernel_stats.csv' -printf '%s %p\n' | sort -nr | head -1 | cut -d' ' -f2-)
 test -n "$f" && cp "$f" gpurun_out/${TAG}_ops_kernel_stats.csv && head -14 "$f" | cut -c1-160
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/prof_o$(echo $c | tr A-Z a-z | cut -d_ -f1)
@@ -72,7 +75,8 @@ def per_kernel(d, counter):
     fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(list)
     if not fs: return acc
-    for r in csv.DictReader(open(fs[0])):
+    import os
+    for r in csv.DictReader(open(max(fs, key=os.path.getsize))):  # (child processes write small files of their own)
         if r["Counter_Name"] != counter: continue
         acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return acc
