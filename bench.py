@@ -1503,7 +1503,8 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     del bo, v1, val
     be.fn("ctx_pool_trim")(be.ctx)
     torch.cuda.empty_cache()
-    res.update(bench_host_resident(be, abi, datagen, torch, dev))
+    if not os.environ.get("SQLRS_BENCH_SKIP_HOST"):  # (tools/profile_round.sh: the counter passes want the device legs only)
+        res.update(bench_host_resident(be, abi, datagen, torch, dev))
     for k_, v_ in res.items():
         log(f"[bench] {k_}: {v_}")
     return res

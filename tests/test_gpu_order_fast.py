@@ -475,3 +475,25 @@ def test_fuzz_order_routes(hip, oracle, seed, monkeypatch):
     (exp,) = list(OrderExecutor(oracle, ob, [b]).execute())
     for i in range(b.num_columns):
         assert got.column(i).equals(exp.column(i)), (seed, b.schema.names[i])
+
+
+@pytest.mark.parametrize("case", ["same_column_twice", "exactly_2p20_rows", "int32_desc_min_max", "second_key_decides_everything"])
+def test_order_composite_edge_cases(hip, oracle, case):
+    rng = np.random.default_rng(len(case))
+    n = 1 << 20 if case == "exactly_2p20_rows" else N
+    a = rng.integers(-1000, 1000, n, dtype=np.int64)
+    b32 = rng.integers(-(1 << 31), (1 << 31) - 1, n, dtype=np.int64, endpoint=True).astype(np.int32)
+    b32[3], b32[4] = -(1 << 31), (1 << 31) - 1
+    row = np.arange(n, dtype=np.int64)
+    if case == "same_column_twice":
+        arrays, ob = [pa.array(a), pa.array(row)], [OrderBy(InputRef(0), asc=True), OrderBy(InputRef(0), asc=False)]
+    elif case == "int32_desc_min_max":
+        arrays, ob = [pa.array(b32), pa.array(a), pa.array(row)], [OrderBy(InputRef(0), asc=False), OrderBy(InputRef(1), asc=True)]
+    elif case == "second_key_decides_everything":   # the first key is constant
+        arrays, ob = [pa.array(np.full(n, 5, dtype=np.int64)), pa.array(a), pa.array(row)], [OrderBy(InputRef(0), asc=False), OrderBy(InputRef(1), asc=False)]
+    else:
+        arrays, ob = [pa.array(a), pa.array(b32), pa.array(row)], [OrderBy(InputRef(0), asc=True), OrderBy(InputRef(1), asc=True)]
+    b = pa.RecordBatch.from_arrays(arrays, names=[f"c{i}" for i in range(len(arrays))])
+    (got,) = list(OrderExecutor(hip, ob, [b]).execute())
+    (exp,) = list(OrderExecutor(oracle, ob, [b]).execute())
+    assert got.equals(exp)

@@ -58,6 +58,7 @@ fi
 # ---- the per-operator legs (C2 / C3 / C4 / Order of bench.py's `operators` object): kernel trace + the two counter passes of
 #      `python tools/operators_only.py` (the same bench_operators() code, no C5 tables) -> gpurun_out/<tag>_ops_kernel_stats.csv,
 #      gpurun_out/<tag>_ops_pmc_traffic.json (every kernel with > 1e5 KiB fetched or written per launch)
+export SQLRS_BENCH_SKIP_HOST=1   # (device-resident legs only: the host-fed legs are PCIe and memcpy, and start child processes)
 OCMD="python tools/operators_only.py"
 rm -rf /tmp/prof_okt /tmp/prof_ofetch /tmp/prof_owrite
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_okt -- $OCMD > gpurun_out/${TAG}_ops_kt.log 2>&1 < /dev/null
@@ -75,8 +76,13 @@ def per_kernel(d, counter):
     fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(list)
     if not fs: return acc
-    import os
-    for r in csv.DictReader(open(max(fs, key=os.path.getsize))):  # (child processes write small files of their own)
+    # (the legs fed by the native caller start child processes, each with a counter file of its own — 20 000 launches each,
+    #  not small files: the profiled command's own file is the one with the most DISTINCT kernels)
+    def distinct(f):
+        return len({r["Kernel_Name"] for r in csv.DictReader(open(f))})
+    path = max(fs, key=distinct)
+    print(counter, "from", path, "of", len(fs), "files")
+    for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter: continue
         acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return acc
