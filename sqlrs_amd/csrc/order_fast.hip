@@ -162,10 +162,10 @@ __global__ __launch_bounds__(256) void order_minmax_kernel(const void *__restric
 constexpr int OW_WG = 512, OW_WAVES = OW_WG / 64, OW_ITEMS = 8, OW_TILE = OW_WG * OW_ITEMS;
 
 // RAW: the pass reads the raw key column (row id = position) and builds  off << 32 | row  in registers
-template <int KIND, bool RAW>
+template <int KIND, bool RAW, bool REC_IN = false>
 __device__ __forceinline__ uint64_t ow_word(const void *__restrict__ src, int64_t i, int desc, uint64_t imin) {
   if (RAW) return ((order_image<KIND>(src, i, desc) - imin) << 32) | (uint64_t)(uint32_t)i;
-  return __builtin_nontemporal_load((const uint64_t *)src + i);
+  return __builtin_nontemporal_load((const uint64_t *)src + (REC_IN ? 2 * i : i)); // (REC_IN: the word of a {word, value} record)
 }
 
 // TILED: the pass runs over the tile list `tiles` (tiles aligned to the digit segments of the previous pass, see
@@ -187,7 +187,7 @@ __device__ __forceinline__ void ow_tile_of(const OwTile *__restrict__ tiles, int
 
 // `oob` (RAW pass with an optimistic key range only): set when a key lies outside [imin, imin + 2^kbits) — the word
 // cannot hold its offset, nothing of the attempt is valid
-template <int KIND, bool RAW, bool TILED = false>
+template <int KIND, bool RAW, bool TILED = false, bool REC_IN = false>
 __global__ __launch_bounds__(OW_WG) void ow_hist_kernel(const void *__restrict__ src, int64_t n, int desc, uint64_t imin,
                                                         int shift, int64_t nblocks, uint32_t *__restrict__ hist,
                                                         const OwTile *__restrict__ tiles, unsigned int *__restrict__ oob = nullptr,
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(OW_WG) void ow_hist_kernel(const void *__restrict__
   if (threadIdx.x < 256) h[threadIdx.x] = 0;
   uint64_t k[OW_ITEMS];
 #pragma unroll
-  for (int r = 0; r < OW_ITEMS; r++) k[r] = ow_word<KIND, RAW>(src, t0 + min((uint32_t)(threadIdx.x + r * OW_WG), tl - 1), desc, imin);
+  for (int r = 0; r < OW_ITEMS; r++) k[r] = ow_word<KIND, RAW, REC_IN>(src, t0 + min((uint32_t)(threadIdx.x + r * OW_WG), tl - 1), desc, imin);
   if (RAW && oob) { // (the word keeps 32 bits of the offset: test the offset itself)
     bool bad = false;
 #pragma unroll
@@ -260,7 +260,8 @@ __device__ __forceinline__ void stable_wave_ranks(const uint32_t (&dig)[ITEMS], 
 // workgroup does not already provide.)
 // REC (NPAY == 1): the pass writes {word, carried value} records into `words_out` (16 B per row) — what the
 // in-LDS finish reads; a (tile, digit) run of 16 rows is one 256-byte piece instead of 128 B in each of two columns
-template <int KIND, bool RAW, int NPAY, bool TILED = false, bool REC = false>
+// REC_IN: the previous pass wrote records (both HBM passes of the usual two then move one 16-byte piece per row)
+template <int KIND, bool RAW, int NPAY, bool TILED = false, bool REC = false, bool REC_IN = false>
 __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay,
                                                            int64_t n, int desc, uint64_t imin, int shift, int64_t nblocks,
                                                            const uint32_t *__restrict__ offsets,
@@ -286,6 +287,12 @@ __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restric
 #pragma unroll
   for (int j = 0; j < OW_ITEMS; j++) {
     const int64_t i = tbase + min(wrow + j * 64, len - 1);
+    if (REC_IN) {
+      const u64x2 rec = __builtin_nontemporal_load((const u64x2 *)src + i);
+      k[j] = rec.x;
+      v[NPAY ? j : 0] = rec.y;
+      continue;
+    }
     k[j] = ow_word<KIND, RAW>(src, i, desc, imin);
     if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
   }
@@ -1312,14 +1319,20 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   }
   // 1. stable multi-split passes on bits [32 + rbits, 32 + kbits) of the word, LSD order
   const int64_t nblocks = ceil_div(n, OW_TILE);
-  BufP wa = ctx->alloc(8 * (size_t)n), wb = ctx->alloc(8 * (size_t)n);
-  BufP pa = NPAY ? ctx->alloc(8 * (size_t)n) : nullptr, pb = NPAY ? ctx->alloc(8 * (size_t)n) : nullptr;
+  // (the usual plan — two passes, one carried column, an in-LDS finish — moves {word, value} records through BOTH passes and
+  //  needs none of the four column buffers; SQLRS_ORDER_REC1=0, read per call: records out of the last pass only)
+  const char *tl_e0 = std::getenv("SQLRS_ORDER_TILED"), *rec_e0 = std::getenv("SQLRS_ORDER_REC"), *rec1_e = std::getenv("SQLRS_ORDER_REC1");
+  const bool rec1 = NPAY == 1 && rbits > 0 && top > 8 && top <= 16 && !(tl_e0 && std::atoi(tl_e0) == 0) && !(rec_e0 && std::atoi(rec_e0) == 0) &&
+                    !(rec1_e && rec1_e[0] == '0');
+  BufP wa = rec1 ? nullptr : ctx->alloc(8 * (size_t)n), wb = rec1 ? nullptr : ctx->alloc(8 * (size_t)n);
+  BufP pa = NPAY && !rec1 ? ctx->alloc(8 * (size_t)n) : nullptr, pb = NPAY && !rec1 ? ctx->alloc(8 * (size_t)n) : nullptr;
+  BufP recbuf1 = rec1 ? ctx->alloc(16 * (size_t)n) : nullptr;
   BufP hist = ctx->alloc(4 * (size_t)(256 * nblocks)), offs = ctx->alloc(4 * (size_t)(256 * nblocks)), total = ctx->alloc(8);
   const void *src = key.values;
   const uint64_t *psrc = NPAY ? carry->v<uint64_t>() : nullptr;
-  uint64_t *wdst = wa->as<uint64_t>(), *walt = wb->as<uint64_t>();
-  uint64_t *pdst = NPAY ? pa->as<uint64_t>() : nullptr, *palt = NPAY ? pb->as<uint64_t>() : nullptr;
-  bool raw = true;
+  uint64_t *wdst = rec1 ? nullptr : wa->as<uint64_t>(), *walt = rec1 ? nullptr : wb->as<uint64_t>();
+  uint64_t *pdst = NPAY && !rec1 ? pa->as<uint64_t>() : nullptr, *palt = NPAY && !rec1 ? pb->as<uint64_t>() : nullptr;
+  bool raw = true, rec_in = false;
   dim3 g((unsigned)nblocks), b(OW_WG);
   // The last of two HBM passes (rbits > 0: an in-LDS finish follows) runs over segment-aligned tiles, which makes
   // the group boundaries a by-product of its count matrix, and (one carried column) writes 16-byte records.
@@ -1346,10 +1359,17 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
           firsttile->as<uint32_t>(), segstart->as<int64_t>(), (uint32_t)ntmax, (OwTile *)tiles2->p);
       dim3 g2((unsigned)ntmax);
       const OwTile *tp = (const OwTile *)tiles2->p;
-      ow_hist_kernel<KIND, false, true><<<g2, b, 0, ctx->stream>>>(src, n, desc, imin, shift, ntmax, hist2->as<uint32_t>(), tp);
+      if (rec_in) ow_hist_kernel<KIND, false, true, true><<<g2, b, 0, ctx->stream>>>(src, n, desc, imin, shift, ntmax, hist2->as<uint32_t>(), tp);
+      else ow_hist_kernel<KIND, false, true><<<g2, b, 0, ctx->stream>>>(src, n, desc, imin, shift, ntmax, hist2->as<uint32_t>(), tp);
       SQ_HIP(hipGetLastError());
       exclusive_scan_u32(ctx, hist2->as<uint32_t>(), 256 * ntmax, nullptr, offs2->as<uint32_t>(), total->as<uint64_t>());
-      if (use_rec) {
+      if (use_rec && rec_in) {
+        ow_scatter_kernel<KIND, false, NPAY, true, NPAY == 1, NPAY == 1><<<g2, b, 0, ctx->stream>>>(
+            src, nullptr, n, desc, imin, shift, ntmax, offs2->as<uint32_t>(), recbuf->as<uint64_t>(), nullptr, tp, oob);
+        src = recbuf->p;
+        psrc = nullptr;
+        rec_form = true;
+      } else if (use_rec) {
         ow_scatter_kernel<KIND, false, NPAY, true, NPAY == 1><<<g2, b, 0, ctx->stream>>>(
             src, psrc, n, desc, imin, shift, ntmax, offs2->as<uint32_t>(), recbuf->as<uint64_t>(), nullptr, tp, oob);
         src = recbuf->p;
@@ -1369,6 +1389,16 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     else ow_hist_kernel<KIND, false><<<g, b, 0, ctx->stream>>>(src, n, desc, imin, shift, nblocks, hist->as<uint32_t>(), nullptr);
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(), total->as<uint64_t>());
+    if (raw && rec1) { // records out of the raw pass: the tiled pass behind it reads one 16-byte piece per row
+      ow_scatter_kernel<KIND, true, NPAY, false, NPAY == 1><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(),
+                                                                                     recbuf1->as<uint64_t>(), nullptr, nullptr, oob);
+      SQ_HIP(hipGetLastError());
+      src = recbuf1->p;
+      psrc = nullptr;
+      raw = false;
+      rec_in = true;
+      return;
+    }
     if (raw) ow_scatter_kernel<KIND, true, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst, nullptr, oob);
     else ow_scatter_kernel<KIND, false, NPAY><<<g, b, 0, ctx->stream>>>(src, psrc, n, desc, imin, shift, nblocks, offs->as<uint32_t>(), wdst, pdst, nullptr, oob);
     SQ_HIP(hipGetLastError());

@@ -21,6 +21,7 @@ g = torch.Generator(device=dev).manual_seed(3)
 keys = {"f64_unit": torch.rand(n, dtype=torch.float64, device=dev, generator=g),
         "i64_63bit": torch.randint(-(1 << 62), 1 << 62, (n,), dtype=torch.int64, device=dev, generator=g),
         "f64_normal": torch.randn(n, dtype=torch.float64, device=dev, generator=g)}
+keys["i64_31bit"] = torch.randint(0, 1 << 31, (n,), dtype=torch.int64, device=dev, generator=g)   # the bench's Order shape
 z = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
 z[torch.rand(n, device=dev, generator=g) < 0.3] = 0.0           # a heavy value: 30 % zeros
 keys["f64_zeros30"] = z
