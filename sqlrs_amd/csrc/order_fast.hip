@@ -549,6 +549,13 @@ __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__res
   }
 }
 
+// the key value of an output row: 4 bytes for an int32 key column, 8 otherwise
+template <int KIND> __device__ __forceinline__ void order_store_key(void *__restrict__ key_out, int64_t i, uint64_t image, int desc) {
+  const uint64_t val = order_unimage<KIND>(image, desc);
+  if (KIND == OKIND_I32) ((int32_t *)key_out)[i] = (int32_t)(int64_t)val;
+  else ((uint64_t *)key_out)[i] = val;
+}
+
 // rbits == 0: everything was sorted in HBM, the finish is a streaming unpack
 template <int KIND, int NPAY>
 __global__ void ow_unpack_kernel(const uint64_t *__restrict__ words, int64_t n, int desc, uint64_t imin,
@@ -874,7 +881,7 @@ __global__ __launch_bounds__(256) void owk_group_table_kernel(const uint32_t *__
 template <int KIND, int NPAY, bool REC>
 __global__ __launch_bounds__(256) void owk_pure_copy_kernel(const uint64_t *__restrict__ words, const uint2 *__restrict__ items,
                                                             const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gend,
-                                                            int desc, uint64_t imin, uint64_t *__restrict__ key_out,
+                                                            int desc, uint64_t imin, void *__restrict__ key_out,
                                                             uint64_t *__restrict__ pay_out, uint32_t *__restrict__ perm_out) {
   const uint2 it = items[blockIdx.x];
   const uint32_t lo = gstart[it.x] + it.y * OWK_PURE_CHUNK, hi = min(gend[it.x], lo + OWK_PURE_CHUNK);
@@ -886,7 +893,7 @@ __global__ __launch_bounds__(256) void owk_pure_copy_kernel(const uint64_t *__re
       v = rec.y;
     } else
       kw = __builtin_nontemporal_load(words + i);
-    key_out[i] = order_unimage<KIND>(kw + imin, desc);
+    order_store_key<KIND>(key_out, i, kw + imin, desc);
     if (perm_out) perm_out[i] = (uint32_t)v;
     else if (NPAY) pay_out[i] = v;
   }
@@ -897,7 +904,7 @@ template <int KIND, int NPAY, int R, bool REC>
 __global__ __launch_bounds__(FIN_WG, R == 8 ? 4 : 1) void owk_finish_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pay,
                                                             const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gend,
                                                             const uint64_t *__restrict__ sub, uint32_t G, int desc, uint64_t imin,
-                                                            uint64_t *__restrict__ key_out, uint64_t *__restrict__ pay_out,
+                                                            void *__restrict__ key_out, uint64_t *__restrict__ pay_out,
                                                             uint32_t *__restrict__ perm_out, uint32_t m_above, uint32_t m_upto) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lo = gstart[blockIdx.x], hi = gend[blockIdx.x];
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(FIN_WG, R == 8 ? 4 : 1) void owk_finish_kernel(cons
       for (int j = 0; j < R; j++) {
         if (!valid[j]) continue;
         const uint32_t i = lo + (uint32_t)(w * cpw + j) * 64 + lane;
-        key_out[i] = order_unimage<KIND>(k[j] + base + imin, desc);
+        order_store_key<KIND>(key_out, i, k[j] + base + imin, desc);
         if (perm_out) perm_out[i] = (uint32_t)v[NPAY ? j : 0];
         else if (NPAY) pay_out[i] = v[j];
       }
@@ -1054,7 +1061,7 @@ __global__ __launch_bounds__(FIN_WG, R == 8 ? 4 : 1) void owk_finish_kernel(cons
         pos = (uint32_t)(q + 1) + before;
       }
       const uint32_t i = lo + pos;
-      key_out[i] = order_unimage<KIND>(me + base + imin, desc);
+      order_store_key<KIND>(key_out, i, me + base + imin, desc);
       if (perm_out) perm_out[i] = (uint32_t)pv;
       else if (NPAY) pay_out[i] = pv;
     }
@@ -1165,7 +1172,7 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   key_out->dtype = key.dtype;
   key_out->length = n;
   key_out->null_count = 0;
-  key_out->own_values = ctx->alloc(8 * (size_t)n + 16);
+  key_out->own_values = ctx->alloc((KIND == OKIND_I32 ? 4 : 8) * (size_t)n + 16);
   key_out->values = key_out->own_values->p;
   uint32_t *perm = nullptr;
   uint64_t *po = nullptr;
@@ -1192,7 +1199,7 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     const size_t lds = (size_t)RR * FIN_WG * 8 * (1 + NP) + 4 * (FIN_WAVES * 256 + 256);                             \
     if (lds > 64 * 1024) allow_big_lds(ctx, kfn);                                                                    \
     kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(out2->as<uint64_t>(), nullptr, gstart->as<uint32_t>(), gend->as<uint32_t>(), subp, G, \
-                                                     desc, imin, key_out->own_values->as<uint64_t>(), po, perm,         \
+                                                     desc, imin, key_out->own_values->p, po, perm,         \
                                                      (uint32_t)(ABOVE), (uint32_t)(UPTO));                           \
   } while (0)
 #define SQ_WFIN_R(NP)                                                                                                \
@@ -1209,10 +1216,10 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
       const uint2 *items = (const uint2 *)pure_items->p;
       if (has_pay)
         owk_pure_copy_kernel<KIND, 1, true><<<dim3(pure_chunks), dim3(256), 0, ctx->stream>>>(
-            out2->as<uint64_t>(), items, gstart->as<uint32_t>(), gend->as<uint32_t>(), desc, imin, key_out->own_values->as<uint64_t>(), po, perm);
+            out2->as<uint64_t>(), items, gstart->as<uint32_t>(), gend->as<uint32_t>(), desc, imin, key_out->own_values->p, po, perm);
       else
         owk_pure_copy_kernel<KIND, 0, false><<<dim3(pure_chunks), dim3(256), 0, ctx->stream>>>(
-            out2->as<uint64_t>(), items, gstart->as<uint32_t>(), gend->as<uint32_t>(), desc, imin, key_out->own_values->as<uint64_t>(), po, perm);
+            out2->as<uint64_t>(), items, gstart->as<uint32_t>(), gend->as<uint32_t>(), desc, imin, key_out->own_values->p, po, perm);
     }
     SQ_HIP(hipGetLastError());
   }
@@ -1231,7 +1238,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   constexpr int FLAG_W = 2 * OW_MM_SLOTS;       // index of the flag word (u64)
   unsigned int *inv = (unsigned int *)(mm->as<uint64_t>() + FLAG_W + 1); // (its upper half: the heavy-value probe's count)
   const char *hp_e = std::getenv("SQLRS_ORDER_HEAVY_PROBE"); // (A/B hook, read per call: 0 = no probe)
-  const bool heavy_probe = KIND != OKIND_I32 && !hbm_only && !(hp_e && hp_e[0] == '0');
+  const bool heavy_probe = !hbm_only && !(hp_e && hp_e[0] == '0');
   {
     ProfScope ps(ctx, "order_minmax");
     order_minmax_init_kernel<<<dim3(1), dim3(128), 0, ctx->stream>>>(mm->as<unsigned long long>());
@@ -1309,7 +1316,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   // (hbm_only: every key bit goes through the HBM passes, <= 4 of them, and the finish is a streaming unpack — the second
   //  try after a group turned out larger than the in-LDS finish takes: few distinct keys spread over many bits)
   const int top = hbm_only ? kbits : std::min(kbits, want), rbits = kbits - top;
-  if constexpr (KIND != OKIND_I32) {
+  {
     // a value with a visible share of the rows: the splitter route gives it a group of its own that is copied, not sorted
     // (order_wide works on any range; if it declines, the plan below runs as before)
     // (only when low bits are left for the in-LDS finish: with every bit sorted in HBM no group is too large)

@@ -209,6 +209,12 @@ def wide_keys_of(rng, shape, n):
         k[(u >= 0.2) & (u < 0.3)] = -0.0
         k[(u >= 0.3) & (u < 0.35)] = k.min()
         return k
+    if shape == "i32_heavy_values":           # an int32 key (4-byte values out) whose heavy values the probe notices: the splitter route
+        k = rng.integers(-(1 << 30), 1 << 30, n).astype(np.int32)
+        u = rng.random(n)
+        k[u < 0.3] = 12345
+        k[(u >= 0.3) & (u < 0.4)] = -(1 << 30)
+        return k
     if shape == "i64_50_distinct_wide":       # every group holds one value
         return rng.choice(rng.integers(-(1 << 62), 1 << 62, 50, dtype=np.int64), n)
     if shape == "i64_heavy_values_and_neighbours":   # heavy values whose neighbours v + 1, v + 2 exist too: the run's last group
@@ -222,7 +228,7 @@ def wide_keys_of(rng, shape, n):
 
 @pytest.mark.parametrize("shape", ["i64_random", "i64_33bit", "i64_ties", "f64_unit", "f64_normal", "f64_lognormal_signed",
                                    "f64_clusters", "i64_one_heavy_value", "f64_many_zeros", "i64_50_distinct_wide",
-                                   "i64_heavy_values_and_neighbours"])
+                                   "i64_heavy_values_and_neighbours", "i32_heavy_values"])
 @pytest.mark.parametrize("asc", [True, False])
 @pytest.mark.parametrize("extra", ["none", "carry", "carry_and_more"])
 def test_order_wide_keys(hip, oracle, shape, asc, extra):
