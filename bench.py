@@ -28,7 +28,7 @@ times the other two strategies too (`exchange.alternative`, `exchange.alternativ
 Output: ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel:
 HIP-event time per launch measured live on the ctx stream; and the operator-level pipeline figure),
 `cpu_baseline` (all-core CPU port + the single-threaded restatement of the reference, on bounded samples),
-and at N = 1 `c5_variants` (sparse keys, three operators, duplicate build keys, GROUP BY a dim attribute) and `operators` (C2 / C3 / C4 / Order).
+and at N = 1 `c5_variants` (sparse keys, three operators, duplicate build keys, GROUP BY a dim attribute, adversarial inputs) and `operators` (C2 / C3 / C4 / Order).
 Every result is checked per group before it is timed.
 """
 from __future__ import annotations
@@ -787,7 +787,7 @@ def main():
     variants = None
     if rank == 0 and not multi and not args.no_operators and not args.unfused:
         variants = bench_variants(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim_total,
-                                  exp_cnt, exp_sum, has_dim)
+                                  exp_cnt, exp_sum, has_dim, ms_headline=ms_per_step)
 
     operators = None
     if rank == 0 and not args.no_operators and not multi:
@@ -890,7 +890,7 @@ def pmc_traffic(kernel, n_fact, n_dim, world, args):
         return None, None
 
 
-def bench_variants(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim, exp_cnt, exp_sum, has_dim):
+def bench_variants(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim, exp_cnt, exp_sum, has_dim, ms_headline=None):
     """The headline query off its three data-dependent specialisations, timed by the same wall clock
     (barrier-free, N = 1) and checked per group like the headline:
       * `three_operators`: Filter, HashJoin, HashAgg as separate operators (joined batch materialised);
@@ -942,6 +942,56 @@ def bench_variants(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim
     res["group_by_dim_attribute"] = bench_group_by_attribute(be, abi, torch, dev, args, fact_key, fact_val, dim_key, n_dim,
                                                              exp_cnt, exp_sum, has_dim)
     be.fn("ctx_pool_trim")(be.ctx)
+    # ---- adversarial inputs for the same fused route (review r03 #9: what the data-dependent parts cost on the inputs they
+    #      like least; `ms_fast_route` = the headline's ms on its uniformly random keys):
+    #      * sorted_fact: the fact rows SORTED by key — every level-1 tile lands in one digit, every level-2 tile in one
+    #        bucket, a workgroup's chunks of one digit fill back to back (early closes), first rows in key order;
+    #      * hot_key: 30 % of the fact rows carry ONE key — one bucket holds a third of the kept rows, its accumulator slot takes
+    #        them all.  Same per-group check as the headline (expectation adjusted for the moved rows).
+    adv = {}
+    order = torch.sort(fact_key, stable=False).indices
+    fk_s, fv_s = fact_key[order], fact_val[order]
+    del order
+    torch.cuda.synchronize()
+    pipe = Pipeline(be, abi, args.threshold, fused=True)
+    db, fb = batches(dim_key, fk_s, fv_s)
+    out = pipe.step(db(), fb())
+    be.synchronize()
+    ok, groups, rows, msg = check_groups(torch, None, dev, out, exp_cnt, exp_sum, has_dim)
+    out.release()
+    ms = timed(pipe, db, fb, 3, 1)
+    adv["sorted_fact"] = {"ms_per_step": round(ms, 3), "fused_route": bool(pipe.fused_batches), "check": "OK" if ok else msg}
+    del fk_s, fv_s
+    be.fn("ctx_pool_trim")(be.ctx)
+    torch.cuda.empty_cache()
+    k0 = int(dim_key[n_dim // 3].item())
+    moved = (torch.arange(n, device=dev, dtype=torch.int64) * 0x9E3779B1 % 10) < 3
+    mp = moved & (fact_val > args.threshold)
+    e_cnt, e_sum = exp_cnt.clone(), exp_sum.clone()
+    e_cnt.index_add_(0, fact_key[mp], torch.full((int(mp.sum().item()),), -1, dtype=torch.int64, device=dev))
+    e_sum.index_add_(0, fact_key[mp], -fact_val[mp])
+    e_cnt[k0] += int(mp.sum().item())
+    e_sum[k0] += fact_val[mp].sum()
+    # (a sum rebuilt by subtraction carries the rounding of both sums: groups that lost all their rows are exactly zero)
+    e_sum = torch.where(e_cnt == 0, torch.zeros_like(e_sum), e_sum)
+    fk_h = torch.where(moved, torch.full_like(fact_key, k0), fact_key)
+    del moved, mp
+    torch.cuda.synchronize()
+    pipe = Pipeline(be, abi, args.threshold, fused=True)
+    db, fb = batches(dim_key, fk_h, fact_val)
+    out = pipe.step(db(), fb())
+    be.synchronize()
+    ok, groups, rows, msg = check_groups(torch, None, dev, out, e_cnt, e_sum, has_dim)
+    out.release()
+    ms = timed(pipe, db, fb, 3, 1)
+    adv["hot_key"] = {"ms_per_step": round(ms, 3), "fused_route": bool(pipe.fused_batches), "check": "OK" if ok else msg}
+    del fk_h, e_cnt, e_sum
+    be.fn("ctx_pool_trim")(be.ctx)
+    torch.cuda.empty_cache()
+    worst = max(v["ms_per_step"] for v in adv.values())
+    res["adversarial"] = {"ms_per_step": worst, "ms_fast_route": None if ms_headline is None else round(ms_headline, 3),
+                          "ratio": None if not ms_headline else round(worst / ms_headline, 3), "shapes": adv,
+                          "check": "OK" if all(v["check"] == "OK" for v in adv.values()) else "; ".join(v["check"] for v in adv.values())}
     # ---- sparse keys: k -> k * A + B in place (wrapping int64 arithmetic), inverse for the check
     A, B = 0x9E3779B97F4A7C15, 0x632BE59BD9B4E019
     A_s = A - (1 << 64)

@@ -706,6 +706,12 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
       cur.a0[j] = nxt.a0[j];
     }
   };
+  // (Rows ORDERED by key put all 64 rows of a wave into one bucket — 64 atomics on one LDS word for the rank and for the chunk
+  //  histogram: bench.py, c5_variants.adversarial.sorted_fact, level 1 7.7 instead of 5.6 ms.  A wave-uniform fast path, one
+  //  lane ranking the wave when all its kept rows share the bucket, was measured in one process against this form: sorted
+  //  rows 7.75 -> 7.17 ms, random keys 5.65 -> 6.00 ms; tried only while it keeps succeeding — one test per tile on random
+  //  keys — it was SLOWER on both, 5.45 -> 5.90 and 7.67 -> 8.07: the kernel sits at 256 VGPRs and the extra live values
+  //  cost more than the atomics.  Not adopted; the headline's random keys decide.)
   auto rank_row = [&](int j) {
     dr[j] = 0xffffffffu;
     if (cur.off[j] != 0xffffffffu) {

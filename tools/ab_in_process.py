@@ -15,6 +15,12 @@ dk = datagen.fill_chunks(torch.empty(nd, dtype=torch.int64, device=dev), lambda 
 if os.environ.get("SPARSE"):  # sparse 64-bit keys (k -> k * odd + c on both sides): hash partition + LDS hash tables
     A_s = 0x9E3779B97F4A7C15 - (1 << 64)
     fk.mul_(A_s).add_(12345); dk.mul_(A_s).add_(12345)
+if os.environ.get("SHAPE") == "sorted":   # the fact rows sorted by key (bench.py, c5_variants.adversarial)
+    o = torch.sort(fk).indices
+    fk, fv = fk[o], fv[o]
+    del o
+elif os.environ.get("SHAPE") == "hot":    # 30 % of the fact rows carry one key
+    fk = torch.where((torch.arange(n, device=dev, dtype=torch.int64) * 0x9E3779B1 % 10) < 3, torch.full_like(fk, int(dk[nd // 3].item())), fk)
 torch.cuda.synchronize()
 print("ptrs", hex(fk.data_ptr()), hex(fv.data_ptr()))
 pipe = bench.Pipeline(be, abi, 0.5, fused=os.environ.get("UNFUSED") != "1")  # UNFUSED=1: Filter, HashJoin, HashAgg as three operators

@@ -10,6 +10,10 @@ n, nd = int(float(os.environ.get("N", 1e9))), int(float(os.environ.get("ND", 1e7
 fk = datagen.fill_chunks(torch.empty(n, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF1, i, nd))
 fv = datagen.fill_chunks(torch.empty(n, dtype=torch.float64, device=dev), lambda i: datagen.val_t(0xF2, i))
 dk = datagen.fill_chunks(torch.empty(nd, dtype=torch.int64, device=dev), lambda i: datagen.dim_key_t(i, nd))
+if os.environ.get("SHAPE") == "sorted":   # the fact rows sorted by key (bench.py, c5_variants.adversarial)
+    o = torch.sort(fk).indices
+    fk, fv = fk[o], fv[o]
+    del o
 torch.cuda.synchronize()
 KEYS = [k for k in "ABCDEF" if os.environ.get(f"LIB_{k}")]  # LIB_A, LIB_B[, LIB_C ...]
 bes = {k: abi.Backend(os.environ[f"LIB_{k}"], "sqlrs_", 0) for k in KEYS}
