@@ -182,6 +182,7 @@ struct LdsAggParams {
   // dense fused join over DUPLICATE build keys: build rows per key offset (0 = no partner); COUNT / SUM cells of a slot
   // are multiplied by it when the slot is emitted
   const unsigned int *partner_mult;
+  int seg_off; // SQLRS_AGG_SEG=0 (read per call): no per-run adds for ordered rows (lds_agg_dense_slim_kernel; A/B)
 };
 
 // cell of accumulator `kind` for a key that has `m` build rows (every probe row = m joined rows)
@@ -879,6 +880,13 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   // the item) go to LDS when they fit: one LDS read per row instead of a global load (1.59 -> ~1.48 ms per C5 step)
   const uint32_t k_first = s_before - 1u, k_count = s_inside + 1u;
   const bool bt_lds = k_count <= SLIM_BT_CAP;
+  // Rows that arrived ORDERED by key reach the bucket as a few dozen long runs (random rows: one run per level-2 tile of
+  // the segment, ~1500 short ones), and consecutive rows — the 64 lanes of a wave — carry two or three keys: 64 atomics on two
+  // LDS cells.  Such an item adds a wave's rows per RUN OF EQUAL SLOTS instead: one inclusive scan of the values over the
+  // wave, the run's last lane adds the difference of two prefix sums and the run's length (COUNT + SUM(double) only;
+  // bench.py c5_variants.adversarial.sorted_fact: bucket pass 4.1 -> see DESIGN.md).  Workgroup-uniform.
+  const bool seg_mode = NACC == 2 && ((C0 == AK_COUNT && C1 == AK_SUM_F64) || (C0 == AK_SUM_F64 && C1 == AK_COUNT)) &&
+                        hi - lo >= 4096 && (int64_t)k_count * 2048 <= hi - lo && !prm.seg_off; // (runs of >= 2048 rows on average; random rows: ~130)
   if (bt_lds)
     for (uint32_t k = threadIdx.x; k < k_count; k += PART_WG) gbt[k] = in.nzbt[col + min(k_first + k, nruns - 1)];
   { // gpre[g] = (runs starting at or before lo) - 1 + bits of the groups before g
@@ -941,6 +949,35 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
       sl[u] = w & mask;
       id[u] = (cur.bt[u] + (w >> (rbits + 13))) * in.tile + ((w >> rbits) & lmask);
       tf[u] = tfirst[sl[u]];
+    }
+    if (seg_mode) {
+      const int lane = (int)lane_id();
+#pragma unroll
+      for (int u = 0; u < LDS_U; u++) {
+        const bool act = i0 + (int64_t)u * PART_WG < hi;
+        const uint32_t key = act ? sl[u] : (0x80000000u | (uint32_t)lane); // (rows past the end: runs of their own, never added)
+        const uint32_t prevk = (uint32_t)__shfl_up((int)key, 1, 64);
+        const uint64_t bm = __ballot(lane == 0 || key != prevk);            // bit = a run starts at this lane
+        const int headl = 63 - __builtin_clzll(bm & le_mask);               // first lane of this lane's run
+        // SEGMENTED inclusive scan: only values of the same run are added (a difference of wave-wide prefix sums would let a
+        // neighbouring key's magnitudes into this key's rounding)
+        double incl = act ? __longlong_as_double((long long)cur.v[u]) : 0.0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const double o = __shfl_up(incl, d, 64);
+          if (lane - d >= headl) incl += o;
+        }
+        const uint32_t idh = (uint32_t)__shfl((int)id[u], headl, 64);        // (rows keep their order: the run's first row is its smallest)
+        const bool tail = act && (lane == 63 || ((bm >> (lane + 1)) & 1ull));
+        if (tail) {
+          const uint32_t s = sl[u];
+          if (idh < tf[u]) atomicMin(&tfirst[s], idh);
+          atomicAdd(tacc + (size_t)(C0 == AK_COUNT ? 0 : 1) * R + s, (unsigned long long)(lane - headl + 1));
+          unsafeAtomicAdd((double *)(tacc + (size_t)(C0 == AK_COUNT ? 1 : 0) * R + s), incl);
+        }
+      }
+      cur = nxt;
+      continue;
     }
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
@@ -1331,6 +1368,10 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   prm.cap = cap;
   prm.partner_bits = dense ? (const unsigned long long *)partner_bits : nullptr;
   prm.partner_mult = (dense && join_mode) ? in.join_mult : nullptr;
+  {
+    const char *seg_e = std::getenv("SQLRS_AGG_SEG");
+    prm.seg_off = (seg_e && seg_e[0] == '0') ? 1 : 0;
+  }
   int64_t gcap = (int64_t)std::min<double>((double)n, est * 1.5 + 65536.0 + 2.0 * P);
   if (dense) gcap = (int64_t)std::min<uint64_t>((uint64_t)n, join_mode ? (uint64_t)in.join_n : kp.range + 1); // one group per key of the range (build key) at most
   size_t lds = dense ? round_up((size_t)cap * (slot_bytes - 8), 16) : round_up((size_t)(cap + 2) * slot_bytes, 16);

@@ -244,8 +244,9 @@ def test_full_size_c5_pipeline(env):
     env.be.fn("ctx_pool_trim")(env.be.ctx)
 
 
-@pytest.mark.parametrize("shape", ["sorted_keys", "hot_digit", "skewed", "every_row_passes", "few_rows_pass", "keys_beyond_the_dim"])
-def test_slim_records_at_scale(env, shape):
+@pytest.mark.parametrize("shape", ["sorted_keys", "sorted_keys_mixed_magnitudes", "sorted_keys_per_run_adds_off", "hot_digit", "skewed",
+                                   "every_row_passes", "few_rows_pass", "keys_beyond_the_dim"])
+def test_slim_records_at_scale(env, shape, monkeypatch):
     """The slim-record route (radix_part.hip) with the 8192-row tiles it takes from 2^28 rows on, on inputs that bend its
     bookkeeping: sorted keys (a tile is ONE digit: chunks fill and spill every tile, every other digit's chunk is closed
     early over and over), one hot digit (most rows in 1/23 of the key range: split bucket work items, long chunk lists),
@@ -256,8 +257,15 @@ def test_slim_records_at_scale(env, shape):
     n_fact, n_dim = (1 << 28) + 12_345, 3_000_000
     fk, fv, dk = gen_c5(env, n_fact, n_dim)
     thr = 0.5
-    if shape == "sorted_keys":
+    if shape.startswith("sorted_keys"):
+        # (ordered rows reach a bucket as a few long runs: the bucket pass adds a wave's rows per run of equal keys, a
+        #  SEGMENTED scan of the values — neighbouring keys of 1e+12 and 1e-6 magnitudes must not leak into each other's
+        #  rounding; SQLRS_AGG_SEG=0, read per call: one atomic per row as for random rows)
         fk = t.sort(fk).values
+        if shape == "sorted_keys_mixed_magnitudes":
+            fv = t.where(fk % 2 == 0, fv * 1e12 + 1.0, fv * 1e-6 + 0.6e-6)   # (> thr = 0.5e-6 ... see below)
+        if shape == "sorted_keys_per_run_adds_off":
+            monkeypatch.setenv("SQLRS_AGG_SEG", "0")
     elif shape == "hot_digit":
         hot = (fv * 7919.0).frac() < 0.9  # (a second stream of pseudo-random bits: independent of the predicate on fv > 0.5)
         fk = t.where(hot, 1_000_000 + fk % 100_000, fk)
@@ -270,6 +278,8 @@ def test_slim_records_at_scale(env, shape):
         del u
     elif shape == "every_row_passes":
         thr = -1.0
+    if shape == "sorted_keys_mixed_magnitudes":
+        thr = 0.8e-6  # keeps every row of the even keys and about four in five of the odd keys' rows
     elif shape == "few_rows_pass":
         thr = 0.9995
     elif shape == "keys_beyond_the_dim":
