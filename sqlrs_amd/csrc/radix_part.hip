@@ -922,6 +922,10 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
   auto tile_of = [&](uint32_t slot) { return slot; };
   SlimRegs<RP_ROWS> cur, nxt;
   uint32_t dr[RP_ROWS]; // digit << 16 | rank inside the tile's run of that digit; ~0 = no row
+  // (a wave-uniform fast path — one lane ranks the wave when its 64 rows share the digit, as they do for rows ordered by
+  //  key — takes this level from 3.49 to 2.63 ms on sorted fact rows; on random keys six alternating measurements of both
+  //  builds in one process gave 2.82 against 2.75 ms, inside the placement noise but not clearly free.  Not adopted: the
+  //  ordered case is already within 1.3x of the headline through the bucket pass's per-run adds.)
   auto rank_row = [&](int j, uint32_t len) {
     dr[j] = 0xffffffffu;
     if ((uint32_t)(j * RP_WG) + threadIdx.x < len) {
