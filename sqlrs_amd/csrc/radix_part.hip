@@ -922,16 +922,31 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
   auto tile_of = [&](uint32_t slot) { return slot; };
   SlimRegs<RP_ROWS> cur, nxt;
   uint32_t dr[RP_ROWS]; // digit << 16 | rank inside the tile's run of that digit; ~0 = no row
-  // (a wave-uniform fast path — one lane ranks the wave when its 64 rows share the digit, as they do for rows ordered by
-  //  key — takes this level from 3.49 to 2.63 ms on sorted fact rows; on random keys six alternating measurements of both
-  //  builds in one process gave 2.82 against 2.75 ms, inside the placement noise but not clearly free.  Not adopted: the
-  //  ordered case is already within 1.3x of the headline through the bucket pass's per-run adds.)
+  // Rows ordered by key: the 64 rows of a wave share their digit, 64 atomics on one LDS word.  One lane ranks such a wave —
+  // but only in a tile that follows a CONCENTRATED tile (>= 90 % of its rows in one digit, seen for free when the counters
+  // are scanned): random keys never take the test (without the gate: 2.82 against 2.75 ms in one process, inside the
+  // placement noise but not clearly free; sorted fact rows: this level 3.49 -> 2.63 ms).
+  __shared__ uint32_t s_conc;
+  bool conc_hint = false; // (workgroup-uniform) the previous tile was concentrated
   auto rank_row = [&](int j, uint32_t len) {
     dr[j] = 0xffffffffu;
-    if ((uint32_t)(j * RP_WG) + threadIdx.x < len) {
-      const uint32_t d = (cur.w[j] >> rbits) & d2mask;
-      dr[j] = (d << 16) | atomicAdd(&cnt[d], 1u);
+    const bool in = (uint32_t)(j * RP_WG) + threadIdx.x < len;
+    const uint32_t d = (cur.w[j] >> rbits) & d2mask;
+    if (conc_hint) {
+      const uint64_t m = __ballot(in);
+      if (m) {
+        const int first = __builtin_ctzll(m);
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+        if (__ballot(in && d == d0) == m) {
+          uint32_t base = 0;
+          if ((int)lane_id() == first) base = atomicAdd(&cnt[d0], (uint32_t)__popcll(m));
+          base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+          if (in) dr[j] = (d0 << 16) | (base + (uint32_t)mbcnt(m));
+          return;
+        }
+      }
     }
+    if (in) dr[j] = (d << 16) | atomicAdd(&cnt[d], 1u);
   };
   // wave 0: the chunk's run table -> rmask (bits), rdelta (k-th non-empty run -> tile delta).  A written cstart entry
   // below the chunk's length IS a non-empty run (level 1 writes an entry only for a tile that brings rows).
@@ -949,8 +964,9 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
       atomicOr(&rmask[cur.cs1 >> 6], 1ull << (cur.cs1 & 63));
     }
   };
-  auto scan_and_stage = [&]() {
+  auto scan_and_stage = [&](uint32_t tile_len) {
     uint32_t c = cnt[threadIdx.x];
+    if (tile_len && c * 10u >= tile_len * 9u) s_conc = 1; // (one digit holds >= 90 % of the tile: the hint for the next tile)
     uint32_t inc = wave_iscan_u32(c);
     if (lane_id() == 63) s_wsum[wave_id()] = inc;
     // prefix count of the run bits per 64-position group (threads 0..127 = waves 0 and 1)
@@ -961,6 +977,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
       if (threadIdx.x == 63) s_psum = pinc;
     }
     __syncthreads();
+    conc_hint = s_conc != 0;
     uint32_t wbase = 0;
     for (int w = 0; w < wave_id(); w++) wbase += s_wsum[w];
     uint32_t ls = wbase + inc - c;
@@ -995,12 +1012,13 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
   cnt[threadIdx.x] = 0;
   if (threadIdx.x < 128) rmask[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_conc = 0;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < RP_ROWS; j++) rank_row(j, t.len);
   build_runs(t.len);
   __syncthreads();
-  scan_and_stage();
+  scan_and_stage(t.len);
   uint32_t staged_len = t.len;
   tix = tile_of(min(t0 + 1, t1 - 1));
   t = tiles[tix];
@@ -1012,6 +1030,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
     rp_slim_load<RP_WG, RP_ROWS>(in, tn, tnext, offs, digits, nxt);
     cnt[threadIdx.x] = 0;
     if (threadIdx.x < 128) rmask[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_conc = 0; // (its last reader passed the barrier inside scan_and_stage)
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
@@ -1021,7 +1040,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
     build_runs(t.len);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    scan_and_stage();
+    scan_and_stage(t.len);
     staged_len = t.len;
     cur = nxt;
     t = tn;
