@@ -187,11 +187,33 @@ constexpr uint32_t DENSE_EMPTY = 0xffffffffu;
 // dense surrogate keys of a dimension table): heads[key - kmin] = build row.  4 bytes per
 // possible key instead of a 16-byte hash slot at load factor <= 2/3: a 1e6-key dimension needs
 // 4 MiB, which one XCD's L2 holds (265 G lookups/s instead of 66 G/s, profiles/r01_ubench).
+// Round 5: the probe kernels read a BIT-PACKED copy of the table when there is one — `bits` = ceil(log2(rows + 1)) bits per
+// possible key (all ones = empty), entry e at bit e * bits, fetched with ONE unaligned 4-byte load (bits <= 25).  20 bits
+// instead of 32 for 1e6 build rows: 2.4 MiB instead of 3.8, which is what lets the table stay in its XCD's 4 MiB L2 NEXT TO
+// the key stream and the pair stores (the probe's time is the sum of its L1 miss latencies over 64 miss slots per CU,
+// profiles/r02_probe_pmc_ta.txt, and a lookup that has left L2 holds its slot 3-5x longer).  tools/ubench2.hip, same memory
+// work and nothing else, 1e8 keys against 1e6: 0.654 ms with 4-byte entries, 0.516 with 3-byte, 0.520 with 20-bit ones
+// (profiles/r05a_ubench2.txt, r05b_ubench2.txt); 2e6 build rows: 1.08 -> 0.78 ms.
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 struct DenseTable {
   const uint32_t *heads;
   uint64_t kmin, range;
   uint32_t null_head; // build row whose key is NULL (NULL = NULL matches) or DENSE_EMPTY
+  const uint8_t *packed = nullptr; // bit-packed copy of heads[0 .. range + 2) or null
+  uint32_t bits = 0, pmask = 0;    // bits per entry, (1 << bits) - 1 = the packed form of DENSE_EMPTY
 };
+__device__ __forceinline__ uint32_t dense_packed_raw(const uint8_t *__restrict__ packed, uint32_t bits, uint32_t pmask, uint32_t e) {
+  const uint32_t bit = e * bits; // (the host packs only tables of less than 2^32 bits)
+  return (*(const u32_unaligned *)(packed + (bit >> 3)) >> (bit & 7)) & pmask;
+}
+// entry d (d <= range + 1) of the table: the build row or DENSE_EMPTY
+__device__ __forceinline__ uint32_t dense_get(const DenseTable &dt, uint64_t d) {
+  if (dt.packed) {
+    const uint32_t v = dense_packed_raw(dt.packed, dt.bits, dt.pmask, (uint32_t)d);
+    return v == dt.pmask ? DENSE_EMPTY : v;
+  }
+  return dt.heads[d];
+}
 
 template <bool DENSE>
 __global__ __launch_bounds__(BLOCK) void join_probe_unique_kernel(
@@ -231,7 +253,7 @@ __global__ __launch_bounds__(BLOCK) void join_probe_unique_kernel(
         int64_t r = wrow + j * 64 + lane;
         uint64_t d = k[j] - dt.kmin;
         head[j] = DENSE_EMPTY;
-        if (r < n) head[j] = isnull[j] ? dt.null_head : (d < dt.range ? dt.heads[d] : DENSE_EMPTY);
+        if (r < n) head[j] = isnull[j] ? dt.null_head : (d < dt.range ? dense_get(dt, d) : DENSE_EMPTY);
       }
 #pragma unroll
       for (int j = 0; j < JP_ITEMS; j++) {
@@ -326,7 +348,7 @@ __global__ void join_probe_dense_sample_kernel(const uint64_t *__restrict__ keys
   if (r >= n) return;
   const uint64_t d = keys[r] - dt.kmin;
   // (heads[range] is the NULL build row's slot — a non-NULL probe key never matches it — heads[range + 1] the always-empty padding)
-  if (dt.heads[d < dt.range ? d : dt.range + 1] == DENSE_EMPTY) atomicOr(miss, 1u);
+  if (dense_get(dt, d < dt.range ? d : dt.range + 1) == DENSE_EMPTY) atomicOr(miss, 1u);
 }
 // thread t of the grid takes rows t, t + S, t + 2 S, ... (S = threads of the grid), JA_ILP of them per trip: the shape of
 // the composite micro-benchmark (per-wave contiguous chunks with clamped tails measured 9 % slower, 0.755 vs 0.69 ms)
@@ -365,6 +387,80 @@ __global__ __launch_bounds__(256) void join_probe_dense_allhit_kernel(const uint
     right_idx[i] = (uint32_t)i;
   }
   if (__ballot(bad) && lane_id() == 0) atomicOr(miss, 1u);
+}
+
+// The same attempt over the BIT-PACKED table (round 5).  A wave takes 512 CONSECUTIVE rows per trip — VEC2: four 16-byte key
+// loads per lane (lane l: rows 2l, 2l + 1 of each 128-row piece), the build rows of a piece stored with one 16-byte and
+// the probe rows with one 8-byte store per lane; !VEC2 (a key column that is not 16-byte aligned): eight 8-byte loads,
+// 8 + 4-byte stores.  Wave-contiguous chunks beat the strided shape above once the table is packed (tools/ubench2.hip,
+// 1e8 x 1e6: 0.520 ms against 0.65-0.76 strided; 4 pieces: 3 are 8 % and 6 are 50 % slower, 16-byte plain stores instead
+// of non-temporal ones 12 % slower, LDS-DMA keys 12 % slower, the grid makes no difference from 1024 blocks on).
+typedef unsigned long long u64x2_vec __attribute__((ext_vector_type(2)));
+constexpr int JAP_ROWS = 512; // rows per wave and trip
+template <bool VEC2>
+__global__ __launch_bounds__(256) void join_probe_dense_allhit_packed_kernel(const uint64_t *__restrict__ keys, int64_t n, DenseTable dt,
+                                                                             uint64_t *__restrict__ left_idx,
+                                                                             uint32_t *__restrict__ right_idx,
+                                                                             unsigned int *__restrict__ miss) {
+  if (*(volatile unsigned int *)miss) return; // (the sample met a row without partner: no attempt)
+  const int lane = lane_id();
+  const int64_t nchunks = n / JAP_ROWS, gw = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),
+                nw = (int64_t)gridDim.x * 4;
+  const uint8_t *__restrict__ tab = dt.packed;
+  const uint32_t bits = dt.bits, pmask = dt.pmask, range = (uint32_t)dt.range, pad = range + 1; // (pad: always empty; never `range`, the NULL row's)
+  const uint64_t kmin = dt.kmin;
+  bool bad = false;
+  for (int64_t c = gw; c < nchunks; c += nw) {
+    if (VEC2) {
+      const int64_t r0 = c * JAP_ROWS + 2 * lane;
+      u64x2_vec k[4];
+      uint32_t h[8];
+#pragma unroll
+      for (int g = 0; g < 4; g++) k[g] = __builtin_nontemporal_load((const u64x2_vec *)(keys + r0 + g * 128));
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const uint64_t d0 = k[g].x - kmin, d1 = k[g].y - kmin;
+        h[2 * g] = dense_packed_raw(tab, bits, pmask, d0 < range ? (uint32_t)d0 : pad);
+        h[2 * g + 1] = dense_packed_raw(tab, bits, pmask, d1 < range ? (uint32_t)d1 : pad);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int64_t r = r0 + g * 128;
+        bad |= (h[2 * g] == pmask) | (h[2 * g + 1] == pmask);
+        u64x2_vec lv;
+        lv.x = h[2 * g];
+        lv.y = h[2 * g + 1];
+        __builtin_nontemporal_store(lv, (u64x2_vec *)(left_idx + r));
+        __builtin_nontemporal_store(((uint64_t)(uint32_t)(r + 1) << 32) | (uint32_t)r, (uint64_t *)(right_idx + r));
+      }
+    } else {
+      const int64_t r0 = c * JAP_ROWS + lane;
+      uint64_t k[8];
+      uint32_t h[8];
+#pragma unroll
+      for (int g = 0; g < 8; g++) k[g] = __builtin_nontemporal_load(keys + r0 + g * 64);
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        const uint64_t d = k[g] - kmin;
+        h[g] = dense_packed_raw(tab, bits, pmask, d < range ? (uint32_t)d : pad);
+      }
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        bad |= h[g] == pmask;
+        __builtin_nontemporal_store((uint64_t)h[g], left_idx + r0 + g * 64);
+        __builtin_nontemporal_store((uint32_t)(r0 + g * 64), right_idx + r0 + g * 64);
+      }
+    }
+  }
+  if (gw == nchunks % nw) // the rows behind the last whole chunk: the wave whose turn it would be
+    for (int64_t r = nchunks * JAP_ROWS + lane; r < n; r += 64) {
+      const uint64_t d = keys[r] - kmin;
+      const uint32_t h = dense_packed_raw(tab, bits, pmask, d < range ? (uint32_t)d : pad);
+      bad |= h == pmask;
+      left_idx[r] = h;
+      right_idx[r] = (uint32_t)r;
+    }
+  if (__ballot(bad) && lane == 0) atomicOr(miss, 1u);
 }
 
 // `skip_unless` (optional): the optimistic kernel above ran first — while its flag is clear every pair is in place
@@ -418,7 +514,7 @@ __global__ __launch_bounds__(JD_BLOCK, JD_OCC) void join_probe_dense_kernel(
       isnull = !((validity[rc >> 6] >> (rc & 63)) & 1);
     }
     uint32_t h = DENSE_EMPTY;
-    if (r < n && !isnull && d < dt.range) h = dt.heads[d];
+    if (r < n && !isnull && d < dt.range) h = dense_get(dt, d);
     if (HASV && r < n && isnull) h = dt.null_head;
     head[j] = h;
   }
@@ -741,7 +837,7 @@ __global__ __launch_bounds__(BLOCK) void join_probe_unique_outer_kernel(
     uint32_t h;
     if (DENSE) {
       uint64_t d = keys[r] - dt.kmin;
-      h = is_null ? dt.null_head : (d < dt.range ? dt.heads[d] : DENSE_EMPTY);
+      h = is_null ? dt.null_head : (d < dt.range ? dense_get(dt, d) : DENSE_EMPTY);
       hit = h != DENSE_EMPTY;
     } else {
       Slot s = probe_slot(table, mask, keys[r], is_null);
@@ -831,6 +927,162 @@ __global__ __launch_bounds__(256) void dense_count_kernel(const uint32_t *__rest
   if (lane_id() == 0) s_c[wave_id()] = c;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(counts, (unsigned long long)(s_c[0] + s_c[1] + s_c[2] + s_c[3]));
+}
+
+// ---- the direct-address build without a host round trip in the middle (round 5) -------------------------------------
+// The build above fetches the key range, sizes the table from it, fills, counts and fetches the verdict: two stream
+// synchronisations and five small device operations for 8 MB of input (0.095 ms for 1e6 keys — 12 % of C3's
+// build + probe).  Here the table is allocated for the LARGEST range that would still take the route (slots per key x
+// rows + 1024, known without looking at a key), the kernels read the range where key_minmax left it on the device and
+// return at once when it is too large, and the ONE fetch at the end carries everything the host decides on:
+//   st[0] = ~min (ordered image; atomicMax, so that a zeroed block is the neutral start), st[1] = max (ordered image),
+//   st[2] = occupied slots, st[3] = NULL keys, st[4] = the NULL row's head.
+// dense_pack_count_kernel also writes the bit-packed copy the probe kernels read (DenseTable).
+struct DenseDev { // what every kernel of the sequence derives from st[0..1]
+  bool ok;
+  uint64_t kmin, range;
+};
+__device__ __forceinline__ DenseDev dense_dev(const unsigned long long *__restrict__ st, uint64_t max_range) {
+  const uint64_t lo = ~st[0], hi = st[1];
+  DenseDev d;
+  d.range = hi - lo + 1;
+  d.ok = lo <= hi && d.range <= max_range && d.range < (1ull << 31);
+  d.kmin = lo ^ (1ull << 63);
+  return d;
+}
+__global__ __launch_bounds__(256) void key_minmax_inv_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
+                                                             int64_t n, unsigned long long *st) {
+  unsigned long long lo = ~0ull, hi = 0;
+  constexpr int KU = 8;
+  for (int64_t base = blockIdx.x * (int64_t)(256 * KU) + threadIdx.x; base < n; base += (int64_t)gridDim.x * (256 * KU)) {
+    uint64_t k[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) k[u] = __builtin_nontemporal_load(keys + min(base + (int64_t)u * 256, n - 1));
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+      const int64_t r = min(base + (int64_t)u * 256, n - 1);
+      if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) continue;
+      const unsigned long long o = i64_to_ordered((int64_t)k[u]);
+      lo = o < lo ? o : lo;
+      hi = o > hi ? o : hi;
+    }
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned long long a = shfl_xor_u64(lo, m), b = shfl_xor_u64(hi, m);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  __shared__ unsigned long long s_lo[4], s_hi[4];
+  if (lane_id() == 0) {
+    s_lo[wave_id()] = lo;
+    s_hi[wave_id()] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+    }
+    if (lo <= hi) { // (a block that saw only NULL keys adds nothing)
+      atomicMax(st, ~lo);
+      atomicMax(st + 1, hi);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void dense_init_dev_kernel(const unsigned long long *__restrict__ st, uint64_t max_range,
+                                                             uint4 *__restrict__ heads4) {
+  const DenseDev d = dense_dev(st, max_range);
+  if (!d.ok) return;
+  const int64_t n4 = (int64_t)((d.range + 2 + 3) / 4); // (the allocation is rounded up to 16 bytes and more)
+  const uint4 e = make_uint4(DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY);
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) heads4[i] = e;
+}
+__global__ __launch_bounds__(256) void dense_fill_dev_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
+                                                             int64_t n, const unsigned long long *__restrict__ st, uint64_t max_range,
+                                                             uint32_t *__restrict__ heads, unsigned long long *counts /* st + 2 */) {
+  const DenseDev d = dense_dev(st, max_range);
+  if (!d.ok) return;
+  const int64_t r = blockIdx.x * 256ll + threadIdx.x;
+  if (r >= n) return;
+  if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) {
+    heads[d.range] = (uint32_t)r; // the spare slot behind the table (unique build keys: at most one NULL row)
+    atomicAdd(counts + 1, 1ull);
+    return;
+  }
+  heads[keys[r] - d.kmin] = (uint32_t)r;
+}
+// lane t of the grid owns entries [32 t, 32 t + 32): `bits` whole dwords of the packed table; counts the occupied slots
+// of [0, range) on the way (what dense_count_kernel does) and leaves the NULL row's head where the host fetches it
+__global__ __launch_bounds__(256) void dense_pack_count_kernel(const uint32_t *__restrict__ heads, const unsigned long long *__restrict__ st,
+                                                               uint64_t max_range, uint32_t bits, uint32_t *__restrict__ packed,
+                                                               unsigned long long *counts /* st + 2 */) {
+  const DenseDev d = dense_dev(st, max_range);
+  if (!d.ok) return;
+  const int64_t total = (int64_t)d.range + 2, ngroups = (total + 31) / 32;
+  const uint32_t pmask = (1u << bits) - 1;
+  uint32_t c = 0;
+  for (int64_t g = blockIdx.x * 256ll + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
+    uint64_t buf = 0;
+    uint32_t fill = 0;
+    uint32_t *out = packed + g * bits;
+#pragma unroll 1
+    for (int q = 0; q < 8; q++) {
+      const int64_t e0 = g * 32 + q * 4;
+      uint32_t v[4];
+      if (e0 + 3 < total) {
+        const uint4 t = *(const uint4 *)(heads + e0);
+        v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = e0 + u < total ? heads[e0 + u] : DENSE_EMPTY;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        c += (e0 + u < (int64_t)d.range) && v[u] != DENSE_EMPTY;
+        buf |= (uint64_t)(v[u] == DENSE_EMPTY ? pmask : v[u]) << fill;
+        fill += bits;
+        if (fill >= 32) {
+          *out++ = (uint32_t)buf;
+          buf >>= 32;
+          fill -= 32;
+        }
+      }
+    }
+  }
+  c = wave_sum_u32(c);
+  __shared__ uint32_t s_c[4];
+  if (lane_id() == 0) s_c[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    if (t) atomicAdd(counts, (unsigned long long)t);
+    if (blockIdx.x == 0) counts[2] = heads[d.range];
+  }
+}
+// the same sequence's last step when the table is not packed (more than 25 bits per entry, or 2^32 bits and more)
+__global__ __launch_bounds__(256) void dense_count_dev_kernel(const uint32_t *__restrict__ heads, const unsigned long long *__restrict__ st,
+                                                              uint64_t max_range, unsigned long long *counts) {
+  const DenseDev d = dense_dev(st, max_range);
+  if (!d.ok) return;
+  const int64_t range = (int64_t)d.range;
+  uint32_t c = 0;
+  constexpr int KU = 8;
+  for (int64_t base = blockIdx.x * (int64_t)(256 * KU) + threadIdx.x; base < range; base += (int64_t)gridDim.x * (256 * KU)) {
+    uint32_t h[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) h[u] = heads[min(base + u * 256, range - 1)];
+#pragma unroll
+    for (int u = 0; u < KU; u++) c += (base + u * 256 < range) && h[u] != DENSE_EMPTY;
+  }
+  c = wave_sum_u32(c);
+  __shared__ uint32_t s_c[4];
+  if (lane_id() == 0) s_c[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    if (t) atomicAdd(counts, (unsigned long long)t);
+    if (blockIdx.x == 0) counts[2] = heads[d.range];
+  }
 }
 
 // ---- key-only build side: existence bitmap ------------------------------------------------------------------
@@ -1143,7 +1395,63 @@ static void build_table(sqlrs_hash_join *j) {
   // 1. dense surrogate keys (range <= 4 x rows — 16 x for a join+aggregate's join — and < 2^31) -> direct-address table.  It is tried
   //    first: when the build keys turn out unique nothing else is needed, and the 16-byte-slot
   //    hash table (1.1 ms for 1e7 keys) is never built.
-  if (j->exact && n > 0 && j->key_dtype != SQLRS_FLOAT64) {
+  const char *db1_e = std::getenv("SQLRS_DENSE_BUILD_ONE_FETCH"); // A/B hook, read per call (0 = the two-fetch sequence below)
+  if (j->exact && n > 0 && n <= (1ll << 24) && j->key_dtype != SQLRS_FLOAT64 && !(db1_e && std::atoi(db1_e) == 0)) {
+    // one fetch (see dense_pack_count_kernel): the table is sized for the largest range that takes the route
+    ProfScope ps(ctx, "join_build_dense");
+    const char *pj_e = std::getenv("SQLRS_DENSE_JOIN_SLOTS_PLAIN"); // tuning hook, read per call
+    const uint64_t slots_per_key = j->lazy_table ? dense_slots_per_key_owned() : (pj_e ? (uint64_t)std::max(1, std::atoi(pj_e)) : 4);
+    const uint64_t max_range = slots_per_key * (uint64_t)n + 1024;
+    uint32_t bits = 1;
+    while (((1ull << bits) - 1) < (uint64_t)n) bits++; // all ones = empty must not be a build row
+    const char *pk_e = std::getenv("SQLRS_DENSE_PACKED"); // A/B hook, read per call (0 = the probe reads the 4-byte table)
+    if (bits < 8) bits = 8;
+    if (bits > 25 || (max_range + 2) * bits >= (1ull << 32) || j->lazy_table || (pk_e && std::atoi(pk_e) == 0)) bits = 0;
+    BufP st = ctx->alloc_zero(40);
+    BufP dense = ctx->alloc(4 * (size_t)max_range + 64);
+    BufP packed = bits ? ctx->alloc(4 * (size_t)((max_range + 2 + 31) / 32) * bits + 16) : nullptr;
+    const uint64_t *vp = validity ? validity->as<uint64_t>() : nullptr;
+    unsigned long long *stp = st->as<unsigned long long>();
+    const unsigned mblocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 4 * (int64_t)ctx->num_cus);
+    key_minmax_inv_kernel<<<dim3(mblocks), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n, stp);
+    const unsigned iblocks = (unsigned)std::min<int64_t>(ceil_div((int64_t)max_range + 2, 256 * 4 * 4), 4 * (int64_t)ctx->num_cus);
+    dense_init_dev_kernel<<<dim3(iblocks), dim3(256), 0, ctx->stream>>>(stp, max_range, dense->as<uint4>());
+    dense_fill_dev_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n, stp, max_range,
+                                                                                          dense->as<uint32_t>(), stp + 2);
+    if (bits) {
+      const unsigned pblocks = (unsigned)std::min<int64_t>(ceil_div(ceil_div((int64_t)max_range + 2, 32), 256), 8 * (int64_t)ctx->num_cus);
+      dense_pack_count_kernel<<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(dense->as<uint32_t>(), stp, max_range, bits,
+                                                                          packed->as<uint32_t>(), stp + 2);
+    } else {
+      const unsigned cblocks = (unsigned)std::min<int64_t>(ceil_div((int64_t)max_range, 256 * 8), 4 * (int64_t)ctx->num_cus);
+      dense_count_dev_kernel<<<dim3(cblocks), dim3(256), 0, ctx->stream>>>(dense->as<uint32_t>(), stp, max_range, stp + 2);
+    }
+    SQ_HIP(hipGetLastError());
+    const uint64_t *h = (const uint64_t *)ctx->fetch(st->p, 40);
+    const uint64_t lo = ~h[0], hi = h[1], occupied = h[2], nulls = h[3];
+    const uint32_t null_head = (uint32_t)h[4];
+    const uint64_t range = hi - lo + 1;
+    if (lo <= hi && range <= max_range && range < (1ull << 31)) { // (what dense_dev decided)
+      const uint64_t dmin = lo ^ (1ull << 63);
+      if (nulls <= 1 && occupied + nulls == (uint64_t)n) {
+        j->unique = true;
+        j->unique_known = j->table_built = true;
+        j->dense = dense;
+        j->dense_min = dmin;
+        j->dense_range = range;
+        j->dense_null_head = null_head;
+        j->dense_packed = packed;
+        j->dense_pbits = bits;
+        return;
+      }
+      j->unique = false; // (see the two-fetch sequence below)
+      j->unique_known = true;
+      if (nulls == 0 && !validity) {
+        j->dup_min = dmin;
+        j->dup_range = range;
+      }
+    }
+  } else if (j->exact && n > 0 && j->key_dtype != SQLRS_FLOAT64) {
     BufP mm = ctx->alloc(16); // {min = ~0, max = 0} without a host round trip
     SQ_HIP(hipMemsetAsync(mm->p, 0xff, 8, ctx->stream));
     SQ_HIP(hipMemsetAsync(mm->as<uint8_t>() + 8, 0, 8, ctx->stream));
@@ -1316,6 +1624,19 @@ static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
   return out;
 }
 
+static DenseTable dense_table_of(const sqlrs_hash_join *j) {
+  DenseTable dt;
+  dt.heads = j->dense ? j->dense->as<uint32_t>() : nullptr;
+  dt.kmin = j->dense_min;
+  dt.range = j->dense_range;
+  dt.null_head = j->dense_null_head;
+  if (j->dense && j->dense_packed) {
+    dt.packed = j->dense_packed->as<uint8_t>();
+    dt.bits = j->dense_pbits;
+    dt.pmask = (1u << j->dense_pbits) - 1;
+  }
+  return dt;
+}
 static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   Ctx *ctx = j->ctx;
   hash_join_ensure_table(j);
@@ -1349,13 +1670,21 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
       if (j->dense && !lm.ok && !pk.validity && n >= (1 << 16) && !j->probe_miss_seen && !(ah_e && std::atoi(ah_e) == 0)) {
         miss = (unsigned int *)(desc->as<uint64_t>() + tiles + 2);
         ProfScope ps(ctx, "join_probe_dense");
-        DenseTable dt{j->dense->as<uint32_t>(), j->dense_min, j->dense_range, j->dense_null_head};
+        DenseTable dt = dense_table_of(j);
         const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * JA_ILP), 16 * (int64_t)ctx->num_cus);
         const int64_t every = std::max<int64_t>(1, n >> 14); // ~16 K sampled rows
         join_probe_dense_sample_kernel<<<dim3((unsigned)ceil_div(ceil_div(n, every), 256)), dim3(256), 0, ctx->stream>>>(
             pk.keys->as<uint64_t>(), n, every, dt, miss);
         const char *sc_e = std::getenv("SQLRS_PROBE_ALLHIT_SC1"); // A/B hook, read per call
-        if (sc_e && std::atoi(sc_e) == 1)
+        if (dt.packed) { // wave-contiguous chunks over the bit-packed table
+          const unsigned pblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / JAP_ROWS, 4), 32 * (int64_t)ctx->num_cus));
+          if (((uintptr_t)pk.keys->p & 15) == 0)
+            join_probe_dense_allhit_packed_kernel<true><<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, dt, p.left->as<uint64_t>(),
+                                                                                                   p.right->as<uint32_t>(), miss);
+          else
+            join_probe_dense_allhit_packed_kernel<false><<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, dt, p.left->as<uint64_t>(),
+                                                                                                    p.right->as<uint32_t>(), miss);
+        } else if (sc_e && std::atoi(sc_e) == 1)
           join_probe_dense_allhit_kernel<true><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, dt, p.left->as<uint64_t>(),
                                                                                           p.right->as<uint32_t>(), miss);
         else
@@ -1378,7 +1707,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
       {
         ProfScope ps(ctx, lm.ok ? "join_match_compact" : (j->dense ? "join_probe_dense" : "join_probe_unique"));
         dim3 gt((unsigned)tiles);
-        DenseTable dt{j->dense ? j->dense->as<uint32_t>() : nullptr, j->dense_min, j->dense_range, j->dense_null_head};
+        DenseTable dt = dense_table_of(j);
         if (lm.ok) {
           allow_big_lds(ctx, lds_join_restore_kernel, 4 * LJ_RANGE + 1024);
           lds_join_restore_kernel<<<gt, dim3(LR_BLOCK), 4 * (size_t)LJ_RANGE, ctx->stream>>>(
@@ -1415,7 +1744,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     p.left_validity = ctx->alloc(bitmap_bytes(n));
     ProfScope ps(ctx, "join_probe_unique");
     int64_t n64 = (int64_t)round_up((size_t)n, 64);
-    DenseTable dt{j->dense ? j->dense->as<uint32_t>() : nullptr, j->dense_min, j->dense_range, j->dense_null_head};
+    DenseTable dt = dense_table_of(j);
     if (j->dense)
       join_probe_unique_outer_kernel<true><<<dim3((unsigned)ceil_div(n64, BLOCK)), b, 0, ctx->stream>>>(
           pk.keys->as<uint64_t>(), pk.validity, n, (j->table ? j->table->as<Slot>() : nullptr), j->mask, dt, p.left->as<uint64_t>(),

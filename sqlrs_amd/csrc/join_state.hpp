@@ -53,6 +53,8 @@ struct sqlrs_hash_join {
   sq::BufP dense;              // direct-address table (u32 build row per key - dense_min) or null
   uint64_t dense_min = 0, dense_range = 0;
   uint32_t dense_null_head = 0xffffffffu;
+  sq::BufP dense_packed; // bit-packed copy of `dense` for the probe kernels (join.hip, DenseTable) or null
+  uint32_t dense_pbits = 0;
   bool probe_miss_seen = false; // a probe batch had a row without partner: no more optimistic all-hit attempts (join.hip)
   sq::BufP dense_bits; // one bit per possible key of the direct-address table (key-only build side, join.hip)
   // duplicate build keys over a dense range (no NULL key): the range the direct-address build found, and — on first
