@@ -961,13 +961,21 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
         const int headl = 63 - __builtin_clzll(bm & le_mask);               // first lane of this lane's run
         // SEGMENTED inclusive scan: only values of the same run are added (a difference of wave-wide prefix sums would let a
         // neighbouring key's magnitudes into this key's rounding)
+        // ... and a segmented MIN of the row ids beside it: both slim partition levels rank a tile's rows of one digit in
+        // LDS-atomic order, so two producer waves can interleave and a run's head lane need not hold its smallest row
+        // (a later key whose first row falls into that gap would otherwise come out ahead in the first-seen order,
+        // hash_agg.rs:98).
         double incl = act ? __longlong_as_double((long long)cur.v[u]) : 0.0;
+        uint32_t idh = act ? id[u] : 0xffffffffu;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
           const double o = __shfl_up(incl, d, 64);
-          if (lane - d >= headl) incl += o;
+          const uint32_t oi = (uint32_t)__shfl_up((int)idh, d, 64);
+          if (lane - d >= headl) {
+            incl += o;
+            idh = oi < idh ? oi : idh;
+          }
         }
-        const uint32_t idh = (uint32_t)__shfl((int)id[u], headl, 64);        // (rows keep their order: the run's first row is its smallest)
         const bool tail = act && (lane == 63 || ((bm >> (lane + 1)) & 1ull));
         if (tail) {
           const uint32_t s = sl[u];

@@ -935,15 +935,24 @@ __global__ __launch_bounds__(256) void dense_count_kernel(const uint32_t *__rest
 // build + probe).  Here the table is allocated for the LARGEST range that would still take the route (slots per key x
 // rows + 1024, known without looking at a key), the kernels read the range where key_minmax left it on the device and
 // return at once when it is too large, and the ONE fetch at the end carries everything the host decides on:
-//   st[0] = ~min (ordered image; atomicMax, so that a zeroed block is the neutral start), st[1] = max (ordered image),
-//   st[2] = occupied slots, st[3] = NULL keys, st[4] = the NULL row's head.
+//   st[0 .. 16) = ~min (ordered image; atomicMax, so that a zeroed block is the neutral start), st[16 .. 32) = max (ordered
+//   image) — SIXTEEN words each, block b adds to word b % 16: two atomics per block on ONE pair of words serialise at
+//   ~12 ns each (489 blocks for 1e6 keys: 12 of the kernel's 14 us); st[32] = occupied slots, st[33] = NULL keys,
+//   st[34] = the NULL row's head.
 // dense_pack_count_kernel also writes the bit-packed copy the probe kernels read (DenseTable).
 struct DenseDev { // what every kernel of the sequence derives from st[0..1]
   bool ok;
   uint64_t kmin, range;
 };
+constexpr int DENSE_MM = 16, DENSE_ST_WORDS = 2 * DENSE_MM + 3;
 __device__ __forceinline__ DenseDev dense_dev(const unsigned long long *__restrict__ st, uint64_t max_range) {
-  const uint64_t lo = ~st[0], hi = st[1];
+  uint64_t nlo = 0, hi = 0; // (uniform addresses: scalar loads)
+#pragma unroll
+  for (int i = 0; i < DENSE_MM; i++) {
+    nlo = st[i] > nlo ? st[i] : nlo;
+    hi = st[DENSE_MM + i] > hi ? st[DENSE_MM + i] : hi;
+  }
+  const uint64_t lo = ~nlo;
   DenseDev d;
   d.range = hi - lo + 1;
   d.ok = lo <= hi && d.range <= max_range && d.range < (1ull << 31);
@@ -984,8 +993,8 @@ __global__ __launch_bounds__(256) void key_minmax_inv_kernel(const uint64_t *__r
       hi = s_hi[w] > hi ? s_hi[w] : hi;
     }
     if (lo <= hi) { // (a block that saw only NULL keys adds nothing)
-      atomicMax(st, ~lo);
-      atomicMax(st + 1, hi);
+      atomicMax(st + (blockIdx.x % DENSE_MM), ~lo);
+      atomicMax(st + DENSE_MM + (blockIdx.x % DENSE_MM), hi);
     }
   }
 }
@@ -999,7 +1008,7 @@ __global__ __launch_bounds__(256) void dense_init_dev_kernel(const unsigned long
 }
 __global__ __launch_bounds__(256) void dense_fill_dev_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
                                                              int64_t n, const unsigned long long *__restrict__ st, uint64_t max_range,
-                                                             uint32_t *__restrict__ heads, unsigned long long *counts /* st + 2 */) {
+                                                             uint32_t *__restrict__ heads, unsigned long long *counts /* st + 2 DENSE_MM */) {
   const DenseDev d = dense_dev(st, max_range);
   if (!d.ok) return;
   const int64_t r = blockIdx.x * 256ll + threadIdx.x;
@@ -1015,7 +1024,7 @@ __global__ __launch_bounds__(256) void dense_fill_dev_kernel(const uint64_t *__r
 // of [0, range) on the way (what dense_count_kernel does) and leaves the NULL row's head where the host fetches it
 __global__ __launch_bounds__(256) void dense_pack_count_kernel(const uint32_t *__restrict__ heads, const unsigned long long *__restrict__ st,
                                                                uint64_t max_range, uint32_t bits, uint32_t *__restrict__ packed,
-                                                               unsigned long long *counts /* st + 2 */) {
+                                                               unsigned long long *counts /* st + 2 DENSE_MM */) {
   const DenseDev d = dense_dev(st, max_range);
   if (!d.ok) return;
   const int64_t total = (int64_t)d.range + 2, ngroups = (total + 31) / 32;
@@ -1407,7 +1416,7 @@ static void build_table(sqlrs_hash_join *j) {
     const char *pk_e = std::getenv("SQLRS_DENSE_PACKED"); // A/B hook, read per call (0 = the probe reads the 4-byte table)
     if (bits < 8) bits = 8;
     if (bits > 25 || (max_range + 2) * bits >= (1ull << 32) || j->lazy_table || (pk_e && std::atoi(pk_e) == 0)) bits = 0;
-    BufP st = ctx->alloc_zero(40);
+    BufP st = ctx->alloc_zero(8 * DENSE_ST_WORDS);
     BufP dense = ctx->alloc(4 * (size_t)max_range + 64);
     BufP packed = bits ? ctx->alloc(4 * (size_t)((max_range + 2 + 31) / 32) * bits + 16) : nullptr;
     const uint64_t *vp = validity ? validity->as<uint64_t>() : nullptr;
@@ -1417,19 +1426,21 @@ static void build_table(sqlrs_hash_join *j) {
     const unsigned iblocks = (unsigned)std::min<int64_t>(ceil_div((int64_t)max_range + 2, 256 * 4 * 4), 4 * (int64_t)ctx->num_cus);
     dense_init_dev_kernel<<<dim3(iblocks), dim3(256), 0, ctx->stream>>>(stp, max_range, dense->as<uint4>());
     dense_fill_dev_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n, stp, max_range,
-                                                                                          dense->as<uint32_t>(), stp + 2);
+                                                                                          dense->as<uint32_t>(), stp + 2 * DENSE_MM);
     if (bits) {
       const unsigned pblocks = (unsigned)std::min<int64_t>(ceil_div(ceil_div((int64_t)max_range + 2, 32), 256), 8 * (int64_t)ctx->num_cus);
       dense_pack_count_kernel<<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(dense->as<uint32_t>(), stp, max_range, bits,
-                                                                          packed->as<uint32_t>(), stp + 2);
+                                                                          packed->as<uint32_t>(), stp + 2 * DENSE_MM);
     } else {
       const unsigned cblocks = (unsigned)std::min<int64_t>(ceil_div((int64_t)max_range, 256 * 8), 4 * (int64_t)ctx->num_cus);
-      dense_count_dev_kernel<<<dim3(cblocks), dim3(256), 0, ctx->stream>>>(dense->as<uint32_t>(), stp, max_range, stp + 2);
+      dense_count_dev_kernel<<<dim3(cblocks), dim3(256), 0, ctx->stream>>>(dense->as<uint32_t>(), stp, max_range, stp + 2 * DENSE_MM);
     }
     SQ_HIP(hipGetLastError());
-    const uint64_t *h = (const uint64_t *)ctx->fetch(st->p, 40);
-    const uint64_t lo = ~h[0], hi = h[1], occupied = h[2], nulls = h[3];
-    const uint32_t null_head = (uint32_t)h[4];
+    const uint64_t *h = (const uint64_t *)ctx->fetch(st->p, 8 * DENSE_ST_WORDS);
+    uint64_t nlo = 0, hi = 0;
+    for (int i = 0; i < DENSE_MM; i++) nlo = std::max(nlo, h[i]), hi = std::max(hi, h[DENSE_MM + i]);
+    const uint64_t lo = ~nlo, occupied = h[2 * DENSE_MM], nulls = h[2 * DENSE_MM + 1];
+    const uint32_t null_head = (uint32_t)h[2 * DENSE_MM + 2];
     const uint64_t range = hi - lo + 1;
     if (lo <= hi && range <= max_range && range < (1ull << 31)) { // (what dense_dev decided)
       const uint64_t dmin = lo ^ (1ull << 63);
@@ -1659,16 +1670,16 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     int64_t tiles = ceil_div(n, lm.ok ? LJ_RANGE : (j->dense ? JD_TILE : JP_TILE));
     p.left = ctx->alloc(8 * (size_t)n);
     p.right = ctx->alloc(4 * (size_t)n);
-    BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 24);
-    unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
-    uint64_t *tot = desc->as<uint64_t>() + tiles + 1;
-    // optimistic all-hit attempt of the direct-address probe (join_probe_dense_allhit_kernel); its miss flag sits behind
-    // the descriptors and is NOT cleared by a look-back rerun.  SQLRS_PROBE_ALLHIT=0 (read per call): never.
+    // optimistic all-hit attempt of the direct-address probe (join_probe_dense_allhit_kernel); its miss flag is a word of its
+    // own (a zeroed slab: no memset) and is NOT cleared by a look-back rerun.  SQLRS_PROBE_ALLHIT=0 (read per call): never.
+    // The look-back descriptors are allocated (and cleared: a memset) only when the compacting kernel runs.
     unsigned int *miss = nullptr;
+    BufP miss_buf;
     {
       const char *ah_e = std::getenv("SQLRS_PROBE_ALLHIT");
       if (j->dense && !lm.ok && !pk.validity && n >= (1 << 16) && !j->probe_miss_seen && !(ah_e && std::atoi(ah_e) == 0)) {
-        miss = (unsigned int *)(desc->as<uint64_t>() + tiles + 2);
+        miss_buf = ctx->alloc_zero(8);
+        miss = miss_buf->as<unsigned int>();
         ProfScope ps(ctx, "join_probe_dense");
         DenseTable dt = dense_table_of(j);
         const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * JA_ILP), 16 * (int64_t)ctx->num_cus);
@@ -1702,6 +1713,9 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
         }
       }
     }
+    BufP desc = ctx->alloc_zero(8 * (size_t)tiles + 24);
+    unsigned *ticket = (unsigned *)(desc->as<uint64_t>() + tiles);
+    uint64_t *tot = desc->as<uint64_t>() + tiles + 1;
     for (int use_ticket = lookback_start_mode(ctx), attempt = 0; use_ticket < 2; use_ticket++, attempt++) {
       if (attempt) SQ_HIP(hipMemsetAsync(desc->p, 0, 8 * (size_t)tiles + 16, ctx->stream)); // rerun after a timeout
       {

@@ -244,7 +244,7 @@ def test_full_size_c5_pipeline(env):
     env.be.fn("ctx_pool_trim")(env.be.ctx)
 
 
-@pytest.mark.parametrize("shape", ["sorted_keys", "sorted_keys_mixed_magnitudes", "sorted_keys_per_run_adds_off", "hot_digit", "skewed",
+@pytest.mark.parametrize("shape", ["sorted_keys", "sorted_keys_mixed_magnitudes", "sorted_keys_per_run_adds_off", "sorted_keys_nearly", "hot_digit", "skewed",
                                    "every_row_passes", "few_rows_pass", "keys_beyond_the_dim"])
 def test_slim_records_at_scale(env, shape, monkeypatch):
     """The slim-record route (radix_part.hip) with the 8192-row tiles it takes from 2^28 rows on, on inputs that bend its
@@ -266,6 +266,17 @@ def test_slim_records_at_scale(env, shape, monkeypatch):
             fv = t.where(fk % 2 == 0, fv * 1e12 + 1.0, fv * 1e-6 + 0.6e-6)   # (> thr = 0.5e-6 ... see below)
         if shape == "sorted_keys_per_run_adds_off":
             monkeypatch.setenv("SQLRS_AGG_SEG", "0")
+        if shape == "sorted_keys_nearly":
+            # 1 % of the rows swapped with a row up to 300 positions on: a neighbouring key's first row now lies INSIDE this
+            # key's first rows, and the partition levels rank a tile's rows of one digit in LDS-atomic order (two waves
+            # interleave) — the first row of a run of equal keys is the minimum over the run, not its head lane's
+            g = t.Generator(device=env.dev).manual_seed(5)
+            p_ = t.randint(0, n_fact - 301, (n_fact // 100,), device=env.dev, generator=g)
+            q_ = p_ + t.randint(1, 300, (n_fact // 100,), device=env.dev, generator=g)
+            a_, b_ = fk[p_].clone(), fk[q_].clone()
+            fk[p_] = b_
+            fk[q_] = a_
+            del p_, q_, a_, b_
     elif shape == "hot_digit":
         hot = (fv * 7919.0).frac() < 0.9  # (a second stream of pseudo-random bits: independent of the predicate on fv > 0.5)
         fk = t.where(hot, 1_000_000 + fk % 100_000, fk)

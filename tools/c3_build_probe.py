@@ -1,0 +1,34 @@
+"""C3 build + probe (hash_join_create .. build_finish .. probe_indices .. destroy) REPS times in one process: what
+tools/timeline_ops.sh slices (CMD="python tools/c3_build_probe.py" DELIM=key_minmax_inv_kernel) and an event-timed figure."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench, sqlrs_amd
+from sqlrs_amd import abi, datagen
+from sqlrs_amd.expr import InputRef
+dev = torch.device("cuda", 0)
+be = sqlrs_amd.new_ctx(0)
+nP, nB = int(float(os.environ.get("NP", 1e8))), int(float(os.environ.get("NB", 1e6)))
+mod = int(os.environ.get("MOD", nB))
+dk = datagen.fill_chunks(torch.empty(nB, dtype=torch.int64, device=dev), lambda i: datagen.dim_key_t(i, nB))
+fk = datagen.fill_chunks(torch.empty(nP, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF1, i, mod))
+torch.cuda.synchronize()
+db, fb = bench.device_batch(abi, [dk], [abi.INT64]), bench.device_batch(abi, [fk], [abi.INT64])
+lk, _k1 = abi.pack_exprs([InputRef(0)]); rk, _k2 = abi.pack_exprs([InputRef(0)])
+rd = (C.c_int32 * 1)(abi.INT64)
+def both():
+    j = C.c_void_p()
+    be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, lk, rk, None, 1, rd, C.byref(j)))
+    be.check(be.fn("hash_join_build_push")(j, db.ptr)); be.check(be.fn("hash_join_build_finish")(j))
+    o = C.POINTER(abi.Batch)()
+    be.check(be.fn("hash_join_probe_indices")(j, fb.ptr, abi.MEM_DEVICE, C.byref(o)))
+    be.fn("batch_release")(o)
+    be.fn("hash_join_destroy")(j)
+both(); both(); be.synchronize()
+t = C.c_void_p(); be.check(be.fn("timer_create")(be.ctx, C.byref(t)))
+best = 1e9
+for _ in range(int(os.environ.get("REPS", 7))):
+    be.check(be.fn("timer_start")(t)); both(); be.check(be.fn("timer_stop")(t))
+    ms = C.c_double(); be.check(be.fn("timer_elapsed_ms")(t, C.byref(ms))); best = min(best, ms.value)
+be.fn("timer_destroy")(t)
+print(f"C3 build + probe: {best:.3f} ms = {(8 * nB + 20 * nP) / best / 1e6 / 8000:.4f} of 8 TB/s", flush=True)
