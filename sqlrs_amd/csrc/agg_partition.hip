@@ -812,6 +812,10 @@ struct SlimBucketIn {
   const uint32_t *nzstart, *nzbt, *nzcount, *bcol;
   uint32_t tile;   // rows per level-1 tile
   uint32_t groups; // 64-position groups the LDS arrays hold (>= those of the largest work item)
+  // BLK (rows of a claimed single level, rp_claim_scatter_slim_kernel): base tile of slot i = blk_bt[i >> log_b], the
+  // word 0xffffffff marks a sentinel row; none of the run arrays above is used
+  const uint32_t *blk_bt;
+  uint32_t log_b;
 };
 constexpr uint32_t SLIM_BT_CAP = 4096; // base tiles of a work item's runs kept in LDS (16 KiB)
 struct SlimAggRows {
@@ -819,7 +823,7 @@ struct SlimAggRows {
   uint32_t w[LDS_U], bt[LDS_U];
 };
 
-template <bool JOIN, int NACC, int C0, int C1>
+template <bool JOIN, int NACC, int C0, int C1, bool BLK = false>
 __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
     LdsAggParams prm, SlimBucketIn in, const uint32_t *__restrict__ work, unsigned long long *out_count,
     uint64_t *__restrict__ gkey, uint32_t *__restrict__ gfirst, uint64_t *__restrict__ gacc, int64_t gcap, KeyPack kp,
@@ -840,8 +844,8 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   unsigned long long *gmask = (unsigned long long *)(tfirst + R); // [groups] bit = a run starts at this position (> lo)
   uint32_t *gpre = (uint32_t *)(gmask + in.groups);              // [groups] index of the run holding the group's first row
   uint32_t *gbt = gpre + in.groups;                              // [SLIM_BT_CAP] base tiles of the item's runs (when they fit)
-  const uint32_t col = in.bcol[b], nruns = in.nzcount[b];
-  const uint32_t ngroups = (uint32_t)((hi - lo + 63) >> 6);
+  const uint32_t col = BLK ? 0u : in.bcol[b], nruns = BLK ? 0u : in.nzcount[b];
+  const uint32_t ngroups = BLK ? 0u : (uint32_t)((hi - lo + 63) >> 6);
   const uint64_t le_mask = (2ull << lane_id()) - 1ull;
   const uint32_t rbits = kp.rbits, lmask = (1u << 13) - 1u;
 
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
     s_inside = 0;
   }
   __syncthreads();
-  { // runs of the bucket: how many start at or before lo, one bit for every start inside (lo, hi)
+  if (!BLK) { // runs of the bucket: how many start at or before lo, one bit for every start inside (lo, hi)
     uint32_t before = 0, inside = 0;
     for (uint32_t k = threadIdx.x; k < nruns; k += PART_WG) {
       const int64_t st = in.nzstart[col + k];
@@ -879,17 +883,17 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   // the base tiles of the runs this item touches (run s_before - 1 holds row lo, then the `inside` runs that start inside
   // the item) go to LDS when they fit: one LDS read per row instead of a global load (1.59 -> ~1.48 ms per C5 step)
   const uint32_t k_first = s_before - 1u, k_count = s_inside + 1u;
-  const bool bt_lds = k_count <= SLIM_BT_CAP;
+  const bool bt_lds = !BLK && k_count <= SLIM_BT_CAP;
   // Rows that arrived ORDERED by key reach the bucket as a few dozen long runs (random rows: one run per level-2 tile of
   // the segment, ~1500 short ones), and consecutive rows — the 64 lanes of a wave — carry two or three keys: 64 atomics on two
   // LDS cells.  Such an item adds a wave's rows per RUN OF EQUAL SLOTS instead: one inclusive scan of the values over the
   // wave, the run's last lane adds the difference of two prefix sums and the run's length (COUNT + SUM(double) only;
   // bench.py c5_variants.adversarial.sorted_fact: bucket pass 4.1 -> see DESIGN.md).  Workgroup-uniform.
   const bool seg_mode = NACC == 2 && ((C0 == AK_COUNT && C1 == AK_SUM_F64) || (C0 == AK_SUM_F64 && C1 == AK_COUNT)) &&
-                        hi - lo >= 4096 && (int64_t)k_count * 2048 <= hi - lo && !prm.seg_off; // (runs of >= 2048 rows on average; random rows: ~130)
+                        hi - lo >= 4096 && (int64_t)k_count * 2048 <= hi - lo && !prm.seg_off && !BLK; // (runs of >= 2048 rows on average; random rows: ~130)
   if (bt_lds)
     for (uint32_t k = threadIdx.x; k < k_count; k += PART_WG) gbt[k] = in.nzbt[col + min(k_first + k, nruns - 1)];
-  { // gpre[g] = (runs starting at or before lo) - 1 + bits of the groups before g
+  if (!BLK) { // gpre[g] = (runs starting at or before lo) - 1 + bits of the groups before g
     constexpr uint32_t GPT = 8; // groups per thread per round
     uint32_t carry = s_before - 1u; // (the bucket's first run starts at its first row <= lo: s_before >= 1)
     for (uint32_t g0 = 0; g0 < ngroups; g0 += PART_WG * GPT) {
@@ -924,6 +928,10 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
     for (int u = 0; u < LDS_U; u++) {
       const int64_t i = min(i0 + (int64_t)u * PART_WG, hi - 1);
       slim_load_nt(in.rows, i, r.w[u], r.v[u]);
+      if (BLK) { // (a wave's 64 consecutive slots lie in one or two blocks: one or two cache lines per load)
+        r.bt[u] = in.blk_bt[i >> in.log_b];
+        continue;
+      }
       const uint32_t g = (uint32_t)((i - lo) >> 6);
       const uint32_t k = gpre[g] + (uint32_t)__popcll(gmask[g] & le_mask);
 #if defined(SLIM_DBG) && (SLIM_DBG & 16)
@@ -991,6 +999,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
     for (int u = 0; u < LDS_U; u++) {
       const uint32_t s = sl[u];
       bool act = i0 + (int64_t)u * PART_WG < hi;
+      if (BLK) act = act && cur.w[u] != 0xffffffffu; // sentinel rows of the claimed level
 #ifdef SLIM_DBG
       const uint64_t actm = (SLIM_DBG & 1) ? 0ull : __ballot(act); // timing experiments only (results invalid)
 #else
@@ -1419,7 +1428,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
       split_above = chunk;
     }
   }
-  if (pr.slim.on) { // slim rows: a work item's run bits live in LDS next to its table (12 bytes per 64 rows)
+  if (pr.slim.on && !pr.slim.blk_bt) { // slim rows: a work item's run bits live in LDS next to its table (12 bytes per 64 rows)
     const size_t table = round_up((size_t)cap * (slot_bytes - 8), 16);
     const size_t room = 159 * 1024 > table + 4 * SLIM_BT_CAP ? 159 * 1024 - table - 4 * SLIM_BT_CAP : 0; // (160 KiB per workgroup, static LDS included)
     const uint32_t item_rows = (uint32_t)std::min<size_t>(1u << 18, (room / 12 > 2 ? room / 12 - 2 : 0) * 64);
@@ -1532,18 +1541,22 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     if (dense && pr.slim.on) { // slim rows (radix_part.hpp): value + 32-bit word, row ids rebuilt from the runs
       uint32_t max_item = 64;
       for (uint32_t i = 0; i < nwork; i++) max_item = std::max(max_item, work[4 * i + 2] - work[4 * i + 1]);
+      const bool blk = pr.slim.blk_bt != nullptr; // rows of a claimed single level: base tiles per block, no run lists
       SlimBucketIn sb;
       sb.rows = pr.slim.rows;
-      sb.nzstart = pr.slim.nzstart->as<uint32_t>();
-      sb.nzbt = pr.slim.nzbt->as<uint32_t>();
-      sb.nzcount = pr.slim.nzcount->as<uint32_t>();
-      sb.bcol = pr.slim.bcol->as<uint32_t>();
+      sb.nzstart = blk ? nullptr : pr.slim.nzstart->as<uint32_t>();
+      sb.nzbt = blk ? nullptr : pr.slim.nzbt->as<uint32_t>();
+      sb.nzcount = blk ? nullptr : pr.slim.nzcount->as<uint32_t>();
+      sb.bcol = blk ? nullptr : pr.slim.bcol->as<uint32_t>();
       sb.tile = pr.slim.tile;
-      sb.groups = (uint32_t)ceil_div((int64_t)max_item, 64) + 1;
-      const size_t slds = round_up((size_t)cap * (slot_bytes - 8), 16) + 12 * (size_t)sb.groups + 4 * SLIM_BT_CAP;
+      sb.groups = blk ? 0u : (uint32_t)ceil_div((int64_t)max_item, 64) + 1;
+      sb.blk_bt = blk ? pr.slim.blk_bt->as<uint32_t>() : nullptr;
+      sb.log_b = pr.slim.log_b;
+      const size_t slds = round_up((size_t)cap * (slot_bytes - 8), 16) + (blk ? 16 : 12 * (size_t)sb.groups + 4 * SLIM_BT_CAP);
 #define SQ_LS(JN, NA, C0, C1)                                                                                  \
   do {                                                                                                         \
     auto kfn = lds_agg_dense_slim_kernel<JN, NA, C0, C1>;                                                       \
+    if (blk) kfn = lds_agg_dense_slim_kernel<JN, NA, C0, C1, true>;                                             \
     allow_big_lds(ctx, kfn, 159 * 1024);                                                                                 \
     kfn<<<dim3(nwork), dim3(PART_WG), slds, ctx->stream>>>(prm, sb, dwork->as<uint32_t>(), ctr->as<unsigned long long>(), \
                                                            out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(), \

@@ -201,6 +201,10 @@ struct DenseTable {
   uint32_t null_head; // build row whose key is NULL (NULL = NULL matches) or DENSE_EMPTY
   const uint8_t *packed = nullptr; // bit-packed copy of heads[0 .. range + 2) or null
   uint32_t bits = 0, pmask = 0;    // bits per entry, (1 << bits) - 1 = the packed form of DENSE_EMPTY
+  // the build's verdict is still on the device (sqlrs_hash_join::dense_pending): kmin / range are read from `st` by the
+  // kernel (dense_table_from_device), which raises bit 1 of its miss flag when the build keys are not a unique dense set
+  const unsigned long long *st = nullptr;
+  uint64_t st_max_range = 0, st_rows = 0;
 };
 __device__ __forceinline__ uint32_t dense_packed_raw(const uint8_t *__restrict__ packed, uint32_t bits, uint32_t pmask, uint32_t e) {
   const uint32_t bit = e * bits; // (the host packs only tables of less than 2^32 bits)
@@ -214,6 +218,9 @@ __device__ __forceinline__ uint32_t dense_get(const DenseTable &dt, uint64_t d) 
   }
   return dt.heads[d];
 }
+
+// (defined with the build kernels below)
+__device__ __forceinline__ bool dense_table_from_device(DenseTable &dt);
 
 template <bool DENSE>
 __global__ __launch_bounds__(BLOCK) void join_probe_unique_kernel(
@@ -344,6 +351,10 @@ constexpr int JA_ILP = 16; // independent table loads in flight per lane
 // rows `every` apart (a sample of the batch): a probe with many misses is recognised before the attempt starts
 __global__ void join_probe_dense_sample_kernel(const uint64_t *__restrict__ keys, int64_t n, int64_t every, DenseTable dt,
                                                unsigned int *__restrict__ miss) {
+  if (dt.st && !dense_table_from_device(dt)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(miss, 2u);
+    return;
+  }
   const int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * every;
   if (r >= n) return;
   const uint64_t d = keys[r] - dt.kmin;
@@ -402,7 +413,8 @@ __global__ __launch_bounds__(256) void join_probe_dense_allhit_packed_kernel(con
                                                                              uint64_t *__restrict__ left_idx,
                                                                              uint32_t *__restrict__ right_idx,
                                                                              unsigned int *__restrict__ miss) {
-  if (*(volatile unsigned int *)miss) return; // (the sample met a row without partner: no attempt)
+  if (*(volatile unsigned int *)miss) return; // (the sample met a row without partner / the build is not dense: no attempt)
+  if (dt.st) dense_table_from_device(dt);     // (true: the sample kernel has checked it)
   const int lane = lane_id();
   const int64_t nchunks = n / JAP_ROWS, gw = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),
                 nw = (int64_t)gridDim.x * 4;
@@ -959,6 +971,13 @@ __device__ __forceinline__ DenseDev dense_dev(const unsigned long long *__restri
   d.kmin = lo ^ (1ull << 63);
   return d;
 }
+__device__ __forceinline__ bool dense_table_from_device(DenseTable &dt) {
+  const DenseDev d = dense_dev(dt.st, dt.st_max_range);
+  const unsigned long long occupied = dt.st[2 * DENSE_MM], nulls = dt.st[2 * DENSE_MM + 1];
+  dt.kmin = d.kmin;
+  dt.range = d.range;
+  return d.ok && nulls <= 1 && occupied + nulls == dt.st_rows; // (what the host decides on the same words, dense_resolve)
+}
 __global__ __launch_bounds__(256) void key_minmax_inv_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
                                                              int64_t n, unsigned long long *st) {
   unsigned long long lo = ~0ull, hi = 0;
@@ -1350,6 +1369,48 @@ static NKeys composite_probe_keys(sqlrs_hash_join *j, const std::function<const 
 }
 
 static void build_hash_table(sqlrs_hash_join *j);
+// The direct-address build's verdict (dense_pack_count_kernel: st[0 .. 35)) -> the join's state; what is not a unique dense
+// key set goes on to the general table.  `h`: the words when the caller has fetched them already (with its own answer, in
+// one round trip), else they are fetched here.
+static void dense_resolve(sqlrs_hash_join *j, const uint64_t *h = nullptr) {
+  if (!j->dense_pending) return;
+  Ctx *ctx = j->ctx;
+  j->dense_pending = false;
+  const int64_t n = j->nB;
+  uint64_t hw[DENSE_ST_WORDS];
+  std::memcpy(hw, h ? h : (const uint64_t *)ctx->fetch(j->pend_st->p, 8 * DENSE_ST_WORDS), sizeof(hw)); // (later fetches reuse the staging buffer)
+  BufP dense = std::move(j->pend_dense), packed = std::move(j->pend_packed);
+  j->pend_st = nullptr;
+  uint64_t nlo = 0, hi = 0;
+  for (int i = 0; i < DENSE_MM; i++) nlo = std::max(nlo, hw[i]), hi = std::max(hi, hw[DENSE_MM + i]);
+  const uint64_t lo = ~nlo, occupied = hw[2 * DENSE_MM], nulls = hw[2 * DENSE_MM + 1];
+  const uint32_t null_head = (uint32_t)hw[2 * DENSE_MM + 2];
+  const uint64_t range = hi - lo + 1;
+  if (lo <= hi && range <= j->pend_max_range && range < (1ull << 31)) { // (what dense_dev decided)
+    const uint64_t dmin = lo ^ (1ull << 63);
+    if (nulls <= 1 && occupied + nulls == (uint64_t)n) {
+      j->unique = true;
+      j->unique_known = j->table_built = true;
+      j->dense = dense;
+      j->dense_min = dmin;
+      j->dense_range = range;
+      j->dense_null_head = null_head;
+      j->dense_packed = packed;
+      j->dense_pbits = j->pend_bits;
+      return;
+    }
+    // fewer occupied slots than valid keys (or several NULL keys, which match each other): the build keys are NOT
+    // unique — a fact the fused join+aggregate need not discover again by inserting them into its bucket tables
+    j->unique = false;
+    j->unique_known = true;
+    if (nulls == 0 && !j->pend_validity) { // (no NULL key: the fused join+aggregate can take multiplicities per key, hash_join_dup_mult)
+      j->dup_min = dmin;
+      j->dup_range = range;
+    }
+  }
+  if (j->lazy_table) return; // built by hash_join_ensure_table when something probes it
+  build_hash_table(j);
+}
 static void build_table(sqlrs_hash_join *j) {
   Ctx *ctx = j->ctx;
   // concat key parts
@@ -1416,7 +1477,7 @@ static void build_table(sqlrs_hash_join *j) {
     const char *pk_e = std::getenv("SQLRS_DENSE_PACKED"); // A/B hook, read per call (0 = the probe reads the 4-byte table)
     if (bits < 8) bits = 8;
     if (bits > 25 || (max_range + 2) * bits >= (1ull << 32) || j->lazy_table || (pk_e && std::atoi(pk_e) == 0)) bits = 0;
-    BufP st = ctx->alloc_zero(8 * DENSE_ST_WORDS);
+    BufP st = ctx->alloc_zero(8 * (DENSE_ST_WORDS + 1)); // (+ the miss flag of a first probe that runs before the verdict is fetched)
     BufP dense = ctx->alloc(4 * (size_t)max_range + 64);
     BufP packed = bits ? ctx->alloc(4 * (size_t)((max_range + 2 + 31) / 32) * bits + 16) : nullptr;
     const uint64_t *vp = validity ? validity->as<uint64_t>() : nullptr;
@@ -1436,32 +1497,19 @@ static void build_table(sqlrs_hash_join *j) {
       dense_count_dev_kernel<<<dim3(cblocks), dim3(256), 0, ctx->stream>>>(dense->as<uint32_t>(), stp, max_range, stp + 2 * DENSE_MM);
     }
     SQ_HIP(hipGetLastError());
-    const uint64_t *h = (const uint64_t *)ctx->fetch(st->p, 8 * DENSE_ST_WORDS);
-    uint64_t nlo = 0, hi = 0;
-    for (int i = 0; i < DENSE_MM; i++) nlo = std::max(nlo, h[i]), hi = std::max(hi, h[DENSE_MM + i]);
-    const uint64_t lo = ~nlo, occupied = h[2 * DENSE_MM], nulls = h[2 * DENSE_MM + 1];
-    const uint32_t null_head = (uint32_t)h[2 * DENSE_MM + 2];
-    const uint64_t range = hi - lo + 1;
-    if (lo <= hi && range <= max_range && range < (1ull << 31)) { // (what dense_dev decided)
-      const uint64_t dmin = lo ^ (1ull << 63);
-      if (nulls <= 1 && occupied + nulls == (uint64_t)n) {
-        j->unique = true;
-        j->unique_known = j->table_built = true;
-        j->dense = dense;
-        j->dense_min = dmin;
-        j->dense_range = range;
-        j->dense_null_head = null_head;
-        j->dense_packed = packed;
-        j->dense_pbits = bits;
-        return;
-      }
-      j->unique = false; // (see the two-fetch sequence below)
-      j->unique_known = true;
-      if (nulls == 0 && !validity) {
-        j->dup_min = dmin;
-        j->dup_range = range;
-      }
-    }
+    j->dense_pending = true;
+    j->pend_st = st;
+    j->pend_dense = dense;
+    j->pend_packed = packed;
+    j->pend_bits = bits;
+    j->pend_max_range = max_range;
+    j->pend_validity = validity != nullptr;
+    // The verdict stays on the device when the first probe can take it from there (dense_resolve): a plain join whose probe
+    // kernels read the packed table.  SQLRS_DENSE_BUILD_DEFER=0 (read per call): decide here.
+    const char *df_e = std::getenv("SQLRS_DENSE_BUILD_DEFER");
+    if (bits && !j->lazy_table && !(df_e && std::atoi(df_e) == 0)) return;
+    dense_resolve(j);
+    return;
   } else if (j->exact && n > 0 && j->key_dtype != SQLRS_FLOAT64) {
     BufP mm = ctx->alloc(16); // {min = ~0, max = 0} without a host round trip
     SQ_HIP(hipMemsetAsync(mm->p, 0xff, 8, ctx->stream));
@@ -1569,6 +1617,7 @@ static void build_hash_table(sqlrs_hash_join *j) {
 }
 
 void hash_join_ensure_table(sqlrs_hash_join *j) {
+  dense_resolve(j);
   if (!j->table_built && j->finished && !j->empty_build) build_hash_table(j);
 }
 
@@ -1650,12 +1699,54 @@ static DenseTable dense_table_of(const sqlrs_hash_join *j) {
 }
 static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   Ctx *ctx = j->ctx;
-  hash_join_ensure_table(j);
   if (pk.exact != j->exact || (pk.exact && pk.dtype != j->key_dtype))
     fail(SQLRS_ERR_INTERNAL, "join keys of different types on the two sides are not supported");
   Pairs p;
   int64_t n = pk.rows;
   int outer_right = j->join_type == SQLRS_JOIN_RIGHT || j->join_type == SQLRS_JOIN_FULL;
+  // The first probe of a direct-address build whose verdict is still on the device: the optimistic all-hit kernel takes
+  // key range and uniqueness from the device-side words and ONE fetch brings back the build's verdict and the probe's —
+  // a host round trip less per join (C3: 8 MB of build keys cost 0.07 ms, a third of it that round trip).
+  if (j->dense_pending) {
+    const char *ah_e = std::getenv("SQLRS_PROBE_ALLHIT");
+    if (!outer_right && !pk.validity && n >= (1 << 16) && n <= 0xffffffffll && j->pend_bits && !(ah_e && std::atoi(ah_e) == 0)) {
+      ProfScope ps(ctx, "join_probe_dense");
+      p.left = ctx->alloc(8 * (size_t)n);
+      p.right = ctx->alloc(4 * (size_t)n);
+      unsigned long long *stp = j->pend_st->as<unsigned long long>();
+      unsigned int *miss = (unsigned int *)(stp + DENSE_ST_WORDS);
+      DenseTable dt;
+      dt.heads = j->pend_dense->as<uint32_t>();
+      dt.packed = j->pend_packed->as<uint8_t>();
+      dt.bits = j->pend_bits;
+      dt.pmask = (1u << j->pend_bits) - 1;
+      dt.st = stp;
+      dt.st_max_range = j->pend_max_range;
+      dt.st_rows = (uint64_t)j->nB;
+      const int64_t every = std::max<int64_t>(1, n >> 14); // ~16 K sampled rows
+      join_probe_dense_sample_kernel<<<dim3((unsigned)ceil_div(ceil_div(n, every), 256)), dim3(256), 0, ctx->stream>>>(
+          pk.keys->as<uint64_t>(), n, every, dt, miss);
+      const unsigned pblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / JAP_ROWS, 4), 32 * (int64_t)ctx->num_cus));
+      if (((uintptr_t)pk.keys->p & 15) == 0)
+        join_probe_dense_allhit_packed_kernel<true><<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, dt, p.left->as<uint64_t>(),
+                                                                                               p.right->as<uint32_t>(), miss);
+      else
+        join_probe_dense_allhit_packed_kernel<false><<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, dt, p.left->as<uint64_t>(),
+                                                                                                p.right->as<uint32_t>(), miss);
+      SQ_HIP(hipGetLastError());
+      uint64_t hw[DENSE_ST_WORDS + 1];
+      std::memcpy(hw, ctx->fetch(j->pend_st->p, 8 * (DENSE_ST_WORDS + 1)), sizeof(hw));
+      dense_resolve(j, hw);
+      if (j->dense && (unsigned int)hw[DENSE_ST_WORDS] == 0) { // a unique dense key set and every probe row found its partner
+        p.m = n;
+        p.right_identity = true;
+        return p;
+      }
+      if (j->dense) j->probe_miss_seen = true; // (later batches of this join go straight to the compacting kernel)
+      p = Pairs();
+    }
+  }
+  hash_join_ensure_table(j);
   if (n == 0) {
     p.left = ctx->alloc(8);
     p.right = ctx->alloc(8);
@@ -1902,6 +1993,7 @@ __global__ void dup_mult_kernel(const uint64_t *__restrict__ keys, int64_t n, ui
   if (r < n) atomicAdd(&mult[keys[r] - kmin], 1u);
 }
 const uint32_t *hash_join_dup_mult(sqlrs_hash_join *j) {
+  dense_resolve(j);
   if (!j->dup_range || !j->bkeys || j->bkeys_validity) return nullptr;
   if (!j->dup_mult) {
     Ctx *ctx = j->ctx;
@@ -1914,6 +2006,7 @@ const uint32_t *hash_join_dup_mult(sqlrs_hash_join *j) {
 }
 
 const uint64_t *hash_join_dense_bits(sqlrs_hash_join *j) {
+  dense_resolve(j);
   if (!j->dense || !j->dense_range) return nullptr;
   if (!j->dense_bits) {
     Ctx *ctx = j->ctx;
@@ -1931,6 +2024,7 @@ static bool semi_join_probe(sqlrs_hash_join *j, InBatch &ib, const NKeys &pk, DB
   Ctx *ctx = j->ctx;
   const char *env_e = std::getenv("SQLRS_SEMI_JOIN"); // test hook, read per call: 0 = never
   if (env_e && std::atoi(env_e) == 0) return false;
+  if (j->dense_pending && j->join_type == SQLRS_JOIN_INNER && !j->has_filter && j->left.cols.size() == 1) dense_resolve(j); // (a candidate: decide now)
   if (j->join_type != SQLRS_JOIN_INNER || j->has_filter || !j->unique || !j->dense || !j->exact || pk.validity ||
       j->left.cols.size() != 1 || j->lkeys.size() != 1 || j->lkeys[0].nodes.size() != 1 || j->rkeys[0].nodes.size() != 1 ||
       j->lkeys[0].nodes[0].op != SQLRS_EXPR_INPUT_REF || j->rkeys[0].nodes[0].op != SQLRS_EXPR_INPUT_REF ||

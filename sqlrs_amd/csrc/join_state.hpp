@@ -56,6 +56,14 @@ struct sqlrs_hash_join {
   sq::BufP dense_packed; // bit-packed copy of `dense` for the probe kernels (join.hip, DenseTable) or null
   uint32_t dense_pbits = 0;
   bool probe_miss_seen = false; // a probe batch had a row without partner: no more optimistic all-hit attempts (join.hip)
+  // The direct-address build WITHOUT its host round trip (join.hip, dense_resolve): the kernels of the attempt are queued,
+  // their verdict (key range, occupied slots, NULL keys: `pend_st`) is still on the device.  The first probe either runs
+  // its optimistic all-hit kernel against the device-side verdict and fetches both answers at once, or resolves first.
+  bool dense_pending = false;
+  sq::BufP pend_st, pend_dense, pend_packed;
+  uint32_t pend_bits = 0;
+  uint64_t pend_max_range = 0;
+  bool pend_validity = false;
   sq::BufP dense_bits; // one bit per possible key of the direct-address table (key-only build side, join.hip)
   // duplicate build keys over a dense range (no NULL key): the range the direct-address build found, and — on first
   // need of the fused join+aggregate — how many build rows carry each key of it (u32 per key, 0 = none)

@@ -545,10 +545,7 @@ static bool order_null_split(sqlrs_order *o, DBatch &all, int kc, int out_mem, s
   const DCol &key = all.cols[(size_t)kc];
   const int64_t nulls = count_nulls(ctx, key);
   if (nulls == 0 || n - nulls < (1 << 20)) return false; // (nothing to split off / the rest is small: general path)
-  Selection sv;
-  sv.rows = n;
-  sv.bits = key.validity;
-  selection_finish(ctx, sv);
+  Selection sv = selection_from_set_bits(ctx, key.validity, n); // (a masked copy: the caller's padding bits are unspecified)
   Selection sn = selection_from_clear_bits(ctx, key.validity, n);
   if (sv.count + sn.count != n) fail(SQLRS_ERR_INTERNAL, "order: NULL / valid rows do not add up");
   DBatch vb, nb;

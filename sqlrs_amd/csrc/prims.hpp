@@ -27,6 +27,8 @@ struct Selection {
 Selection selection_from_mask(Ctx *ctx, const DCol &mask);
 // keep rows whose bit is CLEAR in `bits` (unvisited rows, hash_join.rs:298-301)
 Selection selection_from_clear_bits(Ctx *ctx, const uint64_t *bits, int64_t rows);
+// keep rows whose bit is SET in `bits` (a copy with the padding bits behind row `rows` cleared: Arrow leaves them unspecified)
+Selection selection_from_set_bits(Ctx *ctx, const uint64_t *bits, int64_t rows);
 // finishes a Selection whose bits are given (computes tile offsets + count; syncs)
 void selection_finish(Ctx *ctx, Selection &s);
 DCol compact_column(Ctx *ctx, const DCol &c, const Selection &s);

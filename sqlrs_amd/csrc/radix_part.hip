@@ -690,7 +690,9 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
   SlimCur<RP_ROWS> cur;
   uint32_t dr[RP_ROWS]; // digit << 16 | rank inside the tile's run of that digit; ~0 = row not kept
   uint32_t cur_tile = 0;
-  auto take_rows = [&](uint32_t len, uint32_t nxt_tile) { // nxt (as loaded: tile `nxt_tile`) -> cur
+  // (`report`: false when the tile was loaded a second time — the pipeline re-reads a range's last tile instead of branching —
+  //  so that a key outside the sampled range reaches the outlier list once)
+  auto take_rows = [&](uint32_t len, uint32_t nxt_tile, bool report) { // nxt (as loaded: tile `nxt_tile`) -> cur
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) {
       bool keep = (uint32_t)(j * RP_WG) + threadIdx.x < len;
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
       const uint64_t off = nxt.k[j] - kp.kmin;
       if (keep && off > kp.range) { // no bucket of the range partition holds this key: the row has no group / no partner
         // (optimistically sampled range: the row goes to the outlier list / the caller reruns with the exact range)
-        if (kp.oob) key_out_of_range(kp, (uint32_t)((int64_t)nxt_tile * RP_TILE + (uint32_t)(j * RP_WG) + threadIdx.x));
+        if (kp.oob && report) key_out_of_range(kp, (uint32_t)((int64_t)nxt_tile * RP_TILE + (uint32_t)(j * RP_WG) + threadIdx.x));
         keep = false;
       }
       cur.off[j] = keep ? (uint32_t)off : 0xffffffffu;
@@ -813,7 +815,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
     cur_tile = t0;
     rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(t0), len, nxt);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-    take_rows(len, t0);
+    take_rows(len, t0, true);
     cnt[threadIdx.x] = 0;
     __syncthreads();
 #pragma unroll
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
     cur_tile = tcur;
     rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(tcur), len, nxt);
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    take_rows(len, tcur);
+    take_rows(len, tcur, tcur != t0);
     for (uint32_t ti = t0 + 1; ti < t1; ti++) {
       const uint32_t tnext = min(ti + 1, t1 - 1);
       const uint32_t nlen = tile_len(tnext);
@@ -842,7 +844,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
       __syncthreads();
       scan_and_stage();
       staged_len = s_total;
-      take_rows(nlen, tnext);
+      take_rows(nlen, tnext, tnext != ti);
       cur_tile = tnext;
     }
 #pragma unroll
@@ -1130,13 +1132,14 @@ struct ClaimOut {
 // est[d] += rows of digit d among the sampled rows that pass the filter; est[P] += sampled rows
 __global__ __launch_bounds__(256) void rp_sample_hist_kernel(const uint64_t *__restrict__ key, RowFilter flt, int64_t n,
                                                              uint32_t tile_rows, uint32_t num_tiles, uint32_t P, KeyPack kp,
-                                                             uint32_t *__restrict__ est) {
+                                                             uint32_t sdiv, uint32_t *__restrict__ est) {
   __shared__ uint32_t h[512];
   __shared__ uint32_t s_seen;
   for (uint32_t i = threadIdx.x; i < 512; i += 256) h[i] = 0;
   if (threadIdx.x == 0) s_seen = 0;
   __syncthreads();
-  const uint32_t S = tile_rows / 8; // sampled rows per tile: the (5 t mod 8)-th eighth of tile t
+  // sampled rows per tile: the first tile_rows / sdiv rows (sdiv = 8, 16 or 32) of the (5 t mod 8)-th eighth of tile t
+  const uint32_t S = tile_rows / sdiv;
   const int64_t total = (int64_t)num_tiles * S;
   uint32_t seen = 0;
   constexpr int U = 4;
@@ -1147,7 +1150,7 @@ __global__ __launch_bounds__(256) void rp_sample_hist_kernel(const uint64_t *__r
     for (int u = 0; u < U; u++) {
       const int64_t i = i0 + (int64_t)u * 256;
       const uint32_t t = (uint32_t)(i / S), o = (uint32_t)(i % S);
-      const int64_t row = (int64_t)t * tile_rows + (int64_t)((t * 5u) & 7u) * S + o;
+      const int64_t row = (int64_t)t * tile_rows + (int64_t)((t * 5u) & 7u) * (tile_rows / 8) + o;
       in[u] = i < total && row < n;
       const int64_t r = in[u] ? row : 0;
       k[u] = __builtin_nontemporal_load(key + r);
@@ -1362,6 +1365,213 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_claim_scatter_kernel(
       }
     }
   }
+  if (threadIdx.x == 0 && kept) atomicAdd(out.kept, kept);
+}
+
+// ---- the claimed single level in the SLIM form (round 5): 12 bytes per row out of the level instead of 16 ---------------
+// What "slim records" above are to the two-level partition, for the claimed level (C4: 2e8 rows x 16 B in, the same out,
+// the same again into the bucket pass).  A row leaves as value (8 B) + u32 { slot in the bucket | row inside its TILE <<
+// rbits | tile DELTA << (rbits + 13) }; the bucket and the row id are rebuilt where they are needed: the bucket is the
+// region the row lies in, and row = (base tile of the row's BLOCK + delta) * TILE + row inside the tile.  A block (B
+// consecutive slots of a region, B-aligned) is filled by ONE workgroup with rows of consecutive tiles, so one u32 per block
+// — the tile that claimed it, blk_bt[slot / B] — is all the bucket pass needs: a wave's 64 rows read one or two entries.
+// The delta has 7 bits: a digit that sees a row only every few hundred tiles abandons what is left of its open block
+// (sentinel rows) once the next tile would be more than 127 tiles after the block's first.  Sentinel = all ones: "row
+// 8191 of its tile" does not exist in a tile of 6144 rows.
+struct SlimClaimOut {
+  SlimRowsView rows;
+  uint32_t *cursor;      // [P] next free slot of the bucket's region
+  const uint32_t *rend;  // [P] first slot behind the region
+  uint32_t *blk_bt;      // [slots / B] tile of the claim that took the block
+  unsigned int *flag;    // [0] set when a region overflowed
+  unsigned long long *kept;
+  uint32_t B, log_b;
+  uint32_t max_delta;    // <= 127 (smaller only as a test hook)
+};
+constexpr uint32_t SLIM_SENTINEL = 0xffffffffu;
+
+template <int RP_WG, int RP_ROWS, int PSRC>
+__global__ __launch_bounds__(RP_WG, 1) void rp_claim_scatter_slim_kernel(
+    const uint64_t *__restrict__ key, const uint64_t *__restrict__ v0, RowFilter flt, int64_t n, SlimClaimOut out, uint32_t P,
+    uint32_t num_tiles, uint32_t tiles_per_wg, int64_t sink, KeyPack kp) {
+  constexpr uint32_t RP_TILE = RP_WG * RP_ROWS;
+  static_assert(RP_TILE < (1u << SLIM_LOCAL_BITS), "row 8191 of a tile is the sentinel");
+  constexpr int64_t DEAD = -(1ll << 40); // destination base of a digit whose region overflowed: g < 0 -> the sink
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t *sv0 = (uint64_t *)smem;
+  uint32_t *sw = (uint32_t *)(sv0 + RP_TILE);
+  uint16_t *sdig = (uint16_t *)(sw + RP_TILE);
+  uint32_t *cnt = (uint32_t *)(sdig + RP_TILE); // [RP_WG]
+  uint32_t *split = cnt + RP_WG;                // [RP_WG] tile-local position where a digit's run changes block
+  int64_t *gb0 = (int64_t *)(split + RP_WG);    // [RP_WG] destination of position p: gb0[d] + p below the split,
+  int64_t *gb1 = gb0 + RP_WG;                   //         gb1[d] + p from it on
+  uint32_t *dl0 = (uint32_t *)(gb1 + RP_WG);    // [RP_WG] tile delta (already shifted) of the rows below the split; 0 from it on
+  __shared__ uint32_t s_wsum[RP_WG / 64];
+  __shared__ uint32_t s_total;
+
+  const uint32_t t0 = blockIdx.x * tiles_per_wg;
+  const uint32_t t1 = min(num_tiles, t0 + tiles_per_wg);
+  const bool owner = threadIdx.x < P;
+  uint32_t pos = 0, room = 0, bbase = 0; // open block of digit threadIdx.x: next free slot, slots left, tile of its claim
+  bool dead = false;
+  const uint32_t my_end = owner ? out.rend[threadIdx.x] : 0u;
+  const uint32_t Bm1 = out.B - 1;
+  const uint32_t rbits = kp.rbits, smask = (1u << rbits) - 1u, dshift = rbits + SLIM_LOCAL_BITS;
+  unsigned long long kept = 0;
+  auto tile_start = [&](uint32_t t) { return (int64_t)t * RP_TILE; };
+  auto tile_len = [&](uint32_t t) { return (uint32_t)min((int64_t)RP_TILE, n - (int64_t)t * RP_TILE); };
+
+  ChunkRegs<1, RP_ROWS, PSRC> nxt;
+  SlimCur<RP_ROWS> cur;
+  uint32_t dr[RP_ROWS]; // digit << 16 | rank inside the tile's run of that digit; ~0 = row not kept
+  uint32_t cur_tile = 0;
+  // (`report`: false when the tile was loaded a second time — the pipeline re-reads a range's last tile instead of branching —
+  //  so that a key outside the sampled range reaches the outlier list once)
+  auto take_rows = [&](uint32_t len, uint32_t nxt_tile, bool report, SlimCur<RP_ROWS> &cur) { // nxt (as loaded: tile `nxt_tile`) -> cur
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      bool keep = (uint32_t)(j * RP_WG) + threadIdx.x < len;
+      if (PSRC == 1) keep = keep && row_passes(flt, nxt.a0[j]);
+      if (PSRC == 3) keep = keep && row_passes(flt, nxt.pv[PSRC == 3 ? j : 0]);
+      const uint64_t off = nxt.k[j] - kp.kmin;
+      if (keep && off > kp.range) { // no bucket of the range partition holds this key (see rp_chunk_scatter_slim_kernel)
+        if (kp.oob && report) key_out_of_range(kp, (uint32_t)((int64_t)nxt_tile * RP_TILE + (uint32_t)(j * RP_WG) + threadIdx.x));
+        keep = false;
+      }
+      cur.off[j] = keep ? (uint32_t)off : 0xffffffffu;
+      cur.a0[j] = nxt.a0[j];
+    }
+  };
+  auto rank_row = [&](int j) {
+    dr[j] = 0xffffffffu;
+    if (cur.off[j] != 0xffffffffu) {
+      const uint32_t d = min(cur.off[j] >> rbits, P - 1);
+      dr[j] = (d << 16) | atomicAdd(&cnt[d], 1u);
+    }
+  };
+  auto fill_sentinels = [&](uint32_t from, uint32_t count) {
+    for (uint32_t i = 0; i < count; i++) slim_store(out.rows, (int64_t)from + i, SLIM_SENTINEL, 0ull);
+  };
+  auto scan_and_stage = [&]() {
+    const uint32_t c = cnt[threadIdx.x];
+    // what is left of an open block whose first tile is too far back for this tile's delta: sentinel rows
+    if (owner && c > 0 && room > 0 && cur_tile - bbase > out.max_delta) {
+      fill_sentinels(pos, room);
+      room = 0;
+    }
+    // the claim first: its answer is needed only behind the staging loop
+    const uint32_t used = min(c, room), need = c - used;
+    const bool claim = owner && need > 0;
+    const uint32_t k = (need + Bm1) & ~Bm1;
+    uint32_t got = 0;
+    if (claim && !dead) got = atomicAdd(&out.cursor[threadIdx.x], k);
+    const uint32_t inc = wave_iscan_u32(c);
+    if (lane_id() == 63) s_wsum[wave_id()] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (int w = 0; w < RP_WG / 64; w++) {
+      if (w < wave_id()) wbase += s_wsum[w];
+      tot += s_wsum[w];
+    }
+    const uint32_t ls = wbase + inc - c;
+    if (threadIdx.x == 0) {
+      s_total = tot;
+      kept += tot;
+    }
+    cnt[threadIdx.x] = ls; // run start (rank_row's counters are consumed)
+    split[threadIdx.x] = ls + used;
+    gb0[threadIdx.x] = (int64_t)pos - (int64_t)ls;
+    dl0[threadIdx.x] = (cur_tile - bbase) << dshift; // (used > 0 only while the delta fits, see above)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      if (dr[j] == 0xffffffffu) continue;
+      const uint32_t d = dr[j] >> 16;
+      const uint32_t p = cnt[d] + (dr[j] & 0xffffu);
+      const uint32_t local = (uint32_t)(j * RP_WG) + threadIdx.x;
+      sv0[p] = cur.a0[j];
+      sw[p] = (cur.off[j] & smask) | (local << rbits) | (p < split[d] ? dl0[d] : 0u);
+      sdig[p] = (uint16_t)d;
+    }
+    int64_t g1 = 0;
+    if (claim) {
+      if (!dead && (uint64_t)got + k > (uint64_t)my_end) {
+        dead = true;
+        *out.flag = 1u;
+      }
+      if (dead) {
+        g1 = DEAD;
+        pos = 0;
+        room = 0;
+      } else {
+        g1 = (int64_t)got - (int64_t)(ls + used);
+        pos = got + need;
+        room = k - need;
+        bbase = cur_tile;
+        for (uint32_t b = got >> out.log_b, be = (got + k) >> out.log_b; b < be; b++) out.blk_bt[b] = cur_tile;
+      }
+    } else {
+      pos += c;
+      room -= c;
+    }
+    gb1[threadIdx.x] = g1;
+    __syncthreads();
+  };
+  auto store_row = [&](int j, uint32_t len) { // position p of the staged tile -> its block
+    const uint32_t p = j * RP_WG + threadIdx.x;
+    const uint32_t d = (uint32_t)sdig[p] & (RP_WG - 1);
+    int64_t g = (p < split[d] ? gb0[d] : gb1[d]) + p;
+    if (p >= len || g < 0) g = sink + (int64_t)blockIdx.x * RP_WG + threadIdx.x; // past the staged rows / overflowed region: sink rows
+    slim_store(out.rows, g, sw[p], sv0[p]);
+  };
+
+  if (t0 < t1) {
+    uint32_t len = tile_len(t0);
+    cur_tile = t0;
+    rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(t0), len, nxt);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    take_rows(len, t0, true, cur);
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) rank_row(j);
+    __syncthreads();
+    scan_and_stage();
+    uint32_t staged_len = s_total;
+    uint32_t tcur = min(t0 + 1, t1 - 1);
+    len = tile_len(tcur);
+    cur_tile = tcur;
+    rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(tcur), len, nxt);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    take_rows(len, tcur, tcur != t0, cur);
+    // the software pipeline of rp_chunk_scatter_slim_kernel: while tile i-1 (staged) is written out, tile i (in `cur`) is
+    // ranked and tile i+1 is in flight into `nxt`.  (Measured and dropped, round 5: one tile MORE in flight — tile i+1
+    // taken into a second compressed register set and the loads of tile i+2 issued before tile i is staged, 252 VGPRs, no
+    // spill — so that the staging phase does not run with an idle memory pipe: 1.801 vs 1.804 ms for C4's 2e8 rows.  The
+    // kernel is not waiting for its loads.)
+    for (uint32_t ti = t0 + 1; ti < t1; ti++) {
+      const uint32_t tnext = min(ti + 1, t1 - 1);
+      const uint32_t nlen = tile_len(tnext);
+      rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(tnext), nlen, nxt);
+      cnt[threadIdx.x] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RP_ROWS; j++) {
+        if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);
+        rank_row(j);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      scan_and_stage();
+      staged_len = s_total;
+      take_rows(nlen, tnext, tnext != ti, cur);
+      cur_tile = tnext;
+    }
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++)
+      if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);
+  }
+  if (owner && !dead) fill_sentinels(pos, room); // what is left of every open block
   if (threadIdx.x == 0 && kept) atomicAdd(out.kept, kept);
 }
 
@@ -1798,6 +2008,8 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   if (claimable) {
     const uint32_t tiles1c = (uint32_t)ceil_div(n, RP_TILE);
     uint32_t wgs = std::min<uint32_t>(tiles1c, (uint32_t)ctx->num_cus);
+    if (const char *wg_e = std::getenv("SQLRS_RP_CHUNK_WGS")) // test hook, read per call: fewer workgroups = longer tile ranges per workgroup
+      wgs = std::max(1u, std::min<uint32_t>(wgs, (uint32_t)std::atoi(wg_e)));
     const uint32_t tpw = (uint32_t)ceil_div(tiles1c, std::max(wgs, 1u));
     wgs = (uint32_t)ceil_div(tiles1c, std::max(tpw, 1u));
     // block size: the holes (about wgs * B / 2 per bucket) stay near 3 % of the rows; >= 16 rows = 256 bytes
@@ -1816,17 +2028,42 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       uint64_t *cst = (uint64_t *)(plan->as<uint32_t>() + plan_words);
       {
         ProfScope ps(ctx, "rp_sample_hist");
-        const int64_t samples = (int64_t)tiles1c * (RP_TILE / 8);
+        // an eighth of every tile, or less of it when a bucket still gets >= 4096 sampled rows (+-5 % at three sigma against
+        // the regions' 12.5 % head room): C4's 2e8 rows read 50 MB instead of 200 (0.054 -> see DESIGN.md)
+        uint32_t sdiv = 8;
+        while (sdiv < 32 && (int64_t)P * 4096 * (2 * sdiv) <= n) sdiv *= 2;
+        const int64_t samples = (int64_t)tiles1c * (RP_TILE / sdiv);
         // (four blocks per CU: every block ends with up to P global atomics — 4096 blocks spent more time on those than
         //  on reading the sample)
         const unsigned sblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(samples, 256 * 4 * 2), 4 * (int64_t)ctx->num_cus));
-        rp_sample_hist_kernel<<<dim3(sblocks), dim3(256), 0, ctx->stream>>>(in.keys, in.filter, n, (uint32_t)RP_TILE, tiles1c, P, kp,
+        rp_sample_hist_kernel<<<dim3(sblocks), dim3(256), 0, ctx->stream>>>(in.keys, in.filter, n, (uint32_t)RP_TILE, tiles1c, P, kp, sdiv,
                                                                            est->as<uint32_t>());
         rp_region_plan_kernel<<<dim3(1), dim3(512), 0, ctx->stream>>>(est->as<uint32_t>(), P, n, slack, B, rstart, rend, cursor);
         SQ_HIP(hipGetLastError());
       }
+      // slim form (rp_claim_scatter_slim_kernel): 12 bytes per row out of the level; SQLRS_RP_SLIM=0 (read per call) = the
+      // 16-byte form (tests, A/B)
+      const char *cslim_e = std::getenv("SQLRS_RP_SLIM");
+      const bool claim_slim = nv == 1 && kp.rbits + SLIM_LOCAL_BITS + 7 <= 32 && !(cslim_e && std::atoi(cslim_e) == 0);
       Cols cc;
-      if (use_rec) cc.rec = ctx->alloc(16 * (size_t)pool_rows);
+      PartitionedRows::Slim csl;
+      if (claim_slim) {
+        uint32_t log_b = 0;
+        while ((1u << log_b) < B) log_b++;
+#ifdef SLIM_AOS
+        csl.buf0 = ctx->alloc(sizeof(SlimRec) * (size_t)pool_rows);
+        csl.rows.rec = csl.buf0->as<SlimRec>();
+#else
+        csl.buf0 = ctx->alloc(8 * (size_t)pool_rows);
+        csl.buf1 = ctx->alloc(4 * (size_t)pool_rows);
+        csl.rows.v = csl.buf0->as<uint64_t>();
+        csl.rows.w = csl.buf1->as<uint32_t>();
+#endif
+        csl.blk_bt = ctx->alloc(4 * (size_t)((slots_max >> log_b) + 2));
+        csl.log_b = log_b;
+        csl.tile = (uint32_t)RP_TILE;
+        csl.on = true;
+      } else if (use_rec) cc.rec = ctx->alloc(16 * (size_t)pool_rows);
       else {
         cc.k = ctx->alloc(8 * (size_t)pool_rows);
         cc.v0 = nv >= 1 ? ctx->alloc(8 * (size_t)pool_rows) : nullptr;
@@ -1858,7 +2095,30 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     else if (psrc == 1 && NV >= 1) SQ_CL1(NV, (NV >= 1 ? 1 : 3), RC);                                               \
     else SQ_CL1(NV, 3, RC);                                                                                         \
   } while (0)
-        if (nv == 0) SQ_CL(0, false);
+        if (claim_slim) {
+          SlimClaimOut so;
+          so.rows = csl.rows;
+          so.cursor = cursor;
+          so.rend = rend;
+          so.blk_bt = csl.blk_bt->as<uint32_t>();
+          so.flag = co.flag;
+          so.kept = co.kept;
+          so.B = B;
+          so.log_b = csl.log_b;
+          const char *sd_e = std::getenv("SQLRS_RP_SLIM_DELTA"); // test hook, read per call: blocks abandoned after fewer tiles
+          so.max_delta = sd_e ? (uint32_t)std::max(1, std::min(std::atoi(sd_e), 127)) : 127u;
+          const size_t slds = (size_t)RP_TILE * (8 + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8 + 4);
+#define SQ_CS(PS)                                                                                                   \
+  do {                                                                                                              \
+    auto kfn = rp_claim_scatter_slim_kernel<512, 12, PS>;                                                           \
+    allow_big_lds(ctx, kfn);                                                                                        \
+    kfn<<<dim3(wgs), dim3(512), slds, ctx->stream>>>(k, a0, in.filter, n, so, P, tiles1c, tpw, sink, kp);           \
+  } while (0)
+          if (psrc < 0) SQ_CS(-1);
+          else if (psrc == 1) SQ_CS(1);
+          else SQ_CS(3);
+#undef SQ_CS
+        } else if (nv == 0) SQ_CL(0, false);
         else if (use_rec) SQ_CL(1, true);
         else SQ_CL(1, false);
 #undef SQ_CL
@@ -1873,6 +2133,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         out->n = (int64_t)hc[0];
         out->P = P;
         publish(cc);
+        if (claim_slim) out->slim = csl;
         out->bstart = plan; // (region starts; device consumers of contiguous buckets never see a claimed partition)
         out->bstart_host.assign(hp, hp + P);
         out->bstart_host.push_back((uint32_t)slots_max);

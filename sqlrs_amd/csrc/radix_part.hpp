@@ -169,6 +169,10 @@ struct PartitionedRows {
     BufP nzstart, nzbt; // u32 per run: first row / base tile of the k-th non-empty run of bucket b at [bcol[b] + k]
     BufP nzcount, bcol; // u32 [P]
     uint32_t tile = 0;  // rows per level-1 tile
+    // Claimed single level in the slim form (rp_claim_scatter_slim_kernel): no run lists — the base tile of a row is that
+    // of its BLOCK, blk_bt[slot >> log_b]; sentinel rows carry the word 0xffffffff.  Null = the run lists above.
+    BufP blk_bt;
+    uint32_t log_b = 0;
   } slim;
 };
 

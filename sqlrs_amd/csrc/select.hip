@@ -102,6 +102,9 @@ Selection selection_from_mask(Ctx *ctx, const DCol &mask) {
 Selection selection_from_clear_bits(Ctx *ctx, const uint64_t *bits, int64_t rows) {
   return selection_from_words(ctx, bits, nullptr, true, rows);
 }
+Selection selection_from_set_bits(Ctx *ctx, const uint64_t *bits, int64_t rows) {
+  return selection_from_words(ctx, bits, nullptr, false, rows);
+}
 
 // ------------------------------------------------------------------ compaction --
 // One block per tile.  Every wave loads the tile's 64 mask words (lane l <- word l), scans the

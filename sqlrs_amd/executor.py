@@ -367,8 +367,10 @@ class CrossJoinExecutor:
         h = C.c_void_p()
         be.check(be.fn("cross_join_create")(be.ctx, C.byref(h)))
         try:
+            self._left_rows = 0
             for batch in self.left_child:  # cross_join.rs:30
                 b = abi.as_batch(batch)
+                self._left_rows += b.abi.num_rows if hasattr(b, "abi") else b.num_rows
                 be.check(be.fn("cross_join_build_push")(h, b.ptr))
             for batch in self.right_child:  # cross_join.rs:38-56
                 b = abi.as_batch(batch)
@@ -378,7 +380,11 @@ class CrossJoinExecutor:
                 if whole is None:
                     continue
                 r = b.abi.num_rows if hasattr(b, "abi") else b.num_rows
-                for i in range(whole.num_rows // r if r else 0):
+                if r == 0:  # one EMPTY batch per left row (cross_join.rs:39-55 emits it all the same)
+                    for _ in range(self._left_rows):
+                        yield whole.slice(0, 0)
+                    continue
+                for i in range(whole.num_rows // r):
                     yield whole.slice(i * r, r)
         finally:
             be.fn("cross_join_destroy")(h)

@@ -106,7 +106,10 @@ def test_sparse_within_the_route_and_beyond(hip, oracle):
         prof = hip.profile_read()
         hip.profile(False)
         same(got, run(oracle, [lb], [rb]))
-        assert (prof.get("join_probe_dense", (0, 0))[1] >= 1) == dense, (stride, prof)
+        # (the first probe runs its optimistic kernel against the build's device-side verdict either way — join_probe_dense —
+        #  and the general hash table is built only when that verdict is "not a dense unique key set")
+        assert prof.get("join_probe_dense", (0, 0))[1] >= 1, (stride, prof)
+        assert (prof.get("join_build", (0, 0))[1] == 0) == dense, (stride, prof)
 
 
 def test_duplicate_build_keys_leave_the_route(hip, oracle):
@@ -128,9 +131,10 @@ def test_two_build_batches_and_all_null_keys(hip, oracle):
     same(run(hip, [ln], [rb.slice(0, 100)]), run(oracle, [ln], [rb.slice(0, 100)]))
 
 
-@pytest.mark.parametrize("var", ["SQLRS_DENSE_PACKED", "SQLRS_DENSE_BUILD_ONE_FETCH"])
+@pytest.mark.parametrize("var", ["SQLRS_DENSE_PACKED", "SQLRS_DENSE_BUILD_ONE_FETCH", "SQLRS_DENSE_BUILD_DEFER"])
 def test_ab_hooks_give_the_same_pairs(hip, oracle, var, monkeypatch):
-    """0 = the 4-byte table / the two-fetch build of round 4: same result"""
+    """0 = the 4-byte table / the two-fetch build of round 4 / the build's verdict fetched by build_finish instead of by the
+    first probe: same result"""
     rng = np.random.default_rng(10)
     lb = dim(rng, 400_000, kmin=-3, null_row=5)
     rb = fact(rng, 300_000, -3, 399_997)
@@ -138,3 +142,23 @@ def test_ab_hooks_give_the_same_pairs(hip, oracle, var, monkeypatch):
     for val in ("0", "1"):
         monkeypatch.setenv(var, val)
         same(run(hip, [lb], [rb]), exp)
+
+
+@pytest.mark.parametrize("shape", ["all_hit", "half_hit", "duplicates", "too_sparse", "small_first_batch", "null_probe_keys"])
+def test_first_probe_against_the_device_side_verdict(hip, oracle, shape):
+    """build_finish leaves the direct-address build's verdict on the device; the first probe batch runs the optimistic
+    all-hit kernel against it and fetches both answers together (join.hip, dense_resolve).  Every outcome of that pair —
+    dense + all hit, dense + misses, duplicates, range too wide — and the first batches that cannot take the kernel (small,
+    NULL keys: the verdict is fetched first), each followed by a second batch; pairs in hash_join.rs:217-253 order."""
+    rng = np.random.default_rng(len(shape))
+    nb = 150_000
+    keys = rng.permutation(nb).astype(np.int64) * (7 if shape == "too_sparse" else 1)
+    if shape == "duplicates":
+        keys[5] = keys[99_999]
+    lb = pa.RecordBatch.from_arrays([pa.array(keys), pa.array(np.arange(nb, dtype=np.int64))], names=["k", "p"])
+    hi = int(keys.max()) + 1
+    rb1 = fact(rng, 70_000 if shape != "small_first_batch" else 3_000, 0, hi * 2 if shape == "half_hit" else hi,
+               null_frac=0.02 if shape == "null_probe_keys" else 0.0)
+    rb2 = fact(rng, 80_000, 0, hi)
+    for jt in ("inner", "left"):
+        same(run(hip, [lb], [rb1, rb2], jt), run(oracle, [lb], [rb1, rb2], jt))

@@ -304,15 +304,10 @@ def test_fuzz_hash_agg_distinct_and_utf8_keys(hip, oracle, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.hooked_rerun("early_flushes")
 def test_fuzz_hash_agg_with_early_flushes():
     """SQLRS_STAGE_FLUSH_ROWS=600000: staged batches are aggregated several times before finish, so
     groups of an earlier flush are merged with later ones (deferred groups -> table, table growth);
     the large-batch fuzz families run under it (hook read once per process, hence the subprocess)."""
-    import subprocess
-    import sys
-    env = dict(os.environ, SQLRS_STAGE_FLUSH_ROWS="600000", SQLRS_STAGE_DIRECT_ROWS="1000000000000")
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "((partition_route and not composite) or distinct_and_utf8) and not early_flushes"],
-                       env=env, capture_output=True, text=True, timeout=500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    from conftest import hooked_rerun
+    hooked_rerun("early_flushes")

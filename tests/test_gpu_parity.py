@@ -728,23 +728,14 @@ def test_hash_agg_partition_route_with_key_skew(hip, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.hooked_rerun("forced_table_overflow")
 @pytest.mark.parametrize("scale", ["0.05"])
 def test_hash_agg_partition_route_with_forced_table_overflow(scale):
     """SQLRS_EST_SCALE shrinks the HyperLogLog group estimate, so the per-bucket LDS tables
     overflow and rows take the overflow -> global-table path; group order and values must not
     change (the hook is read once per process, hence the subprocess)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, SQLRS_EST_SCALE=scale)
-    here = os.path.abspath(__file__)
-    # (the milder scale re-runs the partition-route tests only: the driver's GPU suite has a time budget)
-    sel = "((test_hash_agg_partition_route and not packed_and and not few_groups) or mixed_routes or join_agg_fused or " \
-          "join_agg_composed) and not forced"
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", sel],
-                       env=env, capture_output=True, text=True, timeout=400)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    from conftest import hooked_rerun
+    hooked_rerun("forced_table_overflow")
 
 
 # ------------------------------------------- code paths added with the round-1 kernel rework --
@@ -940,23 +931,13 @@ def test_hash_agg_keeps_nothing_borrowed(hip, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.hooked_rerun("without_staging")
 def test_agg_paths_without_staging():
     """SQLRS_STAGE_DIRECT_ROWS=0 aggregates every pushed batch on its own (the path a first batch of
     >= 2^26 rows takes): per-batch pre-aggregation, deferred groups and merges through the table
     stay covered (the hook is read once per process, hence the subprocess)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, SQLRS_STAGE_DIRECT_ROWS="0")
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        # (a representative cut — multi-batch aggregation, both partition routes, the fused join, Utf8 keys —
-                        #  not every aggregation test twice: the driver's GPU suite has a time budget)
-                        "-k", "(mixed_routes or (test_hash_agg_partition_route and not packed_and and not few_groups "
-                              "and not key_skew) or join_agg_fused or join_agg_composed or join_agg_dense or utf8_keys) "
-                              "and not forced and not without"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    from conftest import hooked_rerun
+    hooked_rerun("without_staging")
 
 
 @pytest.mark.gpu
@@ -1298,20 +1279,13 @@ def test_join_agg_build_keys_with_gaps(hip, oracle, keep_one_in, hot):
 
 
 @pytest.mark.gpu
+@pytest.mark.hooked_rerun("without_dense_tables")
 def test_agg_paths_without_dense_tables():
     """SQLRS_DENSE_AGG=0: dense integer keys go through the hashed partition and the probing LDS
     tables like any other key set, so that path stays covered by the same inputs (hook read once
     per process, hence the subprocess)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, SQLRS_DENSE_AGG="0")
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "((dense_key_route and count_sum_f64) or join_agg_dense_build_keys or "
-                              "join_agg_probe_keys_outside) and not forced and not without"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    from conftest import hooked_rerun
+    hooked_rerun("without_dense_tables")
 
 
 @pytest.mark.parametrize("shape", ["int64_7_groups", "int64_sparse_40_groups", "utf8_10_groups", "two_columns_12_groups"])

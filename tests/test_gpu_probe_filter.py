@@ -83,6 +83,27 @@ AGGS = {
 }
 
 
+# The oracle is a row-at-a-time restatement of the reference: 4-6 s for a 2.5e6-row Filter -> HashJoin -> HashAgg.  The
+# two-level cases below therefore share ONE pair of tables per key shape and ONE oracle result per (key shape,
+# predicate, aggregate list) — every variant of the HIP side (hooks, record forms, levels) is checked against the same
+# expectation instead of paying for its own.
+_TABLES, _REF = {}, {}
+
+
+def shared_tables(sparse):
+    if sparse not in _TABLES:
+        _TABLES[sparse] = tables(np.random.default_rng(1234 + int(sparse)), 2_400_000 if not sparse else 400_000, 2_500_000, sparse)
+    return _TABLES[sparse]
+
+
+def shared_reference(oracle, sparse, pred, aggs):
+    key = (sparse, pred, aggs)
+    if key not in _REF:
+        lb, rb, sch = shared_tables(sparse)
+        _REF[key] = reference(oracle, lb, [rb], JoinCondition([(InputRef(0), InputRef(1))]), sch, 2, AGGS[aggs], [InputRef(0)], PREDS[pred])
+    return _REF[key]
+
+
 @pytest.mark.parametrize("pred", ["val_gt_half", "other_ne", "general"])
 @pytest.mark.parametrize("batches", [1, 3])
 def test_probe_filter_small_batches(hip, oracle, pred, batches):
@@ -106,15 +127,14 @@ def test_probe_filter_chunked(hip, oracle, sparse, pred, aggs):
         pytest.skip("the threshold is meant for the dense key range")
     if aggs != "count_sum" and pred not in ("val_gt_half", "other_ne"):
         pytest.skip("aggregate lists are crossed with two predicates only")
-    rng = np.random.default_rng(zlib.crc32(f"{sparse}{pred}{aggs}".encode()))
-    lb, rb, sch = tables(rng, 2_400_000 if not sparse else 400_000, 2_500_000, sparse)
+    lb, rb, sch = shared_tables(sparse)
     cond = JoinCondition([(InputRef(0), InputRef(1))])
     ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, AGGS[aggs], [InputRef(0)], probe_filter=PREDS[pred])
     got = rows_of(ex.execute())
     if FORCED and aggs != "none":  # (without accumulators a bucket table holds 8x the keys: one level, nothing chunked)
         assert ex.fused_batches == 1
         assert ex.filter_fused_batches == (0 if pred == "general" else 1)
-    exp = reference(oracle, lb, [rb], cond, sch, 2, AGGS[aggs], [InputRef(0)], PREDS[pred])
+    exp = shared_reference(oracle, sparse, pred, aggs)
     assert_same(got, exp, float_cols={2} if aggs == "count_sum" else ({1} if aggs == "two_columns" else ()))
 
 
@@ -247,8 +267,7 @@ def test_chunked_slim_records(hip, oracle, hooks, pred, monkeypatch):
            "one_workgroup": {"SQLRS_RP_CHUNK_WGS": "1", "SQLRS_RP_SLIM_DELTA": "127"}, "off": {"SQLRS_RP_SLIM": "0"}}[hooks]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    rng = np.random.default_rng(zlib.crc32(f"slim{hooks}{pred}".encode()))
-    lb, rb, sch = tables(rng, 2_400_000, 2_500_000, sparse=False)
+    lb, rb, sch = shared_tables(False)
     cond = JoinCondition([(InputRef(0), InputRef(1))])
     hip.profile(True)
     ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, AGGS["count_sum"], [InputRef(0)], probe_filter=PREDS[pred])
@@ -257,22 +276,18 @@ def test_chunked_slim_records(hip, oracle, hooks, pred, monkeypatch):
     hip.profile(False)
     assert ex.fused_batches == 1 and ex.filter_fused_batches == 1
     assert (prof.get("rp_slim_runs", (0, 0))[1] > 0) == (hooks != "off"), prof
-    exp = reference(oracle, lb, [rb], cond, sch, 2, AGGS["count_sum"], [InputRef(0)], PREDS[pred])
-    assert_same(got, exp, float_cols={2})
+    assert_same(got, shared_reference(oracle, False, pred, "count_sum"), float_cols={2})
 
 
+@pytest.mark.hooked_rerun("chunked_first_level")
 def test_chunked_first_level_forced():
+    """the `chunked` cases again in a child pytest with SQLRS_RP_CHUNKED=1 / SQLRS_STAGE_DIRECT_ROWS=1 (read once per process;
+    conftest.HOOKED_RERUNS), where they also assert that the filter really was fused.  The same level with SQLRS_RP_H2=0 —
+    level 2 running its own histogram pass — is part of that run (test_chunked_level_without_chunk_histograms: read per call)"""
     if FORCED:
         pytest.skip("already inside the forced run")
-    env = dict(os.environ, SQLRS_RP_CHUNKED="1", SQLRS_STAGE_DIRECT_ROWS="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "(chunked and not forced and ((count_sum and (val_gt_half or (key_ge and False))) "
-                              "or (hot_digit and 0.3) or (hash_agg_chunked and dense) or (without_chunk_histograms and False))) "
-                              "or (child_filter and val_gt_half and (dense_two_level or sparse)) or slim_records"], env=env, capture_output=True,
-                       text=True, timeout=1700)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    # (the same level with SQLRS_RP_H2=0 — level 2 running its own histogram pass — is part of that run:
-    #  test_chunked_level_without_chunk_histograms, the hook is read per call)
+    from conftest import hooked_rerun
+    hooked_rerun("chunked_first_level")
 
 
 @pytest.mark.parametrize("sparse", [False, True])
@@ -295,7 +310,8 @@ def _claimed_case(hip, oracle, k, v, expect_claimed, aggs=None):
     claimed = prof.get("rp_claim_scatter", (0, 0))[1] > 0
     counted = prof.get("rp_scatter", (0, 0))[1] > 0
     assert claimed, prof
-    assert counted == (not expect_claimed), prof  # an overflowed region: the counting level redoes the batch
+    if expect_claimed is not None:
+        assert counted == (not expect_claimed), prof  # an overflowed region: the counting level redoes the batch
 
 
 @pytest.mark.parametrize("shape", ["uniform", "zipf", "few_rows_per_bucket", "one_hot_bucket"])
@@ -317,6 +333,35 @@ def test_hash_agg_claimed_single_level(hip, oracle, shape, monkeypatch):
     else:  # nine rows in ten fall into the key range of one bucket: its region takes most of the batch
         k = np.where(rng.random(n) < 0.9, rng.integers(200_000, 203_000, n), rng.integers(0, G, n)).astype(np.int64)
     _claimed_case(hip, oracle, k, rng.random(n), expect_claimed=True)
+
+
+@pytest.mark.parametrize("shape", ["uniform", "one_hot_bucket"])
+def test_hash_agg_claimed_level_16_byte_form(hip, oracle, shape, monkeypatch):
+    """SQLRS_RP_SLIM=0 (read per call): the claimed level writes 16-byte {key|row, value} records instead of the slim
+    value + 32-bit word rows (rp_claim_scatter_kernel / lds_agg_dense_kernel: the route of lists the slim form does not take)"""
+    monkeypatch.setenv("SQLRS_RP_SLIM", "0")
+    test_hash_agg_claimed_single_level(hip, oracle, shape, monkeypatch)
+
+
+@pytest.mark.parametrize("delta", [1, 3])
+@pytest.mark.parametrize("shape", ["uniform", "rare_buckets"])
+def test_hash_agg_claimed_slim_abandoned_blocks(hip, oracle, shape, delta, monkeypatch):
+    """Slim rows of the claimed level carry a 7-bit tile delta against the tile that claimed their BLOCK; a digit whose open
+    block is older than that abandons it (sentinel rows).  SQLRS_RP_SLIM_DELTA (read per call) makes that happen after 1 / 3
+    tiles: first-seen order (row ids rebuilt from block base tile + delta, hash_agg.rs:87-99) against the oracle.
+    rare_buckets: most digits see a row only every few tiles."""
+    monkeypatch.setenv("SQLRS_RP_CLAIM", "1")
+    monkeypatch.setenv("SQLRS_RP_SLIM_DELTA", str(delta))
+    monkeypatch.setenv("SQLRS_RP_CHUNK_WGS", "40")  # (read per call: ~11 tiles per workgroup instead of 2)
+    rng = np.random.default_rng(11 * delta + len(shape))
+    n, G = 2_500_000, 400_000
+    if shape == "uniform":
+        k = rng.integers(0, G, n, dtype=np.int64)
+    else:  # 88 % of the rows on 2 % of the key range, the rest spread thin over all of it (still most keys of the range: dense)
+        k = np.where(rng.random(n) < 0.88, rng.integers(100_000, 108_000, n), rng.integers(0, G, n)).astype(np.int64)
+    # (rare_buckets: blocks abandoned every few tiles can use up a region's slack — the counting level then redoes the batch;
+    #  either way the result is checked)
+    _claimed_case(hip, oracle, k, rng.random(n), expect_claimed=True if shape == "uniform" else None)
 
 
 def test_hash_agg_claimed_level_natural_size(hip, oracle):
