@@ -77,7 +77,7 @@ def parse():
                    help="N>1: who carries the single-chunk all-to-alls (the dim keys, the partial aggregates of `combine`, the "
                         "partials of `broadcast`): 'abi' = sqlrs_exchange_all_to_all (exchange.hip: RCCL on the ctx stream, "
                         "torch-free; the ncclUniqueId travels over the gloo side group), 'torch' = torch.distributed "
-                        "all_to_all_single.  The chunked, overlapped row exchange of `partition` always uses torch's")
+                        "all_to_all_single.  The chunked row exchange of `partition` runs through sqlrs_exchange_begin / send_chunk / finish with 'abi'")
     p.add_argument("--force-exchange", action="store_true",
                    help="N=1 only: run the multi-GPU code path (RCCL process group of ONE rank, fused filter + hash "
                         "partition, all-to-all, stream hand-over, local HashJoinAgg) instead of the single-GPU step; "
@@ -475,11 +475,34 @@ def main():
         (list all-to-all straight out of the regions) while chunk k + 1 is filtered and partitioned."""
         from sqlrs_amd.expr import Constant
         dtypes = [abi.INT64, abi.FLOAT64]
+        pred = InputRef(1) > Constant(args.threshold, abi.FLOAT64)
+        nloc = fact_key.numel()
+        if abi_x["h"] is not None:
+            # the chunk sequence behind the C ABI (exchange.hip: sqlrs_exchange_begin / send_chunk / finish): everything on the
+            # ctx stream, no torch on the data path — send_chunk(k) puts chunk k's count words on the wire and sends chunk
+            # k - 1's payload, so the host never waits for the device inside the loop
+            be.check(be.fn("ctx_wait_stream")(be.ctx, torch_stream()))  # the fact columns come from torch's stream
+            be.exchange_begin(abi_x["h"], dtypes, int(nloc * 0.75) + 1024)
+            keep = []
+            for c in range(n_chunks):
+                lo, hi = nloc * c // n_chunks, nloc * (c + 1) // n_chunks
+                if hi == lo:
+                    continue
+                b = device_batch(abi, [fact_key[lo:hi], fact_val[lo:hi]], dtypes)
+                parts, starts, rows = be.hash_partition_filter(b, InputRef(0), pred, world, abi.MEM_DEVICE)
+                be.exchange_send_chunk(abi_x["h"], parts, starts, rows)
+                keep.append((parts, b))
+            got = be.exchange_finish(abi_x["h"])
+            for parts, _ in keep:
+                parts.release()  # (the exchange kept its own reference until the chunk's payload was queued)
+            abi_x["keep"] += [got]
+            sent = int(be.fn("exchange_bytes_off_rank")(abi_x["h"]))
+            xstat["bytes_off_rank"] += sent - abi_x["bytes0"]
+            abi_x["bytes0"] = sent
+            return [_tensor_view(torch, got.column(ci).values, got.num_rows, T_DT[d], dev) for ci, d in enumerate(dtypes)]
         ex = D.ChunkedExchange(dist, torch, world, [T_DT[d] for d in dtypes], dev, int(fact_key.numel() * 0.75) + 1024,
                                data_group=data_group, count_group=count_group, wire_out=wire_out, wire_in=wire_in)
-        pred = InputRef(1) > Constant(args.threshold, abi.FLOAT64)
         keep = []
-        nloc = fact_key.numel()
         for c in range(n_chunks):
             lo, hi = nloc * c // n_chunks, nloc * (c + 1) // n_chunks
             if hi == lo:
@@ -702,7 +725,8 @@ def main():
     if multi:  # SURVEY.md §8e scaling report: exchange vs local time, bytes over xGMI, rate per link
         x_ms, x_bytes = xstat["exchange_ms"] / 2, xstat["bytes_off_rank"] / 2
         exchange_info = {"strategy": strategy, "chunks": n_chunks if strategy == "partition" else 1,
-                         "impl": ("sqlrs_exchange_all_to_all (C ABI, RCCL on the ctx stream) for single-chunk exchanges"
+                         "impl": ("C ABI (exchange.hip, RCCL on the ctx stream, no torch on the data path): sqlrs_exchange_all_to_all for "
+                                  "single-chunk exchanges, sqlrs_exchange_begin / send_chunk / finish for the chunked fact rows"
                                   if abi_x["h"] is not None else "torch.distributed"),
                          "fused_filter_partition": bool(fused_exchange and strategy == "partition"),
                          "step_ms_profiled": round(prof_step_ms, 3), "exchange_ms": round(x_ms, 3),
@@ -1210,6 +1234,61 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
                                  "ceiling_frac": (round(by / 0.689 / 1e6 / HBM_PEAK_GBPS, 4) if not sparse and hit == "all_hit" else None),
                                  "ms_probe_composite_ubench": (0.689 if not sparse and hit == "all_hit" else None)}
         del fk
+    # ---- general-key join shapes at the C3 size (review r04 #5; not BASELINE configs, no roofline claim): every build key FOUR times
+    #      (hash_join.rs:172-177 insertion-order chains, :225-234 probe-major pairs — 4e8 pairs out of 1e8 probe rows), and a
+    #      TWO-column key (a.x = b.x AND a.y = b.y: matched by the combined row hash like the reference, hash_utils.rs).
+    #      `check` (torch, on the device): pair count = sum of the build multiplicities of the probe keys, pairs probe-row
+    #      major, build rows of one probe row ascending (= insertion order), every pair's build key equal to its probe key.
+    def join_shape(label, build_cols, probe_cols, nkeys, expect_pairs, key_of_build, key_of_probe):
+        db = device_batch(abi, build_cols, [abi.INT64] * len(build_cols))
+        fb = device_batch(abi, probe_cols, [abi.INT64] * len(probe_cols))
+        lk, _k1 = abi.pack_exprs([InputRef(i) for i in range(nkeys)])
+        rk, _k2 = abi.pack_exprs([InputRef(i) for i in range(nkeys)])
+        rd = (C.c_int32 * len(probe_cols))(*([abi.INT64] * len(probe_cols)))
+        j = C.c_void_p()
+        m, chk = [0], ["not run"]
+
+        def both(check=False):
+            be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, nkeys, lk, rk, None, len(probe_cols), rd, C.byref(j)))
+            be.check(be.fn("hash_join_build_push")(j, db.ptr))
+            be.check(be.fn("hash_join_build_finish")(j))
+            o = C.POINTER(abi.Batch)()
+            be.check(be.fn("hash_join_probe_indices")(j, fb.ptr, D, C.byref(o)))
+            m[0] = o.contents.num_rows
+            if check:
+                be.synchronize()
+                li = _tensor_view(torch, o.contents.columns[0].values, m[0], torch.int64, dev)
+                ri = _tensor_view(torch, o.contents.columns[1].values, m[0], torch.int32, dev).to(torch.int64)
+                ok = m[0] == expect_pairs
+                ok = ok and bool((ri[1:] >= ri[:-1]).all())                                   # probe-row major
+                ok = ok and bool(((ri[1:] != ri[:-1]) | (li[1:] > li[:-1])).all())            # insertion order inside a probe row
+                ok = ok and bool((key_of_build(li) == key_of_probe(ri)).all())                # every pair joins equal keys
+                chk[0] = "OK" if ok else "MISMATCH"
+                del li, ri
+            be.fn("batch_release")(o)
+            be.fn("hash_join_destroy")(j)
+        ms = timed(both)
+        both(check=True)
+        profile_of(both, label)
+        res[label] = {"probe_rows": nP, "build_rows": nB, "pairs": m[0], "ms_build_probe": round(ms, 3),
+                      "probe_Mrows_s": round(nP / ms / 1e3, 1), "pairs_Mrows_s": round(m[0] / ms / 1e3, 1), "check": chk[0]}
+
+    gq = torch.Generator(device=dev).manual_seed(44)
+    dupk = torch.randint(0, nB // 4, (nB,), dtype=torch.int64, device=dev, generator=gq)
+    pk4 = datagen.fill_chunks(torch.empty(nP, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF1, i, nB // 4))
+    mult = torch.bincount(dupk, minlength=nB // 4)
+    expect = int(mult[pk4].sum().item())
+    torch.cuda.synchronize()
+    join_shape("C3_join_dup_build_keys_x4", [dupk], [pk4], 1, expect, lambda li: dupk[li], lambda ri: pk4[ri])
+    del dupk, mult
+    pk = datagen.fill_chunks(torch.empty(nP, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF1, i, nB))
+    # (the second column's values lie outside the first one's: the reference combines the column hashes symmetrically —
+    #  hash_utils.rs, (x, y) and (y, x) are ONE key to it — and with both columns over 0..999 every probe row finds two partners)
+    bx, by_ = dim_key % 1000, dim_key // 1000 + 10_000
+    px, py = pk % 1000, pk // 1000 + 10_000
+    torch.cuda.synchronize()
+    join_shape("C3_join_two_column_keys", [bx, by_], [px, py], 2, nP, lambda li: bx[li] + 1000 * by_[li], lambda ri: px[ri] + 1000 * py[ri])
+    del pk, pk4, bx, by_, px, py
     # ---- C4: 2e8 rows, 1e6 int64 groups, COUNT(val), SUM(val) f64
     n, G = 200_000_000, 1_000_000
     key = datagen.fill_chunks(torch.empty(n, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xA1, i, G))

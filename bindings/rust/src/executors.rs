@@ -223,6 +223,37 @@ impl HipOrderExecutor {
 
 // -------------------------------------------- Project / Limit / SimpleAgg --
 pub struct HipProjectExecutor { pub ctx: Arc<HipCtx>, pub exprs: Vec<BoundExpr>, pub child: BoxedExecutor }
+/// The same operator pulling `group` batches of its child at a time and handing them to `sqlrs_project_push_many`: the same
+/// stream of output batches (one per input batch, project.rs:15-27) at one upload / launch sequence / download per GROUP.
+pub struct HipProjectManyExecutor { pub ctx: Arc<HipCtx>, pub exprs: Vec<BoundExpr>, pub child: BoxedExecutor, pub group: usize }
+impl HipProjectManyExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let (_l, ex) = lower_all(&self.exprs)?;
+        let mut p = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_project_create(self.ctx.raw(), ex.len() as i32, ex.as_ptr(), &mut p) })?;
+        let _g = Guard(p, sqlrs_project_destroy);
+        let mut pending: Vec<RecordBatch> = Vec::with_capacity(self.group);
+        let mut child = self.child;
+        loop {
+            let next = futures::StreamExt::next(&mut child).await;
+            if let Some(b) = next { pending.push(b?); }
+            let end = pending.len() < self.group || self.group == 0;
+            if pending.len() == self.group.max(1) || (end && !pending.is_empty()) {
+                let views: Vec<AbiBatch> = pending.iter().map(AbiBatch::new).collect::<Result<_, _>>()?;
+                let ins: Vec<*const sqlrs_batch_t> = views.iter().map(|v| &v.raw as *const _).collect();
+                let mut outs: Vec<*mut sqlrs_batch_t> = vec![std::ptr::null_mut(); ins.len()];
+                self.ctx.check(unsafe { sqlrs_project_push_many(p, ins.len() as i32, ins.as_ptr(), SQLRS_MEM_HOST, outs.as_mut_ptr()) })?;
+                for (b, o) in pending.iter().zip(outs) {
+                    let schema: SchemaRef = Arc::new(Schema::new(self.exprs.iter().map(|e| e.eval_field(b)).collect::<Vec<_>>()));
+                    yield import_batch(schema, o)?;
+                }
+                pending.clear();
+            }
+            if end { break; }
+        }
+    }
+}
 impl HipProjectExecutor {
     #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
     pub async fn execute(self) {

@@ -25,6 +25,7 @@
 #pragma once
 
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <optional>
 #include <sstream>
@@ -378,15 +379,43 @@ inline RecordBatch import_batch(sqlrs_batch_t *out, SchemaRef schema) { // copie
 } // namespace detail
 
 // ---------------------------------------------------------------- operators --
+// `group` (Filter, Project, the probe side of HashJoin): 0 = one library call per child batch, as the reference's loop
+// reads; g > 1 = the operator pulls up to g batches of its child and hands them to the *_push_many entry point together —
+// the SAME stream of output batches (one per input batch, in order), at one upload / launch sequence / download per group
+// instead of per 1024-row batch (storage/csv.rs:105): 23 -> 1071 Mrows/s for the Filter, 12 -> 219 for the probe.
 struct FilterExecutor { // filter.rs:7-10
   HipCtxRef ctx;
   BoundExpr expr;
   BoxedExecutor child;
+  size_t group = 0;
   BoxedExecutor execute() {
     struct S : Executor {
       HipCtxRef ctx; BoxedExecutor child; sqlrs_filter_t *f = nullptr; detail::Lowered low;
+      size_t group = 0; std::deque<RecordBatch> ready; bool ended = false;
       ~S() override { if (f) sqlrs_filter_destroy(f); }
       std::optional<RecordBatch> next() override { // filter.rs:15-24
+        if (group > 1) {
+          if (ready.empty() && !ended) {
+            std::vector<RecordBatch> pending;
+            while (pending.size() < group) {
+              auto b = child->next();
+              if (!b) { ended = true; break; }
+              pending.push_back(std::move(*b));
+            }
+            if (!pending.empty()) {
+              std::vector<std::unique_ptr<detail::AbiBatch>> views;
+              std::vector<const sqlrs_batch_t *> ins;
+              for (auto &b : pending) { views.push_back(std::make_unique<detail::AbiBatch>(b)); ins.push_back(&views.back()->b); }
+              std::vector<sqlrs_batch_t *> outs(ins.size(), nullptr);
+              ctx->check(sqlrs_filter_push_many(f, (int)ins.size(), ins.data(), SQLRS_MEM_HOST, outs.data()));
+              for (size_t i = 0; i < outs.size(); i++) ready.push_back(detail::import_batch(outs[i], pending[i].schema));
+            }
+          }
+          if (ready.empty()) return std::nullopt;
+          RecordBatch r = std::move(ready.front());
+          ready.pop_front();
+          return r;
+        }
         auto batch = child->next();
         if (!batch) return std::nullopt;
         detail::AbiBatch in(*batch);
@@ -396,7 +425,7 @@ struct FilterExecutor { // filter.rs:7-10
       }
     };
     auto s = std::make_unique<S>();
-    s->ctx = ctx; s->child = std::move(child); s->low = detail::lower(expr);
+    s->ctx = ctx; s->child = std::move(child); s->low = detail::lower(expr); s->group = group;
     sqlrs_expr_t e = s->low.abi();
     ctx->check(sqlrs_filter_create(ctx->raw, &e, &s->f));
     return s;
@@ -410,17 +439,40 @@ struct HashJoinExecutor { // hash_join.rs:16-23
   JoinCondition join_condition;
   std::vector<ColumnCatalog> join_output_schema;
   size_t num_left_columns; // where the right part of join_output_schema starts
+  size_t group = 0;        // probe batches per library call (see FilterExecutor)
 
   BoxedExecutor execute() {
     struct S : Executor {
       HipCtxRef ctx; BoxedExecutor left, right; sqlrs_hash_join_t *j = nullptr; SchemaRef schema;
       int phase = 0; // 0 build, 1 probe, 2 tail, 3 done
+      size_t group = 0; std::deque<RecordBatch> ready;
       ~S() override { if (j) sqlrs_hash_join_destroy(j); }
       std::optional<RecordBatch> next() override {
         if (phase == 0) { // build phase (hash_join.rs:161-187)
           while (auto b = left->next()) { detail::AbiBatch in(*b); ctx->check(sqlrs_hash_join_build_push(j, &in.b)); }
           ctx->check(sqlrs_hash_join_build_finish(j));
           phase = 1;
+        }
+        while (phase == 1 && group > 1) { // probe phase (:207-292), `group` probe batches per call
+          if (!ready.empty()) {
+            RecordBatch r = std::move(ready.front());
+            ready.pop_front();
+            return r;
+          }
+          std::vector<RecordBatch> pending;
+          while (pending.size() < group) {
+            auto b = right->next();
+            if (!b) break;
+            pending.push_back(std::move(*b));
+          }
+          if (pending.empty()) { phase = 2; break; }
+          std::vector<std::unique_ptr<detail::AbiBatch>> views;
+          std::vector<const sqlrs_batch_t *> ins;
+          for (auto &b : pending) { views.push_back(std::make_unique<detail::AbiBatch>(b)); ins.push_back(&views.back()->b); }
+          std::vector<sqlrs_batch_t *> outs(ins.size(), nullptr);
+          ctx->check(sqlrs_hash_join_probe_push_many(j, (int)ins.size(), ins.data(), SQLRS_MEM_HOST, outs.data()));
+          for (sqlrs_batch_t *o : outs)
+            if (o) ready.push_back(detail::import_batch(o, schema));
         }
         while (phase == 1) { // probe phase (:207-292)
           auto b = right->next();
@@ -440,7 +492,7 @@ struct HashJoinExecutor { // hash_join.rs:16-23
       }
     };
     auto s = std::make_unique<S>();
-    s->ctx = ctx; s->left = std::move(left_child); s->right = std::move(right_child);
+    s->ctx = ctx; s->left = std::move(left_child); s->right = std::move(right_child); s->group = group;
     auto sch = std::make_shared<Schema>(); // join_output_arrow_schema (hash_join.rs:136-143)
     for (auto &c : join_output_schema) sch->push_back(c.to_arrow_field());
     s->schema = sch;
@@ -597,25 +649,52 @@ struct ProjectExecutor { // project.rs:6-9
   std::vector<BoundExpr> exprs;
   BoxedExecutor child;
   std::vector<std::string> output_names; // eval_field's names are the caller's business (binder); optional here
+  size_t group = 0;                      // child batches per library call (see FilterExecutor)
   BoxedExecutor execute() {
     struct S : Executor {
       HipCtxRef ctx; BoxedExecutor child; sqlrs_project_t *p = nullptr; std::vector<std::string> names;
+      size_t group = 0; std::deque<RecordBatch> ready; bool ended = false;
       ~S() override { if (p) sqlrs_project_destroy(p); }
-      std::optional<RecordBatch> next() override { // one output batch per input batch (project.rs:15-27)
-        auto b = child->next();
-        if (!b) return std::nullopt;
-        detail::AbiBatch in(*b);
-        sqlrs_batch_t *out = nullptr;
-        ctx->check(sqlrs_project_push(p, &in.b, SQLRS_MEM_HOST, &out));
+      RecordBatch named(sqlrs_batch_t *out) {
         RecordBatch rb = detail::import_batch(out, nullptr);
         auto sch = std::make_shared<Schema>(*rb.schema);
         for (size_t i = 0; i < sch->size() && i < names.size(); i++) (*sch)[i].name = names[i];
         rb.schema = sch;
         return rb;
       }
+      std::optional<RecordBatch> next() override { // one output batch per input batch (project.rs:15-27)
+        if (group > 1) {
+          if (ready.empty() && !ended) {
+            std::vector<RecordBatch> pending;
+            while (pending.size() < group) {
+              auto b = child->next();
+              if (!b) { ended = true; break; }
+              pending.push_back(std::move(*b));
+            }
+            if (!pending.empty()) {
+              std::vector<std::unique_ptr<detail::AbiBatch>> views;
+              std::vector<const sqlrs_batch_t *> ins;
+              for (auto &b : pending) { views.push_back(std::make_unique<detail::AbiBatch>(b)); ins.push_back(&views.back()->b); }
+              std::vector<sqlrs_batch_t *> outs(ins.size(), nullptr);
+              ctx->check(sqlrs_project_push_many(p, (int)ins.size(), ins.data(), SQLRS_MEM_HOST, outs.data()));
+              for (sqlrs_batch_t *o : outs) ready.push_back(named(o));
+            }
+          }
+          if (ready.empty()) return std::nullopt;
+          RecordBatch r = std::move(ready.front());
+          ready.pop_front();
+          return r;
+        }
+        auto b = child->next();
+        if (!b) return std::nullopt;
+        detail::AbiBatch in(*b);
+        sqlrs_batch_t *out = nullptr;
+        ctx->check(sqlrs_project_push(p, &in.b, SQLRS_MEM_HOST, &out));
+        return named(out);
+      }
     };
     auto s = std::make_unique<S>();
-    s->ctx = ctx; s->child = std::move(child); s->names = output_names;
+    s->ctx = ctx; s->child = std::move(child); s->names = output_names; s->group = group;
     std::vector<detail::Lowered> low;
     std::vector<sqlrs_expr_t> ex;
     for (auto &e : exprs) low.push_back(detail::lower(e));

@@ -256,6 +256,63 @@ int main() {
       std::printf("FAIL order offset 2 limit 1\n");
     }
   }
+  // ---- `group` > 1: Filter / Project / the probe side of HashJoin hand several child batches to the *_push_many entry
+  //      points at once and must yield the SAME stream of batches — one per input batch, in order (filter.rs:15-24,
+  //      project.rs:15-27, hash_join.rs:284-291) — as the per-batch loop.  The reference's own tables, cut into 1-2 row batches.
+  {
+    auto sch = std::make_shared<Schema>(Schema{{"id", DataType::Int64, false}, {"salary", DataType::Int64, false}});
+    std::vector<RecordBatch> parts;
+    for (int64_t i = 0; i < 7; i++) parts.push_back(RecordBatch::try_new(sch, {Int64Array({i, i + 10}), Int64Array({100 * (i % 3), 100 * ((i + 1) % 3)})}));
+    for (size_t group : {(size_t)0, (size_t)3, (size_t)16}) {
+      FilterExecutor fe;
+      fe.ctx = ctx;
+      fe.expr = BoundExpr::binary_op(BinaryOperator::Gt, build_bound_input_ref(1), BoundExpr::constant(ScalarValue::Int64(50)));
+      fe.child = stream_iter(parts);
+      fe.group = group;
+      ProjectExecutor pe;
+      pe.ctx = ctx;
+      pe.exprs = {build_bound_input_ref(1), BoundExpr::binary_op(BinaryOperator::Plus, build_bound_input_ref(0), BoundExpr::constant(ScalarValue::Int64(1)))};
+      pe.child = fe.execute();
+      pe.output_names = {"salary", "id1"};
+      pe.group = group;
+      std::vector<RecordBatch> out = try_collect(pe.execute());
+      bool ok = out.size() == parts.size(); // one output batch per input batch, empty ones included
+      std::string got;
+      for (size_t b = 0; ok && b < out.size(); b++)
+        for (int64_t r = 0; r < out[b].num_rows(); r++) got += out[b].columns[0]->value_to_string(r) + "," + out[b].columns[1]->value_to_string(r) + ";";
+      const std::string exp = "100,11;100,2;200,12;200,3;100,14;100,5;200,15;200,6;100,17;";
+      if (!ok || got != exp) {
+        failures++;
+        std::printf("FAIL filter+project with group %zu: %zu batches, rows %s\n", group, out.size(), got.c_str());
+      } else {
+        std::printf("ok   filter+project, %zu batches per call\n", group);
+      }
+    }
+    for (size_t group : {(size_t)2, (size_t)8}) { // test_inner_join_results / test_left_join_results with the probe side in three batches
+      for (JoinType jt : {JoinType::Inner, JoinType::Left}) {
+        TestChild t = build_test_child(jt);
+        RecordBatch rb = build_table_i32({"a2", {10, 20, 30}}, {"b1", {4, 5, 6}}, {"c2", {70, 80, 90}});
+        HashJoinExecutor ex;
+        ex.ctx = ctx;
+        ex.left_child = std::move(t.left);
+        ex.right_child = stream_iter({rb.slice(0, 1), rb.slice(1, 1), rb.slice(2, 1)});
+        ex.join_type = jt;
+        ex.join_condition.on = {{build_bound_input_ref(1), build_bound_input_ref(1)}};
+        ex.join_output_schema = t.schema;
+        ex.num_left_columns = 3;
+        ex.group = group;
+        std::vector<std::string> exp = {"+------+------+------+------+------+------+", "| l.a1 | l.b1 | l.c1 | r.a2 | r.b1 | r.c2 |",
+                                        "+------+------+------+------+------+------+", "| 1    | 4    | 7    | 10   | 4    | 70   |",
+                                        "| 2    | 5    | 8    | 20   | 5    | 80   |", "| 3    | 5    | 9    | 20   | 5    | 80   |"};
+        if (jt == JoinType::Left) {
+          exp.push_back("| 0    | 0    | 10   |      |      |      |");
+          exp.push_back("| 4    | 8    | 10   |      |      |      |");
+        }
+        exp.push_back("+------+------+------+------+------+------+");
+        expect_table(jt == JoinType::Inner ? "inner join, grouped probe batches" : "left join, grouped probe batches", try_collect(ex.execute()), exp);
+      }
+    }
+  }
   { // error behaviour: HashAgg without input panics in the reference (hash_agg.rs:125) -> InternalError here
     HashAggExecutor ex;
     ex.ctx = ctx;

@@ -385,6 +385,12 @@ void sqlrs_join_agg_destroy(sqlrs_join_agg_t *ja);
 typedef struct sqlrs_project sqlrs_project_t;
 int sqlrs_project_create(sqlrs_ctx_t *ctx, int num_exprs, const sqlrs_expr_t *exprs, sqlrs_project_t **out);
 int sqlrs_project_push(sqlrs_project_t *p, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out);
+/* n input batches in ONE call: out[i] (n entries) is what sqlrs_project_push(in[i]) returns — one output batch per input
+ * batch, in order [ref: project.rs:15-27] — for the reference's batch shape, 1024-row HOST batches
+ * [ref: src/storage/csv.rs:105]: small HOST batches of fixed-width columns are uploaded together and projected by one
+ * launch sequence (an expression's row i depends on row i alone); anything else runs batch by batch.  On error no output
+ * batch is left allocated. */
+int sqlrs_project_push_many(sqlrs_project_t *p, int n, const sqlrs_batch_t *const *in, int out_mem, sqlrs_batch_t **out);
 void sqlrs_project_destroy(sqlrs_project_t *p);
 
 /* [ref: src/executor/limit.rs:4-81  LimitExecutor{limit, offset, child}]  limit / offset are the constants
@@ -410,6 +416,12 @@ typedef struct sqlrs_cross_join sqlrs_cross_join_t;
 int sqlrs_cross_join_create(sqlrs_ctx_t *ctx, sqlrs_cross_join_t **out);
 int sqlrs_cross_join_build_push(sqlrs_cross_join_t *j, const sqlrs_batch_t *left);
 int sqlrs_cross_join_probe_push(sqlrs_cross_join_t *j, const sqlrs_batch_t *right, int out_mem, sqlrs_batch_t **out);
+/* The same for the left rows [left_begin, left_begin + left_rows) only: a library batch holds < 2^31 rows, the reference's
+ * one-batch-per-left-row stream has no such limit, so a caller whose left rows x right rows exceed it takes the left rows in
+ * ranges (sqlrs_cross_join_left_rows = rows pushed so far) and gets the same stream, range after range. */
+int sqlrs_cross_join_probe_push_range(sqlrs_cross_join_t *j, const sqlrs_batch_t *right, int64_t left_begin, int64_t left_rows,
+                                      int out_mem, sqlrs_batch_t **out);
+int64_t sqlrs_cross_join_left_rows(const sqlrs_cross_join_t *j);
 void sqlrs_cross_join_destroy(sqlrs_cross_join_t *j);
 
 /* [ref: src/executor/aggregate/simple_agg.rs:10-66  SimpleAggExecutor{agg_funcs, child}]  Aggregates
@@ -481,11 +493,22 @@ int sqlrs_hash_partition_filter(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, const
  * exchange of the children's hash partitions).  RCCL is dlopen'ed at the first call; none of this needs torch.
  *   sqlrs_exchange_unique_id   one rank makes the 128-byte id (ncclGetUniqueId) and hands it to the others out of band;
  *   sqlrs_exchange_create      collective: every rank calls it with the same id, its rank and the world size;
- *   sqlrs_exchange_all_to_all  collective: `in` is a DEVICE batch of fixed-width columns without NULLs whose rows
- *       [part_start[p], part_start[p] + part_rows[p]) go to rank p (what sqlrs_hash_partition / _filter return; host
- *       arrays of `world` entries); *out = the rows received from rank 0, 1, ... in this order (DEVICE);
- *       recv_rows (optional, host, `world` entries) = rows received per rank.  `in` is read stream-ordered: keep it alive
- *       until the ctx stream has passed (sqlrs_ctx_synchronize / release_to_stream), like every borrowed device batch;
+ *   sqlrs_exchange_all_to_all  collective: `in` is a DEVICE batch of fixed-width columns (NULLs allowed: validity travels
+ *       as a byte per row beside the values) whose rows [part_start[p], part_start[p] + part_rows[p]) go to rank p (what
+ *       sqlrs_hash_partition / _filter return; host arrays of `world` entries); *out = the rows received from rank 0, 1,
+ *       ... in this order (DEVICE); recv_rows (optional, host, `world` entries) = rows received per rank.  All columns of
+ *       the call travel in ONE ncclGroupStart/End.  A rank whose arguments are unusable (Utf8 / Boolean column, partition
+ *       outside the batch) says so in the count all-gather: EVERY rank then returns SQLRS_ERR_INTERNAL from this call and
+ *       nothing is sent (*out = NULL).  `in` is read stream-ordered: keep it alive until the ctx stream has passed
+ *       (sqlrs_ctx_synchronize / release_to_stream), like every borrowed device batch;
+ *   sqlrs_exchange_begin / _send_chunk / _finish  the same exchange for a SEQUENCE of chunks into ONE received batch (the
+ *       fact rows of the partitioned join, filtered and partitioned chunk by chunk): begin names the column types (and a
+ *       capacity hint in rows; the receive batch grows as needed), every send_chunk is a collective like all_to_all, finish
+ *       returns the rows of all chunks (per chunk: from rank 0, 1, ...).  send_chunk(k) puts the count words of chunk k on the
+ *       wire and sends the payload of chunk k - 1, whose words reached the host while chunk k was being produced: the
+ *       host does not wait for the device inside the loop, and the transfer of chunk k - 1 overlaps the partitioning of
+ *       chunk k + 1 on the stream.  A batch this library produced is retained by reference until its payload is queued;
+ *       any other DEVICE batch is copied once;
  *   sqlrs_exchange_plan        the receive side's bookkeeping as plain host arithmetic (no device): send_rows_all[q * world
  *       + p] = rows rank q sends to rank p -> rows / start offsets this rank receives per source rank. */
 #define SQLRS_EXCHANGE_ID_BYTES 128
@@ -494,6 +517,9 @@ int sqlrs_exchange_unique_id(sqlrs_ctx_t *ctx, void *id_out);
 int sqlrs_exchange_create(sqlrs_ctx_t *ctx, const void *unique_id, int rank, int world, sqlrs_exchange_t **out);
 int sqlrs_exchange_all_to_all(sqlrs_exchange_t *x, const sqlrs_batch_t *in, const int64_t *part_start, const int64_t *part_rows,
                               sqlrs_batch_t **out, int64_t *recv_rows);
+int sqlrs_exchange_begin(sqlrs_exchange_t *x, int num_columns, const int32_t *dtypes, int64_t capacity_rows);
+int sqlrs_exchange_send_chunk(sqlrs_exchange_t *x, const sqlrs_batch_t *in, const int64_t *part_start, const int64_t *part_rows);
+int sqlrs_exchange_finish(sqlrs_exchange_t *x, sqlrs_batch_t **out);
 int sqlrs_exchange_plan(int world, int rank, const int64_t *send_rows_all, int64_t *recv_rows, int64_t *recv_start, int64_t *total);
 int64_t sqlrs_exchange_bytes_off_rank(const sqlrs_exchange_t *x);
 void sqlrs_exchange_destroy(sqlrs_exchange_t *x);

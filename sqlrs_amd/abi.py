@@ -312,6 +312,9 @@ class Backend:
             "exchange_unique_id": (i, [vp, vp]),
             "exchange_create": (i, [vp, vp, i, i, pvp]),
             "exchange_all_to_all": (i, [vp, pb, C.POINTER(C.c_int64), C.POINTER(C.c_int64), ppb, C.POINTER(C.c_int64)]),
+            "exchange_begin": (i, [vp, i, C.POINTER(C.c_int32), C.c_int64]),
+            "exchange_send_chunk": (i, [vp, pb, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+            "exchange_finish": (i, [vp, ppb]),
             "exchange_plan": (i, [i, i, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
             "exchange_bytes_off_rank": (C.c_int64, [vp]),
             "exchange_destroy": (None, [vp]),
@@ -336,9 +339,12 @@ class Backend:
             "cross_join_create": (i, [vp, pvp]),
             "cross_join_build_push": (i, [vp, pb]),
             "cross_join_probe_push": (i, [vp, pb, i, ppb]),
+            "cross_join_probe_push_range": (i, [vp, pb, C.c_int64, C.c_int64, i, ppb]),
+            "cross_join_left_rows": (C.c_int64, [vp]),
             "cross_join_destroy": (None, [vp]),
             "project_create": (i, [vp, i, pe, pvp]),
             "project_push": (i, [vp, pb, i, ppb]),
+            "project_push_many": (i, [vp, i, C.POINTER(pb), i, C.POINTER(pb)]),
             "project_destroy": (None, [vp]),
             "limit_create": (i, [vp, i, C.c_int64, i, C.c_int64, pvp]),
             "limit_push": (i, [vp, pb, i, ppb, C.POINTER(C.c_int)]),
@@ -454,6 +460,24 @@ class Backend:
         out = C.POINTER(Batch)()
         self.check(self.fn("exchange_all_to_all")(h, b.ptr, ps, pr, C.byref(out), rr))
         return self.wrap(out), list(rr)
+
+    def exchange_begin(self, h, dtypes, capacity_rows: int = 0):
+        """opens a chunk sequence: columns of `dtypes`, one received batch at the end (sqlrs_exchange_begin)"""
+        arr = (C.c_int32 * len(dtypes))(*dtypes)
+        self.check(self.fn("exchange_begin")(h, len(dtypes), arr, int(capacity_rows)))
+
+    def exchange_send_chunk(self, h, parts, part_start, part_rows):
+        """collective: rows [part_start[p], + part_rows[p]) of the DEVICE batch `parts` are this chunk's share for rank p"""
+        b = as_batch(parts)
+        w = len(part_rows)
+        ps, pr = (C.c_int64 * w)(*[int(v) for v in part_start]), (C.c_int64 * w)(*[int(v) for v in part_rows])
+        self.check(self.fn("exchange_send_chunk")(h, b.ptr, ps, pr))
+
+    def exchange_finish(self, h):
+        """-> LibBatch (DEVICE) of everything received since exchange_begin"""
+        out = C.POINTER(Batch)()
+        self.check(self.fn("exchange_finish")(h, C.byref(out)))
+        return self.wrap(out)
 
     def exchange_plan(self, world: int, rank: int, send_rows_all):
         """host arithmetic only: send_rows_all[q][p] = rows rank q sends to rank p -> (recv_rows, recv_start, total)"""

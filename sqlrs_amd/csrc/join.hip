@@ -2156,7 +2156,10 @@ static int hash_join_build_push_device(sqlrs_hash_join_t *j, const sqlrs_batch_t
       if (i < 0 || (size_t)i >= b.cols.size()) fail(SQLRS_ERR_INTERNAL, "input ref out of range");
       return b.cols[(size_t)i];
     };
-    if (j->lkeys.size() >= 2 && j->lkeys.size() <= 4 && !j->lazy_table) { // (kept for the composite key, build_table)
+    // (the evaluated key columns are kept only for the opt-in composite key, build_table: 8 B x rows x keys of device memory
+    //  otherwise held until build_finish for nothing)
+    const char *ck_e = std::getenv("SQLRS_JOIN_COMPOSITE");
+    if (j->lkeys.size() >= 2 && j->lkeys.size() <= 4 && !j->lazy_table && ck_e && std::atoi(ck_e) == 1) {
       std::vector<DCol> kc = eval_key_cols(j->ctx, j->lkeys, colfn, b.rows);
       j->left_key_parts.push_back(normalize_keys(j->ctx, kc, b.rows));
       j->left_keycol_parts.push_back(std::move(kc));
@@ -2275,9 +2278,14 @@ int sqlrs_hash_join_probe_push_many(sqlrs_hash_join_t *j, int n, const sqlrs_bat
       return;
     }
     std::vector<int64_t> bounds((size_t)n + 1, 0);
-    for (int i = 0; i < n; i++) {
-      st.append(right[i]);
-      bounds[(size_t)i + 1] = bounds[(size_t)i] + right[i]->num_rows;
+    try {
+      for (int i = 0; i < n; i++) {
+        st.append(right[i]);
+        bounds[(size_t)i + 1] = bounds[(size_t)i] + right[i]->num_rows;
+      }
+    } catch (...) {
+      j->probe_stage.reset(); // (a half-staged call must not leave its schema and rows behind: the staged path would stay off)
+      throw;
     }
     sqlrs_batch_t *dev = st.take();
     struct Rel {

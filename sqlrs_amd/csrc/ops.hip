@@ -222,9 +222,14 @@ int sqlrs_filter_push_many(sqlrs_filter_t *f, int n, const sqlrs_batch_t *const 
       return;
     }
     std::vector<int64_t> bounds((size_t)n + 1, 0);
-    for (int i = 0; i < n; i++) {
-      st.append(in[i]);
-      bounds[(size_t)i + 1] = bounds[(size_t)i] + in[i]->num_rows;
+    try {
+      for (int i = 0; i < n; i++) {
+        st.append(in[i]);
+        bounds[(size_t)i + 1] = bounds[(size_t)i] + in[i]->num_rows;
+      }
+    } catch (...) {
+      f->stage.reset(); // (a half-staged call must not leave its schema and rows behind: the staged path would stay off)
+      throw;
     }
     sqlrs_batch_t *dev = st.take(); // one upload per column
     struct Rel {

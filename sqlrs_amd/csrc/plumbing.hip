@@ -11,6 +11,7 @@
 #include <strings.h>
 
 #include "common.hpp"
+#include "host_stage.hpp"
 #include "device_utils.hpp"
 #include "prims.hpp"
 
@@ -31,10 +32,10 @@ __global__ void iota_offset_u32_kernel(uint32_t *out, int64_t n, uint32_t start)
   if (i < n) out[i] = start + (uint32_t)i;
 }
 // cross join: output row k = (left row k / R, right row k % R)
-__global__ void cross_index_kernel(uint32_t *left_idx, uint32_t *right_idx, int64_t n, uint32_t R) {
+__global__ void cross_index_kernel(uint32_t *left_idx, uint32_t *right_idx, int64_t n, uint32_t R, uint32_t left0) {
   int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (k < n) {
-    left_idx[k] = (uint32_t)(k / R);
+    left_idx[k] = left0 + (uint32_t)(k / R);
     right_idx[k] = (uint32_t)(k % R);
   }
 }
@@ -49,6 +50,12 @@ __global__ void fill_zero_u64_kernel(uint64_t *out, int64_t n) {
 struct sqlrs_project {
   Ctx *ctx = nullptr;
   std::vector<Expr> exprs;
+  std::unique_ptr<HostStage> stage; // sqlrs_project_push_many: the call's small HOST batches, uploaded together
+  void *pin_out = nullptr;          // ... and where their projected rows land on the host (pinned)
+  size_t pin_cap = 0;
+  ~sqlrs_project() {
+    if (pin_out) (void)hipHostFree(pin_out);
+  }
 };
 
 // ======================================================================= CrossJoin ==
@@ -197,23 +204,96 @@ int sqlrs_project_create(sqlrs_ctx_t *ctx, int num_exprs, const sqlrs_expr_t *ex
   });
 }
 // [ref: project.rs:14-27] a bare InputRef shares the input column's buffers (the reference clones an Arc)
+static DBatch project_batch(sqlrs_project *p, InBatch &ib, int out_mem);
 int sqlrs_project_push(sqlrs_project_t *p, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out) {
   return guard(p->ctx, [&] {
     Ctx *ctx = p->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
     InBatch ib(ctx, in);
-    auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
-    DBatch o;
-    o.rows = ib.rows();
-    for (const Expr &e : p->exprs) {
-      DCol c = eval_expr(ctx, e, colfn, ib.rows(), true);
-      c.length = ib.rows();
-      // a column borrowed from a caller-built DEVICE batch must not outlive the call as a view
-      const bool borrowed = (c.values && !c.own_values) || (c.validity && !c.own_validity) || (c.offsets && !c.own_offsets);
-      if (borrowed && out_mem == SQLRS_MEM_DEVICE) c = copy_column(ctx, c);
-      o.cols.push_back(std::move(c));
+    *out = emit_batch(ctx, project_batch(p, ib, out_mem), out_mem);
+  });
+}
+// n input batches in one call (see sqlrs_filter_push_many): small HOST batches of fixed-width columns are staged, uploaded
+// once, projected by ONE launch sequence — an expression's row i depends on row i alone (project.rs:15-27) — and cut
+// back into one HOST batch per input batch; anything else (DEVICE memory, Utf8 / Boolean columns in or out, a constant
+// projection) runs batch by batch.
+static DBatch project_batch(sqlrs_project *p, InBatch &ib, int out_mem) {
+  Ctx *ctx = p->ctx;
+  auto colfn = [&](int i) -> const DCol & { return ib.col(i); };
+  DBatch o;
+  o.rows = ib.rows();
+  for (const Expr &e : p->exprs) {
+    DCol c = eval_expr(ctx, e, colfn, ib.rows(), true);
+    c.length = ib.rows();
+    // a column borrowed from a caller-built DEVICE batch must not outlive the call as a view
+    const bool borrowed = (c.values && !c.own_values) || (c.validity && !c.own_validity) || (c.offsets && !c.own_offsets);
+    if (borrowed && out_mem == SQLRS_MEM_DEVICE) c = copy_column(ctx, c);
+    o.cols.push_back(std::move(c));
+  }
+  return o;
+}
+int sqlrs_project_push_many(sqlrs_project_t *p, int n, const sqlrs_batch_t *const *in, int out_mem, sqlrs_batch_t **out) {
+  return guard(p->ctx, [&] {
+    Ctx *ctx = p->ctx;
+    SQ_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    if (n <= 0) return;
+    if (!p->stage) {
+      p->stage.reset(new HostStage());
+      p->stage->ctx = ctx;
     }
-    *out = emit_batch(ctx, std::move(o), out_mem);
+    HostStage &st = *p->stage;
+    bool stageable = out_mem == SQLRS_MEM_HOST && !st.has_schema && n > 1;
+    int64_t total_rows = 0;
+    for (int i = 0; i < n && stageable; i++) {
+      stageable = st.accepts(in[i]) && in[i]->num_columns == in[0]->num_columns;
+      for (int c = 0; c < in[i]->num_columns && stageable; c++) stageable = in[i]->columns[c].dtype == in[0]->columns[c].dtype;
+      total_rows += in[i] ? in[i]->num_rows : 0;
+    }
+    auto one_by_one = [&] {
+      int i = 0;
+      try {
+        for (; i < n; i++) {
+          InBatch ib(ctx, in[i]);
+          out[i] = emit_batch(ctx, project_batch(p, ib, out_mem), out_mem);
+        }
+      } catch (...) {
+        for (int k = 0; k < i; k++) {
+          sqlrs_batch_release(out[k]);
+          out[k] = nullptr;
+        }
+        throw;
+      }
+    };
+    if (!stageable || total_rows == 0 || total_rows > (1ll << 30)) {
+      one_by_one();
+      return;
+    }
+    std::vector<int64_t> bounds((size_t)n + 1, 0);
+    try {
+      for (int i = 0; i < n; i++) {
+        st.append(in[i]);
+        bounds[(size_t)i + 1] = bounds[(size_t)i] + in[i]->num_rows;
+      }
+    } catch (...) {
+      p->stage.reset(); // (a half-staged call must not leave its schema and rows behind)
+      throw;
+    }
+    sqlrs_batch_t *dev = st.take(); // one upload per column
+    struct Rel {
+      sqlrs_batch_t *b;
+      ~Rel() { if (b) sqlrs_batch_release(b); }
+    } rel{dev};
+    DBatch o;
+    {
+      InBatch ib(ctx, dev);
+      o = project_batch(p, ib, SQLRS_MEM_DEVICE);
+    }
+    if (!all_fixed_width(o)) { // Utf8 / Boolean results, constants (stride 0): the ordinary path, batch by batch
+      one_by_one();
+      return;
+    }
+    split_rows_to_host(ctx, o, bounds, &p->pin_out, &p->pin_cap, n, out); // one copy per column, one slice per input batch
   });
 }
 void sqlrs_project_destroy(sqlrs_project_t *p) { delete p; }
@@ -235,42 +315,67 @@ int sqlrs_cross_join_build_push(sqlrs_cross_join_t *j, const sqlrs_batch_t *left
     j->left.push_back(ib.materialize(true));
   });
 }
-// [ref: cross_join.rs:38-56] all (left row, right batch) outputs of one right batch, left row major
-int sqlrs_cross_join_probe_push(sqlrs_cross_join_t *j, const sqlrs_batch_t *right, int out_mem, sqlrs_batch_t **out) {
-  return guard(j->ctx, [&] {
-    Ctx *ctx = j->ctx;
-    SQ_HIP(hipSetDevice(ctx->device));
-    *out = nullptr;
-    if (j->left.empty()) return; // cross_join.rs:32-34
-    if (!j->concatenated) {
-      j->left_all.rows = 0;
-      for (const DBatch &b : j->left) j->left_all.rows += b.rows;
-      for (size_t c = 0; c < j->left[0].cols.size(); c++) {
-        std::vector<const DCol *> parts;
-        for (const DBatch &b : j->left) {
-          if (b.cols.size() != j->left[0].cols.size()) fail(SQLRS_ERR_ARROW, "cross join: left batches of different schemas");
-          parts.push_back(&b.cols[c]);
-        }
-        j->left_all.cols.push_back(concat_columns(ctx, parts));
+// [ref: cross_join.rs:38-56] the (left row, right batch) outputs of one right batch for left rows [left_begin, left_begin +
+// left_rows), left row major; left_rows < 0 = all of them
+static void cross_join_probe(sqlrs_cross_join *j, const sqlrs_batch_t *right, int64_t left_begin, int64_t left_rows, int out_mem,
+                             sqlrs_batch_t **out) {
+  Ctx *ctx = j->ctx;
+  SQ_HIP(hipSetDevice(ctx->device));
+  *out = nullptr;
+  if (j->left.empty()) return; // cross_join.rs:32-34
+  if (!j->concatenated) {
+    j->left_all.rows = 0;
+    for (const DBatch &b : j->left) j->left_all.rows += b.rows;
+    for (size_t c = 0; c < j->left[0].cols.size(); c++) {
+      std::vector<const DCol *> parts;
+      for (const DBatch &b : j->left) {
+        if (b.cols.size() != j->left[0].cols.size()) fail(SQLRS_ERR_ARROW, "cross join: left batches of different schemas");
+        parts.push_back(&b.cols[c]);
       }
-      j->concatenated = true;
+      j->left_all.cols.push_back(concat_columns(ctx, parts));
     }
-    InBatch ib(ctx, right);
-    const int64_t L = j->left_all.rows, R = ib.rows();
-    if (L == 0) return;
-    if (L * R > 0x7fffffffll) fail(SQLRS_ERR_INTERNAL, "cross join: more than 2^31 output rows per probe batch");
-    const int64_t n = L * R;
-    DBatch o;
-    o.rows = n;
-    BufP li = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1)), ri = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
-    if (n) {
-      cross_index_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(li->as<uint32_t>(), ri->as<uint32_t>(), n, (uint32_t)R);
-      SQ_HIP(hipGetLastError());
-    }
-    for (const DCol &c : j->left_all.cols) o.cols.push_back(gather_column(ctx, c, li->p, false, nullptr, n));
-    for (int c = 0; c < ib.num_columns(); c++) o.cols.push_back(gather_column(ctx, ib.col(c), ri->p, false, nullptr, n));
-    *out = emit_batch(ctx, std::move(o), out_mem);
+    j->concatenated = true;
+  }
+  InBatch ib(ctx, right);
+  const int64_t Lall = j->left_all.rows, R = ib.rows();
+  if (left_rows < 0) {
+    left_begin = 0;
+    left_rows = Lall;
+  }
+  if (left_begin < 0 || left_begin + left_rows > Lall) fail(SQLRS_ERR_INTERNAL, "cross join: left row range outside the build side");
+  if (Lall > 0xffffffffll) fail(SQLRS_ERR_INTERNAL, "cross join: more than 2^32 left rows");
+  const int64_t L = left_rows;
+  if (L == 0) return;
+  // one library batch holds < 2^31 rows (the reference emits one batch per left row and has no such limit: callers with more
+  // take the left rows in ranges, sqlrs_cross_join_probe_push_range)
+  if (R > 0 && L > 0x7fffffffll / R) fail(SQLRS_ERR_INTERNAL, "cross join: more than 2^31 output rows in one call (use sqlrs_cross_join_probe_push_range)");
+  const int64_t n = L * R;
+  DBatch o;
+  o.rows = n;
+  BufP li = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1)), ri = ctx->alloc(4 * (size_t)std::max<int64_t>(n, 1));
+  if (n) {
+    cross_index_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(li->as<uint32_t>(), ri->as<uint32_t>(), n, (uint32_t)R,
+                                                                                      (uint32_t)left_begin);
+    SQ_HIP(hipGetLastError());
+  }
+  for (const DCol &c : j->left_all.cols) o.cols.push_back(gather_column(ctx, c, li->p, false, nullptr, n));
+  for (int c = 0; c < ib.num_columns(); c++) o.cols.push_back(gather_column(ctx, ib.col(c), ri->p, false, nullptr, n));
+  *out = emit_batch(ctx, std::move(o), out_mem);
+}
+int sqlrs_cross_join_probe_push(sqlrs_cross_join_t *j, const sqlrs_batch_t *right, int out_mem, sqlrs_batch_t **out) {
+  return guard(j->ctx, [&] { cross_join_probe(j, right, 0, -1, out_mem, out); });
+}
+int sqlrs_cross_join_probe_push_range(sqlrs_cross_join_t *j, const sqlrs_batch_t *right, int64_t left_begin, int64_t left_rows, int out_mem,
+                                      sqlrs_batch_t **out) {
+  return guard(j->ctx, [&] {
+    if (left_rows < 0) fail(SQLRS_ERR_INTERNAL, "cross join: negative row count");
+    cross_join_probe(j, right, left_begin, left_rows, out_mem, out);
   });
+}
+int64_t sqlrs_cross_join_left_rows(const sqlrs_cross_join_t *j) {
+  int64_t n = 0;
+  for (const DBatch &b : j->left) n += b.rows;
+  return n;
 }
 void sqlrs_cross_join_destroy(sqlrs_cross_join_t *j) { delete j; }
 

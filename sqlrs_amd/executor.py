@@ -335,8 +335,11 @@ class ProjectExecutor:
     """``ProjectExecutor { exprs, child }`` (project.rs:6-9)."""
 
     def __init__(self, backend: abi.Backend, exprs: List[BoundExpr], child: Iterable, out_mem: int = abi.MEM_HOST,
-                 output_names: Optional[Sequence[str]] = None):
+                 output_names: Optional[Sequence[str]] = None, many: int = 0):
         self.backend, self.exprs, self.child, self.out_mem, self.output_names = backend, exprs, child, out_mem, output_names
+        # many > 1: that many batches of the child go to sqlrs_project_push_many together (the same stream of output batches,
+        # one per input batch, project.rs:15-27)
+        self.many = many
 
     def execute(self):
         be = self.backend
@@ -344,6 +347,25 @@ class ProjectExecutor:
         h = C.c_void_p()
         be.check(be.fn("project_create")(be.ctx, len(self.exprs), arr, C.byref(h)))
         try:
+            if self.many > 1 and getattr(be.lib, be.prefix + "project_push_many", None) is not None:
+                group = []
+
+                def flush():
+                    n = len(group)
+                    hb = [abi.as_batch(b) for b in group]
+                    ins = (C.POINTER(abi.Batch) * n)(*[C.pointer(b.abi) if hasattr(b, "abi") else b.ptr for b in hb])
+                    outs = (C.POINTER(abi.Batch) * n)()
+                    be.check(be.fn("project_push_many")(h, n, ins, self.out_mem, outs))
+                    res = [_emit(be, outs[i], self.out_mem, self.output_names) for i in range(n)]
+                    group.clear()
+                    return res
+                for batch in self.child:
+                    group.append(batch)
+                    if len(group) == self.many:
+                        yield from flush()
+                if group:
+                    yield from flush()
+                return
             for batch in self.child:  # project.rs:14-27
                 b = abi.as_batch(batch)
                 out = C.POINTER(abi.Batch)()
@@ -359,8 +381,10 @@ class CrossJoinExecutor:
     like the reference (cross_join.rs:39-55): the library returns the batches of one right batch as a single batch in
     the same row order, sliced back here (host output only)."""
 
-    def __init__(self, backend: abi.Backend, left_child: Iterable, right_child: Iterable, join_output_schema: pa.Schema):
+    def __init__(self, backend: abi.Backend, left_child: Iterable, right_child: Iterable, join_output_schema: pa.Schema,
+                 max_rows_per_call: int = (1 << 31) - 1):
         self.backend, self.left_child, self.right_child, self.schema = backend, left_child, right_child, join_output_schema
+        self.max_rows_per_call = max_rows_per_call
 
     def execute(self):
         be = self.backend
@@ -374,18 +398,25 @@ class CrossJoinExecutor:
                 be.check(be.fn("cross_join_build_push")(h, b.ptr))
             for batch in self.right_child:  # cross_join.rs:38-56
                 b = abi.as_batch(batch)
-                out = C.POINTER(abi.Batch)()
-                be.check(be.fn("cross_join_probe_push")(h, b.ptr, abi.MEM_HOST, C.byref(out)))
-                whole = _emit(be, out, abi.MEM_HOST, list(self.schema.names))
-                if whole is None:
-                    continue
                 r = b.abi.num_rows if hasattr(b, "abi") else b.num_rows
-                if r == 0:  # one EMPTY batch per left row (cross_join.rs:39-55 emits it all the same)
-                    for _ in range(self._left_rows):
-                        yield whole.slice(0, 0)
-                    continue
-                for i in range(whole.num_rows // r):
-                    yield whole.slice(i * r, r)
+                # a library batch holds < 2^31 rows: the left rows are taken in ranges of at most that many output rows
+                # (one range for anything but a very large product; max_rows_per_call is a test hook)
+                per_call = max(1, self.max_rows_per_call // max(r, 1))
+                for l0 in range(0, max(self._left_rows, 1), per_call):
+                    out = C.POINTER(abi.Batch)()
+                    if per_call >= self._left_rows:
+                        be.check(be.fn("cross_join_probe_push")(h, b.ptr, abi.MEM_HOST, C.byref(out)))
+                    else:
+                        be.check(be.fn("cross_join_probe_push_range")(h, b.ptr, l0, min(per_call, self._left_rows - l0), abi.MEM_HOST, C.byref(out)))
+                    whole = _emit(be, out, abi.MEM_HOST, list(self.schema.names))
+                    if whole is None:
+                        continue
+                    if r == 0:  # one EMPTY batch per left row (cross_join.rs:39-55 emits it all the same)
+                        for _ in range(self._left_rows):
+                            yield whole.slice(0, 0)
+                        break
+                    for i in range(whole.num_rows // r):
+                        yield whole.slice(i * r, r)
         finally:
             be.fn("cross_join_destroy")(h)
 

@@ -48,23 +48,26 @@ def test_bench_two_ranks_on_one_gpu(exchange, launcher, fused):
     assert x["fused_filter_partition"] == (exchange == "partition" and fused == "1")
 
 
-@pytest.mark.parametrize("fused", ["1", "0", "combine"])
-def test_bench_exchange_path_over_rccl_world_1(fused):
+@pytest.mark.parametrize("fused,impl", [("1", "abi"), ("1", "torch"), ("0", "abi"), ("combine", "abi")])
+def test_bench_exchange_path_over_rccl_world_1(fused, impl):
     """The N > 1 code path on ONE GPU over the real transport: an RCCL process group of one rank
     (`--force-exchange`), so init_process_group("nccl"), the collectives on device tensors (all_reduce,
     all_to_all_single of the dim, the list all-to-all out of the partition regions / all_to_all_single of
-    the stable partition), and the ctx-stream <-> torch-stream hand-over all run on the hardware once."""
+    the stable partition), and the ctx-stream <-> torch-stream hand-over all run on the hardware once.  impl = abi (the
+    default): the data path is exchange.hip behind the C ABI — sqlrs_exchange_all_to_all for the dim keys / partials and the
+    chunk sequence sqlrs_exchange_begin / send_chunk / finish for the fact rows — torch only launches the processes."""
     strategy = "combine" if fused == "combine" else "partition"  # (combine: the default strategy of --gpus N)
     fused = "1" if fused == "combine" else fused
     env = dict(os.environ, SQLRS_BENCH_EXCHANGE_CHUNKS="3", HSA_ENABLE_IPC_MODE_LEGACY="0", SQLRS_BENCH_EXCHANGE_FUSED=fused)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SQLRS_BENCH_SINGLE_DEVICE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-exchange", "--steps", "3", "--warmup", "1",
-           "--rows", "2e7", "--dim-rows", "1e6", "--exchange", strategy, "--no-cpu-baseline"]
+           "--rows", "2e7", "--dim-rows", "1e6", "--exchange", strategy, "--exchange-impl", impl, "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     x = line["exchange"]
+    assert x["impl"].startswith("C ABI") == (impl == "abi")
     assert line["n_gpus"] == 1 and x["ranks"]["backend"].startswith("nccl") and x["ranks"]["world"] == 1
     assert x["strategy"] == strategy and x["fused_filter_partition"] == (strategy == "partition" and fused == "1")
     assert x["alternative"].get("check") == "OK", x["alternative"]

@@ -54,13 +54,94 @@ def test_exchange_sub_range_and_empty(hip, xchg):
 
 
 def test_exchange_rejects_what_it_cannot_carry(hip, xchg):
-    nulls = pa.RecordBatch.from_arrays([pa.array([1, None, 3], type=pa.int64())], names=["k"])
+    """a Utf8 column: the rank says so in the count all-gather, the call fails (on every rank alike) and nothing is sent;
+    the communicator is usable afterwards"""
     text = pa.RecordBatch.from_arrays([pa.array(["a", "b", "c"])], names=["s"])
-    for b in (nulls, text):
+    d = hip.to_device(text)
+    with pytest.raises(abi.ExecutorError):
+        hip.exchange_all_to_all(xchg, d, [0], [3])
+    d.release()
+    ok = hip.to_device(pa.RecordBatch.from_arrays([pa.array([1, 2, 3], type=pa.int64())], names=["k"]))
+    got, recv = hip.exchange_all_to_all(xchg, ok, [0], [3])
+    assert recv == [3] and hip.to_host(got).to_arrow(["k"]).column(0).to_pylist() == [1, 2, 3]
+    got.release()
+    ok.release()
+
+
+def test_exchange_carries_validity(hip, xchg):
+    """NULLs travel (a byte per row beside the values): slices that start inside a bitmap byte, a column without NULLs next to
+    nullable ones, int32; against the same slice taken on the host"""
+    rng = np.random.default_rng(12)
+    n = 100_003
+    k = pa.array(rng.integers(0, 1000, n, dtype=np.int64), mask=rng.random(n) < 0.1)
+    v = pa.array(rng.random(n), mask=rng.random(n) < 0.3)
+    w = pa.array(rng.integers(-9, 9, n).astype(np.int32))
+    u = pa.array(rng.integers(-9, 9, n).astype(np.int32), mask=rng.random(n) < 0.5)
+    b = pa.RecordBatch.from_arrays([k, v, w, u], names=["k", "v", "w", "u"])
+    d = hip.to_device(b)
+    for start, rows in ((0, n), (13, 70_001), (n - 5, 5)):
+        got, recv = hip.exchange_all_to_all(xchg, d, [start], [rows])
+        assert recv == [rows]
+        t = hip.to_host(got).to_arrow(["k", "v", "w", "u"])
+        assert t.equals(b.slice(start, rows)), (start, rows)
+        got.release()
+    d.release()
+
+
+@pytest.mark.parametrize("capacity", [0, 10_000_000])
+def test_exchange_chunk_sequence(hip, xchg, capacity):
+    """sqlrs_exchange_begin / send_chunk / finish: chunks of different sizes (an empty one, one whose column has NULLs after
+    chunks without any, library-owned and pyarrow-built device batches) arrive as ONE batch in chunk order; the receive
+    batch grows from a small capacity hint; the payload of chunk k goes out with the count words of chunk k + 1"""
+    rng = np.random.default_rng(13)
+    hip.exchange_begin(xchg, [abi.INT64, abi.FLOAT64], capacity)
+    exp = []
+    keep = []
+    for ci, n in enumerate([50_000, 0, 300_001, 7, 120_000]):
+        mask = (rng.random(n) < 0.2) if ci >= 2 else None
+        b = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 1 << 40, n, dtype=np.int64)), pa.array(rng.random(n), mask=mask)], names=["k", "v"])
         d = hip.to_device(b)
-        with pytest.raises(abi.ExecutorError):
-            hip.exchange_all_to_all(xchg, d, [0], [3])
+        lo = min(3, n)
+        hip.exchange_send_chunk(xchg, d, [lo], [n - lo])
+        exp.append(b.slice(lo))
+        keep.append(d)
+    got = hip.exchange_finish(xchg)
+    want = pa.Table.from_batches(exp).combine_chunks()
+    t = hip.to_host(got).to_arrow(["k", "v"])
+    assert got.num_rows == want.num_rows
+    assert pa.Table.from_batches([t]).equals(want)
+    got.release()
+    for d in keep:
         d.release()
+    # a sequence is over when finish returns: the single-shot call works again, a second finish does not
+    with pytest.raises(abi.ExecutorError):
+        hip.exchange_finish(xchg)
+    d = hip.to_device(pa.RecordBatch.from_arrays([pa.array([5, 6], type=pa.int64())], names=["k"]))
+    g2, _ = hip.exchange_all_to_all(xchg, d, [0], [2])
+    assert g2.num_rows == 2
+    g2.release()
+    d.release()
+
+
+def test_exchange_chunk_sequence_error_reaches_the_next_call(hip, xchg):
+    """a chunk whose columns do not match the sequence's types raises its flag in ITS count words: the call that sends its
+    payload (the next send_chunk, or finish) fails — on every rank in the same call — and the sequence is over"""
+    hip.exchange_begin(xchg, [abi.INT64], 1000)
+    good = hip.to_device(pa.RecordBatch.from_arrays([pa.array([1, 2, 3], type=pa.int64())], names=["k"]))
+    bad = hip.to_device(pa.RecordBatch.from_arrays([pa.array([1.0, 2.0])], names=["v"]))
+    hip.exchange_send_chunk(xchg, good, [0], [3])
+    hip.exchange_send_chunk(xchg, bad, [0], [2])  # (sends the payload of `good`; its own flag is on the wire)
+    with pytest.raises(abi.ExecutorError):
+        hip.exchange_finish(xchg)
+    good.release()
+    bad.release()
+    hip.exchange_begin(xchg, [abi.INT64], 1000)  # a new sequence starts clean
+    ok = hip.to_device(pa.RecordBatch.from_arrays([pa.array([9], type=pa.int64())], names=["k"]))
+    hip.exchange_send_chunk(xchg, ok, [0], [1])
+    got = hip.exchange_finish(xchg)
+    assert hip.to_host(got).to_arrow(["k"]).column(0).to_pylist() == [9]
+    got.release()
+    ok.release()
 
 
 def test_partitioned_join_group_by_through_the_exchange(hip, oracle, xchg):

@@ -112,3 +112,23 @@ def test_hip_text_form_matches_oracle(hip, oracle):
 def test_two_column_keys_inherit_symmetric_combine(hip, oracle):
     from test_oracle_golden import symmetric_combine_case
     assert symmetric_combine_case(hip) == symmetric_combine_case(oracle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_call", [1, 7, 1000, (1 << 31) - 1])
+def test_cross_join_left_rows_in_ranges(hip, oracle, per_call):
+    """CrossJoinExecutor (cross_join.rs:8-58): one output batch per (right batch, left row).  A library batch holds < 2^31
+    rows, so a large product takes the left rows in ranges (sqlrs_cross_join_probe_push_range) — forced here with a small
+    per-call row budget; an empty right batch still yields one empty batch per left row.  Against the oracle."""
+    import numpy as np
+    import pyarrow as pa
+    from sqlrs_amd.executor import CrossJoinExecutor
+    rng = np.random.default_rng(per_call % 97)
+    lbs = [pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 99, n, dtype=np.int64)), pa.array(rng.random(n))], names=["a", "b"]) for n in (5, 0, 12)]
+    rbs = [pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 9, n, dtype=np.int64), mask=rng.random(n) < 0.2)], names=["c"]) for n in (3, 0, 40)]
+    sch = pa.schema([("l.a", pa.int64()), ("l.b", pa.float64()), ("r.c", pa.int64())])
+    exp = list(CrossJoinExecutor(oracle, lbs, rbs, sch).execute())
+    got = list(CrossJoinExecutor(hip, lbs, rbs, sch, max_rows_per_call=per_call).execute())
+    assert [b.num_rows for b in got] == [b.num_rows for b in exp] and len(got) == 17 * 3
+    for g, e in zip(got, exp):
+        assert g.equals(e)

@@ -1379,6 +1379,42 @@ def test_filter_push_many_yields_the_batches_of_push(hip, oracle, shape):
             assert g.equals(e), (many, g.num_rows)
 
 
+@pytest.mark.parametrize("shape", ["arith", "with_nulls", "compare_is_boolean", "utf8_falls_back", "constant_column"])
+def test_project_push_many_yields_the_batches_of_push(hip, oracle, shape):
+    """sqlrs_project_push_many: a group of small HOST batches projected by one launch sequence must come back as exactly the
+    batches sqlrs_project_push yields one by one — one output batch per input batch, in order (project.rs:15-27); results
+    that are not fixed-width columns (Boolean, Utf8, a constant) and Utf8 inputs fall back to batch by batch; against the
+    oracle's per-batch Project."""
+    from sqlrs_amd.executor import ProjectExecutor
+    rng = np.random.default_rng(len(shape))
+    sizes = [0, 1, 63, 64, 65, 1024, 1024, 1, 0, 4095, 4097, 1024, 7, 20_000, 0, 3]
+    batches = []
+    for n in sizes:
+        v = rng.integers(-50, 50, n, dtype=np.int64)
+        w = rng.random(n)
+        if shape == "with_nulls":
+            cols = [pa.array(v, mask=rng.random(n) < 0.2), pa.array(w, mask=rng.random(n) < 0.1)]
+        elif shape == "utf8_falls_back":
+            cols = [pa.array(v), pa.array([f"s{int(x * 100)}" for x in w], type=pa.string())]
+        else:
+            cols = [pa.array(v), pa.array(w)]
+        batches.append(pa.RecordBatch.from_arrays(cols, names=["v", "w"]))
+    if shape == "compare_is_boolean":
+        exprs = [InputRef(0) > Constant(3, abi.INT64), InputRef(1)]
+    elif shape == "utf8_falls_back":
+        exprs = [InputRef(1), InputRef(0) + Constant(1, abi.INT64)]
+    elif shape == "constant_column":
+        exprs = [Constant(7, abi.INT64), InputRef(0)]
+    else:
+        exprs = [InputRef(1), InputRef(0) * Constant(3, abi.INT64) + InputRef(0), InputRef(0)]
+    exp = list(ProjectExecutor(oracle, exprs, batches).execute())
+    for many in (5, 64):
+        got = list(ProjectExecutor(hip, exprs, batches, many=many).execute())
+        assert [b.num_rows for b in got] == [b.num_rows for b in exp]
+        for g, e in zip(got, exp):
+            assert g.equals(e), (many, g.num_rows)
+
+
 @pytest.mark.parametrize("jt", ["inner", "left", "right"])
 @pytest.mark.parametrize("build", ["unique_all_hit", "unique_some_miss", "duplicates", "with_filter"])
 def test_hash_join_probe_push_many_yields_the_batches_of_probe_push(hip, oracle, jt, build):

@@ -127,6 +127,10 @@ def test_probe_filter_chunked(hip, oracle, sparse, pred, aggs):
         pytest.skip("the threshold is meant for the dense key range")
     if aggs != "count_sum" and pred not in ("val_gt_half", "other_ne"):
         pytest.skip("aggregate lists are crossed with two predicates only")
+    # (every case costs an oracle run of 4-9 s: the hashed-bucket shape keeps the predicates that differ in HOW the filter
+    #  reaches the partition pass — on the aggregated column, on another column, not fusable — and the COUNT + SUM list)
+    if sparse and (pred not in ("val_gt_half", "other_ne", "general") or (aggs != "count_sum" and pred != "val_gt_half")):
+        pytest.skip("the sparse key shape is crossed with three predicates / one predicate per other aggregate list")
     lb, rb, sch = shared_tables(sparse)
     cond = JoinCondition([(InputRef(0), InputRef(1))])
     ex = HashJoinAggExecutor(hip, [lb], [rb], cond, sch, 2, AGGS[aggs], [InputRef(0)], probe_filter=PREDS[pred])
