@@ -1225,14 +1225,15 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
                                  "GBps": round(by / ms_all / 1e6, 1), "frac": round(by / ms_all / 1e6 / HBM_PEAK_GBPS, 4),
                                  # what bounds the probe: one random L2 lookup per row, not the HBM stream
                                  "bound": ("one random L2 lookup per probe row: key stream + lookups + pair stores are ADDITIVE on "
-                                           "the CU's vector memory path (composite microbenchmark with nothing but that memory work, "
-                                           "no compaction: 0.689 ms per 1e8 rows on a 4 MiB table = ceiling_frac; "
-                                           "profiles/r03_probe_composite.txt, r02_probe_pmc_ta.txt)" if not sparse else
+                                           "the CU's vector memory path (profiles/r02_probe_pmc_ta.txt); the lookups read a BIT-PACKED "
+                                           "table (20 bits per possible key for 1e6 build rows: 2.4 MiB, inside one XCD's 4 MiB L2 next to "
+                                           "the streams) — the composite microbenchmark with nothing but that memory work takes 0.520 ms per "
+                                           "1e8 rows on it = ceiling_frac (0.654 with 4-byte entries; profiles/r05b_ubench2.txt)" if not sparse else
                                            "general keys: blocked partitioned join on LDS tables (per-range partition -> per-bucket LDS "
                                            "probe -> per-range LDS un-permute + compaction); each of the three passes is latency- not "
                                            "bandwidth-bound (5.2 GB moved for 2.0 GB algorithmic)"),
-                                 "ceiling_frac": (round(by / 0.689 / 1e6 / HBM_PEAK_GBPS, 4) if not sparse and hit == "all_hit" else None),
-                                 "ms_probe_composite_ubench": (0.689 if not sparse and hit == "all_hit" else None)}
+                                 "ceiling_frac": (round(by / 0.520 / 1e6 / HBM_PEAK_GBPS, 4) if not sparse and hit == "all_hit" else None),
+                                 "ms_probe_composite_ubench": (0.520 if not sparse and hit == "all_hit" else None)}
         del fk
     # ---- general-key join shapes at the C3 size (review r04 #5; not BASELINE configs, no roofline claim): every build key FOUR times
     #      (hash_join.rs:172-177 insertion-order chains, :225-234 probe-major pairs — 4e8 pairs out of 1e8 probe rows), and a
@@ -1479,9 +1480,12 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
         be.fn("order_destroy")(h)
     ms = timed(run_order)
     profile_of(run_order, "Order")
-    by = 16 * n + 16 * n  # read key + carried column, write both permuted (SURVEY.md §8d minimum)
+    # 16 N (read key, write permuted key) + 8 N per carried column = 24 B/row is what `frac` is computed from; the
+    # carried column is read AND written, so the operator's streams are 32 B/row: `frac_streams_32B`, a differently named field
+    by = 16 * n + 8 * n
     res["Order_int64_1col"] = {"rows": n, "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
-                               "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+                               "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                               "bytes_per_row": 24, "frac_streams_32B": round(32 * n / ms / 1e6 / HBM_PEAK_GBPS, 4)}
     # ---- what a MISS of the optimistic key range costs (review r03 #9): one key far outside the sampled range in a chunk the
     #      sample skips; the raw pass's histogram kernel notices, the split passes behind it return at once, the exact form
     #      runs.  `ms_exact` = the same column with SQLRS_ORDER_SAMPLE=0 (read per call: key range from a full pass)
@@ -1552,7 +1556,8 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
         ms_g = timed(run_order_wide)
         os.environ.pop("SQLRS_ORDER_WIDE", None)
         res[leg] = {"rows": n, "ms": round(ms_w, 3), "Mrows_s": round(n / ms_w / 1e3, 1), "GBps": round(by / ms_w / 1e6, 1),
-                    "frac": round(by / ms_w / 1e6 / HBM_PEAK_GBPS, 4), "ms_general": round(ms_g, 3),
+                    "frac": round(by / ms_w / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_row": 24,
+                    "frac_streams_32B": round(32 * n / ms_w / 1e6 / HBM_PEAK_GBPS, 4), "ms_general": round(ms_g, 3),
                     "check": "OK" if checked[0] else "mismatch"}
         del batch
         torch.cuda.empty_cache()
@@ -1590,9 +1595,10 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     os.environ["SQLRS_ORDER_COMPOSITE"] = "0"
     ms_2g = timed(run_order2)
     os.environ.pop("SQLRS_ORDER_COMPOSITE", None)
-    by2 = 24 * n + 24 * n
+    by2 = 2 * 16 * n + 8 * n  # (§8d: 16 N per key column + 8 N per carried column = 40 B/row; the streams are 48)
     res["Order_two_int64_keys"] = {"rows": n, "ms": round(ms_2, 3), "Mrows_s": round(n / ms_2 / 1e3, 1), "GBps": round(by2 / ms_2 / 1e6, 1),
-                                   "frac": round(by2 / ms_2 / 1e6 / HBM_PEAK_GBPS, 4), "ms_general": round(ms_2g, 3),
+                                   "frac": round(by2 / ms_2 / 1e6 / HBM_PEAK_GBPS, 4), "bytes_per_row": 40,
+                                   "frac_streams_48B": round(48 * n / ms_2 / 1e6 / HBM_PEAK_GBPS, 4), "ms_general": round(ms_2g, 3),
                                    "check": "OK" if checked2[0] else "mismatch"}
     del bo2, ka
     torch.cuda.empty_cache()

@@ -308,11 +308,16 @@ __device__ unsigned long long filter_timing[8];
 #define FILTER_WAVES_N 8
 #endif
 constexpr int FILTER_WAVES = FILTER_WAVES_N; // even: two worker waves per 4096-row compaction tile
-constexpr int FILTER_CHUNKS = 32;                                // 64-row chunks per worker wave
+#ifndef FILTER_CHUNKS_N
+#define FILTER_CHUNKS_N 32
+#endif
+constexpr int FILTER_CHUNKS = FILTER_CHUNKS_N;                   // 64-row chunks per worker wave
 constexpr int FILTER_TILE_ROWS = FILTER_WAVES * FILTER_CHUNKS * 64; // 16384
 constexpr int FILTER_SUB = FILTER_TILE_ROWS / TILE_ROWS;           // 4096-row tiles per filter tile
 constexpr int FILTER_BLOCK = (FILTER_WAVES + 1) * 64;
-static_assert(FILTER_CHUNKS <= 64 && FILTER_SUB * 2 == FILTER_WAVES, "tile_off mapping assumes 2 waves per 4096 rows");
+constexpr int FILTER_WPS = TILE_ROWS / (FILTER_CHUNKS * 64);      // worker waves per 4096-row compaction tile
+static_assert(FILTER_CHUNKS <= 64 && FILTER_WPS >= 1 && FILTER_SUB * FILTER_WPS == FILTER_WAVES && (FILTER_CHUNKS & (FILTER_CHUNKS - 1)) == 0,
+              "tile_off mapping: whole worker waves per 4096-row tile");
 
 template <class T, int OP, bool HASV>
 __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_kernel(
@@ -347,8 +352,8 @@ __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_kernel(
     uint64_t agg = (uint32_t)__shfl((int)inc, 63, 64);
     uint64_t excl = lookback_wave<FILTER_LB_LOADS>(desc, tile, agg, timeout);
     // kept rows before each 4096-row tile = before waves 0, 2, 4, 6
-    if (lane < FILTER_WAVES && (lane & 1) == 0 && tile_off) {
-      int64_t t4 = tile * FILTER_SUB + (lane >> 1);
+    if (lane < FILTER_WAVES && (lane % FILTER_WPS) == 0 && tile_off) {
+      int64_t t4 = tile * FILTER_SUB + (lane / FILTER_WPS);
       if (t4 * TILE_ROWS < rows) tile_off[t4] = excl + (inc - c);
     }
     if (lane == 0) {
@@ -484,8 +489,8 @@ __global__ __launch_bounds__(FILTER_BLOCK) void filter_cmp_const_persistent_kern
       uint32_t inc = wave_iscan_u32(c);
       uint64_t agg = (uint32_t)__shfl((int)inc, 63, 64);
       uint64_t excl = lookback_wave<FILTER_LB_LOADS>(desc, tile, agg, timeout);
-      if (lane < FILTER_WAVES && (lane & 1) == 0 && tile_off) {
-        int64_t t4 = tile * FILTER_SUB + (lane >> 1);
+      if (lane < FILTER_WAVES && (lane % FILTER_WPS) == 0 && tile_off) {
+        int64_t t4 = tile * FILTER_SUB + (lane / FILTER_WPS);
         if (t4 * TILE_ROWS < rows) tile_off[t4] = excl + (inc - c);
       }
       if (lane == 0) {
@@ -549,8 +554,9 @@ static void launch_filter(Ctx *ctx, int op, const DCol &c, T k, int64_t rows, T 
       if (!occ) {                                                                                                \
         SQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, filter_cmp_const_persistent_kernel<T, OP, HV>, \
                                                             FILTER_BLOCK, 0));                                   \
-        occ = std::max(1, std::min({occ, 2, simd_safe_blocks((const void *)filter_cmp_const_persistent_kernel<T, OP, HV>, \
-                                                              FILTER_BLOCK)}));                                  \
+        const char *fo_e = std::getenv("SQLRS_FILTER_OCC"); /* tuning hook: most resident workgroups per CU */   \
+        occ = std::max(1, std::min({occ, fo_e ? std::max(1, std::atoi(fo_e)) : 2,                                \
+                                    simd_safe_blocks((const void *)filter_cmp_const_persistent_kernel<T, OP, HV>, FILTER_BLOCK)})); \
       }                                                                                                          \
       unsigned g = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->num_cus * occ);                              \
       filter_cmp_const_persistent_kernel<T, OP, HV><<<dim3(g), dim3(FILTER_BLOCK), 0, ctx->stream>>>(            \
