@@ -28,7 +28,19 @@
 
 namespace sq {
 
-constexpr int PART_WG = 512;
+#ifndef PART_WG_N
+#define PART_WG_N 512
+#endif
+constexpr int PART_WG = PART_WG_N;
+// The direct-addressed bucket passes (lds_agg_dense_kernel, lds_agg_dense_slim_kernel) run 1024-thread workgroups: their table
+// fills the CU's LDS, so ONE workgroup is resident, and at 512 threads that is two waves per SIMD — too few to overlap a wave's
+// load wait with another's LDS atomics.  Sixteen waves on the same table (60-81 VGPRs, no spill): C5 bucket pass 1.64 -> 1.42-1.48 ms,
+// sorted fact rows 2.81 -> 2.38, C4 0.447 -> 0.432 (profiles/r05n_bucket_wg_ab.txt, r05o: one process, three builds).  The probing
+// kernel (two 72 KiB tables per CU already) got SLOWER at 1024 (sparse-key C5: 2.52 -> 2.81 ms) and keeps 512.
+#ifndef DENSE_WG_N
+#define DENSE_WG_N 1024
+#endif
+constexpr int DENSE_WG = DENSE_WG_N;
 #ifndef HOT_MIN_PEERS_N
 #define HOT_MIN_PEERS_N 8
 #endif
@@ -232,14 +244,14 @@ template <int NV> struct AggRows {
 };
 
 // every lane loads (rows past `hi` re-read row hi-1), so all loads of a trip issue back to back
-template <int NV, bool FLAGS, bool PACK>
+template <int NV, bool FLAGS, bool PACK, int WG = PART_WG>
 __device__ __forceinline__ void lds_agg_load(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pi,
                                              const uint64_t *__restrict__ pv0, const uint64_t *__restrict__ pv1,
                                              const uint8_t *__restrict__ pf, int64_t i0, int64_t hi,
                                              AggRows<NV> &r) {
 #pragma unroll
   for (int u = 0; u < LDS_U; u++) {
-    int64_t i = min(i0 + (int64_t)u * PART_WG, hi - 1);
+    int64_t i = min(i0 + (int64_t)u * WG, hi - 1);
     r.k[u] = __builtin_nontemporal_load(pk + i);
     if (!PACK) r.id[u] = pi ? __builtin_nontemporal_load(pi + i) : (uint32_t)i; // no id column: rows in place
     if (NV >= 1) r.v0[u] = __builtin_nontemporal_load(pv0 + i);
@@ -249,11 +261,11 @@ __device__ __forceinline__ void lds_agg_load(const uint64_t *__restrict__ pk, co
 }
 
 // the same from {key|row word, value 0} records (radix_part.hpp PartitionedRows::rec): one 16-byte load per row
-template <int NV>
+template <int NV, int WG = PART_WG>
 __device__ __forceinline__ void lds_agg_load_rec(const uint64_t *__restrict__ prec, int64_t i0, int64_t hi, AggRows<NV> &r) {
 #pragma unroll
   for (int u = 0; u < LDS_U; u++) {
-    int64_t i = min(i0 + (int64_t)u * PART_WG, hi - 1);
+    int64_t i = min(i0 + (int64_t)u * WG, hi - 1);
     const u64x2 t = __builtin_nontemporal_load((const u64x2 *)prec + i);
     r.k[u] = t.x;
     r.v0[0 + (NV >= 1 ? u : 0)] = t.y;
@@ -650,7 +662,7 @@ __global__ void split_emit_dense_kernel(SplitTables stb, const uint32_t *__restr
 }
 
 template <int NV, bool JOIN, int NACC, int C0, int C1, bool REC = false>
-__global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
+__global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_kernel(
     LdsAggParams prm, const uint64_t *__restrict__ pk, const uint64_t *__restrict__ pv0,
     const uint32_t *__restrict__ work, unsigned long long *out_count, uint64_t *__restrict__ gkey,
     uint32_t *__restrict__ gfirst, uint64_t *__restrict__ gacc, int64_t gcap, KeyPack kp, SplitTables stb) {
@@ -668,10 +680,10 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
   unsigned int *tfirst = (unsigned int *)(tacc + (size_t)n_acc * R);
   AggRows<NV> cur, nxt;
   if (lo < hi) {
-    if (REC) lds_agg_load_rec<NV>(pk, lo + threadIdx.x, hi, cur);
-    else lds_agg_load<NV, false, true>(pk, nullptr, pv0, nullptr, nullptr, lo + threadIdx.x, hi, cur);
+    if (REC) lds_agg_load_rec<NV, DENSE_WG>(pk, lo + threadIdx.x, hi, cur);
+    else lds_agg_load<NV, false, true, DENSE_WG>(pk, nullptr, pv0, nullptr, nullptr, lo + threadIdx.x, hi, cur);
   }
-  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+  for (uint32_t s = threadIdx.x; s < R; s += DENSE_WG) {
     tfirst[s] = 0xffffffffu;
 #pragma unroll
     for (int a = 0; a < PART_MAX_ACC; a++) {
@@ -682,16 +694,16 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
-  for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {
+  for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * DENSE_WG) {
     const int64_t i0 = base + threadIdx.x;
-    if (REC) lds_agg_load_rec<NV>(pk, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
-    else lds_agg_load<NV, false, true>(pk, nullptr, pv0, nullptr, nullptr, i0 + (int64_t)LDS_U * PART_WG, hi, nxt);
+    if (REC) lds_agg_load_rec<NV, DENSE_WG>(pk, i0 + (int64_t)LDS_U * DENSE_WG, hi, nxt);
+    else lds_agg_load<NV, false, true, DENSE_WG>(pk, nullptr, pv0, nullptr, nullptr, i0 + (int64_t)LDS_U * DENSE_WG, hi, nxt);
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
       const uint64_t off = packed_off(kp, cur.k[u]);
       const uint32_t id = packed_row(kp, cur.k[u]);
       const uint32_t s = (uint32_t)off & mask;
-      bool act = i0 + (int64_t)u * PART_WG < hi;
+      bool act = i0 + (int64_t)u * DENSE_WG < hi;
       // outside the range of the keys of interest: a probe row without partner (fused join), or a sentinel row of a
       // claimed partition (radix_part.hip; every real row of a plain aggregation lies inside the range)
       act = act && off <= kp.range;
@@ -753,7 +765,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
   __syncthreads();
   if (JOIN && (prm.partner_bits || prm.partner_mult)) { // build keys with gaps: a slot whose key has no build partner is not a group
     const uint64_t off0 = (uint64_t)b << kp.rbits; // (a multiple of 64 or R < 64: rbits >= 8)
-    for (uint32_t s = threadIdx.x; s < R; s += PART_WG) { // (the slots this thread stores / counts below)
+    for (uint32_t s = threadIdx.x; s < R; s += DENSE_WG) { // (the slots this thread stores / counts below)
       if (tfirst[s] == 0xffffffffu) continue;
       const uint64_t o = off0 + s;
       const bool partner = prm.partner_mult ? prm.partner_mult[o] != 0 : (((prm.partner_bits[o >> 6] >> (o & 63)) & 1ull) != 0);
@@ -762,7 +774,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
   }
   if (split != 0xffffffffu) { // chunk of a split bucket: its table goes out as chunk table `split` (split_emit_dense_kernel reduces)
     unsigned int *gf = stb.first + (size_t)split * R;
-    for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+    for (uint32_t s = threadIdx.x; s < R; s += DENSE_WG) {
       gf[s] = tfirst[s];
 #pragma unroll
       for (int a = 0; a < PART_MAX_ACC; a++) {
@@ -773,14 +785,14 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_kernel(
     return;
   }
   unsigned int mine = 0;
-  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) mine += tfirst[s] != 0xffffffffu;
+  for (uint32_t s = threadIdx.x; s < R; s += DENSE_WG) mine += tfirst[s] != 0xffffffffu;
   unsigned int my_off = atomicAdd(&s_cnt, mine);
   __syncthreads();
   if (threadIdx.x == 0) s_base = atomicAdd(out_count, (unsigned long long)s_cnt);
   __syncthreads();
   unsigned long long base = s_base + my_off;
   const uint64_t key0 = kp.kmin + ((uint64_t)b << kp.rbits);
-  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+  for (uint32_t s = threadIdx.x; s < R; s += DENSE_WG) {
     unsigned int first = tfirst[s];
     if (first == 0xffffffffu) continue;
     if ((int64_t)base < gcap) {
@@ -824,14 +836,14 @@ struct SlimAggRows {
 };
 
 template <bool JOIN, int NACC, int C0, int C1, bool BLK = false>
-__global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
+__global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
     LdsAggParams prm, SlimBucketIn in, const uint32_t *__restrict__ work, unsigned long long *out_count,
     uint64_t *__restrict__ gkey, uint32_t *__restrict__ gfirst, uint64_t *__restrict__ gacc, int64_t gcap, KeyPack kp,
     SplitTables stb) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
   __shared__ unsigned int s_cnt, s_before, s_inside;
   __shared__ unsigned long long s_base;
-  __shared__ uint32_t s_wsum[PART_WG / 64];
+  __shared__ uint32_t s_wsum[DENSE_WG / 64];
   const uint32_t b = work[4 * blockIdx.x];
   const int64_t lo = work[4 * blockIdx.x + 1];
   const int64_t hi = work[4 * blockIdx.x + 2];
@@ -849,7 +861,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   const uint64_t le_mask = (2ull << lane_id()) - 1ull;
   const uint32_t rbits = kp.rbits, lmask = (1u << 13) - 1u;
 
-  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+  for (uint32_t s = threadIdx.x; s < R; s += DENSE_WG) {
     tfirst[s] = 0xffffffffu;
 #pragma unroll
     for (int a = 0; a < PART_MAX_ACC; a++) {
@@ -857,7 +869,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
       tacc[(size_t)a * R + s] = acc_identity_cell(code_of(a) & 7);
     }
   }
-  for (uint32_t g = threadIdx.x; g < ngroups; g += PART_WG) gmask[g] = 0;
+  for (uint32_t g = threadIdx.x; g < ngroups; g += DENSE_WG) gmask[g] = 0;
   if (threadIdx.x == 0) {
     s_cnt = 0;
     s_before = 0;
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   __syncthreads();
   if (!BLK) { // runs of the bucket: how many start at or before lo, one bit for every start inside (lo, hi)
     uint32_t before = 0, inside = 0;
-    for (uint32_t k = threadIdx.x; k < nruns; k += PART_WG) {
+    for (uint32_t k = threadIdx.x; k < nruns; k += DENSE_WG) {
       const int64_t st = in.nzstart[col + k];
       if (st <= lo) before++;
       else if (st < hi) {
@@ -892,11 +904,11 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   const bool seg_mode = NACC == 2 && ((C0 == AK_COUNT && C1 == AK_SUM_F64) || (C0 == AK_SUM_F64 && C1 == AK_COUNT)) &&
                         hi - lo >= 4096 && (int64_t)k_count * 2048 <= hi - lo && !prm.seg_off && !BLK; // (runs of >= 2048 rows on average; random rows: ~130)
   if (bt_lds)
-    for (uint32_t k = threadIdx.x; k < k_count; k += PART_WG) gbt[k] = in.nzbt[col + min(k_first + k, nruns - 1)];
+    for (uint32_t k = threadIdx.x; k < k_count; k += DENSE_WG) gbt[k] = in.nzbt[col + min(k_first + k, nruns - 1)];
   if (!BLK) { // gpre[g] = (runs starting at or before lo) - 1 + bits of the groups before g
     constexpr uint32_t GPT = 8; // groups per thread per round
     uint32_t carry = s_before - 1u; // (the bucket's first run starts at its first row <= lo: s_before >= 1)
-    for (uint32_t g0 = 0; g0 < ngroups; g0 += PART_WG * GPT) {
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += DENSE_WG * GPT) {
       const uint32_t gb = g0 + threadIdx.x * GPT;
       uint32_t pc[GPT], sum = 0;
 #pragma unroll
@@ -908,7 +920,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
       if (lane_id() == 63) s_wsum[wave_id()] = inc;
       __syncthreads();
       uint32_t wbase = 0, tot = 0;
-      for (int w = 0; w < PART_WG / 64; w++) {
+      for (int w = 0; w < DENSE_WG / 64; w++) {
         if (w < wave_id()) wbase += s_wsum[w];
         tot += s_wsum[w];
       }
@@ -922,11 +934,11 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
       __syncthreads();
     }
   }
-  // rows [i0, i0 + LDS_U * PART_WG) step PART_WG of this thread: value, word, and the base tile of their run
+  // rows [i0, i0 + LDS_U * DENSE_WG) step DENSE_WG of this thread: value, word, and the base tile of their run
   auto load = [&](int64_t i0, SlimAggRows &r) {
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
-      const int64_t i = min(i0 + (int64_t)u * PART_WG, hi - 1);
+      const int64_t i = min(i0 + (int64_t)u * DENSE_WG, hi - 1);
       slim_load_nt(in.rows, i, r.w[u], r.v[u]);
       if (BLK) { // (a wave's 64 consecutive slots lie in one or two blocks: one or two cache lines per load)
         r.bt[u] = in.blk_bt[i >> in.log_b];
@@ -944,9 +956,9 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   SlimAggRows cur, nxt;
   if (lo < hi) load(lo + threadIdx.x, cur);
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
-  for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * PART_WG) {
+  for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * DENSE_WG) {
     const int64_t i0 = base + threadIdx.x;
-    load(i0 + (int64_t)LDS_U * PART_WG, nxt);
+    load(i0 + (int64_t)LDS_U * DENSE_WG, nxt);
     // LDS operations complete in order: a read behind an atomic waits for it.  So the trip's reads (the slots' current
     // first rows) are all issued BEFORE its atomics — a stale (larger) first row only costs a redundant atomicMin —
     // and the hot-key test takes the first active lane's slot with v_readlane, not with a ds_bpermute shuffle.
@@ -962,7 +974,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
       const int lane = (int)lane_id();
 #pragma unroll
       for (int u = 0; u < LDS_U; u++) {
-        const bool act = i0 + (int64_t)u * PART_WG < hi;
+        const bool act = i0 + (int64_t)u * DENSE_WG < hi;
         const uint32_t key = act ? sl[u] : (0x80000000u | (uint32_t)lane); // (rows past the end: runs of their own, never added)
         const uint32_t prevk = (uint32_t)__shfl_up((int)key, 1, 64);
         const uint64_t bm = __ballot(lane == 0 || key != prevk);            // bit = a run starts at this lane
@@ -998,7 +1010,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
       const uint32_t s = sl[u];
-      bool act = i0 + (int64_t)u * PART_WG < hi;
+      bool act = i0 + (int64_t)u * DENSE_WG < hi;
       if (BLK) act = act && cur.w[u] != 0xffffffffu; // sentinel rows of the claimed level
 #ifdef SLIM_DBG
       const uint64_t actm = (SLIM_DBG & 1) ? 0ull : __ballot(act); // timing experiments only (results invalid)
@@ -1067,7 +1079,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   __syncthreads();
   if (JOIN && (prm.partner_bits || prm.partner_mult)) { // build keys with gaps: a slot whose key has no build partner is not a group
     const uint64_t off0 = (uint64_t)b << kp.rbits;
-    for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+    for (uint32_t s = threadIdx.x; s < R; s += DENSE_WG) {
       if (tfirst[s] == 0xffffffffu) continue;
       const uint64_t o = off0 + s;
       const bool partner = prm.partner_mult ? prm.partner_mult[o] != 0 : (((prm.partner_bits[o >> 6] >> (o & 63)) & 1ull) != 0);
@@ -1076,7 +1088,7 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
   }
   if (split != 0xffffffffu) { // chunk of a split bucket: its table goes out as chunk table `split` (split_emit_dense_kernel reduces)
     unsigned int *gf = stb.first + (size_t)split * R;
-    for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+    for (uint32_t s = threadIdx.x; s < R; s += DENSE_WG) {
       gf[s] = tfirst[s];
 #pragma unroll
       for (int a = 0; a < PART_MAX_ACC; a++) {
@@ -1087,14 +1099,14 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_dense_slim_kernel(
     return;
   }
   unsigned int mine = 0;
-  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) mine += tfirst[s] != 0xffffffffu;
+  for (uint32_t s = threadIdx.x; s < R; s += DENSE_WG) mine += tfirst[s] != 0xffffffffu;
   unsigned int my_off = atomicAdd(&s_cnt, mine);
   __syncthreads();
   if (threadIdx.x == 0) s_base = atomicAdd(out_count, (unsigned long long)s_cnt);
   __syncthreads();
   unsigned long long obase = s_base + my_off;
   const uint64_t key0 = kp.kmin + ((uint64_t)b << kp.rbits);
-  for (uint32_t s = threadIdx.x; s < R; s += PART_WG) {
+  for (uint32_t s = threadIdx.x; s < R; s += DENSE_WG) {
     unsigned int first = tfirst[s];
     if (first == 0xffffffffu) continue;
     if ((int64_t)obase < gcap) {
@@ -1558,7 +1570,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     auto kfn = lds_agg_dense_slim_kernel<JN, NA, C0, C1>;                                                       \
     if (blk) kfn = lds_agg_dense_slim_kernel<JN, NA, C0, C1, true>;                                             \
     allow_big_lds(ctx, kfn, 159 * 1024);                                                                                 \
-    kfn<<<dim3(nwork), dim3(PART_WG), slds, ctx->stream>>>(prm, sb, dwork->as<uint32_t>(), ctr->as<unsigned long long>(), \
+    kfn<<<dim3(nwork), dim3(DENSE_WG), slds, ctx->stream>>>(prm, sb, dwork->as<uint32_t>(), ctr->as<unsigned long long>(), \
                                                            out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(), \
                                                            out->gacc->as<uint64_t>(), gcap, pr.pack, stb);        \
     launched = true;                                                                                           \
@@ -1584,7 +1596,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     auto kfn = lds_agg_dense_kernel<NV, JN, NA, C0, C1>;                                                        \
     if (NV == 1 && pr.rec) kfn = lds_agg_dense_kernel<NV, JN, NA, C0, C1, NV == 1>;                            \
     allow_big_lds(ctx, kfn);                                                                                   \
-    kfn<<<dim3(nwork), dim3(PART_WG), lds, ctx->stream>>>(                                                     \
+    kfn<<<dim3(nwork), dim3(DENSE_WG), lds, ctx->stream>>>(                                                    \
         prm, pr.rec ? pr.rec->as<uint64_t>() : pk->as<uint64_t>(), pv0 ? pv0->as<uint64_t>() : nullptr, dwork->as<uint32_t>(), \
         ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(),                 \
         out->gacc->as<uint64_t>(), gcap, pr.pack, stb);                                                        \

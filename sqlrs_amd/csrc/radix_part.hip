@@ -1921,6 +1921,8 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       const int mode = level == 1 ? (flags ? RP_L1_NULL : RP_L1) : (flags ? RP_LN_FLAG : RP_LN);
       if (slim) {
         const size_t slds = (size_t)RP_TILE * 13 + 1024 + (size_t)WG * 16 + 512 + 128;
+        // (1024-thread workgroups over the same 8192-row tile, eight rows per thread — sixteen waves per CU as in the bucket pass —
+        //  were measured in round 5: 128 VGPRs, 17 spilled, level 2 3.00 -> 3.21 ms in one process; not kept)
         if (ROWS == 16) {
           auto kfn = rp_scatter_slim_kernel<512, 16>;
           allow_big_lds(ctx, kfn);

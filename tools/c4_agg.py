@@ -10,7 +10,7 @@ import bench, sqlrs_amd
 from sqlrs_amd import abi, datagen
 from sqlrs_amd.expr import AggFunc, Constant, InputRef
 dev = torch.device("cuda", 0)
-be = sqlrs_amd.new_ctx(0)
+be = abi.Backend(os.environ["LIB"], "sqlrs_", 0) if os.environ.get("LIB") else sqlrs_amd.new_ctx(0)
 n, G = int(float(os.environ.get("N", 2e8))), int(float(os.environ.get("G", 1e6)))
 shape = os.environ.get("SHAPE", "uniform")
 key = datagen.fill_chunks(torch.empty(n, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xA1, i, G))
@@ -51,5 +51,5 @@ for rnd in range(int(os.environ.get("ROUNDS", 2))):
             ms = C.c_double(); be.check(be.fn("timer_elapsed_ms")(t, C.byref(ms))); best = min(best, ms.value)
         be.profile(True); run(); pr = be.profile_read(); be.profile(False)
         cls = ", ".join(f"{k} {x[0]:.3f}" for k, x in sorted(pr.items(), key=lambda kv: -kv[1][0]) if x[0] > 0.01)
-        print(f"C4 {shape} {var}={v}: {best:.3f} ms  {groups[0]} groups  frac {(16 * n + 24 * groups[0]) / best / 1e6 / 8000:.4f} | {cls}", flush=True)
+        print(f"C4 {os.path.basename(os.environ.get('LIB', 'default'))} {shape} {var}={v}: {best:.3f} ms  {groups[0]} groups  frac {(16 * n + 24 * groups[0]) / best / 1e6 / 8000:.4f} | {cls}", flush=True)
 be.fn("timer_destroy")(t)
