@@ -282,7 +282,7 @@ __global__ __launch_bounds__(RP_WG, (RP_ROWS <= 6 || (PACK && RP_ROWS <= 8 && NV
     uint32_t p = j * RP_WG + threadIdx.x;
     const uint64_t kw = skey[p];
     const uint32_t d = PACK ? rp_digit(rp_bucket(kp, packed_key(kp, kw), true, P), level, p2_bits) : sdig[p];
-    int64_t g = gbase[d & (RP_WG - 1)] + p;
+    int64_t g = gbase[min(d, (uint32_t)(RP_WG - 1))] + p;
     if (p >= len) g = sink + threadIdx.x;
     if (REC) {
       u64x2 rec;
@@ -532,7 +532,8 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_kernel(
   auto store_row = [&](int j, uint32_t len) { // position p of the staged tile -> its chunk
     const uint32_t p = j * RP_WG + threadIdx.x;
     const uint64_t kw = skey[p];
-    const uint32_t d = (PACK ? rp_digit(rp_bucket(kp, packed_key(kp, kw), true, P), 1, p2_bits) : (uint32_t)sdig[p]) & (RP_WG - 1);
+    // (clamped, not masked: RP_WG = 768 is no power of two; the clamp only keeps the garbage digit of a position past the staged rows inside the arrays)
+    const uint32_t d = min(PACK ? rp_digit(rp_bucket(kp, packed_key(kp, kw), true, P), 1, p2_bits) : (uint32_t)sdig[p], (uint32_t)(RP_WG - 1));
     int64_t g = (p < split[d] ? gb0[d] : gb1[d]) + p;
     if (p >= len) g = sink + (int64_t)blockIdx.x * RP_WG + threadIdx.x; // lanes past the staged rows (boundary slot): this workgroup's sink rows
     RP_ST(&out.key[g], kw);
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
   };
   auto store_row = [&](int j, uint32_t len) {
     const uint32_t p = j * RP_WG + threadIdx.x;
-    const uint32_t d = (uint32_t)sdig[p] & (RP_WG - 1);
+    const uint32_t d = min((uint32_t)sdig[p], (uint32_t)(RP_WG - 1)); // (clamped, not masked: RP_WG = 768 is no power of two)
     int64_t g = (p < split[d] ? gb0[d] : gb1[d]) + p;
     if (p >= len) g = sink + (int64_t)blockIdx.x * RP_WG + threadIdx.x;
     slim_store(out.rows, g, sw[p], sv0[p]);
@@ -1295,7 +1296,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_claim_scatter_kernel(
   auto store_row = [&](int j, uint32_t len) { // position p of the staged tile -> its block
     const uint32_t p = j * RP_WG + threadIdx.x;
     const uint64_t kw = skey[p];
-    const uint32_t d = rp_bucket(kp, packed_key(kp, kw), true, P) & (RP_WG - 1);
+    const uint32_t d = min(rp_bucket(kp, packed_key(kp, kw), true, P), (uint32_t)(RP_WG - 1));
     int64_t g = (p < split[d] ? gb0[d] : gb1[d]) + p;
     if (p >= len || g < 0) g = sink + (int64_t)blockIdx.x * RP_WG + threadIdx.x; // past the staged rows / overflowed region: sink rows
     if (REC) {
@@ -1519,7 +1520,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_claim_scatter_slim_kernel(
   };
   auto store_row = [&](int j, uint32_t len) { // position p of the staged tile -> its block
     const uint32_t p = j * RP_WG + threadIdx.x;
-    const uint32_t d = (uint32_t)sdig[p] & (RP_WG - 1);
+    const uint32_t d = min((uint32_t)sdig[p], (uint32_t)(RP_WG - 1)); // (clamped, not masked: RP_WG = 768 is no power of two)
     int64_t g = (p < split[d] ? gb0[d] : gb1[d]) + p;
     if (p >= len || g < 0) g = sink + (int64_t)blockIdx.x * RP_WG + threadIdx.x; // past the staged rows / overflowed region: sink rows
     slim_store(out.rows, g, sw[p], sv0[p]);
@@ -1832,8 +1833,10 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // level 2 3.66 -> 3.61 ms); smaller batches keep 6144-row tiles (less arena slack, more tiles per workgroup)
   // (two-level partitions only — the counting single level is slower with them, C4: 1.55 -> 1.96 ms — and not with the
   //  predicate on a column of its own: that instantiation needs more than 256 VGPRs and spills)
-  const bool big16 = pack && nv == 1 && (rows_env == 16 || (rows_env == 0 && n >= (1ll << 28) && P_wanted > 512 &&
-                                                          (!in.filter.col || (const void *)in.filter.col == in.vals[0])));
+  // Round 5: the slim first level runs 768-thread workgroups over 6144-row tiles by default (twelve waves per CU instead of
+  // eight, 159 VGPRs, no spill: C5 level 1 5.33 (8192-row tiles, 512 threads) / 5.39 (6144, 512) -> 4.95 ms in one process,
+  // step 10.45 -> 10.10; 1024 threads x 6 rows: the same 4.98 with 3 spilled registers).  8192-row tiles only on request.
+  const bool big16 = pack && nv == 1 && rows_env == 16;
   const int ROWS = nv > 1 ? 8 : (rows_env == 6 ? 6 : ((rows_env == 8 && pack) ? 8 : (big16 ? 16 : 12)));
   const int RP_TILE = WG * ROWS;
   const size_t lds = (size_t)RP_TILE * (pack ? 8 * (1 + nv) : 8 * (1 + nv) + 4 + 2 + 1) + (size_t)WG * (4 + 4 + 8);
@@ -1928,6 +1931,11 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
           allow_big_lds(ctx, kfn);
           kfn<<<g, b, slds, ctx->stream>>>(slim->in, slim->out, tp, p2_bits, digits, offs_tm->as<uint32_t>(), nt, tpw, sink,
                                           slim->kshift, slim->rbits);
+        } else if (std::getenv("SQLRS_RP_L2_WG") && std::atoi(std::getenv("SQLRS_RP_L2_WG")) == 768) { // A/B hook, read per call
+          auto kfn = rp_scatter_slim_kernel<768, 8>;
+          allow_big_lds(ctx, kfn);
+          kfn<<<g, dim3(768), slds + 256 * 16, ctx->stream>>>(slim->in, slim->out, tp, p2_bits, digits, offs_tm->as<uint32_t>(), nt, tpw, sink,
+                                                            slim->kshift, slim->rbits);
         } else {
           auto kfn = rp_scatter_slim_kernel<512, 12>;
           allow_big_lds(ctx, kfn);
@@ -2019,7 +2027,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     while (B < 256 && (uint64_t)(2 * B) * 16 * wgs * P <= (uint64_t)n) B *= 2;
     const uint32_t slack = 4096 + wgs * B;
     const uint64_t slots_max = (uint64_t)n + (uint64_t)n / 8 + (uint64_t)P * ((uint64_t)slack + B) + 64;
-    const uint64_t pool_rows = slots_max + (uint64_t)WG * wgs; // + one sink per workgroup
+    const uint64_t pool_rows = slots_max + (uint64_t)1024 * wgs; // + one sink per workgroup (of up to 1024 threads)
     if (pool_rows <= 0xffffffffull) {
       BufP est = ctx->alloc_zero(4 * ((size_t)P + 1));
       // region start | region end | cursor | {kept rows (u64), overflow flag (u64)}: one buffer, one fetch
@@ -2110,11 +2118,22 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
           const char *sd_e = std::getenv("SQLRS_RP_SLIM_DELTA"); // test hook, read per call: blocks abandoned after fewer tiles
           so.max_delta = sd_e ? (uint32_t)std::max(1, std::min(std::atoi(sd_e), 127)) : 127u;
           const size_t slds = (size_t)RP_TILE * (8 + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8 + 4);
+          // 768-thread workgroups (twelve waves on the same 6144-row tile, 159 VGPRs, no spill) by default: C4 scatter 1.49 -> 1.43 ms,
+          // with the WHERE fused 1.31 -> 1.14 (one process, three rounds); SQLRS_RP_CLAIM_WG=512 (read per call) = the eight-wave form
+          const char *cwg_e = std::getenv("SQLRS_RP_CLAIM_WG");
+          const bool wg768 = psrc != 3 && !(cwg_e && std::atoi(cwg_e) == 512); // (own predicate column: 4 spilled registers at 768)
+          const size_t slds768 = (size_t)RP_TILE * (8 + 4 + 2) + (size_t)768 * (4 + 4 + 8 + 8 + 4);
 #define SQ_CS(PS)                                                                                                   \
   do {                                                                                                              \
-    auto kfn = rp_claim_scatter_slim_kernel<512, 12, PS>;                                                           \
-    allow_big_lds(ctx, kfn);                                                                                        \
-    kfn<<<dim3(wgs), dim3(512), slds, ctx->stream>>>(k, a0, in.filter, n, so, P, tiles1c, tpw, sink, kp);           \
+    if (wg768) {                                                                                                    \
+      auto kfn = rp_claim_scatter_slim_kernel<768, 8, PS>;                                                          \
+      allow_big_lds(ctx, kfn);                                                                                      \
+      kfn<<<dim3(wgs), dim3(768), slds768, ctx->stream>>>(k, a0, in.filter, n, so, P, tiles1c, tpw, sink, kp);      \
+    } else {                                                                                                        \
+      auto kfn = rp_claim_scatter_slim_kernel<512, 12, PS>;                                                         \
+      allow_big_lds(ctx, kfn);                                                                                      \
+      kfn<<<dim3(wgs), dim3(512), slds, ctx->stream>>>(k, a0, in.filter, n, so, P, tiles1c, tpw, sink, kp);         \
+    }                                                                                                               \
   } while (0)
           if (psrc < 0) SQ_CS(-1);
           else if (psrc == 1) SQ_CS(1);
@@ -2191,7 +2210,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       chunked = false;
     }
     if (chunked && slim_on) {
-      const size_t pool_rows = (size_t)max_chunks * (CAP + RP_CHUNK_SKEW) + (size_t)WG * cwgs; // + one sink per workgroup
+      const size_t pool_rows = (size_t)max_chunks * (CAP + RP_CHUNK_SKEW) + (size_t)1024 * cwgs; // + one sink per workgroup (of up to 1024 threads)
       const uint32_t digits2 = 1u << p2_bits;
       auto slim_alloc = [&](size_t rows, BufP &b0, BufP &b1) {
         SlimRowsView v;
@@ -2239,7 +2258,31 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
                                                       tiles1, ctpw, sink, kp);                                      \
   } while (0)
 #define SQ_SL(R) do { if (psrc < 0) SQ_SL1(R, -1); else if (psrc == 1) SQ_SL1(R, 1); else SQ_SL1(R, 3); } while (0)
-        if (ROWS == 16) SQ_SL(16); else SQ_SL(12);
+        const char *l1wg_e = std::getenv("SQLRS_RP_L1_WG"); // A/B hook, read per call: 512 = the eight-wave form, 1024 x 6 rows
+        const int l1wg = l1wg_e ? std::atoi(l1wg_e) : 768;
+        if (ROWS == 12 && psrc != 3 && l1wg == 1024) {
+          const size_t clds1k = (size_t)RP_TILE * 14 + (size_t)1024 * (4 + 4 + 8 + 8 + 4 + 4) + (size_t)P * 4;
+          if (psrc < 0) {
+            auto kfn = rp_chunk_scatter_slim_kernel<1024, 6, -1>;
+            allow_big_lds(ctx, kfn);
+            kfn<<<dim3(cwgs), dim3(1024), clds1k, ctx->stream>>>(in.keys, (const uint64_t *)in.vals[0], in.filter, n, so, P, p2_bits, d1, tiles1, ctpw, sink, kp);
+          } else {
+            auto kfn = rp_chunk_scatter_slim_kernel<1024, 6, 1>;
+            allow_big_lds(ctx, kfn);
+            kfn<<<dim3(cwgs), dim3(1024), clds1k, ctx->stream>>>(in.keys, (const uint64_t *)in.vals[0], in.filter, n, so, P, p2_bits, d1, tiles1, ctpw, sink, kp);
+          }
+        } else if (ROWS == 12 && psrc != 3 && l1wg == 768) {
+          const size_t clds768 = (size_t)RP_TILE * 14 + (size_t)768 * (4 + 4 + 8 + 8 + 4 + 4) + (size_t)P * 4;
+          if (psrc < 0) {
+            auto kfn = rp_chunk_scatter_slim_kernel<768, 8, -1>;
+            allow_big_lds(ctx, kfn);
+            kfn<<<dim3(cwgs), dim3(768), clds768, ctx->stream>>>(in.keys, (const uint64_t *)in.vals[0], in.filter, n, so, P, p2_bits, d1, tiles1, ctpw, sink, kp);
+          } else {
+            auto kfn = rp_chunk_scatter_slim_kernel<768, 8, 1>;
+            allow_big_lds(ctx, kfn);
+            kfn<<<dim3(cwgs), dim3(768), clds768, ctx->stream>>>(in.keys, (const uint64_t *)in.vals[0], in.filter, n, so, P, p2_bits, d1, tiles1, ctpw, sink, kp);
+          }
+        } else if (ROWS == 16) SQ_SL(16); else SQ_SL(12);
 #undef SQ_SL
 #undef SQ_SL1
         SQ_HIP(hipGetLastError());
@@ -2277,7 +2320,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         out->bstart = nullptr;
         return true;
       }
-      const size_t np = (size_t)kept + WG; // + the sink rows
+      const size_t np = (size_t)kept + 1024; // + the sink rows (workgroups of up to 1024 threads)
       PartitionedRows::Slim &sl = out->slim;
       sl = PartitionedRows::Slim();
       sl.rows = slim_alloc(np, sl.buf0, sl.buf1);
@@ -2316,7 +2359,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       return true;
     }
     if (chunked) {
-      const size_t pool_rows = (size_t)max_chunks * (CAP + RP_CHUNK_SKEW) + (size_t)WG * cwgs; // + one sink per workgroup
+      const size_t pool_rows = (size_t)max_chunks * (CAP + RP_CHUNK_SKEW) + (size_t)1024 * cwgs; // + one sink per workgroup (of up to 1024 threads)
       BufP ck = staggered(8 * pool_rows, 0), c0 = nv >= 1 ? staggered(8 * pool_rows, 1) : nullptr,
            c1 = nv >= 2 ? staggered(8 * pool_rows, 2) : nullptr, ci = pack ? nullptr : staggered(4 * pool_rows, 3);
       BufP clen = ctx->alloc_zero(4 * (size_t)max_chunks);
@@ -2364,6 +2407,17 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         else if (ROWS == 16) SQ_CS(1, 16, true);
         else if (ROWS != 12) { chunked = false; } // tuning shapes (SQLRS_RP_ROWS) keep the counting first level
         else if (nv == 0) { if (pack) SQ_CS(0, 12, true); else SQ_CS(0, 12, false); }
+        else if (!pack && std::getenv("SQLRS_RP_L1G_WG") && std::atoi(std::getenv("SQLRS_RP_L1G_WG")) == 768) { // A/B hook, read per call
+          const size_t clds768 = (size_t)RP_TILE * (8 * (1 + nv) + 4 + 2) + (size_t)768 * (4 + 4 + 8 + 8) + (clds - ((size_t)RP_TILE * (8 * (1 + nv) + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8)));
+#define SQ_CG(PS)                                                                                                   \
+  do {                                                                                                              \
+    auto kfn = rp_chunk_scatter_kernel<1, 768, 8, false, PS>;                                                       \
+    allow_big_lds(ctx, kfn);                                                                                        \
+    kfn<<<dim3(cwgs), dim3(768), clds768, ctx->stream>>>(k, a0, a1, in.filter, n, co, P, p2_bits, d1, tiles1, ctpw, sink, kp); \
+  } while (0)
+          if (psrc < 0) SQ_CG(-1); else if (psrc == 1) SQ_CG(1); else SQ_CG(3);
+#undef SQ_CG
+        }
         else { if (pack) SQ_CS(1, 12, true); else SQ_CS(1, 12, false); }
 #undef SQ_CS
 #undef SQ_CS1

@@ -318,7 +318,7 @@ def _claimed_case(hip, oracle, k, v, expect_claimed, aggs=None):
         assert counted == (not expect_claimed), prof  # an overflowed region: the counting level redoes the batch
 
 
-@pytest.mark.parametrize("shape", ["uniform", "zipf", "few_rows_per_bucket", "one_hot_bucket"])
+@pytest.mark.parametrize("shape", ["uniform", "zipf", "few_rows_per_bucket", "one_hot_bucket", "more_than_256_buckets"])
 def test_hash_agg_claimed_single_level(hip, oracle, shape, monkeypatch):
     """One-level range partitions without a histogram pass (rp_claim_scatter_kernel): bucket regions sized from a
     sample, blocks claimed with one atomic per (workgroup, digit, block), sentinel rows in what is left of a block.
@@ -331,6 +331,9 @@ def test_hash_agg_claimed_single_level(hip, oracle, shape, monkeypatch):
     elif shape == "zipf":
         k = (np.minimum(rng.zipf(1.2, n), G) - 1).astype(np.int64)
         k = (k * 7919 + 13) % G
+    elif shape == "more_than_256_buckets":  # 1.5e6 keys = 367 buckets of 4096 slots: digits beyond 255 (768-thread workgroups: no power-of-two masks)
+        n, G = 3_000_000, 1_500_000
+        k = rng.integers(0, G, n, dtype=np.int64)
     elif shape == "few_rows_per_bucket":
         n, G = 2_200_000, 2_000_000  # 489 buckets, ~17 rows per (workgroup, bucket): 16-row blocks
         k = rng.integers(0, G, n, dtype=np.int64)
