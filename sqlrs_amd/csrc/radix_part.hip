@@ -1854,7 +1854,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     BufP k, v0, v1, idx, fl, rec;
   };
   auto alloc_cols = [&](int64_t rows, bool final_level, Cols &c, RpOut &ro) {
-    const size_t np = (size_t)rows + WG; // + the sink rows of rp_scatter_kernel
+    const size_t np = (size_t)rows + 1024; // + the sink rows of rp_scatter_kernel (workgroups of up to 1024 threads)
     c = Cols();
     if (final_level && use_rec) {
       c.rec = ctx->alloc(16 * np);
@@ -1967,6 +1967,12 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       else if (ROWS == 6) { if (nv == 0) SQ_RP(0, 6); else SQ_RP(1, 6); }
       else if (ROWS == 8) { if (nv == 0) SQ_RP(0, 8); else SQ_RP(1, 8); }
       else if (ROWS == 16) { if (pack && mode == RP_LN) SQ_RP1(1, 16, RP_LN, true); else SQ_RP1(1, 16, RP_L1, true); }
+      else if (nv == 1 && !pack && mode == RP_LN && std::getenv("SQLRS_RP_LN_WG") && std::atoi(std::getenv("SQLRS_RP_LN_WG")) == 768) { // A/B hook
+        auto kfn = rp_scatter_kernel<1, 768, 8, RP_LN, false>;
+        allow_big_lds(ctx, kfn);
+        const size_t lds768 = (size_t)RP_TILE * (8 * (1 + nv) + 4 + 2 + 1) + (size_t)768 * (4 + 4 + 8);
+        kfn<<<g, dim3(768), lds768, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs_tm->as<uint32_t>(), nt, tpw, sink, kp);
+      }
       else { if (nv == 0) SQ_RP(0, 12); else SQ_RP(1, 12); }
 #undef SQ_RP1
 #undef SQ_RP
@@ -2407,7 +2413,9 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         else if (ROWS == 16) SQ_CS(1, 16, true);
         else if (ROWS != 12) { chunked = false; } // tuning shapes (SQLRS_RP_ROWS) keep the counting first level
         else if (nv == 0) { if (pack) SQ_CS(0, 12, true); else SQ_CS(0, 12, false); }
-        else if (!pack && std::getenv("SQLRS_RP_L1G_WG") && std::atoi(std::getenv("SQLRS_RP_L1G_WG")) == 768) { // A/B hook, read per call
+        // (768 threads x 8 rows for the unpacked rows of hashed partitions too: sparse-key C5 level 1 6.91 -> 6.81 ms in one process;
+        //  SQLRS_RP_L1G_WG=512, read per call, = the eight-wave form; a predicate on a column of its own keeps it: 14 spilled registers)
+        else if (!pack && psrc != 3 && !(std::getenv("SQLRS_RP_L1G_WG") && std::atoi(std::getenv("SQLRS_RP_L1G_WG")) == 512)) {
           const size_t clds768 = (size_t)RP_TILE * (8 * (1 + nv) + 4 + 2) + (size_t)768 * (4 + 4 + 8 + 8) + (clds - ((size_t)RP_TILE * (8 * (1 + nv) + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8)));
 #define SQ_CG(PS)                                                                                                   \
   do {                                                                                                              \

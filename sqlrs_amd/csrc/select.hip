@@ -280,7 +280,7 @@ template <int OP, class K> __device__ __forceinline__ bool cmp_op(K a, K b) {
   return a != b;
 }
 
-// One block = FILTER_WAVES worker waves + 1 scan wave per FILTER tile of 16384 rows (four of the
+// One block = FILTER_WAVES worker waves + 1 scan wave per FILTER tile of FILTER_WAVES x 2048 rows (whole multiples of the
 // 4096-row tiles that `tile_off` and the other compaction kernels use).  Worker wave w owns 32
 // chunks of 64 rows, so each ballot IS one word of the selection mask; all 32 loads of a wave are
 // issued up front (16 KiB per wave in flight).  Ranks come from popcounts, the tile's global
@@ -304,8 +304,12 @@ __device__ unsigned long long filter_timing[8];
 #ifndef FILTER_LB_LOADS
 #define FILTER_LB_LOADS 1
 #endif
+// Round 5: TEN worker waves + the scan wave (20480-row tiles).  The int64 / f64 kernel holds two tiles in 163 VGPRs, i.e. three
+// waves fit a SIMD and twelve a CU, and one persistent workgroup is resident per CU: with 8 + 1 waves a quarter of the CU's wave
+// slots stood empty.  One box, same process order: s = 0.5 0.349 -> 0.312 ms, s = 0.01 0.270 -> 0.246 (6 workers: 0.353 / 0.305;
+// smaller tiles at higher occupancy were all slower: profiles/r05m_filter_block_shapes.txt, r05s_filter_waves.txt).
 #ifndef FILTER_WAVES_N
-#define FILTER_WAVES_N 8
+#define FILTER_WAVES_N 10
 #endif
 constexpr int FILTER_WAVES = FILTER_WAVES_N; // even: two worker waves per 4096-row compaction tile
 #ifndef FILTER_CHUNKS_N
