@@ -642,6 +642,7 @@ struct SlimChunkOut {
   uint32_t *hist;       // [chunk][next level's digits]
   uint32_t kshift;      // rbits + p2_bits: bits of the key offset inside a level-1 digit
   uint32_t max_delta;   // a chunk holds runs of tiles base .. base + max_delta (< SLIM_RUNS; smaller only as a test hook)
+  uint32_t conc_eighths; // a tile with >= this many eighths of its row slots in ONE digit makes the next tile try the one-lane rank (9 = never)
 };
 
 // rows of the tile being ranked / staged: the key as its 32-bit offset in the dense range, ~0 = the row does not take
@@ -715,10 +716,43 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
   //  rows 7.75 -> 7.17 ms, random keys 5.65 -> 6.00 ms; tried only while it keeps succeeding — one test per tile on random
   //  keys — it was SLOWER on both, 5.45 -> 5.90 and 7.67 -> 8.07: the kernel sits at 256 VGPRs and the extra live values
   //  cost more than the atomics.  Not adopted; the headline's random keys decide.)
+  // Round 5: the one-lane rank again, GATED like level 2's — tried only in a tile that follows a CONCENTRATED tile (one digit holds
+  // >= 3/8 of the tile's row slots: ordered / clustered fact rows; random keys never take the test; SlimChunkOut::conc_eighths) — now that the 768-thread form
+  // has the registers for it.  A wave whose kept rows all fall into ONE bucket is ranked by its first lane: one add on the digit's
+  // counter, one on the bucket's chunk histogram (rows below the chunk's room / rows that spill, both halves in one add).
+  __shared__ uint32_t s_conc;
+  uint32_t conc_digit = 0xffffffffu; // (workgroup-uniform) the digit the previous tile was concentrated on, or none
   auto rank_row = [&](int j) {
     dr[j] = 0xffffffffu;
-    if (cur.off[j] != 0xffffffffu) {
-      const uint32_t bkt = cur.off[j] >> kp.rbits;
+    const bool in = cur.off[j] != 0xffffffffu;
+    const uint32_t bkt = cur.off[j] >> kp.rbits;
+    if (conc_digit != 0xffffffffu) {
+      const uint64_t m = __ballot(in && (bkt >> p2_bits) == conc_digit); // (a hot key is the first row of ITS digit far more often than of the wave)
+      if (m) {
+        const int first = __builtin_ctzll(m);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bkt, first);
+        const bool peer = in && bkt == b0; // the first kept lane's bucket: ranked by that lane; the other lanes (a hot key next to a few others) rank themselves
+        const uint64_t same = __ballot(peer);
+        if (__popcll(same) >= 8) {
+          const uint32_t d0 = b0 >> p2_bits, cntm = (uint32_t)__popcll(same);
+          uint32_t base = 0;
+          if ((int)lane_id() == first) base = atomicAdd(&cnt[d0], cntm);
+          base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+          const uint32_t room = room_s[d0];
+          const uint32_t nlo = room > base ? min(room - base, cntm) : 0u; // ranks base .. base + cntm - 1: those below the room
+          if ((int)lane_id() == first) atomicAdd(&h2[b0], nlo + ((cntm - nlo) << 16));
+          if (peer) dr[j] = (d0 << 16) | (base + (uint32_t)mbcnt(same));
+          if (in && !peer) {
+            const uint32_t d = bkt >> p2_bits;
+            const uint32_t r = atomicAdd(&cnt[d], 1u);
+            atomicAdd(&h2[bkt], r < room_s[d] ? 1u : 0x10000u);
+            dr[j] = (d << 16) | r;
+          }
+          return;
+        }
+      }
+    }
+    if (in) {
       const uint32_t d = bkt >> p2_bits;
       const uint32_t r = atomicAdd(&cnt[d], 1u);
       atomicAdd(&h2[bkt], r < room_s[d] ? 1u : 0x10000u);
@@ -741,9 +775,11 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
   };
   auto scan_and_stage = [&]() {
     const uint32_t c = cnt[threadIdx.x];
+    if (c * 8u >= (uint32_t)RP_TILE * out.conc_eighths) s_conc = threadIdx.x + 1; // (this digit holds >= conc_eighths / 8 of the tile's row slots: the hint for the next tile)
     const uint32_t inc = wave_iscan_u32(c);
     if (lane_id() == 63) s_wsum[wave_id()] = inc;
     __syncthreads();
+    conc_digit = s_conc - 1u; // (0 - 1 = none)
     uint32_t wbase = 0, tot = 0;
     for (int w = 0; w < RP_WG / 64; w++) {
       if (w < wave_id()) wbase += s_wsum[w];
@@ -818,6 +854,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     take_rows(len, t0, true);
     cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_conc = 0;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) rank_row(j);
@@ -835,6 +872,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
       const uint32_t nlen = tile_len(tnext);
       rp_chunk_load<1, RP_WG, RP_ROWS, PSRC>(key, v0, nullptr, flt.col, tile_start(tnext), nlen, nxt);
       cnt[threadIdx.x] = 0;
+      if (threadIdx.x == 0) s_conc = 0; // (its last reader passed the barriers inside scan_and_stage)
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < RP_ROWS; j++) {
@@ -940,11 +978,14 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_scatter_slim_kernel(SlimIn in, Sl
       if (m) {
         const int first = __builtin_ctzll(m);
         const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
-        if (__ballot(in && d == d0) == m) {
+        const bool peer = in && d == d0; // (round 5: the first lane's digit by one lane, the few other lanes — a hot key's neighbours — by themselves)
+        const uint64_t same = __ballot(peer);
+        if (__popcll(same) >= 8) {
           uint32_t base = 0;
-          if ((int)lane_id() == first) base = atomicAdd(&cnt[d0], (uint32_t)__popcll(m));
+          if ((int)lane_id() == first) base = atomicAdd(&cnt[d0], (uint32_t)__popcll(same));
           base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-          if (in) dr[j] = (d0 << 16) | (base + (uint32_t)mbcnt(m));
+          if (peer) dr[j] = (d0 << 16) | (base + (uint32_t)mbcnt(same));
+          else if (in) dr[j] = (d << 16) | atomicAdd(&cnt[d], 1u);
           return;
         }
       }
@@ -1967,12 +2008,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       else if (ROWS == 6) { if (nv == 0) SQ_RP(0, 6); else SQ_RP(1, 6); }
       else if (ROWS == 8) { if (nv == 0) SQ_RP(0, 8); else SQ_RP(1, 8); }
       else if (ROWS == 16) { if (pack && mode == RP_LN) SQ_RP1(1, 16, RP_LN, true); else SQ_RP1(1, 16, RP_L1, true); }
-      else if (nv == 1 && !pack && mode == RP_LN && std::getenv("SQLRS_RP_LN_WG") && std::atoi(std::getenv("SQLRS_RP_LN_WG")) == 768) { // A/B hook
-        auto kfn = rp_scatter_kernel<1, 768, 8, RP_LN, false>;
-        allow_big_lds(ctx, kfn);
-        const size_t lds768 = (size_t)RP_TILE * (8 * (1 + nv) + 4 + 2 + 1) + (size_t)768 * (4 + 4 + 8);
-        kfn<<<g, dim3(768), lds768, ctx->stream>>>(rin, rout, tp, P, p2_bits, level, digits, offs_tm->as<uint32_t>(), nt, tpw, sink, kp);
-      }
+      // (768 threads x 8 rows for the counting level 2 of hashed partitions: measured in round 5, 6.08 vs 6.08 ms — not kept)
       else { if (nv == 0) SQ_RP(0, 12); else SQ_RP(1, 12); }
 #undef SQ_RP1
 #undef SQ_RP
@@ -2251,6 +2287,10 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       so.hist = chist->as<uint32_t>();
       so.kshift = kp.rbits + p2_bits;
       so.max_delta = slim_delta;
+      {
+        const char *cc_e = std::getenv("SQLRS_RP_CONC"); // tuning / test hook, read per call: 1 .. 8 eighths of a tile's row slots, 9 = never
+        so.conc_eighths = cc_e ? (uint32_t)std::max(1, std::min(std::atoi(cc_e), 9)) : 3u;
+      }
       const int psrc = !in.filter.col ? -1 : ((const void *)in.filter.col == in.vals[0] ? 1 : 3);
       const size_t clds = (size_t)RP_TILE * 14 + (size_t)WG * (4 + 4 + 8 + 8 + 4 + 4) + (size_t)P * 4;
       {

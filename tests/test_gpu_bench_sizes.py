@@ -244,14 +244,17 @@ def test_full_size_c5_pipeline(env):
     env.be.fn("ctx_pool_trim")(env.be.ctx)
 
 
-@pytest.mark.parametrize("shape", ["sorted_keys", "sorted_keys_mixed_magnitudes", "sorted_keys_per_run_adds_off", "sorted_keys_nearly", "hot_digit", "skewed",
+@pytest.mark.parametrize("shape", ["sorted_keys", "sorted_keys_mixed_magnitudes", "sorted_keys_per_run_adds_off", "sorted_keys_nearly",
+                                   "sorted_keys_one_lane_rank_off", "hot_digit", "hot_digit_one_lane_rank_eager", "skewed",
                                    "every_row_passes", "few_rows_pass", "keys_beyond_the_dim"])
 def test_slim_records_at_scale(env, shape, monkeypatch):
-    """The slim-record route (radix_part.hip) with the 8192-row tiles it takes from 2^28 rows on, on inputs that bend its
+    """The slim-record route (radix_part.hip; 768-thread workgroups over 6144-row tiles) at 2^28 rows, on inputs that bend its
     bookkeeping: sorted keys (a tile is ONE digit: chunks fill and spill every tile, every other digit's chunk is closed
     early over and over), one hot digit (most rows in 1/23 of the key range: split bucket work items, long chunk lists),
     skewed keys (hot slots, split buckets), a predicate that keeps everything / almost nothing (full staging area / runs of a row or two),
-    and probe keys far beyond the build range (dropped by level 1).  Every group against torch (COUNT bit-exact,
+    and probe keys far beyond the build range (dropped by level 1).  `*_one_lane_rank_*` (SQLRS_RP_CONC, read per call): level 1's
+    gated one-lane rank never / already behind a tile with an eighth of its row slots in one digit (mixed waves: the first lane's
+    bucket by one lane, the other lanes by themselves).  Every group against torch (COUNT bit-exact,
     SUM 1e-9), groups in first-seen order, and the route really is the slim one."""
     t, abi, d = env.torch, env.abi, env.datagen
     n_fact, n_dim = (1 << 28) + 12_345, 3_000_000
@@ -266,6 +269,8 @@ def test_slim_records_at_scale(env, shape, monkeypatch):
             fv = t.where(fk % 2 == 0, fv * 1e12 + 1.0, fv * 1e-6 + 0.6e-6)   # (> thr = 0.5e-6 ... see below)
         if shape == "sorted_keys_per_run_adds_off":
             monkeypatch.setenv("SQLRS_AGG_SEG", "0")
+        if shape == "sorted_keys_one_lane_rank_off":
+            monkeypatch.setenv("SQLRS_RP_CONC", "9")
         if shape == "sorted_keys_nearly":
             # 1 % of the rows swapped with a row up to 300 positions on: a neighbouring key's first row now lies INSIDE this
             # key's first rows, and the partition levels rank a tile's rows of one digit in LDS-atomic order (two waves
@@ -277,7 +282,9 @@ def test_slim_records_at_scale(env, shape, monkeypatch):
             fk[p_] = b_
             fk[q_] = a_
             del p_, q_, a_, b_
-    elif shape == "hot_digit":
+    elif shape.startswith("hot_digit"):
+        if shape == "hot_digit_one_lane_rank_eager":
+            monkeypatch.setenv("SQLRS_RP_CONC", "1")
         hot = (fv * 7919.0).frac() < 0.9  # (a second stream of pseudo-random bits: independent of the predicate on fv > 0.5)
         fk = t.where(hot, 1_000_000 + fk % 100_000, fk)
     elif shape == "skewed":
