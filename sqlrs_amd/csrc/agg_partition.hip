@@ -623,24 +623,53 @@ __global__ __launch_bounds__(PART_WG) void lds_agg_kernel(
 // at 24 G/s): splitting was affordable for a few skewed buckets only, and a batch of Zipf keys — ~245 unequal buckets
 // on 256 CUs, one work item each — ran at the pace of its slowest bucket (C4: bucket pass 1.58 ms against 0.63 for
 // uniform keys).  With stores a chunk costs 80 KB of traffic, so EVERY bucket can be cut into several work items.
-__global__ void split_emit_dense_kernel(SplitTables stb, const uint32_t *__restrict__ split_bucket,
-                                        const uint32_t *__restrict__ chunk_lo, uint32_t nbuckets_split, uint32_t R,
-                                        KeyPack kp, LdsAggParams prm, int n_acc, unsigned long long *out_count,
-                                        uint64_t *__restrict__ gkey, uint32_t *__restrict__ gfirst,
-                                        uint64_t *__restrict__ gacc, int64_t gcap) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= (int64_t)nbuckets_split * R) return;
-  const uint32_t s = (uint32_t)(i % R), t = (uint32_t)(i / R);
+// (round 5: 16 slots x 16 CHUNK GROUPS per workgroup.  One thread per slot walking all chunk tables of its bucket was a chain
+//  of dependent loads as long as the bucket has chunks — a bucket that is one hot key has ~1500: 1.3 ms for 4096 threads on 16
+//  CUs, half of what `c5_variants.adversarial.hot_key` cost over the headline)
+constexpr int SED_SLOTS = 16, SED_GROUPS = 16;
+__global__ __launch_bounds__(SED_SLOTS * SED_GROUPS) void split_emit_dense_kernel(
+    SplitTables stb, const uint32_t *__restrict__ split_bucket, const uint32_t *__restrict__ chunk_lo, uint32_t nbuckets_split,
+    uint32_t R, KeyPack kp, LdsAggParams prm, int n_acc, unsigned long long *out_count, uint64_t *__restrict__ gkey,
+    uint32_t *__restrict__ gfirst, uint64_t *__restrict__ gacc, int64_t gcap) {
+  __shared__ unsigned int s_first[SED_GROUPS][SED_SLOTS];
+  __shared__ unsigned long long s_acc[PART_MAX_ACC][SED_GROUPS][SED_SLOTS];
+  const uint32_t tiles_per_bucket = (R + SED_SLOTS - 1) / SED_SLOTS;
+  const uint32_t t = blockIdx.x / tiles_per_bucket, sl = threadIdx.x % SED_SLOTS, cg = threadIdx.x / SED_SLOTS;
+  const uint32_t s = (blockIdx.x % tiles_per_bucket) * SED_SLOTS + sl;
+  if (t >= nbuckets_split) return;
   const int64_t total = (int64_t)stb.nsplit * R;
   unsigned int first = 0xffffffffu;
   unsigned long long acc[PART_MAX_ACC];
   for (int a = 0; a < n_acc; a++) acc[a] = acc_identity_cell(prm.code[a] & 7);
-  for (uint32_t c = chunk_lo[t]; c < chunk_lo[t + 1]; c++) {
-    const unsigned int f = stb.first[(size_t)c * R + s];
-    if (f == 0xffffffffu) continue; // (a slot no row of this chunk touched holds identities)
+  if (s < R) {
+    const uint32_t c1 = chunk_lo[t + 1];
+    for (uint32_t c = chunk_lo[t] + cg; c < c1; c += SED_GROUPS) {
+      const unsigned int f = stb.first[(size_t)c * R + s];
+      if (f == 0xffffffffu) continue; // (a slot no row of this chunk touched holds identities)
+      first = min(first, f);
+      for (int a = 0; a < n_acc; a++) {
+        const unsigned long long v = stb.acc[(size_t)a * total + (size_t)c * R + s];
+        switch (prm.code[a] & 7) {
+        case AK_COUNT:
+        case AK_SUM_I64: acc[a] += v; break;
+        case AK_SUM_F64: acc[a] = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)acc[a]) + __longlong_as_double((long long)v)); break;
+        case AK_MIN_I64:
+        case AK_MIN_F64: acc[a] = min(acc[a], v); break;
+        default: acc[a] = max(acc[a], v);
+        }
+      }
+    }
+  }
+  s_first[cg][sl] = first;
+  for (int a = 0; a < n_acc; a++) s_acc[a][cg][sl] = acc[a];
+  __syncthreads();
+  if (cg != 0 || s >= R) return;
+  for (int g = 1; g < SED_GROUPS; g++) { // (chunk groups in order: the sums add up in one fixed order per slot)
+    const unsigned int f = s_first[g][sl];
+    if (f == 0xffffffffu) continue;
     first = min(first, f);
     for (int a = 0; a < n_acc; a++) {
-      const unsigned long long v = stb.acc[(size_t)a * total + (size_t)c * R + s];
+      const unsigned long long v = s_acc[a][g][sl];
       switch (prm.code[a] & 7) {
       case AK_COUNT:
       case AK_SUM_I64: acc[a] += v; break;
@@ -693,6 +722,56 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_kernel(
   }
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
+  // Hot-slot CARRY (round 5): the wave-level reductions of the hot-key path used to reach the table with three LDS atomics per row
+  // slot — and when a bucket is ONE hot key (30 % of the fact rows on a key: 1.5e8 rows in one bucket, cut into ~1500 chunks) all
+  // sixteen waves queue on the same three addresses: the atomics of one address are serial in the LDS unit, ~90 cycles per 64 rows.
+  // The wave keeps (slot, first row, accumulators) of its current hot slot in registers (wave-uniform values) across row slots and
+  // adds them to the table when the slot changes and once at the end.
+  uint32_t hc_slot = 0xffffffffu, hc_min = 0xffffffffu;
+  uint64_t hc_acc[PART_MAX_ACC];
+  auto hot_flush = [&]() {
+    if (hc_slot == 0xffffffffu) return;
+    if (lane_id() == 0) {
+      atomicMin(&tfirst[hc_slot], hc_min);
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        unsigned long long *cell = tacc + (size_t)a * R + hc_slot;
+        switch (code_of(a) & 7) {
+        case AK_COUNT:
+        case AK_SUM_I64: atomicAdd(cell, (unsigned long long)hc_acc[a]); break;
+        case AK_SUM_F64: unsafeAtomicAdd((double *)cell, __longlong_as_double((long long)hc_acc[a])); break;
+        case AK_MIN_I64:
+        case AK_MIN_F64: atomicMin(cell, (unsigned long long)hc_acc[a]); break;
+        default: atomicMax(cell, (unsigned long long)hc_acc[a]);
+        }
+      }
+    }
+    hc_slot = 0xffffffffu;
+  };
+  auto hot_take = [&](uint32_t s0, uint32_t idmin) { // the carry now belongs to slot s0
+    if (hc_slot != s0) {
+      hot_flush();
+      hc_slot = s0;
+      hc_min = 0xffffffffu;
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        hc_acc[a] = acc_identity_cell(code_of(a) & 7);
+      }
+    }
+    hc_min = idmin < hc_min ? idmin : hc_min;
+  };
+  auto hot_add = [&](int a, int kind, uint64_t red) {
+    switch (kind) {
+    case AK_COUNT:
+    case AK_SUM_I64: hc_acc[a] += red; break;
+    case AK_SUM_F64: hc_acc[a] = (uint64_t)__double_as_longlong(__longlong_as_double((long long)hc_acc[a]) + __longlong_as_double((long long)red)); break;
+    case AK_MIN_I64:
+    case AK_MIN_F64: hc_acc[a] = red < hc_acc[a] ? red : hc_acc[a]; break;
+    default: hc_acc[a] = red > hc_acc[a] ? red : hc_acc[a];
+    }
+  };
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
   for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * DENSE_WG) {
     const int64_t i0 = base + threadIdx.x;
@@ -718,13 +797,12 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_kernel(
         const uint64_t peers = __ballot(hot);
         if (__popcll(peers) >= HOT_MIN_PEERS) {
           const uint32_t idmin = wave_min_u32_dpp(hot ? id : 0xffffffffu);
-          if (lane_id() == first) atomicMin(&tfirst[s0], idmin);
+          hot_take(s0, idmin);
 #pragma unroll
           for (int a = 0; a < PART_MAX_ACC; a++) {
             if (a >= n_acc) break;
             const int kind = code_of(a) & 7;
             const uint64_t v = NV >= 1 ? cur.v0[u] : 0ull;
-            unsigned long long *cell = tacc + (size_t)a * R + s0;
             uint64_t red;
             switch (kind) {
             case AK_COUNT: red = (uint64_t)__popcll(peers); break;
@@ -735,16 +813,7 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_kernel(
             case AK_MAX_I64: red = wave_max_u64(hot ? i64_to_ordered((int64_t)v) : 0ull); break;
             default: red = wave_max_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : 0ull);
             }
-            if (lane_id() == first) {
-              switch (kind) {
-              case AK_COUNT:
-              case AK_SUM_I64: atomicAdd(cell, (unsigned long long)red); break;
-              case AK_SUM_F64: unsafeAtomicAdd((double *)cell, __longlong_as_double((long long)red)); break;
-              case AK_MIN_I64:
-              case AK_MIN_F64: atomicMin(cell, (unsigned long long)red); break;
-              default: atomicMax(cell, (unsigned long long)red);
-              }
-            }
+            hot_add(a, kind, red);
           }
           act = act && !hot;
         }
@@ -762,6 +831,7 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_kernel(
     }
     cur = nxt;
   }
+  hot_flush();
   __syncthreads();
   if (JOIN && (prm.partner_bits || prm.partner_mult)) { // build keys with gaps: a slot whose key has no build partner is not a group
     const uint64_t off0 = (uint64_t)b << kp.rbits; // (a multiple of 64 or R < 64: rbits >= 8)
@@ -953,6 +1023,56 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
 #endif
     }
   };
+  // Hot-slot CARRY (round 5): the wave-level reductions of the hot-key path used to reach the table with three LDS atomics per row
+  // slot — and when a bucket is ONE hot key (30 % of the fact rows on a key: 1.5e8 rows in one bucket, cut into ~1500 chunks) all
+  // sixteen waves queue on the same three addresses: the atomics of one address are serial in the LDS unit, ~90 cycles per 64 rows.
+  // The wave keeps (slot, first row, accumulators) of its current hot slot in registers (wave-uniform values) across row slots and
+  // adds them to the table when the slot changes and once at the end.
+  uint32_t hc_slot = 0xffffffffu, hc_min = 0xffffffffu;
+  uint64_t hc_acc[PART_MAX_ACC];
+  auto hot_flush = [&]() {
+    if (hc_slot == 0xffffffffu) return;
+    if (lane_id() == 0) {
+      atomicMin(&tfirst[hc_slot], hc_min);
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        unsigned long long *cell = tacc + (size_t)a * R + hc_slot;
+        switch (code_of(a) & 7) {
+        case AK_COUNT:
+        case AK_SUM_I64: atomicAdd(cell, (unsigned long long)hc_acc[a]); break;
+        case AK_SUM_F64: unsafeAtomicAdd((double *)cell, __longlong_as_double((long long)hc_acc[a])); break;
+        case AK_MIN_I64:
+        case AK_MIN_F64: atomicMin(cell, (unsigned long long)hc_acc[a]); break;
+        default: atomicMax(cell, (unsigned long long)hc_acc[a]);
+        }
+      }
+    }
+    hc_slot = 0xffffffffu;
+  };
+  auto hot_take = [&](uint32_t s0, uint32_t idmin) { // the carry now belongs to slot s0
+    if (hc_slot != s0) {
+      hot_flush();
+      hc_slot = s0;
+      hc_min = 0xffffffffu;
+#pragma unroll
+      for (int a = 0; a < PART_MAX_ACC; a++) {
+        if (a >= n_acc) break;
+        hc_acc[a] = acc_identity_cell(code_of(a) & 7);
+      }
+    }
+    hc_min = idmin < hc_min ? idmin : hc_min;
+  };
+  auto hot_add = [&](int a, int kind, uint64_t red) {
+    switch (kind) {
+    case AK_COUNT:
+    case AK_SUM_I64: hc_acc[a] += red; break;
+    case AK_SUM_F64: hc_acc[a] = (uint64_t)__double_as_longlong(__longlong_as_double((long long)hc_acc[a]) + __longlong_as_double((long long)red)); break;
+    case AK_MIN_I64:
+    case AK_MIN_F64: hc_acc[a] = red < hc_acc[a] ? red : hc_acc[a]; break;
+    default: hc_acc[a] = red > hc_acc[a] ? red : hc_acc[a];
+    }
+  };
   SlimAggRows cur, nxt;
   if (lo < hi) load(lo + threadIdx.x, cur);
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
@@ -975,6 +1095,15 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
 #pragma unroll
       for (int u = 0; u < LDS_U; u++) {
         const bool act = i0 + (int64_t)u * DENSE_WG < hi;
+        { // the whole wave is ONE run (a hot key's bucket; long runs of ordered rows): a plain wave reduction into the hot-slot carry
+          const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl[u]);
+          if (__ballot(act && sl[u] == s0) == ~0ull) {
+            hot_take(s0, wave_min_u32_dpp(id[u]));
+            hot_add(C0 == AK_COUNT ? 0 : 1, AK_COUNT, 64ull);
+            hot_add(C0 == AK_COUNT ? 1 : 0, AK_SUM_F64, (uint64_t)__double_as_longlong(wave_sum_f64_dpp(__longlong_as_double((long long)cur.v[u]))));
+            continue;
+          }
+        }
         const uint32_t key = act ? sl[u] : (0x80000000u | (uint32_t)lane); // (rows past the end: runs of their own, never added)
         const uint32_t prevk = (uint32_t)__shfl_up((int)key, 1, 64);
         const uint64_t bm = __ballot(lane == 0 || key != prevk);            // bit = a run starts at this lane
@@ -1024,13 +1153,12 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
         const uint64_t peers = __ballot(hot);
         if (__popcll(peers) >= HOT_MIN_PEERS) {
           const uint32_t idmin = wave_min_u32_dpp(hot ? id[u] : 0xffffffffu);
-          if (lane_id() == first) atomicMin(&tfirst[s0], idmin);
+          hot_take(s0, idmin);
 #pragma unroll
           for (int a = 0; a < PART_MAX_ACC; a++) {
             if (a >= n_acc) break;
             const int kind = code_of(a) & 7;
             const uint64_t v = cur.v[u];
-            unsigned long long *cell = tacc + (size_t)a * R + s0;
             uint64_t red;
             switch (kind) {
             case AK_COUNT: red = (uint64_t)__popcll(peers); break;
@@ -1041,16 +1169,7 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
             case AK_MAX_I64: red = wave_max_u64(hot ? i64_to_ordered((int64_t)v) : 0ull); break;
             default: red = wave_max_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : 0ull);
             }
-            if (lane_id() == first) {
-              switch (kind) {
-              case AK_COUNT:
-              case AK_SUM_I64: atomicAdd(cell, (unsigned long long)red); break;
-              case AK_SUM_F64: unsafeAtomicAdd((double *)cell, __longlong_as_double((long long)red)); break;
-              case AK_MIN_I64:
-              case AK_MIN_F64: atomicMin(cell, (unsigned long long)red); break;
-              default: atomicMax(cell, (unsigned long long)red);
-              }
-            }
+            hot_add(a, kind, red);
           }
           act = act && !hot;
         }
@@ -1076,6 +1195,7 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
     }
     cur = nxt;
   }
+  hot_flush();
   __syncthreads();
   if (JOIN && (prm.partner_bits || prm.partner_mult)) { // build keys with gaps: a slot whose key has no build partner is not a group
     const uint64_t off0 = (uint64_t)b << kp.rbits;
@@ -1585,8 +1705,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
 #undef SQ_LS_J
 #undef SQ_LS
       if (nsplit) {
-        const int64_t total = (int64_t)nsplit * nslots_h;
-        split_emit_dense_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
+        split_emit_dense_kernel<<<dim3((unsigned)(nsplit * ceil_div((int64_t)nslots_h, SED_SLOTS))), dim3(SED_SLOTS * SED_GROUPS), 0, ctx->stream>>>(
             stb, dsplit->as<uint32_t>(), dchunk_lo->as<uint32_t>(), nsplit, cap, pr.pack, prm, spec.n_acc,
             ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(), out->gacc->as<uint64_t>(), gcap);
       }
@@ -1619,8 +1738,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
 #undef SQ_LD_J
 #undef SQ_LD
       if (nsplit) {
-        const int64_t total = (int64_t)nsplit * nslots_h;
-        split_emit_dense_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream>>>(
+        split_emit_dense_kernel<<<dim3((unsigned)(nsplit * ceil_div((int64_t)nslots_h, SED_SLOTS))), dim3(SED_SLOTS * SED_GROUPS), 0, ctx->stream>>>(
             stb, dsplit->as<uint32_t>(), dchunk_lo->as<uint32_t>(), nsplit, cap, pr.pack, prm, spec.n_acc,
             ctr->as<unsigned long long>(), out->gkey->as<uint64_t>(), out->gfirst->as<uint32_t>(), out->gacc->as<uint64_t>(), gcap);
       }
