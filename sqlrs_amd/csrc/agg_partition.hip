@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t h, uint32_t P) {
 }
 
 // ---------------------------------------------------------------- key statistics --
-// HyperLogLog registers + min / max of the keys' signed-order image (hll[4096..4099] as two u64).
+// HyperLogLog registers + min / max of the keys' signed-order image (hll[8192..8195] as two u64).
 // Min / max see every row; the HyperLogLog registers only every 2^sample_shift-th 64-row group
 // (the hash + LDS atomic per row is what made this kernel slower than a plain read).
 // block_stride > 1: only every block_stride-th chunk of PART_WG * KU rows is read at all (plus the first and the
@@ -60,16 +60,23 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t h, uint32_t P) {
 // estimate_distinct.
 // hll_bits: log2 of the number of registers in use (<= 12).  The block-sampled pass uses 1024: every block merges its
 // registers with one global atomicMax each (24 G/s), and 512 blocks x 4096 registers cost more than reading the sample.
+// TWO register sets, hll[0..4096) and hll[4096..8192), each fed by HALF of the sample (block-sampled pass: the chunks of
+// the odd / the even workgroups; sample_shift > 0: the 64-row groups 0 and 2^(sample_shift-1) of every 2^sample_shift):
+// the host estimates the union and one half, and a half that holds clearly fewer keys than the union says the sample has
+// not seen every group yet — keys that arrive ORDERED or clustered, where a sample of the ROWS is no sample of the
+// GROUPS (2e8 sorted rows of 1e6 groups: an eighth of the chunks holds an eighth of the groups; the tables were sized
+// for 1.5e5 groups and the batch took the overflow path, 250 ms instead of 2.2 — round 5).
 __global__ __launch_bounds__(PART_WG) void key_stats_kernel(const uint64_t *__restrict__ keys,
                                                             const uint64_t *__restrict__ validity,
                                                             int64_t n, int sample_shift, int block_stride, int hll_bits,
                                                             unsigned int *__restrict__ hll) {
-  __shared__ unsigned int reg[4096];
+  __shared__ unsigned int reg[2 * 4096];
   const int nreg = 1 << hll_bits;
-  for (int i = threadIdx.x; i < nreg; i += PART_WG) reg[i] = 0;
+  for (int i = threadIdx.x; i < 2 * 4096; i += PART_WG) reg[i] = 0;
   __syncthreads();
   uint64_t kmin = ~0ull, kmax = 0;
-  const int64_t smask = (1ll << sample_shift) - 1;
+  const int64_t smask = (1ll << sample_shift) - 1, shalf = sample_shift ? 1ll << (sample_shift - 1) : -1;
+  const unsigned blk_set = block_stride > 1 && (blockIdx.x & 1) ? 4096u : 0u; // (block-sampled: the workgroup's set)
   constexpr int KU = 12; // loads in flight per lane (the loaded HBM latency needs ~100 KiB per CU)
   const int64_t nchunks = (n + PART_WG * KU - 1) / (PART_WG * KU);
   const int64_t nsel = block_stride > 1 ? (nchunks + block_stride - 1) / block_stride + 1 : nchunks;
@@ -87,16 +94,19 @@ __global__ __launch_bounds__(PART_WG) void key_stats_kernel(const uint64_t *__re
       const uint64_t o = k[u] ^ (1ull << 63);
       kmin = min(kmin, o);
       kmax = max(kmax, o);
-      if (((r >> 6) & smask) != 0) continue; // wave-uniform
+      const int64_t grp = (r >> 6) & smask; // wave-uniform
+      if (grp != 0 && grp != shalf) continue;
       uint64_t h = mix64(k[u] ^ 0x2545f4914f6cdd1dULL);
-      unsigned idx = (unsigned)(h >> (64 - hll_bits));
+      unsigned idx = (unsigned)(h >> (64 - hll_bits)) + (grp == shalf ? 4096u : blk_set);
       unsigned rank = (unsigned)__builtin_clzll((h << hll_bits) | (1ull << (hll_bits - 1))) + 1;
       if (reg[idx] < rank) atomicMax(&reg[idx], rank);
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nreg; i += PART_WG)
+  for (int i = threadIdx.x; i < nreg; i += PART_WG) {
     if (reg[i]) atomicMax(&hll[i], reg[i]);
+    if (reg[4096 + i]) atomicMax(&hll[4096 + i], reg[4096 + i]);
+  }
   // one atomic pair per BLOCK: atomics on one address are serialised in L2, and a pair per wave (8192 of them on two
   // addresses) was most of the sampled pass's 0.125 ms
   __shared__ unsigned long long s_mm[2][PART_WG / 64];
@@ -112,17 +122,18 @@ __global__ __launch_bounds__(PART_WG) void key_stats_kernel(const uint64_t *__re
       kmin = min(kmin, (uint64_t)s_mm[0][w]);
       kmax = max(kmax, (uint64_t)s_mm[1][w]);
     }
-    unsigned long long *mm = (unsigned long long *)(hll + 4096);
+    unsigned long long *mm = (unsigned long long *)(hll + 8192);
     atomicMin(mm, (unsigned long long)kmin);
     atomicMax(mm + 1, (unsigned long long)kmax);
   }
 }
 
+// (returns the estimate over the whole sample; *half = the estimate over one half of it, see key_stats_kernel)
 static double hll_pass(Ctx *ctx, const uint64_t *keys, const uint64_t *validity, int64_t n, int sample_shift,
-                       uint64_t *omin, uint64_t *omax, int block_stride = 1) {
+                       uint64_t *omin, uint64_t *omax, int block_stride = 1, double *half = nullptr) {
   const int hll_bits = block_stride > 1 ? 10 : 12; // (1024 registers: 3 % standard error, the estimate only sizes tables)
-  BufP hll = ctx->alloc_zero(4096 * 4 + 16);
-  SQ_HIP(hipMemsetAsync(hll->as<uint8_t>() + 4096 * 4, 0xff, 8, ctx->stream)); // min starts at ~0
+  BufP hll = ctx->alloc_zero(8192 * 4 + 16);
+  SQ_HIP(hipMemsetAsync(hll->as<uint8_t>() + 8192 * 4, 0xff, 8, ctx->stream)); // min starts at ~0
   {
     ProfScope ps(ctx, "key_stats");
     // two blocks per CU: every block ends with up to 4096 global atomicMax (24 G/s on MI355X), so
@@ -133,25 +144,31 @@ static double hll_pass(Ctx *ctx, const uint64_t *keys, const uint64_t *validity,
     SQ_HIP(hipGetLastError());
   }
   // (through the pinned staging buffer: a copy into pageable memory cost ~50 us of host time before the partition)
-  const unsigned int *hreg = (const unsigned int *)ctx->fetch(hll->p, 4096 * 4 + 16);
-  std::vector<unsigned int> reg(hreg, hreg + 4096 + 4);
-  if (omin) std::memcpy(omin, &reg[4096], 8);
-  if (omax) std::memcpy(omax, &reg[4098], 8);
-  reg.resize((size_t)1 << hll_bits);
-  const double m = (double)(1 << hll_bits);
-  double sum = 0;
-  int zeros = 0;
-  for (unsigned r : reg) {
-    sum += std::ldexp(1.0, -(int)r);
-    zeros += (r == 0);
-  }
-  double e = (0.7213 / (1.0 + 1.079 / m)) * m * m / sum;
-  if (e <= 2.5 * m && zeros) e = m * std::log(m / zeros);
+  const unsigned int *hreg = (const unsigned int *)ctx->fetch(hll->p, 8192 * 4 + 16);
+  if (omin) std::memcpy(omin, hreg + 8192, 8);
+  if (omax) std::memcpy(omax, hreg + 8194, 8);
+  const int nreg = 1 << hll_bits;
+  const double m = (double)nreg;
+  auto estimate = [&](bool both) {
+    double sum = 0;
+    int zeros = 0;
+    for (int i = 0; i < nreg; i++) {
+      const unsigned r = both ? std::max(hreg[i], hreg[4096 + i]) : hreg[i];
+      sum += std::ldexp(1.0, -(int)r);
+      zeros += (r == 0);
+    }
+    double e = (0.7213 / (1.0 + 1.079 / m)) * m * m / sum;
+    if (e <= 2.5 * m && zeros) e = m * std::log(m / zeros);
+    return e;
+  };
+  const double e_half = estimate(false), e = estimate(true);
+  if (half) *half = e_half;
   return e;
 }
 
-// Distinct keys of the batch.  A 1/8 sample (every eighth 64-row group) is enough while every
-// group is seen several times in it; when the sample looks like mostly distinct keys the full
+// Distinct keys of the batch.  A sample of the 64-row groups (two of every eight) is enough while every
+// group is seen several times in it; when the sample looks like mostly distinct keys — or one half of it holds
+// clearly fewer keys than the whole: ordered / clustered keys, see key_stats_kernel — the full
 // pass decides (the partition route is then usually rejected anyway).  A low estimate is not a
 // correctness problem: rows that do not fit their bucket table take the overflow path.
 //
@@ -166,17 +183,20 @@ double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validit
     const char *e = std::getenv("SQLRS_SAMPLED_STATS");
     return e ? std::atoi(e) : 1;
   }();
+  constexpr double SATURATED = 0.8; // half the sample holds >= this share of the sample's keys: every group has been seen
+  double half = 0;
   if (sampled && opt_env && !validity && n >= (1ll << 24)) {
     const int stride = 8;
-    const double e = hll_pass(ctx, keys, validity, n, 0, omin, omax, stride);
-    if (e <= 0.2 * (double)(n / stride)) { // every group is seen several times in the sample: the estimate stands
+    const double e = hll_pass(ctx, keys, validity, n, 0, omin, omax, stride, &half);
+    if (e <= 0.2 * (double)(n / stride) && half >= SATURATED * e) { // every group is seen several times in the sample: the estimate stands
       *sampled = true;
       return e * 1.25;
     }
+    if (half < SATURATED * e) return hll_pass(ctx, keys, validity, n, 0, omin, omax); // ordered keys: every row decides
   }
   const int shift = n >= (1ll << 22) ? 3 : 0;
-  double e = hll_pass(ctx, keys, validity, n, shift, omin, omax);
-  if (shift && e > 0.2 * (double)(n >> shift)) e = hll_pass(ctx, keys, validity, n, 0, omin, omax);
+  double e = hll_pass(ctx, keys, validity, n, shift, omin, omax, 1, &half);
+  if (shift && (e > 0.2 * (double)(n >> shift) || half < SATURATED * e)) e = hll_pass(ctx, keys, validity, n, 0, omin, omax);
   return e;
 }
 
@@ -1004,11 +1024,20 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
       __syncthreads();
     }
   }
-  // rows [i0, i0 + LDS_U * DENSE_WG) step DENSE_WG of this thread: value, word, and the base tile of their run
+  // A wave's rows of one trip are CONSECUTIVE (LDS_U groups of 64, wave w from row w * LDS_U * 64 of the trip), not DENSE_WG
+  // apart: rows that arrive ordered by key keep the wave on one key for several row slots, and the hot-slot carry below
+  // reaches the table once per key instead of once per row slot (SLIM_WAVE_SPAN=0: the old mapping).  Every load is still
+  // 64 consecutive slots per wave.
+#ifndef SLIM_WAVE_SPAN
+#define SLIM_WAVE_SPAN 1
+#endif
+  constexpr int64_t SLIM_USTEP = SLIM_WAVE_SPAN ? 64 : DENSE_WG;
+  const int64_t slim_toff = SLIM_WAVE_SPAN ? (int64_t)wave_id() * (LDS_U * 64) + lane_id() : (int64_t)threadIdx.x;
+  // rows i0 + u * SLIM_USTEP of this thread: value, word, and the base tile of their run
   auto load = [&](int64_t i0, SlimAggRows &r) {
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
-      const int64_t i = min(i0 + (int64_t)u * DENSE_WG, hi - 1);
+      const int64_t i = min(i0 + (int64_t)u * SLIM_USTEP, hi - 1);
       slim_load_nt(in.rows, i, r.w[u], r.v[u]);
       if (BLK) { // (a wave's 64 consecutive slots lie in one or two blocks: one or two cache lines per load)
         r.bt[u] = in.blk_bt[i >> in.log_b];
@@ -1074,10 +1103,10 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
     }
   };
   SlimAggRows cur, nxt;
-  if (lo < hi) load(lo + threadIdx.x, cur);
+  if (lo < hi) load(lo + slim_toff, cur);
   __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): same entry state as the loop's back edge
   for (int64_t base = lo; base < hi; base += (int64_t)LDS_U * DENSE_WG) {
-    const int64_t i0 = base + threadIdx.x;
+    const int64_t i0 = base + slim_toff;
     load(i0 + (int64_t)LDS_U * DENSE_WG, nxt);
     // LDS operations complete in order: a read behind an atomic waits for it.  So the trip's reads (the slots' current
     // first rows) are all issued BEFORE its atomics — a stale (larger) first row only costs a redundant atomicMin —
@@ -1090,11 +1119,36 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
       id[u] = (cur.bt[u] + (w >> (rbits + 13))) * in.tile + ((w >> rbits) & lmask);
       tf[u] = tfirst[sl[u]];
     }
+    // a wave's rows added per RUN OF EQUAL SLOTS (COUNT + SUM(double) only): the run's last lane adds the run's length, its
+    // sum and its smallest row
+    constexpr bool SEG_CAPABLE = NACC == 2 && ((C0 == AK_COUNT && C1 == AK_SUM_F64) || (C0 == AK_SUM_F64 && C1 == AK_COUNT));
+    const int lane = (int)lane_id();
+    auto seg_rows = [&](bool act, uint32_t sl_u, uint64_t v_u, uint32_t id_u, uint32_t tf_u) {
+      const uint32_t key = act ? sl_u : (0x80000000u | (uint32_t)lane); // (rows past the end: runs of their own, never added)
+      const uint32_t prevk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x138, 0xf, 0xf, false); // wave_shr:1 (lane 0 is a run start anyway)
+      const uint64_t bm = __ballot(lane == 0 || key != prevk);            // bit = a run starts at this lane
+      const int headl = 63 - __builtin_clzll(bm & le_mask);               // first lane of this lane's run
+      // SEGMENTED inclusive scan: only values of the same run are added (a difference of wave-wide prefix sums would let a
+      // neighbouring key's magnitudes into this key's rounding)
+      // ... and a segmented MIN of the row ids beside it: both slim partition levels rank a tile's rows of one digit in
+      // LDS-atomic order, so two producer waves can interleave and a run's head lane need not hold its smallest row
+      // (a later key whose first row falls into that gap would otherwise come out ahead in the first-seen order,
+      // hash_agg.rs:98).
+      double incl = act ? __longlong_as_double((long long)v_u) : 0.0;
+      uint32_t idh = act ? id_u : 0xffffffffu;
+      wave_seg_iscan_f64_min_u32(incl, idh, headl, lane); // (DPP; the __shfl_up form: SQLRS history, round 4)
+      const bool tail = act && (lane == 63 || ((bm >> (lane + 1)) & 1ull));
+      if (tail) {
+        const uint32_t s = sl_u;
+        if (idh < tf_u) atomicMin(&tfirst[s], idh);
+        atomicAdd(tacc + (size_t)(C0 == AK_COUNT ? 0 : 1) * R + s, (unsigned long long)(lane - headl + 1));
+        unsafeAtomicAdd((double *)(tacc + (size_t)(C0 == AK_COUNT ? 1 : 0) * R + s), incl);
+      }
+    };
     if (seg_mode) {
-      const int lane = (int)lane_id();
 #pragma unroll
       for (int u = 0; u < LDS_U; u++) {
-        const bool act = i0 + (int64_t)u * DENSE_WG < hi;
+        const bool act = i0 + (int64_t)u * SLIM_USTEP < hi;
         { // the whole wave is ONE run (a hot key's bucket; long runs of ordered rows): a plain wave reduction into the hot-slot carry
           const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl[u]);
           if (__ballot(act && sl[u] == s0) == ~0ull) {
@@ -1104,34 +1158,7 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
             continue;
           }
         }
-        const uint32_t key = act ? sl[u] : (0x80000000u | (uint32_t)lane); // (rows past the end: runs of their own, never added)
-        const uint32_t prevk = (uint32_t)__shfl_up((int)key, 1, 64);
-        const uint64_t bm = __ballot(lane == 0 || key != prevk);            // bit = a run starts at this lane
-        const int headl = 63 - __builtin_clzll(bm & le_mask);               // first lane of this lane's run
-        // SEGMENTED inclusive scan: only values of the same run are added (a difference of wave-wide prefix sums would let a
-        // neighbouring key's magnitudes into this key's rounding)
-        // ... and a segmented MIN of the row ids beside it: both slim partition levels rank a tile's rows of one digit in
-        // LDS-atomic order, so two producer waves can interleave and a run's head lane need not hold its smallest row
-        // (a later key whose first row falls into that gap would otherwise come out ahead in the first-seen order,
-        // hash_agg.rs:98).
-        double incl = act ? __longlong_as_double((long long)cur.v[u]) : 0.0;
-        uint32_t idh = act ? id[u] : 0xffffffffu;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const double o = __shfl_up(incl, d, 64);
-          const uint32_t oi = (uint32_t)__shfl_up((int)idh, d, 64);
-          if (lane - d >= headl) {
-            incl += o;
-            idh = oi < idh ? oi : idh;
-          }
-        }
-        const bool tail = act && (lane == 63 || ((bm >> (lane + 1)) & 1ull));
-        if (tail) {
-          const uint32_t s = sl[u];
-          if (idh < tf[u]) atomicMin(&tfirst[s], idh);
-          atomicAdd(tacc + (size_t)(C0 == AK_COUNT ? 0 : 1) * R + s, (unsigned long long)(lane - headl + 1));
-          unsafeAtomicAdd((double *)(tacc + (size_t)(C0 == AK_COUNT ? 1 : 0) * R + s), incl);
-        }
+        seg_rows(act, sl[u], cur.v[u], id[u], tf[u]);
       }
       cur = nxt;
       continue;
@@ -1139,40 +1166,52 @@ __global__ __launch_bounds__(DENSE_WG) void lds_agg_dense_slim_kernel(
 #pragma unroll
     for (int u = 0; u < LDS_U; u++) {
       const uint32_t s = sl[u];
-      bool act = i0 + (int64_t)u * DENSE_WG < hi;
+      bool act = i0 + (int64_t)u * SLIM_USTEP < hi;
       if (BLK) act = act && cur.w[u] != 0xffffffffu; // sentinel rows of the claimed level
 #ifdef SLIM_DBG
-      const uint64_t actm = (SLIM_DBG & 1) ? 0ull : __ballot(act); // timing experiments only (results invalid)
+      uint64_t actm = (SLIM_DBG & 1) ? 0ull : __ballot(act); // timing experiments only (results invalid)
 #else
-      const uint64_t actm = __ballot(act);
+      uint64_t actm = __ballot(act);
 #endif
-      if (actm) { // hot keys: see lds_agg_kernel
+      // hot keys (see lds_agg_kernel): the rows on the slot of the first active lane, when there are enough of them, are
+      // reduced over the wave into the carry — and then the same again for the lanes that are left, up to three slots
+      // (rows ordered by key: a wave holds the tail of one key's run and the head of the next; the second key's lanes used
+      // to queue on one LDS address, C4's bucket pass 1.39 ms on sorted rows against 0.45).  Random keys fail the first
+      // test and leave.
+      for (int it = 0; it < 3 && actm; it++) {
         const int first = __builtin_ctzll(actm);
         const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)s, first);
         const bool hot = act && s == s0;
         const uint64_t peers = __ballot(hot);
-        if (__popcll(peers) >= HOT_MIN_PEERS) {
-          const uint32_t idmin = wave_min_u32_dpp(hot ? id[u] : 0xffffffffu);
-          hot_take(s0, idmin);
-#pragma unroll
-          for (int a = 0; a < PART_MAX_ACC; a++) {
-            if (a >= n_acc) break;
-            const int kind = code_of(a) & 7;
-            const uint64_t v = cur.v[u];
-            uint64_t red;
-            switch (kind) {
-            case AK_COUNT: red = (uint64_t)__popcll(peers); break;
-            case AK_SUM_I64: red = wave_sum_u64_dpp(hot ? v : 0ull); break;
-            case AK_SUM_F64: red = (uint64_t)__double_as_longlong(wave_sum_f64_dpp(hot ? __longlong_as_double((long long)v) : 0.0)); break;
-            case AK_MIN_I64: red = wave_min_u64(hot ? i64_to_ordered((int64_t)v) : ~0ull); break;
-            case AK_MIN_F64: red = wave_min_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : ~0ull); break;
-            case AK_MAX_I64: red = wave_max_u64(hot ? i64_to_ordered((int64_t)v) : 0ull); break;
-            default: red = wave_max_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : 0ull);
-            }
-            hot_add(a, kind, red);
-          }
-          act = act && !hot;
+        if (__popcll(peers) < HOT_MIN_PEERS) break;
+        // a hot slot on CONSECUTIVE lanes, and other rows behind it: runs of equal keys (rows ordered by key; a hot key among
+        // random ones sits on scattered lanes and stays with the reduction below) — the whole wave per run
+        if (SEG_CAPABLE && it == 0 && peers != actm && (((peers >> first) + 1) & (peers >> first)) == 0 && !prm.seg_off) {
+          seg_rows(act, s, cur.v[u], id[u], tf[u]);
+          act = false;
+          break;
         }
+        const uint32_t idmin = wave_min_u32_dpp(hot ? id[u] : 0xffffffffu);
+        hot_take(s0, idmin);
+#pragma unroll
+        for (int a = 0; a < PART_MAX_ACC; a++) {
+          if (a >= n_acc) break;
+          const int kind = code_of(a) & 7;
+          const uint64_t v = cur.v[u];
+          uint64_t red;
+          switch (kind) {
+          case AK_COUNT: red = (uint64_t)__popcll(peers); break;
+          case AK_SUM_I64: red = wave_sum_u64_dpp(hot ? v : 0ull); break;
+          case AK_SUM_F64: red = (uint64_t)__double_as_longlong(wave_sum_f64_dpp(hot ? __longlong_as_double((long long)v) : 0.0)); break;
+          case AK_MIN_I64: red = wave_min_u64(hot ? i64_to_ordered((int64_t)v) : ~0ull); break;
+          case AK_MIN_F64: red = wave_min_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : ~0ull); break;
+          case AK_MAX_I64: red = wave_max_u64(hot ? i64_to_ordered((int64_t)v) : 0ull); break;
+          default: red = wave_max_u64(hot ? f64_to_ordered(__longlong_as_double((long long)v)) : 0ull);
+          }
+          hot_add(a, kind, red);
+        }
+        act = act && !hot;
+        actm &= ~peers;
       }
       if (act) {
 #ifdef SLIM_DBG

@@ -112,6 +112,50 @@ __device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) {
              min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
 }
 
+// SEGMENTED inclusive scan over the wave without the LDS crossbar: lane l ends with the sum of v (and the minimum of m)
+// over lanes [head .. l], head = first lane of l's segment (head <= l, equal for all lanes of a segment; ALL 64 lanes
+// active).  row_shr:1/2/4/8 scan the 16-lane rows; row_bcast15 hands lane 15 / 47 to the row above (rows 1 and 3),
+// row_bcast31 lane 31 to rows 2 and 3 — a lane takes them when its segment began before its row / before lane 32.
+// (The __shfl_up form is three ds_bpermute per step, 18 per scan: the bucket pass on rows ordered by key spent its time
+// there, SQ_ACTIVE_INST_LDS x 4 against random rows, profiles/r05x_sq_sorted.txt.)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_take_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_take_f64(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return __longlong_as_double((long long)(((uint64_t)dpp_take_u32<CTRL, ROW_MASK>((uint32_t)(b >> 32)) << 32) | dpp_take_u32<CTRL, ROW_MASK>((uint32_t)b)));
+}
+__device__ __forceinline__ void wave_seg_iscan_f64_min_u32(double &v, uint32_t &m, int head, int lane) {
+  const int in_row = lane & 15;
+#define SQ_SEG_STEP(D)                                                      \
+  {                                                                         \
+    const double o = dpp_take_f64<0x110 + D, 0xf>(v);                       \
+    const uint32_t om = dpp_take_u32<0x110 + D, 0xf>(m);                    \
+    if (in_row >= D && lane - D >= head) {                                  \
+      v += o;                                                               \
+      m = om < m ? om : m;                                                  \
+    }                                                                       \
+  }
+  SQ_SEG_STEP(1) SQ_SEG_STEP(2) SQ_SEG_STEP(4) SQ_SEG_STEP(8)
+#undef SQ_SEG_STEP
+  {
+    const double o = dpp_take_f64<0x142, 0xa>(v); // row_bcast15 -> rows 1, 3
+    const uint32_t om = dpp_take_u32<0x142, 0xa>(m);
+    if ((lane & 16) && head < (lane & ~15)) {
+      v += o;
+      m = om < m ? om : m;
+    }
+  }
+  {
+    const double o = dpp_take_f64<0x143, 0xc>(v); // row_bcast31 -> rows 2, 3
+    const uint32_t om = dpp_take_u32<0x143, 0xc>(m);
+    if (lane >= 32 && head < 32) {
+      v += o;
+      m = om < m ? om : m;
+    }
+  }
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);

@@ -722,35 +722,55 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
   // counter, one on the bucket's chunk histogram (rows below the chunk's room / rows that spill, both halves in one add).
   __shared__ uint32_t s_conc;
   uint32_t conc_digit = 0xffffffffu; // (workgroup-uniform) the digit the previous tile was concentrated on, or none
+  // The one-lane rank, once per WAVE and tile: while the previous tile was concentrated on one digit, the wave takes the
+  // bucket b0 of its first row of that digit, counts its rows of b0 over all RP_ROWS slots, and ONE lane adds the total to
+  // cnt / h2; the rows of b0 then take consecutive ranks from that base (slot by slot), every other row ranks itself.
+  // (Per SLOT — two same-address LDS atomics per wave and slot, 192 per tile — ordered fact rows still cost level 1
+  // 6.11 ms against 4.95 on random ones with the LDS pipe idle, profiles/r05x_sq_*.txt: the returning atomics of twelve
+  // waves on one address are served one after the other.)
+  uint32_t w_b0 = 0xffffffffu, w_base = 0; // (wave-uniform) the wave's bucket and the next free rank of its rows
+  auto plan_wave = [&]() {
+    w_b0 = 0xffffffffu;
+    if (conc_digit == 0xffffffffu) return;
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++) {
+      const uint32_t bkt = cur.off[j] >> kp.rbits;
+      const uint64_t m = __ballot(cur.off[j] != 0xffffffffu && (bkt >> p2_bits) == conc_digit);
+      if (w_b0 == 0xffffffffu && m) w_b0 = (uint32_t)__builtin_amdgcn_readlane((int)bkt, __builtin_ctzll(m));
+    }
+    if (w_b0 == 0xffffffffu) return;
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < RP_ROWS; j++)
+      total += (uint32_t)__popcll(__ballot(cur.off[j] != 0xffffffffu && (cur.off[j] >> kp.rbits) == w_b0));
+    if (total < 4u * RP_ROWS) { // a few rows only: every lane for itself
+      w_b0 = 0xffffffffu;
+      return;
+    }
+    const uint32_t d0 = w_b0 >> p2_bits;
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(&cnt[d0], total);
+    w_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const uint32_t room = room_s[d0];
+    const uint32_t nlo = room > w_base ? min(room - w_base, total) : 0u; // ranks w_base .. w_base + total - 1: those below the room
+    if (lane_id() == 0) atomicAdd(&h2[w_b0], nlo + ((total - nlo) << 16));
+  };
   auto rank_row = [&](int j) {
     dr[j] = 0xffffffffu;
     const bool in = cur.off[j] != 0xffffffffu;
     const uint32_t bkt = cur.off[j] >> kp.rbits;
-    if (conc_digit != 0xffffffffu) {
-      const uint64_t m = __ballot(in && (bkt >> p2_bits) == conc_digit); // (a hot key is the first row of ITS digit far more often than of the wave)
-      if (m) {
-        const int first = __builtin_ctzll(m);
-        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bkt, first);
-        const bool peer = in && bkt == b0; // the first kept lane's bucket: ranked by that lane; the other lanes (a hot key next to a few others) rank themselves
-        const uint64_t same = __ballot(peer);
-        if (__popcll(same) >= 8) {
-          const uint32_t d0 = b0 >> p2_bits, cntm = (uint32_t)__popcll(same);
-          uint32_t base = 0;
-          if ((int)lane_id() == first) base = atomicAdd(&cnt[d0], cntm);
-          base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-          const uint32_t room = room_s[d0];
-          const uint32_t nlo = room > base ? min(room - base, cntm) : 0u; // ranks base .. base + cntm - 1: those below the room
-          if ((int)lane_id() == first) atomicAdd(&h2[b0], nlo + ((cntm - nlo) << 16));
-          if (peer) dr[j] = (d0 << 16) | (base + (uint32_t)mbcnt(same));
-          if (in && !peer) {
-            const uint32_t d = bkt >> p2_bits;
-            const uint32_t r = atomicAdd(&cnt[d], 1u);
-            atomicAdd(&h2[bkt], r < room_s[d] ? 1u : 0x10000u);
-            dr[j] = (d << 16) | r;
-          }
-          return;
-        }
+    if (w_b0 != 0xffffffffu) {
+      const bool peer = in && bkt == w_b0;
+      const uint64_t same = __ballot(peer);
+      if (peer) dr[j] = ((w_b0 >> p2_bits) << 16) | (w_base + (uint32_t)mbcnt(same));
+      w_base += (uint32_t)__popcll(same);
+      if (in && !peer) {
+        const uint32_t d = bkt >> p2_bits;
+        const uint32_t r = atomicAdd(&cnt[d], 1u);
+        atomicAdd(&h2[bkt], r < room_s[d] ? 1u : 0x10000u);
+        dr[j] = (d << 16) | r;
       }
+      return;
     }
     if (in) {
       const uint32_t d = bkt >> p2_bits;
@@ -856,6 +876,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
     cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_conc = 0;
     __syncthreads();
+    plan_wave();
 #pragma unroll
     for (int j = 0; j < RP_ROWS; j++) rank_row(j);
     __syncthreads();
@@ -874,6 +895,7 @@ __global__ __launch_bounds__(RP_WG, 1) void rp_chunk_scatter_slim_kernel(
       cnt[threadIdx.x] = 0;
       if (threadIdx.x == 0) s_conc = 0; // (its last reader passed the barriers inside scan_and_stage)
       __syncthreads();
+      plan_wave();
 #pragma unroll
       for (int j = 0; j < RP_ROWS; j++) {
         if ((uint32_t)(j * RP_WG) < staged_len) store_row(j, staged_len);

@@ -183,13 +183,18 @@ def _run_hash_agg(env, key, val):
     return be.wrap(o)
 
 
-@pytest.mark.parametrize("keys", ["uniform", "sparse"])
+@pytest.mark.parametrize("keys", ["uniform", "sparse", "sorted", "sorted_sparse"])
 def test_full_size_c4_group_by(env, keys):
     """C4: 2e8 rows, 1e6 int64 groups, COUNT + SUM(f64): counts = bincount (bit-exact), sums =
-    index_add_ (1e-9 relative), every key once, groups in first-seen order (hash_agg.rs:98,132)"""
+    index_add_ (1e-9 relative), every key once, groups in first-seen order (hash_agg.rs:98,132).
+    `sorted*`: the rows ordered by key — a sample of the ROWS is then no sample of the GROUPS (an eighth of the chunks
+    holds an eighth of the groups): the statistics pass has to notice (key_stats_kernel's two register sets), or the
+    bucket tables are sized for 1.5e5 groups and the batch takes the overflow path (250 ms instead of ~3; seen round 5)"""
     t, d = env.torch, env.datagen
     n, G = 200_000_000, 1_000_000
     key = d.fill_chunks(t.empty(n, dtype=t.int64, device=env.dev), lambda i: d.key_t(0xA1, i, G))
+    if keys.startswith("sorted"):
+        key = t.sort(key).values
     val = d.fill_chunks(t.empty(n, dtype=t.float64, device=env.dev), lambda i: d.val_t(0xF2, i))
     t.cuda.synchronize()
     exp_cnt = t.bincount(key, minlength=G)
@@ -197,13 +202,18 @@ def test_full_size_c4_group_by(env, keys):
     first = first_seen_rows(env, key, G)
     A_s, A_inv = 0x9E3779B97F4A7C15 - (1 << 64), pow(0x9E3779B97F4A7C15, -1, 1 << 64)
     A_inv_s = A_inv - (1 << 64) if A_inv >= (1 << 63) else A_inv
-    if keys == "sparse":  # hashed buckets instead of the key-range partition
+    if keys.endswith("sparse"):  # hashed buckets instead of the key-range partition
         key.mul_(A_s).add_(777)
         t.cuda.synchronize()
+    env.be.profile(True)
     out = _run_hash_agg(env, key, val)
+    prof = env.be.profile_read()
+    env.be.profile(False)
+    if keys.startswith("sorted"):
+        assert "agg_resolve" not in prof and "agg_update" not in prof, sorted(prof)  # no row took the overflow path
     g = out.num_rows
     gk = view(env, out.column(0), g, t.int64)
-    if keys == "sparse":
+    if keys.endswith("sparse"):
         gk = (gk - 777) * A_inv_s
     gc, gs = view(env, out.column(1), g, t.int64), view(env, out.column(2), g, t.float64)
     assert g == int((exp_cnt > 0).sum().item())
