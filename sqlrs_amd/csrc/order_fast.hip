@@ -273,8 +273,10 @@ __device__ __forceinline__ void stable_wave_ranks(const uint32_t (&dig)[ITEMS], 
 constexpr uint32_t OLB_AGG = 1u << 30, OLB_PFX = 2u << 30, OLB_VAL = (1u << 30) - 1u;
 __device__ __forceinline__ uint32_t olb_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void olb_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <int KIND, bool RAW, int NPAY, bool TILED = false, bool REC = false, bool REC_IN = false, bool LB = false>
-__global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay,
+// TWO (records out): word and carried value take turns in ONE LDS tile instead of two — 43 KB and <= 80 VGPRs: three
+// workgroups per CU instead of two, for two more barriers per tile
+template <int KIND, bool RAW, int NPAY, bool TILED = false, bool REC = false, bool REC_IN = false, bool LB = false, bool TWO = false>
+__global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void ow_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay,
                                                            int64_t n, int desc, uint64_t imin, int shift, int64_t nblocks,
                                                            const uint32_t *__restrict__ offsets,
                                                            uint64_t *__restrict__ words_out, uint64_t *__restrict__ pay_out,
@@ -287,8 +289,9 @@ __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restric
   // (optimistic key range: the raw pass's histogram kernel has already seen every key; once it raised the flag, nothing
   //  this attempt produces is used — a miss then costs that histogram pass, not the two split passes behind it)
   if (abort_flag && *abort_flag) return;
+  static_assert(!TWO || (REC && NPAY == 1), "TWO: the record form");
   __shared__ uint64_t sword[OW_TILE];
-  __shared__ uint64_t spay[NPAY ? OW_TILE : 1];
+  __shared__ uint64_t spay[NPAY && !TWO ? OW_TILE : 1];
   __shared__ uint32_t wcnt[OW_WAVES][256];
   __shared__ uint32_t dstart[256];
   __shared__ int64_t gbase[256];
@@ -366,7 +369,8 @@ __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restric
     if (!valid[j]) continue;
     const uint32_t p = dstart[dig[j]] + wcnt[w][dig[j]] + rnk[j];
     sword[p] = k[j];
-    if (NPAY) spay[p] = v[j];
+    if (TWO) rnk[j] = p; // (kept for the value's turn)
+    else if (NPAY) spay[p] = v[j];
   }
   if (LB && threadIdx.x < 256) {
     uint32_t excl = 0;
@@ -395,6 +399,26 @@ __global__ __launch_bounds__(OW_WG) void ow_scatter_kernel(const void *__restric
     if (TILED && bound && tiles[blockIdx.x].pad) bound[(size_t)(tiles[blockIdx.x].pad - 1) * 256 + threadIdx.x] = gex + excl;
   }
   __syncthreads();
+  if constexpr (TWO) {
+#pragma unroll
+    for (int j = 0; j < OW_ITEMS; j++) k[j] = sword[min((uint32_t)(j * OW_WG) + threadIdx.x, (uint32_t)(OW_TILE - 1))]; // the words in output order
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < OW_ITEMS; j++)
+      if (valid[j]) sword[rnk[j]] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < OW_ITEMS; j++) {
+      const uint32_t p = j * OW_WG + threadIdx.x;
+      if (p < len) {
+        u64x2 rec;
+        rec.x = k[j];
+        rec.y = sword[p];
+        ((u64x2 *)words_out)[gbase[(uint32_t)(k[j] >> shift) & 255u] + p] = rec;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < OW_ITEMS; j++) {
     const uint32_t p = j * OW_WG + threadIdx.x;
@@ -1586,6 +1610,12 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     const unsigned gblocks = (unsigned)std::min<int64_t>(nblocks, 4 * (int64_t)ctx->num_cus);
     ow_ghist_kernel<KIND><<<dim3(gblocks), b, 0, ctx->stream>>>(src, n, desc, imin, s1, s2, nblocks, gh, oob_lb, kbits);
     uint64_t *out1 = NPAY == 1 ? recbuf1->as<uint64_t>() : wdst, *out2 = NPAY == 1 ? recbuf->as<uint64_t>() : walt; // (records / words)
+    const char *two_e = std::getenv("SQLRS_ORDER_TWO"); // (read per call: 0 = word and value side by side in LDS, two workgroups per CU)
+    const bool two = NPAY == 1 && !(two_e && two_e[0] == '0');
+    if (two)
+      ow_scatter_kernel<KIND, true, NPAY, false, NPAY == 1, false, true, NPAY == 1><<<g, b, 0, ctx->stream>>>(
+          src, psrc, n, desc, imin, s1, nblocks, nullptr, out1, nullptr, nullptr, oob_lb, gh, lbdesc->as<uint32_t>(), nullptr, lbw);
+    else
     ow_scatter_kernel<KIND, true, NPAY, false, NPAY == 1, false, true><<<g, b, 0, ctx->stream>>>(
         src, psrc, n, desc, imin, s1, nblocks, nullptr, out1, nullptr, nullptr, oob_lb, gh, lbdesc->as<uint32_t>(), nullptr, lbw);
     firsttile = ctx->alloc(4 * 257);
@@ -1594,6 +1624,11 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     ow_tile_plan_gh_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(gh, n, firsttile->as<uint32_t>(), segstart->as<int64_t>());
     ow_tile_fill_kernel<<<dim3((unsigned)ceil_div(ntmax, 256)), dim3(256), 0, ctx->stream>>>(
         firsttile->as<uint32_t>(), segstart->as<int64_t>(), (uint32_t)ntmax, (OwTile *)tiles2->p);
+    if (two)
+      ow_scatter_kernel<KIND, false, NPAY, true, NPAY == 1, NPAY == 1, true, NPAY == 1><<<dim3((unsigned)ntmax), b, 0, ctx->stream>>>(
+          out1, nullptr, n, desc, imin, s2, ntmax, nullptr, out2, nullptr, (const OwTile *)tiles2->p, oob_lb, gh + 256,
+          lbdesc->as<uint32_t>() + 256 * (size_t)nblocks, boundb->as<uint32_t>(), lbw);
+    else
     ow_scatter_kernel<KIND, false, NPAY, true, NPAY == 1, NPAY == 1, true><<<dim3((unsigned)ntmax), b, 0, ctx->stream>>>(
         out1, nullptr, n, desc, imin, s2, ntmax, nullptr, out2, nullptr, (const OwTile *)tiles2->p, oob_lb, gh + 256,
         lbdesc->as<uint32_t>() + 256 * (size_t)nblocks, boundb->as<uint32_t>(), lbw);
