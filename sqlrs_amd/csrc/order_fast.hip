@@ -874,15 +874,17 @@ __global__ __launch_bounds__(OW_WG) void owk_hist_kernel(const void *__restrict_
 }
 
 // pay == nullptr with NPAY: the payload is the row id (LEVEL 1 only).  REC: {word, payload} records out (LEVEL 2, NPAY)
-template <int KIND, int LEVEL, int NPAY, bool REC, bool REC_IN = false>
-__global__ __launch_bounds__(OW_WG) void owk_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay, int64_t n,
+// TWO: as in ow_scatter_kernel — word and payload take turns in one LDS tile, three workgroups per CU
+template <int KIND, int LEVEL, int NPAY, bool REC, bool REC_IN = false, bool TWO = false>
+__global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void owk_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay, int64_t n,
                                                             int desc, uint64_t imin, int64_t nblocks,
                                                             const uint32_t *__restrict__ offsets, uint64_t *__restrict__ words_out,
                                                             uint64_t *__restrict__ pay_out, const OwkTile *__restrict__ tiles,
                                                             const uint64_t *__restrict__ sub, uint32_t nk1,
                                                             const uint32_t *__restrict__ topfirst) {
+  static_assert(!TWO || (REC && NPAY == 1), "TWO: the record form");
   __shared__ uint64_t sword[OW_TILE];
-  __shared__ uint64_t spay[NPAY ? OW_TILE : 1];
+  __shared__ uint64_t spay[NPAY && !TWO ? OW_TILE : 1];
   __shared__ uint32_t wcnt[OW_WAVES][256]; // (its first 2 KB hold the splitters until the digits are known)
   __shared__ uint32_t dstart[256];
   __shared__ uint32_t gbase[256]; // position of the digit's run in the output minus its start in the tile (mod 2^32)
@@ -968,9 +970,30 @@ __global__ __launch_bounds__(OW_WG) void owk_scatter_kernel(const void *__restri
     const uint32_t p = dstart[dig[j]] + wcnt[w][dig[j]] + rnk[j];
     sword[p] = k[j];
     sdig[p] = (uint8_t)dig[j];
-    if (NPAY) spay[p] = v[j];
+    if (TWO) rnk[j] = p; // (kept for the payload's turn)
+    else if (NPAY) spay[p] = v[j];
   }
   __syncthreads();
+  if constexpr (TWO) {
+#pragma unroll
+    for (int j = 0; j < OW_ITEMS; j++) k[j] = sword[min((uint32_t)(j * OW_WG) + threadIdx.x, (uint32_t)(OW_TILE - 1))]; // the words in output order
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < OW_ITEMS; j++)
+      if (valid[j]) sword[rnk[j]] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < OW_ITEMS; j++) {
+      const uint32_t p = j * OW_WG + threadIdx.x;
+      if (p < len) {
+        u64x2 rec;
+        rec.x = k[j];
+        rec.y = sword[p];
+        ((u64x2 *)words_out)[(size_t)(uint32_t)(gbase[sdig[p]] + p)] = rec;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < OW_ITEMS; j++) {
     const uint32_t p = j * OW_WG + threadIdx.x;
@@ -1279,12 +1302,17 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   BufP hist = ctx->alloc(4 * (size_t)(256 * nblocks)), offs = ctx->alloc(4 * (size_t)(256 * nblocks)), total = ctx->alloc(8);
   const uint64_t *psrc = (carry && !pay_rows) ? carry->v<uint64_t>() : nullptr;
   dim3 g1((unsigned)nblocks), g2((unsigned)ntmax), b(OW_WG);
+  const char *two_e = std::getenv("SQLRS_ORDER_TWO"); // (read per call: 0 = word and payload side by side in LDS, two workgroups per CU)
+  const bool two = !(two_e && two_e[0] == '0');
   {
     ProfScope ps(ctx, "order_split");
     owk_hist_kernel<KIND, 1><<<g1, b, 0, ctx->stream>>>(key.values, n, desc, imin, nblocks, hist->as<uint32_t>(), nullptr, subp, nk1, tfp);
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist->as<uint32_t>(), 256 * nblocks, nullptr, offs->as<uint32_t>(), total->as<uint64_t>());
-    if (rec1)
+    if (rec1 && two)
+      owk_scatter_kernel<KIND, 1, 1, true, false, true><<<g1, b, 0, ctx->stream>>>(key.values, psrc, n, desc, imin, nblocks, offs->as<uint32_t>(),
+                                                                                  w1->as<uint64_t>(), nullptr, nullptr, subp, nk1, tfp);
+    else if (rec1)
       owk_scatter_kernel<KIND, 1, 1, true><<<g1, b, 0, ctx->stream>>>(key.values, psrc, n, desc, imin, nblocks, offs->as<uint32_t>(),
                                                                      w1->as<uint64_t>(), nullptr, nullptr, subp, nk1, tfp);
     else if (has_pay)
@@ -1309,9 +1337,15 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     else owk_hist_kernel<KIND, 2><<<g2, b, 0, ctx->stream>>>(w1->p, n, desc, imin, ntmax, hist2->as<uint32_t>(), tp, subp, nk1, tfp);
     SQ_HIP(hipGetLastError());
     exclusive_scan_u32(ctx, hist2->as<uint32_t>(), 256 * ntmax, nullptr, offs2->as<uint32_t>(), total->as<uint64_t>());
-    if (rec1)
+    if (rec1 && two)
+      owk_scatter_kernel<KIND, 2, 1, true, true, true><<<g2, b, 0, ctx->stream>>>(w1->p, nullptr, n, desc, imin, ntmax, offs2->as<uint32_t>(),
+                                                                                 out2->as<uint64_t>(), nullptr, tp, subp, nk1, tfp);
+    else if (rec1)
       owk_scatter_kernel<KIND, 2, 1, true, true><<<g2, b, 0, ctx->stream>>>(w1->p, nullptr, n, desc, imin, ntmax, offs2->as<uint32_t>(),
                                                                            out2->as<uint64_t>(), nullptr, tp, subp, nk1, tfp);
+    else if (has_pay && two)
+      owk_scatter_kernel<KIND, 2, 1, true, false, true><<<g2, b, 0, ctx->stream>>>(w1->p, p1->as<uint64_t>(), n, desc, imin, ntmax, offs2->as<uint32_t>(),
+                                                                                  out2->as<uint64_t>(), nullptr, tp, subp, nk1, tfp);
     else if (has_pay)
       owk_scatter_kernel<KIND, 2, 1, true><<<g2, b, 0, ctx->stream>>>(w1->p, p1->as<uint64_t>(), n, desc, imin, ntmax, offs2->as<uint32_t>(),
                                                                      out2->as<uint64_t>(), nullptr, tp, subp, nk1, tfp);
@@ -1670,8 +1704,10 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   // 2. groups = distinct values of the top bits
   const uint32_t G = 1u << top;
   BufP gstart = ctx->alloc(4 * (size_t)G), gend = ctx->alloc(4 * ((size_t)G + 1)); // gend[G] = largest group
-  SQ_HIP(hipMemsetAsync(gstart->p, 0xff, 4 * (size_t)G, ctx->stream));
-  SQ_HIP(hipMemsetAsync(gend->p, 0, 4 * ((size_t)G + 1), ctx->stream));
+  if (!lb_done) { // (the look-back form's table kernel writes every entry, its largest group goes to lbw[1])
+    SQ_HIP(hipMemsetAsync(gstart->p, 0xff, 4 * (size_t)G, ctx->stream));
+    SQ_HIP(hipMemsetAsync(gend->p, 0, 4 * ((size_t)G + 1), ctx->stream));
+  }
   {
     ProfScope ps(ctx, "order_groups");
     if (lb_done) {
