@@ -1480,12 +1480,20 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
         be.fn("order_destroy")(h)
     ms = timed(run_order)
     profile_of(run_order, "Order")
+    # (round 5: the two split passes run in their look-back form — one histogram of the column, passes chained over their tiles;
+    #  `ms_counting_form` = the same call with SQLRS_ORDER_LB=0, read per call: per-tile count matrices + scans as before)
+    os.environ["SQLRS_ORDER_LB"] = "0"
+    try:
+        ms_counting = timed(run_order)
+    finally:
+        os.environ.pop("SQLRS_ORDER_LB", None)
     # 16 N (read key, write permuted key) + 8 N per carried column = 24 B/row is what `frac` is computed from; the
     # carried column is read AND written, so the operator's streams are 32 B/row: `frac_streams_32B`, a differently named field
     by = 16 * n + 8 * n
     res["Order_int64_1col"] = {"rows": n, "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
                                "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4),
-                               "bytes_per_row": 24, "frac_streams_32B": round(32 * n / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+                               "bytes_per_row": 24, "frac_streams_32B": round(32 * n / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                               "ms_counting_form": round(ms_counting, 3)}
     # ---- what a MISS of the optimistic key range costs (review r03 #9): one key far outside the sampled range in a chunk the
     #      sample skips; the raw pass's histogram kernel notices, the split passes behind it return at once, the exact form
     #      runs.  `ms_exact` = the same column with SQLRS_ORDER_SAMPLE=0 (read per call: key range from a full pass)
