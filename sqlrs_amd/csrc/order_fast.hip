@@ -1431,6 +1431,7 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
 // `optimistic`: the key range comes from a SAMPLE (every 16th chunk of 2048 rows: 0.19 -> 0.03 ms for 1e8 rows), widened
 // as far as the same number of key bits allows; the first split pass tests every key against it and *retry_exact is set
 // (nothing produced, return false) when one lies outside — the caller runs the exact form once.
+static std::atomic<bool> g_order_lb_off{false}; // a look-back spin ran out once: the counting form for the rest of the process
 template <int KIND, int NPAY>
 static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, DCol *key_out, DCol *carry_out,
                             BufP *perm_out, bool want_perm, bool optimistic, bool *retry_exact, bool *in_order,
@@ -1621,12 +1622,11 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   // chained over their tiles — no count matrices, no scans (1e8 rows: 0.24 + 0.33 ms of histograms and 0.08 of scans
   // against 0.2 for the one histogram).  SQLRS_ORDER_LB=0 (read per call): the counting form; also taken for the rest of
   // the process once a look-back spin ran out (a predecessor tile that never showed up: see ow_scatter_kernel).
-  static std::atomic<bool> lb_off{false};
   const char *lb_e = std::getenv("SQLRS_ORDER_LB");
   static thread_local bool lb_skip = false; // (set around the one re-run after a failed attempt)
   const char *lbf_e = std::getenv("SQLRS_ORDER_LB_TEST_FAIL"); // (test hook, read per call: treat the attempt as failed)
   const bool two_pass = rbits > 0 && top > 8 && top <= 16 && use_tiled;
-  const bool lb = two_pass && (NPAY == 1 ? (rec1 && use_rec) : true) && n < (1ll << 30) && !lb_off.load() && !lb_skip && !(lb_e && lb_e[0] == '0');
+  const bool lb = two_pass && (NPAY == 1 ? (rec1 && use_rec) : true) && n < (1ll << 30) && !g_order_lb_off.load() && !lb_skip && !(lb_e && lb_e[0] == '0');
   BufP ghb, lbdesc, boundb;
   unsigned int *lbw = nullptr; // {look-back spin ran out, largest group, key outside the optimistic range}
   bool lb_done = false;
@@ -1728,7 +1728,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   if (lb_done) { // one round trip for the three
     const uint32_t *hv = (const uint32_t *)ctx->fetch(lbw, 12);
     if (hv[0] || (lbf_e && lbf_e[0] == '1')) { // a look-back spin ran out: nothing of this attempt is valid; the counting form from here on
-      if (hv[0]) lb_off.store(true);
+      if (hv[0]) g_order_lb_off.store(true);
       struct Skip {
         Skip() { lb_skip = true; }
         ~Skip() { lb_skip = false; }
