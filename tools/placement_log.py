@@ -19,10 +19,12 @@ pipe = bench.Pipeline(be, abi, 0.5)
 def step():
     pipe.step(bench.device_batch(abi, [dk], [abi.INT64]), bench.device_batch(abi, [fk, fv], [abi.INT64, abi.FLOAT64])).release()
 for rep in range(int(os.environ.get("REPS", 10))):
+    be.synchronize(); t_trim = time.perf_counter()
     be.fn("ctx_pool_trim")(be.ctx)
+    t_trim = (time.perf_counter() - t_trim) * 1e3
     if os.environ.get("HOLD"):  # perturb the next placement: keep an odd-sized block alive across the round
         hold = torch.empty((rep * 37 + 11) << 20, dtype=torch.uint8, device=dev)
-    step(); be.synchronize()
+    t_first = time.perf_counter(); step(); be.synchronize(); t_first = (time.perf_counter() - t_first) * 1e3
     os.environ.pop("SQLRS_RP_TRACE", None)
     be.profile(True)
     t = time.perf_counter()
@@ -32,4 +34,4 @@ for rep in range(int(os.environ.get("REPS", 10))):
     ms = (time.perf_counter() - t) / 4 * 1e3
     pr = be.profile_read(); be.profile(False)
     os.environ["SQLRS_RP_TRACE"] = "1"
-    print(f"round {rep}: step {ms:6.2f} ms | " + " ".join(f"{k} {v[0]/max(v[1],1):.2f}" for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])[:3]), flush=True)
+    print(f"round {rep}: trim {t_trim:6.1f} ms, first step {t_first:6.1f} ms, step {ms:6.2f} ms | " + " ".join(f"{k} {v[0]/max(v[1],1):.2f}" for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])[:3]), flush=True)
