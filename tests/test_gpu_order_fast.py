@@ -83,6 +83,27 @@ def test_order_fast_route_ab_hooks(hip, oracle, hooks, monkeypatch):
     assert got.equals(exp)
 
 
+@pytest.mark.parametrize("lb", ["1", "0"])
+@pytest.mark.parametrize("asc", [True, False])
+def test_order_split_passes_with_empty_segments(hip, oracle, asc, lb, monkeypatch):
+    """26-bit keys whose first-pass digit (bits 16..23) takes 64 of its 256 values and whose second-pass digit two bits: 192
+    segments of the tiled pass have no tile, so the look-back form's group table must pair every segment's bounds with those
+    of the NEXT SEGMENT THAT HAS ROWS (ow_group_table_lb_kernel); 256 groups of ~5000 rows each reach the in-LDS finish.
+    Both forms of the split passes (SQLRS_ORDER_LB, read per call)."""
+    monkeypatch.setenv("SQLRS_ORDER_LB", lb)
+    rng = np.random.default_rng(260 + asc)
+    k = (rng.integers(0, 4, N, dtype=np.int64) << 24) | ((rng.integers(0, 64, N, dtype=np.int64) * 4) << 16) | rng.integers(0, 1 << 16, N, dtype=np.int64)
+    b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(np.arange(N, dtype=np.int64))], names=["k", "row"])
+    hip.profile(True)
+    (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=asc)], [b]).execute())
+    assert got.column(0).equals(exp.column(0)) and got.column(1).equals(exp.column(1))
+    # (no second attempt: the groups fit the finish; the look-back form is one scope, the counting form two)
+    assert prof.get("order_split", (0, 0))[1] == (1 if lb == "1" else 2) and prof.get("order_finish", (0, 0))[1] == 1, prof
+
+
 @pytest.mark.parametrize("shape", ["sample_holds", "outlier_low", "outlier_high", "sorted"])
 @pytest.mark.parametrize("asc", [True, False])
 def test_order_fast_optimistic_key_range(hip, oracle, shape, asc, monkeypatch):
