@@ -451,7 +451,8 @@ def test_order_heavy_values_with_all_bits_in_hbm_stay_on_the_narrow_route(hip, o
     assert prof.get("order_knots", (0, 0))[1] == 0 and prof.get("order_split", (0, 0))[1] == 2, prof
 
 
-@pytest.mark.parametrize("seed", range(24))
+# (SQLRS_ORDER_FUZZ_EXTRA=N: N more seeds for a soak outside the suite)
+@pytest.mark.parametrize("seed", range(24 + int(os.environ.get("SQLRS_ORDER_FUZZ_EXTRA", "0"))))
 def test_fuzz_order_routes(hip, oracle, seed, monkeypatch):
     """random key type / width / distribution / heavy values / NULLs / key count / directions / column mix at sizes where the
     fast routes run (narrow, splitters, composite, NULL split, their fallbacks and the general path) — against the oracle"""
