@@ -313,14 +313,18 @@ def test_hash_join_lds_tables_f64_keys_and_fallbacks(hip, oracle, monkeypatch):
 
 @pytest.mark.parametrize("hit", ["all", "some", "none"])
 @pytest.mark.parametrize("batches", [1, 2])
-def test_hash_join_key_only_build_side(hip, oracle, hit, batches):
+@pytest.mark.parametrize("fill", ["full_range", "gaps"])
+def test_hash_join_key_only_build_side(hip, oracle, hit, batches, fill):
     """Inner join whose build side is nothing but its unique dense key column (a dimension projected to its key):
     the probe is an existence test against a bitmap and the joined batch the probe batch restricted to the matching
     rows (all of them: shared outright) — same batches as the general route (hash_join.rs:207-292)."""
     rng = np.random.default_rng(len(hit) + batches)
     nb, npr = 50_000, 400_000
-    bk = (rng.permutation(nb) + 1000).astype(np.int64)
-    lo, hi = {"all": (1000, 1000 + nb), "some": (0, 2000 + nb), "none": (2 * nb + 5000, 3 * nb + 5000)}[hit]
+    # full_range: the keys fill their range — a probe key inside it has its partner, no bitmap is read; gaps: every other
+    # value of the range is missing (the bitmap decides; "all" then means every probe key inside the range, half of them hit)
+    bk = (rng.permutation(nb) + 1000).astype(np.int64) if fill == "full_range" else (rng.permutation(nb) * 2 + 1000).astype(np.int64)
+    span = nb if fill == "full_range" else 2 * nb
+    lo, hi = {"all": (1000, 1000 + span), "some": (0, 2000 + span), "none": (2 * span + 5000, 3 * span + 5000)}[hit]
     lb = pa.RecordBatch.from_arrays([pa.array(bk)], names=["c0"])
     rb = pa.RecordBatch.from_arrays([pa.array(rng.random(npr)), pa.array(rng.integers(lo, hi, npr, dtype=np.int64))], names=["c0", "c1"])
     rbs = [rb] if batches == 1 else [rb.slice(0, 150_000), rb.slice(150_000)]
