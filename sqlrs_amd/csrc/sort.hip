@@ -194,7 +194,10 @@ void radix_sort_pairs(Ctx *ctx, uint64_t *keys, uint32_t *vals, int64_t n, int b
   if (keys_below_end_bit && begin_bit == 0 && end_bit <= 32) {
     varying = (1ull << end_bit) - 1; // (all of it sorted, nothing above it: the packed form applies without asking)
     key0 = 0;
-  } else if (end_bit - begin_bit > 16 && n >= (1 << 22)) {
+  } else if ((end_bit - begin_bit > 16 && n >= (1 << 22)) || (end_bit - begin_bit > 32 && n >= (1 << 15))) {
+    // (more than four passes requested of a column that is small enough for its passes to be launch-bound, ~23 us each: the
+    //  question costs about two passes and an int64 column of 31-bit values answers "four of the eight" — ORDER BY ... LIMIT's
+    //  sample and candidate sorts 0.19 -> ms each)
     BufP diff = ctx->alloc_zero(16);
     unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 4 * (int64_t)ctx->num_cus);
     rs_diff_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(keys, n, diff->as<unsigned long long>());
