@@ -873,15 +873,56 @@ __global__ __launch_bounds__(OW_WG) void owk_hist_kernel(const void *__restrict_
   if (threadIdx.x < 256) hist[hbase + threadIdx.x * hstride + hcol] = h[threadIdx.x];
 }
 
+// The first pass's 256 segment sizes in ONE persistent launch (the look-back form of that pass: ow_scatter_kernel's LB):
+// the search of owk_hist_kernel<KIND, 1>, counted into 256 global words instead of a (tile, digit) matrix
+template <int KIND>
+__global__ __launch_bounds__(OW_WG) void owk_ghist_kernel(const void *__restrict__ src, int64_t n, int desc, uint64_t imin,
+                                                          int64_t nblocks, uint32_t *__restrict__ ghist,
+                                                          const uint64_t *__restrict__ sub, uint32_t nk1,
+                                                          const uint32_t *__restrict__ topfirst) {
+  __shared__ uint32_t h[256];
+  __shared__ uint64_t sk[256];
+  __shared__ uint32_t sfirst[256];
+  if (threadIdx.x < 256) {
+    sk[threadIdx.x] = threadIdx.x < nk1 ? sub[(size_t)threadIdx.x << 8] : ~0ull;
+    sfirst[threadIdx.x] = threadIdx.x < nk1 ? topfirst[threadIdx.x] >> 8 : 0;
+    h[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  for (int64_t t = blockIdx.x; t < nblocks; t += gridDim.x) {
+    const int64_t t0 = t * OW_TILE;
+    const uint32_t tl = (uint32_t)min<int64_t>(OW_TILE, n - t0);
+    uint64_t k[OW_ITEMS];
+#pragma unroll
+    for (int r = 0; r < OW_ITEMS; r++) k[r] = order_image<KIND>(src, t0 + min((uint32_t)(threadIdx.x + r * OW_WG), tl - 1), desc) - imin;
+    uint32_t dig[OW_ITEMS];
+    knot_digits<OW_ITEMS>(sk, nk1, k, dig);
+#pragma unroll
+    for (int r = 0; r < OW_ITEMS; r++)
+      if (sk[dig[r]] == k[r]) dig[r] = sfirst[dig[r]];
+#pragma unroll
+    for (int r = 0; r < OW_ITEMS; r++)
+      if ((uint32_t)(threadIdx.x + r * OW_WG) < tl) atomicAdd(&h[dig[r]], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 256 && h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
+}
+
 // pay == nullptr with NPAY: the payload is the row id (LEVEL 1 only).  REC: {word, payload} records out (LEVEL 2, NPAY)
 // TWO: as in ow_scatter_kernel — word and payload take turns in one LDS tile, three workgroups per CU
-template <int KIND, int LEVEL, int NPAY, bool REC, bool REC_IN = false, bool TWO = false>
+// LB (LEVEL 1): the chained look-back of ow_scatter_kernel instead of the scanned count matrix — `ghist` = the 256 segment
+// sizes (owk_ghist_kernel), `lbdesc` [tile][256] zeroed, `lb_fail` raised when a spin runs out
+template <int KIND, int LEVEL, int NPAY, bool REC, bool REC_IN = false, bool TWO = false, bool LB = false>
 __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void owk_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay, int64_t n,
                                                             int desc, uint64_t imin, int64_t nblocks,
                                                             const uint32_t *__restrict__ offsets, uint64_t *__restrict__ words_out,
                                                             uint64_t *__restrict__ pay_out, const OwkTile *__restrict__ tiles,
                                                             const uint64_t *__restrict__ sub, uint32_t nk1,
-                                                            const uint32_t *__restrict__ topfirst) {
+                                                            const uint32_t *__restrict__ topfirst,
+                                                            const uint32_t *__restrict__ ghist = nullptr,
+                                                            uint32_t *__restrict__ lbdesc = nullptr,
+                                                            unsigned int *__restrict__ lb_fail = nullptr) {
+  static_assert(!LB || LEVEL == 1, "look-back: the first pass");
   static_assert(!TWO || (REC && NPAY == 1), "TWO: the record form");
   __shared__ uint64_t sword[OW_TILE];
   __shared__ uint64_t spay[NPAY && !TWO ? OW_TILE : 1];
@@ -890,6 +931,7 @@ __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void owk_scatter_kernel(const v
   __shared__ uint32_t gbase[256]; // position of the digit's run in the output minus its start in the tile (mod 2^32)
   __shared__ uint8_t sdig[OW_TILE];
   __shared__ uint32_t s_wsum[4];
+  __shared__ uint32_t s_gsum[4];
   uint64_t *sk = (uint64_t *)&wcnt[0][0];
   uint32_t *sfirst = &wcnt[2][0]; // (behind the 2 KB of splitters; LEVEL 1 only)
   const int w = wave_id(), lane = lane_id();
@@ -928,7 +970,8 @@ __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void owk_scatter_kernel(const v
     k[j] = LEVEL == 1 ? order_image<KIND>(src, i, desc) - imin : __builtin_nontemporal_load((const uint64_t *)src + i);
     if (NPAY) v[j] = pay ? __builtin_nontemporal_load(pay + i) : (uint64_t)i;
   }
-  const uint32_t goff = threadIdx.x < 256 ? offsets[hbase + threadIdx.x * hstride + hcol] : 0;
+  const uint32_t goff = !LB && threadIdx.x < 256 ? offsets[hbase + threadIdx.x * hstride + hcol] : 0;
+  const uint32_t gcnt = LB && threadIdx.x < 256 ? ghist[threadIdx.x] : 0;
   __syncthreads();
   uint32_t dig[OW_ITEMS], rnk[OW_ITEMS];
   knot_digits<OW_ITEMS>(sk, nk, k, dig);
@@ -943,6 +986,8 @@ __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void owk_scatter_kernel(const v
   for (int j = 0; j < OW_ITEMS; j++) valid[j] = wrow + j * 64 < len;
   stable_wave_ranks<OW_ITEMS>(dig, valid, wcnt[w], rnk);
   __syncthreads();
+  uint32_t my_cnt = 0, my_ds = 0, gex = 0, lb_first = 0; // (LB, threads < 256: digit threadIdx.x of this tile)
+  uint32_t *my_desc = LB ? lbdesc + (size_t)blockIdx.x * 256 + min(threadIdx.x, 255u) : nullptr;
   if (threadIdx.x < 256) {
     uint32_t acc = 0;
 #pragma unroll
@@ -950,6 +995,14 @@ __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void owk_scatter_kernel(const v
       uint32_t c = wcnt[q][threadIdx.x];
       wcnt[q][threadIdx.x] = acc;
       acc += c;
+    }
+    if (LB) { // publish the count, ask for the predecessor's word (consumed behind the staging loop)
+      olb_store(my_desc, (blockIdx.x == 0 ? OLB_PFX : OLB_AGG) | acc);
+      if (blockIdx.x > 0) lb_first = olb_load(my_desc - 256);
+      my_cnt = acc;
+      const uint32_t ginc = wave_iscan_u32(gcnt);
+      if (lane == 63) s_gsum[w] = ginc;
+      gex = ginc - gcnt;
     }
     uint32_t inc = wave_iscan_u32(acc);
     if (lane == 63) s_wsum[w] = inc;
@@ -961,7 +1014,11 @@ __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void owk_scatter_kernel(const v
     for (int q = 0; q < w; q++) wb += s_wsum[q];
     const uint32_t ds = dstart[threadIdx.x] + wb;
     dstart[threadIdx.x] = ds;
-    gbase[threadIdx.x] = goff - ds;
+    if (LB) {
+      my_ds = ds;
+      for (int q = 0; q < w; q++) gex += s_gsum[q];
+    } else
+      gbase[threadIdx.x] = goff - ds;
   }
   __syncthreads();
 #pragma unroll
@@ -972,6 +1029,31 @@ __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void owk_scatter_kernel(const v
     sdig[p] = (uint8_t)dig[j];
     if (TWO) rnk[j] = p; // (kept for the payload's turn)
     else if (NPAY) spay[p] = v[j];
+  }
+  if (LB && threadIdx.x < 256) { // (the walk of ow_scatter_kernel)
+    uint32_t excl = 0;
+    if (blockIdx.x > 0) {
+      const uint32_t *p = my_desc - 256;
+      uint32_t st = lb_first;
+      for (;;) {
+        unsigned spins = 0;
+        while ((st >> 30) == 0) {
+          if (++spins > LB_SPIN_LIMIT) {
+            *lb_fail = 1u;
+            st = OLB_PFX;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          st = olb_load(p);
+        }
+        excl += st & OLB_VAL;
+        if ((st >> 30) == 2 || p == lbdesc + threadIdx.x) break;
+        p -= 256;
+        st = olb_load(p);
+      }
+      olb_store(my_desc, OLB_PFX | ((excl + my_cnt) & OLB_VAL));
+    }
+    gbase[threadIdx.x] = gex + excl - my_ds;
   }
   __syncthreads();
   if constexpr (TWO) {
@@ -1264,6 +1346,7 @@ __global__ __launch_bounds__(FIN_WG, R == 8 ? 4 : 1) void owk_finish_kernel(cons
 // the wide route; false = not taken (nothing produced that the caller may use).  `imin`, `range`: EXACT extremes of the
 // key image.  want_perm: the row ids travel as the payload and `carry_out` stays empty (the caller gathers that column
 // like the others)
+static std::atomic<bool> g_order_lb_off{false}; // a look-back spin ran out once: the counting forms for the rest of the process
 template <int KIND>
 static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, uint64_t imin, uint64_t range,
                        DCol *key_out, DCol *carry_out, BufP *perm_out, bool want_perm) {
@@ -1304,7 +1387,28 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   dim3 g1((unsigned)nblocks), g2((unsigned)ntmax), b(OW_WG);
   const char *two_e = std::getenv("SQLRS_ORDER_TWO"); // (read per call: 0 = word and payload side by side in LDS, two workgroups per CU)
   const bool two = !(two_e && two_e[0] == '0');
-  {
+  // The first pass in its look-back form (the narrow route's, see ow_scatter_kernel): its 256 segment sizes from one persistent
+  // launch, the tiles chained — no count matrix, no scan.  The second pass keeps its counting form: its digit is a search in the
+  // row's own segment's splitters, so nothing ahead of the first pass can count it.  SQLRS_ORDER_LB=0 (read per call) / a spin
+  // that ran out: the counting form.
+  static thread_local bool wide_lb_skip = false;
+  const char *lb_e = std::getenv("SQLRS_ORDER_LB"), *lbf_e = std::getenv("SQLRS_ORDER_LB_TEST_FAIL");
+  const bool lb1 = rec1 && two && n < (1ll << 30) && !g_order_lb_off.load() && !wide_lb_skip && !(lb_e && lb_e[0] == '0');
+  BufP ghb1, lbdesc1;
+  if (lb1) {
+    ProfScope ps(ctx, "order_split");
+    ghb1 = ctx->alloc(4 * 260);
+    lbdesc1 = ctx->alloc(4 * 256 * (size_t)nblocks);
+    SQ_HIP(hipMemsetAsync(ghb1->p, 0, 4 * 260, ctx->stream));
+    SQ_HIP(hipMemsetAsync(lbdesc1->p, 0, 4 * 256 * (size_t)nblocks, ctx->stream));
+    const unsigned gblocks = (unsigned)std::min<int64_t>(nblocks, 4 * (int64_t)ctx->num_cus);
+    owk_ghist_kernel<KIND><<<dim3(gblocks), b, 0, ctx->stream>>>(key.values, n, desc, imin, nblocks, ghb1->as<uint32_t>(), subp, nk1, tfp);
+    owk_scatter_kernel<KIND, 1, 1, true, false, true, true><<<g1, b, 0, ctx->stream>>>(key.values, psrc, n, desc, imin, nblocks, nullptr,
+                                                                                        w1->as<uint64_t>(), nullptr, nullptr, subp, nk1, tfp,
+                                                                                        ghb1->as<uint32_t>(), lbdesc1->as<uint32_t>(),
+                                                                                        ghb1->as<uint32_t>() + 256);
+    SQ_HIP(hipGetLastError());
+  } else {
     ProfScope ps(ctx, "order_split");
     owk_hist_kernel<KIND, 1><<<g1, b, 0, ctx->stream>>>(key.values, n, desc, imin, nblocks, hist->as<uint32_t>(), nullptr, subp, nk1, tfp);
     SQ_HIP(hipGetLastError());
@@ -1329,7 +1433,8 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   BufP out2 = ctx->alloc((has_pay ? 16 : 8) * (size_t)n);
   {
     ProfScope ps(ctx, "order_split");
-    ow_tile_plan_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(offs->as<uint32_t>(), nblocks, n, firsttile->as<uint32_t>(), segstart->as<int64_t>());
+    if (lb1) ow_tile_plan_gh_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(ghb1->as<uint32_t>(), n, firsttile->as<uint32_t>(), segstart->as<int64_t>());
+    else ow_tile_plan_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(offs->as<uint32_t>(), nblocks, n, firsttile->as<uint32_t>(), segstart->as<int64_t>());
     owk_tile_fill_kernel<<<dim3((unsigned)ceil_div(ntmax, 256)), dim3(256), 0, ctx->stream>>>(firsttile->as<uint32_t>(), segstart->as<int64_t>(),
                                                                                              (uint32_t)ntmax, (OwkTile *)tiles2->p);
     const OwkTile *tp = (const OwkTile *)tiles2->p;
@@ -1355,17 +1460,26 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     SQ_HIP(hipGetLastError());
   }
   // 3. groups
-  BufP gstart = ctx->alloc(4 * (size_t)65536), gend = ctx->alloc(4 * ((size_t)65536 + 2)); // [G]: largest group, [G + 1]: pure chunks
+  BufP gstart = ctx->alloc(4 * (size_t)65536), gend = ctx->alloc(4 * ((size_t)65536 + 4)); // [G]: largest group, [G + 1]: pure chunks, [G + 2]: look-back spin ran out
   BufP pure_items = ctx->alloc(8 * ((size_t)ceil_div(n, (int64_t)OWK_PURE_CHUNK) + G + 1));
-  SQ_HIP(hipMemsetAsync(gend->as<uint32_t>() + G, 0, 8, ctx->stream));
+  SQ_HIP(hipMemsetAsync(gend->as<uint32_t>() + G, 0, 12, ctx->stream));
+  if (lb1) SQ_HIP(hipMemcpyAsync(gend->as<uint32_t>() + G + 2, ghb1->as<uint32_t>() + 256, 4, hipMemcpyDeviceToDevice, ctx->stream));
   {
     ProfScope ps(ctx, "order_groups");
     owk_group_table_kernel<<<dim3(nk1), dim3(256), 0, ctx->stream>>>(offs2->as<uint32_t>(), firsttile->as<uint32_t>(), segstart->as<int64_t>(), subp, G,
                                                                    gstart->as<uint32_t>(), gend->as<uint32_t>(), (uint2 *)pure_items->p);
     SQ_HIP(hipGetLastError());
   }
-  const uint32_t *gh = (const uint32_t *)ctx->fetch(gend->as<uint32_t>() + G, 8);
+  const uint32_t *gh = (const uint32_t *)ctx->fetch(gend->as<uint32_t>() + G, 12);
   const uint32_t max_group = gh[0], pure_chunks = gh[1];
+  if (lb1 && (gh[2] || (lbf_e && lbf_e[0] == '1'))) { // nothing of this attempt is valid: once more in the counting form
+    if (gh[2]) g_order_lb_off.store(true);
+    struct Skip {
+      Skip() { wide_lb_skip = true; }
+      ~Skip() { wide_lb_skip = false; }
+    } skip;
+    return order_wide<KIND>(ctx, key, desc, carry, n, imin, range, key_out, carry_out, perm_out, want_perm);
+  }
   if (std::getenv("SQLRS_ORDER_TRACE"))
     std::fprintf(stderr, "[order_wide] n=%lld key bits=%d groups=%u largest group to sort=%u rows, %u chunks of single-value groups\n",
                  (long long)n, kb, G, max_group, pure_chunks);
@@ -1431,7 +1545,6 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
 // `optimistic`: the key range comes from a SAMPLE (every 16th chunk of 2048 rows: 0.19 -> 0.03 ms for 1e8 rows), widened
 // as far as the same number of key bits allows; the first split pass tests every key against it and *retry_exact is set
 // (nothing produced, return false) when one lies outside — the caller runs the exact form once.
-static std::atomic<bool> g_order_lb_off{false}; // a look-back spin ran out once: the counting form for the rest of the process
 template <int KIND, int NPAY>
 static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, DCol *key_out, DCol *carry_out,
                             BufP *perm_out, bool want_perm, bool optimistic, bool *retry_exact, bool *in_order,

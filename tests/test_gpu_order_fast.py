@@ -69,14 +69,16 @@ def hash_seed(*parts):
 
 
 @pytest.mark.parametrize("hooks", [{"SQLRS_ORDER_TILED": "0"}, {"SQLRS_ORDER_REC": "0"}, {"SQLRS_ORDER_REC1": "0"}, {"SQLRS_ORDER_WIDE_REC1": "0"},
-                                   {"SQLRS_ORDER_LB": "0"}, {"SQLRS_ORDER_LB_TEST_FAIL": "1"}])
+                                   {"SQLRS_ORDER_LB": "0"}, {"SQLRS_ORDER_LB_TEST_FAIL": "1"},
+                                   {"SQLRS_ORDER_LB": "0", "TEST_WIDE_KEYS": "1"}, {"SQLRS_ORDER_LB_TEST_FAIL": "1", "TEST_WIDE_KEYS": "1"}])
 def test_order_fast_route_ab_hooks(hip, oracle, hooks, monkeypatch):
     """the A/B hooks of the fast route (read per call) keep the older forms alive: plain 4096-row blocks with a
     boundary scan of the sorted words, and key / value columns instead of 16-byte records into the finish"""
     for k_, v_ in hooks.items():
         monkeypatch.setenv(k_, v_)
     rng = np.random.default_rng(77)
-    k = rng.integers(0, 1 << 31, N, dtype=np.int64) if "SQLRS_ORDER_WIDE_REC1" not in hooks else rng.integers(-(1 << 62), 1 << 62, N, dtype=np.int64)
+    wide = "SQLRS_ORDER_WIDE_REC1" in hooks or "TEST_WIDE_KEYS" in hooks   # (TEST_WIDE_KEYS: no hook of the library, only this choice)
+    k = rng.integers(0, 1 << 31, N, dtype=np.int64) if not wide else rng.integers(-(1 << 62), 1 << 62, N, dtype=np.int64)
     b = pa.RecordBatch.from_arrays([pa.array(k), pa.array(np.arange(N, dtype=np.int64))], names=["k", "row"])
     (got,) = list(OrderExecutor(hip, [OrderBy(InputRef(0), asc=True)], [b]).execute())
     (exp,) = list(OrderExecutor(oracle, [OrderBy(InputRef(0), asc=True)], [b]).execute())
