@@ -591,6 +591,9 @@ constexpr int LJ_WG = 1024, LJ_WAVES = LJ_WG / 64, LJ_RANGE_LOG2 = 15, LJ_RANGE 
 #define LJ_Q_N 8
 #endif
 constexpr int LJ_Q = LJ_Q_N; // slivers a wave probes at a time
+#ifndef LJ_DBG
+#define LJ_DBG 0
+#endif
 struct LjSlot {
   uint64_t key;
   uint32_t row1, pad; // build row + 1, 0 = empty
@@ -617,7 +620,7 @@ constexpr int LP_ROWS = LJ_RANGE / LJ_WG; // 32 rows per thread
 constexpr int LP_STAGE = LJ_RANGE / 4;    // rows staged per round (96 KiB)
 __global__ __launch_bounds__(LJ_WG) void lds_join_partition_kernel(const uint64_t *__restrict__ keys, int64_t n, uint32_t P,
                                                                    uint64_t *__restrict__ okey, uint32_t *__restrict__ oidx,
-                                                                   uint32_t *__restrict__ pbstart) {
+                                                                   uint32_t *__restrict__ pbs, uint32_t nrs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lp_smem[];
   uint64_t *skey = (uint64_t *)lp_smem;            // [LP_STAGE]
   uint32_t *sidx = (uint32_t *)(skey + LP_STAGE);  // [LP_STAGE]
@@ -652,8 +655,8 @@ __global__ __launch_bounds__(LJ_WG) void lds_join_partition_kernel(const uint64_
     for (int w = 0; w < wave_id(); w++) wb += s_wsum[w];
     const uint32_t st = cnt[threadIdx.x] + wb;
     start[threadIdx.x] = st;
-    if (threadIdx.x < P) pbstart[(size_t)blockIdx.x * P + threadIdx.x] = (uint32_t)rbase + st;
-    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) pbstart[(size_t)gridDim.x * P] = (uint32_t)n;
+    // (bucket-major: the probe pass of bucket b reads the starts of 64 consecutive ranges with one coalesced load)
+    if (threadIdx.x < P) pbs[(size_t)threadIdx.x * nrs + blockIdx.x] = (uint32_t)rbase + st;
   }
   __syncthreads();
 #pragma unroll
@@ -686,9 +689,10 @@ __global__ __launch_bounds__(LJ_WG) void lds_join_partition_kernel(const uint64_
     __syncthreads();
   }
 }
+template <int Q> // slivers a wave probes per trip
 __global__ __launch_bounds__(LJ_WG) void lds_join_probe_kernel(
     const uint64_t *__restrict__ bkey, const uint32_t *__restrict__ brow, const uint32_t *__restrict__ bbstart,
-    const uint64_t *__restrict__ pkey, const uint32_t *__restrict__ pbstart, uint32_t pn, uint32_t P, uint32_t nranges,
+    const uint64_t *__restrict__ pkey, const uint32_t *__restrict__ pbs, uint32_t nrs, uint32_t pn, uint32_t P, uint32_t nranges,
     uint32_t ranges_per_item, uint32_t slots, uint32_t *__restrict__ mpart) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lj_smem[];
   LjSlot *tab = (LjSlot *)lj_smem;
@@ -728,33 +732,97 @@ __global__ __launch_bounds__(LJ_WG) void lds_join_probe_kernel(
   };
   const int lane = lane_id();
   const uint32_t r1 = min(nranges, (g + 1) * ranges_per_item);
-  // a wave takes LJ_Q slivers at a time (their first 128 rows: 2 x LJ_Q independent loads in flight per lane);
-  // the few slivers longer than 128 rows finish in the tail loop
-  for (uint32_t r = g * ranges_per_item + LJ_Q * wave_id(); r < r1; r += LJ_Q * LJ_WAVES) {
-    uint32_t lo[LJ_Q], hi[LJ_Q];
-    uint64_t k[2 * LJ_Q];
+  // Round 6.  A wave takes the bucket's slivers of 64 CONSECUTIVE ranges per round: their bounds arrive with two coalesced
+  // loads (bucket-major starts; before: two dependent 4-byte loads per sliver, each its own cache line) and are handed out
+  // with v_readlane.  The slivers are probed Q at a time, software-pipelined: the keys of trip t + 1 (first 128 rows of
+  // each sliver, 2 Q loads per lane) are in flight while trip t is looked up and stored — the loop was a chain of dependent
+  // latencies (bounds -> keys -> LDS probes -> stores) on 16 waves per CU.  The few slivers longer than 128 rows finish in
+  // a tail loop.
+  for (uint32_t rb = g * ranges_per_item + 64 * wave_id(); rb < r1; rb += 64 * LJ_WAVES) {
+    const uint32_t ns = min(64u, r1 - rb); // (uniform)
+    const uint32_t rr = rb + min((uint32_t)lane, ns - 1);
+    const uint32_t lo_l = pbs[(size_t)b * nrs + rr];
+    const uint32_t hi_l = b + 1 < P ? pbs[(size_t)(b + 1) * nrs + rr] : (uint32_t)min<uint64_t>((uint64_t)(rr + 1) << LJ_RANGE_LOG2, pn);
+    auto bounds = [&](uint32_t sv, uint32_t &lo, uint32_t &hi) { // sliver sv of the round (uniform); past the end: empty
+      const uint32_t sc = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(sv, ns - 1));
+      lo = (uint32_t)__builtin_amdgcn_readlane((int)lo_l, (int)sc);
+      hi = sv < ns ? (uint32_t)__builtin_amdgcn_readlane((int)hi_l, (int)sc) : lo;
+    };
+    auto load = [&](uint32_t c, uint64_t(&k)[2 * Q]) {
 #pragma unroll
-    for (int q = 0; q < LJ_Q; q++) {
-      const uint32_t rr = min(r + q, r1 - 1);
-      lo[q] = pbstart[(size_t)rr * P + b];
-      hi[q] = r + q < r1 ? pbstart[(size_t)rr * P + b + 1] : lo[q];
+      for (int q = 0; q < Q; q++) {
+        uint32_t lo, hi;
+        bounds(c * Q + q, lo, hi);
+#pragma unroll
+        for (int h = 0; h < 2; h++) { // unconditional loads: lanes past the sliver re-read its first row (or row 0)
+          const uint32_t i = lo + h * 64 + lane;
+          k[2 * q + h] = __builtin_nontemporal_load(pkey + (i < hi ? i : min(lo, pn - 1)));
+        }
+      }
+    };
+    // (the lookups of a trip batched — all first slot reads in flight, unresolved keys advancing one step per round — were
+    //  measured SLOWER, 0.73 against 0.54 ms: the resolved keys' re-reads and the registers cost more than the chain saves)
+    auto work = [&](uint32_t c, const uint64_t(&k)[2 * Q]) {
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        uint32_t lo, hi;
+        bounds(c * Q + q, lo, hi);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const uint32_t i = lo + h * 64 + lane;
+#if LJ_DBG == 1 // (measurement: no LDS lookups)
+          if (i < hi) __builtin_nontemporal_store((uint32_t)k[2 * q + h], mpart + i);
+#elif LJ_DBG == 2 // (measurement: no stores)
+          if (i < hi && lookup(k[2 * q + h]) == 12345u) mpart[i] = 0;
+#else
+          if (i < hi) __builtin_nontemporal_store(lookup(k[2 * q + h]), mpart + i);
+#endif
+        }
+        for (uint32_t i = lo + 128 + lane; i < hi; i += 64) mpart[i] = lookup(pkey[i]);
+      }
+    };
+    const uint32_t nc = (ns + Q - 1) / Q;
+    uint64_t ka[2 * Q], kb[2 * Q];
+    load(0, ka);
+    for (uint32_t c = 0; c < nc; c += 2) {
+      if (c + 1 < nc) load(c + 1, kb);
+      work(c, ka);
+      if (c + 2 < nc) load(c + 2, ka);
+      if (c + 1 < nc) work(c + 1, kb);
     }
-    // a sliver has 64 rows on average (Poisson: almost half of them have a few more), so its first 128 rows are
-    // loaded at once — a dependent second load per sliver was 4 extra HBM latencies per trip
-#pragma unroll
-    for (int q = 0; q < 2 * LJ_Q; q++) { // unconditional loads: lanes past the sliver re-read its first row (or row 0)
-      const uint32_t i = lo[q >> 1] + (q & 1) * 64 + lane;
-      k[q] = __builtin_nontemporal_load(pkey + (i < hi[q >> 1] ? i : min(lo[q >> 1], pn - 1)));
-    }
-#pragma unroll
-    for (int q = 0; q < 2 * LJ_Q; q++) {
-      const uint32_t i = lo[q >> 1] + (q & 1) * 64 + lane;
-      if (i < hi[q >> 1]) __builtin_nontemporal_store(lookup(k[q]), mpart + i);
-    }
-#pragma unroll
-    for (int q = 0; q < LJ_Q; q++)
-      for (uint32_t i = lo[q] + 128 + lane; i < hi[q]; i += 64) mpart[i] = lookup(pkey[i]);
   }
+}
+
+// Uniqueness of the build keys, bucket by bucket, on the same LDS tables (round 6): a build side that takes this route
+// never needs the global 16-byte-slot table (32 MiB memset + 1e6 random CAS inserts = 0.13 ms for 1e6 keys, a twelfth of
+// the C3 sparse-key join) — but `unique` was a by-product of building it.  One workgroup per bucket inserts the bucket's
+// keys exactly as the probe kernel does and then looks every key up again: the FIRST slot of a key's probe sequence that
+// holds an equal key is the same for all rows that carry the key, so of two rows with one key at least one finds a row
+// other than itself.
+__global__ __launch_bounds__(LJ_WG) void lds_join_unique_kernel(const uint64_t *__restrict__ bkey, const uint32_t *__restrict__ brow,
+                                                                const uint32_t *__restrict__ bbstart, uint32_t slots,
+                                                                unsigned int *__restrict__ dup) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lu_smem[];
+  LjSlot *tab = (LjSlot *)lu_smem;
+  const uint32_t b = blockIdx.x, mask = slots - 1;
+  for (uint32_t s = threadIdx.x; s < slots; s += LJ_WG) tab[s].row1 = 0;
+  __syncthreads();
+  const uint32_t b0 = bbstart[b], b1 = bbstart[b + 1];
+  for (uint32_t i = b0 + threadIdx.x; i < b1; i += LJ_WG) {
+    const uint64_t k = bkey[i];
+    uint32_t s = (uint32_t)mix64(k) & mask;
+    while (atomicCAS(&tab[s].row1, 0u, brow[i] + 1u) != 0u) s = (s + 1) & mask;
+    tab[s].key = k;
+  }
+  __syncthreads();
+  bool bad = false;
+  for (uint32_t i = b0 + threadIdx.x; i < b1; i += LJ_WG) {
+    const uint64_t k = bkey[i];
+    uint32_t s = (uint32_t)mix64(k) & mask;
+    while (!(tab[s].row1 && tab[s].key == k)) s = (s + 1) & mask; // (the key is in the table: terminates)
+    bad |= tab[s].row1 != brow[i] + 1u;
+  }
+  if (__ballot(bad) && lane_id() == 0) atomicOr(dup, 1u);
 }
 
 // probe 3: un-permute one range through LDS and compact it (see above).  8 worker waves + the scan wave.
@@ -1369,6 +1437,7 @@ static NKeys composite_probe_keys(sqlrs_hash_join *j, const std::function<const 
 }
 
 static void build_hash_table(sqlrs_hash_join *j);
+static bool lds_build_first(sqlrs_hash_join *j);
 // The direct-address build's verdict (dense_pack_count_kernel: st[0 .. 35)) -> the join's state; what is not a unique dense
 // key set goes on to the general table.  `h`: the words when the caller has fetched them already (with its own answer, in
 // one round trip), else they are fetched here.
@@ -1409,6 +1478,7 @@ static void dense_resolve(sqlrs_hash_join *j, const uint64_t *h = nullptr) {
     }
   }
   if (j->lazy_table) return; // built by hash_join_ensure_table when something probes it
+  if (lds_build_first(j)) return; // general keys on LDS tables: uniqueness from there, the global table on first need only
   build_hash_table(j);
 }
 static void build_table(sqlrs_hash_join *j) {
@@ -1566,6 +1636,7 @@ static void build_table(sqlrs_hash_join *j) {
     }
   }
   if (j->lazy_table) return; // built by hash_join_ensure_table when something probes it
+  if (lds_build_first(j)) return; // general keys on LDS tables: uniqueness from there, the global table on first need only
   build_hash_table(j);
 }
 
@@ -1629,6 +1700,63 @@ struct LdsJoinMatch {
   bool ok = false;
   BufP idx, mpart; // u32[n] each: original row, build row | DENSE_EMPTY
 };
+// the build keys in bucket order + the LDS table size of the fullest bucket, once per join (lds_slots = 0: not this route)
+constexpr uint32_t LJ_P = 512;
+static void lds_join_prepare(sqlrs_hash_join *j) {
+  if (j->lds_build) return;
+  Ctx *ctx = j->ctx;
+  const uint32_t P = LJ_P;
+  auto pr = std::make_shared<PartitionedRows>();
+  PartitionInput bin;
+  bin.keys = j->bkeys->as<uint64_t>();
+  bin.n = j->nB;
+  bin.nv = 0;
+  bin.build_side = true;
+  j->lds_slots = 0;
+  j->lds_build = pr; // (remembered either way: do not try again)
+  if (!partition_rows(ctx, bin, P, pr.get()) || pr->P != P || !pr->idx || pr->pack.kbits) return;
+  uint32_t maxb = 0;
+  for (uint32_t bkt = 0; bkt < P; bkt++) maxb = std::max(maxb, pr->bstart_host[bkt + 1] - pr->bstart_host[bkt]);
+  // load <= 1/2 in the fullest bucket.  (Round 6 tried <= 0.7, which puts C3's 1e6 build keys — 1953 per bucket, the fullest
+  // ~2090 — on 4096-slot tables, two workgroups per CU instead of one: probe pass 0.54 -> 0.81 ms.  A wave's lookup takes as
+  // long as the longest probe sequence among its 64 lanes, and that length, not the number of resident waves, sets the pace:
+  // without any lookup the pass takes 0.38 ms.  SQLRS_LJ_LOAD = percent, read once per join.)
+  const char *ld_e = std::getenv("SQLRS_LJ_LOAD");
+  const uint32_t pct = ld_e ? (uint32_t)std::min(90, std::max(10, std::atoi(ld_e))) : 50;
+  uint32_t slots = 1024;
+  while ((uint64_t)slots * pct < 100ull * maxb) slots <<= 1;
+  j->lds_slots = slots <= 8192 ? slots : 0; // (8192 x 16 B = 128 KiB: one workgroup per CU)
+}
+// A build side that will be probed on LDS tables establishes `unique` there (lds_join_unique_kernel) and leaves the global
+// table unbuilt (`table_built` stays false: hash_join_ensure_table builds it when a probe cannot take the route — a small
+// batch, NULL probe keys, a Right / Full join never get here).  false: not such a build side, or its keys are not unique.
+// SQLRS_LDS_FIRST=0 (read per call): the table first, as before round 6.
+static bool lds_build_first(sqlrs_hash_join *j) {
+  Ctx *ctx = j->ctx;
+  const char *env_e = std::getenv("SQLRS_LDS_JOIN"), *first_e = std::getenv("SQLRS_LDS_FIRST");
+  const int env = env_e ? std::atoi(env_e) : -1;
+  const bool outer_right = j->join_type == SQLRS_JOIN_RIGHT || j->join_type == SQLRS_JOIN_FULL;
+  if (env == 0 || (first_e && std::atoi(first_e) == 0) || outer_right || j->lazy_table || !j->exact || j->bkeys_validity || !j->bkeys ||
+      j->nB < 2 || j->nB > (1ll << 24))
+    return false;
+  if (env != 1 && j->nB < (1 << 18)) return false;
+  lds_join_prepare(j);
+  if (!j->lds_slots || !j->lds_build->key) return false;
+  const PartitionedRows &bp = *j->lds_build;
+  BufP dup = ctx->alloc_zero(8);
+  {
+    ProfScope ps(ctx, "join_build_lds_unique");
+    allow_big_lds(ctx, lds_join_unique_kernel, 136 * 1024);
+    lds_join_unique_kernel<<<dim3(LJ_P), dim3(LJ_WG), (size_t)j->lds_slots * sizeof(LjSlot), ctx->stream>>>(
+        bp.key->as<uint64_t>(), bp.idx->as<uint32_t>(), bp.bstart->as<uint32_t>(), j->lds_slots, dup->as<unsigned int>());
+    SQ_HIP(hipGetLastError());
+  }
+  if (ctx->fetch_value(dup->as<unsigned int>()) != 0) return false; // duplicates: the general table (CSR chains)
+  j->unique = true;
+  j->unique_known = true;
+  j->lds_first = true;
+  return true;
+}
 static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
   Ctx *ctx = j->ctx;
   LdsJoinMatch out;
@@ -1637,33 +1765,19 @@ static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
   const int env = env_e ? std::atoi(env_e) : -1;
   if (env == 0 || !j->exact || pk.validity || j->bkeys_validity || !j->bkeys || nB < 2 || n > 0xffffffffll) return out;
   if (env != 1 && (nB < (1 << 18) || n < (1 << 22) || n < 8 * nB)) return out;
-  const uint32_t P = 512;
-  if (!j->lds_build) { // build keys in bucket order, once per join
-    auto pr = std::make_shared<PartitionedRows>();
-    PartitionInput bin;
-    bin.keys = j->bkeys->as<uint64_t>();
-    bin.n = nB;
-    bin.nv = 0;
-    bin.build_side = true;
-    j->lds_slots = 0;
-    j->lds_build = pr; // (remembered either way: do not try again)
-    if (!partition_rows(ctx, bin, P, pr.get()) || pr->P != P || !pr->idx || pr->pack.kbits) return out;
-    uint32_t maxb = 0;
-    for (uint32_t bkt = 0; bkt < P; bkt++) maxb = std::max(maxb, pr->bstart_host[bkt + 1] - pr->bstart_host[bkt]);
-    uint32_t slots = 1024;
-    while (slots < 2 * maxb) slots <<= 1; // load <= 1/2 in the fullest bucket
-    j->lds_slots = slots <= 8192 ? slots : 0; // (8192 x 16 B = 128 KiB: one workgroup per CU)
-  }
+  lds_join_prepare(j);
+  const uint32_t P = LJ_P;
   if (!j->lds_slots || !j->lds_build->key) return out;
   const PartitionedRows &bp = *j->lds_build;
   const uint32_t nranges = (uint32_t)ceil_div(n, LJ_RANGE);
-  BufP pkey = ctx->alloc(8 * (size_t)n + 16), pbstart = ctx->alloc(4 * ((size_t)nranges * P + 1));
+  const uint32_t nrs = (uint32_t)round_up((size_t)nranges, 64) + 64; // row stride of the bucket-major sliver starts
+  BufP pkey = ctx->alloc(8 * (size_t)n + 16), pbstart = ctx->alloc(4 * (size_t)nrs * P);
   out.idx = ctx->alloc(4 * (size_t)n + 16);
   {
     ProfScope ps(ctx, "join_partition_lds");
     allow_big_lds(ctx, lds_join_partition_kernel, 112 * 1024);
     lds_join_partition_kernel<<<dim3(nranges), dim3(LJ_WG), (size_t)LP_STAGE * 12, ctx->stream>>>(
-        pk.keys->as<uint64_t>(), n, P, pkey->as<uint64_t>(), out.idx->as<uint32_t>(), pbstart->as<uint32_t>());
+        pk.keys->as<uint64_t>(), n, P, pkey->as<uint64_t>(), out.idx->as<uint32_t>(), pbstart->as<uint32_t>(), nrs);
     SQ_HIP(hipGetLastError());
   }
   // ranges per work item: one LDS table build (~2 K inserts) per rpi x ~64 probe rows
@@ -1674,10 +1788,10 @@ static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
   {
     ProfScope ps(ctx, "join_probe_lds");
     const size_t lds = (size_t)j->lds_slots * sizeof(LjSlot);
-    allow_big_lds(ctx, lds_join_probe_kernel, 112 * 1024);
-    lds_join_probe_kernel<<<dim3(P * ngroups), dim3(LJ_WG), lds, ctx->stream>>>(
+    allow_big_lds(ctx, lds_join_probe_kernel<LJ_Q>, 136 * 1024);
+    lds_join_probe_kernel<LJ_Q><<<dim3(P * ngroups), dim3(LJ_WG), lds, ctx->stream>>>(
         bp.key->as<uint64_t>(), bp.idx->as<uint32_t>(), bp.bstart->as<uint32_t>(), pkey->as<uint64_t>(),
-        pbstart->as<uint32_t>(), (uint32_t)n, P, nranges, rpi, j->lds_slots, out.mpart->as<uint32_t>());
+        pbstart->as<uint32_t>(), nrs, (uint32_t)n, P, nranges, rpi, j->lds_slots, out.mpart->as<uint32_t>());
     SQ_HIP(hipGetLastError());
   }
   out.ok = true;
@@ -1746,7 +1860,12 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
       p = Pairs();
     }
   }
-  hash_join_ensure_table(j);
+  // a build side whose uniqueness came from its LDS bucket tables (lds_build_first) has no global table yet: it is built
+  // only when this batch cannot take the LDS route
+  LdsJoinMatch lm;
+  dense_resolve(j);
+  if (j->lds_first && !j->table_built && j->unique && !outer_right && !j->dense && n > 0) lm = lds_join_match(j, pk);
+  if (!lm.ok) hash_join_ensure_table(j);
   if (n == 0) {
     p.left = ctx->alloc(8);
     p.right = ctx->alloc(8);
@@ -1755,8 +1874,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   if (n > 0xffffffffll) fail(SQLRS_ERR_INTERNAL, "probe batch larger than 2^32 rows");
   dim3 g((unsigned)ceil_div(n, BLOCK)), b(BLOCK);
   // general keys, build side beyond an L2-resident table: LDS tables over a blocked partition (see lds_join_probe_kernel)
-  LdsJoinMatch lm;
-  if (j->unique && !outer_right && !j->dense) lm = lds_join_match(j, pk);
+  if (!lm.ok && j->unique && !outer_right && !j->dense) lm = lds_join_match(j, pk);
   if (j->unique && !outer_right) { // one lookup per row, compaction with look-back
     int64_t tiles = ceil_div(n, lm.ok ? LJ_RANGE : (j->dense ? JD_TILE : JP_TILE));
     p.left = ctx->alloc(8 * (size_t)n);

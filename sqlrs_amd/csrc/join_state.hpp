@@ -74,6 +74,9 @@ struct sqlrs_hash_join {
   // that takes the route; lds_slots = 0: the route does not apply to this build side
   std::shared_ptr<sq::PartitionedRows> lds_build;
   uint32_t lds_slots = 0;
+  // round 6: `unique` established on the LDS bucket tables (lds_build_first); the global table is not built until a
+  // probe batch that cannot take the LDS route asks for it (`table_built` stays false until then)
+  bool lds_first = false;
 };
 
 // builds the deferred hash table of a `lazy_table` join (join.hip); no-op otherwise

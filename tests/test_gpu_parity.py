@@ -311,6 +311,42 @@ def test_hash_join_lds_tables_f64_keys_and_fallbacks(hip, oracle, monkeypatch):
         assert_same(rows_of(got), rows_of(exp))
 
 
+@pytest.mark.parametrize("first", ["1", "0"])
+def test_hash_join_lds_route_builds_no_global_table(hip, oracle, monkeypatch, first):
+    """Round 6: a build side that is probed on LDS bucket tables takes `unique` from those tables (lds_join_unique_kernel) and
+    never builds the global 16-byte-slot table — until a probe batch that cannot take the route (here: NULL probe keys)
+    asks for it.  Same pairs as the oracle either way, and as with SQLRS_LDS_FIRST=0 (the table first, as before)."""
+    monkeypatch.setenv("SQLRS_LDS_JOIN", "1")
+    monkeypatch.setenv("SQLRS_LDS_FIRST", first)
+    rng = np.random.default_rng(23)
+    nb, npr = 30_000, 500_000
+    A = np.int64(0x9E3779B97F4A7C15 - (1 << 64))
+    with np.errstate(over="ignore"):
+        bk = rng.permutation(2 * nb)[:nb].astype(np.int64) * A + np.int64(5)
+        pk = rng.integers(0, 3 * nb, npr, dtype=np.int64) * A + np.int64(5)
+    lb = pa.RecordBatch.from_arrays([pa.array(bk), pa.array(np.arange(nb, dtype=np.int64))], names=["c0", "c1"])
+    plain = pa.RecordBatch.from_arrays([pa.array(pk), pa.array(rng.random(npr))], names=["c0", "c1"])
+    nulls = pa.RecordBatch.from_arrays([pa.array(pk[:50_000], mask=rng.random(50_000) < 0.1), pa.array(rng.random(50_000))], names=["c0", "c1"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, plain)
+    for rbs, table_builds in (([plain, plain.slice(1000, 200_000)], 0), ([plain, nulls, plain.slice(7, 100_000)], 1)):
+        hip.profile(True)
+        got = list(HashJoinExecutor(hip, [lb], rbs, "inner", cond, sch, 2).execute())
+        prof = hip.profile_read()
+        hip.profile(False)
+        if first == "1":
+            assert prof.get("join_build_lds_unique", (0, 0))[1] == 1, prof
+            assert prof.get("join_build", (0, 0))[1] == table_builds, prof
+        else:
+            assert prof.get("join_build_lds_unique", (0, 0))[1] == 0 and prof.get("join_build", (0, 0))[1] == 1, prof
+        assert prof.get("join_probe_lds", (0, 0))[1] == len(rbs) - table_builds, prof
+        exp = list(HashJoinExecutor(oracle, [lb], rbs, "inner", cond, sch, 2).execute())
+        assert [b.num_rows for b in got] == [b.num_rows for b in exp]
+        for g, e in zip(got, exp):
+            for c in range(g.num_columns):
+                assert g.column(c).equals(e.column(c)), c
+
+
 @pytest.mark.parametrize("hit", ["all", "some", "none"])
 @pytest.mark.parametrize("batches", [1, 2])
 @pytest.mark.parametrize("fill", ["full_range", "gaps"])

@@ -7,7 +7,8 @@ import sqlrs_amd
 from sqlrs_amd import abi, datagen
 from sqlrs_amd.expr import InputRef
 from bench import device_batch
-dev = torch.device("cuda", 0); be = sqlrs_amd.new_ctx(0)
+dev = torch.device("cuda", 0)
+be = abi.Backend(os.environ["LIB"], "sqlrs_", 0) if os.environ.get("LIB") else sqlrs_amd.new_ctx(0)
 nP, nB = int(float(os.environ.get("NP", 1e8))), int(float(os.environ.get("NB", 1e6)))
 A_s = 0x9E3779B97F4A7C15 - (1 << 64)
 dk = datagen.fill_chunks(torch.empty(nB, dtype=torch.int64, device=dev), lambda i: datagen.dim_key_t(i, nB)) * A_s + 12345
@@ -34,3 +35,18 @@ for rep in range(int(os.environ.get("REPS", 2))):
         be.profile(True); probe(); pr = be.profile_read(); be.profile(False)
         be.fn("hash_join_destroy")(j)
         print(f"{VAR}={val:>4}: pairs {m}  probe {ms:6.3f} ms | " + " ".join(f"{k} {v[0]:.3f}" for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0]) if v[0] > 0.01), flush=True)
+# BOTH=1: build + probe timed and profiled together (what the bench leg's ms_build_probe covers)
+if os.environ.get("BOTH") == "1":
+    def both():
+        j = C.c_void_p()
+        be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, lk, rk, None, 1, rd, C.byref(j)))
+        be.check(be.fn("hash_join_build_push")(j, db.ptr)); be.check(be.fn("hash_join_build_finish")(j))
+        o = C.POINTER(abi.Batch)()
+        be.check(be.fn("hash_join_probe_indices")(j, fb.ptr, abi.MEM_DEVICE, C.byref(o)))
+        be.fn("batch_release")(o); be.fn("hash_join_destroy")(j)
+    for _ in range(3): both()
+    be.synchronize(); t = time.perf_counter()
+    for _ in range(5): both()
+    be.synchronize(); ms = (time.perf_counter() - t) * 200
+    be.profile(True); both(); pr = be.profile_read(); be.profile(False)
+    print(f"build + probe {ms:6.3f} ms | " + " ".join(f"{k} {v[0]:.3f}" for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0]) if v[0] > 0.002), flush=True)
