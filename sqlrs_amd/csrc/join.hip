@@ -408,6 +408,12 @@ __global__ __launch_bounds__(256) void join_probe_dense_allhit_kernel(const uint
 // of non-temporal ones 12 % slower, LDS-DMA keys 12 % slower, the grid makes no difference from 1024 blocks on).
 typedef unsigned long long u64x2_vec __attribute__((ext_vector_type(2)));
 constexpr int JAP_ROWS = 512; // rows per wave and trip
+#ifndef JAP_DBG
+#define JAP_DBG 0
+#endif
+#ifndef JAP_GRID
+#define JAP_GRID 32
+#endif
 template <bool VEC2>
 __global__ __launch_bounds__(256) void join_probe_dense_allhit_packed_kernel(const uint64_t *__restrict__ keys, int64_t n, DenseTable dt,
                                                                              uint64_t *__restrict__ left_idx,
@@ -422,6 +428,7 @@ __global__ __launch_bounds__(256) void join_probe_dense_allhit_packed_kernel(con
   const uint32_t bits = dt.bits, pmask = dt.pmask, range = (uint32_t)dt.range, pad = range + 1; // (pad: always empty; never `range`, the NULL row's)
   const uint64_t kmin = dt.kmin;
   bool bad = false;
+  uint32_t hmax = 0; // (an empty entry is all ones = the largest value an entry takes: one max per entry, one compare at the end)
   for (int64_t c = gw; c < nchunks; c += nw) {
     if (VEC2) {
       const int64_t r0 = c * JAP_ROWS + 2 * lane;
@@ -432,13 +439,20 @@ __global__ __launch_bounds__(256) void join_probe_dense_allhit_packed_kernel(con
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const uint64_t d0 = k[g].x - kmin, d1 = k[g].y - kmin;
+#if JAP_DBG & 1
+        h[2 * g] = dense_packed_raw(tab, bits, pmask, (uint32_t)d0);
+        h[2 * g + 1] = dense_packed_raw(tab, bits, pmask, (uint32_t)d1);
+#else
         h[2 * g] = dense_packed_raw(tab, bits, pmask, d0 < range ? (uint32_t)d0 : pad);
         h[2 * g + 1] = dense_packed_raw(tab, bits, pmask, d1 < range ? (uint32_t)d1 : pad);
+#endif
       }
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const int64_t r = r0 + g * 128;
-        bad |= (h[2 * g] == pmask) | (h[2 * g + 1] == pmask);
+#if !(JAP_DBG & 2)
+        hmax = max(hmax, max(h[2 * g], h[2 * g + 1]));
+#endif
         u64x2_vec lv;
         lv.x = h[2 * g];
         lv.y = h[2 * g + 1];
@@ -458,7 +472,7 @@ __global__ __launch_bounds__(256) void join_probe_dense_allhit_packed_kernel(con
       }
 #pragma unroll
       for (int g = 0; g < 8; g++) {
-        bad |= h[g] == pmask;
+        hmax = max(hmax, h[g]);
         __builtin_nontemporal_store((uint64_t)h[g], left_idx + r0 + g * 64);
         __builtin_nontemporal_store((uint32_t)(r0 + g * 64), right_idx + r0 + g * 64);
       }
@@ -472,6 +486,7 @@ __global__ __launch_bounds__(256) void join_probe_dense_allhit_packed_kernel(con
       left_idx[r] = h;
       right_idx[r] = (uint32_t)r;
     }
+  bad |= hmax == pmask;
   if (__ballot(bad) && lane == 0) atomicOr(miss, 1u);
 }
 
@@ -1046,8 +1061,15 @@ __device__ __forceinline__ bool dense_table_from_device(DenseTable &dt) {
   dt.range = d.range;
   return d.ok && nulls <= 1 && occupied + nulls == dt.st_rows; // (what the host decides on the same words, dense_resolve)
 }
+// `init4` (optional, round 6): the direct-address table of the LARGEST admissible range is set to "empty" by this launch too
+// — the build of a small dimension is a chain of launch-bound kernels (7 + 3 + 20 + 11 us of work behind ~5 us of launch
+// each), and a table of <= 32 MiB is written faster than a separate launch is issued
 __global__ __launch_bounds__(256) void key_minmax_inv_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
-                                                             int64_t n, unsigned long long *st) {
+                                                             int64_t n, unsigned long long *st, uint4 *__restrict__ init4, int64_t init_n4) {
+  if (init4) {
+    const uint4 e = make_uint4(DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY);
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < init_n4; i += (int64_t)gridDim.x * 256) init4[i] = e;
+  }
   unsigned long long lo = ~0ull, hi = 0;
   constexpr int KU = 8;
   for (int64_t base = blockIdx.x * (int64_t)(256 * KU) + threadIdx.x; base < n; base += (int64_t)gridDim.x * (256 * KU)) {
@@ -1093,22 +1115,33 @@ __global__ __launch_bounds__(256) void dense_init_dev_kernel(const unsigned long
   const uint4 e = make_uint4(DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY);
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) heads4[i] = e;
 }
+constexpr int DENSE_FILL_U = 4; // build rows per thread (independent key loads / table stores in flight)
 __global__ __launch_bounds__(256) void dense_fill_dev_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
                                                              int64_t n, const unsigned long long *__restrict__ st, uint64_t max_range,
                                                              uint32_t *__restrict__ heads, unsigned long long *counts /* st + 2 DENSE_MM */) {
   const DenseDev d = dense_dev(st, max_range);
   if (!d.ok) return;
-  const int64_t r = blockIdx.x * 256ll + threadIdx.x;
-  if (r >= n) return;
-  if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) {
-    heads[d.range] = (uint32_t)r; // the spare slot behind the table (unique build keys: at most one NULL row)
-    atomicAdd(counts + 1, 1ull);
-    return;
+  const int64_t r0 = blockIdx.x * (256ll * DENSE_FILL_U) + threadIdx.x;
+  uint64_t k[DENSE_FILL_U];
+#pragma unroll
+  for (int u = 0; u < DENSE_FILL_U; u++) k[u] = keys[min(r0 + u * 256, n - 1)];
+#pragma unroll
+  for (int u = 0; u < DENSE_FILL_U; u++) {
+    const int64_t r = r0 + u * 256;
+    if (r >= n) continue;
+    if (validity && !((validity[r >> 6] >> (r & 63)) & 1)) {
+      heads[d.range] = (uint32_t)r; // the spare slot behind the table (unique build keys: at most one NULL row)
+      atomicAdd(counts + 1, 1ull);
+      continue;
+    }
+    heads[k[u] - d.kmin] = (uint32_t)r;
   }
-  heads[keys[r] - d.kmin] = (uint32_t)r;
 }
 // lane t of the grid owns entries [32 t, 32 t + 32): `bits` whole dwords of the packed table; counts the occupied slots
 // of [0, range) on the way (what dense_count_kernel does) and leaves the NULL row's head where the host fetches it
+// (Round 6 measured a form that stages a block's 8192 entries and its packed dwords through LDS — coalesced both ways —
+//  at 15.9 us against this one's 11.0 for a 1e6-entry range: the range fills 122 blocks, and two barriers per trip cost more
+//  there than the strided 16-byte loads.)
 __global__ __launch_bounds__(256) void dense_pack_count_kernel(const uint32_t *__restrict__ heads, const unsigned long long *__restrict__ st,
                                                                uint64_t max_range, uint32_t bits, uint32_t *__restrict__ packed,
                                                                unsigned long long *counts /* st + 2 DENSE_MM */) {
@@ -1536,7 +1569,11 @@ static void build_table(sqlrs_hash_join *j) {
   //    first: when the build keys turn out unique nothing else is needed, and the 16-byte-slot
   //    hash table (1.1 ms for 1e7 keys) is never built.
   const char *db1_e = std::getenv("SQLRS_DENSE_BUILD_ONE_FETCH"); // A/B hook, read per call (0 = the two-fetch sequence below)
-  if (j->exact && n > 0 && n <= (1ll << 24) && j->key_dtype != SQLRS_FLOAT64 && !(db1_e && std::atoi(db1_e) == 0)) {
+  // (the one-fetch form allocates the table of the LARGEST admissible range before it has looked at a key: only while that
+  //  stays under 1 GiB — advisor r05; beyond, the two-fetch sequence below sizes the table from the range it has seen)
+  const uint64_t spk1 = j->lazy_table ? dense_slots_per_key_owned() : 4;
+  if (j->exact && n > 0 && n <= (1ll << 24) && 4 * (spk1 * (uint64_t)n + 1024) <= (1ull << 30) && j->key_dtype != SQLRS_FLOAT64 &&
+      !(db1_e && std::atoi(db1_e) == 0)) {
     // one fetch (see dense_pack_count_kernel): the table is sized for the largest range that takes the route
     ProfScope ps(ctx, "join_build_dense");
     const char *pj_e = std::getenv("SQLRS_DENSE_JOIN_SLOTS_PLAIN"); // tuning hook, read per call
@@ -1553,11 +1590,15 @@ static void build_table(sqlrs_hash_join *j) {
     const uint64_t *vp = validity ? validity->as<uint64_t>() : nullptr;
     unsigned long long *stp = st->as<unsigned long long>();
     const unsigned mblocks = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 8), 4 * (int64_t)ctx->num_cus);
-    key_minmax_inv_kernel<<<dim3(mblocks), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n, stp);
-    const unsigned iblocks = (unsigned)std::min<int64_t>(ceil_div((int64_t)max_range + 2, 256 * 4 * 4), 4 * (int64_t)ctx->num_cus);
-    dense_init_dev_kernel<<<dim3(iblocks), dim3(256), 0, ctx->stream>>>(stp, max_range, dense->as<uint4>());
-    dense_fill_dev_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n, stp, max_range,
-                                                                                          dense->as<uint32_t>(), stp + 2 * DENSE_MM);
+    const bool init_fused = max_range + 2 <= (8ull << 20); // (entries: <= 32 MiB of table)
+    key_minmax_inv_kernel<<<dim3(mblocks), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n, stp, init_fused ? dense->as<uint4>() : nullptr,
+                                                                        (int64_t)((max_range + 2 + 3) / 4));
+    if (!init_fused) {
+      const unsigned iblocks = (unsigned)std::min<int64_t>(ceil_div((int64_t)max_range + 2, 256 * 4 * 4), 4 * (int64_t)ctx->num_cus);
+      dense_init_dev_kernel<<<dim3(iblocks), dim3(256), 0, ctx->stream>>>(stp, max_range, dense->as<uint4>());
+    }
+    dense_fill_dev_kernel<<<dim3((unsigned)ceil_div(n, 256 * DENSE_FILL_U)), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n, stp, max_range,
+                                                                                                         dense->as<uint32_t>(), stp + 2 * DENSE_MM);
     if (bits) {
       const unsigned pblocks = (unsigned)std::min<int64_t>(ceil_div(ceil_div((int64_t)max_range + 2, 32), 256), 8 * (int64_t)ctx->num_cus);
       dense_pack_count_kernel<<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(dense->as<uint32_t>(), stp, max_range, bits,
@@ -1840,7 +1881,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
       const int64_t every = std::max<int64_t>(1, n >> 14); // ~16 K sampled rows
       join_probe_dense_sample_kernel<<<dim3((unsigned)ceil_div(ceil_div(n, every), 256)), dim3(256), 0, ctx->stream>>>(
           pk.keys->as<uint64_t>(), n, every, dt, miss);
-      const unsigned pblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / JAP_ROWS, 4), 32 * (int64_t)ctx->num_cus));
+      const unsigned pblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / JAP_ROWS, 4), JAP_GRID * (int64_t)ctx->num_cus));
       if (((uintptr_t)pk.keys->p & 15) == 0)
         join_probe_dense_allhit_packed_kernel<true><<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, dt, p.left->as<uint64_t>(),
                                                                                                p.right->as<uint32_t>(), miss);
@@ -1897,7 +1938,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
             pk.keys->as<uint64_t>(), n, every, dt, miss);
         const char *sc_e = std::getenv("SQLRS_PROBE_ALLHIT_SC1"); // A/B hook, read per call
         if (dt.packed) { // wave-contiguous chunks over the bit-packed table
-          const unsigned pblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / JAP_ROWS, 4), 32 * (int64_t)ctx->num_cus));
+          const unsigned pblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / JAP_ROWS, 4), JAP_GRID * (int64_t)ctx->num_cus));
           if (((uintptr_t)pk.keys->p & 15) == 0)
             join_probe_dense_allhit_packed_kernel<true><<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, dt, p.left->as<uint64_t>(),
                                                                                                    p.right->as<uint32_t>(), miss);

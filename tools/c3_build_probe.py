@@ -7,7 +7,7 @@ import bench, sqlrs_amd
 from sqlrs_amd import abi, datagen
 from sqlrs_amd.expr import InputRef
 dev = torch.device("cuda", 0)
-be = sqlrs_amd.new_ctx(0)
+be = abi.Backend(os.environ["LIB"], "sqlrs_", 0) if os.environ.get("LIB") else sqlrs_amd.new_ctx(0)
 nP, nB = int(float(os.environ.get("NP", 1e8))), int(float(os.environ.get("NB", 1e6)))
 mod = int(os.environ.get("MOD", nB))
 dk = datagen.fill_chunks(torch.empty(nB, dtype=torch.int64, device=dev), lambda i: datagen.dim_key_t(i, nB))
@@ -32,3 +32,38 @@ for _ in range(int(os.environ.get("REPS", 7))):
     ms = C.c_double(); be.check(be.fn("timer_elapsed_ms")(t, C.byref(ms))); best = min(best, ms.value)
 be.fn("timer_destroy")(t)
 print(f"C3 build + probe: {best:.3f} ms = {(8 * nB + 20 * nP) / best / 1e6 / 8000:.4f} of 8 TB/s", flush=True)
+
+# probe alone (the join built once), event-timed + kernel classes
+j = C.c_void_p()
+be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, lk, rk, None, 1, rd, C.byref(j)))
+be.check(be.fn("hash_join_build_push")(j, db.ptr)); be.check(be.fn("hash_join_build_finish")(j))
+def probe():
+    o = C.POINTER(abi.Batch)()
+    be.check(be.fn("hash_join_probe_indices")(j, fb.ptr, abi.MEM_DEVICE, C.byref(o)))
+    be.fn("batch_release")(o)
+probe(); probe(); be.synchronize()
+t = C.c_void_p(); be.check(be.fn("timer_create")(be.ctx, C.byref(t)))
+best = 1e9
+for _ in range(int(os.environ.get("REPS", 7))):
+    be.check(be.fn("timer_start")(t)); probe(); be.check(be.fn("timer_stop")(t))
+    ms = C.c_double(); be.check(be.fn("timer_elapsed_ms")(t, C.byref(ms))); best = min(best, ms.value)
+be.profile(True); probe(); pr = be.profile_read(); be.profile(False)
+print(f"C3 probe alone: {best:.3f} ms | " + " ".join(f"{k} {v[0]:.3f}" for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0]) if v[0] > 0.002), flush=True)
+be.fn("hash_join_destroy")(j)
+# host wall time of every call of one build + probe (the GPU work before the probe kernel is ~45 us: is the host slower?)
+import time
+if os.environ.get("HOSTTIMES", "1") == "1":
+    acc = {}
+    for rep in range(20):
+        be.synchronize()
+        j = C.c_void_p(); o = C.POINTER(abi.Batch)()
+        t0 = time.perf_counter(); be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, lk, rk, None, 1, rd, C.byref(j)))
+        t1 = time.perf_counter(); be.check(be.fn("hash_join_build_push")(j, db.ptr))
+        t2 = time.perf_counter(); be.check(be.fn("hash_join_build_finish")(j))
+        t3 = time.perf_counter(); be.check(be.fn("hash_join_probe_indices")(j, fb.ptr, abi.MEM_DEVICE, C.byref(o)))
+        t4 = time.perf_counter(); be.fn("batch_release")(o); be.fn("hash_join_destroy")(j)
+        t5 = time.perf_counter()
+        if rep >= 5:
+            for k, v in (("create", t1 - t0), ("build_push", t2 - t1), ("build_finish", t3 - t2), ("probe_indices", t4 - t3), ("release+destroy", t5 - t4)):
+                acc.setdefault(k, []).append(v * 1e6)
+    print("host us per call (median): " + ", ".join(f"{k} {sorted(v)[len(v)//2]:.1f}" for k, v in acc.items()), flush=True)
