@@ -64,6 +64,16 @@ struct Pool {
   uint8_t *arena = nullptr;
   size_t arena_bytes = 0, arena_used = 0;
   bool in_arena(const void *p) const { return arena && (const uint8_t *)p >= arena && (const uint8_t *)p < arena + arena_bytes; }
+  // blocks backed through the virtual-memory API (SQLRS_POOL_VMM=1, placement experiment of round 6: one physical handle
+  // per block at the recommended granularity): pointer -> {handle, mapped size}
+  struct VmmBlock {
+    std::vector<hipMemGenericAllocationHandle_t> handles; // equal pieces of `size`
+    size_t size = 0;
+  };
+  std::map<void *, VmmBlock> vmm_blocks;
+  int vmm = -1; // -1: environment not read yet
+  void *vmm_alloc(size_t want);
+  bool vmm_free(void *p); // false: not a VMM block
   void *alloc(size_t bytes, size_t *cap);
   void release(void *p, size_t cap);
   void trim();

@@ -22,6 +22,63 @@ static size_t pool_size_class(size_t bytes) {
   return round_up(bytes, (size_t)2 << 20); // 2 MiB granules
 }
 
+void *Pool::vmm_alloc(size_t want) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) return nullptr;
+  // (one physical handle per block; pieces of 32 MiB ... 1 GiB per handle and 1 / 4 GiB virtual alignment were measured too:
+  //  profiles/r06e_placement.txt — pieces are slower, alignment makes no difference)
+  const size_t chunk = 0, size = round_up(want, gran), align = gran;
+  void *va = nullptr;
+  if (hipMemAddressReserve(&va, size, align, nullptr, 0) != hipSuccess) return nullptr;
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  VmmBlock blk;
+  blk.size = size;
+  const size_t step = chunk ? chunk : size;
+  bool ok = true;
+  for (size_t off = 0; off < size && ok; off += step) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, step, &prop, 0) != hipSuccess) {
+      ok = false;
+      break;
+    }
+    if (hipMemMap((uint8_t *)va + off, step, 0, h, 0) != hipSuccess) {
+      (void)hipMemRelease(h);
+      ok = false;
+      break;
+    }
+    blk.handles.push_back(h);
+  }
+  if (ok && hipMemSetAccess(va, size, &acc, 1) != hipSuccess) ok = false;
+  if (!ok) {
+    for (size_t i = 0; i < blk.handles.size(); i++) {
+      (void)hipMemUnmap((uint8_t *)va + i * step, step);
+      (void)hipMemRelease(blk.handles[i]);
+    }
+    (void)hipMemAddressFree(va, size);
+    return nullptr;
+  }
+  vmm_blocks[va] = std::move(blk);
+  return va;
+}
+bool Pool::vmm_free(void *p) {
+  auto it = vmm_blocks.find(p);
+  if (it == vmm_blocks.end()) return false;
+  const VmmBlock &blk = it->second;
+  const size_t step = blk.size / blk.handles.size();
+  for (size_t i = 0; i < blk.handles.size(); i++) {
+    (void)hipMemUnmap((uint8_t *)p + i * step, step);
+    (void)hipMemRelease(blk.handles[i]);
+  }
+  (void)hipMemAddressFree(p, blk.size);
+  vmm_blocks.erase(it);
+  return true;
+}
 void *Pool::alloc(size_t bytes, size_t *cap) {
   size_t want = pool_size_class(bytes);
   auto it = free_blocks.lower_bound(want);
@@ -41,6 +98,17 @@ void *Pool::alloc(size_t bytes, size_t *cap) {
     live_bytes += want;
     return p;
   }
+  if (vmm < 0) {
+    const char *v = std::getenv("SQLRS_POOL_VMM");
+    vmm = v ? std::atoi(v) : 0;
+  }
+  if (vmm > 0 && want >= ((size_t)vmm << 20)) { // (blocks of SQLRS_POOL_VMM MiB and more)
+    if ((p = vmm_alloc(want))) {
+      *cap = want;
+      live_bytes += want;
+      return p;
+    }
+  }
   hipError_t e = hipMalloc(&p, want);
   if (e != hipSuccess) {
     trim();
@@ -59,7 +127,7 @@ void Pool::release(void *p, size_t cap) {
     int cur = -1;
     (void)hipGetDevice(&cur);
     if (cur != device) (void)hipSetDevice(device);
-    (void)hipFree(p);
+    if (!vmm_free(p)) (void)hipFree(p);
     if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     return;
   }
@@ -73,7 +141,7 @@ void Pool::trim() {
     if (in_arena(kv.second)) { // arena blocks cannot go back to the driver one by one: they stay cached
       keep.emplace(kv.first, kv.second);
       kept += kv.first;
-    } else
+    } else if (!vmm_free(kv.second))
       (void)hipFree(kv.second);
   }
   free_blocks.swap(keep);
