@@ -707,17 +707,32 @@ def main():
     elapsed = el.item()
     ms_per_step = elapsed / args.steps * 1e3
     value = n_fact_total / (elapsed / args.steps) / 1e6
+    # (review r05 #5) the same K steps once more, each timed on its own: median / min / max beside the contract's mean
+    step_times = None
+    if not multi:
+        ts = []
+        for _ in range(args.steps):
+            t_one = time.perf_counter()
+            one_step().release()
+            be.synchronize()
+            ts.append((time.perf_counter() - t_one) * 1e3)
+        ts.sort()
+        step_times = {"median": round(ts[len(ts) // 2], 3), "min": round(ts[0], 3), "max": round(ts[-1], 3), "steps": len(ts),
+                      "note": "K further steps, a stream synchronisation behind each (value / ms_per_step stay the K steps between two barriers)"}
 
     # ---- per-kernel device time (HIP events on the ctx stream), separate profiled steps
     be.profile(True)
     xstat.update(on=multi, exchange_ms=0.0, bytes_off_rank=0)
     torch.cuda.synchronize()
     t_prof = time.perf_counter()
-    for _ in range(2):
+    # (N = 1: as many profiled steps as timed ones, so that `roofline` rests on the MEAN of K launches of the dominant
+    #  kernel — two launches read like the minimum of a rocprofv3 trace; N > 1 keeps two: the exchange statistics are per 2)
+    nprof = 2 if multi else max(2, args.steps)
+    for _ in range(nprof):
         one_step().release()
     torch.cuda.synchronize()
     be.synchronize()
-    prof_step_ms = (time.perf_counter() - t_prof) * 1e3 / 2
+    prof_step_ms = (time.perf_counter() - t_prof) * 1e3 / nprof
     xstat["on"] = False
     prof = be.profile_read()
     be.profile(False)
@@ -770,11 +785,11 @@ def main():
     if rank == 0:
         rows = sorted(prof.items(), key=lambda kv: -kv[1][0])
         tot = sum(v[0] for _, v in rows) or 1.0
-        log("[bench] device time per kernel class (2 profiled steps):")
+        log(f"[bench] device time per kernel class ({nprof} profiled steps):")
         for name, (ms, launches) in rows:
             ab = algorithmic_bytes(name, workload)
             extra = f"  {ab / (ms / launches) / 1e6:8.0f} GB/s algorithmic" if (ab and launches) else ""
-            log(f"    {name:22s} {ms / 2:9.3f} ms/step  {launches // 2:4d} launches/step  {100 * ms / tot:5.1f}%{extra}")
+            log(f"    {name:22s} {ms / nprof:9.3f} ms/step  {launches // nprof:4d} launches/step  {100 * ms / tot:5.1f}%{extra}")
         for name, (ms, launches) in rows:
             ab = algorithmic_bytes(name, workload)
             if ab and launches:
@@ -787,10 +802,16 @@ def main():
                 pipe_gbps = pipe_bytes / ms_per_step / 1e6
                 sb = survey_bytes(name, workload) or ab
                 s_ach = sb / per_launch_ms / 1e6
+                prof_avg_ms, prof_src = profile_average_ms(name, n_fact_total, n_dim_total, world, args)
                 roofline = {"kernel": name, "bound": "hbm", "achieved": round(s_ach, 1), "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": round(s_ach / HBM_PEAK_GBPS, 4),
                             "traffic": traffic, "traffic_source": traffic_src,
-                            "ms_per_launch": round(per_launch_ms, 4), "algorithmic_bytes": int(sb),
+                            "ms_per_launch": round(per_launch_ms, 4), "launches_averaged": int(launches),
+                            # the same fraction from the newest COMMITTED rocprofv3 kernel trace of this command (its average
+                            # duration for the kernel): another box, another day — the two must agree to a few percent
+                            "frac_profile": (round(sb / prof_avg_ms / 1e6 / HBM_PEAK_GBPS, 4) if prof_avg_ms else None),
+                            "ms_per_launch_profile": prof_avg_ms, "profile_source": prof_src,
+                            "algorithmic_bytes": int(sb),
                             "kernel_own_bytes": int(ab), "kernel_own_GBps": round(ach, 1),
                             "kernel_own_frac": round(ach / HBM_PEAK_GBPS, 4),
                             "pipeline_bytes": int(pipe_bytes), "pipeline_GBps": round(pipe_gbps, 1),
@@ -852,6 +873,9 @@ def main():
             # evaluated inside the first partition pass (0 = the operators were composed: the 2.5x slower form)
             "fused_batches": int(pipe.fused_batches), "filter_fused_batches": int(pipe.filter_fused_batches),
         }
+        if step_times:
+            line["ms_per_step_median"] = step_times["median"]
+            line["ms_per_step_each"] = step_times
         if processes:
             line["ms_per_step_processes"] = processes
         if operators:
@@ -910,6 +934,55 @@ def pmc_traffic(kernel, n_fact, n_dim, world, args):
             v = json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
         return v, (f"profiles/{os.path.basename(newest)} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                    "this command on another box; NOT measured in this run)")
+    except (OSError, KeyError, ValueError, IndexError):
+        return None, None
+
+
+def ops_traffic(substrings):
+    """HBM bytes per launch of the named kernels (counter traffic, summed) from the newest committed
+    profiles/*_ops_pmc_traffic.json (tools/profile_round.sh: rocprofv3 --pmc passes of `--operators`), and that file's name."""
+    try:
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_ops_pmc_traffic.json")))[-1]
+        with open(newest) as f:
+            ks = json.load(f)["kernels"]
+        tot, seen = 0, []
+        for sub in substrings:
+            hit = [(k, v) for k, v in ks.items() if sub in k]
+            if not hit:
+                return None, None
+            k, v = max(hit, key=lambda kv: kv[1]["hbm_bytes_per_launch"])
+            tot += int(v["hbm_bytes_per_launch"])
+            seen.append(k.split("(")[0][-48:])
+        return tot, f"profiles/{os.path.basename(newest)}: " + " + ".join(seen) + " (committed counter passes; NOT measured in this run)"
+    except (OSError, KeyError, ValueError, IndexError):
+        return None, None
+
+
+# kernel classes of the profile (ProfScope labels) -> the kernel symbol a rocprofv3 trace lists
+PROFILE_SYMBOL = {"rp_chunk_scatter_filter": "rp_chunk_scatter_", "rp_chunk_scatter": "rp_chunk_scatter_", "rp_scatter": "rp_scatter_",
+                  "lds_agg": "lds_agg_", "filter_cmp_const": "filter_cmp_const"}
+
+
+def profile_average_ms(kernel, n_fact, n_dim, world, args):
+    """(average duration in ms of the dominant kernel in the newest committed profiles/*_kernel_stats.csv, that file's name):
+    the rocprofv3 --kernel-trace --stats summary of this very command, written by tools/profile_round.sh.  Default workload
+    only; the row with the largest total duration among the kernels whose symbol carries the class's name."""
+    if not (n_fact == 1_000_000_000 and n_dim == 10_000_000 and world == 1 and args.threshold == 0.5
+            and not args.unfused and not args.force_exchange) or kernel not in PROFILE_SYMBOL:
+        return None, None
+    try:
+        import csv
+        import glob
+        newest = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")) if "_ops_" not in f)[-1]
+        best = None
+        with open(newest, newline="") as f:
+            for r in csv.DictReader(f):
+                if PROFILE_SYMBOL[kernel] in r["Name"].split("(")[0] and (best is None or float(r["TotalDurationNs"]) > best[0]):
+                    best = (float(r["TotalDurationNs"]), float(r["AverageNs"]))
+        if best is None:
+            return None, None
+        return round(best[1] / 1e6, 4), f"profiles/{os.path.basename(newest)} (AverageNs of the kernel's launches; another run of this command)"
     except (OSError, KeyError, ValueError, IndexError):
         return None, None
 
@@ -1240,6 +1313,10 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
                                            "bandwidth-bound (5.2 GB moved for 2.0 GB algorithmic)"),
                                  "ceiling_frac": (round(by / 0.520 / 1e6 / HBM_PEAK_GBPS, 4) if not sparse and hit == "all_hit" else None),
                                  "ms_probe_composite_ubench": (0.520 if not sparse and hit == "all_hit" else None)}
+        if sparse:  # (review r05 #5) the general-key leg carries its counter traffic against the algorithmic bytes
+            tb, tsrc = ops_traffic(["lds_join_partition_kernel", "lds_join_probe_kernel", "lds_join_restore_kernel"])
+            res[f"C3_join_{hit}"].update({"algorithmic_bytes": int(by), "traffic": tb, "traffic_ratio": (round(tb / by, 2) if tb else None),
+                                          "traffic_source": tsrc})
         del fk
     # ---- general-key join shapes at the C3 size (review r04 #5; not BASELINE configs, no roofline claim): every build key FOUR times
     #      (hash_join.rs:172-177 insertion-order chains, :225-234 probe-major pairs — 4e8 pairs out of 1e8 probe rows), and a
@@ -1322,6 +1399,26 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     by = 16 * n + 24 * groups[0]
     res["C4_agg"] = {"rows": n, "groups": groups[0], "ms": round(ms, 3), "Mrows_s": round(n / ms / 1e3, 1),
                      "GBps": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    # (review r05 #3d / #5) counter traffic against the algorithmic bytes, and the same leg in two FRESH processes: the
+    # claimed level's time follows the physical placement of its output regions (profiles/r06e_placement.txt: 1.45-1.97 ms
+    # for one binary), so one process's figure is a draw like the headline's
+    tb, tsrc = ops_traffic(["rp_claim_scatter", "lds_agg_dense_slim"])
+    res["C4_agg"].update({"algorithmic_bytes": int(by), "traffic": tb, "traffic_ratio": (round(tb / by, 2) if tb else None),
+                          "traffic_source": tsrc})
+    if os.environ.get("SQLRS_BENCH_C4_PROCESSES", "1") != "0":
+        import re
+        import subprocess
+        vals = [round(ms, 3)]
+        for _ in range(2):
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c4_agg.py")], capture_output=True, text=True, timeout=300,
+                                   env=dict(os.environ, ROUNDS="1", REPS="5"))
+                vals.append(float(re.search(r"C4 .*?: ([0-9.]+) ms", r.stdout).group(1)))
+            except Exception as e:  # informational
+                log(f"[bench] a C4 child process failed: {e!r}")
+        sv = sorted(vals)
+        res["C4_agg"]["ms_processes"] = {"n": len(vals), "min": sv[0], "median": sv[len(sv) // 2], "max": sv[-1], "values": vals,
+                                         "note": "the same leg (tools/c4_agg.py, event-timed best of 5) in fresh processes; values[0] = this process"}
     # ---- C4 with a WHERE: HashAgg(Filter(scan)), val > 0.5 — the filter handed to the aggregate (sqlrs_hash_agg_set_filter:
     #      evaluated by the partition pass) against the same plan as two operators (filter.rs:13-25 feeding hash_agg.rs:44)
     pred = (InputRef(1) > Constant(0.5, abi.FLOAT64)).pack()
@@ -1832,7 +1929,9 @@ def cpu_baseline(args, abi, datagen, n_dim_total):
     log(f"[bench] cpu_baseline faithful: {n1:,} fact rows x {nd1:,} dim rows in {dt:.1f}s on 1 thread = {faithful:.3f} Mrows/s")
     return {"value": round(fair, 2), "unit": "Mrows/s", "cores": threads, "kind": "port",
             "sample": f"first {n} fact rows x all {n_dim_total} dim rows, single batch, same query and generator, "
-                      f"oracle/libsqlrs_cpu_fair.so (OpenMP, {threads} threads of {os.cpu_count()} host cpus, radix-partitioned "
+                      f"oracle/libsqlrs_cpu_fair.so (OpenMP, {threads} threads = omp_get_max_threads() = the "
+                      f"{len(os.sched_getaffinity(0))} cpus this process is allowed to run on (sched_getaffinity) of the host's "
+                      f"{os.cpu_count()}: more threads than that would share cores; --cpu-threads overrides, radix-partitioned "
                       "flat tables), best of 3",
             "faithful": {"value": round(faithful, 4), "unit": "Mrows/s", "cores": 1, "kind": "port",
                          "sample": f"first {n1} fact rows x {nd1} dim rows, single batch, oracle/libsqlrs_oracle.so: the "

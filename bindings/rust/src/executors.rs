@@ -63,10 +63,12 @@ impl HipFilterManyExecutor {
         let mut pending: Vec<RecordBatch> = Vec::with_capacity(self.group);
         let mut child = self.child;
         loop {
+            // (advisor r05: the end of the child's stream is `None`, not a short group — testing the group's fill right after
+            //  the first push ended the loop after ONE batch and dropped the rest of the stream)
             let next = futures::StreamExt::next(&mut child).await;
+            let end = next.is_none();
             if let Some(b) = next { pending.push(b?); }
-            let end = pending.len() < self.group || self.group == 0;
-            if pending.len() == self.group.max(1) || (end && !pending.is_empty()) {
+            if pending.len() >= self.group.max(1) || (end && !pending.is_empty()) {
                 let views: Vec<AbiBatch> = pending.iter().map(AbiBatch::new).collect::<Result<_, _>>()?;
                 let ins: Vec<*const sqlrs_batch_t> = views.iter().map(|v| &v.raw as *const _).collect();
                 let mut outs: Vec<*mut sqlrs_batch_t> = vec![std::ptr::null_mut(); ins.len()];
@@ -236,10 +238,12 @@ impl HipProjectManyExecutor {
         let mut pending: Vec<RecordBatch> = Vec::with_capacity(self.group);
         let mut child = self.child;
         loop {
+            // (advisor r05: the end of the child's stream is `None`, not a short group — testing the group's fill right after
+            //  the first push ended the loop after ONE batch and dropped the rest of the stream)
             let next = futures::StreamExt::next(&mut child).await;
+            let end = next.is_none();
             if let Some(b) = next { pending.push(b?); }
-            let end = pending.len() < self.group || self.group == 0;
-            if pending.len() == self.group.max(1) || (end && !pending.is_empty()) {
+            if pending.len() >= self.group.max(1) || (end && !pending.is_empty()) {
                 let views: Vec<AbiBatch> = pending.iter().map(AbiBatch::new).collect::<Result<_, _>>()?;
                 let ins: Vec<*const sqlrs_batch_t> = views.iter().map(|v| &v.raw as *const _).collect();
                 let mut outs: Vec<*mut sqlrs_batch_t> = vec![std::ptr::null_mut(); ins.len()];

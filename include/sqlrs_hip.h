@@ -90,7 +90,10 @@ typedef struct sqlrs_column {
  *     (A stream-ordered allocator on another stream — e.g. torch's caching allocator — may hand a freed
  *     block to later work of ITS stream: order that stream behind the ctx with release_to_stream.)
  *   - Device bitmaps (validity, BOOLEAN values) must be 8-byte aligned and readable up to the next multiple
- *     of 8 bytes (kernels read whole 64-bit words); host bitmaps have no such requirement. */
+ *     of 8 bytes (kernels read whole 64-bit words); host bitmaps have no such requirement.
+ * Size limit, the same for every operator: 0 <= num_rows < 2^31 per batch (row ids travel as 32-bit words); a batch
+ * outside that range is refused by every call that takes one with SQLRS_ERR_ARROW, before any column is read.  Larger
+ * inputs arrive as several batches — the reference's own batches are 1024 rows (src/storage/csv.rs:105). */
 typedef struct sqlrs_batch {
   int64_t num_rows;
   int32_t num_columns;

@@ -139,6 +139,7 @@ struct Ctx {
   std::set<const void *> big_lds_set;
   std::map<const void *, int> occ_cache;
   int64_t lb_timeouts = 0; // look-back launches that timed out and were redone with tickets
+  int64_t order_lb_fallbacks = 0; // Order split passes whose chained look-back ran out of spins (redone in the counting form)
   int lb_backoff = 0; // resident blocks per CU of the persistent kernels, per kernel
   void sync() { SQ_HIP(hipStreamSynchronize(stream)); }
   // copies `bytes` from device to the pinned area and synchronises; returns host pointer

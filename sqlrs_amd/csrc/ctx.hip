@@ -364,6 +364,9 @@ static const DBatch *shared_columns_of(Ctx *c, const sqlrs_batch_t *b) {
 InBatch::InBatch(Ctx *c, const sqlrs_batch_t *b) : ctx(c), abi(b) {
   if (!b) fail(SQLRS_ERR_ARROW, "null batch");
   if (b->num_columns < 0 || (b->num_columns > 0 && !b->columns)) fail(SQLRS_ERR_ARROW, "bad batch");
+  // ONE limit for every operator (sqlrs_hip.h, sqlrs_batch_t): row ids are 32-bit (30-bit in the slim partition records and
+  // the gather indices), so a batch holds fewer than 2^31 rows; larger inputs arrive as several batches
+  if (b->num_rows < 0 || b->num_rows >= (1ll << 31)) fail(SQLRS_ERR_ARROW, "batch num_rows outside [0, 2^31)");
   for (int i = 0; i < b->num_columns; i++)
     if (b->columns[i].length != b->num_rows) fail(SQLRS_ERR_ARROW, "column length != num_rows");
   cache.resize((size_t)b->num_columns);
@@ -472,7 +475,7 @@ sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem) {
 
 // --------------------------------------------------------------- host staging --
 bool HostStage::accepts(const sqlrs_batch_t *b) const {
-  if (!b || b->num_columns <= 0 || b->num_rows > HOST_STAGE_MAX_BATCH) return false;
+  if (!b || b->num_columns <= 0 || b->num_rows < 0 || b->num_rows > HOST_STAGE_MAX_BATCH) return false; // (< 0: InBatch rejects it)
   if (has_schema && (size_t)b->num_columns != cols.size()) return false;
   for (int i = 0; i < b->num_columns; i++) {
     const sqlrs_column_t &c = b->columns[i];
@@ -903,6 +906,14 @@ int sqlrs_ctx_profile_read(sqlrs_ctx_t *ctx, int cap, const char **names, double
       names[n] = "lookback_ticket_reruns";
       total_ms[n] = 0;
       launches[n] = ctx->lb_timeouts;
+    }
+    n++;
+  }
+  if (ctx->order_lb_fallbacks) { // (advisor r05: the process-wide switch-off of the Order look-back is visible, tests/conftest.py checks it)
+    if (n < cap) {
+      names[n] = "order_lookback_fallbacks";
+      total_ms[n] = 0;
+      launches[n] = ctx->order_lb_fallbacks;
     }
     n++;
   }

@@ -289,15 +289,34 @@ int sqlrs_exchange_all_to_all(sqlrs_exchange_t *x, const sqlrs_batch_t *in, cons
     Ctx *ctx = x->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
     const int W = x->world;
-    if (!in || !out) fail(SQLRS_ERR_INTERNAL, "exchange: null argument");
-    if (x->open) fail(SQLRS_ERR_INTERNAL, "exchange: a chunk sequence is open (sqlrs_exchange_finish it first)");
-    InBatch ib(ctx, in);
+    // (advisor r05) EVERY local failure ahead of the collectives — a null argument, an open chunk sequence, a batch the
+    // entrance rejects, a column that cannot be brought to the device — becomes the ERR flag of this rank's count words:
+    // the ranks then fail TOGETHER in wait_counts instead of this one returning while its peers sit in the all-gather
+    std::unique_ptr<InBatch> ibp;
+    DBatch rows;
+    uint64_t flags = 0;
+    std::string why;
+    try {
+      if (!in || !out) fail(SQLRS_ERR_INTERNAL, "exchange: null argument");
+      if (x->open) fail(SQLRS_ERR_INTERNAL, "exchange: a chunk sequence is open (sqlrs_exchange_finish it first)");
+      ibp.reset(new InBatch(ctx, in));
+      flags = check_chunk(x, *ibp, part_start, part_rows, nullptr);
+      if (!(flags & XB_ERR)) rows = ibp->materialize(false); // (before the count words go out: it may throw)
+    } catch (const Error &e) {
+      flags = XB_ERR;
+      why = e.msg;
+    }
     // 1. who sends how much to whom — and whether every rank accepted its arguments: ONE all-gather, one fetch
-    const uint64_t flags = check_chunk(x, ib, part_start, part_rows, nullptr);
     gather_counts(x, 0, (flags & XB_ERR) ? nullptr : part_rows, flags);
-    Counts c = wait_counts(x, 0); // (throws on every rank alike when one of them raised ERR)
+    Counts c;
+    try {
+      c = wait_counts(x, 0); // (throws on every rank alike when one of them raised ERR)
+    } catch (const Error &e) {
+      if (!why.empty()) fail(e.status, e.msg + " [this rank: " + why + "]");
+      throw;
+    }
+    InBatch &ib = *ibp;
     // 2. the payload
-    DBatch rows = ib.materialize(false);
     std::vector<BufP> vb = validity_bytes(ctx, rows, c.flags_or);
     const int nc = ib.num_columns();
     std::vector<BufP> vals((size_t)nc), rv((size_t)nc);
@@ -396,18 +415,25 @@ int sqlrs_exchange_send_chunk(sqlrs_exchange_t *x, const sqlrs_batch_t *in, cons
     Ctx *ctx = x->ctx;
     SQ_HIP(hipSetDevice(ctx->device));
     if (!x->open) fail(SQLRS_ERR_INTERNAL, "exchange: send_chunk without begin");
-    if (!in) fail(SQLRS_ERR_INTERNAL, "exchange: null argument");
     const int W = x->world;
-    InBatch ib(ctx, in);
-    const uint64_t flags = check_chunk(x, ib, part_start, part_rows, &x->dtypes);
+    // (advisor r05: local failures become the ERR flag, see sqlrs_exchange_all_to_all; the rows are materialised BEFORE the
+    //  chunk's count words are queued, so nothing can throw between this rank's all-gather and its peers')
+    sqlrs_exchange::Chunk ch;
+    uint64_t flags = 0;
+    try {
+      if (!in) fail(SQLRS_ERR_INTERNAL, "exchange: null argument");
+      InBatch ib(ctx, in);
+      flags = check_chunk(x, ib, part_start, part_rows, &x->dtypes);
+      if (!(flags & XB_ERR)) ch.rows = ib.materialize(true); // retained until its payload is queued (the library's own batches are shared, not copied)
+    } catch (const Error &) {
+      flags = XB_ERR;
+    }
     const int slot = (int)(x->chunk_no & 1);
     // (slot `slot` was last used by chunk_no - 2, whose payload went out in the previous call: its words have been read)
     gather_counts(x, slot, (flags & XB_ERR) ? nullptr : part_rows, flags);
-    sqlrs_exchange::Chunk ch;
     ch.slot = slot;
     ch.flags = flags;
     if (!(flags & XB_ERR)) {
-      ch.rows = ib.materialize(true); // retained until its payload is queued (the library's own batches are shared, not copied)
       ch.start.assign(part_start, part_start + W);
       ch.cnt.assign(part_rows, part_rows + W);
     } else {

@@ -289,6 +289,10 @@ __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void ow_scatter_kernel(const vo
   // (optimistic key range: the raw pass's histogram kernel has already seen every key; once it raised the flag, nothing
   //  this attempt produces is used — a miss then costs that histogram pass, not the two split passes behind it)
   if (abort_flag && *abort_flag) return;
+  // (advisor r05, medium) a look-back spin that ran out in the FIRST split pass leaves overlapped and never-written records
+  // behind; the tiled pass would count its digits from those stale words against the bases of the TRUE histogram and store
+  // past its output — it must not run at all.  (Inside one pass a failed spin only shortens a prefix: positions stay in range.)
+  if (LB && lb_fail && *lb_fail) return;
   static_assert(!TWO || (REC && NPAY == 1), "TWO: the record form");
   __shared__ uint64_t sword[OW_TILE];
   __shared__ uint64_t spay[NPAY && !TWO ? OW_TILE : 1];
@@ -565,6 +569,7 @@ __global__ __launch_bounds__(256) void ow_tile_plan_gh_kernel(const uint32_t *__
 __global__ __launch_bounds__(256) void ow_group_table_lb_kernel(const uint32_t *__restrict__ bound, const uint32_t *__restrict__ ghist,
                                                                 uint32_t *__restrict__ gstart, uint32_t *__restrict__ gend,
                                                                 unsigned int *__restrict__ out) {
+  if (out[0]) return; // (a look-back spin ran out: `bound` was never written; the host discards the attempt)
   __shared__ uint32_t s_seg[256], s_w[4];
   __shared__ uint32_t s_end;
   const uint32_t hi = blockIdx.x, lo = threadIdx.x;
@@ -1473,7 +1478,10 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   const uint32_t *gh = (const uint32_t *)ctx->fetch(gend->as<uint32_t>() + G, 12);
   const uint32_t max_group = gh[0], pure_chunks = gh[1];
   if (lb1 && (gh[2] || (lbf_e && lbf_e[0] == '1'))) { // nothing of this attempt is valid: once more in the counting form
-    if (gh[2]) g_order_lb_off.store(true);
+    if (gh[2]) {
+      g_order_lb_off.store(true);
+      ctx->order_lb_fallbacks++;
+    }
     struct Skip {
       Skip() { wide_lb_skip = true; }
       ~Skip() { wide_lb_skip = false; }
@@ -1765,6 +1773,10 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     else
     ow_scatter_kernel<KIND, true, NPAY, false, NPAY == 1, false, true><<<g, b, 0, ctx->stream>>>(
         src, psrc, n, desc, imin, s1, nblocks, nullptr, out1, nullptr, nullptr, oob_lb, gh, lbdesc->as<uint32_t>(), nullptr, lbw);
+    if (lbf_e && lbf_e[0] == '2') { // test hook: as if a spin had run out in the first pass — its output is garbage, the flag is up
+      SQ_HIP(hipMemsetAsync(out1, 0xff, (NPAY == 1 ? 16 : 8) * (size_t)n, ctx->stream));
+      SQ_HIP(hipMemsetAsync(lbw, 1, 4, ctx->stream));
+    }
     firsttile = ctx->alloc(4 * 257);
     segstart = ctx->alloc(8 * 257);
     tiles2 = ctx->alloc(sizeof(OwTile) * (size_t)ntmax);
@@ -1841,7 +1853,10 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   if (lb_done) { // one round trip for the three
     const uint32_t *hv = (const uint32_t *)ctx->fetch(lbw, 12);
     if (hv[0] || (lbf_e && lbf_e[0] == '1')) { // a look-back spin ran out: nothing of this attempt is valid; the counting form from here on
-      if (hv[0]) g_order_lb_off.store(true);
+      if (hv[0] && !(lbf_e && lbf_e[0] == '2')) { // (not for the test hook's forced failure)
+        g_order_lb_off.store(true);
+        ctx->order_lb_fallbacks++;
+      }
       struct Skip {
         Skip() { lb_skip = true; }
         ~Skip() { lb_skip = false; }

@@ -126,3 +126,85 @@ def test_stream_ordered_handover_with_a_torch_stream():
         o.release()
     finally:
         be.close()
+
+
+def _claimed_batch(be, num_rows, ncols=2):
+    """a caller-built DEVICE batch that CLAIMS `num_rows` rows over 64-byte buffers: an operator that reads a column
+    before it has checked the claim faults instead of returning an error"""
+    import torch
+    keep = [torch.zeros(8, dtype=torch.int64, device="cuda:0") for _ in range(ncols)]
+    cols = (abi.Column * ncols)()
+    for i, t in enumerate(keep):
+        cols[i].dtype, cols[i].mem, cols[i].length, cols[i].null_count = abi.INT64, abi.MEM_DEVICE, num_rows, 0
+        cols[i].values = t.data_ptr()
+    b = abi.Batch()
+    b.num_rows, b.num_columns, b.columns = num_rows, ncols, cols
+    return b, (keep, cols)
+
+
+@pytest.mark.parametrize("rows", [1 << 31, (1 << 31) + 12345, -1, -(1 << 40)])
+def test_every_operator_refuses_a_batch_outside_the_row_limit(hip, rows):
+    """Review r05 #7: one guard at the ABI entrance (InBatch) instead of piecemeal checks inside the routes — a batch that
+    claims < 0 or >= 2^31 rows is SQLRS_ERR_ARROW from every call that takes a batch, and the operator stays usable."""
+    from sqlrs_amd.expr import AggFunc
+    be = hip
+    b, keep = _claimed_batch(be, rows)
+    ok, keep_ok = _claimed_batch(be, 8)
+    e0, _k0 = abi.pack_exprs([InputRef(0)])
+    pred = (InputRef(0) > Constant(0, abi.INT64)).pack()
+    rd = (C.c_int32 * 2)(abi.INT64, abi.INT64)
+    kk = []
+    aggs = (abi.AggFunc * 1)(AggFunc("count", InputRef(1), abi.INT64).abi_struct(kk))
+    out = C.POINTER(abi.Batch)()
+
+    def refused(st):
+        assert st == abi.ERR_ARROW, st
+        assert b"2^31" in (be.fn("last_error")(be.ctx) or b"")
+
+    h = C.c_void_p()
+    be.check(be.fn("filter_create")(be.ctx, C.byref(pred.abi), C.byref(h)))
+    refused(be.fn("filter_push")(h, C.byref(b), abi.MEM_DEVICE, C.byref(out)))
+    be.check(be.fn("filter_push")(h, C.byref(ok), abi.MEM_DEVICE, C.byref(out)))
+    be.fn("batch_release")(out)
+    be.fn("filter_destroy")(h)
+    be.check(be.fn("project_create")(be.ctx, 1, e0, C.byref(h)))
+    refused(be.fn("project_push")(h, C.byref(b), abi.MEM_DEVICE, C.byref(out)))
+    be.fn("project_destroy")(h)
+    be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, e0, e0, None, 2, rd, C.byref(h)))
+    refused(be.fn("hash_join_build_push")(h, C.byref(b)))
+    be.check(be.fn("hash_join_build_push")(h, C.byref(ok)))
+    be.check(be.fn("hash_join_build_finish")(h))
+    refused(be.fn("hash_join_probe_push")(h, C.byref(b), abi.MEM_DEVICE, C.byref(out)))
+    refused(be.fn("hash_join_probe_indices")(h, C.byref(b), abi.MEM_DEVICE, C.byref(out)))
+    be.check(be.fn("hash_join_probe_push")(h, C.byref(ok), abi.MEM_DEVICE, C.byref(out)))
+    be.fn("batch_release")(out)
+    be.fn("hash_join_destroy")(h)
+    be.check(be.fn("hash_agg_create")(be.ctx, 1, e0, 1, aggs, C.byref(h)))
+    refused(be.fn("hash_agg_push")(h, C.byref(b)))
+    be.check(be.fn("hash_agg_push")(h, C.byref(ok)))
+    be.check(be.fn("hash_agg_finish")(h, abi.MEM_DEVICE, C.byref(out)))
+    assert out.contents.num_rows == 1
+    be.fn("batch_release")(out)
+    be.fn("hash_agg_destroy")(h)
+    be.check(be.fn("join_agg_create")(be.ctx, 1, e0, e0, 2, 2, rd, 1, e0, 1, aggs, C.byref(h)))
+    refused(be.fn("join_agg_build_push")(h, C.byref(b)))
+    be.check(be.fn("join_agg_build_push")(h, C.byref(ok)))
+    be.check(be.fn("join_agg_build_finish")(h))
+    refused(be.fn("join_agg_probe_push")(h, C.byref(b)))
+    be.fn("join_agg_destroy")(h)
+    keys = (abi.OrderBy * 1)()
+    keys[0].expr, keys[0].asc = e0[0], 1
+    be.check(be.fn("order_create")(be.ctx, 1, keys, C.byref(h)))
+    refused(be.fn("order_push")(h, C.byref(b)))
+    be.fn("order_destroy")(h)
+    be.check(be.fn("limit_create")(be.ctx, 1, 5, 0, 0, C.byref(h)))
+    done = C.c_int(0)
+    refused(be.fn("limit_push")(h, C.byref(b), abi.MEM_DEVICE, C.byref(out), C.byref(done)))
+    be.fn("limit_destroy")(h)
+    be.check(be.fn("simple_agg_create")(be.ctx, 1, aggs, C.byref(h)))
+    refused(be.fn("simple_agg_push")(h, C.byref(b)))
+    be.fn("simple_agg_destroy")(h)
+    refused(be.fn("eval_expr")(be.ctx, C.byref(pred.abi), C.byref(b), abi.MEM_DEVICE, C.byref(out)))
+    offs = (C.c_int64 * 3)()
+    refused(be.fn("hash_partition")(be.ctx, C.byref(b), e0, 2, abi.MEM_DEVICE, C.byref(out), offs))
+    be.synchronize()
