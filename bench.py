@@ -33,6 +33,7 @@ Every result is checked per group before it is timed.
 """
 from __future__ import annotations
 
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import argparse
 import ctypes as C
 import json

@@ -23,6 +23,12 @@
  *
  * No CPU fallback exists in this library: without a usable gfx950 device
  * sqlrs_ctx_create fails with SQLRS_ERR_DEVICE.
+ *
+ * Environment.  Three deployment settings are read when a ctx / operator is created: SQLRS_POOL_RESERVE_GB (one up-front
+ * device allocation that the ctx pool carves its blocks from), SQLRS_POOL_VMM=<MiB> (pool blocks of that size and more are
+ * backed through hipMemCreate / hipMemMap), SQLRS_JOIN_COMPOSITE=1 (several integer join keys compared exactly instead of
+ * by the reference's combined hash).  Every other SQLRS_* name (tools/HOOKS.md) is a test / tuning hook and is looked at
+ * only in a process started with SQLRS_HOOKS=1; without it the library never calls getenv on an operator's path.
  */
 #ifndef SQLRS_HIP_H
 #define SQLRS_HIP_H

@@ -180,7 +180,7 @@ double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validit
                          uint64_t *omin, uint64_t *omax, bool *sampled) {
   if (sampled) *sampled = false;
   static const int opt_env = [] { // test / tuning hook: 0 = always the exact pass
-    const char *e = std::getenv("SQLRS_SAMPLED_STATS");
+    const char *e = hook("SQLRS_SAMPLED_STATS");
     return e ? std::atoi(e) : 1;
   }();
   constexpr double SATURATED = 0.8; // half the sample holds >= this share of the sample's keys: every group has been seen
@@ -189,7 +189,7 @@ double estimate_distinct(Ctx *ctx, const uint64_t *keys, const uint64_t *validit
   // of the rare groups only: the estimate is scaled by the missing share instead of hashing every row (C4 Zipf: the exact pass
   // cost 0.34 of 2.97 ms); SQLRS_STATS_DISJOINT (read per call) moves the line
   double DISJOINT = 0.6;
-  if (const char *dj = std::getenv("SQLRS_STATS_DISJOINT")) DISJOINT = std::atof(dj);
+  if (const char *dj = hook("SQLRS_STATS_DISJOINT")) DISJOINT = std::atof(dj);
   double half = 0;
   if (sampled && opt_env && !validity && n >= (1ll << 24)) {
     const int stride = 8;
@@ -1348,7 +1348,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   const bool join_mode = in.join_keys != nullptr;
   uint64_t omin = ~0ull, omax = 0; // signed-order image of the smallest / largest key of interest
   bool sampled = false; // omin / omax are a sample's (widened below): rows are packed optimistically
-  const char *kse = std::getenv("SQLRS_KEY_STATS_EXACT"); // measurement hook, read per call: 1 = key statistics from a full pass
+  const char *kse = hook("SQLRS_KEY_STATS_EXACT"); // measurement hook, read per call: 1 = key statistics from a full pass
   const bool stats_exact_env = kse && kse[0] == '1';
   double est = join_mode ? (double)in.join_n
                          : estimate_distinct(ctx, in.keys, in.key_validity, n, &omin, &omax, (in.exact_stats || stats_exact_env) ? nullptr : &sampled);
@@ -1360,7 +1360,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     omax = omax <= ~0ull - pad ? omax + pad : ~0ull;
   }
   static const double est_scale = [] { // test hook: mis-scale the estimate to force the overflow path
-    const char *e = std::getenv("SQLRS_EST_SCALE");
+    const char *e = hook("SQLRS_EST_SCALE");
     return e ? std::atof(e) : 1.0;
   }();
   if (!join_mode) est = std::max(1.0, est * est_scale);
@@ -1409,19 +1409,19 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   // (36 KiB tables, four workgroups per CU) that was ~5 trips per row instead of ~2:
   // 3.7 ms vs 3.0 ms for the C5 bucket pass.  Fewer groups per table would need more buckets,
   // which costs more in the partition passes than it saves here.
-  const char *lds_e = std::getenv("SQLRS_LDS_AGG_KB"); // tuning hook, read per call
+  const char *lds_e = hook("SQLRS_LDS_AGG_KB"); // tuning hook, read per call
   const size_t lds_budget = (size_t)(lds_e ? std::atoi(lds_e) : 72) * 1024;
   const size_t slot_bytes = 8 + 8 * (size_t)spec.n_acc + 4; // key, accumulators, first row
   uint32_t cap = 1;
   while ((size_t)(cap * 2 + 2) * slot_bytes <= lds_budget) cap *= 2;
   static const double load_factor = [] { // tuning hook
-    const char *e = std::getenv("SQLRS_LDS_LOAD");
+    const char *e = hook("SQLRS_LDS_LOAD");
     return e ? std::atof(e) : 0.275;
   }();
   const double groups_per_table = cap * load_factor;
   double want = est * 1.15 / groups_per_table;
   static const double max_frac = [] { // tuning hook: largest groups / rows ratio taken by this route
-    const char *e = std::getenv("SQLRS_PART_MAX_FRAC");
+    const char *e = hook("SQLRS_PART_MAX_FRAC");
     return e ? std::atof(e) : 1.0;
   }();
   // (mostly distinct keys used to be sent to the row route, "est > n / 2": 17 ms instead of 1.7 ms
@@ -1433,7 +1433,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   // R = 2^rbits slots of 8 * n_acc + 4 bytes at 100 % fill instead of cap slots of 8 more bytes
   // at 27 %, i.e. ~5x fewer buckets (often one partition level instead of two), no probing and,
   // for the fused join, no build-side partition and no insert phase.
-  const char *dense_e = std::getenv("SQLRS_DENSE_AGG"); // test / tuning hook, read per call
+  const char *dense_e = hook("SQLRS_DENSE_AGG"); // test / tuning hook, read per call
   const bool dense_on = !(dense_e && dense_e[0] == '0');
   const uint64_t *partner_bits = nullptr; // dense fused join over build keys with gaps (PartAggInput::join_bits)
   const double want_hashed = want; // probing tables needed if the bucket pass ran on hashed buckets
@@ -1445,7 +1445,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     // 3.35 -> 3.07 ms, the bucket pass itself 1.63 -> 1.60 ms with one workgroup per CU instead of three; C4: 489 ->
     // 245 buckets, scatter 2.12 -> 1.52 ms).  8192 slots (first row kept inside the COUNT cell, 16-byte slots) were
     // measured too: level 1 -0.1 ms, bucket pass +0.13 ms, nothing gained.
-    const char *dk_e = std::getenv("SQLRS_LDS_DENSE_KB"); // tuning hook, read per call
+    const char *dk_e = hook("SQLRS_LDS_DENSE_KB"); // tuning hook, read per call
     const size_t dense_budget = (size_t)(dk_e ? std::atoi(dk_e) : 150) * 1024;
     const size_t dslot = 8 * (size_t)spec.n_acc + 4;
     uint32_t rbits = 8;
@@ -1563,7 +1563,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
   prm.partner_bits = dense ? (const unsigned long long *)partner_bits : nullptr;
   prm.partner_mult = (dense && join_mode) ? in.join_mult : nullptr;
   {
-    const char *seg_e = std::getenv("SQLRS_AGG_SEG");
+    const char *seg_e = hook("SQLRS_AGG_SEG");
     prm.seg_off = (seg_e && seg_e[0] == '0') ? 1 : 0;
   }
   int64_t gcap = (int64_t)std::min<double>((double)n, est * 1.5 + 65536.0 + 2.0 * P);
@@ -1586,7 +1586,7 @@ bool partitioned_preaggregate(Ctx *ctx, const PartAggSpec &spec, const PartAggIn
     int64_t nonempty_d = 0;
     for (uint32_t bkt = 0; bkt < P; bkt++) nonempty_d += pr.bucket_end(bkt) > hb[bkt];
     const int64_t avg = n / std::max<int64_t>(nonempty_d, 1);
-    const char *cd_e = std::getenv("SQLRS_DENSE_CHUNK_DIV"), *sa_e = std::getenv("SQLRS_DENSE_SPLIT_PCT"); // tuning hooks, read per call
+    const char *cd_e = hook("SQLRS_DENSE_CHUNK_DIV"), *sa_e = hook("SQLRS_DENSE_SPLIT_PCT"); // tuning hooks, read per call
     const int cdiv = cd_e ? std::max(1, std::atoi(cd_e)) : 2;        // chunk = average / this
     const int sa_pct = sa_e ? std::max(1, std::atoi(sa_e)) : 125;    // buckets above this % of the average are split
     chunk = (uint32_t)std::max<int64_t>(32768, avg / cdiv);

@@ -17,6 +17,20 @@
 
 namespace sq {
 
+// Tuning / test hooks (the SQLRS_* names tools/HOOKS.md lists): consulted ONLY in a process that opted in with SQLRS_HOOKS=1
+// (read once) — tests/conftest.py, bench.py's A/B legs and the tools/ scripts do; a production process never calls getenv
+// on an operator's path and cannot have its routes bent by a stray variable.  (Review r05 #9: 64 switches were live in
+// every process.)  Deployment knobs stay plain environment reads at ctx / operator creation: SQLRS_POOL_RESERVE_GB,
+// SQLRS_POOL_VMM, SQLRS_JOIN_COMPOSITE (include/sqlrs_hip.h).
+inline bool hooks_enabled() {
+  static const bool on = [] {
+    const char *e = std::getenv("SQLRS_HOOKS");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+inline const char *hook(const char *name) { return hooks_enabled() ? std::getenv(name) : nullptr; }
+
 struct Error {
   int status;
   std::string msg;
@@ -245,7 +259,7 @@ template <class F> int guard(Ctx *ctx, F &&f) {
 // fallback is exercised by the parity tests instead of only by a timeout.
 inline int first_lookback_mode() {
   static const int forced = [] {
-    const char *e = std::getenv("SQLRS_FORCE_TICKET");
+    const char *e = hook("SQLRS_FORCE_TICKET");
     return (e && e[0] == '1') ? 1 : 0;
   }();
   return forced;

@@ -545,7 +545,7 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
     // ---- partition route ----------------------------------------------------------
     bool done = false;
     static const int64_t PART_MIN_ROWS = [] {
-      const char *e = std::getenv("SQLRS_PART_MIN_ROWS"); // test hook: force the partition route
+      const char *e = hook("SQLRS_PART_MIN_ROWS"); // test hook: force the partition route
       return e ? std::atoll(e) : (1ll << 21);
     }();
     if ((n >= PART_MIN_ROWS || js) && pcols.size() <= 2) {
@@ -698,11 +698,11 @@ static bool agg_consume(sqlrs_hash_agg *a, int64_t n, const std::vector<DCol> &k
 // a first batch this large is aggregated in place; staged rows that trigger an aggregation before
 // finish (SQLRS_STAGE_DIRECT_ROWS / SQLRS_STAGE_FLUSH_ROWS: test hooks, read once)
 static const int64_t STAGE_DIRECT_ROWS = [] {
-  const char *e = std::getenv("SQLRS_STAGE_DIRECT_ROWS");
+  const char *e = hook("SQLRS_STAGE_DIRECT_ROWS");
   return e ? std::atoll(e) : (1ll << 26);
 }();
 static const int64_t STAGE_FLUSH_ROWS = [] {
-  const char *e = std::getenv("SQLRS_STAGE_FLUSH_ROWS");
+  const char *e = hook("SQLRS_STAGE_FLUSH_ROWS");
   return e ? std::atoll(e) : (1ll << 28);
 }();
 
@@ -760,7 +760,7 @@ int sqlrs_hash_agg_create(sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t
 // the two-column part alone 7 ms of two-level column-form passes).
 static void hash_agg_plan_parts(sqlrs_hash_agg *a, sqlrs_ctx_t *ctx, int num_group_by, const sqlrs_expr_t *group_by,
                                 const sqlrs_agg_func_t *aggs) {
-  const char *env = std::getenv("SQLRS_AGG_SPLIT"); // test / tuning hook, read per create: 0 = never
+  const char *env = hook("SQLRS_AGG_SPLIT"); // test / tuning hook, read per create: 0 = never
   if (env && std::atoi(env) == 0) return;
   if (!a->distinct_aggs.empty() || a->aggs.size() < 3) return;
   std::vector<int> col_of((size_t)a->aggs.size(), -1); // distinct argument expression of every aggregate (casts aside)
@@ -1252,7 +1252,7 @@ struct sqlrs_join_agg {
 // INPUT_REF key pair, plain aggregates whose arguments read the probe side: sets up `inner` and `outer`
 static void join_agg_plan_eager(sqlrs_join_agg *ja, int num_keys, const sqlrs_expr_t *left_keys, const sqlrs_expr_t *right_keys,
                                 int num_group_by, const sqlrs_expr_t *group_by, int num_aggs, const sqlrs_agg_func_t *aggs) {
-  const char *env = std::getenv("SQLRS_EAGER_AGG"); // test / tuning hook: 0 = never
+  const char *env = hook("SQLRS_EAGER_AGG"); // test / tuning hook: 0 = never
   if (env && std::atoi(env) == 0) return;
   if (num_keys != 1 || num_group_by < 1 || left_keys[0].num_nodes != 1 || right_keys[0].num_nodes != 1 ||
       left_keys[0].nodes[0].op != SQLRS_EXPR_INPUT_REF || right_keys[0].nodes[0].op != SQLRS_EXPR_INPUT_REF)

@@ -947,7 +947,7 @@ __global__ __launch_bounds__(BLOCK) void join_probe_unique_outer_kernel(
 }
 
 static uint64_t dense_slots_per_key_owned() {
-  const char *e = std::getenv("SQLRS_DENSE_JOIN_SLOTS"); // test / tuning hook, read per call
+  const char *e = hook("SQLRS_DENSE_JOIN_SLOTS"); // test / tuning hook, read per call
   return e ? (uint64_t)std::max(1, std::atoi(e)) : 16;
 }
 // min / max of the valid build keys as signed integers (dense-range detection)
@@ -1568,7 +1568,7 @@ static void build_table(sqlrs_hash_join *j) {
   // 1. dense surrogate keys (range <= 4 x rows — 16 x for a join+aggregate's join — and < 2^31) -> direct-address table.  It is tried
   //    first: when the build keys turn out unique nothing else is needed, and the 16-byte-slot
   //    hash table (1.1 ms for 1e7 keys) is never built.
-  const char *db1_e = std::getenv("SQLRS_DENSE_BUILD_ONE_FETCH"); // A/B hook, read per call (0 = the two-fetch sequence below)
+  const char *db1_e = hook("SQLRS_DENSE_BUILD_ONE_FETCH"); // A/B hook, read per call (0 = the two-fetch sequence below)
   // (the one-fetch form allocates the table of the LARGEST admissible range before it has looked at a key: only while that
   //  stays under 1 GiB — advisor r05; beyond, the two-fetch sequence below sizes the table from the range it has seen)
   const uint64_t spk1 = j->lazy_table ? dense_slots_per_key_owned() : 4;
@@ -1576,12 +1576,12 @@ static void build_table(sqlrs_hash_join *j) {
       !(db1_e && std::atoi(db1_e) == 0)) {
     // one fetch (see dense_pack_count_kernel): the table is sized for the largest range that takes the route
     ProfScope ps(ctx, "join_build_dense");
-    const char *pj_e = std::getenv("SQLRS_DENSE_JOIN_SLOTS_PLAIN"); // tuning hook, read per call
+    const char *pj_e = hook("SQLRS_DENSE_JOIN_SLOTS_PLAIN"); // tuning hook, read per call
     const uint64_t slots_per_key = j->lazy_table ? dense_slots_per_key_owned() : (pj_e ? (uint64_t)std::max(1, std::atoi(pj_e)) : 4);
     const uint64_t max_range = slots_per_key * (uint64_t)n + 1024;
     uint32_t bits = 1;
     while (((1ull << bits) - 1) < (uint64_t)n) bits++; // all ones = empty must not be a build row
-    const char *pk_e = std::getenv("SQLRS_DENSE_PACKED"); // A/B hook, read per call (0 = the probe reads the 4-byte table)
+    const char *pk_e = hook("SQLRS_DENSE_PACKED"); // A/B hook, read per call (0 = the probe reads the 4-byte table)
     if (bits < 8) bits = 8;
     if (bits > 25 || (max_range + 2) * bits >= (1ull << 32) || j->lazy_table || (pk_e && std::atoi(pk_e) == 0)) bits = 0;
     BufP st = ctx->alloc_zero(8 * (DENSE_ST_WORDS + 1)); // (+ the miss flag of a first probe that runs before the verdict is fetched)
@@ -1617,7 +1617,7 @@ static void build_table(sqlrs_hash_join *j) {
     j->pend_validity = validity != nullptr;
     // The verdict stays on the device when the first probe can take it from there (dense_resolve): a plain join whose probe
     // kernels read the packed table.  SQLRS_DENSE_BUILD_DEFER=0 (read per call): decide here.
-    const char *df_e = std::getenv("SQLRS_DENSE_BUILD_DEFER");
+    const char *df_e = hook("SQLRS_DENSE_BUILD_DEFER");
     if (bits && !j->lazy_table && !(df_e && std::atoi(df_e) == 0)) return;
     dense_resolve(j);
     return;
@@ -1638,7 +1638,7 @@ static void build_table(sqlrs_hash_join *j) {
       // (a join owned by a HashJoin+HashAgg takes the table up to 16 slots per key: its fused route then partitions
       //  by key range and needs only the existence bitmap of the range — a filtered dimension, or the hash-partitioned
       //  shard of one that a rank of the multi-GPU plan receives, 1/8 of the keys of the range for 8 ranks)
-      const char *pj_e = std::getenv("SQLRS_DENSE_JOIN_SLOTS_PLAIN"); // tuning hook, read per call
+      const char *pj_e = hook("SQLRS_DENSE_JOIN_SLOTS_PLAIN"); // tuning hook, read per call
       const uint64_t slots_per_key = j->lazy_table ? dense_slots_per_key_owned() : (pj_e ? (uint64_t)std::max(1, std::atoi(pj_e)) : 4);
       if (range <= slots_per_key * (uint64_t)n + 1024 && range < (1ull << 31)) {
         ProfScope ps(ctx, "join_build_dense");
@@ -1762,7 +1762,7 @@ static void lds_join_prepare(sqlrs_hash_join *j) {
   // ~2090 — on 4096-slot tables, two workgroups per CU instead of one: probe pass 0.54 -> 0.81 ms.  A wave's lookup takes as
   // long as the longest probe sequence among its 64 lanes, and that length, not the number of resident waves, sets the pace:
   // without any lookup the pass takes 0.38 ms.  SQLRS_LJ_LOAD = percent, read once per join.)
-  const char *ld_e = std::getenv("SQLRS_LJ_LOAD");
+  const char *ld_e = hook("SQLRS_LJ_LOAD");
   const uint32_t pct = ld_e ? (uint32_t)std::min(90, std::max(10, std::atoi(ld_e))) : 50;
   uint32_t slots = 1024;
   while ((uint64_t)slots * pct < 100ull * maxb) slots <<= 1;
@@ -1774,7 +1774,7 @@ static void lds_join_prepare(sqlrs_hash_join *j) {
 // SQLRS_LDS_FIRST=0 (read per call): the table first, as before round 6.
 static bool lds_build_first(sqlrs_hash_join *j) {
   Ctx *ctx = j->ctx;
-  const char *env_e = std::getenv("SQLRS_LDS_JOIN"), *first_e = std::getenv("SQLRS_LDS_FIRST");
+  const char *env_e = hook("SQLRS_LDS_JOIN"), *first_e = hook("SQLRS_LDS_FIRST");
   const int env = env_e ? std::atoi(env_e) : -1;
   const bool outer_right = j->join_type == SQLRS_JOIN_RIGHT || j->join_type == SQLRS_JOIN_FULL;
   if (env == 0 || (first_e && std::atoi(first_e) == 0) || outer_right || j->lazy_table || !j->exact || j->bkeys_validity || !j->bkeys ||
@@ -1802,7 +1802,7 @@ static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
   Ctx *ctx = j->ctx;
   LdsJoinMatch out;
   const int64_t n = pk.rows, nB = j->nB;
-  const char *env_e = std::getenv("SQLRS_LDS_JOIN"); // test / tuning hook, read per call: 0 = never, 1 = whenever the shapes allow
+  const char *env_e = hook("SQLRS_LDS_JOIN"); // test / tuning hook, read per call: 0 = never, 1 = whenever the shapes allow
   const int env = env_e ? std::atoi(env_e) : -1;
   if (env == 0 || !j->exact || pk.validity || j->bkeys_validity || !j->bkeys || nB < 2 || n > 0xffffffffll) return out;
   if (env != 1 && (nB < (1 << 18) || n < (1 << 22) || n < 8 * nB)) return out;
@@ -1822,7 +1822,7 @@ static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
     SQ_HIP(hipGetLastError());
   }
   // ranges per work item: one LDS table build (~2 K inserts) per rpi x ~64 probe rows
-  const char *rpi_e = std::getenv("SQLRS_LJ_RPI");
+  const char *rpi_e = hook("SQLRS_LJ_RPI");
   const uint32_t rpi = rpi_e ? (uint32_t)std::max(1, std::atoi(rpi_e)) : 1024;
   const uint32_t ngroups = (uint32_t)ceil_div((int64_t)nranges, (int64_t)rpi);
   out.mpart = ctx->alloc(4 * (size_t)n + 16);
@@ -1863,7 +1863,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   // key range and uniqueness from the device-side words and ONE fetch brings back the build's verdict and the probe's —
   // a host round trip less per join (C3: 8 MB of build keys cost 0.07 ms, a third of it that round trip).
   if (j->dense_pending) {
-    const char *ah_e = std::getenv("SQLRS_PROBE_ALLHIT");
+    const char *ah_e = hook("SQLRS_PROBE_ALLHIT");
     if (!outer_right && !pk.validity && n >= (1 << 16) && n <= 0xffffffffll && j->pend_bits && !(ah_e && std::atoi(ah_e) == 0)) {
       ProfScope ps(ctx, "join_probe_dense");
       p.left = ctx->alloc(8 * (size_t)n);
@@ -1926,7 +1926,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     unsigned int *miss = nullptr;
     BufP miss_buf;
     {
-      const char *ah_e = std::getenv("SQLRS_PROBE_ALLHIT");
+      const char *ah_e = hook("SQLRS_PROBE_ALLHIT");
       if (j->dense && !lm.ok && !pk.validity && n >= (1 << 16) && !j->probe_miss_seen && !(ah_e && std::atoi(ah_e) == 0)) {
         miss_buf = ctx->alloc_zero(8);
         miss = miss_buf->as<unsigned int>();
@@ -1936,7 +1936,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
         const int64_t every = std::max<int64_t>(1, n >> 14); // ~16 K sampled rows
         join_probe_dense_sample_kernel<<<dim3((unsigned)ceil_div(ceil_div(n, every), 256)), dim3(256), 0, ctx->stream>>>(
             pk.keys->as<uint64_t>(), n, every, dt, miss);
-        const char *sc_e = std::getenv("SQLRS_PROBE_ALLHIT_SC1"); // A/B hook, read per call
+        const char *sc_e = hook("SQLRS_PROBE_ALLHIT_SC1"); // A/B hook, read per call
         if (dt.packed) { // wave-contiguous chunks over the bit-packed table
           const unsigned pblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / JAP_ROWS, 4), JAP_GRID * (int64_t)ctx->num_cus));
           if (((uintptr_t)pk.keys->p & 15) == 0)
@@ -1952,7 +1952,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
           join_probe_dense_allhit_kernel<false><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, dt, p.left->as<uint64_t>(),
                                                                                            p.right->as<uint32_t>(), miss);
         SQ_HIP(hipGetLastError());
-        const char *hc_e = std::getenv("SQLRS_PROBE_ALLHIT_HOSTCHECK"); // A/B hook, read per call (default on)
+        const char *hc_e = hook("SQLRS_PROBE_ALLHIT_HOSTCHECK"); // A/B hook, read per call (default on)
         if (!(hc_e && std::atoi(hc_e) == 0)) {
           if (ctx->fetch_value(miss) == 0) { // every pair is in place
             p.m = n;
@@ -2181,7 +2181,7 @@ const uint64_t *hash_join_dense_bits(sqlrs_hash_join *j) {
 // Key-only build side (see dense_bits_kernel): true = `out` holds the joined batch
 static bool semi_join_probe(sqlrs_hash_join *j, InBatch &ib, const NKeys &pk, DBatch *out) {
   Ctx *ctx = j->ctx;
-  const char *env_e = std::getenv("SQLRS_SEMI_JOIN"); // test hook, read per call: 0 = never
+  const char *env_e = hook("SQLRS_SEMI_JOIN"); // test hook, read per call: 0 = never
   if (env_e && std::atoi(env_e) == 0) return false;
   if (j->dense_pending && j->join_type == SQLRS_JOIN_INNER && !j->has_filter && j->left.cols.size() == 1) dense_resolve(j); // (a candidate: decide now)
   if (j->join_type != SQLRS_JOIN_INNER || j->has_filter || !j->unique || !j->dense || !j->exact || pk.validity ||

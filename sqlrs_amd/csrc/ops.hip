@@ -679,7 +679,7 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
     // ---- ORDER BY ... LIMIT k (sqlrs_order_set_limit): the first key a plain fixed-width column without NULLs, k a small part of the rows
     o->topk_candidates = 0;
     {
-      const char *tk_e = std::getenv("SQLRS_ORDER_TOPK"); // test / tuning hook, read per call: 0 = ignore the hint, 1 = whatever the sizes
+      const char *tk_e = hook("SQLRS_ORDER_TOPK"); // test / tuning hook, read per call: 0 = ignore the hint, 1 = whatever the sizes
       const int tk = tk_e ? std::atoi(tk_e) : -1;
       // (several keys: the threshold is taken on the FIRST one — a row whose first key lies beyond k rows' first keys
       //  cannot be among the first k whatever the other keys say; the candidates are sorted on all of them)
@@ -695,7 +695,7 @@ int sqlrs_order_finish(sqlrs_order_t *o, int out_mem, sqlrs_batch_t **out) {
       }
     }
     // ---- fast route: one plain key column without NULLs (order_fast.hip)
-    const char *fast_e = std::getenv("SQLRS_ORDER_FAST"); // (test / A-B hook, read per call: 0 = the general path)
+    const char *fast_e = hook("SQLRS_ORDER_FAST"); // (test / A-B hook, read per call: 0 = the general path)
     const bool fast_on = !(fast_e && fast_e[0] == '0');
     if (fast_on && o->exprs.size() == 1 && o->exprs[0].nodes.size() == 1 && o->exprs[0].nodes[0].op == SQLRS_EXPR_INPUT_REF) {
       const int kc = o->exprs[0].nodes[0].index;

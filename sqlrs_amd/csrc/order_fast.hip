@@ -1355,13 +1355,13 @@ static std::atomic<bool> g_order_lb_off{false}; // a look-back spin ran out once
 template <int KIND>
 static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t n, uint64_t imin, uint64_t range,
                        DCol *key_out, DCol *carry_out, BufP *perm_out, bool want_perm) {
-  if (const char *e = std::getenv("SQLRS_ORDER_WIDE")) // (A/B hook, read per call: 0 = the general path)
+  if (const char *e = hook("SQLRS_ORDER_WIDE")) // (A/B hook, read per call: 0 = the general path)
     if (e[0] == '0') return false;
   int top = 9;
   while (top < 16 && (n >> top) > 2048) top++;
   const uint32_t G = 1u << top, nk1 = G >> 8;
   int per_group = OWK_SAMPLES;
-  if (const char *e = std::getenv("SQLRS_ORDER_SAMPLES")) per_group = std::max(1, std::min(256, std::atoi(e))); // (A/B hook, read per call)
+  if (const char *e = hook("SQLRS_ORDER_SAMPLES")) per_group = std::max(1, std::min(256, std::atoi(e))); // (A/B hook, read per call)
   const int64_t S = (int64_t)G * per_group;
   if (n < S) return false;
   const int kb = range ? 64 - __builtin_clzll(range) : 1;
@@ -1384,20 +1384,20 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
   const int64_t nblocks = ceil_div(n, OW_TILE), ntmax = nblocks + 256;
   // (with a payload both passes write {word, payload} records: a (tile, digit) run is one piece instead of one per column.
   //  SQLRS_ORDER_WIDE_REC1=0, read per call: pass 1 writes two columns)
-  const char *rec1_e = std::getenv("SQLRS_ORDER_WIDE_REC1");
+  const char *rec1_e = hook("SQLRS_ORDER_WIDE_REC1");
   const bool rec1 = has_pay && !(rec1_e && rec1_e[0] == '0');
   BufP w1 = ctx->alloc((rec1 ? 16 : 8) * (size_t)n), p1 = has_pay && !rec1 ? ctx->alloc(8 * (size_t)n) : nullptr;
   BufP hist = ctx->alloc(4 * (size_t)(256 * nblocks)), offs = ctx->alloc(4 * (size_t)(256 * nblocks)), total = ctx->alloc(8);
   const uint64_t *psrc = (carry && !pay_rows) ? carry->v<uint64_t>() : nullptr;
   dim3 g1((unsigned)nblocks), g2((unsigned)ntmax), b(OW_WG);
-  const char *two_e = std::getenv("SQLRS_ORDER_TWO"); // (read per call: 0 = word and payload side by side in LDS, two workgroups per CU)
+  const char *two_e = hook("SQLRS_ORDER_TWO"); // (read per call: 0 = word and payload side by side in LDS, two workgroups per CU)
   const bool two = !(two_e && two_e[0] == '0');
   // The first pass in its look-back form (the narrow route's, see ow_scatter_kernel): its 256 segment sizes from one persistent
   // launch, the tiles chained — no count matrix, no scan.  The second pass keeps its counting form: its digit is a search in the
   // row's own segment's splitters, so nothing ahead of the first pass can count it.  SQLRS_ORDER_LB=0 (read per call) / a spin
   // that ran out: the counting form.
   static thread_local bool wide_lb_skip = false;
-  const char *lb_e = std::getenv("SQLRS_ORDER_LB"), *lbf_e = std::getenv("SQLRS_ORDER_LB_TEST_FAIL");
+  const char *lb_e = hook("SQLRS_ORDER_LB"), *lbf_e = hook("SQLRS_ORDER_LB_TEST_FAIL");
   const bool lb1 = rec1 && two && n < (1ll << 30) && !g_order_lb_off.load() && !wide_lb_skip && !(lb_e && lb_e[0] == '0');
   BufP ghb1, lbdesc1;
   if (lb1) {
@@ -1488,7 +1488,7 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     } skip;
     return order_wide<KIND>(ctx, key, desc, carry, n, imin, range, key_out, carry_out, perm_out, want_perm);
   }
-  if (std::getenv("SQLRS_ORDER_TRACE"))
+  if (hook("SQLRS_ORDER_TRACE"))
     std::fprintf(stderr, "[order_wide] n=%lld key bits=%d groups=%u largest group to sort=%u rows, %u chunks of single-value groups\n",
                  (long long)n, kb, G, max_group, pure_chunks);
   if (max_group > FIN_CAP) return false; // thousands of distinct keys between two neighbouring samples: general path
@@ -1561,7 +1561,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   BufP mm = ctx->alloc(16 * OW_MM_SLOTS + 16); // {min = ~0, max = 0} x OW_MM_SLOTS | out-of-range flag (u32), largest group (u32) | inversion seen (u32)
   constexpr int FLAG_W = 2 * OW_MM_SLOTS;       // index of the flag word (u64)
   unsigned int *inv = (unsigned int *)(mm->as<uint64_t>() + FLAG_W + 1); // (its upper half: the heavy-value probe's count)
-  const char *hp_e = std::getenv("SQLRS_ORDER_HEAVY_PROBE"); // (A/B hook, read per call: 0 = no probe)
+  const char *hp_e = hook("SQLRS_ORDER_HEAVY_PROBE"); // (A/B hook, read per call: 0 = no probe)
   const bool heavy_probe = !hbm_only && !(hp_e && hp_e[0] == '0');
   {
     ProfScope ps(ctx, "order_minmax");
@@ -1600,7 +1600,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
       //  range do — the first and the last group then span far more values than their rows use, which their workgroups
       //  notice as one long run of equal top bits and sort on all bits.  SQLRS_ORDER_WIDE_EXACT=1: the exact pass first)
       if (optimistic) {
-        const char *ex = std::getenv("SQLRS_ORDER_WIDE_EXACT");
+        const char *ex = hook("SQLRS_ORDER_WIDE_EXACT");
         if (ex && ex[0] == '1') {
           *retry_exact = true;
           return false;
@@ -1652,7 +1652,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   const int64_t nblocks = ceil_div(n, OW_TILE);
   // (the usual plan — two passes, one carried column, an in-LDS finish — moves {word, value} records through BOTH passes and
   //  needs none of the four column buffers; SQLRS_ORDER_REC1=0, read per call: records out of the last pass only)
-  const char *tl_e0 = std::getenv("SQLRS_ORDER_TILED"), *rec_e0 = std::getenv("SQLRS_ORDER_REC"), *rec1_e = std::getenv("SQLRS_ORDER_REC1");
+  const char *tl_e0 = hook("SQLRS_ORDER_TILED"), *rec_e0 = hook("SQLRS_ORDER_REC"), *rec1_e = hook("SQLRS_ORDER_REC1");
   const bool rec1 = NPAY == 1 && rbits > 0 && top > 8 && top <= 16 && !(tl_e0 && std::atoi(tl_e0) == 0) && !(rec_e0 && std::atoi(rec_e0) == 0) &&
                     !(rec1_e && rec1_e[0] == '0');
   BufP wa = rec1 ? nullptr : ctx->alloc(8 * (size_t)n), wb = rec1 ? nullptr : ctx->alloc(8 * (size_t)n);
@@ -1668,7 +1668,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   // The last of two HBM passes (rbits > 0: an in-LDS finish follows) runs over segment-aligned tiles, which makes
   // the group boundaries a by-product of its count matrix, and (one carried column) writes 16-byte records.
   // SQLRS_ORDER_TILED=0 / SQLRS_ORDER_REC=0 (read per call) keep the plain blocks / the column form for A/B runs.
-  const char *tl_e = std::getenv("SQLRS_ORDER_TILED"), *rec_e = std::getenv("SQLRS_ORDER_REC");
+  const char *tl_e = hook("SQLRS_ORDER_TILED"), *rec_e = hook("SQLRS_ORDER_REC");
   const bool use_tiled = rbits > 0 && !(tl_e && std::atoi(tl_e) == 0);
   const bool use_rec = use_tiled && NPAY == 1 && !(rec_e && std::atoi(rec_e) == 0);
   const int64_t ntmax = nblocks + 256; // tiles of the segment-aligned pass: at most one ragged tile per segment more
@@ -1743,9 +1743,9 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   // chained over their tiles — no count matrices, no scans (1e8 rows: 0.24 + 0.33 ms of histograms and 0.08 of scans
   // against 0.2 for the one histogram).  SQLRS_ORDER_LB=0 (read per call): the counting form; also taken for the rest of
   // the process once a look-back spin ran out (a predecessor tile that never showed up: see ow_scatter_kernel).
-  const char *lb_e = std::getenv("SQLRS_ORDER_LB");
+  const char *lb_e = hook("SQLRS_ORDER_LB");
   static thread_local bool lb_skip = false; // (set around the one re-run after a failed attempt)
-  const char *lbf_e = std::getenv("SQLRS_ORDER_LB_TEST_FAIL"); // (test hook, read per call: treat the attempt as failed)
+  const char *lbf_e = hook("SQLRS_ORDER_LB_TEST_FAIL"); // (test hook, read per call: treat the attempt as failed)
   const bool two_pass = rbits > 0 && top > 8 && top <= 16 && use_tiled;
   const bool lb = two_pass && (NPAY == 1 ? (rec1 && use_rec) : true) && n < (1ll << 30) && !g_order_lb_off.load() && !lb_skip && !(lb_e && lb_e[0] == '0');
   BufP ghb, lbdesc, boundb;
@@ -1765,7 +1765,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     const unsigned gblocks = (unsigned)std::min<int64_t>(nblocks, 4 * (int64_t)ctx->num_cus);
     ow_ghist_kernel<KIND><<<dim3(gblocks), b, 0, ctx->stream>>>(src, n, desc, imin, s1, s2, nblocks, gh, oob_lb, kbits);
     uint64_t *out1 = NPAY == 1 ? recbuf1->as<uint64_t>() : wdst, *out2 = NPAY == 1 ? recbuf->as<uint64_t>() : walt; // (records / words)
-    const char *two_e = std::getenv("SQLRS_ORDER_TWO"); // (read per call: 0 = word and value side by side in LDS, two workgroups per CU)
+    const char *two_e = hook("SQLRS_ORDER_TWO"); // (read per call: 0 = word and value side by side in LDS, two workgroups per CU)
     const bool two = NPAY == 1 && !(two_e && two_e[0] == '0');
     if (two)
       ow_scatter_kernel<KIND, true, NPAY, false, NPAY == 1, false, true, NPAY == 1><<<g, b, 0, ctx->stream>>>(
@@ -1922,7 +1922,7 @@ bool order_fast(Ctx *ctx, const DCol &key, int desc, const DCol *carry, int64_t 
   if (n < (1 << 20) || n > 0xffffffffll || key.stride == 0 || (key.validity && key.null_count != 0)) return false;
   if (carry && (width_of(carry->dtype) != 8 || carry->stride == 0 || (carry->validity && carry->null_count != 0))) return false;
   // optimistic key range for large columns (SQLRS_ORDER_SAMPLE, read per call: 0 = always the exact pass, 1 = always sampled)
-  const char *smp_e = std::getenv("SQLRS_ORDER_SAMPLE");
+  const char *smp_e = hook("SQLRS_ORDER_SAMPLE");
   const bool optimistic = smp_e ? std::atoi(smp_e) != 0 : n >= (1ll << 24); // (1 = whatever the size: tests)
 #define SQ_OF(K)                                                                                                     \
   do {                                                                                                               \
@@ -2010,7 +2010,7 @@ bool order_composite(Ctx *ctx, const std::vector<const DCol *> &keys, const std:
   if (in_order) *in_order = false;
   const int nk = (int)keys.size();
   if (nk < 1 || nk > 4 || n < (1 << 20) || n > 0xffffffffll) return false;
-  if (const char *e = std::getenv("SQLRS_ORDER_COMPOSITE")) // (A/B hook, read per call: 0 = the general path)
+  if (const char *e = hook("SQLRS_ORDER_COMPOSITE")) // (A/B hook, read per call: 0 = the general path)
     if (e[0] == '0') return false;
   CompKeys ck{};
   ck.nk = nk;

@@ -1856,7 +1856,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   if (P_wanted > 512) { // one level handles up to 512 digits (runs of >= 8 rows per tile)
     // split the digits evenly between the two levels: 2^p2_bits second-level digits with
     // 2^p2_bits >= sqrt(P) (runs get longer as a level's digit count drops)
-    const char *p2_e = std::getenv("SQLRS_RP_P2BITS"); // tuning hook, read per call (in-process A/B)
+    const char *p2_e = hook("SQLRS_RP_P2BITS"); // tuning hook, read per call (in-process A/B)
     const int p2_env = p2_e ? std::atoi(p2_e) : 0;
     p2_bits = 5;
     while (p2_bits < 8 && (1u << (2 * p2_bits)) < P_wanted) p2_bits++;
@@ -1889,7 +1889,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   const int WG = 512;
   // rows per thread: 12 -> 6144-row tiles, 8 -> 4096-row tiles (two value columns); one
   // workgroup per CU either way (the staging area is ~140 KiB)
-  const char *rows_e = std::getenv("SQLRS_RP_ROWS"); // tuning only, read per call (in-process A/B)
+  const char *rows_e = hook("SQLRS_RP_ROWS"); // tuning only, read per call (in-process A/B)
   const int rows_env = rows_e ? std::atoi(rows_e) : 0;
   // 16 = 8192-row tiles (packed rows with one value column only: 128 KiB of staging, 256 VGPRs, no spills): the
   // default for very large batches — a third fewer barrier rounds per row (C5, one process: level 1 5.50 -> 5.36 ms,
@@ -1911,7 +1911,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // two 8-byte columns — one store per row here, one load per row in the bucket pass, and a (tile, digit) run
   // of ~24 rows covers three cache lines instead of 2 x 1.5 (C5: level 2 4.93 -> 4.26 ms, bucket pass 1.81 ->
   // 1.67 ms in one process)
-  const char *rec_e = std::getenv("SQLRS_RP_REC"); // read per call: 0 = column form (in-process A/B, tools/ab_in_process.py)
+  const char *rec_e = hook("SQLRS_RP_REC"); // read per call: 0 = column form (in-process A/B, tools/ab_in_process.py)
   const bool use_rec = pack && nv == 1 && (ROWS == 12 || ROWS == 16) && !(rec_e && std::atoi(rec_e) == 0);
   struct Cols {
     BufP k, v0, v1, idx, fl, rec;
@@ -1994,7 +1994,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
           allow_big_lds(ctx, kfn);
           kfn<<<g, b, slds, ctx->stream>>>(slim->in, slim->out, tp, p2_bits, digits, offs_tm->as<uint32_t>(), nt, tpw, sink,
                                           slim->kshift, slim->rbits);
-        } else if (std::getenv("SQLRS_RP_L2_WG") && std::atoi(std::getenv("SQLRS_RP_L2_WG")) == 768) { // A/B hook, read per call
+        } else if (hook("SQLRS_RP_L2_WG") && std::atoi(hook("SQLRS_RP_L2_WG")) == 768) { // A/B hook, read per call
           auto kfn = rp_scatter_slim_kernel<768, 8>;
           allow_big_lds(ctx, kfn);
           kfn<<<g, dim3(768), slds + 256 * 16, ctx->stream>>>(slim->in, slim->out, tp, p2_bits, digits, offs_tm->as<uint32_t>(), nt, tpw, sink,
@@ -2075,14 +2075,14 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // ---- claimed single level (no histogram pass, optional fused row filter): one-level range partitions of packed
   // rows; see rp_claim_scatter_kernel.  Hashed buckets keep the counting level (their bucket pass takes a sentinel
   // row for a key of its own).
-  const char *claim_e = std::getenv("SQLRS_RP_CLAIM"); // test / tuning hook, read per call: 0 = never, 1 = whatever the batch size
+  const char *claim_e = hook("SQLRS_RP_CLAIM"); // test / tuning hook, read per call: 0 = never, 1 = whatever the batch size
   const int claim_env = claim_e ? std::atoi(claim_e) : -1;
   const bool claimable = p2_bits == 0 && pack && kp.dense && nv <= 1 && ROWS == 12 && P <= (uint32_t)WG && P >= 2 &&
                          claim_env != 0 && (claim_env == 1 || n >= (1ll << 22));
   if (claimable) {
     const uint32_t tiles1c = (uint32_t)ceil_div(n, RP_TILE);
     uint32_t wgs = std::min<uint32_t>(tiles1c, (uint32_t)ctx->num_cus);
-    if (const char *wg_e = std::getenv("SQLRS_RP_CHUNK_WGS")) // test hook, read per call: fewer workgroups = longer tile ranges per workgroup
+    if (const char *wg_e = hook("SQLRS_RP_CHUNK_WGS")) // test hook, read per call: fewer workgroups = longer tile ranges per workgroup
       wgs = std::max(1u, std::min<uint32_t>(wgs, (uint32_t)std::atoi(wg_e)));
     const uint32_t tpw = (uint32_t)ceil_div(tiles1c, std::max(wgs, 1u));
     wgs = (uint32_t)ceil_div(tiles1c, std::max(tpw, 1u));
@@ -2117,7 +2117,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       }
       // slim form (rp_claim_scatter_slim_kernel): 12 bytes per row out of the level; SQLRS_RP_SLIM=0 (read per call) = the
       // 16-byte form (tests, A/B)
-      const char *cslim_e = std::getenv("SQLRS_RP_SLIM");
+      const char *cslim_e = hook("SQLRS_RP_SLIM");
       const bool claim_slim = nv == 1 && kp.rbits + SLIM_LOCAL_BITS + 7 <= 32 && !(cslim_e && std::atoi(cslim_e) == 0);
       Cols cc;
       PartitionedRows::Slim csl;
@@ -2179,12 +2179,12 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
           so.kept = co.kept;
           so.B = B;
           so.log_b = csl.log_b;
-          const char *sd_e = std::getenv("SQLRS_RP_SLIM_DELTA"); // test hook, read per call: blocks abandoned after fewer tiles
+          const char *sd_e = hook("SQLRS_RP_SLIM_DELTA"); // test hook, read per call: blocks abandoned after fewer tiles
           so.max_delta = sd_e ? (uint32_t)std::max(1, std::min(std::atoi(sd_e), 127)) : 127u;
           const size_t slds = (size_t)RP_TILE * (8 + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8 + 4);
           // 768-thread workgroups (twelve waves on the same 6144-row tile, 159 VGPRs, no spill) by default: C4 scatter 1.49 -> 1.43 ms,
           // with the WHERE fused 1.31 -> 1.14 (one process, three rounds); SQLRS_RP_CLAIM_WG=512 (read per call) = the eight-wave form
-          const char *cwg_e = std::getenv("SQLRS_RP_CLAIM_WG");
+          const char *cwg_e = hook("SQLRS_RP_CLAIM_WG");
           const bool wg768 = psrc != 3 && !(cwg_e && std::atoi(cwg_e) == 512); // (own predicate column: 4 spilled registers at 768)
           const size_t slds768 = (size_t)RP_TILE * (8 + 4 + 2) + (size_t)768 * (4 + 4 + 8 + 8 + 4);
 #define SQ_CS(PS)                                                                                                   \
@@ -2233,7 +2233,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   // ---- chunked first level (no histogram pass, optional fused row filter): two-level partitions of
   // batches large enough that the slack of the arenas (workgroups x (digits + 1) chunks) is a fraction of the input
   static const int chunk_env = [] { // test / tuning hook: 1 = whenever two levels are needed, 0 = never
-    const char *e = std::getenv("SQLRS_RP_CHUNKED");
+    const char *e = hook("SQLRS_RP_CHUNKED");
     return e ? std::atoi(e) : -1;
   }();
   // (3072-row tiles with two workgroups per CU were measured slower for this level too: 6.4 vs 5.7 ms; so were 1024-thread
@@ -2241,13 +2241,13 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
   //  6.65 vs 5.68 ms, round 4)
   const uint32_t tiles1 = (uint32_t)ceil_div(n, RP_TILE);
   uint32_t cwgs = std::min<uint32_t>(tiles1, (uint32_t)ctx->num_cus);
-  if (const char *wg_e = std::getenv("SQLRS_RP_CHUNK_WGS")) // test hook, read per call: fewer workgroups = longer tile ranges per workgroup
+  if (const char *wg_e = hook("SQLRS_RP_CHUNK_WGS")) // test hook, read per call: fewer workgroups = longer tile ranges per workgroup
     cwgs = std::max(1u, std::min<uint32_t>(cwgs, (uint32_t)std::atoi(wg_e)));
   const uint32_t ctpw = (uint32_t)ceil_div(tiles1, std::max(cwgs, 1u));
   cwgs = (uint32_t)ceil_div(tiles1, std::max(ctpw, 1u));
   const uint64_t spare_chunks = (uint64_t)cwgs * (d1 + 1); // chunks that may stay partly filled or unused
   static const int ct_env = [] { // tuning hook: tiles per chunk (1, 4, 8, 16 measured alike: 1 = smallest reservation)
-    const char *e = std::getenv("SQLRS_RP_CHUNK_TILES");
+    const char *e = hook("SQLRS_RP_CHUNK_TILES");
     return e ? std::max(1, std::min(64, std::atoi(e))) : 1;
   }();
   const uint64_t CAP = (uint64_t)RP_TILE * (uint64_t)ct_env;
@@ -2258,13 +2258,13 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     // Slim records (12 instead of 16 bytes per row through level 1, level 2 and the bucket pass; see the section
     // "slim records" above): dense packed rows with one value column whose chunk histograms fit LDS, bucket tables of
     // <= 4096 slots.  SQLRS_RP_SLIM=0 (read per call) keeps the 16-byte form (in-process A/B, tests).
-    const char *slim_e = std::getenv("SQLRS_RP_SLIM");
+    const char *slim_e = hook("SQLRS_RP_SLIM");
     const bool slim_on = pack && kp.dense && nv == 1 && (ROWS == 12 || ROWS == 16) && ct_env == 1 && (size_t)P * 4 <= 24 * 1024 &&
                          kp.rbits + SLIM_LOCAL_BITS + 7 <= 32 && kp.rbits + p2_bits + SLIM_LOCAL_BITS <= 32 &&
-                         !(slim_e && std::atoi(slim_e) == 0) && !(std::getenv("SQLRS_RP_H2") && std::atoi(std::getenv("SQLRS_RP_H2")) == 0);
+                         !(slim_e && std::atoi(slim_e) == 0) && !(hook("SQLRS_RP_H2") && std::atoi(hook("SQLRS_RP_H2")) == 0);
     // arena mode: a workgroup fills at most ceil(its rows / CAP) chunks completely and leaves <= d1 partly filled
     // (slim: + the chunks closed early because their next run would be more than SLIM_RUNS - 1 tiles after their first)
-    const char *sd_e = std::getenv("SQLRS_RP_SLIM_DELTA"); // test hook, read per call: early closes at test sizes
+    const char *sd_e = hook("SQLRS_RP_SLIM_DELTA"); // test hook, read per call: early closes at test sizes
     const uint32_t slim_delta = sd_e ? (uint32_t)std::max(1, std::min<int>(std::atoi(sd_e), (int)SLIM_RUNS - 1)) : SLIM_RUNS - 1;
     const uint64_t arena = (uint64_t)ceil_div((int64_t)ctpw, (int64_t)ct_env) + d1 + 1 +
                            (slim_on ? (uint64_t)d1 * (uint64_t)ceil_div((int64_t)ctpw, (int64_t)slim_delta + 1) : 0);
@@ -2310,7 +2310,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       so.kshift = kp.rbits + p2_bits;
       so.max_delta = slim_delta;
       {
-        const char *cc_e = std::getenv("SQLRS_RP_CONC"); // tuning / test hook, read per call: 1 .. 8 eighths of a tile's row slots, 9 = never
+        const char *cc_e = hook("SQLRS_RP_CONC"); // tuning / test hook, read per call: 1 .. 8 eighths of a tile's row slots, 9 = never
         so.conc_eighths = cc_e ? (uint32_t)std::max(1, std::min(std::atoi(cc_e), 9)) : 3u;
       }
       const int psrc = !in.filter.col ? -1 : ((const void *)in.filter.col == in.vals[0] ? 1 : 3);
@@ -2326,7 +2326,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
                                                       tiles1, ctpw, sink, kp);                                      \
   } while (0)
 #define SQ_SL(R) do { if (psrc < 0) SQ_SL1(R, -1); else if (psrc == 1) SQ_SL1(R, 1); else SQ_SL1(R, 3); } while (0)
-        const char *l1wg_e = std::getenv("SQLRS_RP_L1_WG"); // A/B hook, read per call: 512 = the eight-wave form, 1024 x 6 rows
+        const char *l1wg_e = hook("SQLRS_RP_L1_WG"); // A/B hook, read per call: 512 = the eight-wave form, 1024 x 6 rows
         const int l1wg = l1wg_e ? std::atoi(l1wg_e) : 768;
         if (ROWS == 12 && psrc != 3 && l1wg == 1024) {
           const size_t clds1k = (size_t)RP_TILE * 14 + (size_t)1024 * (4 + 4 + 8 + 8 + 4 + 4) + (size_t)P * 4;
@@ -2416,7 +2416,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
           tile_chunk->as<uint32_t>(), so.chunk_base, digits2, sl.nzstart->as<uint32_t>(), sl.nzbt->as<uint32_t>(),
           sl.nzcount->as<uint32_t>(), sl.bcol->as<uint32_t>());
       SQ_HIP(hipGetLastError());
-      if (std::getenv("SQLRS_RP_TRACE")) // placement experiments (tools/placement_log.py): where the big buffers sit
+      if (hook("SQLRS_RP_TRACE")) // placement experiments (tools/placement_log.py): where the big buffers sit
         std::fprintf(stderr, "[rp_slim] keys %p vals %p chunks %p %p rows %p %p kept %llu tiles %u\n", (const void *)in.keys, in.vals[0],
                      cb0 ? cb0->p : nullptr, cb1 ? cb1->p : nullptr, sl.buf0 ? sl.buf0->p : nullptr, sl.buf1 ? sl.buf1->p : nullptr,
                      (unsigned long long)kept, L2.num_tiles);
@@ -2447,7 +2447,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       co.cap = (uint32_t)CAP;
       const int psrc = !in.filter.col ? -1 : ((nv >= 1 && (const void *)in.filter.col == in.vals[0]) ? 1 : 3);
       // chunk histograms of the next level counted by this kernel (H2): every bucket needs a 4-byte counter in LDS
-      const char *h2_e = std::getenv("SQLRS_RP_H2"); // A/B hook, read per call: 0 = level 2 runs its own histogram pass
+      const char *h2_e = hook("SQLRS_RP_H2"); // A/B hook, read per call: 0 = level 2 runs its own histogram pass
       const bool h2 = pack && nv == 1 && (ROWS == 12 || ROWS == 16) && ct_env == 1 && (size_t)P * 4 <= 24 * 1024 && !(h2_e && std::atoi(h2_e) == 0);
       BufP chist = h2 ? ctx->alloc(4 * (size_t)max_chunks * ((size_t)1 << p2_bits)) : nullptr;
       co.hist = chist ? chist->as<uint32_t>() : nullptr;
@@ -2477,7 +2477,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         else if (nv == 0) { if (pack) SQ_CS(0, 12, true); else SQ_CS(0, 12, false); }
         // (768 threads x 8 rows for the unpacked rows of hashed partitions too: sparse-key C5 level 1 6.91 -> 6.81 ms in one process;
         //  SQLRS_RP_L1G_WG=512, read per call, = the eight-wave form; a predicate on a column of its own keeps it: 14 spilled registers)
-        else if (!pack && psrc != 3 && !(std::getenv("SQLRS_RP_L1G_WG") && std::atoi(std::getenv("SQLRS_RP_L1G_WG")) == 512)) {
+        else if (!pack && psrc != 3 && !(hook("SQLRS_RP_L1G_WG") && std::atoi(hook("SQLRS_RP_L1G_WG")) == 512)) {
           const size_t clds768 = (size_t)RP_TILE * (8 * (1 + nv) + 4 + 2) + (size_t)768 * (4 + 4 + 8 + 8) + (clds - ((size_t)RP_TILE * (8 * (1 + nv) + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8)));
 #define SQ_CG(PS)                                                                                                   \
   do {                                                                                                              \

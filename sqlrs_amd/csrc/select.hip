@@ -558,7 +558,7 @@ static void launch_filter(Ctx *ctx, int op, const DCol &c, T k, int64_t rows, T 
       if (!occ) {                                                                                                \
         SQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, filter_cmp_const_persistent_kernel<T, OP, HV>, \
                                                             FILTER_BLOCK, 0));                                   \
-        const char *fo_e = std::getenv("SQLRS_FILTER_OCC"); /* tuning hook: most resident workgroups per CU */   \
+        const char *fo_e = hook("SQLRS_FILTER_OCC"); /* tuning hook: most resident workgroups per CU */   \
         occ = std::max(1, std::min({occ, fo_e ? std::max(1, std::atoi(fo_e)) : 2,                                \
                                     simd_safe_blocks((const void *)filter_cmp_const_persistent_kernel<T, OP, HV>, FILTER_BLOCK)})); \
       }                                                                                                          \

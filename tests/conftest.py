@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault("SQLRS_HOOKS", "1")  # the library consults its SQLRS_* test / tuning hooks only in a process that opts in (common.hpp: hook)
 import os
 import subprocess
 import sys

@@ -1,6 +1,7 @@
 """In-process A/B of a tuning hook (VAR=name VALUES=a,b,c): C5 steps with the fused filter, per-kernel
 device time from the ctx profile.  Kernel times differ by 10-15 % BETWEEN processes (physical placement
 of the buffers) but repeat to 0.2 % inside one, so variants must be compared in one process."""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,6 @@
 """C3 probe (1e8 x 1e6, all hit) in ONE process under several settings of a per-call hook: VAR=<env name> VALUES=a,b,c.
 python tools/c3_probe_ab.py"""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

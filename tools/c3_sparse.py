@@ -1,5 +1,6 @@
 """C3 with sparse keys (1e8 probe x 1e6 build, all hit): probe time + kernel classes, with an in-process A/B of a per-call
 hook (VAR / VALUES), e.g.  VAR=SQLRS_LDS_JOIN VALUES=0,-1  or  VAR=SQLRS_LJ_RPI VALUES=1,8."""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import os, sys, time, ctypes as C
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import torch

@@ -3,6 +3,7 @@ event-timed best of REPS per variant of an env hook that the library reads per c
   VAR=SQLRS_RP_SLIM VALS=1,0 python tools/c4_agg.py        (slim / 16-byte rows out of the claimed level)
 and what tools/timeline_ops.sh slices:  CMD="python tools/c4_agg.py" DELIM=key_stats_kernel bash tools/timeline_ops.sh
 SHAPE=uniform|zipf|sorted, N / G = rows / groups, WHERE=1 adds `val > 0.5` handed to the aggregate."""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

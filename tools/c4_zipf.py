@@ -1,4 +1,5 @@
 """C4 with Zipf(1.1) keys (and uniform) in one process with an A/B of a per-call hook (VAR / VALUES)."""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import os, sys, ctypes as C
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np, torch

@@ -3,6 +3,7 @@ timed phase by phase — everything but the wire: (1) HashAgg(Filter(fact slice)
 (2) hash partition of the partials W ways, (3) the merge on the owning rank: HashJoinAgg(dim partition, the partials that
 W ranks send to partition 0).  The other ranks' partials for (3) are computed from their own fact slices the same way.
   python tools/c5_combine_rank.py [W ...]       (default 2 4 8)"""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import ctypes as C, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

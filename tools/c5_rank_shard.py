@@ -4,6 +4,7 @@ the dim keys and the kept fact rows rank 0 would receive — is collected, and t
 timed.  The received keys are a pseudo-random 1/W subset of 0..n_dim: whether they still take the direct-addressed
 (dense) routes decides how the per-rank time scales with W.
   python tools/c5_rank_shard.py [W ...]      (default 1 2 4 8; SQLRS_BENCH_ROWS / SQLRS_BENCH_DIM as in bench.py)"""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

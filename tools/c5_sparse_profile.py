@@ -1,5 +1,6 @@
 """Kernel classes of ONE step of the sparse-key C5 variant (keys k -> k * A + B: hashed LDS buckets, general join
 table deferred) — where bench.py's `c5_variants.sparse_keys` spends its time.  python tools/c5_sparse_profile.py"""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

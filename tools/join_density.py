@@ -1,5 +1,6 @@
 """Inner join, unique build keys that cover 1 / D of their range (D = 2, 8, 16), 1e6 build rows, N probe rows (all hit):
 direct-address table (SQLRS_DENSE_JOIN_SLOTS_PLAIN >= D) against the general routes.  python tools/join_density.py"""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, pyarrow as pa

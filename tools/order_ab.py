@@ -1,5 +1,6 @@
 """ORDER BY on 1e8 rows of a wide key (f64 uniform / 63-bit int64), one carried column: time per call under the values of one
 environment hook that order_fast.hip reads per call.  VAR=SQLRS_ORDER_SAMPLES VALUES=16,32,64 python tools/order_ab.py"""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import ctypes as C
 import os
 import sys

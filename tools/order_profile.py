@@ -1,4 +1,5 @@
 """Per-kernel-class device time of ORDER BY v1 (int64, 31 bits) carrying one f64 column, N rows (bench's Order shape)."""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -2,6 +2,7 @@
 rounds (fresh hipMalloc blocks = fresh placement), SQLRS_RP_TRACE prints the device pointers.  The spread of the partition
 kernels between processes (10-20 %) follows placement; this shows whether it follows the VIRTUAL addresses.
     python tools/placement_log.py        (REPS=10)"""
+import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SQLRS_RP_TRACE"] = "1"
