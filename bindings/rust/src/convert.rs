@@ -88,6 +88,38 @@ impl AbiBatch {
     }
 }
 
+/// The same hand-over through the Arrow C Data Interface (`sqlrs_batch_import_arrow`, round 6): the batch is exported as a
+/// struct array with arrow's own `arrow::ffi` and MOVED into the library — no descriptor is built by hand and nothing is
+/// copied; the library releases the arrow buffers when the returned batch is released.
+pub struct FfiBatch(pub *mut sqlrs_batch_t);
+impl FfiBatch {
+    pub fn new(ctx: &HipCtx, batch: &RecordBatch) -> Result<Self, ExecutorError> {
+        let data = arrow::array::StructArray::from(batch.clone()).into_data();
+        let mut array = arrow::ffi::FFI_ArrowArray::new(&data);
+        let mut schema = arrow::ffi::FFI_ArrowSchema::try_from(data.data_type())?;
+        let mut out = std::ptr::null_mut();
+        // (on failure nothing was consumed: `array` / `schema` release their exports when they drop)
+        ctx.check(unsafe { sqlrs_batch_import_arrow(ctx.raw(), &mut array, &mut schema, &mut out) })?;
+        std::mem::forget(array); // moved: their `release` fields are NULL now, nothing left to drop
+        std::mem::forget(schema);
+        Ok(FfiBatch(out))
+    }
+}
+impl Drop for FfiBatch {
+    fn drop(&mut self) { unsafe { sqlrs_batch_release(self.0) } }
+}
+/// ... and back: a library batch MOVED out as (FFI_ArrowArray, FFI_ArrowSchema) and imported by arrow without a copy
+/// (`sqlrs_batch_export_arrow`; device-resident batches are downloaded by the call).
+pub fn export_batch_ffi(ctx: &HipCtx, schema: SchemaRef, out: *mut sqlrs_batch_t) -> Result<RecordBatch, ExecutorError> {
+    let names: Vec<CString> = schema.fields().iter().map(|f| CString::new(f.name().as_str()).unwrap()).collect();
+    let ptrs: Vec<*const std::os::raw::c_char> = names.iter().map(|n| n.as_ptr()).collect();
+    let mut array = arrow::ffi::FFI_ArrowArray::empty();
+    let mut fschema = arrow::ffi::FFI_ArrowSchema::empty();
+    ctx.check(unsafe { sqlrs_batch_export_arrow(ctx.raw(), out, ptrs.as_ptr(), &mut array, &mut fschema) })?;
+    let data = arrow::ffi::ArrowArray::new(array, fschema).to_data()?;
+    Ok(RecordBatch::from(&arrow::array::StructArray::from(data)))
+}
+
 /// Copies a library batch (out_mem = HOST) into arrow buffers, then releases it.
 pub fn import_batch(schema: SchemaRef, out: *mut sqlrs_batch_t) -> Result<RecordBatch, ExecutorError> {
     let b = unsafe { &*out };

@@ -213,6 +213,55 @@ void sqlrs_batch_release(sqlrs_batch_t *batch);
  * this is the "Arrow column buffers move to HBM once per pipeline" step. */
 int sqlrs_batch_copy(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, int out_mem, sqlrs_batch_t **out);
 
+/* --------------------------------------------------- Arrow C Data Interface -- */
+/* [ref: src/executor/mod.rs:34  BoxedExecutor = BoxStream<'static, Result<RecordBatch, ExecutorError>> — the item every
+ *  operator of the reference consumes and yields is an arrow RecordBatch]  The two structs of the Arrow C Data Interface,
+ * exactly as the specification defines them (the guard is the specification's own, so this header coexists with
+ * arrow/c/abi.h); arrow-rs binds them as arrow::ffi::{FFI_ArrowArray, FFI_ArrowSchema}, pyarrow as _export_to_c /
+ * _import_from_c. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+#define ARROW_FLAG_DICTIONARY_ORDERED 1
+#define ARROW_FLAG_NULLABLE 2
+#define ARROW_FLAG_MAP_KEYS_SORTED 4
+struct ArrowSchema {
+  const char *format;
+  const char *name;
+  const char *metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema **children;
+  struct ArrowSchema *dictionary;
+  void (*release)(struct ArrowSchema *);
+  void *private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void **buffers;
+  struct ArrowArray **children;
+  struct ArrowArray *dictionary;
+  void (*release)(struct ArrowArray *);
+  void *private_data;
+};
+#endif
+/* A RecordBatch exported as a struct array ("+s": what RecordBatch::into / pyarrow's RecordBatch._export_to_c produce) ->
+ * a HOST batch of this library WITHOUT copying its buffers: both structures are MOVED into the call (their `release`
+ * fields are NULL afterwards, as the specification's move rule says; the schema is released before the call returns, the
+ * array when the batch is: sqlrs_batch_release).  Children of type int32 "i", int64 "l", float64 "g", bool "b", utf8 "u";
+ * anything else, a dictionary, or NULLs at the struct level: SQLRS_ERR_ARROW and nothing is consumed.  A child whose
+ * offset is not a multiple of eight has its bitmaps re-packed (the only copy). */
+int sqlrs_batch_import_arrow(sqlrs_ctx_t *ctx, struct ArrowArray *array, struct ArrowSchema *schema, sqlrs_batch_t **out);
+/* The reverse: `batch` (produced by this library; HOST or DEVICE resident — device columns are downloaded first) is MOVED
+ * into `out_array` / `out_schema` and must not be used or released by the caller afterwards: the consumer's `release`
+ * callbacks give the memory back.  `names`: num_columns field names or NULL ("c0", "c1", ...).  A caller-built batch
+ * (owner == NULL) is copied, since its buffers are only borrowed. */
+int sqlrs_batch_export_arrow(sqlrs_ctx_t *ctx, sqlrs_batch_t *batch, const char *const *names, struct ArrowArray *out_array,
+                             struct ArrowSchema *out_schema);
+
 /* ----------------------------------------------------------------- Filter -- */
 /* [ref: src/executor/filter.rs:7-25  FilterExecutor{expr, child}::execute]
  * One output batch per input batch, row order preserved, rows whose predicate

@@ -157,6 +157,68 @@ class RawBatch:
         return C.byref(self.abi)
 
 
+class ArrowSchemaC(C.Structure):
+    pass
+
+
+class ArrowArrayC(C.Structure):
+    pass
+
+
+ArrowSchemaC._fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64),
+                         ("n_children", C.c_int64), ("children", C.POINTER(C.POINTER(ArrowSchemaC))),
+                         ("dictionary", C.POINTER(ArrowSchemaC)), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+ArrowArrayC._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+                        ("n_children", C.c_int64), ("buffers", C.POINTER(C.c_void_p)),
+                        ("children", C.POINTER(C.POINTER(ArrowArrayC))), ("dictionary", C.POINTER(ArrowArrayC)),
+                        ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+# When set to a Backend that has sqlrs_batch_import_arrow / _export_arrow, pyarrow RecordBatches cross the boundary through
+# the Arrow C Data Interface (RecordBatch._export_to_c / _import_from_c: what arrow-rs's arrow::ffi does) instead of through
+# hand-built sqlrs_column_t descriptors; tests/test_gpu_arrow_c.py replays the reference's goldens that way.
+ARROW_C_BACKEND = None
+
+
+class ArrowCBatch:
+    """A pyarrow RecordBatch handed over through the Arrow C Data Interface: pyarrow exports (array, schema), the library
+    imports them WITHOUT copying and owns them until release."""
+
+    def __init__(self, backend: "Backend", rb: pa.RecordBatch):
+        self.backend = backend
+        arr, sch = ArrowArrayC(), ArrowSchemaC()
+        rb._export_to_c(C.addressof(arr), C.addressof(sch))
+        out = C.POINTER(Batch)()
+        st = backend.fn("batch_import_arrow")(backend.ctx, C.byref(arr), C.byref(sch), C.byref(out))
+        if st != OK:  # nothing was consumed: give pyarrow's exports back
+            pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
+            backend.check(st)
+        assert not arr.release and not sch.release  # moved
+        self.p = out
+
+    @property
+    def ptr(self):
+        return self.p
+
+    @property
+    def num_rows(self) -> int:
+        return self.p.contents.num_rows
+
+    @property
+    def num_columns(self) -> int:
+        return self.p.contents.num_columns
+
+    def release(self):
+        if self.p is not None:
+            self.backend.fn("batch_release")(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class LibBatch:
     """A batch owned by a library (host or device resident) until released."""
 
@@ -181,6 +243,17 @@ class LibBatch:
 
     def to_arrow(self, names: Optional[Sequence[str]] = None) -> pa.RecordBatch:
         """Copies a HOST resident library batch into a pyarrow RecordBatch."""
+        if ARROW_C_BACKEND is not None and self.backend is ARROW_C_BACKEND:
+            # the batch is MOVED into the exported structures; pyarrow's import takes them over (zero copy) and a final
+            # copy detaches the result from this library's memory like the path below does
+            arr, sch = ArrowArrayC(), ArrowSchemaC()
+            nm = None
+            if names is not None:
+                enc = [n.encode() for n in names]
+                nm = (C.c_char_p * len(enc))(*enc)
+            p, self.p = self.p, None
+            self.backend.check(self.backend.fn("batch_export_arrow")(self.backend.ctx, p, nm, C.byref(arr), C.byref(sch)))
+            return pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
         b = self.p.contents
         arrays = []
         for i in range(b.num_columns):
@@ -223,7 +296,7 @@ class LibBatch:
 def as_batch(x):
     """pyarrow RecordBatch / HostBatch / RawBatch / LibBatch -> object with .ptr"""
     if isinstance(x, pa.RecordBatch):
-        return HostBatch(x)
+        return ArrowCBatch(ARROW_C_BACKEND, x) if ARROW_C_BACKEND is not None else HostBatch(x)
     if isinstance(x, pa.Table):
         return HostBatch(x.combine_chunks().to_batches()[0] if x.num_rows else
                          pa.RecordBatch.from_pylist([], schema=x.schema))
@@ -309,6 +382,8 @@ class Backend:
             "ctx_pool_bytes": (C.c_int64, [vp]),
             "ctx_pool_trim": (None, [vp]),
             "batch_copy": (i, [vp, pb, i, ppb]),
+            "batch_import_arrow": (i, [vp, C.POINTER(ArrowArrayC), C.POINTER(ArrowSchemaC), ppb]),
+            "batch_export_arrow": (i, [vp, pb, C.POINTER(C.c_char_p), C.POINTER(ArrowArrayC), C.POINTER(ArrowSchemaC)]),
             "exchange_unique_id": (i, [vp, vp]),
             "exchange_create": (i, [vp, vp, i, i, pvp]),
             "exchange_all_to_all": (i, [vp, pb, C.POINTER(C.c_int64), C.POINTER(C.c_int64), ppb, C.POINTER(C.c_int64)]),

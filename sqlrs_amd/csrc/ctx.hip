@@ -1,6 +1,8 @@
 // ctx.hip — ctx lifecycle, device memory pool, ABI <-> HBM column conversion, timers.
 #include <cstdlib>
 
+#include <array>
+#include <atomic>
 #include <mutex>
 #include <unordered_set>
 
@@ -330,6 +332,7 @@ struct OwnedBatch {
   uint64_t magic = OWNED_BATCH_MAGIC;
   Ctx *ctx = nullptr;
   int out_mem = SQLRS_MEM_HOST;
+  ArrowArray imported = {}; // sqlrs_batch_import_arrow: the array whose buffers the columns point into (released with the batch)
   OwnedBatch() {
     std::lock_guard<std::mutex> lk(g_owned_mu);
     g_owned.insert(this);
@@ -341,6 +344,7 @@ struct OwnedBatch {
     }
     magic = 0;
     for (void *p : host_blocks) std::free(p);
+    if (imported.release) imported.release(&imported);
   }
 };
 
@@ -832,6 +836,251 @@ int sqlrs_batch_copy(sqlrs_ctx_t *ctx, const sqlrs_batch_t *in, int out_mem, sql
     InBatch ib(ctx, in);
     DBatch b = ib.materialize(true);
     *out = emit_batch(ctx, std::move(b), out_mem);
+  });
+}
+
+// ---- Arrow C Data Interface (sqlrs_hip.h) ---------------------------------------------------------------------------
+namespace {
+int32_t arrow_dtype(const char *f) {
+  if (!f) return -1;
+  if (!std::strcmp(f, "i")) return SQLRS_INT32;
+  if (!std::strcmp(f, "l")) return SQLRS_INT64;
+  if (!std::strcmp(f, "g")) return SQLRS_FLOAT64;
+  if (!std::strcmp(f, "b")) return SQLRS_BOOLEAN;
+  if (!std::strcmp(f, "u")) return SQLRS_UTF8;
+  return -1;
+}
+const char *arrow_format(int32_t dtype) {
+  switch (dtype) {
+  case SQLRS_INT32: return "i";
+  case SQLRS_INT64: return "l";
+  case SQLRS_FLOAT64: return "g";
+  case SQLRS_BOOLEAN: return "b";
+  case SQLRS_UTF8: return "u";
+  default: return nullptr;
+  }
+}
+// `n` bits of `src` from bit `off` on, re-packed from bit 0 (a sliced array whose offset is not a whole byte)
+uint8_t *repack_bits(const uint8_t *src, int64_t off, int64_t n, std::vector<void *> &blocks) {
+  uint8_t *dst = (uint8_t *)std::calloc((size_t)(n + 7) / 8 + 8, 1);
+  if (!dst) fail(SQLRS_ERR_INTERNAL, "host allocation failed");
+  blocks.push_back(dst);
+  for (int64_t i = 0; i < n; i++)
+    if ((src[(off + i) >> 3] >> ((off + i) & 7)) & 1) dst[i >> 3] |= (uint8_t)(1u << (i & 7));
+  return dst;
+}
+const uint8_t *bits_at(const void *buf, int64_t off, int64_t n, std::vector<void *> &blocks) {
+  if (!buf) return nullptr;
+  if ((off & 7) == 0) return (const uint8_t *)buf + (off >> 3);
+  return repack_bits((const uint8_t *)buf, off, n, blocks);
+}
+int64_t clear_bits(const uint8_t *bits, int64_t n) {
+  int64_t set = 0;
+  for (int64_t i = 0; i < (n >> 3); i++) set += __builtin_popcount(bits[i]);
+  for (int64_t i = n & ~7ll; i < n; i++) set += (bits[i >> 3] >> (i & 7)) & 1;
+  return n - set;
+}
+
+// what an exported array / schema keeps alive; one reference per structure that still points into it
+struct ExportHolder {
+  std::atomic<int> refs{0};
+  sqlrs_batch_t *batch = nullptr;
+  std::vector<ArrowArray> children;
+  std::vector<ArrowArray *> child_ptrs;
+  std::vector<std::array<const void *, 3>> bufs;
+  const void *top_buf[1] = {nullptr};
+  void unref() {
+    if (refs.fetch_sub(1) == 1) {
+      sqlrs_batch_release(batch);
+      delete this;
+    }
+  }
+};
+void export_child_release(ArrowArray *a) {
+  if (!a || !a->release) return;
+  ExportHolder *h = (ExportHolder *)a->private_data;
+  a->release = nullptr;
+  h->unref();
+}
+void export_parent_release(ArrowArray *a) {
+  if (!a || !a->release) return;
+  ExportHolder *h = (ExportHolder *)a->private_data;
+  for (int64_t i = 0; i < a->n_children; i++) // (children the consumer has moved out carry release == NULL here)
+    if (a->children[i] && a->children[i]->release) a->children[i]->release(a->children[i]);
+  a->release = nullptr;
+  h->unref();
+}
+struct SchemaHolder {
+  std::vector<ArrowSchema> children;
+  std::vector<ArrowSchema *> child_ptrs;
+  std::vector<std::string> names;
+};
+void export_schema_child_release(ArrowSchema *s) {
+  if (s) s->release = nullptr; // (its strings belong to the parent's holder)
+}
+void export_schema_release(ArrowSchema *s) {
+  if (!s || !s->release) return;
+  SchemaHolder *h = (SchemaHolder *)s->private_data;
+  for (int64_t i = 0; i < s->n_children; i++)
+    if (s->children[i] && s->children[i]->release) s->children[i]->release(s->children[i]);
+  s->release = nullptr;
+  delete h;
+}
+} // namespace
+
+int sqlrs_batch_import_arrow(sqlrs_ctx_t *ctx, struct ArrowArray *array, struct ArrowSchema *schema, sqlrs_batch_t **out) {
+  if (out) *out = nullptr;
+  return guard(ctx, [&] {
+    if (!array || !schema || !out || !array->release || !schema->release) fail(SQLRS_ERR_ARROW, "import_arrow: null or released structure");
+    if (!schema->format || std::strcmp(schema->format, "+s") != 0) fail(SQLRS_ERR_ARROW, "import_arrow: a struct array (\"+s\", an exported RecordBatch) is expected");
+    if (array->n_children != schema->n_children || array->dictionary || array->length < 0 || array->offset < 0)
+      fail(SQLRS_ERR_ARROW, "import_arrow: array and schema do not match");
+    if (array->null_count > 0 || (array->null_count < 0 && array->n_buffers > 0 && array->buffers && array->buffers[0]))
+      fail(SQLRS_ERR_ARROW, "import_arrow: NULL rows at the struct level");
+    if (array->length >= (1ll << 31)) fail(SQLRS_ERR_ARROW, "batch num_rows outside [0, 2^31)");
+    const int64_t n = array->length;
+    const int nc = (int)array->n_children;
+    auto o = std::unique_ptr<OwnedBatch>(new OwnedBatch());
+    o->ctx = ctx;
+    o->out_mem = SQLRS_MEM_HOST;
+    o->descs.resize((size_t)nc);
+    for (int c = 0; c < nc; c++) {
+      const ArrowArray *a = array->children[c];
+      const ArrowSchema *sc = schema->children[c];
+      const int32_t dt = (a && sc && !a->dictionary) ? arrow_dtype(sc->format) : -1;
+      if (dt < 0) fail(SQLRS_ERR_ARROW, std::string("import_arrow: unsupported column type \"") + ((sc && sc->format) ? sc->format : "?") + "\"");
+      const int64_t off = array->offset + a->offset;
+      if (a->offset < 0 || a->length < array->offset + n) fail(SQLRS_ERR_ARROW, "import_arrow: child shorter than the struct");
+      const int64_t need = dt == SQLRS_UTF8 ? 3 : 2;
+      if (a->n_buffers < need || !a->buffers) fail(SQLRS_ERR_ARROW, "import_arrow: missing buffers");
+      sqlrs_column_t &d = o->descs[(size_t)c];
+      d.dtype = dt;
+      d.mem = SQLRS_MEM_HOST;
+      d.length = n;
+      d.values = nullptr;
+      d.validity = nullptr;
+      d.offsets = nullptr;
+      d.null_count = 0;
+      if (a->null_count != 0 && a->buffers[0] && n > 0) {
+        d.validity = bits_at(a->buffers[0], off, n, o->host_blocks);
+        d.null_count = a->null_count > 0 && a->offset == 0 && a->length == n && array->offset == 0 ? a->null_count : clear_bits(d.validity, n);
+        if (d.null_count == 0) d.validity = nullptr;
+      }
+      if (n > 0 && !a->buffers[1] && dt != SQLRS_UTF8) fail(SQLRS_ERR_ARROW, "import_arrow: missing values buffer");
+      switch (dt) {
+      case SQLRS_BOOLEAN: d.values = bits_at(a->buffers[1], off, n, o->host_blocks); break;
+      case SQLRS_UTF8: {
+        static const int32_t zero_off[1] = {0};
+        const int32_t *po = a->buffers[1] ? (const int32_t *)a->buffers[1] + off : zero_off;
+        if (po[0] != 0) { // a sliced string column: offsets re-based (the values are not copied)
+          int32_t *no = (int32_t *)std::malloc(4 * (size_t)(n + 1) + 8);
+          if (!no) fail(SQLRS_ERR_INTERNAL, "host allocation failed");
+          o->host_blocks.push_back(no);
+          for (int64_t i = 0; i <= n; i++) no[i] = po[i] - po[0];
+          d.values = (const uint8_t *)a->buffers[2] + po[0];
+          d.offsets = no;
+        } else {
+          d.offsets = po;
+          d.values = a->buffers[2] ? a->buffers[2] : (const void *)zero_off; // (an all-empty column may come without a data buffer)
+        }
+        break;
+      }
+      default: d.values = (const uint8_t *)a->buffers[1] + (size_t)off * width_of(dt);
+      }
+    }
+    o->abi.num_rows = n;
+    o->abi.num_columns = nc;
+    o->abi.reserved = 0;
+    o->abi.columns = o->descs.data();
+    o->abi.owner = o.get();
+    // nothing can fail from here on: the move (Arrow C Data Interface, "moving an array")
+    o->imported = *array;
+    array->release = nullptr;
+    schema->release(schema);
+    *out = &o.release()->abi;
+  });
+}
+
+int sqlrs_batch_export_arrow(sqlrs_ctx_t *ctx, sqlrs_batch_t *batch, const char *const *names, struct ArrowArray *out_array,
+                             struct ArrowSchema *out_schema) {
+  return guard(ctx, [&] {
+    if (!batch || !out_array || !out_schema) fail(SQLRS_ERR_ARROW, "export_arrow: null argument");
+    SQ_HIP(hipSetDevice(ctx->device));
+    bool ours = false;
+    if (batch->owner) {
+      std::lock_guard<std::mutex> lk(g_owned_mu);
+      ours = g_owned.count(batch->owner) != 0;
+    }
+    bool host = true;
+    for (int c = 0; c < batch->num_columns; c++) host = host && batch->columns[c].mem == SQLRS_MEM_HOST;
+    sqlrs_batch_t *hb = batch;
+    if (!ours || !host) { // borrowed buffers / device columns: a host copy owned by the library
+      InBatch ib(ctx, batch);
+      hb = emit_batch(ctx, ib.materialize(true), SQLRS_MEM_HOST);
+    }
+    const int nc = hb->num_columns;
+    for (int c = 0; c < nc; c++)
+      if (!arrow_format(hb->columns[c].dtype)) {
+        if (hb != batch) sqlrs_batch_release(hb);
+        fail(SQLRS_ERR_ARROW, "export_arrow: column type without an Arrow format");
+      }
+    auto h = std::unique_ptr<ExportHolder>(new ExportHolder());
+    auto sh = std::unique_ptr<SchemaHolder>(new SchemaHolder());
+    h->children.resize((size_t)nc);
+    h->child_ptrs.resize((size_t)nc);
+    h->bufs.resize((size_t)nc);
+    sh->children.resize((size_t)nc);
+    sh->child_ptrs.resize((size_t)nc);
+    sh->names.resize((size_t)nc);
+    static const int32_t zero_off[1] = {0};
+    for (int c = 0; c < nc; c++) {
+      const sqlrs_column_t &col = hb->columns[c];
+      ArrowArray &a = h->children[(size_t)c];
+      a = ArrowArray{};
+      a.length = col.length;
+      a.null_count = col.validity ? col.null_count : 0;
+      a.offset = 0;
+      h->bufs[(size_t)c] = {col.validity && col.null_count != 0 ? col.validity : nullptr, nullptr, nullptr};
+      if (col.dtype == SQLRS_UTF8) {
+        a.n_buffers = 3;
+        h->bufs[(size_t)c][1] = col.offsets ? (const void *)col.offsets : (const void *)zero_off;
+        h->bufs[(size_t)c][2] = col.values;
+      } else {
+        a.n_buffers = 2;
+        h->bufs[(size_t)c][1] = col.values;
+      }
+      a.buffers = h->bufs[(size_t)c].data();
+      a.release = export_child_release;
+      a.private_data = h.get();
+      h->child_ptrs[(size_t)c] = &a;
+      ArrowSchema &s = sh->children[(size_t)c];
+      s = ArrowSchema{};
+      sh->names[(size_t)c] = (names && names[c]) ? names[c] : ("c" + std::to_string(c));
+      s.format = arrow_format(col.dtype);
+      s.name = sh->names[(size_t)c].c_str();
+      s.flags = ARROW_FLAG_NULLABLE;
+      s.release = export_schema_child_release;
+      sh->child_ptrs[(size_t)c] = &s;
+    }
+    *out_array = ArrowArray{};
+    out_array->length = hb->num_rows;
+    out_array->n_buffers = 1;
+    out_array->buffers = h->top_buf;
+    out_array->n_children = nc;
+    out_array->children = h->child_ptrs.data();
+    out_array->release = export_parent_release;
+    out_array->private_data = h.get();
+    *out_schema = ArrowSchema{};
+    out_schema->format = "+s";
+    out_schema->name = "";
+    out_schema->n_children = nc;
+    out_schema->children = sh->child_ptrs.data();
+    out_schema->release = export_schema_release;
+    out_schema->private_data = sh.release();
+    h->batch = hb;
+    h->refs.store(nc + 1);
+    h.release();
+    if (hb != batch) sqlrs_batch_release(batch); // (moved either way: the caller's reference is gone)
   });
 }
 
