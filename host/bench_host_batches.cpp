@@ -74,10 +74,11 @@ static int bench_filter(int argc, char **argv) {
     batches[(size_t)b].columns = &cols[(size_t)b];
     ptrs[(size_t)b] = &batches[(size_t)b];
   }
-  double best[2] = {1e30, 1e30};
-  int64_t kept[2] = {0, 0};
+  double best[3] = {1e30, 1e30, 1e30};
+  int64_t kept[3] = {0, 0, 0};
   bool order_ok = true;
-  for (int mode = 0; mode < 2; mode++) {
+  const int DEPTH = 8; // tickets in flight of the async mode (the caller waits that many batches behind)
+  for (int mode = 0; mode < 3; mode++) {
     for (int rep = 0; rep < 3; rep++) {
       auto t0 = std::chrono::steady_clock::now();
       sqlrs_filter_t *f = nullptr;
@@ -91,6 +92,30 @@ static int bench_filter(int argc, char **argv) {
           got += o->num_rows;
           sqlrs_batch_release(o);
         }
+      } else if (mode == 2) { // one batch per call, no synchronisation per call: sqlrs_filter_push_async + sqlrs_batch_wait
+        std::vector<sqlrs_ticket_t *> q((size_t)DEPTH, nullptr);
+        auto take = [&](int64_t b) { // the batch of input batch b
+          sqlrs_batch_t *o = nullptr;
+          CHECK(sqlrs_batch_wait(q[(size_t)(b % DEPTH)], &o));
+          const int64_t m = o->num_rows;
+          if (rep == 0 && m) {
+            const int64_t *ov = (const int64_t *)o->columns[0].values;
+            const int64_t *iv = v.data() + b * B;
+            int64_t j = 0;
+            for (int64_t r = 0; r < batches[(size_t)b].num_rows && j < m; r++)
+              if (iv[r] > k) order_ok = order_ok && ov[j++] == iv[r];
+            order_ok = order_ok && j == m;
+          }
+          got += m;
+          sqlrs_batch_release(o);
+          return 0;
+        };
+        for (int64_t b = 0; b < nb; b++) {
+          if (b >= DEPTH && take(b - DEPTH)) return 1;
+          CHECK(sqlrs_filter_push_async(f, ptrs[(size_t)b], &q[(size_t)(b % DEPTH)]));
+        }
+        for (int64_t b = std::max<int64_t>(0, nb - DEPTH); b < nb; b++)
+          if (take(b)) return 1;
       } else {
         for (int64_t b0 = 0; b0 < nb; b0 += group) {
           const int g = (int)std::min<int64_t>(group, nb - b0);
@@ -116,13 +141,15 @@ static int bench_filter(int argc, char **argv) {
       if (rep > 0 && ms < best[mode]) best[mode] = ms;
     }
   }
-  const bool ok = kept[0] == expect && kept[1] == expect && order_ok;
+  const bool ok = kept[0] == expect && kept[1] == expect && kept[2] == expect && order_ok;
   std::printf("{\"rows\": %lld, \"batches\": %lld, \"batch_rows\": %lld, \"kept\": %lld, \"ms_push\": %.1f, \"Mrows_s_push\": %.1f, "
-              "\"group\": %d, \"ms_push_many\": %.1f, \"Mrows_s_push_many\": %.1f, \"check\": \"%s\", \"note\": \"native caller (C ABI): "
+              "\"group\": %d, \"ms_push_many\": %.1f, \"Mrows_s_push_many\": %.1f, \"depth\": %d, \"ms_push_async\": %.1f, "
+              "\"Mrows_s_push_async\": %.1f, \"check\": \"%s\", \"note\": \"native caller (C ABI): "
               "pageable %lld-row host batches, one result batch per input batch on the host; push = sqlrs_filter_push per batch, "
-              "push_many = sqlrs_filter_push_many over groups of batches; best of 2 after a warm-up\"}\n",
+              "push_many = sqlrs_filter_push_many over groups of batches, push_async = sqlrs_filter_push_async per batch with `depth` "
+              "tickets in flight + sqlrs_batch_wait; best of 2 after a warm-up\"}\n",
               (long long)n, (long long)nb, (long long)B, (long long)kept[1], best[0], (double)n / best[0] / 1e3, group, best[1],
-              (double)n / best[1] / 1e3, ok ? "OK" : "mismatch", (long long)B);
+              (double)n / best[1] / 1e3, DEPTH, best[2], (double)n / best[2] / 1e3, ok ? "OK" : "mismatch", (long long)B);
   sqlrs_ctx_destroy(ctx);
   return ok ? 0 : 1;
 }
@@ -250,7 +277,65 @@ static int bench_probe(int argc, char **argv) {
     if (rep > 0 && ms < best) best = ms;
   }
   ok = ok && joined == n;
-  std::printf("{\"probe_rows\": %lld, \"build_rows\": %lld, \"batch_rows\": %lld, \"joined\": %lld, \"ms_push\": %.1f, \"Mrows_s_push\": %.1f, "
+  // one probe batch per call without a synchronisation per call: sqlrs_hash_join_probe_push_async + sqlrs_batch_wait
+  const int DEPTH = 8;
+  double best_async = 1e30;
+  int64_t joined_async = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    auto t0 = std::chrono::steady_clock::now();
+    sqlrs_hash_join_t *j = nullptr;
+    CHECK(sqlrs_hash_join_create(ctx, SQLRS_JOIN_INNER, 1, &key, &key, nullptr, 2, right_dtypes, &j));
+    sqlrs_column_t lc[2];
+    host_col(lc[0], SQLRS_INT64, dk.data(), nB);
+    host_col(lc[1], SQLRS_INT64, dp.data(), nB);
+    sqlrs_batch_t lb{};
+    lb.num_rows = nB;
+    lb.num_columns = 2;
+    lb.columns = lc;
+    CHECK(sqlrs_hash_join_build_push(j, &lb));
+    CHECK(sqlrs_hash_join_build_finish(j));
+    joined_async = 0;
+    const int64_t nb = (n + B - 1) / B;
+    std::vector<sqlrs_ticket_t *> q((size_t)DEPTH, nullptr);
+    auto take = [&](int64_t b) {
+      sqlrs_batch_t *o = nullptr;
+      CHECK(sqlrs_batch_wait(q[(size_t)(b % DEPTH)], &o));
+      if (o) {
+        const int64_t m = std::min<int64_t>(B, n - b * B);
+        if (rep == 0 && o->num_rows == m) {
+          const int64_t *k = (const int64_t *)o->columns[0].values, *p = (const int64_t *)o->columns[1].values;
+          const int64_t *rk = (const int64_t *)o->columns[2].values;
+          const double *rv = (const double *)o->columns[3].values;
+          for (int64_t r = 0; r < m; r += 97)
+            ok = ok && k[r] == fk[(size_t)(b * B + r)] && p[r] == 3 * k[r] + 1 && rk[r] == k[r] && rv[r] == fv[(size_t)(b * B + r)];
+        } else if (rep == 0)
+          ok = false;
+        joined_async += o->num_rows;
+        sqlrs_batch_release(o);
+      }
+      return 0;
+    };
+    for (int64_t b = 0; b < nb; b++) {
+      if (b >= DEPTH && take(b - DEPTH)) return 1;
+      const int64_t lo = b * B, m = std::min<int64_t>(B, n - lo);
+      sqlrs_column_t rc[2];
+      host_col(rc[0], SQLRS_INT64, fk.data() + lo, m);
+      host_col(rc[1], SQLRS_FLOAT64, fv.data() + lo, m);
+      sqlrs_batch_t rb{};
+      rb.num_rows = m;
+      rb.num_columns = 2;
+      rb.columns = rc;
+      CHECK(sqlrs_hash_join_probe_push_async(j, &rb, &q[(size_t)(b % DEPTH)]));
+    }
+    for (int64_t b = std::max<int64_t>(0, nb - DEPTH); b < nb; b++)
+      if (take(b)) return 1;
+    sqlrs_hash_join_destroy(j);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rep > 0 && ms < best_async) best_async = ms;
+  }
+  ok = ok && joined_async == n;
+  std::printf("{\"depth\": %d, \"ms_push_async\": %.1f, \"Mrows_s_push_async\": %.1f, ", DEPTH, best_async, (double)n / best_async / 1e3);
+  std::printf("\"probe_rows\": %lld, \"build_rows\": %lld, \"batch_rows\": %lld, \"joined\": %lld, \"ms_push\": %.1f, \"Mrows_s_push\": %.1f, "
               "\"group\": 1024, \"ms_push_many\": %.1f, \"Mrows_s_push_many\": %.1f, "
               "\"check\": \"%s\", \"note\": \"native caller (C ABI): build side one host batch, probe side pageable %lld-row host batches, "
               "joined batches (4 columns) on the host, one per probe batch; push = sqlrs_hash_join_probe_push per batch, push_many = "

@@ -288,6 +288,47 @@ int main() {
         std::printf("ok   filter+project, %zu batches per call\n", group);
       }
     }
+    for (size_t depth : {(size_t)1, (size_t)4}) { // the same streams through push_async / batch_wait, `depth` tickets in flight
+      FilterExecutor fe;
+      fe.ctx = ctx;
+      fe.expr = BoundExpr::binary_op(BinaryOperator::Gt, build_bound_input_ref(1), BoundExpr::constant(ScalarValue::Int64(50)));
+      fe.child = stream_iter(parts);
+      fe.depth = depth;
+      std::vector<RecordBatch> out = try_collect(fe.execute());
+      bool ok = out.size() == parts.size();
+      std::string got;
+      for (size_t b = 0; ok && b < out.size(); b++)
+        for (int64_t r = 0; r < out[b].num_rows(); r++) got += out[b].columns[0]->value_to_string(r) + "," + out[b].columns[1]->value_to_string(r) + ";";
+      const std::string exp = "10,100;1,100;11,200;2,200;13,100;4,100;14,200;5,200;16,100;";
+      if (!ok || got != exp) {
+        failures++;
+        std::printf("FAIL filter with %zu tickets in flight: %zu batches, rows %s\n", depth, out.size(), got.c_str());
+      } else {
+        std::printf("ok   filter, push_async with %zu tickets in flight\n", depth);
+      }
+      for (JoinType jt : {JoinType::Inner, JoinType::Left}) {
+        TestChild t = build_test_child(jt);
+        RecordBatch rb = build_table_i32({"a2", {10, 20, 30}}, {"b1", {4, 5, 6}}, {"c2", {70, 80, 90}});
+        HashJoinExecutor ex;
+        ex.ctx = ctx;
+        ex.left_child = std::move(t.left);
+        ex.right_child = stream_iter({rb.slice(0, 1), rb.slice(1, 1), rb.slice(2, 1)});
+        ex.join_type = jt;
+        ex.join_condition.on = {{build_bound_input_ref(1), build_bound_input_ref(1)}};
+        ex.join_output_schema = t.schema;
+        ex.num_left_columns = 3;
+        ex.depth = depth;
+        std::vector<std::string> exp2 = {"+------+------+------+------+------+------+", "| l.a1 | l.b1 | l.c1 | r.a2 | r.b1 | r.c2 |",
+                                         "+------+------+------+------+------+------+", "| 1    | 4    | 7    | 10   | 4    | 70   |",
+                                         "| 2    | 5    | 8    | 20   | 5    | 80   |", "| 3    | 5    | 9    | 20   | 5    | 80   |"};
+        if (jt == JoinType::Left) {
+          exp2.push_back("| 0    | 0    | 10   |      |      |      |");
+          exp2.push_back("| 4    | 8    | 10   |      |      |      |");
+        }
+        exp2.push_back("+------+------+------+------+------+------+");
+        expect_table(jt == JoinType::Inner ? "inner join, async probe batches" : "left join, async probe batches", try_collect(ex.execute()), exp2);
+      }
+    }
     for (size_t group : {(size_t)2, (size_t)8}) { // test_inner_join_results / test_left_join_results with the probe side in three batches
       for (JoinType jt : {JoinType::Inner, JoinType::Left}) {
         TestChild t = build_test_child(jt);

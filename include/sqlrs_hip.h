@@ -275,6 +275,17 @@ int sqlrs_filter_push(sqlrs_filter_t *f, const sqlrs_batch_t *in, int out_mem, s
  * by one launch sequence and the kept rows of every input batch handed out as a batch of its own (out_mem = HOST); any
  * other input runs through sqlrs_filter_push batch by batch.  On error no output batch is left allocated. */
 int sqlrs_filter_push_many(sqlrs_filter_t *f, int n, const sqlrs_batch_t *const *in, int out_mem, sqlrs_batch_t **out);
+/* The reference's own calling shape — ONE batch per poll (filter.rs:15-24; 1024 rows, storage/csv.rs:105) — without a stream
+ * synchronisation per call: push_async queues the batch and returns a TICKET for the HOST batch sqlrs_filter_push(f, in,
+ * SQLRS_MEM_HOST, ..) would have returned; sqlrs_batch_wait(ticket, &out) blocks until that batch exists, hands it out and
+ * consumes the ticket (also after an error).  `in` is read completely before push_async returns.  Tickets of one ctx
+ * complete in issue order; a caller that waits a few batches behind (the stream adaptor of the Rust / C++ mirrors keeps
+ * `depth` tickets in flight) never blocks on the device.  HOST batches of <= 4096 rows and <= 12 int32 / int64 / float64
+ * columns under a `column OP constant` predicate over an int64 / float64 column take ONE launch and no copy call (pinned,
+ * device-mapped ring); every other batch runs the synchronous operator inside push_async: same batches, no speed-up. */
+typedef struct sqlrs_ticket sqlrs_ticket_t;
+int sqlrs_filter_push_async(sqlrs_filter_t *f, const sqlrs_batch_t *in, sqlrs_ticket_t **ticket);
+int sqlrs_batch_wait(sqlrs_ticket_t *ticket, sqlrs_batch_t **out);
 void sqlrs_filter_destroy(sqlrs_filter_t *f);
 
 /* Evaluates one expression on a batch -> one-column batch.
@@ -311,6 +322,11 @@ int sqlrs_hash_join_probe_push(sqlrs_hash_join_t *j, const sqlrs_batch_t *right,
  * left allocated. */
 int sqlrs_hash_join_probe_push_many(sqlrs_hash_join_t *j, int n, const sqlrs_batch_t *const *right, int out_mem,
                                     sqlrs_batch_t **out);
+/* sqlrs_hash_join_probe_push without the wait (see sqlrs_filter_push_async; hash_join.rs:207-292 polled one batch at a
+ * time): the fast path takes Inner joins without a join filter over ONE exactly compared INPUT_REF key (int32 / int64 /
+ * float64, no NULL probe keys), unique build keys and fixed-width columns on both sides; *out of the wait is NULL for an
+ * empty build side, as for probe_push. */
+int sqlrs_hash_join_probe_push_async(sqlrs_hash_join_t *j, const sqlrs_batch_t *right, sqlrs_ticket_t **ticket);
 /* The index-pair form of one probe batch, before any gather: 2 columns
  * (UINT64 left index, nullable; UINT32 right index), in the reference's order
  * (probe-row major, build insertion order minor), join filter NOT applied.

@@ -382,6 +382,9 @@ class Backend:
             "ctx_pool_bytes": (C.c_int64, [vp]),
             "ctx_pool_trim": (None, [vp]),
             "batch_copy": (i, [vp, pb, i, ppb]),
+            "filter_push_async": (i, [vp, pb, pvp]),
+            "hash_join_probe_push_async": (i, [vp, pb, pvp]),
+            "batch_wait": (i, [vp, ppb]),
             "batch_import_arrow": (i, [vp, C.POINTER(ArrowArrayC), C.POINTER(ArrowSchemaC), ppb]),
             "batch_export_arrow": (i, [vp, pb, C.POINTER(C.c_char_p), C.POINTER(ArrowArrayC), C.POINTER(ArrowSchemaC)]),
             "exchange_unique_id": (i, [vp, vp]),

@@ -1,0 +1,144 @@
+// async_small.hip — ring, tickets and sqlrs_batch_wait of the single-batch async path (small_async.hpp).
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
+#include "small_async.hpp"
+
+extern "C" void sqlrs_batch_release(sqlrs_batch_t *batch);
+
+namespace sq {
+
+SaRing *sa_ring(Ctx *ctx) {
+  if (!ctx->small_ring) {
+    auto r = std::make_shared<SaRing>();
+    // coherent (fine-grained) + mapped: the kernel's stores are visible to a polling host thread while the stream runs on
+    SQ_HIP(hipHostMalloc((void **)&r->pin, (size_t)SA_SLOTS * 2 * SA_AREA, hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(r->pin, 0, (size_t)SA_SLOTS * 2 * SA_AREA);
+    for (int i = 0; i < SA_STREAMS; i++) SQ_HIP(hipStreamCreateWithFlags(&r->side[i], hipStreamNonBlocking));
+    SQ_HIP(hipEventCreateWithFlags(&r->order_ev, hipEventDisableTiming));
+    ctx->small_ring = r;
+  }
+  return (SaRing *)ctx->small_ring.get();
+}
+void sa_order_after_ctx(Ctx *ctx, SaRing *r) {
+  SQ_HIP(hipEventRecord(r->order_ev, ctx->stream));
+  for (int i = 0; i < SA_STREAMS; i++) SQ_HIP(hipStreamWaitEvent(r->side[i], r->order_ev, 0));
+}
+void sa_drain(Ctx *ctx) {
+  SaRing *r = (SaRing *)ctx->small_ring.get();
+  if (!r || !r->dirty) return;
+  for (int i = 0; i < SA_STREAMS; i++) (void)hipStreamSynchronize(r->side[i]);
+  r->dirty = false;
+}
+int sa_take_slot(SaRing *r) {
+  for (int k = 0; k < SA_SLOTS; k++) {
+    const int s = (r->next + k) % SA_SLOTS;
+    if (!r->busy[s]) {
+      r->busy[s] = true;
+      r->next = (s + 1) % SA_SLOTS;
+      return s;
+    }
+  }
+  return -1;
+}
+
+static uint32_t sa_width(int32_t dtype) { return dtype == SQLRS_INT32 ? 4u : (dtype == SQLRS_INT64 || dtype == SQLRS_FLOAT64) ? 8u : 0u; }
+
+bool sa_stage_input(const sqlrs_batch_t *in, uint8_t *area, SaLayout *lay, int first_out_col, const int32_t *front_dtypes) {
+  if (!in || in->num_rows < 0 || in->num_rows > (int64_t)SA_MAX_ROWS || in->num_columns <= 0 ||
+      in->num_columns + first_out_col > SA_MAX_COLS)
+    return false;
+  const uint32_t rows = (uint32_t)in->num_rows, vbytes = (rows + 7) / 8;
+  for (int c = 0; c < in->num_columns; c++) {
+    const sqlrs_column_t &col = in->columns[c];
+    if (col.mem != SQLRS_MEM_HOST || !sa_width(col.dtype) || col.length != in->num_rows || (rows && !col.values)) return false;
+  }
+  auto up64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  // output: header | per column values (SA_MAX rows are never needed: `rows` bound both sides) + validity
+  size_t in_at = 0, out_at = up64(sizeof(SaHeader));
+  lay->ncols = first_out_col + in->num_columns;
+  lay->rows = rows;
+  for (int c = 0; c < lay->ncols; c++) {
+    SaCol &d = lay->c[c];
+    d.dtype = c < first_out_col ? front_dtypes[c] : in->columns[c - first_out_col].dtype;
+    d.width = sa_width(d.dtype);
+    if (!d.width) return false;
+    d.in_off = d.in_voff = SA_NONE;
+    d.out_off = (uint32_t)out_at;
+    out_at = up64(out_at + (size_t)d.width * rows);
+    d.out_voff = (uint32_t)out_at;
+    out_at = up64(out_at + vbytes);
+    if (c >= first_out_col) {
+      d.in_off = (uint32_t)in_at;
+      in_at = up64(in_at + (size_t)d.width * rows);
+      const sqlrs_column_t &col = in->columns[c - first_out_col];
+      if (col.validity && col.null_count != 0) {
+        d.in_voff = (uint32_t)in_at;
+        in_at = up64(in_at + vbytes + 8); // (+ 8: the kernel may read the bitmap in whole words)
+      }
+    }
+  }
+  if (in_at > SA_AREA || out_at > SA_AREA) return false;
+  for (int c = first_out_col; c < lay->ncols; c++) { // the only copies of the fast path: 4-32 KB per column, host to pinned host
+    const sqlrs_column_t &col = in->columns[c - first_out_col];
+    const SaCol &d = lay->c[c];
+    if (rows) std::memcpy(area + d.in_off, col.values, (size_t)d.width * rows);
+    if (d.in_voff != SA_NONE) std::memcpy(area + d.in_voff, col.validity, vbytes);
+  }
+  return true;
+}
+
+} // namespace sq
+
+using namespace sq;
+
+extern "C" {
+
+// [ref: src/executor/mod.rs:34 — the consumer polls its child one batch at a time]  Blocks until the batch behind
+// `ticket` exists, hands it out as a HOST batch (possibly NULL where the synchronous call would have set *out = NULL) and
+// consumes the ticket.  Tickets of one ctx complete in the order they were issued.
+int sqlrs_batch_wait(sqlrs_ticket_t *ticket, sqlrs_batch_t **out) {
+  if (!ticket) return SQLRS_ERR_INTERNAL;
+  Ctx *ctx = ticket->ctx;
+  int st = guard(ctx, [&] {
+    if (!out) fail(SQLRS_ERR_INTERNAL, "batch_wait: null argument");
+    *out = nullptr;
+    if (ticket->slot < 0) {
+      *out = ticket->done;
+      ticket->done = nullptr;
+      return;
+    }
+    SaRing *r = sa_ring(ctx);
+    const SaHeader *h = (const SaHeader *)r->out_area(ticket->slot);
+    bool seen = false;
+    for (int spin = 0; spin < 20000 && !seen; spin++) {
+      seen = __atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == ticket->seq;
+      if (!seen) __builtin_ia32_pause();
+    }
+    if (!seen) { // (not there yet — a long queue ahead, or stores that only a finished stream makes visible)
+      SQ_HIP(hipSetDevice(ctx->device));
+      SQ_HIP(hipStreamSynchronize(r->stream_of(ticket->slot)));
+      if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != ticket->seq) fail(SQLRS_ERR_DEVICE, "batch_wait: the batch's kernel left no result");
+    }
+    const SaLayout &lay = ticket->lay;
+    const uint8_t *oa = r->out_area(ticket->slot);
+    const void *vals[SA_MAX_COLS];
+    const uint8_t *valid[SA_MAX_COLS];
+    int64_t nulls[SA_MAX_COLS];
+    int32_t dts[SA_MAX_COLS];
+    for (int c = 0; c < lay.ncols; c++) {
+      vals[c] = oa + lay.c[c].out_off;
+      valid[c] = oa + lay.c[c].out_voff;
+      nulls[c] = h->nulls[c];
+      dts[c] = lay.c[c].dtype;
+    }
+    *out = emit_host_copy(ctx, lay.ncols, dts, (int64_t)h->count, vals, valid, nulls);
+  });
+  if (ticket->slot >= 0) sa_ring(ctx)->busy[ticket->slot] = false;
+  if (ticket->done) sqlrs_batch_release(ticket->done); // (an error above: nothing leaks)
+  delete ticket;
+  return st;
+}
+
+} // extern "C"

@@ -155,6 +155,7 @@ struct Ctx {
   int64_t lb_timeouts = 0; // look-back launches that timed out and were redone with tickets
   int64_t order_lb_fallbacks = 0; // Order split passes whose chained look-back ran out of spins (redone in the counting form)
   int lb_backoff = 0; // resident blocks per CU of the persistent kernels, per kernel
+  std::shared_ptr<void> small_ring; // the pinned ring of the single-batch async path (small_async.hpp), created on first use
   void sync() { SQ_HIP(hipStreamSynchronize(stream)); }
   // copies `bytes` from device to the pinned area and synchronises; returns host pointer
   const void *fetch(const void *dptr, size_t bytes);
@@ -232,6 +233,10 @@ struct InBatch {
 DCol upload_column(Ctx *ctx, const sqlrs_column_t &c, bool force_copy);
 // Device batch -> library-owned ABI batch in `out_mem` (host: D2H into malloc'd buffers).
 sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem);
+// a HOST batch of `rows` rows copied out of host memory (values[c]: rows x width bytes; validity[c]: bitmap or null;
+// fixed-width dtypes only) — what the single-batch async path hands out (small_async.hpp)
+sqlrs_batch_t *emit_host_copy(Ctx *ctx, int ncols, const int32_t *dtypes, int64_t rows, const void *const *values,
+                              const uint8_t *const *validity, const int64_t *null_counts);
 sqlrs_batch_t *emit_host_columns(Ctx *ctx, std::vector<sqlrs_column_t> &&cols, int64_t rows); // takes over malloc'd blocks
 // *_push_many (small HOST batches handled together): every column fixed width? / rows [cut[i], cut[i + 1]) of a device batch
 // as n library-owned HOST batches through one pinned copy per column (ctx.hip)

@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "host_stage.hpp"
 #include "prims.hpp"
+#include "small_async.hpp"
 
 extern "C" void sqlrs_batch_release(sqlrs_batch_t *batch);
 namespace sq {
@@ -477,6 +478,45 @@ sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem) {
   return &o.release()->abi;
 }
 
+sqlrs_batch_t *emit_host_copy(Ctx *ctx, int ncols, const int32_t *dtypes, int64_t rows, const void *const *values,
+                              const uint8_t *const *validity, const int64_t *null_counts) {
+  auto o = std::unique_ptr<OwnedBatch>(new OwnedBatch());
+  o->ctx = ctx;
+  o->out_mem = SQLRS_MEM_HOST;
+  o->descs.resize((size_t)ncols);
+  for (int c = 0; c < ncols; c++) {
+    const size_t w = width_of(dtypes[c]);
+    if (!w) fail(SQLRS_ERR_INTERNAL, "emit_host_copy: fixed-width columns only");
+    sqlrs_column_t &d = o->descs[(size_t)c];
+    d.dtype = dtypes[c];
+    d.mem = SQLRS_MEM_HOST;
+    d.length = rows;
+    d.offsets = nullptr;
+    d.validity = nullptr;
+    d.null_count = 0;
+    void *v = std::malloc(w * (size_t)rows + 64);
+    if (!v) fail(SQLRS_ERR_INTERNAL, "host allocation failed");
+    o->host_blocks.push_back(v);
+    if (rows) std::memcpy(v, values[c], w * (size_t)rows);
+    d.values = v;
+    if (validity && validity[c] && null_counts[c] > 0) {
+      const size_t nb = (size_t)(rows + 7) / 8;
+      uint8_t *b = (uint8_t *)std::malloc(nb + 64);
+      if (!b) fail(SQLRS_ERR_INTERNAL, "host allocation failed");
+      o->host_blocks.push_back(b);
+      std::memcpy(b, validity[c], nb);
+      d.validity = b;
+      d.null_count = null_counts[c];
+    }
+  }
+  o->abi.num_rows = rows;
+  o->abi.num_columns = ncols;
+  o->abi.reserved = 0;
+  o->abi.columns = o->descs.data();
+  o->abi.owner = o.get();
+  return &o.release()->abi;
+}
+
 // --------------------------------------------------------------- host staging --
 bool HostStage::accepts(const sqlrs_batch_t *b) const {
   if (!b || b->num_columns <= 0 || b->num_rows < 0 || b->num_rows > HOST_STAGE_MAX_BATCH) return false; // (< 0: InBatch rejects it)
@@ -791,7 +831,10 @@ void sqlrs_ctx_destroy(sqlrs_ctx_t *ctx) {
 const char *sqlrs_last_error(const sqlrs_ctx_t *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 int sqlrs_ctx_synchronize(sqlrs_ctx_t *ctx) {
-  return guard(ctx, [&] { ctx->sync(); });
+  return guard(ctx, [&] {
+    ctx->sync();
+    sa_drain(ctx); // (the async single-batch path's side streams, small_async.hpp)
+  });
 }
 void *sqlrs_ctx_stream(sqlrs_ctx_t *ctx) { return (void *)ctx->stream; }
 

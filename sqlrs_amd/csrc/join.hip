@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "prims.hpp"
+#include "small_async.hpp"
 
 namespace sq {
 
@@ -2378,6 +2379,147 @@ int sqlrs_hash_join_probe_push(sqlrs_hash_join_t *j, const sqlrs_batch_t *right,
 } // extern "C"
 
 namespace sq {
+// ---- one small HOST probe batch, one launch, no copy call (small_async.hpp) ------------------------------------------
+// Inner join over unique build keys: one lookup per probe row (the direct-address table or the 16-byte-slot table), the
+// rows with a partner compacted in probe-row order (= the reference's pair order, hash_join.rs:225-234), the build
+// columns gathered by the build row, the probe columns copied — the joined batch (build_batch, hash_join.rs:25-45)
+// written straight into the pinned slot.
+struct SaProbeParams {
+  SaLayout lay;
+  int nleft, key_col, key_is32, dense;
+  const void *lvals[SA_MAX_COLS];
+  const uint64_t *lvalid[SA_MAX_COLS];
+  const Slot *table;
+  uint64_t mask;
+  DenseTable dt;
+  const uint8_t *in;
+  uint8_t *out;
+  unsigned long long seq;
+};
+__global__ __launch_bounds__(1024) void sa_probe_kernel(SaProbeParams p) {
+  __shared__ uint32_t s_w[17], s_nulls[SA_MAX_COLS];
+  __shared__ uint8_t s_v[SA_MAX_ROWS];
+  if (threadIdx.x < SA_MAX_COLS) s_nulls[threadIdx.x] = 0;
+  const SaCol &kc = p.lay.c[p.nleft + p.key_col];
+  uint32_t m[4] = {DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY}, pos[4], total;
+  const uint32_t bits = sa_positions(
+      p.lay.rows,
+      [&](uint32_t r, int t) {
+        const uint64_t key = p.key_is32 ? (uint64_t)(int64_t)((const int32_t *)(p.in + kc.in_off))[r] : ((const uint64_t *)(p.in + kc.in_off))[r];
+        uint32_t h = DENSE_EMPTY;
+        if (p.dense) {
+          const uint64_t d = key - p.dt.kmin;
+          h = dense_get(p.dt, d < p.dt.range ? d : p.dt.range + 1);
+        } else {
+          const Slot sl = probe_slot(p.table, p.mask, key, false);
+          if (sl.count) h = sl.head;
+        }
+        m[t] = h;
+        return h != DENSE_EMPTY;
+      },
+      pos, s_w, &total);
+  for (int c = 0; c < p.lay.ncols; c++) {
+    const SaCol &col = p.lay.c[c];
+    const bool left = c < p.nleft;
+    const uint8_t *rvalid = !left && col.in_voff != SA_NONE ? p.in + col.in_voff : nullptr;
+    const uint64_t *lvalid = left ? p.lvalid[c] : nullptr;
+    const uint8_t *src = left ? (const uint8_t *)p.lvals[c] : p.in + col.in_off;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (!((bits >> t) & 1)) continue;
+      const uint32_t r = left ? m[t] : (uint32_t)t * 1024u + threadIdx.x;
+      if (col.width == 8) ((uint64_t *)(p.out + col.out_off))[pos[t]] = ((const uint64_t *)src)[r];
+      else ((uint32_t *)(p.out + col.out_off))[pos[t]] = ((const uint32_t *)src)[r];
+      if (lvalid) s_v[pos[t]] = (uint8_t)((lvalid[r >> 6] >> (r & 63)) & 1);
+      else if (rvalid) s_v[pos[t]] = (rvalid[r >> 3] >> (r & 7)) & 1;
+    }
+    if (lvalid || rvalid) sa_pack_validity(s_v, total, p.out + col.out_voff, &s_nulls[c]);
+  }
+  sa_publish((SaHeader *)p.out, p.seq, total, s_nulls, p.lay.ncols);
+}
+// true = the kernel above was queued for `right` and *t describes its slot
+static bool sa_probe_try(sqlrs_hash_join *j, const sqlrs_batch_t *right, sqlrs_ticket *t) {
+  Ctx *ctx = j->ctx;
+  const char *off_e = hook("SQLRS_ASYNC_FAST"); // test hook, read per call: 0 = every batch through the synchronous operator
+  if (off_e && off_e[0] == '0') return false;
+  if (j->join_type != SQLRS_JOIN_INNER || j->has_filter || !j->exact || j->comp.on || j->lkeys.size() != 1 || j->rkeys[0].nodes.size() != 1 ||
+      j->rkeys[0].nodes[0].op != SQLRS_EXPR_INPUT_REF || !right)
+    return false;
+  const int kc = j->rkeys[0].nodes[0].index;
+  if (kc < 0 || kc >= right->num_columns) return false;
+  const sqlrs_column_t &kcol = right->columns[kc];
+  if (kcol.dtype != j->key_dtype || (kcol.validity && kcol.null_count != 0)) return false; // (NULL probe keys: the general route)
+  if (kcol.dtype != SQLRS_INT64 && kcol.dtype != SQLRS_FLOAT64 && kcol.dtype != SQLRS_INT32) return false;
+  const int nleft = (int)j->left.cols.size();
+  if (nleft + right->num_columns > SA_MAX_COLS) return false;
+  int32_t ldt[SA_MAX_COLS];
+  for (int c = 0; c < nleft; c++) {
+    const DCol &lc = j->left.cols[(size_t)c];
+    if ((lc.dtype != SQLRS_INT32 && lc.dtype != SQLRS_INT64 && lc.dtype != SQLRS_FLOAT64) || lc.stride == 0) return false;
+    ldt[c] = lc.dtype;
+  }
+  dense_resolve(j);
+  if (!j->dense) hash_join_ensure_table(j);
+  if (!j->unique || (!j->dense && !j->table)) return false;
+  SaRing *r = sa_ring(ctx);
+  const int slot = sa_take_slot(r);
+  if (slot < 0) return false;
+  SaProbeParams p;
+  if (!sa_stage_input(right, r->in_area(slot), &p.lay, nleft, ldt)) {
+    r->busy[slot] = false;
+    return false;
+  }
+  p.nleft = nleft;
+  p.key_col = kc;
+  p.key_is32 = kcol.dtype == SQLRS_INT32;
+  p.dense = j->dense ? 1 : 0;
+  for (int c = 0; c < SA_MAX_COLS; c++) {
+    p.lvals[c] = c < nleft ? j->left.cols[(size_t)c].values : nullptr;
+    p.lvalid[c] = c < nleft && j->left.cols[(size_t)c].has_nulls() ? j->left.cols[(size_t)c].validity : nullptr;
+  }
+  p.table = j->table ? j->table->as<Slot>() : nullptr;
+  p.mask = j->mask;
+  p.dt = dense_table_of(j);
+  p.in = r->in_area(slot);
+  p.out = r->out_area(slot);
+  p.seq = ++r->seq;
+  if (!j->async_ordered) { // the table and the build columns were queued on the ctx stream: the side streams wait for them, once
+    sa_order_after_ctx(ctx, r);
+    j->async_ordered = true;
+  }
+  sa_probe_kernel<<<dim3(1), dim3(1024), 0, r->stream_of(slot)>>>(p);
+  SQ_HIP(hipGetLastError());
+  r->dirty = true;
+  t->slot = slot;
+  t->seq = p.seq;
+  t->lay = p.lay;
+  return true;
+}
+} // namespace sq
+
+extern "C" {
+// sqlrs_hash_join_probe_push without the wait (small_async.hpp): *ticket stands for the HOST batch
+// sqlrs_hash_join_probe_push(j, right, SQLRS_MEM_HOST, ..) would return — NULL for an empty build side.
+int sqlrs_hash_join_probe_push_async(sqlrs_hash_join_t *j, const sqlrs_batch_t *right, sqlrs_ticket_t **ticket) {
+  if (ticket) *ticket = nullptr;
+  return guard(j->ctx, [&] {
+    Ctx *ctx = j->ctx;
+    if (!ticket) fail(SQLRS_ERR_INTERNAL, "push_async: null ticket");
+    SQ_HIP(hipSetDevice(ctx->device));
+    if (!j->finished) fail(SQLRS_ERR_INTERNAL, "probe before build_finish");
+    auto t = std::unique_ptr<sqlrs_ticket>(new sqlrs_ticket());
+    t->ctx = ctx;
+    if (!j->empty_build && !sa_probe_try(j, right, t.get())) {
+      InBatch ib(ctx, right);
+      DBatch r = probe_batch(j, ib, nullptr);
+      t->done = emit_batch(ctx, std::move(r), SQLRS_MEM_HOST);
+    }
+    *ticket = t.release();
+  });
+}
+} // extern "C"
+
+namespace sq {
 // cut[i] = pairs whose probe row (right[], ascending: pairs are probe-row major) lies before bounds[i]
 __global__ void pairs_before_kernel(const uint32_t *__restrict__ right, int64_t m, const int64_t *__restrict__ bounds, int64_t n,
                                     int64_t *__restrict__ cut) {
@@ -2525,6 +2667,9 @@ int sqlrs_hash_join_finish(sqlrs_hash_join_t *j, int out_mem, sqlrs_batch_t **ou
   });
 }
 
-void sqlrs_hash_join_destroy(sqlrs_hash_join_t *j) { delete j; }
+void sqlrs_hash_join_destroy(sqlrs_hash_join_t *j) {
+  if (j && j->async_ordered) sa_drain(j->ctx); // (probe kernels of the async path may still read the table on a side stream)
+  delete j;
+}
 
 } // extern "C"

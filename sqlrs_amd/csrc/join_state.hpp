@@ -77,6 +77,7 @@ struct sqlrs_hash_join {
   // round 6: `unique` established on the LDS bucket tables (lds_build_first); the global table is not built until a
   // probe batch that cannot take the LDS route asks for it (`table_built` stays false until then)
   bool lds_first = false;
+  bool async_ordered = false; // the async path's side streams have been ordered behind this join's build (small_async.hpp)
 };
 
 // builds the deferred hash table of a `lazy_table` join (join.hip); no-op otherwise

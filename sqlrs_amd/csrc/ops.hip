@@ -8,6 +8,7 @@
 #include "host_stage.hpp"
 #include "prims.hpp"
 #include "radix_part.hpp"
+#include "small_async.hpp"
 
 using namespace sq;
 
@@ -176,6 +177,109 @@ int sqlrs_filter_push(sqlrs_filter_t *f, const sqlrs_batch_t *in, int out_mem, s
     SQ_HIP(hipSetDevice(ctx->device));
     InBatch ib(ctx, in);
     *out = emit_batch(ctx, filter_batch(f, ib, nullptr), out_mem);
+  });
+}
+
+} // extern "C"
+
+namespace sq {
+// ---- one small HOST batch, one launch, no copy call (small_async.hpp) ------------------------------------------------
+// mask = `column OP constant` (RowFilter: the stand-alone filter's comparison, NULL -> dropped, filter.rs:16-24); every
+// column of the batch compacted through the same positions; validity bitmaps re-packed in output order.
+struct SaFilterParams {
+  SaLayout lay;
+  int pred_col;
+  RowFilter rf; // (rf.col unused: the predicate column is read from the slot)
+  const uint8_t *in;
+  uint8_t *out;
+  unsigned long long seq;
+};
+__global__ __launch_bounds__(1024) void sa_filter_kernel(SaFilterParams p) {
+  __shared__ uint32_t s_w[17], s_nulls[SA_MAX_COLS];
+  __shared__ uint8_t s_v[SA_MAX_ROWS];
+  if (threadIdx.x < SA_MAX_COLS) s_nulls[threadIdx.x] = 0;
+  const SaCol &pc = p.lay.c[p.pred_col];
+  const uint64_t *pv = (const uint64_t *)(p.in + pc.in_off);
+  const uint8_t *pvalid = pc.in_voff != SA_NONE ? p.in + pc.in_voff : nullptr;
+  uint32_t pos[4], total;
+  const uint32_t bits = sa_positions(
+      p.lay.rows, [&](uint32_t r, int) { return (!pvalid || ((pvalid[r >> 3] >> (r & 7)) & 1)) && row_passes(p.rf, pv[r]); }, pos, s_w, &total);
+  for (int c = 0; c < p.lay.ncols; c++) { // (uniform loop: the layout is a kernel argument)
+    const SaCol &col = p.lay.c[c];
+    const uint8_t *valid = col.in_voff != SA_NONE ? p.in + col.in_voff : nullptr;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (!((bits >> t) & 1)) continue;
+      const uint32_t r = (uint32_t)t * 1024u + threadIdx.x;
+      if (col.width == 8) ((uint64_t *)(p.out + col.out_off))[pos[t]] = ((const uint64_t *)(p.in + col.in_off))[r];
+      else ((uint32_t *)(p.out + col.out_off))[pos[t]] = ((const uint32_t *)(p.in + col.in_off))[r];
+      if (valid) s_v[pos[t]] = (valid[r >> 3] >> (r & 7)) & 1;
+    }
+    if (valid) sa_pack_validity(s_v, total, p.out + col.out_voff, &s_nulls[c]);
+  }
+  sa_publish((SaHeader *)p.out, p.seq, total, s_nulls, p.lay.ncols);
+}
+// the shape the fast path evaluates: INPUT_REF CONSTANT CMP over an int64 / float64 column, constant of the column's type
+static bool sa_filter_shape(const Expr &e, const sqlrs_batch_t *in, int *pred_col, RowFilter *rf) {
+  if (e.nodes.size() != 3) return false;
+  const sqlrs_expr_node_t &a = e.nodes[0], &b = e.nodes[1], &o = e.nodes[2];
+  if (a.op != SQLRS_EXPR_INPUT_REF || b.op != SQLRS_EXPR_CONSTANT || b.is_null) return false;
+  if (o.op < SQLRS_EXPR_GT || o.op > SQLRS_EXPR_NOTEQ) return false;
+  if (!in || a.index < 0 || a.index >= in->num_columns) return false;
+  const int32_t dt = in->columns[a.index].dtype;
+  if (dt != b.dtype || (dt != SQLRS_INT64 && dt != SQLRS_FLOAT64)) return false;
+  *pred_col = a.index;
+  rf->col = nullptr;
+  rf->is_f64 = dt == SQLRS_FLOAT64;
+  if (rf->is_f64) {
+    uint64_t bits;
+    std::memcpy(&bits, &b.f, 8);
+    rf->kord = (bits >> 63) ? ~bits : (bits | (1ull << 63)); // f64_to_ordered (hashagg_op.hip, fusable_row_filter)
+  } else
+    rf->kord = (uint64_t)b.i ^ (1ull << 63);
+  static const uint32_t masks[6] = {4, 1, 6, 3, 2, 5}; // GT, LT, GTEQ, LTEQ, EQ, NOTEQ: keep if {<, ==, >}
+  rf->keep_mask = masks[o.op - SQLRS_EXPR_GT];
+  return true;
+}
+} // namespace sq
+
+extern "C" {
+
+// sqlrs_filter_push without the wait: *ticket stands for the HOST batch sqlrs_filter_push(f, in, SQLRS_MEM_HOST, ..) would
+// return (small_async.hpp; sqlrs_batch_wait hands it out).  `in` is read completely before the call returns, as for push.
+int sqlrs_filter_push_async(sqlrs_filter_t *f, const sqlrs_batch_t *in, sqlrs_ticket_t **ticket) {
+  if (ticket) *ticket = nullptr;
+  return guard(f->ctx, [&] {
+    Ctx *ctx = f->ctx;
+    if (!ticket) fail(SQLRS_ERR_INTERNAL, "push_async: null ticket");
+    SQ_HIP(hipSetDevice(ctx->device));
+    auto t = std::unique_ptr<sqlrs_ticket>(new sqlrs_ticket());
+    t->ctx = ctx;
+    SaFilterParams p;
+    const char *off_e = hook("SQLRS_ASYNC_FAST"); // test hook, read per call: 0 = every batch through the synchronous operator
+    if (!(off_e && off_e[0] == '0') && sa_filter_shape(f->expr, in, &p.pred_col, &p.rf)) {
+      SaRing *r = sa_ring(ctx);
+      const int slot = sa_take_slot(r);
+      if (slot >= 0) {
+        if (sa_stage_input(in, r->in_area(slot), &p.lay, 0, nullptr)) {
+          p.in = r->in_area(slot);
+          p.out = r->out_area(slot);
+          p.seq = ++r->seq;
+          sa_filter_kernel<<<dim3(1), dim3(1024), 0, r->stream_of(slot)>>>(p); // (reads nothing the ctx stream produces)
+          SQ_HIP(hipGetLastError());
+          r->dirty = true;
+          t->slot = slot;
+          t->seq = p.seq;
+          t->lay = p.lay;
+          *ticket = t.release();
+          return;
+        }
+        r->busy[slot] = false;
+      }
+    }
+    InBatch ib(ctx, in); // the synchronous operator, its batch parked in the ticket
+    t->done = emit_batch(ctx, filter_batch(f, ib, nullptr), SQLRS_MEM_HOST);
+    *ticket = t.release();
   });
 }
 

@@ -1,0 +1,155 @@
+// small_async.hpp — the reference's calling shape without a stream synchronisation per call (round 6, review r05 #6).
+//
+// The reference polls ONE 1024-row batch at a time (storage/csv.rs:105, filter.rs:15-24, hash_join.rs:284-291).  A
+// synchronous `push` of such a batch is a chain of round trips — upload, two to four launches, the count, the download, a
+// stream synchronisation: ~47 us for 8 KB of rows, 21 Mrows/s (Filter) / 11 Mrows/s (HashJoin probe).  `push_async` hands
+// back a TICKET instead of a batch and `sqlrs_batch_wait(ticket)` the batch; a caller that waits one (or a few) batches
+// behind never blocks on the device.  The fast path is ONE launch per batch and no copy call at all:
+//   * the batch's columns are copied (memcpy, 8 KB per column) into a slot of a pinned, device-mapped ring;
+//   * one 1024-thread workgroup reads them over PCIe, evaluates `column OP constant` (Filter) or looks the keys up in the
+//     join's table (HashJoin, unique build keys), compacts the kept rows with ballots, gathers the build columns, and
+//     writes the output columns + validity bitmaps + a header {sequence number, rows, NULL counts} back into the slot;
+//   * `wait` polls the header's sequence number (system-scope release store behind `__threadfence_system`), falling
+//     back to a stream synchronisation when it does not show up, and copies the rows into an ordinary HOST batch.
+// Anything the fast path does not take — Utf8 / Boolean columns, other predicates, more than 4096 rows, DEVICE input,
+// duplicate build keys, join filters, outer joins — runs the synchronous operator inside push_async and parks the finished
+// batch in the ticket: same results, same one-output-per-input rule, no speed-up.
+#pragma once
+
+#include "common.hpp"
+
+namespace sq {
+
+constexpr int SA_SLOTS = 32, SA_MAX_COLS = 12;
+constexpr uint32_t SA_MAX_ROWS = 4096, SA_NONE = 0xffffffffu;
+constexpr size_t SA_AREA = 512 * 1024; // bytes of a slot's input area and of its output area
+
+struct SaHeader { // at the start of a slot's output area
+  unsigned long long seq; // written LAST by the kernel: the ticket's sequence number
+  uint32_t count, pad;
+  uint32_t nulls[SA_MAX_COLS];
+};
+struct SaCol {
+  uint32_t in_off, in_voff;   // values / validity bitmap in the input area (in_voff = SA_NONE: no NULLs); build columns: unused
+  uint32_t out_off, out_voff; // values / validity bitmap in the output area (always reserved)
+  uint32_t width;             // 4 or 8
+  int32_t dtype;
+};
+struct SaLayout {
+  int ncols = 0;
+  uint32_t rows = 0;
+  SaCol c[SA_MAX_COLS];
+};
+
+constexpr int SA_STREAMS = 4;
+struct SaRing {
+  uint8_t *pin = nullptr; // SA_SLOTS x (input area | output area), pinned + device mapped
+  bool busy[SA_SLOTS] = {};
+  int next = 0;
+  unsigned long long seq = 0;
+  // The one-workgroup kernels of consecutive batches are independent of each other; on ONE stream they run back to back
+  // (launch latency + a PCIe read round trip + the write-back: ~9 us per batch, 111 Mrows/s measured), on SA_STREAMS side
+  // streams they overlap.  A kernel that reads operator state built on the ctx stream (the join's table) is ordered behind
+  // it with one event per operator (sa_order_after_ctx), and an operator that is destroyed drains the side streams first.
+  hipStream_t side[SA_STREAMS] = {};
+  hipEvent_t order_ev = nullptr;
+  bool dirty = false; // a kernel was queued on a side stream since the last drain
+  ~SaRing() {
+    for (hipStream_t s : side)
+      if (s) {
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamDestroy(s);
+      }
+    if (order_ev) (void)hipEventDestroy(order_ev);
+    if (pin) (void)hipHostFree(pin);
+  }
+  hipStream_t stream_of(int slot) const { return side[slot % SA_STREAMS]; }
+  uint8_t *in_area(int s) const { return pin + (size_t)s * 2 * SA_AREA; }
+  uint8_t *out_area(int s) const { return pin + (size_t)s * 2 * SA_AREA + SA_AREA; }
+};
+SaRing *sa_ring(Ctx *ctx);  // the ctx's ring, created on first use
+int sa_take_slot(SaRing *r); // -1: every slot has a ticket outstanding
+void sa_order_after_ctx(Ctx *ctx, SaRing *r); // every side stream waits for what the ctx stream holds now
+void sa_drain(Ctx *ctx);                      // waits for the side streams (operator teardown); no-op without a ring
+
+// Lays `in` (HOST columns of int32 / int64 / float64, <= SA_MAX_ROWS rows) out in `area` and describes it in `lay`;
+// `first_out_col` output columns are reserved in front of the batch's own (the join's build columns).  false = not a batch
+// for the fast path (nothing written that matters).
+bool sa_stage_input(const sqlrs_batch_t *in, uint8_t *area, SaLayout *lay, int first_out_col, const int32_t *front_dtypes);
+
+} // namespace sq
+
+// what push_async returns and sqlrs_batch_wait consumes
+struct sqlrs_ticket {
+  sq::Ctx *ctx = nullptr;
+  int slot = -1; // -1: the slow path ran, `done` is the batch (may be NULL: an operator that emits nothing)
+  unsigned long long seq = 0;
+  sqlrs_batch_t *done = nullptr;
+  sq::SaLayout lay; // (output side: offsets, widths, dtypes of the columns the kernel writes)
+};
+
+#if defined(__HIPCC__)
+#include "device_utils.hpp"
+namespace sq {
+// Output positions of the kept rows of <= 4096 rows on ONE 1024-thread workgroup: pos[t] for row t * 1024 + tid, bit t of
+// the return value = kept; *total = kept rows.  `s_w`: 17 words of LDS.
+template <class KeepFn>
+__device__ __forceinline__ uint32_t sa_positions(uint32_t rows, KeepFn keep_of, uint32_t (&pos)[4], uint32_t *s_w, uint32_t *total) {
+  const int lane = lane_id(), w = wave_id();
+  uint32_t base = 0, bits = 0;
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    if ((uint32_t)t * 1024u >= rows) break; // (uniform)
+    const uint32_t r = (uint32_t)t * 1024u + threadIdx.x;
+    const bool k = r < rows && keep_of(r, t);
+    const uint64_t bm = __ballot(k);
+    if (lane == 0) s_w[w] = (uint32_t)__popcll(bm);
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const uint32_t c = s_w[q];
+      before += q < w ? c : 0;
+      all += c;
+    }
+    pos[t] = base + before + mbcnt(bm);
+    bits |= k ? 1u << t : 0u;
+    base += all;
+    __syncthreads();
+  }
+  *total = base;
+  return bits;
+}
+// the validity bitmap of one output column from per-row flags in LDS (`s_v[pos]` = 1 valid / 0 NULL, written by the kept
+// rows before the call's first barrier); returns nothing, adds the NULLs to *s_nulls (LDS)
+__device__ __forceinline__ void sa_pack_validity(const uint8_t *s_v, uint32_t total, uint8_t *out_bits, uint32_t *s_nulls) {
+  __syncthreads();
+  uint32_t nulls = 0;
+  for (uint32_t i = threadIdx.x; i < (total + 7) / 8; i += blockDim.x) {
+    uint32_t byte = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const uint32_t p = i * 8 + b;
+      const uint32_t v = p < total ? s_v[p] : 0u;
+      byte |= v << b;
+      nulls += p < total && !v;
+    }
+    out_bits[i] = (uint8_t)byte;
+  }
+  if (nulls) atomicAdd(s_nulls, nulls);
+  __syncthreads();
+}
+// the last step of a fast-path kernel: every thread's stores to the pinned output are pushed out, then ONE thread
+// publishes the header
+__device__ __forceinline__ void sa_publish(SaHeader *hdr, unsigned long long seq, uint32_t total, const uint32_t *s_nulls, int ncols) {
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    hdr->count = total;
+    for (int c = 0; c < ncols; c++) hdr->nulls[c] = s_nulls[c];
+    __threadfence_system();
+    __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+} // namespace sq
+#endif

@@ -40,6 +40,38 @@ def _emit(backend: abi.Backend, p, out_mem: int, names: Optional[Sequence[str]])
         lb.release()
 
 
+def _async_stream(be, child, depth, push, names_of):
+    """the stream adaptor of the async entry points: `depth` tickets in flight, batches handed out in input order"""
+    from collections import deque
+    q = deque()
+
+    def wait_one():
+        t, names = q.popleft()
+        out = C.POINTER(abi.Batch)()
+        be.check(be.fn("batch_wait")(t, C.byref(out)))
+        return _emit(be, out, abi.MEM_HOST, names)
+    try:
+        for batch in child:
+            b = abi.as_batch(batch)
+            t = C.c_void_p()
+            be.check(push(b, C.byref(t)))
+            q.append((t, names_of(batch)))
+            if len(q) > depth:
+                r = wait_one()
+                if r is not None:
+                    yield r
+        while q:
+            r = wait_one()
+            if r is not None:
+                yield r
+    finally:
+        while q:  # (an error / an abandoned generator: every ticket is consumed)
+            t, _ = q.popleft()
+            out = C.POINTER(abi.Batch)()
+            if be.fn("batch_wait")(t, C.byref(out)) == abi.OK and out:
+                be.fn("batch_release")(out)
+
+
 def _names_of(batch) -> Optional[List[str]]:
     if isinstance(batch, pa.RecordBatch):
         return list(batch.schema.names)
@@ -50,8 +82,11 @@ class FilterExecutor:
     """``FilterExecutor { expr, child }`` (filter.rs:7-10)."""
 
     def __init__(self, backend: abi.Backend, expr: BoundExpr, child: Iterable,
-                 out_mem: int = abi.MEM_HOST, many: int = 0):
+                 out_mem: int = abi.MEM_HOST, many: int = 0, depth: int = 0):
         self.backend, self.expr, self.child, self.out_mem = backend, expr, child, out_mem
+        # depth > 0: sqlrs_filter_push_async with that many tickets in flight — the same stream of HOST batches, the
+        # operator polled one batch at a time as the reference does, no stream synchronisation per batch
+        self.depth = depth
         # many > 1: pull that many batches of the child, hand them to sqlrs_filter_push_many together and yield its
         # outputs one by one — the same stream of batches (one per input batch, filter.rs:15-24), fewer uploads
         self.many = many
@@ -84,6 +119,9 @@ class FilterExecutor:
             if self.many > 1 and getattr(be.lib, be.prefix + "filter_push_many", None) is not None:
                 yield from self._execute_many(be, h)
                 return
+            if self.depth > 0 and self.out_mem == abi.MEM_HOST and getattr(be.lib, be.prefix + "filter_push_async", None) is not None:
+                yield from _async_stream(be, self.child, self.depth, lambda b, t: be.fn("filter_push_async")(h, b.ptr, t), _names_of)
+                return
             for batch in self.child:  # filter.rs:15-24
                 b = abi.as_batch(batch)
                 out = C.POINTER(abi.Batch)()
@@ -102,8 +140,9 @@ class HashJoinExecutor:
 
     def __init__(self, backend: abi.Backend, left_child: Iterable, right_child: Iterable,
                  join_type: str, join_condition: JoinCondition, join_output_schema: pa.Schema,
-                 num_left_columns: int, out_mem: int = abi.MEM_HOST, many: int = 0):
+                 num_left_columns: int, out_mem: int = abi.MEM_HOST, many: int = 0, depth: int = 0):
         self.backend = backend
+        self.depth = depth  # > 0: probe batches through sqlrs_hash_join_probe_push_async, that many tickets in flight
         # many > 1: that many probe batches go to sqlrs_hash_join_probe_push_many together (same stream of joined batches)
         self.many = many
         self.left_child, self.right_child = left_child, right_child
@@ -157,6 +196,16 @@ class HashJoinExecutor:
                         yield from flush()
                 if group:
                     yield from flush()
+                out = C.POINTER(abi.Batch)()  # tail, hash_join.rs:296-322
+                be.check(be.fn("hash_join_finish")(h, self.out_mem, C.byref(out)))
+                r = _emit(be, out, self.out_mem, names)
+                if r is not None:
+                    yield r
+                return
+            if self.depth > 0 and not indices_only and self.out_mem == abi.MEM_HOST and \
+                    getattr(be.lib, be.prefix + "hash_join_probe_push_async", None) is not None:
+                yield from _async_stream(be, self.right_child, self.depth,
+                                         lambda b, t: be.fn("hash_join_probe_push_async")(h, b.ptr, t), lambda _b: names)
                 out = C.POINTER(abi.Batch)()  # tail, hash_join.rs:296-322
                 be.check(be.fn("hash_join_finish")(h, self.out_mem, C.byref(out)))
                 r = _emit(be, out, self.out_mem, names)

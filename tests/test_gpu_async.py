@@ -1,0 +1,101 @@
+"""Single-batch streaming without a synchronisation per call (sqlrs_filter_push_async / sqlrs_hash_join_probe_push_async /
+sqlrs_batch_wait, review r05 #6): the reference's calling shape — one 1024-row batch per poll, filter.rs:15-24,
+hash_join.rs:284-291, storage/csv.rs:105.  The async stream must be the synchronous stream, batch for batch."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from sqlrs_amd import abi
+from sqlrs_amd.executor import FilterExecutor, HashJoinExecutor
+from sqlrs_amd.expr import Constant, InputRef, JoinCondition
+from test_gpu_parity import join_schema
+
+pytestmark = pytest.mark.gpu
+
+
+def same_batches(got, exp):
+    assert [g.num_rows for g in got] == [e.num_rows for e in exp]
+    for g, e in zip(got, exp):
+        assert g.schema.names == e.schema.names
+        for c in range(g.num_columns):
+            assert g.column(c).equals(e.column(c)), (g.schema.names[c], g.column(c).null_count, e.column(c).null_count)
+
+
+def batches(rng, n, sizes, nulls, with_str=False):
+    out = []
+    for rows in sizes:
+        cols = [pa.array(rng.integers(-100, 100, rows), mask=(rng.random(rows) < nulls) if nulls else None),
+                pa.array(rng.random(rows), mask=(rng.random(rows) < nulls) if nulls else None),
+                pa.array(rng.integers(-5, 5, rows).astype(np.int32), mask=(rng.random(rows) < nulls) if nulls else None)]
+        names = ["a", "b", "c"]
+        if with_str:
+            cols.append(pa.array([str(i) for i in range(rows)]))
+            names.append("s")
+        out.append(pa.RecordBatch.from_arrays(cols, names=names))
+    return out
+
+
+@pytest.mark.parametrize("pred", ["i64_gt", "f64_le", "i64_ne", "pred_nulls", "compound", "i32"])
+@pytest.mark.parametrize("depth", [1, 4, 40])
+def test_filter_push_async_yields_the_batches_of_push(hip, oracle, monkeypatch, pred, depth):
+    """fast path (column OP constant over int64 / float64, NULLs in the predicate column dropped, validity re-packed), the
+    slow path inside the same stream (compound predicate, int32 predicate, a Utf8 column, > 4096 rows, an empty batch) and
+    more tickets than ring slots (depth 40): always the batches of sqlrs_filter_push and of the oracle"""
+    rng = np.random.default_rng(5 + depth)
+    nulls = 0.2 if pred == "pred_nulls" else 0.1
+    bs = batches(rng, 0, [1024] * 20 + [0, 1, 63, 64, 65, 1023, 1025, 4096, 4097, 20000] + [1024] * 45, nulls)
+    bs += batches(rng, 0, [1024, 100], nulls, with_str=True)
+    e = {"i64_gt": InputRef(0) > Constant(3, abi.INT64), "f64_le": InputRef(1) <= Constant(0.37, abi.FLOAT64),
+         "i64_ne": InputRef(0).ne(Constant(-7, abi.INT64)), "pred_nulls": InputRef(1) > Constant(0.5, abi.FLOAT64),
+         "compound": (InputRef(0) > Constant(3, abi.INT64)) & (InputRef(1) < Constant(0.9, abi.FLOAT64)),
+         "i32": InputRef(2) > Constant(0, abi.INT32)}[pred]
+    hip.profile(True)
+    got = list(FilterExecutor(hip, e, bs, depth=depth).execute())
+    hip.profile_read()
+    hip.profile(False)
+    same_batches(got, list(FilterExecutor(hip, e, bs).execute()))
+    same_batches(got, list(FilterExecutor(oracle, e, bs).execute()))
+    monkeypatch.setenv("SQLRS_ASYNC_FAST", "0")  # every batch through the synchronous operator inside push_async
+    same_batches(list(FilterExecutor(hip, e, bs, depth=depth).execute()), got)
+
+
+@pytest.mark.parametrize("keys", ["dense", "sparse", "f64", "i32"])
+@pytest.mark.parametrize("depth", [1, 8])
+def test_hash_join_probe_push_async_yields_the_batches_of_probe_push(hip, oracle, keys, depth):
+    """Inner join over unique build keys: direct-address table, 16-byte-slot hash table, f64 keys by bit pattern, int32 keys;
+    NULLs in the build and probe PAYLOAD columns travel; batches with NULL probe keys, big batches and empty ones take the
+    synchronous operator inside the same stream"""
+    rng = np.random.default_rng(11 + depth)
+    nb = 20_000
+    raw = rng.permutation(3 * nb)[:nb]
+    conv = {"dense": lambda x: x.astype(np.int64), "sparse": lambda x: x.astype(np.int64) * 7919 - 5,
+            "f64": lambda x: x.astype(np.float64) * 0.25, "i32": lambda x: x.astype(np.int32)}[keys]
+    lb = pa.RecordBatch.from_arrays([pa.array(conv(raw)), pa.array(rng.random(nb), mask=rng.random(nb) < 0.1),
+                                     pa.array(np.arange(nb, dtype=np.int32))], names=["k", "x", "i"])
+    rbs = []
+    for rows in [1024] * 30 + [0, 1, 64, 1023, 4096, 5000, 1024, 1024]:
+        rbs.append(pa.RecordBatch.from_arrays([pa.array(rng.random(rows), mask=rng.random(rows) < 0.2),
+                                               pa.array(conv(rng.integers(0, 3 * nb, rows)))], names=["v", "k"]))
+    pk = conv(rng.integers(0, 3 * nb, 1024))
+    rbs.insert(7, pa.RecordBatch.from_arrays([pa.array(rng.random(1024)), pa.array(pk, mask=rng.random(1024) < 0.1)], names=["v", "k"]))
+    cond = JoinCondition([(InputRef(0), InputRef(1))])
+    sch = join_schema(lb, rbs[0])
+    got = list(HashJoinExecutor(hip, [lb], rbs, "inner", cond, sch, 3, depth=depth).execute())
+    same_batches(got, list(HashJoinExecutor(hip, [lb], rbs, "inner", cond, sch, 3).execute()))
+    same_batches(got, list(HashJoinExecutor(oracle, [lb], rbs, "inner", cond, sch, 3).execute()))
+
+
+def test_async_shapes_that_only_the_synchronous_operator_takes(hip, oracle):
+    """Left join, a join filter, duplicate build keys, an empty build side: push_async runs the synchronous operator and
+    parks its batch in the ticket — the stream (including the Left join's tail batch) is unchanged"""
+    rng = np.random.default_rng(3)
+    nb = 3000
+    lb = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 2000, nb)), pa.array(rng.random(nb))], names=["k", "x"])  # duplicates
+    rbs = [pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 2500, 1024)), pa.array(rng.random(1024))], names=["k", "v"]) for _ in range(6)]
+    sch = join_schema(lb, rbs[0])
+    for jt, cond, lbs in (("inner", JoinCondition([(InputRef(0), InputRef(0))]), [lb]),
+                          ("left", JoinCondition([(InputRef(0), InputRef(0))]), [lb.slice(0, 500)]),
+                          ("inner", JoinCondition([(InputRef(0), InputRef(0))], InputRef(1) > InputRef(3)), [lb.slice(0, 500)]),
+                          ("inner", JoinCondition([(InputRef(0), InputRef(0))]), [lb.slice(0, 0)])):
+        got = list(HashJoinExecutor(hip, lbs, rbs, jt, cond, sch, 2, depth=3).execute())
+        same_batches(got, list(HashJoinExecutor(oracle, lbs, rbs, jt, cond, sch, 2).execute()))
