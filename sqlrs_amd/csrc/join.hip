@@ -1778,9 +1778,10 @@ static bool lds_build_first(sqlrs_hash_join *j) {
   const char *env_e = hook("SQLRS_LDS_JOIN"), *first_e = hook("SQLRS_LDS_FIRST");
   const int env = env_e ? std::atoi(env_e) : -1;
   const bool outer_right = j->join_type == SQLRS_JOIN_RIGHT || j->join_type == SQLRS_JOIN_FULL;
-  if (env == 0 || (first_e && std::atoi(first_e) == 0) || outer_right || j->lazy_table || !j->exact || j->bkeys_validity || !j->bkeys ||
+  if (env == 0 || (first_e && std::atoi(first_e) == 0) || outer_right || j->lazy_table || j->bkeys_validity || !j->bkeys ||
       j->nB < 2 || j->nB > (1ll << 24))
     return false;
+  if (j->unique_known && !j->unique) return false; // (the direct-address build has already seen duplicates: nothing to establish)
   if (env != 1 && j->nB < (1 << 18)) return false;
   lds_join_prepare(j);
   if (!j->lds_slots || !j->lds_build->key) return false;
@@ -1805,7 +1806,9 @@ static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
   const int64_t n = pk.rows, nB = j->nB;
   const char *env_e = hook("SQLRS_LDS_JOIN"); // test / tuning hook, read per call: 0 = never, 1 = whenever the shapes allow
   const int env = env_e ? std::atoi(env_e) : -1;
-  if (env == 0 || !j->exact || pk.validity || j->bkeys_validity || !j->bkeys || nB < 2 || n > 0xffffffffll) return out;
+  // (hashed keys — several key columns, Utf8 — are matched by their 64-bit hash alone, the reference's rule, hash_join.rs:222-232:
+  //  the hash IS the key of this route, compared exactly; they carry no validity: a NULL leaves the hash unchanged)
+  if (env == 0 || pk.validity || j->bkeys_validity || !j->bkeys || nB < 2 || n > 0xffffffffll) return out;
   if (env != 1 && (nB < (1 << 18) || n < (1 << 22) || n < 8 * nB)) return out;
   lds_join_prepare(j);
   const uint32_t P = LJ_P;

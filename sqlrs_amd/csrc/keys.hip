@@ -60,6 +60,31 @@ __global__ void fold_utf8_kernel(const uint8_t *__restrict__ data, const int32_t
   h[i] = multi ? combine_hashes(v, h[i]) : v;
 }
 
+// Several fixed-width key columns folded in ONE pass (round 6): the column-by-column form above reads and rewrites the running
+// hash once per column behind a memset — 5.6 GB for two int64 columns of 1e8 rows (0.99 ms of the 3.7 ms two-column-key join);
+// this reads the columns once and writes the hash once (2.4 GB).  Same arithmetic, same order: h = 0, then per column
+// h = combine_hashes(mix64(value + tag), h) unless the value is NULL.
+struct FoldCols {
+  const void *v[4];
+  const uint64_t *valid[4];
+  uint64_t tag[4];
+  int is32[4];
+  int n;
+};
+__global__ __launch_bounds__(256) void fold_fixed_multi_kernel(FoldCols fc, int64_t rows, uint64_t *__restrict__ h) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) {
+    uint64_t acc = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (c >= fc.n) break;
+      if (fc.valid[c] && !((fc.valid[c][i >> 6] >> (i & 63)) & 1)) continue;
+      const uint64_t x = fc.is32[c] ? (uint64_t)((const uint32_t *)fc.v[c])[i] : ((const uint64_t *)fc.v[c])[i];
+      acc = combine_hashes(mix64(x + fc.tag[c]), acc);
+    }
+    h[i] = acc;
+  }
+}
+
 // Strong (asymmetric, position-dependent) 64-bit fold for library-internal de-duplication keys
 // such as (group key..., DISTINCT argument): unlike combine_hashes, (a, b) and (b, a) differ and
 // a NULL is a value of its own.  mode: 0 = fixed 8 B, 1 = fixed 4 B, 2 = bool bits, 3 = utf8
@@ -174,6 +199,30 @@ NKeys normalize_keys(Ctx *ctx, const std::vector<DCol> &cols_in, int64_t rows) {
   }
   // hash mode: every_rows_hashes = vec![0; n]; create_hashes(...)   (hash_join.rs:169-170)
   k.exact = false;
+  if (rows > 0 && cols.size() >= 2 && cols.size() <= 4) { // all fixed-width: one pass, no memset
+    FoldCols fc;
+    fc.n = (int)cols.size();
+    bool ok = true;
+    for (int c = 0; c < 4; c++) {
+      fc.v[c] = nullptr;
+      fc.valid[c] = nullptr;
+      fc.tag[c] = 0;
+      fc.is32[c] = 0;
+      if (c >= fc.n) continue;
+      const DCol &col = cols[(size_t)c];
+      ok = ok && (col.dtype == SQLRS_INT32 || col.dtype == SQLRS_INT64 || col.dtype == SQLRS_FLOAT64);
+      fc.v[c] = col.values;
+      fc.valid[c] = (col.validity && col.null_count != 0) ? col.validity : nullptr;
+      fc.is32[c] = col.dtype == SQLRS_INT32;
+      fc.tag[c] = col.dtype == SQLRS_INT32 ? 0x3232323200000000ULL : 0x9e3779b97f4a7c15ULL;
+    }
+    if (ok) {
+      const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(rows, 256 * 4), 16 * (int64_t)ctx->num_cus));
+      fold_fixed_multi_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(fc, rows, k.keys->as<uint64_t>());
+      SQ_HIP(hipGetLastError());
+      return k;
+    }
+  }
   SQ_HIP(hipMemsetAsync(k.keys->p, 0, 8 * (size_t)n1, ctx->stream));
   if (rows == 0) return k;
   int multi = cols.size() > 1;
