@@ -17,6 +17,7 @@ SaRing *sa_ring(Ctx *ctx) {
     std::memset(r->pin, 0, (size_t)SA_SLOTS * 2 * SA_AREA);
     for (int i = 0; i < SA_STREAMS; i++) SQ_HIP(hipStreamCreateWithFlags(&r->side[i], hipStreamNonBlocking));
     SQ_HIP(hipEventCreateWithFlags(&r->order_ev, hipEventDisableTiming));
+    if (const char *g = hook("SQLRS_ASYNC_GROUP")) r->group = std::min(SA_GROUP_MAX, std::max(1, std::atoi(g))); // test hook: batches per launch
     ctx->small_ring = r;
   }
   return (SaRing *)ctx->small_ring.get();
@@ -25,9 +26,19 @@ void sa_order_after_ctx(Ctx *ctx, SaRing *r) {
   SQ_HIP(hipEventRecord(r->order_ev, ctx->stream));
   for (int i = 0; i < SA_STREAMS; i++) SQ_HIP(hipStreamWaitEvent(r->side[i], r->order_ev, 0));
 }
+void sa_flush(Ctx *ctx) {
+  SaRing *r = (SaRing *)ctx->small_ring.get();
+  if (!r || !r->pend_n) return;
+  r->pend_launch(r, ctx);
+  r->pend_n = 0;
+  r->launched_seq = r->seq;
+  r->dirty = true;
+}
 void sa_drain(Ctx *ctx) {
   SaRing *r = (SaRing *)ctx->small_ring.get();
-  if (!r || !r->dirty) return;
+  if (!r) return;
+  sa_flush(ctx);
+  if (!r->dirty) return;
   for (int i = 0; i < SA_STREAMS; i++) (void)hipStreamSynchronize(r->side[i]);
   r->dirty = false;
 }
@@ -110,6 +121,10 @@ int sqlrs_batch_wait(sqlrs_ticket_t *ticket, sqlrs_batch_t **out) {
       return;
     }
     SaRing *r = sa_ring(ctx);
+    if (ticket->seq > r->launched_seq) { // its kernel is still waiting for its group to fill
+      SQ_HIP(hipSetDevice(ctx->device));
+      sa_flush(ctx);
+    }
     const SaHeader *h = (const SaHeader *)r->out_area(ticket->slot);
     bool seen = false;
     for (int spin = 0; spin < 20000 && !seen; spin++) {
@@ -118,7 +133,7 @@ int sqlrs_batch_wait(sqlrs_ticket_t *ticket, sqlrs_batch_t **out) {
     }
     if (!seen) { // (not there yet — a long queue ahead, or stores that only a finished stream makes visible)
       SQ_HIP(hipSetDevice(ctx->device));
-      SQ_HIP(hipStreamSynchronize(r->stream_of(ticket->slot)));
+      for (int i = 0; i < SA_STREAMS; i++) SQ_HIP(hipStreamSynchronize(r->side[i]));
       if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != ticket->seq) fail(SQLRS_ERR_DEVICE, "batch_wait: the batch's kernel left no result");
     }
     const SaLayout &lay = ticket->lay;

@@ -2401,7 +2401,8 @@ struct SaProbeParams {
   uint8_t *out;
   unsigned long long seq;
 };
-__global__ __launch_bounds__(1024) void sa_probe_kernel(SaProbeParams p) {
+__global__ __launch_bounds__(1024) void sa_probe_kernel(SaGroup<SaProbeParams> grp) {
+  const SaProbeParams &p = grp.p[blockIdx.x]; // (one workgroup per batch of the group)
   __shared__ uint32_t s_w[17], s_nulls[SA_MAX_COLS];
   __shared__ uint8_t s_v[SA_MAX_ROWS];
   if (threadIdx.x < SA_MAX_COLS) s_nulls[threadIdx.x] = 0;
@@ -2441,6 +2442,12 @@ __global__ __launch_bounds__(1024) void sa_probe_kernel(SaProbeParams p) {
     if (lvalid || rvalid) sa_pack_validity(s_v, total, p.out + col.out_voff, &s_nulls[c]);
   }
   sa_publish((SaHeader *)p.out, p.seq, total, s_nulls, p.lay.ncols);
+}
+static void sa_probe_launch(SaRing *r, Ctx *ctx) {
+  SaGroup<SaProbeParams> g;
+  for (int i = 0; i < r->pend_n; i++) std::memcpy(&g.p[i], r->pend_buf + (size_t)i * SA_PARAM_MAX, sizeof(SaProbeParams));
+  sa_probe_kernel<<<dim3((unsigned)r->pend_n), dim3(1024), 0, r->stream_of(r->pend_first_slot)>>>(g);
+  SQ_HIP(hipGetLastError());
 }
 // true = the kernel above was queued for `right` and *t describes its slot
 static bool sa_probe_try(sqlrs_hash_join *j, const sqlrs_batch_t *right, sqlrs_ticket *t) {
@@ -2492,9 +2499,7 @@ static bool sa_probe_try(sqlrs_hash_join *j, const sqlrs_batch_t *right, sqlrs_t
     sa_order_after_ctx(ctx, r);
     j->async_ordered = true;
   }
-  sa_probe_kernel<<<dim3(1), dim3(1024), 0, r->stream_of(slot)>>>(p);
-  SQ_HIP(hipGetLastError());
-  r->dirty = true;
+  sa_enqueue(ctx, r, j, sa_probe_launch, p, slot);
   t->slot = slot;
   t->seq = p.seq;
   t->lay = p.lay;
@@ -2515,6 +2520,7 @@ int sqlrs_hash_join_probe_push_async(sqlrs_hash_join_t *j, const sqlrs_batch_t *
     auto t = std::unique_ptr<sqlrs_ticket>(new sqlrs_ticket());
     t->ctx = ctx;
     if (!j->empty_build && !sa_probe_try(j, right, t.get())) {
+      sa_flush(ctx); // (tickets complete in issue order)
       InBatch ib(ctx, right);
       DBatch r = probe_batch(j, ib, nullptr);
       t->done = emit_batch(ctx, std::move(r), SQLRS_MEM_HOST);

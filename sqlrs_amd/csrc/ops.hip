@@ -194,7 +194,8 @@ struct SaFilterParams {
   uint8_t *out;
   unsigned long long seq;
 };
-__global__ __launch_bounds__(1024) void sa_filter_kernel(SaFilterParams p) {
+__global__ __launch_bounds__(1024) void sa_filter_kernel(SaGroup<SaFilterParams> grp) {
+  const SaFilterParams &p = grp.p[blockIdx.x]; // (one workgroup per batch of the group)
   __shared__ uint32_t s_w[17], s_nulls[SA_MAX_COLS];
   __shared__ uint8_t s_v[SA_MAX_ROWS];
   if (threadIdx.x < SA_MAX_COLS) s_nulls[threadIdx.x] = 0;
@@ -218,6 +219,12 @@ __global__ __launch_bounds__(1024) void sa_filter_kernel(SaFilterParams p) {
     if (valid) sa_pack_validity(s_v, total, p.out + col.out_voff, &s_nulls[c]);
   }
   sa_publish((SaHeader *)p.out, p.seq, total, s_nulls, p.lay.ncols);
+}
+static void sa_filter_launch(SaRing *r, Ctx *ctx) {
+  SaGroup<SaFilterParams> g;
+  for (int i = 0; i < r->pend_n; i++) std::memcpy(&g.p[i], r->pend_buf + (size_t)i * SA_PARAM_MAX, sizeof(SaFilterParams));
+  sa_filter_kernel<<<dim3((unsigned)r->pend_n), dim3(1024), 0, r->stream_of(r->pend_first_slot)>>>(g); // (reads nothing the ctx stream produces)
+  SQ_HIP(hipGetLastError());
 }
 // the shape the fast path evaluates: INPUT_REF CONSTANT CMP over an int64 / float64 column, constant of the column's type
 static bool sa_filter_shape(const Expr &e, const sqlrs_batch_t *in, int *pred_col, RowFilter *rf) {
@@ -265,9 +272,7 @@ int sqlrs_filter_push_async(sqlrs_filter_t *f, const sqlrs_batch_t *in, sqlrs_ti
           p.in = r->in_area(slot);
           p.out = r->out_area(slot);
           p.seq = ++r->seq;
-          sa_filter_kernel<<<dim3(1), dim3(1024), 0, r->stream_of(slot)>>>(p); // (reads nothing the ctx stream produces)
-          SQ_HIP(hipGetLastError());
-          r->dirty = true;
+          sa_enqueue(ctx, r, f, sa_filter_launch, p, slot);
           t->slot = slot;
           t->seq = p.seq;
           t->lay = p.lay;
@@ -277,6 +282,7 @@ int sqlrs_filter_push_async(sqlrs_filter_t *f, const sqlrs_batch_t *in, sqlrs_ti
         r->busy[slot] = false;
       }
     }
+    sa_flush(ctx); // (tickets complete in issue order: what waits for a launch goes first)
     InBatch ib(ctx, in); // the synchronous operator, its batch parked in the ticket
     t->done = emit_batch(ctx, filter_batch(f, ib, nullptr), SQLRS_MEM_HOST);
     *ticket = t.release();
@@ -360,7 +366,10 @@ int sqlrs_filter_push_many(sqlrs_filter_t *f, int n, const sqlrs_batch_t *const 
   });
 }
 
-void sqlrs_filter_destroy(sqlrs_filter_t *f) { delete f; }
+void sqlrs_filter_destroy(sqlrs_filter_t *f) {
+  if (f) sa_flush(f->ctx); // (a group of its batches may still wait for its launch; their tickets stay valid)
+  delete f;
+}
 
 // [ref: evaluator.rs:13-28]
 int sqlrs_eval_expr(sqlrs_ctx_t *ctx, const sqlrs_expr_t *expr, const sqlrs_batch_t *in, int out_mem,

@@ -16,6 +16,8 @@
 // batch in the ticket: same results, same one-output-per-input rule, no speed-up.
 #pragma once
 
+#include <cstring>
+
 #include "common.hpp"
 
 namespace sq {
@@ -41,7 +43,8 @@ struct SaLayout {
   SaCol c[SA_MAX_COLS];
 };
 
-constexpr int SA_STREAMS = 4;
+constexpr int SA_STREAMS = 4, SA_GROUP_MAX = 4;
+constexpr size_t SA_PARAM_MAX = 1024; // bytes of one batch's kernel parameters
 struct SaRing {
   uint8_t *pin = nullptr; // SA_SLOTS x (input area | output area), pinned + device mapped
   bool busy[SA_SLOTS] = {};
@@ -54,6 +57,14 @@ struct SaRing {
   hipStream_t side[SA_STREAMS] = {};
   hipEvent_t order_ev = nullptr;
   bool dirty = false; // a kernel was queued on a side stream since the last drain
+  // Grouped launches: the parameters of up to `group` consecutive batches of ONE operator wait here and leave with ONE launch
+  // (grid = batches, a workgroup each) — the launch call is the largest part of the host's ~6 us per batch.  Flushed when the
+  // group is full, when another operator (or the synchronous path) comes, and by whoever waits for a ticket of the group.
+  unsigned char pend_buf[SA_GROUP_MAX * SA_PARAM_MAX];
+  int pend_n = 0, pend_first_slot = 0, group = SA_GROUP_MAX;
+  const void *pend_owner = nullptr;
+  void (*pend_launch)(SaRing *, Ctx *) = nullptr;
+  unsigned long long launched_seq = 0; // the kernels of all tickets up to this sequence number are queued
   ~SaRing() {
     for (hipStream_t s : side)
       if (s) {
@@ -70,7 +81,20 @@ struct SaRing {
 SaRing *sa_ring(Ctx *ctx);  // the ctx's ring, created on first use
 int sa_take_slot(SaRing *r); // -1: every slot has a ticket outstanding
 void sa_order_after_ctx(Ctx *ctx, SaRing *r); // every side stream waits for what the ctx stream holds now
-void sa_drain(Ctx *ctx);                      // waits for the side streams (operator teardown); no-op without a ring
+void sa_drain(Ctx *ctx);                      // flushes, then waits for the side streams (operator teardown); no-op without a ring
+void sa_flush(Ctx *ctx);                      // launches the pending group, if any
+template <class P> struct SaGroup { P p[SA_GROUP_MAX]; };
+// appends one batch's parameters to the pending group of `owner` (launching what another operator left there first)
+template <class P> inline void sa_enqueue(Ctx *ctx, SaRing *r, const void *owner, void (*launch)(SaRing *, Ctx *), const P &p, int slot) {
+  static_assert(sizeof(P) <= SA_PARAM_MAX, "parameter block too large");
+  if (r->pend_n && (r->pend_owner != owner || r->pend_launch != launch)) sa_flush(ctx);
+  if (!r->pend_n) r->pend_first_slot = slot;
+  std::memcpy(r->pend_buf + (size_t)r->pend_n * SA_PARAM_MAX, &p, sizeof(P));
+  r->pend_owner = owner;
+  r->pend_launch = launch;
+  r->pend_n++;
+  if (r->pend_n >= r->group) sa_flush(ctx);
+}
 
 // Lays `in` (HOST columns of int32 / int64 / float64, <= SA_MAX_ROWS rows) out in `area` and describes it in `lay`;
 // `first_out_col` output columns are reserved in front of the batch's own (the join's build columns).  false = not a batch

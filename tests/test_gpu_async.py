@@ -99,3 +99,21 @@ def test_async_shapes_that_only_the_synchronous_operator_takes(hip, oracle):
                           ("inner", JoinCondition([(InputRef(0), InputRef(0))]), [lb.slice(0, 0)])):
         got = list(HashJoinExecutor(hip, lbs, rbs, jt, cond, sch, 2, depth=3).execute())
         same_batches(got, list(HashJoinExecutor(oracle, lbs, rbs, jt, cond, sch, 2).execute()))
+
+
+@pytest.mark.parametrize("group", ["1", "2", "3"])
+def test_async_group_sizes(oracle, monkeypatch, group):
+    """the launches of the async path carry up to four batches; a ticket waited for before its group is full flushes it — here
+    with groups of 1 / 2 / 3 batches (SQLRS_ASYNC_GROUP, read when a ctx's ring is created) and depths below, at and above them"""
+    import sqlrs_amd
+    monkeypatch.setenv("SQLRS_ASYNC_GROUP", group)
+    be = sqlrs_amd.new_ctx(0)
+    try:
+        rng = np.random.default_rng(int(group))
+        bs = batches(rng, 0, [1024] * 11 + [5000] + [1024] * 6, 0.1)
+        e = InputRef(0) > Constant(3, abi.INT64)
+        exp = list(FilterExecutor(oracle, e, bs).execute())
+        for depth in (1, 2, 5):
+            same_batches(list(FilterExecutor(be, e, bs, depth=depth).execute()), exp)
+    finally:
+        be.close()
