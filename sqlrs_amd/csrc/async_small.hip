@@ -11,13 +11,20 @@ namespace sq {
 
 SaRing *sa_ring(Ctx *ctx) {
   if (!ctx->small_ring) {
+    static thread_local bool failed_once = false; // (a platform without coherent mapped host memory: the synchronous path, quietly)
+    if (failed_once) return nullptr;
     auto r = std::make_shared<SaRing>();
+    try {
     // coherent (fine-grained) + mapped: the kernel's stores are visible to a polling host thread while the stream runs on
     SQ_HIP(hipHostMalloc((void **)&r->pin, (size_t)SA_SLOTS * 2 * SA_AREA, hipHostMallocCoherent | hipHostMallocMapped));
     std::memset(r->pin, 0, (size_t)SA_SLOTS * 2 * SA_AREA);
     for (int i = 0; i < SA_STREAMS; i++) SQ_HIP(hipStreamCreateWithFlags(&r->side[i], hipStreamNonBlocking));
     SQ_HIP(hipEventCreateWithFlags(&r->order_ev, hipEventDisableTiming));
     if (const char *g = hook("SQLRS_ASYNC_GROUP")) r->group = std::min(SA_GROUP_MAX, std::max(1, std::atoi(g))); // test hook: batches per launch
+    } catch (const Error &) {
+      failed_once = true;
+      return nullptr;
+    }
     ctx->small_ring = r;
   }
   return (SaRing *)ctx->small_ring.get();
@@ -121,6 +128,7 @@ int sqlrs_batch_wait(sqlrs_ticket_t *ticket, sqlrs_batch_t **out) {
       return;
     }
     SaRing *r = sa_ring(ctx);
+    if (!r) fail(SQLRS_ERR_INTERNAL, "batch_wait: a slot ticket without a ring");
     if (ticket->seq > r->launched_seq) { // its kernel is still waiting for its group to fill
       SQ_HIP(hipSetDevice(ctx->device));
       sa_flush(ctx);
@@ -150,7 +158,7 @@ int sqlrs_batch_wait(sqlrs_ticket_t *ticket, sqlrs_batch_t **out) {
     }
     *out = emit_host_copy(ctx, lay.ncols, dts, (int64_t)h->count, vals, valid, nulls);
   });
-  if (ticket->slot >= 0) sa_ring(ctx)->busy[ticket->slot] = false;
+  if (ticket->slot >= 0 && ctx->small_ring) ((SaRing *)ctx->small_ring.get())->busy[ticket->slot] = false;
   if (ticket->done) sqlrs_batch_release(ticket->done); // (an error above: nothing leaks)
   delete ticket;
   return st;

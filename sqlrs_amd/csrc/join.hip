@@ -2474,7 +2474,7 @@ static bool sa_probe_try(sqlrs_hash_join *j, const sqlrs_batch_t *right, sqlrs_t
   if (!j->dense) hash_join_ensure_table(j);
   if (!j->unique || (!j->dense && !j->table)) return false;
   SaRing *r = sa_ring(ctx);
-  const int slot = sa_take_slot(r);
+  const int slot = r ? sa_take_slot(r) : -1;
   if (slot < 0) return false;
   SaProbeParams p;
   if (!sa_stage_input(right, r->in_area(slot), &p.lay, nleft, ldt)) {

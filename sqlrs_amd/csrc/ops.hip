@@ -266,7 +266,7 @@ int sqlrs_filter_push_async(sqlrs_filter_t *f, const sqlrs_batch_t *in, sqlrs_ti
     const char *off_e = hook("SQLRS_ASYNC_FAST"); // test hook, read per call: 0 = every batch through the synchronous operator
     if (!(off_e && off_e[0] == '0') && sa_filter_shape(f->expr, in, &p.pred_col, &p.rf)) {
       SaRing *r = sa_ring(ctx);
-      const int slot = sa_take_slot(r);
+      const int slot = r ? sa_take_slot(r) : -1;
       if (slot >= 0) {
         if (sa_stage_input(in, r->in_area(slot), &p.lay, 0, nullptr)) {
           p.in = r->in_area(slot);
