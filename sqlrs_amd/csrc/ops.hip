@@ -184,12 +184,16 @@ int sqlrs_filter_push(sqlrs_filter_t *f, const sqlrs_batch_t *in, int out_mem, s
 
 namespace sq {
 // ---- one small HOST batch, one launch, no copy call (small_async.hpp) ------------------------------------------------
-// mask = `column OP constant` (RowFilter: the stand-alone filter's comparison, NULL -> dropped, filter.rs:16-24); every
-// column of the batch compacted through the same positions; validity bitmaps re-packed in output order.
+// mask = `column OP constant [AND column OP constant ...]` (up to four terms; RowFilter: the stand-alone filter's comparison;
+// a row is kept when EVERY term is true — a NULL term is not, filter.rs:16-24 over Kleene AND); every column of the batch
+// compacted through the same positions; validity bitmaps re-packed in output order.
+constexpr int SA_TERMS = 4;
 struct SaFilterParams {
   SaLayout lay;
-  int pred_col;
-  RowFilter rf; // (rf.col unused: the predicate column is read from the slot)
+  int nterms;
+  int pred_col[SA_TERMS];
+  int pred_is32[SA_TERMS]; // an int32 column: compared through its sign-extended value
+  RowFilter rf[SA_TERMS];  // (rf.col unused: the predicate columns are read from the slot)
   const uint8_t *in;
   uint8_t *out;
   unsigned long long seq;
@@ -199,12 +203,20 @@ __global__ __launch_bounds__(1024) void sa_filter_kernel(SaGroup<SaFilterParams>
   __shared__ uint32_t s_w[17], s_nulls[SA_MAX_COLS];
   __shared__ uint8_t s_v[SA_MAX_ROWS];
   if (threadIdx.x < SA_MAX_COLS) s_nulls[threadIdx.x] = 0;
-  const SaCol &pc = p.lay.c[p.pred_col];
-  const uint64_t *pv = (const uint64_t *)(p.in + pc.in_off);
-  const uint8_t *pvalid = pc.in_voff != SA_NONE ? p.in + pc.in_voff : nullptr;
   uint32_t pos[4], total;
   const uint32_t bits = sa_positions(
-      p.lay.rows, [&](uint32_t r, int) { return (!pvalid || ((pvalid[r >> 3] >> (r & 7)) & 1)) && row_passes(p.rf, pv[r]); }, pos, s_w, &total);
+      p.lay.rows,
+      [&](uint32_t r, int) {
+        bool keep = true;
+        for (int q = 0; q < p.nterms; q++) { // (uniform trip count)
+          const SaCol &pc = p.lay.c[p.pred_col[q]];
+          const uint8_t *pvalid = pc.in_voff != SA_NONE ? p.in + pc.in_voff : nullptr;
+          const uint64_t v = p.pred_is32[q] ? (uint64_t)(int64_t)((const int32_t *)(p.in + pc.in_off))[r] : ((const uint64_t *)(p.in + pc.in_off))[r];
+          keep = keep && (!pvalid || ((pvalid[r >> 3] >> (r & 7)) & 1)) && row_passes(p.rf[q], v);
+        }
+        return keep;
+      },
+      pos, s_w, &total);
   for (int c = 0; c < p.lay.ncols; c++) { // (uniform loop: the layout is a kernel argument)
     const SaCol &col = p.lay.c[c];
     const uint8_t *valid = col.in_voff != SA_NONE ? p.in + col.in_voff : nullptr;
@@ -226,16 +238,17 @@ static void sa_filter_launch(SaRing *r, Ctx *ctx) {
   sa_filter_kernel<<<dim3((unsigned)r->pend_n), dim3(1024), 0, r->stream_of(r->pend_first_slot)>>>(g); // (reads nothing the ctx stream produces)
   SQ_HIP(hipGetLastError());
 }
-// the shape the fast path evaluates: INPUT_REF CONSTANT CMP over an int64 / float64 column, constant of the column's type
-static bool sa_filter_shape(const Expr &e, const sqlrs_batch_t *in, int *pred_col, RowFilter *rf) {
-  if (e.nodes.size() != 3) return false;
-  const sqlrs_expr_node_t &a = e.nodes[0], &b = e.nodes[1], &o = e.nodes[2];
+// the shapes the fast path evaluates: t1 [t2 AND [t3 AND [t4 AND]]] in postfix, every term INPUT_REF CONSTANT CMP over an
+// int32 / int64 / float64 column with a constant of the column's type
+static bool sa_filter_term(const sqlrs_expr_node_t *nd, const sqlrs_batch_t *in, int *pred_col, int *is32, RowFilter *rf) {
+  const sqlrs_expr_node_t &a = nd[0], &b = nd[1], &o = nd[2];
   if (a.op != SQLRS_EXPR_INPUT_REF || b.op != SQLRS_EXPR_CONSTANT || b.is_null) return false;
   if (o.op < SQLRS_EXPR_GT || o.op > SQLRS_EXPR_NOTEQ) return false;
-  if (!in || a.index < 0 || a.index >= in->num_columns) return false;
+  if (a.index < 0 || a.index >= in->num_columns) return false;
   const int32_t dt = in->columns[a.index].dtype;
-  if (dt != b.dtype || (dt != SQLRS_INT64 && dt != SQLRS_FLOAT64)) return false;
+  if (dt != b.dtype || (dt != SQLRS_INT64 && dt != SQLRS_FLOAT64 && dt != SQLRS_INT32)) return false;
   *pred_col = a.index;
+  *is32 = dt == SQLRS_INT32;
   rf->col = nullptr;
   rf->is_f64 = dt == SQLRS_FLOAT64;
   if (rf->is_f64) {
@@ -243,9 +256,22 @@ static bool sa_filter_shape(const Expr &e, const sqlrs_batch_t *in, int *pred_co
     std::memcpy(&bits, &b.f, 8);
     rf->kord = (bits >> 63) ? ~bits : (bits | (1ull << 63)); // f64_to_ordered (hashagg_op.hip, fusable_row_filter)
   } else
-    rf->kord = (uint64_t)b.i ^ (1ull << 63);
+    rf->kord = (uint64_t)(dt == SQLRS_INT32 ? (int64_t)(int32_t)b.i : b.i) ^ (1ull << 63);
   static const uint32_t masks[6] = {4, 1, 6, 3, 2, 5}; // GT, LT, GTEQ, LTEQ, EQ, NOTEQ: keep if {<, ==, >}
   rf->keep_mask = masks[o.op - SQLRS_EXPR_GT];
+  return true;
+}
+static bool sa_filter_shape(const Expr &e, const sqlrs_batch_t *in, SaFilterParams *p) {
+  const size_t nn = e.nodes.size();
+  if (!in || nn < 3 || (nn - 3) % 4 != 0) return false;
+  const size_t nterms = 1 + (nn - 3) / 4;
+  if (nterms > (size_t)SA_TERMS) return false;
+  for (size_t k = 0; k < nterms; k++) {
+    const size_t at = k == 0 ? 0 : 3 + (k - 1) * 4;
+    if (k > 0 && e.nodes[at + 3].op != SQLRS_EXPR_AND) return false;
+    if (!sa_filter_term(&e.nodes[at], in, &p->pred_col[k], &p->pred_is32[k], &p->rf[k])) return false;
+  }
+  p->nterms = (int)nterms;
   return true;
 }
 } // namespace sq
@@ -264,7 +290,7 @@ int sqlrs_filter_push_async(sqlrs_filter_t *f, const sqlrs_batch_t *in, sqlrs_ti
     t->ctx = ctx;
     SaFilterParams p;
     const char *off_e = hook("SQLRS_ASYNC_FAST"); // test hook, read per call: 0 = every batch through the synchronous operator
-    if (!(off_e && off_e[0] == '0') && sa_filter_shape(f->expr, in, &p.pred_col, &p.rf)) {
+    if (!(off_e && off_e[0] == '0') && sa_filter_shape(f->expr, in, &p)) {
       SaRing *r = sa_ring(ctx);
       const int slot = r ? sa_take_slot(r) : -1;
       if (slot >= 0) {

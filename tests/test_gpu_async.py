@@ -35,11 +35,11 @@ def batches(rng, n, sizes, nulls, with_str=False):
     return out
 
 
-@pytest.mark.parametrize("pred", ["i64_gt", "f64_le", "i64_ne", "pred_nulls", "compound", "i32"])
+@pytest.mark.parametrize("pred", ["i64_gt", "f64_le", "i64_ne", "pred_nulls", "compound", "i32", "three_terms", "or", "col_col"])
 @pytest.mark.parametrize("depth", [1, 4, 40])
 def test_filter_push_async_yields_the_batches_of_push(hip, oracle, monkeypatch, pred, depth):
-    """fast path (column OP constant over int64 / float64, NULLs in the predicate column dropped, validity re-packed), the
-    slow path inside the same stream (compound predicate, int32 predicate, a Utf8 column, > 4096 rows, an empty batch) and
+    """fast path (conjunctions of up to four `column OP constant` terms over int32 / int64 / float64, a row with a NULL term
+    dropped, validity re-packed), the slow path inside the same stream (OR, column-to-column, a Utf8 column, > 4096 rows) and
     more tickets than ring slots (depth 40): always the batches of sqlrs_filter_push and of the oracle"""
     rng = np.random.default_rng(5 + depth)
     nulls = 0.2 if pred == "pred_nulls" else 0.1
@@ -48,7 +48,10 @@ def test_filter_push_async_yields_the_batches_of_push(hip, oracle, monkeypatch, 
     e = {"i64_gt": InputRef(0) > Constant(3, abi.INT64), "f64_le": InputRef(1) <= Constant(0.37, abi.FLOAT64),
          "i64_ne": InputRef(0).ne(Constant(-7, abi.INT64)), "pred_nulls": InputRef(1) > Constant(0.5, abi.FLOAT64),
          "compound": (InputRef(0) > Constant(3, abi.INT64)) & (InputRef(1) < Constant(0.9, abi.FLOAT64)),
-         "i32": InputRef(2) > Constant(0, abi.INT32)}[pred]
+         "i32": InputRef(2) > Constant(0, abi.INT32),
+         "three_terms": ((InputRef(0) >= Constant(-50, abi.INT64)) & (InputRef(1) < Constant(0.8, abi.FLOAT64))) & InputRef(2).ne(Constant(1, abi.INT32)),
+         "or": (InputRef(0) > Constant(90, abi.INT64)) | (InputRef(1) < Constant(0.1, abi.FLOAT64)),  # (not a conjunction: the synchronous operator)
+         "col_col": InputRef(0) > InputRef(0)}[pred]
     hip.profile(True)
     got = list(FilterExecutor(hip, e, bs, depth=depth).execute())
     hip.profile_read()
