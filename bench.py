@@ -1374,6 +1374,12 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
     torch.cuda.synchronize()
     join_shape("C3_join_two_column_keys", [bx, by_], [px, py], 2, nP, lambda li: bx[li] + 1000 * by_[li], lambda ri: px[ri] + 1000 * py[ri])
     del pk, pk4, bx, by_, px, py
+    # (every BASELINE config starts from an EMPTY pool, like a fresh process: what the earlier legs left cached decides where the
+    #  next leg's regions land physically, and the scatter kernels' time follows that — profiles/r06e_placement.txt)
+    if os.environ.get("SQLRS_BENCH_TRIM_LEGS", "1") != "0":
+        be.synchronize()
+        be.fn("ctx_pool_trim")(be.ctx)
+        torch.cuda.empty_cache()
     # ---- C4: 2e8 rows, 1e6 int64 groups, COUNT(val), SUM(val) f64
     n, G = 200_000_000, 1_000_000
     key = datagen.fill_chunks(torch.empty(n, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xA1, i, G))

@@ -155,6 +155,7 @@ struct Ctx {
   int64_t lb_timeouts = 0; // look-back launches that timed out and were redone with tickets
   int64_t order_lb_fallbacks = 0; // Order split passes whose chained look-back ran out of spins (redone in the counting form)
   int lb_backoff = 0; // resident blocks per CU of the persistent kernels, per kernel
+  int64_t async_fast_batches = 0;   // batches the single-batch async path took with its one-launch kernels (profile: "async_fast_batches")
   std::shared_ptr<void> small_ring; // the pinned ring of the single-batch async path (small_async.hpp), created on first use
   void sync() { SQ_HIP(hipStreamSynchronize(stream)); }
   // copies `bytes` from device to the pinned area and synchronises; returns host pointer

@@ -1201,6 +1201,14 @@ int sqlrs_ctx_profile_read(sqlrs_ctx_t *ctx, int cap, const char **names, double
     }
     n++;
   }
+  if (ctx->async_fast_batches) { // (a count: batches of the async path that took its one-launch kernels)
+    if (n < cap) {
+      names[n] = "async_fast_batches";
+      total_ms[n] = 0;
+      launches[n] = ctx->async_fast_batches;
+    }
+    n++;
+  }
   if (ctx->order_lb_fallbacks) { // (advisor r05: the process-wide switch-off of the Order look-back is visible, tests/conftest.py checks it)
     if (n < cap) {
       names[n] = "order_lookback_fallbacks";

@@ -93,6 +93,7 @@ template <class P> inline void sa_enqueue(Ctx *ctx, SaRing *r, const void *owner
   r->pend_owner = owner;
   r->pend_launch = launch;
   r->pend_n++;
+  ctx->async_fast_batches++;
   if (r->pend_n >= r->group) sa_flush(ctx);
 }
 

@@ -13,6 +13,10 @@ from test_gpu_parity import join_schema
 pytestmark = pytest.mark.gpu
 
 
+def fast_batches(be):
+    return be.profile_read().get("async_fast_batches", (0, 0))[1]
+
+
 def same_batches(got, exp):
     assert [g.num_rows for g in got] == [e.num_rows for e in exp]
     for g, e in zip(got, exp):
@@ -52,10 +56,18 @@ def test_filter_push_async_yields_the_batches_of_push(hip, oracle, monkeypatch, 
          "three_terms": ((InputRef(0) >= Constant(-50, abi.INT64)) & (InputRef(1) < Constant(0.8, abi.FLOAT64))) & InputRef(2).ne(Constant(1, abi.INT32)),
          "or": (InputRef(0) > Constant(90, abi.INT64)) | (InputRef(1) < Constant(0.1, abi.FLOAT64)),  # (not a conjunction: the synchronous operator)
          "col_col": InputRef(0) > InputRef(0)}[pred]
-    hip.profile(True)
+    before = fast_batches(hip)
     got = list(FilterExecutor(hip, e, bs, depth=depth).execute())
-    hip.profile_read()
-    hip.profile(False)
+    took = fast_batches(hip) - before
+    # every <= 4096-row batch without the Utf8 column takes the one-launch kernel, unless the predicate is not a conjunction of
+    # column-OP-constant terms (then none does); with more tickets than ring slots some run the synchronous operator
+    eligible = sum(1 for b in bs if b.num_rows <= 4096 and b.num_columns == 3)
+    if pred in ("or", "col_col"):
+        assert took == 0
+    elif depth < 32:
+        assert took == eligible, (took, eligible)
+    else:
+        assert 0 < took <= eligible
     same_batches(got, list(FilterExecutor(hip, e, bs).execute()))
     same_batches(got, list(FilterExecutor(oracle, e, bs).execute()))
     monkeypatch.setenv("SQLRS_ASYNC_FAST", "0")  # every batch through the synchronous operator inside push_async
@@ -83,7 +95,9 @@ def test_hash_join_probe_push_async_yields_the_batches_of_probe_push(hip, oracle
     rbs.insert(7, pa.RecordBatch.from_arrays([pa.array(rng.random(1024)), pa.array(pk, mask=rng.random(1024) < 0.1)], names=["v", "k"]))
     cond = JoinCondition([(InputRef(0), InputRef(1))])
     sch = join_schema(lb, rbs[0])
+    before = fast_batches(hip)
     got = list(HashJoinExecutor(hip, [lb], rbs, "inner", cond, sch, 3, depth=depth).execute())
+    assert fast_batches(hip) - before == sum(1 for b in rbs if b.num_rows <= 4096 and b.column(1).null_count == 0)
     same_batches(got, list(HashJoinExecutor(hip, [lb], rbs, "inner", cond, sch, 3).execute()))
     same_batches(got, list(HashJoinExecutor(oracle, [lb], rbs, "inner", cond, sch, 3).execute()))
 
@@ -100,7 +114,9 @@ def test_async_shapes_that_only_the_synchronous_operator_takes(hip, oracle):
                           ("left", JoinCondition([(InputRef(0), InputRef(0))]), [lb.slice(0, 500)]),
                           ("inner", JoinCondition([(InputRef(0), InputRef(0))], InputRef(1) > InputRef(3)), [lb.slice(0, 500)]),
                           ("inner", JoinCondition([(InputRef(0), InputRef(0))]), [lb.slice(0, 0)])):
+        before = fast_batches(hip)
         got = list(HashJoinExecutor(hip, lbs, rbs, jt, cond, sch, 2, depth=3).execute())
+        assert fast_batches(hip) == before or lbs[0].num_rows == 0  # (a build side of one 0-row batch is unique: its probes may take the kernel)
         same_batches(got, list(HashJoinExecutor(oracle, lbs, rbs, jt, cond, sch, 2).execute()))
 
 
@@ -120,3 +136,44 @@ def test_async_group_sizes(oracle, monkeypatch, group):
             same_batches(list(FilterExecutor(be, e, bs, depth=depth).execute()), exp)
     finally:
         be.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_async_filter_and_probe(hip, oracle, seed):
+    """random schemas (1-9 fixed-width columns, NULL rates 0 / 5 / 50 / 100 %), batch sizes 0-4096, conjunctions of 1-4 random terms;
+    random Inner joins over unique build keys (dense or sparse, int32 / int64) with NULL-bearing payload columns on both sides —
+    the async stream equals the oracle's, batch for batch"""
+    rng = np.random.default_rng(1000 + seed)
+    ncols = int(rng.integers(1, 10))
+    kinds = [str(rng.choice(["i64", "f64", "i32"])) for _ in range(ncols)]
+    nullp = [float(rng.choice([0.0, 0.05, 0.5, 1.0], p=[0.5, 0.3, 0.15, 0.05])) for _ in range(ncols)]
+
+    def col(kind, rows, p):
+        vals = {"i64": lambda: rng.integers(-20, 20, rows), "f64": lambda: np.round(rng.random(rows), 2),
+                "i32": lambda: rng.integers(-20, 20, rows).astype(np.int32)}[kind]()
+        return pa.array(vals, mask=(rng.random(rows) < p) if p else None)
+    sizes = [int(x) for x in rng.choice([0, 1, 7, 64, 100, 1000, 1024, 2047, 4096], size=14)]
+    bs = [pa.RecordBatch.from_arrays([col(k, n, p) for k, p in zip(kinds, nullp)], names=[f"c{i}" for i in range(ncols)]) for n in sizes]
+    e = None
+    for _ in range(int(rng.integers(1, 5))):
+        c = int(rng.integers(0, ncols))
+        const = {"i64": Constant(int(rng.integers(-10, 10)), abi.INT64), "f64": Constant(float(np.round(rng.random(), 2)), abi.FLOAT64),
+                 "i32": Constant(int(rng.integers(-10, 10)), abi.INT32)}[kinds[c]]
+        op = str(rng.choice([">", "<", ">=", "<=", "=", "!="]))
+        t = {">": lambda a, b: a > b, "<": lambda a, b: a < b, ">=": lambda a, b: a >= b, "<=": lambda a, b: a <= b,
+             "=": lambda a, b: a.eq(b), "!=": lambda a, b: a.ne(b)}[op](InputRef(c), const)
+        e = t if e is None else (e & t)
+    same_batches(list(FilterExecutor(hip, e, bs, depth=int(rng.integers(1, 7))).execute()), list(FilterExecutor(oracle, e, bs).execute()))
+    # ---- join
+    nb = int(rng.choice([50, 3000, 40000]))
+    kk = str(rng.choice(["i64", "i32"]))
+    mul = int(rng.choice([1, 7919]))
+    raw = rng.permutation(3 * nb)[:nb] * mul
+    kconv = (lambda x: x.astype(np.int64)) if kk == "i64" else (lambda x: x.astype(np.int32))
+    lb = pa.RecordBatch.from_arrays([col("f64", nb, 0.2), pa.array(kconv(raw)), col("i32", nb, 0.1)], names=["x", "k", "y"])
+    rbs = [pa.RecordBatch.from_arrays([pa.array(kconv(rng.integers(0, 3 * nb, n) * mul)), col("i64", n, 0.3), col("f64", n, 0.0)], names=["k", "v", "w"])
+           for n in sizes]
+    cond = JoinCondition([(InputRef(1), InputRef(0))])
+    sch = join_schema(lb, rbs[0])
+    same_batches(list(HashJoinExecutor(hip, [lb], rbs, "inner", cond, sch, 3, depth=int(rng.integers(1, 7))).execute()),
+                 list(HashJoinExecutor(oracle, [lb], rbs, "inner", cond, sch, 3).execute()))
