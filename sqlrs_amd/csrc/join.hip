@@ -350,6 +350,9 @@ constexpr int JD_BLOCK = (JD_WAVES + 1) * 64;
 // for the attempt (0.7 of the compacting kernel's time) once.
 constexpr int JA_ILP = 16; // independent table loads in flight per lane
 // rows `every` apart (a sample of the batch): a probe with many misses is recognised before the attempt starts
+// (Round 6 measured the sample INSIDE the all-hit kernel — its first 64 workgroups test the rows, every wave looks at the flag
+//  behind its first trip: one dispatch less, but an attempt that has to be given up then costs every wave a trip, C3 half-hit
+//  build + probe 0.65 -> 0.68 ms for ~5 us on the all-hit side; the separate launch stays.)
 __global__ void join_probe_dense_sample_kernel(const uint64_t *__restrict__ keys, int64_t n, int64_t every, DenseTable dt,
                                                unsigned int *__restrict__ miss) {
   if (dt.st && !dense_table_from_device(dt)) {
