@@ -63,45 +63,65 @@ int sa_take_slot(SaRing *r) {
 
 static uint32_t sa_width(int32_t dtype) { return dtype == SQLRS_INT32 ? 4u : (dtype == SQLRS_INT64 || dtype == SQLRS_FLOAT64) ? 8u : 0u; }
 
-bool sa_stage_input(const sqlrs_batch_t *in, uint8_t *area, SaLayout *lay, int first_out_col, const int32_t *front_dtypes) {
+bool sa_stage_input(const sqlrs_batch_t *in, uint8_t *area, SaLayout *lay, int first_out_col, const int32_t *front_dtypes, bool allow_utf8) {
   if (!in || in->num_rows < 0 || in->num_rows > (int64_t)SA_MAX_ROWS || in->num_columns <= 0 ||
       in->num_columns + first_out_col > SA_MAX_COLS)
     return false;
   const uint32_t rows = (uint32_t)in->num_rows, vbytes = (rows + 7) / 8;
   for (int c = 0; c < in->num_columns; c++) {
     const sqlrs_column_t &col = in->columns[c];
-    if (col.mem != SQLRS_MEM_HOST || !sa_width(col.dtype) || col.length != in->num_rows || (rows && !col.values)) return false;
+    if (col.mem != SQLRS_MEM_HOST || col.length != in->num_rows) return false;
+    if (col.dtype == SQLRS_UTF8) {
+      if (!allow_utf8 || !col.offsets || col.offsets[rows] < col.offsets[0] || (col.offsets[rows] > col.offsets[0] && !col.values)) return false;
+    } else if (!sa_width(col.dtype) || (rows && !col.values))
+      return false;
   }
   auto up64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
-  // output: header | per column values (SA_MAX rows are never needed: `rows` bound both sides) + validity
+  // output: header | per column values (`rows` bound both sides) + validity (+ the bytes of a Utf8 column)
   size_t in_at = 0, out_at = up64(sizeof(SaHeader));
   lay->ncols = first_out_col + in->num_columns;
   lay->rows = rows;
   for (int c = 0; c < lay->ncols; c++) {
     SaCol &d = lay->c[c];
     d.dtype = c < first_out_col ? front_dtypes[c] : in->columns[c - first_out_col].dtype;
-    d.width = sa_width(d.dtype);
+    const bool utf8 = d.dtype == SQLRS_UTF8;
+    d.width = utf8 ? 4u : sa_width(d.dtype);
     if (!d.width) return false;
-    d.in_off = d.in_voff = SA_NONE;
+    d.in_off = d.in_voff = d.in_data = d.out_data = SA_NONE;
+    d.data_base = 0;
+    const size_t nval = utf8 ? (size_t)rows + 1 : rows;
     d.out_off = (uint32_t)out_at;
-    out_at = up64(out_at + (size_t)d.width * rows);
+    out_at = up64(out_at + (size_t)d.width * nval);
     d.out_voff = (uint32_t)out_at;
     out_at = up64(out_at + vbytes);
     if (c >= first_out_col) {
-      d.in_off = (uint32_t)in_at;
-      in_at = up64(in_at + (size_t)d.width * rows);
       const sqlrs_column_t &col = in->columns[c - first_out_col];
+      d.in_off = (uint32_t)in_at;
+      in_at = up64(in_at + (size_t)d.width * nval);
       if (col.validity && col.null_count != 0) {
         d.in_voff = (uint32_t)in_at;
         in_at = up64(in_at + vbytes + 8); // (+ 8: the kernel may read the bitmap in whole words)
       }
+      if (utf8) {
+        const size_t nbytes = (size_t)(col.offsets[rows] - col.offsets[0]);
+        d.data_base = (uint32_t)col.offsets[0];
+        d.in_data = (uint32_t)in_at;
+        in_at = up64(in_at + nbytes);
+        d.out_data = (uint32_t)out_at;
+        out_at = up64(out_at + nbytes);
+      }
     }
+    if (in_at > SA_AREA || out_at > SA_AREA) return false;
   }
-  if (in_at > SA_AREA || out_at > SA_AREA) return false;
   for (int c = first_out_col; c < lay->ncols; c++) { // the only copies of the fast path: 4-32 KB per column, host to pinned host
     const sqlrs_column_t &col = in->columns[c - first_out_col];
     const SaCol &d = lay->c[c];
-    if (rows) std::memcpy(area + d.in_off, col.values, (size_t)d.width * rows);
+    if (d.dtype == SQLRS_UTF8) {
+      std::memcpy(area + d.in_off, col.offsets, 4 * ((size_t)rows + 1));
+      const size_t nbytes = (size_t)(col.offsets[rows] - col.offsets[0]);
+      if (nbytes) std::memcpy(area + d.in_data, (const uint8_t *)col.values + col.offsets[0], nbytes);
+    } else if (rows)
+      std::memcpy(area + d.in_off, col.values, (size_t)d.width * rows);
     if (d.in_voff != SA_NONE) std::memcpy(area + d.in_voff, col.validity, vbytes);
   }
   return true;
@@ -148,15 +168,18 @@ int sqlrs_batch_wait(sqlrs_ticket_t *ticket, sqlrs_batch_t **out) {
     const uint8_t *oa = r->out_area(ticket->slot);
     const void *vals[SA_MAX_COLS];
     const uint8_t *valid[SA_MAX_COLS];
+    const int32_t *offs[SA_MAX_COLS];
     int64_t nulls[SA_MAX_COLS];
     int32_t dts[SA_MAX_COLS];
     for (int c = 0; c < lay.ncols; c++) {
-      vals[c] = oa + lay.c[c].out_off;
+      const bool utf8 = lay.c[c].dtype == SQLRS_UTF8;
+      vals[c] = oa + (utf8 ? lay.c[c].out_data : lay.c[c].out_off);
+      offs[c] = utf8 ? (const int32_t *)(oa + lay.c[c].out_off) : nullptr;
       valid[c] = oa + lay.c[c].out_voff;
       nulls[c] = h->nulls[c];
       dts[c] = lay.c[c].dtype;
     }
-    *out = emit_host_copy(ctx, lay.ncols, dts, (int64_t)h->count, vals, valid, nulls);
+    *out = emit_host_copy(ctx, lay.ncols, dts, (int64_t)h->count, vals, valid, nulls, offs);
   });
   if (ticket->slot >= 0 && ctx->small_ring) ((SaRing *)ctx->small_ring.get())->busy[ticket->slot] = false;
   if (ticket->done) sqlrs_batch_release(ticket->done); // (an error above: nothing leaks)

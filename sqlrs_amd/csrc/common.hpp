@@ -236,8 +236,9 @@ DCol upload_column(Ctx *ctx, const sqlrs_column_t &c, bool force_copy);
 sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem);
 // a HOST batch of `rows` rows copied out of host memory (values[c]: rows x width bytes; validity[c]: bitmap or null;
 // fixed-width dtypes only) — what the single-batch async path hands out (small_async.hpp)
+// (a Utf8 column: offsets[c] = its rows + 1 int32 offsets starting at 0, values[c] = its bytes)
 sqlrs_batch_t *emit_host_copy(Ctx *ctx, int ncols, const int32_t *dtypes, int64_t rows, const void *const *values,
-                              const uint8_t *const *validity, const int64_t *null_counts);
+                              const uint8_t *const *validity, const int64_t *null_counts, const int32_t *const *offsets = nullptr);
 sqlrs_batch_t *emit_host_columns(Ctx *ctx, std::vector<sqlrs_column_t> &&cols, int64_t rows); // takes over malloc'd blocks
 // *_push_many (small HOST batches handled together): every column fixed width? / rows [cut[i], cut[i + 1]) of a device batch
 // as n library-owned HOST batches through one pinned copy per column (ctx.hip)

@@ -479,14 +479,15 @@ sqlrs_batch_t *emit_batch(Ctx *ctx, DBatch &&b, int out_mem) {
 }
 
 sqlrs_batch_t *emit_host_copy(Ctx *ctx, int ncols, const int32_t *dtypes, int64_t rows, const void *const *values,
-                              const uint8_t *const *validity, const int64_t *null_counts) {
+                              const uint8_t *const *validity, const int64_t *null_counts, const int32_t *const *offsets) {
   auto o = std::unique_ptr<OwnedBatch>(new OwnedBatch());
   o->ctx = ctx;
   o->out_mem = SQLRS_MEM_HOST;
   o->descs.resize((size_t)ncols);
   for (int c = 0; c < ncols; c++) {
-    const size_t w = width_of(dtypes[c]);
-    if (!w) fail(SQLRS_ERR_INTERNAL, "emit_host_copy: fixed-width columns only");
+    const bool utf8 = dtypes[c] == SQLRS_UTF8 && offsets && offsets[c];
+    const size_t w = utf8 ? 1 : width_of(dtypes[c]);
+    if (!w) fail(SQLRS_ERR_INTERNAL, "emit_host_copy: fixed-width and Utf8 columns only");
     sqlrs_column_t &d = o->descs[(size_t)c];
     d.dtype = dtypes[c];
     d.mem = SQLRS_MEM_HOST;
@@ -494,11 +495,19 @@ sqlrs_batch_t *emit_host_copy(Ctx *ctx, int ncols, const int32_t *dtypes, int64_
     d.offsets = nullptr;
     d.validity = nullptr;
     d.null_count = 0;
-    void *v = std::malloc(w * (size_t)rows + 64);
+    const size_t nbytes = utf8 ? (size_t)offsets[c][rows] : w * (size_t)rows;
+    void *v = std::malloc(nbytes + 64);
     if (!v) fail(SQLRS_ERR_INTERNAL, "host allocation failed");
     o->host_blocks.push_back(v);
-    if (rows) std::memcpy(v, values[c], w * (size_t)rows);
+    if (nbytes) std::memcpy(v, values[c], nbytes);
     d.values = v;
+    if (utf8) {
+      int32_t *po = (int32_t *)std::malloc(4 * ((size_t)rows + 1) + 64);
+      if (!po) fail(SQLRS_ERR_INTERNAL, "host allocation failed");
+      o->host_blocks.push_back(po);
+      std::memcpy(po, offsets[c], 4 * ((size_t)rows + 1));
+      d.offsets = po;
+    }
     if (validity && validity[c] && null_counts[c] > 0) {
       const size_t nb = (size_t)(rows + 7) / 8;
       uint8_t *b = (uint8_t *)std::malloc(nb + 64);

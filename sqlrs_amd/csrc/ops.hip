@@ -202,6 +202,7 @@ __global__ __launch_bounds__(1024) void sa_filter_kernel(SaGroup<SaFilterParams>
   const SaFilterParams &p = grp.p[blockIdx.x]; // (one workgroup per batch of the group)
   __shared__ uint32_t s_w[17], s_nulls[SA_MAX_COLS];
   __shared__ uint8_t s_v[SA_MAX_ROWS];
+  __shared__ uint32_t s_len[SA_MAX_ROWS + 4]; // Utf8: lengths of the kept rows in output order, then their exclusive prefix
   if (threadIdx.x < SA_MAX_COLS) s_nulls[threadIdx.x] = 0;
   uint32_t pos[4], total;
   const uint32_t bits = sa_positions(
@@ -220,6 +221,54 @@ __global__ __launch_bounds__(1024) void sa_filter_kernel(SaGroup<SaFilterParams>
   for (int c = 0; c < p.lay.ncols; c++) { // (uniform loop: the layout is a kernel argument)
     const SaCol &col = p.lay.c[c];
     const uint8_t *valid = col.in_voff != SA_NONE ? p.in + col.in_voff : nullptr;
+    if (col.dtype == SQLRS_UTF8) { // lengths -> exclusive prefix (the output offsets) -> the bytes, row by row
+      const int32_t *ioff = (const int32_t *)(p.in + col.in_off);
+      int32_t *ooff = (int32_t *)(p.out + col.out_off);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (!((bits >> t) & 1)) continue;
+        const uint32_t r = (uint32_t)t * 1024u + threadIdx.x;
+        s_len[pos[t]] = (uint32_t)(ioff[r + 1] - ioff[r]);
+        if (valid) s_v[pos[t]] = (valid[r >> 3] >> (r & 7)) & 1;
+      }
+      __syncthreads();
+      { // thread i owns entries 4 i .. 4 i + 3 of the (<= 4096) lengths
+        uint32_t a[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t i = threadIdx.x * 4 + q;
+          a[q] = i < total ? s_len[i] : 0u;
+          sum += a[q];
+        }
+        const uint32_t inc = wave_iscan_u32(sum);
+        if (lane_id() == 63) s_w[wave_id()] = inc;
+        __syncthreads();
+        uint32_t base = inc - sum;
+        for (int q = 0; q < wave_id(); q++) base += s_w[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t i = threadIdx.x * 4 + q;
+          if (i <= total) { // (entry `total` = the end of the last string)
+            s_len[i] = base;
+            ooff[i] = (int32_t)base;
+          }
+          base += a[q];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (!((bits >> t) & 1)) continue;
+        const uint32_t r = (uint32_t)t * 1024u + threadIdx.x;
+        const uint8_t *src = p.in + col.in_data + ((uint32_t)ioff[r] - col.data_base);
+        uint8_t *dst = p.out + col.out_data + s_len[pos[t]];
+        const uint32_t len = (uint32_t)(ioff[r + 1] - ioff[r]);
+        for (uint32_t b = 0; b < len; b++) dst[b] = src[b];
+      }
+      if (valid) sa_pack_validity(s_v, total, p.out + col.out_voff, &s_nulls[c]);
+      else __syncthreads(); // (s_len is reused by the next Utf8 column)
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       if (!((bits >> t) & 1)) continue;
@@ -294,7 +343,7 @@ int sqlrs_filter_push_async(sqlrs_filter_t *f, const sqlrs_batch_t *in, sqlrs_ti
       SaRing *r = sa_ring(ctx);
       const int slot = r ? sa_take_slot(r) : -1;
       if (slot >= 0) {
-        if (sa_stage_input(in, r->in_area(slot), &p.lay, 0, nullptr)) {
+        if (sa_stage_input(in, r->in_area(slot), &p.lay, 0, nullptr, true)) { // (Utf8 payload columns travel too)
           p.in = r->in_area(slot);
           p.out = r->out_area(slot);
           p.seq = ++r->seq;

@@ -11,7 +11,8 @@
 //     writes the output columns + validity bitmaps + a header {sequence number, rows, NULL counts} back into the slot;
 //   * `wait` polls the header's sequence number (system-scope release store behind `__threadfence_system`), falling
 //     back to a stream synchronisation when it does not show up, and copies the rows into an ordinary HOST batch.
-// Anything the fast path does not take — Utf8 / Boolean columns, other predicates, more than 4096 rows, DEVICE input,
+// Anything the fast path does not take — Boolean columns, predicates that are not conjunctions of column-OP-constant terms, Utf8
+// columns around a join, more than 4096 rows, DEVICE input,
 // duplicate build keys, join filters, outer joins — runs the synchronous operator inside push_async and parks the finished
 // batch in the ticket: same results, same one-output-per-input rule, no speed-up.
 #pragma once
@@ -34,8 +35,10 @@ struct SaHeader { // at the start of a slot's output area
 struct SaCol {
   uint32_t in_off, in_voff;   // values / validity bitmap in the input area (in_voff = SA_NONE: no NULLs); build columns: unused
   uint32_t out_off, out_voff; // values / validity bitmap in the output area (always reserved)
-  uint32_t width;             // 4 or 8
+  uint32_t width;             // 4 or 8; Utf8: 4 (in_off / out_off are the int32 offsets, rows + 1 of them)
   int32_t dtype;
+  // Utf8 (Filter only): the bytes [offsets[0], offsets[rows]) of the input column sit at in_data; the kept rows' bytes go to out_data
+  uint32_t in_data, out_data, data_base; // data_base = offsets[0] of the input column
 };
 struct SaLayout {
   int ncols = 0;
@@ -97,10 +100,11 @@ template <class P> inline void sa_enqueue(Ctx *ctx, SaRing *r, const void *owner
   if (r->pend_n >= r->group) sa_flush(ctx);
 }
 
-// Lays `in` (HOST columns of int32 / int64 / float64, <= SA_MAX_ROWS rows) out in `area` and describes it in `lay`;
+// Lays `in` (HOST columns of int32 / int64 / float64 — and Utf8 when `allow_utf8` — <= SA_MAX_ROWS rows) out in `area` and describes it in `lay`;
 // `first_out_col` output columns are reserved in front of the batch's own (the join's build columns).  false = not a batch
 // for the fast path (nothing written that matters).
-bool sa_stage_input(const sqlrs_batch_t *in, uint8_t *area, SaLayout *lay, int first_out_col, const int32_t *front_dtypes);
+bool sa_stage_input(const sqlrs_batch_t *in, uint8_t *area, SaLayout *lay, int first_out_col, const int32_t *front_dtypes,
+                    bool allow_utf8 = false);
 
 } // namespace sq
 

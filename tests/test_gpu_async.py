@@ -33,7 +33,7 @@ def batches(rng, n, sizes, nulls, with_str=False):
                 pa.array(rng.integers(-5, 5, rows).astype(np.int32), mask=(rng.random(rows) < nulls) if nulls else None)]
         names = ["a", "b", "c"]
         if with_str:
-            cols.append(pa.array([str(i) for i in range(rows)]))
+            cols.append(pa.array([None if i % 7 == 3 else ("" if i % 5 == 0 else "s" * (i % 11) + str(i)) for i in range(rows)], type=pa.string()))
             names.append("s")
         out.append(pa.RecordBatch.from_arrays(cols, names=names))
     return out
@@ -43,12 +43,12 @@ def batches(rng, n, sizes, nulls, with_str=False):
 @pytest.mark.parametrize("depth", [1, 4, 40])
 def test_filter_push_async_yields_the_batches_of_push(hip, oracle, monkeypatch, pred, depth):
     """fast path (conjunctions of up to four `column OP constant` terms over int32 / int64 / float64, a row with a NULL term
-    dropped, validity re-packed), the slow path inside the same stream (OR, column-to-column, a Utf8 column, > 4096 rows) and
+    dropped, validity re-packed), Utf8 payload columns with NULL and empty strings, the slow path inside the same stream (OR, column-to-column, > 4096 rows) and
     more tickets than ring slots (depth 40): always the batches of sqlrs_filter_push and of the oracle"""
     rng = np.random.default_rng(5 + depth)
     nulls = 0.2 if pred == "pred_nulls" else 0.1
     bs = batches(rng, 0, [1024] * 20 + [0, 1, 63, 64, 65, 1023, 1025, 4096, 4097, 20000] + [1024] * 45, nulls)
-    bs += batches(rng, 0, [1024, 100], nulls, with_str=True)
+    bs += batches(rng, 0, [1024, 100, 0, 4096, 3000], nulls, with_str=True)  # (Utf8 payload columns travel through the kernel too)
     e = {"i64_gt": InputRef(0) > Constant(3, abi.INT64), "f64_le": InputRef(1) <= Constant(0.37, abi.FLOAT64),
          "i64_ne": InputRef(0).ne(Constant(-7, abi.INT64)), "pred_nulls": InputRef(1) > Constant(0.5, abi.FLOAT64),
          "compound": (InputRef(0) > Constant(3, abi.INT64)) & (InputRef(1) < Constant(0.9, abi.FLOAT64)),
@@ -59,9 +59,9 @@ def test_filter_push_async_yields_the_batches_of_push(hip, oracle, monkeypatch, 
     before = fast_batches(hip)
     got = list(FilterExecutor(hip, e, bs, depth=depth).execute())
     took = fast_batches(hip) - before
-    # every <= 4096-row batch without the Utf8 column takes the one-launch kernel, unless the predicate is not a conjunction of
+    # every <= 4096-row batch takes the one-launch kernel, unless the predicate is not a conjunction of
     # column-OP-constant terms (then none does); with more tickets than ring slots some run the synchronous operator
-    eligible = sum(1 for b in bs if b.num_rows <= 4096 and b.num_columns == 3)
+    eligible = sum(1 for b in bs if b.num_rows <= 4096)
     if pred in ("or", "col_col"):
         assert took == 0
     elif depth < 32:
@@ -145,10 +145,15 @@ def test_fuzz_async_filter_and_probe(hip, oracle, seed):
     the async stream equals the oracle's, batch for batch"""
     rng = np.random.default_rng(1000 + seed)
     ncols = int(rng.integers(1, 10))
-    kinds = [str(rng.choice(["i64", "f64", "i32"])) for _ in range(ncols)]
+    kinds = [str(rng.choice(["i64", "f64", "i32", "str"], p=[0.3, 0.3, 0.2, 0.2])) for _ in range(ncols)]
+    if all(k == "str" for k in kinds):
+        kinds[0] = "i64"
     nullp = [float(rng.choice([0.0, 0.05, 0.5, 1.0], p=[0.5, 0.3, 0.15, 0.05])) for _ in range(ncols)]
 
     def col(kind, rows, p):
+        if kind == "str":
+            m = rng.random(rows) < p
+            return pa.array([None if m[i] else "x" * int(rng.integers(0, 9)) + str(i) for i in range(rows)], type=pa.string())
         vals = {"i64": lambda: rng.integers(-20, 20, rows), "f64": lambda: np.round(rng.random(rows), 2),
                 "i32": lambda: rng.integers(-20, 20, rows).astype(np.int32)}[kind]()
         return pa.array(vals, mask=(rng.random(rows) < p) if p else None)
@@ -156,7 +161,7 @@ def test_fuzz_async_filter_and_probe(hip, oracle, seed):
     bs = [pa.RecordBatch.from_arrays([col(k, n, p) for k, p in zip(kinds, nullp)], names=[f"c{i}" for i in range(ncols)]) for n in sizes]
     e = None
     for _ in range(int(rng.integers(1, 5))):
-        c = int(rng.integers(0, ncols))
+        c = int(rng.choice([i for i, k in enumerate(kinds) if k != "str"]))
         const = {"i64": Constant(int(rng.integers(-10, 10)), abi.INT64), "f64": Constant(float(np.round(rng.random(), 2)), abi.FLOAT64),
                  "i32": Constant(int(rng.integers(-10, 10)), abi.INT32)}[kinds[c]]
         op = str(rng.choice([">", "<", ">=", "<=", "=", "!="]))
@@ -177,3 +182,23 @@ def test_fuzz_async_filter_and_probe(hip, oracle, seed):
     sch = join_schema(lb, rbs[0])
     same_batches(list(HashJoinExecutor(hip, [lb], rbs, "inner", cond, sch, 3, depth=int(rng.integers(1, 7))).execute()),
                  list(HashJoinExecutor(oracle, [lb], rbs, "inner", cond, sch, 3).execute()))
+
+
+def test_async_filter_over_the_reference_csv_table(hip, oracle):
+    """tests/csv/employee.csv of the reference (Utf8 and Int64 columns) in 3-row batches, `salary > 10000 AND id < 4` polled one
+    batch at a time through push_async: the oracle's stream, and every batch took the one-launch kernel"""
+    import os
+    import pyarrow.csv as pacsv
+    root = os.path.dirname(os.path.abspath(__file__))
+    t = pacsv.read_csv(os.path.join(root, "golden", "csv", "employee.csv"))
+    t = t.cast(pa.schema([pa.field(f.name, pa.int64() if pa.types.is_integer(f.type) else pa.string()) for f in t.schema]))
+    rb = t.combine_chunks().to_batches()[0]
+    bs = [rb.slice(i, 3) for i in range(0, rb.num_rows, 3)]
+    names = rb.schema.names
+    e = (InputRef(names.index("salary")) > Constant(10000, abi.INT64)) & (InputRef(names.index("id")) < Constant(4, abi.INT64))
+    before = fast_batches(hip)
+    got = list(FilterExecutor(hip, e, bs, depth=2).execute())
+    assert fast_batches(hip) - before == len(bs)
+    exp = list(FilterExecutor(oracle, e, bs).execute())
+    same_batches(got, exp)
+    assert sum(g.num_rows for g in got) > 0
