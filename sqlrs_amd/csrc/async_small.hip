@@ -127,6 +127,79 @@ bool sa_stage_input(const sqlrs_batch_t *in, uint8_t *area, SaLayout *lay, int f
   return true;
 }
 
+bool sa_compile(const Expr &e, const sqlrs_batch_t *in, SaProgram *out) {
+  if (!in || e.nodes.empty() || e.nodes.size() > (size_t)SA_PROG_MAX) return false;
+  int32_t st[SA_STACK_MAX];
+  int sp = 0;
+  out->n = 0;
+  auto numeric = [](int32_t d) { return d == SQLRS_INT32 || d == SQLRS_INT64 || d == SQLRS_FLOAT64; };
+  for (size_t k = 0; k < e.nodes.size(); k++) {
+    const sqlrs_expr_node_t &n = e.nodes[k];
+    SaInstr I{};
+    switch (n.op) {
+    case SQLRS_EXPR_INPUT_REF: {
+      if (n.index < 0 || n.index >= in->num_columns || sp >= SA_STACK_MAX) return false;
+      const int32_t d = in->columns[n.index].dtype;
+      if (!numeric(d)) return false; // (Boolean columns are bit-packed, Utf8 has no place on this stack)
+      I.op = SAO_COL;
+      I.dtype = (uint8_t)d;
+      I.col = (uint32_t)n.index;
+      st[sp++] = d;
+      break;
+    }
+    case SQLRS_EXPR_CONSTANT: {
+      if (sp >= SA_STACK_MAX || !(numeric(n.dtype) || n.dtype == SQLRS_BOOLEAN)) return false;
+      I.op = SAO_CONST;
+      I.dtype = (uint8_t)n.dtype;
+      I.is_null = n.is_null ? 1 : 0;
+      if (n.dtype == SQLRS_FLOAT64) std::memcpy(&I.imm, &n.f, 8);
+      else if (n.dtype == SQLRS_INT32) I.imm = (unsigned long long)(long long)(int32_t)n.i;
+      else if (n.dtype == SQLRS_BOOLEAN) I.imm = n.i ? 1ull : 0ull;
+      else I.imm = (unsigned long long)n.i;
+      st[sp++] = n.dtype;
+      break;
+    }
+    case SQLRS_EXPR_TYPE_CAST: {
+      if (sp < 1) return false;
+      const int32_t from = st[sp - 1], to = n.dtype;
+      if (from == to) continue; // (cast_col: the column as it is)
+      if (!numeric(to) || !(numeric(from) || from == SQLRS_BOOLEAN)) return false;
+      I.op = SAO_CAST;
+      I.dtype = (uint8_t)to;
+      I.from = (uint8_t)from;
+      st[sp - 1] = to;
+      break;
+    }
+    default: {
+      if (sp < 2) return false;
+      const int32_t r = st[sp - 1], l = st[sp - 2];
+      if (n.op >= SQLRS_EXPR_PLUS && n.op <= SQLRS_EXPR_DIVIDE) {
+        if (l != r || !numeric(l)) return false;
+        I.op = (uint8_t)(SAO_ADD + (n.op - SQLRS_EXPR_PLUS));
+        I.dtype = (uint8_t)l;
+        st[sp - 2] = l;
+      } else if (n.op >= SQLRS_EXPR_GT && n.op <= SQLRS_EXPR_NOTEQ) {
+        if (l != r || !(numeric(l) || l == SQLRS_BOOLEAN)) return false;
+        I.op = (uint8_t)(SAO_GT + (n.op - SQLRS_EXPR_GT));
+        I.dtype = (uint8_t)l;
+        st[sp - 2] = SQLRS_BOOLEAN;
+      } else if (n.op == SQLRS_EXPR_AND || n.op == SQLRS_EXPR_OR) {
+        if (l != SQLRS_BOOLEAN || r != SQLRS_BOOLEAN) return false;
+        I.op = n.op == SQLRS_EXPR_AND ? SAO_AND : SAO_OR;
+        I.dtype = SQLRS_BOOLEAN;
+        st[sp - 2] = SQLRS_BOOLEAN;
+      } else
+        return false;
+      sp--;
+    }
+    }
+    out->ins[out->n++] = I;
+  }
+  if (sp != 1) return false;
+  out->result_dtype = st[0];
+  return true;
+}
+
 } // namespace sq
 
 using namespace sq;
@@ -164,6 +237,7 @@ int sqlrs_batch_wait(sqlrs_ticket_t *ticket, sqlrs_batch_t **out) {
       for (int i = 0; i < SA_STREAMS; i++) SQ_HIP(hipStreamSynchronize(r->side[i]));
       if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != ticket->seq) fail(SQLRS_ERR_DEVICE, "batch_wait: the batch's kernel left no result");
     }
+    if (h->pad) fail(SQLRS_ERR_ARROW, "Divide by zero error"); // (what the synchronous evaluator raises at the push, expr.hip)
     const SaLayout &lay = ticket->lay;
     const uint8_t *oa = r->out_area(ticket->slot);
     const void *vals[SA_MAX_COLS];

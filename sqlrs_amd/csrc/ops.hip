@@ -188,12 +188,19 @@ namespace sq {
 // a row is kept when EVERY term is true — a NULL term is not, filter.rs:16-24 over Kleene AND); every column of the batch
 // compacted through the same positions; validity bitmaps re-packed in output order.
 constexpr int SA_TERMS = 4;
-struct SaFilterParams {
-  SaLayout lay;
-  int nterms;
+struct SaFilterConj {
   int pred_col[SA_TERMS];
   int pred_is32[SA_TERMS]; // an int32 column: compared through its sign-extended value
   RowFilter rf[SA_TERMS];  // (rf.col unused: the predicate columns are read from the slot)
+};
+struct SaFilterParams {
+  SaLayout lay;
+  int nterms; // > 0: the conjunction `conj`; 0: the postfix program `prog` (any other predicate over fixed-width columns)
+  union {
+    SaFilterConj conj;
+    SaProgram prog;
+  };
+  SaFilterParams() : nterms(0), prog() {}
   const uint8_t *in;
   uint8_t *out;
   unsigned long long seq;
@@ -203,17 +210,26 @@ __global__ __launch_bounds__(1024) void sa_filter_kernel(SaGroup<SaFilterParams>
   __shared__ uint32_t s_w[17], s_nulls[SA_MAX_COLS];
   __shared__ uint8_t s_v[SA_MAX_ROWS];
   __shared__ uint32_t s_len[SA_MAX_ROWS + 4]; // Utf8: lengths of the kept rows in output order, then their exclusive prefix
+  __shared__ uint32_t s_div0;
   if (threadIdx.x < SA_MAX_COLS) s_nulls[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_div0 = 0;
+  __syncthreads();
   uint32_t pos[4], total;
   const uint32_t bits = sa_positions(
       p.lay.rows,
       [&](uint32_t r, int) {
+        if (p.nterms == 0) { // the general predicate: kept = the program's value is TRUE (NULL -> dropped, filter.rs:16-24)
+          bool valid, div0 = false;
+          const unsigned long long v = sa_eval_row(p.prog, p.lay, p.in, r, &valid, &div0);
+          if (div0) s_div0 = 1u;
+          return valid && v != 0;
+        }
         bool keep = true;
         for (int q = 0; q < p.nterms; q++) { // (uniform trip count)
-          const SaCol &pc = p.lay.c[p.pred_col[q]];
+          const SaCol &pc = p.lay.c[p.conj.pred_col[q]];
           const uint8_t *pvalid = pc.in_voff != SA_NONE ? p.in + pc.in_voff : nullptr;
-          const uint64_t v = p.pred_is32[q] ? (uint64_t)(int64_t)((const int32_t *)(p.in + pc.in_off))[r] : ((const uint64_t *)(p.in + pc.in_off))[r];
-          keep = keep && (!pvalid || ((pvalid[r >> 3] >> (r & 7)) & 1)) && row_passes(p.rf[q], v);
+          const uint64_t v = p.conj.pred_is32[q] ? (uint64_t)(int64_t)((const int32_t *)(p.in + pc.in_off))[r] : ((const uint64_t *)(p.in + pc.in_off))[r];
+          keep = keep && (!pvalid || ((pvalid[r >> 3] >> (r & 7)) & 1)) && row_passes(p.conj.rf[q], v);
         }
         return keep;
       },
@@ -254,6 +270,7 @@ __global__ __launch_bounds__(1024) void sa_filter_kernel(SaGroup<SaFilterParams>
           }
           base += a[q];
         }
+        if (total == SA_MAX_ROWS && threadIdx.x == 1023) ooff[SA_MAX_ROWS] = (int32_t)base; // (a full batch kept whole: its end offset has no owner above)
       }
       __syncthreads();
 #pragma unroll
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(1024) void sa_filter_kernel(SaGroup<SaFilterParams>
     }
     if (valid) sa_pack_validity(s_v, total, p.out + col.out_voff, &s_nulls[c]);
   }
-  sa_publish((SaHeader *)p.out, p.seq, total, s_nulls, p.lay.ncols);
+  sa_publish((SaHeader *)p.out, p.seq, total, s_nulls, p.lay.ncols, s_div0);
 }
 static void sa_filter_launch(SaRing *r, Ctx *ctx) {
   SaGroup<SaFilterParams> g;
@@ -318,10 +335,15 @@ static bool sa_filter_shape(const Expr &e, const sqlrs_batch_t *in, SaFilterPara
   for (size_t k = 0; k < nterms; k++) {
     const size_t at = k == 0 ? 0 : 3 + (k - 1) * 4;
     if (k > 0 && e.nodes[at + 3].op != SQLRS_EXPR_AND) return false;
-    if (!sa_filter_term(&e.nodes[at], in, &p->pred_col[k], &p->pred_is32[k], &p->rf[k])) return false;
+    if (!sa_filter_term(&e.nodes[at], in, &p->conj.pred_col[k], &p->conj.pred_is32[k], &p->conj.rf[k])) return false;
   }
   p->nterms = (int)nterms;
   return true;
+}
+// ... and any other predicate over the batch's int32 / int64 / float64 columns, as a postfix program (small_async.hpp)
+static bool sa_filter_program(const Expr &e, const sqlrs_batch_t *in, SaFilterParams *p) {
+  p->nterms = 0;
+  return sa_compile(e, in, &p->prog) && p->prog.result_dtype == SQLRS_BOOLEAN;
 }
 } // namespace sq
 
@@ -339,7 +361,7 @@ int sqlrs_filter_push_async(sqlrs_filter_t *f, const sqlrs_batch_t *in, sqlrs_ti
     t->ctx = ctx;
     SaFilterParams p;
     const char *off_e = hook("SQLRS_ASYNC_FAST"); // test hook, read per call: 0 = every batch through the synchronous operator
-    if (!(off_e && off_e[0] == '0') && sa_filter_shape(f->expr, in, &p)) {
+    if (!(off_e && off_e[0] == '0') && (sa_filter_shape(f->expr, in, &p) || sa_filter_program(f->expr, in, &p))) {
       SaRing *r = sa_ring(ctx);
       const int slot = r ? sa_take_slot(r) : -1;
       if (slot >= 0) {

@@ -106,6 +106,26 @@ template <class P> inline void sa_enqueue(Ctx *ctx, SaRing *r, const void *owner
 bool sa_stage_input(const sqlrs_batch_t *in, uint8_t *area, SaLayout *lay, int first_out_col, const int32_t *front_dtypes,
                     bool allow_utf8 = false);
 
+// ---- a postfix program over the batch's fixed-width columns, evaluated per row INSIDE the one-launch kernels -----------------
+// BoundExpr::eval_column (evaluator.rs:13-28, array_compute.rs:70-90) restated for one row: the same arithmetic (integers wrap,
+// x / 0 on a valid row is the Arrow error), the same comparisons (doubles in IEEE total order), Kleene AND / OR, the same casts
+// (out of range -> NULL), NULL = an operand was NULL — expr.hip does this column by column with one launch per node.
+constexpr int SA_PROG_MAX = 24, SA_STACK_MAX = 8;
+enum SaOp : uint8_t { SAO_COL = 0, SAO_CONST, SAO_CAST, SAO_ADD, SAO_SUB, SAO_MUL, SAO_DIV, SAO_GT, SAO_LT, SAO_GE, SAO_LE, SAO_EQ, SAO_NE, SAO_AND, SAO_OR };
+struct SaInstr {
+  uint8_t op, dtype, from, is_null; // dtype: operand type of an arithmetic / comparison, target of a cast, type of a constant / column
+  uint32_t col;                     // SAO_COL: column of the batch
+  unsigned long long imm;           // SAO_CONST: the value's bits (int32 sign-extended, bool 0 / 1)
+};
+struct SaProgram {
+  int n = 0;
+  int32_t result_dtype = 0;
+  SaInstr ins[SA_PROG_MAX];
+};
+// Expr -> program over the columns of `in`; false = not expressible here (a Utf8 / Boolean column or constant, mixed operand
+// types, an unsupported cast, too long): the synchronous evaluator takes the batch and raises whatever error there is to raise
+bool sa_compile(const Expr &e, const sqlrs_batch_t *in, SaProgram *out);
+
 } // namespace sq
 
 // what push_async returns and sqlrs_batch_wait consumes
@@ -120,6 +140,104 @@ struct sqlrs_ticket {
 #if defined(__HIPCC__)
 #include "device_utils.hpp"
 namespace sq {
+// one row of the program: *valid = the result is not NULL; *div0 raised when a valid row divides by zero
+__device__ __forceinline__ unsigned long long sa_eval_row(const SaProgram &pr, const SaLayout &lay, const uint8_t *in, uint32_t r, bool *valid,
+                                                          bool *div0) {
+  unsigned long long v[SA_STACK_MAX];
+  bool ok[SA_STACK_MAX];
+  int sp = 0;
+  for (int k = 0; k < pr.n; k++) {
+    const SaInstr I = pr.ins[k];
+    if (I.op == SAO_COL) {
+      const SaCol &c = lay.c[I.col];
+      ok[sp] = c.in_voff == SA_NONE || ((in[c.in_voff + (r >> 3)] >> (r & 7)) & 1);
+      v[sp] = c.width == 8 ? ((const unsigned long long *)(in + c.in_off))[r] : (unsigned long long)(long long)((const int32_t *)(in + c.in_off))[r];
+      sp++;
+    } else if (I.op == SAO_CONST) {
+      ok[sp] = !I.is_null;
+      v[sp] = I.imm;
+      sp++;
+    } else if (I.op == SAO_CAST) {
+      unsigned long long x = v[sp - 1];
+      bool o = ok[sp - 1];
+      if (I.from == SQLRS_BOOLEAN || I.from == SQLRS_INT32 || (I.from == SQLRS_INT64 && I.dtype != SQLRS_INT32)) { // widening / exact sources
+        const long long iv = (long long)x;
+        if (I.dtype == SQLRS_FLOAT64) x = (unsigned long long)__double_as_longlong((double)iv);
+      } else if (I.from == SQLRS_INT64) { // -> int32: out of range = NULL
+        const long long iv = (long long)x;
+        const bool in_range = iv <= 2147483647ll && iv >= -2147483648ll;
+        x = in_range ? x : 0ull;
+        o = o && in_range;
+      } else { // float64 -> integer
+        const double f = __longlong_as_double((long long)x);
+        const double lim = I.dtype == SQLRS_INT32 ? 2147483648.0 : 9223372036854775808.0;
+        const bool in_range = (f > -lim - 1) && (f < lim);
+        x = in_range ? (I.dtype == SQLRS_INT32 ? (unsigned long long)(long long)(int32_t)f : (unsigned long long)(long long)f) : 0ull;
+        o = o && in_range;
+      }
+      v[sp - 1] = x;
+      ok[sp - 1] = o;
+    } else {
+      const unsigned long long b = v[sp - 1], a = v[sp - 2];
+      const bool bo = ok[sp - 1], ao = ok[sp - 2];
+      sp -= 2;
+      unsigned long long res = 0;
+      bool ro = ao && bo;
+      if (I.op >= SAO_ADD && I.op <= SAO_DIV) {
+        if (I.dtype == SQLRS_FLOAT64) {
+          const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
+          double q = 0;
+          if (I.op == SAO_DIV) {
+            if (ro && y == 0.0) *div0 = true;
+            else if (ro) q = x / y;
+          } else
+            q = I.op == SAO_ADD ? x + y : I.op == SAO_SUB ? x - y : x * y;
+          res = (unsigned long long)__double_as_longlong(q);
+        } else if (I.dtype == SQLRS_INT64) {
+          if (I.op == SAO_DIV) {
+            if (ro && b == 0) *div0 = true;
+            else if (ro) res = (long long)b == -1 ? 0ull - a : (unsigned long long)((long long)a / (long long)b);
+          } else
+            res = I.op == SAO_ADD ? a + b : I.op == SAO_SUB ? a - b : a * b;
+        } else { // int32: wraps at 32 bits, kept sign-extended
+          const uint32_t x = (uint32_t)a, y = (uint32_t)b;
+          uint32_t q = 0;
+          if (I.op == SAO_DIV) {
+            if (ro && y == 0) *div0 = true;
+            else if (ro) q = (int32_t)y == -1 ? 0u - x : (uint32_t)((int32_t)x / (int32_t)y);
+          } else
+            q = I.op == SAO_ADD ? x + y : I.op == SAO_SUB ? x - y : x * y;
+          res = (unsigned long long)(long long)(int32_t)q;
+        }
+      } else if (I.op >= SAO_GT && I.op <= SAO_NE) {
+        bool lt, eq;
+        if (I.dtype == SQLRS_FLOAT64) {
+          const unsigned long long x = f64_to_ordered(__longlong_as_double((long long)a)), y = f64_to_ordered(__longlong_as_double((long long)b));
+          lt = x < y;
+          eq = x == y;
+        } else { // int32 (sign-extended), int64, bool (0 / 1)
+          lt = (long long)a < (long long)b;
+          eq = a == b;
+        }
+        res = I.op == SAO_GT ? (!lt && !eq) : I.op == SAO_LT ? lt : I.op == SAO_GE ? !lt : I.op == SAO_LE ? (lt || eq) : I.op == SAO_EQ ? eq : !eq;
+      } else if (I.op == SAO_AND) { // Kleene (bool_words_kernel, mode 6)
+        const bool kf = (ao && !a) || (bo && !b), kt = ao && a && bo && b;
+        res = kt;
+        ro = kf || kt;
+      } else { // SAO_OR (mode 7)
+        const bool kt = (ao && a) || (bo && b), kf = ao && !a && bo && !b;
+        res = kt;
+        ro = kf || kt;
+      }
+      v[sp] = res;
+      ok[sp] = ro;
+      sp++;
+    }
+  }
+  *valid = ok[0];
+  return v[0];
+}
+
 // Output positions of the kept rows of <= 4096 rows on ONE 1024-thread workgroup: pos[t] for row t * 1024 + tid, bit t of
 // the return value = kept; *total = kept rows.  `s_w`: 17 words of LDS.
 template <class KeepFn>
@@ -170,11 +288,13 @@ __device__ __forceinline__ void sa_pack_validity(const uint8_t *s_v, uint32_t to
 }
 // the last step of a fast-path kernel: every thread's stores to the pinned output are pushed out, then ONE thread
 // publishes the header
-__device__ __forceinline__ void sa_publish(SaHeader *hdr, unsigned long long seq, uint32_t total, const uint32_t *s_nulls, int ncols) {
+__device__ __forceinline__ void sa_publish(SaHeader *hdr, unsigned long long seq, uint32_t total, const uint32_t *s_nulls, int ncols,
+                                           uint32_t error = 0) {
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
     hdr->count = total;
+    hdr->pad = error; // (1: a valid row divided by zero — sqlrs_batch_wait turns it into the evaluator's Arrow error)
     for (int c = 0; c < ncols; c++) hdr->nulls[c] = s_nulls[c];
     __threadfence_system();
     __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

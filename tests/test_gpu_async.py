@@ -7,7 +7,7 @@ import pytest
 
 from sqlrs_amd import abi
 from sqlrs_amd.executor import FilterExecutor, HashJoinExecutor
-from sqlrs_amd.expr import Constant, InputRef, JoinCondition
+from sqlrs_amd.expr import Constant, InputRef, JoinCondition, TypeCast
 from test_gpu_parity import join_schema
 
 pytestmark = pytest.mark.gpu
@@ -39,7 +39,8 @@ def batches(rng, n, sizes, nulls, with_str=False):
     return out
 
 
-@pytest.mark.parametrize("pred", ["i64_gt", "f64_le", "i64_ne", "pred_nulls", "compound", "i32", "three_terms", "or", "col_col"])
+@pytest.mark.parametrize("pred", ["i64_gt", "f64_le", "i64_ne", "pred_nulls", "compound", "i32", "three_terms", "or", "col_col", "arith",
+                                  "cast", "div", "null_const", "bool_cmp"])
 @pytest.mark.parametrize("depth", [1, 4, 40])
 def test_filter_push_async_yields_the_batches_of_push(hip, oracle, monkeypatch, pred, depth):
     """fast path (conjunctions of up to four `column OP constant` terms over int32 / int64 / float64, a row with a NULL term
@@ -55,16 +56,22 @@ def test_filter_push_async_yields_the_batches_of_push(hip, oracle, monkeypatch, 
          "i32": InputRef(2) > Constant(0, abi.INT32),
          "three_terms": ((InputRef(0) >= Constant(-50, abi.INT64)) & (InputRef(1) < Constant(0.8, abi.FLOAT64))) & InputRef(2).ne(Constant(1, abi.INT32)),
          "or": (InputRef(0) > Constant(90, abi.INT64)) | (InputRef(1) < Constant(0.1, abi.FLOAT64)),  # (not a conjunction: the synchronous operator)
-         "col_col": InputRef(0) > InputRef(0)}[pred]
+         "col_col": InputRef(0) > InputRef(0),
+         # the postfix program evaluated per row inside the kernel: arithmetic (wrapping), casts (out of range -> NULL), division,
+         # NULL constants, Kleene OR, comparisons of comparison results
+         "arith": ((InputRef(0) + Constant(5, abi.INT64)) * InputRef(0)) > (InputRef(0) - Constant(7, abi.INT64)),
+         "cast": (TypeCast(InputRef(2), abi.INT64) * Constant(3_000_000_000, abi.INT64) + InputRef(0)).ne(Constant(0, abi.INT64))
+                 & (TypeCast(TypeCast(InputRef(1), abi.INT64) * Constant(1 << 40, abi.INT64) + InputRef(0) * Constant(1 << 26, abi.INT64), abi.INT32) > Constant(-1, abi.INT32)),
+         "div": (InputRef(1) / Constant(0.25, abi.FLOAT64)) > (TypeCast(InputRef(0), abi.FLOAT64) / Constant(50.0, abi.FLOAT64)),
+         "null_const": (InputRef(0) > Constant(None, abi.INT64)) | (InputRef(1) < Constant(0.3, abi.FLOAT64)),
+         "bool_cmp": (InputRef(0) > Constant(0, abi.INT64)).eq(InputRef(1) > Constant(0.5, abi.FLOAT64))}[pred]
     before = fast_batches(hip)
     got = list(FilterExecutor(hip, e, bs, depth=depth).execute())
     took = fast_batches(hip) - before
-    # every <= 4096-row batch takes the one-launch kernel, unless the predicate is not a conjunction of
-    # column-OP-constant terms (then none does); with more tickets than ring slots some run the synchronous operator
+    # every <= 4096-row batch takes the one-launch kernel (conjunctions through the specialised path, everything else over fixed-width
+    # columns through the in-kernel postfix program); with more tickets than ring slots some run the synchronous operator
     eligible = sum(1 for b in bs if b.num_rows <= 4096)
-    if pred in ("or", "col_col"):
-        assert took == 0
-    elif depth < 32:
+    if depth < 32:
         assert took == eligible, (took, eligible)
     else:
         assert 0 < took <= eligible
@@ -138,7 +145,19 @@ def test_async_group_sizes(oracle, monkeypatch, group):
         be.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+def test_async_filter_keeps_a_full_utf8_batch_whole(hip, oracle):
+    """4096 rows, every one kept: the Utf8 end offset (entry 4096 of the offsets) is written too"""
+    n = 4096
+    b = pa.RecordBatch.from_arrays([pa.array(np.arange(n)), pa.array(["s" * (i % 11) + str(i) for i in range(n)], type=pa.string()),
+                                    pa.array([None if i % 5 == 0 else "t" + str(i) for i in range(n)], type=pa.string())], names=["a", "s", "t"])
+    for e in (InputRef(0) >= Constant(0, abi.INT64), (InputRef(0) + Constant(1, abi.INT64)) > Constant(0, abi.INT64)):
+        before = fast_batches(hip)
+        got = list(FilterExecutor(hip, e, [b, b.slice(0, 4095), b], depth=4).execute())
+        assert fast_batches(hip) - before == 3
+        same_batches(got, list(FilterExecutor(oracle, e, [b, b.slice(0, 4095), b]).execute()))
+
+
+@pytest.mark.parametrize("seed", range(16))
 def test_fuzz_async_filter_and_probe(hip, oracle, seed):
     """random schemas (1-9 fixed-width columns, NULL rates 0 / 5 / 50 / 100 %), batch sizes 0-4096, conjunctions of 1-4 random terms;
     random Inner joins over unique build keys (dense or sparse, int32 / int64) with NULL-bearing payload columns on both sides —
@@ -169,6 +188,39 @@ def test_fuzz_async_filter_and_probe(hip, oracle, seed):
              "=": lambda a, b: a.eq(b), "!=": lambda a, b: a.ne(b)}[op](InputRef(c), const)
         e = t if e is None else (e & t)
     same_batches(list(FilterExecutor(hip, e, bs, depth=int(rng.integers(1, 7))).execute()), list(FilterExecutor(oracle, e, bs).execute()))
+    # ---- a random predicate TREE (arithmetic, casts, comparisons, Kleene AND / OR, NULL constants): the in-kernel postfix program
+    DT = {"i64": abi.INT64, "f64": abi.FLOAT64, "i32": abi.INT32}
+
+    def rand_num(kind, depth):
+        cols_k = [i for i, k in enumerate(kinds) if k == kind]
+        r = rng.random()
+        if depth == 0 or r < 0.3:
+            if cols_k and rng.random() < 0.7:
+                return InputRef(int(rng.choice(cols_k)))
+            if rng.random() < 0.1:
+                return Constant(None, DT[kind])
+            return Constant(float(np.round(rng.random() * 4 - 2, 2)) if kind == "f64" else int(rng.integers(-5, 6)), DT[kind])
+        if r < 0.45:
+            other = str(rng.choice([k for k in DT if k != kind]))
+            return TypeCast(rand_num(other, depth - 1), DT[kind])
+        a, b = rand_num(kind, depth - 1), rand_num(kind, depth - 1)
+        return {0: lambda: a + b, 1: lambda: a - b, 2: lambda: a * b}[int(rng.integers(0, 3))]()
+
+    def rand_bool(depth):
+        if depth == 0 or rng.random() < 0.5:
+            kind = str(rng.choice(list(DT)))
+            a, b = rand_num(kind, 2), rand_num(kind, 2)
+            return {0: lambda: a > b, 1: lambda: a < b, 2: lambda: a >= b, 3: lambda: a <= b, 4: lambda: a.eq(b), 5: lambda: a.ne(b)}[int(rng.integers(0, 6))]()
+        a, b = rand_bool(depth - 1), rand_bool(depth - 1)
+        return (a & b) if rng.random() < 0.5 else (a | b)
+    for _ in range(3):
+        e2 = rand_bool(2)
+        if len(e2.nodes()) > 24:
+            continue
+        before = fast_batches(hip)
+        got2 = list(FilterExecutor(hip, e2, bs, depth=3).execute())
+        assert fast_batches(hip) - before == len(bs)
+        same_batches(got2, list(FilterExecutor(oracle, e2, bs).execute()))
     # ---- join
     nb = int(rng.choice([50, 3000, 40000]))
     kk = str(rng.choice(["i64", "i32"]))
@@ -202,3 +254,23 @@ def test_async_filter_over_the_reference_csv_table(hip, oracle):
     exp = list(FilterExecutor(oracle, e, bs).execute())
     same_batches(got, exp)
     assert sum(g.num_rows for g in got) > 0
+
+
+def test_async_divide_by_zero_is_the_evaluators_error(hip, oracle):
+    """x / 0 on a VALID row is Arrow's DivideByZero (array_compute.rs via evaluator.rs:19-27): the synchronous push raises it at the
+    push, the async path at the wait for that batch's ticket; a NULL divisor or dividend divides nothing; the operator-side state
+    survives (the next stream runs)"""
+    rng = np.random.default_rng(9)
+    n = 1000
+    num = pa.array(rng.integers(1, 100, n))
+    zero_where_null = pa.array(np.where(np.arange(n) % 10 == 0, 0, rng.integers(1, 9, n)), mask=(np.arange(n) % 10 == 0))
+    zero_valid = pa.array(np.where(np.arange(n) == 777, 0, rng.integers(1, 9, n)))
+    ok = pa.RecordBatch.from_arrays([num, zero_where_null], names=["a", "b"])
+    bad = pa.RecordBatch.from_arrays([num, zero_valid], names=["a", "b"])
+    e = (InputRef(0) / InputRef(1)) > Constant(3, abi.INT64)
+    same_batches(list(FilterExecutor(hip, e, [ok, ok], depth=2).execute()), list(FilterExecutor(oracle, e, [ok, ok]).execute()))
+    for be, kw in ((oracle, {}), (hip, {}), (hip, {"depth": 2})):
+        with pytest.raises(abi.ExecutorError) as ei:
+            list(FilterExecutor(be, e, [ok, bad, ok], **kw).execute())
+        assert ei.value.status == abi.ERR_ARROW and "ivide by zero" in str(ei.value), (kw, str(ei.value))
+    same_batches(list(FilterExecutor(hip, e, [ok], depth=1).execute()), list(FilterExecutor(oracle, e, [ok]).execute()))
