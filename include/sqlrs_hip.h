@@ -281,9 +281,12 @@ int sqlrs_filter_push_many(sqlrs_filter_t *f, int n, const sqlrs_batch_t *const 
  * consumes the ticket (also after an error).  `in` is read completely before push_async returns.  Tickets of one ctx
  * complete in issue order; a caller that waits a few batches behind (the stream adaptor of the Rust / C++ mirrors keeps
  * `depth` tickets in flight) never blocks on the device.  HOST batches of <= 4096 rows and <= 12 int32 / int64 / float64 /
- * utf8 columns under a conjunction of up to four `column OP constant` terms over int32 / int64 / float64 columns share ONE launch
- * with up to three neighbours and take no copy call (pinned, device-mapped ring); every other batch runs the synchronous
- * operator inside push_async: same batches, no speed-up.  Tickets must be waited for before their ctx is destroyed. */
+ * utf8 columns under ANY predicate over their int32 / int64 / float64 columns (comparisons, + - * / with the evaluator's wrapping
+ * and its "Divide by zero error" — reported by sqlrs_batch_wait of that ticket —, casts between the three types, NULL
+ * constants, AND / OR; <= 24 expression nodes) share ONE launch with up to three neighbours and take no copy call (pinned,
+ * device-mapped ring); every other batch (a predicate that reads a utf8 / boolean column, DEVICE input, more rows or columns)
+ * runs the synchronous operator inside push_async: same batches, no speed-up.  Tickets must be waited for before their ctx is
+ * destroyed. */
 typedef struct sqlrs_ticket sqlrs_ticket_t;
 int sqlrs_filter_push_async(sqlrs_filter_t *f, const sqlrs_batch_t *in, sqlrs_ticket_t **ticket);
 int sqlrs_batch_wait(sqlrs_ticket_t *ticket, sqlrs_batch_t **out);

@@ -6,12 +6,13 @@
 // back a TICKET instead of a batch and `sqlrs_batch_wait(ticket)` the batch; a caller that waits one (or a few) batches
 // behind never blocks on the device.  The fast path is ONE launch per batch and no copy call at all:
 //   * the batch's columns are copied (memcpy, 8 KB per column) into a slot of a pinned, device-mapped ring;
-//   * one 1024-thread workgroup reads them over PCIe, evaluates `column OP constant` (Filter) or looks the keys up in the
+//   * one 1024-thread workgroup reads them over PCIe, evaluates the predicate — a conjunction of `column OP constant` terms directly, anything else over the
+//     int32 / int64 / float64 columns as a postfix program (SaProgram, sa_eval_row: the evaluator's semantics row by row) — or looks the keys up in the
 //     join's table (HashJoin, unique build keys), compacts the kept rows with ballots, gathers the build columns, and
 //     writes the output columns + validity bitmaps + a header {sequence number, rows, NULL counts} back into the slot;
 //   * `wait` polls the header's sequence number (system-scope release store behind `__threadfence_system`), falling
 //     back to a stream synchronisation when it does not show up, and copies the rows into an ordinary HOST batch.
-// Anything the fast path does not take — Boolean columns, predicates that are not conjunctions of column-OP-constant terms, Utf8
+// Anything the fast path does not take — predicates that read a Boolean / Utf8 column or need more than 24 nodes, Utf8
 // columns around a join, more than 4096 rows, DEVICE input,
 // duplicate build keys, join filters, outer joins — runs the synchronous operator inside push_async and parks the finished
 // batch in the ticket: same results, same one-output-per-input rule, no speed-up.
