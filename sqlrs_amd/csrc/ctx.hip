@@ -180,6 +180,10 @@ BufP Ctx::alloc_zero(size_t bytes) {
   SQ_HIP(hipMemsetAsync(b->p, 0, bytes ? bytes : 8, stream));
   return b;
 }
+// (Round 6 measured a POLLED form — one workgroup copies the bytes into a coherent host-mapped block and release-stores a sequence
+//  word the host spins on, as the single-batch async path publishes its headers: C4 (four fetches per query) 2.199 / 2.191 ms
+//  against 2.207 / 2.201, C3 within the noise.  The runtime's synchronisation already spins; the ~20 us between a fetched word and
+//  the next kernel are the launch path, not the wake-up.  The copy call stays.)
 const void *Ctx::fetch(const void *dptr, size_t bytes) {
   if (bytes > pinned_bytes) fail(SQLRS_ERR_INTERNAL, "fetch too large");
   SQ_HIP(hipMemcpyAsync(pinned, dptr, bytes, hipMemcpyDeviceToHost, stream));
