@@ -353,6 +353,9 @@ constexpr int JA_ILP = 16; // independent table loads in flight per lane
 // (Round 6 measured the sample INSIDE the all-hit kernel — its first 64 workgroups test the rows, every wave looks at the flag
 //  behind its first trip: one dispatch less, but an attempt that has to be given up then costs every wave a trip, C3 half-hit
 //  build + probe 0.65 -> 0.68 ms for ~5 us on the all-hit side; the separate launch stays.)
+// (Round 6 also measured the compacting kernel QUEUED BEHIND the attempt of a first probe — a no-op while the flag is clear, its
+//  descriptors cleared by the sample launch, its pair count fetched with the verdict: C3 half-hit build + probe 0.651 -> 0.632 ms,
+//  but the empty 6104-workgroup launch costs the all-hit side 18 us, 0.626 -> 0.644 ms.  The host decides between the two.)
 __global__ void join_probe_dense_sample_kernel(const uint64_t *__restrict__ keys, int64_t n, int64_t every, DenseTable dt,
                                                unsigned int *__restrict__ miss) {
   if (dt.st && !dense_table_from_device(dt)) {
