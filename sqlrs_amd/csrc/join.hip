@@ -121,15 +121,21 @@ __global__ __launch_bounds__(BLOCK) void join_count_kernel(const uint64_t *__res
                                                            const uint64_t *__restrict__ validity,
                                                            int64_t n, const Slot *__restrict__ table,
                                                            uint64_t mask, int outer_right,
-                                                           uint32_t *__restrict__ counts, uint2 *__restrict__ match) {
+                                                           uint32_t *__restrict__ counts, uint2 *__restrict__ match, int grouped) {
   int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  bool is_null = validity && !((validity[r >> 6] >> (r & 63)) & 1);
-  Slot s = probe_slot(table, mask, keys[r], is_null);
-  uint32_t c = s.count;
-  match[r] = make_uint2(s.head, c); // what the fill pass needs: no second probe
-  if (outer_right && c == 0) c = 1;
-  counts[r] = c;
+  uint32_t c = 0;
+  if (r < n) {
+    bool is_null = validity && !((validity[r >> 6] >> (r & 63)) & 1);
+    Slot s = probe_slot(table, mask, keys[r], is_null);
+    c = s.count;
+    match[r] = make_uint2(s.head, c); // what the fill pass needs: no second probe
+    if (outer_right && c == 0) c = 1;
+    if (!grouped) counts[r] = c;
+  }
+  if (grouped) { // the fill pass scans inside its 64-row group itself: only the groups' sums are scanned globally
+    const uint32_t wsum = wave_sum_u32(c);
+    if (lane_id() == 0 && (r & ~63ll) < n) counts[r >> 6] = wsum;
+  }
 }
 
 // pass 2, wave-cooperative: a wave owns 64 consecutive probe rows and writes THEIR pairs as one contiguous
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(BLOCK) void join_count_kernel(const uint64_t *__res
 __global__ __launch_bounds__(BLOCK) void join_fill_expand_kernel(
     const uint2 *__restrict__ match, int64_t n, int unique, int outer_right, const uint32_t *__restrict__ rows_by_slot,
     const uint64_t *__restrict__ offsets, uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx,
-    uint8_t *__restrict__ left_valid_bytes) {
+    uint8_t *__restrict__ left_valid_bytes, int grouped) {
   const int lane = lane_id();
   const int64_t wbase = (blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_id()) * 64;
   if (wbase >= n) return;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void join_fill_expand_kernel(
   if (outer_right && r < n && cnt == 0) cnt = 1; // (NULL, row)  hash_join.rs:241-246
   const uint32_t incl = wave_iscan_u32(cnt), excl = incl - cnt;
   const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-  const uint64_t obase = offsets[wbase];
+  const uint64_t obase = offsets[grouped ? wbase >> 6 : wbase]; // (grouped: one scanned offset per 64-row group)
   for (uint32_t t0 = 0; t0 < total; t0 += 64) {
     const uint32_t t = t0 + lane;
     // owner of output t = number of rows of the wave whose inclusive scan is <= t
@@ -169,8 +175,8 @@ __global__ __launch_bounds__(BLOCK) void join_fill_expand_kernel(
       const uint64_t o = obase + t;
       uint64_t l = 0;
       if (phit) l = unique ? head : rows_by_slot[head + j];
-      left_idx[o] = l;
-      right_idx[o] = (uint32_t)(wbase + pos);
+      __builtin_nontemporal_store(l, &left_idx[o]);
+      __builtin_nontemporal_store((uint32_t)(wbase + pos), &right_idx[o]);
       if (left_valid_bytes) left_valid_bytes[o] = phit ? 1 : 0;
     }
   }
@@ -925,6 +931,81 @@ __global__ __launch_bounds__(LR_BLOCK) void lds_join_restore_kernel(
       __builtin_nontemporal_store((uint32_t)(rbase + r), &right_idx[o]);
     }
     pos += (uint32_t)__popcll(bm);
+  }
+}
+
+// probe 3 for everything that is not "unique build keys, Inner / Left" (round 6): duplicate build keys (every probe row emits
+// the RUN of build rows that carry its key, hash_join.rs:225-234) and Right / Full joins (an unmatched probe row emits (NULL,
+// row), :235-248).  The range is un-permuted through LDS as above, but nothing is compacted: row r of the batch gets
+// match[r] = {first entry of its key's run, rows of the run} and counts[r] = the pairs it emits — exactly what
+// join_count_kernel leaves after probing the general table at the random-access rate of the memory behind L2 (2.6 ms per 1e8
+// probe rows against 0.5 + 0.5 + 0.4 ms for partition + LDS probe + this pass) — and the scan + join_fill_expand_kernel
+// go on from there.  `dmatch` null: unique build keys (the matched "row" is the build row, a run of one).
+__global__ __launch_bounds__(1024) void lds_join_unpermute_kernel(const uint32_t *__restrict__ pidx, const uint32_t *__restrict__ mpart,
+                                                                  int64_t n, const uint2 *__restrict__ dmatch, int outer_right,
+                                                                  uint2 *__restrict__ match, uint32_t *__restrict__ counts, int grouped) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lu2_smem[];
+  uint32_t *m = (uint32_t *)lu2_smem; // [LJ_RANGE]
+  const int64_t rbase = (int64_t)blockIdx.x * LJ_RANGE;
+  const uint32_t len = (uint32_t)min<int64_t>(LJ_RANGE, n - rbase);
+  constexpr int U = 8;
+  for (uint32_t base = threadIdx.x; base < len; base += 1024 * U) {
+    uint32_t id[U], mv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t i = min(base + u * 1024, len - 1);
+      id[u] = __builtin_nontemporal_load(pidx + rbase + i);
+      mv[u] = __builtin_nontemporal_load(mpart + rbase + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (base + u * 1024 < len) m[id[u] - (uint32_t)rbase] = mv[u];
+  }
+  __syncthreads();
+  for (uint32_t r0 = 0; r0 < len; r0 += 1024) { // (uniform trip count: the group sums are wave reductions)
+    const uint32_t r = r0 + threadIdx.x;
+    uint32_t c = 0;
+    if (r < len) {
+      const uint32_t d = m[r];
+      uint2 mt = make_uint2(0u, 0u);
+      if (d != DENSE_EMPTY) mt = dmatch ? dmatch[d] : make_uint2(d, 1u);
+      __builtin_nontemporal_store(((uint64_t)mt.y << 32) | mt.x, (uint64_t *)(match + rbase + r));
+      c = (outer_right && mt.y == 0) ? 1u : mt.y;
+      if (!grouped) __builtin_nontemporal_store(c, counts + rbase + r);
+    }
+    if (grouped) {
+      const uint32_t wsum = wave_sum_u32(c);
+      if (lane_id() == 0 && (r & ~63u) < len) counts[(rbase + r) >> 6] = wsum;
+    }
+  }
+}
+// the distinct keys of the general table (non-empty slots; the slot of the key whose value is the table's "empty" word
+// included, the NULL keys' slot not: this route takes no NULL keys) with their runs, in no particular order
+__global__ __launch_bounds__(1024) void distinct_slots_kernel(const Slot *__restrict__ t, int64_t cap, uint64_t *__restrict__ dkey,
+                                                              uint2 *__restrict__ dmatch, unsigned int *__restrict__ counter) {
+  __shared__ uint32_t s_w[16], s_base;
+  const int64_t i = blockIdx.x * 1024ll + threadIdx.x;
+  Slot sl;
+  sl.count = 0;
+  if (i <= cap + 1 && i != cap) sl = load_slot(&t[i]);
+  const bool has = sl.count != 0;
+  const uint64_t bm = __ballot(has);
+  if (lane_id() == 0) s_w[wave_id()] = (uint32_t)__popcll(bm);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int w = 0; w < 16; w++) {
+      const uint32_t c = s_w[w];
+      s_w[w] = tot;
+      tot += c;
+    }
+    s_base = tot ? atomicAdd(counter, tot) : 0u;
+  }
+  __syncthreads();
+  if (has) {
+    const uint32_t d = s_base + s_w[wave_id()] + mbcnt(bm);
+    dkey[d] = i == cap + 1 ? EMPTY_KEY : sl.key;
+    dmatch[d] = make_uint2(sl.head, sl.count);
   }
 }
 
@@ -1752,19 +1833,15 @@ struct LdsJoinMatch {
 };
 // the build keys in bucket order + the LDS table size of the fullest bucket, once per join (lds_slots = 0: not this route)
 constexpr uint32_t LJ_P = 512;
-static void lds_join_prepare(sqlrs_hash_join *j) {
-  if (j->lds_build) return;
-  Ctx *ctx = j->ctx;
+// `keys` (n of them, no NULLs) in bucket order; returns the LDS table size of the fullest bucket (0: the route does not apply)
+static uint32_t lds_partition_keys(Ctx *ctx, const uint64_t *keys, int64_t n, PartitionedRows *pr) {
   const uint32_t P = LJ_P;
-  auto pr = std::make_shared<PartitionedRows>();
   PartitionInput bin;
-  bin.keys = j->bkeys->as<uint64_t>();
-  bin.n = j->nB;
+  bin.keys = keys;
+  bin.n = n;
   bin.nv = 0;
   bin.build_side = true;
-  j->lds_slots = 0;
-  j->lds_build = pr; // (remembered either way: do not try again)
-  if (!partition_rows(ctx, bin, P, pr.get()) || pr->P != P || !pr->idx || pr->pack.kbits) return;
+  if (!partition_rows(ctx, bin, P, pr) || pr->P != P || !pr->idx || !pr->key || pr->pack.kbits) return 0;
   uint32_t maxb = 0;
   for (uint32_t bkt = 0; bkt < P; bkt++) maxb = std::max(maxb, pr->bstart_host[bkt + 1] - pr->bstart_host[bkt]);
   // load <= 1/2 in the fullest bucket.  (Round 6 tried <= 0.7, which puts C3's 1e6 build keys — 1953 per bucket, the fullest
@@ -1775,7 +1852,36 @@ static void lds_join_prepare(sqlrs_hash_join *j) {
   const uint32_t pct = ld_e ? (uint32_t)std::min(90, std::max(10, std::atoi(ld_e))) : 50;
   uint32_t slots = 1024;
   while ((uint64_t)slots * pct < 100ull * maxb) slots <<= 1;
-  j->lds_slots = slots <= 8192 ? slots : 0; // (8192 x 16 B = 128 KiB: one workgroup per CU)
+  return slots <= 8192 ? slots : 0; // (8192 x 16 B = 128 KiB: one workgroup per CU)
+}
+static void lds_join_prepare(sqlrs_hash_join *j) {
+  if (j->lds_build) return;
+  auto pr = std::make_shared<PartitionedRows>();
+  j->lds_slots = 0;
+  j->lds_build = pr; // (remembered either way: do not try again)
+  j->lds_slots = lds_partition_keys(j->ctx, j->bkeys->as<uint64_t>(), j->nB, pr.get());
+}
+// ... of a build side with duplicate keys: the distinct keys of its general table (built by now: rows_by_slot holds the runs)
+static void lds_join_prepare_distinct(sqlrs_hash_join *j) {
+  if (j->lds_distinct) return;
+  Ctx *ctx = j->ctx;
+  auto pr = std::make_shared<PartitionedRows>();
+  j->lds_dslots = 0;
+  j->lds_distinct = pr;
+  if (!j->table || !j->rows_by_slot) return;
+  const int64_t cap = (int64_t)j->mask + 1;
+  j->lds_dkeys = ctx->alloc(8 * (size_t)j->nB);
+  j->lds_dmatch = ctx->alloc(8 * (size_t)j->nB);
+  BufP counter = ctx->alloc_zero(8);
+  {
+    ProfScope ps(ctx, "join_build_lds_distinct");
+    distinct_slots_kernel<<<dim3((unsigned)ceil_div(cap + 2, 1024)), dim3(1024), 0, ctx->stream>>>(
+        j->table->as<Slot>(), cap, j->lds_dkeys->as<uint64_t>(), j->lds_dmatch->as<uint2>(), counter->as<unsigned int>());
+    SQ_HIP(hipGetLastError());
+  }
+  const int64_t D = (int64_t)ctx->fetch_value(counter->as<unsigned int>());
+  if (D < 2) return;
+  j->lds_dslots = lds_partition_keys(ctx, j->lds_dkeys->as<uint64_t>(), D, pr.get());
 }
 // A build side that will be probed on LDS tables establishes `unique` there (lds_join_unique_kernel) and leaves the global
 // table unbuilt (`table_built` stays false: hash_join_ensure_table builds it when a probe cannot take the route — a small
@@ -1808,7 +1914,8 @@ static bool lds_build_first(sqlrs_hash_join *j) {
   j->lds_first = true;
   return true;
 }
-static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
+// `distinct`: the build side has duplicate keys — the tables hold its DISTINCT keys, a match is an index into lds_dmatch
+static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk, bool distinct = false) {
   Ctx *ctx = j->ctx;
   LdsJoinMatch out;
   const int64_t n = pk.rows, nB = j->nB;
@@ -1818,10 +1925,12 @@ static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
   //  the hash IS the key of this route, compared exactly; they carry no validity: a NULL leaves the hash unchanged)
   if (env == 0 || pk.validity || j->bkeys_validity || !j->bkeys || nB < 2 || n > 0xffffffffll) return out;
   if (env != 1 && (nB < (1 << 18) || n < (1 << 22) || n < 8 * nB)) return out;
-  lds_join_prepare(j);
+  if (distinct) lds_join_prepare_distinct(j);
+  else lds_join_prepare(j);
   const uint32_t P = LJ_P;
-  if (!j->lds_slots || !j->lds_build->key) return out;
-  const PartitionedRows &bp = *j->lds_build;
+  const uint32_t lds_slots = distinct ? j->lds_dslots : j->lds_slots;
+  if (!lds_slots) return out;
+  const PartitionedRows &bp = distinct ? *j->lds_distinct : *j->lds_build;
   const uint32_t nranges = (uint32_t)ceil_div(n, LJ_RANGE);
   const uint32_t nrs = (uint32_t)round_up((size_t)nranges, 64) + 64; // row stride of the bucket-major sliver starts
   BufP pkey = ctx->alloc(8 * (size_t)n + 16), pbstart = ctx->alloc(4 * (size_t)nrs * P);
@@ -1840,11 +1949,11 @@ static LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk) {
   out.mpart = ctx->alloc(4 * (size_t)n + 16);
   {
     ProfScope ps(ctx, "join_probe_lds");
-    const size_t lds = (size_t)j->lds_slots * sizeof(LjSlot);
+    const size_t lds = (size_t)lds_slots * sizeof(LjSlot);
     allow_big_lds(ctx, lds_join_probe_kernel<LJ_Q>, 136 * 1024);
     lds_join_probe_kernel<LJ_Q><<<dim3(P * ngroups), dim3(LJ_WG), lds, ctx->stream>>>(
         bp.key->as<uint64_t>(), bp.idx->as<uint32_t>(), bp.bstart->as<uint32_t>(), pkey->as<uint64_t>(),
-        pbstart->as<uint32_t>(), nrs, (uint32_t)n, P, nranges, rpi, j->lds_slots, out.mpart->as<uint32_t>());
+        pbstart->as<uint32_t>(), nrs, (uint32_t)n, P, nranges, rpi, lds_slots, out.mpart->as<uint32_t>());
     SQ_HIP(hipGetLastError());
   }
   out.ok = true;
@@ -2012,7 +2121,11 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     p.right_identity = p.m == n;
     return p;
   }
-  if (j->unique && outer_right) { // exactly one pair per probe row
+  // duplicate build keys, and Right / Full joins over general keys: matched on the LDS tables too, un-permuted into the
+  // {run, pairs} the fill pass expands (lds_join_unpermute_kernel)
+  LdsJoinMatch lmg;
+  if (!j->dense && (!j->unique || outer_right)) lmg = lds_join_match(j, pk, !j->unique);
+  if (j->unique && outer_right && !lmg.ok) { // exactly one pair per probe row
     p.m = n;
     p.right_identity = true; // (pair i = (build row | NULL, probe row i))
     p.left = ctx->alloc(8 * (size_t)n);
@@ -2032,16 +2145,28 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     SQ_HIP(hipGetLastError());
     return p;
   }
-  BufP counts = ctx->alloc(4 * (size_t)n), offsets = ctx->alloc(8 * (size_t)n), total = ctx->alloc(8);
+  // The fill pass scans the pair counts of its 64 probe rows itself, so only one sum per 64-row group is scanned globally
+  // (round 6: per-row counts + offsets were 0.4 + 0.8 GB written and 1.2 GB read for 1e8 probe rows, 0.45 ms of scan).  A build
+  // side of >= 2^26 rows — 64 runs of that length overflow a 32-bit sum — keeps per-row counts.
+  const int grouped = j->nB < (1ll << 26) ? 1 : 0;
+  const int64_t nscan = grouped ? ceil_div(n, 64) : n;
+  BufP counts = ctx->alloc(4 * (size_t)nscan), offsets = ctx->alloc(8 * (size_t)nscan), total = ctx->alloc(8);
   BufP match = ctx->alloc(8 * (size_t)n);
-  {
+  if (lmg.ok) {
+    ProfScope ps(ctx, "join_match_unpermute");
+    allow_big_lds(ctx, lds_join_unpermute_kernel, 4 * LJ_RANGE + 1024);
+    lds_join_unpermute_kernel<<<dim3((unsigned)ceil_div(n, LJ_RANGE)), dim3(1024), 4 * (size_t)LJ_RANGE, ctx->stream>>>(
+        lmg.idx->as<uint32_t>(), lmg.mpart->as<uint32_t>(), n, j->unique ? nullptr : j->lds_dmatch->as<uint2>(), outer_right,
+        match->as<uint2>(), counts->as<uint32_t>(), grouped);
+    SQ_HIP(hipGetLastError());
+  } else {
     ProfScope ps(ctx, "join_probe_count");
     join_count_kernel<<<g, b, 0, ctx->stream>>>(pk.keys->as<uint64_t>(), pk.validity, n,
                                                 (j->table ? j->table->as<Slot>() : nullptr), j->mask, outer_right,
-                                                counts->as<uint32_t>(), match->as<uint2>());
+                                                counts->as<uint32_t>(), match->as<uint2>(), grouped);
     SQ_HIP(hipGetLastError());
   }
-  exclusive_scan_u32(ctx, counts->as<uint32_t>(), n, offsets->as<uint64_t>(), nullptr,
+  exclusive_scan_u32(ctx, counts->as<uint32_t>(), nscan, offsets->as<uint64_t>(), nullptr,
                      total->as<uint64_t>());
   p.m = (int64_t)ctx->fetch_value(total->as<uint64_t>());
   int64_t m1 = std::max<int64_t>(p.m, 1);
@@ -2053,7 +2178,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
     ProfScope ps(ctx, "join_probe_fill");
     join_fill_expand_kernel<<<dim3((unsigned)ceil_div(n, BLOCK)), b, 0, ctx->stream>>>(
         match->as<uint2>(), n, j->unique ? 1 : 0, outer_right, j->rows_by_slot ? j->rows_by_slot->as<uint32_t>() : nullptr,
-        offsets->as<uint64_t>(), p.left->as<uint64_t>(), p.right->as<uint32_t>(), lvb ? lvb->as<uint8_t>() : nullptr);
+        offsets->as<uint64_t>(), p.left->as<uint64_t>(), p.right->as<uint32_t>(), lvb ? lvb->as<uint8_t>() : nullptr, grouped);
     SQ_HIP(hipGetLastError());
   }
   if (outer_right) {

@@ -74,6 +74,11 @@ struct sqlrs_hash_join {
   // that takes the route; lds_slots = 0: the route does not apply to this build side
   std::shared_ptr<sq::PartitionedRows> lds_build;
   uint32_t lds_slots = 0;
+  // ... and of a build side with DUPLICATE keys, its DISTINCT keys (the non-empty slots of the general table) in bucket order:
+  // "row" d of that partition indexes lds_dmatch[d] = {first entry of the key's run in rows_by_slot, rows of the run}
+  std::shared_ptr<sq::PartitionedRows> lds_distinct;
+  sq::BufP lds_dkeys, lds_dmatch;
+  uint32_t lds_dslots = 0;
   // round 6: `unique` established on the LDS bucket tables (lds_build_first); the global table is not built until a
   // probe batch that cannot take the LDS route asks for it (`table_built` stays false until then)
   bool lds_first = false;

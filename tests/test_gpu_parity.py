@@ -284,8 +284,8 @@ def test_hash_join_lds_tables_general_keys(hip, oracle, monkeypatch, jt, nb, npr
 
 
 def test_hash_join_lds_tables_f64_keys_and_fallbacks(hip, oracle, monkeypatch):
-    """f64 keys compare by bit pattern on the LDS route too; NULL keys on either side, duplicate build keys and
-    Right / Full joins keep the global-table routes (same results)."""
+    """f64 keys compare by bit pattern on the LDS route too; NULL probe keys keep the global-table route; duplicate build
+    keys and Right / Full joins take the LDS tables through the un-permuted {run, pairs} form (same results)."""
     monkeypatch.setenv("SQLRS_LDS_JOIN", "1")
     rng = np.random.default_rng(19)
     nb, npr = 5000, 60_000
@@ -306,9 +306,59 @@ def test_hash_join_lds_tables_f64_keys_and_fallbacks(hip, oracle, monkeypatch):
         got = list(HashJoinExecutor(hip, [lb], [rb], jt, cond, sch, 2).execute())
         prof = hip.profile_read()
         hip.profile(False)
-        assert (prof.get("join_probe_lds", (0, 0))[1] > 0) == (variant == "plain"), (variant, prof)
+        assert (prof.get("join_probe_lds", (0, 0))[1] > 0) == (variant != "probe_nulls"), (variant, prof)
+        assert (prof.get("join_match_unpermute", (0, 0))[1] > 0) == (variant in ("dup_build", "full")), (variant, prof)
         exp = list(HashJoinExecutor(oracle, [lb], [rb], jt, cond, sch, 2).execute())
         assert_same(rows_of(got), rows_of(exp))
+
+
+@pytest.mark.parametrize("jt", ["inner", "left", "right", "full"])
+@pytest.mark.parametrize("shape", ["dup_x4", "dup_skewed", "unique", "empty_word_key"])
+@pytest.mark.parametrize("nb,npr,forced", [(900, 11_000, True), (60_000, 700_000, True), (280_000, 4_300_000, False)])
+def test_hash_join_lds_tables_duplicate_build_keys_and_outer_joins(hip, oracle, monkeypatch, jt, shape, nb, npr, forced):
+    """Round 6: DUPLICATE build keys (a probe row emits the run of build rows with its key in build order, hash_join.rs:172-177,
+    225-234) and Right / Full joins (an unmatched probe row emits (NULL, row), :235-248) matched on the LDS tables: the
+    tables hold the DISTINCT keys of the general table, the range is un-permuted into {run, pairs} per probe row and the
+    fill pass expands it.  Batches equal the oracle's bit for bit, over several probe batches."""
+    if shape == "unique" and jt in ("inner", "left"):
+        pytest.skip("the compacting form: test_hash_join_lds_tables_general_keys")
+    if not forced and (shape not in ("dup_x4", "unique") or jt in ("left",)):
+        pytest.skip("one large case per route")
+    if forced:
+        monkeypatch.setenv("SQLRS_LDS_JOIN", "1")
+    rng = np.random.default_rng(nb + len(jt) + len(shape))
+    A = np.int64(0x9E3779B97F4A7C15 - (1 << 64))
+    with np.errstate(over="ignore"):
+        if shape == "dup_x4":
+            base = rng.permutation(nb)[: nb // 4].astype(np.int64)
+            bk = np.concatenate([base] * 4)
+            rng.shuffle(bk)
+        elif shape == "dup_skewed":  # one key on a tenth of the build rows, the rest unique or doubled
+            bk = rng.integers(0, nb, nb, dtype=np.int64)
+            bk[rng.random(nb) < 0.1] = 5
+        else:
+            bk = rng.permutation(nb + nb // 3)[:nb].astype(np.int64)
+        bk = bk * A + np.int64(77)
+        pk = rng.integers(0, nb + nb // 2, npr, dtype=np.int64) * A + np.int64(77)
+        if shape == "empty_word_key":  # the key whose value is the general table's "empty" word, on both sides
+            bk[3] = bk[7] = np.int64(-1)
+            pk[::97] = np.int64(-1)
+    lb = pa.RecordBatch.from_arrays([pa.array(bk), pa.array(rng.integers(0, 1000, nb, dtype=np.int64))], names=["c0", "c1"])
+    rb = pa.RecordBatch.from_arrays([pa.array(pk), pa.array(rng.random(npr))], names=["c0", "c1"])
+    rbs = [rb] if (npr < 100_000 or not forced) else [rb.slice(0, npr // 3), rb.slice(npr // 3)]
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    hip.profile(True)
+    got = list(HashJoinExecutor(hip, [lb], rbs, jt, cond, sch, 2).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    assert prof.get("join_probe_lds", (0, 0))[1] > 0 and prof.get("join_match_unpermute", (0, 0))[1] > 0, prof
+    assert prof.get("join_probe_count", (0, 0))[1] == 0, prof
+    exp = list(HashJoinExecutor(oracle, [lb], rbs, jt, cond, sch, 2).execute())
+    assert [b.num_rows for b in got] == [b.num_rows for b in exp]
+    for g, e in zip(got, exp):
+        for c in range(g.num_columns):
+            assert g.column(c).equals(e.column(c)), c
 
 
 @pytest.mark.parametrize("first", ["1", "0"])

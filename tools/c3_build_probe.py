@@ -1,5 +1,6 @@
 """C3 build + probe (hash_join_create .. build_finish .. probe_indices .. destroy) REPS times in one process: what
-tools/timeline_ops.sh slices (CMD="python tools/c3_build_probe.py" DELIM=key_minmax_inv_kernel) and an event-timed figure."""
+tools/timeline_ops.sh slices (CMD="python tools/c3_build_probe.py" DELIM=key_minmax_inv_kernel) and an event-timed figure.
+MOD = probe key modulus (2 * NB: half the probe rows miss), DUP = build key multiplicity, JT = inner | left | right | full."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,13 +13,18 @@ nP, nB = int(float(os.environ.get("NP", 1e8))), int(float(os.environ.get("NB", 1
 mod = int(os.environ.get("MOD", nB))
 dk = datagen.fill_chunks(torch.empty(nB, dtype=torch.int64, device=dev), lambda i: datagen.dim_key_t(i, nB))
 fk = datagen.fill_chunks(torch.empty(nP, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF1, i, mod))
+if os.environ.get("DUP"):  # DUP=4: every build key ~4 times (bench.py's C3_join_dup_build_keys_x4), all probe rows match
+    dup = int(os.environ["DUP"])
+    dk = torch.randint(0, nB // dup, (nB,), dtype=torch.int64, device=dev, generator=torch.Generator(device=dev).manual_seed(44))
+    fk = datagen.fill_chunks(torch.empty(nP, dtype=torch.int64, device=dev), lambda i: datagen.key_t(0xF1, i, nB // dup))
+JT = {"inner": abi.JOIN_INNER, "left": abi.JOIN_LEFT, "right": abi.JOIN_RIGHT, "full": abi.JOIN_FULL}[os.environ.get("JT", "inner")]
 torch.cuda.synchronize()
 db, fb = bench.device_batch(abi, [dk], [abi.INT64]), bench.device_batch(abi, [fk], [abi.INT64])
 lk, _k1 = abi.pack_exprs([InputRef(0)]); rk, _k2 = abi.pack_exprs([InputRef(0)])
 rd = (C.c_int32 * 1)(abi.INT64)
 def both():
     j = C.c_void_p()
-    be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, lk, rk, None, 1, rd, C.byref(j)))
+    be.check(be.fn("hash_join_create")(be.ctx, JT, 1, lk, rk, None, 1, rd, C.byref(j)))
     be.check(be.fn("hash_join_build_push")(j, db.ptr)); be.check(be.fn("hash_join_build_finish")(j))
     o = C.POINTER(abi.Batch)()
     be.check(be.fn("hash_join_probe_indices")(j, fb.ptr, abi.MEM_DEVICE, C.byref(o)))
@@ -35,7 +41,7 @@ print(f"C3 build + probe: {best:.3f} ms = {(8 * nB + 20 * nP) / best / 1e6 / 800
 
 # probe alone (the join built once), event-timed + kernel classes
 j = C.c_void_p()
-be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, lk, rk, None, 1, rd, C.byref(j)))
+be.check(be.fn("hash_join_create")(be.ctx, JT, 1, lk, rk, None, 1, rd, C.byref(j)))
 be.check(be.fn("hash_join_build_push")(j, db.ptr)); be.check(be.fn("hash_join_build_finish")(j))
 def probe():
     o = C.POINTER(abi.Batch)()
@@ -57,7 +63,7 @@ if os.environ.get("HOSTTIMES", "1") == "1":
     for rep in range(20):
         be.synchronize()
         j = C.c_void_p(); o = C.POINTER(abi.Batch)()
-        t0 = time.perf_counter(); be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER, 1, lk, rk, None, 1, rd, C.byref(j)))
+        t0 = time.perf_counter(); be.check(be.fn("hash_join_create")(be.ctx, JT, 1, lk, rk, None, 1, rd, C.byref(j)))
         t1 = time.perf_counter(); be.check(be.fn("hash_join_build_push")(j, db.ptr))
         t2 = time.perf_counter(); be.check(be.fn("hash_join_build_finish")(j))
         t3 = time.perf_counter(); be.check(be.fn("hash_join_probe_indices")(j, fb.ptr, abi.MEM_DEVICE, C.byref(o)))
