@@ -346,8 +346,98 @@ static int bench_probe(int argc, char **argv) {
   return ok ? 0 : 1;
 }
 
+// ./bench_host_batches project [rows = 2e7] [batch = 1024]
+// ProjectExecutor `SELECT v, v * 3 + 1, v > 2^30` over pageable 1024-row host batches (one bare column, two computed ones):
+// sqlrs_project_push per batch against sqlrs_project_push_async with DEPTH tickets in flight.
+static int bench_project(int argc, char **argv) {
+  const int64_t n = argc > 2 ? (int64_t)std::atof(argv[2]) : 20000000, B = argc > 3 ? std::atoll(argv[3]) : 1024;
+  sqlrs_ctx_t *ctx = nullptr;
+  if (sqlrs_ctx_create(0, &ctx) != SQLRS_OK) {
+    std::printf("{\"error\": \"no device\"}\n");
+    return 2;
+  }
+  std::vector<int64_t> v((size_t)n);
+  for (int64_t i = 0; i < n; i++) v[(size_t)i] = (int64_t)(splitmix64(0xC2, (uint64_t)i) % (1ull << 31));
+  const int64_t k = (1ll << 30);
+  sqlrs_expr_node_t e0[1] = {}, e1[5] = {}, e2[3] = {};
+  e0[0].op = SQLRS_EXPR_INPUT_REF;
+  e1[0].op = SQLRS_EXPR_INPUT_REF;
+  e1[1].op = SQLRS_EXPR_CONSTANT; e1[1].dtype = SQLRS_INT64; e1[1].i = 3;
+  e1[2].op = SQLRS_EXPR_MULTIPLY;
+  e1[3].op = SQLRS_EXPR_CONSTANT; e1[3].dtype = SQLRS_INT64; e1[3].i = 1;
+  e1[4].op = SQLRS_EXPR_PLUS;
+  e2[0].op = SQLRS_EXPR_INPUT_REF;
+  e2[1].op = SQLRS_EXPR_CONSTANT; e2[1].dtype = SQLRS_INT64; e2[1].i = k;
+  e2[2].op = SQLRS_EXPR_GT;
+  sqlrs_expr_t exprs[3] = {{e0, 1, 0}, {e1, 5, 0}, {e2, 3, 0}};
+  const int64_t nb = (n + B - 1) / B;
+  std::vector<sqlrs_column_t> cols((size_t)nb);
+  std::vector<sqlrs_batch_t> batches((size_t)nb);
+  for (int64_t b = 0; b < nb; b++) {
+    const int64_t m = std::min<int64_t>(B, n - b * B);
+    host_col(cols[(size_t)b], SQLRS_INT64, v.data() + b * B, m);
+    std::memset(&batches[(size_t)b], 0, sizeof(sqlrs_batch_t));
+    batches[(size_t)b].num_rows = m;
+    batches[(size_t)b].num_columns = 1;
+    batches[(size_t)b].columns = &cols[(size_t)b];
+  }
+  const int DEPTH = 8;
+  double best[2] = {1e30, 1e30};
+  bool ok = true;
+  int64_t rows_out[2] = {0, 0};
+  for (int mode = 0; mode < 2; mode++)
+    for (int rep = 0; rep < 3; rep++) {
+      auto t0 = std::chrono::steady_clock::now();
+      sqlrs_project_t *pj = nullptr;
+      CHECK(sqlrs_project_create(ctx, 3, exprs, &pj));
+      int64_t got = 0;
+      auto consume = [&](sqlrs_batch_t *o, int64_t b) {
+        const int64_t m = o->num_rows;
+        if (rep == 0) { // every row of every column
+          const int64_t *iv = v.data() + b * B, *c0 = (const int64_t *)o->columns[0].values, *c1 = (const int64_t *)o->columns[1].values;
+          const uint8_t *c2 = (const uint8_t *)o->columns[2].values;
+          ok = ok && m == batches[(size_t)b].num_rows && o->num_columns == 3;
+          for (int64_t r = 0; ok && r < m; r++)
+            ok = c0[r] == iv[r] && c1[r] == iv[r] * 3 + 1 && (((c2[r >> 3] >> (r & 7)) & 1) != 0) == (iv[r] > k);
+        }
+        got += m;
+        sqlrs_batch_release(o);
+      };
+      if (mode == 0) {
+        for (int64_t b = 0; b < nb; b++) {
+          sqlrs_batch_t *o = nullptr;
+          CHECK(sqlrs_project_push(pj, &batches[(size_t)b], SQLRS_MEM_HOST, &o));
+          consume(o, b);
+        }
+      } else {
+        std::vector<sqlrs_ticket_t *> q((size_t)DEPTH, nullptr);
+        for (int64_t b = 0; b < nb + DEPTH; b++) {
+          if (b >= DEPTH) {
+            sqlrs_batch_t *o = nullptr;
+            CHECK(sqlrs_batch_wait(q[(size_t)(b % DEPTH)], &o));
+            consume(o, b - DEPTH);
+          }
+          if (b < nb) CHECK(sqlrs_project_push_async(pj, &batches[(size_t)b], &q[(size_t)(b % DEPTH)]));
+        }
+      }
+      sqlrs_project_destroy(pj);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      rows_out[mode] = got;
+      if (rep > 0 && ms < best[mode]) best[mode] = ms;
+    }
+  ok = ok && rows_out[0] == n && rows_out[1] == n;
+  std::printf("{\"rows\": %lld, \"batches\": %lld, \"batch_rows\": %lld, \"ms_push\": %.1f, \"Mrows_s_push\": %.1f, \"depth\": %d, "
+              "\"ms_push_async\": %.1f, \"Mrows_s_push_async\": %.1f, \"check\": \"%s\", \"note\": \"native caller (C ABI): SELECT v, v * 3 + 1, "
+              "v > 2^30 over pageable %lld-row host batches, one result batch per input batch on the host; best of 2 after a warm-up\"}\n",
+              (long long)n, (long long)nb, (long long)B, best[0], (double)n / best[0] / 1e3, DEPTH, best[1], (double)n / best[1] / 1e3,
+              ok ? "OK" : "mismatch", (long long)B);
+  sqlrs_ctx_destroy(ctx);
+  return ok ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && std::strcmp(argv[1], "filter") == 0) return bench_filter(argc, argv);
+  if (argc > 1 && std::strcmp(argv[1], "project") == 0) return bench_project(argc, argv);
   if (argc > 1 && std::strcmp(argv[1], "probe") == 0) return bench_probe(argc, argv);
   const int64_t n = argc > 1 ? (int64_t)std::atof(argv[1]) : 20000000, G = argc > 2 ? (int64_t)std::atof(argv[2]) : 1000000;
   const int64_t B = argc > 3 ? std::atoll(argv[3]) : 1024;

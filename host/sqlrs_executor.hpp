@@ -694,11 +694,16 @@ struct ProjectExecutor { // project.rs:6-9
   BoxedExecutor child;
   std::vector<std::string> output_names; // eval_field's names are the caller's business (binder); optional here
   size_t group = 0;                      // child batches per library call (see FilterExecutor)
+  size_t depth = 0;                      // sqlrs_project_push_async, that many tickets in flight (see FilterExecutor)
   BoxedExecutor execute() {
     struct S : Executor {
       HipCtxRef ctx; BoxedExecutor child; sqlrs_project_t *p = nullptr; std::vector<std::string> names;
-      size_t group = 0; std::deque<RecordBatch> ready; bool ended = false;
-      ~S() override { if (p) sqlrs_project_destroy(p); }
+      size_t group = 0, depth = 0; std::deque<RecordBatch> ready; bool ended = false;
+      std::deque<sqlrs_ticket_t *> inflight;
+      ~S() override {
+        for (sqlrs_ticket_t *t : inflight) { sqlrs_batch_t *o = nullptr; if (sqlrs_batch_wait(t, &o) == SQLRS_OK && o) sqlrs_batch_release(o); }
+        if (p) sqlrs_project_destroy(p);
+      }
       RecordBatch named(sqlrs_batch_t *out) {
         RecordBatch rb = detail::import_batch(out, nullptr);
         auto sch = std::make_shared<Schema>(*rb.schema);
@@ -707,6 +712,22 @@ struct ProjectExecutor { // project.rs:6-9
         return rb;
       }
       std::optional<RecordBatch> next() override { // one output batch per input batch (project.rs:15-27)
+        if (depth > 0) {
+          while (!ended && inflight.size() <= depth) {
+            auto b = child->next();
+            if (!b) { ended = true; break; }
+            detail::AbiBatch in(*b);
+            sqlrs_ticket_t *t = nullptr;
+            ctx->check(sqlrs_project_push_async(p, &in.b, &t)); // (`in` is read before the call returns)
+            inflight.push_back(t);
+          }
+          if (inflight.empty()) return std::nullopt;
+          sqlrs_ticket_t *t = inflight.front();
+          inflight.pop_front();
+          sqlrs_batch_t *out = nullptr;
+          ctx->check(sqlrs_batch_wait(t, &out));
+          return named(out);
+        }
         if (group > 1) {
           if (ready.empty() && !ended) {
             std::vector<RecordBatch> pending;
@@ -738,7 +759,7 @@ struct ProjectExecutor { // project.rs:6-9
       }
     };
     auto s = std::make_unique<S>();
-    s->ctx = ctx; s->child = std::move(child); s->names = output_names; s->group = group;
+    s->ctx = ctx; s->child = std::move(child); s->names = output_names; s->group = group; s->depth = depth;
     std::vector<detail::Lowered> low;
     std::vector<sqlrs_expr_t> ex;
     for (auto &e : exprs) low.push_back(detail::lower(e));

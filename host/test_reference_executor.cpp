@@ -306,6 +306,29 @@ int main() {
       } else {
         std::printf("ok   filter, push_async with %zu tickets in flight\n", depth);
       }
+      { // ... and Filter -> Project, both through their push_async (project.rs:15-27 over filter.rs:15-24)
+        FilterExecutor f2;
+        f2.ctx = ctx;
+        f2.expr = BoundExpr::binary_op(BinaryOperator::Gt, build_bound_input_ref(1), BoundExpr::constant(ScalarValue::Int64(50)));
+        f2.child = stream_iter(parts);
+        f2.depth = depth;
+        ProjectExecutor pe;
+        pe.ctx = ctx;
+        pe.exprs = {build_bound_input_ref(1), BoundExpr::binary_op(BinaryOperator::Plus, build_bound_input_ref(0), BoundExpr::constant(ScalarValue::Int64(1)))};
+        pe.child = f2.execute();
+        pe.output_names = {"salary", "id1"};
+        pe.depth = depth;
+        std::vector<RecordBatch> out2 = try_collect(pe.execute());
+        std::string got2;
+        for (size_t b = 0; b < out2.size(); b++)
+          for (int64_t r = 0; r < out2[b].num_rows(); r++) got2 += out2[b].columns[0]->value_to_string(r) + "," + out2[b].columns[1]->value_to_string(r) + ";";
+        if (out2.size() != parts.size() || got2 != "100,11;100,2;200,12;200,3;100,14;100,5;200,15;200,6;100,17;") {
+          failures++;
+          std::printf("FAIL filter+project with %zu tickets in flight: %zu batches, rows %s\n", depth, out2.size(), got2.c_str());
+        } else {
+          std::printf("ok   filter+project, push_async with %zu tickets in flight\n", depth);
+        }
+      }
       for (JoinType jt : {JoinType::Inner, JoinType::Left}) {
         TestChild t = build_test_child(jt);
         RecordBatch rb = build_table_i32({"a2", {10, 20, 30}}, {"b1", {4, 5, 6}}, {"c2", {70, 80, 90}});

@@ -469,6 +469,11 @@ int sqlrs_project_push(sqlrs_project_t *p, const sqlrs_batch_t *in, int out_mem,
  * launch sequence (an expression's row i depends on row i alone); anything else runs batch by batch.  On error no output
  * batch is left allocated. */
 int sqlrs_project_push_many(sqlrs_project_t *p, int n, const sqlrs_batch_t *const *in, int out_mem, sqlrs_batch_t **out);
+/* sqlrs_project_push without the wait (see sqlrs_filter_push_async; project.rs:15-27 polled one batch at a time): the fast
+ * path takes HOST batches of <= 4096 rows whose output columns are bare column references (int32 / int64 / float64 /
+ * boolean / utf8) or expressions over int32 / int64 / float64 columns with an int32 / int64 / float64 / boolean result
+ * (<= 6 computed columns, <= 12 columns in and out); sqlrs_batch_wait reports a division by zero of that batch. */
+int sqlrs_project_push_async(sqlrs_project_t *p, const sqlrs_batch_t *in, sqlrs_ticket_t **ticket);
 void sqlrs_project_destroy(sqlrs_project_t *p);
 
 /* [ref: src/executor/limit.rs:4-81  LimitExecutor{limit, offset, child}]  limit / offset are the constants

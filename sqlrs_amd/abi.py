@@ -384,6 +384,7 @@ class Backend:
             "batch_copy": (i, [vp, pb, i, ppb]),
             "filter_push_async": (i, [vp, pb, pvp]),
             "hash_join_probe_push_async": (i, [vp, pb, pvp]),
+            "project_push_async": (i, [vp, pb, pvp]),
             "batch_wait": (i, [vp, ppb]),
             "batch_import_arrow": (i, [vp, C.POINTER(ArrowArrayC), C.POINTER(ArrowSchemaC), ppb]),
             "batch_export_arrow": (i, [vp, pb, C.POINTER(C.c_char_p), C.POINTER(ArrowArrayC), C.POINTER(ArrowSchemaC)]),

@@ -38,7 +38,7 @@ void sa_flush(Ctx *ctx) {
   if (!r || !r->pend_n) return;
   r->pend_launch(r, ctx);
   r->pend_n = 0;
-  r->launched_seq = r->seq;
+  r->launched_seq = r->pend_last_seq;
   r->dirty = true;
 }
 void sa_drain(Ctx *ctx) {

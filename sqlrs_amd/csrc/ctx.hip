@@ -489,9 +489,9 @@ sqlrs_batch_t *emit_host_copy(Ctx *ctx, int ncols, const int32_t *dtypes, int64_
   o->out_mem = SQLRS_MEM_HOST;
   o->descs.resize((size_t)ncols);
   for (int c = 0; c < ncols; c++) {
-    const bool utf8 = dtypes[c] == SQLRS_UTF8 && offsets && offsets[c];
-    const size_t w = utf8 ? 1 : width_of(dtypes[c]);
-    if (!w) fail(SQLRS_ERR_INTERNAL, "emit_host_copy: fixed-width and Utf8 columns only");
+    const bool utf8 = dtypes[c] == SQLRS_UTF8 && offsets && offsets[c], boolean = dtypes[c] == SQLRS_BOOLEAN;
+    const size_t w = (utf8 || boolean) ? 1 : width_of(dtypes[c]);
+    if (!w) fail(SQLRS_ERR_INTERNAL, "emit_host_copy: fixed-width, Boolean and Utf8 columns only");
     sqlrs_column_t &d = o->descs[(size_t)c];
     d.dtype = dtypes[c];
     d.mem = SQLRS_MEM_HOST;
@@ -499,7 +499,7 @@ sqlrs_batch_t *emit_host_copy(Ctx *ctx, int ncols, const int32_t *dtypes, int64_
     d.offsets = nullptr;
     d.validity = nullptr;
     d.null_count = 0;
-    const size_t nbytes = utf8 ? (size_t)offsets[c][rows] : w * (size_t)rows;
+    const size_t nbytes = utf8 ? (size_t)offsets[c][rows] : boolean ? (size_t)(rows + 7) / 8 : w * (size_t)rows; // (Boolean: bit-packed)
     void *v = std::malloc(nbytes + 64);
     if (!v) fail(SQLRS_ERR_INTERNAL, "host allocation failed");
     o->host_blocks.push_back(v);

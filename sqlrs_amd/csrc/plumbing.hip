@@ -14,6 +14,7 @@
 #include "host_stage.hpp"
 #include "device_utils.hpp"
 #include "prims.hpp"
+#include "small_async.hpp"
 
 using namespace sq;
 
@@ -232,6 +233,251 @@ static DBatch project_batch(sqlrs_project *p, InBatch &ib, int out_mem) {
   }
   return o;
 }
+} // extern "C"
+
+namespace sq {
+// ---- one small HOST batch, one launch, no copy call (small_async.hpp): Project -------------------------------------------------
+// An output column is either a bare InputRef — copied by the HOST into the slot's output area at the push (int32 / int64 /
+// float64 / boolean / utf8: the rows do not move, project.rs:15-27) — or an expression over the batch's int32 / int64 /
+// float64 columns, run per row as a postfix program (sa_eval_row: the evaluator's semantics; int32 / int64 / float64 / boolean
+// results).  A wave owns 64 consecutive rows, so a validity bitmap (and a boolean result) leaves as one ballot word per wave.
+constexpr int SP_PROGS = 6; // computed columns per projection (their programs are copied into LDS: 6 x 392 B)
+struct SaOutCol {
+  uint32_t out_off, out_voff, width;
+  int32_t dtype;
+  int32_t prog;       // -1: the host copied the column at the push
+  uint32_t pre_nulls; // ... and counted its NULLs
+};
+struct SaProjectParams {
+  SaLayout lay; // the INPUT columns the programs read (in_off = SA_NONE: not staged)
+  int nout, nprog;
+  uint32_t prog_off; // SaProgram[nprog] in the slot's input area
+  SaOutCol oc[SA_MAX_COLS];
+  const uint8_t *in;
+  uint8_t *out;
+  unsigned long long seq;
+};
+static_assert(sizeof(SaProjectParams) <= SA_PARAM_MAX, "parameter block too large");
+__global__ __launch_bounds__(1024) void sa_project_kernel(SaGroup<SaProjectParams> grp) {
+  const SaProjectParams &p = grp.p[blockIdx.x]; // (one workgroup per batch of the group)
+  __shared__ __attribute__((aligned(8))) unsigned char s_prog_raw[SP_PROGS * sizeof(SaProgram)]; // (SaProgram has member initialisers)
+  const SaProgram *s_prog = (const SaProgram *)s_prog_raw;
+  __shared__ uint32_t s_nulls[SA_MAX_COLS], s_div0;
+  {
+    const uint32_t *src = (const uint32_t *)(p.in + p.prog_off);
+    uint32_t *dst = (uint32_t *)s_prog_raw;
+    const uint32_t nw = (uint32_t)p.nprog * (uint32_t)(sizeof(SaProgram) / 4);
+    for (uint32_t i = threadIdx.x; i < nw; i += 1024) dst[i] = src[i];
+  }
+  if (threadIdx.x < SA_MAX_COLS) s_nulls[threadIdx.x] = (int)threadIdx.x < p.nout ? p.oc[threadIdx.x].pre_nulls : 0u;
+  if (threadIdx.x == 0) s_div0 = 0;
+  __syncthreads();
+  const uint32_t rows = p.lay.rows;
+  const int lane = lane_id();
+  for (int c = 0; c < p.nout; c++) { // (uniform loop: the plan is a kernel argument)
+    const SaOutCol &oc = p.oc[c];
+    if (oc.prog < 0) continue;
+    const SaProgram &pr = s_prog[oc.prog];
+    for (int t = 0; t < 4; t++) {
+      if ((uint32_t)t * 1024u >= rows) break; // (uniform)
+      const uint32_t r = (uint32_t)t * 1024u + threadIdx.x, wbase = r & ~63u;
+      bool valid = false, div0 = false;
+      unsigned long long v = 0;
+      if (r < rows) v = sa_eval_row(pr, p.lay, p.in, r, &valid, &div0);
+      if (div0) s_div0 = 1u;
+      if (!valid) v = 0; // (the slot of a NULL: zero)
+      const uint64_t vm = __ballot(valid);
+      if (oc.dtype == SQLRS_BOOLEAN) {
+        const uint64_t bm = __ballot(valid && v != 0);
+        if (lane == 0 && wbase < rows) ((uint64_t *)(p.out + oc.out_off))[r >> 6] = bm;
+      } else if (r < rows) {
+        if (oc.width == 8) ((unsigned long long *)(p.out + oc.out_off))[r] = v;
+        else ((uint32_t *)(p.out + oc.out_off))[r] = (uint32_t)v;
+      }
+      if (lane == 0 && wbase < rows) {
+        ((uint64_t *)(p.out + oc.out_voff))[r >> 6] = vm;
+        const uint32_t nulls = min(64u, rows - wbase) - (uint32_t)__popcll(vm);
+        if (nulls) atomicAdd(&s_nulls[c], nulls);
+      }
+    }
+  }
+  sa_publish((SaHeader *)p.out, p.seq, rows, s_nulls, p.nout, s_div0);
+}
+static void sa_project_launch(SaRing *r, Ctx *ctx) {
+  SaGroup<SaProjectParams> g;
+  for (int i = 0; i < r->pend_n; i++) std::memcpy(&g.p[i], r->pend_buf + (size_t)i * SA_PARAM_MAX, sizeof(SaProjectParams));
+  sa_project_kernel<<<dim3((unsigned)r->pend_n), dim3(1024), 0, r->stream_of(r->pend_first_slot)>>>(g); // (reads nothing the ctx stream produces)
+  SQ_HIP(hipGetLastError());
+}
+// plans the batch (which columns are copied, which computed), lays it out in the slot and copies what the host copies;
+// false: not a batch for the fast path
+static bool sa_project_stage(const sqlrs_project *pj, const sqlrs_batch_t *in, uint8_t *in_area, uint8_t *out_area, SaProjectParams *pp,
+                             SaLayout *olay) {
+  if (!in || in->num_rows < 0 || in->num_rows > (int64_t)SA_MAX_ROWS || in->num_columns <= 0 || in->num_columns > SA_MAX_COLS ||
+      pj->exprs.empty() || pj->exprs.size() > (size_t)SA_MAX_COLS)
+    return false;
+  const uint32_t rows = (uint32_t)in->num_rows, vbytes = (rows + 7) / 8;
+  auto fixed_w = [](int32_t d) { return d == SQLRS_INT32 ? 4u : (d == SQLRS_INT64 || d == SQLRS_FLOAT64) ? 8u : 0u; };
+  for (int c = 0; c < in->num_columns; c++) {
+    const sqlrs_column_t &col = in->columns[c];
+    if (col.mem != SQLRS_MEM_HOST || col.length != in->num_rows) return false;
+  }
+  SaProgram progs[SP_PROGS];
+  bool read[SA_MAX_COLS] = {};
+  pp->nout = (int)pj->exprs.size();
+  pp->nprog = 0;
+  for (int e = 0; e < pp->nout; e++) {
+    const Expr &ex = pj->exprs[(size_t)e];
+    SaOutCol &oc = pp->oc[e];
+    oc.pre_nulls = 0;
+    if (ex.nodes.size() == 1 && ex.nodes[0].op == SQLRS_EXPR_INPUT_REF) {
+      const int ci = ex.nodes[0].index;
+      if (ci < 0 || ci >= in->num_columns) return false;
+      const sqlrs_column_t &col = in->columns[ci];
+      oc.prog = -1;
+      oc.dtype = col.dtype;
+      oc.width = fixed_w(col.dtype);
+      if (col.dtype == SQLRS_UTF8) {
+        if (!col.offsets || col.offsets[rows] < col.offsets[0] || (col.offsets[rows] > col.offsets[0] && !col.values)) return false;
+      } else if (col.dtype == SQLRS_BOOLEAN) {
+        if (rows && !col.values) return false;
+      } else if (!oc.width || (rows && !col.values))
+        return false;
+      continue;
+    }
+    if (pp->nprog >= SP_PROGS || !sa_compile(ex, in, &progs[pp->nprog])) return false;
+    const SaProgram &pr = progs[pp->nprog];
+    oc.prog = pp->nprog++;
+    oc.dtype = pr.result_dtype;
+    oc.width = fixed_w(pr.result_dtype);
+    if (!oc.width && pr.result_dtype != SQLRS_BOOLEAN) return false;
+    for (int k = 0; k < pr.n; k++)
+      if (pr.ins[k].op == SAO_COL) read[pr.ins[k].col] = true;
+  }
+  auto up64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  // input area: the columns a program reads | the programs
+  size_t in_at = 0;
+  SaLayout &lay = pp->lay;
+  lay.ncols = in->num_columns;
+  lay.rows = rows;
+  for (int c = 0; c < in->num_columns; c++) {
+    const sqlrs_column_t &col = in->columns[c];
+    SaCol &d = lay.c[c];
+    d.dtype = col.dtype;
+    d.width = fixed_w(col.dtype);
+    d.in_off = d.in_voff = d.out_off = d.out_voff = d.in_data = d.out_data = SA_NONE;
+    d.data_base = 0;
+    if (!read[c]) continue;
+    if (!d.width || (rows && !col.values)) return false; // (sa_compile admits only the fixed-width types)
+    d.in_off = (uint32_t)in_at;
+    in_at = up64(in_at + (size_t)d.width * rows);
+    if (col.validity && col.null_count != 0) {
+      d.in_voff = (uint32_t)in_at;
+      in_at = up64(in_at + vbytes + 8);
+    }
+  }
+  pp->prog_off = (uint32_t)in_at;
+  in_at = up64(in_at + sizeof(SaProgram) * (size_t)pp->nprog);
+  // output area: header | per column values (+ the bytes of a Utf8 column) + validity, whole 64-bit words of bitmap
+  size_t out_at = up64(sizeof(SaHeader));
+  olay->ncols = pp->nout;
+  olay->rows = rows;
+  for (int e = 0; e < pp->nout; e++) {
+    SaOutCol &oc = pp->oc[e];
+    SaCol &d = olay->c[e];
+    d.dtype = oc.dtype;
+    d.width = oc.width;
+    d.in_off = d.in_voff = d.in_data = d.out_data = SA_NONE;
+    d.data_base = 0;
+    const bool utf8 = oc.dtype == SQLRS_UTF8, boolean = oc.dtype == SQLRS_BOOLEAN;
+    d.out_off = (uint32_t)out_at;
+    out_at = up64(out_at + (utf8 ? 4 * ((size_t)rows + 1) : boolean ? (size_t)vbytes + 8 : (size_t)oc.width * rows));
+    d.out_voff = (uint32_t)out_at;
+    out_at = up64(out_at + vbytes + 8);
+    if (utf8) {
+      const sqlrs_column_t &col = in->columns[pj->exprs[(size_t)e].nodes[0].index];
+      d.out_data = (uint32_t)out_at;
+      out_at = up64(out_at + (size_t)(col.offsets[rows] - col.offsets[0]));
+    }
+    oc.out_off = d.out_off;
+    oc.out_voff = d.out_voff;
+  }
+  if (in_at > SA_AREA || out_at > SA_AREA) return false;
+  // the copies: what the programs read into the input area, bare columns straight into the output area
+  for (int c = 0; c < in->num_columns; c++) {
+    const SaCol &d = lay.c[c];
+    if (d.in_off == SA_NONE) continue;
+    const sqlrs_column_t &col = in->columns[c];
+    if (rows) std::memcpy(in_area + d.in_off, col.values, (size_t)d.width * rows);
+    if (d.in_voff != SA_NONE) std::memcpy(in_area + d.in_voff, col.validity, vbytes);
+  }
+  if (pp->nprog) std::memcpy(in_area + pp->prog_off, progs, sizeof(SaProgram) * (size_t)pp->nprog);
+  for (int e = 0; e < pp->nout; e++) {
+    SaOutCol &oc = pp->oc[e];
+    if (oc.prog >= 0) continue;
+    const sqlrs_column_t &col = in->columns[pj->exprs[(size_t)e].nodes[0].index];
+    const SaCol &d = olay->c[e];
+    if (oc.dtype == SQLRS_UTF8) {
+      int32_t *oo = (int32_t *)(out_area + d.out_off);
+      const int32_t base = col.offsets[0];
+      for (uint32_t i = 0; i <= rows; i++) oo[i] = col.offsets[i] - base;
+      if (oo[rows]) std::memcpy(out_area + d.out_data, (const uint8_t *)col.values + base, (size_t)oo[rows]);
+    } else if (oc.dtype == SQLRS_BOOLEAN) {
+      if (rows) std::memcpy(out_area + d.out_off, col.values, vbytes);
+    } else if (rows)
+      std::memcpy(out_area + d.out_off, col.values, (size_t)oc.width * rows);
+    if (col.validity && col.null_count != 0) {
+      std::memcpy(out_area + d.out_voff, col.validity, vbytes);
+      int64_t nulls = col.null_count;
+      if (nulls < 0) { // unknown: counted here
+        nulls = 0;
+        for (uint32_t i = 0; i < rows; i++) nulls += !((col.validity[i >> 3] >> (i & 7)) & 1);
+      }
+      oc.pre_nulls = (uint32_t)nulls;
+    }
+  }
+  return true;
+}
+} // namespace sq
+
+extern "C" {
+
+// sqlrs_project_push without the wait (see sqlrs_filter_push_async): *ticket stands for the HOST batch
+// sqlrs_project_push(p, in, SQLRS_MEM_HOST, ..) would return.  [ref: project.rs:15-27, polled one batch at a time]
+int sqlrs_project_push_async(sqlrs_project_t *p, const sqlrs_batch_t *in, sqlrs_ticket_t **ticket) {
+  if (ticket) *ticket = nullptr;
+  return guard(p->ctx, [&] {
+    Ctx *ctx = p->ctx;
+    if (!ticket) fail(SQLRS_ERR_INTERNAL, "push_async: null ticket");
+    SQ_HIP(hipSetDevice(ctx->device));
+    auto t = std::unique_ptr<sqlrs_ticket>(new sqlrs_ticket());
+    t->ctx = ctx;
+    const char *off_e = hook("SQLRS_ASYNC_FAST"); // test hook, read per call: 0 = every batch through the synchronous operator
+    if (!(off_e && off_e[0] == '0')) {
+      SaRing *r = sa_ring(ctx);
+      const int slot = r ? sa_take_slot(r) : -1;
+      if (slot >= 0) {
+        SaProjectParams pp;
+        if (sa_project_stage(p, in, r->in_area(slot), r->out_area(slot), &pp, &t->lay)) {
+          pp.in = r->in_area(slot);
+          pp.out = r->out_area(slot);
+          pp.seq = ++r->seq;
+          sa_enqueue(ctx, r, p, sa_project_launch, pp, slot);
+          t->slot = slot;
+          t->seq = pp.seq;
+          *ticket = t.release();
+          return;
+        }
+        r->busy[slot] = false;
+      }
+    }
+    sa_flush(ctx); // (tickets complete in issue order: what waits for a launch goes first)
+    InBatch ib(ctx, in); // the synchronous operator, its batch parked in the ticket
+    t->done = emit_batch(ctx, project_batch(p, ib, SQLRS_MEM_HOST), SQLRS_MEM_HOST);
+    *ticket = t.release();
+  });
+}
+
 int sqlrs_project_push_many(sqlrs_project_t *p, int n, const sqlrs_batch_t *const *in, int out_mem, sqlrs_batch_t **out) {
   return guard(p->ctx, [&] {
     Ctx *ctx = p->ctx;
@@ -296,7 +542,10 @@ int sqlrs_project_push_many(sqlrs_project_t *p, int n, const sqlrs_batch_t *cons
     split_rows_to_host(ctx, o, bounds, &p->pin_out, &p->pin_cap, n, out); // one copy per column, one slice per input batch
   });
 }
-void sqlrs_project_destroy(sqlrs_project_t *p) { delete p; }
+void sqlrs_project_destroy(sqlrs_project_t *p) {
+  if (p) sa_flush(p->ctx); // (a group of its batches may still wait for its launch; their tickets stay valid)
+  delete p;
+}
 
 // ------------------------------------------------------------------------- CrossJoin --
 int sqlrs_cross_join_create(sqlrs_ctx_t *ctx, sqlrs_cross_join_t **out) {

@@ -69,6 +69,8 @@ struct SaRing {
   const void *pend_owner = nullptr;
   void (*pend_launch)(SaRing *, Ctx *) = nullptr;
   unsigned long long launched_seq = 0; // the kernels of all tickets up to this sequence number are queued
+  unsigned long long pend_last_seq = 0; // the newest ticket of the pending group (NOT `seq`: the ticket whose push flushes another
+                                        // operator's group has its number already and joins the NEXT group)
   ~SaRing() {
     for (hipStream_t s : side)
       if (s) {
@@ -96,6 +98,7 @@ template <class P> inline void sa_enqueue(Ctx *ctx, SaRing *r, const void *owner
   std::memcpy(r->pend_buf + (size_t)r->pend_n * SA_PARAM_MAX, &p, sizeof(P));
   r->pend_owner = owner;
   r->pend_launch = launch;
+  r->pend_last_seq = p.seq;
   r->pend_n++;
   ctx->async_fast_batches++;
   if (r->pend_n >= r->group) sa_flush(ctx);

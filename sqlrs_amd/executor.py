@@ -384,8 +384,9 @@ class ProjectExecutor:
     """``ProjectExecutor { exprs, child }`` (project.rs:6-9)."""
 
     def __init__(self, backend: abi.Backend, exprs: List[BoundExpr], child: Iterable, out_mem: int = abi.MEM_HOST,
-                 output_names: Optional[Sequence[str]] = None, many: int = 0):
+                 output_names: Optional[Sequence[str]] = None, many: int = 0, depth: int = 0):
         self.backend, self.exprs, self.child, self.out_mem, self.output_names = backend, exprs, child, out_mem, output_names
+        self.depth = depth  # > 0: sqlrs_project_push_async with that many tickets in flight (see FilterExecutor)
         # many > 1: that many batches of the child go to sqlrs_project_push_many together (the same stream of output batches,
         # one per input batch, project.rs:15-27)
         self.many = many
@@ -414,6 +415,10 @@ class ProjectExecutor:
                         yield from flush()
                 if group:
                     yield from flush()
+                return
+            if self.depth > 0 and self.out_mem == abi.MEM_HOST and getattr(be.lib, be.prefix + "project_push_async", None) is not None:
+                yield from _async_stream(be, self.child, self.depth, lambda b, t: be.fn("project_push_async")(h, b.ptr, t),
+                                         lambda _b: self.output_names)
                 return
             for batch in self.child:  # project.rs:14-27
                 b = abi.as_batch(batch)

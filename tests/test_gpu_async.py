@@ -274,3 +274,139 @@ def test_async_divide_by_zero_is_the_evaluators_error(hip, oracle):
             list(FilterExecutor(be, e, [ok, bad, ok], **kw).execute())
         assert ei.value.status == abi.ERR_ARROW and "ivide by zero" in str(ei.value), (kw, str(ei.value))
     same_batches(list(FilterExecutor(hip, e, [ok], depth=1).execute()), list(FilterExecutor(oracle, e, [ok]).execute()))
+
+
+# ---- Project ---------------------------------------------------------------------------------------------------------
+def bool_batches(rng, sizes):
+    out = []
+    for rows in sizes:
+        out.append(pa.RecordBatch.from_arrays(
+            [pa.array(rng.integers(-100, 100, rows), mask=rng.random(rows) < 0.1), pa.array(rng.random(rows), mask=rng.random(rows) < 0.1),
+             pa.array(rng.integers(-5, 5, rows).astype(np.int32), mask=rng.random(rows) < 0.1),
+             pa.array([None if i % 7 == 3 else ("" if i % 5 == 0 else "s" * (i % 11) + str(i)) for i in range(rows)], type=pa.string()),
+             pa.array(rng.random(rows) < 0.5, mask=rng.random(rows) < 0.2)], names=["a", "b", "c", "s", "t"]))
+    return out
+
+
+PROJECTIONS = {
+    "refs": lambda: [InputRef(3), InputRef(0), InputRef(4), InputRef(1), InputRef(2), InputRef(0)],
+    "arith": lambda: [InputRef(0) + Constant(1, abi.INT64), InputRef(1) * InputRef(1), InputRef(2) - Constant(3, abi.INT32), InputRef(3)],
+    "bool_results": lambda: [InputRef(0) > Constant(0, abi.INT64), (InputRef(1) < Constant(0.5, abi.FLOAT64)) | (InputRef(0).eq(Constant(7, abi.INT64))),
+                             InputRef(4)],
+    "casts": lambda: [TypeCast(InputRef(1) * Constant(1e10, abi.FLOAT64), abi.INT32), TypeCast(InputRef(2), abi.FLOAT64) / Constant(4.0, abi.FLOAT64),
+                      TypeCast(InputRef(0) > Constant(0, abi.INT64), abi.INT64)],
+    "constants": lambda: [Constant(5, abi.INT64), Constant(None, abi.FLOAT64), InputRef(0), Constant(True, abi.BOOLEAN)],
+    "six_programs": lambda: [InputRef(0) + Constant(k, abi.INT64) for k in range(6)],
+}
+
+
+@pytest.mark.parametrize("proj", sorted(PROJECTIONS))
+@pytest.mark.parametrize("depth", [1, 5, 40])
+def test_project_push_async_yields_the_batches_of_push(hip, oracle, proj, depth):
+    """Round 6: sqlrs_project_push_async — bare column references copied by the host into the slot, expressions over the
+    fixed-width columns evaluated per row inside ONE launch (validity and boolean results as one ballot word per wave) —
+    is the synchronous ProjectExecutor's stream, and the oracle's, batch for batch (project.rs:15-27)."""
+    from sqlrs_amd.executor import ProjectExecutor
+    rng = np.random.default_rng(77 + depth)
+    bs = bool_batches(rng, [1024] * 12 + [0, 1, 63, 64, 65, 1000, 4096, 4097, 9000] + [1024] * 30)
+    exprs = PROJECTIONS[proj]()
+    names = [f"o{i}" for i in range(len(exprs))]
+    before = fast_batches(hip)
+    got = list(ProjectExecutor(hip, exprs, bs, output_names=names, depth=depth).execute())
+    took = fast_batches(hip) - before
+    eligible = sum(1 for b in bs if b.num_rows <= 4096)
+    if depth < 32:
+        assert took == eligible, (took, eligible)
+    else:
+        assert took > 0
+    same_batches(got, list(ProjectExecutor(hip, exprs, bs, output_names=names).execute()))
+    same_batches(got, list(ProjectExecutor(oracle, exprs, bs, output_names=names).execute()))
+
+
+def test_project_async_shapes_that_take_the_synchronous_operator(hip, oracle):
+    """a Utf8 / Boolean column inside an expression, more than six computed columns: the synchronous operator
+    inside push_async, same batches; a division by zero is the evaluator's error at the wait"""
+    from sqlrs_amd.executor import ProjectExecutor
+    rng = np.random.default_rng(9)
+    bs = bool_batches(rng, [1024, 10, 0, 2000])
+    for exprs in ([InputRef(4) & InputRef(4)], [InputRef(3).eq(InputRef(3))], [InputRef(0) + Constant(k, abi.INT64) for k in range(7)]):
+        names = [f"o{i}" for i in range(len(exprs))]
+        before = fast_batches(hip)
+        got = list(ProjectExecutor(hip, exprs, bs, output_names=names, depth=3).execute())
+        assert fast_batches(hip) == before
+        same_batches(got, list(ProjectExecutor(oracle, exprs, bs, output_names=names).execute()))
+    z = pa.RecordBatch.from_arrays([pa.array(np.arange(-3, 5)), pa.array(np.arange(8.0))], names=["a", "b"])
+    with pytest.raises(abi.ExecutorError, match="Divide by zero"):
+        list(ProjectExecutor(hip, [Constant(10, abi.INT64) / InputRef(0)], [z], output_names=["q"], depth=2).execute())
+    with pytest.raises(abi.ExecutorError, match="Divide by zero"):
+        list(ProjectExecutor(oracle, [Constant(10, abi.INT64) / InputRef(0)], [z], output_names=["q"]).execute())
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_async_project(hip, oracle, seed):
+    """random projections (column references of every type, random expression trees over the fixed-width columns) over random
+    schemas and batch sizes"""
+    from sqlrs_amd.executor import ProjectExecutor
+    rng = np.random.default_rng(4000 + seed)
+    bs = bool_batches(rng, [int(x) for x in rng.choice([0, 1, 7, 64, 100, 1000, 1024, 2047, 4096], size=10)])
+    kinds = {0: "i64", 1: "f64", 2: "i32"}
+    DT = {"i64": abi.INT64, "f64": abi.FLOAT64, "i32": abi.INT32}
+
+    def rand_num(kind, depth):
+        cols_k = [i for i, k in kinds.items() if k == kind]
+        r = rng.random()
+        if depth == 0 or r < 0.3:
+            if rng.random() < 0.7:
+                return InputRef(int(rng.choice(cols_k)))
+            return Constant(None if rng.random() < 0.1 else (float(np.round(rng.random() * 4 - 2, 2)) if kind == "f64" else int(rng.integers(-5, 6))), DT[kind])
+        if r < 0.45:
+            other = str(rng.choice([k for k in DT if k != kind]))
+            return TypeCast(rand_num(other, depth - 1), DT[kind])
+        a, b = rand_num(kind, depth - 1), rand_num(kind, depth - 1)
+        return {0: lambda: a + b, 1: lambda: a - b, 2: lambda: a * b}[int(rng.integers(0, 3))]()
+
+    def rand_bool(depth):
+        if depth == 0 or rng.random() < 0.5:
+            kind = str(rng.choice(list(DT)))
+            a, b = rand_num(kind, 2), rand_num(kind, 2)
+            return {0: lambda: a > b, 1: lambda: a <= b, 2: lambda: a.eq(b), 3: lambda: a.ne(b)}[int(rng.integers(0, 4))]()
+        a, b = rand_bool(depth - 1), rand_bool(depth - 1)
+        return (a & b) if rng.random() < 0.5 else (a | b)
+    exprs = []
+    for _ in range(int(rng.integers(1, 9))):
+        r = rng.random()
+        e = InputRef(int(rng.integers(0, 5))) if r < 0.4 else (rand_bool(2) if r < 0.6 else rand_num(str(rng.choice(list(DT))), 3))
+        if len(e.nodes()) <= 24 and (len(e.nodes()) == 1 or sum(1 for x in exprs if len(x.nodes()) > 1) < 6):
+            exprs.append(e)
+    if not exprs:
+        exprs = [InputRef(0)]
+    names = [f"o{i}" for i in range(len(exprs))]
+    before = fast_batches(hip)
+    got = list(ProjectExecutor(hip, exprs, bs, output_names=names, depth=int(rng.integers(1, 7))).execute())
+    assert fast_batches(hip) - before == len(bs)
+    same_batches(got, list(ProjectExecutor(oracle, exprs, bs, output_names=names).execute()))
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4, 7])
+def test_async_operators_chained_on_one_ctx(hip, oracle, depth):
+    """Filter -> Project -> HashJoin probe, every operator through its push_async on ONE ctx: a push that flushes another operator's
+    pending group must not mark its own ticket as launched (the C++ mirror's replay found the last ticket of such a chain
+    waiting for a launch that never came)"""
+    from sqlrs_amd.executor import ProjectExecutor
+    rng = np.random.default_rng(300 + depth)
+    bs = batches(rng, 0, [2, 2, 2, 1024, 1, 0, 3000, 7, 1024, 64, 2, 2, 2], 0.0)
+    pred = InputRef(0) > Constant(-20, abi.INT64)
+    exprs = [InputRef(0), InputRef(1) * Constant(2.0, abi.FLOAT64), InputRef(2)]
+    names = ["a", "b2", "c"]
+    lb = pa.RecordBatch.from_arrays([pa.array(np.arange(-100, 100, dtype=np.int64)), pa.array(np.arange(200, dtype=np.int64) * 10)], names=["k", "p"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+
+    def plan(be, d):
+        f = FilterExecutor(be, pred, bs, depth=d).execute()
+        pr = ProjectExecutor(be, exprs, f, output_names=names, depth=d).execute()
+        rb0 = pa.RecordBatch.from_arrays([pa.array([], type=pa.int64()), pa.array([], type=pa.float64()), pa.array([], type=pa.int32())], names=names)
+        return list(HashJoinExecutor(be, [lb], pr, "inner", cond, join_schema(lb, rb0), 2, depth=d).execute())
+    before = fast_batches(hip)
+    got = plan(hip, depth)
+    assert fast_batches(hip) - before == 3 * len(bs)
+    same_batches(got, plan(oracle, 0))
