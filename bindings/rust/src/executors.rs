@@ -24,6 +24,19 @@ impl<T> Drop for Guard<T> {
     fn drop(&mut self) { if !self.0.is_null() { unsafe { (self.1)(self.0) } } }
 }
 unsafe impl<T> Send for Guard<T> {}
+/// the tickets an async stream has in flight: every one is waited for (and its batch released) when the stream is dropped
+/// early — a ticket must be consumed before its ctx goes (sqlrs_hip.h) — declared AFTER the operator's Guard so that it is
+/// dropped first
+struct Tickets(std::collections::VecDeque<(*mut sqlrs_ticket_t, SchemaRef)>);
+impl Drop for Tickets {
+    fn drop(&mut self) {
+        for (t, _) in self.0.drain(..) {
+            let mut out = std::ptr::null_mut();
+            if unsafe { sqlrs_batch_wait(t, &mut out) } == SQLRS_OK && !out.is_null() { unsafe { sqlrs_batch_release(out) } }
+        }
+    }
+}
+unsafe impl Send for Tickets {}
 
 fn lower_all(exprs: &[BoundExpr]) -> Result<(Vec<Lowered>, Vec<sqlrs_expr_t>), ExecutorError> {
     let low: Vec<Lowered> = exprs.iter().map(lower).collect::<Result<_, _>>()?;
@@ -91,11 +104,11 @@ impl HipFilterAsyncExecutor {
         let mut f = std::ptr::null_mut();
         self.ctx.check(unsafe { sqlrs_filter_create(self.ctx.raw(), &expr.abi(), &mut f) })?;
         let _g = Guard(f, sqlrs_filter_destroy);
-        let mut inflight: std::collections::VecDeque<(*mut sqlrs_ticket_t, SchemaRef)> = std::collections::VecDeque::new();
+        let mut inflight = Tickets(std::collections::VecDeque::new());
         let mut child = self.child;
         let mut ended = false;
         loop {
-            while !ended && inflight.len() <= self.depth.max(1) {
+            while !ended && inflight.0.len() <= self.depth.max(1) {
                 match futures::StreamExt::next(&mut child).await {
                     None => ended = true,
                     Some(b) => {
@@ -103,11 +116,11 @@ impl HipFilterAsyncExecutor {
                         let inb = AbiBatch::new(&b)?; // read completely before push_async returns
                         let mut t = std::ptr::null_mut();
                         self.ctx.check(unsafe { sqlrs_filter_push_async(f, &inb.raw, &mut t) })?;
-                        inflight.push_back((t, b.schema()));
+                        inflight.0.push_back((t, b.schema()));
                     }
                 }
             }
-            match inflight.pop_front() {
+            match inflight.0.pop_front() {
                 None => break,
                 Some((t, schema)) => {
                     let mut out = std::ptr::null_mut();
@@ -293,6 +306,44 @@ impl HipProjectManyExecutor {
                 pending.clear();
             }
             if end { break; }
+        }
+    }
+}
+/// ... and polled ONE batch at a time through `sqlrs_project_push_async` with `depth` tickets in flight (see
+/// HipFilterAsyncExecutor; 11 -> 250 Mrows/s at 1024-row batches from the native caller).
+pub struct HipProjectAsyncExecutor { pub ctx: Arc<HipCtx>, pub exprs: Vec<BoundExpr>, pub child: BoxedExecutor, pub depth: usize }
+impl HipProjectAsyncExecutor {
+    #[try_stream(boxed, ok = RecordBatch, error = ExecutorError)]
+    pub async fn execute(self) {
+        let (_l, ex) = lower_all(&self.exprs)?;
+        let mut p = std::ptr::null_mut();
+        self.ctx.check(unsafe { sqlrs_project_create(self.ctx.raw(), ex.len() as i32, ex.as_ptr(), &mut p) })?;
+        let _g = Guard(p, sqlrs_project_destroy);
+        let mut inflight = Tickets(std::collections::VecDeque::new());
+        let mut child = self.child;
+        let mut ended = false;
+        loop {
+            while !ended && inflight.0.len() <= self.depth.max(1) {
+                match futures::StreamExt::next(&mut child).await {
+                    None => ended = true,
+                    Some(b) => {
+                        let b = b?;
+                        let schema: SchemaRef = Arc::new(Schema::new(self.exprs.iter().map(|e| e.eval_field(&b)).collect::<Vec<_>>()));
+                        let inb = AbiBatch::new(&b)?; // read completely before push_async returns
+                        let mut t = std::ptr::null_mut();
+                        self.ctx.check(unsafe { sqlrs_project_push_async(p, &inb.raw, &mut t) })?;
+                        inflight.0.push_back((t, schema));
+                    }
+                }
+            }
+            match inflight.0.pop_front() {
+                None => break,
+                Some((t, schema)) => {
+                    let mut out = std::ptr::null_mut();
+                    self.ctx.check(unsafe { sqlrs_batch_wait(t, &mut out) })?; // consumes the ticket, also on error
+                    yield import_batch(schema, out)?;
+                }
+            }
         }
     }
 }
