@@ -94,4 +94,19 @@ const uint64_t *hash_join_dense_bits(sqlrs_hash_join *j);
 // build rows per key of [dup_min, dup_min + dup_range) of a join with duplicate build keys over a dense range
 // (join.hip); null when the build side has no such range
 const uint32_t *hash_join_dup_mult(sqlrs_hash_join *j);
+// ---- general keys on LDS bucket tables (join_lds.hip) ----
+// the probe rows of one batch in (range, bucket) order with the match of every row's key beside them — the build row, or an
+// index into lds_dmatch when `distinct` (duplicate build keys), or 0xffffffff; `ok` = false: route not taken
+struct LdsJoinMatch {
+  bool ok = false;
+  BufP idx, mpart; // u32[n] each: original row, build row | DENSE_EMPTY
+};
+// a build side that will be probed on LDS tables establishes `unique` there and leaves the general table unbuilt; false: not such
+// a build side, or its keys are not unique (the caller builds the general table)
+bool lds_build_first(sqlrs_hash_join *j);
+LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk, bool distinct = false);
+int64_t lds_join_tiles(int64_t n); // look-back descriptors lds_join_restore needs for a batch of n rows
+void lds_join_restore(Ctx *ctx, const LdsJoinMatch &lm, int64_t n, uint64_t *left_idx, uint32_t *right_idx, uint64_t *desc, unsigned *ticket,
+                      uint64_t *total, int use_ticket);
+void lds_join_unpermute(sqlrs_hash_join *j, const LdsJoinMatch &lm, int64_t n, int outer_right, uint2 *match, uint32_t *counts, int grouped);
 }
