@@ -1857,7 +1857,8 @@ def bench_host_resident(be, abi, datagen, torch, dev):
             out["C4_host_batches_1024_native"] = {"error": repr(e)[:200]}
         # the STREAMING operators at the same batch shape (round-3 review: "a real drop-in would be slower than the CPU there,
         # and the line hides it"): Filter per batch and through sqlrs_filter_push_many; HashJoin probe per batch and _many
-        for leg, mode in (("C2_host_batches_1024", "filter"), ("C3_probe_host_batches_1024", "probe")):
+        # (round 6: Project — SELECT v, v * 3 + 1, v > k — per batch and through sqlrs_project_push_async)
+        for leg, mode in (("C2_host_batches_1024", "filter"), ("C3_probe_host_batches_1024", "probe"), ("Project_host_batches_1024", "project")):
             try:
                 r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=600)
                 out[leg] = json.loads(r.stdout.strip().splitlines()[-1])

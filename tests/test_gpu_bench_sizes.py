@@ -199,6 +199,64 @@ def test_full_size_c3_join_pairs(env, variant):
     out.release()
 
 
+@pytest.mark.parametrize("jt", ["inner", "full"])
+def test_full_size_c3_join_duplicate_build_keys(env, jt):
+    """Round 6: 1e8 probe rows against 1e6 build rows whose sparse keys repeat ~4 times (Inner: every probe row matches ->
+    ~4e8 pairs) and, for Full, a probe side half of whose keys have no partner — the LDS bucket-table route with the DISTINCT keys
+    of the general table (join_lds.hip).  Checked on the device: pair count = sum of the build multiplicities of the probe keys
+    (+ one pair per unmatched probe row), probe-row major, build insertion order inside a probe row, equal keys on both sides,
+    NULL left index exactly on the unmatched rows (hash_join.rs:172-177, 225-248)."""
+    t, abi, d = env.torch, env.abi, env.datagen
+    from sqlrs_amd.expr import InputRef
+    nP, nB, D = 100_000_000, 1_000_000, 250_000
+    A_s = 0x9E3779B97F4A7C15 - (1 << 64)
+    g = t.Generator(device=env.dev).manual_seed(44)
+    bslot = t.randint(0, D, (nB,), dtype=t.int64, device=env.dev, generator=g)
+    pslot = d.fill_chunks(t.empty(nP, dtype=t.int64, device=env.dev), lambda i: d.key_t(0xF1, i, D if jt == "inner" else 2 * D))
+    dk, fk = bslot * A_s + 12345, pslot * A_s + 12345
+    mult = t.bincount(bslot, minlength=2 * D)
+    per_row = mult[pslot]
+    expect = int(per_row.sum().item()) + (int((per_row == 0).sum().item()) if jt == "full" else 0)
+    del per_row
+    t.cuda.synchronize()
+    be = env.be
+    lk, _k1 = abi.pack_exprs([InputRef(0)])
+    rk, _k2 = abi.pack_exprs([InputRef(0)])
+    rd = (C.c_int32 * 1)(abi.INT64)
+    j = C.c_void_p()
+    be.check(be.fn("hash_join_create")(be.ctx, abi.JOIN_INNER if jt == "inner" else abi.JOIN_FULL, 1, lk, rk, None, 1, rd, C.byref(j)))
+    be.check(be.fn("hash_join_build_push")(j, env.bench.device_batch(abi, [dk], [abi.INT64]).ptr))
+    be.check(be.fn("hash_join_build_finish")(j))
+    be.profile(True)
+    o = C.POINTER(abi.Batch)()
+    be.check(be.fn("hash_join_probe_indices")(j, env.bench.device_batch(abi, [fk], [abi.INT64]).ptr, abi.MEM_DEVICE, C.byref(o)))
+    prof = be.profile_read()
+    be.profile(False)
+    out = be.wrap(o)
+    be.fn("hash_join_destroy")(j)
+    be.synchronize()
+    assert prof.get("join_match_unpermute", (0, 0))[1] > 0 and prof.get("join_probe_count", (0, 0))[1] == 0, prof
+    m = out.num_rows
+    assert m == expect
+    left = view(env, out.column(0), m, t.int64)
+    right = view(env, out.column(1), m, t.int32).to(t.int64) & 0xffffffff
+    assert bool((right[1:] >= right[:-1]).all().item())                              # probe-row major
+    if jt == "inner":
+        assert bool(((right[1:] != right[:-1]) | (left[1:] > left[:-1])).all().item())   # build insertion order inside a probe row
+        assert bool((dk[left] == fk[right]).all().item())                                # the pair joins equal keys
+    else:
+        lv = out.column(0)
+        assert lv.null_count == int((mult[pslot] == 0).sum().item())
+        vb = env.bench._tensor_view(t, lv.validity, (m + 63) // 64, t.int64, env.dev)  # (device bitmaps are whole 64-bit words)
+        valid = ((vb[:, None] >> t.arange(64, device=env.dev, dtype=t.int64)[None, :]) & 1).flatten()[:m].to(t.bool)
+        assert bool((valid == (mult[pslot[right]] > 0)).all().item())                    # NULL exactly where the probe key has no partner
+        lm, rm = left[valid], right[valid]
+        assert bool((dk[lm] == fk[rm]).all().item())
+        assert bool(((rm[1:] != rm[:-1]) | (lm[1:] > lm[:-1])).all().item())
+        del valid, lm, rm, vb
+    out.release()
+
+
 def _run_hash_agg(env, key, val):
     abi, be = env.abi, env.be
     from sqlrs_amd.expr import AggFunc, InputRef

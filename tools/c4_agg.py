@@ -2,7 +2,7 @@
 event-timed best of REPS per variant of an env hook that the library reads per call, e.g.
   VAR=SQLRS_RP_SLIM VALS=1,0 python tools/c4_agg.py        (slim / 16-byte rows out of the claimed level)
 and what tools/timeline_ops.sh slices:  CMD="python tools/c4_agg.py" DELIM=key_stats_kernel bash tools/timeline_ops.sh
-SHAPE=uniform|zipf|sorted, N / G = rows / groups, WHERE=1 adds `val > 0.5` handed to the aggregate."""
+SHAPE=uniform|zipf|sorted, SPARSE=1 = the same groups under keys k * A + B, N / G = rows / groups, WHERE=1 adds `val > 0.5` handed to the aggregate."""
 import os as _os; _os.environ.setdefault("SQLRS_HOOKS", "1")  # the SQLRS_* tuning hooks are consulted only in a process that opts in (common.hpp: hook)
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,6 +20,8 @@ if shape == "sorted":
 elif shape == "zipf":
     u = torch.rand(n, device=dev, dtype=torch.float64)
     key = ((G ** u - 1).to(torch.int64).clamp_(0, G - 1) * 7919 + 13) % G  # log-uniform ranks: Zipf(1)-like weights
+if os.environ.get("SPARSE") == "1":  # keys k -> k * A + B: a bijection of int64, the groups no longer fill a range
+    key = key * (0x9E3779B97F4A7C15 - (1 << 64)) + 12345
 val = datagen.fill_chunks(torch.empty(n, dtype=torch.float64, device=dev), lambda i: datagen.val_t(0xF2, i))
 torch.cuda.synchronize()
 b = bench.device_batch(abi, [key, val], [abi.INT64, abi.FLOAT64])
