@@ -1576,7 +1576,8 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   // The fill pass scans the pair counts of its 64 probe rows itself, so only one sum per 64-row group is scanned globally
   // (round 6: per-row counts + offsets were 0.4 + 0.8 GB written and 1.2 GB read for 1e8 probe rows, 0.45 ms of scan).  A build
   // side of >= 2^26 rows — 64 runs of that length overflow a 32-bit sum — keeps per-row counts.
-  const int grouped = j->nB < (1ll << 26) ? 1 : 0;
+  const char *gr_e = hook("SQLRS_JOIN_GROUPED"); // test hook, read per call: 0 = per-row counts whatever the build side's size
+  const int grouped = (j->nB < (1ll << 26) && !(gr_e && std::atoi(gr_e) == 0)) ? 1 : 0;
   const int64_t nscan = grouped ? ceil_div(n, 64) : n;
   BufP counts = ctx->alloc(4 * (size_t)nscan), offsets = ctx->alloc(8 * (size_t)nscan), total = ctx->alloc(8);
   BufP match = ctx->alloc(8 * (size_t)n);

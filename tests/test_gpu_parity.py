@@ -312,6 +312,29 @@ def test_hash_join_lds_tables_f64_keys_and_fallbacks(hip, oracle, monkeypatch):
         assert_same(rows_of(got), rows_of(exp))
 
 
+@pytest.mark.parametrize("jt", ["inner", "full"])
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_hash_join_per_row_counts_form(hip, oracle, monkeypatch, jt, lds):
+    """build sides of >= 2^26 rows keep per-row pair counts + offsets (64 runs of that length overflow a 32-bit group sum): the
+    form is forced here (SQLRS_JOIN_GROUPED=0) on both count passes — the LDS route's un-permute and the general table's probe"""
+    monkeypatch.setenv("SQLRS_JOIN_GROUPED", "0")
+    monkeypatch.setenv("SQLRS_LDS_JOIN", lds)
+    rng = np.random.default_rng(5 + len(jt))
+    nb, npr = 30_000, 400_001
+    bk = rng.integers(0, nb // 3, nb, dtype=np.int64) * np.int64(1_000_003) + np.int64(9)
+    pk = rng.integers(0, nb // 2, npr, dtype=np.int64) * np.int64(1_000_003) + np.int64(9)
+    lb = pa.RecordBatch.from_arrays([pa.array(bk), pa.array(np.arange(nb, dtype=np.int64))], names=["c0", "c1"])
+    rb = pa.RecordBatch.from_arrays([pa.array(pk), pa.array(rng.random(npr))], names=["c0", "c1"])
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    got = list(HashJoinExecutor(hip, [lb], [rb.slice(0, 100_000), rb.slice(100_000)], jt, cond, sch, 2).execute())
+    exp = list(HashJoinExecutor(oracle, [lb], [rb.slice(0, 100_000), rb.slice(100_000)], jt, cond, sch, 2).execute())
+    assert [b.num_rows for b in got] == [b.num_rows for b in exp]
+    for g, e in zip(got, exp):
+        for c in range(g.num_columns):
+            assert g.column(c).equals(e.column(c)), c
+
+
 @pytest.mark.parametrize("jt", ["inner", "left", "right", "full"])
 @pytest.mark.parametrize("shape", ["dup_x4", "dup_skewed", "unique", "empty_word_key"])
 @pytest.mark.parametrize("nb,npr,forced", [(900, 11_000, True), (60_000, 700_000, True), (280_000, 4_300_000, False)])
