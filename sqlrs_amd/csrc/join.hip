@@ -329,6 +329,9 @@ constexpr int JD_WAVES = 8;
 #ifndef JD_OCC
 #define JD_OCC 2
 #endif
+#ifndef JD_DBG
+#define JD_DBG 0
+#endif
 constexpr int JD_ITEMS = JD_ITEMS_N;
 constexpr int JD_TILE = JD_WAVES * JD_ITEMS * 64;
 constexpr int JD_BLOCK = (JD_WAVES + 1) * 64;
@@ -517,7 +520,11 @@ __global__ __launch_bounds__(JD_BLOCK, JD_OCC) void join_probe_dense_kernel(
     __syncthreads(); // (1) the workers' counts are in s_wave
     uint32_t c = lane < JD_WAVES ? s_wave[lane] : 0;
     uint64_t agg = wave_sum_u32(c);
+#if JD_DBG & 2 // (measurement: no look-back; wrong offsets)
+    uint64_t excl = (uint64_t)tile * (JD_TILE / 2);
+#else
     uint64_t excl = lookback_wave(desc, tile, agg, timeout);
+#endif
     if (lane == 0) {
       s_excl = excl;
       if (tile == num_tiles - 1) *total = excl + agg;
@@ -542,7 +549,11 @@ __global__ __launch_bounds__(JD_BLOCK, JD_OCC) void join_probe_dense_kernel(
       isnull = !((validity[rc >> 6] >> (rc & 63)) & 1);
     }
     uint32_t h = DENSE_EMPTY;
+#if JD_DBG & 1 // (measurement: no table lookups)
+    if (r < n && !isnull && d < dt.range) h = (uint32_t)d;
+#else
     if (r < n && !isnull && d < dt.range) h = dense_get(dt, d);
+#endif
     if (HASV && r < n && isnull) h = dt.null_head;
     head[j] = h;
   }
