@@ -322,7 +322,17 @@ __global__ __launch_bounds__(BLOCK) void join_probe_unique_kernel(
 // block, plus a scan wave that owns the decoupled look-back (same structure and same reason as
 // filter_cmp_const_kernel, select.hip: with 2048-row tiles the probe ran at the look-back's pace,
 // ~47 tiles/us = 97 Grows/s, not at the memory system's).
-constexpr int JD_WAVES = 8;
+// (Round 6, where the compacting probe's time goes — C3 half-hit, 1e8 probe rows, probe alone, tools/build_obj_variant.sh with
+//  -DJD_DBG / -DJD_WAVES_N / -DJD_ITEMS_N / -DJD_OCC: as shipped 0.56-0.59 ms; without the table lookups 0.40; without the
+//  look-back (wrong offsets) 0.50; without both 0.34 = the 1.4 GB of keys and pairs at 4.1 TB/s.  8 waves x 16 rows per lane at
+//  four workgroups per CU: 0.43 without the look-back — twice the waves hide the lookups — but 0.71 with it (twice the tiles on
+//  the chain); 8 x 16 / 8 x 24 at two per CU: 0.70 / 0.54.  More worker waves on the SAME number of tiles — 15 x 16, 11 x 24,
+//  12 x 20 at two per CU, 15 x 24 at one: 0.54-0.55, 15 x 32: 0.60.  The look-back's cost is the cross-XCD latency of a
+//  predecessor's word times the rounds a tile waits, and only long tiles amortise it; nothing here is worth a changed default.)
+#ifndef JD_WAVES_N
+#define JD_WAVES_N 8
+#endif
+constexpr int JD_WAVES = JD_WAVES_N;
 #ifndef JD_ITEMS_N
 #define JD_ITEMS_N 32
 #endif
