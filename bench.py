@@ -1426,6 +1426,20 @@ def bench_operators(be, abi, datagen, torch, dev, reps=3):
         sv = sorted(vals)
         res["C4_agg"]["ms_processes"] = {"n": len(vals), "min": sv[0], "median": sv[len(sv) // 2], "max": sv[-1], "values": vals,
                                          "note": "the same leg (tools/c4_agg.py, event-timed best of 5) in fresh processes; values[0] = this process"}
+    # ---- C4 over GENERAL int64 keys (round 6: the keys k -> k * A + B no longer fill a range — the groups of a real id
+    #      column): hashed buckets, probing LDS tables, 20-byte rows through two partition levels instead of the dense keys'
+    #      12-byte rows through one.  Not a BASELINE config; the fraction is of the same algorithmic bytes as C4's.
+    key_sp = key * (0x9E3779B97F4A7C15 - (1 << 64)) + 12345
+    torch.cuda.synchronize()
+    b_dense, b = b, device_batch(abi, [key_sp, val], [abi.INT64, abi.FLOAT64])
+    ms_sp = timed(run_agg)
+    profile_of(run_agg, "C4 agg sparse keys")
+    by_sp = 16 * n + 24 * groups[0]
+    res["C4_agg_sparse_keys"] = {"rows": n, "groups": groups[0], "ms": round(ms_sp, 3), "Mrows_s": round(n / ms_sp / 1e3, 1),
+                                 "GBps": round(by_sp / ms_sp / 1e6, 1), "frac": round(by_sp / ms_sp / 1e6 / HBM_PEAK_GBPS, 4),
+                                 "note": "general (non-dense) int64 group keys: two hashed partition levels + probing LDS tables"}
+    b = b_dense
+    del key_sp
     # ---- C4 with a WHERE: HashAgg(Filter(scan)), val > 0.5 — the filter handed to the aggregate (sqlrs_hash_agg_set_filter:
     #      evaluated by the partition pass) against the same plan as two operators (filter.rs:13-25 feeding hash_agg.rs:44)
     pred = (InputRef(1) > Constant(0.5, abi.FLOAT64)).pack()
