@@ -2452,7 +2452,12 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       const int psrc = !in.filter.col ? -1 : ((nv >= 1 && (const void *)in.filter.col == in.vals[0]) ? 1 : 3);
       // chunk histograms of the next level counted by this kernel (H2): every bucket needs a 4-byte counter in LDS
       const char *h2_e = hook("SQLRS_RP_H2"); // A/B hook, read per call: 0 = level 2 runs its own histogram pass
-      const bool h2 = pack && nv == 1 && (ROWS == 12 || ROWS == 16) && ct_env == 1 && (size_t)P * 4 <= 24 * 1024 && !(h2_e && std::atoi(h2_e) == 0);
+      // (round 6: unpacked rows of hashed partitions too, on the 512-thread tile — its 22-byte staging rows leave 16 KiB: P <= ~3000
+      //  buckets, C4 over general keys; 65 536 buckets — the sparse-key C5 — keep the histogram pass.  SQLRS_RP_H2_UNPACKED=0: off)
+      const char *h2u_e = hook("SQLRS_RP_H2_UNPACKED");
+      const bool h2_unpacked = !pack && nv == 1 && ROWS == 12 && psrc != 3 && !(h2u_e && std::atoi(h2u_e) == 0) &&
+                               (size_t)RP_TILE * (8 * 2 + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8) + (size_t)WG * 8 + (size_t)P * 4 <= 159 * 1024;
+      const bool h2 = (pack || h2_unpacked) && nv == 1 && (ROWS == 12 || ROWS == 16) && ct_env == 1 && (size_t)P * 4 <= 24 * 1024 && !(h2_e && std::atoi(h2_e) == 0);
       BufP chist = h2 ? ctx->alloc(4 * (size_t)max_chunks * ((size_t)1 << p2_bits)) : nullptr;
       co.hist = chist ? chist->as<uint32_t>() : nullptr;
       const size_t clds = (size_t)RP_TILE * (pack ? 8 * (1 + nv) : 8 * (1 + nv) + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8) +
@@ -2481,6 +2486,16 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
         else if (nv == 0) { if (pack) SQ_CS(0, 12, true); else SQ_CS(0, 12, false); }
         // (768 threads x 8 rows for the unpacked rows of hashed partitions too: sparse-key C5 level 1 6.91 -> 6.81 ms in one process;
         //  SQLRS_RP_L1G_WG=512, read per call, = the eight-wave form; a predicate on a column of its own keeps it: 14 spilled registers)
+        else if (!pack && h2) { // unpacked rows + the next level's counts: the 512-thread tile (the 768-thread one has no room for them)
+#define SQ_CH(PS)                                                                                                   \
+  do {                                                                                                              \
+    auto kfn = rp_chunk_scatter_kernel<1, 512, 12, false, PS, true>;                                                \
+    allow_big_lds(ctx, kfn, 159 * 1024);                                                                            \
+    kfn<<<dim3(cwgs), dim3(512), clds, ctx->stream>>>(k, a0, a1, in.filter, n, co, P, p2_bits, d1, tiles1, ctpw, sink, kp); \
+  } while (0)
+          if (psrc < 0) SQ_CH(-1); else SQ_CH(1);
+#undef SQ_CH
+        }
         else if (!pack && psrc != 3 && !(hook("SQLRS_RP_L1G_WG") && std::atoi(hook("SQLRS_RP_L1G_WG")) == 512)) {
           const size_t clds768 = (size_t)RP_TILE * (8 * (1 + nv) + 4 + 2) + (size_t)768 * (4 + 4 + 8 + 8) + (clds - ((size_t)RP_TILE * (8 * (1 + nv) + 4 + 2) + (size_t)WG * (4 + 4 + 8 + 8)));
 #define SQ_CG(PS)                                                                                                   \

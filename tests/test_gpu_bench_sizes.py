@@ -257,15 +257,18 @@ def test_full_size_c3_join_duplicate_build_keys(env, jt):
     out.release()
 
 
-def _run_hash_agg(env, key, val):
+def _run_hash_agg(env, key, val, where=False):
     abi, be = env.abi, env.be
-    from sqlrs_amd.expr import AggFunc, InputRef
+    from sqlrs_amd.expr import AggFunc, Constant, InputRef
     gb, _k = abi.pack_exprs([InputRef(0)])
     keep = []
     aggs = (abi.AggFunc * 2)(AggFunc("count", InputRef(1), abi.INT64).abi_struct(keep),
                              AggFunc("sum", InputRef(1), abi.FLOAT64).abi_struct(keep))
     a = C.c_void_p()
     be.check(be.fn("hash_agg_create")(be.ctx, 1, gb, 2, aggs, C.byref(a)))
+    if where:  # WHERE val > 0.5 handed to the aggregate: evaluated inside the first partition pass
+        pred = (InputRef(1) > Constant(0.5, abi.FLOAT64)).pack()
+        be.check(be.fn("hash_agg_set_filter")(a, C.byref(pred.abi)))
     be.check(be.fn("hash_agg_push")(a, env.bench.device_batch(abi, [key, val], [abi.INT64, abi.FLOAT64]).ptr))
     o = C.POINTER(abi.Batch)()
     be.check(be.fn("hash_agg_finish")(a, abi.MEM_DEVICE, C.byref(o)))
@@ -274,7 +277,7 @@ def _run_hash_agg(env, key, val):
     return be.wrap(o)
 
 
-@pytest.mark.parametrize("keys", ["uniform", "sparse", "sorted", "sorted_sparse"])
+@pytest.mark.parametrize("keys", ["uniform", "sparse", "sorted", "sorted_sparse", "where_sparse"])
 def test_full_size_c4_group_by(env, keys):
     """C4: 2e8 rows, 1e6 int64 groups, COUNT + SUM(f64): counts = bincount (bit-exact), sums =
     index_add_ (1e-9 relative), every key once, groups in first-seen order (hash_agg.rs:98,132).
@@ -288,18 +291,30 @@ def test_full_size_c4_group_by(env, keys):
         key = t.sort(key).values
     val = d.fill_chunks(t.empty(n, dtype=t.float64, device=env.dev), lambda i: d.val_t(0xF2, i))
     t.cuda.synchronize()
-    exp_cnt = t.bincount(key, minlength=G)
-    exp_sum = t.zeros(G, dtype=t.float64, device=env.dev).index_add_(0, key, val)
-    first = first_seen_rows(env, key, G)
+    where = keys.startswith("where")  # (round 6: general keys + a fused WHERE: the unpacked first level counts level 2's digits itself)
+    if where:
+        keep = val > 0.5
+        kk, vk = key[keep], val[keep]
+        exp_cnt = t.bincount(kk, minlength=G)
+        exp_sum = t.zeros(G, dtype=t.float64, device=env.dev).index_add_(0, kk, vk)
+        first = t.full((G,), 1 << 62, dtype=t.int64, device=env.dev)
+        first.scatter_reduce_(0, kk, t.nonzero(keep).flatten(), reduce="amin")
+        del keep, kk, vk
+    else:
+        exp_cnt = t.bincount(key, minlength=G)
+        exp_sum = t.zeros(G, dtype=t.float64, device=env.dev).index_add_(0, key, val)
+        first = first_seen_rows(env, key, G)
     A_s, A_inv = 0x9E3779B97F4A7C15 - (1 << 64), pow(0x9E3779B97F4A7C15, -1, 1 << 64)
     A_inv_s = A_inv - (1 << 64) if A_inv >= (1 << 63) else A_inv
     if keys.endswith("sparse"):  # hashed buckets instead of the key-range partition
         key.mul_(A_s).add_(777)
         t.cuda.synchronize()
     env.be.profile(True)
-    out = _run_hash_agg(env, key, val)
+    out = _run_hash_agg(env, key, val, where=where)
     prof = env.be.profile_read()
     env.be.profile(False)
+    if keys in ("sparse", "where_sparse"):
+        assert "rp_hist" not in prof and ("rp_chunk_scatter" in prof or "rp_chunk_scatter_filter" in prof), sorted(prof)  # level 2's counts came from level 1
     if keys.startswith("sorted"):
         assert "agg_resolve" not in prof and "agg_update" not in prof, sorted(prof)  # no row took the overflow path
     g = out.num_rows
