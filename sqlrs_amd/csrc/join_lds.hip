@@ -71,11 +71,11 @@ __device__ __forceinline__ uint32_t lj_bucket(uint64_t key, uint32_t P) { // = r
 constexpr int LP_ROWS = LJ_RANGE / LJ_WG; // 32 rows per thread
 constexpr int LP_STAGE = LJ_RANGE / 4;    // rows staged per round (96 KiB)
 __global__ __launch_bounds__(LJ_WG) void lds_join_partition_kernel(const uint64_t *__restrict__ keys, int64_t n, uint32_t P,
-                                                                   uint64_t *__restrict__ okey, uint32_t *__restrict__ oidx,
+                                                                   uint64_t *__restrict__ okey, uint16_t *__restrict__ oidx,
                                                                    uint32_t *__restrict__ pbs, uint32_t nrs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lp_smem[];
   uint64_t *skey = (uint64_t *)lp_smem;            // [LP_STAGE]
-  uint32_t *sidx = (uint32_t *)(skey + LP_STAGE);  // [LP_STAGE]
+  uint16_t *sidx = (uint16_t *)(skey + LP_STAGE);  // [LP_STAGE] row inside the range (< 2^15: 16 bits; round 6 — 32-bit row ids before)
   __shared__ uint32_t cnt[512], start[512 + 1];
   __shared__ uint32_t s_wsum[8];
   const int64_t rbase = (int64_t)blockIdx.x * LJ_RANGE;
@@ -129,14 +129,16 @@ __global__ __launch_bounds__(LJ_WG) void lds_join_partition_kernel(const uint64_
       const uint32_t p = ((w >> ((j & 1) * 16)) & 0xffffu) - q0; // (0xffff - q0 stays >= LP_STAGE)
       if (p < (uint32_t)LP_STAGE) {
         skey[p] = k[j];
-        sidx[p] = (uint32_t)rbase + (uint32_t)(j * LJ_WG) + tid;
+        sidx[p] = (uint16_t)((uint32_t)(j * LJ_WG) + tid);
       }
     }
     __syncthreads();
     const uint32_t m = min((uint32_t)LP_STAGE, len - q0);
-    for (uint32_t p = threadIdx.x; p < m; p += LJ_WG) {
-      __builtin_nontemporal_store(skey[p], okey + rbase + q0 + p);
-      __builtin_nontemporal_store(sidx[p], oidx + rbase + q0 + p);
+    for (uint32_t p = threadIdx.x; p < m; p += LJ_WG) __builtin_nontemporal_store(skey[p], okey + rbase + q0 + p);
+    for (uint32_t p = 2 * threadIdx.x; p < m; p += 2 * LJ_WG) { // (two 16-bit row numbers per store; rbase + q0 is even)
+      const uint32_t w2 = (uint32_t)sidx[p] | ((p + 1 < m ? (uint32_t)sidx[p + 1] : 0u) << 16);
+      if (p + 1 < m) __builtin_nontemporal_store(w2, (uint32_t *)(oidx + rbase + q0 + p));
+      else oidx[rbase + q0 + p] = (uint16_t)w2;
     }
     __syncthreads();
   }
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(LJ_WG) void lds_join_unique_kernel(const uint64_t *
 // probe 3: un-permute one range through LDS and compact it (see above).  8 worker waves + the scan wave.
 constexpr int LR_WAVES = 8, LR_BLOCK = (LR_WAVES + 1) * 64, LR_PER_WAVE = LJ_RANGE / LR_WAVES / 64; // 64 chunks of 64 rows per wave
 __global__ __launch_bounds__(LR_BLOCK) void lds_join_restore_kernel(
-    const uint32_t *__restrict__ pidx, const uint32_t *__restrict__ mpart, int64_t n, int64_t num_tiles,
+    const uint16_t *__restrict__ pidx, const uint32_t *__restrict__ mpart, int64_t n, int64_t num_tiles,
     uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx, uint64_t *desc, unsigned *ticket, uint64_t *total,
     int use_ticket) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(LR_BLOCK) void lds_join_restore_kernel(
       }
 #pragma unroll
       for (int u = 0; u < U; u++)
-        if (base + u * LR_WAVES * 64 < len) m[id[u] - (uint32_t)rbase] = mv[u];
+        if (base + u * LR_WAVES * 64 < len) m[id[u]] = mv[u];
     }
   }
   __syncthreads(); // (0) the match array of the range is complete
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(LR_BLOCK) void lds_join_restore_kernel(
 // join_count_kernel leaves after probing the general table at the random-access rate of the memory behind L2 (2.6 ms per 1e8
 // probe rows against 0.5 + 0.5 + 0.4 ms for partition + LDS probe + this pass) — and the scan + join_fill_expand_kernel
 // go on from there.  `dmatch` null: unique build keys (the matched "row" is the build row, a run of one).
-__global__ __launch_bounds__(1024) void lds_join_unpermute_kernel(const uint32_t *__restrict__ pidx, const uint32_t *__restrict__ mpart,
+__global__ __launch_bounds__(1024) void lds_join_unpermute_kernel(const uint16_t *__restrict__ pidx, const uint32_t *__restrict__ mpart,
                                                                   int64_t n, const uint2 *__restrict__ dmatch, int outer_right,
                                                                   uint2 *__restrict__ match, uint32_t *__restrict__ counts, int grouped) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lu2_smem[];
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(1024) void lds_join_unpermute_kernel(const uint32_t
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
-      if (base + u * 1024 < len) m[id[u] - (uint32_t)rbase] = mv[u];
+      if (base + u * 1024 < len) m[id[u]] = mv[u];
   }
   __syncthreads();
   for (uint32_t r0 = 0; r0 < len; r0 += 1024) { // (uniform trip count: the group sums are wave reductions)
@@ -540,12 +542,12 @@ LdsJoinMatch lds_join_match(sqlrs_hash_join *j, const NKeys &pk, bool distinct) 
   const uint32_t nranges = (uint32_t)ceil_div(n, LJ_RANGE);
   const uint32_t nrs = (uint32_t)round_up((size_t)nranges, 64) + 64; // row stride of the bucket-major sliver starts
   BufP pkey = ctx->alloc(8 * (size_t)n + 16), pbstart = ctx->alloc(4 * (size_t)nrs * P);
-  out.idx = ctx->alloc(4 * (size_t)n + 16);
+  out.idx = ctx->alloc(2 * (size_t)n + 16);
   {
     ProfScope ps(ctx, "join_partition_lds");
     allow_big_lds(ctx, lds_join_partition_kernel, 112 * 1024);
     lds_join_partition_kernel<<<dim3(nranges), dim3(LJ_WG), (size_t)LP_STAGE * 12, ctx->stream>>>(
-        pk.keys->as<uint64_t>(), n, P, pkey->as<uint64_t>(), out.idx->as<uint32_t>(), pbstart->as<uint32_t>(), nrs);
+        pk.keys->as<uint64_t>(), n, P, pkey->as<uint64_t>(), out.idx->as<uint16_t>(), pbstart->as<uint32_t>(), nrs);
     SQ_HIP(hipGetLastError());
   }
   // ranges per work item: one LDS table build (~2 K inserts) per rpi x ~64 probe rows
@@ -574,7 +576,7 @@ void lds_join_restore(Ctx *ctx, const LdsJoinMatch &lm, int64_t n, uint64_t *lef
   const int64_t tiles = lds_join_tiles(n);
   allow_big_lds(ctx, lds_join_restore_kernel, 4 * LJ_RANGE + 1024);
   lds_join_restore_kernel<<<dim3((unsigned)tiles), dim3(LR_BLOCK), 4 * (size_t)LJ_RANGE, ctx->stream>>>(
-      lm.idx->as<uint32_t>(), lm.mpart->as<uint32_t>(), n, tiles, left_idx, right_idx, desc, ticket, total, use_ticket);
+      lm.idx->as<uint16_t>(), lm.mpart->as<uint32_t>(), n, tiles, left_idx, right_idx, desc, ticket, total, use_ticket);
   SQ_HIP(hipGetLastError());
 }
 // ... or, for duplicate build keys / Right / Full joins: match[r] = {run, pairs} and the pair counts (per row, or one sum per
@@ -583,7 +585,7 @@ void lds_join_unpermute(sqlrs_hash_join *j, const LdsJoinMatch &lm, int64_t n, i
   Ctx *ctx = j->ctx;
   allow_big_lds(ctx, lds_join_unpermute_kernel, 4 * LJ_RANGE + 1024);
   lds_join_unpermute_kernel<<<dim3((unsigned)lds_join_tiles(n)), dim3(1024), 4 * (size_t)LJ_RANGE, ctx->stream>>>(
-      lm.idx->as<uint32_t>(), lm.mpart->as<uint32_t>(), n, j->unique ? nullptr : j->lds_dmatch->as<uint2>(), outer_right, match, counts, grouped);
+      lm.idx->as<uint16_t>(), lm.mpart->as<uint32_t>(), n, j->unique ? nullptr : j->lds_dmatch->as<uint2>(), outer_right, match, counts, grouped);
   SQ_HIP(hipGetLastError());
 }
 

@@ -99,7 +99,7 @@ const uint32_t *hash_join_dup_mult(sqlrs_hash_join *j);
 // index into lds_dmatch when `distinct` (duplicate build keys), or 0xffffffff; `ok` = false: route not taken
 struct LdsJoinMatch {
   bool ok = false;
-  BufP idx, mpart; // u32[n] each: original row, build row | DENSE_EMPTY
+  BufP idx, mpart; // u16[n]: the row's number inside its 2^15-row range; u32[n]: build row | DENSE_EMPTY
 };
 // a build side that will be probed on LDS tables establishes `unique` there and leaves the general table unbuilt; false: not such
 // a build side, or its keys are not unique (the caller builds the general table)
