@@ -131,7 +131,8 @@ __global__ __launch_bounds__(BLOCK) void join_count_kernel(const uint64_t *__res
 // consecutive pairs.  (One lane per probe row, each walking its own run of `count` pairs, stored at the
 // random-store rate: 1.8 ms for 8e7 pairs; this form: see DESIGN.md.)
 // (Round 6 measured FOUR 64-row groups per wave, their match words and offsets in flight together: 1.74 -> 2.00 ms for 4e8 pairs —
-//  the pass lives on the number of waves that have stores in flight, not on the latency in front of them.)
+//  the pass lives on the number of waves that have stores in flight, not on the latency in front of them.  Four 64-output steps of ONE
+//  group per trip, their owner searches and rows_by_slot loads issued before the stores: 1.60 -> 1.67 ms.)
 __global__ __launch_bounds__(BLOCK) void join_fill_expand_kernel(
     const uint2 *__restrict__ match, int64_t n, int unique, int outer_right, const uint32_t *__restrict__ rows_by_slot,
     const uint64_t *__restrict__ offsets, uint64_t *__restrict__ left_idx, uint32_t *__restrict__ right_idx,
