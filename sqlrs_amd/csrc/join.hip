@@ -1151,6 +1151,7 @@ static NKeys composite_probe_keys(sqlrs_hash_join *j, const std::function<const 
 }
 
 static void build_hash_table(sqlrs_hash_join *j);
+static bool build_dense_dup(sqlrs_hash_join *j);
 // The direct-address build's verdict (dense_pack_count_kernel: st[0 .. 35)) -> the join's state; what is not a unique dense
 // key set goes on to the general table.  `h`: the words when the caller has fetched them already (with its own answer, in
 // one round trip), else they are fetched here.
@@ -1191,6 +1192,7 @@ static void dense_resolve(sqlrs_hash_join *j, const uint64_t *h = nullptr) {
     }
   }
   if (j->lazy_table) return; // built by hash_join_ensure_table when something probes it
+  if (build_dense_dup(j)) return; // duplicate keys over a dense range: runs by key, no general table
   if (lds_build_first(j)) return; // general keys on LDS tables: uniqueness from there, the global table on first need only
   build_hash_table(j);
 }
@@ -1357,8 +1359,163 @@ static void build_table(sqlrs_hash_join *j) {
     }
   }
   if (j->lazy_table) return; // built by hash_join_ensure_table when something probes it
+  if (build_dense_dup(j)) return; // duplicate keys over a dense range: runs by key, no general table
   if (lds_build_first(j)) return; // general keys on LDS tables: uniqueness from there, the global table on first need only
   build_hash_table(j);
+}
+
+// 1b. (round 6) DUPLICATE build keys over a dense range — a foreign key joined to a foreign key, a dimension attribute: the direct-
+// address attempt above has found the range and that some key repeats.  The general table (32 MiB of slots for 1e6 rows, a CAS
+// insert per row, a stable radix sort by SLOT for the runs, then — for the LDS route — its distinct keys partitioned again: 0.56 ms
+// of small launches and six host round trips for 1e6 rows) is not needed: the rows counted per key of the range
+// (hash_join_dup_mult), an exclusive scan, and the rows stably sorted by (key - min) ARE the runs; the probe's count pass reads
+// {run start, rows} with one 8-byte load per probe row from a table the size of the range (L2-resident for C3's shapes) instead
+// of three passes over LDS tables.  1e8 x 1e6 rows, every key ~4 times (4e8 pairs), build + probe: 3.76 -> 2.57 ms.
+// the run starts with three entries behind the range: start[range] = rows (the end of the last run), start[range + 1] =
+// start[range + 2] = rows — the empty run every key without partner reads (unconditional loads in dd_count_kernel)
+__global__ void dd_table_kernel(const uint32_t *__restrict__ start, int64_t range, uint32_t rows, uint32_t *__restrict__ t) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < range) t[i] = start[i];
+  else if (i < range + 3) t[i] = rows;
+}
+__global__ void dd_sort_keys_kernel(const uint64_t *__restrict__ keys, int64_t n, uint64_t kmin, uint64_t *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = keys[i] - kmin;
+}
+// the count pass over that table: match[r] = {run start, rows}, pair counts per row or per 64-row group (join_count_kernel's outputs)
+#ifndef DD_DBG
+#define DD_DBG 0
+#endif
+#ifndef DD_U_N
+#define DD_U_N 8
+#endif
+constexpr int DD_U = DD_U_N;
+typedef uint2 __attribute__((aligned(4))) uint2_unaligned; // 64-row groups per wave: their keys, then their table entries, in flight together
+__global__ __launch_bounds__(BLOCK) void dd_count_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n,
+                                                         uint64_t kmin, uint64_t range, const uint32_t *__restrict__ table, int outer_right,
+                                                         uint32_t *__restrict__ counts, uint2 *__restrict__ match, int grouped) {
+  const int lane = lane_id();
+  const int64_t wbase = (blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_id()) * (64 * DD_U);
+  if (wbase >= n) return;
+  uint64_t k[DD_U];
+#pragma unroll
+  for (int u = 0; u < DD_U; u++) k[u] = __builtin_nontemporal_load(keys + min(wbase + u * 64 + lane, n - 1));
+  unsigned long long m[DD_U];
+#pragma unroll
+  for (int u = 0; u < DD_U; u++) {
+    const int64_t r = min(wbase + u * 64 + lane, n - 1);
+    const bool is_null = validity && !((validity[r >> 6] >> (r & 63)) & 1); // (no NULL build key on this route: a NULL probe key has no partner)
+    const uint64_t d = k[u] - kmin;
+#if DD_DBG & 1 // (measurement: no table lookup)
+    m[u] = (!is_null && d < range) ? (d | (4ull << 32)) : 0ull;
+#else
+    // UNCONDITIONAL: a key without partner reads the empty entry behind the range — a load under a condition is a branch, and the
+    // eight lookups of a lane then wait for one another (0.73 ms per 1e8 rows; without any lookup 0.27)
+    // (4-byte entries, a run's length = the next start - its own: half the table of {start, rows} pairs, 1 MiB for 2.5e5 keys)
+    const uint2 se = *(const uint2_unaligned *)(table + ((!is_null && d < range) ? d : range + 1)); // {start, next start}
+    m[u] = (unsigned long long)se.x | ((unsigned long long)(se.y - se.x) << 32); // {run start | rows << 32}
+#endif
+  }
+#pragma unroll
+  for (int u = 0; u < DD_U; u++) {
+    const int64_t r = wbase + u * 64 + lane;
+    uint32_t c = 0;
+    if (r < n) {
+      c = (uint32_t)(m[u] >> 32);
+#if !(DD_DBG & 2) // (measurement: no match store)
+      __builtin_nontemporal_store(m[u], (unsigned long long *)(match + r));
+#endif
+      if (outer_right && c == 0) c = 1;
+      if (!grouped) counts[r] = c;
+    }
+    if (grouped) {
+      const uint32_t wsum = wave_sum_u32(c);
+      if (lane == 0 && wbase + u * 64 < n) counts[(wbase + u * 64) >> 6] = wsum;
+    }
+  }
+}
+// The same pass in the shape of join_probe_dense_allhit_packed_kernel (persistent waves, 512 CONSECUTIVE rows per wave and trip,
+// 16-byte key loads and match stores): probe keys without NULLs in a 16-byte aligned column.  The lookups and the two streams
+// share the CU's vector memory path; this shape is what got the all-hit probe from 0.69 to 0.52 ms per 1e8 rows (tools/ubench2.hip).
+__global__ __launch_bounds__(256) void dd_count_stream_kernel(const uint64_t *__restrict__ keys, int64_t n, uint64_t kmin, uint64_t range,
+                                                              const uint32_t *__restrict__ table, int outer_right,
+                                                              uint32_t *__restrict__ counts, uint2 *__restrict__ match, int grouped) {
+  const int lane = lane_id();
+  const int64_t nchunks = n / JAP_ROWS, gw = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),
+                nw = (int64_t)gridDim.x * 4;
+  const uint32_t miss = (uint32_t)range + 1;
+  for (int64_t c = gw; c < nchunks; c += nw) {
+    const int64_t r0 = c * JAP_ROWS + 2 * lane;
+    u64x2_vec k[4];
+    uint2 se[8];
+#pragma unroll
+    for (int g = 0; g < 4; g++) k[g] = __builtin_nontemporal_load((const u64x2_vec *)(keys + r0 + g * 128));
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const uint64_t d0 = k[g].x - kmin, d1 = k[g].y - kmin;
+      se[2 * g] = *(const uint2_unaligned *)(table + (d0 < range ? (uint32_t)d0 : miss));
+      se[2 * g + 1] = *(const uint2_unaligned *)(table + (d1 < range ? (uint32_t)d1 : miss));
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) { // rows r0 + 128 g, + 1: lanes 2 l, 2 l + 1 of the 128-row piece
+      const uint32_t c0 = se[2 * g].y - se[2 * g].x, c1 = se[2 * g + 1].y - se[2 * g + 1].x;
+      u64x2_vec mv;
+      mv.x = (unsigned long long)se[2 * g].x | ((unsigned long long)c0 << 32);
+      mv.y = (unsigned long long)se[2 * g + 1].x | ((unsigned long long)c1 << 32);
+      __builtin_nontemporal_store(mv, (u64x2_vec *)(match + r0 + g * 128));
+      const uint32_t e0 = (outer_right && c0 == 0) ? 1u : c0, e1 = (outer_right && c1 == 0) ? 1u : c1;
+      if (grouped) { // two 64-row groups per piece: lanes 0-31 hold the first, 32-63 the second
+        uint32_t v = e0 + e1;
+        for (int m = 16; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
+        if ((lane & 31) == 0) counts[((c * JAP_ROWS + g * 128) >> 6) + (lane >> 5)] = v;
+      } else {
+        *(uint2 *)(counts + r0 + g * 128) = make_uint2(e0, e1);
+      }
+    }
+  }
+  if (gw == nchunks % nw) // the rows behind the last whole chunk (< 512, whole 64-row groups first): the wave whose turn it would be
+    for (int64_t rb = nchunks * JAP_ROWS; rb < n; rb += 64) {
+      const int64_t r = rb + lane;
+      uint32_t cv = 0;
+      if (r < n) {
+        const uint64_t d = keys[r] - kmin;
+        const uint2 e = *(const uint2_unaligned *)(table + (d < range ? (uint32_t)d : miss));
+        const uint32_t c0 = e.y - e.x;
+        match[r] = make_uint2(e.x, c0);
+        cv = (outer_right && c0 == 0) ? 1u : c0;
+        if (!grouped) counts[r] = cv;
+      }
+      if (grouped) {
+        const uint32_t wsum = wave_sum_u32(cv);
+        if (lane == 0) counts[rb >> 6] = wsum;
+      }
+    }
+}
+static bool build_dense_dup(sqlrs_hash_join *j) {
+  Ctx *ctx = j->ctx;
+  const char *dd_e = hook("SQLRS_JOIN_DENSE_DUP"); // test / A-B hook, read per call: 0 = the general table
+  if ((dd_e && std::atoi(dd_e) == 0) || !j->dup_range || !j->exact || !j->bkeys || j->bkeys_validity || j->nB <= 0 ||
+      j->nB > 0x7fffffffll || j->dup_range >= (1ull << 31))
+    return false;
+  const uint32_t *mult = hash_join_dup_mult(j);
+  if (!mult) return false;
+  ProfScope ps(ctx, "join_build_dense_dup");
+  const int64_t range = (int64_t)j->dup_range, n = j->nB;
+  BufP start = ctx->alloc(4 * (size_t)range + 8), total = ctx->alloc(8);
+  exclusive_scan_u32(ctx, mult, range, nullptr, start->as<uint32_t>(), total->as<uint64_t>());
+  j->dd_table = ctx->alloc(4 * (size_t)range + 16);
+  dd_table_kernel<<<dim3((unsigned)ceil_div(range + 3, 256)), dim3(256), 0, ctx->stream>>>(start->as<uint32_t>(), range, (uint32_t)n, j->dd_table->as<uint32_t>());
+  BufP k64 = ctx->alloc(8 * (size_t)n);
+  j->rows_by_slot = ctx->alloc(4 * (size_t)n);
+  dd_sort_keys_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(j->bkeys->as<uint64_t>(), n, j->dup_min, k64->as<uint64_t>());
+  iota_u32(ctx, j->rows_by_slot->as<uint32_t>(), n);
+  SQ_HIP(hipGetLastError());
+  int bits = 1;
+  while ((1ull << bits) < (uint64_t)range) bits++;
+  radix_sort_pairs(ctx, k64->as<uint64_t>(), j->rows_by_slot->as<uint32_t>(), n, 0, bits); // (stable: a run keeps build insertion order, hash_join.rs:172-177)
+  j->unique = false;
+  j->table_built = j->unique_known = true; // (no general table: every probe of this join counts on dd_table)
+  return true;
 }
 
 // 2. open-addressing table over the key hash (any key type, duplicates allowed)
@@ -1410,7 +1567,7 @@ static void build_hash_table(sqlrs_hash_join *j) {
 
 void hash_join_ensure_table(sqlrs_hash_join *j) {
   dense_resolve(j);
-  if (!j->table_built && j->finished && !j->empty_build) build_hash_table(j);
+  if (!j->table_built && j->finished && !j->empty_build && !build_dense_dup(j)) build_hash_table(j);
 }
 
 static DenseTable dense_table_of(const sqlrs_hash_join *j) {
@@ -1574,7 +1731,7 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   // duplicate build keys, and Right / Full joins over general keys: matched on the LDS tables too, un-permuted into the
   // {run, pairs} the fill pass expands (lds_join_unpermute_kernel)
   LdsJoinMatch lmg;
-  if (!j->dense && (!j->unique || outer_right)) lmg = lds_join_match(j, pk, !j->unique);
+  if (!j->dense && !j->dd_table && (!j->unique || outer_right)) lmg = lds_join_match(j, pk, !j->unique);
   if (j->unique && outer_right && !lmg.ok) { // exactly one pair per probe row
     p.m = n;
     p.right_identity = true; // (pair i = (build row | NULL, probe row i))
@@ -1606,6 +1763,17 @@ static Pairs probe_pairs(sqlrs_hash_join *j, const NKeys &pk) {
   if (lmg.ok) {
     ProfScope ps(ctx, "join_match_unpermute");
     lds_join_unpermute(j, lmg, n, outer_right, match->as<uint2>(), counts->as<uint32_t>(), grouped);
+  } else if (j->dd_table) { // duplicate keys over a dense range: {run, rows} by direct address
+    ProfScope ps(ctx, "join_probe_count_dense_dup");
+    const char *ds_e = hook("SQLRS_DD_STREAM"); // A/B hook, read per call: 0 = the one-row-per-lane form for every batch
+    if (!pk.validity && n >= JAP_ROWS && ((uintptr_t)pk.keys->p & 15) == 0 && !(ds_e && std::atoi(ds_e) == 0)) {
+      const unsigned pblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / JAP_ROWS, 4), JAP_GRID * (int64_t)ctx->num_cus));
+      dd_count_stream_kernel<<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(pk.keys->as<uint64_t>(), n, j->dup_min, j->dup_range, j->dd_table->as<uint32_t>(),
+                                                                         outer_right, counts->as<uint32_t>(), match->as<uint2>(), grouped);
+    } else
+      dd_count_kernel<<<dim3((unsigned)ceil_div(n, (int64_t)BLOCK * DD_U)), b, 0, ctx->stream>>>(pk.keys->as<uint64_t>(), pk.validity, n, j->dup_min, j->dup_range, j->dd_table->as<uint32_t>(), outer_right,
+                                                counts->as<uint32_t>(), match->as<uint2>(), grouped);
+    SQ_HIP(hipGetLastError());
   } else {
     ProfScope ps(ctx, "join_probe_count");
     join_count_kernel<<<g, b, 0, ctx->stream>>>(pk.keys->as<uint64_t>(), pk.validity, n,

@@ -69,6 +69,10 @@ struct sqlrs_hash_join {
   // need of the fused join+aggregate — how many build rows carry each key of it (u32 per key, 0 = none)
   uint64_t dup_min = 0, dup_range = 0;
   sq::BufP dup_mult;
+  // round 6: duplicate build keys over a dense range WITHOUT the general table: dd_table[key - dup_min] = first entry of the
+  // key's run in rows_by_slot, dd_table[.. + 1] = the end of the run (build_dense_dup, join.hip) — the count pass of a probe is
+  // one L2-resident 8-byte lookup per row
+  sq::BufP dd_table;
   sq::BufP bkeys, bkeys_validity; // normalised build keys (u64[nB]) and their validity bitmap
   // general keys on LDS tables (join.hip, lds_join_match): the build keys in bucket order, built at the first probe
   // that takes the route; lds_slots = 0: the route does not apply to this build side

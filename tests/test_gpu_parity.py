@@ -312,6 +312,41 @@ def test_hash_join_lds_tables_f64_keys_and_fallbacks(hip, oracle, monkeypatch):
         assert_same(rows_of(got), rows_of(exp))
 
 
+@pytest.mark.parametrize("jt", ["inner", "left", "right", "full"])
+@pytest.mark.parametrize("shape", ["x4", "skewed", "int32_keys", "probe_nulls", "two_build_batches"])
+def test_hash_join_duplicate_keys_over_a_dense_range(hip, oracle, jt, shape):
+    """Round 6: build keys that REPEAT inside a dense range (a foreign key on the build side) take neither the general table
+    nor the LDS tables: runs by key (count per key of the range, scan, rows stably sorted by key) and one direct-address
+    {run, rows} lookup per probe row.  Probe keys outside the range, NULL probe keys, int32 keys, a build side in two batches,
+    all four join types — batches equal the oracle's bit for bit (hash_join.rs:172-177, 225-248)."""
+    rng = np.random.default_rng(len(jt) * 7 + len(shape))
+    nb, npr = 50_000, 600_000
+    if shape == "skewed":
+        bk = rng.integers(100, 100 + nb // 2, nb, dtype=np.int64)
+        bk[rng.random(nb) < 0.2] = 123
+    else:
+        bk = rng.integers(-500, -500 + nb // 4, nb, dtype=np.int64)
+    pk = rng.integers(bk.min() - 2000, bk.max() + 2000, npr, dtype=np.int64)
+    kt = np.int32 if shape == "int32_keys" else np.int64
+    lb = pa.RecordBatch.from_arrays([pa.array(bk.astype(kt)), pa.array(np.arange(nb, dtype=np.int64))], names=["c0", "c1"])
+    rb = pa.RecordBatch.from_arrays([pa.array(pk.astype(kt), mask=(rng.random(npr) < 0.1) if shape == "probe_nulls" else None),
+                                     pa.array(rng.random(npr))], names=["c0", "c1"])
+    lbs = [lb.slice(0, nb // 3), lb.slice(nb // 3)] if shape == "two_build_batches" else [lb]
+    rbs = [rb.slice(0, 70_000), rb.slice(70_000, 1), rb.slice(70_001)]
+    cond = JoinCondition([(InputRef(0), InputRef(0))])
+    sch = join_schema(lb, rb)
+    hip.profile(True)
+    got = list(HashJoinExecutor(hip, lbs, rbs, jt, cond, sch, 2).execute())
+    prof = hip.profile_read()
+    hip.profile(False)
+    assert prof.get("join_probe_count_dense_dup", (0, 0))[1] > 0 and prof.get("join_build", (0, 0))[1] == 0, prof
+    exp = list(HashJoinExecutor(oracle, lbs, rbs, jt, cond, sch, 2).execute())
+    assert [b.num_rows for b in got] == [b.num_rows for b in exp]
+    for g, e in zip(got, exp):
+        for c in range(g.num_columns):
+            assert g.column(c).equals(e.column(c)), c
+
+
 @pytest.mark.parametrize("jt", ["inner", "full"])
 @pytest.mark.parametrize("lds", ["1", "0"])
 def test_hash_join_per_row_counts_form(hip, oracle, monkeypatch, jt, lds):
