@@ -1390,7 +1390,8 @@ __global__ void dd_sort_keys_kernel(const uint64_t *__restrict__ keys, int64_t n
 #define DD_U_N 8
 #endif
 constexpr int DD_U = DD_U_N;
-typedef uint2 __attribute__((aligned(4))) uint2_unaligned; // 64-row groups per wave: their keys, then their table entries, in flight together
+struct __attribute__((aligned(4))) uint2_unaligned { uint32_t x, y; }; // (two adjacent 4-byte entries, one 8-byte load)
+// 64-row groups per wave: their keys, then their table entries, in flight together
 __global__ __launch_bounds__(BLOCK) void dd_count_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity, int64_t n,
                                                          uint64_t kmin, uint64_t range, const uint32_t *__restrict__ table, int outer_right,
                                                          uint32_t *__restrict__ counts, uint2 *__restrict__ match, int grouped) {
@@ -1412,7 +1413,7 @@ __global__ __launch_bounds__(BLOCK) void dd_count_kernel(const uint64_t *__restr
     // UNCONDITIONAL: a key without partner reads the empty entry behind the range — a load under a condition is a branch, and the
     // eight lookups of a lane then wait for one another (0.73 ms per 1e8 rows; without any lookup 0.27)
     // (4-byte entries, a run's length = the next start - its own: half the table of {start, rows} pairs, 1 MiB for 2.5e5 keys)
-    const uint2 se = *(const uint2_unaligned *)(table + ((!is_null && d < range) ? d : range + 1)); // {start, next start}
+    const uint2_unaligned se = *(const uint2_unaligned *)(table + ((!is_null && d < range) ? d : range + 1)); // {start, next start}
     m[u] = (unsigned long long)se.x | ((unsigned long long)(se.y - se.x) << 32); // {run start | rows << 32}
 #endif
   }
@@ -1447,7 +1448,7 @@ __global__ __launch_bounds__(256) void dd_count_stream_kernel(const uint64_t *__
   for (int64_t c = gw; c < nchunks; c += nw) {
     const int64_t r0 = c * JAP_ROWS + 2 * lane;
     u64x2_vec k[4];
-    uint2 se[8];
+    uint2_unaligned se[8];
 #pragma unroll
     for (int g = 0; g < 4; g++) k[g] = __builtin_nontemporal_load((const u64x2_vec *)(keys + r0 + g * 128));
 #pragma unroll
@@ -1479,7 +1480,7 @@ __global__ __launch_bounds__(256) void dd_count_stream_kernel(const uint64_t *__
       uint32_t cv = 0;
       if (r < n) {
         const uint64_t d = keys[r] - kmin;
-        const uint2 e = *(const uint2_unaligned *)(table + (d < range ? (uint32_t)d : miss));
+        const uint2_unaligned e = *(const uint2_unaligned *)(table + (d < range ? (uint32_t)d : miss));
         const uint32_t c0 = e.y - e.x;
         match[r] = make_uint2(e.x, c0);
         cv = (outer_right && c0 == 0) ? 1u : c0;

@@ -199,13 +199,16 @@ def test_full_size_c3_join_pairs(env, variant):
     out.release()
 
 
+@pytest.mark.parametrize("keys", ["sparse", "dense_range"])
 @pytest.mark.parametrize("jt", ["inner", "full"])
-def test_full_size_c3_join_duplicate_build_keys(env, jt):
+def test_full_size_c3_join_duplicate_build_keys(env, jt, keys):
     """Round 6: 1e8 probe rows against 1e6 build rows whose sparse keys repeat ~4 times (Inner: every probe row matches ->
     ~4e8 pairs) and, for Full, a probe side half of whose keys have no partner — the LDS bucket-table route with the DISTINCT keys
     of the general table (join_lds.hip).  Checked on the device: pair count = sum of the build multiplicities of the probe keys
     (+ one pair per unmatched probe row), probe-row major, build insertion order inside a probe row, equal keys on both sides,
-    NULL left index exactly on the unmatched rows (hash_join.rs:172-177, 225-248)."""
+    NULL left index exactly on the unmatched rows (hash_join.rs:172-177, 225-248).  `dense_range`: the same multiplicities over keys
+    that fill 0 .. 2.5e5 (bench.py's C3_join_dup_build_keys_x4) — runs by key and one direct-address lookup per probe row
+    (join.hip: build_dense_dup), neither table."""
     t, abi, d = env.torch, env.abi, env.datagen
     from sqlrs_amd.expr import InputRef
     nP, nB, D = 100_000_000, 1_000_000, 250_000
@@ -213,7 +216,7 @@ def test_full_size_c3_join_duplicate_build_keys(env, jt):
     g = t.Generator(device=env.dev).manual_seed(44)
     bslot = t.randint(0, D, (nB,), dtype=t.int64, device=env.dev, generator=g)
     pslot = d.fill_chunks(t.empty(nP, dtype=t.int64, device=env.dev), lambda i: d.key_t(0xF1, i, D if jt == "inner" else 2 * D))
-    dk, fk = bslot * A_s + 12345, pslot * A_s + 12345
+    dk, fk = (bslot * A_s + 12345, pslot * A_s + 12345) if keys == "sparse" else (bslot + 7, pslot + 7)
     mult = t.bincount(bslot, minlength=2 * D)
     per_row = mult[pslot]
     expect = int(per_row.sum().item()) + (int((per_row == 0).sum().item()) if jt == "full" else 0)
@@ -235,7 +238,8 @@ def test_full_size_c3_join_duplicate_build_keys(env, jt):
     out = be.wrap(o)
     be.fn("hash_join_destroy")(j)
     be.synchronize()
-    assert prof.get("join_match_unpermute", (0, 0))[1] > 0 and prof.get("join_probe_count", (0, 0))[1] == 0, prof
+    route = "join_match_unpermute" if keys == "sparse" else "join_probe_count_dense_dup"
+    assert prof.get(route, (0, 0))[1] > 0 and prof.get("join_probe_count", (0, 0))[1] == 0, prof
     m = out.num_rows
     assert m == expect
     left = view(env, out.column(0), m, t.int64)
