@@ -796,7 +796,10 @@ __global__ __launch_bounds__(256) void dense_init_dev_kernel(const unsigned long
   const uint4 e = make_uint4(DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY, DENSE_EMPTY);
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) heads4[i] = e;
 }
-constexpr int DENSE_FILL_U = 4; // build rows per thread (independent key loads / table stores in flight)
+// DENSE_FILL_U build rows per thread (independent key loads / table stores in flight): 4 for a small dimension, whose build is a
+// chain of launch-bound kernels (1e6 keys: C3), 1 from 2^21 rows on — the 1e7-row dimension of C5 fills in 0.145 ms with one row
+// per thread and 0.217 with four (profiles/r05zzzzz_kernel_stats.csv against r06k: the round-6 change had cost the C5 step 70 us)
+template <int DENSE_FILL_U>
 __global__ __launch_bounds__(256) void dense_fill_dev_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ validity,
                                                              int64_t n, const unsigned long long *__restrict__ st, uint64_t max_range,
                                                              uint32_t *__restrict__ heads, unsigned long long *counts /* st + 2 DENSE_MM */) {
@@ -1279,8 +1282,12 @@ static void build_table(sqlrs_hash_join *j) {
       const unsigned iblocks = (unsigned)std::min<int64_t>(ceil_div((int64_t)max_range + 2, 256 * 4 * 4), 4 * (int64_t)ctx->num_cus);
       dense_init_dev_kernel<<<dim3(iblocks), dim3(256), 0, ctx->stream>>>(stp, max_range, dense->as<uint4>());
     }
-    dense_fill_dev_kernel<<<dim3((unsigned)ceil_div(n, 256 * DENSE_FILL_U)), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n, stp, max_range,
-                                                                                                         dense->as<uint32_t>(), stp + 2 * DENSE_MM);
+    if (n < (1ll << 21))
+      dense_fill_dev_kernel<4><<<dim3((unsigned)ceil_div(n, 256 * 4)), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n, stp, max_range,
+                                                                                                  dense->as<uint32_t>(), stp + 2 * DENSE_MM);
+    else
+      dense_fill_dev_kernel<1><<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream>>>(keys->as<uint64_t>(), vp, n, stp, max_range,
+                                                                                              dense->as<uint32_t>(), stp + 2 * DENSE_MM);
     if (bits) {
       const unsigned pblocks = (unsigned)std::min<int64_t>(ceil_div(ceil_div((int64_t)max_range + 2, 32), 256), 8 * (int64_t)ctx->num_cus);
       dense_pack_count_kernel<<<dim3(pblocks), dim3(256), 0, ctx->stream>>>(dense->as<uint32_t>(), stp, max_range, bits,

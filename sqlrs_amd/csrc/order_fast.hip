@@ -275,7 +275,28 @@ __device__ __forceinline__ uint32_t olb_load(const uint32_t *p) { return __hip_a
 __device__ __forceinline__ void olb_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // TWO (records out): word and carried value take turns in ONE LDS tile instead of two — 43 KB and <= 80 VGPRs: three
 // workgroups per CU instead of two, for two more barriers per tile
-template <int KIND, bool RAW, int NPAY, bool TILED = false, bool REC = false, bool REC_IN = false, bool LB = false, bool TWO = false>
+// SLIM (round 6, with TWO): the records between the passes and into the finish are 12 bytes — {key offset (u32), carried value} —
+// instead of 16.  The low half of the word, the row id, is dead weight on this route whenever the caller does not ask for the
+// permutation: both passes and the finish's LDS passes are STABLE (stable_wave_ranks, tiles chained in launch order), so equal
+// keys keep their input order without it.  1.6 GB less per 1e8 rows over the three passes (10.4 -> 8.8).
+struct __attribute__((aligned(4))) OwRec12 {
+  uint32_t off, vlo, vhi;
+};
+__device__ __forceinline__ void ow_rec12_load(const void *__restrict__ recs, int64_t i, uint64_t &word, uint64_t &val) {
+  const uint32_t *p = (const uint32_t *)recs + 3 * i;
+  const uint32_t o = __builtin_nontemporal_load(p), lo = __builtin_nontemporal_load(p + 1), hi = __builtin_nontemporal_load(p + 2);
+  word = (uint64_t)o << 32;
+  val = (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ void ow_rec12_store(void *__restrict__ recs, int64_t i, uint64_t word, uint64_t val) {
+  OwRec12 r;
+  r.off = (uint32_t)(word >> 32);
+  r.vlo = (uint32_t)val;
+  r.vhi = (uint32_t)(val >> 32);
+  ((OwRec12 *)recs)[i] = r;
+}
+template <int KIND, bool RAW, int NPAY, bool TILED = false, bool REC = false, bool REC_IN = false, bool LB = false, bool TWO = false,
+          bool SLIM = false>
 __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void ow_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay,
                                                            int64_t n, int desc, uint64_t imin, int shift, int64_t nblocks,
                                                            const uint32_t *__restrict__ offsets,
@@ -294,6 +315,7 @@ __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void ow_scatter_kernel(const vo
   // past its output — it must not run at all.  (Inside one pass a failed spin only shortens a prefix: positions stay in range.)
   if (LB && lb_fail && *lb_fail) return;
   static_assert(!TWO || (REC && NPAY == 1), "TWO: the record form");
+  static_assert(!SLIM || (TWO && LB), "SLIM: 12-byte records of the look-back form");
   __shared__ uint64_t sword[OW_TILE];
   __shared__ uint64_t spay[NPAY && !TWO ? OW_TILE : 1];
   __shared__ uint32_t wcnt[OW_WAVES][256];
@@ -312,6 +334,10 @@ __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void ow_scatter_kernel(const vo
   for (int j = 0; j < OW_ITEMS; j++) {
     const int64_t i = tbase + min(wrow + j * 64, len - 1);
     if (REC_IN) {
+      if constexpr (SLIM) {
+        ow_rec12_load(src, i, k[j], v[NPAY ? j : 0]);
+        continue;
+      }
       const u64x2 rec = __builtin_nontemporal_load((const u64x2 *)src + i);
       k[j] = rec.x;
       v[NPAY ? j : 0] = rec.y;
@@ -415,10 +441,15 @@ __global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void ow_scatter_kernel(const vo
     for (int j = 0; j < OW_ITEMS; j++) {
       const uint32_t p = j * OW_WG + threadIdx.x;
       if (p < len) {
+        const int64_t g = gbase[(uint32_t)(k[j] >> shift) & 255u] + p;
+        if constexpr (SLIM) {
+          ow_rec12_store(words_out, g, k[j], sword[p]);
+          continue;
+        }
         u64x2 rec;
         rec.x = k[j];
         rec.y = sword[p];
-        ((u64x2 *)words_out)[gbase[(uint32_t)(k[j] >> shift) & 255u] + p] = rec;
+        ((u64x2 *)words_out)[g] = rec;
       }
     }
     return;
@@ -630,7 +661,7 @@ __global__ void ow_group_max_kernel(const uint32_t *__restrict__ gstart, const u
 
 // ---- finish: sort every group on its low bits inside LDS, write the final columns ----------------------
 constexpr int FIN_WG = 256, FIN_WAVES = FIN_WG / 64;
-template <int KIND, int NPAY, int R, bool REC = false>
+template <int KIND, int NPAY, int R, bool REC = false, bool SLIM = false>
 __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pay,
                                                            const uint32_t *__restrict__ gstart,
                                                            const uint32_t *__restrict__ gend, int rbits, int desc,
@@ -656,7 +687,9 @@ __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__res
     const uint32_t e = (uint32_t)(w * cpw + j) * 64 + lane;
     valid[j] = (uint32_t)j < cpw && e < m;
     const uint32_t i = lo + min(e, m - 1);
-    if (REC) {
+    if (REC && SLIM) { // 12-byte records {key offset, value}: no row id (perm_out == nullptr)
+      ow_rec12_load(words, i, k[j], v[NPAY ? j : 0]);
+    } else if (REC) {
       const u64x2 rec = __builtin_nontemporal_load((const u64x2 *)words + i);
       k[j] = rec.x;
       v[NPAY ? j : 0] = rec.y;
@@ -1749,6 +1782,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   const bool two_pass = rbits > 0 && top > 8 && top <= 16 && use_tiled;
   const bool lb = two_pass && (NPAY == 1 ? (rec1 && use_rec) : true) && n < (1ll << 30) && !g_order_lb_off.load() && !lb_skip && !(lb_e && lb_e[0] == '0');
   BufP ghb, lbdesc, boundb;
+  bool slim = false; // the look-back form moved 12-byte records (ow_scatter_kernel<.., SLIM>): the finish reads those
   unsigned int *lbw = nullptr; // {look-back spin ran out, largest group, key outside the optimistic range}
   bool lb_done = false;
   if (lb) {
@@ -1767,7 +1801,12 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     uint64_t *out1 = NPAY == 1 ? recbuf1->as<uint64_t>() : wdst, *out2 = NPAY == 1 ? recbuf->as<uint64_t>() : walt; // (records / words)
     const char *two_e = hook("SQLRS_ORDER_TWO"); // (read per call: 0 = word and value side by side in LDS, two workgroups per CU)
     const bool two = NPAY == 1 && !(two_e && two_e[0] == '0');
-    if (two)
+    const char *slim_e = hook("SQLRS_ORDER_SLIM"); // (A/B hook, read per call: 0 = 16-byte records {word, value} between the passes)
+    slim = two && !want_perm && !(slim_e && slim_e[0] == '0'); // 12-byte records {key offset, value}: nobody reads the row id
+    if (slim)
+      ow_scatter_kernel<KIND, true, NPAY, false, NPAY == 1, false, true, NPAY == 1, NPAY == 1><<<g, b, 0, ctx->stream>>>(
+          src, psrc, n, desc, imin, s1, nblocks, nullptr, out1, nullptr, nullptr, oob_lb, gh, lbdesc->as<uint32_t>(), nullptr, lbw);
+    else if (two)
       ow_scatter_kernel<KIND, true, NPAY, false, NPAY == 1, false, true, NPAY == 1><<<g, b, 0, ctx->stream>>>(
           src, psrc, n, desc, imin, s1, nblocks, nullptr, out1, nullptr, nullptr, oob_lb, gh, lbdesc->as<uint32_t>(), nullptr, lbw);
     else
@@ -1783,7 +1822,11 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     ow_tile_plan_gh_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(gh, n, firsttile->as<uint32_t>(), segstart->as<int64_t>());
     ow_tile_fill_kernel<<<dim3((unsigned)ceil_div(ntmax, 256)), dim3(256), 0, ctx->stream>>>(
         firsttile->as<uint32_t>(), segstart->as<int64_t>(), (uint32_t)ntmax, (OwTile *)tiles2->p);
-    if (two)
+    if (slim)
+      ow_scatter_kernel<KIND, false, NPAY, true, NPAY == 1, NPAY == 1, true, NPAY == 1, NPAY == 1><<<dim3((unsigned)ntmax), b, 0, ctx->stream>>>(
+          out1, nullptr, n, desc, imin, s2, ntmax, nullptr, out2, nullptr, (const OwTile *)tiles2->p, oob_lb, gh + 256,
+          lbdesc->as<uint32_t>() + 256 * (size_t)nblocks, boundb->as<uint32_t>(), lbw);
+    else if (two)
       ow_scatter_kernel<KIND, false, NPAY, true, NPAY == 1, NPAY == 1, true, NPAY == 1><<<dim3((unsigned)ntmax), b, 0, ctx->stream>>>(
           out1, nullptr, n, desc, imin, s2, ntmax, nullptr, out2, nullptr, (const OwTile *)tiles2->p, oob_lb, gh + 256,
           lbdesc->as<uint32_t>() + 256 * (size_t)nblocks, boundb->as<uint32_t>(), lbw);
@@ -1897,6 +1940,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   do {                                                                                                               \
     auto kfn = ow_finish_kernel<KIND, NPAY, RR>;                                                                     \
     if (NPAY == 1 && rec_form) kfn = ow_finish_kernel<KIND, NPAY, RR, NPAY == 1>;                                    \
+    if (NPAY == 1 && rec_form && slim) kfn = ow_finish_kernel<KIND, NPAY, RR, NPAY == 1, NPAY == 1>;                 \
     const size_t lds = (size_t)RR * FIN_WG * 8 * (1 + NPAY) + 4 * (FIN_WAVES * 256 + 256);                           \
     if (lds > 64 * 1024) allow_big_lds(ctx, kfn);                                                                    \
     kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(words, pays, gstart->as<uint32_t>(), gend->as<uint32_t>(), rbits, desc, imin, \

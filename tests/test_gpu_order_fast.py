@@ -69,11 +69,13 @@ def hash_seed(*parts):
 
 
 @pytest.mark.parametrize("hooks", [{"SQLRS_ORDER_TILED": "0"}, {"SQLRS_ORDER_REC": "0"}, {"SQLRS_ORDER_REC1": "0"}, {"SQLRS_ORDER_WIDE_REC1": "0"},
-                                   {"SQLRS_ORDER_LB": "0"}, {"SQLRS_ORDER_LB_TEST_FAIL": "1"}, {"SQLRS_ORDER_LB_TEST_FAIL": "2"},
+                                   {"SQLRS_ORDER_LB": "0"}, {"SQLRS_ORDER_LB_TEST_FAIL": "1"}, {"SQLRS_ORDER_LB_TEST_FAIL": "2"}, {"SQLRS_ORDER_SLIM": "0"},
                                    {"SQLRS_ORDER_LB": "0", "TEST_WIDE_KEYS": "1"}, {"SQLRS_ORDER_LB_TEST_FAIL": "1", "TEST_WIDE_KEYS": "1"}])
 def test_order_fast_route_ab_hooks(hip, oracle, hooks, monkeypatch):
     """the A/B hooks of the fast route (read per call) keep the older forms alive: plain 4096-row blocks with a
-    boundary scan of the sorted words, and key / value columns instead of 16-byte records into the finish"""
+    boundary scan of the sorted words, key / value columns instead of 16-byte records into the finish, and (SQLRS_ORDER_SLIM=0) the
+    16-byte {word, value} records of round 5 instead of the 12-byte {key offset, value} ones the look-back form moves when nobody
+    asks for the permutation"""
     for k_, v_ in hooks.items():
         monkeypatch.setenv(k_, v_)
     rng = np.random.default_rng(77)

@@ -14,7 +14,7 @@ if mc:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "memcpy " + r.get("Direction", "")))
 rows.sort()
 # steps are delimited by the join build's key_minmax_kernel; take the last three
-starts = [i for i, r in enumerate(rows) if "key_minmax_kernel" in r[2]]
+starts = [i for i, r in enumerate(rows) if "key_minmax_inv_kernel" in r[2]]
 for si in range(len(starts) - 3, len(starts) - 1):
     seg = rows[starts[si]:starts[si + 1]]
     span = (seg[-1][1] - seg[0][0]) / 1e6

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf /tmp/tl
 CMD=${CMD:-python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-operators}
-export DELIM=${DELIM:-key_minmax_kernel}
+export DELIM=${DELIM:-key_minmax_inv_kernel}
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- $CMD > /dev/null 2>&1 < /dev/null
 python - <<'PY'
 import csv, glob, os
