@@ -661,12 +661,14 @@ __global__ void ow_group_max_kernel(const uint32_t *__restrict__ gstart, const u
 
 // ---- finish: sort every group on its low bits inside LDS, write the final columns ----------------------
 constexpr int FIN_WG = 256, FIN_WAVES = FIN_WG / 64;
+constexpr uint32_t FIN_BUCKET_CAP = 24; // rows of the largest bucket the bucket + count form of the finish ranks by counting
 template <int KIND, int NPAY, int R, bool REC = false, bool SLIM = false>
 __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ pay,
                                                            const uint32_t *__restrict__ gstart,
                                                            const uint32_t *__restrict__ gend, int rbits, int desc,
                                                            uint64_t imin, void *__restrict__ key_out,
-                                                           uint64_t *__restrict__ pay_out, uint32_t *__restrict__ perm_out) {
+                                                           uint64_t *__restrict__ pay_out, uint32_t *__restrict__ perm_out,
+                                                           int count_form = 1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lo = gstart[blockIdx.x], hi = gend[blockIdx.x];
   if (lo == 0xffffffffu || lo >= hi) return; // no row carries these top bits
@@ -698,7 +700,86 @@ __global__ __launch_bounds__(FIN_WG) void ow_finish_kernel(const uint64_t *__res
       if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
     }
   }
-  for (int shift = 32; shift < 32 + rbits; shift += 8) { // stable LSD passes over the low key bits, all in LDS
+  // Round 6 — more than 8 low bits (two LSD passes below, ~60 VALU instructions per row and pass for the 8 ballots of the stable
+  // ranking: the finish was bound by them, not by its bytes): BUCKET + COUNT instead.  The group's ~1.5 K rows fall into up to
+  // 1024 buckets by the top bits of what is left of the key (one LDS atomic per row, one scan of the counts), take any free slot of
+  // their bucket (a second atomic: the order inside a bucket is whatever the LDS unit makes it), and every row then counts the
+  // entries of its bucket that are smaller than its own {low bits | position in the group} — one to a handful of 4-byte LDS reads.
+  // The position makes the entries distinct, so the ranks are a permutation and equal keys keep their input order whatever
+  // order the atomics ran in.  A bucket of more than FIN_BUCKET_CAP rows (keys that repeat a lot) sends the group through
+  // the LSD passes as before (workgroup-uniform).  SQLRS_ORDER_FINISH_COUNT=0 (host, read per call): the LSD passes always.
+  bool placed = false;
+  if (count_form && rbits > 8) {
+    const int nbb = rbits < 10 ? rbits : 10, lowb = rbits - nbb; // (rbits <= 16: lowb <= 6, entries of <= 19 bits)
+    const uint32_t NB = 1u << nbb, per = NB / FIN_WG;           // (NB = 512 or 1024: 2 or 4 counters per thread)
+    uint32_t *A = wcnt + 1; // A[b] (A[-1] = 0): count -> start -> end of bucket b; 1025 words of the 1280 wcnt + dstart hold
+    uint32_t *sbuf = (uint32_t *)sword; // the buckets' entries (the words / values take the space over afterwards)
+    __shared__ uint32_t s_maxb;
+    for (uint32_t q = threadIdx.x; q <= NB; q += FIN_WG) wcnt[q] = 0;
+    if (threadIdx.x == 0) s_maxb = 0;
+    __syncthreads();
+    uint32_t bk[R], ent[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const uint32_t rel = (uint32_t)(k[j] >> 32) & ((1u << rbits) - 1u);
+      bk[j] = rel >> lowb;
+      ent[j] = ((rel & ((1u << lowb) - 1u)) << 13) | ((uint32_t)(w * cpw + j) * 64 + lane); // (position < 6144 < 2^13)
+      if (valid[j]) atomicAdd(&A[bk[j]], 1u);
+    }
+    __syncthreads();
+    {
+      uint32_t c[4], sum = 0, mx = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        c[i] = i < per ? A[threadIdx.x * per + i] : 0u;
+        sum += c[i];
+        mx = max(mx, c[i]);
+      }
+      const uint32_t inc = wave_iscan_u32(sum);
+      if (lane == 63) s_wsum[w] = inc;
+      for (int q = 32; q >= 1; q >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, q, 64));
+      if (lane == 0 && mx > FIN_BUCKET_CAP) s_maxb = mx; // (any writer will do)
+      __syncthreads();
+      uint32_t run = inc - sum;
+      for (int q = 0; q < w; q++) run += s_wsum[q];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        if (i < per) A[threadIdx.x * per + i] = run;
+        run += c[i];
+      }
+    }
+    __syncthreads();
+    if (s_maxb == 0) {
+#pragma unroll
+      for (int j = 0; j < R; j++)
+        if (valid[j]) sbuf[atomicAdd(&A[bk[j]], 1u)] = ent[j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        if (!valid[j]) continue;
+        const uint32_t s0 = A[(int)bk[j] - 1], s1 = A[bk[j]]; // (after the placement A[b] is the END of bucket b)
+        uint32_t r = s0;
+        for (uint32_t q = s0; q < s1; q++) r += sbuf[q] < ent[j];
+        bk[j] = r;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        if (!valid[j]) continue;
+        sword[bk[j]] = k[j];
+        if (NPAY) spay[bk[j]] = v[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const uint32_t e = min((uint32_t)(w * cpw + j) * 64 + lane, m - 1);
+        k[j] = sword[e];
+        if (NPAY) v[j] = spay[e];
+      }
+      placed = true;
+    }
+  }
+  for (int shift = 32; !placed && shift < 32 + rbits; shift += 8) { // stable LSD passes over the low key bits, all in LDS
     for (int q = lane; q < 256; q += 64) wcnt[w * 256 + q] = 0;
     uint32_t dig[R], rnk[R];
 #pragma unroll
@@ -1936,6 +2017,8 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
   {
     ProfScope ps(ctx, "order_finish");
     uint64_t *po = NPAY ? carry_out->own_values->as<uint64_t>() : nullptr;
+    const char *fc_e = hook("SQLRS_ORDER_FINISH_COUNT"); // (A/B hook, read per call: 0 = the finish sorts on its low bits with LSD passes only)
+    const int fin_count = !(fc_e && fc_e[0] == '0');
 #define SQ_FIN(RR)                                                                                                   \
   do {                                                                                                               \
     auto kfn = ow_finish_kernel<KIND, NPAY, RR>;                                                                     \
@@ -1944,7 +2027,7 @@ static bool order_fast_impl(Ctx *ctx, const DCol &key, int desc, const DCol *car
     const size_t lds = (size_t)RR * FIN_WG * 8 * (1 + NPAY) + 4 * (FIN_WAVES * 256 + 256);                           \
     if (lds > 64 * 1024) allow_big_lds(ctx, kfn);                                                                    \
     kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(words, pays, gstart->as<uint32_t>(), gend->as<uint32_t>(), rbits, desc, imin, \
-                                                     key_out->own_values->p, po, perm);                              \
+                                                     key_out->own_values->p, po, perm, fin_count);                   \
   } while (0)
     if (max_group <= 8 * FIN_WG) SQ_FIN(8);
     else if (max_group <= 16 * FIN_WG) SQ_FIN(16);

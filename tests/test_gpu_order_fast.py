@@ -69,7 +69,7 @@ def hash_seed(*parts):
 
 
 @pytest.mark.parametrize("hooks", [{"SQLRS_ORDER_TILED": "0"}, {"SQLRS_ORDER_REC": "0"}, {"SQLRS_ORDER_REC1": "0"}, {"SQLRS_ORDER_WIDE_REC1": "0"},
-                                   {"SQLRS_ORDER_LB": "0"}, {"SQLRS_ORDER_LB_TEST_FAIL": "1"}, {"SQLRS_ORDER_LB_TEST_FAIL": "2"}, {"SQLRS_ORDER_SLIM": "0"},
+                                   {"SQLRS_ORDER_LB": "0"}, {"SQLRS_ORDER_LB_TEST_FAIL": "1"}, {"SQLRS_ORDER_LB_TEST_FAIL": "2"}, {"SQLRS_ORDER_SLIM": "0"}, {"SQLRS_ORDER_FINISH_COUNT": "0"},
                                    {"SQLRS_ORDER_LB": "0", "TEST_WIDE_KEYS": "1"}, {"SQLRS_ORDER_LB_TEST_FAIL": "1", "TEST_WIDE_KEYS": "1"}])
 def test_order_fast_route_ab_hooks(hip, oracle, hooks, monkeypatch):
     """the A/B hooks of the fast route (read per call) keep the older forms alive: plain 4096-row blocks with a
