@@ -1297,7 +1297,8 @@ __global__ __launch_bounds__(FIN_WG, R == 8 ? 4 : 1) void owk_finish_kernel(cons
                                                             const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gend,
                                                             const uint64_t *__restrict__ sub, uint32_t G, int desc, uint64_t imin,
                                                             void *__restrict__ key_out, uint64_t *__restrict__ pay_out,
-                                                            uint32_t *__restrict__ perm_out, uint32_t m_above, uint32_t m_upto) {
+                                                            uint32_t *__restrict__ perm_out, uint32_t m_above, uint32_t m_upto,
+                                                            int count_form) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lo = gstart[blockIdx.x], hi = gend[blockIdx.x];
   if (lo == 0xffffffffu || lo >= hi) return;
@@ -1322,6 +1323,116 @@ __global__ __launch_bounds__(FIN_WG, R == 8 ? 4 : 1) void owk_finish_kernel(cons
   uint64_t relmax = own_extremes ? 0 : sub[blockIdx.x + 1] - 1 - base; // (next > base: the group has rows)
   int sh = 0, top = 16; // in-LDS passes on bits [sh, top) of rel, counting below sh
   if (threadIdx.x == 0) s_heavy = 0;
+  // (before the attempts below and with its own loads, so that the two forms do not hold each other's registers: inside the
+  //  attempt loop the bucket + count form spilled 312 bytes per lane at the 128 VGPRs four workgroups per CU allow and ran the
+  //  finish at 2.9 ms instead of 1.9)
+  if (count_form && !own_extremes) {
+    const int tbits = relmax ? 64 - __builtin_clzll(relmax) : 0; // rel < 2^tbits
+    uint64_t k[R], v[NPAY ? R : 1];
+    bool valid[R];
+    if (tbits > 8) {
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const uint32_t e = (uint32_t)(w * cpw + j) * 64 + lane;
+        valid[j] = (uint32_t)j < cpw && e < m;
+        const uint32_t i = lo + min(e, m - 1);
+        if (REC) {
+          const u64x2 rec = __builtin_nontemporal_load((const u64x2 *)words + i);
+          k[j] = rec.x - base;
+          v[NPAY ? j : 0] = rec.y;
+        } else {
+          k[j] = __builtin_nontemporal_load(words + i) - base;
+          if (NPAY) v[j] = __builtin_nontemporal_load(pay + i);
+        }
+      }
+    }
+    // Round 6 — BUCKET + COUNT (see ow_finish_kernel): the rows go into up to 1024 buckets by the top bits of rel, take any free slot
+    // of their bucket, and every row counts the entries of its bucket below its own (rel, then position in the group — with no
+    // payload equal words are interchangeable and the slot breaks the tie).  Replaces the two LSD passes AND the neighbour walk
+    // when no bucket holds more than FIN_BUCKET_CAP rows; heavy values and dense clusters take the passes below as before.
+    if (tbits > 8) {
+      const int nbb = tbits < 10 ? tbits : 10, lowb = tbits - nbb;
+      const uint32_t NB = 1u << nbb, per = NB / FIN_WG;
+      uint32_t *A = wcnt + 1;               // A[b] (A[-1] = 0): count -> start -> end of bucket b
+      uint32_t *spos = (uint32_t *)spay;    // positions of the entries (NPAY only)
+      __shared__ uint32_t s_maxb;
+      for (uint32_t q = threadIdx.x; q <= NB; q += FIN_WG) wcnt[q] = 0;
+      if (threadIdx.x == 0) s_maxb = 0;
+      __syncthreads();
+      uint32_t bk[R];
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        bk[j] = (uint32_t)(k[j] >> lowb); // (rel <= relmax < 2^tbits)
+        if (valid[j]) atomicAdd(&A[bk[j]], 1u);
+      }
+      __syncthreads();
+      {
+        uint32_t c[4], sum = 0, mx = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+          c[i] = i < per ? A[threadIdx.x * per + i] : 0u;
+          sum += c[i];
+          mx = max(mx, c[i]);
+        }
+        const uint32_t inc = wave_iscan_u32(sum);
+        if (lane == 63) s_wsum[w] = inc;
+        for (int q = 32; q >= 1; q >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, q, 64));
+        if (lane == 0 && mx > FIN_BUCKET_CAP) s_maxb = mx;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int q = 0; q < w; q++) run += s_wsum[q];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+          if (i < per) A[threadIdx.x * per + i] = run;
+          run += c[i];
+        }
+      }
+      __syncthreads();
+      if (s_maxb == 0) {
+        uint32_t slot[NPAY ? 1 : R]; // (no payload: the slot is the tie-break)
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+          if (!valid[j]) continue;
+          const uint32_t sl = atomicAdd(&A[bk[j]], 1u);
+          sword[sl] = k[j];
+          if (NPAY) spos[sl] = (uint32_t)(w * cpw + j) * 64 + lane;
+          else slot[j] = sl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+          if (!valid[j]) continue;
+          const uint32_t s0 = A[(int)bk[j] - 1], s1 = A[bk[j]], mypos = NPAY ? (uint32_t)(w * cpw + j) * 64 + lane : slot[NPAY ? 0 : j];
+          uint32_t r = s0;
+          for (uint32_t q = s0; q < s1; q++) {
+            const uint64_t o = sword[q];
+            const uint32_t op = NPAY ? spos[q] : q;
+            r += (o < k[j]) || (o == k[j] && op < mypos);
+          }
+          bk[j] = r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+          if (!valid[j]) continue;
+          sword[bk[j]] = k[j];
+          if (NPAY) spay[bk[j]] = v[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+          if (!valid[j]) continue;
+          const uint32_t e = (uint32_t)(w * cpw + j) * 64 + lane;
+          const uint64_t pv = spay[NPAY ? e : 0];
+          order_store_key<KIND>(key_out, lo + e, sword[e] + base + imin, desc);
+          if (perm_out) perm_out[lo + e] = (uint32_t)pv;
+          else if (NPAY) pay_out[lo + e] = pv;
+        }
+        return;
+      }
+      __syncthreads(); // (the passes below start from the registers; wcnt is theirs again)
+    }
+  }
   for (int attempt = 0; attempt < 2; attempt++) {
     uint64_t k[R], v[NPAY ? R : 1];
     bool valid[R];
@@ -1625,6 +1736,8 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     carry_out->values = carry_out->own_values->p;
     po = carry_out->own_values->as<uint64_t>();
   }
+  const char *fc_e = hook("SQLRS_ORDER_FINISH_COUNT"); // (A/B hook, read per call: 0 = LSD passes + neighbour walk only)
+  const int fin_count = !(fc_e && fc_e[0] == '0');
   {
     ProfScope ps(ctx, "order_finish");
     // The splitters balance the groups only statistically (16 samples per group: sizes spread like a Gamma(16), the largest of
@@ -1638,7 +1751,7 @@ static bool order_wide(Ctx *ctx, const DCol &key, int desc, const DCol *carry, i
     if (lds > 64 * 1024) allow_big_lds(ctx, kfn);                                                                    \
     kfn<<<dim3(G), dim3(FIN_WG), lds, ctx->stream>>>(out2->as<uint64_t>(), nullptr, gstart->as<uint32_t>(), gend->as<uint32_t>(), subp, G, \
                                                      desc, imin, key_out->own_values->p, po, perm,         \
-                                                     (uint32_t)(ABOVE), (uint32_t)(UPTO));                           \
+                                                     (uint32_t)(ABOVE), (uint32_t)(UPTO), fin_count);                \
   } while (0)
 #define SQ_WFIN_R(NP)                                                                                                \
   do {                                                                                                               \
