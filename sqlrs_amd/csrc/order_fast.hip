@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(FIN_WG, R == 8 ? 4 : 1) void owk_finish_kernel(cons
       uint32_t bk[R];
 #pragma unroll
       for (int j = 0; j < R; j++) {
-        bk[j] = (uint32_t)(k[j] >> lowb); // (rel <= relmax < 2^tbits)
+        bk[j] = (uint32_t)min(k[j] >> lowb, (uint64_t)(NB - 1)); // (rel <= relmax < 2^tbits; clamped all the same: a counter index)
         if (valid[j]) atomicAdd(&A[bk[j]], 1u);
       }
       __syncthreads();
