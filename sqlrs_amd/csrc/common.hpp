@@ -161,6 +161,12 @@ struct Ctx {
   // copies `bytes` from device to the pinned area and synchronises; returns host pointer
   const void *fetch(const void *dptr, size_t bytes);
   template <class T> T fetch_value(const T *dptr) { return *(const T *)fetch(dptr, sizeof(T)); }
+  // the same in two halves (round 6): the copy is queued where the words are ready, the host waits for it — an event, not the
+  // stream — after it has queued the kernels that do not depend on the answer: the round trip hides behind them
+  void *pinned_early = nullptr;
+  hipEvent_t early_event = nullptr;
+  bool fetch_early(const void *dptr, size_t bytes); // false: not available (nothing queued)
+  const void *fetch_early_wait();
   int prof_entry(const char *name);
   void prof_resolve();
 };

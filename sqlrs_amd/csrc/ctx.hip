@@ -190,6 +190,24 @@ const void *Ctx::fetch(const void *dptr, size_t bytes) {
   sync();
   return pinned;
 }
+bool Ctx::fetch_early(const void *dptr, size_t bytes) {
+  if (bytes > pinned_bytes) return false;
+  if (!pinned_early && hipHostMalloc(&pinned_early, pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+    pinned_early = nullptr;
+    return false;
+  }
+  if (!early_event && hipEventCreateWithFlags(&early_event, hipEventDisableTiming) != hipSuccess) {
+    early_event = nullptr;
+    return false;
+  }
+  SQ_HIP(hipMemcpyAsync(pinned_early, dptr, bytes, hipMemcpyDeviceToHost, stream));
+  SQ_HIP(hipEventRecord(early_event, stream));
+  return true;
+}
+const void *Ctx::fetch_early_wait() {
+  SQ_HIP(hipEventSynchronize(early_event));
+  return pinned_early;
+}
 int Ctx::prof_entry(const char *name) {
   for (size_t i = 0; i < prof.size(); i++)
     if (prof[i].name == name || std::strcmp(prof[i].name, name) == 0) return (int)i;
@@ -837,6 +855,8 @@ void sqlrs_ctx_destroy(sqlrs_ctx_t *ctx) {
   }
   ctx->pool.closed = true;
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pinned_early) (void)hipHostFree(ctx->pinned_early);
+  if (ctx->early_event) (void)hipEventDestroy(ctx->early_event);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -1949,8 +1949,11 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     uint32_t kshift, rbits;
     BufP total; // (out) the scan's grand total, device u64
   };
+  // `before_scatter` (optional): called with the scanned offsets once they are queued and before the scatter is — what only needs
+  // the offsets (the bucket starts and their way to the host) then runs ahead of the level's long kernel
   auto exec_level = [&](int level, uint32_t digits, const Level &L, const RpIn &rin, const RpOut &rout, int64_t sink,
-                        BufP *offs_out, BufP premat = nullptr, SlimLaunch *slim = nullptr) {
+                        BufP *offs_out, BufP premat = nullptr, SlimLaunch *slim = nullptr,
+                        const std::function<void(const BufP &)> *before_scatter = nullptr) {
     const int64_t entries = std::max<int64_t>(L.mat_entries, 1);
     BufP mat = premat ? premat : ctx->alloc(4 * (size_t)entries);
     BufP offs = ctx->alloc(4 * (size_t)entries);
@@ -1981,6 +1984,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       rp_transpose_kernel<true><<<dim3(tblocks), dim3(256), tlds, ctx->stream>>>(
           offs->as<uint32_t>(), offs_tm->as<uint32_t>(), tp, nt, digits);
     SQ_HIP(hipGetLastError());
+    if (before_scatter) (*before_scatter)(offs);
     if (nt) {
       ProfScope ps(ctx, in.build_side ? "rp_scatter_build" : "rp_scatter");
       // one workgroup per CU slot; contiguous tile ranges (8 per workgroup at least)
@@ -2408,7 +2412,22 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       rp_hist_from_chunks_kernel<<<dim3((unsigned)ceil_div(L2.mat_entries, 256)), dim3(256), 0, ctx->stream>>>(
           so.hist, tile_chunk->as<uint32_t>(), L2.mat_entries, digits2, premat->as<uint32_t>());
       SQ_HIP(hipGetLastError());
-      exec_level(2, digits2, L2, RpIn(), RpOut(), (int64_t)kept, &offs2, premat, &sln);
+      // The bucket starts need the scanned offsets of level 2, not its rows: kernel + copy to the host are queued AHEAD of the
+      // level-2 scatter (3 ms) and the host waits for the copy's event behind the launches below — the bucket pass's work list
+      // is planned while the GPU is busy (the round trip + planning were a 55-70 us hole in front of the bucket pass of every
+      // C5 step).  SQLRS_RP_EARLY_STARTS=0 (read per call): fetched behind the level as before.
+      BufP bs_early;
+      const int64_t bs_total = (int64_t)L2.nseg * digits2 + 1;
+      const char *es_e = hook("SQLRS_RP_EARLY_STARTS");
+      const std::function<void(const BufP &)> early_starts = [&](const BufP &offs) {
+        if (es_e && es_e[0] == '0') return;
+        BufP bs = ctx->alloc(4 * (size_t)bs_total);
+        rp_bucket_starts_kernel<<<dim3((unsigned)ceil_div(bs_total, 256)), dim3(256), 0, ctx->stream>>>(
+            offs->as<uint32_t>(), L2.d_seg_mat, L2.d_seg_tiles, L2.d_seg_start, digits2, L2.nseg, (int64_t)kept, bs->as<uint32_t>());
+        SQ_HIP(hipGetLastError());
+        if (ctx->fetch_early(bs->p, 4 * (size_t)bs_total)) bs_early = bs;
+      };
+      exec_level(2, digits2, L2, RpIn(), RpOut(), (int64_t)kept, &offs2, premat, &sln, &early_starts);
       // the non-empty runs of every bucket with the base tile of the chunk they came from
       sl.nzstart = ctx->alloc(4 * (size_t)L2.mat_entries);
       sl.nzbt = ctx->alloc(4 * (size_t)L2.mat_entries);
@@ -2427,7 +2446,12 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       sl.tile = (uint32_t)RP_TILE;
       sl.on = true;
       out->key = out->v0 = out->v1 = out->idx = out->flags = out->rec = nullptr;
-      out->bstart = bucket_starts(L2, offs2, digits2, (int64_t)kept, &out->bstart_host);
+      if (bs_early) { // (the event also covers L2's uploads, queued ahead of the level: their host sources may go)
+        const uint32_t *h = (const uint32_t *)ctx->fetch_early_wait();
+        out->bstart_host.assign(h, h + bs_total);
+        out->bstart = bs_early;
+      } else
+        out->bstart = bucket_starts(L2, offs2, digits2, (int64_t)kept, &out->bstart_host);
       return true;
     }
     if (chunked) {
