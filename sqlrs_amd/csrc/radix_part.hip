@@ -2080,6 +2080,36 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
     return bs;
   };
 
+  // The bucket starts of a LAST level need its scanned offsets, not its rows: kernel + copy to the host are queued AHEAD of the
+  // level's scatter (exec_level's `before_scatter`) and the host waits for the copy's event behind the launches that follow — the
+  // bucket pass's work list is planned while the GPU is busy (round trip + planning were a 55-70 us hole in front of the bucket
+  // pass of every C5 step).  SQLRS_RP_EARLY_STARTS=0 (read per call): fetched behind the level as before.
+  struct EarlyStarts {
+    BufP bs;
+    int64_t total = 0;
+    std::function<void(const BufP &)> queue;
+  };
+  auto early_starts_for = [&](const Level &L, uint32_t digits, int64_t rows, EarlyStarts &es) {
+    es.total = (int64_t)L.nseg * digits + 1;
+    const char *es_e = hook("SQLRS_RP_EARLY_STARTS");
+    const bool off = es_e && es_e[0] == '0';
+    es.queue = [&L, &es, digits, rows, off, ctx](const BufP &offs) {
+      if (off) return;
+      BufP bs = ctx->alloc(4 * (size_t)es.total);
+      rp_bucket_starts_kernel<<<dim3((unsigned)ceil_div(es.total, 256)), dim3(256), 0, ctx->stream>>>(
+          offs->as<uint32_t>(), L.d_seg_mat, L.d_seg_tiles, L.d_seg_start, digits, L.nseg, rows, bs->as<uint32_t>());
+      SQ_HIP(hipGetLastError());
+      if (ctx->fetch_early(bs->p, 4 * (size_t)es.total)) es.bs = bs;
+    };
+  };
+  // (the event also covers the level's uploads, queued ahead of it: their host sources may go)
+  auto finish_starts = [&](EarlyStarts &es, const Level &L, const BufP &offs, uint32_t digits, int64_t rows, std::vector<uint32_t> *host) -> BufP {
+    if (!es.bs) return bucket_starts(L, offs, digits, rows, host);
+    const uint32_t *h = (const uint32_t *)ctx->fetch_early_wait();
+    host->assign(h, h + es.total);
+    return es.bs;
+  };
+
   // ---- claimed single level (no histogram pass, optional fused row filter): one-level range partitions of packed
   // rows; see rp_claim_scatter_kernel.  Hashed buckets keep the counting level (their bucket pass takes a sentinel
   // row for a key of its own).
@@ -2412,22 +2442,9 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       rp_hist_from_chunks_kernel<<<dim3((unsigned)ceil_div(L2.mat_entries, 256)), dim3(256), 0, ctx->stream>>>(
           so.hist, tile_chunk->as<uint32_t>(), L2.mat_entries, digits2, premat->as<uint32_t>());
       SQ_HIP(hipGetLastError());
-      // The bucket starts need the scanned offsets of level 2, not its rows: kernel + copy to the host are queued AHEAD of the
-      // level-2 scatter (3 ms) and the host waits for the copy's event behind the launches below — the bucket pass's work list
-      // is planned while the GPU is busy (the round trip + planning were a 55-70 us hole in front of the bucket pass of every
-      // C5 step).  SQLRS_RP_EARLY_STARTS=0 (read per call): fetched behind the level as before.
-      BufP bs_early;
-      const int64_t bs_total = (int64_t)L2.nseg * digits2 + 1;
-      const char *es_e = hook("SQLRS_RP_EARLY_STARTS");
-      const std::function<void(const BufP &)> early_starts = [&](const BufP &offs) {
-        if (es_e && es_e[0] == '0') return;
-        BufP bs = ctx->alloc(4 * (size_t)bs_total);
-        rp_bucket_starts_kernel<<<dim3((unsigned)ceil_div(bs_total, 256)), dim3(256), 0, ctx->stream>>>(
-            offs->as<uint32_t>(), L2.d_seg_mat, L2.d_seg_tiles, L2.d_seg_start, digits2, L2.nseg, (int64_t)kept, bs->as<uint32_t>());
-        SQ_HIP(hipGetLastError());
-        if (ctx->fetch_early(bs->p, 4 * (size_t)bs_total)) bs_early = bs;
-      };
-      exec_level(2, digits2, L2, RpIn(), RpOut(), (int64_t)kept, &offs2, premat, &sln, &early_starts);
+      EarlyStarts es;
+      early_starts_for(L2, digits2, (int64_t)kept, es);
+      exec_level(2, digits2, L2, RpIn(), RpOut(), (int64_t)kept, &offs2, premat, &sln, &es.queue);
       // the non-empty runs of every bucket with the base tile of the chunk they came from
       sl.nzstart = ctx->alloc(4 * (size_t)L2.mat_entries);
       sl.nzbt = ctx->alloc(4 * (size_t)L2.mat_entries);
@@ -2446,12 +2463,7 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
       sl.tile = (uint32_t)RP_TILE;
       sl.on = true;
       out->key = out->v0 = out->v1 = out->idx = out->flags = out->rec = nullptr;
-      if (bs_early) { // (the event also covers L2's uploads, queued ahead of the level: their host sources may go)
-        const uint32_t *h = (const uint32_t *)ctx->fetch_early_wait();
-        out->bstart_host.assign(h, h + bs_total);
-        out->bstart = bs_early;
-      } else
-        out->bstart = bucket_starts(L2, offs2, digits2, (int64_t)kept, &out->bstart_host);
+      out->bstart = finish_starts(es, L2, offs2, digits2, (int64_t)kept, &out->bstart_host);
       return true;
     }
     if (chunked) {
@@ -2585,9 +2597,11 @@ bool partition_rows(Ctx *ctx, const PartitionInput &in, uint32_t P_wanted, Parti
               co.hist, tile_chunk->as<uint32_t>(), L2.mat_entries, digits2, premat->as<uint32_t>());
           SQ_HIP(hipGetLastError());
         }
-        exec_level(2, digits2, L2, rin2, rout2, (int64_t)kept, &offs2, premat);
+        EarlyStarts es;
+        early_starts_for(L2, digits2, (int64_t)kept, es);
+        exec_level(2, digits2, L2, rin2, rout2, (int64_t)kept, &offs2, premat, nullptr, &es.queue);
         publish(c2);
-        out->bstart = bucket_starts(L2, offs2, digits2, (int64_t)kept, &out->bstart_host);
+        out->bstart = finish_starts(es, L2, offs2, digits2, (int64_t)kept, &out->bstart_host);
         return true;
       }
     }
