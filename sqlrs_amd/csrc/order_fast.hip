@@ -236,12 +236,30 @@ __device__ __forceinline__ void stable_wave_ranks(const uint32_t (&dig)[ITEMS], 
       rnk[j] = 0;
       continue;
     }
+    // (lanes whose digit DIFFERS from this lane's in some bit, accumulated: mask = all ones where this lane's bit is set, so
+    //  ballot ^ mask has a lane's bit set exactly when the two bits differ — a signed bit-field extract, a compare for the ballot,
+    //  two XORs and v_or3 per two bits instead of a select between bm and ~bm: 1089 -> 905 VALU instructions per tile of the
+    //  tiled scatter.  Measured in one process against the select form (tools/order_two_builds.py, profiles/r06q_order_rank_ab.txt):
+    //  narrow route split phase 1.704 vs 1.688 ms, splitter route 2.27 vs 2.30 — NO effect either way: the passes do not run at
+    //  the pace of their ranking instructions, contrary to the round-3 note below.)
+#if defined(OW_RANK_SELECT) // (the form of rounds 3-5, kept for A/B builds: tools/order_two_builds.py)
 #pragma unroll
     for (int b = 0; b < 8; b++) {
       const bool bit = (dig[j] >> b) & 1;
       const uint64_t bm = __ballot(bit);
       peers &= bit ? bm : ~bm;
     }
+#else
+    uint32_t dlo = 0, dhi = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const int32_t mask = ((int32_t)(dig[j] << (31 - b))) >> 31; // 0 or -1
+      const uint64_t bm = __ballot(mask != 0);
+      dlo |= (uint32_t)bm ^ (uint32_t)mask;
+      dhi |= (uint32_t)(bm >> 32) ^ (uint32_t)mask;
+    }
+    peers &= ~(((uint64_t)dhi << 32) | dlo);
+#endif
     const uint32_t r = (uint32_t)mbcnt(peers);
     uint32_t old = 0;
     if (valid[j] && r == 0) {

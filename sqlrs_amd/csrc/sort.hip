@@ -85,12 +85,17 @@ __global__ __launch_bounds__(RS_WG) void rs_scatter_kernel(
     const bool valid = wrow + j * 64 < n;
     const uint32_t d = (uint32_t)(k[j] >> shift) & 255u;
     uint64_t peers = __ballot(valid);
+    // (lanes whose digit differs from this lane's in some bit, accumulated — order_fast.hip, stable_wave_ranks: a signed bit-field
+    //  extract, one compare, two XORs and two ORs per bit instead of a select between the ballot and its complement)
+    uint32_t dlo = 0, dhi = 0;
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-      const bool bit = (d >> b) & 1;
-      const uint64_t bm = __ballot(bit);
-      peers &= bit ? bm : ~bm;
+      const int32_t mask = ((int32_t)(d << (31 - b))) >> 31; // 0 or -1
+      const uint64_t bm = __ballot(mask != 0);
+      dlo |= (uint32_t)bm ^ (uint32_t)mask;
+      dhi |= (uint32_t)(bm >> 32) ^ (uint32_t)mask;
     }
+    peers &= ~(((uint64_t)dhi << 32) | dlo);
     const uint32_t r = (uint32_t)mbcnt(peers);
     uint32_t old = 0;
     if (valid && r == 0) { // first lane of the digit in this chunk
