@@ -160,7 +160,14 @@ __global__ __launch_bounds__(256) void order_minmax_kernel(const void *__restric
 }
 
 // ---- stable 8-bit multi-split over HBM, rows = (word, carried column) -------------------------------
-constexpr int OW_WG = 512, OW_WAVES = OW_WG / 64, OW_ITEMS = 8, OW_TILE = OW_WG * OW_ITEMS;
+#ifndef OW_ITEMS_N
+#define OW_ITEMS_N 8 // (rows per thread of the split passes' tile; tools/order_two_builds.py compares builds.  Round 6, one process,
+                     //  1e8 rows, 12 against 8 (profiles/r06q_order_items12_ab.txt): narrow route split phase 1.68-1.71 vs 1.73-1.75 ms,
+                     //  but the counting form 2.48 vs 2.32, three columns 4.72 vs 4.65, doubles 3.92 vs 3.82; 6, 10 and 16 lose
+                     //  everywhere: 8 stays)
+#endif
+constexpr int OW_WG = 512, OW_WAVES = OW_WG / 64, OW_ITEMS = OW_ITEMS_N, OW_TILE = OW_WG * OW_ITEMS;
+constexpr int OW_TWO_WGS = OW_ITEMS <= 8 ? 3 : 2; // workgroups per CU the TWO form is compiled for (its one LDS tile: 8 bytes x OW_TILE)
 
 // RAW: the pass reads the raw key column (row id = position) and builds  off << 32 | row  in registers
 template <int KIND, bool RAW, bool REC_IN = false>
@@ -315,7 +322,7 @@ __device__ __forceinline__ void ow_rec12_store(void *__restrict__ recs, int64_t 
 }
 template <int KIND, bool RAW, int NPAY, bool TILED = false, bool REC = false, bool REC_IN = false, bool LB = false, bool TWO = false,
           bool SLIM = false>
-__global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void ow_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay,
+__global__ __launch_bounds__(OW_WG, TWO ? OW_TWO_WGS : 1) void ow_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay,
                                                            int64_t n, int desc, uint64_t imin, int shift, int64_t nblocks,
                                                            const uint32_t *__restrict__ offsets,
                                                            uint64_t *__restrict__ words_out, uint64_t *__restrict__ pay_out,
@@ -1050,7 +1057,7 @@ __global__ __launch_bounds__(OW_WG) void owk_ghist_kernel(const void *__restrict
 // LB (LEVEL 1): the chained look-back of ow_scatter_kernel instead of the scanned count matrix — `ghist` = the 256 segment
 // sizes (owk_ghist_kernel), `lbdesc` [tile][256] zeroed, `lb_fail` raised when a spin runs out
 template <int KIND, int LEVEL, int NPAY, bool REC, bool REC_IN = false, bool TWO = false, bool LB = false>
-__global__ __launch_bounds__(OW_WG, TWO ? 3 : 1) void owk_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay, int64_t n,
+__global__ __launch_bounds__(OW_WG, TWO ? OW_TWO_WGS : 1) void owk_scatter_kernel(const void *__restrict__ src, const uint64_t *__restrict__ pay, int64_t n,
                                                             int desc, uint64_t imin, int64_t nblocks,
                                                             const uint32_t *__restrict__ offsets, uint64_t *__restrict__ words_out,
                                                             uint64_t *__restrict__ pay_out, const OwkTile *__restrict__ tiles,
