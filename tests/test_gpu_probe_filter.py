@@ -258,7 +258,8 @@ def test_hash_agg_column_form_hook(hip, oracle, dense, monkeypatch):
 
 @pytest.mark.parametrize("hooks,pred", [("default", "val_gt_half"), ("default", "other_ne"), ("default", "key_ge"),
                                         ("long_tile_ranges_early_closes", "val_gt_half"), ("long_tile_ranges_early_closes", "key_ge"),
-                                        ("one_workgroup", "other_ne"), ("off", "val_gt_half")])
+                                        ("one_workgroup", "other_ne"), ("off", "val_gt_half"), ("late_starts", "val_gt_half"),
+                                        ("off_late_starts", "key_ge")])
 def test_chunked_slim_records(hip, oracle, hooks, pred, monkeypatch):
     """Slim records (radix_part.hip): 12-byte rows {value, slot | row-in-tile | tile delta} through both partition levels
     and the bucket pass, row ids rebuilt from the chunk / run tables — the groups' first-seen order (hash_agg.rs:87-99)
@@ -268,7 +269,10 @@ def test_chunked_slim_records(hip, oracle, hooks, pred, monkeypatch):
     if not FORCED:
         pytest.skip("needs the chunked first level (SQLRS_RP_CHUNKED=1: the forced run)")
     env = {"default": {}, "long_tile_ranges_early_closes": {"SQLRS_RP_CHUNK_WGS": "3", "SQLRS_RP_SLIM_DELTA": "5"},
-           "one_workgroup": {"SQLRS_RP_CHUNK_WGS": "1", "SQLRS_RP_SLIM_DELTA": "127"}, "off": {"SQLRS_RP_SLIM": "0"}}[hooks]
+           "one_workgroup": {"SQLRS_RP_CHUNK_WGS": "1", "SQLRS_RP_SLIM_DELTA": "127"}, "off": {"SQLRS_RP_SLIM": "0"},
+           # (round 6: the bucket starts of level 2 are fetched AHEAD of its scatter by default; 0 = behind the level as before —
+           #  slim and 16-byte rows take different call sites of the same helper)
+           "late_starts": {"SQLRS_RP_EARLY_STARTS": "0"}, "off_late_starts": {"SQLRS_RP_SLIM": "0", "SQLRS_RP_EARLY_STARTS": "0"}}[hooks]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     lb, rb, sch = shared_tables(False)
@@ -279,7 +283,7 @@ def test_chunked_slim_records(hip, oracle, hooks, pred, monkeypatch):
     prof = hip.profile_read()
     hip.profile(False)
     assert ex.fused_batches == 1 and ex.filter_fused_batches == 1
-    assert (prof.get("rp_slim_runs", (0, 0))[1] > 0) == (hooks != "off"), prof
+    assert (prof.get("rp_slim_runs", (0, 0))[1] > 0) == (not hooks.startswith("off")), prof
     assert_same(got, shared_reference(oracle, False, pred, "count_sum"), float_cols={2})
 
 
