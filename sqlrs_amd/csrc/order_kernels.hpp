@@ -147,8 +147,11 @@ __global__ __launch_bounds__(256) void order_minmax_kernel(const void *__restric
                      //  but the counting form 2.48 vs 2.32, three columns 4.72 vs 4.65, doubles 3.92 vs 3.82; 6, 10 and 16 lose
                      //  everywhere: 8 stays)
 #endif
-constexpr int OW_WG = 512, OW_WAVES = OW_WG / 64, OW_ITEMS = OW_ITEMS_N, OW_TILE = OW_WG * OW_ITEMS;
-constexpr int OW_TWO_WGS = OW_ITEMS <= 8 ? 3 : 2; // workgroups per CU the TWO form is compiled for (its one LDS tile: 8 bytes x OW_TILE)
+#ifndef OW_WG_N
+#define OW_WG_N 512 // (threads of a split pass's workgroup; 1024 x 4 rows = the same tile on sixteen waves: tools/order_two_builds.py)
+#endif
+constexpr int OW_WG = OW_WG_N, OW_WAVES = OW_WG / 64, OW_ITEMS = OW_ITEMS_N, OW_TILE = OW_WG * OW_ITEMS;
+constexpr int OW_TWO_WGS = OW_WG > 512 ? 2 : (OW_ITEMS <= 8 ? 3 : 2); // workgroups per CU the TWO form is compiled for (its one LDS tile: 8 bytes x OW_TILE)
 
 // RAW: the pass reads the raw key column (row id = position) and builds  off << 32 | row  in registers
 template <int KIND, bool RAW, bool REC_IN = false>
@@ -553,8 +556,8 @@ __global__ __launch_bounds__(OW_WG) void ow_ghist_kernel(const void *__restrict_
                                                          int shift_lo, int shift_hi, int64_t nblocks, uint32_t *__restrict__ ghist,
                                                          unsigned int *__restrict__ oob, int kbits) {
   __shared__ uint32_t h[512];
-  static_assert(OW_WG == 512, "one counter per thread");
-  h[threadIdx.x] = 0;
+  static_assert(OW_WG >= 512, "one counter per thread");
+  if (threadIdx.x < 512) h[threadIdx.x] = 0;
   __syncthreads();
   bool bad = false;
   for (int64_t t = blockIdx.x; t < nblocks; t += gridDim.x) {
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(OW_WG) void ow_ghist_kernel(const void *__restrict_
   }
   if (oob && __ballot(bad) && lane_id() == 0) atomicOr(oob, 1u);
   __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
+  if (threadIdx.x < 512 && h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
 }
 // ow_tile_plan_kernel from the first pass's 256 digit counts instead of its scanned count matrix
 __global__ __launch_bounds__(256) void ow_tile_plan_gh_kernel(const uint32_t *__restrict__ ghist, int64_t n,
